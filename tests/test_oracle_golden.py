@@ -1,0 +1,178 @@
+"""The CPU oracle must reproduce the fixtures that tests/golden/make_golden.py recorded FROM THE
+REFERENCE (imported in the build container).  This is what pins the oracle (prompt section 3)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, SEED
+from eeg_image_decode_amd import synthetic as syn
+from oracle import atms as oatms
+from oracle import loops as oloops
+from oracle import loss as oloss
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def state():
+    return oloops.torch_state(syn.make_state(SEED, oatms.state_spec()))
+
+
+def test_state_dict_keys_match_reference():
+    with open(os.path.join(GOLDEN, "atms_keys.json")) as f:
+        ref = json.load(f)
+    ours = {k: list(s) for k, s, _ in oatms.state_spec()}
+    assert ours == ref["keys"]
+    n_params = sum(int(np.prod(s)) for k, s, _ in oatms.state_spec() if not oloops.is_buffer(k))
+    assert n_params == ref["n_params"] == 3202413
+
+
+def test_encoder_eval_embeddings(state, golden):
+    g = golden("atms_eval.npz")
+    x = T(syn.eeg_batch(SEED + 1, 8))
+    for key, ids in (("emb_sub1", torch.full((8,), 1)), ("emb_sub10", torch.full((8,), 10)),
+                     ("emb_mixed", torch.tensor([1, 2, 3, 4, 5, 6, 7, 9]))):
+        z = oatms.atms_forward(state, x, ids.long(), train=False)
+        np.testing.assert_allclose(z.numpy(), g[key], atol=2e-5, rtol=0)
+    want = {}
+    oatms.atms_forward(state, x[:2], torch.full((2,), 1).long(), train=False, want=want)
+    np.testing.assert_allclose(want["enc_out"][:, :63].numpy(), g["enc_out_b2"], atol=1e-5)
+    np.testing.assert_allclose(want["feat"].numpy(), g["feat_b2"], atol=1e-5)
+    np.testing.assert_allclose(want["conv1_pool"][:, :4].numpy(), g["pool_b2_c0_3"], atol=1e-5)
+
+
+def test_fused_75tap_filter_equals_conv_then_pool(state):
+    """The HIP kernel folds AvgPool(1x51,s5) into the conv: check the tap table identity."""
+    w = state["enc_eeg.0.tsconv.0.weight"].view(40, 25)
+    b = state["enc_eeg.0.tsconv.0.bias"]
+    x = T(syn.eeg_batch(3, 2))
+    ref = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x.unsqueeze(1), w.view(40, 1, 1, 25), b), (1, 51), (1, 5))
+    weff = oatms.fused_temporal_filter(w)
+    fused = torch.nn.functional.conv2d(x.unsqueeze(1), weff.view(40, 1, 1, 75), b, stride=(1, 5))
+    assert fused.shape == ref.shape == (2, 40, 63, 36)
+    np.testing.assert_allclose(fused.numpy(), ref.numpy(), atol=2e-6)
+
+
+def test_encoder_train_p0_loss_and_grads(state, golden):
+    g = golden("atms_train_p0.npz")
+    B = 16
+    x = T(syn.eeg_batch(SEED + 2, B))
+    img = T(syn.unit_features(SEED + 2, B, tag="img"))
+    txt = T(syn.unit_features(SEED + 2, B, tag="txt"))
+    tr = oloops.OracleTrainer(state, p_scale=0.0)
+    loss, z, grads, want = tr.loss_and_grads(x, torch.full((B,), 1).long(), img, txt, train=True)
+    np.testing.assert_allclose(z.numpy(), g["z"], atol=2e-5)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    for k in tr.params:
+        if "gradnone:" + k in g.files:
+            assert grads[k] is None, k
+        else:
+            gr = grads[k].flatten()
+            assert abs(float(gr.norm()) - float(g["gnorm:" + k])) <= 1e-4 * max(1.0, float(g["gnorm:" + k])), k
+            np.testing.assert_allclose(gr[:32].numpy(), g["ghead:" + k], atol=1e-5 + 1e-4 * np.abs(g["ghead:" + k]).max(), err_msg=k)
+    # dead parameters get no gradient
+    for k in tr.params:
+        assert (grads[k] is None) == (oloops.is_dead(k) or k.endswith("shared_embedding")), k
+
+
+def test_clip_loss_and_closed_form_grads(golden):
+    g = golden("loss.npz")
+    for n in (32, 256):
+        a = T(syn.unit_features(SEED + 3, n, tag="a") * 32.0)
+        b = T(syn.unit_features(SEED + 3, n, tag="b"))
+        s = torch.tensor(float(np.log(1 / 0.07)))
+        assert abs(float(oloss.clip_loss(a, b, s)) - float(g[f"loss_{n}"])) < 1e-5
+        da, db, ds = oloss.clip_loss_grads(a, b, s)
+        np.testing.assert_allclose(da[:8].numpy(), g[f"da_{n}"], atol=1e-6)
+        np.testing.assert_allclose(db[:8].numpy(), g[f"db_{n}"], atol=2e-5)
+        assert abs(float(ds) - float(g[f"ds_{n}"])) < 1e-4 * max(1, abs(float(g[f"ds_{n}"])))
+
+
+def _make_batches(seed, n_batches, B, n_classes, img_all, txt_all):
+    rng = np.random.Generator(np.random.Philox(key=[seed, 77]))
+    out = []
+    for i in range(n_batches):
+        x = T(syn.eeg_batch(seed + 100 + i, B))
+        labels = T(rng.integers(0, n_classes, size=B).astype(np.int64))
+        out.append((x, labels, None, txt_all[labels], None, img_all[labels * 10]))
+    return out
+
+
+def test_train_loop_matches_reference(state, golden):
+    g = golden("train_loop.npz")
+    n_classes, B = 20, 16
+    img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
+    txt_all = T(syn.unit_features(SEED + 4, n_classes, tag="txtall"))
+    tr = oloops.OracleTrainer(state, lr=3e-4, p_scale=0.0)
+    before = {k: v.clone() for k, v in tr.P.items()}
+    losses, accs = [], []
+    for ep in range(2):
+        l, a, feats = oloops.train_epoch(tr, 1, _make_batches(SEED + 4, 3, B, n_classes, img_all, txt_all), img_all)
+        losses.append(l)
+        accs.append(a)
+        if ep == 0:
+            np.testing.assert_allclose(feats.numpy()[:, :64], g["feats_ep0"], atol=5e-4)
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-4)
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k in tr.params:
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue    # exact gradient is 0 -> the reference's Adam step on these is pure round-off noise
+        d = float((tr.P[k] - before[k]).norm())
+        assert abs(d - float(g["dnorm:" + k])) <= 2e-3 * max(float(g["dnorm:" + k]), 1e-3) + 1e-6, k
+    for k in tr.P:
+        if "running" in k:
+            # running_mean absorbs the conv bias, whose Adam steps are round-off noise (ZERO_GRAD_KEYS): +-lr per step
+            tol = 6 * 3e-4 if k.endswith("running_mean") else 1e-4
+            np.testing.assert_allclose(tr.P[k].numpy(), g["bn:" + k], atol=tol, err_msg=k)
+        if "num_batches" in k:
+            assert int(tr.P[k]) == int(g["bn:" + k]) == 6
+
+
+def test_evaluate_matches_reference(state, golden):
+    g = golden("eval.npz")
+    n_test = 200
+    txt_all = T(syn.unit_features(SEED + 5, n_test, tag="txttest"))
+    img_all = T(g["img_all_mixed"])
+    x_all = T(syn.eeg_batch(SEED + 6, n_test))
+    z = oatms.atms_forward(state, x_all, torch.full((n_test,), 8).long(), train=False)
+    np.testing.assert_allclose(z.numpy()[:, :32], g["z_test_head"], atol=2e-5)
+    top5 = torch.topk(state["logit_scale"] * z @ img_all.T, 5, dim=1).indices.numpy()
+    assert (top5 == g["top5_full"]).all()              # bit-exact indices
+    samples = [(x_all[i:i + 1], i, txt_all[i:i + 1], img_all[i:i + 1]) for i in range(n_test)]
+    for k in (200, 10):                                  # two of the six (each is 200 bs=1 forwards)
+        random.seed(1234 + k)
+        l, a, t5 = oloops.evaluate(state, 8, samples, img_all, txt_all, k)
+        ref = g[f"k{k}"]
+        assert abs(l - ref[0]) < 1e-4 and a == ref[1] and t5 == ref[2], (k, l, a, t5, ref)
+
+
+def test_distributed_loss_modes_closed_form(golden):
+    """gloo fixtures recorded from the reference ClipLoss(world_size=W): check the closed forms the
+    HIP/RCCL path implements."""
+    g = golden("dist_loss.npz")
+    s = torch.tensor(float(np.log(1 / 0.07)))
+    for W in (2, 4):
+        n = 8
+        a_all = T(syn.unit_features(SEED + 7, n * W, tag="da") * 32.0)
+        b_all = T(syn.unit_features(SEED + 7, n * W, tag="db"))
+        glob = float(oloss.clip_loss(a_all, b_all, s))
+        da, db, _ = oloss.clip_loss_grads(a_all, b_all, s)
+        da, db = da.float().view(W, n, -1)[:, :, :128], db.float().view(W, n, -1)[:, :, :128]
+        # default mode: every rank sees the global loss, local-shard grads x1
+        np.testing.assert_allclose(g[f"w{W}_ll0_gwg0_loss"], glob, atol=1e-5)
+        np.testing.assert_allclose(g[f"w{W}_ll0_gwg0_da"], da.numpy(), atol=1e-6)
+        # gather_with_grad: grads are W x
+        np.testing.assert_allclose(g[f"w{W}_ll0_gwg1_loss"], glob, atol=1e-5)
+        np.testing.assert_allclose(g[f"w{W}_ll0_gwg1_da"], W * da.numpy(), atol=2e-6)
+        # local_loss + gather_with_grad: per-rank loss differs, mean over ranks = global; grads W x
+        ll = [float(oloss.clip_loss_local(a_all[r * n:(r + 1) * n], b_all[r * n:(r + 1) * n], a_all, b_all, s, r)) for r in range(W)]
+        np.testing.assert_allclose(g[f"w{W}_ll1_gwg1_loss"], ll, atol=1e-5)
+        assert abs(np.mean(ll) - glob) < 1e-5
+        np.testing.assert_allclose(g[f"w{W}_ll1_gwg1_da"], W * da.numpy(), atol=2e-6)
+        np.testing.assert_allclose(g[f"w{W}_ll1_gwg1_db"], W * db.numpy(), atol=5e-5)
