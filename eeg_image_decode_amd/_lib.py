@@ -1,0 +1,43 @@
+"""Loader for libeegclip_hip.so.  There is NO fallback: a missing library or a missing GPU is an error."""
+import ctypes
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeegclip_hip.so")
+_lib = None
+
+
+class EegclipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The hipcc-built kernel library (loaded once).  torch is imported first so that the library binds to the
+    very libamdhip64 instance PyTorch-ROCm already loaded (same SONAME) -- streams and pointers are shared."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (must precede the dlopen, see docstring)
+        if not os.path.exists(LIB_PATH):
+            raise EegclipError(
+                f"{LIB_PATH} is missing: build it with `python -m eeg_image_decode_amd.build` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU or eager-PyTorch fallback.")
+        l = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        _abi.declare(l)
+        v = l.eegclip_abi_version()
+        if v != 1:
+            raise EegclipError(f"ABI version mismatch: library {v}, python binding 1")
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EegclipError(f"{what} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
+
+
+def require_cuda(t, name="tensor"):
+    if not t.is_cuda:
+        raise EegclipError(f"{name} must live on the GPU (got {t.device}); eeg_image_decode_amd has no CPU path")
+    return t

@@ -1,0 +1,155 @@
+// Common device helpers for the eegclip HIP kernels (gfx950 / CDNA4: 64-lane wavefronts, MFMA, LDS).
+//
+// The kernels are written against a handful of thin wrappers (LDS base, launch, wave shuffles, MFMA)
+// so that the same source also builds under the test-only lane emulator (tests/hipemu, -DEEG_EMU).
+// Product builds (hipcc --offload-arch=gfx950) never define EEG_EMU.
+#pragma once
+
+#if defined(EEG_EMU)
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <stdint.h>
+
+#include "../../include/eegclip.h"
+
+namespace eeg {
+
+constexpr int kWave = 64;   // CDNA wavefront width -- hard-coded on purpose (guide section 1)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#if defined(EEG_EMU)
+#define EEG_LDS_BASE(T, name) T* name = reinterpret_cast<T*>(hipemu::smem())
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipemu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
+#else
+// one dynamic LDS region per kernel, 16-byte aligned (guide G17); never mix with static __shared__
+#define EEG_LDS_BASE(T, name)                                                         \
+    extern __shared__ __attribute__((aligned(16))) unsigned char eeg_lds_raw_[];      \
+    T* name = reinterpret_cast<T*>(eeg_lds_raw_)
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- wave-level reductions (64 lanes, xor butterfly) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---- MFMA wrappers (gfx950 fragment layouts, guide section 3) ----
+// 16x16x4 f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)*4+r][col=l&15] in reg r.
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+#if defined(EEG_EMU)
+    struct AB { float a, b; } in{a, b};
+    auto all = hipemu::wave_allgather(&in, sizeof(in));
+    const int l = hipemu::cur->lane, col = l & 15, rb = (l >> 4) * 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB ra, rbv;
+            memcpy(&ra, all[(rb + r) + 16 * k], sizeof(AB));
+            memcpy(&rbv, all[col + 16 * k], sizeof(AB));
+            acc = fmaf(ra.a, rbv.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even f32 -> bf16 bits (inputs are finite here)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// 16x16x32 bf16: lane l supplies A[i=l&15][k=8*(l>>4)..+7], B[k=8*(l>>4)..+7][j=l&15]; D as above.
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#if defined(EEG_EMU)
+    struct AB { bf16x8 a, b; } in{a, b};
+    auto all = hipemu::wave_allgather(&in, sizeof(in));
+    const int l = hipemu::cur->lane, col = l & 15, rb = (l >> 4) * 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int q = 0; q < 4; ++q) {
+            AB ra, rbv;
+            memcpy(&ra, all[(rb + r) + 16 * q], sizeof(AB));
+            memcpy(&rbv, all[col + 16 * q], sizeof(AB));
+            for (int e = 0; e < 8; ++e)
+                acc += bf16_bits_to_f32((unsigned short)ra.a[e]) * bf16_bits_to_f32((unsigned short)rbv.b[e]);
+        }
+        d[r] = acc;
+    }
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// ---- two-level index -> element offset  (eegclip_dim: offset(i) = (i / div) * so + (i % div) * si) ----
+__device__ __forceinline__ long long dim_off(const eegclip_dim& d, int i) {
+    if ((long long)i < d.div) return (long long)i * d.si;      // plain strided dimension (div = 2^62) or first run
+    const int dv = (int)d.div;                                  // here div <= i <= INT_MAX
+    return (long long)(i / dv) * d.so + (long long)(i % dv) * d.si;
+}
+
+// ---- Philox4x32-10 counter-based RNG: dropout masks are a pure function of (seed, site, element) so the
+//      backward pass regenerates them instead of storing them ----
+struct philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ philox4 philox4x32_10(unsigned long long seed, unsigned long long ctr_lo, unsigned ctr_hi) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned h0 = __umulhi(M0, c0), l0 = M0 * c0;
+        unsigned h1 = __umulhi(M1, c2), l1 = M1 * c2;
+        unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return philox4{c0, c1, c2, c3};
+}
+// keep-decision for element `idx` of dropout site `site`: uniform u in [0,1) from 32 Philox bits, keep iff u >= p.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
+    philox4 r = philox4x32_10(seed, idx >> 2, site);
+    unsigned sel = (unsigned)(idx & 3);
+    unsigned bits = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+    return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+}  // namespace eeg
