@@ -29,12 +29,40 @@ class GemmDesc(C.Structure):
 
 
 ACT_NONE, ACT_GELU = 0, 1
-_P, _I, _F, _L, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong
+_P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
 # name -> argtypes   (restype is always int)
 PROTOTYPES = {
     "eegclip_abi_version": [],
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
+    "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eegclip_bn_stats": [_P, _I, _I, _I, _P, _P],
+    "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P],
+    "eegclip_bn_elu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_embed_finish": [_P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_embed_finish_bwd": [_P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_dropout_scale": [_P, _L, _F, _U64, _U, _P],
+    "eegclip_gelu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],
+    "eegclip_axpby": [_P, _P, _L, _F, _F, _P],
+    "eegclip_reduce_mid": [_P, _I, _I, _I, _P, _P],
+    "eegclip_sumsq": [_P, _L, _P, _P],
+    "eegclip_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
+    "eegclip_clip_scale": [_P, _F, _P, _P],
+    "eegclip_attention_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_tsconv_fold": [_P, _P, _P],
+    "eegclip_tsconv_unfold_grad": [_P, _P, _P],
+    "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
+    "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
+    "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],
+    "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
+    "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],
+    "eegclip_infonce_loss": [_P, _I, _L, _P, _P, _P, _F, _P, _P],
+    "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P],
+    "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
 }
 
 

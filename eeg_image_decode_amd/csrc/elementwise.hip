@@ -1,0 +1,226 @@
+// Small streaming kernels around the GEMMs: subject-token insertion + embedding dropout, dropout/GELU backward,
+// bias-gradient reductions, fused AdamW.  All are flat grid-stride, coalesced, HBM-bound.
+#include "eeg_common.h"
+
+namespace eeg {
+
+static inline int ew_grid(long long n, int block = 256, int cap = 4096) {
+    long long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// h: (B, L, D).  Row 0 of every sample <- subject token (table[ids[b]] or the shared token), then inverted dropout
+// over the whole (B,L,D) block in place.            (models/subject_layers/Embed.py:116-121,158-162)
+__global__ __launch_bounds__(256) void embed_finish_kernel(float* __restrict__ h, const float* __restrict__ tokens,
+                                                            const long long* __restrict__ ids, int B, int L, int D, float drop_p,
+                                                            unsigned long long seed, unsigned site) {
+    const long long n = (long long)B * L * D;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int l = (int)((i / D) % L);
+        float v;
+        if (l == 0) {
+            const int b = (int)(i / ((long long)D * L));
+            v = tokens[(ids ? ids[b] : 0) * D + d];
+        } else {
+            v = h[i];
+        }
+        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+        h[i] = v;
+    }
+}
+
+// backward of the above: dh *= mask/(1-p) in place; dtokens[id] += sum_b dh[b,0,:]
+__global__ __launch_bounds__(256) void embed_finish_bwd_kernel(float* __restrict__ dh, float* __restrict__ dtokens,
+                                                                const long long* __restrict__ ids, int B, int L, int D, float drop_p,
+                                                                unsigned long long seed, unsigned site) {
+    const long long n = (long long)B * L * D;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = dh[i];
+        if (drop_p > 0.f) {
+            v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+            dh[i] = v;
+        }
+        const int l = (int)((i / D) % L);
+        if (l == 0 && dtokens) {
+            const int d = (int)(i % D);
+            const int b = (int)(i / ((long long)D * L));
+            atomicAdd(dtokens + (ids ? ids[b] : 0) * D + d, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_scale_kernel(float* __restrict__ x, long long n, float drop_p,
+                                                             unsigned long long seed, unsigned site) {
+    const float ks = 1.f / (1.f - drop_p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[i] = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? x[i] * ks : 0.f;
+}
+
+// dx (+)= dy * mask/(1-p) * gelu'(pre)      (backward of y = dropout(gelu(pre)); p = 0 -> plain GELU backward)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                        float* __restrict__ dx, long long n, int accumulate, float drop_p,
+                                                        unsigned long long seed, unsigned site) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float d = dy[i];
+        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
+        const float v = d * gelu_erf_grad(pre[i]);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// y = a*x + b*y
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a,
+                                                     float b) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+// out[m] += sum_{o,i} x[o][m][i]   over an (outer, mid, inner) view   (bias gradients)
+// grid (chunks, ceil(mid/64)); block 256 = 4 row-groups x 64 consecutive `mid` (inner == 1) or flat (inner > 1)
+__global__ __launch_bounds__(256) void reduce_mid_kernel(const float* __restrict__ x, int outer, int mid, int inner,
+                                                          float* __restrict__ out) {
+    EEG_LDS_BASE(float, red);   // [4][64]
+    if (inner == 1) {
+        const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int m = blockIdx.y * 64 + lane;
+        float s = 0.f;
+        if (m < mid)
+            for (int o = blockIdx.x * 4 + g; o < outer; o += gridDim.x * 4) s += x[(long long)o * mid + m];
+        red[g * 64 + lane] = s;
+        __syncthreads();
+        if (g == 0 && m < mid) atomicAdd(out + m, red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+    } else {
+        // one `mid` index per blockIdx.y*64 + wave-slot is wasteful for tiny tensors, but these are (B,40,36)-sized
+        for (int mm = 0; mm < 64; ++mm) {
+            const int m = blockIdx.y * 64 + mm;
+            if (m >= mid) break;
+            float s = 0.f;
+            for (int o = blockIdx.x; o < outer; o += gridDim.x) {
+                const float* p = x + ((long long)o * mid + m) * inner;
+                for (int i = threadIdx.x; i < inner; i += blockDim.x) s += p[i];
+            }
+            s = wave_sum(s);
+            if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(out + m, s);
+        }
+    }
+}
+
+// torch.optim.AdamW / Adam single-step math on a flat fp32 segment (decoupled weight decay, bias correction).
+// bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t) are computed on the host in double.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2s, float grad_scale,
+                                                     const float* __restrict__ grad_scale_dev) {
+    const float step = lr / bc1;
+    if (grad_scale_dev) grad_scale *= *grad_scale_dev;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i];
+        pi *= (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = pi - step * (mi / denom);
+    }
+}
+
+// sum of squares of a flat fp32 buffer into a double accumulator (clip_grad_norm_)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ out) {
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        s += (double)x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+__global__ void clip_scale_kernel(const double* __restrict__ sumsq, float max_norm, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float nrm = (float)sqrt(*sumsq);
+        const float c = max_norm / (nrm + 1e-6f);
+        *out = c < 1.f ? c : 1.f;
+    }
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, void* stream) {
+    if (!sumsq || !scale_out || max_norm <= 0.f) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(clip_scale_kernel, dim3(1), dim3(64), 0, stream, sumsq, max_norm, scale_out);
+    return (int)hipGetLastError();
+}
+
+
+extern "C" int eegclip_embed_finish(float* h, const float* tokens, const long long* ids, int B, int L, int D, float drop_p,
+                                    unsigned long long seed, unsigned site, void* stream) {
+    if (!h || !tokens || B < 1 || L < 1 || D < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(embed_finish_kernel, dim3(ew_grid((long long)B * L * D)), dim3(256), 0, stream, h, tokens, ids, B, L, D, drop_p, seed,
+               site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_embed_finish_bwd(float* dh, float* dtokens, const long long* ids, int B, int L, int D, float drop_p,
+                                        unsigned long long seed, unsigned site, void* stream) {
+    if (!dh || B < 1 || L < 1 || D < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(embed_finish_bwd_kernel, dim3(ew_grid((long long)B * L * D)), dim3(256), 0, stream, dh, dtokens, ids, B, L, D, drop_p,
+               seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_dropout_scale(float* x, long long n, float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!x || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (n == 0 || drop_p == 0.f) return 0;
+    EEG_LAUNCH(dropout_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, n, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
+                                unsigned long long seed, unsigned site, void* stream) {
+    if (!dy || !pre || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    EEG_LAUNCH(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, pre, dx, n, accumulate, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_axpby(const float* x, float* y, long long n, float a, float b, void* stream) {
+    if (!x || !y || n < 0) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    EEG_LAUNCH(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, y, n, a, b);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out, void* stream) {
+    if (!x || !out || outer < 1 || mid < 1 || inner < 1) return EEGCLIP_EINVAL;
+    int chunks = inner == 1 ? (outer + 3) / 4 : outer;
+    if (chunks > 128) chunks = 128;
+    EEG_LAUNCH(reduce_mid_kernel, dim3(chunks, (mid + 63) / 64), dim3(256), 4 * 64 * sizeof(float), stream, x, outer, mid, inner, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, long long step, float grad_scale, const float* grad_scale_dev,
+                                  void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    EEG_LAUNCH(adamw_kernel, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+               (float)bc1, (float)sqrt(bc2), grad_scale, grad_scale_dev);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_sumsq(const float* x, long long n, double* out, void* stream) {
+    if (!x || !out || n < 0) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    EEG_LAUNCH(sumsq_kernel, dim3(ew_grid(n, 256, 1024)), dim3(256), 0, stream, x, n, out);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,299 @@
+// LayerNorm forward/backward (rows of 250 or 1024 floats) and the BatchNorm2d(+ELU, +dropout) pieces of tsconv.
+// All of these are HBM-bound streaming kernels: one wavefront per row / coalesced lane-strided access,
+// 64-lane xor-butterfly reductions, statistics kept in fp32 (LN) or fp64 atomics (BN batch sums).
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int LN_MAXC = 16;   // columns per lane: cols <= 1024
+
+// y = (x - mean) * rstd * gamma + beta ; mean/rstd saved for backward.  One wave per row, grid-stride over rows.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (long long)row * cols;
+        float v[LN_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? xr[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = c < cols ? v[i] - mean : 0.f;
+            q += dlt * dlt;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+        float* yr = y + (long long)row * cols;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+// dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                             int cols, int accumulate_dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    float pg[LN_MAXC], pb[LN_MAXC], gm[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        pg[i] = 0.f;
+        pb[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = c < cols ? gamma[c] : 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (long long)row * cols;
+        const float* dr = dy + (long long)row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXC], g[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < cols;
+            const float d = ok ? dr[c] : 0.f;
+            xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
+            g[i] = d * gm[i];
+            s1 += g[i];
+            s2 += g[i] * xh[i];
+            pg[i] += d * xh[i];
+            pb[i] += d;
+        }
+        const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
+        float* dxr = dx + (long long)row * cols;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) {
+                const float v = rs * (g[i] - c1 - xh[i] * c2);
+                dxr[c] = accumulate_dx ? dxr[c] + v : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) {
+            atomicAdd(dgamma + c, pg[i]);
+            atomicAdd(dbeta + c, pb[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm2d over a (outer, C, inner) view: channel c owns elements x[o][c][i].
+// sums[c] = sum x, sums[C + c] = sum x^2   (fp64 atomics: 5.8e5 terms per channel at B=256)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int outer, int C, int inner,
+                                                        double* __restrict__ sums) {
+    // grid: (chunks, C).  each block reduces a strided set of (o) slabs of channel blockIdx.y
+    const int c = blockIdx.y;
+    double s = 0.0, q = 0.0;
+    const long long per = (long long)inner;
+    for (int o = blockIdx.x; o < outer; o += gridDim.x) {
+        const float* p = x + ((long long)o * C + c) * per;
+        for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+            const float v = p[i];
+            s += v;
+            q += (double)v * v;
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sums + c, s);
+        atomicAdd(sums + C + c, q);
+    }
+}
+
+// train: mean/rstd from batch sums (biased variance), running stats updated with the unbiased variance
+// (torch BatchNorm semantics, momentum 0.1).  eval: mean/rstd from the running stats.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum, int C,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, int train) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (train) {
+        const double m = sums[c] / count;
+        double var = sums[C + c] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    } else {
+        mean[c] = running_mean[c];
+        rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
+}
+
+// y = dropout( ELU( gamma * (x - mean) * rstd + beta ) )   over the (outer, C, inner) view, flat grid-stride
+__global__ __launch_bounds__(256) void bn_elu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y, long long n,
+                                                          int C, int inner, float drop_p, unsigned long long seed,
+                                                          unsigned site) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / inner) % C);
+        float v = elu1(gamma[c] * (x[i] - mean[c]) * rstd[c] + beta[c]);
+        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+        y[i] = v;
+    }
+}
+
+// backward, pass 1:  da = dz * mask/(1-p) * ELU'(bn(x)) ; sums[c] += da ; sums[C+c] += da * xhat
+__global__ __launch_bounds__(256) void bn_elu_bwd_stats_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int outer, int C, int inner, float drop_p,
+                                                                unsigned long long seed, unsigned site,
+                                                                double* __restrict__ sums) {
+    const int c = blockIdx.y;
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    double s = 0.0, q = 0.0;
+    for (int o = blockIdx.x; o < outer; o += gridDim.x) {
+        const long long base = ((long long)o * C + c) * inner;
+        for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+            const float xh = (x[base + i] - mu) * rs;
+            const float u = g * xh + b;
+            float d = dz[base + i];
+            if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)(base + i), drop_p) ? d * ks : 0.f;
+            const float da = u > 0.f ? d : d * expf(u);
+            s += da;
+            q += (double)da * xh;
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sums + c, s);
+        atomicAdd(sums + C + c, q);
+    }
+}
+
+// backward, pass 2:  dx = gamma * rstd * (da - sum_da/n - xhat * sum_da_xhat/n) ; dgamma += sum_da_xhat ; dbeta += sum_da
+__global__ __launch_bounds__(256) void bn_elu_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const double* __restrict__ sums, double count, float* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long long n,
+                                                                int C, int inner, float drop_p, unsigned long long seed,
+                                                                unsigned site) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid < C) {
+        atomicAdd(dgamma + gtid, (float)sums[C + gtid]);
+        atomicAdd(dbeta + gtid, (float)sums[gtid]);
+    }
+    for (long long i = gtid; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / inner) % C);
+        const float rs = rstd[c], g = gamma[c];
+        const float xh = (x[i] - mean[c]) * rs;
+        const float u = g * xh + beta[c];
+        float d = dz[i];
+        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
+        const float da = u > 0.f ? d : d * expf(u);
+        const float m1 = (float)(sums[c] / count), m2 = (float)(sums[C + c] / count);
+        dx[i] = g * rs * (da - m1 - xh * m2);
+    }
+}
+
+static inline int grid_for(long long n, int block, int cap) {
+    long long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                     int rows, int cols, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || cols < 1 || cols > 64 * LN_MAXC) return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const int grid = grid_for(rows, 4, 2048);
+    EEG_LAUNCH(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols < 1 || cols > 64 * LN_MAXC)
+        return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const int grid = grid_for(rows, 4 * 8, 512);   // >= 8 rows per wave so the dgamma/dbeta atomics amortise
+    EEG_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
+               accumulate_dx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bn_stats(const float* x, int outer, int C, int inner, double* sums, void* stream) {
+    if (!x || !sums || outer < 1 || C < 1 || inner < 1) return EEGCLIP_EINVAL;
+    int chunks = outer < 64 ? outer : 64;
+    EEG_LAUNCH(bn_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, x, outer, C, inner, sums);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bn_finalize(const double* sums, double count, float eps, float momentum, int C, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, int train, void* stream) {
+    if (!mean || !rstd || C < 1) return EEGCLIP_EINVAL;
+    if (train && (!sums || count < 1.0)) return EEGCLIP_EINVAL;
+    if (!train && (!running_mean || !running_var)) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, sums, count, eps, momentum, C, mean, rstd,
+               running_mean, running_var, train);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bn_elu_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  float* y, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site,
+                                  void* stream) {
+    if (!x || !mean || !rstd || !gamma || !beta || !y || outer < 1 || C < 1 || inner < 1 || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    const long long n = (long long)outer * C * inner;
+    EEG_LAUNCH(bn_elu_fwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, x, mean, rstd, gamma, beta, y, n, C, inner,
+               drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, double* sums /* [2C], zeroed by the caller */, float* dx, float* dgamma,
+                                  float* dbeta, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site,
+                                  void* stream) {
+    if (!dz || !x || !mean || !rstd || !gamma || !beta || !sums || !dx || !dgamma || !dbeta || outer < 1 || C < 1 || inner < 1 ||
+        drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    const long long n = (long long)outer * C * inner;
+    int chunks = outer < 64 ? outer : 64;
+    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, dz, x, mean, rstd, gamma, beta,
+               outer, C, inner, drop_p, seed, site, sums);
+    EEG_LAUNCH(bn_elu_bwd_apply_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, dz, x, mean, rstd, gamma, beta, sums,
+               (double)outer * inner, dx, dgamma, dbeta, n, C, inner, drop_p, seed, site);
+    return (int)hipGetLastError();
+}

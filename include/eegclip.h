@@ -68,6 +68,85 @@ typedef struct {
 
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);
 
+/* ---- LayerNorm (rows of <= 1024 floats).  Transformer_EncDec.py:47,51,77-78 ; ATMS_retrieval.py:166 ; diffusion_prior.py:120,140,155
+ * fwd: y = (x-mean)*rstd*gamma+beta, mean/rstd[rows] saved (may be NULL).  bwd: dx (+)= ..., dgamma/dbeta += (atomic). */
+int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          int rows, int cols, float eps, void* stream);
+int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, void* stream);
+
+/* ---- BatchNorm2d (+ELU, +dropout) over an (outer, C, inner) view.  ATMS_retrieval.py:104-105,107-109
+ * sums: double[2C] (sum, sum of squares) accumulated atomically -- zero it first.
+ * finalize: train=1 -> mean/rstd from the batch sums (biased var) and running stats updated in place with the unbiased
+ * var (momentum); train=0 -> mean/rstd from the running stats.
+ * bn_elu_fwd: y = dropout(ELU(gamma*(x-mean)*rstd+beta)).   bn_elu_bwd: dx, dgamma +=, dbeta += (sums = double[2C] scratch, zeroed). */
+int eegclip_bn_stats(const float* x, int outer, int C, int inner, double* sums, void* stream);
+int eegclip_bn_finalize(const double* sums, double count, float eps, float momentum, int C, float* mean, float* rstd,
+                        float* running_mean, float* running_var, int train, void* stream);
+int eegclip_bn_elu_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                       int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       double* sums, float* dx, float* dgamma, float* dbeta, int outer, int C, int inner, float drop_p,
+                       unsigned long long seed, unsigned int site, void* stream);
+
+/* ---- token insertion + embedding dropout on h (B,L,D) in place.  Embed.py:116-121,158-162
+ * row 0 of sample b <- tokens[ids[b]] (ids == NULL: tokens[0], the shared token).  bwd: dh *= mask/(1-p); dtokens[id] += dh[b,0,:] */
+int eegclip_embed_finish(float* h, const float* tokens, const long long* ids, int B, int L, int D, float drop_p,
+                         unsigned long long seed, unsigned int site, void* stream);
+int eegclip_embed_finish_bwd(float* dh, float* dtokens, const long long* ids, int B, int L, int D, float drop_p,
+                             unsigned long long seed, unsigned int site, void* stream);
+
+/* ---- elementwise helpers (backward of the fused GEMM epilogues) */
+int eegclip_dropout_scale(float* x, long long n, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
+                     unsigned long long seed, unsigned int site, void* stream);        /* dx (+)= dy*mask/(1-p)*gelu'(pre) */
+int eegclip_axpby(const float* x, float* y, long long n, float a, float b, void* stream); /* y = a*x + b*y */
+int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out, void* stream); /* out[m] += sum_{o,i} x[o][m][i] */
+int eegclip_sumsq(const float* x, long long n, double* out, void* stream);              /* *out += sum x^2 */
+
+/* ---- fused AdamW / Adam step on a flat fp32 segment (torch.optim.AdamW math; ATMS_retrieval.py:548, diffusion_prior.py:286)
+ * `step` is the 1-based step count of this update.  g is multiplied by grad_scale and, if grad_scale_dev != NULL, by
+ * *grad_scale_dev (device scalar: gradient clipping without a host sync). */
+int eegclip_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, long long step, float grad_scale, const float* grad_scale_dev, void* stream);
+int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, void* stream); /* min(1, max_norm/(sqrt(sumsq)+1e-6)) */
+
+/* ---- 64-token multi-head self-attention.  SelfAttention_Family.py:56-75
+ * qkv: (B*L, ld) rows with q | k | v column blocks of H*E each; ctx/dctx: (B*L, H*E); dqkv like qkv.  L must be 64, E <= 64.
+ * dropout acts on the softmax probabilities; the mask is Philox(seed, site, ((b*H+h)*L+i)*L+j) and is regenerated in bwd. */
+int eegclip_attention_fwd(const float* qkv, float* ctx, int B, int L, int H, int E, int ld, float scale, float drop_p,
+                          unsigned long long seed, unsigned int site, void* stream);
+int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
+                          float drop_p, unsigned long long seed, unsigned int site, void* stream);
+
+/* ---- tsconv front: Conv2d(1,40,(1,25)) + AvgPool2d((1,51),(1,5)) folded into one 75-tap stride-5 filter.  ATMS_retrieval.py:102-103
+ * x: token rows of T=250 floats at x + b*xs_b + h*xs_h (h < H); y/dy: (B,40,H,36).  fold: (40,25) taps -> weff (40,75).
+ * fwd optionally accumulates the BatchNorm batch sums of y into sums (double[80], zeroed by the caller).
+ * bwd_w: dweff += ... (atomic, zero first); unfold_grad: dw25 += fold^T(dweff).  bwd_x overwrites dx rows h < H. */
+int eegclip_tsconv_fold(const float* w25, float* weff, void* stream);
+int eegclip_tsconv_unfold_grad(const float* dweff, float* dw25, void* stream);
+int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* weff, const float* bias, float* y, int B, int H,
+                       int T, int C, double* sums, void* stream);
+int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, int B, int H, int T, int C,
+                         void* stream);
+int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* dx, long long xs_b, long long xs_h, int B, int H, int T, int C,
+                         void* stream);
+
+/* ---- InfoNCE around the logits GEMM.  models/loss.py:122-140  (scale = pointer to the RAW logit_scale on the device)
+ * lse_rows/cols: log-sum-exp of scale*X along rows / columns.  infonce_grad: X (rows x cols block of raw logits, positives at
+ * column i+col0) <- scale * G in place, *loss += weighted loss contribution, *dscale += sum G.*raw.  lse_r or lse_c may be NULL
+ * (row-only / column-only term of the row-sharded loss).  infonce_loss: loss only (eval). */
+int eegclip_lse_rows(const float* X, int rows, int cols, long long ld, const float* scale, float* lse, void* stream);
+int eegclip_lse_cols(const float* X, int rows, int cols, long long ld, const float* scale, float* lse, void* stream);
+int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, int n_total, const float* scale, const float* lse_r,
+                         const float* lse_c, float weight, float* loss, float* dscale, void* stream);
+int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
+                         float* loss, void* stream);
+
+/* ---- retrieval readouts.  ATMS_retrieval.py:246 (argmax), :320 (top-5).  ties -> lowest index; out_idx: int64 (rows, k), k <= 8 */
+int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, long long* out_idx, void* stream);
+int eegclip_count_equal(const long long* pred, int stride, const long long* labels, int n, int* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""csrc/gemm.hip through the C ABI on both backends (CPU lane emulator; MI355X with -m gpu): all four operand layouts,
+ragged sizes, two-level index maps (the encoder's strided views), every epilogue stage, split-K, argument errors."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from backends import be  # noqa: F401
+from eeg_image_decode_amd import _abi
+from philox_np import keep_mask
+
+D = _abi.dim
+
+
+def run(be, desc):
+    rc = be.lib.eegclip_gemm_f32(ctypes.byref(desc), be.stream)
+    assert rc == 0, rc
+
+
+def mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, **kw):
+    d = _abi.GemmDesc(M=M, N=N, K=K, A=be.ptr(A), Am=Am, Ak=Ak, B=be.ptr(B), Bk=Bk, Bn=Bn, C=be.ptr(C), Cm=Cm, Cn=Cn,
+                      Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0,
+                      drop_p=0.0, seed=0, drop_site=0, split_k=1)
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def f32(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (64, 64, 32), (100, 70, 50), (63, 250, 250), (130, 33, 97)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(be, M, N, K, ta, tb):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K + ta * 2 + tb)
+    a = f32(rng, *((K, M) if ta else (M, K)))
+    b = f32(rng, *((N, K) if tb else (K, N)))
+    A, B, C = be.dev(a), be.dev(b), be.dev(np.full((M, N), np.nan, np.float32))
+    Am, Ak = (D(1), D(M)) if ta else (D(K), D(1))
+    Bk, Bn = (D(1), D(K)) if tb else (D(N), D(1))
+    run(be, mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), alpha=0.5))
+    ref = 0.5 * (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    np.testing.assert_allclose(be.host(C), ref, atol=2e-5 * max(1, np.abs(ref).max()))
+
+
+def test_gemm_epilogue_bias_gelu_pre_residual_accumulate(be):
+    from scipy.special import erf
+    rng = np.random.default_rng(5)
+    M, N, K = 70, 90, 40
+    a, w, bn, bm, r, c0 = f32(rng, M, K), f32(rng, N, K), f32(rng, N), f32(rng, M), f32(rng, M, N), f32(rng, M, N)
+    A, W, BN, BM, R, C, CP = be.dev(a), be.dev(w), be.dev(bn), be.dev(bm), be.dev(r), be.dev(c0), be.zeros((M, N))
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1), Cpre=be.ptr(CP), bias_n=be.ptr(BN), bias_m=be.ptr(BM),
+               R=be.ptr(R), Rm=D(N), Rn=D(1), act=_abi.ACT_GELU, accumulate=1))
+    pre = a.astype(np.float64) @ w.T + bn + bm[:, None]
+    ref = 0.5 * pre * (1 + erf(pre / np.sqrt(2))) + r + c0
+    np.testing.assert_allclose(be.host(CP), pre, atol=2e-5)
+    np.testing.assert_allclose(be.host(C), ref, atol=3e-5)
+
+
+def test_gemm_dropout_mask_is_philox_of_logical_index(be):
+    rng = np.random.default_rng(6)
+    M, N, K = 65, 67, 8
+    a, w = f32(rng, M, K), f32(rng, N, K)
+    A, W, C = be.dev(a), be.dev(w), be.zeros((M, N))
+    p, seed, site = 0.25, 0x1234567890ABCDEF, 3
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1), drop_p=p, seed=seed, drop_site=site))
+    keep = keep_mask(seed, site, M * N, p).reshape(M, N)
+    np.testing.assert_allclose(be.host(C), (a.astype(np.float64) @ w.T) * keep / (1 - p), atol=2e-5)
+    assert 0.6 < keep.mean() < 0.9
+
+
+def test_gemm_split_k_accumulates_atomically(be):
+    rng = np.random.default_rng(7)
+    M, N, K = 40, 75, 1000
+    a, b, bn, c0 = f32(rng, K, M), f32(rng, K, N), f32(rng, N), f32(rng, M, N)      # dW = dY^T X
+    A, B, BN, C = be.dev(a), be.dev(b), be.dev(bn), be.dev(c0)
+    run(be, mk(be, M, N, K, A, D(1), D(M), B, D(N), D(1), C, D(N), D(1), split_k=5, bias_n=be.ptr(BN), alpha=2.0))
+    ref = c0 + 2.0 * a.T.astype(np.float64) @ b + bn
+    np.testing.assert_allclose(be.host(C), ref, atol=3e-4)
+
+
+def test_gemm_two_level_dims_embedding_view(be):
+    """Value-embedding GEMM writes rows 1..63 of each (64,T) token block and adds PE[channel] (Embed.py:146-160)."""
+    rng = np.random.default_rng(8)
+    Bt, Cc, T = 3, 63, 50
+    x, w, b, pe = f32(rng, Bt, Cc, T), f32(rng, T, T), f32(rng, T), f32(rng, Cc, T)
+    X, W, Bv, PE, OUT = be.dev(x), be.dev(w), be.dev(b), be.dev(pe), be.zeros((Bt, Cc + 1, T))
+    d = mk(be, Bt * Cc, T, T, X, D(T), D(1), W, D(1), D(T), OUT, D(T, div=Cc, so=(Cc + 1) * T), D(1), bias_n=be.ptr(Bv),
+           R=be.ptr(PE), Rm=D(T, div=Cc, so=0), Rn=D(1))
+    d.C = be.ptr(OUT) + T * 4            # skip token row 0 of sample 0
+    run(be, d)
+    out = be.host(OUT)
+    np.testing.assert_allclose(out[:, 1:], x.astype(np.float64) @ w.T + b + pe, atol=2e-5)
+    assert (out[:, 0] == 0).all()
+
+
+def test_gemm_spatial_conv_view(be):
+    """(63x1) conv as one GEMM over the (B,40,63,36) tensor: M = out ch, N = (b,w) two-level, K = (c,h)."""
+    rng = np.random.default_rng(9)
+    Bt, Ci, H, Wd, Co = 3, 5, 7, 36, 6
+    z, w2, bias = f32(rng, Bt, Ci, H, Wd), f32(rng, Co, Ci, H), f32(rng, Co)
+    Z, W2, BI, Y = be.dev(z), be.dev(w2), be.dev(bias), be.zeros((Bt, Co, Wd))
+    run(be, mk(be, Co, Bt * Wd, Ci * H, W2, D(Ci * H), D(1), Z, D(Wd), D(1, div=Wd, so=Ci * H * Wd), Y, D(Wd),
+               D(1, div=Wd, so=Co * Wd), bias_m=be.ptr(BI)))
+    ref = np.einsum("och,bchw->bow", w2.astype(np.float64), z.astype(np.float64)) + bias[None, :, None]
+    np.testing.assert_allclose(be.host(Y), ref, atol=2e-5)
+
+
+def test_gemm_big_tile_grid(be):
+    """A shape with many tiles in both directions and a long K (proj head 1440 -> 1024 at B = 96)."""
+    rng = np.random.default_rng(10)
+    M, N, K = 96, 1024, 1440
+    a, w = f32(rng, M, K), f32(rng, N, K) * 0.03
+    A, W, C = be.dev(a), be.dev(w), be.zeros((M, N))
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1)))
+    ref = a.astype(np.float64) @ w.T.astype(np.float64)
+    np.testing.assert_allclose(be.host(C), ref, atol=1e-4)
+
+
+def test_gemm_rejects_bad_arguments(be):
+    L = be.lib
+    assert L.eegclip_gemm_f32(None, be.stream) < 0
+    A = be.zeros((4, 4))
+    d = mk(be, 4, 4, 4, A, D(4), D(1), A, D(4), D(1), be.zeros((4, 4)), D(4), D(1), split_k=2, act=_abi.ACT_GELU)
+    assert L.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0       # act with split-K is not allowed
+    d = mk(be, 4, 4, 4, A, D(4), D(1), A, D(4), D(1), be.zeros((4, 4)), D(4), D(1), drop_p=1.0)
+    assert L.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0

@@ -1,0 +1,254 @@
+"""Per-kernel parity: every C-ABI op vs a plain torch-CPU fp64 reference of the same op, on both backends
+(CPU lane emulator here, MI355X with -m gpu).  Tolerances are fp32 round-off (1e-5 .. 1e-4 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backends import be, ok  # noqa: F401
+from philox_np import keep_mask
+
+SEED = 0x5EEDC0FFEE
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 250), (64, 1024), (130, 64), (3, 7)])
+def test_layernorm_fwd_bwd(be, rows, cols):
+    rng = np.random.default_rng(rows * 7 + cols)
+    x, g, b, dy = rnd(rng, rows, cols), 1 + 0.1 * rnd(rng, cols), 0.1 * rnd(rng, cols), rnd(rng, rows, cols)
+    X, G, Bt, DY = be.dev(x), be.dev(g), be.dev(b), be.dev(dy)
+    Y, MU, RS = be.zeros((rows, cols)), be.zeros(rows), be.zeros(rows)
+    ok(be.lib.eegclip_layernorm_fwd(be.ptr(X), be.ptr(G), be.ptr(Bt), be.ptr(Y), be.ptr(MU), be.ptr(RS), rows, cols, 1e-5, be.stream))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yt = F.layer_norm(xt, (cols,), gt, bt, 1e-5)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    np.testing.assert_allclose(be.host(Y), yt.detach().numpy(), atol=2e-5)
+    dx0 = rnd(rng, rows, cols)
+    DX, DG, DB = be.dev(dx0), be.zeros(cols), be.zeros(cols)
+    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX), be.ptr(DG), be.ptr(DB),
+                                    rows, cols, 1, be.stream))
+    np.testing.assert_allclose(be.host(DX), dx0 + xt.grad.numpy(), atol=5e-5)
+    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
+    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
+
+
+@pytest.mark.parametrize("outer,C,inner,p", [(6, 40, 63 * 36, 0.0), (9, 40, 36, 0.5), (2, 3, 5, 0.0)])
+def test_batchnorm_elu_train_fwd_bwd(be, outer, C, inner, p):
+    rng = np.random.default_rng(outer + C + inner)
+    x, g, b = rnd(rng, outer, C, inner) * 1.5 + 0.3, 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C)
+    dz = rnd(rng, outer, C, inner)
+    rm0, rv0 = 0.1 * rnd(rng, C), (1 + 0.2 * rng.random(C)).astype(np.float32)
+    X, G, Bt, DZ = be.dev(x), be.dev(g), be.dev(b), be.dev(dz)
+    SUMS = be.zeros(2 * C, np.float64)
+    MU, RS, RM, RV = be.zeros(C), be.zeros(C), be.dev(rm0), be.dev(rv0)
+    n = outer * inner
+    ok(be.lib.eegclip_bn_stats(be.ptr(X), outer, C, inner, be.ptr(SUMS), be.stream))
+    ok(be.lib.eegclip_bn_finalize(be.ptr(SUMS), float(n), 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 1, be.stream))
+    Y = be.zeros((outer, C, inner))
+    ok(be.lib.eegclip_bn_elu_fwd(be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(Bt), be.ptr(Y), outer, C, inner, p, SEED, 5, be.stream))
+    keep = keep_mask(SEED, 5, outer * C * inner, p).reshape(outer, C, inner) if p > 0 else np.ones((outer, C, inner), bool)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    rm, rv = torch.tensor(rm0, dtype=torch.float64), torch.tensor(rv0, dtype=torch.float64)
+    yt = F.elu(F.batch_norm(xt, rm, rv, gt, bt, True, 0.1, 1e-5)) * torch.tensor(keep) / (1 - p)
+    yt.backward(torch.tensor(dz, dtype=torch.float64))
+    np.testing.assert_allclose(be.host(Y), yt.detach().numpy(), atol=3e-5)
+    np.testing.assert_allclose(be.host(RM), rm.numpy(), atol=1e-6)
+    np.testing.assert_allclose(be.host(RV), rv.numpy(), atol=1e-5)
+    S2, DX, DG, DB = be.zeros(2 * C, np.float64), be.zeros((outer, C, inner)), be.zeros(C), be.zeros(C)
+    ok(be.lib.eegclip_bn_elu_bwd(be.ptr(DZ), be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(Bt), be.ptr(S2), be.ptr(DX), be.ptr(DG),
+                                 be.ptr(DB), outer, C, inner, p, SEED, 5, be.stream))
+    np.testing.assert_allclose(be.host(DX), xt.grad.numpy(), atol=5e-5)
+    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1, n ** 0.5 / 10))
+    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1, n ** 0.5 / 10))
+    # eval mode: statistics come from the running buffers
+    ok(be.lib.eegclip_bn_finalize(None, 0.0, 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 0, be.stream))
+    ok(be.lib.eegclip_bn_elu_fwd(be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(Bt), be.ptr(Y), outer, C, inner, 0.0, 0, 0, be.stream))
+    ye = F.elu(F.batch_norm(xt.detach(), rm, rv, gt.detach(), bt.detach(), False, 0.1, 1e-5))
+    np.testing.assert_allclose(be.host(Y), ye.numpy(), atol=3e-5)
+
+
+@pytest.mark.parametrize("use_ids,p", [(True, 0.0), (False, 0.25), (True, 0.25)])
+def test_embed_finish_fwd_bwd(be, use_ids, p):
+    rng = np.random.default_rng(3)
+    B, L, D = 5, 64, 250
+    h = rnd(rng, B, L, D)
+    tokens = rnd(rng, 10, D)
+    ids = np.array([1, 9, 3, 3, 0], np.int64)
+    H, TK, IDS = be.dev(h), be.dev(tokens), be.dev(ids) if use_ids else None
+    ok(be.lib.eegclip_embed_finish(be.ptr(H), be.ptr(TK), be.ptr(IDS), B, L, D, p, SEED, 0, be.stream))
+    ref = h.copy()
+    ref[:, 0] = tokens[ids] if use_ids else tokens[0]
+    keep = keep_mask(SEED, 0, B * L * D, p).reshape(B, L, D) if p > 0 else np.ones((B, L, D), bool)
+    np.testing.assert_allclose(be.host(H), ref * keep / (1 - p), rtol=1e-6)
+    dh = rnd(rng, B, L, D)
+    DH, DT = be.dev(dh), be.zeros((10, D))
+    ok(be.lib.eegclip_embed_finish_bwd(be.ptr(DH), be.ptr(DT), be.ptr(IDS), B, L, D, p, SEED, 0, be.stream))
+    dref = dh * keep / (1 - p)
+    np.testing.assert_allclose(be.host(DH), dref, rtol=1e-6)
+    dt = np.zeros((10, D))
+    for b in range(B):
+        dt[ids[b] if use_ids else 0] += dref[b, 0]
+    np.testing.assert_allclose(be.host(DT), dt, atol=1e-5)
+
+
+def test_elementwise_helpers(be):
+    rng = np.random.default_rng(4)
+    n = 10007
+    x, y, pre = rnd(rng, n), rnd(rng, n), rnd(rng, n)
+    X, Y = be.dev(x), be.dev(y)
+    ok(be.lib.eegclip_axpby(be.ptr(X), be.ptr(Y), n, 2.0, -0.5, be.stream))
+    np.testing.assert_allclose(be.host(Y), 2 * x - 0.5 * y, rtol=1e-6, atol=1e-6)
+    Y2 = be.dev(y)
+    ok(be.lib.eegclip_dropout_scale(be.ptr(Y2), n, 0.25, SEED, 2, be.stream))
+    keep = keep_mask(SEED, 2, n, 0.25)
+    np.testing.assert_allclose(be.host(Y2), y * keep / 0.75, rtol=1e-6)
+    PRE, DX = be.dev(pre), be.dev(y)
+    ok(be.lib.eegclip_gelu_bwd(be.ptr(X), be.ptr(PRE), be.ptr(DX), n, 1, 0.25, SEED, 2, be.stream))
+    pt = torch.tensor(pre, dtype=torch.float64, requires_grad=True)
+    (F.gelu(pt) * torch.tensor(keep) / 0.75).backward(torch.tensor(x, dtype=torch.float64))
+    np.testing.assert_allclose(be.host(DX), y + pt.grad.numpy(), atol=1e-5)
+    SS = be.zeros(1, np.float64)
+    ok(be.lib.eegclip_sumsq(be.ptr(X), n, be.ptr(SS), be.stream))
+    assert abs(be.host(SS)[0] - (x.astype(np.float64) ** 2).sum()) < 1e-6 * n
+    SC = be.zeros(1)
+    ok(be.lib.eegclip_clip_scale(be.ptr(SS), 1.0, be.ptr(SC), be.stream))
+    assert abs(be.host(SC)[0] - min(1.0, 1.0 / (np.sqrt((x.astype(np.float64) ** 2).sum()) + 1e-6))) < 1e-7
+
+
+@pytest.mark.parametrize("outer,mid,inner", [(1000, 250, 1), (7, 40, 36), (3, 1024, 1), (1, 5, 1)])
+def test_reduce_mid(be, outer, mid, inner):
+    rng = np.random.default_rng(outer)
+    x = rnd(rng, outer, mid, inner)
+    o0 = rnd(rng, mid)
+    X, O = be.dev(x), be.dev(o0)
+    ok(be.lib.eegclip_reduce_mid(be.ptr(X), outer, mid, inner, be.ptr(O), be.stream))
+    np.testing.assert_allclose(be.host(O), o0 + x.astype(np.float64).sum(axis=(0, 2)), atol=1e-4 * max(1, (outer * inner) ** 0.5 / 8))
+
+
+def test_adamw_matches_torch(be):
+    rng = np.random.default_rng(6)
+    n = 5000
+    p0 = rnd(rng, n)
+    P, M, V = be.dev(p0), be.zeros(n), be.zeros(n)
+    pt = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.AdamW([pt], lr=3e-4)
+    for step in range(1, 4):
+        g = rnd(rng, n) * (1e-3 if step == 2 else 1.0)
+        G = be.dev(g)
+        ok(be.lib.eegclip_adamw_step(be.ptr(P), be.ptr(G), be.ptr(M), be.ptr(V), n, 3e-4, 0.9, 0.999, 1e-8, 0.01, step, 1.0, None, be.stream))
+        pt.grad = torch.tensor(g)
+        opt.step()
+    np.testing.assert_allclose(be.host(P), pt.detach().numpy(), atol=2e-7, rtol=1e-6)
+
+
+def _attn_ref(qkv, B, H, E, scale, keep, p):
+    L = 64
+    q, k, v = [t.view(B, L, H, E).permute(0, 2, 1, 3) for t in qkv.view(B * L, 3, H * E).unbind(1)]
+    A = torch.softmax(q @ k.transpose(-1, -2) * scale, -1)
+    A = A * keep / (1 - p)
+    return (A @ v).permute(0, 2, 1, 3).reshape(B * L, H * E)
+
+
+@pytest.mark.parametrize("B,H,E,p", [(2, 4, 62, 0.0), (3, 4, 62, 0.25), (1, 2, 64, 0.0), (1, 1, 5, 0.0)])
+def test_attention_fwd_bwd(be, B, H, E, p):
+    rng = np.random.default_rng(B * 100 + H * 10 + E)
+    L, ld = 64, 3 * H * E
+    qkv = rnd(rng, B * L, ld, scale=0.8)
+    dctx = rnd(rng, B * L, H * E)
+    scale = 1.0 / math.sqrt(E)
+    QKV, DCTX = be.dev(qkv), be.dev(dctx)
+    CTX, DQKV = be.zeros((B * L, H * E)), be.zeros((B * L, ld))
+    ok(be.lib.eegclip_attention_fwd(be.ptr(QKV), be.ptr(CTX), B, L, H, E, ld, scale, p, SEED, 1, be.stream))
+    ok(be.lib.eegclip_attention_bwd(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQKV), B, L, H, E, ld, scale, p, SEED, 1, be.stream))
+    keep = torch.tensor(keep_mask(SEED, 1, B * H * L * L, p).reshape(B, H, L, L)) if p > 0 else torch.ones(B, H, L, L, dtype=torch.bool)
+    qt = torch.tensor(qkv, dtype=torch.float64, requires_grad=True)
+    out = _attn_ref(qt, B, H, E, scale, keep, p)
+    out.backward(torch.tensor(dctx, dtype=torch.float64))
+    np.testing.assert_allclose(be.host(CTX), out.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(be.host(DQKV), qt.grad.numpy(), atol=5e-5)
+
+
+@pytest.mark.parametrize("B,H", [(2, 63), (3, 5)])
+def test_tsconv_fold_fwd_bwd(be, B, H):
+    rng = np.random.default_rng(B + H)
+    w25, bias = rnd(rng, 40, 25, scale=0.2), rnd(rng, 40, scale=0.1)
+    xfull = rnd(rng, B, 64, 250)                       # encoder output; rows h < H are convolved in place
+    W25, BIAS, X = be.dev(w25), be.dev(bias), be.dev(xfull)
+    WEFF = be.zeros((40, 75))
+    ok(be.lib.eegclip_tsconv_fold(be.ptr(W25), be.ptr(WEFF), be.stream))
+    Y, SUMS = be.zeros((B, 40, H, 36)), be.zeros(80, np.float64)
+    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(WEFF), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS), be.stream))
+    xt = torch.tensor(xfull, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w25, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(bias, dtype=torch.float64)
+    yt = F.avg_pool2d(F.conv2d(xt[:, :H].unsqueeze(1), wt.view(40, 1, 1, 25), bt), (1, 51), (1, 5))
+    assert yt.shape == (B, 40, H, 36)
+    np.testing.assert_allclose(be.host(Y), yt.detach().numpy(), atol=2e-5)
+    s = be.host(SUMS)
+    np.testing.assert_allclose(s[:40], yt.detach().sum((0, 2, 3)).numpy(), atol=1e-3)
+    np.testing.assert_allclose(s[40:], (yt.detach() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-5)
+    dy = rnd(rng, B, 40, H, 36)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    DY, DWEFF, DW25 = be.dev(dy), be.zeros((40, 75)), be.dev(np.ones((40, 25), np.float32))
+    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY), be.ptr(DWEFF), B, H, 250, 40, be.stream))
+    ok(be.lib.eegclip_tsconv_unfold_grad(be.ptr(DWEFF), be.ptr(DW25), be.stream))
+    np.testing.assert_allclose(be.host(DW25) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+    DX = be.dev(np.full((B, 64, 250), 7.0, np.float32))
+    ok(be.lib.eegclip_tsconv_bwd_x(be.ptr(DY), be.ptr(WEFF), be.ptr(DX), 64 * 250, 250, B, H, 250, 40, be.stream))
+    dx = be.host(DX)
+    np.testing.assert_allclose(dx[:, :H], xt.grad.numpy()[:, :H], atol=3e-5)
+    assert (dx[:, H:] == 7.0).all()                   # rows beyond H are not touched
+
+
+@pytest.mark.parametrize("N,w", [(32, 1.0), (200, 0.99)])
+def test_infonce_pieces_match_closed_form(be, N, w):
+    rng = np.random.default_rng(N)
+    D = 64
+    a = rnd(rng, N, D, scale=2.0)
+    b = rnd(rng, N, D)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    s = np.float32(math.log(1 / 0.07))
+    raw = (a.astype(np.float64) @ b.T.astype(np.float64))
+    X, SC = be.dev(raw.astype(np.float32)), be.dev(np.array([s], np.float32))
+    LR, LC = be.zeros(N), be.zeros(N)
+    ok(be.lib.eegclip_lse_rows(be.ptr(X), N, N, N, be.ptr(SC), be.ptr(LR), be.stream))
+    ok(be.lib.eegclip_lse_cols(be.ptr(X), N, N, N, be.ptr(SC), be.ptr(LC), be.stream))
+    S = torch.tensor(raw.astype(np.float32), dtype=torch.float64) * float(s)
+    np.testing.assert_allclose(be.host(LR), torch.logsumexp(S, 1).numpy(), atol=2e-5)
+    np.testing.assert_allclose(be.host(LC), torch.logsumexp(S, 0).numpy(), atol=2e-5)
+    LOSS, DS, LOSS2 = be.zeros(1), be.zeros(1), be.zeros(1)
+    ok(be.lib.eegclip_infonce_loss(be.ptr(X), N, N, be.ptr(SC), be.ptr(LR), be.ptr(LC), w, be.ptr(LOSS2), be.stream))
+    ok(be.lib.eegclip_infonce_grad(be.ptr(X), N, N, N, 0, N, be.ptr(SC), be.ptr(LR), be.ptr(LC), w, be.ptr(LOSS), be.ptr(DS), be.stream))
+    idx = torch.arange(N)
+    lref = w * 0.5 * ((torch.logsumexp(S, 1) - S[idx, idx]).mean() + (torch.logsumexp(S, 0) - S[idx, idx]).mean())
+    G = w * (torch.softmax(S, 1) + torch.softmax(S, 0) - 2 * torch.eye(N, dtype=torch.float64)) / (2 * N)
+    assert abs(be.host(LOSS)[0] - float(lref)) < 2e-5 and abs(be.host(LOSS2)[0] - float(lref)) < 2e-5
+    np.testing.assert_allclose(be.host(X), (float(s) * G).numpy(), atol=2e-6)
+    assert abs(be.host(DS)[0] - float((G * torch.tensor(raw.astype(np.float32), dtype=torch.float64)).sum())) < 2e-5
+
+
+def test_topk_and_count(be):
+    rng = np.random.default_rng(11)
+    rows, cols = 37, 200
+    x = rnd(rng, rows, cols)
+    x[3, 10] = x[3, 150] = 9.0                           # tie -> lowest index first
+    X = be.dev(x)
+    for k in (1, 5):
+        OUT = be.zeros((rows, k), np.int64)
+        ok(be.lib.eegclip_topk_rows(be.ptr(X), rows, cols, cols, k, be.ptr(OUT), be.stream))
+        ref = np.argsort(-x, axis=1, kind="stable")[:, :k]
+        assert (be.host(OUT) == ref).all()
+    labels = ref[:, 0].copy()
+    labels[::3] = (labels[::3] + 1) % cols
+    CNT = be.zeros(1, np.int32)
+    ok(be.lib.eegclip_count_equal(be.ptr(OUT), 5, be.ptr(be.dev(labels.astype(np.int64))), rows, be.ptr(CNT), be.stream))
+    assert be.host(CNT)[0] == int((ref[:, 0] == labels).sum())
