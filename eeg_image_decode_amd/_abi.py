@@ -47,6 +47,7 @@ PROTOTYPES = {
     "eegclip_gelu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],
     "eegclip_axpby": [_P, _P, _L, _F, _F, _P],
     "eegclip_reduce_mid": [_P, _I, _I, _I, _P, _P],
+    "eegclip_colsum_blocks": [_P, _I, _I, _I, _I, _L, _P, _P],
     "eegclip_sumsq": [_P, _L, _P, _P],
     "eegclip_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
     "eegclip_clip_scale": [_P, _F, _P, _P],

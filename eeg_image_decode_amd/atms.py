@@ -1,0 +1,596 @@
+"""ATM-S EEG encoder on MI355X: same Python surface as the reference (Retrieval/ATMS_retrieval.py:171-191), all
+arithmetic in hand-written HIP kernels reached through the C ABI (include/eegclip.h).
+
+    model = ATMS().cuda();  z = model(eeg (B,63,250) f32, subject_ids (B,) i64)   ->  (B,1024) f32
+
+* The module tree reproduces the reference ``state_dict()`` key for key, so reference
+  ``.pth`` checkpoints load with ``load_state_dict`` and ours load into the reference.  The ``nn.Linear`` / ``nn.Conv2d``
+  / ``nn.LayerNorm`` ... children are parameter holders with torch's default initialisers; they are never *called*.
+* All parameters are views into ONE flat fp32 buffer (and their ``.grad`` into one flat gradient buffer): Q/K/V weights
+  are adjacent so the three projections are a single GEMM, the optimizer step is one fused kernel launch per segment,
+  and data-parallel gradient reduction is one RCCL all-reduce.
+* forward/backward are replayed launch plans (plan.py) per batch size; activations live in persistent buffers, so the
+  backward of a batch must run before the next forward at the same batch size (the training loop does exactly that).
+* There is no CPU / eager-PyTorch fallback: a CPU tensor or a missing library raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi
+from ._lib import EegclipError, lib, require_cuda
+from .loss import ClipLoss
+from .plan import Plan
+
+D = _abi.dim
+ACT_GELU = _abi.ACT_GELU
+
+N_CH, T_LEN, D_MODEL, N_HEADS, D_HEAD, D_FF = 63, 250, 250, 4, 62, 256
+L_TOK = N_CH + 1
+HE = N_HEADS * D_HEAD            # 248: d_keys = 250 // 4 (SelfAttention_Family.py:184)
+C_TS, W_TS, F_TS, P_DIM = 40, 36, 1440, 1024
+EPS = 1e-5
+SITE_EMBED, SITE_ATTN, SITE_ATTN_OUT, SITE_FFN_ACT, SITE_FFN_OUT, SITE_CONV, SITE_PROJ = range(7)
+
+
+class Config:
+    """Hyper-parameters of the iTransformer front (Retrieval/ATMS_retrieval.py:44-59)."""
+
+    def __init__(self):
+        self.task_name = 'classification'
+        self.seq_len = 250
+        self.pred_len = 250
+        self.output_attention = False
+        self.d_model = 250
+        self.embed = 'timeF'
+        self.freq = 'h'
+        self.dropout = 0.25
+        self.factor = 1
+        self.n_heads = 4
+        self.e_layers = 1
+        self.d_ff = 256
+        self.activation = 'gelu'
+        self.enc_in = 63
+
+
+class _Holder(nn.Module):
+    """Parameter container: its arithmetic runs inside ATMS.forward (HIP kernels), never on its own."""
+
+    def forward(self, *a, **k):
+        raise EegclipError(f"{type(self).__name__} holds parameters only; call ATMS.forward (HIP kernels). There is no eager path.")
+
+
+class PositionalEmbedding(_Holder):
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        pos = torch.arange(0, max_len).float().unsqueeze(1)
+        div = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+
+class TimeFeatureEmbedding(_Holder):
+    def __init__(self, d_model):
+        super().__init__()
+        self.embed = nn.Linear(4, d_model, bias=False)      # dead parameter in the reference (x_mark is None)
+
+
+class SubjectEmbedding(_Holder):
+    def __init__(self, num_subjects, d_model):
+        super().__init__()
+        self.subject_embedding = nn.Embedding(num_subjects, d_model)
+        self.shared_embedding = nn.Parameter(torch.randn(1, d_model))
+        self.mask_embedding = nn.Parameter(torch.randn(1, d_model))
+
+
+class DataEmbedding(_Holder):
+    def __init__(self, c_in, d_model, dropout, num_subjects):
+        super().__init__()
+        self.value_embedding = nn.Linear(c_in, d_model)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.temporal_embedding = TimeFeatureEmbedding(d_model)
+        self.dropout = nn.Dropout(p=dropout)
+        self.subject_embedding = SubjectEmbedding(num_subjects, d_model)
+        self.mask_token = nn.Parameter(torch.randn(1, d_model))
+
+
+class FullAttention(_Holder):
+    def __init__(self, attention_dropout):
+        super().__init__()
+        self.dropout = nn.Dropout(attention_dropout)
+
+
+class AttentionLayer(_Holder):
+    def __init__(self, attention, d_model, n_heads):
+        super().__init__()
+        dk = d_model // n_heads
+        self.inner_attention = attention
+        self.query_projection = nn.Linear(d_model, dk * n_heads)
+        self.key_projection = nn.Linear(d_model, dk * n_heads)
+        self.value_projection = nn.Linear(d_model, dk * n_heads)
+        self.out_projection = nn.Linear(dk * n_heads, d_model)
+        self.n_heads = n_heads
+
+
+class EncoderLayer(_Holder):
+    def __init__(self, attention, d_model, d_ff, dropout):
+        super().__init__()
+        self.attention = attention
+        self.conv1 = nn.Conv1d(d_model, d_ff, 1)
+        self.conv2 = nn.Conv1d(d_ff, d_model, 1)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+
+class Encoder(_Holder):
+    def __init__(self, attn_layers, norm_layer):
+        super().__init__()
+        self.attn_layers = nn.ModuleList(attn_layers)
+        self.norm = norm_layer
+
+
+class iTransformer(_Holder):
+    def __init__(self, configs, joint_train=False, num_subjects=10):
+        super().__init__()
+        self.enc_embedding = DataEmbedding(configs.seq_len, configs.d_model, configs.dropout, num_subjects)
+        self.encoder = Encoder(
+            [EncoderLayer(AttentionLayer(FullAttention(configs.dropout), configs.d_model, configs.n_heads),
+                          configs.d_model, configs.d_ff, configs.dropout) for _ in range(configs.e_layers)],
+            norm_layer=nn.LayerNorm(configs.d_model))
+
+
+class PatchEmbedding(_Holder):
+    def __init__(self, emb_size=40):
+        super().__init__()
+        self.tsconv = nn.Sequential(
+            nn.Conv2d(1, 40, (1, 25), stride=(1, 1)), nn.AvgPool2d((1, 51), (1, 5)), nn.BatchNorm2d(40), nn.ELU(),
+            nn.Conv2d(40, 40, (63, 1), stride=(1, 1)), nn.BatchNorm2d(40), nn.ELU(), nn.Dropout(0.5))
+        self.projection = nn.Sequential(nn.Conv2d(40, emb_size, (1, 1), stride=(1, 1)), nn.Identity())
+
+
+class FlattenHead(_Holder):
+    pass
+
+
+class Enc_eeg(nn.Sequential):
+    def __init__(self, emb_size=40, **kwargs):
+        super().__init__(PatchEmbedding(emb_size), FlattenHead())
+
+    def forward(self, *a, **k):
+        raise EegclipError("Enc_eeg holds parameters only; call ATMS.forward")
+
+
+class ResidualAdd(_Holder):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class Proj_eeg(nn.Sequential):
+    def __init__(self, embedding_dim=1440, proj_dim=1024, drop_proj=0.5):
+        super().__init__(nn.Linear(embedding_dim, proj_dim),
+                         ResidualAdd(nn.Sequential(nn.GELU(), nn.Linear(proj_dim, proj_dim), nn.Dropout(drop_proj))),
+                         nn.LayerNorm(proj_dim))
+
+    def forward(self, *a, **k):
+        raise EegclipError("Proj_eeg holds parameters only; call ATMS.forward")
+
+
+# flat-buffer order: the always-live group first (QKV adjacent), then the two conditionally-live token tensors, then dead
+_E, _LY, _TS = "encoder.enc_embedding.", "encoder.encoder.attn_layers.0.", "enc_eeg.0.tsconv."
+_LIVE = [
+    "logit_scale",
+    _E + "value_embedding.weight", _E + "value_embedding.bias",
+    _LY + "attention.query_projection.weight", _LY + "attention.key_projection.weight", _LY + "attention.value_projection.weight",
+    _LY + "attention.query_projection.bias", _LY + "attention.key_projection.bias", _LY + "attention.value_projection.bias",
+    _LY + "attention.out_projection.weight", _LY + "attention.out_projection.bias",
+    _LY + "conv1.weight", _LY + "conv1.bias", _LY + "conv2.weight", _LY + "conv2.bias",
+    _LY + "norm1.weight", _LY + "norm1.bias", _LY + "norm2.weight", _LY + "norm2.bias",
+    "encoder.encoder.norm.weight", "encoder.encoder.norm.bias",
+    _TS + "0.weight", _TS + "0.bias", _TS + "2.weight", _TS + "2.bias", _TS + "4.weight", _TS + "4.bias", _TS + "5.weight", _TS + "5.bias",
+    "enc_eeg.0.projection.0.weight", "enc_eeg.0.projection.0.bias",
+    "proj_eeg.0.weight", "proj_eeg.0.bias", "proj_eeg.1.fn.1.weight", "proj_eeg.1.fn.1.bias", "proj_eeg.2.weight", "proj_eeg.2.bias",
+]
+_TOK_TABLE = _E + "subject_embedding.subject_embedding.weight"
+_TOK_SHARED = _E + "subject_embedding.shared_embedding"
+
+
+class ATMS(nn.Module):
+    def __init__(self, num_channels=63, sequence_length=250, num_subjects=2, num_features=64, num_latents=1024, num_blocks=1):
+        super().__init__()
+        if num_channels != N_CH or sequence_length != T_LEN:
+            raise EegclipError("the HIP kernels are specialised for 63 channels x 250 samples (the reference's only configuration)")
+        cfg = Config()
+        self.encoder = iTransformer(cfg)
+        self.subject_wise_linear = nn.ModuleList([nn.Linear(cfg.d_model, sequence_length) for _ in range(num_subjects)])
+        self.enc_eeg = Enc_eeg()
+        self.proj_eeg = Proj_eeg()
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.loss_func = ClipLoss()
+        self._eng = None
+
+    # ---- flat parameter storage ------------------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self._eng = None                     # .cuda()/.to()/.float() re-created the tensors: re-flatten lazily
+        return r
+
+    def _engine(self):
+        p0 = self.logit_scale
+        if self._eng is None or self._eng.stale(self):
+            require_cuda(p0.data, "ATMS parameters (call model.cuda() first)")
+            self._eng = _Engine(self)
+        return self._eng
+
+    def flat_parameters(self):
+        """(flat weights, flat grads, segments) -- segments = [(offset, numel, keys)] live / table / shared / dead."""
+        e = self._engine()
+        return e.flat, e.gflat, e.segments
+
+    # ---- reference API ---------------------------------------------------------------------------------------
+    def forward(self, x, subject_ids):
+        """x (B,63,250) f32 cuda, subject_ids (B,) int64 (or an int / None) -> (B,1024) f32.
+        Any id >= 10 (e.g. 'sub-10'), or None, selects the shared token for the whole batch (Embed.py:116-119)."""
+        eng = self._engine()
+        require_cuda(x, "x")
+        if x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != N_CH or x.shape[2] != T_LEN:
+            raise EegclipError(f"x must be float32 (B,{N_CH},{T_LEN}); got {x.dtype} {tuple(x.shape)}")
+        if subject_ids is None:
+            ids, shared = None, True
+        elif isinstance(subject_ids, int):
+            shared = subject_ids >= 10
+            ids = None if shared else torch.full((x.shape[0],), subject_ids, dtype=torch.long, device=x.device)
+        else:
+            ids = subject_ids.to(device=x.device, dtype=torch.long)
+            hint = getattr(subject_ids, "_eegclip_uniform_id", None)        # set by our train/eval loops: no host sync
+            shared = (hint >= 10) if hint is not None else bool((ids >= 10).any())   # the reference syncs here too
+            if shared:
+                ids = None
+        x = x.contiguous()
+        train = self.training
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if need_grad:
+            return _AtmsFn.apply(x, eng.anchor, self, ids, shared, train)
+        return eng.forward(x, ids, shared, train).clone()
+
+    def drop_probs(self, train):
+        if not train:
+            return (0.0, 0.0, 0.0)
+        e = self.encoder
+        pe = {e.enc_embedding.dropout.p, e.encoder.attn_layers[0].attention.inner_attention.dropout.p, e.encoder.attn_layers[0].dropout.p}
+        if len(pe) != 1:
+            raise EegclipError("the three encoder dropout modules must share one p (the reference uses Config.dropout for all)")
+        return (float(pe.pop()), float(self.enc_eeg[0].tsconv[7].p), float(self.proj_eeg[1].fn[2].p))
+
+
+class _AtmsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model, ids, shared, train):
+        eng = model._engine()
+        out = eng.forward(x, ids, shared, train)
+        ctx.eng, ctx.key, ctx.version = eng, eng.last_key, eng.version[eng.last_key]
+        ctx.x = x
+        ctx.want_dx = x.requires_grad
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        if eng.version.get(ctx.key) != ctx.version:
+            raise EegclipError("ATMS activations were overwritten by a later forward at the same batch size; "
+                               "run backward before the next forward (persistent activation buffers).")
+        dx = eng.backward(ctx.key, ctx.x, dout.contiguous(), ctx.want_dx)
+        return dx, None, None, None, None, None
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+class _Engine:
+    """Flat parameter/gradient storage + per-batch-size activation buffers and launch plans."""
+
+    def __init__(self, model):
+        sd_params = dict(model.named_parameters())
+        dev = model.logit_scale.device
+        self.device = dev
+        self.model = model
+        dead = [k for k in sd_params if k not in _LIVE and k not in (_TOK_TABLE, _TOK_SHARED)]
+        order = _LIVE + [_TOK_TABLE, _TOK_SHARED] + dead
+        assert sorted(order) == sorted(sd_params), "parameter list drifted from the reference state_dict"
+        offs, off = {}, 0
+        for k in order:
+            offs[k] = off
+            off += (sd_params[k].numel() + 3) // 4 * 4          # 16-byte aligned segments
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)     # makes autograd call _AtmsFn.backward
+        self.P, self.G, self.params = {}, {}, {}
+        for k in order:
+            p = sd_params[k]
+            n = p.numel()
+            view = self.flat[offs[k]:offs[k] + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            self.P[k] = view
+            self.G[k] = self.gflat[offs[k]:offs[k] + n].view(p.shape)
+            self.params[k] = p
+        n_live = offs[_TOK_TABLE]
+        self.segments = [(0, n_live, list(_LIVE)),
+                         (offs[_TOK_TABLE], sd_params[_TOK_TABLE].numel(), [_TOK_TABLE]),
+                         (offs[_TOK_SHARED], sd_params[_TOK_SHARED].numel(), [_TOK_SHARED]),
+                         (offs[dead[0]] if dead else off, off - (offs[dead[0]] if dead else off), dead)]
+        self.offs = offs
+        self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])
+        self.buffers = dict(model.named_buffers())
+        self.bufs, self.plans, self.version = {}, {}, {}
+        self.last_key = None
+        self.grad_fresh = True               # gflat holds zeros / stale values that must be cleared before accumulation
+        lib()
+
+    def stale(self, model):
+        a, b = self._check
+        return (a.data_ptr() != self.flat.data_ptr() or b.data.data_ptr() != self.P[_LIVE[-1]].data_ptr()
+                or model.logit_scale.device != self.device)
+
+    # ---- buffers -----------------------------------------------------------------------------------------------
+    def _alloc(self, B):
+        dev = self.device
+
+        def f(*s):
+            return torch.empty(*s, dtype=torch.float32, device=dev)
+
+        R = B * L_TOK
+        b = dict(
+            h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
+            f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
+            weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), z1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
+            feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
+            sums=torch.zeros(4, 2 * C_TS, dtype=torch.float64, device=dev), bn=f(4, C_TS),
+            ids=torch.zeros(B, dtype=torch.long, device=dev),
+        )
+        return b
+
+    def _alloc_bwd(self, B, b):
+        dev = self.device
+
+        def f(*s):
+            return torch.empty(*s, dtype=torch.float32, device=dev)
+
+        R = B * L_TOK
+        b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dgu=f(B, P_DIM), dfeat=f(B, F_TS), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
+                 dz1=f(B, C_TS, N_CH, W_TS), dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75), dn3=f(B, L_TOK, D_MODEL),
+                 dn2=f(R, D_MODEL), dr2=f(R, D_MODEL), df2=f(R, D_MODEL), dg1=f(R, D_FF), dr1=f(R, D_MODEL), da1=f(R, D_MODEL),
+                 dctx=f(R, HE), dqkv=f(R, 3 * HE))
+
+    # ---- forward plan -----------------------------------------------------------------------------------------
+    def _build_fwd(self, B, train, shared, probs):
+        P, b = self.P, self.bufs[B]
+        pe_, pc_, pp_ = probs
+        pl = Plan(f"atms_fwd[B={B}]")
+        R = B * L_TOK
+        pe = self.buffers[_E + "position_embedding.pe"]
+        # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
+        pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
+                _p(b["h"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
+                R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1))
+        tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
+        pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
+        # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
+        pl.gemm(R, 3 * HE, D_MODEL, _p(b["h"]), D(D_MODEL), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(1), D(D_MODEL),
+                _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]))
+        pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
+                SITE_ATTN, seed_at=9)
+        pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
+                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), drop_p=pe_, drop_site=SITE_ATTN_OUT,
+                R=_p(b["h"]), Rm=D(D_MODEL), Rn=D(1))
+        # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
+        pl.call("eegclip_layernorm_fwd", _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]),
+                _p(b["rs1"]), R, D_MODEL, EPS)
+        pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
+                Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT)
+        pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
+                bias_n=_p(P[_LY + "conv2.bias"]), drop_p=pe_, drop_site=SITE_FFN_OUT, R=_p(b["n1"]), Rm=D(D_MODEL), Rn=D(1))
+        pl.call("eegclip_layernorm_fwd", _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]),
+                _p(b["rs2"]), R, D_MODEL, EPS)
+        pl.call("eegclip_layernorm_fwd", _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]),
+                _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS)
+        # A4+A5: tokens 0..62 -> fused conv+pool (75 taps, stride 5) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
+        sums, bn = b["sums"], b["bn"]
+        pl.call("eegclip_tsconv_fold", _p(P[_TS + "0.weight"]), _p(b["weff"]))
+        pl.memset(sums)
+        pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["weff"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
+                C_TS, _p(sums[0]) if train else None)
+        pl.call("eegclip_bn_finalize", _p(sums[0]), float(B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
+                _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train))
+        pl.call("eegclip_bn_elu_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(b["z1"]), B, C_TS,
+                N_CH * W_TS, 0.0, 0, 0)
+        # spatial (63x1) conv as ONE GEMM over the (B,40,63,36) view: M = out ch, N = (b,w), K = (c,h)      (:106)
+        KS = C_TS * N_CH
+        pl.memset(b["y2"])
+        pl.gemm(C_TS, B * W_TS, KS, _p(P[_TS + "4.weight"]), D(KS), D(1), _p(b["z1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS),
+                _p(b["y2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), bias_m=_p(P[_TS + "4.bias"]), split_k=4)
+        if train:
+            pl.call("eegclip_bn_stats", _p(b["y2"]), B, C_TS, W_TS, _p(sums[1]))
+        pl.call("eegclip_bn_finalize", _p(sums[1]), float(B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
+                _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train))
+        pl.call("eegclip_bn_elu_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["z2"]), B, C_TS,
+                W_TS, pc_, 0, SITE_CONV, seed_at=10)
+        # 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e]      (:113-114,145)
+        pl.gemm(B * W_TS, C_TS, C_TS, _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS), _p(P["enc_eeg.0.projection.0.weight"]), D(1), D(C_TS),
+                _p(b["feat"]), D(C_TS, div=W_TS, so=F_TS), D(1), bias_n=_p(P["enc_eeg.0.projection.0.bias"]))
+        # A6: projection head      (:157-167)
+        pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
+                Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU)
+        pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
+                bias_n=_p(P["proj_eeg.1.fn.1.bias"]), drop_p=pp_, drop_site=SITE_PROJ, R=_p(b["u"]), Rm=D(P_DIM), Rn=D(1))
+        pl.call("eegclip_layernorm_fwd", _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(P["proj_eeg.2.bias"]), _p(b["out"]), _p(b["mu4"]),
+                _p(b["rs4"]), B, P_DIM, EPS)
+        return pl
+
+    # ---- backward plan -----------------------------------------------------------------------------------------
+    def _build_bwd(self, B, shared, probs, want_dx):
+        P, G, b = self.P, self.G, self.bufs[B]
+        pe_, pc_, pp_ = probs
+        pl = Plan(f"atms_bwd[B={B}]")
+        R = B * L_TOK
+        sums, bn = b["sums"], b["bn"]
+        sk = lambda k: max(1, min(64, k // 512))      # split-K for the reduce-over-batch weight-gradient GEMMs
+
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K):
+            """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major"""
+            pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K))
+
+        def bgrad(name, dY, rows, cols):
+            pl.call("eegclip_reduce_mid", dY, rows, cols, 1, _p(G[name]))
+
+        # head LayerNorm
+        pl.dout_op = len(pl.ops)
+        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
+                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0)
+        # s = u + dropout(W4 gelu(u) + b4)
+        pl.call("eegclip_axpby", _p(b["ds"]), _p(b["dv"]), B * P_DIM, 1.0, 0.0)
+        if pp_ > 0:
+            pl.call("eegclip_dropout_scale", _p(b["dv"]), B * P_DIM, pp_, 0, SITE_PROJ, seed_at=3)
+        bgrad("proj_eeg.1.fn.1.bias", _p(b["dv"]), B, P_DIM)
+        wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B)
+        pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1))
+        pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
+        bgrad("proj_eeg.0.bias", _p(b["ds"]), B, P_DIM)
+        wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B)
+        pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1))
+        # 1x1 conv: dfeat is [(b,w)][e]
+        bgrad("enc_eeg.0.projection.0.bias", _p(b["dfeat"]), B * W_TS, C_TS)
+        pl.gemm(C_TS, C_TS, B * W_TS, _p(b["dfeat"]), D(1), D(C_TS), _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS),
+                _p(G["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1), accumulate=1, split_k=sk(B * W_TS * 8))
+        pl.gemm(B * W_TS, C_TS, C_TS, _p(b["dfeat"]), D(C_TS), D(1), _p(P["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1),
+                _p(b["dz2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS))
+        # BN2 + ELU + dropout backward
+        pl.memset(sums)
+        pl.call("eegclip_bn_elu_bwd", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(sums[2]),
+                _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS, W_TS, pc_, 0, SITE_CONV, seed_at=14)
+        # spatial conv backward
+        KS = C_TS * N_CH
+        pl.call("eegclip_reduce_mid", _p(b["dy2"]), B, C_TS, W_TS, _p(G[_TS + "4.bias"]))
+        pl.gemm(C_TS, KS, B * W_TS, _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), _p(b["z1"]), D(1, div=W_TS, so=KS * W_TS), D(W_TS),
+                _p(G[_TS + "4.weight"]), D(KS), D(1), accumulate=1, split_k=sk(B * W_TS * 2))
+        pl.gemm(KS, B * W_TS, C_TS, _p(P[_TS + "4.weight"]), D(1), D(KS), _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS),
+                _p(b["dz1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS))
+        # BN1 + ELU backward, then the fused conv+pool backward
+        pl.call("eegclip_bn_elu_bwd", _p(b["dz1"]), _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(sums[3]),
+                _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, C_TS, N_CH * W_TS, 0.0, 0, 0)
+        pl.call("eegclip_reduce_mid", _p(b["dy1"]), B, C_TS, N_CH * W_TS, _p(G[_TS + "0.bias"]))
+        pl.memset(b["dweff"])
+        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), B, N_CH, T_LEN, C_TS)
+        pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))
+        pl.memset(b["dn3"])                       # token row 63 (EEG channel 62) gets no gradient from the conv path
+        pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(b["weff"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
+        # final LN, LN2
+        pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
+                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0)
+        pl.call("eegclip_layernorm_bwd", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
+                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0)
+        # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2)
+        pl.call("eegclip_axpby", _p(b["dr2"]), _p(b["df2"]), R * D_MODEL, 1.0, 0.0)
+        if pe_ > 0:
+            pl.call("eegclip_dropout_scale", _p(b["df2"]), R * D_MODEL, pe_, 0, SITE_FFN_OUT, seed_at=3)
+        bgrad(_LY + "conv2.bias", _p(b["df2"]), R, D_MODEL)
+        wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R)
+        pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1))
+        pl.call("eegclip_gelu_bwd", _p(b["dg1"]), _p(b["f1"]), _p(b["dg1"]), R * D_FF, 0, pe_, 0, SITE_FFN_ACT, seed_at=6)   # in place: df1
+        bgrad(_LY + "conv1.bias", _p(b["dg1"]), R, D_FF)
+        wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R)
+        pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
+                accumulate=1)                                                                  # dr2 := dn1
+        pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
+                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0)
+        # attention block: r1 = h + dropout(Wo ctx + bo)
+        pl.call("eegclip_axpby", _p(b["dr1"]), _p(b["da1"]), R * D_MODEL, 1.0, 0.0)
+        if pe_ > 0:
+            pl.call("eegclip_dropout_scale", _p(b["da1"]), R * D_MODEL, pe_, 0, SITE_ATTN_OUT, seed_at=3)
+        bgrad(_LY + "attention.out_projection.bias", _p(b["da1"]), R, D_MODEL)
+        wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R)
+        pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1))
+        pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                pe_, 0, SITE_ATTN, seed_at=10)
+        bgrad(_LY + "attention.query_projection.bias", _p(b["dqkv"]), R, 3 * HE)              # q|k|v biases are adjacent
+        wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R)
+        pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
+                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=1)                                   # dr1 := dh
+        # embedding: dropout + token row + value embedding
+        tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
+        pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
+        pl.call("eegclip_colsum_blocks", _p(b["dr1"]), B, L_TOK, 1, D_MODEL, L_TOK * D_MODEL, _p(G[_E + "value_embedding.bias"]))
+        pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), 0, D(T_LEN), D(1),
+                _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH))
+        if want_dx:
+            b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
+            pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1),
+                    _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
+        return pl
+
+    # ---- execution -----------------------------------------------------------------------------------------------
+    def forward(self, x, ids, shared, train):
+        B = x.shape[0]
+        probs = self.model.drop_probs(train)
+        if B not in self.bufs:
+            self.bufs[B] = self._alloc(B)
+        key = (B, train, shared, probs)
+        pk = ("f",) + key
+        if pk not in self.plans:
+            self.plans[pk] = self._build_fwd(B, train, shared, probs)
+        pl = self.plans[pk]
+        b = self.bufs[B]
+        if not shared:
+            b["ids"].copy_(ids)
+        pl.x_gemm.A = x.data_ptr()              # the only per-call pointer: the EEG batch itself
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and max(probs) > 0 else 0
+        b["seed"] = seed
+        pl.run(torch.cuda.current_stream().cuda_stream, seed)
+        if train:
+            self.buffers[_TS + "2.num_batches_tracked"].add_(1)
+            self.buffers[_TS + "5.num_batches_tracked"].add_(1)
+        self.last_key = key
+        self.version[key] = self.version.get(key, 0) + 1
+        return b["out"]
+
+    def attach_grads(self, shared):
+        """Make p.grad views of the flat gradient buffer for every parameter that receives a gradient; zero the
+        buffer if the optimizer cleared the grads (zero_grad(set_to_none=True) is torch's default)."""
+        live = list(_LIVE) + [_TOK_SHARED if shared else _TOK_TABLE]
+        mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
+        if all(mine(k) for k in live):
+            return False                                   # accumulating onto existing gradients
+        foreign = {k: self.params[k].grad for k in live if self.params[k].grad is not None and not mine(k)}
+        if all(self.params[k].grad is None or k in foreign for k in live):
+            self.gflat.zero_()                             # the common case after optimizer.zero_grad(): one memset
+        else:
+            for k in live:
+                if not mine(k):
+                    self.G[k].zero_()
+        for k, g in foreign.items():                       # e.g. logit_scale.grad written by the loss before this backward ran
+            self.G[k].copy_(g)
+        for k in live:
+            self.params[k].grad = self.G[k]
+        return True
+
+    def backward(self, key, x, dout, want_dx):
+        B, train, shared, probs = key
+        b = self.bufs[B]
+        if "ds" not in b:
+            self._alloc_bwd(B, b)
+        pk = ("b", B, shared, probs, want_dx)
+        if pk not in self.plans:
+            self.plans[pk] = self._build_bwd(B, shared, probs, want_dx)
+        pl = self.plans[pk]
+        self.attach_grads(shared)
+        pl.ops[pl.dout_op][1][0] = dout.data_ptr()
+        pl._keep_x = (x, dout)
+        pl.x_gemm.B = x.data_ptr()              # the value-embedding weight-gradient GEMM reads the EEG batch
+        pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
+        return b["dx"].clone() if want_dx else None

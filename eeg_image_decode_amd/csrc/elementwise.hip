@@ -111,6 +111,27 @@ __global__ __launch_bounds__(256) void reduce_mid_kernel(const float* __restrict
     }
 }
 
+// out[c] += sum_{blk} sum_{r=row0}^{blk_rows-1} x[blk*blk_stride + r*cols + c]     (value-embedding bias gradient: every
+// row of each (64,250) token block except the subject-token row 0).  grid (chunks, ceil(cols/64)), block 4 x 64.
+__global__ __launch_bounds__(256) void colsum_blocks_kernel(const float* __restrict__ x, int nblk, int blk_rows, int row0, int cols,
+                                                             long long blk_stride, float* __restrict__ out) {
+    EEG_LDS_BASE(float, red);   // [4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const int per = blk_rows - row0;
+    const long long total = (long long)nblk * per;
+    float s = 0.f;
+    if (c < cols)
+        for (long long o = blockIdx.x * 4 + g; o < total; o += (long long)gridDim.x * 4) {
+            const long long blk = o / per;
+            const int r = row0 + (int)(o % per);
+            s += x[blk * blk_stride + (long long)r * cols + c];
+        }
+    red[g * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) atomicAdd(out + c, red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+}
+
 // torch.optim.AdamW / Adam single-step math on a flat fp32 segment (decoupled weight decay, bias correction).
 // bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t) are computed on the host in double.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -203,6 +224,17 @@ extern "C" int eegclip_reduce_mid(const float* x, int outer, int mid, int inner,
     int chunks = inner == 1 ? (outer + 3) / 4 : outer;
     if (chunks > 128) chunks = 128;
     EEG_LAUNCH(reduce_mid_kernel, dim3(chunks, (mid + 63) / 64), dim3(256), 4 * 64 * sizeof(float), stream, x, outer, mid, inner, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_colsum_blocks(const float* x, int nblk, int blk_rows, int row0, int cols, long long blk_stride, float* out,
+                                     void* stream) {
+    if (!x || !out || nblk < 1 || blk_rows < 1 || row0 < 0 || row0 >= blk_rows || cols < 1) return EEGCLIP_EINVAL;
+    long long total = (long long)nblk * (blk_rows - row0);
+    long long chunks = (total + 3) / 4;
+    if (chunks > 128) chunks = 128;
+    EEG_LAUNCH(colsum_blocks_kernel, dim3((int)chunks, (cols + 63) / 64), dim3(256), 4 * 64 * sizeof(float), stream, x, nblk, blk_rows,
+               row0, cols, blk_stride, out);
     return (int)hipGetLastError();
 }
 

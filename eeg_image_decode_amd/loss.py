@@ -1,0 +1,166 @@
+"""CLIP-symmetric InfoNCE with the reference's constructor and call signature (models/loss.py:78-141) on HIP kernels.
+
+    loss = ClipLoss(local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1)(z_eeg, z_tgt, logit_scale)
+
+`logit_scale` multiplies the logits RAW (no exp) exactly like the reference.  The N x N
+logits are produced by the fp32-MFMA GEMM, row/column log-sum-exp and the gradient matrix by the loss kernels
+(csrc/loss.hip); gradients w.r.t. both feature matrices and the scale are computed in the same pass and handed to
+autograd.  world_size > 1 reproduces the three gather modes of models/loss.py:20-75 over torch.distributed (RCCL on
+ROCm): all-gather forward, reduce-scatter of the gathered-feature gradients when gather_with_grad is set.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from ._lib import check, lib, require_cuda
+
+D = _abi.dim
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gemm(M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, alpha=1.0, accumulate=0, split_k=1):
+    d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=None, bias_n=None, bias_m=None,
+                      R=None, Rm=D(0), Rn=D(0), alpha=alpha, accumulate=accumulate, act=0, drop_p=0.0, seed=0, drop_site=0, split_k=split_k)
+    check(lib().eegclip_gemm_f32(ctypes.byref(d), _stream()), "gemm")
+
+
+def _scale_ptr(logit_scale, device):
+    if torch.is_tensor(logit_scale):
+        s = logit_scale.detach()
+        if s.device != device or s.dtype != torch.float32:
+            s = s.to(device=device, dtype=torch.float32)
+        return s.reshape(1).contiguous()
+    return torch.full((1,), float(logit_scale), dtype=torch.float32, device=device)
+
+
+def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term, need_grad):
+    """One (n x N) logits block: loss contribution and, if need_grad, X <- s*G in place.
+    Returns (loss[1], dscale[1], X or None)."""
+    L = lib()
+    n, Dm = a_rows.shape
+    N = b_cols.shape[0]
+    dev = a_rows.device
+    X = torch.empty(n, N, dtype=torch.float32, device=dev)
+    _gemm(n, N, Dm, a_rows.data_ptr(), D(Dm), D(1), b_cols.data_ptr(), D(1), D(Dm), X.data_ptr(), D(N), D(1))
+    st = _stream()
+    lr = lc = None
+    if row_term:
+        lr = torch.empty(n, dtype=torch.float32, device=dev)
+        check(L.eegclip_lse_rows(X.data_ptr(), n, N, N, sc.data_ptr(), lr.data_ptr(), st), "lse_rows")
+    if col_term:
+        lc = torch.empty(N, dtype=torch.float32, device=dev)
+        check(L.eegclip_lse_cols(X.data_ptr(), n, N, N, sc.data_ptr(), lc.data_ptr(), st), "lse_cols")
+    acc = torch.zeros(2, dtype=torch.float32, device=dev)
+    if need_grad or not (row_term and col_term and n == N):
+        check(L.eegclip_infonce_grad(X.data_ptr(), n, N, N, col0, n_total, sc.data_ptr(), lr.data_ptr() if row_term else None,
+                                     lc.data_ptr() if col_term else None, weight, acc.data_ptr(), acc.data_ptr() + 4, st), "infonce_grad")
+    else:
+        check(L.eegclip_infonce_loss(X.data_ptr(), n, N, sc.data_ptr(), lr.data_ptr(), lc.data_ptr(), weight, acc.data_ptr(), st), "infonce_loss")
+        X = None
+    return acc[0:1], acc[1:2], X
+
+
+def _grad_rows(X, b_cols):
+    """dA = (s G) B  -> (n, D)"""
+    n, N = X.shape
+    Dm = b_cols.shape[1]
+    out = torch.empty(n, Dm, dtype=torch.float32, device=X.device)
+    _gemm(n, Dm, N, X.data_ptr(), D(N), D(1), b_cols.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1))
+    return out
+
+
+def _grad_cols(X, a_rows):
+    """dB = (s G)^T A -> (N, D)"""
+    n, N = X.shape
+    Dm = a_rows.shape[1]
+    out = torch.empty(N, Dm, dtype=torch.float32, device=X.device)
+    _gemm(N, Dm, n, X.data_ptr(), D(1), D(N), a_rows.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1))
+    return out
+
+
+class _ClipLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, scale_t, mod):
+        dev = a.device
+        sc = _scale_ptr(scale_t, dev)
+        need = [a.requires_grad, b.requires_grad, torch.is_tensor(scale_t) and scale_t.requires_grad]
+        W, rank = mod.world_size, mod.rank
+        a_, b_ = a.detach().contiguous(), b.detach().contiguous()
+        n = a_.shape[0]
+        da = db = ds = None
+        if W == 1:
+            loss, dsv, X = infonce_block(a_, b_, sc, 0, n, 1.0, True, True, any(need))
+            if need[0]:
+                da = _grad_rows(X, b_)
+            if need[1]:
+                db = _grad_cols(X, a_)
+            ds = dsv
+        else:
+            import torch.distributed as dist
+            a_all = torch.empty(W * n, a_.shape[1], dtype=torch.float32, device=dev)
+            b_all = torch.empty(W * n, b_.shape[1], dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(a_all, a_)
+            dist.all_gather_into_tensor(b_all, b_)
+            if not mod.local_loss:
+                # every rank scores the full N x N matrix (models/loss.py:117-121)
+                loss, dsv, X = infonce_block(a_all, b_all, sc, 0, W * n, 1.0, True, True, any(need))
+                mult = float(W) if mod.gather_with_grad else 1.0     # all_gather backward sums W identical copies
+                sl = slice(rank * n, (rank + 1) * n)
+                if need[0]:
+                    da = _grad_rows(X[sl].contiguous(), b_all) * mult
+                if need[1]:
+                    db = _grad_cols(X, a_all)[sl] * mult
+                ds = dsv
+            else:
+                # row-sharded: n x N blocks, positives at column i + n*rank (models/loss.py:113-115,129-130)
+                l1, d1, X1 = infonce_block(a_, b_all, sc, rank * n, n, 1.0, True, False, True)
+                l2, d2, X2 = infonce_block(b_, a_all, sc, rank * n, n, 1.0, True, False, True)
+                loss, ds = l1 + l2, d1 + d2
+                if need[0]:
+                    da = _grad_rows(X1, b_all)
+                if need[1]:
+                    db = _grad_rows(X2, a_all)
+                if mod.gather_with_grad:
+                    # gradients that reached the GATHERED copies flow back through all_gather = reduce-scatter(sum)
+                    if need[0]:
+                        ga = _grad_cols(X2, b_)                       # (N, D): d loss_r / d a_all
+                        part = torch.empty_like(a_)
+                        dist.reduce_scatter_tensor(part, ga)
+                        da = da + part
+                    if need[1]:
+                        gb = _grad_cols(X1, a_)
+                        part = torch.empty_like(b_)
+                        dist.reduce_scatter_tensor(part, gb)
+                        db = db + part
+        ctx.grads = (da, db, ds.reshape(()).clone() if need[2] else None)
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        da, db, ds = ctx.grads
+        return (da * go if da is not None else None, db * go if db is not None else None, ds * go if ds is not None else None, None)
+
+
+class ClipLoss(nn.Module):
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, use_horovod=False):
+        super().__init__()
+        if use_horovod:
+            raise NotImplementedError("horovod is not part of the MI355X build; use torch.distributed (RCCL)")
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.cache_labels = cache_labels      # labels are implicit (diagonal + rank offset) in the kernels; kept for API parity
+        self.rank = rank
+        self.world_size = world_size
+        self.use_horovod = use_horovod
+
+    def forward(self, image_features, text_features, logit_scale):
+        require_cuda(image_features, "image_features")
+        require_cuda(text_features, "text_features")
+        if image_features.dtype != torch.float32 or text_features.dtype != torch.float32:
+            raise TypeError("ClipLoss expects float32 features (the reference casts with .float())")
+        return _ClipLossFn.apply(image_features, text_features, logit_scale, self)

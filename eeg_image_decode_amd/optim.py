@@ -1,0 +1,88 @@
+"""Fused AdamW / Adam for the flat-buffer models (drop-in for ``torch.optim.AdamW(model.parameters(), lr)``,
+Retrieval/ATMS_retrieval.py:548, and ``optim.Adam`` of Generation/diffusion_prior.py:286).
+
+Parameters of ATMS / DiffusionPriorUNet are views into one flat fp32 buffer and so are their gradients.  step() groups
+the parameters that received a gradient into maximal contiguous runs and issues ONE eegclip_adamw_step launch per run
+(normally 2 per step instead of ~45 tiny foreach kernels).  Semantics are torch's: decoupled weight decay, bias
+correction with a per-parameter step count, parameters whose grad is None are skipped entirely (no decay, no step).
+"""
+import torch
+
+from ._lib import EegclipError, check, lib
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._runs_cache = {}
+        self._moments = {}           # storage base ptr -> (m, v) shaped like the whole flat storage
+        self.grad_scale_dev = None   # optional device scalar multiplied into every gradient (clipping)
+
+    def _moments_for(self, p):
+        st = p.untyped_storage()
+        key = st.data_ptr()
+        if key not in self._moments:
+            n = st.nbytes() // 4
+            self._moments[key] = (torch.zeros(n, dtype=torch.float32, device=p.device), torch.zeros(n, dtype=torch.float32, device=p.device))
+        return self._moments[key]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        L = lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            for p in live:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.grad.is_cuda:
+                    raise EegclipError("eeg_image_decode_amd.optim works on float32 CUDA parameters only (no CPU path)")
+                st = self.state[p]
+                st["step"] = st.get("step", 0) + 1
+            steps = {self.state[p]["step"] for p in live}
+            ck = (id(group), tuple((id(p), p.data_ptr(), p.grad.data_ptr()) for p in live))
+            if len(steps) == 1 and ck in self._runs_cache:
+                st = steps.pop()
+                runs = [(p0, n, st) for (p0, n) in self._runs_cache[ck]]
+            else:
+                runs = self._make_runs(live)
+                if len(steps) == 1:
+                    self._runs_cache[ck] = [(p0, n) for (p0, n, _) in runs]
+            b1, b2 = group["betas"]
+            for (p0, n, step) in runs:
+                m, v = self._moments_for(p0)
+                off = (p0.data_ptr() - p0.untyped_storage().data_ptr()) // 4
+                rc = L.eegclip_adamw_step(p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, n,
+                                          group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0,
+                                          self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None, stream)
+                check(rc, "adamw_step")
+        return loss
+
+    def _make_runs(self, live):
+        """maximal runs of parameters that are contiguous (up to 12 bytes of alignment padding) in BOTH the weight and
+        the gradient storage and share a step count -> [(first param, numel incl. padding, step)]"""
+        items = sorted(live, key=lambda p: p.data_ptr())
+        runs = []
+        cur = None
+        for p in items:
+            step = self.state[p]["step"]
+            if cur is not None:
+                p0, end_w, end_g, st0 = cur
+                gap_w, gap_g = p.data_ptr() - end_w, p.grad.data_ptr() - end_g
+                same = p.untyped_storage().data_ptr() == p0.untyped_storage().data_ptr()
+                if same and st0 == step and 0 <= gap_w <= 12 and gap_w == gap_g:
+                    cur = (p0, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), st0)
+                    continue
+                runs.append((p0, (end_w - p0.data_ptr()) // 4, st0))
+            cur = (p, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), step)
+        p0, end_w, _, st0 = cur
+        runs.append((p0, (end_w - p0.data_ptr()) // 4, st0))
+        return runs
+
+
+class Adam(AdamW):
+    """torch.optim.Adam semantics (no weight decay) on the same fused kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0)

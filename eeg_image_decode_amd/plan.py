@@ -1,0 +1,59 @@
+"""A Plan is a pre-built, replayable list of C-ABI kernel launches (one training-step phase at one batch size).
+
+Building the ctypes argument records costs tens of microseconds per launch in Python, so they are built ONCE for a
+given shape; replaying a plan is a tight loop of foreign calls on the current HIP stream (and is what gets captured into
+a hipGraph by `torch.cuda.graph`).  Only the dropout seed changes between replays: ops that draw a mask register a
+seed slot that `run()` patches.
+"""
+import ctypes
+
+from . import _abi
+from ._lib import check, lib
+
+D = _abi.dim
+
+
+class Plan:
+    def __init__(self, name=""):
+        self.name = name
+        self.ops = []          # [fn, [args..., stream]]
+        self._keep = []        # keep ctypes structs / tensors alive
+        self._seed_descs = []
+        self._seed_slots = []  # (op index, arg index)
+        self.L = lib()
+
+    # -- generic positional op; `seed_at` = index of the seed argument (patched at run time)
+    def call(self, fname, *args, seed_at=None):
+        fn = getattr(self.L, fname)
+        self.ops.append((fn, list(args) + [None], fname))
+        if seed_at is not None:
+            self._seed_slots.append((len(self.ops) - 1, seed_at))
+
+    def gemm(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1):
+        d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
+                          bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
+                          drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k)
+        self._keep.append(d)
+        if drop_p > 0.0:
+            self._seed_descs.append(d)
+        self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32"))
+        return d
+
+    def memset(self, tensor):
+        """zero a torch tensor as part of the plan (stream-ordered)"""
+        self.ops.append((None, [tensor], "memset"))
+
+    def run(self, stream, seed=0):
+        for d in self._seed_descs:
+            d.seed = seed
+        for i, j in self._seed_slots:
+            self.ops[i][1][j] = seed
+        for fn, args, name in self.ops:
+            if fn is None:
+                args[0].zero_()
+                continue
+            args[-1] = stream
+            rc = fn(*args)
+            if rc:
+                check(rc, f"{self.name}:{name}")

@@ -1,0 +1,195 @@
+"""Contrastive train / eval loops with the reference's signatures (Retrieval/ATMS_retrieval.py:199-512), driven by
+the HIP encoder + loss.  Differences that do NOT change results: running loss / accuracy are accumulated on the device
+and read back once per epoch (the reference calls .item() twice per step: two host syncs), and the k-way evaluation
+scores every query with one GEMM + a top-k kernel instead of a Python loop of 1xk matmuls.  ``random.sample`` is consumed
+in exactly the reference's order, so a seeded run reproduces the reference's candidate sets.
+"""
+import ctypes
+import os
+import random
+import re
+
+import torch
+
+from . import _abi
+from ._lib import check, lib, require_cuda
+
+D = _abi.dim
+
+
+def extract_id_from_string(s):
+    m = re.search(r'\d+$', s)
+    return int(m.group()) if m else None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def scaled_logits(z, feats):
+    """raw z @ feats.T on the fp32-MFMA GEMM (the monotone logit_scale factor is irrelevant for argmax / top-k and is
+    applied by the caller where values matter)."""
+    z, feats = z.contiguous(), feats.contiguous()
+    n, dm = z.shape
+    c = feats.shape[0]
+    out = torch.empty(n, c, dtype=torch.float32, device=z.device)
+    d = _abi.GemmDesc(M=n, N=c, K=dm, A=z.data_ptr(), Am=D(dm), Ak=D(1), B=feats.data_ptr(), Bk=D(1), Bn=D(dm), C=out.data_ptr(),
+                      Cm=D(c), Cn=D(1), Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0,
+                      drop_p=0.0, seed=0, drop_site=0, split_k=1)
+    check(lib().eegclip_gemm_f32(ctypes.byref(d), _stream()), "logits gemm")
+    return out
+
+
+def topk_rows(logits, k):
+    n, c = logits.shape
+    out = torch.empty(n, k, dtype=torch.long, device=logits.device)
+    check(lib().eegclip_topk_rows(logits.data_ptr(), n, c, logits.stride(0), k, out.data_ptr(), _stream()), "topk")
+    return out
+
+
+def topk_retrieval(z, class_feats, logit_scale, k):
+    """indices of the k best classes per query, ties -> lowest index (ATMS_retrieval.py:246 argmax, :320 topk)."""
+    require_cuda(z, "z")
+    s = float(logit_scale) if not torch.is_tensor(logit_scale) else None
+    logits = scaled_logits(z.detach().float(), class_feats.detach().float())
+    if (s is not None and s < 0) or (s is None and float(logit_scale.detach()) < 0):
+        logits = -logits
+    return topk_rows(logits, k)
+
+
+def _uniform_ids(batch_size, subject_id, device):
+    ids = torch.full((batch_size,), subject_id, dtype=torch.long, device=device)
+    ids._eegclip_uniform_id = subject_id          # lets ATMS.forward pick the token branch without a device->host sync
+    return ids
+
+
+def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config):
+    eeg_model.train()
+    text_features_all = text_features_all.to(device).float()
+    img_features_all = (img_features_all[::10]).to(device).float().contiguous()
+    alpha = 0.99
+    features_list = []
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device)
+    correct = torch.zeros(1, dtype=torch.int32, device=device)
+    total, n_batches = 0, 0
+    subject_id = extract_id_from_string(sub)
+    L = lib()
+    for batch_idx, (eeg_data, labels, text, text_features, img, img_features) in enumerate(dataloader):
+        eeg_data = eeg_data.to(device, non_blocking=True).float()
+        text_features = text_features.to(device, non_blocking=True).float()
+        img_features = img_features.to(device, non_blocking=True).float()
+        labels = labels.to(device, non_blocking=True).long()
+        optimizer.zero_grad()
+        batch_size = eeg_data.size(0)
+        subject_ids = _uniform_ids(batch_size, subject_id, device)
+        eeg_features = eeg_model(eeg_data, subject_ids).float()
+        features_list.append(eeg_features.detach())
+        logit_scale = eeg_model.logit_scale
+        img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
+        text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
+        loss = alpha * img_loss + (1 - alpha) * text_loss
+        loss.backward()
+        optimizer.step()
+        loss_acc += loss.detach()
+        pred = topk_retrieval(eeg_features, img_features_all, logit_scale, 1)
+        check(L.eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
+        total += batch_size
+        n_batches += 1
+    average_loss = float(loss_acc) / n_batches            # the only host syncs of the epoch
+    accuracy = int(correct) / total
+    return average_loss, accuracy, torch.cat(features_list, dim=0)
+
+
+def evaluate_model(sub, eeg_model, dataloader, device, text_features_all, img_features_all, k, config):
+    eeg_model.eval()
+    text_features_all = text_features_all.to(device).float()
+    img_features_all = img_features_all.to(device).float().contiguous()
+    alpha = 0.99
+    all_labels = set(range(text_features_all.size(0)))
+    subject_id = extract_id_from_string(sub)
+    loss_acc = torch.zeros((), dtype=torch.float32, device=device)
+    feats, labs, cands = [], [], []
+    n_batches = 0
+    with torch.no_grad():
+        for batch_idx, (eeg_data, labels, text, text_features, img, img_features) in enumerate(dataloader):
+            labels_host = labels.tolist() if labels.device.type == "cpu" else labels.cpu().tolist()
+            eeg_data = eeg_data.to(device).float()
+            text_features = text_features.to(device).float()
+            img_features = img_features.to(device).float()
+            batch_size = eeg_data.size(0)
+            eeg_features = eeg_model(eeg_data, _uniform_ids(batch_size, subject_id, device))
+            logit_scale = eeg_model.logit_scale
+            img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
+            text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
+            loss_acc += img_loss * alpha + text_loss * (1 - alpha)
+            n_batches += 1
+            for label in labels_host:
+                if k not in (200, 100, 50, 10, 4, 2):
+                    print("Error.")
+                    continue
+                possible_classes = list(all_labels - {label})
+                selected_classes = random.sample(possible_classes, k - 1) + [label]
+                cands.append(selected_classes)                      # these index the features that are scored ...
+                if k != 200:
+                    random.sample(possible_classes, k - 1)          # ... the reference re-samples AFTER gathering (:328); label stays last
+                labs.append(label)
+            feats.append(eeg_features)
+        z = torch.cat(feats, 0)
+        n = z.shape[0]
+        full = scaled_logits(z, img_features_all)                                   # (n, n_classes) raw dot products
+        if float(eeg_model.logit_scale.detach()) < 0:
+            full = -full
+        sel = torch.tensor(cands, dtype=torch.long, device=device)                  # (n, k) candidate class ids
+        cand_logits = torch.gather(full, 1, sel).contiguous()
+        kk = min(5, k)
+        top = topk_rows(cand_logits, kk).cpu()                                      # positions within each candidate list
+    total = n
+    correct = int((top[:, 0] == k - 1).sum())                                       # the label is always the last candidate
+    top5_correct = int((top == k - 1).any(dim=1).sum()) if k in (200, 100, 50) else 0
+    average_loss = float(loss_acc) / max(1, n_batches)
+    return average_loss, correct / total, top5_correct / total
+
+
+def get_eegfeatures(sub, eeg_model, dataloader, device):
+    """Feature dump used to condition the diffusion prior (Generation notebooks, cell 2-3): eval-mode embeddings."""
+    eeg_model.eval()
+    subject_id = extract_id_from_string(sub)
+    out = []
+    with torch.no_grad():
+        for batch in dataloader:
+            x = batch[0].to(device).float()
+            out.append(eeg_model(x, _uniform_ids(x.size(0), subject_id, device)))
+    return torch.cat(out, 0)
+
+
+def main_train_loop(sub, current_time, eeg_model, train_dataloader, test_dataloader, optimizer, device, text_features_train_all,
+                    text_features_test_all, img_features_train_all, img_features_test_all, config, logger=None):
+    """Epoch loop + 6 k-way evaluations per epoch; returns the reference's list of per-epoch dicts (:410-424).
+    `logger` is optional here (the reference dereferences it unconditionally)."""
+    results = []
+    best_accuracy = 0.0
+    for epoch in range(config.epochs):
+        train_loss, train_accuracy, _ = train_model(sub, eeg_model, train_dataloader, optimizer, device, text_features_train_all,
+                                                    img_features_train_all, config=config)
+        if (epoch + 1) % 5 == 0 and getattr(config, "save_checkpoints", True):
+            base = f"./models/contrast/{config.encoder_type}/{sub}/{current_time}" if getattr(config, "insubject", True) \
+                else f"./models/contrast/across/{config.encoder_type}/{current_time}"
+            os.makedirs(base, exist_ok=True)
+            torch.save(eeg_model.state_dict(), f"{base}/{epoch + 1}.pth")
+        ev = lambda kk: evaluate_model(sub, eeg_model, test_dataloader, device, text_features_test_all, img_features_test_all, k=kk, config=config)
+        test_loss, test_accuracy, top5_acc = ev(200)
+        _, v2_acc, _ = ev(2)
+        _, v4_acc, _ = ev(4)
+        _, v10_acc, _ = ev(10)
+        _, v50_acc, v50_top5_acc = ev(50)
+        _, v100_acc, v100_top5_acc = ev(100)
+        results.append({"epoch": epoch + 1, "test_loss": test_loss, "test_accuracy": test_accuracy, "v2_acc": v2_acc, "v4_acc": v4_acc,
+                        "v10_acc": v10_acc, "top5_acc": top5_acc, "v50_acc": v50_acc, "v100_acc": v100_acc,
+                        "v50_top5_acc": v50_top5_acc, "v100_top5_acc": v100_top5_acc})
+        best_accuracy = max(best_accuracy, test_accuracy)
+        if logger is not None:
+            logger.log({"Train Loss": train_loss, "Train Accuracy": train_accuracy, "Test Loss": test_loss, "Test Accuracy": test_accuracy,
+                        "v2 Accuracy": v2_acc, "v4 Accuracy": v4_acc, "v10 Accuracy": v10_acc, "Epoch": epoch})
+        print(f"Epoch {epoch + 1}/{config.epochs} - Train Loss: {train_loss:.4f}, Train Accuracy: {train_accuracy:.4f}, "
+              f"Test Loss: {test_loss:.4f}, Test Accuracy: {test_accuracy:.4f}, Top5 Accuracy: {top5_acc:.4f}")
+    return results

@@ -102,6 +102,8 @@ int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, 
                      unsigned long long seed, unsigned int site, void* stream);        /* dx (+)= dy*mask/(1-p)*gelu'(pre) */
 int eegclip_axpby(const float* x, float* y, long long n, float a, float b, void* stream); /* y = a*x + b*y */
 int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out, void* stream); /* out[m] += sum_{o,i} x[o][m][i] */
+/* out[c] += sum over blocks and rows r in [row0, blk_rows) of x[blk*blk_stride + r*cols + c] */
+int eegclip_colsum_blocks(const float* x, int nblk, int blk_rows, int row0, int cols, long long blk_stride, float* out, void* stream);
 int eegclip_sumsq(const float* x, long long n, double* out, void* stream);              /* *out += sum x^2 */
 
 /* ---- fused AdamW / Adam step on a flat fp32 segment (torch.optim.AdamW math; ATMS_retrieval.py:548, diffusion_prior.py:286)

@@ -1,0 +1,270 @@
+"""MI355X parity of the full ATMS path (HIP kernels through the C ABI) against the CPU oracle and against the golden
+fixtures recorded from the reference.  Tolerances (north_star): embeddings / logits within 1e-3 fp32 -- we assert
+tighter (1e-4 class) because the kernels compute in exact fp32 (f32 MFMA); retrieval indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SEED
+from eeg_image_decode_amd import synthetic as syn
+from oracle import atms as oatms
+from oracle import loops as oloops
+from oracle import loss as oloss
+from philox_np import keep_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def state_np():
+    return syn.make_state(SEED, oatms.state_spec())
+
+
+@pytest.fixture(scope="module")
+def state(state_np):
+    return oloops.torch_state(state_np)
+
+
+def make_model(state_np):
+    from eeg_image_decode_amd.atms import ATMS
+    m = ATMS()
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state_np.items()})
+    return m.cuda()
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+def test_eval_embeddings_match_reference_fixture_and_oracle(state_np, state, golden):
+    g = golden("atms_eval.npz")
+    m = make_model(state_np).eval()
+    x = T(syn.eeg_batch(SEED + 1, 8)).cuda()
+    for key, ids in (("emb_sub1", torch.full((8,), 1)), ("emb_sub10", torch.full((8,), 10)), ("emb_mixed", torch.tensor([1, 2, 3, 4, 5, 6, 7, 9]))):
+        with torch.no_grad():
+            z = m(x, ids.long().cuda()).cpu().numpy()
+        np.testing.assert_allclose(z, g[key], atol=1e-4, err_msg=key)                       # the reference itself
+        zo = oatms.atms_forward(state, x.cpu(), ids.long(), train=False).numpy()            # the travelling oracle
+        np.testing.assert_allclose(z, zo, atol=1e-4, err_msg=key)
+    # python-int and None subject ids take the no-sync path
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x, 1).cpu().numpy(), g["emb_sub1"], atol=1e-4)
+        np.testing.assert_allclose(m(x, None).cpu().numpy(), g["emb_sub10"], atol=1e-4)
+    # intermediates
+    eng = m._engine()
+    with torch.no_grad():
+        m(x[:2].contiguous(), 1)
+    b = eng.bufs[2]
+    np.testing.assert_allclose(b["n3"][:, :63].cpu().numpy(), g["enc_out_b2"], atol=5e-5)
+    np.testing.assert_allclose(b["feat"].cpu().numpy(), g["feat_b2"], atol=5e-5)
+
+
+def test_eval_batch_independence_and_odd_batch(state_np, state):
+    m = make_model(state_np).eval()
+    x = T(syn.eeg_batch(SEED + 9, 5)).cuda()
+    with torch.no_grad():
+        z5 = m(x, 3).cpu().numpy()
+        z1 = np.concatenate([m(x[i:i + 1].contiguous(), 3).cpu().numpy() for i in range(5)])
+    np.testing.assert_allclose(z5, z1, atol=2e-5)
+    zo = oatms.atms_forward(state, x.cpu(), torch.full((5,), 3).long(), train=False).numpy()
+    np.testing.assert_allclose(z5, zo, atol=1e-4)
+
+
+def _check_grads(m, ref_grads, atol_rel=2e-3):
+    bad = []
+    for k, p in m.named_parameters():
+        rg = ref_grads.get(k)
+        if rg is None:
+            assert p.grad is None, f"{k}: reference has no grad, ours does"
+            continue
+        assert p.grad is not None, k
+        g = p.grad.detach().cpu().numpy().ravel()
+        r = np.asarray(rg, dtype=np.float64).ravel()
+        if k in oloops.ZERO_GRAD_KEYS:
+            assert np.abs(g).max() < 1e-4 * max(1.0, np.abs(r).max() * 1e3), k          # exact value is 0: both are round-off
+            continue
+        err = np.abs(g - r).max()
+        tol = atol_rel * max(np.abs(r).max(), 1e-6) + 1e-7
+        if err > tol:
+            bad.append((k, err, tol))
+    assert not bad, bad
+
+
+def test_train_p0_loss_and_grads_match_reference_fixture(state_np, state, golden):
+    g = golden("atms_train_p0.npz")
+    m = make_model(state_np)
+    zero_dropout(m)
+    m.train()
+    B = 16
+    x = T(syn.eeg_batch(SEED + 2, B)).cuda()
+    img = T(syn.unit_features(SEED + 2, B, tag="img")).cuda()
+    txt = T(syn.unit_features(SEED + 2, B, tag="txt")).cuda()
+    z = m(x, torch.full((B,), 1, dtype=torch.long).cuda())
+    z.retain_grad()
+    li = m.loss_func(z, img, m.logit_scale)
+    lt = m.loss_func(z, txt, m.logit_scale)
+    loss = 0.99 * li + 0.01 * lt
+    loss.backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], atol=1e-4)
+    assert abs(float(li) - float(g["loss_img"])) < 1e-4 and abs(float(lt) - float(g["loss_txt"])) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g["dz"], atol=1e-6 + 2e-3 * np.abs(g["dz"]).max())
+    # gradient norms + heads recorded from the reference
+    for k, p in m.named_parameters():
+        if "gradnone:" + k in g.files:
+            assert p.grad is None, k
+            continue
+        gr = p.grad.detach().flatten()
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue
+        ref_n = float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - ref_n) <= 2e-3 * max(ref_n, 1e-6), (k, float(gr.norm()), ref_n)
+        np.testing.assert_allclose(gr[:32].cpu().numpy(), g["ghead:" + k], atol=1e-6 + 2e-3 * np.abs(g["ghead:" + k]).max(), err_msg=k)
+    # full gradients against the oracle's autograd
+    tr = oloops.OracleTrainer(state, p_scale=0.0)
+    _, _, grads, _ = tr.loss_and_grads(x.cpu(), torch.full((B,), 1).long(), img.cpu(), txt.cpu(), train=True)
+    _check_grads(m, {k: (v.numpy() if v is not None else None) for k, v in grads.items()})
+    # BatchNorm running statistics after one train-mode forward
+    sd = m.state_dict()
+    for k in ("enc_eeg.0.tsconv.2.running_mean", "enc_eeg.0.tsconv.2.running_var", "enc_eeg.0.tsconv.5.running_mean", "enc_eeg.0.tsconv.5.running_var"):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=2e-5, err_msg=k)
+    assert int(sd["enc_eeg.0.tsconv.2.num_batches_tracked"]) == 1
+
+
+def test_train_with_dropout_matches_oracle_under_same_philox_masks(state_np, state):
+    """Train-mode forward AND backward with the real dropout probabilities: the oracle is fed the masks the kernels
+    draw (Philox is a pure function of seed/site/element, restated in tests/philox_np.py)."""
+    m = make_model(state_np).train()
+    B = 8
+    x = T(syn.eeg_batch(SEED + 12, B)).cuda()
+    img = T(syn.unit_features(SEED + 12, B, tag="img")).cuda()
+    txt = T(syn.unit_features(SEED + 12, B, tag="txt")).cuda()
+    ids = torch.full((B,), 10, dtype=torch.long).cuda()              # shared-token branch
+    z = m(x, ids)
+    loss = 0.99 * m.loss_func(z, img, m.logit_scale) + 0.01 * m.loss_func(z, txt, m.logit_scale)
+    loss.backward()
+    seed = m._engine().bufs[B]["seed"]
+    shapes = {"embed": (B, 64, 250), "attn": (B, 4, 64, 64), "attn_out": (B, 64, 250), "ffn_act": (B, 64, 256), "ffn_out": (B, 64, 250),
+              "conv": (B, 40, 1, 36), "proj": (B, 1024)}
+    ps = {"embed": .25, "attn": .25, "attn_out": .25, "ffn_act": .25, "ffn_out": .25, "conv": .5, "proj": .5}
+    masks = {s: T(keep_mask(seed, i, int(np.prod(shapes[s])), ps[s]).reshape(shapes[s])) for i, s in enumerate(oatms.DROPOUT_SITES)}
+    tr = oloops.OracleTrainer(state)
+    lo, zo, grads, _ = tr.loss_and_grads(x.cpu(), ids.cpu(), img.cpu(), txt.cpu(), train=True, masks=masks)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zo.numpy(), atol=2e-4)
+    assert abs(float(loss) - float(lo)) < 2e-4
+    _check_grads(m, {k: (v.numpy() if v is not None else None) for k, v in grads.items()}, atol_rel=3e-3)
+    assert m.encoder.enc_embedding.subject_embedding.subject_embedding.weight.grad is None      # table is dead on the shared branch
+    assert m.encoder.enc_embedding.subject_embedding.shared_embedding.grad is not None
+
+
+def test_clip_loss_matches_reference_fixture(golden):
+    from eeg_image_decode_amd.loss import ClipLoss
+    g = golden("loss.npz")
+    for n in (32, 256):
+        a = T(syn.unit_features(SEED + 3, n, tag="a") * 32.0).cuda().requires_grad_(True)
+        b = T(syn.unit_features(SEED + 3, n, tag="b")).cuda().requires_grad_(True)
+        s = torch.tensor(float(np.log(1 / 0.07)), device="cuda", requires_grad=True)
+        l = ClipLoss()(a, b, s)
+        l.backward()
+        assert abs(float(l) - float(g[f"loss_{n}"])) < 2e-5
+        np.testing.assert_allclose(a.grad[:8].cpu().numpy(), g[f"da_{n}"], atol=2e-6)
+        np.testing.assert_allclose(b.grad[:8].cpu().numpy(), g[f"db_{n}"], atol=5e-5)
+        assert abs(float(s.grad) - float(g[f"ds_{n}"])) < 2e-4 * max(1, abs(float(g[f"ds_{n}"])))
+        # eval path (no grad) gives the same value
+        with torch.no_grad():
+            assert abs(float(ClipLoss()(a.detach(), b.detach(), s.detach())) - float(g[f"loss_{n}"])) < 2e-5
+
+
+def test_topk_indices_bit_exact_vs_reference(state_np, golden):
+    """200-way retrieval: top-5 index lists must equal the reference's exactly (north_star: bit-exact top-k indices)."""
+    from eeg_image_decode_amd import retrieval
+    g = golden("eval.npz")
+    m = make_model(state_np).eval()
+    x_all = T(syn.eeg_batch(SEED + 6, 200)).cuda()
+    img_all = T(g["img_all_mixed"]).cuda()
+    with torch.no_grad():
+        z = m(x_all, 8)
+    np.testing.assert_allclose(z.cpu().numpy()[:, :32], g["z_test_head"], atol=1e-4)
+    top5 = retrieval.topk_retrieval(z, img_all, m.logit_scale, 5).cpu().numpy()
+    assert (top5 == g["top5_full"]).all()
+
+
+class _ListLoader:
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _make_batches(seed, n_batches, B, n_classes, img_all, txt_all):
+    rng = np.random.Generator(np.random.Philox(key=[seed, 77]))
+    out = []
+    for i in range(n_batches):
+        x = T(syn.eeg_batch(seed + 100 + i, B))
+        labels = T(rng.integers(0, n_classes, size=B).astype(np.int64))
+        out.append((x, labels, ["t"] * B, txt_all[labels], ["p"] * B, img_all[labels * 10]))
+    return out
+
+
+@pytest.mark.parametrize("which_opt", ["fused", "torch"])
+def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
+    """C1: retrieval.train_model == reference train_model on the same 3-batch loader (dropout p=0), 2 epochs of AdamW."""
+    from eeg_image_decode_amd import optim, retrieval
+    g = golden("train_loop.npz")
+    n_classes, B = 20, 16
+    img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
+    txt_all = T(syn.unit_features(SEED + 4, n_classes, tag="txtall"))
+    m = make_model(state_np)
+    zero_dropout(m)
+    opt = optim.AdamW(m.parameters(), lr=3e-4) if which_opt == "fused" else torch.optim.AdamW(m.parameters(), lr=3e-4)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    losses, accs = [], []
+    for ep in range(2):
+        l, a, feats = retrieval.train_model("sub-01", m, _ListLoader(_make_batches(SEED + 4, 3, B, n_classes, img_all, txt_all)), opt, "cuda",
+                                            txt_all, img_all, None)
+        losses.append(l)
+        accs.append(a)
+        if ep == 0:
+            np.testing.assert_allclose(feats.cpu().numpy()[:, :64], g["feats_ep0"], atol=1e-3)
+    np.testing.assert_allclose(losses, g["losses"], atol=5e-4)
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k, p in m.named_parameters():
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue
+        d = float((p.detach() - before[k]).norm())
+        ref = float(g["dnorm:" + k])
+        assert abs(d - ref) <= 5e-3 * max(ref, 1e-3) + 1e-6, (k, d, ref)
+    sd = m.state_dict()
+    for k in sd:
+        if "running_var" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=2e-4, err_msg=k)
+        if "num_batches" in k:
+            assert int(sd[k]) == 6
+
+
+def test_evaluate_model_matches_reference_fixture(state_np, golden):
+    """C2: same (loss, acc, top5) as the reference when python's `random` is seeded identically."""
+    import random
+    from eeg_image_decode_amd import retrieval
+    g = golden("eval.npz")
+    n_test = 200
+    txt_all = T(syn.unit_features(SEED + 5, n_test, tag="txttest"))
+    img_all = T(g["img_all_mixed"])
+    x_all = T(syn.eeg_batch(SEED + 6, n_test))
+    m = make_model(state_np)
+    batches = [(x_all[i:i + 1], torch.tensor([i]), ["t"], txt_all[i:i + 1], ["p"], img_all[i:i + 1]) for i in range(n_test)]
+    for k in (200, 100, 50, 10, 4, 2):
+        random.seed(1234 + k)
+        l, a, t5 = retrieval.evaluate_model("sub-08", m, _ListLoader(batches), "cuda", txt_all, img_all, k, None)
+        ref = g[f"k{k}"]
+        assert abs(l - ref[0]) < 1e-4 and a == ref[1] and t5 == ref[2], (k, l, a, t5, ref)
