@@ -62,7 +62,7 @@ PROTOTYPES = {
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],
     "eegclip_infonce_loss": [_P, _I, _L, _P, _P, _P, _F, _P, _P],
-    "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P],
+    "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
 }
 

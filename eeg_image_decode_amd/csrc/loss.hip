@@ -105,8 +105,9 @@ __global__ void infonce_loss_kernel(const float* __restrict__ X, int n, long lon
 // top-k (k <= 8) per row, one wave per row, ties -> lowest index; k == 1 is argmax.  Optional row-gather `sel`
 // (candidate subset, ATMS_retrieval.py:299-305): logical column j reads X[row][sel[j]].
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ X, int rows, int cols, long long ld, int k,
-                                                         long long* __restrict__ out_idx) {
+                                                         const float* __restrict__ scale, long long* __restrict__ out_idx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float sgn = (scale && *scale < 0.f) ? -1.f : 1.f;     // ranking by scale*x without a host-side sign check
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = X + row * ld;
         int taken[8];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
             for (int c = lane; c < cols; c += 64) {
                 bool skip = false;
                 for (int u = 0; u < t; ++u) skip |= (taken[u] == c);
-                const float v = xr[c];
+                const float v = sgn * xr[c];
                 if (!skip && (v > best || (v == best && c < bi) || bi == 0x7fffffff)) { best = v; bi = c; }
             }
 #pragma unroll
@@ -172,11 +173,12 @@ extern "C" int eegclip_infonce_loss(const float* X, int n, long long ld, const f
     EEG_LAUNCH(infonce_loss_kernel, dim3(1), dim3(256), 0, stream, X, n, ld, scale, lse_r, lse_c, weight, loss);
     return (int)hipGetLastError();
 }
-extern "C" int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, long long* out_idx, void* stream) {
+extern "C" int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, const float* scale, long long* out_idx,
+                                 void* stream) {
     if (!X || !out_idx || rows < 1 || cols < 1 || ld < cols || k < 1 || k > 8 || k > cols) return EEGCLIP_EINVAL;
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
-    EEG_LAUNCH(topk_rows_kernel, dim3(grid), dim3(256), 0, stream, X, rows, cols, ld, k, out_idx);
+    EEG_LAUNCH(topk_rows_kernel, dim3(grid), dim3(256), 0, stream, X, rows, cols, ld, k, scale, out_idx);
     return (int)hipGetLastError();
 }
 extern "C" int eegclip_count_equal(const long long* pred, int stride, const long long* labels, int n, int* count, void* stream) {

@@ -21,6 +21,7 @@ class Plan:
         self._seed_descs = []
         self._seed_slots = []  # (op index, arg index)
         self.L = lib()
+        self.timed = {}        # op index -> list of (start, end) torch.cuda.Event pairs (HIP events on the launch stream)
 
     # -- generic positional op; `seed_at` = index of the seed argument (patched at run time)
     def call(self, fname, *args, seed_at=None):
@@ -44,16 +45,38 @@ class Plan:
         """zero a torch tensor as part of the plan (stream-ordered)"""
         self.ops.append((None, [tensor], "memset"))
 
+    def op_names(self):
+        return [name for _, _, name in self.ops]
+
+    def time_ops(self, indices):
+        """record a HIP event pair around the given ops on every run (bench.py roofline / per-kernel breakdown)"""
+        self.timed = {i: [] for i in indices}
+
+    def timings_ms(self):
+        import torch
+        torch.cuda.synchronize()
+        return {i: [a.elapsed_time(b) for a, b in evs] for i, evs in self.timed.items()}
+
     def run(self, stream, seed=0):
         for d in self._seed_descs:
             d.seed = seed
         for i, j in self._seed_slots:
             self.ops[i][1][j] = seed
-        for fn, args, name in self.ops:
+        timed = self.timed
+        if timed:
+            import torch
+            ts = torch.cuda.current_stream()
+        for idx, (fn, args, name) in enumerate(self.ops):
+            if timed and idx in timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
             if fn is None:
                 args[0].zero_()
-                continue
-            args[-1] = stream
-            rc = fn(*args)
-            if rc:
-                check(rc, f"{self.name}:{name}")
+            else:
+                args[-1] = stream
+                rc = fn(*args)
+                if rc:
+                    check(rc, f"{self.name}:{name}")
+            if timed and idx in timed:
+                e1.record(ts)
+                timed[idx].append((e0, e1))

@@ -40,21 +40,23 @@ def scaled_logits(z, feats):
     return out
 
 
-def topk_rows(logits, k):
+def topk_rows(logits, k, scale=None):
+    """scale: optional device scalar; ranking is by scale*x (sign handled on the device, no host sync)"""
     n, c = logits.shape
     out = torch.empty(n, k, dtype=torch.long, device=logits.device)
-    check(lib().eegclip_topk_rows(logits.data_ptr(), n, c, logits.stride(0), k, out.data_ptr(), _stream()), "topk")
+    sp = scale.detach().reshape(1) if torch.is_tensor(scale) else None
+    check(lib().eegclip_topk_rows(logits.data_ptr(), n, c, logits.stride(0), k, sp.data_ptr() if sp is not None else None,
+                                  out.data_ptr(), _stream()), "topk")
     return out
 
 
 def topk_retrieval(z, class_feats, logit_scale, k):
     """indices of the k best classes per query, ties -> lowest index (ATMS_retrieval.py:246 argmax, :320 topk)."""
     require_cuda(z, "z")
-    s = float(logit_scale) if not torch.is_tensor(logit_scale) else None
     logits = scaled_logits(z.detach().float(), class_feats.detach().float())
-    if (s is not None and s < 0) or (s is None and float(logit_scale.detach()) < 0):
-        logits = -logits
-    return topk_rows(logits, k)
+    if not torch.is_tensor(logit_scale):
+        logit_scale = torch.full((1,), float(logit_scale), dtype=torch.float32, device=z.device)
+    return topk_rows(logits, k, logit_scale)
 
 
 def _uniform_ids(batch_size, subject_id, device):
@@ -63,37 +65,47 @@ def _uniform_ids(batch_size, subject_id, device):
     return ids
 
 
+def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
+                     alpha=0.99):
+    """One iteration of the reference batch loop (ATMS_retrieval.py:209-250) with every tensor already on the device:
+    forward, image + text InfoNCE (0.99/0.01), backward, optimizer step, running loss and train-accuracy -- no host sync.
+    Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
+    from . import dist as edist
+    optimizer.zero_grad()
+    batch_size = eeg_data.size(0)
+    subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
+    eeg_features = eeg_model(eeg_data, subject_ids).float()
+    logit_scale = eeg_model.logit_scale
+    img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
+    text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
+    loss = alpha * img_loss + (1 - alpha) * text_loss
+    loss.backward()
+    if edist.world_size() > 1:
+        edist.average_flat_grads(eeg_model.flat_parameters()[1])
+    optimizer.step()
+    loss_acc += loss.detach()
+    pred = topk_retrieval(eeg_features, class_feats, logit_scale, 1)
+    check(lib().eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
+    return eeg_features.detach()
+
+
 def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config):
     eeg_model.train()
     text_features_all = text_features_all.to(device).float()
     img_features_all = (img_features_all[::10]).to(device).float().contiguous()
-    alpha = 0.99
     features_list = []
     loss_acc = torch.zeros((), dtype=torch.float32, device=device)
     correct = torch.zeros(1, dtype=torch.int32, device=device)
     total, n_batches = 0, 0
     subject_id = extract_id_from_string(sub)
-    L = lib()
     for batch_idx, (eeg_data, labels, text, text_features, img, img_features) in enumerate(dataloader):
         eeg_data = eeg_data.to(device, non_blocking=True).float()
         text_features = text_features.to(device, non_blocking=True).float()
         img_features = img_features.to(device, non_blocking=True).float()
         labels = labels.to(device, non_blocking=True).long()
-        optimizer.zero_grad()
-        batch_size = eeg_data.size(0)
-        subject_ids = _uniform_ids(batch_size, subject_id, device)
-        eeg_features = eeg_model(eeg_data, subject_ids).float()
-        features_list.append(eeg_features.detach())
-        logit_scale = eeg_model.logit_scale
-        img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
-        text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
-        loss = alpha * img_loss + (1 - alpha) * text_loss
-        loss.backward()
-        optimizer.step()
-        loss_acc += loss.detach()
-        pred = topk_retrieval(eeg_features, img_features_all, logit_scale, 1)
-        check(L.eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
-        total += batch_size
+        features_list.append(contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels,
+                                              img_features_all, loss_acc, correct))
+        total += eeg_data.size(0)
         n_batches += 1
     average_loss = float(loss_acc) / n_batches            # the only host syncs of the epoch
     accuracy = int(correct) / total
@@ -137,12 +149,10 @@ def evaluate_model(sub, eeg_model, dataloader, device, text_features_all, img_fe
         z = torch.cat(feats, 0)
         n = z.shape[0]
         full = scaled_logits(z, img_features_all)                                   # (n, n_classes) raw dot products
-        if float(eeg_model.logit_scale.detach()) < 0:
-            full = -full
         sel = torch.tensor(cands, dtype=torch.long, device=device)                  # (n, k) candidate class ids
         cand_logits = torch.gather(full, 1, sel).contiguous()
         kk = min(5, k)
-        top = topk_rows(cand_logits, kk).cpu()                                      # positions within each candidate list
+        top = topk_rows(cand_logits, kk, eeg_model.logit_scale).cpu()                                      # positions within each candidate list
     total = n
     correct = int((top[:, 0] == k - 1).sum())                                       # the label is always the last candidate
     top5_correct = int((top == k - 1).any(dim=1).sum()) if k in (200, 100, 50) else 0

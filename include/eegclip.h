@@ -146,7 +146,8 @@ int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale
                          float* loss, void* stream);
 
 /* ---- retrieval readouts.  ATMS_retrieval.py:246 (argmax), :320 (top-5).  ties -> lowest index; out_idx: int64 (rows, k), k <= 8 */
-int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, long long* out_idx, void* stream);
+int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, const float* scale /* device scalar or NULL: rank by scale*x */,
+                      long long* out_idx, void* stream);
 int eegclip_count_equal(const long long* pred, int stride, const long long* labels, int n, int* count, void* stream);
 
 #ifdef __cplusplus

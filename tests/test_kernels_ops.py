@@ -244,9 +244,12 @@ def test_topk_and_count(be):
     X = be.dev(x)
     for k in (1, 5):
         OUT = be.zeros((rows, k), np.int64)
-        ok(be.lib.eegclip_topk_rows(be.ptr(X), rows, cols, cols, k, be.ptr(OUT), be.stream))
+        ok(be.lib.eegclip_topk_rows(be.ptr(X), rows, cols, cols, k, None, be.ptr(OUT), be.stream))
         ref = np.argsort(-x, axis=1, kind="stable")[:, :k]
         assert (be.host(OUT) == ref).all()
+    NEG, OUTN = be.dev(np.array([-2.0], np.float32)), be.zeros((rows, 1), np.int64)
+    ok(be.lib.eegclip_topk_rows(be.ptr(X), rows, cols, cols, 1, be.ptr(NEG), be.ptr(OUTN), be.stream))
+    assert (be.host(OUTN)[:, 0] == np.argmin(x, axis=1)).all()        # negative scale ranks by -x
     labels = ref[:, 0].copy()
     labels[::3] = (labels[::3] + 1) % cols
     CNT = be.zeros(1, np.int32)
