@@ -36,6 +36,9 @@ def algorithmic_cost(name, desc, B):
     y1 = B * 40 * 63 * 36 * 4
     if name == "eegclip_gemm_f32":
         return "mfma", 2.0 * desc.M * desc.N * desc.K, "flop"
+    if name in ("eegclip_attention_fwd", "eegclip_attention_bwd"):
+        per = 4 if name.endswith("fwd") else 10                    # QK^T + PV  |  + recompute, dP, dQ, dK, dV  (x 2 L^2 E flops)
+        return "mfma", float(per * 64 * 64 * 62 * B * 4), "flop"
     table = {
         "eegclip_tsconv_fwd": ("hbm", B * 63 * 250 * 4 + y1),                # read tokens, write y1
         "eegclip_bn_elu_fwd": ("hbm", 2 * y1),                              # read y1, write z1
@@ -67,11 +70,11 @@ def build(world, rank, B, seed=0):
     return model, opt, pool, classes
 
 
-def cpu_baseline(B, seconds=20.0):
+def cpu_baseline(B, seconds=12.0):
     """The oracle ("port" of the reference's PyTorch-CPU step) timed on this box's host cores: same step, same shapes."""
     from eeg_image_decode_amd import synthetic as syn
     from oracle import atms as oatms, loops as oloops, loss as oloss
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = os.cpu_count() or 1
     state = oloops.torch_state(syn.make_state(0, oatms.state_spec()))
     tr = oloops.OracleTrainer(state)
     x = torch.from_numpy(syn.eeg_batch(1, B))
@@ -84,13 +87,25 @@ def cpu_baseline(B, seconds=20.0):
         _, z = tr.step(x, ids, img, txt)
         oloss.train_accuracy_predictions(z, classes, tr.P["logit_scale"])
 
+    # torch-CPU oversubscribes badly on many-core hosts for these small ops: probe a few thread counts (one step each) and
+    # keep the fastest -- the baseline is the reference path at its best on this box, with the thread count reported.
     step()                                                       # warm-up (first step pays allocator / MKL-DNN setup)
+    best = None
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        step()
+        t = time.perf_counter()
+        step()
+        t = time.perf_counter() - t
+        if best is None or t < best[0]:
+            best = (t, nt)
+    torch.set_num_threads(best[1])
     n, t0 = 0, time.perf_counter()
     while True:
         step()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > seconds or n >= 50:
+        if dt > seconds or n >= 40:
             break
     return {"value": round(n * B / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full train steps at B={B} (fwd, img+txt InfoNCE, bwd, AdamW, accuracy GEMM), fp32, torch-CPU oracle, "

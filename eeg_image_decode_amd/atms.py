@@ -476,7 +476,8 @@ class _Engine:
                 _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS, W_TS, pc_, 0, SITE_CONV, seed_at=14)
         # spatial conv backward
         KS = C_TS * N_CH
-        pl.call("eegclip_reduce_mid", _p(b["dy2"]), B, C_TS, W_TS, _p(G[_TS + "4.bias"]))
+        # d(conv bias) in front of a train-mode BatchNorm is identically zero (sum_x dy = 0 by the BN backward formula): the
+        # gradient tensors of tsconv.0.bias / tsconv.4.bias stay at the zero the flat buffer was cleared to.
         pl.gemm(C_TS, KS, B * W_TS, _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), _p(b["z1"]), D(1, div=W_TS, so=KS * W_TS), D(W_TS),
                 _p(G[_TS + "4.weight"]), D(KS), D(1), accumulate=1, split_k=sk(B * W_TS * 2))
         pl.gemm(KS, B * W_TS, C_TS, _p(P[_TS + "4.weight"]), D(1), D(KS), _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS),
@@ -484,7 +485,6 @@ class _Engine:
         # BN1 + ELU backward, then the fused conv+pool backward
         pl.call("eegclip_bn_elu_bwd", _p(b["dz1"]), _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(sums[3]),
                 _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, C_TS, N_CH * W_TS, 0.0, 0, 0)
-        pl.call("eegclip_reduce_mid", _p(b["dy1"]), B, C_TS, N_CH * W_TS, _p(G[_TS + "0.bias"]))
         pl.memset(b["dweff"])
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), B, N_CH, T_LEN, C_TS)
         pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))

@@ -91,12 +91,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    // block-level combine of the 4 waves' partial dgamma/dbeta through LDS, then ONE atomic per column per block
+    EEG_LDS_BASE(float, red);            // [2][4][64 * LN_MAXC] would be 32 KB; do it one 64-column stripe at a time: [2][4][64]
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
+        if (64 * i >= cols) break;       // uniform
+        __syncthreads();
+        red[wave * 64 + lane] = pg[i];
+        red[256 + wave * 64 + lane] = pb[i];
+        __syncthreads();
         const int c = lane + 64 * i;
-        if (c < cols) {
-            atomicAdd(dgamma + c, pg[i]);
-            atomicAdd(dbeta + c, pb[i]);
+        if (wave == 0 && c < cols) {
+            atomicAdd(dgamma + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+            atomicAdd(dbeta + c, (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
         }
     }
 }
@@ -248,8 +255,8 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols < 1 || cols > 64 * LN_MAXC)
         return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    const int grid = grid_for(rows, 4 * 8, 512);   // >= 8 rows per wave so the dgamma/dbeta atomics amortise
-    EEG_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
+    const int grid = grid_for(rows, 4 * 8, 256);   // >= 8 rows per wave so the dgamma/dbeta atomics amortise
+    EEG_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), 512 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
                accumulate_dx);
     return (int)hipGetLastError();
 }
