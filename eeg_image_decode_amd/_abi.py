@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
 # name -> argtypes   (restype is always int)
@@ -37,6 +37,12 @@ PROTOTYPES = {
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eegclip_layernorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_silu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],
+    "eegclip_timestep_embedding": [_P, _I, _I, _P, _P],
+    "eegclip_ddpm_add_noise": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "eegclip_ddpm_step": [_P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _L, _P],
+    "eegclip_mse_loss_grad": [_P, _P, _L, _P, _P, _P],
     "eegclip_bn_stats": [_P, _I, _I, _I, _P, _P],
     "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P],
     "eegclip_bn_elu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],

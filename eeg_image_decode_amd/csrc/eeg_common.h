@@ -150,6 +150,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float sg = 1.0f / (1.0f + expf(-x));
+    return sg * (1.0f + x * (1.0f - sg));
+}
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 
 }  // namespace eeg

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
                 }
                 if (d.Cpre) d.Cpre[coff] = v;
                 if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
+                else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
                 if (d.drop_p > 0.f)
                     v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
                 if (d.R) v += d.R[dim_off(d.Rm, m) + dim_off(d.Rn, n)];
@@ -147,7 +148,7 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     if (d.K > 0 && (!d.A || !d.B)) return EEGCLIP_EINVAL;
     if (d.split_k < 1) return EEGCLIP_EINVAL;
     if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre)) return EEGCLIP_EINVAL;
-    if (d.drop_p < 0.f || d.drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_SILU) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;
     const dim3 grid((d.N + G_BN - 1) / G_BN, (d.M + G_BM - 1) / G_BM, d.split_k);

@@ -1,0 +1,174 @@
+// Diffusion-prior pieces around the GEMMs (Generation/diffusion_prior.py): LayerNorm->SiLU->dropout stage tail, SiLU backward,
+// sinusoidal timestep embedding, DDPM add_noise / ancestral step (+ classifier-free-guidance mix), MSE loss + gradient.
+// All streaming / HBM-bound; the DDPM step fuses what the reference does in ~12 separate elementwise launches per step.
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int LNS_MAXC = 16;
+
+__global__ __launch_bounds__(256) void layernorm_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ y_ln,
+                                                                  float* __restrict__ y_act, float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out, int rows, int cols, float eps,
+                                                                  float drop_p, unsigned long long seed, unsigned site) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (long long)row * cols;
+        float v[LNS_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? xr[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = c < cols ? v[i] - mean : 0.f;
+            q += dlt * dlt;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) {
+                const long long idx = (long long)row * cols + c;
+                const float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+                y_ln[idx] = y;
+                float a = silu(y);
+                if (drop_p > 0.f) a = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? a * ks : 0.f;
+                y_act[idx] = a;
+            }
+        }
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx,
+                                                        long long n, int accumulate, float drop_p, unsigned long long seed, unsigned site) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float d = dy[i];
+        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
+        const float v = d * silu_grad(pre[i]);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, float* __restrict__ out) {
+    const int half = dim / 2;
+    const int total = n * half;
+    const float k = -9.210340371976184f / (float)half;      // -ln(10000) / half
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / half, j = i % half;
+        const float ang = t[r] * expf(k * (float)j);
+        out[(long long)r * dim + j] = cosf(ang);
+        out[(long long)r * dim + half + j] = sinf(ang);
+    }
+}
+
+__global__ __launch_bounds__(256) void ddpm_add_noise_kernel(const float* __restrict__ h, const float* __restrict__ noise,
+                                                              const long long* __restrict__ t, const float* __restrict__ sa,
+                                                              const float* __restrict__ sb, float* __restrict__ out, int n, int d) {
+    const long long total = (long long)n * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long tt = t[i / d];
+        out[i] = sa[tt] * h[i] + sb[tt] * noise[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                                         const float* __restrict__ eps_u, float g, float sa, float sb, float c0, float ct,
+                                                         float sigma, const float* __restrict__ noise, float* __restrict__ out, long long n) {
+    const float inv_sa = 1.0f / sa;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float e = eps_c[i];
+        if (eps_u) { const float u = eps_u[i]; e = u + g * (e - u); }
+        const float xi = x[i];
+        float x0 = (xi - sb * e) * inv_sa;
+        x0 = fminf(1.0f, fmaxf(-1.0f, x0));
+        float v = c0 * x0 + ct * xi;
+        if (noise && sigma != 0.f) v += sigma * noise[i];
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
+                                                             float* __restrict__ loss, float* __restrict__ dpred) {
+    const float inv = 1.0f / (float)n;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        s += d * d;
+        if (dpred) dpred[i] = 2.0f * d * inv;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, s * inv);
+}
+
+static inline int pgrid(long long n, int cap = 2048) {
+    long long g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_layernorm_silu_fwd(const float* x, const float* gamma, const float* beta, float* y_ln, float* y_act, float* mean,
+                                          float* rstd, int rows, int cols, float eps, float drop_p, unsigned long long seed, unsigned site,
+                                          void* stream) {
+    if (!x || !gamma || !beta || !y_ln || !y_act || !mean || !rstd || rows < 0 || cols < 1 || cols > 64 * LNS_MAXC || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    EEG_LAUNCH(layernorm_silu_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y_ln, y_act, mean, rstd, rows, cols, eps, drop_p,
+               seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_silu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
+                                unsigned long long seed, unsigned site, void* stream) {
+    if (!dy || !pre || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    EEG_LAUNCH(silu_bwd_kernel, dim3(pgrid(n, 4096)), dim3(256), 0, stream, dy, pre, dx, n, accumulate, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_timestep_embedding(const float* t, int n, int dim, float* out, void* stream) {
+    if (!t || !out || n < 1 || dim < 2 || (dim & 1)) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(timestep_embedding_kernel, dim3(pgrid((long long)n * dim / 2, 256)), dim3(256), 0, stream, t, n, dim, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_ddpm_add_noise(const float* h, const float* noise, const long long* t, const float* sqrt_acp, const float* sqrt_1macp,
+                                      float* out, int n, int d, void* stream) {
+    if (!h || !noise || !t || !sqrt_acp || !sqrt_1macp || !out || n < 1 || d < 1) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(ddpm_add_noise_kernel, dim3(pgrid((long long)n * d)), dim3(256), 0, stream, h, noise, t, sqrt_acp, sqrt_1macp, out, n, d);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_ddpm_step(const float* x, const float* eps_c, const float* eps_u, float guidance, float sa, float sb, float c0, float ct,
+                                 float sigma, const float* noise, float* out, long long n, void* stream) {
+    if (!x || !eps_c || !out || n < 1 || sa == 0.f) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(ddpm_step_kernel, dim3(pgrid(n)), dim3(256), 0, stream, x, eps_c, eps_u, guidance, sa, sb, c0, ct, sigma, noise, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream) {
+    if (!pred || !target || n < 1 || (!loss && !dpred)) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n, 512)), dim3(256), 0, stream, pred, target, n, loss, dpred);
+    return (int)hipGetLastError();
+}

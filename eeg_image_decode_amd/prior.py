@@ -1,0 +1,494 @@
+"""Diffusion prior (EEG embedding -> CLIP image embedding) on MI355X with the reference's surface
+(Generation/diffusion_prior.py): DiffusionPriorUNet, EmbeddingDataset, Pipe.train / Pipe.generate, plus the DDPM
+scheduler pieces the reference takes from diffusers==0.30.0 (restated: diffusers is not a dependency here).
+
+* DiffusionPriorUNet keeps the reference's state_dict keys (input_layer.0/1, encode_time_embedding.i.linear_1/2, ...,
+  output_layer); parameters / gradients are views of flat buffers; forward and backward are replayed launch plans of the
+  fp32-MFMA GEMM (SiLU / residual / accumulate epilogues) + LayerNorm->SiLU->dropout kernels (csrc/prior.hip).
+* Pipe.train reproduces the reference step order: 10 % whole-batch condition drop, epsilon-MSE, clip_grad_norm_(1.0),
+  LR scheduler stepped BEFORE the optimizer, Adam.  Loss is accumulated on the device (one host sync per epoch); the
+  gradient-norm clip factor stays on the device (no sync per step).
+* Pipe.generate is batched (the reference is batch-1 only because of `t.long().item()`): each of the N rows is an
+  independent chain; with a seeded CPU generator it reproduces the reference's noise stream exactly.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from . import _abi
+from ._lib import EegclipError, check, lib, require_cuda
+from .plan import Plan
+
+D = _abi.dim
+ACT_SILU = _abi.ACT_SILU
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise EegclipError(f"{type(self).__name__} holds parameters only; call DiffusionPriorUNet.forward (HIP kernels)")
+
+
+class Timesteps(_Holder):
+    def __init__(self, num_channels, flip_sin_to_cos=True, downscale_freq_shift=0):
+        super().__init__()
+        if not flip_sin_to_cos or downscale_freq_shift != 0:
+            raise EegclipError("only Timesteps(dim, True, 0) (the reference's configuration) is implemented")
+        self.num_channels = num_channels
+
+
+class TimestepEmbedding(_Holder):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+class DiffusionPriorUNet(nn.Module):
+    def __init__(self, embed_dim=1024, cond_dim=42, hidden_dim=[1024, 512, 256, 128, 64], time_embed_dim=512, act_fn=nn.SiLU, dropout=0.0):
+        super().__init__()
+        if act_fn is not nn.SiLU:
+            raise EegclipError("the HIP stage kernel fuses LayerNorm->SiLU->dropout; act_fn must be nn.SiLU (the reference default)")
+        if max(hidden_dim) > 1024 or embed_dim > 1024:
+            raise EegclipError("LayerNorm kernel handles rows of <= 1024 features")
+        self.embed_dim, self.cond_dim, self.hidden_dim = embed_dim, cond_dim, list(hidden_dim)
+        self.time_embed_dim = time_embed_dim
+        self.time_proj = Timesteps(time_embed_dim, True, 0)
+        h = self.hidden_dim
+        self.input_layer = nn.Sequential(nn.Linear(embed_dim, h[0]), nn.LayerNorm(h[0]), act_fn())
+        self.num_layers = len(h)
+        n = self.num_layers
+        self.encode_time_embedding = nn.ModuleList([TimestepEmbedding(time_embed_dim, h[i]) for i in range(n - 1)])
+        self.encode_cond_embedding = nn.ModuleList([nn.Linear(cond_dim, h[i]) for i in range(n - 1)])
+        self.encode_layers = nn.ModuleList([nn.Sequential(nn.Linear(h[i], h[i + 1]), nn.LayerNorm(h[i + 1]), act_fn(), nn.Dropout(dropout)) for i in range(n - 1)])
+        self.decode_time_embedding = nn.ModuleList([TimestepEmbedding(time_embed_dim, h[i]) for i in range(n - 1, 0, -1)])
+        self.decode_cond_embedding = nn.ModuleList([nn.Linear(cond_dim, h[i]) for i in range(n - 1, 0, -1)])
+        self.decode_layers = nn.ModuleList([nn.Sequential(nn.Linear(h[i], h[i - 1]), nn.LayerNorm(h[i - 1]), act_fn(), nn.Dropout(dropout)) for i in range(n - 1, 0, -1)])
+        self.output_layer = nn.Linear(h[0], embed_dim)
+        self._eng = None
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self._eng = None
+        return r
+
+    def _engine(self):
+        if self._eng is None or self._eng.stale():
+            require_cuda(self.output_layer.weight.data, "DiffusionPriorUNet parameters (call .cuda() first)")
+            self._eng = _PriorEngine(self)
+        return self._eng
+
+    def flat_parameters(self):
+        e = self._engine()
+        return e.flat, e.gflat
+
+    def drop_p(self):
+        ps = {float(l[3].p) for l in list(self.encode_layers) + list(self.decode_layers)}
+        if len(ps) != 1:
+            raise EegclipError("all stage dropouts must share one p")
+        return ps.pop() if self.training else 0.0
+
+    def forward(self, x, t, c=None):
+        """x (N,embed) f32, t (N,) int or float timesteps, c (N,cond) f32 or None -> predicted noise (N,embed)."""
+        eng = self._engine()
+        require_cuda(x, "x")
+        x = x.float().contiguous()
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        if c is not None:
+            c = c.to(x.device).float().contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _PriorFn.apply(x, eng.anchor, self, t, c)
+        return eng.forward(x, t, c, self.drop_p()).clone()
+
+
+class _PriorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model, t, c):
+        eng = model._engine()
+        out = eng.forward(x, t, c, model.drop_p())
+        ctx.eng, ctx.key, ctx.version = eng, eng.last_key, eng.version[eng.last_key]
+        ctx.saved = (x, t, c)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        if eng.version.get(ctx.key) != ctx.version:
+            raise EegclipError("prior activations were overwritten by a later forward at the same batch size")
+        x, t, c = ctx.saved
+        eng.backward(ctx.key, x, c, dout.contiguous())
+        return None, None, None, None, None
+
+
+class _PriorEngine:
+    def __init__(self, model):
+        self.model = model
+        params = dict(model.named_parameters())
+        dev = model.output_layer.weight.device
+        self.device = dev
+        offs, off = {}, 0
+        for k, p in params.items():
+            offs[k] = off
+            off += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self.P, self.G, self.params = {}, {}, params
+        for k, p in params.items():
+            v = self.flat[offs[k]:offs[k] + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.P[k] = v
+            self.G[k] = self.gflat[offs[k]:offs[k] + p.numel()].view(p.shape)
+        self._first = next(iter(params.values()))
+        h = model.hidden_dim
+        n = model.num_layers
+        # stage table: (prefix_time, prefix_cond, prefix_layer, h_in, h_out, skip_from / skip_to bookkeeping)
+        self.stages = []
+        for i in range(n - 1):
+            self.stages.append(dict(t=f"encode_time_embedding.{i}.", c=f"encode_cond_embedding.{i}.", l=f"encode_layers.{i}.", hin=h[i], hout=h[i + 1], dec=None))
+        for j, i in enumerate(range(n - 1, 0, -1)):
+            self.stages.append(dict(t=f"decode_time_embedding.{j}.", c=f"decode_cond_embedding.{j}.", l=f"decode_layers.{j}.", hin=h[i], hout=h[i - 1], dec=j))
+        self.cond_keys = [k for k in params if "cond_embedding" in k]
+        self.bufs, self.plans, self.version = {}, {}, {}
+        self.last_key = None
+        lib()
+
+    def stale(self):
+        return self._first.data_ptr() != self.flat.data_ptr()
+
+    def _alloc(self, N):
+        dev, m = self.device, self.model
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        h0 = m.hidden_dim[0]
+        b = dict(temb=f(N, m.time_embed_dim), linI=f(N, h0), lnI=f(N, h0), muI=f(N), rsI=f(N), actI=f(N, h0), out=f(N, m.embed_dim),
+                 tt=f(N), dout=f(N, m.embed_dim), dactI=f(N, h0), dlnI=f(N, h0), dlinI=f(N, h0))
+        for s, st in enumerate(self.stages):
+            hi, ho = st["hin"], st["hout"]
+            b.update({f"t1pre{s}": f(N, hi), f"t1act{s}": f(N, hi), f"xin{s}": f(N, hi), f"lin{s}": f(N, ho), f"ln{s}": f(N, ho), f"mu{s}": f(N),
+                      f"rs{s}": f(N), f"act{s}": f(N, ho), f"dact{s}": f(N, ho), f"dln{s}": f(N, ho), f"dlin{s}": f(N, ho), f"dxin{s}": f(N, hi),
+                      f"dt1{s}": f(N, hi)})
+        return b
+
+    def _build_fwd(self, N, cond, p):
+        P, b, m = self.P, self.bufs[N], self.model
+        pl = Plan(f"prior_fwd[N={N}]")
+        E, Td, Cd, h0 = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0]
+        pl.call("eegclip_timestep_embedding", _p(b["tt"]), N, Td, _p(b["temb"]))
+        pl.x_gemm = pl.gemm(N, h0, E, 0, D(E), D(1), _p(P["input_layer.0.weight"]), D(1), D(E), _p(b["linI"]), D(h0), D(1), bias_n=_p(P["input_layer.0.bias"]))
+        pl.call("eegclip_layernorm_silu_fwd", _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(P["input_layer.1.bias"]), _p(b["lnI"]), _p(b["actI"]),
+                _p(b["muI"]), _p(b["rsI"]), N, h0, 1e-5, 0.0, 0, 0)
+        pl.c_gemms = []
+        cur = "actI"
+        n_enc = m.num_layers - 1
+        skips = []
+        for s, st in enumerate(self.stages):
+            hi, ho = st["hin"], st["hout"]
+            if st["dec"] is None:
+                skips.append(cur)
+            pl.gemm(N, hi, Td, _p(b["temb"]), D(Td), D(1), _p(P[st["t"] + "linear_1.weight"]), D(1), D(Td), _p(b[f"t1act{s}"]), D(hi), D(1),
+                    Cpre=_p(b[f"t1pre{s}"]), bias_n=_p(P[st["t"] + "linear_1.bias"]), act=ACT_SILU)
+            pl.gemm(N, hi, hi, _p(b[f"t1act{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(1), D(hi), _p(b[f"xin{s}"]), D(hi), D(1),
+                    bias_n=_p(P[st["t"] + "linear_2.bias"]), R=_p(b[cur]), Rm=D(hi), Rn=D(1))
+            if cond:
+                pl.c_gemms.append(pl.gemm(N, hi, Cd, 0, D(Cd), D(1), _p(P[st["c"] + "weight"]), D(1), D(Cd), _p(b[f"xin{s}"]), D(hi), D(1),
+                                          bias_n=_p(P[st["c"] + "bias"]), accumulate=1))
+            pl.gemm(N, ho, hi, _p(b[f"xin{s}"]), D(hi), D(1), _p(P[st["l"] + "0.weight"]), D(1), D(hi), _p(b[f"lin{s}"]), D(ho), D(1),
+                    bias_n=_p(P[st["l"] + "0.bias"]))
+            pl.call("eegclip_layernorm_silu_fwd", _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(P[st["l"] + "1.bias"]), _p(b[f"ln{s}"]), _p(b[f"act{s}"]),
+                    _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), N, ho, 1e-5, p, 0, s, seed_at=11)
+            if st["dec"] is not None:
+                pl.call("eegclip_axpby", _p(b[skips[n_enc - 1 - st["dec"]]]), _p(b[f"act{s}"]), N * ho, 1.0, 1.0)     # x += hidden_activations[-1-j]
+            cur = f"act{s}"
+        pl.gemm(N, E, h0, _p(b[cur]), D(h0), D(1), _p(P["output_layer.weight"]), D(1), D(h0), _p(b["out"]), D(E), D(1), bias_n=_p(P["output_layer.bias"]))
+        return pl
+
+    def _build_bwd(self, N, cond, p):
+        P, G, b, m = self.P, self.G, self.bufs[N], self.model
+        pl = Plan(f"prior_bwd[N={N}]")
+        E, Td, Cd, h0 = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0]
+        sk = lambda k: max(1, min(16, k // 256))
+
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, small):
+            g = pl.gemm(Nout, Nin, N, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(N) if small else 1)
+            return g
+
+        def bgrad(name, dY, cols):
+            pl.call("eegclip_reduce_mid", dY, N, cols, 1, _p(G[name]))
+
+        n_st = len(self.stages)
+        n_enc = m.num_layers - 1
+        last = f"act{n_st - 1}"
+        bgrad("output_layer.bias", _p(b["dout"]), E)
+        wgrad("output_layer.weight", _p(b["dout"]), E, _p(b[last]), h0, E, h0, False)
+        pl.gemm(N, h0, E, _p(b["dout"]), D(E), D(1), _p(P["output_layer.weight"]), D(h0), D(1), _p(b[f"dact{n_st - 1}"]), D(h0), D(1))
+        pl.c_gemms = []
+        for s in range(n_st - 1, -1, -1):
+            st = self.stages[s]
+            hi, ho = st["hin"], st["hout"]
+            small = hi * ho < 256 * 256
+            pl.call("eegclip_silu_bwd", _p(b[f"dact{s}"]), _p(b[f"ln{s}"]), _p(b[f"dln{s}"]), N * ho, 0, p, 0, s, seed_at=6)
+            pl.call("eegclip_layernorm_bwd", _p(b[f"dln{s}"]), _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), _p(b[f"dlin{s}"]),
+                    _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), N, ho, 0)
+            bgrad(st["l"] + "0.bias", _p(b[f"dlin{s}"]), ho)
+            wgrad(st["l"] + "0.weight", _p(b[f"dlin{s}"]), ho, _p(b[f"xin{s}"]), hi, ho, hi, small)
+            pl.gemm(N, hi, ho, _p(b[f"dlin{s}"]), D(ho), D(1), _p(P[st["l"] + "0.weight"]), D(hi), D(1), _p(b[f"dxin{s}"]), D(hi), D(1))
+            if cond:
+                bgrad(st["c"] + "bias", _p(b[f"dxin{s}"]), hi)
+                pl.c_gemms.append(wgrad(st["c"] + "weight", _p(b[f"dxin{s}"]), hi, 0, Cd, hi, Cd, hi < 256))
+            bgrad(st["t"] + "linear_2.bias", _p(b[f"dxin{s}"]), hi)
+            wgrad(st["t"] + "linear_2.weight", _p(b[f"dxin{s}"]), hi, _p(b[f"t1act{s}"]), hi, hi, hi, hi < 256)
+            pl.gemm(N, hi, hi, _p(b[f"dxin{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(hi), D(1), _p(b[f"dt1{s}"]), D(hi), D(1))
+            pl.call("eegclip_silu_bwd", _p(b[f"dt1{s}"]), _p(b[f"t1pre{s}"]), _p(b[f"dt1{s}"]), N * hi, 0, 0.0, 0, 0)
+            bgrad(st["t"] + "linear_1.bias", _p(b[f"dt1{s}"]), hi)
+            wgrad(st["t"] + "linear_1.weight", _p(b[f"dt1{s}"]), hi, _p(b["temb"]), Td, hi, Td, hi < 256)
+            # gradient w.r.t. the stage input x: dxin, plus the skip branch for encoder stages (decode stage j = n_enc-1-i adds skips[i])
+            if st["dec"] is None:
+                dec_s = n_enc + (n_enc - 1 - s)
+                pl.call("eegclip_axpby", _p(b[f"dact{dec_s}"]), _p(b[f"dxin{s}"]), N * hi, 1.0, 1.0)
+            if s > 0:
+                pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), _p(b[f"dact{s - 1}"]), N * hi, 1.0, 0.0)
+            else:
+                pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), _p(b["dactI"]), N * hi, 1.0, 0.0)
+        pl.call("eegclip_silu_bwd", _p(b["dactI"]), _p(b["lnI"]), _p(b["dlnI"]), N * h0, 0, 0.0, 0, 0)
+        pl.call("eegclip_layernorm_bwd", _p(b["dlnI"]), _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(b["muI"]), _p(b["rsI"]), _p(b["dlinI"]),
+                _p(G["input_layer.1.weight"]), _p(G["input_layer.1.bias"]), N, h0, 0)
+        bgrad("input_layer.0.bias", _p(b["dlinI"]), h0)
+        pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False)
+        return pl
+
+    def forward(self, x, t, c, p):
+        N = x.shape[0]
+        if N not in self.bufs:
+            self.bufs[N] = self._alloc(N)
+        b = self.bufs[N]
+        cond = c is not None
+        key = (N, cond, p)
+        pk = ("f",) + key
+        if pk not in self.plans:
+            self.plans[pk] = self._build_fwd(N, cond, p)
+        pl = self.plans[pk]
+        b["tt"].copy_(t)
+        pl.x_gemm.A = x.data_ptr()
+        for g in pl.c_gemms:
+            g.A = c.data_ptr()
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        b["seed"] = seed
+        pl.run(torch.cuda.current_stream().cuda_stream, seed)
+        self.last_key = key
+        self.version[key] = self.version.get(key, 0) + 1
+        return b["out"]
+
+    def attach_grads(self, cond):
+        live = [k for k in self.params if cond or k not in self.cond_keys]
+        mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
+        if all(mine(k) for k in live):
+            return
+        if all(self.params[k].grad is None for k in self.params):
+            self.gflat.zero_()
+        else:
+            for k in live:
+                if not mine(k):
+                    self.G[k].zero_()
+        for k in live:
+            self.params[k].grad = self.G[k]
+
+    def backward(self, key, x, c, dout):
+        N, cond, p = key
+        b = self.bufs[N]
+        pk = ("b",) + key
+        if pk not in self.plans:
+            self.plans[pk] = self._build_bwd(N, cond, p)
+        pl = self.plans[pk]
+        self.attach_grads(cond)
+        if dout.data_ptr() != b["dout"].data_ptr():
+            b["dout"].copy_(dout)
+        pl.x_gemm.B = x.data_ptr()
+        for g in pl.c_gemms:
+            g.B = c.data_ptr()
+        pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
+
+
+class EmbeddingDataset(Dataset):
+    def __init__(self, c_embeddings, h_embeddings):
+        self.c_embeddings = c_embeddings
+        self.h_embeddings = h_embeddings
+
+    def __len__(self):
+        return len(self.c_embeddings)
+
+    def __getitem__(self, idx):
+        return {"c_embedding": self.c_embeddings[idx], "h_embedding": self.h_embeddings[idx]}
+
+
+class DDPMScheduler:
+    """diffusers-0.30.0 DDPMScheduler defaults, restated (parity unpinned, see oracle/prior.py): 1000 steps, linear betas
+    1e-4..0.02, epsilon prediction, variance fixed_small, clip_sample to [-1,1], "leading" timestep spacing."""
+
+    class _Cfg:
+        num_train_timesteps = 1000
+        prediction_type = "epsilon"
+        clip_sample = True
+        clip_sample_range = 1.0
+
+    class _Out:
+        def __init__(self, prev):
+            self.prev_sample = prev
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        self.config = self._Cfg()
+        betas = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self._acp = [float(v) for v in self.alphas_cumprod]
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(999, -1, -1)
+        self._tabs = {}
+
+    def _tables(self, device):
+        if device not in self._tabs:
+            self._tabs[device] = (self.alphas_cumprod.sqrt().to(device).contiguous(), (1 - self.alphas_cumprod).sqrt().to(device).contiguous())
+        return self._tabs[device]
+
+    def set_timesteps(self, num_inference_steps, device=None, **kw):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        self.timesteps = (torch.arange(0, num_inference_steps) * ratio).flip(0).long()      # kept on the HOST: no .item() sync per step
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        require_cuda(original_samples, "original_samples")
+        sa, sb = self._tables(original_samples.device)
+        h, nz = original_samples.float().contiguous(), noise.float().contiguous()
+        out = torch.empty_like(h)
+        n = h.shape[0]
+        check(lib().eegclip_ddpm_add_noise(h.data_ptr(), nz.data_ptr(), timesteps.to(h.device).long().contiguous().data_ptr(), sa.data_ptr(),
+                                           sb.data_ptr(), out.data_ptr(), n, h.numel() // n, torch.cuda.current_stream().cuda_stream), "ddpm_add_noise")
+        return out
+
+    def step_coeffs(self, t):
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        tp = t - self.config.num_train_timesteps // n
+        acp_t = self._acp[t]
+        acp_prev = self._acp[tp] if tp >= 0 else 1.0
+        bt, bp = 1 - acp_t, 1 - acp_prev
+        ca = acp_t / acp_prev
+        cb = 1 - ca
+        var = max(bp / bt * cb, 1e-20)
+        return acp_t ** 0.5, bt ** 0.5, (acp_prev ** 0.5 * cb) / bt, ca ** 0.5 * bp / bt, (var ** 0.5 if t > 0 else 0.0)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, model_output_uncond=None, guidance_scale=0.0):
+        """x_t -> x_{t-1}.  `model_output_uncond` (+ guidance_scale) fuses the classifier-free-guidance mix into the same kernel."""
+        t = int(timestep)
+        sa, sb, c0, ct, sigma = self.step_coeffs(t)
+        x = sample.contiguous()
+        noise = None
+        if t > 0:
+            gdev = generator.device if generator is not None else x.device
+            noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32).to(x.device)
+        out = torch.empty_like(x)
+        eu = model_output_uncond
+        check(lib().eegclip_ddpm_step(x.data_ptr(), model_output.contiguous().data_ptr(), eu.contiguous().data_ptr() if eu is not None else None,
+                                      float(guidance_scale), sa, sb, c0, ct, sigma, noise.data_ptr() if noise is not None else None, out.data_ptr(),
+                                      x.numel(), torch.cuda.current_stream().cuda_stream), "ddpm_step")
+        return self._Out(out)
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, **kw):
+    scheduler.set_timesteps(num_inference_steps, device=device)
+    return scheduler.timesteps, num_inference_steps
+
+
+def cosine_with_warmup_lr(step, base_lr, warmup, total, cycles=0.5):
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    prog = (step - warmup) / max(1, total - warmup)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * prog)))
+
+
+class Pipe:
+    def __init__(self, diffusion_prior=None, scheduler=None, device='cuda'):
+        self.diffusion_prior = diffusion_prior.to(device)
+        self.scheduler = scheduler if scheduler is not None else DDPMScheduler()
+        self.device = device
+        self.lr_history = []
+
+    def train(self, dataloader, num_epochs=10, learning_rate=1e-4):
+        from . import dist as edist
+        from . import optim
+        prior = self.diffusion_prior
+        prior.train()
+        device = self.device
+        optimizer = optim.Adam(prior.parameters(), lr=learning_rate)
+        total_steps = len(dataloader) * num_epochs
+        T = self.scheduler.config.num_train_timesteps
+        eng = prior._engine()
+        L = lib()
+        sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+        clip = torch.ones(1, dtype=torch.float32, device=device)
+        optimizer.grad_scale_dev = clip
+        step = 0
+        for epoch in range(num_epochs):
+            loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
+            for batch in dataloader:
+                c_embeds = batch['c_embedding'].to(device) if 'c_embedding' in batch.keys() else None
+                h_embeds = batch['h_embedding'].to(device).float()
+                N = h_embeds.shape[0]
+                if torch.rand(1) < 0.1:                                   # whole-batch condition drop (diffusion_prior.py:304)
+                    c_embeds = None
+                noise = torch.randn_like(h_embeds)
+                timesteps = torch.randint(0, T, (N,), device=device)
+                perturbed = self.scheduler.add_noise(h_embeds, noise, timesteps)
+                st = torch.cuda.current_stream().cuda_stream
+                optimizer.zero_grad()
+                c32 = c_embeds.float().contiguous() if c_embeds is not None else None
+                pred = eng.forward(perturbed, timesteps.float(), c32, prior.drop_p())
+                b = eng.bufs[N]
+                check(L.eegclip_mse_loss_grad(pred.data_ptr(), noise.data_ptr(), pred.numel(), loss_sum.data_ptr(), b["dout"].data_ptr(), st), "mse")
+                eng.backward(eng.last_key, perturbed, c32, b["dout"])
+                if edist.world_size() > 1:
+                    edist.average_flat_grads(eng.gflat)
+                sumsq.zero_()                                             # clip_grad_norm_(params, 1.0) without a host sync
+                check(L.eegclip_sumsq(eng.gflat.data_ptr(), eng.gflat.numel(), sumsq.data_ptr(), st), "sumsq")
+                check(L.eegclip_clip_scale(sumsq.data_ptr(), 1.0, clip.data_ptr(), st), "clip_scale")
+                step += 1
+                lr = cosine_with_warmup_lr(step, learning_rate, 500, total_steps)      # lr_scheduler.step() BEFORE optimizer.step() (:331-332)
+                self.lr_history.append(lr)
+                for gq in optimizer.param_groups:
+                    gq["lr"] = lr
+                optimizer.step()
+            loss_epoch = float(loss_sum) / len(dataloader)
+            print(f'epoch: {epoch}, loss: {loss_epoch}')
+        return self
+
+    def generate(self, c_embeds=None, num_inference_steps=50, timesteps=None, guidance_scale=5.0, generator=None):
+        prior = self.diffusion_prior
+        prior.eval()
+        N = c_embeds.shape[0] if c_embeds is not None else 1
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, self.device, timesteps)
+        if c_embeds is not None:
+            c_embeds = c_embeds.to(self.device).float().contiguous()
+        gdev = generator.device if generator is not None else self.device
+        h_t = torch.randn(N, prior.embed_dim, generator=generator, device=gdev).to(self.device)
+        eng = prior._engine()
+        with torch.no_grad():
+            for t in timesteps.tolist():                                   # host-side schedule: no device->host sync in the loop
+                tt = torch.full((N,), float(t), dtype=torch.float32, device=self.device)
+                if guidance_scale == 0 or c_embeds is None:
+                    eps = eng.forward(h_t, tt, None, 0.0)
+                    h_t = self.scheduler.step(eps, t, h_t, generator=generator).prev_sample
+                else:
+                    eps_c = eng.forward(h_t, tt, c_embeds, 0.0).clone()
+                    eps_u = eng.forward(h_t, tt, None, 0.0)
+                    h_t = self.scheduler.step(eps_c, t, h_t, generator=generator, model_output_uncond=eps_u, guidance_scale=guidance_scale).prev_sample
+        return h_t

@@ -35,6 +35,7 @@ typedef struct {
 
 #define EEGCLIP_ACT_NONE 0
 #define EEGCLIP_ACT_GELU 1 /* exact erf GELU (F.gelu default) */
+#define EEGCLIP_ACT_SILU 2 /* x * sigmoid(x) (nn.SiLU: diffusion prior) */
 
 /* C[m,n] (+)= epilogue( alpha * sum_k A[m,k] * B[k,n] )          fp32 in, fp32 MFMA (exact f32), fp32 out.
  * epilogue order: +bias_n[n] +bias_m[m] -> (store Cpre) -> act -> dropout(p, Philox(seed, site, m*N+n)) -> +R[m,n]
@@ -75,6 +76,13 @@ int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta,
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, void* stream);
 
+/* LayerNorm -> SiLU -> dropout in one pass (prior stage, Generation/diffusion_prior.py:117-121,137-143): y_ln = LN(x) is kept for
+ * the backward, y_act = dropout(silu(y_ln)).  silu_bwd: dx (+)= dy*mask/(1-p)*silu'(pre). */
+int eegclip_layernorm_silu_fwd(const float* x, const float* gamma, const float* beta, float* y_ln, float* y_act, float* mean, float* rstd,
+                               int rows, int cols, float eps, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_silu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p, unsigned long long seed,
+                     unsigned int site, void* stream);
+
 /* ---- BatchNorm2d (+ELU, +dropout) over an (outer, C, inner) view.  ATMS_retrieval.py:104-105,107-109
  * sums: double[2C] (sum, sum of squares) accumulated atomically -- zero it first.
  * finalize: train=1 -> mean/rstd from the batch sums (biased var) and running stats updated in place with the unbiased
@@ -112,6 +120,19 @@ int eegclip_sumsq(const float* x, long long n, double* out, void* stream);      
 int eegclip_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, long long step, float grad_scale, const float* grad_scale_dev, void* stream);
 int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, void* stream); /* min(1, max_norm/(sqrt(sumsq)+1e-6)) */
+
+/* ---- diffusion prior / DDPM pieces (diffusers==0.30.0 semantics restated; Generation/diffusion_prior.py:29,314,370-376)
+ * timestep_embedding: out[n] = [cos(t_n f_i) | sin(t_n f_i)], f_i = exp(-ln(1e4) i/(dim/2))      (Timesteps(dim, True, 0))
+ * ddpm_add_noise:     out = sqrt_acp[t_n]*h + sqrt_1macp[t_n]*noise        (tables: float[1000] on the device)
+ * ddpm_step:          eps = eps_u + g*(eps_c-eps_u) (eps_u NULL: eps = eps_c); x0 = clamp((x - sb*eps)/sa, -1, 1);
+ *                     out = c0*x0 + ct*x + sigma*noise (noise NULL or sigma 0: none).  out may alias x.
+ * mse_loss_grad:      *loss += mean((pred-target)^2); dpred = 2*(pred-target)/n */
+int eegclip_timestep_embedding(const float* t, int n, int dim, float* out, void* stream);
+int eegclip_ddpm_add_noise(const float* h, const float* noise, const long long* t, const float* sqrt_acp, const float* sqrt_1macp,
+                           float* out, int n, int d, void* stream);
+int eegclip_ddpm_step(const float* x, const float* eps_c, const float* eps_u, float guidance, float sa, float sb, float c0, float ct,
+                      float sigma, const float* noise, float* out, long long n, void* stream);
+int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream);
 
 /* ---- 64-token multi-head self-attention.  SelfAttention_Family.py:56-75
  * qkv: (B*L, ld) rows with q | k | v column blocks of H*E each; ctx/dctx: (B*L, H*E); dqkv like qkv.  L must be 64, E <= 64.

@@ -255,3 +255,70 @@ def test_topk_and_count(be):
     CNT = be.zeros(1, np.int32)
     ok(be.lib.eegclip_count_equal(be.ptr(OUT), 5, be.ptr(be.dev(labels.astype(np.int64))), rows, be.ptr(CNT), be.stream))
     assert be.host(CNT)[0] == int((ref[:, 0] == labels).sum())
+
+
+def test_gemm_silu_epilogue_and_prior_stage_kernels(be):
+    import ctypes
+    from eeg_image_decode_amd import _abi
+    rng = np.random.default_rng(21)
+    rows, cols, K = 37, 200, 24
+    a, w, bias = rnd(rng, rows, K), rnd(rng, cols, K), rnd(rng, cols)
+    A, W, BI, C, CP = be.dev(a), be.dev(w), be.dev(bias), be.zeros((rows, cols)), be.zeros((rows, cols))
+    Dm = _abi.dim
+    d = _abi.GemmDesc(M=rows, N=cols, K=K, A=be.ptr(A), Am=Dm(K), Ak=Dm(1), B=be.ptr(W), Bk=Dm(1), Bn=Dm(K), C=be.ptr(C), Cm=Dm(cols), Cn=Dm(1),
+                      Cpre=be.ptr(CP), bias_n=be.ptr(BI), bias_m=None, R=None, Rm=Dm(0), Rn=Dm(0), alpha=1.0, accumulate=0, act=_abi.ACT_SILU,
+                      drop_p=0.0, seed=0, drop_site=0, split_k=1)
+    ok(be.lib.eegclip_gemm_f32(ctypes.byref(d), be.stream))
+    pre = torch.tensor(a, dtype=torch.float64) @ torch.tensor(w, dtype=torch.float64).T + torch.tensor(bias, dtype=torch.float64)
+    np.testing.assert_allclose(be.host(C), F.silu(pre).numpy(), atol=3e-5)
+    # LayerNorm -> SiLU -> dropout and its backward pieces
+    x, g, b, dy = rnd(rng, rows, cols), 1 + 0.1 * rnd(rng, cols), 0.1 * rnd(rng, cols), rnd(rng, rows, cols)
+    X, G, Bt, DY = be.dev(x), be.dev(g), be.dev(b), be.dev(dy)
+    YL, YA, MU, RS = be.zeros((rows, cols)), be.zeros((rows, cols)), be.zeros(rows), be.zeros(rows)
+    p = 0.1
+    ok(be.lib.eegclip_layernorm_silu_fwd(be.ptr(X), be.ptr(G), be.ptr(Bt), be.ptr(YL), be.ptr(YA), be.ptr(MU), be.ptr(RS), rows, cols, 1e-5, p, SEED, 4, be.stream))
+    keep = torch.tensor(keep_mask(SEED, 4, rows * cols, p).reshape(rows, cols))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ln = F.layer_norm(xt, (cols,), torch.tensor(g, dtype=torch.float64), torch.tensor(b, dtype=torch.float64), 1e-5)
+    ya = F.silu(ln) * keep / (1 - p)
+    ya.backward(torch.tensor(dy, dtype=torch.float64))
+    np.testing.assert_allclose(be.host(YL), ln.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(be.host(YA), ya.detach().numpy(), atol=3e-5)
+    DLN, DX, DG, DB = be.zeros((rows, cols)), be.zeros((rows, cols)), be.zeros(cols), be.zeros(cols)
+    ok(be.lib.eegclip_silu_bwd(be.ptr(DY), be.ptr(YL), be.ptr(DLN), rows * cols, 0, p, SEED, 4, be.stream))
+    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DLN), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX), be.ptr(DG), be.ptr(DB), rows, cols, 0, be.stream))
+    np.testing.assert_allclose(be.host(DX), xt.grad.numpy(), atol=5e-5)
+
+
+def test_timestep_embedding_ddpm_and_mse(be):
+    from oracle import prior as oprior
+    rng = np.random.default_rng(22)
+    n, dim = 9, 512
+    t = np.array([0, 1, 5, 20, 333, 980, 999, 500, 7], np.float32)
+    Tt, OUT = be.dev(t), be.zeros((n, dim))
+    ok(be.lib.eegclip_timestep_embedding(be.ptr(Tt), n, dim, be.ptr(OUT), be.stream))
+    np.testing.assert_allclose(be.host(OUT), oprior.timestep_embedding(torch.tensor(t), dim).numpy(), atol=3e-4)   # |t f| up to 999: fp32 sin/cos argument
+    sch = oprior.DDPMSchedulerOracle()
+    d = 1024
+    h, nz = rnd(rng, n, d), rnd(rng, n, d)
+    ts = t.astype(np.int64)
+    SA, SB = be.dev(sch.alphas_cumprod.sqrt().numpy()), be.dev((1 - sch.alphas_cumprod).sqrt().numpy())
+    H, NZ, TS, O2 = be.dev(h), be.dev(nz), be.dev(ts), be.zeros((n, d))
+    ok(be.lib.eegclip_ddpm_add_noise(be.ptr(H), be.ptr(NZ), be.ptr(TS), be.ptr(SA), be.ptr(SB), be.ptr(O2), n, d, be.stream))
+    np.testing.assert_allclose(be.host(O2), sch.add_noise(torch.tensor(h), torch.tensor(nz), torch.tensor(ts)).numpy(), atol=1e-6)
+    # one ancestral step with CFG, against the oracle scheduler
+    sch.set_timesteps(50)
+    x, ec, eu, noise = rnd(rng, n, d), rnd(rng, n, d), rnd(rng, n, d), rnd(rng, n, d)
+    for tstep in (980, 20, 0):
+        sa, sb, c0, ct, sg = sch.step_coeffs(tstep)
+        X, EC, EU, NO, O3 = be.dev(x), be.dev(ec), be.dev(eu), be.dev(noise), be.zeros((n, d))
+        ok(be.lib.eegclip_ddpm_step(be.ptr(X), be.ptr(EC), be.ptr(EU), 5.0, sa, sb, c0, ct, sg, be.ptr(NO), be.ptr(O3), n * d, be.stream))
+        eps = torch.tensor(eu) + 5.0 * (torch.tensor(ec) - torch.tensor(eu))
+        x0 = ((torch.tensor(x) - sb * eps) / sa).clamp(-1, 1)
+        ref = c0 * x0 + ct * torch.tensor(x) + sg * torch.tensor(noise)
+        np.testing.assert_allclose(be.host(O3), ref.numpy(), atol=2e-5)
+    pred, tgt = rnd(rng, n, d), rnd(rng, n, d)
+    PR, TG, LS, DP = be.dev(pred), be.dev(tgt), be.zeros(1), be.zeros((n, d))
+    ok(be.lib.eegclip_mse_loss_grad(be.ptr(PR), be.ptr(TG), n * d, be.ptr(LS), be.ptr(DP), be.stream))
+    assert abs(be.host(LS)[0] - float(((pred - tgt).astype(np.float64) ** 2).mean())) < 1e-5
+    np.testing.assert_allclose(be.host(DP), 2 * (pred - tgt) / (n * d), atol=1e-9)
