@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
 
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
 # name -> argtypes   (restype is always int)
@@ -64,6 +65,7 @@ PROTOTYPES = {
     "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
     "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
+    "eegclip_cross_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],

@@ -166,6 +166,16 @@ int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, i
 int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
                          float* loss, void* stream);
 
+/* ---- SDXL UNet cross-attention with the IP-Adapter image branch fused (call site Generation/custom_pipeline.py:365-373; arithmetic =
+ * diffusers 0.30.0 AttnProcessor2_0 / IPAdapterAttnProcessor2_0, restated -- parity unpinned):
+ *   out = softmax(q k^T / sqrt(64)) v + ip_scale * softmax(q k_ip^T / 8) v_ip
+ * q/out (B, HW, heads*64); k/v (B, S, heads*64); k_ip/v_ip (B, S_ip, heads*64) or NULL with S_ip = 0.  16-bit I/O (dtype), fp32 accumulate.
+ * head_dim must be 64, S and S_ip <= 128, pointers 16-byte aligned. */
+#define EEGCLIP_DT_BF16 0
+#define EEGCLIP_DT_F16 1
+int eegclip_cross_attn_fwd(const void* q, const void* k, const void* v, const void* k_ip, const void* v_ip, void* out, int B, int HW, int heads,
+                           int head_dim, int S, int S_ip, float ip_scale, int dtype, void* stream);
+
 /* ---- retrieval readouts.  ATMS_retrieval.py:246 (argmax), :320 (top-5).  ties -> lowest index; out_idx: int64 (rows, k), k <= 8 */
 int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, const float* scale /* device scalar or NULL: rank by scale*x */,
                       long long* out_idx, void* stream);

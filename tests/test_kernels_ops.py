@@ -322,3 +322,33 @@ def test_timestep_embedding_ddpm_and_mse(be):
     ok(be.lib.eegclip_mse_loss_grad(be.ptr(PR), be.ptr(TG), n * d, be.ptr(LS), be.ptr(DP), be.stream))
     assert abs(be.host(LS)[0] - float(((pred - tgt).astype(np.float64) ** 2).mean())) < 1e-5
     np.testing.assert_allclose(be.host(DP), 2 * (pred - tgt) / (n * d), atol=1e-9)
+
+
+def _to16(a, f16):
+    t = torch.tensor(a)
+    t16 = t.to(torch.float16 if f16 else torch.bfloat16)
+    return t16.view(torch.int16).numpy().copy(), t16.float().numpy()
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B,HW,heads,S,S_ip", [(2, 300, 3, 77, 4), (1, 64, 2, 77, 0), (1, 40, 1, 5, 16)])
+def test_sdxl_cross_attention_with_ip_adapter_branch(be, f16, B, HW, heads, S, S_ip):
+    from oracle import sdxl_attn
+    rng = np.random.default_rng(B * 1000 + HW + S + S_ip + int(f16))
+    C = heads * 64
+    q16, qf = _to16(rnd(rng, B, HW, C), f16)
+    k16, kf = _to16(rnd(rng, B, S, C), f16)
+    v16, vf = _to16(rnd(rng, B, S, C), f16)
+    Q, K, V, OUT = be.dev(q16), be.dev(k16), be.dev(v16), be.zeros((B, HW, C), np.int16)
+    KI = VI = None
+    kif = vif = None
+    if S_ip:
+        ki16, kif = _to16(rnd(rng, B, S_ip, C), f16)
+        vi16, vif = _to16(rnd(rng, B, S_ip, C), f16)
+        KI, VI = be.dev(ki16), be.dev(vi16)
+    ok(be.lib.eegclip_cross_attn_fwd(be.ptr(Q), be.ptr(K), be.ptr(V), be.ptr(KI), be.ptr(VI), be.ptr(OUT), B, HW, heads, 64, S, S_ip, 0.75, int(f16), be.stream))
+    got = torch.tensor(be.host(OUT)).view(torch.float16 if f16 else torch.bfloat16).float().numpy()
+    ref = sdxl_attn.cross_attention(qf, kf, vf, heads, kif, vif, 0.75)
+    tol = 6e-3 if f16 else 2.5e-2            # 16-bit probabilities and outputs: ~2^-11 (f16) / 2^-8 (bf16) relative
+    np.testing.assert_allclose(got, ref, atol=tol)
+    assert np.abs(got - ref).mean() < tol / 6
