@@ -48,6 +48,8 @@ PROTOTYPES = {
     "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P],
     "eegclip_bn_elu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_bn_elu_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
+    "eegclip_bn_elu_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_embed_finish": [_P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_embed_finish_bwd": [_P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_dropout_scale": [_P, _L, _F, _U64, _U, _P],

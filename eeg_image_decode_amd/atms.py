@@ -212,6 +212,7 @@ class ATMS(nn.Module):
         self.proj_eeg = Proj_eeg()
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self.loss_func = ClipLoss()
+        self.sync_batchnorm = True      # under torch.distributed: BatchNorm batch statistics over the global batch (= the single-process semantics)
         self._eng = None
 
     # ---- flat parameter storage ------------------------------------------------------------------------------
@@ -406,7 +407,10 @@ class _Engine:
         pl.memset(sums)
         pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["weff"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
                 C_TS, _p(sums[0]) if train else None)
-        pl.call("eegclip_bn_finalize", _p(sums[0]), float(B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
+        W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
+        if W > 1:
+            pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
+        pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
                 _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train))
         pl.call("eegclip_bn_elu_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(b["z1"]), B, C_TS,
                 N_CH * W_TS, 0.0, 0, 0)
@@ -417,7 +421,9 @@ class _Engine:
                 _p(b["y2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), bias_m=_p(P[_TS + "4.bias"]), split_k=4)
         if train:
             pl.call("eegclip_bn_stats", _p(b["y2"]), B, C_TS, W_TS, _p(sums[1]))
-        pl.call("eegclip_bn_finalize", _p(sums[1]), float(B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
+        if W > 1:
+            pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
+        pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
                 _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train))
         pl.call("eegclip_bn_elu_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["z2"]), B, C_TS,
                 W_TS, pc_, 0, SITE_CONV, seed_at=10)
@@ -472,8 +478,8 @@ class _Engine:
                 _p(b["dz2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS))
         # BN2 + ELU + dropout backward
         pl.memset(sums)
-        pl.call("eegclip_bn_elu_bwd", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(sums[2]),
-                _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS, W_TS, pc_, 0, SITE_CONV, seed_at=14)
+        W = self._world()
+        self._bn_bwd(pl, W, b["dz2"], b["y2"], bn[2], bn[3], _TS + "5.", sums[2], b["dy2"], B, W_TS, pc_, SITE_CONV)
         # spatial conv backward
         KS = C_TS * N_CH
         # d(conv bias) in front of a train-mode BatchNorm is identically zero (sum_x dy = 0 by the BN backward formula): the
@@ -483,8 +489,7 @@ class _Engine:
         pl.gemm(KS, B * W_TS, C_TS, _p(P[_TS + "4.weight"]), D(1), D(KS), _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS),
                 _p(b["dz1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS))
         # BN1 + ELU backward, then the fused conv+pool backward
-        pl.call("eegclip_bn_elu_bwd", _p(b["dz1"]), _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(sums[3]),
-                _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, C_TS, N_CH * W_TS, 0.0, 0, 0)
+        self._bn_bwd(pl, W, b["dz1"], b["y1"], bn[0], bn[1], _TS + "2.", sums[3], b["dy1"], B, N_CH * W_TS, 0.0, 0)
         pl.memset(b["dweff"])
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), B, N_CH, T_LEN, C_TS)
         pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))
@@ -534,13 +539,42 @@ class _Engine:
                     _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
         return pl
 
+    def _bn_bwd(self, pl, W, dz, x, mean, rstd, prefix, sums, dx, B, inner, p, site):
+        P, G = self.P, self.G
+        if W == 1:
+            pl.call("eegclip_bn_elu_bwd", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), _p(dx),
+                    _p(G[prefix + "weight"]), _p(G[prefix + "bias"]), B, C_TS, inner, p, 0, site, seed_at=14)
+            return
+        # SyncBN backward: dx needs the GLOBAL channel sums (all-reduced); dgamma/dbeta take this rank's LOCAL sums, so the later
+        # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.
+        pl.call("eegclip_bn_elu_bwd_stats", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), B, C_TS,
+                inner, p, 0, site, seed_at=11)
+        local = torch.zeros_like(sums)
+        pl._keep.append(local)
+
+        def exchange():
+            local.copy_(sums)
+            self._allreduce(sums)
+        pl.callback(exchange, "allreduce_bn_bwd")
+        pl.call("eegclip_bn_elu_bwd_apply", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), _p(local),
+                float(W * B * inner), _p(dx), _p(G[prefix + "weight"]), _p(G[prefix + "bias"]), B, C_TS, inner, p, 0, site, seed_at=16)
+
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if (self.model.sync_batchnorm and dist.is_available() and dist.is_initialized()) else 1
+
+    @staticmethod
+    def _allreduce(t):
+        import torch.distributed as dist
+        dist.all_reduce(t)
+
     # ---- execution -----------------------------------------------------------------------------------------------
     def forward(self, x, ids, shared, train):
         B = x.shape[0]
         probs = self.model.drop_probs(train)
         if B not in self.bufs:
             self.bufs[B] = self._alloc(B)
-        key = (B, train, shared, probs)
+        key = (B, train, shared, probs, self._world())
         pk = ("f",) + key
         if pk not in self.plans:
             self.plans[pk] = self._build_fwd(B, train, shared, probs)
@@ -580,11 +614,11 @@ class _Engine:
         return True
 
     def backward(self, key, x, dout, want_dx):
-        B, train, shared, probs = key
+        B, train, shared, probs, W = key
         b = self.bufs[B]
         if "ds" not in b:
             self._alloc_bwd(B, b)
-        pk = ("b", B, shared, probs, want_dx)
+        pk = ("b", B, shared, probs, want_dx, W)
         if pk not in self.plans:
             self.plans[pk] = self._build_bwd(B, shared, probs, want_dx)
         pl = self.plans[pk]

@@ -207,15 +207,16 @@ __global__ __launch_bounds__(256) void bn_elu_bwd_stats_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_elu_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const double* __restrict__ sums, double count, float* __restrict__ dx,
+                                                                const double* __restrict__ sums, const double* __restrict__ sums_param,
+                                                                double count, float* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, long long n,
                                                                 int C, int inner, float drop_p, unsigned long long seed,
                                                                 unsigned site) {
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gtid < C) {
-        atomicAdd(dgamma + gtid, (float)sums[C + gtid]);
-        atomicAdd(dbeta + gtid, (float)sums[gtid]);
+    if (gtid < C) {      // parameter gradients come from `sums_param` (this rank's own sums under SyncBN; == sums otherwise)
+        atomicAdd(dgamma + gtid, (float)sums_param[C + gtid]);
+        atomicAdd(dbeta + gtid, (float)sums_param[gtid]);
     }
     for (long long i = gtid; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)((i / inner) % C);
@@ -289,6 +290,30 @@ extern "C" int eegclip_bn_elu_fwd(const float* x, const float* mean, const float
     return (int)hipGetLastError();
 }
 
+// split form for data-parallel SyncBN: all-reduce `sums` across ranks between the two calls and pass the GLOBAL element count
+extern "C" int eegclip_bn_elu_bwd_stats(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                        const float* beta, double* sums, int outer, int C, int inner, float drop_p, unsigned long long seed,
+                                        unsigned site, void* stream) {
+    if (!dz || !x || !mean || !rstd || !gamma || !beta || !sums || outer < 1 || C < 1 || inner < 1 || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    int chunks = outer < 64 ? outer : 64;
+    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, dz, x, mean, rstd, gamma, beta, outer, C,
+               inner, drop_p, seed, site, sums);
+    return (int)hipGetLastError();
+}
+extern "C" int eegclip_bn_elu_bwd_apply(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                        const float* beta, const double* sums, const double* sums_local, double count, float* dx, float* dgamma,
+                                        float* dbeta, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site,
+                                        void* stream) {
+    if (!dz || !x || !mean || !rstd || !gamma || !beta || !sums || !dx || !dgamma || !dbeta || outer < 1 || C < 1 || inner < 1 || count < 1.0 ||
+        drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    const long long n = (long long)outer * C * inner;
+    EEG_LAUNCH(bn_elu_bwd_apply_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, dz, x, mean, rstd, gamma, beta, sums,
+               sums_local ? sums_local : sums, count, dx, dgamma, dbeta, n, C, inner, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
 extern "C" int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, double* sums /* [2C], zeroed by the caller */, float* dx, float* dgamma,
                                   float* dbeta, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site,
@@ -300,7 +325,7 @@ extern "C" int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* 
     int chunks = outer < 64 ? outer : 64;
     EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, dz, x, mean, rstd, gamma, beta,
                outer, C, inner, drop_p, seed, site, sums);
-    EEG_LAUNCH(bn_elu_bwd_apply_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, dz, x, mean, rstd, gamma, beta, sums,
+    EEG_LAUNCH(bn_elu_bwd_apply_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, dz, x, mean, rstd, gamma, beta, sums, sums,
                (double)outer * inner, dx, dgamma, dbeta, n, C, inner, drop_p, seed, site);
     return (int)hipGetLastError();
 }

@@ -8,7 +8,7 @@ correction with a per-parameter step count, parameters whose grad is None are sk
 """
 import torch
 
-from ._lib import EegclipError, check, lib
+from ._lib import EegclipError, check, lib, require_cuda
 
 
 class AdamW(torch.optim.Optimizer):
@@ -36,8 +36,9 @@ class AdamW(torch.optim.Optimizer):
             if not live:
                 continue
             for p in live:
-                if not p.is_cuda or p.dtype != torch.float32 or not p.grad.is_cuda:
-                    raise EegclipError("eeg_image_decode_amd.optim works on float32 CUDA parameters only (no CPU path)")
+                require_cuda(p, "parameter")
+                if p.dtype != torch.float32:
+                    raise EegclipError("eeg_image_decode_amd.optim works on float32 parameters")
                 st = self.state[p]
                 st["step"] = st.get("step", 0) + 1
             steps = {self.state[p]["step"] for p in live}

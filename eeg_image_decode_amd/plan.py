@@ -41,6 +41,10 @@ class Plan:
         self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32"))
         return d
 
+    def callback(self, fn, name="callback"):
+        """run a host callable in stream order (collectives between kernels: SyncBN statistics)"""
+        self.ops.append((None, [fn], name))
+
     def memset(self, tensor):
         """zero a torch tensor as part of the plan (stream-ordered)"""
         self.ops.append((None, [tensor], "memset"))
@@ -71,7 +75,10 @@ class Plan:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(ts)
             if fn is None:
-                args[0].zero_()
+                if name == "memset":
+                    args[0].zero_()
+                else:
+                    args[0]()
             else:
                 args[-1] = stream
                 rc = fn(*args)

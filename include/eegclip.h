@@ -97,6 +97,15 @@ int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const
                        double* sums, float* dx, float* dgamma, float* dbeta, int outer, int C, int inner, float drop_p,
                        unsigned long long seed, unsigned int site, void* stream);
 
+/* split form of bn_elu_bwd for data-parallel SyncBN: stats -> copy sums to sums_local -> all-reduce sums[2C] -> apply with the GLOBAL
+ * count.  dx uses the global sums; dgamma/dbeta += this rank's own sums (sums_local; NULL = sums) so that the later mean-all-reduce of
+ * the parameter gradients reproduces the single-process value. */
+int eegclip_bn_elu_bwd_stats(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             double* sums, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_bn_elu_bwd_apply(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const double* sums, const double* sums_local, double count, float* dx, float* dgamma, float* dbeta, int outer, int C, int inner, float drop_p,
+                             unsigned long long seed, unsigned int site, void* stream);
+
 /* ---- token insertion + embedding dropout on h (B,L,D) in place.  Embed.py:116-121,158-162
  * row 0 of sample b <- tokens[ids[b]] (ids == NULL: tokens[0], the shared token).  bwd: dh *= mask/(1-p); dtokens[id] += dh[b,0,:] */
 int eegclip_embed_finish(float* h, const float* tokens, const long long* ids, int B, int L, int D, float drop_p,

@@ -36,7 +36,8 @@ def test_ip_adapter_cross_attention_processor(dtype, dim, heads):
     hs = torch.randn(B, HW, dim, device="cuda", dtype=dtype)
     text = torch.randn(B, 77, cross, device="cuda", dtype=dtype)
     ip = torch.randn(B, 1, 4, cross, device="cuda", dtype=dtype)
-    out = proc(attn, hs, encoder_hidden_states=(text, [ip]))
+    with torch.no_grad():
+        out = proc(attn, hs, encoder_hidden_states=(text, [ip]))
     assert out.shape == hs.shape and out.dtype == dtype
     # oracle on the same 16-bit projections
     with torch.no_grad():
@@ -47,7 +48,8 @@ def test_ip_adapter_cross_attention_processor(dtype, dim, heads):
     tol = 1e-2 if dtype == torch.float16 else 4e-2
     np.testing.assert_allclose(out.float().cpu().numpy(), ref_out.float().cpu().numpy(), atol=tol)
     # 4-D (B,C,H,W) input path of the diffusers processors
-    out4 = proc(attn, hs.transpose(1, 2).reshape(B, dim, 16, 16), encoder_hidden_states=(text, [ip]))
+    with torch.no_grad():
+        out4 = proc(attn, hs.transpose(1, 2).reshape(B, dim, 16, 16), encoder_hidden_states=(text, [ip]))
     np.testing.assert_allclose(out4.float().cpu().numpy(), out.transpose(1, 2).reshape(B, dim, 16, 16).float().cpu().numpy(), atol=1e-3)
 
 
