@@ -65,7 +65,8 @@ PROTOTYPES = {
     "eegclip_tsconv_fold": [_P, _P, _P],
     "eegclip_tsconv_unfold_grad": [_P, _P, _P],
     "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
+    "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eegclip_tsconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
     "eegclip_cross_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],
@@ -81,6 +82,6 @@ def declare(lib):
     """Attach prototypes; raises AttributeError if the library lacks a symbol the header declares."""
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
-        fn.restype = C.c_int
+        fn.restype = C.c_longlong if name.endswith("_floats") else C.c_int
         fn.argtypes = args
     return lib

@@ -490,8 +490,9 @@ class _Engine:
                 _p(b["dz1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS))
         # BN1 + ELU backward, then the fused conv+pool backward
         self._bn_bwd(pl, W, b["dz1"], b["y1"], bn[0], bn[1], _TS + "2.", sums[3], b["dy1"], B, N_CH * W_TS, 0.0, 0)
-        pl.memset(b["dweff"])
-        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), B, N_CH, T_LEN, C_TS)
+        if "tsw_ws" not in b:
+            b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS)
         pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))
         pl.memset(b["dn3"])                       # token row 63 (EEG channel 62) gets no gradient from the conv path
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(b["weff"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)

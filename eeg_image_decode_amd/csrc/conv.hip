@@ -4,11 +4,6 @@
 // so the (B,40,63,226) intermediate (583 MB at B=256) never exists.  x is the encoder output (B,64,250) read in
 // place (rows 0..62 of every sample: subject token + channels 0..61, ATMS_retrieval.py:91) -- no slice copy.
 //
-// The stride-5 filter is evaluated in polyphase form (u = 5g + r, X[q][r] = x[5q+r]) so that each lane keeps a
-// register window and every LDS operand feeds >= 4 FMAs:
-//   fwd   : lane (c, 4 outputs)      : 90-float x window in registers, 1 weight read per 4 FMAs
-//   bwd_w : lane (c, r)              : dy[c][0..35] in registers, 1 x read per ~11 FMAs, 15 accumulators
-//   bwd_x : lane (r, 10 outputs)     : per channel a 24-float dy window + 15 taps in registers, 150 FMAs
 #include "eeg_common.h"
 
 namespace eeg {
@@ -40,161 +35,234 @@ __global__ void tsconv_unfold_grad_kernel(const float* __restrict__ dweff, float
     dw25[i] += s * (1.0f / TS_POOL);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward.  block = 384 threads (360 active): t -> (wg = t % 9, c = t / 9); outputs w = 4wg .. 4wg+3 of channel c.
-// LDS: weff transposed [u][c] (3000 f) | x row (250 f, padded to 256) | stats scratch 2*360 f
-__global__ __launch_bounds__(384) void tsconv_fwd_kernel(const float* __restrict__ x, long long xs_b, long long xs_h,
+// ===============================================================================================================
+// All three heavy kernels are implicit GEMMs on the f32 matrix cores (v_mfma_f32_16x16x4_f32) over the flattened output-position
+// index m = (row, w), row = (b, h), X[m][u] = x[row][5w + u] read straight from the token rows staged in LDS:
+//   fwd   : Y^T[c][m]   = sum_u  weff[c][u] * X[m][u]         (M = 40->48 filters, N = positions, K = 75->76 taps)
+//   bwd_w : dW[c][u]    = sum_m  dy[c][m]   * X[m][u]         (15 accumulator tiles live across the whole reduction)
+//   bwd_x : T[m][u]     = sum_c  dy[c][m]   * weff[c][u]      then overlap-add dx[row][5w + u] += T[m][u] in LDS (ds_add_f32)
+// Channel-major accumulators in fwd (rows = filters, cols = 16 consecutive positions) make every store a 64-byte run of y.
+constexpr int TS_CP = 48;     // filters padded to 3 MFMA tiles
+constexpr int TS_UP = 80;     // taps padded to 5 MFMA tiles (bwd) ; fwd uses 76 = 19 k-steps
+constexpr int TS_XS = 256;    // staged token-row stride (250 samples + zero pad: windows may read up to index 254)
+
+__device__ __forceinline__ void stage_x_rows(float* xl, const float* x, long long xs_b, long long xs_h, int row0, int nrows, int rows, int H) {
+    for (int i = threadIdx.x; i < nrows * TS_XS; i += blockDim.x) {
+        const int rl = i / TS_XS, tt = i % TS_XS;
+        const int row = row0 + rl;
+        float v = 0.f;
+        if (row < rows && tt < TS_T) v = x[(row / H) * xs_b + (row % H) * xs_h + tt];
+        xl[i] = v;
+    }
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+constexpr int TSF_R = 32;                       // token rows per work item: 32*36/16 = 72 position tiles, 18 per wave
+__global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict__ x, long long xs_b, long long xs_h,
                                                           const float* __restrict__ weff, const float* __restrict__ bias,
                                                           float* __restrict__ y, int B, int H, double* __restrict__ sums) {
     EEG_LDS_BASE(float, lds);
-    float* wl = lds;                    // [75][40]
-    float* xl = lds + TS_U * TS_C;      // [256]
-    float* sc = xl + 256;               // [2][360]
-    const int t = threadIdx.x;
-    for (int i = t; i < TS_U * TS_C; i += blockDim.x) {
-        const int u = i / TS_C, c = i % TS_C;
-        wl[i] = weff[c * TS_U + u];
-    }
-    const bool active = t < 360;
-    const int wg = active ? t % 9 : 0, c = active ? t / 9 : 0;
-    const float bc = bias[c];
-    float ssum = 0.f, ssq = 0.f;
+    float* wl = lds;                             // [76][48]  taps-major: A operand (filters) read = 16 consecutive floats
+    float* xl = wl + 76 * TS_CP;                 // [32][256]
+    float* sc = xl + TSF_R * TS_XS;              // [4][2][48] per-wave channel sums
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int b = row / H, h = row % H;
-        __syncthreads();                 // previous row's window reads are done (also covers the weight staging)
-        if (t < TS_T) xl[t] = x[b * xs_b + h * xs_h + t];
+    for (int i = t; i < 76 * TS_CP; i += blockDim.x) {
+        const int u = i / TS_CP, c = i % TS_CP;
+        wl[i] = (u < TS_U && c < TS_C) ? weff[c * TS_U + u] : 0.f;
+    }
+    float bc[3][4], ss[3][4], sq[3][4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * g + r;
+            bc[ct][r] = c < TS_C ? bias[c] : 0.f;
+            ss[ct][r] = 0.f;
+            sq[ct][r] = 0.f;
+        }
+    const int nchunks = (rows + TSF_R - 1) / TSF_R;
+    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int row0 = ch * TSF_R;
+        __syncthreads();                          // previous chunk fully consumed (also orders the weight staging)
+        stage_x_rows(xl, x, xs_b, xs_h, row0, TSF_R, rows, H);
         __syncthreads();
-        if (active) {
-            float win[90];
+        for (int mt = wv; mt < TSF_R * TS_W / 16; mt += 4) {
+            const int m = 16 * mt + fr;          // B-operand column: output position
+            const float* xp = xl + (m / TS_W) * TS_XS + 5 * (m % TS_W) + g;
+            f32x4 acc[3];
 #pragma unroll
-            for (int i = 0; i < 90; ++i) win[i] = xl[20 * wg + i];
-            float a0 = bc, a1 = bc, a2 = bc, a3 = bc;
+            for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < TS_U; ++u) {
-                const float wv = wl[u * TS_C + c];
-                a0 += wv * win[u];
-                a1 += wv * win[5 + u];
-                a2 += wv * win[10 + u];
-                a3 += wv * win[15 + u];
+            for (int kk = 0; kk < 19; ++kk) {
+                const float xv = xp[4 * kk];
+                const float* wp = wl + (4 * kk + g) * TS_CP + fr;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma_f32_16x16x4(wp[16 * ct], xv, acc[ct]);   // D[c = 16ct+4g+r][m = 16mt+fr]
             }
-            float* yp = y + (((long long)b * TS_C + c) * H + h) * TS_W + 4 * wg;
-            *reinterpret_cast<float4*>(yp) = make_float4(a0, a1, a2, a3);
-            ssum += (a0 + a1) + (a2 + a3);
-            ssq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            const int row = row0 + m / TS_W;
+            if (row < rows) {
+                const int w = m % TS_W;
+                float* yp = y + ((long long)(row / H) * TS_C * H + (row % H)) * TS_W + w;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * ct + 4 * g + r;
+                        if (c < TS_C) {
+                            const float v = acc[ct][r] + bc[ct][r];
+                            yp[(long long)c * H * TS_W] = v;
+                            ss[ct][r] += v;
+                            sq[ct][r] += v * v;
+                        }
+                    }
+            }
         }
     }
-    if (sums) {                          // BatchNorm batch statistics fused into the producer
-        __syncthreads();
-        if (active) { sc[t] = ssum; sc[360 + t] = ssq; }
+    if (sums) {                                   // BatchNorm batch statistics fused into the producer (fp64 atomics, one per channel per block)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = ss[ct][r], b2 = sq[ct][r];
+#pragma unroll
+                for (int msk = 8; msk >= 1; msk >>= 1) { a += __shfl_xor(a, msk, 64); b2 += __shfl_xor(b2, msk, 64); }
+                if (fr == 0) { sc[(wv * 2 + 0) * TS_CP + 16 * ct + 4 * g + r] = a; sc[(wv * 2 + 1) * TS_CP + 16 * ct + 4 * g + r] = b2; }
+            }
         __syncthreads();
         if (t < TS_C) {
             double s = 0.0, q = 0.0;
-            for (int k = 0; k < 9; ++k) { s += sc[t * 9 + k]; q += sc[360 + t * 9 + k]; }
+            for (int k = 0; k < 4; ++k) { s += sc[(k * 2 + 0) * TS_CP + t]; q += sc[(k * 2 + 1) * TS_CP + t]; }
             atomicAdd(sums + t, s);
             atomicAdd(sums + TS_C + t, q);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// dweff[c][5g+r] += sum_rows sum_w dy[row][c][w] * x[row][5(w+g)+r].   block = 256 (200 active): t -> (c = t % 40, r = t / 40)
-// LDS: dy slab [40][37] | x row [256]
+// ---- backward w.r.t. the taps -----------------------------------------------------------------------------------------
+constexpr int TSW_R = 9;                        // rows per work item (7 items per 63-row sample): 324 positions = 81 k-steps
+constexpr int TSW_MS = TSW_R * TS_W + 17;       // dy slab row stride (341 = 21 mod 32: skewed banks for the 16 filter rows)
 __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restrict__ x, long long xs_b, long long xs_h,
-                                                            const float* __restrict__ dy, float* __restrict__ dweff, int B, int H) {
+                                                            const float* __restrict__ dy, float* __restrict__ partials, int B, int H) {
     EEG_LDS_BASE(float, lds);
-    float* dl = lds;                     // [40][37]
-    float* xl = lds + TS_C * 37;         // [256]
-    const int t = threadIdx.x;
-    const bool active = t < 200;
-    const int c = active ? t % TS_C : 0, r = active ? t / TS_C : 0;
-    float acc[15];
-#pragma unroll
-    for (int g = 0; g < 15; ++g) acc[g] = 0.f;
+    float* dl = lds;                             // [48][TSW_MS]  dy slab, filter-major (rows >= 40 zero)
+    float* xl = dl + TS_CP * TSW_MS;             // [9][256]
+    float* red = xl + TSW_R * TS_XS;             // [48][80] cross-wave reduction
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int b = row / H, h = row % H;
+    const int per = (H + TSW_R - 1) / TSW_R;     // work items per sample
+    f32x4 acc[3][5];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int ut = 0; ut < 5; ++ut) acc[ct][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < TS_CP * TSW_MS; i += blockDim.x) dl[i] = 0.f;         // pad filters 40..47 stay zero for ever
+    for (int item = blockIdx.x; item < B * per; item += gridDim.x) {
+        const int b = item / per, h0 = (item % per) * TSW_R;
+        const int nr = H - h0 < TSW_R ? H - h0 : TSW_R;
+        const int mc = nr * TS_W;                 // positions in this slab (multiple of 4)
         __syncthreads();
-        if (t < TS_T) xl[t] = x[b * xs_b + h * xs_h + t];
-        for (int i = t; i < TS_C * TS_W; i += blockDim.x) {
-            const int cc = i / TS_W, w = i % TS_W;
-            dl[cc * 37 + w] = dy[(((long long)b * TS_C + cc) * H + h) * TS_W + w];
+        stage_x_rows(xl, x, xs_b, xs_h, b * H + h0, TSW_R, b * H + h0 + nr, H);
+        for (int i = t; i < TS_C * mc; i += blockDim.x) {
+            const int c = i / mc, m = i % mc;    // (h, w) is contiguous in dy for a fixed (b, c)
+            dl[c * TSW_MS + m] = dy[(((long long)b * TS_C + c) * H + h0) * TS_W + m];
         }
         __syncthreads();
-        if (active) {
-            float d[TS_W];
+        for (int ks = wv; ks < mc / 4; ks += 4) {
+            const int m = 4 * ks + g;            // this lane's k index (position)
+            const float* xp = xl + (m / TS_W) * TS_XS + 5 * (m % TS_W) + fr;
+            float av[3], bv[5];
 #pragma unroll
-            for (int w = 0; w < TS_W; ++w) d[w] = dl[c * 37 + w];
+            for (int ct = 0; ct < 3; ++ct) av[ct] = dl[(16 * ct + fr) * TSW_MS + m];
 #pragma unroll
-            for (int q = 0; q < 50; ++q) {
-                const float xv = xl[5 * q + r];
+            for (int ut = 0; ut < 5; ++ut) bv[ut] = xp[16 * ut];
 #pragma unroll
-                for (int g = 0; g < 15; ++g) {
-                    const int w = q - g;
-                    if (w >= 0 && w < TS_W) acc[g] += d[w] * xv;
-                }
-            }
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int ut = 0; ut < 5; ++ut) acc[ct][ut] = mfma_f32_16x16x4(av[ct], bv[ut], acc[ct][ut]);   // D[c][u]
         }
     }
-    if (active) {
+    __syncthreads();
+    for (int i = t; i < TS_CP * TS_UP; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 15; ++g) atomicAdd(dweff + c * TS_U + 5 * g + r, acc[g]);
-    }
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int ut = 0; ut < 5; ++ut)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * ct + 4 * g + r) * TS_UP + 16 * ut + fr, acc[ct][ut][r]);
+    __syncthreads();
+    float* out = partials + (long long)blockIdx.x * (TS_C * TS_U);
+    for (int i = t; i < TS_C * TS_U; i += blockDim.x) out[i] = red[(i / TS_U) * TS_UP + (i % TS_U)];
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// dx[row][5q+r] = sum_c sum_g dy[row][c][q-g] * weff[c][5g+r].   block = 256 (250 active) = 10 rows x (5 q-blocks x 5 r)
-// LDS: weff [40][75] | dy slabs [10][40*36]
-constexpr int TSX_ROWS = 10;
+// dweff[i] = sum over blocks of partials[blk][i]
+__global__ void tsconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ dweff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TS_C * TS_U) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partials[(long long)k * (TS_C * TS_U) + i];
+    dweff[i] = s;
+}
+
+// ---- backward w.r.t. the token rows ------------------------------------------------------------------------------------
+constexpr int TSX_R = 8;                        // rows per work item: 288 positions = 18 tiles
+constexpr int TSX_MS = TSX_R * TS_W + 16;       // 304 = 16 (mod 32)
 __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
                                                             float* __restrict__ dx, long long xs_b, long long xs_h, int B, int H) {
     EEG_LDS_BASE(float, lds);
-    float* wl = lds;                         // [40][75]
-    float* dl = lds + TS_C * TS_U;           // [10][1440]
-    const int t = threadIdx.x;
-    for (int i = t; i < TS_C * TS_U; i += blockDim.x) wl[i] = weff[i];
-    const bool active = t < 250;
-    const int rl = active ? t / 25 : 0, qb = active ? (t % 25) / 5 : 0, r = active ? t % 5 : 0;
+    float* wl = lds;                             // [40][80]  filter-major taps (cols >= 75 zero)
+    float* dl = wl + TS_C * TS_UP;               // [40][TSX_MS] dy slab
+    float* xo = dl + TS_C * TSX_MS;              // [8][256]  overlap-add target
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
-    for (int row0 = blockIdx.x * TSX_ROWS; row0 < rows; row0 += gridDim.x * TSX_ROWS) {
+    for (int i = t; i < TS_C * TS_UP; i += blockDim.x) {
+        const int c = i / TS_UP, u = i % TS_UP;
+        wl[i] = u < TS_U ? weff[c * TS_U + u] : 0.f;
+    }
+    const int nitems = (rows + TSX_R - 1) / TSX_R;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int row0 = item * TSX_R;
         __syncthreads();
-        for (int i = t; i < TSX_ROWS * TS_C * TS_W; i += blockDim.x) {
-            const int rr = i / (TS_C * TS_W), rem = i % (TS_C * TS_W);
-            const int cc = rem / TS_W, w = rem % TS_W;
-            const int row = row0 + rr;
+        for (int i = t; i < TSX_R * TS_C * TS_W; i += blockDim.x) {
+            const int rl = i / (TS_C * TS_W), rem = i % (TS_C * TS_W);
+            const int c = rem / TS_W, w = rem % TS_W;
+            const int row = row0 + rl;
             float v = 0.f;
-            if (row < rows) {
-                const int b = row / H, h = row % H;
-                v = dy[(((long long)b * TS_C + cc) * H + h) * TS_W + w];
+            if (row < rows) v = dy[(((long long)(row / H) * TS_C + c) * H + (row % H)) * TS_W + w];
+            dl[c * TSX_MS + rl * TS_W + w] = v;
+        }
+        for (int i = t; i < TSX_R * TS_XS; i += blockDim.x) xo[i] = 0.f;
+        __syncthreads();
+        for (int mt = wv; mt < TSX_R * TS_W / 16; mt += 4) {
+            f32x4 acc[5];
+#pragma unroll
+            for (int ut = 0; ut < 5; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < TS_C / 4; ++kk) {
+                const int c = 4 * kk + g;
+                const float a = dl[c * TSX_MS + 16 * mt + fr];                     // A[m = 16mt+fr][k = c]
+                const float* wp = wl + c * TS_UP + fr;
+#pragma unroll
+                for (int ut = 0; ut < 5; ++ut) acc[ut] = mfma_f32_16x16x4(a, wp[16 * ut], acc[ut]);   // D[m = 16mt+4g+r][u = 16ut+fr]
             }
-            dl[i] = v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mt + 4 * g + r;
+                float* xr = xo + (m / TS_W) * TS_XS + 5 * (m % TS_W) + fr;
+#pragma unroll
+                for (int ut = 0; ut < 5; ++ut)
+                    if (16 * ut + fr < TS_U) atomicAdd(xr + 16 * ut, acc[ut][r]);  // LDS overlap-add (ds_add_f32)
+            }
         }
         __syncthreads();
-        const int row = row0 + rl;
-        if (active && row < rows) {
-            float acc[10];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-            const int q0 = qb * 10;
-            for (int c = 0; c < TS_C; ++c) {
-                float dw[24], wv[15];
-                const float* dp = dl + rl * (TS_C * TS_W) + c * TS_W;
-#pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    const int w = q0 - 14 + i;
-                    dw[i] = (w >= 0 && w < TS_W) ? dp[w] : 0.f;
-                }
-#pragma unroll
-                for (int g = 0; g < 15; ++g) wv[g] = wl[c * TS_U + 5 * g + r];
-#pragma unroll
-                for (int k = 0; k < 10; ++k)
-#pragma unroll
-                    for (int g = 0; g < 15; ++g) acc[k] += dw[k - g + 14] * wv[g];
-            }
-            const int b = row / H, h = row % H;
-            float* xp = dx + b * xs_b + h * xs_h;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) xp[5 * (q0 + k) + r] = acc[k];
+        for (int i = t; i < TSX_R * TS_T; i += blockDim.x) {
+            const int rl = i / TS_T, tt = i % TS_T;
+            const int row = row0 + rl;
+            if (row < rows) dx[(row / H) * xs_b + (row % H) * xs_h + tt] = xo[rl * TS_XS + tt];
         }
     }
 }
@@ -222,20 +290,28 @@ extern "C" int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h
                                   int B, int H, int T, int C, double* sums, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!x || !weff || !bias || !y) return EEGCLIP_EINVAL;
-    if (((uintptr_t)y & 15) != 0) return EEGCLIP_EALIGN;
-    int grid = B * H < 1024 ? B * H : 1024;
-    const size_t lds = (TS_U * TS_C + 256 + 720) * sizeof(float);
-    EEG_LAUNCH(tsconv_fwd_kernel, dim3(grid), dim3(384), lds, stream, x, xs_b, xs_h, weff, bias, y, B, H, sums);
+    const int nchunks = (B * H + TSF_R - 1) / TSF_R;
+    int grid = nchunks < 768 ? nchunks : 768;
+    const size_t lds = (76 * TS_CP + TSF_R * TS_XS + 8 * TS_CP) * sizeof(float);
+    EEG_LAUNCH(tsconv_fwd_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, weff, bias, y, B, H, sums);
     return (int)hipGetLastError();
 }
 
-extern "C" int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, int B, int H, int T,
-                                    int C, void* stream) {
+static int tsw_grid(int B, int H) {
+    const int items = B * ((H + TSW_R - 1) / TSW_R);
+    return items < 512 ? items : 512;
+}
+
+extern "C" long long eegclip_tsconv_bwd_w_workspace_floats(int B, int H) { return (long long)tsw_grid(B, H) * TS_C * TS_U; }
+
+extern "C" int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, float* workspace, int B,
+                                    int H, int T, int C, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
-    if (!x || !dy || !dweff) return EEGCLIP_EINVAL;
-    int grid = B * H < 768 ? B * H : 768;
-    const size_t lds = (TS_C * 37 + 256) * sizeof(float);
-    EEG_LAUNCH(tsconv_bwd_w_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, dy, dweff, B, H);
+    if (!x || !dy || !dweff || !workspace) return EEGCLIP_EINVAL;
+    const int grid = tsw_grid(B, H);
+    const size_t lds = (TS_CP * TSW_MS + TSW_R * TS_XS + TS_CP * TS_UP) * sizeof(float);
+    EEG_LAUNCH(tsconv_bwd_w_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, dy, workspace, B, H);
+    EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_U + 255) / 256), dim3(256), 0, stream, workspace, grid, dweff);
     return (int)hipGetLastError();
 }
 
@@ -243,9 +319,9 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* d
                                     int C, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!dy || !weff || !dx) return EEGCLIP_EINVAL;
-    const int groups = (B * H + TSX_ROWS - 1) / TSX_ROWS;
-    int grid = groups < 2048 ? groups : 2048;
-    const size_t lds = (TS_C * TS_U + TSX_ROWS * TS_C * TS_W) * sizeof(float);
+    const int items = (B * H + TSX_R - 1) / TSX_R;
+    int grid = items < 1024 ? items : 1024;
+    const size_t lds = (TS_C * TS_UP + TS_C * TSX_MS + TSX_R * TS_XS) * sizeof(float);
     EEG_LAUNCH(tsconv_bwd_x_kernel, dim3(grid), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);
     return (int)hipGetLastError();
 }

@@ -2,31 +2,44 @@
 //
 //   C[m,n] (+)= epilogue(alpha * sum_k A[m,k] B[k,n])        -- see include/eegclip.h: eegclip_gemm_desc
 //
-// Tiling (CDNA4): 64x64 output tile per 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning a
-// 32x32 sub-tile as 2x2 MFMA 16x16 accumulators; BK = 32.  Both operand tiles are staged k-major in LDS
-// (As[k][m], Bs[k][n], row stride 81 floats): the MFMA operand read "lane l -> (row l&15, k l>>4)" is then a
-// ds_read_b32 of 16 consecutive floats per 16-lane group, and 81 = 17 (mod 32) keeps both that read and the
-// k-contiguous staging write (lanes walk k) off each other's banks.  Global->register prefetch of tile t+1
+// Tiling (CDNA4): BM x BN output tile (128x128, 128x64 or 64x64, chosen per problem so the grid still fills 256 CUs) per
+// 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning (BM/2)x(BN/2) as (BM/32)x(BN/32) MFMA 16x16
+// accumulators; BK = 32.  Both operand tiles are staged k-major in LDS (As[k][m], Bs[k][n], row stride BM+17 floats):
+// the MFMA operand read "lane l -> (row l&15, k l>>4)" is then a ds_read_b32 of 16 consecutive floats per 16-lane group,
+// and stride = 17 (mod 32) keeps both that read and the k-contiguous staging write (lanes walk k) off each other's banks.  Global->register prefetch of tile t+1
 // overlaps the MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
 // aligned: every load and store is guarded, padding lives only in LDS (zeros), never in HBM.
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
-constexpr int G_BM = 64, G_BN = 64, G_BK = 32, G_LD = 81;
+constexpr int G_BK = 32;
 constexpr int G_THREADS = 256;
-constexpr int G_EPT = (G_BM * G_BK) / G_THREADS;   // 8 staged elements per thread per operand
 
-template <bool A_KC, bool B_KC>
+// LDS image: element (k, m) of a BK x BT operand tile lives at k*BT + (m ^ swz(k)), swz(k) = ((k&1)<<4) | (k>>1):
+//   * MFMA operand read (16 lanes walk m at k, the next 16 at k+1, ds_read_b32 services 32 lanes per cycle over 32 banks): the
+//     two 16-float runs land in opposite halves of the 32 banks (bit 4 of swz = k&1)                           -> conflict free
+//   * k-contiguous staging write (32 lanes walk k at one m): swz is a bijection of 0..31                         -> conflict free
+//   * m-contiguous staging write (lanes walk m at one k): XOR with a constant permutes the 32 banks              -> conflict free
+// (a padded stride of 17 mod 32 measured 1.5 conflict cycles per LDS instruction: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS)
+template <int BT> struct g_ld { static constexpr int v = BT; };
+__device__ __forceinline__ int g_swz(int k) { return ((k & 1) << 4) | ((k >> 1) & 15); }
+
+template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_desc d) {
+    constexpr int LDA = g_ld<BM>::v, LDB = g_ld<BN>::v;
+    constexpr int EA = (BM * G_BK) / G_THREADS, EB = (BN * G_BK) / G_THREADS;   // staged elements per thread
+    constexpr int MT = BM / 32, NT = BN / 32;                                    // 16x16 MFMA tiles per wave (2x2 wave grid)
     EEG_LDS_BASE(float, lds);
-    float* As = lds;                    // [G_BK][G_LD]
-    float* Bs = lds + G_BK * G_LD;      // [G_BK][G_LD]
+    float* As = lds;                    // [G_BK][LDA]
+    float* Bs = lds + G_BK * LDA;       // [G_BK][LDB]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
     // K slice of this workgroup (split-K along blockIdx.z)
     const int nsplit = d.split_k;
@@ -37,49 +50,54 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     if (kt_end > ktiles) kt_end = ktiles;
 
     // ---- per-thread staging coordinates -------------------------------------------------------------
-    // m-contiguous operand: lane walks m (coalesced), k = (t>>6) + 4 i.   k-contiguous: lane walks k, m = (t>>5) + 8 i.
-    int a_row[G_EPT], a_k[G_EPT];
-    long long a_off[G_EPT];
-    bool a_ok[G_EPT];
-    int b_col[G_EPT], b_k[G_EPT];
-    long long b_off[G_EPT];
-    bool b_ok[G_EPT];
+    // m-contiguous operand: lane walks m (coalesced), k = t / BM + (256/BM) i.   k-contiguous: lane walks k, m = (t>>5) + 8 i.
+    int a_row[EA], a_k[EA];
+    long long a_off[EA];
+    bool a_ok[EA];
+    int b_col[EB], b_k[EB];
+    long long b_off[EB];
+    bool b_ok[EB];
 #pragma unroll
-    for (int i = 0; i < G_EPT; ++i) {
+    for (int i = 0; i < EA; ++i) {
         if (A_KC) { a_k[i] = t & 31; a_row[i] = (t >> 5) + 8 * i; }
-        else      { a_row[i] = t & 63; a_k[i] = (t >> 6) + 4 * i; }
+        else      { a_row[i] = t % BM; a_k[i] = t / BM + (G_THREADS / BM) * i; }
         a_ok[i] = (m0 + a_row[i]) < d.M;
         a_off[i] = a_ok[i] ? dim_off(d.Am, m0 + a_row[i]) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
         if (B_KC) { b_k[i] = t & 31; b_col[i] = (t >> 5) + 8 * i; }
-        else      { b_col[i] = t & 63; b_k[i] = (t >> 6) + 4 * i; }
+        else      { b_col[i] = t % BN; b_k[i] = t / BN + (G_THREADS / BN) * i; }
         b_ok[i] = (n0 + b_col[i]) < d.N;
         b_off[i] = b_ok[i] ? dim_off(d.Bn, n0 + b_col[i]) : 0;
     }
 
-    float ra[G_EPT], rb[G_EPT];
+    float ra[EA], rb[EB];
     auto load_tile = [&](int kt) {
         const int k0 = kt * G_BK;
 #pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
+        for (int i = 0; i < EA; ++i) {
             const int ka = k0 + a_k[i];
             ra[i] = (a_ok[i] && ka < d.K) ? d.A[a_off[i] + dim_off(d.Ak, ka)] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
             const int kb = k0 + b_k[i];
             rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + dim_off(d.Bk, kb)] : 0.f;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
-            As[a_k[i] * G_LD + a_row[i]] = ra[i];
-            Bs[b_k[i] * G_LD + b_col[i]] = rb[i];
-        }
+        for (int i = 0; i < EA; ++i) As[a_k[i] * LDA + (a_row[i] ^ g_swz(a_k[i]))] = ra[i];
+#pragma unroll
+        for (int i = 0; i < EB; ++i) Bs[b_k[i] * LDB + (b_col[i] ^ g_swz(b_k[i]))] = rb[i];
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (kt_begin < kt_end) load_tile(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -90,14 +108,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
             const int kq = kk * 4 + fq;
-            const float a0 = As[kq * G_LD + wr * 32 + fr];
-            const float a1 = As[kq * G_LD + wr * 32 + 16 + fr];
-            const float b0 = Bs[kq * G_LD + wc * 32 + fr];
-            const float b1 = Bs[kq * G_LD + wc * 32 + 16 + fr];
-            acc[0][0] = mfma_f32_16x16x4(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_f32_16x16x4(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_f32_16x16x4(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_f32_16x16x4(a1, b1, acc[1][1]);
+            const int sw = g_swz(kq);
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = As[kq * LDA + ((wr * (BM / 2) + 16 * i + fr) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = Bs[kq * LDB + ((wc * (BN / 2) + 16 * j + fr) ^ sw)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -106,13 +126,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     const bool first_slice = (blockIdx.z == 0);
     const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wc * 32 + nt * 16 + (lane & 15);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wc * (BN / 2) + nt * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + mt * 16 + (lane >> 4) * 4 + r;
+                const int m = m0 + wr * (BM / 2) + mt * 16 + (lane >> 4) * 4 + r;
                 if (m >= d.M || n >= d.N) continue;
                 float v = d.alpha * acc[mt][nt][r];
                 if (first_slice) {
@@ -137,6 +157,19 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     }
 }
 
+template <int BM, int BN>
+static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
+    const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.split_k);
+    const dim3 block(G_THREADS);
+    const size_t lds = G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
+    const bool akc = (d.Ak.si == 1), bkc = (d.Bk.si == 1);
+    if (akc && bkc)        EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, true>), grid, block, lds, stream, d);
+    else if (akc && !bkc)  EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, false>), grid, block, lds, stream, d);
+    else if (!akc && bkc)  EEG_LAUNCH((gemm_f32_kernel<BM, BN, false, true>), grid, block, lds, stream, d);
+    else                   EEG_LAUNCH((gemm_f32_kernel<BM, BN, false, false>), grid, block, lds, stream, d);
+    return (int)hipGetLastError();
+}
+
 }  // namespace eeg
 
 extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
@@ -151,15 +184,18 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_SILU) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;
-    const dim3 grid((d.N + G_BN - 1) / G_BN, (d.M + G_BM - 1) / G_BM, d.split_k);
-    const dim3 block(G_THREADS);
-    const size_t lds = 2 * G_BK * G_LD * sizeof(float);
-    const bool akc = (d.Ak.si == 1), bkc = (d.Bk.si == 1);
-    if (akc && bkc)        EEG_LAUNCH((gemm_f32_kernel<true, true>), grid, block, lds, stream, d);
-    else if (akc && !bkc)  EEG_LAUNCH((gemm_f32_kernel<true, false>), grid, block, lds, stream, d);
-    else if (!akc && bkc)  EEG_LAUNCH((gemm_f32_kernel<false, true>), grid, block, lds, stream, d);
-    else                   EEG_LAUNCH((gemm_f32_kernel<false, false>), grid, block, lds, stream, d);
-    return (int)hipGetLastError();
+    // tile choice: 128x128 (4x4 MFMA tiles per wave, 4 MFMAs per LDS operand read) once the grid still fills the 256 CUs;
+    // 128x64 for narrow N; 64x64 for small problems where occupancy matters more than per-wave reuse.
+    const long long b128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.split_k;
+    const long long b12864 = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.split_k;
+    static const int force = getenv("EEGCLIP_GEMM_TILE") ? atoi(getenv("EEGCLIP_GEMM_TILE")) : 0;   // tuning aid: 64 | 12864 | 128
+    static const long long thr = getenv("EEGCLIP_GEMM_THR") ? atoll(getenv("EEGCLIP_GEMM_THR")) : 1024;
+    if (force == 128) return launch_gemm<128, 128>(d, stream);
+    if (force == 12864) return launch_gemm<128, 64>(d, stream);
+    if (force == 64) return launch_gemm<64, 64>(d, stream);
+    if (b128 >= thr && d.N > 64) return launch_gemm<128, 128>(d, stream);
+    if (b12864 >= thr && d.M > 64) return launch_gemm<128, 64>(d, stream);
+    return launch_gemm<64, 64>(d, stream);
 }
 
 extern "C" int eegclip_abi_version(void) { return EEGCLIP_ABI_VERSION; }

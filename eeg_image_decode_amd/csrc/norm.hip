@@ -46,22 +46,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-// dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ;  dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                             int cols, int accumulate_dx) {
+// backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.   One wave per row, one row per wave
+// (maximum waves in flight: the row work is tiny, the kernel is latency-bound otherwise).
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
+                                                                int accumulate_dx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
-    float pg[LN_MAXC], pb[LN_MAXC], gm[LN_MAXC];
-#pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        pg[i] = 0.f;
-        pb[i] = 0.f;
-        const int c = lane + 64 * i;
-        gm[i] = c < cols ? gamma[c] : 0.f;
-    }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (long long)row * cols;
         const float* dr = dy + (long long)row * cols;
@@ -72,13 +64,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < LN_MAXC; ++i) {
             const int c = lane + 64 * i;
             const bool ok = c < cols;
-            const float d = ok ? dr[c] : 0.f;
             xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
-            g[i] = d * gm[i];
+            g[i] = ok ? dr[c] * gamma[c] : 0.f;
             s1 += g[i];
             s2 += g[i] * xh[i];
-            pg[i] += d * xh[i];
-            pb[i] += d;
         }
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
         float* dxr = dx + (long long)row * cols;
@@ -91,20 +80,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    // block-level combine of the 4 waves' partial dgamma/dbeta through LDS, then ONE atomic per column per block
-    EEG_LDS_BASE(float, red);            // [2][4][64 * LN_MAXC] would be 32 KB; do it one 64-column stripe at a time: [2][4][64]
-#pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        if (64 * i >= cols) break;       // uniform
-        __syncthreads();
-        red[wave * 64 + lane] = pg[i];
-        red[256 + wave * 64 + lane] = pb[i];
-        __syncthreads();
-        const int c = lane + 64 * i;
-        if (wave == 0 && c < cols) {
-            atomicAdd(dgamma + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
-            atomicAdd(dbeta + c, (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
+}
+
+// backward, part 2:  dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy.   Column-parallel: block = 64 columns x 4 row groups,
+// lanes walk columns (coalesced), each thread strides over its share of the rows; LDS combine, one atomic per column per block.
+__global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
+    EEG_LDS_BASE(float, red);   // [2][4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    float pg = 0.f, pb = 0.f;
+    if (c < cols) {
+        for (int r = blockIdx.x * 4 + g; r < rows; r += gridDim.x * 4) {
+            const float d = dy[(long long)r * cols + c];
+            pg += d * (x[(long long)r * cols + c] - mean[r]) * rstd[r];
+            pb += d;
         }
+    }
+    red[g * 64 + lane] = pg;
+    red[256 + g * 64 + lane] = pb;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        atomicAdd(dgamma + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+        atomicAdd(dbeta + c, (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
     }
 }
 
@@ -256,9 +255,12 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols < 1 || cols > 64 * LN_MAXC)
         return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    const int grid = grid_for(rows, 4 * 8, 256);   // >= 8 rows per wave so the dgamma/dbeta atomics amortise
-    EEG_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), 512 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
+    EEG_LAUNCH(layernorm_bwd_dx_kernel, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols,
                accumulate_dx);
+    int chunks = (rows + 127) / 128;            // >= 32 rows per thread before the atomics
+    if (chunks > 128) chunks = 128;
+    EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
+               dbeta, rows, cols);
     return (int)hipGetLastError();
 }
 

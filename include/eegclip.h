@@ -154,13 +154,15 @@ int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int 
 /* ---- tsconv front: Conv2d(1,40,(1,25)) + AvgPool2d((1,51),(1,5)) folded into one 75-tap stride-5 filter.  ATMS_retrieval.py:102-103
  * x: token rows of T=250 floats at x + b*xs_b + h*xs_h (h < H); y/dy: (B,40,H,36).  fold: (40,25) taps -> weff (40,75).
  * fwd optionally accumulates the BatchNorm batch sums of y into sums (double[80], zeroed by the caller).
- * bwd_w: dweff += ... (atomic, zero first); unfold_grad: dw25 += fold^T(dweff).  bwd_x overwrites dx rows h < H. */
+ * bwd_w: dweff = sum over workgroup partials (deterministic two-stage reduction through `workspace`); unfold_grad: dw25 += fold^T(dweff).
+ * bwd_x overwrites dx rows h < H. */
 int eegclip_tsconv_fold(const float* w25, float* weff, void* stream);
 int eegclip_tsconv_unfold_grad(const float* dweff, float* dw25, void* stream);
 int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* weff, const float* bias, float* y, int B, int H,
                        int T, int C, double* sums, void* stream);
-int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, int B, int H, int T, int C,
-                         void* stream);
+long long eegclip_tsconv_bwd_w_workspace_floats(int B, int H);   /* size of `workspace` below (per-workgroup partial tap gradients) */
+int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, float* workspace, int B, int H,
+                         int T, int C, void* stream);
 int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* dx, long long xs_b, long long xs_h, int B, int H, int T, int C,
                          void* stream);
 

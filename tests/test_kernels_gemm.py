@@ -118,6 +118,21 @@ def test_gemm_big_tile_grid(be):
     np.testing.assert_allclose(be.host(C), ref, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(1800, 1790, 9, 0, 1), (1800, 1790, 9, 1, 0), (6200, 250, 7, 0, 1), (6200, 250, 7, 0, 0), (6200, 250, 7, 1, 1)])
+def test_gemm_large_tile_variants(be, M, N, K, ta, tb):
+    """shapes whose grids select the 128x128 / 128x64 workgroup tiles (>= 192 workgroups), ragged edges included"""
+    rng = np.random.default_rng(M + N + K + ta * 2 + tb)
+    a = f32(rng, *((K, M) if ta else (M, K)))
+    b = f32(rng, *((N, K) if tb else (K, N)))
+    bias = f32(rng, N)
+    A, B, BI, C = be.dev(a), be.dev(b), be.dev(bias), be.dev(np.full((M, N), np.nan, np.float32))
+    Am, Ak = (D(1), D(M)) if ta else (D(K), D(1))
+    Bk, Bn = (D(1), D(K)) if tb else (D(N), D(1))
+    run(be, mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), bias_n=be.ptr(BI)))
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
+    np.testing.assert_allclose(be.host(C), ref, atol=3e-5)
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0

@@ -177,7 +177,7 @@ def test_attention_fwd_bwd(be, B, H, E, p):
     np.testing.assert_allclose(be.host(DQKV), qt.grad.numpy(), atol=5e-5)
 
 
-@pytest.mark.parametrize("B,H", [(2, 63), (3, 5)])
+@pytest.mark.parametrize("B,H", [(2, 63), (3, 5), (5, 63)])
 def test_tsconv_fold_fwd_bwd(be, B, H):
     rng = np.random.default_rng(B + H)
     w25, bias = rnd(rng, 40, 25, scale=0.2), rnd(rng, 40, scale=0.1)
@@ -199,7 +199,8 @@ def test_tsconv_fold_fwd_bwd(be, B, H):
     dy = rnd(rng, B, 40, H, 36)
     yt.backward(torch.tensor(dy, dtype=torch.float64))
     DY, DWEFF, DW25 = be.dev(dy), be.zeros((40, 75)), be.dev(np.ones((40, 25), np.float32))
-    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY), be.ptr(DWEFF), B, H, 250, 40, be.stream))
+    WS = be.zeros(int(be.lib.eegclip_tsconv_bwd_w_workspace_floats(B, H)))
+    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY), be.ptr(DWEFF), be.ptr(WS), B, H, 250, 40, be.stream))
     ok(be.lib.eegclip_tsconv_unfold_grad(be.ptr(DWEFF), be.ptr(DW25), be.stream))
     np.testing.assert_allclose(be.host(DW25) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
     DX = be.dev(np.full((B, 64, 250), 7.0, np.float32))
