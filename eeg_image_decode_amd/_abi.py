@@ -54,6 +54,7 @@ PROTOTYPES = {
     "eegclip_embed_finish_bwd": [_P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_dropout_scale": [_P, _L, _F, _U64, _U, _P],
     "eegclip_gelu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],
+    "eegclip_bias_act": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_axpby": [_P, _P, _L, _F, _F, _P],
     "eegclip_reduce_mid": [_P, _I, _I, _I, _P, _P],
     "eegclip_colsum_blocks": [_P, _I, _I, _I, _I, _L, _P, _P],

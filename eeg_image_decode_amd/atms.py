@@ -351,7 +351,7 @@ class _Engine:
             h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
             f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
             weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), z1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
-            feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
+            feat=f(B, F_TS), hacc=f(2, B, P_DIM), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
             sums=torch.zeros(4, 2 * C_TS, dtype=torch.float64, device=dev), bn=f(4, C_TS),
             ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
@@ -430,11 +430,23 @@ class _Engine:
         # 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e]      (:113-114,145)
         pl.gemm(B * W_TS, C_TS, C_TS, _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS), _p(P["enc_eeg.0.projection.0.weight"]), D(1), D(C_TS),
                 _p(b["feat"]), D(C_TS, div=W_TS, so=F_TS), D(1), bias_n=_p(P["enc_eeg.0.projection.0.bias"]))
-        # A6: projection head      (:157-167)
-        pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
-                Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU)
-        pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
-                bias_n=_p(P["proj_eeg.1.fn.1.bias"]), drop_p=pp_, drop_site=SITE_PROJ, R=_p(b["u"]), Rm=D(P_DIM), Rn=D(1))
+        # A6: projection head      (:157-167).  M = B is small (256): a 4 x 16 tile grid cannot fill 256 CUs and each workgroup walks K = 1440
+        # serially, so the products are split over K (atomics into a zeroed buffer) and bias/GELU/dropout/residual run as a tiny epilogue.
+        skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
+        if skh > 1:
+            pl.memset(b["hacc"])
+            pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
+                    accumulate=1, split_k=skh)
+            pl.call("eegclip_bias_act", _p(b["hacc"][0]), _p(P["proj_eeg.0.bias"]), _p(b["u"]), None, _p(b["gu"]), B, P_DIM, ACT_GELU, 0.0, 0, 0)
+            pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["hacc"][1]), D(P_DIM), D(1),
+                    accumulate=1, split_k=skh)
+            pl.call("eegclip_bias_act", _p(b["hacc"][1]), _p(P["proj_eeg.1.fn.1.bias"]), None, _p(b["u"]), _p(b["s"]), B, P_DIM, 0, pp_, 0, SITE_PROJ,
+                    seed_at=9)
+        else:
+            pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
+                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU)
+            pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), drop_p=pp_, drop_site=SITE_PROJ, R=_p(b["u"]), Rm=D(P_DIM), Rn=D(1))
         pl.call("eegclip_layernorm_fwd", _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(P["proj_eeg.2.bias"]), _p(b["out"]), _p(b["mu4"]),
                 _p(b["rs4"]), B, P_DIM, EPS)
         return pl
@@ -465,11 +477,17 @@ class _Engine:
             pl.call("eegclip_dropout_scale", _p(b["dv"]), B * P_DIM, pp_, 0, SITE_PROJ, seed_at=3)
         bgrad("proj_eeg.1.fn.1.bias", _p(b["dv"]), B, P_DIM)
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B)
-        pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1))
+        skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
+        if skh > 1:
+            pl.memset(b["dgu"])
+            pl.memset(b["dfeat"])
+        pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
+                accumulate=int(skh > 1), split_k=skh)
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
         bgrad("proj_eeg.0.bias", _p(b["ds"]), B, P_DIM)
         wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B)
-        pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1))
+        pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
+                accumulate=int(skh > 1), split_k=skh)
         # 1x1 conv: dfeat is [(b,w)][e]
         bgrad("enc_eeg.0.projection.0.bias", _p(b["dfeat"]), B * W_TS, C_TS)
         pl.gemm(C_TS, C_TS, B * W_TS, _p(b["dfeat"]), D(1), D(C_TS), _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS),

@@ -46,13 +46,21 @@ constexpr int TS_CP = 48;     // filters padded to 3 MFMA tiles
 constexpr int TS_UP = 80;     // taps padded to 5 MFMA tiles (bwd) ; fwd uses 76 = 19 k-steps
 constexpr int TS_XS = 256;    // staged token-row stride (250 samples + zero pad: windows may read up to index 254)
 
+// one token row per pass, lanes walk the 250 samples (coalesced); (b, h) of a row is wave-uniform scalar math, no per-element division
+// Loads are issued in batches of 8 independent rows BEFORE any is consumed: with one workgroup per CU a load->LDS-store chain per
+// row would pay the full HBM latency (~1 us) per row (measured: 32 serialized rows = half of the forward kernel's time).
 __device__ __forceinline__ void stage_x_rows(float* xl, const float* x, long long xs_b, long long xs_h, int row0, int nrows, int rows, int H) {
-    for (int i = threadIdx.x; i < nrows * TS_XS; i += blockDim.x) {
-        const int rl = i / TS_XS, tt = i % TS_XS;
-        const int row = row0 + rl;
-        float v = 0.f;
-        if (row < rows && tt < TS_T) v = x[(row / H) * xs_b + (row % H) * xs_h + tt];
-        xl[i] = v;
+    const int t = threadIdx.x;            // blockDim.x == TS_XS == 256
+    for (int r0 = 0; r0 < nrows; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + r0 + j;
+            v[j] = (r0 + j < nrows && row < rows && t < TS_T) ? x[(row / H) * xs_b + (row % H) * xs_h + t] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (r0 + j < nrows) xl[(r0 + j) * TS_XS + t] = v[j];
     }
 }
 
@@ -165,9 +173,19 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
         const int mc = nr * TS_W;                 // positions in this slab (multiple of 4)
         __syncthreads();
         stage_x_rows(xl, x, xs_b, xs_h, b * H + h0, TSW_R, b * H + h0 + nr, H);
-        for (int i = t; i < TS_C * mc; i += blockDim.x) {
-            const int c = i / mc, m = i % mc;    // (h, w) is contiguous in dy for a fixed (b, c)
-            dl[c * TSW_MS + m] = dy[(((long long)b * TS_C + c) * H + h0) * TS_W + m];
+        {                                         // (h, w) is contiguous in dy for a fixed (b, c): lanes walk it, 8 filters in flight per batch
+            const float* src = dy + (((long long)b * TS_C) * H + h0) * TS_W;
+            const long long cs = (long long)H * TS_W;
+            for (int m = t; m < mc; m += blockDim.x) {
+#pragma unroll
+                for (int c0 = 0; c0 < TS_C; c0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = src[(c0 + j) * cs + m];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dl[(c0 + j) * TSW_MS + m] = v[j];
+                }
+            }
         }
         __syncthreads();
         for (int ks = wv; ks < mc / 4; ks += 4) {
@@ -198,13 +216,14 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
     for (int i = t; i < TS_C * TS_U; i += blockDim.x) out[i] = red[(i / TS_U) * TS_UP + (i % TS_U)];
 }
 
-// dweff[i] = sum over blocks of partials[blk][i]
+// dweff[i] += sum over a slice of the workgroup partials (grid.y slices; dweff zeroed by the launcher): 3000 x 16 threads keep
+// enough loads in flight -- a single thread walking 512 partials is pure memory latency
 __global__ void tsconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ dweff) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= TS_C * TS_U) return;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partials[(long long)k * (TS_C * TS_U) + i];
-    dweff[i] = s;
+    for (int k = blockIdx.y; k < nblk; k += gridDim.y) s += partials[(long long)k * (TS_C * TS_U) + i];
+    atomicAdd(dweff + i, s);
 }
 
 // ---- backward w.r.t. the token rows ------------------------------------------------------------------------------------
@@ -227,13 +246,21 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int row0 = item * TSX_R;
         __syncthreads();
-        for (int i = t; i < TSX_R * TS_C * TS_W; i += blockDim.x) {
-            const int rl = i / (TS_C * TS_W), rem = i % (TS_C * TS_W);
-            const int c = rem / TS_W, w = rem % TS_W;
+        for (int rl = 0; rl < TSX_R; ++rl) {       // 6 independent loads per thread per row are issued before the LDS stores
             const int row = row0 + rl;
-            float v = 0.f;
-            if (row < rows) v = dy[(((long long)(row / H) * TS_C + c) * H + (row % H)) * TS_W + w];
-            dl[c * TSX_MS + rl * TS_W + w] = v;
+            const bool ok = row < rows;
+            const float* src = dy + ((long long)(ok ? row / H : 0) * TS_C * H + (ok ? row % H : 0)) * TS_W;
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int i = t + 256 * j;
+                v[j] = (ok && i < TS_C * TS_W) ? src[(long long)(i / TS_W) * H * TS_W + (i % TS_W)] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int i = t + 256 * j;
+                if (i < TS_C * TS_W) dl[(i / TS_W) * TSX_MS + rl * TS_W + (i % TS_W)] = v[j];
+            }
         }
         for (int i = t; i < TSX_R * TS_XS; i += blockDim.x) xo[i] = 0.f;
         __syncthreads();
@@ -259,10 +286,9 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
             }
         }
         __syncthreads();
-        for (int i = t; i < TSX_R * TS_T; i += blockDim.x) {
-            const int rl = i / TS_T, tt = i % TS_T;
+        for (int rl = 0; rl < TSX_R; ++rl) {
             const int row = row0 + rl;
-            if (row < rows) dx[(row / H) * xs_b + (row % H) * xs_h + tt] = xo[rl * TS_XS + tt];
+            if (row < rows && t < TS_T) dx[(row / H) * xs_b + (row % H) * xs_h + t] = xo[rl * TS_XS + t];
         }
     }
 }
@@ -311,7 +337,8 @@ extern "C" int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs
     const int grid = tsw_grid(B, H);
     const size_t lds = (TS_CP * TSW_MS + TSW_R * TS_XS + TS_CP * TS_UP) * sizeof(float);
     EEG_LAUNCH(tsconv_bwd_w_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, dy, workspace, B, H);
-    EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_U + 255) / 256), dim3(256), 0, stream, workspace, grid, dweff);
+    hipMemsetAsync(dweff, 0, TS_C * TS_U * sizeof(float), (hipStream_t)stream);
+    EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_U + 255) / 256, grid < 32 ? grid : 32), dim3(256), 0, stream, workspace, grid, dweff);
     return (int)hipGetLastError();
 }
 

@@ -74,6 +74,24 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     }
 }
 
+// epilogue of a split-K GEMM whose raw product sits in `acc` (M, N) row-major:
+//   v = acc + bias_n ; pre = v (optional) ; v = act(v) ; v = dropout(v) ; v += resid ; out = v       (same order as the fused GEMM epilogue)
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ acc, const float* __restrict__ bias_n, float* __restrict__ pre,
+                                                        const float* __restrict__ resid, float* __restrict__ out, long long n, int N, int act,
+                                                        float drop_p, unsigned long long seed, unsigned site) {
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = acc[i];
+        if (bias_n) v += bias_n[i % N];
+        if (pre) pre[i] = v;
+        if (act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
+        else if (act == EEGCLIP_ACT_SILU) v = silu(v);
+        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+        if (resid) v += resid[i];
+        out[i] = v;
+    }
+}
+
 // y = a*x + b*y
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a,
                                                      float b) {
@@ -209,6 +227,14 @@ extern "C" int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, lo
     if (!dy || !pre || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (n == 0) return 0;
     EEG_LAUNCH(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, dy, pre, dx, n, accumulate, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bias_act(const float* acc, const float* bias_n, float* pre, const float* resid, float* out, int M, int N, int act,
+                                float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!acc || !out || M < 1 || N < 1 || act < 0 || act > EEGCLIP_ACT_SILU || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    const long long n = (long long)M * N;
+    EEG_LAUNCH(bias_act_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, acc, bias_n, pre, resid, out, n, N, act, drop_p, seed, site);
     return (int)hipGetLastError();
 }
 

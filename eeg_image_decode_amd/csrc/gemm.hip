@@ -4,10 +4,10 @@
 //
 // Tiling (CDNA4): BM x BN output tile (128x128, 128x64 or 64x64, chosen per problem so the grid still fills 256 CUs) per
 // 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning (BM/2)x(BN/2) as (BM/32)x(BN/32) MFMA 16x16
-// accumulators; BK = 32.  Both operand tiles are staged k-major in LDS (As[k][m], Bs[k][n], row stride BM+17 floats):
+// accumulators; BK = 32.  Both operand tiles are staged k-major in LDS (As[k][m ^ swz(k)], Bs[k][n ^ swz(k)], see g_swz):
 // the MFMA operand read "lane l -> (row l&15, k l>>4)" is then a ds_read_b32 of 16 consecutive floats per 16-lane group,
 // and stride = 17 (mod 32) keeps both that read and the k-contiguous staging write (lanes walk k) off each other's banks.  Global->register prefetch of tile t+1
-// overlaps the MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
+// overlaps the MFMAs of tile t; LDS is double-buffered (one barrier per k-tile).  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
 // aligned: every load and store is guarded, padding lives only in LDS (zeros), never in HBM.
 #include "eeg_common.h"
 
@@ -33,8 +33,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     constexpr int EA = (BM * G_BK) / G_THREADS, EB = (BN * G_BK) / G_THREADS;   // staged elements per thread
     constexpr int MT = BM / 32, NT = BN / 32;                                    // 16x16 MFMA tiles per wave (2x2 wave grid)
     EEG_LDS_BASE(float, lds);
-    float* As = lds;                    // [G_BK][LDA]
-    float* Bs = lds + G_BK * LDA;       // [G_BK][LDB]
+    constexpr int STAGE = G_BK * (LDA + LDB);       // one (A,B) tile pair; two stages are double-buffered: ONE barrier per k-tile
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -86,7 +85,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
             rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + dim_off(d.Bk, kb)] : 0.f;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
+        float* As = lds + stage * STAGE;
+        float* Bs = As + G_BK * LDA;
 #pragma unroll
         for (int i = 0; i < EA; ++i) As[a_k[i] * LDA + (a_row[i] ^ g_swz(a_k[i]))] = ra[i];
 #pragma unroll
@@ -99,11 +100,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (kt_begin < kt_end) load_tile(kt_begin);
+    int cur = 0;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);     // prefetch into registers under the MFMAs
+        if (kt + 1 < kt_end) load_tile(kt + 1);     // global -> registers, in flight under the MFMAs of tile kt
+        const float* As = lds + cur * STAGE;
+        const float* Bs = As + G_BK * LDA;
         const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
@@ -119,7 +125,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);
         }
+        // the other stage was last read during tile kt-1 and every wave has passed the barrier that ended it: safe to overwrite now
+        if (kt + 1 < kt_end) store_tile(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] ------------------------------------------
@@ -161,7 +170,7 @@ template <int BM, int BN>
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.split_k);
     const dim3 block(G_THREADS);
-    const size_t lds = G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
+    const size_t lds = 2 * G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
     const bool akc = (d.Ak.si == 1), bkc = (d.Bk.si == 1);
     if (akc && bkc)        EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, true>), grid, block, lds, stream, d);
     else if (akc && !bkc)  EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, false>), grid, block, lds, stream, d);
@@ -189,7 +198,7 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     const long long b128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.split_k;
     const long long b12864 = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.split_k;
     static const int force = getenv("EEGCLIP_GEMM_TILE") ? atoi(getenv("EEGCLIP_GEMM_TILE")) : 0;   // tuning aid: 64 | 12864 | 128
-    static const long long thr = getenv("EEGCLIP_GEMM_THR") ? atoll(getenv("EEGCLIP_GEMM_THR")) : 1024;
+    static const long long thr = getenv("EEGCLIP_GEMM_THR") ? atoll(getenv("EEGCLIP_GEMM_THR")) : (1LL << 40);   // measured on MI355X: the 64x64 tile wins on every shape of this path (occupancy > reuse)
     if (force == 128) return launch_gemm<128, 128>(d, stream);
     if (force == 12864) return launch_gemm<128, 64>(d, stream);
     if (force == 64) return launch_gemm<64, 64>(d, stream);

@@ -117,6 +117,10 @@ int eegclip_embed_finish_bwd(float* dh, float* dtokens, const long long* ids, in
 int eegclip_dropout_scale(float* x, long long n, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
                      unsigned long long seed, unsigned int site, void* stream);        /* dx (+)= dy*mask/(1-p)*gelu'(pre) */
+/* epilogue for a split-K GEMM product `acc` (M,N): out = dropout(act(acc + bias_n))[+ resid], pre = acc + bias_n (optional) -- the
+ * same stage order and the same Philox element index (m*N+n) as the fused GEMM epilogue, so the two forms are interchangeable */
+int eegclip_bias_act(const float* acc, const float* bias_n, float* pre, const float* resid, float* out, int M, int N, int act, float drop_p,
+                     unsigned long long seed, unsigned int site, void* stream);
 int eegclip_axpby(const float* x, float* y, long long n, float a, float b, void* stream); /* y = a*x + b*y */
 int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out, void* stream); /* out[m] += sum_{o,i} x[o][m][i] */
 /* out[c] += sum over blocks and rows r in [row0, blk_rows) of x[blk*blk_stride + r*cols + c] */
