@@ -7,7 +7,7 @@
 // accumulators; BK = 32.  Both operand tiles are staged k-major in LDS (As[k][m ^ swz(k)], Bs[k][n ^ swz(k)], see g_swz):
 // the MFMA operand read "lane l -> (row l&15, k l>>4)" is then a ds_read_b32 of 16 consecutive floats per 16-lane group,
 // and stride = 17 (mod 32) keeps both that read and the k-contiguous staging write (lanes walk k) off each other's banks.  Global->register prefetch of tile t+1
-// overlaps the MFMAs of tile t; LDS is double-buffered (one barrier per k-tile).  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
+// overlaps the MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
 // aligned: every load and store is guarded, padding lives only in LDS (zeros), never in HBM.
 #include "eeg_common.h"
 
@@ -27,13 +27,25 @@ constexpr int G_THREADS = 256;
 template <int BT> struct g_ld { static constexpr int v = BT; };
 __device__ __forceinline__ int g_swz(int k) { return ((k & 1) << 4) | ((k >> 1) & 15); }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+// PLAIN = every index map is a plain stride (div = 2^62): offsets are one multiply, and the integer-division path of the two-level
+// maps is not even instantiated (it was >1000 instructions of the unrolled staging/epilogue code)
+template <bool PLAIN>
+__device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
+    if (PLAIN) return (long long)i * d.si;
+    return dim_off(d, i);
+}
+__device__ __forceinline__ bool gemm_dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
+    return dropout_keep(seed, site, idx, p);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool PLAIN>
 __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_desc d) {
     constexpr int LDA = g_ld<BM>::v, LDB = g_ld<BN>::v;
     constexpr int EA = (BM * G_BK) / G_THREADS, EB = (BN * G_BK) / G_THREADS;   // staged elements per thread
     constexpr int MT = BM / 32, NT = BN / 32;                                    // 16x16 MFMA tiles per wave (2x2 wave grid)
     EEG_LDS_BASE(float, lds);
-    constexpr int STAGE = G_BK * (LDA + LDB);       // one (A,B) tile pair; two stages are double-buffered: ONE barrier per k-tile
+    float* As = lds;                    // [G_BK][LDA]
+    float* Bs = lds + G_BK * LDA;       // [G_BK][LDB]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -61,14 +73,14 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
         if (A_KC) { a_k[i] = t & 31; a_row[i] = (t >> 5) + 8 * i; }
         else      { a_row[i] = t % BM; a_k[i] = t / BM + (G_THREADS / BM) * i; }
         a_ok[i] = (m0 + a_row[i]) < d.M;
-        a_off[i] = a_ok[i] ? dim_off(d.Am, m0 + a_row[i]) : 0;
+        a_off[i] = a_ok[i] ? goff<PLAIN>(d.Am, m0 + a_row[i]) : 0;
     }
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
         if (B_KC) { b_k[i] = t & 31; b_col[i] = (t >> 5) + 8 * i; }
         else      { b_col[i] = t % BN; b_k[i] = t / BN + (G_THREADS / BN) * i; }
         b_ok[i] = (n0 + b_col[i]) < d.N;
-        b_off[i] = b_ok[i] ? dim_off(d.Bn, n0 + b_col[i]) : 0;
+        b_off[i] = b_ok[i] ? goff<PLAIN>(d.Bn, n0 + b_col[i]) : 0;
     }
 
     float ra[EA], rb[EB];
@@ -77,17 +89,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
         for (int i = 0; i < EA; ++i) {
             const int ka = k0 + a_k[i];
-            ra[i] = (a_ok[i] && ka < d.K) ? d.A[a_off[i] + dim_off(d.Ak, ka)] : 0.f;
+            ra[i] = (a_ok[i] && ka < d.K) ? d.A[a_off[i] + goff<PLAIN>(d.Ak, ka)] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
             const int kb = k0 + b_k[i];
-            rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + dim_off(d.Bk, kb)] : 0.f;
+            rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + goff<PLAIN>(d.Bk, kb)] : 0.f;
         }
     };
-    auto store_tile = [&](int stage) {
-        float* As = lds + stage * STAGE;
-        float* Bs = As + G_BK * LDA;
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < EA; ++i) As[a_k[i] * LDA + (a_row[i] ^ g_swz(a_k[i]))] = ra[i];
 #pragma unroll
@@ -100,16 +110,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int cur = 0;
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
+    // (a double-buffered LDS variant with one barrier per k-tile measured 10-25 % SLOWER on MI355X: the second stage halves the
+    //  workgroups per CU and occupancy, not barrier count, is what hides latency for these short-K problems)
+    if (kt_begin < kt_end) load_tile(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);     // global -> registers, in flight under the MFMAs of tile kt
-        const float* As = lds + cur * STAGE;
-        const float* Bs = As + G_BK * LDA;
         const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
@@ -125,10 +132,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);
         }
-        // the other stage was last read during tile kt-1 and every wave has passed the barrier that ended it: safe to overwrite now
-        if (kt + 1 < kt_end) store_tile(cur ^ 1);
         __syncthreads();
-        cur ^= 1;
     }
 
     // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] ------------------------------------------
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
                     if (d.bias_n) v += d.bias_n[n];
                     if (d.bias_m) v += d.bias_m[m];
                 }
-                const long long coff = dim_off(d.Cm, m) + dim_off(d.Cn, n);
+                const long long coff = goff<PLAIN>(d.Cm, m) + goff<PLAIN>(d.Cn, n);
                 if (nsplit > 1) {
                     atomicAdd(d.C + coff, v);
                     continue;
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
                 if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
                 else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
                 if (d.drop_p > 0.f)
-                    v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
-                if (d.R) v += d.R[dim_off(d.Rm, m) + dim_off(d.Rn, n)];
+                    v = gemm_dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
+                if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
                 if (d.accumulate) v += d.C[coff];
                 d.C[coff] = v;
             }
@@ -170,12 +174,21 @@ template <int BM, int BN>
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.split_k);
     const dim3 block(G_THREADS);
-    const size_t lds = 2 * G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
+    const size_t lds = G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
     const bool akc = (d.Ak.si == 1), bkc = (d.Bk.si == 1);
-    if (akc && bkc)        EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, true>), grid, block, lds, stream, d);
-    else if (akc && !bkc)  EEG_LAUNCH((gemm_f32_kernel<BM, BN, true, false>), grid, block, lds, stream, d);
-    else if (!akc && bkc)  EEG_LAUNCH((gemm_f32_kernel<BM, BN, false, true>), grid, block, lds, stream, d);
-    else                   EEG_LAUNCH((gemm_f32_kernel<BM, BN, false, false>), grid, block, lds, stream, d);
+    const long long big = 1LL << 40;
+    const bool plain = d.Am.div > big && d.Ak.div > big && d.Bk.div > big && d.Bn.div > big && d.Cm.div > big && d.Cn.div > big &&
+                       (!d.R || (d.Rm.div > big && d.Rn.div > big));
+#define EEG_GEMM_GO(AK, BK_)                                                                                         \
+    do {                                                                                                             \
+        if (plain) EEG_LAUNCH((gemm_f32_kernel<BM, BN, AK, BK_, true>), grid, block, lds, stream, d);               \
+        else       EEG_LAUNCH((gemm_f32_kernel<BM, BN, AK, BK_, false>), grid, block, lds, stream, d);              \
+    } while (0)
+    if (akc && bkc)        EEG_GEMM_GO(true, true);
+    else if (akc && !bkc)  EEG_GEMM_GO(true, false);
+    else if (!akc && bkc)  EEG_GEMM_GO(false, true);
+    else                   EEG_GEMM_GO(false, false);
+#undef EEG_GEMM_GO
     return (int)hipGetLastError();
 }
 
