@@ -350,7 +350,7 @@ class _Engine:
         b = dict(
             h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
             f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
-            weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), z1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
+            weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
             feat=f(B, F_TS), hacc=f(2, B, P_DIM), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
             sums=torch.zeros(4, 2 * C_TS, dtype=torch.float64, device=dev), bn=f(4, C_TS),
             ids=torch.zeros(B, dtype=torch.long, device=dev),
@@ -365,7 +365,7 @@ class _Engine:
 
         R = B * L_TOK
         b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dgu=f(B, P_DIM), dfeat=f(B, F_TS), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
-                 dz1=f(B, C_TS, N_CH, W_TS), dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75), dn3=f(B, L_TOK, D_MODEL),
+                 dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75), dn3=f(B, L_TOK, D_MODEL),
                  dn2=f(R, D_MODEL), dr2=f(R, D_MODEL), df2=f(R, D_MODEL), dg1=f(R, D_FF), dr1=f(R, D_MODEL), da1=f(R, D_MODEL),
                  dctx=f(R, HE), dqkv=f(R, 3 * HE))
 
@@ -412,15 +412,10 @@ class _Engine:
             pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
         pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
                 _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train))
-        pl.call("eegclip_bn_elu_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(b["z1"]), B, C_TS,
-                N_CH * W_TS, 0.0, 0, 0)
-        # spatial (63x1) conv as ONE GEMM over the (B,40,63,36) view: M = out ch, N = (b,w), K = (c,h)      (:106)
-        KS = C_TS * N_CH
-        pl.memset(b["y2"])
-        pl.gemm(C_TS, B * W_TS, KS, _p(P[_TS + "4.weight"]), D(KS), D(1), _p(b["z1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS),
-                _p(b["y2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), bias_m=_p(P[_TS + "4.bias"]), split_k=4)
-        if train:
-            pl.call("eegclip_bn_stats", _p(b["y2"]), B, C_TS, W_TS, _p(sums[1]))
+        # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
+        # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
+        pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
+                _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH)
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
@@ -498,16 +493,25 @@ class _Engine:
         pl.memset(sums)
         W = self._world()
         self._bn_bwd(pl, W, b["dz2"], b["y2"], bn[2], bn[3], _TS + "5.", sums[2], b["dy2"], B, W_TS, pc_, SITE_CONV)
-        # spatial conv backward
-        KS = C_TS * N_CH
-        # d(conv bias) in front of a train-mode BatchNorm is identically zero (sum_x dy = 0 by the BN backward formula): the
-        # gradient tensors of tsconv.0.bias / tsconv.4.bias stay at the zero the flat buffer was cleared to.
-        pl.gemm(C_TS, KS, B * W_TS, _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS), _p(b["z1"]), D(1, div=W_TS, so=KS * W_TS), D(W_TS),
-                _p(G[_TS + "4.weight"]), D(KS), D(1), accumulate=1, split_k=sk(B * W_TS * 2))
-        pl.gemm(KS, B * W_TS, C_TS, _p(P[_TS + "4.weight"]), D(1), D(KS), _p(b["dy2"]), D(W_TS), D(1, div=W_TS, so=C_TS * W_TS),
-                _p(b["dz1"]), D(W_TS), D(1, div=W_TS, so=KS * W_TS))
-        # BN1 + ELU backward, then the fused conv+pool backward
-        self._bn_bwd(pl, W, b["dz1"], b["y1"], bn[0], bn[1], _TS + "2.", sums[3], b["dy1"], B, N_CH * W_TS, 0.0, 0)
+        # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
+        # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
+        # (d(conv bias) in front of a train-mode BatchNorm is identically zero: tsconv.0.bias / tsconv.4.bias keep the cleared zero.)
+        if "scw_ws" not in b:
+            b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+        bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
+        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH)
+        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]), B, N_CH)
+        local1 = None
+        if W > 1:
+            local1 = torch.zeros_like(sums[3])
+            pl._keep.append(local1)
+
+            def exchange1():
+                local1.copy_(sums[3])
+                self._allreduce(sums[3])
+            pl.callback(exchange1, "allreduce_bn1_bwd")
+        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]), _p(local1) if local1 is not None else None,
+                float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
         if "tsw_ws" not in b:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS)

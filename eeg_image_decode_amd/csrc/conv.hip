@@ -40,7 +40,7 @@ __global__ void tsconv_unfold_grad_kernel(const float* __restrict__ dweff, float
 // index m = (row, w), row = (b, h), X[m][u] = x[row][5w + u] read straight from the token rows staged in LDS:
 //   fwd   : Y^T[c][m]   = sum_u  weff[c][u] * X[m][u]         (M = 40->48 filters, N = positions, K = 75->76 taps)
 //   bwd_w : dW[c][u]    = sum_m  dy[c][m]   * X[m][u]         (15 accumulator tiles live across the whole reduction)
-//   bwd_x : T[m][u]     = sum_c  dy[c][m]   * weff[c][u]      then overlap-add dx[row][5w + u] += T[m][u] in LDS (ds_add_f32)
+//   bwd_x : dX[row][s]  = sum_{w,c} dy[row][c][w] * weff[c][s-5w]   (M = 16 EEG rows, N = samples, K = banded (w,c): see the kernel)
 // Channel-major accumulators in fwd (rows = filters, cols = 16 consecutive positions) make every store a 64-byte run of y.
 constexpr int TS_CP = 48;     // filters padded to 3 MFMA tiles
 constexpr int TS_UP = 80;     // taps padded to 5 MFMA tiles (bwd) ; fwd uses 76 = 19 k-steps
@@ -227,68 +227,84 @@ __global__ void tsconv_bwd_w_reduce_kernel(const float* __restrict__ partials, i
 }
 
 // ---- backward w.r.t. the token rows ------------------------------------------------------------------------------------
-constexpr int TSX_R = 8;                        // rows per work item: 288 positions = 18 tiles
-constexpr int TSX_MS = TSX_R * TS_W + 16;       // 304 = 16 (mod 32)
+// dx[row][s] = sum_{c,w} dy[row][c][w] * weff[c][s - 5w]  as a GEMM whose M dimension is 16 different EEG rows, N = s and
+// K = (w, c) restricted, per 16-wide s tile, to the <= 19 output positions w whose 75-tap window touches the tile (202 of the
+// 16 x 36 (tile, w) pairs).  The overlap-add of the transposed convolution happens INSIDE the MFMA accumulation -- a first
+// version that scattered per-position tiles with ds_add_f32 was LDS-atomic bound (SQ_LDS_IDX_ACTIVE 136 M cycles, 277 us).
+// B operand = Toeplitz view of the taps: lane (s, c) reads weff[c][s - 5w] (zero outside 0..74) straight from LDS.
+constexpr int TSX_R = 16;                       // EEG rows per work item = MFMA M
+constexpr int TSX_WS = 17;                      // floats per (c, w) cell: 16 rows + 1 pad -> conflict-free staging writes
+constexpr int TSX_CS = 624;                     // floats per channel: 36*17 = 612 padded to 16 (mod 32) for the operand reads
+constexpr int TSX_CH = 20;                      // channels per LDS pass (two passes: keeps 2 workgroups per CU)
 __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
                                                             float* __restrict__ dx, long long xs_b, long long xs_h, int B, int H) {
     EEG_LDS_BASE(float, lds);
     float* wl = lds;                             // [40][80]  filter-major taps (cols >= 75 zero)
-    float* dl = wl + TS_C * TS_UP;               // [40][TSX_MS] dy slab
-    float* xo = dl + TS_C * TSX_MS;              // [8][256]  overlap-add target
+    float* dl = wl + TS_C * TS_UP;               // [20][TSX_CS]  dy slab: dl[c][w][row]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
-    for (int i = t; i < TS_C * TS_UP; i += blockDim.x) {
-        const int c = i / TS_UP, u = i % TS_UP;
-        wl[i] = u < TS_U ? weff[c * TS_U + u] : 0.f;
+    {
+        float v[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) { const int i = t + 256 * j; v[j] = (i < TS_C * TS_UP && i % TS_UP < TS_U) ? weff[(i / TS_UP) * TS_U + i % TS_UP] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) { const int i = t + 256 * j; if (i < TS_C * TS_UP) wl[i] = v[j]; }
     }
     const int nitems = (rows + TSX_R - 1) / TSX_R;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int row0 = item * TSX_R;
-        __syncthreads();
-        for (int rl = 0; rl < TSX_R; ++rl) {       // 6 independent loads per thread per row are issued before the LDS stores
-            const int row = row0 + rl;
-            const bool ok = row < rows;
-            const float* src = dy + ((long long)(ok ? row / H : 0) * TS_C * H + (ok ? row % H : 0)) * TS_W;
-            float v[6];
+        f32x4 acc[4];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int i = t + 256 * j;
-                v[j] = (ok && i < TS_C * TS_W) ? src[(long long)(i / TS_W) * H * TS_W + (i % TS_W)] : 0.f;
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int half = 0; half < TS_C / TSX_CH; ++half) {
+            const int cbase = half * TSX_CH;
+            __syncthreads();                      // previous slab fully consumed (also orders the tap staging)
+            // stage dy[row][cbase..+19][0..35] -> dl[c][w][row]: per row 720 contiguous-by-36 floats; 2 rows x 3 loads in flight per batch
+            for (int rl0 = 0; rl0 < TSX_R; rl0 += 2) {
+                float v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int rl = rl0 + j / 3, i = t + 256 * (j % 3), row = row0 + rl;
+                    const bool ok = row < rows && i < TSX_CH * TS_W;
+                    v[j] = ok ? dy[(((long long)(row / H) * TS_C + cbase + i / TS_W) * H + (row % H)) * TS_W + i % TS_W] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int rl = rl0 + j / 3, i = t + 256 * (j % 3);
+                    if (i < TSX_CH * TS_W) dl[(i / TS_W) * TSX_CS + (i % TS_W) * TSX_WS + rl] = v[j];
+                }
             }
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int i = t + 256 * j;
-                if (i < TS_C * TS_W) dl[(i / TS_W) * TSX_MS + rl * TS_W + (i % TS_W)] = v[j];
+            for (int q = 0; q < 4; ++q) {
+                const int j = wv + 4 * q;                         // s tile: s = 16j .. 16j+15
+                int w_lo = (16 * j - (TS_U - 1) + 4) / 5;         // ceil((16j - 74) / 5) for the positive case
+                if (16 * j - (TS_U - 1) <= 0) w_lo = 0;
+                int w_hi = (16 * j + 15) / 5;
+                if (w_hi > TS_W - 1) w_hi = TS_W - 1;
+                const int s = 16 * j + fr;
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const int u = s - 5 * w;
+                    const bool inb = u >= 0 && u < TS_U;
+#pragma unroll
+                    for (int cc = 0; cc < TSX_CH / 4; ++cc) {
+                        const int cl = 4 * cc + g;
+                        const float a = dl[cl * TSX_CS + w * TSX_WS + fr];                     // A[row = fr][k = (w, c)]
+                        const float bq = inb ? wl[(cbase + cl) * TS_UP + u] : 0.f;             // B[k][s] = weff[c][s - 5w]
+                        acc[q] = mfma_f32_16x16x4(a, bq, acc[q]);                               // D[row = 4g + r][s = 16j + fr]
+                    }
+                }
             }
         }
-        for (int i = t; i < TSX_R * TS_XS; i += blockDim.x) xo[i] = 0.f;
-        __syncthreads();
-        for (int mt = wv; mt < TSX_R * TS_W / 16; mt += 4) {
-            f32x4 acc[5];
 #pragma unroll
-            for (int ut = 0; ut < 5; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < TS_C / 4; ++kk) {
-                const int c = 4 * kk + g;
-                const float a = dl[c * TSX_MS + 16 * mt + fr];                     // A[m = 16mt+fr][k = c]
-                const float* wp = wl + c * TS_UP + fr;
-#pragma unroll
-                for (int ut = 0; ut < 5; ++ut) acc[ut] = mfma_f32_16x16x4(a, wp[16 * ut], acc[ut]);   // D[m = 16mt+4g+r][u = 16ut+fr]
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int s = 16 * (wv + 4 * q) + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = 16 * mt + 4 * g + r;
-                float* xr = xo + (m / TS_W) * TS_XS + 5 * (m % TS_W) + fr;
-#pragma unroll
-                for (int ut = 0; ut < 5; ++ut)
-                    if (16 * ut + fr < TS_U) atomicAdd(xr + 16 * ut, acc[ut][r]);  // LDS overlap-add (ds_add_f32)
+                const int row = row0 + 4 * g + r;
+                if (row < rows && s < TS_T) dx[(row / H) * xs_b + (row % H) * xs_h + s] = acc[q][r];
             }
-        }
-        __syncthreads();
-        for (int rl = 0; rl < TSX_R; ++rl) {
-            const int row = row0 + rl;
-            if (row < rows && t < TS_T) dx[(row / H) * xs_b + (row % H) * xs_h + t] = xo[rl * TS_XS + t];
         }
     }
 }
@@ -348,7 +364,7 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* d
     if (!dy || !weff || !dx) return EEGCLIP_EINVAL;
     const int items = (B * H + TSX_R - 1) / TSX_R;
     int grid = items < 1024 ? items : 1024;
-    const size_t lds = (TS_C * TS_UP + TS_C * TSX_MS + TSX_R * TS_XS) * sizeof(float);
+    const size_t lds = (TS_C * TS_UP + TSX_CH * TSX_CS) * sizeof(float);
     EEG_LAUNCH(tsconv_bwd_x_kernel, dim3(grid), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);
     return (int)hipGetLastError();
 }

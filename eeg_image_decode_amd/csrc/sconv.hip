@@ -1,0 +1,347 @@
+// The spatial stage of tsconv, fused around the only HBM-heavy tensor of the network, y1 = conv+pool output (B,40,H=63,36) fp32
+// (93 MB at B=256):      BatchNorm2d(40) -> ELU -> Conv2d(40,40,(63,1))        (Retrieval/ATMS_retrieval.py:104-106)
+//
+// The reference materialises BN(y1), ELU(.) and their gradients (5 more tensors of that size per direction).  Here y1 is the ONLY
+// big tensor that exists: z1 = ELU(BN(y1)) is re-evaluated inside the operand staging of every kernel that needs it, and the
+// gradient w.r.t. z1 (a K=40 contraction) is recomputed on the matrix cores instead of being written and re-read:
+//   sconv_fwd          y2[b,o,w]   = bs[o] + sum_{c,h} Ws[o,c,h] * z1[b,c,h,w]          reads y1 once, (+ BN2 batch sums)
+//   sconv_bwd_w        dWs[o,c,h] += sum_{b,w} dy2[b,o,w] * z1[b,c,h,w]                  reads y1 once
+//   sconv_bwd_x<false> BN1 backward sums of da = (Ws^T dy2) * ELU'(BN(y1))               reads y1 once
+//   sconv_bwd_x<true>  dy1 = BN1 backward(da)                                            reads y1 once, writes dy1 once
+// All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32).  HBM traffic: 5 passes over the 93 MB tensor per step instead of 14.
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int SC_C = 40;      // channels in and out
+constexpr int SC_W = 36;      // positions per row
+constexpr int SC_OP = 48;     // out channels / positions padded to 3 MFMA tiles
+
+struct bn_affine {            // per-channel BatchNorm as y -> xhat -> u: xhat = (y - mean) * rstd ; u = gamma * xhat + beta
+    const float *mean, *rstd, *gamma, *beta;
+};
+__device__ __forceinline__ float bn_elu(float y, float mean, float rstd, float gamma, float beta) {
+    return elu1(gamma * (y - mean) * rstd + beta);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward: one workgroup per sample; K = (c,h) = 40*H streamed in chunks of 128; the 4 waves split each chunk's 32 k-steps and
+// keep private 3x3 accumulator tiles (o x w), combined through LDS at the end.
+constexpr int SCF_KC = 128;
+constexpr int SCF_LW = SCF_KC + 1;     // weight tile row stride (odd: the 16 out-channel rows of an operand read hit distinct banks)
+__global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
+                                                         const float* __restrict__ bs, float* __restrict__ y2, double* __restrict__ sums2,
+                                                         int B, int H) {
+    EEG_LDS_BASE(float, lds);
+    float* wl = lds;                          // [48][SCF_LW]   Ws[o][k0 + kk]   (rows >= 40 zero)
+    float* zl = wl + SC_OP * SCF_LW;          // [128][48]      z1[k0 + kk][w]   (cols >= 36 zero)
+    float* red = zl + SCF_KC * SC_OP;         // [48][48]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int K = SC_C * H;
+    for (int i = t; i < SC_OP * SCF_LW; i += 256) wl[i] = 0.f;
+    for (int i = t; i < SCF_KC * SC_OP; i += 256) zl[i] = 0.f;
+    for (int i = t; i < SC_OP * SC_OP; i += 256) red[i] = 0.f;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* yb = y1 + (long long)b * K * SC_W;
+    for (int k0 = 0; k0 < K; k0 += SCF_KC) {
+        __syncthreads();
+        // stage the weight tile: 40 rows x 128 k (contiguous in k) -- 20 loads per thread, all in flight before the stores
+        {
+            float v[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const int i = t + 256 * j, o = i >> 7, kk = i & 127;
+                v[j] = (k0 + kk < K) ? Ws[(long long)o * K + k0 + kk] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const int i = t + 256 * j;
+                wl[(i >> 7) * SCF_LW + (i & 127)] = v[j];
+            }
+        }
+        // stage z1 = ELU(BN(y1)): 128 k x 36 w = 4608 contiguous floats of this sample -- 18 loads per thread
+        {
+            float v[18];
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int i = t + 256 * j, kk = i / SC_W;
+                v[j] = (k0 + kk < K) ? yb[(long long)k0 * SC_W + i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int i = t + 256 * j, kk = i / SC_W, w = i % SC_W;
+                float z = 0.f;
+                if (k0 + kk < K) {
+                    const int c = (k0 + kk) / H;
+                    z = bn_elu(v[j], bn.mean[c], bn.rstd[c], bn.gamma[c], bn.beta[c]);
+                }
+                zl[kk * SC_OP + w] = z;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int kq = 4 * (wv * 8 + s8) + g;
+            float av[3], bv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[i] = wl[(16 * i + fr) * SCF_LW + kq];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bv[j] = zl[kq * SC_OP + 16 * j + fr];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * i + 4 * g + r) * SC_OP + 16 * j + fr, acc[i][j][r]);
+    __syncthreads();
+    float* yo = y2 + (long long)b * SC_C * SC_W;
+    for (int i = t; i < SC_C * SC_W; i += 256) {
+        const int o = i / SC_W, w = i % SC_W;
+        const float v = red[o * SC_OP + w] + bs[o];
+        yo[i] = v;
+        red[o * SC_OP + w] = v;
+    }
+    if (sums2) {                              // BatchNorm2d #2 batch statistics of y2 (fp64 atomics, 80 per workgroup)
+        __syncthreads();
+        if (t < SC_C) {
+            double s = 0.0, q = 0.0;
+            for (int w = 0; w < SC_W; ++w) { const float v = red[t * SC_OP + w]; s += v; q += (double)v * v; }
+            atomicAdd(sums2 + t, s);
+            atomicAdd(sums2 + SC_C + t, q);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient: workgroup (n-slab of 256 (c,h) columns, group of samples); per sample K = 36 positions; accumulators 3 x 16 tiles
+// spread over the 4 waves (4 n-tiles each); partial results go to the workspace, a second kernel sums the sample groups.
+constexpr int SCW_NS = 256;                  // (c,h) columns per workgroup
+constexpr int SCW_L = 37;                    // LDS row stride for 36-float rows
+__global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
+                                                           float* __restrict__ partials, int B, int H, int bgroups) {
+    EEG_LDS_BASE(float, lds);
+    float* zl = lds;                          // [256][37]  z1[n0 + n][w]
+    float* dl = zl + SCW_NS * SCW_L;          // [48][37]   dy2[o][w]   (rows >= 40 zero)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int K = SC_C * H;
+    const int n0 = blockIdx.x * SCW_NS, bg = blockIdx.y;
+    for (int i = t; i < SC_OP * SCW_L; i += 256) dl[i] = 0.f;
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ncols = K - n0 < SCW_NS ? K - n0 : SCW_NS;
+    for (int b = bg; b < B; b += bgroups) {
+        __syncthreads();
+        {
+            const float* src = y1 + ((long long)b * K + n0) * SC_W;      // ncols*36 contiguous floats
+            float v[36];
+#pragma unroll
+            for (int j = 0; j < 36; ++j) {
+                const int i = t + 256 * j;
+                v[j] = (i < ncols * SC_W) ? src[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 36; ++j) {
+                const int i = t + 256 * j, n = i / SC_W, w = i % SC_W;
+                float z = 0.f;
+                if (n < ncols) {
+                    const int c = (n0 + n) / H;
+                    z = bn_elu(v[j], bn.mean[c], bn.rstd[c], bn.gamma[c], bn.beta[c]);
+                }
+                zl[n * SCW_L + w] = z;
+            }
+            const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
+            float d6[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; d6[j] = i < SC_C * SC_W ? dsrc[i] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; if (i < SC_C * SC_W) dl[(i / SC_W) * SCW_L + i % SC_W] = d6[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SC_W / 4; ++kk) {
+            const int kq = 4 * kk + g;
+            float av[3], bv[4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[i] = dl[(16 * i + fr) * SCW_L + kq];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = zl[(64 * wv + 16 * j + fr) * SCW_L + kq];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);      // D[o][n = n0 + 64wv + 16j + fr]
+        }
+    }
+    float* out = partials + (long long)bg * SC_C * K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wv + 16 * j + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * i + 4 * g + r;
+                if (o < SC_C && n < K) out[(long long)o * K + n] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < groups; ++k) s += partials[(long long)k * n + i];
+    dW[i] += s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// input gradient + BatchNorm1 backward.  One workgroup per sample; wave tasks = (channel c, 16-row block of h): dz[h][w] =
+// sum_o Ws[o][c][h] * dy2[o][w] on the matrix cores (K = 40), then da = dz * ELU'(u) with u = BN(y1).
+//   APPLY = false: accumulate sum(da), sum(da * xhat) per channel (LDS, then 80 fp64 atomics per workgroup)
+//   APPLY = true : dy1 = gamma * rstd * (da - S1/n - xhat * S2/n)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restrict__ dy2, const float* __restrict__ Ws,
+                                                           const float* __restrict__ y1, const bn_affine bn, double* __restrict__ sums,
+                                                           const double* __restrict__ sums_param, double count, float* __restrict__ dy1,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H) {
+    EEG_LDS_BASE(float, lds);
+    float* dl = lds;                          // [40][48]  dy2[o][w]  (cols >= 36 zero)
+    float* sl = dl + SC_C * SC_OP;            // [80] per-workgroup channel sums
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int K = SC_C * H;
+    for (int i = t; i < SC_C * SC_OP; i += 256) {
+        const int o = i / SC_OP, w = i % SC_OP;
+        dl[i] = w < SC_W ? dy2[((long long)b * SC_C + o) * SC_W + w] : 0.f;
+    }
+    if (t < 2 * SC_C) sl[t] = 0.f;
+    if (APPLY && b == 0 && t < SC_C) {        // parameter gradients from this rank's own sums (see norm.hip: bn_elu_bwd_apply)
+        atomicAdd(dgamma + t, (float)sums_param[SC_C + t]);
+        atomicAdd(dbeta + t, (float)sums_param[t]);
+    }
+    __syncthreads();
+    const int MT = (H + 15) / 16;
+    for (int p = wv; p < SC_C * MT; p += 4) {
+        const int c = p / MT, mt = p % MT;
+        const int hA = 16 * mt + fr;                         // A-operand row of this lane
+        float av[10];
+#pragma unroll
+        for (int kk = 0; kk < 10; ++kk) av[kk] = hA < H ? Ws[((long long)(4 * kk + g) * SC_C + c) * H + hA] : 0.f;
+        // y1 values of the accumulator positions (row h = 16mt + 4g + r, col w = 16j + fr), issued before the MFMAs
+        float yv[3][4];
+        const float* yb = y1 + ((long long)b * SC_C + c) * H * SC_W;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = 16 * mt + 4 * g + r, w = 16 * j + fr;
+                yv[j][r] = (h < H && w < SC_W) ? yb[h * SC_W + w] : 0.f;
+            }
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 10; ++kk) {
+            const float* dp = dl + (4 * kk + g) * SC_OP + fr;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = mfma_f32_16x16x4(av[kk], dp[16 * j], acc[j]);      // D[h][w]
+        }
+        const float mean = bn.mean[c], rstd = bn.rstd[c], gam = bn.gamma[c], bet = bn.beta[c];
+        float m1 = 0.f, m2 = 0.f;
+        if (APPLY) { m1 = (float)(sums[c] / count); m2 = (float)(sums[SC_C + c] / count); }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = 16 * mt + 4 * g + r, w = 16 * j + fr;
+                if (h < H && w < SC_W) {
+                    const float xh = (yv[j][r] - mean) * rstd;
+                    const float u = gam * xh + bet;
+                    const float da = u > 0.f ? acc[j][r] : acc[j][r] * expf(u);
+                    if (APPLY) dy1[(((long long)b * SC_C + c) * H + h) * SC_W + w] = gam * rstd * (da - m1 - xh * m2);
+                    else { s1 += da; s2 += da * xh; }
+                }
+            }
+        if (!APPLY) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) { atomicAdd(sl + c, s1); atomicAdd(sl + SC_C + c, s2); }
+        }
+    }
+    if (!APPLY) {
+        __syncthreads();
+        if (t < 2 * SC_C) atomicAdd(sums + t, (double)sl[t]);
+    }
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+static int sc_check(int B, int H) { return (B < 1 || H < 1 || H > 64) ? EEGCLIP_EINVAL : 0; }
+
+extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
+                                 const float* bs, float* y2, double* sums2, int B, int H, void* stream) {
+    if (int rc = sc_check(B, H)) return rc;
+    if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
+    const bn_affine bn{mean, rstd, gamma, beta};
+    const size_t lds = (SC_OP * SCF_LW + SCF_KC * SC_OP + SC_OP * SC_OP) * sizeof(float);
+    EEG_LAUNCH(sconv_fwd_kernel, dim3(B), dim3(256), lds, stream, y1, bn, Ws, bs, y2, sums2, B, H);
+    return (int)hipGetLastError();
+}
+
+static int scw_groups(int B) { return B < 32 ? B : 32; }
+extern "C" long long eegclip_sconv_bwd_w_workspace_floats(int B, int H) { return (long long)scw_groups(B) * SC_C * SC_C * H; }
+
+extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
+                                   float* dWs, float* workspace, int B, int H, void* stream) {
+    if (int rc = sc_check(B, H)) return rc;
+    if (!y1 || !mean || !rstd || !gamma || !beta || !dy2 || !dWs || !workspace) return EEGCLIP_EINVAL;
+    const bn_affine bn{mean, rstd, gamma, beta};
+    const int K = SC_C * H, groups = scw_groups(B);
+    const size_t lds = (SCW_NS * SCW_L + SC_OP * SCW_L) * sizeof(float);
+    EEG_LAUNCH(sconv_bwd_w_kernel, dim3((K + SCW_NS - 1) / SCW_NS, groups), dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+    const long long n = (long long)SC_C * K;
+    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, groups, n, dWs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, double* sums, int B, int H, void* stream) {
+    if (int rc = sc_check(B, H)) return rc;
+    if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums) return EEGCLIP_EINVAL;
+    const bn_affine bn{mean, rstd, gamma, beta};
+    const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
+    EEG_LAUNCH((sconv_bwd_x_kernel<false>), dim3(B), dim3(256), lds, stream, dy2, Ws, y1, bn, sums, (const double*)nullptr, 1.0, (float*)nullptr,
+               (float*)nullptr, (float*)nullptr, B, H);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, const double* sums, const double* sums_local, double count,
+                                         float* dy1, float* dgamma, float* dbeta, int B, int H, void* stream) {
+    if (int rc = sc_check(B, H)) return rc;
+    if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums || !dy1 || !dgamma || !dbeta || count < 1.0) return EEGCLIP_EINVAL;
+    const bn_affine bn{mean, rstd, gamma, beta};
+    const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
+    EEG_LAUNCH((sconv_bwd_x_kernel<true>), dim3(B), dim3(256), lds, stream, dy2, Ws, y1, bn, const_cast<double*>(sums),
+               sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+    return (int)hipGetLastError();
+}

@@ -170,6 +170,26 @@ int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const f
 int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* dx, long long xs_b, long long xs_h, int B, int H, int T, int C,
                          void* stream);
 
+/* ---- fused spatial stage of tsconv: BatchNorm2d(40) -> ELU -> Conv2d(40,40,(H,1)) and its backward (ATMS_retrieval.py:104-106).
+ * y1/dy1: (B,40,H,36) conv+pool output and its gradient; mean/rstd/gamma/beta: BatchNorm1 statistics and affine (float[40]);
+ * Ws: (40,40,H) spatial weights; y2/dy2: (B,40,36).  z1 = ELU(BN(y1)) is never materialised: every kernel re-evaluates it while
+ * staging y1, and bwd_x recomputes dz1 = Ws^T dy2 on the matrix cores.  H <= 64.
+ *   fwd         y2 = bs + Ws * z1 ; optional BatchNorm2 batch sums of y2 into sums2 (double[80], zeroed by the caller)
+ *   bwd_w       dWs += sum_{b,w} dy2 (x) z1       (two-stage reduction through `workspace`, size from ..._workspace_floats)
+ *   bwd_x_stats sums[c] += sum da, sums[40+c] += sum da*xhat,  da = (Ws^T dy2) * ELU'(BN(y1))     (double[80], zeroed by the caller)
+ *   bwd_x_apply dy1 = gamma*rstd*(da - sums/count - xhat*sums'/count); dgamma/dbeta += sums_local (NULL = sums) -- SyncBN: all-reduce
+ *               sums between the two calls and pass the global count. */
+int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
+                      const float* bs, float* y2, double* sums2, int B, int H, void* stream);
+long long eegclip_sconv_bwd_w_workspace_floats(int B, int H);
+int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
+                        float* dWs, float* workspace, int B, int H, void* stream);
+int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, double* sums, int B, int H, void* stream);
+int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const double* sums, const double* sums_local, double count, float* dy1, float* dgamma,
+                              float* dbeta, int B, int H, void* stream);
+
 /* ---- InfoNCE around the logits GEMM.  models/loss.py:122-140  (scale = pointer to the RAW logit_scale on the device)
  * lse_rows/cols: log-sum-exp of scale*X along rows / columns.  infonce_grad: X (rows x cols block of raw logits, positives at
  * column i+col0) <- scale * G in place, *loss += weighted loss contribution, *dscale += sum G.*raw.  lse_r or lse_c may be NULL

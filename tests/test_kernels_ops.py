@@ -353,3 +353,41 @@ def test_sdxl_cross_attention_with_ip_adapter_branch(be, f16, B, HW, heads, S, S
     tol = 6e-3 if f16 else 2.5e-2            # 16-bit probabilities and outputs: ~2^-11 (f16) / 2^-8 (bf16) relative
     np.testing.assert_allclose(got, ref, atol=tol)
     assert np.abs(got - ref).mean() < tol / 6
+
+
+@pytest.mark.parametrize("B,H", [(3, 63), (2, 5), (33, 63)])
+def test_fused_spatial_stage(be, B, H):
+    """csrc/sconv.hip: BN1 -> ELU -> (H x 1) conv forward, weight gradient, and the two-pass input gradient + BatchNorm backward."""
+    rng = np.random.default_rng(B * 100 + H)
+    C, Wd = 40, 36
+    y1 = rnd(rng, B, C, H, Wd) * 1.3 + 0.2
+    g1, b1 = 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C)
+    Ws, bs = (rnd(rng, C, C, H) / np.sqrt(C * H)).astype(np.float32), 0.1 * rnd(rng, C)
+    dy2 = rnd(rng, B, C, Wd)
+    yt = torch.tensor(y1, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g1, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b1, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(Ws, dtype=torch.float64, requires_grad=True)
+    z = F.elu(F.batch_norm(yt, None, None, gt, bt, True, 0.1, 1e-5))
+    y2t = F.conv2d(z, wt.view(C, C, H, 1), torch.tensor(bs, dtype=torch.float64)).squeeze(2)
+    y2t.backward(torch.tensor(dy2, dtype=torch.float64))
+    mean = y1.astype(np.float64).mean((0, 2, 3))
+    var = y1.astype(np.float64).var((0, 2, 3))
+    Y1, G1, B1, WS, BS, DY2 = be.dev(y1), be.dev(g1), be.dev(b1), be.dev(Ws), be.dev(bs), be.dev(dy2)
+    MU, RS = be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
+    Y2, S2 = be.zeros((B, C, Wd)), be.zeros(80, np.float64)
+    ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(BS), be.ptr(Y2), be.ptr(S2), B, H, be.stream))
+    np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
+    np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3)
+    np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
+    DWS = be.dev(np.ones((C, C, H), np.float32))
+    WSP = be.zeros(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)))
+    ok(be.lib.eegclip_sconv_bwd_w(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(DWS), be.ptr(WSP), B, H, be.stream))
+    np.testing.assert_allclose(be.host(DWS) - 1.0, wt.grad.numpy(), atol=1e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+    SUMS, DY1, DG, DB = be.zeros(80, np.float64), be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
+    ok(be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), B, H, be.stream))
+    ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), None,
+                                        float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
+    np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
+    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
+    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
