@@ -47,6 +47,22 @@ constexpr int TS_UP = 80;     // taps padded to 5 MFMA tiles (bwd) ; fwd uses 76
 constexpr int TS_XS = 256;    // staged token-row stride (250 samples + zero pad: windows may read up to index 254)
 
 // one token row per pass, lanes walk the 250 samples (coalesced); (b, h) of a row is wave-uniform scalar math, no per-element division
+// register-staged variant used by the software-pipelined loops: NR rows -> NR registers per thread, stored to LDS one iteration later
+template <int NR>
+__device__ __forceinline__ void load_x_rows(float (&v)[NR], const float* x, long long xs_b, long long xs_h, int row0, int rows, int H) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int row = row0 + j;
+        v[j] = (row < rows && t < TS_T) ? x[(row / H) * xs_b + (row % H) * xs_h + t] : 0.f;
+    }
+}
+template <int NR>
+__device__ __forceinline__ void store_x_rows(float* xl, const float (&v)[NR]) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) xl[j * TS_XS + threadIdx.x] = v[j];
+}
+
 // Loads are issued in batches of 8 independent rows BEFORE any is consumed: with one workgroup per CU a load->LDS-store chain per
 // row would pay the full HBM latency (~1 us) per row (measured: 32 serialized rows = half of the forward kernel's time).
 __device__ __forceinline__ void stage_x_rows(float* xl, const float* x, long long xs_b, long long xs_h, int row0, int nrows, int rows, int H) {
@@ -91,11 +107,14 @@ __global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict
             sq[ct][r] = 0.f;
         }
     const int nchunks = (rows + TSF_R - 1) / TSF_R;
+    float vx[TSF_R];                               // next chunk's token rows, in flight under the current chunk's MFMAs
+    if ((int)blockIdx.x < nchunks) load_x_rows<TSF_R>(vx, x, xs_b, xs_h, blockIdx.x * TSF_R, rows, H);
     for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
         const int row0 = ch * TSF_R;
         __syncthreads();                          // previous chunk fully consumed (also orders the weight staging)
-        stage_x_rows(xl, x, xs_b, xs_h, row0, TSF_R, rows, H);
+        store_x_rows<TSF_R>(xl, vx);
         __syncthreads();
+        if (ch + (int)gridDim.x < nchunks) load_x_rows<TSF_R>(vx, x, xs_b, xs_h, (ch + gridDim.x) * TSF_R, rows, H);
         for (int mt = wv; mt < TSF_R * TS_W / 16; mt += 4) {
             const int m = 16 * mt + fr;          // B-operand column: output position
             const float* xp = xl + (m / TS_W) * TS_XS + 5 * (m % TS_W) + g;
@@ -167,27 +186,40 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
 #pragma unroll
         for (int ut = 0; ut < 5; ++ut) acc[ct][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = t; i < TS_CP * TSW_MS; i += blockDim.x) dl[i] = 0.f;         // pad filters 40..47 stay zero for ever
-    for (int item = blockIdx.x; item < B * per; item += gridDim.x) {
+    // software pipeline: the next work item's dy slab (up to 2 x 40 floats per thread) and token rows are loaded into registers
+    // before the MFMAs of the current item -- one workgroup per CU (LDS), so nothing else would hide the HBM latency
+    float vd[2][TS_C], vx[TSW_R];
+    auto load_item = [&](int item) {
         const int b = item / per, h0 = (item % per) * TSW_R;
+        const int nr = H - h0 < TSW_R ? H - h0 : TSW_R;
+        const int mc = nr * TS_W;
+        load_x_rows<TSW_R>(vx, x, xs_b, xs_h, b * H + h0, b * H + h0 + nr, H);
+        const float* src = dy + (((long long)b * TS_C) * H + h0) * TS_W;      // (h, w) contiguous for a fixed (b, c): lanes walk it
+        const long long cs = (long long)H * TS_W;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = t + 256 * q;
+#pragma unroll
+            for (int c = 0; c < TS_C; ++c) vd[q][c] = m < mc ? src[c * cs + m] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < B * per) load_item(blockIdx.x);
+    for (int item = blockIdx.x; item < B * per; item += gridDim.x) {
+        const int h0 = (item % per) * TSW_R;
         const int nr = H - h0 < TSW_R ? H - h0 : TSW_R;
         const int mc = nr * TS_W;                 // positions in this slab (multiple of 4)
         __syncthreads();
-        stage_x_rows(xl, x, xs_b, xs_h, b * H + h0, TSW_R, b * H + h0 + nr, H);
-        {                                         // (h, w) is contiguous in dy for a fixed (b, c): lanes walk it, 8 filters in flight per batch
-            const float* src = dy + (((long long)b * TS_C) * H + h0) * TS_W;
-            const long long cs = (long long)H * TS_W;
-            for (int m = t; m < mc; m += blockDim.x) {
+        store_x_rows<TSW_R>(xl, vx);
 #pragma unroll
-                for (int c0 = 0; c0 < TS_C; c0 += 8) {
-                    float v[8];
+        for (int q = 0; q < 2; ++q) {
+            const int m = t + 256 * q;
+            if (m < mc) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = src[(c0 + j) * cs + m];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) dl[(c0 + j) * TSW_MS + m] = v[j];
-                }
+                for (int c = 0; c < TS_C; ++c) dl[c * TSW_MS + m] = vd[q][c];
             }
         }
         __syncthreads();
+        if (item + (int)gridDim.x < B * per) load_item(item + gridDim.x);
         for (int ks = wv; ks < mc / 4; ks += 4) {
             const int m = 4 * ks + g;            // this lane's k index (position)
             const float* xp = xl + (m / TS_W) * TS_XS + 5 * (m % TS_W) + fr;

@@ -36,10 +36,16 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     float* wl = lds;                          // [48][SCF_LW]   Ws[o][k0 + kk]   (rows >= 40 zero)
     float* zl = wl + SC_OP * SCF_LW;          // [128][48]      z1[k0 + kk][w]   (cols >= 36 zero)
     float* red = zl + SCF_KC * SC_OP;         // [48][48]
+    float* aff = red + SC_OP * SC_OP;         // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int K = SC_C * H;
+    if (t < SC_C) {
+        const float sc = bn.gamma[t] * bn.rstd[t];
+        aff[t] = sc;
+        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
+    }
     for (int i = t; i < SC_OP * SCF_LW; i += 256) wl[i] = 0.f;
     for (int i = t; i < SCF_KC * SC_OP; i += 256) zl[i] = 0.f;
     for (int i = t; i < SC_OP * SC_OP; i += 256) red[i] = 0.f;
@@ -49,42 +55,44 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* yb = y1 + (long long)b * K * SC_W;
+    // software pipeline: the global loads of chunk k0+128 (20 weight + 18 activation floats per thread) are issued before the MFMAs of
+    // chunk k0 and land under them -- with one workgroup per CU nothing else hides the HBM latency
+    float vw[20], vy[18];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            const int i = t + 256 * j, o = i >> 7, kk = i & 127;
+            vw[j] = (k0 + kk < K) ? Ws[(long long)o * K + k0 + kk] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int i = t + 256 * j, kk = i / SC_W;
+            vy[j] = (k0 + kk < K) ? yb[(long long)k0 * SC_W + i] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            const int i = t + 256 * j;
+            wl[(i >> 7) * SCF_LW + (i & 127)] = vw[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int i = t + 256 * j, kk = i / SC_W, w = i % SC_W;
+            float z = 0.f;
+            if (k0 + kk < K) {
+                const int c = (k0 + kk) / H;
+                z = elu1(vy[j] * aff[c] + aff[SC_C + c]);      // z1 = ELU(BN(y1)) evaluated on the way into LDS
+            }
+            zl[kk * SC_OP + w] = z;
+        }
+    };
+    load_chunk(0);
     for (int k0 = 0; k0 < K; k0 += SCF_KC) {
         __syncthreads();
-        // stage the weight tile: 40 rows x 128 k (contiguous in k) -- 20 loads per thread, all in flight before the stores
-        {
-            float v[20];
-#pragma unroll
-            for (int j = 0; j < 20; ++j) {
-                const int i = t + 256 * j, o = i >> 7, kk = i & 127;
-                v[j] = (k0 + kk < K) ? Ws[(long long)o * K + k0 + kk] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 20; ++j) {
-                const int i = t + 256 * j;
-                wl[(i >> 7) * SCF_LW + (i & 127)] = v[j];
-            }
-        }
-        // stage z1 = ELU(BN(y1)): 128 k x 36 w = 4608 contiguous floats of this sample -- 18 loads per thread
-        {
-            float v[18];
-#pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const int i = t + 256 * j, kk = i / SC_W;
-                v[j] = (k0 + kk < K) ? yb[(long long)k0 * SC_W + i] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const int i = t + 256 * j, kk = i / SC_W, w = i % SC_W;
-                float z = 0.f;
-                if (k0 + kk < K) {
-                    const int c = (k0 + kk) / H;
-                    z = bn_elu(v[j], bn.mean[c], bn.rstd[c], bn.gamma[c], bn.beta[c]);
-                }
-                zl[kk * SC_OP + w] = z;
-            }
-        }
+        store_chunk(k0);
         __syncthreads();
+        if (k0 + SCF_KC < K) load_chunk(k0 + SCF_KC);
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             const int kq = 4 * (wv * 8 + s8) + g;
@@ -134,10 +142,16 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restric
     EEG_LDS_BASE(float, lds);
     float* zl = lds;                          // [256][37]  z1[n0 + n][w]
     float* dl = zl + SCW_NS * SCW_L;          // [48][37]   dy2[o][w]   (rows >= 40 zero)
+    float* aff = dl + SC_OP * SCW_L;          // [2][40]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int K = SC_C * H;
     const int n0 = blockIdx.x * SCW_NS, bg = blockIdx.y;
+    if (t < SC_C) {
+        const float sc = bn.gamma[t] * bn.rstd[t];
+        aff[t] = sc;
+        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
+    }
     for (int i = t; i < SC_OP * SCW_L; i += 256) dl[i] = 0.f;
     f32x4 acc[3][4];
 #pragma unroll
@@ -145,34 +159,38 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ncols = K - n0 < SCW_NS ? K - n0 : SCW_NS;
+    float vz[36], vd[6];
+    auto load_sample = [&](int b) {
+        const float* src = y1 + ((long long)b * K + n0) * SC_W;      // ncols*36 contiguous floats
+#pragma unroll
+        for (int j = 0; j < 36; ++j) {
+            const int i = t + 256 * j;
+            vz[j] = (i < ncols * SC_W) ? src[i] : 0.f;
+        }
+        const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; vd[j] = i < SC_C * SC_W ? dsrc[i] : 0.f; }
+    };
+    auto store_sample = [&]() {
+#pragma unroll
+        for (int j = 0; j < 36; ++j) {
+            const int i = t + 256 * j, n = i / SC_W, w = i % SC_W;
+            float z = 0.f;
+            if (n < ncols) {
+                const int c = (n0 + n) / H;
+                z = elu1(vz[j] * aff[c] + aff[SC_C + c]);
+            }
+            zl[n * SCW_L + w] = z;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; if (i < SC_C * SC_W) dl[(i / SC_W) * SCW_L + i % SC_W] = vd[j]; }
+    };
+    if (bg < B) load_sample(bg);
     for (int b = bg; b < B; b += bgroups) {
         __syncthreads();
-        {
-            const float* src = y1 + ((long long)b * K + n0) * SC_W;      // ncols*36 contiguous floats
-            float v[36];
-#pragma unroll
-            for (int j = 0; j < 36; ++j) {
-                const int i = t + 256 * j;
-                v[j] = (i < ncols * SC_W) ? src[i] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 36; ++j) {
-                const int i = t + 256 * j, n = i / SC_W, w = i % SC_W;
-                float z = 0.f;
-                if (n < ncols) {
-                    const int c = (n0 + n) / H;
-                    z = bn_elu(v[j], bn.mean[c], bn.rstd[c], bn.gamma[c], bn.beta[c]);
-                }
-                zl[n * SCW_L + w] = z;
-            }
-            const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
-            float d6[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; d6[j] = i < SC_C * SC_W ? dsrc[i] : 0.f; }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { const int i = t + 256 * j; if (i < SC_C * SC_W) dl[(i / SC_W) * SCW_L + i % SC_W] = d6[j]; }
-        }
+        store_sample();
         __syncthreads();
+        if (b + bgroups < B) load_sample(b + bgroups);          // next sample's loads land under this sample's MFMAs
 #pragma unroll
         for (int kk = 0; kk < SC_W / 4; ++kk) {
             const int kq = 4 * kk + g;
@@ -231,28 +249,40 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
         dl[i] = w < SC_W ? dy2[((long long)b * SC_C + o) * SC_W + w] : 0.f;
     }
     if (t < 2 * SC_C) sl[t] = 0.f;
-    if (APPLY && b == 0 && t < SC_C) {        // parameter gradients from this rank's own sums (see norm.hip: bn_elu_bwd_apply)
+    if (APPLY && b == 0 && blockIdx.y == 0 && t < SC_C) {        // parameter gradients from this rank's own sums (see norm.hip: bn_elu_bwd_apply)
         atomicAdd(dgamma + t, (float)sums_param[SC_C + t]);
         atomicAdd(dbeta + t, (float)sums_param[t]);
     }
     __syncthreads();
     const int MT = (H + 15) / 16;
-    for (int p = wv; p < SC_C * MT; p += 4) {
+    // register double-buffer: the 10 weight and 12 y1 loads of task p+4 are issued before the MFMAs / epilogue of task p
+    float nav[10], nyv[3][4];
+    auto load_task = [&](int p) {
         const int c = p / MT, mt = p % MT;
         const int hA = 16 * mt + fr;                         // A-operand row of this lane
-        float av[10];
 #pragma unroll
-        for (int kk = 0; kk < 10; ++kk) av[kk] = hA < H ? Ws[((long long)(4 * kk + g) * SC_C + c) * H + hA] : 0.f;
-        // y1 values of the accumulator positions (row h = 16mt + 4g + r, col w = 16j + fr), issued before the MFMAs
-        float yv[3][4];
-        const float* yb = y1 + ((long long)b * SC_C + c) * H * SC_W;
+        for (int kk = 0; kk < 10; ++kk) nav[kk] = hA < H ? Ws[((long long)(4 * kk + g) * SC_C + c) * H + hA] : 0.f;
+        const float* yb = y1 + ((long long)b * SC_C + c) * H * SC_W;      // accumulator positions: row h = 16mt + 4g + r, col w = 16j + fr
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = 16 * mt + 4 * g + r, w = 16 * j + fr;
-                yv[j][r] = (h < H && w < SC_W) ? yb[h * SC_W + w] : 0.f;
+                nyv[j][r] = (h < H && w < SC_W) ? yb[h * SC_W + w] : 0.f;
             }
+    };
+    const int pstep = 4 * gridDim.y, p0 = 4 * blockIdx.y + wv;      // gridDim.y workgroups share a sample: more waves per CU to overlap
+    if (p0 < SC_C * MT) load_task(p0);                                 // one wave's MFMA phase with another's VALU epilogue
+    for (int p = p0; p < SC_C * MT; p += pstep) {
+        const int c = p / MT, mt = p % MT;
+        float av[10], yv[3][4];
+#pragma unroll
+        for (int kk = 0; kk < 10; ++kk) av[kk] = nav[kk];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[j][r] = nyv[j][r];
+        if (p + pstep < SC_C * MT) load_task(p + pstep);
         f32x4 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -302,7 +332,7 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
     const bn_affine bn{mean, rstd, gamma, beta};
-    const size_t lds = (SC_OP * SCF_LW + SCF_KC * SC_OP + SC_OP * SC_OP) * sizeof(float);
+    const size_t lds = (SC_OP * SCF_LW + SCF_KC * SC_OP + SC_OP * SC_OP + 2 * SC_C) * sizeof(float);
     EEG_LAUNCH(sconv_fwd_kernel, dim3(B), dim3(256), lds, stream, y1, bn, Ws, bs, y2, sums2, B, H);
     return (int)hipGetLastError();
 }
@@ -316,7 +346,7 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
     if (!y1 || !mean || !rstd || !gamma || !beta || !dy2 || !dWs || !workspace) return EEGCLIP_EINVAL;
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H, groups = scw_groups(B);
-    const size_t lds = (SCW_NS * SCW_L + SC_OP * SCW_L) * sizeof(float);
+    const size_t lds = (SCW_NS * SCW_L + SC_OP * SCW_L + 2 * SC_C) * sizeof(float);
     EEG_LAUNCH(sconv_bwd_w_kernel, dim3((K + SCW_NS - 1) / SCW_NS, groups), dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
     const long long n = (long long)SC_C * K;
     EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, groups, n, dWs);
@@ -329,7 +359,7 @@ extern "C" int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, cons
     if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums) return EEGCLIP_EINVAL;
     const bn_affine bn{mean, rstd, gamma, beta};
     const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
-    EEG_LAUNCH((sconv_bwd_x_kernel<false>), dim3(B), dim3(256), lds, stream, dy2, Ws, y1, bn, sums, (const double*)nullptr, 1.0, (float*)nullptr,
+    EEG_LAUNCH((sconv_bwd_x_kernel<false>), dim3(B, 4), dim3(256), lds, stream, dy2, Ws, y1, bn, sums, (const double*)nullptr, 1.0, (float*)nullptr,
                (float*)nullptr, (float*)nullptr, B, H);
     return (int)hipGetLastError();
 }
@@ -341,7 +371,7 @@ extern "C" int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, cons
     if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums || !dy1 || !dgamma || !dbeta || count < 1.0) return EEGCLIP_EINVAL;
     const bn_affine bn{mean, rstd, gamma, beta};
     const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
-    EEG_LAUNCH((sconv_bwd_x_kernel<true>), dim3(B), dim3(256), lds, stream, dy2, Ws, y1, bn, const_cast<double*>(sums),
+    EEG_LAUNCH((sconv_bwd_x_kernel<true>), dim3(B, 4), dim3(256), lds, stream, dy2, Ws, y1, bn, const_cast<double*>(sums),
                sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
     return (int)hipGetLastError();
 }
