@@ -39,17 +39,37 @@ def algorithmic_cost(name, desc, B):
     if name in ("eegclip_attention_fwd", "eegclip_attention_bwd"):
         per = 4 if name.endswith("fwd") else 10                    # QK^T + PV  |  + recompute, dP, dQ, dK, dV  (x 2 L^2 E flops)
         return "mfma", float(per * 64 * 64 * 62 * B * 4), "flop"
-    table = {
-        "eegclip_tsconv_fwd": ("hbm", B * 63 * 250 * 4 + y1),                # read tokens, write y1
-        "eegclip_bn_elu_fwd": ("hbm", 2 * y1),                              # read y1, write z1
-        "eegclip_bn_elu_bwd": ("hbm", 5 * y1),                              # 2 passes: (dz,x) + (dz,x,dx)
-        "eegclip_tsconv_bwd_w": ("hbm", B * 63 * 250 * 4 + y1),
-        "eegclip_tsconv_bwd_x": ("hbm", B * 63 * 250 * 4 + y1),
-        "eegclip_reduce_mid": ("hbm", y1),
+    tok = B * 63 * 250 * 4
+    table = {                                                               # HBM-bound streaming over the (B,40,63,36) tensor y1
+        "eegclip_tsconv_fwd": ("hbm", tok + y1),                            # read tokens, write y1
+        "eegclip_tsconv_bwd_w": ("hbm", tok + y1),                          # read tokens + dy1
+        "eegclip_tsconv_bwd_x": ("hbm", tok + y1),                          # read dy1, write token gradients
+        "eegclip_sconv_fwd": ("hbm", y1),                                   # read y1 (z1 recomputed, y2 is tiny)
+        "eegclip_sconv_bwd_w": ("hbm", y1),
+        "eegclip_sconv_bwd_x_stats": ("hbm", y1),
+        "eegclip_sconv_bwd_x_apply": ("hbm", 2 * y1),                       # read y1, write dy1
     }
     if name in table:
         return table[name][0], float(table[name][1]), "byte"
     return None
+
+
+_KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel", "eegclip_attention_fwd": "eeg::attention_fwd_kernel",
+              "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel",
+              "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
+              "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_kernel", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false>",
+              "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true>"}
+
+
+def pmc_traffic(op_name, B):
+    """HBM bytes per launch of the op's kernel from the committed rocprofv3 PMC summary (profiles/r1_pmc_hbm_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH doubled per the gfx950 correction).  Only valid for the profiled B=256."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+    if B != 256 or op_name not in _KERNEL_OF or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f).get(_KERNEL_OF[op_name])
+    return round(d["hbm_bytes_per_launch"]) if d and "hbm_bytes_per_launch" in d else None
 
 
 def build(world, rank, B, seed=0):
@@ -210,7 +230,7 @@ def main():
                 ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             d = _desc_of(plans[k], idx)
             roof = {"kernel": name + (f"[{d.M}x{d.N}x{d.K}]" if d is not None else ""), "bound": bound, "achieved": round(ach, 2),
-                    "peak": peak, "unit": u, "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
+                    "peak": peak, "unit": u, "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B), "avg_launch_ms": round(ms, 5),
                     "algorithmic_work_per_launch": work, "work_unit": unit}
 
     out = {
