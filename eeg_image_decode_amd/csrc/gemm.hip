@@ -2,30 +2,25 @@
 //
 //   C[m,n] (+)= epilogue(alpha * sum_k A[m,k] B[k,n])        -- see include/eegclip.h: eegclip_gemm_desc
 //
-// Tiling (CDNA4): BM x BN output tile (128x128, 128x64 or 64x64, chosen per problem so the grid still fills 256 CUs) per
-// 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning (BM/2)x(BN/2) as (BM/32)x(BN/32) MFMA 16x16
-// accumulators; BK = 32.  Both operand tiles are staged k-major in LDS (As[k][m ^ swz(k)], Bs[k][n ^ swz(k)], see g_swz):
-// the MFMA operand read "lane l -> (row l&15, k l>>4)" is then a ds_read_b32 of 16 consecutive floats per 16-lane group,
-// and stride = 17 (mod 32) keeps both that read and the k-contiguous staging write (lanes walk k) off each other's banks.  Global->register prefetch of tile t+1
-// overlaps the MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile
-// aligned: every load and store is guarded, padding lives only in LDS (zeros), never in HBM.
+// Two kernels share one epilogue:
+//   gemm_f32_fast_kernel  plain-stride operands with even leading dimensions (every Linear of the encoder, forward and backward):
+//                         8-byte global loads, no branches in the staging path, ds_read_b64 operand fetches, XCD-aware tile order
+//   gemm_f32_kernel       everything else (two-level index maps, odd sizes): element-wise guarded staging
+// Tiling (CDNA4): 64 x 64 output tile per 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning 32x32 as 2x2 MFMA
+// 16x16 accumulators; BK = 32 (128x128 / 128x64 tiles and an LDS double buffer were built and measured slower on every shape of
+// this path: at K ~ 250 occupancy, not per-wave reuse, hides the latency).  Global->register prefetch of k-tile t+1 overlaps the
+// MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile aligned: padding lives only in LDS
+// (zeros) or in clamped addresses, never in HBM.
 #include "eeg_common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace eeg {
 
 constexpr int G_BK = 32;
+constexpr int G_BT = 64;        // tile edge (M and N)
 constexpr int G_THREADS = 256;
-
-// LDS image: element (k, m) of a BK x BT operand tile lives at k*BT + (m ^ swz(k)), swz(k) = ((k&1)<<4) | (k>>1):
-//   * MFMA operand read (16 lanes walk m at k, the next 16 at k+1, ds_read_b32 services 32 lanes per cycle over 32 banks): the
-//     two 16-float runs land in opposite halves of the 32 banks (bit 4 of swz = k&1)                           -> conflict free
-//   * k-contiguous staging write (32 lanes walk k at one m): swz is a bijection of 0..31                         -> conflict free
-//   * m-contiguous staging write (lanes walk m at one k): XOR with a constant permutes the 32 banks              -> conflict free
-// (a padded stride of 17 mod 32 measured 1.5 conflict cycles per LDS instruction: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS)
-template <int BT> struct g_ld { static constexpr int v = BT; };
-__device__ __forceinline__ int g_swz(int k) { return ((k & 1) << 4) | ((k >> 1) & 15); }
 
 // PLAIN = every index map is a plain stride (div = 2^62): offsets are one multiply, and the integer-division path of the two-level
 // maps is not even instantiated (it was >1000 instructions of the unrolled staging/epilogue code)
@@ -34,118 +29,21 @@ __device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
     if (PLAIN) return (long long)i * d.si;
     return dim_off(d, i);
 }
-__device__ __forceinline__ bool gemm_dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
-    return dropout_keep(seed, site, idx, p);
-}
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool PLAIN>
-__global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_desc d) {
-    constexpr int LDA = g_ld<BM>::v, LDB = g_ld<BN>::v;
-    constexpr int EA = (BM * G_BK) / G_THREADS, EB = (BN * G_BK) / G_THREADS;   // staged elements per thread
-    constexpr int MT = BM / 32, NT = BN / 32;                                    // 16x16 MFMA tiles per wave (2x2 wave grid)
-    EEG_LDS_BASE(float, lds);
-    float* As = lds;                    // [G_BK][LDA]
-    float* Bs = lds + G_BK * LDA;       // [G_BK][LDB]
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    // K slice of this workgroup (split-K along blockIdx.z)
+// ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 accumulator -----------------------------------------------
+template <bool PLAIN>
+__device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const f32x4 (&acc)[2][2], int m0, int n0, int wr, int wc,
+                                              int lane, bool first_slice) {
     const int nsplit = d.split_k;
-    const int ktiles = (d.K + G_BK - 1) / G_BK;
-    const int tiles_per = (ktiles + nsplit - 1) / nsplit;
-    const int kt_begin = blockIdx.z * tiles_per;
-    int kt_end = kt_begin + tiles_per;
-    if (kt_end > ktiles) kt_end = ktiles;
-
-    // ---- per-thread staging coordinates -------------------------------------------------------------
-    // m-contiguous operand: lane walks m (coalesced), k = t / BM + (256/BM) i.   k-contiguous: lane walks k, m = (t>>5) + 8 i.
-    int a_row[EA], a_k[EA];
-    long long a_off[EA];
-    bool a_ok[EA];
-    int b_col[EB], b_k[EB];
-    long long b_off[EB];
-    bool b_ok[EB];
-#pragma unroll
-    for (int i = 0; i < EA; ++i) {
-        if (A_KC) { a_k[i] = t & 31; a_row[i] = (t >> 5) + 8 * i; }
-        else      { a_row[i] = t % BM; a_k[i] = t / BM + (G_THREADS / BM) * i; }
-        a_ok[i] = (m0 + a_row[i]) < d.M;
-        a_off[i] = a_ok[i] ? goff<PLAIN>(d.Am, m0 + a_row[i]) : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < EB; ++i) {
-        if (B_KC) { b_k[i] = t & 31; b_col[i] = (t >> 5) + 8 * i; }
-        else      { b_col[i] = t % BN; b_k[i] = t / BN + (G_THREADS / BN) * i; }
-        b_ok[i] = (n0 + b_col[i]) < d.N;
-        b_off[i] = b_ok[i] ? goff<PLAIN>(d.Bn, n0 + b_col[i]) : 0;
-    }
-
-    float ra[EA], rb[EB];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * G_BK;
-#pragma unroll
-        for (int i = 0; i < EA; ++i) {
-            const int ka = k0 + a_k[i];
-            ra[i] = (a_ok[i] && ka < d.K) ? d.A[a_off[i] + goff<PLAIN>(d.Ak, ka)] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < EB; ++i) {
-            const int kb = k0 + b_k[i];
-            rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + goff<PLAIN>(d.Bk, kb)] : 0.f;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < EA; ++i) As[a_k[i] * LDA + (a_row[i] ^ g_swz(a_k[i]))] = ra[i];
-#pragma unroll
-        for (int i = 0; i < EB; ++i) Bs[b_k[i] * LDB + (b_col[i] ^ g_swz(b_k[i]))] = rb[i];
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // (a double-buffered LDS variant with one barrier per k-tile measured 10-25 % SLOWER on MI355X: the second stage halves the
-    //  workgroups per CU and occupancy, not barrier count, is what hides latency for these short-K problems)
-    if (kt_begin < kt_end) load_tile(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);     // global -> registers, in flight under the MFMAs of tile kt
-        const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-        for (int kk = 0; kk < G_BK / 4; ++kk) {
-            const int kq = kk * 4 + fq;
-            const int sw = g_swz(kq);
-            float av[MT], bv[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = As[kq * LDA + ((wr * (BM / 2) + 16 * i + fr) ^ sw)];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = Bs[kq * LDB + ((wc * (BN / 2) + 16 * j + fr) ^ sw)];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] ------------------------------------------
-    const bool first_slice = (blockIdx.z == 0);
     const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + wc * (BN / 2) + nt * 16 + (lane & 15);
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wc * 32 + nt * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * (BM / 2) + mt * 16 + (lane >> 4) * 4 + r;
+                const int m = m0 + wr * 32 + mt * 16 + (lane >> 4) * 4 + r;
                 if (m >= d.M || n >= d.N) continue;
                 float v = d.alpha * acc[mt][nt][r];
                 if (first_slice) {
@@ -161,7 +59,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
                 if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
                 else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
                 if (d.drop_p > 0.f)
-                    v = gemm_dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
+                    v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
                 if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
                 if (d.accumulate) v += d.C[coff];
                 d.C[coff] = v;
@@ -170,19 +68,308 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     }
 }
 
-template <int BM, int BN>
+__device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int slice, int& kt_begin, int& kt_end) {
+    const int ktiles = (d.K + G_BK - 1) / G_BK;
+    const int tiles_per = (ktiles + d.split_k - 1) / d.split_k;
+    kt_begin = slice * tiles_per;
+    kt_end = kt_begin + tiles_per;
+    if (kt_end > ktiles) kt_end = ktiles;
+}
+
+// =================================================================================================================================
+// general kernel.  LDS image: element (k, m) of a BK x 64 operand tile lives at k*64 + (m ^ swz(k)), swz(k) = ((k&1)<<4) | (k>>1):
+//   * MFMA operand read (16 lanes walk m at k, the next 16 at k+1, ds_read_b32 services 32 lanes per cycle over 32 banks): the
+//     two 16-float runs land in opposite halves of the 32 banks (bit 4 of swz = k&1)                           -> conflict free
+//   * k-contiguous staging write (32 lanes walk k at one m): swz is a bijection of 0..31                         -> conflict free
+//   * m-contiguous staging write (lanes walk m at one k): XOR with a constant permutes the 32 banks              -> conflict free
+// (a padded stride of 17 mod 32 measured 1.5 conflict cycles per LDS instruction: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS)
+__device__ __forceinline__ int g_swz(int k) { return ((k & 1) << 4) | ((k >> 1) & 15); }
+
+template <bool A_KC, bool B_KC, bool PLAIN>
+__global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_desc d) {
+    constexpr int E = (G_BT * G_BK) / G_THREADS;   // staged elements per thread and operand
+    EEG_LDS_BASE(float, lds);
+    float* As = lds;                    // [G_BK][64]
+    float* Bs = lds + G_BK * G_BT;      // [G_BK][64]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * G_BT, n0 = blockIdx.x * G_BT;
+    int kt_begin, kt_end;
+    gemm_k_slice(d, blockIdx.z, kt_begin, kt_end);
+
+    // ---- per-thread staging coordinates -------------------------------------------------------------
+    // m-contiguous operand: lane walks m (coalesced), k = t / 64 + 4 i.   k-contiguous: lane walks k, m = (t>>5) + 8 i.
+    int a_row[E], a_k[E];
+    long long a_off[E];
+    bool a_ok[E];
+    int b_col[E], b_k[E];
+    long long b_off[E];
+    bool b_ok[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (A_KC) { a_k[i] = t & 31; a_row[i] = (t >> 5) + 8 * i; }
+        else      { a_row[i] = t % G_BT; a_k[i] = t / G_BT + (G_THREADS / G_BT) * i; }
+        a_ok[i] = (m0 + a_row[i]) < d.M;
+        a_off[i] = a_ok[i] ? goff<PLAIN>(d.Am, m0 + a_row[i]) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        if (B_KC) { b_k[i] = t & 31; b_col[i] = (t >> 5) + 8 * i; }
+        else      { b_col[i] = t % G_BT; b_k[i] = t / G_BT + (G_THREADS / G_BT) * i; }
+        b_ok[i] = (n0 + b_col[i]) < d.N;
+        b_off[i] = b_ok[i] ? goff<PLAIN>(d.Bn, n0 + b_col[i]) : 0;
+    }
+
+    float ra[E], rb[E];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * G_BK;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int ka = k0 + a_k[i];
+            ra[i] = (a_ok[i] && ka < d.K) ? d.A[a_off[i] + goff<PLAIN>(d.Ak, ka)] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int kb = k0 + b_k[i];
+            rb[i] = (b_ok[i] && kb < d.K) ? d.B[b_off[i] + goff<PLAIN>(d.Bk, kb)] : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < E; ++i) As[a_k[i] * G_BT + (a_row[i] ^ g_swz(a_k[i]))] = ra[i];
+#pragma unroll
+        for (int i = 0; i < E; ++i) Bs[b_k[i] * G_BT + (b_col[i] ^ g_swz(b_k[i]))] = rb[i];
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);     // global -> registers, in flight under the MFMAs of tile kt
+        const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < G_BK / 4; ++kk) {
+            const int kq = kk * 4 + fq;
+            const int sw = g_swz(kq);
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[kq * G_BT + ((wr * 32 + 16 * i + fr) ^ sw)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[kq * G_BT + ((wc * 32 + 16 * j + fr) ^ sw)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<PLAIN>(d, acc, m0, n0, wr, wc, lane, blockIdx.z == 0);
+}
+
+// =================================================================================================================================
+// fast kernel: plain strides, leading dimensions / contiguous extents even, base pointers 8-byte aligned, offsets < 2^31.
+//
+// LDS images (both conflict free for every access below; ds_*_b64 services 2 x 32 lanes over 64 banks, ds_read_b32 2 x 32 over 32):
+//   k-contiguous operand ("KC", e.g. X and W of Y = X W^T): [row][36]; staged with ds_write_b64 (16 lanes = one 128-byte row),
+//       fetched with ds_read_b64: lane (fr, g) takes k = 8r + 2g + {0,1} of row fr          (row stride 36 = 4 * odd)
+//   row-contiguous operand ("MC", e.g. dY^T and X of dW = dY^T X, W of dX = dY W): [k][64] with column ^ (((k>>1)&1) << 4);
+//       staged with ds_write_b64 along the row, fetched with ds_read_b32 at k = 8r + 2g + e (g and g+1 land in opposite bank halves)
+// Any bijection between the 4 lane groups x 8 MFMA steps and the 32 k of a tile is a valid contraction order as long as A and B
+// agree; "group g, step 2r+e  <->  k = 8r + 2g + e" is the one that lets the KC side fetch two steps per LDS instruction.
+//
+// Staging never branches: rows beyond M / N are clamped to the last valid row (their products only reach accumulator rows that the
+// epilogue never stores), k beyond K loads from a clamped in-bounds address and is replaced by 0.
+//
+// Tile order: the dispatcher places workgroup b on XCD b % 8 and every XCD has a private 4 MiB L2; logical tile = (b % 8) * chunk
+// + b / 8 gives each XCD a contiguous run of tiles (n fastest), so the 4..12 column tiles that share one 64-row slab of A hit the
+// same L2 instead of fetching the slab into up to 8 of them.
+constexpr int F_LDK = 36;
+__device__ __forceinline__ int f_swz(int k) { return ((k >> 1) & 1) << 4; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool A_KC, bool B_KC, bool C_PLAIN>
+__global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+    constexpr int A_FLOATS = A_KC ? G_BT * F_LDK : G_BK * G_BT;
+    EEG_LDS_BASE(float, lds);
+    float* As = lds;
+    float* Bs = lds + A_FLOATS;
+
+    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (logical >= ntiles) return;                       // whole workgroup leaves before any barrier
+    const int m0 = (logical / gx) * G_BT, n0 = (logical % gx) * G_BT;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+    int kt_begin, kt_end;
+    gemm_k_slice(d, blockIdx.y, kt_begin, kt_end);
+
+    // staging roles: KC operand -> thread (row = r0 + 16 i, k pair kp);  MC operand -> thread (k = kr0 + 8 i, row pair mp)
+    const int kp = t & 15, r0 = t >> 4, mp = t & 31, kr0 = t >> 5;
+    const int a_ld = A_KC ? (int)d.Am.si : (int)d.Ak.si, b_ld = B_KC ? (int)d.Bn.si : (int)d.Bk.si;
+    int a_fix[4], b_fix[4];          // KC: element offset of the (clamped) row;  MC: running element offset of the k row
+    int a_col = 0, b_col = 0;        // MC: clamped first row of the pair
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (A_KC) { const int m = m0 + r0 + 16 * i; a_fix[i] = (m < d.M ? m : d.M - 1) * a_ld; }
+        else      a_fix[i] = (kt_begin * G_BK + kr0 + 8 * i) * a_ld;
+        if (B_KC) { const int n = n0 + r0 + 16 * i; b_fix[i] = (n < d.N ? n : d.N - 1) * b_ld; }
+        else      b_fix[i] = (kt_begin * G_BK + kr0 + 8 * i) * b_ld;
+    }
+    if (!A_KC) { const int m = m0 + 2 * mp; a_col = m < d.M ? m : d.M - 2; }
+    if (!B_KC) { const int n = n0 + 2 * mp; b_col = n < d.N ? n : d.N - 2; }
+
+    // the "k beyond K -> 0" select is applied when the registers are written to LDS (store_tile), not where the loads are issued:
+    // a select next to the load makes the wave wait for its prefetch before the MFMAs it is supposed to overlap with
+    f32x2 ra[4], rb[4];
+    unsigned okbits = 0;             // bit i: A pass i in range, bit 4+i: B pass i
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * G_BK;
+        const bool kc_ok = k0 + 2 * kp < d.K;
+        const int kc_k = kc_ok ? k0 + 2 * kp : 0;
+        okbits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (A_KC) {
+                ra[i] = *reinterpret_cast<const f32x2*>(d.A + a_fix[i] + kc_k);
+                okbits |= (kc_ok ? 1u : 0u) << i;
+            } else {
+                const bool ok = k0 + kr0 + 8 * i < d.K;
+                ra[i] = *reinterpret_cast<const f32x2*>(d.A + (ok ? a_fix[i] : 0) + a_col);
+                okbits |= (ok ? 1u : 0u) << i;
+                a_fix[i] += G_BK * a_ld;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (B_KC) {
+                rb[i] = *reinterpret_cast<const f32x2*>(d.B + b_fix[i] + kc_k);
+                okbits |= (kc_ok ? 1u : 0u) << (4 + i);
+            } else {
+                const bool ok = k0 + kr0 + 8 * i < d.K;
+                rb[i] = *reinterpret_cast<const f32x2*>(d.B + (ok ? b_fix[i] : 0) + b_col);
+                okbits |= (ok ? 1u : 0u) << (4 + i);
+                b_fix[i] += G_BK * b_ld;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        const f32x2 zero{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 v = (okbits >> i) & 1u ? ra[i] : zero;
+            if (A_KC) *reinterpret_cast<f32x2*>(As + (r0 + 16 * i) * F_LDK + 2 * kp) = v;
+            else      *reinterpret_cast<f32x2*>(As + (kr0 + 8 * i) * G_BT + ((2 * mp) ^ f_swz(kr0))) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 v = (okbits >> (4 + i)) & 1u ? rb[i] : zero;
+            if (B_KC) *reinterpret_cast<f32x2*>(Bs + (r0 + 16 * i) * F_LDK + 2 * kp) = v;
+            else      *reinterpret_cast<f32x2*>(Bs + (kr0 + 8 * i) * G_BT + ((2 * mp) ^ f_swz(kr0))) = v;
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        const int sw = (g & 1) << 4;                     // f_swz(8r + 2g + e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float av[2][2], bv[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (A_KC) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(As + (wr * 32 + 16 * i + fr) * F_LDK + 8 * r + 2 * g);
+                    av[i][0] = v[0]; av[i][1] = v[1];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) av[i][e] = As[(8 * r + 2 * g + e) * G_BT + ((wr * 32 + 16 * i + fr) ^ sw)];
+                }
+                if (B_KC) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(Bs + (wc * 32 + 16 * i + fr) * F_LDK + 8 * r + 2 * g);
+                    bv[i][0] = v[0]; bv[i][1] = v[1];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) bv[i][e] = Bs[(8 * r + 2 * g + e) * G_BT + ((wc * 32 + 16 * i + fr) ^ sw)];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32_16x16x4(av[i][e], bv[j][e], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<C_PLAIN>(d, acc, m0, n0, wr, wc, lane, blockIdx.y == 0);
+}
+
+static inline bool is_plain(const eegclip_dim& x) { return x.div > (1LL << 40); }
+static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// operand eligibility for the fast kernel: `rows` = M or N, row / k strides in elements
+static bool fast_operand_ok(const float* p, long long row_si, long long k_si, int rows, int K, bool& kc) {
+    if (!aligned8(p) || row_si < 0 || k_si < 0) return false;
+    const long long reach = (long long)(rows - 1) * row_si + (long long)(K - 1) * k_si + 2;
+    if (reach >= (1LL << 31)) return false;
+    if (k_si == 1 && (row_si & 1) == 0 && (K & 1) == 0) { kc = true; return true; }
+    if (row_si == 1 && (k_si & 1) == 0 && (rows & 1) == 0 && rows >= 2) { kc = false; return true; }
+    return false;
+}
+
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
-    const dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.split_k);
+    const int gx = (d.N + G_BT - 1) / G_BT, gy = (d.M + G_BT - 1) / G_BT;
     const dim3 block(G_THREADS);
-    const size_t lds = G_BK * (g_ld<BM>::v + g_ld<BN>::v) * sizeof(float);
-    const bool akc = (d.Ak.si == 1), bkc = (d.Bk.si == 1);
-    const long long big = 1LL << 40;
-    const bool plain = d.Am.div > big && d.Ak.div > big && d.Bk.div > big && d.Bn.div > big && d.Cm.div > big && d.Cn.div > big &&
-                       (!d.R || (d.Rm.div > big && d.Rn.div > big));
-#define EEG_GEMM_GO(AK, BK_)                                                                                         \
-    do {                                                                                                             \
-        if (plain) EEG_LAUNCH((gemm_f32_kernel<BM, BN, AK, BK_, true>), grid, block, lds, stream, d);               \
-        else       EEG_LAUNCH((gemm_f32_kernel<BM, BN, AK, BK_, false>), grid, block, lds, stream, d);              \
+    const bool ab_plain = is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) && is_plain(d.Bn);
+    const bool c_plain = is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn)));
+    const bool plain = ab_plain && c_plain;
+    static const bool allow_fast = !(getenv("EEGCLIP_GEMM_FAST") && atoi(getenv("EEGCLIP_GEMM_FAST")) == 0);   // tuning aid
+    bool akc = false, bkc = false;
+    if (allow_fast && ab_plain && d.K >= 2 && (long long)gx * gy < (1LL << 28) && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) &&
+        fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) {
+        const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
+        const dim3 grid(8 * chunk, d.split_k);
+        static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                       // tuning aid
+        if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
+        const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
+#define EEG_FAST_GO(AK, BK_)                                                                                                         \
+    do {                                                                                                                             \
+        if (c_plain) EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);             \
+        else         EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);            \
+    } while (0)
+        if (akc && bkc)        EEG_FAST_GO(true, true);
+        else if (akc && !bkc)  EEG_FAST_GO(true, false);
+        else if (!akc && bkc)  EEG_FAST_GO(false, true);
+        else                   EEG_FAST_GO(false, false);
+#undef EEG_FAST_GO
+        return (int)hipGetLastError();
+    }
+    const dim3 grid(gx, gy, d.split_k);
+    const size_t lds = 2 * G_BK * G_BT * sizeof(float);
+    akc = (d.Ak.si == 1);
+    bkc = (d.Bk.si == 1);
+#define EEG_GEMM_GO(AK, BK_)                                                                              \
+    do {                                                                                                  \
+        if (plain) EEG_LAUNCH((gemm_f32_kernel<AK, BK_, true>), grid, block, lds, stream, d);            \
+        else       EEG_LAUNCH((gemm_f32_kernel<AK, BK_, false>), grid, block, lds, stream, d);           \
     } while (0)
     if (akc && bkc)        EEG_GEMM_GO(true, true);
     else if (akc && !bkc)  EEG_GEMM_GO(true, false);
@@ -206,18 +393,7 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_SILU) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;
-    // tile choice: 128x128 (4x4 MFMA tiles per wave, 4 MFMAs per LDS operand read) once the grid still fills the 256 CUs;
-    // 128x64 for narrow N; 64x64 for small problems where occupancy matters more than per-wave reuse.
-    const long long b128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.split_k;
-    const long long b12864 = (long long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.split_k;
-    static const int force = getenv("EEGCLIP_GEMM_TILE") ? atoi(getenv("EEGCLIP_GEMM_TILE")) : 0;   // tuning aid: 64 | 12864 | 128
-    static const long long thr = getenv("EEGCLIP_GEMM_THR") ? atoll(getenv("EEGCLIP_GEMM_THR")) : (1LL << 40);   // measured on MI355X: the 64x64 tile wins on every shape of this path (occupancy > reuse)
-    if (force == 128) return launch_gemm<128, 128>(d, stream);
-    if (force == 12864) return launch_gemm<128, 64>(d, stream);
-    if (force == 64) return launch_gemm<64, 64>(d, stream);
-    if (b128 >= thr && d.N > 64) return launch_gemm<128, 128>(d, stream);
-    if (b12864 >= thr && d.M > 64) return launch_gemm<128, 64>(d, stream);
-    return launch_gemm<64, 64>(d, stream);
+    return launch_gemm(d, stream);
 }
 
 extern "C" int eegclip_abi_version(void) { return EEGCLIP_ABI_VERSION; }

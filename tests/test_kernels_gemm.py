@@ -133,6 +133,23 @@ def test_gemm_large_tile_variants(be, M, N, K, ta, tb):
     np.testing.assert_allclose(be.host(C), ref, atol=3e-5)
 
 
+@pytest.mark.parametrize("M,N,K,split", [(2, 2, 2, 1), (130, 70, 50, 1), (64, 128, 96, 1), (250, 744, 250, 1), (72, 66, 330, 3)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_fast_path(be, M, N, K, split, ta, tb):
+    """even sizes + plain strides select gemm_f32_fast_kernel (8-byte staging, clamped edges, XCD tile order) in all four operand
+    layouts; the k tail (K % 32 != 0), ragged tile edges and split-K slices must behave exactly like the general kernel"""
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = f32(rng, *((K, M) if ta else (M, K)))
+    b = f32(rng, *((N, K) if tb else (K, N)))
+    bias, c0 = f32(rng, N), f32(rng, M, N)
+    A, B, BI, C = be.dev(a), be.dev(b), be.dev(bias), be.dev(c0 if split > 1 else np.full((M, N), np.nan, np.float32))
+    Am, Ak = (D(1), D(M)) if ta else (D(K), D(1))
+    Bk, Bn = (D(1), D(K)) if tb else (D(N), D(1))
+    run(be, mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), bias_n=be.ptr(BI), split_k=split))
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias + (c0 if split > 1 else 0)
+    np.testing.assert_allclose(be.host(C), ref, atol=3e-5 * max(1.0, np.abs(ref).max()))
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0
