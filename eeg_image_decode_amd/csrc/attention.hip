@@ -27,11 +27,37 @@ struct attn_args {
     unsigned site;
 };
 
-// cooperative coalesced load of one (64 x E) head slice into LDS [64][AT_LD], zero padded to 64 columns
-__device__ __forceinline__ void load_head(float* dst, const float* src, int ld, int E) {
-    for (int i = threadIdx.x; i < AT_L * AT_L; i += blockDim.x) {
-        const int r = i >> 6, c = i & 63;
-        dst[r * AT_LD + c] = c < E ? src[(long long)r * ld + c] : 0.f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// cooperative coalesced load of (64 x E) head slices into LDS [64][AT_LD], zero padded to 64 columns.  All N slices' global loads are
+// issued before the first LDS store (one exposed memory latency per kernel instead of one per slice); VEC2: 8-byte loads when E, the
+// row strides and the base pointers are even (the encoder: E = 62, ld = 744 / 248).
+template <int N, bool VEC2>
+__device__ __forceinline__ void load_heads(float* const (&dst)[N], const float* const (&src)[N], const int (&ld)[N], int E) {
+    const int t = threadIdx.x;
+    if (VEC2) {
+        f32x2 v[N][8];
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = t + 256 * j, r = i >> 5, c = 2 * (i & 31);
+                v[n][j] = *reinterpret_cast<const f32x2*>(src[n] + (long long)r * ld[n] + (c < E ? c : 0));
+            }
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = t + 256 * j, r = i >> 5, c = 2 * (i & 31);
+                *reinterpret_cast<f32x2*>(dst[n] + r * AT_LD + c) = c < E ? v[n][j] : f32x2{0.f, 0.f};
+            }
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+            for (int i = t; i < AT_L * AT_L; i += 256) {
+                const int r = i >> 6, c = i & 63;
+                dst[n][r * AT_LD + c] = c < E ? src[n][(long long)r * ld[n] + c] : 0.f;
+            }
     }
 }
 
@@ -129,6 +155,7 @@ __device__ __forceinline__ void store_rows(float* dst, int ld, int row0, const f
     }
 }
 
+template <bool VEC2>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const attn_args a, float* __restrict__ ctx /* (B*L, H*E) */) {
     EEG_LDS_BASE(float, lds);
     float *Qs = lds, *Ks = lds + AT_T, *Vs = lds + 2 * AT_T, *Ps = lds + 3 * AT_T;
@@ -137,9 +164,12 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const attn_args a, f
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int HE = a.H * a.E;
     const float* base = a.qkv + (long long)b * AT_L * a.ld + h * a.E;
-    load_head(Qs, base, a.ld, a.E);
-    load_head(Ks, base + HE, a.ld, a.E);
-    load_head(Vs, base + 2 * HE, a.ld, a.E);
+    {
+        float* const dst[3] = {Qs, Ks, Vs};
+        const float* const src[3] = {base, base + HE, base + 2 * HE};
+        const int lds_[3] = {a.ld, a.ld, a.ld};
+        load_heads<3, VEC2>(dst, src, lds_, a.E);
+    }
     __syncthreads();
     f32x4 s[4];
     zero4(s);
@@ -150,12 +180,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const attn_args a, f
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * g + r;
         const unsigned long long rbase = ((unsigned long long)blockIdx.x * AT_L + row) * AT_L;
+        bool keep[4] = {true, true, true, true};
+        if (a.drop_p > 0.f) dropout_keep_quad(a.seed, a.site, rbase, fr, a.drop_p, keep);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float p = s[t][r];
-            if (a.drop_p > 0.f) p = dropout_keep(a.seed, a.site, rbase + 16 * t + fr, a.drop_p) ? p * ks : 0.f;
-            Ps[row * AT_LD + 16 * t + fr] = p;
-        }
+        for (int t = 0; t < 4; ++t) Ps[row * AT_LD + 16 * t + fr] = keep[t] ? s[t][r] * ks : 0.f;
     }
     __syncthreads();                                          // P rows of this wave are complete in LDS (A-operand order on re-read)
     f32x4 o[4];
@@ -164,20 +192,26 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const attn_args a, f
     store_rows(ctx + (long long)b * AT_L * HE + h * a.E, HE, 16 * w, o, a.E, lane);
 }
 
+// Backward keeps FOUR 17 KB tiles (Q, K, V, dO) = 70 KB so two workgroups share a CU: the dropped probabilities replace V once every
+// wave has its dP, and dS replaces dO once every wave has its dV (the first version held six tiles, 104 KB, one workgroup per CU).
+template <bool VEC2>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const attn_args a, const float* __restrict__ dctx /* (B*L, H*E) */,
                                                              float* __restrict__ dqkv /* (B*L, ld) */) {
     EEG_LDS_BASE(float, lds);
-    float *Qs = lds, *Ks = lds + AT_T, *Vs = lds + 2 * AT_T, *Ds = lds + 3 * AT_T, *Ps = lds + 4 * AT_T, *Ss = lds + 5 * AT_T;
+    float *Qs = lds, *Ks = lds + AT_T, *Vs = lds + 2 * AT_T, *Ds = lds + 3 * AT_T;
+    float *Ps = Vs, *Ss = Ds;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int HE = a.H * a.E;
     const float* qbase = a.qkv + (long long)b * AT_L * a.ld + h * a.E;
     float* dqbase = dqkv + (long long)b * AT_L * a.ld + h * a.E;
-    load_head(Qs, qbase, a.ld, a.E);
-    load_head(Ks, qbase + HE, a.ld, a.E);
-    load_head(Vs, qbase + 2 * HE, a.ld, a.E);
-    load_head(Ds, dctx + (long long)b * AT_L * HE + h * a.E, HE, a.E);
+    {
+        float* const dst[4] = {Qs, Ks, Vs, Ds};
+        const float* const src[4] = {qbase, qbase + HE, qbase + 2 * HE, dctx + (long long)b * AT_L * HE + h * a.E};
+        const int lds_[4] = {a.ld, a.ld, a.ld, HE};
+        load_heads<4, VEC2>(dst, src, lds_, a.E);
+    }
     __syncthreads();
     f32x4 p[4], dp[4];
     zero4(p);
@@ -186,44 +220,52 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const attn_args a, c
     softmax_rows(p, a.scale);
     mma_rows_x_rowsT(Ds, 16 * w, Vs, dp, lane);               // dP[row][j] = sum_e dO[row][e] V[j][e]
     const float ks = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    float dsv[4][4];                                          // dS rows of this wave, parked in registers until dO is dead
+    __syncthreads();                                          // every wave is done with V: its tile becomes Pdrop
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * g + r;
         const unsigned long long rbase = ((unsigned long long)blockIdx.x * AT_L + row) * AT_L;
-        float pd[4], dd[4];
+        bool keep[4] = {true, true, true, true};
+        if (a.drop_p > 0.f) dropout_keep_quad(a.seed, a.site, rbase, fr, a.drop_p, keep);
+        float dd[4];
         float delta = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            bool keep = true;
-            if (a.drop_p > 0.f) keep = dropout_keep(a.seed, a.site, rbase + 16 * t + fr, a.drop_p);
-            pd[t] = keep ? p[t][r] * ks : 0.f;                // dropped probabilities (feed dV)
-            dd[t] = keep ? dp[t][r] * ks : 0.f;               // gradient w.r.t. the un-dropped probabilities
+            dd[t] = keep[t] ? dp[t][r] * ks : 0.f;            // gradient w.r.t. the un-dropped probabilities
             delta += p[t][r] * dd[t];
         }
         delta = group16_sum(delta);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            Ps[row * AT_LD + 16 * t + fr] = pd[t];
-            Ss[row * AT_LD + 16 * t + fr] = p[t][r] * (dd[t] - delta) * a.scale;      // dS (scale folded in)
+            Ps[row * AT_LD + 16 * t + fr] = keep[t] ? p[t][r] * ks : 0.f;             // dropped probabilities (feed dV)
+            dsv[r][t] = p[t][r] * (dd[t] - delta) * a.scale;                          // dS (scale folded in)
         }
     }
-    __syncthreads();                                          // all 64 rows of Pdrop and dS are in LDS
+    __syncthreads();                                          // all 64 rows of Pdrop are in LDS
     f32x4 acc[4];
+    zero4(acc);
+    mma_colsT_x_mat(Ps, 16 * w, Ds, acc, lane);               // dV[j][e] = sum_i Pdrop[i][j] dO[i][e]
+    store_rows(dqbase + 2 * HE, a.ld, 16 * w, acc, a.E, lane);
+    __syncthreads();                                          // every wave is done with dO: its tile becomes dS
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Ss[(16 * w + 4 * g + r) * AT_LD + 16 * t + fr] = dsv[r][t];
+    __syncthreads();
     zero4(acc);
     mma_rows_x_mat(Ss, 16 * w, Ks, acc, lane);                // dQ[row][e] = sum_j dS[row][j] K[j][e]
     store_rows(dqbase, a.ld, 16 * w, acc, a.E, lane);
     zero4(acc);
     mma_colsT_x_mat(Ss, 16 * w, Qs, acc, lane);               // dK[j][e] = sum_i dS[i][j] Q[i][e]      (rows j = 16w..)
     store_rows(dqbase + HE, a.ld, 16 * w, acc, a.E, lane);
-    zero4(acc);
-    mma_colsT_x_mat(Ps, 16 * w, Ds, acc, lane);               // dV[j][e] = sum_i Pdrop[i][j] dO[i][e]
-    store_rows(dqbase + 2 * HE, a.ld, 16 * w, acc, a.E, lane);
 }
 
 }  // namespace eeg
 
 using namespace eeg;
 
+static bool attn_aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 static int attn_check(const float* qkv, int B, int L, int H, int E, int ld, float drop_p) {
     if (!qkv || B < 1 || L != AT_L || H < 1 || E < 1 || E > 64 || ld < 3 * H * E || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     return 0;
@@ -234,7 +276,9 @@ extern "C" int eegclip_attention_fwd(const float* qkv, float* ctx, int B, int L,
     if (int rc = attn_check(qkv, B, L, H, E, ld, drop_p)) return rc;
     if (!ctx) return EEGCLIP_EINVAL;
     attn_args a{qkv, B, H, E, ld, scale, drop_p, seed, site};
-    EEG_LAUNCH(attention_fwd_kernel, dim3(B * H), dim3(256), 4 * AT_T * sizeof(float), stream, a, ctx);
+    const bool vec2 = (E % 2 == 0) && (ld % 2 == 0) && attn_aligned8(qkv);
+    if (vec2) EEG_LAUNCH(attention_fwd_kernel<true>, dim3(B * H), dim3(256), 4 * AT_T * sizeof(float), stream, a, ctx);
+    else      EEG_LAUNCH(attention_fwd_kernel<false>, dim3(B * H), dim3(256), 4 * AT_T * sizeof(float), stream, a, ctx);
     return (int)hipGetLastError();
 }
 
@@ -243,6 +287,8 @@ extern "C" int eegclip_attention_bwd(const float* qkv, const float* dctx, float*
     if (int rc = attn_check(qkv, B, L, H, E, ld, drop_p)) return rc;
     if (!dctx || !dqkv) return EEGCLIP_EINVAL;
     attn_args a{qkv, B, H, E, ld, scale, drop_p, seed, site};
-    EEG_LAUNCH(attention_bwd_kernel, dim3(B * H), dim3(256), 6 * AT_T * sizeof(float), stream, a, dctx, dqkv);
+    const bool vec2 = (E % 2 == 0) && (ld % 2 == 0) && attn_aligned8(qkv) && attn_aligned8(dctx);
+    if (vec2) EEG_LAUNCH(attention_bwd_kernel<true>, dim3(B * H), dim3(256), 4 * AT_T * sizeof(float), stream, a, dctx, dqkv);
+    else      EEG_LAUNCH(attention_bwd_kernel<false>, dim3(B * H), dim3(256), 4 * AT_T * sizeof(float), stream, a, dctx, dqkv);
     return (int)hipGetLastError();
 }

@@ -6,6 +6,8 @@
 //
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
 constexpr int TS_C = 40;     // temporal filters
@@ -168,36 +170,38 @@ __global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict
 }
 
 // ---- backward w.r.t. the taps -----------------------------------------------------------------------------------------
-constexpr int TSW_R = 9;                        // rows per work item (7 items per 63-row sample): 324 positions = 81 k-steps
-constexpr int TSW_MS = TSW_R * TS_W + 17;       // dy slab row stride (341 = 21 mod 32: skewed banks for the 16 filter rows)
+// R = token rows per work item.  LDS = dy slab [48][36R + 17] + token rows [R][256] (the cross-wave reduction tile aliases the slab):
+// R = 9: 75 KB, R = 7: 59 KB (2 workgroups per CU, 63 = 9 * 7 rows split evenly), R = 6: 51 KB (3 per CU).
+template <int R>
 __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restrict__ x, long long xs_b, long long xs_h,
                                                             const float* __restrict__ dy, float* __restrict__ partials, int B, int H) {
+    constexpr int MS = R * TS_W + 17;            // dy slab row stride (odd: skewed banks for the 16 filter rows of an operand read)
+    constexpr int NQ = (R * TS_W + 255) / 256;   // slab positions per thread
     EEG_LDS_BASE(float, lds);
-    float* dl = lds;                             // [48][TSW_MS]  dy slab, filter-major (rows >= 40 zero)
-    float* xl = dl + TS_CP * TSW_MS;             // [9][256]
-    float* red = xl + TSW_R * TS_XS;             // [48][80] cross-wave reduction
+    float* dl = lds;                             // [48][MS]  dy slab, filter-major (rows >= 40 zero)
+    float* xl = dl + TS_CP * MS;                 // [R][256]
+    float* red = dl;                             // [48][80] cross-wave reduction (after the last item)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int rows = B * H;
-    const int per = (H + TSW_R - 1) / TSW_R;     // work items per sample
+    const int per = (H + R - 1) / R;             // work items per sample
     f32x4 acc[3][5];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int ut = 0; ut < 5; ++ut) acc[ct][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = t; i < TS_CP * TSW_MS; i += blockDim.x) dl[i] = 0.f;         // pad filters 40..47 stay zero for ever
-    // software pipeline: the next work item's dy slab (up to 2 x 40 floats per thread) and token rows are loaded into registers
-    // before the MFMAs of the current item -- one workgroup per CU (LDS), so nothing else would hide the HBM latency
-    float vd[2][TS_C], vx[TSW_R];
+    for (int i = t; i < TS_CP * MS; i += blockDim.x) dl[i] = 0.f;         // pad filters 40..47 stay zero for ever
+    // software pipeline: the next work item's dy slab (NQ x 40 floats per thread) and token rows are loaded into registers
+    // before the MFMAs of the current item
+    float vd[NQ][TS_C], vx[R];
     auto load_item = [&](int item) {
-        const int b = item / per, h0 = (item % per) * TSW_R;
-        const int nr = H - h0 < TSW_R ? H - h0 : TSW_R;
+        const int b = item / per, h0 = (item % per) * R;
+        const int nr = H - h0 < R ? H - h0 : R;
         const int mc = nr * TS_W;
-        load_x_rows<TSW_R>(vx, x, xs_b, xs_h, b * H + h0, b * H + h0 + nr, H);
+        load_x_rows<R>(vx, x, xs_b, xs_h, b * H + h0, b * H + h0 + nr, H);
         const float* src = dy + (((long long)b * TS_C) * H + h0) * TS_W;      // (h, w) contiguous for a fixed (b, c): lanes walk it
         const long long cs = (long long)H * TS_W;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int m = t + 256 * q;
 #pragma unroll
             for (int c = 0; c < TS_C; ++c) vd[q][c] = m < mc ? src[c * cs + m] : 0.f;
@@ -205,17 +209,17 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
     };
     if ((int)blockIdx.x < B * per) load_item(blockIdx.x);
     for (int item = blockIdx.x; item < B * per; item += gridDim.x) {
-        const int h0 = (item % per) * TSW_R;
-        const int nr = H - h0 < TSW_R ? H - h0 : TSW_R;
+        const int h0 = (item % per) * R;
+        const int nr = H - h0 < R ? H - h0 : R;
         const int mc = nr * TS_W;                 // positions in this slab (multiple of 4)
         __syncthreads();
-        store_x_rows<TSW_R>(xl, vx);
+        store_x_rows<R>(xl, vx);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int m = t + 256 * q;
             if (m < mc) {
 #pragma unroll
-                for (int c = 0; c < TS_C; ++c) dl[c * TSW_MS + m] = vd[q][c];
+                for (int c = 0; c < TS_C; ++c) dl[c * MS + m] = vd[q][c];
             }
         }
         __syncthreads();
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
             const float* xp = xl + (m / TS_W) * TS_XS + 5 * (m % TS_W) + fr;
             float av[3], bv[5];
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) av[ct] = dl[(16 * ct + fr) * TSW_MS + m];
+            for (int ct = 0; ct < 3; ++ct) av[ct] = dl[(16 * ct + fr) * MS + m];
 #pragma unroll
             for (int ut = 0; ut < 5; ++ut) bv[ut] = xp[16 * ut];
 #pragma unroll
@@ -284,6 +288,35 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
         for (int j = 0; j < 13; ++j) { const int i = t + 256 * j; if (i < TS_C * TS_UP) wl[i] = v[j]; }
     }
     const int nitems = (rows + TSX_R - 1) / TSX_R;
+    // A slab = (work item, channel half): 16 rows x 20 channels x 36 positions.  For one channel the 16 rows are (h, w)-contiguous in dy
+    // (576 floats, split in two where the item crosses a sample), so the slab is fetched as 16-byte loads (<= 12 per thread), and the
+    // NEXT slab's loads are issued before the MFMAs of the current one: the first version staged 2 rows at a time with a full memory
+    // round trip per batch (16 serialized latencies per item -- that, not the matrix cores, set the kernel's time).
+    constexpr int NV = (TSX_CH * TSX_R * (TS_W / 4) + 255) / 256;                  // 2880 float4 / 256 threads -> 12
+    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
+    f32x4 v[NV];
+    auto load_slab = [&](int item, int half) {
+        const int row0 = item * TSX_R, b0 = row0 / H, h0 = row0 % H;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = t + 256 * j, cl = e / (TSX_R * 9), rem = e % (TSX_R * 9), rl = rem / 9, w4 = rem % 9;
+            int bb = b0, h = h0 + rl;
+            while (h >= H) { h -= H; ++bb; }
+            const bool ok = e < TSX_CH * TSX_R * 9 && row0 + rl < rows;
+            v[j] = ok ? *reinterpret_cast<const f32x4*>(dy + (((long long)bb * TS_C + half * TSX_CH + cl) * H + h) * TS_W + 4 * w4) : zero4v;
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = t + 256 * j, cl = e / (TSX_R * 9), rem = e % (TSX_R * 9), rl = rem / 9, w4 = rem % 9;
+            if (e < TSX_CH * TSX_R * 9) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dl[cl * TSX_CS + (4 * w4 + q) * TSX_WS + rl] = v[j][q];
+            }
+        }
+    };
+    if ((int)blockIdx.x < nitems) load_slab(blockIdx.x, 0);
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int row0 = item * TSX_R;
         f32x4 acc[4];
@@ -292,22 +325,10 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
         for (int half = 0; half < TS_C / TSX_CH; ++half) {
             const int cbase = half * TSX_CH;
             __syncthreads();                      // previous slab fully consumed (also orders the tap staging)
-            // stage dy[row][cbase..+19][0..35] -> dl[c][w][row]: per row 720 contiguous-by-36 floats; 2 rows x 3 loads in flight per batch
-            for (int rl0 = 0; rl0 < TSX_R; rl0 += 2) {
-                float v[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const int rl = rl0 + j / 3, i = t + 256 * (j % 3), row = row0 + rl;
-                    const bool ok = row < rows && i < TSX_CH * TS_W;
-                    v[j] = ok ? dy[(((long long)(row / H) * TS_C + cbase + i / TS_W) * H + (row % H)) * TS_W + i % TS_W] : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const int rl = rl0 + j / 3, i = t + 256 * (j % 3);
-                    if (i < TSX_CH * TS_W) dl[(i / TS_W) * TSX_CS + (i % TS_W) * TSX_WS + rl] = v[j];
-                }
-            }
+            store_slab();
             __syncthreads();
+            if (half + 1 < TS_C / TSX_CH) load_slab(item, half + 1);
+            else if (item + (int)gridDim.x < nitems) load_slab(item + gridDim.x, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = wv + 4 * q;                         // s tile: s = 16j .. 16j+15
@@ -371,20 +392,33 @@ extern "C" int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h
     return (int)hipGetLastError();
 }
 
+// rows per work item / resident workgroups per CU (tuning aid: EEGCLIP_TSW_R = 6 | 7 | 9)
+static int tsw_rows() {
+    static const int r = getenv("EEGCLIP_TSW_R") ? atoi(getenv("EEGCLIP_TSW_R")) : 7;
+    return (r == 6 || r == 9) ? r : 7;
+}
 static int tsw_grid(int B, int H) {
-    const int items = B * ((H + TSW_R - 1) / TSW_R);
-    return items < 512 ? items : 512;
+    const int r = tsw_rows();
+    const int items = B * ((H + r - 1) / r), cap = r == 6 ? 768 : 512;
+    return items < cap ? items : cap;
 }
 
 extern "C" long long eegclip_tsconv_bwd_w_workspace_floats(int B, int H) { return (long long)tsw_grid(B, H) * TS_C * TS_U; }
+
+template <int R>
+static void tsw_launch(int grid, void* stream, const float* x, long long xs_b, long long xs_h, const float* dy, float* workspace, int B, int H) {
+    const size_t lds = (TS_CP * (R * TS_W + 17) + R * TS_XS) * sizeof(float);
+    EEG_LAUNCH(tsconv_bwd_w_kernel<R>, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, dy, workspace, B, H);
+}
 
 extern "C" int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, float* workspace, int B,
                                     int H, int T, int C, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!x || !dy || !dweff || !workspace) return EEGCLIP_EINVAL;
-    const int grid = tsw_grid(B, H);
-    const size_t lds = (TS_CP * TSW_MS + TSW_R * TS_XS + TS_CP * TS_UP) * sizeof(float);
-    EEG_LAUNCH(tsconv_bwd_w_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, dy, workspace, B, H);
+    const int grid = tsw_grid(B, H), r = tsw_rows();
+    if (r == 6)      tsw_launch<6>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
+    else if (r == 9) tsw_launch<9>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
+    else             tsw_launch<7>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
     hipMemsetAsync(dweff, 0, TS_C * TS_U * sizeof(float), (hipStream_t)stream);
     EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_U + 255) / 256, grid < 32 ? grid : 32), dim3(256), 0, stream, workspace, grid, dweff);
     return (int)hipGetLastError();
@@ -394,6 +428,7 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* d
                                     int C, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!dy || !weff || !dx) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dy) & 15u) return EEGCLIP_EALIGN;
     const int items = (B * H + TSX_R - 1) / TSX_R;
     int grid = items < 1024 ? items : 1024;
     const size_t lds = (TS_C * TS_UP + TSX_CH * TSX_CS) * sizeof(float);

@@ -144,6 +144,33 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned s
     return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// value held by lane T of the caller's quad (lanes 4q..4q+3): one DPP move, no LDS crossbar
+template <int T>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+#if defined(EEG_EMU)
+    return hipemu::shfl_idx(v, (hipemu::cur->lane & ~3) | T);
+#else
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, T * 0x55, 0xF, 0xF, true);      // quad_perm [T,T,T,T]
+#endif
+}
+// dropout_keep() for the four elements base + 16 t + fr (t = 0..3; base % 4 == 0, fr = lane & 15) of a 16-lane row group, bit-identical
+// to four dropout_keep calls: element (t, fr) lives in Philox block (base >> 2) + 4t + (fr >> 2), word fr & 3, so the four lanes of a
+// quad run ONE block each (lane j takes t = j) and trade words -- 4x fewer Philox evaluations in the attention kernels
+__device__ __forceinline__ void dropout_keep_quad(unsigned long long seed, unsigned site, unsigned long long base, int fr, float p, bool (&keep)[4]) {
+    const int q = fr >> 2, j = fr & 3;
+    const philox4 r = philox4x32_10(seed, (base >> 2) + 4 * j + q, site);
+    unsigned bits[4];
+#define EEG_QUAD_PICK(T)                                                                                      \
+    {                                                                                                         \
+        const unsigned x = quad_bcast<T>(r.x), y = quad_bcast<T>(r.y), z = quad_bcast<T>(r.z), w = quad_bcast<T>(r.w); \
+        bits[T] = j == 0 ? x : j == 1 ? y : j == 2 ? z : w;                                                   \
+    }
+    EEG_QUAD_PICK(0) EEG_QUAD_PICK(1) EEG_QUAD_PICK(2) EEG_QUAD_PICK(3)
+#undef EEG_QUAD_PICK
+#pragma unroll
+    for (int t = 0; t < 4; ++t) keep[t] = (float)(bits[t] >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -156,5 +183,15 @@ __device__ __forceinline__ float silu_grad(float x) {
     return sg * (1.0f + x * (1.0f - sg));
 }
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU for the fused spatial stage, evaluated 23 M times per pass inside operand staging: hardware exp2 (v_exp_f32) instead of the
+// ~40-instruction expm1f; absolute error <= 2e-7 (the subtraction only loses RELATIVE precision near 0, where ELU(x) ~ x ~ 0)
+__device__ __forceinline__ float fast_exp(float x) {
+#if defined(EEG_EMU)
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+__device__ __forceinline__ float elu1_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.0f; }
 
 }  // namespace eeg
