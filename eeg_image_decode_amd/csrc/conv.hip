@@ -271,12 +271,13 @@ __global__ void tsconv_bwd_w_reduce_kernel(const float* __restrict__ partials, i
 constexpr int TSX_R = 16;                       // EEG rows per work item = MFMA M
 constexpr int TSX_WS = 17;                      // floats per (c, w) cell: 16 rows + 1 pad -> conflict-free staging writes
 constexpr int TSX_CS = 624;                     // floats per channel: 36*17 = 612 padded to 16 (mod 32) for the operand reads
-constexpr int TSX_CH = 20;                      // channels per LDS pass (two passes: keeps 2 workgroups per CU)
-__global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
-                                                            float* __restrict__ dx, long long xs_b, long long xs_h, int B, int H) {
+// CH = channels per LDS slab: 20 (2 slabs per item, 63 KB: 2 workgroups per CU) or 8 (5 slabs, 33 KB: 4 per CU)
+template <int CH>
+__global__ __launch_bounds__(256, CH == 20 ? 2 : 4) void tsconv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
+                                                                            float* __restrict__ dx, long long xs_b, long long xs_h, int B, int H) {
     EEG_LDS_BASE(float, lds);
     float* wl = lds;                             // [40][80]  filter-major taps (cols >= 75 zero)
-    float* dl = wl + TS_C * TS_UP;               // [20][TSX_CS]  dy slab: dl[c][w][row]
+    float* dl = wl + TS_C * TS_UP;               // [CH][TSX_CS]  dy slab: dl[c][w][row]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
@@ -288,32 +289,48 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
         for (int j = 0; j < 13; ++j) { const int i = t + 256 * j; if (i < TS_C * TS_UP) wl[i] = v[j]; }
     }
     const int nitems = (rows + TSX_R - 1) / TSX_R;
-    // A slab = (work item, channel half): 16 rows x 20 channels x 36 positions.  For one channel the 16 rows are (h, w)-contiguous in dy
-    // (576 floats, split in two where the item crosses a sample), so the slab is fetched as 16-byte loads (<= 12 per thread), and the
-    // NEXT slab's loads are issued before the MFMAs of the current one: the first version staged 2 rows at a time with a full memory
-    // round trip per batch (16 serialized latencies per item -- that, not the matrix cores, set the kernel's time).
-    constexpr int NV = (TSX_CH * TSX_R * (TS_W / 4) + 255) / 256;                  // 2880 float4 / 256 threads -> 12
+    // A slab = (work item, CH channels): 16 rows x CH channels x 36 positions.  For one channel the 16 rows are (h, w)-contiguous in
+    // dy (144 float4, split in two where the item crosses a sample), so the slab is fetched as 16-byte loads, and the NEXT slab's
+    // loads are issued before the MFMAs of the current one: the first version staged 2 rows at a time with a full memory round trip
+    // per batch (16 serialized latencies per item -- that, not the matrix cores, set the kernel's time).
+    // Thread -> float4 map: NT active threads, element e = t + NT * j with NT = 240 (CH 20) / 192 (CH 8): NT * 3 is a whole number
+    // of channels (5 / 4), so j = 3m + r needs only THREE (channel, row, w) decodes per thread, m adds a constant LDS / HBM offset
+    // (a t + 256 j map made every one of the 12 decodes loop invariant: 268 VGPRs, one wave per SIMD).
+    constexpr int NT = CH == 20 ? 240 : 192, MCH = NT * 3 / 144, NM = CH / MCH;
+    static_assert(MCH * NM == CH && CH % 4 == 0 && TS_C % CH == 0, "slab shape");
     const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    f32x4 v[NV];
-    auto load_slab = [&](int item, int half) {
-        const int row0 = item * TSX_R, b0 = row0 / H, h0 = row0 % H;
+    int e_rl[3], e_lds[3], e_gl[3];              // per r: row in the item, LDS float offset, dy float offset relative to (b0, c0, h0)
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int e = t + 256 * j, cl = e / (TSX_R * 9), rem = e % (TSX_R * 9), rl = rem / 9, w4 = rem % 9;
-            int bb = b0, h = h0 + rl;
-            while (h >= H) { h -= H; ++bb; }
-            const bool ok = e < TSX_CH * TSX_R * 9 && row0 + rl < rows;
-            v[j] = ok ? *reinterpret_cast<const f32x4*>(dy + (((long long)bb * TS_C + half * TSX_CH + cl) * H + h) * TS_W + 4 * w4) : zero4v;
+    for (int r = 0; r < 3; ++r) {
+        const int e = t + NT * r, cl = e / 144, rem = e % 144, rl = rem / 9, w4 = rem % 9;
+        e_rl[r] = rl;
+        e_lds[r] = cl * TSX_CS + 4 * w4 * TSX_WS + rl;
+        e_gl[r] = (cl * H + rl) * TS_W + 4 * w4;
+    }
+    f32x4 v[NM][3];
+    auto load_slab = [&](int item, int sl) {
+        const int row0 = item * TSX_R, b0 = row0 / H, h0 = row0 % H;
+        const float* base = dy + (((long long)b0 * TS_C + sl * CH) * H + h0) * TS_W;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            // row h0 + rl of sample b0, or -- past the sample's last row -- row h0 + rl - k H of sample b0 + k: + k * 39 H rows
+            int wraps = 0;
+            if (H >= TSX_R) wraps = h0 + e_rl[r] >= H ? 1 : 0;
+            else wraps = (h0 + e_rl[r]) / H;
+            const bool ok = t < NT && row0 + e_rl[r] < rows;
+            const float* p = base + e_gl[r] + (long long)wraps * (TS_C - 1) * H * TS_W;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) v[m][r] = ok ? *reinterpret_cast<const f32x4*>(p + (long long)m * MCH * H * TS_W) : zero4v;
         }
     };
     auto store_slab = [&]() {
+        if (t < NT) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int e = t + 256 * j, cl = e / (TSX_R * 9), rem = e % (TSX_R * 9), rl = rem / 9, w4 = rem % 9;
-            if (e < TSX_CH * TSX_R * 9) {
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dl[cl * TSX_CS + (4 * w4 + q) * TSX_WS + rl] = v[j][q];
-            }
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dl[e_lds[r] + m * MCH * TSX_CS + q * TSX_WS] = v[m][r][q];
         }
     };
     if ((int)blockIdx.x < nitems) load_slab(blockIdx.x, 0);
@@ -322,12 +339,12 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int half = 0; half < TS_C / TSX_CH; ++half) {
-            const int cbase = half * TSX_CH;
+        for (int sl = 0; sl < TS_C / CH; ++sl) {
+            const int cbase = sl * CH;
             __syncthreads();                      // previous slab fully consumed (also orders the tap staging)
             store_slab();
             __syncthreads();
-            if (half + 1 < TS_C / TSX_CH) load_slab(item, half + 1);
+            if (sl + 1 < TS_C / CH) load_slab(item, sl + 1);
             else if (item + (int)gridDim.x < nitems) load_slab(item + gridDim.x, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256) void tsconv_bwd_x_kernel(const float* __restri
                     const int u = s - 5 * w;
                     const bool inb = u >= 0 && u < TS_U;
 #pragma unroll
-                    for (int cc = 0; cc < TSX_CH / 4; ++cc) {
+                    for (int cc = 0; cc < CH / 4; ++cc) {
                         const int cl = 4 * cc + g;
                         const float a = dl[cl * TSX_CS + w * TSX_WS + fr];                     // A[row = fr][k = (w, c)]
                         const float bq = inb ? wl[(cbase + cl) * TS_UP + u] : 0.f;             // B[k][s] = weff[c][s - 5w]
@@ -429,9 +446,15 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* d
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!dy || !weff || !dx) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(dy) & 15u) return EEGCLIP_EALIGN;
+    if ((long long)B * TS_C * H * TS_W >= (1LL << 31)) return EEGCLIP_EINVAL;
     const int items = (B * H + TSX_R - 1) / TSX_R;
-    int grid = items < 1024 ? items : 1024;
-    const size_t lds = (TS_C * TS_UP + TSX_CH * TSX_CS) * sizeof(float);
-    EEG_LAUNCH(tsconv_bwd_x_kernel, dim3(grid), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);
+    static const int ch = getenv("EEGCLIP_TSX_CH") ? atoi(getenv("EEGCLIP_TSX_CH")) : 20;      // tuning aid: 20 | 8
+    if (ch == 8) {
+        const size_t lds = (TS_C * TS_UP + 8 * TSX_CS) * sizeof(float);
+        EEG_LAUNCH(tsconv_bwd_x_kernel<8>, dim3(items < 1024 ? items : 1024), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);
+    } else {
+        const size_t lds = (TS_C * TS_UP + 20 * TSX_CS) * sizeof(float);
+        EEG_LAUNCH(tsconv_bwd_x_kernel<20>, dim3(items < 1024 ? items : 1024), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);
+    }
     return (int)hipGetLastError();
 }
