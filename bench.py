@@ -194,6 +194,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (no sync inside a step): must stay below the GPU time
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -240,7 +241,8 @@ def main():
         "config": {"workload": "configs[1]: full ATM-S EEG encoder (63ch x 250t -> 1024-d) contrastive train step vs frozen 1024-d CLIP "
                                "embeddings, 256 samples/GPU" + (f", global batch {world * B} with RCCL all-gather negatives (configs[2])" if world > 1 else ""),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "n_classes_for_accuracy": N_CLASSES,
-                   "optimizer": "AdamW lr 3e-4 (fused)", "final_mean_loss": round(final_loss, 4)},
+                   "optimizer": "AdamW lr 3e-4 (fused)", "final_mean_loss": round(final_loss, 4),
+                   "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4)},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

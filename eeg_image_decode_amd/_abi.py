@@ -25,10 +25,11 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("accumulate", C.c_int), ("act", C.c_int),
         ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("drop_site", C.c_uint),
         ("split_k", C.c_int),
+        ("rowsum_a", C.c_void_p),
     ]
 
 
-ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -37,7 +38,7 @@ PROTOTYPES = {
     "eegclip_abi_version": [],
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
-    "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P],
     "eegclip_layernorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_silu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],
     "eegclip_timestep_embedding": [_P, _I, _I, _P, _P],
@@ -45,7 +46,7 @@ PROTOTYPES = {
     "eegclip_ddpm_step": [_P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _L, _P],
     "eegclip_mse_loss_grad": [_P, _P, _L, _P, _P, _P],
     "eegclip_bn_stats": [_P, _I, _I, _I, _P, _P],
-    "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P],
+    "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P, _P],
     "eegclip_bn_elu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_bn_elu_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],

@@ -26,6 +26,7 @@ from .plan import Plan
 
 D = _abi.dim
 ACT_GELU = _abi.ACT_GELU
+ACT_GELU_GRAD = _abi.ACT_GELU_GRAD
 
 N_CH, T_LEN, D_MODEL, N_HEADS, D_HEAD, D_FF = 63, 250, 250, 4, 62, 256
 L_TOK = N_CH + 1
@@ -351,10 +352,17 @@ class _Engine:
             h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
             f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
             weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
-            feat=f(B, F_TS), hacc=f(2, B, P_DIM), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
-            sums=torch.zeros(4, 2 * C_TS, dtype=torch.float64, device=dev), bn=f(4, C_TS),
-            ids=torch.zeros(B, dtype=torch.long, device=dev),
+            feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
+            bn=f(4, C_TS), ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
+        # everything a plan must clear before use lives in two arenas (forward / backward): ONE memset each instead of five
+        nsum = 2 * 2 * C_TS                                        # two BatchNorm sum rows of 2C doubles per direction
+        zf = torch.zeros(nsum + B * P_DIM, dtype=torch.float64, device=dev)              # fwd: sums[0..1] | hacc (2,B,P_DIM) f32
+        zb = torch.zeros(nsum + (B * P_DIM + B * F_TS + 1) // 2, dtype=torch.float64, device=dev)   # bwd: sums[2..3] | dgu | dfeat
+        sf, sb = zf[:nsum].view(2, 2 * C_TS), zb[:nsum].view(2, 2 * C_TS)
+        zbf = zb[nsum:].view(torch.float32)
+        b.update(zf=zf, zb=zb, sums=[sf[0], sf[1], sb[0], sb[1]], hacc=zf[nsum:].view(torch.float32).view(2, B, P_DIM),
+                 dgu=zbf[:B * P_DIM].view(B, P_DIM), dfeat=zbf[B * P_DIM:B * P_DIM + B * F_TS].view(B, F_TS))
         return b
 
     def _alloc_bwd(self, B, b):
@@ -364,8 +372,11 @@ class _Engine:
             return torch.empty(*s, dtype=torch.float32, device=dev)
 
         R = B * L_TOK
-        b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dgu=f(B, P_DIM), dfeat=f(B, F_TS), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
-                 dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75), dn3=f(B, L_TOK, D_MODEL),
+        b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
+                 dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75),
+                 # tsconv_bwd_x writes token rows 0..62 of every sample; row 63 (EEG channel 62, dropped by the reference's [:, :63]
+                 # slice) never receives a gradient from the conv path: zeroed once here, nothing else ever writes dn3
+                 dn3=torch.zeros(B, L_TOK, D_MODEL, dtype=torch.float32, device=dev),
                  dn2=f(R, D_MODEL), dr2=f(R, D_MODEL), df2=f(R, D_MODEL), dg1=f(R, D_FF), dr1=f(R, D_MODEL), da1=f(R, D_MODEL),
                  dctx=f(R, HE), dqkv=f(R, 3 * HE))
 
@@ -404,14 +415,15 @@ class _Engine:
         # A4+A5: tokens 0..62 -> fused conv+pool (75 taps, stride 5) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
         pl.call("eegclip_tsconv_fold", _p(P[_TS + "0.weight"]), _p(b["weff"]))
-        pl.memset(sums)
+        pl.memset(b["zf"])
         pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["weff"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
                 C_TS, _p(sums[0]) if train else None)
         W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
         pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
-                _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train))
+                _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train),
+                _p(self.buffers[_TS + "2.num_batches_tracked"]))
         # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
         # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
         pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
@@ -419,7 +431,8 @@ class _Engine:
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
-                _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train))
+                _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train),
+                _p(self.buffers[_TS + "5.num_batches_tracked"]))
         pl.call("eegclip_bn_elu_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["z2"]), B, C_TS,
                 W_TS, pc_, 0, SITE_CONV, seed_at=10)
         # 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e]      (:113-114,145)
@@ -429,7 +442,6 @@ class _Engine:
         # serially, so the products are split over K (atomics into a zeroed buffer) and bias/GELU/dropout/residual run as a tiny epilogue.
         skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
         if skh > 1:
-            pl.memset(b["hacc"])
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
                     accumulate=1, split_k=skh)
             pl.call("eegclip_bias_act", _p(b["hacc"][0]), _p(P["proj_eeg.0.bias"]), _p(b["u"]), None, _p(b["gu"]), B, P_DIM, ACT_GELU, 0.0, 0, 0)
@@ -455,42 +467,33 @@ class _Engine:
         sums, bn = b["sums"], b["bn"]
         sk = lambda k: max(1, min(64, k // 512))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
-        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K):
-            """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major"""
-            pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K))
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None):
+            """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major; bias: G[bias] (Nout) += column sums of dY, taken
+            from the A tiles the same launch stages (rowsum_a) instead of a separate pass over dY"""
+            pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
+                    rowsum_a=_p(G[bias]) if bias else None)
 
-        def bgrad(name, dY, rows, cols):
-            pl.call("eegclip_reduce_mid", dY, rows, cols, 1, _p(G[name]))
-
+        pl.memset(b["zb"])                        # BatchNorm backward sums + the split-K accumulators dgu / dfeat
         # head LayerNorm
         pl.dout_op = len(pl.ops)
+        # s = u + dropout(W4 gelu(u) + b4): the LayerNorm backward writes ds and dv = ds * mask / (1 - p) in one pass
         pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
-                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0)
-        # s = u + dropout(W4 gelu(u) + b4)
-        pl.call("eegclip_axpby", _p(b["ds"]), _p(b["dv"]), B * P_DIM, 1.0, 0.0)
-        if pp_ > 0:
-            pl.call("eegclip_dropout_scale", _p(b["dv"]), B * P_DIM, pp_, 0, SITE_PROJ, seed_at=3)
-        bgrad("proj_eeg.1.fn.1.bias", _p(b["dv"]), B, P_DIM)
-        wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B)
+                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
+        wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
         skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
-        if skh > 1:
-            pl.memset(b["dgu"])
-            pl.memset(b["dfeat"])
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
                 accumulate=int(skh > 1), split_k=skh)
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
-        bgrad("proj_eeg.0.bias", _p(b["ds"]), B, P_DIM)
-        wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B)
+        wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
         pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
                 accumulate=int(skh > 1), split_k=skh)
         # 1x1 conv: dfeat is [(b,w)][e]
-        bgrad("enc_eeg.0.projection.0.bias", _p(b["dfeat"]), B * W_TS, C_TS)
         pl.gemm(C_TS, C_TS, B * W_TS, _p(b["dfeat"]), D(1), D(C_TS), _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS),
-                _p(G["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1), accumulate=1, split_k=sk(B * W_TS * 8))
+                _p(G["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1), accumulate=1, split_k=sk(B * W_TS * 8),
+                rowsum_a=_p(G["enc_eeg.0.projection.0.bias"]))
         pl.gemm(B * W_TS, C_TS, C_TS, _p(b["dfeat"]), D(C_TS), D(1), _p(P["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1),
                 _p(b["dz2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS))
         # BN2 + ELU + dropout backward
-        pl.memset(sums)
         W = self._world()
         self._bn_bwd(pl, W, b["dz2"], b["y2"], bn[2], bn[3], _TS + "5.", sums[2], b["dy2"], B, W_TS, pc_, SITE_CONV)
         # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
@@ -516,46 +519,39 @@ class _Engine:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS)
         pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))
-        pl.memset(b["dn3"])                       # token row 63 (EEG channel 62) gets no gradient from the conv path
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(b["weff"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
         pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
-                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0)
+                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0)
+        # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2).  LN2 backward emits dr2 (residual path) and df2 = dropout'(dr2);
+        # bias gradients ride on the weight-gradient GEMMs; dropout' and gelu' of the hidden activation are the epilogue of the GEMM
+        # that produces its gradient -- 5 elementwise / reduction passes over (B*64, 250..256) tensors gone
         pl.call("eegclip_layernorm_bwd", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
-                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0)
-        # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2)
-        pl.call("eegclip_axpby", _p(b["dr2"]), _p(b["df2"]), R * D_MODEL, 1.0, 0.0)
-        if pe_ > 0:
-            pl.call("eegclip_dropout_scale", _p(b["df2"]), R * D_MODEL, pe_, 0, SITE_FFN_OUT, seed_at=3)
-        bgrad(_LY + "conv2.bias", _p(b["df2"]), R, D_MODEL)
-        wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R)
-        pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1))
-        pl.call("eegclip_gelu_bwd", _p(b["dg1"]), _p(b["f1"]), _p(b["dg1"]), R * D_FF, 0, pe_, 0, SITE_FFN_ACT, seed_at=6)   # in place: df1
-        bgrad(_LY + "conv1.bias", _p(b["dg1"]), R, D_FF)
-        wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R)
+                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, seed_at=13)
+        wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
+        pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
+                act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT)                  # dg1 := df1
+        wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
         pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
                 accumulate=1)                                                                  # dr2 := dn1
-        pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
-                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0)
         # attention block: r1 = h + dropout(Wo ctx + bo)
-        pl.call("eegclip_axpby", _p(b["dr1"]), _p(b["da1"]), R * D_MODEL, 1.0, 0.0)
-        if pe_ > 0:
-            pl.call("eegclip_dropout_scale", _p(b["da1"]), R * D_MODEL, pe_, 0, SITE_ATTN_OUT, seed_at=3)
-        bgrad(_LY + "attention.out_projection.bias", _p(b["da1"]), R, D_MODEL)
-        wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R)
+        pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
+                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, seed_at=13)
+        wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
+              bias=_LY + "attention.out_projection.bias")
         pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1))
         pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                 pe_, 0, SITE_ATTN, seed_at=10)
-        bgrad(_LY + "attention.query_projection.bias", _p(b["dqkv"]), R, 3 * HE)              # q|k|v biases are adjacent
-        wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R)
+        wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
+              bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
         pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
                 _p(b["dr1"]), D(D_MODEL), D(1), accumulate=1)                                   # dr1 := dh
         # embedding: dropout + token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
         pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
-        pl.call("eegclip_colsum_blocks", _p(b["dr1"]), B, L_TOK, 1, D_MODEL, L_TOK * D_MODEL, _p(G[_E + "value_embedding.bias"]))
         pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), 0, D(T_LEN), D(1),
-                _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH))
+                _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH),
+                rowsum_a=_p(G[_E + "value_embedding.bias"]))      # bias gradient = sum of the 63 channel rows of every sample
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
             pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1),
@@ -609,9 +605,6 @@ class _Engine:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and max(probs) > 0 else 0
         b["seed"] = seed
         pl.run(torch.cuda.current_stream().cuda_stream, seed)
-        if train:
-            self.buffers[_TS + "2.num_batches_tracked"].add_(1)
-            self.buffers[_TS + "5.num_batches_tracked"].add_(1)
         self.last_key = key
         self.version[key] = self.version.get(key, 0) + 1
         return b["out"]

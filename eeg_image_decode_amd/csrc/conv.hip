@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
     EEG_LDS_BASE(float, lds);
     float* dl = lds;                             // [48][MS]  dy slab, filter-major (rows >= 40 zero)
     float* xl = dl + TS_CP * MS;                 // [R][256]
-    float* red = dl;                             // [48][80] cross-wave reduction (after the last item)
+    float* red = dl;                             // 2 x [48][84] cross-wave reduction scratch (after the last item)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int per = (H + R - 1) / R;             // work items per sample
@@ -238,18 +238,46 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
                 for (int ut = 0; ut < 5; ++ut) acc[ct][ut] = mfma_f32_16x16x4(av[ct], bv[ut], acc[ct][ut]);   // D[c][u]
         }
     }
-    __syncthreads();
-    for (int i = t; i < TS_CP * TS_UP; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
+    // cross-wave sum of the four position-partial accumulator sets: two-level tree through LDS with plain stores (60 ds_add_f32 per
+    // lane into one shared tile cost ~170 LDS cycles per wave instruction: a third of this kernel's time at 2 workgroups per CU)
+    constexpr int RLD = 84;                      // 4 accumulator row groups land 16 banks apart
+    auto put = [&](float* reg) {
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int ut = 0; ut < 5; ++ut)
+            for (int ut = 0; ut < 5; ++ut)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * ct + 4 * g + r) * TS_UP + 16 * ut + fr, acc[ct][ut][r]);
+                for (int r = 0; r < 4; ++r) reg[(16 * ct + 4 * g + r) * RLD + 16 * ut + fr] = acc[ct][ut][r];
+    };
+    auto add = [&](const float* reg) {
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int ut = 0; ut < 5; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ct][ut][r] += reg[(16 * ct + 4 * g + r) * RLD + 16 * ut + fr];
+    };
+    static_assert(2 * TS_CP * RLD <= TS_CP * MS + R * TS_XS, "reduction scratch must fit in the operand tiles");
     __syncthreads();
-    float* out = partials + (long long)blockIdx.x * (TS_C * TS_U);
-    for (int i = t; i < TS_C * TS_U; i += blockDim.x) out[i] = red[(i / TS_U) * TS_UP + (i % TS_U)];
+    if (wv >= 2) put(red + (wv - 2) * TS_CP * RLD);
+    __syncthreads();
+    if (wv < 2) add(red + wv * TS_CP * RLD);
+    __syncthreads();
+    if (wv == 1) put(red);
+    __syncthreads();
+    if (wv == 0) {
+        add(red);
+        float* out = partials + (long long)blockIdx.x * (TS_C * TS_U);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int ut = 0; ut < 5; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * ct + 4 * g + r, u = 16 * ut + fr;
+                    if (c < TS_C && u < TS_U) out[c * TS_U + u] = acc[ct][ut][r];
+                }
+    }
 }
 
 // dweff[i] += sum over a slice of the workgroup partials (grid.y slices; dweff zeroed by the launcher): 3000 x 16 threads keep
@@ -448,7 +476,7 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* d
     if (reinterpret_cast<uintptr_t>(dy) & 15u) return EEGCLIP_EALIGN;
     if ((long long)B * TS_C * H * TS_W >= (1LL << 31)) return EEGCLIP_EINVAL;
     const int items = (B * H + TSX_R - 1) / TSX_R;
-    static const int ch = getenv("EEGCLIP_TSX_CH") ? atoi(getenv("EEGCLIP_TSX_CH")) : 20;      // tuning aid: 20 | 8
+    static const int ch = getenv("EEGCLIP_TSX_CH") ? atoi(getenv("EEGCLIP_TSX_CH")) : 8;       // tuning aid: 20 | 8 (measured 78 / 66 us)
     if (ch == 8) {
         const size_t lds = (TS_C * TS_UP + 8 * TSX_CS) * sizeof(float);
         EEG_LAUNCH(tsconv_bwd_x_kernel<8>, dim3(items < 1024 ? items : 1024), dim3(256), lds, stream, dy, weff, dx, xs_b, xs_h, B, H);

@@ -144,6 +144,16 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned s
     return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// dropout_keep() for the 4 consecutive elements idx4 .. idx4+3 (idx4 % 4 == 0): they share ONE Philox block
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned site, unsigned long long idx4, float p, bool (&keep)[4]) {
+    const philox4 r = philox4x32_10(seed, idx4 >> 2, site);
+    const float k = 1.0f / 16777216.0f;
+    keep[0] = (float)(r.x >> 8) * k >= p;
+    keep[1] = (float)(r.y >> 8) * k >= p;
+    keep[2] = (float)(r.z >> 8) * k >= p;
+    keep[3] = (float)(r.w >> 8) * k >= p;
+}
+
 // value held by lane T of the caller's quad (lanes 4q..4q+3): one DPP move, no LDS crossbar
 template <int T>
 __device__ __forceinline__ unsigned quad_bcast(unsigned v) {

@@ -13,23 +13,29 @@ static inline int ew_grid(long long n, int block = 256, int cap = 4096) {
 
 // h: (B, L, D).  Row 0 of every sample <- subject token (table[ids[b]] or the shared token), then inverted dropout
 // over the whole (B,L,D) block in place.            (models/subject_layers/Embed.py:116-121,158-162)
+// Both embedding kernels walk the (B, L, D) tensor in groups of 4 consecutive elements (n % 4 == 0 required by the launcher): one
+// 16-byte access and ONE Philox block per group instead of four of each.
 __global__ __launch_bounds__(256) void embed_finish_kernel(float* __restrict__ h, const float* __restrict__ tokens,
                                                             const long long* __restrict__ ids, int B, int L, int D, float drop_p,
                                                             unsigned long long seed, unsigned site) {
-    const long long n = (long long)B * L * D;
+    const long long n4 = (long long)B * L * D / 4;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int l = (int)((i / D) % L);
-        float v;
-        if (l == 0) {
-            const int b = (int)(i / ((long long)D * L));
-            v = tokens[(ids ? ids[b] : 0) * D + d];
-        } else {
-            v = h[i];
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const long long i0 = 4 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(h + i0);
+        bool keep[4] = {true, true, true, true};
+        if (drop_p > 0.f) dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = i0 + e;
+            const int l = (int)((i / D) % L);
+            if (l == 0) {
+                const int b = (int)(i / ((long long)D * L));
+                v[e] = tokens[(ids ? ids[b] : 0) * D + (int)(i % D)];
+            }
+            v[e] = keep[e] ? v[e] * ks : 0.f;
         }
-        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
-        h[i] = v;
+        *reinterpret_cast<f32x4*>(h + i0) = v;
     }
 }
 
@@ -37,19 +43,27 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(float* __restrict__ h
 __global__ __launch_bounds__(256) void embed_finish_bwd_kernel(float* __restrict__ dh, float* __restrict__ dtokens,
                                                                 const long long* __restrict__ ids, int B, int L, int D, float drop_p,
                                                                 unsigned long long seed, unsigned site) {
-    const long long n = (long long)B * L * D;
+    const long long n4 = (long long)B * L * D / 4;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = dh[i];
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const long long i0 = 4 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(dh + i0);
         if (drop_p > 0.f) {
-            v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
-            dh[i] = v;
+            bool keep[4];
+            dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ks : 0.f;
+            *reinterpret_cast<f32x4*>(dh + i0) = v;
         }
-        const int l = (int)((i / D) % L);
-        if (l == 0 && dtokens) {
-            const int d = (int)(i % D);
-            const int b = (int)(i / ((long long)D * L));
-            atomicAdd(dtokens + (ids ? ids[b] : 0) * D + d, v);
+        if (dtokens) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long i = i0 + e;
+                if ((int)((i / D) % L) == 0) {
+                    const int b = (int)(i / ((long long)D * L));
+                    atomicAdd(dtokens + (ids ? ids[b] : 0) * D + (int)(i % D), v[e]);
+                }
+            }
         }
     }
 }
@@ -202,7 +216,9 @@ extern "C" int eegclip_clip_scale(const double* sumsq, float max_norm, float* sc
 extern "C" int eegclip_embed_finish(float* h, const float* tokens, const long long* ids, int B, int L, int D, float drop_p,
                                     unsigned long long seed, unsigned site, void* stream) {
     if (!h || !tokens || B < 1 || L < 1 || D < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(embed_finish_kernel, dim3(ew_grid((long long)B * L * D)), dim3(256), 0, stream, h, tokens, ids, B, L, D, drop_p, seed,
+    if (((long long)L * D) % 4 != 0) return EEGCLIP_EINVAL;                 // 4-element groups never straddle the end of the tensor
+    if (reinterpret_cast<uintptr_t>(h) & 15u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(embed_finish_kernel, dim3(ew_grid((long long)B * L * D / 4)), dim3(256), 0, stream, h, tokens, ids, B, L, D, drop_p, seed,
                site);
     return (int)hipGetLastError();
 }
@@ -210,7 +226,9 @@ extern "C" int eegclip_embed_finish(float* h, const float* tokens, const long lo
 extern "C" int eegclip_embed_finish_bwd(float* dh, float* dtokens, const long long* ids, int B, int L, int D, float drop_p,
                                         unsigned long long seed, unsigned site, void* stream) {
     if (!dh || B < 1 || L < 1 || D < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(embed_finish_bwd_kernel, dim3(ew_grid((long long)B * L * D)), dim3(256), 0, stream, dh, dtokens, ids, B, L, D, drop_p,
+    if (((long long)L * D) % 4 != 0) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dh) & 15u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(embed_finish_bwd_kernel, dim3(ew_grid((long long)B * L * D / 4)), dim3(256), 0, stream, dh, dtokens, ids, B, L, D, drop_p,
                seed, site);
     return (int)hipGetLastError();
 }

@@ -60,7 +60,8 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
                 else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
                 if (d.drop_p > 0.f)
                     v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
-                if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
+                if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)]);
+                else if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
                 if (d.accumulate) v += d.C[coff];
                 d.C[coff] = v;
             }
@@ -149,11 +150,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool do_rowsum = d.rowsum_a != nullptr && blockIdx.x == 0;
+    float rowsum = 0.f;
     if (kt_begin < kt_end) load_tile(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         store_tile();
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);     // global -> registers, in flight under the MFMAs of tile kt
+        if (do_rowsum && t < G_BT) {                // first wave of the n = 0 tiles: row sums of the staged A tile (bias gradients)
+#pragma unroll
+            for (int k = 0; k < G_BK; ++k) rowsum += As[k * G_BT + (t ^ g_swz(k))];
+        }
         const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
         for (int kk = 0; kk < G_BK / 4; ++kk) {
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
         }
         __syncthreads();
     }
+    if (do_rowsum && t < G_BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
     gemm_epilogue<PLAIN>(d, acc, m0, n0, wr, wc, lane, blockIdx.z == 0);
 }
 
@@ -284,11 +292,25 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool do_rowsum = d.rowsum_a != nullptr && n0 == 0;
+    float rowsum = 0.f;
     if (kt_begin < kt_end) load_tile(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         store_tile();
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
+        if (do_rowsum && t < G_BT) {                     // first wave of the n = 0 tiles: row sums of the staged A tile (bias gradients)
+            if (A_KC) {
+#pragma unroll
+                for (int k = 0; k < G_BK; k += 2) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(As + t * F_LDK + k);
+                    rowsum += v[0] + v[1];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < G_BK; ++k) rowsum += As[k * G_BT + (t ^ f_swz(k))];
+            }
+        }
         const int sw = (g & 1) << 4;                     // f_swz(8r + 2g + e)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -319,6 +341,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
         }
         __syncthreads();
     }
+    if (do_rowsum && t < G_BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
     gemm_epilogue<C_PLAIN>(d, acc, m0, n0, wr, wc, lane, blockIdx.y == 0);
 }
 
@@ -390,7 +413,8 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     if (d.K > 0 && (!d.A || !d.B)) return EEGCLIP_EINVAL;
     if (d.split_k < 1) return EEGCLIP_EINVAL;
     if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre)) return EEGCLIP_EINVAL;
-    if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_SILU) return EEGCLIP_EINVAL;
+    if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_GELU_GRAD) return EEGCLIP_EINVAL;
+    if (d.act == EEGCLIP_ACT_GELU_GRAD && (!d.R || d.split_k > 1)) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;
     return launch_gemm(d, stream);

@@ -27,31 +27,33 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
     }
 }
 
-// lse[j] = log sum_i exp(s * X[i][j]);  block = 64 columns x 4 row-groups, online (max,sum) per thread, LDS merge
+// lse[j] = log sum_i exp(s * X[i][j]);  block = 16 columns x 16 row groups (64-byte row segments), online (max,sum) per thread, LDS
+// merge.  (64 columns x 4 row groups left 4 workgroups walking 64 dependent exp steps at N = 256: 24 us for a 256 KB matrix.)
 __global__ __launch_bounds__(256) void lse_cols_kernel(const float* __restrict__ X, int rows, int cols, long long ld,
                                                         const float* __restrict__ scale, float* __restrict__ lse) {
-    EEG_LDS_BASE(float, red);   // [2][4][64]
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    EEG_LDS_BASE(float, red);   // [2][16][16]
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const float s = scale ? *scale : 1.f;
     float mx = -INFINITY, sum = 0.f;
     if (c < cols) {
-        for (int r = g; r < rows; r += 4) {
+#pragma unroll 4
+        for (int r = g; r < rows; r += 16) {
             const float v = s * X[r * ld + c];
             if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
             else sum += expf(v - mx);
         }
     }
-    red[g * 64 + lane] = mx;
-    red[256 + g * 64 + lane] = sum;
+    red[g * 16 + cl] = mx;
+    red[256 + g * 16 + cl] = sum;
     __syncthreads();
     if (g == 0 && c < cols) {
-        float M = red[lane];
-        for (int k = 1; k < 4; ++k) M = fmaxf(M, red[k * 64 + lane]);
+        float M = red[cl];
+        for (int k = 1; k < 16; ++k) M = fmaxf(M, red[k * 16 + cl]);
         float S = 0.f;
-        for (int k = 0; k < 4; ++k) {
-            const float mk = red[k * 64 + lane];
-            if (mk > -INFINITY) S += red[256 + k * 64 + lane] * expf(mk - M);
+        for (int k = 0; k < 16; ++k) {
+            const float mk = red[k * 16 + cl];
+            if (mk > -INFINITY) S += red[256 + k * 16 + cl] * expf(mk - M);
         }
         lse[c] = M + logf(S);
     }
@@ -83,11 +85,16 @@ __global__ __launch_bounds__(256) void infonce_grad_kernel(float* __restrict__ X
         dsum += g * raw;
         X[i * ld + j] = s * g;
     }
+    // one atomic pair per WORKGROUP: a pair per wave (1024 waves at N = 256) serialised 2048 same-address atomics in L2
+    EEG_LDS_BASE(float, red);   // [2][4]
     lsum = wave_sum(lsum);
     dsum = wave_sum(dsum);
-    if ((threadIdx.x & 63) == 0) {
-        if (loss && lsum != 0.f) atomicAdd(loss, k * lsum);
-        if (dscale) atomicAdd(dscale, dsum);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lsum; red[4 + (threadIdx.x >> 6)] = dsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l4 = (red[0] + red[1]) + (red[2] + red[3]), d4 = (red[4] + red[5]) + (red[6] + red[7]);
+        if (loss && l4 != 0.f) atomicAdd(loss, k * l4);
+        if (dscale) atomicAdd(dscale, d4);
     }
 }
 
@@ -154,17 +161,17 @@ extern "C" int eegclip_lse_rows(const float* X, int rows, int cols, long long ld
 }
 extern "C" int eegclip_lse_cols(const float* X, int rows, int cols, long long ld, const float* scale, float* lse, void* stream) {
     if (!X || !lse || rows < 1 || cols < 1 || ld < cols) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(lse_cols_kernel, dim3((cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, X, rows, cols, ld, scale, lse);
+    EEG_LAUNCH(lse_cols_kernel, dim3((cols + 15) / 16), dim3(256), 512 * sizeof(float), stream, X, rows, cols, ld, scale, lse);
     return (int)hipGetLastError();
 }
 extern "C" int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, int n_total, const float* scale,
                                     const float* lse_r, const float* lse_c, float weight, float* loss, float* dscale, void* stream) {
     if (!X || !scale || (!lse_r && !lse_c) || rows < 1 || cols < 1 || ld < cols || n_total < 1 || col0 < 0) return EEGCLIP_EINVAL;
     long long n = (long long)rows * cols;
-    long long g = (n + 255) / 256;
+    long long g = (n + 1023) / 1024;          // 4 elements per thread
     if (g > 2048) g = 2048;
-    EEG_LAUNCH(infonce_grad_kernel, dim3((int)g), dim3(256), 0, stream, X, rows, cols, ld, col0, n_total, scale, lse_r, lse_c, weight,
-               loss, dscale);
+    EEG_LAUNCH(infonce_grad_kernel, dim3((int)g), dim3(256), 8 * sizeof(float), stream, X, rows, cols, ld, col0, n_total, scale, lse_r, lse_c,
+               weight, loss, dscale);
     return (int)hipGetLastError();
 }
 extern "C" int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c,

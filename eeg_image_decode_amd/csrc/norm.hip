@@ -5,9 +5,11 @@
 
 namespace eeg {
 
-constexpr int LN_MAXC = 16;   // columns per lane: cols <= 1024
+constexpr int LN_MAXC = 16;   // columns per lane: cols <= 1024 (NC = 4 instantiation for cols <= 256: the encoder's 250-wide rows
+                              // would otherwise drag 12 dead guarded iterations through every loop)
 
 // y = (x - mean) * rstd * gamma + beta ; mean/rstd saved for backward.  One wave per row, grid-stride over rows.
+template <int NC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -16,10 +18,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float inv = 1.0f / (float)cols;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (long long)row * cols;
-        float v[LN_MAXC];
+        float v[NC];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             v[i] = c < cols ? xr[c] : 0.f;
             s += v[i];
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const float mean = wave_sum(s) * inv;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             const float dlt = c < cols ? v[i] - mean : 0.f;
             q += dlt * dlt;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const float rstd = rsqrtf(wave_sum(q) * inv + eps);
         float* yr = y + (long long)row * cols;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < cols) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
         }
@@ -48,20 +50,23 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.   One wave per row, one row per wave
 // (maximum waves in flight: the row work is tiny, the kernel is latency-bound otherwise).
+template <int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
-                                                                int accumulate_dx) {
+                                                                int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
+                                                                unsigned long long seed, unsigned site) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (long long)row * cols;
         const float* dr = dy + (long long)row * cols;
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXC], g[LN_MAXC];
+        float xh[NC], g[NC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             const bool ok = c < cols;
             xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
@@ -72,11 +77,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
         float* dxr = dx + (long long)row * cols;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < cols) {
-                const float v = rs * (g[i] - c1 - xh[i] * c2);
-                dxr[c] = accumulate_dx ? dxr[c] + v : v;
+                float v = rs * (g[i] - c1 - xh[i] * c2);
+                if (accumulate_dx) v += dxr[c];
+                dxr[c] = v;
+                if (dx_drop) {       // second output: the gradient pushed back through the dropout that fed this LayerNorm's residual branch
+                    const unsigned long long idx = (unsigned long long)row * cols + c;
+                    dx_drop[idx] = (drop_p > 0.f && !dropout_keep(seed, site, idx, drop_p)) ? 0.f : v * keep_scale;
+                }
             }
         }
     }
@@ -92,6 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* _
     const int c = blockIdx.y * 64 + lane;
     float pg = 0.f, pb = 0.f;
     if (c < cols) {
+#pragma unroll 8
         for (int r = blockIdx.x * 4 + g; r < rows; r += gridDim.x * 4) {
             const float d = dy[(long long)r * cols + c];
             pg += d * (x[(long long)r * cols + c] - mean[r]) * rstd[r];
@@ -136,9 +147,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // (torch BatchNorm semantics, momentum 0.1).  eval: mean/rstd from the running stats.
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum, int C,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int train) {
+                                   float* __restrict__ running_var, int train, long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (train && c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's step counter, kept on the device
     if (train) {
         const double m = sums[c] / count;
         double var = sums[C + c] / count - m * m;
@@ -182,23 +194,29 @@ __global__ __launch_bounds__(256) void bn_elu_bwd_stats_kernel(const float* __re
     const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     double s = 0.0, q = 0.0;
-    for (int o = blockIdx.x; o < outer; o += gridDim.x) {
-        const long long base = ((long long)o * C + c) * inner;
-        for (int i = threadIdx.x; i < inner; i += blockDim.x) {
-            const float xh = (x[base + i] - mu) * rs;
-            const float u = g * xh + b;
-            float d = dz[base + i];
-            if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)(base + i), drop_p) ? d * ks : 0.f;
-            const float da = u > 0.f ? d : d * expf(u);
-            s += da;
-            q += (double)da * xh;
-        }
+    // the channel's outer * inner elements as one flat index space: every thread busy also when inner is tiny (BatchNorm #2: 36)
+    const long long per = (long long)outer * inner;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (long long)gridDim.x * blockDim.x) {
+        const long long idx = ((j / inner) * C + c) * inner + j % inner;
+        const float xh = (x[idx] - mu) * rs;
+        const float u = g * xh + b;
+        float d = dz[idx];
+        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? d * ks : 0.f;
+        const float da = u > 0.f ? d : d * expf(u);
+        s += da;
+        q += (double)da * xh;
     }
+    EEG_LDS_BASE(double, red);   // [2][4]: one fp64 atomic pair per workgroup, not per wave
     s = wave_sum(s);
     q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(sums + c, s);
-        atomicAdd(sums + C + c, q);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double ts = 0.0, tq = 0.0;
+        for (int k = 0; k < nw; ++k) { ts += red[k]; tq += red[4 + k]; }
+        atomicAdd(sums + c, ts);
+        atomicAdd(sums + C + c, tq);
     }
 }
 
@@ -245,20 +263,26 @@ extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const f
                                      int rows, int cols, float eps, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || cols < 1 || cols > 64 * LN_MAXC) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    const int grid = grid_for(rows, 4, 2048);
-    EEG_LAUNCH(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
+    const int grid = grid_for(rows, 4, 8192);
+    if (cols <= 256) EEG_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
+    else             EEG_LAUNCH(layernorm_fwd_kernel<LN_MAXC>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
     return (int)hipGetLastError();
 }
 
 extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                     float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, void* stream) {
+                                     float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop,
+                                     float drop_p, unsigned long long seed, unsigned int site, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols < 1 || cols > 64 * LN_MAXC)
         return EEGCLIP_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    EEG_LAUNCH(layernorm_bwd_dx_kernel, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols,
-               accumulate_dx);
-    int chunks = (rows + 127) / 128;            // >= 32 rows per thread before the atomics
-    if (chunks > 128) chunks = 128;
+    const dim3 grid(grid_for(rows, 4, 8192));
+    if (cols <= 256)
+        EEG_LAUNCH(layernorm_bwd_dx_kernel<4>, grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, drop_p, seed, site);
+    else
+        EEG_LAUNCH(layernorm_bwd_dx_kernel<LN_MAXC>, grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, drop_p, seed, site);
+    int chunks = (rows + 63) / 64;              // >= 16 rows per thread before the atomics
+    if (chunks > 256) chunks = 256;
     EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
                dbeta, rows, cols);
     return (int)hipGetLastError();
@@ -272,12 +296,12 @@ extern "C" int eegclip_bn_stats(const float* x, int outer, int C, int inner, dou
 }
 
 extern "C" int eegclip_bn_finalize(const double* sums, double count, float eps, float momentum, int C, float* mean, float* rstd,
-                                   float* running_mean, float* running_var, int train, void* stream) {
+                                   float* running_mean, float* running_var, int train, long long* num_batches_tracked, void* stream) {
     if (!mean || !rstd || C < 1) return EEGCLIP_EINVAL;
     if (train && (!sums || count < 1.0)) return EEGCLIP_EINVAL;
     if (!train && (!running_mean || !running_var)) return EEGCLIP_EINVAL;
     EEG_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, sums, count, eps, momentum, C, mean, rstd,
-               running_mean, running_var, train);
+               running_mean, running_var, train, num_batches_tracked);
     return (int)hipGetLastError();
 }
 
@@ -298,8 +322,8 @@ extern "C" int eegclip_bn_elu_bwd_stats(const float* dz, const float* x, const f
                                         unsigned site, void* stream) {
     if (!dz || !x || !mean || !rstd || !gamma || !beta || !sums || outer < 1 || C < 1 || inner < 1 || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
-    int chunks = outer < 64 ? outer : 64;
-    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, dz, x, mean, rstd, gamma, beta, outer, C,
+    const int chunks = grid_for((long long)outer * inner, 1024, 64);        // >= 4 elements per thread
+    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(256), 8 * sizeof(double), stream, dz, x, mean, rstd, gamma, beta, outer, C,
                inner, drop_p, seed, site, sums);
     return (int)hipGetLastError();
 }
@@ -324,8 +348,8 @@ extern "C" int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* 
         drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     const long long n = (long long)outer * C * inner;
-    int chunks = outer < 64 ? outer : 64;
-    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(inner >= 256 ? 256 : 64), 0, stream, dz, x, mean, rstd, gamma, beta,
+    const int chunks = grid_for((long long)outer * inner, 1024, 64);
+    EEG_LAUNCH(bn_elu_bwd_stats_kernel, dim3(chunks, C), dim3(256), 8 * sizeof(double), stream, dz, x, mean, rstd, gamma, beta,
                outer, C, inner, drop_p, seed, site, sums);
     EEG_LAUNCH(bn_elu_bwd_apply_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, dz, x, mean, rstd, gamma, beta, sums, sums,
                (double)outer * inner, dx, dgamma, dbeta, n, C, inner, drop_p, seed, site);

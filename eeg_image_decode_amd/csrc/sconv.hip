@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     float* wl = lds;                          // [48][SCF_LW]   Ws[o][k0 + kk]   (rows >= 40 zero)
     float* zl = wl + SC_OP * SCF_LW;          // [128][48]      z1[k0 + kk][w]   (cols >= 36 zero)
     float* aff = zl + SCF_KC * SC_OP;         // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
-    float* red = zl;                          // [48][48] cross-wave reduction, aliases the activation tile after the last chunk
+    float* red = lds;                         // 2 x [48][52] cross-wave reduction scratch, aliases the operand tiles after the last chunk
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
@@ -113,20 +113,45 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
                 for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
         }
     }
-    __syncthreads();
-    for (int i = t; i < SC_OP * SC_OP; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // cross-wave sum of the four k-partial accumulator sets: a two-level tree through LDS with plain stores (waves 2,3 -> 0,1, then
+    // 1 -> 0).  The first version used 36 ds_add_f32 per lane into one tile: LDS float atomics retire at ~170 cycles per wave
+    // instruction, and with 4 K-slice workgroups per sample that epilogue alone was ~40 % of the kernel.
+    constexpr int RLD = 52;                   // 4 accumulator row groups land 16 banks apart: 2-way at most, free for stores
+    auto put = [&](float* reg) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * i + 4 * g + r) * SC_OP + 16 * j + fr, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr] = acc[i][j][r];
+    };
+    auto add = [&](const float* reg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr];
+    };
+    __syncthreads();                          // every wave is done with the operand tiles: LDS becomes reduction scratch
+    if (wv >= 2) put(red + (wv - 2) * SC_OP * RLD);
     __syncthreads();
-    float* yo = y2 + (long long)b * SC_C * SC_W;
-    for (int i = t; i < SC_C * SC_W; i += 256) {
-        const int o = i / SC_W, w = i % SC_W;
-        atomicAdd(yo + i, red[o * SC_OP + w] + (blockIdx.y == 0 ? bs[o] : 0.f));
+    if (wv < 2) add(red + wv * SC_OP * RLD);
+    __syncthreads();
+    if (wv == 1) put(red);
+    __syncthreads();
+    if (wv == 0) {
+        add(red);
+        float* yo = y2 + (long long)b * SC_C * SC_W;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * i + 4 * g + r, w = 16 * j + fr;
+                    if (o < SC_C && w < SC_W) atomicAdd(yo + o * SC_W + w, acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f));
+                }
     }
 }
 
@@ -249,7 +274,8 @@ __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, in
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < groups; ++k) s += partials[(long long)k * n + i];
+#pragma unroll 8
+    for (int k = 0; k < groups; ++k) s += partials[(long long)k * n + i];      // independent loads: keep 8 in flight per thread
     dW[i] += s;
 }
 

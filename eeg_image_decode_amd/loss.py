@@ -38,9 +38,9 @@ def _scale_ptr(logit_scale, device):
     return torch.full((1,), float(logit_scale), dtype=torch.float32, device=device)
 
 
-def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term, need_grad):
-    """One (n x N) logits block: loss contribution and, if need_grad, X <- s*G in place.
-    Returns (loss[1], dscale[1], X or None)."""
+def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term, need_grad, acc=None):
+    """One (n x N) logits block: loss contribution and, if need_grad, X <- weight * s*G in place.
+    `acc` (2 floats: loss, dscale) is accumulated into when given.  Returns (loss[1], dscale[1], X or None)."""
     L = lib()
     n, Dm = a_rows.shape
     N = b_cols.shape[0]
@@ -48,14 +48,14 @@ def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term,
     X = torch.empty(n, N, dtype=torch.float32, device=dev)
     _gemm(n, N, Dm, a_rows.data_ptr(), D(Dm), D(1), b_cols.data_ptr(), D(1), D(Dm), X.data_ptr(), D(N), D(1))
     st = _stream()
-    lr = lc = None
+    lse = torch.empty(n + N, dtype=torch.float32, device=dev)
+    lr, lc = lse[:n], lse[n:]
     if row_term:
-        lr = torch.empty(n, dtype=torch.float32, device=dev)
         check(L.eegclip_lse_rows(X.data_ptr(), n, N, N, sc.data_ptr(), lr.data_ptr(), st), "lse_rows")
     if col_term:
-        lc = torch.empty(N, dtype=torch.float32, device=dev)
         check(L.eegclip_lse_cols(X.data_ptr(), n, N, N, sc.data_ptr(), lc.data_ptr(), st), "lse_cols")
-    acc = torch.zeros(2, dtype=torch.float32, device=dev)
+    if acc is None:
+        acc = torch.zeros(2, dtype=torch.float32, device=dev)
     if need_grad or not (row_term and col_term and n == N):
         check(L.eegclip_infonce_grad(X.data_ptr(), n, N, N, col0, n_total, sc.data_ptr(), lr.data_ptr() if row_term else None,
                                      lc.data_ptr() if col_term else None, weight, acc.data_ptr(), acc.data_ptr() + 4, st), "infonce_grad")
@@ -65,85 +65,103 @@ def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term,
     return acc[0:1], acc[1:2], X
 
 
-def _grad_rows(X, b_cols):
-    """dA = (s G) B  -> (n, D)"""
+def _grad_rows(X, b_cols, out=None):
+    """dA (+)= (s G) B  -> (n, D)"""
     n, N = X.shape
     Dm = b_cols.shape[1]
-    out = torch.empty(n, Dm, dtype=torch.float32, device=X.device)
-    _gemm(n, Dm, N, X.data_ptr(), D(N), D(1), b_cols.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1))
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(n, Dm, dtype=torch.float32, device=X.device)
+    _gemm(n, Dm, N, X.data_ptr(), D(N), D(1), b_cols.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate))
     return out
 
 
-def _grad_cols(X, a_rows):
-    """dB = (s G)^T A -> (N, D)"""
+def _grad_cols(X, a_rows, out=None):
+    """dB (+)= (s G)^T A -> (N, D)"""
     n, N = X.shape
     Dm = a_rows.shape[1]
-    out = torch.empty(N, Dm, dtype=torch.float32, device=X.device)
-    _gemm(N, Dm, n, X.data_ptr(), D(1), D(N), a_rows.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1))
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(N, Dm, dtype=torch.float32, device=X.device)
+    _gemm(N, Dm, n, X.data_ptr(), D(1), D(N), a_rows.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate))
     return out
 
 
 class _ClipLossFn(torch.autograd.Function):
+    """loss = sum_t w_t * ClipLoss(a, b_t, scale) for one or more target matrices b_t that share the query features `a`
+    (the training loop mixes an image and a text target, ATMS_retrieval.py:224-229): one (loss, dscale) accumulator, one gradient
+    w.r.t. `a` (the second target's dA GEMM accumulates onto the first), a_all gathered once, and -- data parallel -- ONE
+    reduce-scatter for the gradients that reached the gathered copies of `a`."""
+
     @staticmethod
-    def forward(ctx, a, b, scale_t, mod):
+    def forward(ctx, a, scale_t, mod, weights, *targets):
         dev = a.device
         sc = _scale_ptr(scale_t, dev)
-        need = [a.requires_grad, b.requires_grad, torch.is_tensor(scale_t) and scale_t.requires_grad]
+        need_a = a.requires_grad
+        need_b = [b.requires_grad for b in targets]
+        need_s = torch.is_tensor(scale_t) and scale_t.requires_grad
+        need = need_a or any(need_b) or need_s
         W, rank = mod.world_size, mod.rank
-        a_, b_ = a.detach().contiguous(), b.detach().contiguous()
+        a_ = a.detach().contiguous()
+        bs = [b.detach().contiguous() for b in targets]
         n = a_.shape[0]
-        da = db = ds = None
+        acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        da = None
+        dbs = [None] * len(bs)
         if W == 1:
-            loss, dsv, X = infonce_block(a_, b_, sc, 0, n, 1.0, True, True, any(need))
-            if need[0]:
-                da = _grad_rows(X, b_)
-            if need[1]:
-                db = _grad_cols(X, a_)
-            ds = dsv
+            for t, (b_, w) in enumerate(zip(bs, weights)):
+                _, _, X = infonce_block(a_, b_, sc, 0, n, w, True, True, need, acc)
+                if need_a:
+                    da = _grad_rows(X, b_, da)
+                if need_b[t]:
+                    dbs[t] = _grad_cols(X, a_)
         else:
             import torch.distributed as dist
             a_all = torch.empty(W * n, a_.shape[1], dtype=torch.float32, device=dev)
-            b_all = torch.empty(W * n, b_.shape[1], dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(a_all, a_)
-            dist.all_gather_into_tensor(b_all, b_)
-            if not mod.local_loss:
-                # every rank scores the full N x N matrix (models/loss.py:117-121)
-                loss, dsv, X = infonce_block(a_all, b_all, sc, 0, W * n, 1.0, True, True, any(need))
-                mult = float(W) if mod.gather_with_grad else 1.0     # all_gather backward sums W identical copies
-                sl = slice(rank * n, (rank + 1) * n)
-                if need[0]:
-                    da = _grad_rows(X[sl].contiguous(), b_all) * mult
-                if need[1]:
-                    db = _grad_cols(X, a_all)[sl] * mult
-                ds = dsv
-            else:
-                # row-sharded: n x N blocks, positives at column i + n*rank (models/loss.py:113-115,129-130)
-                l1, d1, X1 = infonce_block(a_, b_all, sc, rank * n, n, 1.0, True, False, True)
-                l2, d2, X2 = infonce_block(b_, a_all, sc, rank * n, n, 1.0, True, False, True)
-                loss, ds = l1 + l2, d1 + d2
-                if need[0]:
-                    da = _grad_rows(X1, b_all)
-                if need[1]:
-                    db = _grad_rows(X2, a_all)
-                if mod.gather_with_grad:
-                    # gradients that reached the GATHERED copies flow back through all_gather = reduce-scatter(sum)
-                    if need[0]:
-                        ga = _grad_cols(X2, b_)                       # (N, D): d loss_r / d a_all
-                        part = torch.empty_like(a_)
-                        dist.reduce_scatter_tensor(part, ga)
-                        da = da + part
-                    if need[1]:
-                        gb = _grad_cols(X1, a_)
-                        part = torch.empty_like(b_)
-                        dist.reduce_scatter_tensor(part, gb)
-                        db = db + part
-        ctx.grads = (da, db, ds.reshape(()).clone() if need[2] else None)
-        return loss.reshape(()).clone()
+            ga = None                                              # gradient w.r.t. the gathered copies of a (local_loss + gather_with_grad)
+            sl = slice(rank * n, (rank + 1) * n)
+            for t, (b_, w) in enumerate(zip(bs, weights)):
+                b_all = torch.empty(W * n, b_.shape[1], dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(b_all, b_)
+                if not mod.local_loss:
+                    # every rank scores the full N x N matrix (models/loss.py:117-121)
+                    _, _, X = infonce_block(a_all, b_all, sc, 0, W * n, w, True, True, need, acc)
+                    mult = float(W) if mod.gather_with_grad else 1.0     # all_gather backward sums W identical copies
+                    if need_a:
+                        part = _grad_rows(X[sl].contiguous(), b_all) * mult
+                        da = part if da is None else da + part
+                    if need_b[t]:
+                        dbs[t] = _grad_cols(X, a_all)[sl] * mult
+                else:
+                    # row-sharded: n x N blocks, positives at column i + n*rank (models/loss.py:113-115,129-130)
+                    _, _, X1 = infonce_block(a_, b_all, sc, rank * n, n, w, True, False, True, acc)
+                    _, _, X2 = infonce_block(b_, a_all, sc, rank * n, n, w, True, False, True, acc)
+                    if need_a:
+                        da = _grad_rows(X1, b_all, da)
+                    if need_b[t]:
+                        dbs[t] = _grad_rows(X2, a_all)
+                    if mod.gather_with_grad:
+                        # gradients that reached the GATHERED copies flow back through all_gather = reduce-scatter(sum)
+                        if need_a:
+                            ga = _grad_cols(X2, b_, ga)                   # (N, D): d loss_r / d a_all, summed over the targets
+                        if need_b[t]:
+                            gb = _grad_cols(X1, a_)
+                            part = torch.empty_like(b_)
+                            dist.reduce_scatter_tensor(part, gb)
+                            dbs[t] = dbs[t] + part
+            if ga is not None:
+                part = torch.empty_like(a_)
+                dist.reduce_scatter_tensor(part, ga)
+                da = da + part
+        ctx.grads = (da, acc[1].reshape(()) if need_s else None, dbs)
+        return acc[0].reshape(())
 
     @staticmethod
     def backward(ctx, go):
-        da, db, ds = ctx.grads
-        return (da * go if da is not None else None, db * go if db is not None else None, ds * go if ds is not None else None, None)
+        da, ds, dbs = ctx.grads
+        return (da * go if da is not None else None, ds * go if ds is not None else None, None, None) + \
+            tuple(db * go if db is not None else None for db in dbs)
 
 
 class ClipLoss(nn.Module):
@@ -163,4 +181,16 @@ class ClipLoss(nn.Module):
         require_cuda(text_features, "text_features")
         if image_features.dtype != torch.float32 or text_features.dtype != torch.float32:
             raise TypeError("ClipLoss expects float32 features (the reference casts with .float())")
-        return _ClipLossFn.apply(image_features, text_features, logit_scale, self)
+        return _ClipLossFn.apply(image_features, logit_scale, self, (1.0,), text_features)
+
+    def forward_mixed(self, features, targets, logit_scale):
+        """sum_t w_t * self(features, target_t, logit_scale) in one pass; targets = [(tensor, weight), ...].  Equal (up to fp32
+        summation order) to calling forward per target and mixing the scalars, which is what the reference loop does."""
+        require_cuda(features, "features")
+        for b, _ in targets:
+            require_cuda(b, "target")
+            if b.dtype != torch.float32:
+                raise TypeError("ClipLoss expects float32 features (the reference casts with .float())")
+        if features.dtype != torch.float32:
+            raise TypeError("ClipLoss expects float32 features (the reference casts with .float())")
+        return _ClipLossFn.apply(features, logit_scale, self, tuple(float(w) for _, w in targets), *[b for b, _ in targets])

@@ -31,10 +31,10 @@ class Plan:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
     def gemm(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1):
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None):
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
-                          drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k)
+                          drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a)
         self._keep.append(d)
         if drop_p > 0.0:
             self._seed_descs.append(d)

@@ -235,7 +235,7 @@ class _PriorEngine:
             small = hi * ho < 256 * 256
             pl.call("eegclip_silu_bwd", _p(b[f"dact{s}"]), _p(b[f"ln{s}"]), _p(b[f"dln{s}"]), N * ho, 0, p, 0, s, seed_at=6)
             pl.call("eegclip_layernorm_bwd", _p(b[f"dln{s}"]), _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), _p(b[f"dlin{s}"]),
-                    _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), N, ho, 0)
+                    _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), N, ho, 0, None, 0.0, 0, 0)
             bgrad(st["l"] + "0.bias", _p(b[f"dlin{s}"]), ho)
             wgrad(st["l"] + "0.weight", _p(b[f"dlin{s}"]), ho, _p(b[f"xin{s}"]), hi, ho, hi, small)
             pl.gemm(N, hi, ho, _p(b[f"dlin{s}"]), D(ho), D(1), _p(P[st["l"] + "0.weight"]), D(hi), D(1), _p(b[f"dxin{s}"]), D(hi), D(1))
@@ -258,7 +258,7 @@ class _PriorEngine:
                 pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), _p(b["dactI"]), N * hi, 1.0, 0.0)
         pl.call("eegclip_silu_bwd", _p(b["dactI"]), _p(b["lnI"]), _p(b["dlnI"]), N * h0, 0, 0.0, 0, 0)
         pl.call("eegclip_layernorm_bwd", _p(b["dlnI"]), _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(b["muI"]), _p(b["rsI"]), _p(b["dlinI"]),
-                _p(G["input_layer.1.weight"]), _p(G["input_layer.1.bias"]), N, h0, 0)
+                _p(G["input_layer.1.weight"]), _p(G["input_layer.1.bias"]), N, h0, 0, None, 0.0, 0, 0)
         bgrad("input_layer.0.bias", _p(b["dlinI"]), h0)
         pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False)
         return pl

@@ -76,9 +76,11 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
     eeg_features = eeg_model(eeg_data, subject_ids).float()
     logit_scale = eeg_model.logit_scale
-    img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
-    text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
-    loss = alpha * img_loss + (1 - alpha) * text_loss
+    loss_func = eeg_model.loss_func
+    if hasattr(loss_func, "forward_mixed"):          # both targets in one pass: one gradient w.r.t. the EEG features, one accumulator
+        loss = loss_func.forward_mixed(eeg_features, [(img_features, alpha), (text_features, 1 - alpha)], logit_scale)
+    else:                                            # a user-supplied loss module: the reference's two calls (ATMS_retrieval.py:224-229)
+        loss = alpha * loss_func(eeg_features, img_features, logit_scale) + (1 - alpha) * loss_func(eeg_features, text_features, logit_scale)
     loss.backward()
     if edist.world_size() > 1:
         edist.average_flat_grads(eeg_model.flat_parameters()[1])

@@ -36,9 +36,14 @@ typedef struct {
 #define EEGCLIP_ACT_NONE 0
 #define EEGCLIP_ACT_GELU 1 /* exact erf GELU (F.gelu default) */
 #define EEGCLIP_ACT_SILU 2 /* x * sigmoid(x) (nn.SiLU: diffusion prior) */
+#define EEGCLIP_ACT_GELU_GRAD 3 /* backward of GELU: v *= gelu'(R[m,n]) -- R holds the forward PRE-activation and is not added */
 
 /* C[m,n] (+)= epilogue( alpha * sum_k A[m,k] * B[k,n] )          fp32 in, fp32 MFMA (exact f32), fp32 out.
  * epilogue order: +bias_n[n] +bias_m[m] -> (store Cpre) -> act -> dropout(p, Philox(seed, site, m*N+n)) -> +R[m,n]
+ * (act = EEGCLIP_ACT_GELU_GRAD: no forward activation; after the dropout stage v *= gelu'(R[m,n]) instead of v += R[m,n] -- the
+ *  gradient of dropout(gelu(pre)) w.r.t. pre fused into the GEMM that produces the upstream gradient, Transformer_EncDec.py:48).
+ * rowsum_a (optional, [M]): rowsum_a[m] += sum_k A[m,k] (atomic; every K slice adds its share).  With A = dY^T this is the bias
+ * gradient of the Linear whose weight gradient dW = dY^T X the same launch computes (one pass over dY instead of two).
  * Replaces every nn.Linear / 1x1-conv / (63x1)-conv GEMM and its backward on the path:
  *   models/subject_layers/Embed.py:146-149 (value embedding + PE), SelfAttention_Family.py:199-201,213 (Q/K/V/out),
  *   Transformer_EncDec.py:48-51 (FFN), Retrieval/ATMS_retrieval.py:106,113 (spatial / 1x1 conv), :157-167 (head),
@@ -65,16 +70,20 @@ typedef struct {
     unsigned long long seed;
     unsigned int drop_site;
     int split_k;          /* >= 1 */
+    float* rowsum_a;      /* [M] or NULL: += sum_k A[m,k] */
 } eegclip_gemm_desc;
 
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);
 
 /* ---- LayerNorm (rows of <= 1024 floats).  Transformer_EncDec.py:47,51,77-78 ; ATMS_retrieval.py:166 ; diffusion_prior.py:120,140,155
- * fwd: y = (x-mean)*rstd*gamma+beta, mean/rstd[rows] saved (may be NULL).  bwd: dx (+)= ..., dgamma/dbeta += (atomic). */
+ * fwd: y = (x-mean)*rstd*gamma+beta, mean/rstd[rows] saved (may be NULL).  bwd: dx (+)= ..., dgamma/dbeta += (atomic);
+ * dx_drop (optional): second output dx * mask/(1-p), mask = Philox(seed, site, row*cols+c) -- the gradient entering the
+ * dropout(sublayer(.)) branch of the residual that fed this LayerNorm (Transformer_EncDec.py:45,51), saving a copy + a mask pass. */
 int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           int rows, int cols, float eps, void* stream);
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                          float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, void* stream);
+                          float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p,
+                          unsigned long long seed, unsigned int site, void* stream);
 
 /* LayerNorm -> SiLU -> dropout in one pass (prior stage, Generation/diffusion_prior.py:117-121,137-143): y_ln = LN(x) is kept for
  * the backward, y_act = dropout(silu(y_ln)).  silu_bwd: dx (+)= dy*mask/(1-p)*silu'(pre). */
@@ -86,11 +95,11 @@ int eegclip_silu_bwd(const float* dy, const float* pre, float* dx, long long n, 
 /* ---- BatchNorm2d (+ELU, +dropout) over an (outer, C, inner) view.  ATMS_retrieval.py:104-105,107-109
  * sums: double[2C] (sum, sum of squares) accumulated atomically -- zero it first.
  * finalize: train=1 -> mean/rstd from the batch sums (biased var) and running stats updated in place with the unbiased
- * var (momentum); train=0 -> mean/rstd from the running stats.
+ * var (momentum) and *num_batches_tracked += 1 (int64 on the device, may be NULL); train=0 -> mean/rstd from the running stats.
  * bn_elu_fwd: y = dropout(ELU(gamma*(x-mean)*rstd+beta)).   bn_elu_bwd: dx, dgamma +=, dbeta += (sums = double[2C] scratch, zeroed). */
 int eegclip_bn_stats(const float* x, int outer, int C, int inner, double* sums, void* stream);
 int eegclip_bn_finalize(const double* sums, double count, float eps, float momentum, int C, float* mean, float* rstd,
-                        float* running_mean, float* running_var, int train, void* stream);
+                        float* running_mean, float* running_var, int train, long long* num_batches_tracked, void* stream);
 int eegclip_bn_elu_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
                        int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

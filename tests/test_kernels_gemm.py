@@ -150,6 +150,41 @@ def test_gemm_fast_path(be, M, N, K, split, ta, tb):
     np.testing.assert_allclose(be.host(C), ref, atol=3e-5 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("M,N,K,split", [(130, 70, 50, 1), (72, 66, 330, 3), (63, 33, 97, 2)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_rowsum_a_is_the_bias_gradient(be, M, N, K, split, ta, tb):
+    """rowsum_a[m] += sum_k A[m,k], added once per K slice by the n = 0 tiles (fast and general kernels, all layouts)"""
+    rng = np.random.default_rng(M + N + K + ta * 2 + tb)
+    a = f32(rng, *((K, M) if ta else (M, K)))
+    b = f32(rng, *((N, K) if tb else (K, N)))
+    r0 = f32(rng, M)
+    A, B, C, RS = be.dev(a), be.dev(b), be.zeros((M, N)), be.dev(r0)
+    Am, Ak = (D(1), D(M)) if ta else (D(K), D(1))
+    Bk, Bn = (D(1), D(K)) if tb else (D(N), D(1))
+    run(be, mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), split_k=split, accumulate=int(split > 1), rowsum_a=be.ptr(RS)))
+    am = (a.T if ta else a).astype(np.float64)
+    np.testing.assert_allclose(be.host(C), am @ (b.T if tb else b).astype(np.float64), atol=1e-4)
+    np.testing.assert_allclose(be.host(RS), r0 + am.sum(1), atol=1e-4)
+
+
+def test_gemm_gelu_grad_epilogue(be):
+    """dX = dropout-mask(dY W) * gelu'(pre): the FFN activation backward fused into the GEMM (Transformer_EncDec.py:48)"""
+    from scipy.special import erf
+    rng = np.random.default_rng(12)
+    M, N, K = 70, 90, 40
+    dy, w, pre = f32(rng, M, K), f32(rng, K, N), f32(rng, M, N)
+    DY, W, PRE, C = be.dev(dy), be.dev(w), be.dev(pre), be.zeros((M, N))
+    p, seed, site = 0.25, 0x1234567890ABCDEF, 5
+    run(be, mk(be, M, N, K, DY, D(K), D(1), W, D(N), D(1), C, D(N), D(1), R=be.ptr(PRE), Rm=D(N), Rn=D(1), act=_abi.ACT_GELU_GRAD,
+               drop_p=p, seed=seed, drop_site=site))
+    keep = keep_mask(seed, site, M * N, p).reshape(M, N)
+    x = pre.astype(np.float64)
+    gprime = 0.5 * (1 + erf(x / np.sqrt(2))) + x * np.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
+    np.testing.assert_allclose(be.host(C), (dy.astype(np.float64) @ w) * keep / (1 - p) * gprime, atol=3e-5)
+    d = mk(be, M, N, K, DY, D(K), D(1), W, D(N), D(1), C, D(N), D(1), act=_abi.ACT_GELU_GRAD)
+    assert be.lib.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0      # needs the pre-activation in R
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0

@@ -32,9 +32,12 @@ def test_layernorm_fwd_bwd(be, rows, cols):
     np.testing.assert_allclose(be.host(Y), yt.detach().numpy(), atol=2e-5)
     dx0 = rnd(rng, rows, cols)
     DX, DG, DB = be.dev(dx0), be.zeros(cols), be.zeros(cols)
+    DXD = be.zeros((rows, cols))
     ok(be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX), be.ptr(DG), be.ptr(DB),
-                                    rows, cols, 1, be.stream))
+                                    rows, cols, 1, be.ptr(DXD), 0.25, SEED, 4, be.stream))
     np.testing.assert_allclose(be.host(DX), dx0 + xt.grad.numpy(), atol=5e-5)
+    keep = keep_mask(SEED, 4, rows * cols, 0.25).reshape(rows, cols)          # second output: dx pushed back through a dropout
+    np.testing.assert_allclose(be.host(DXD), (dx0 + xt.grad.numpy()) * keep / 0.75, atol=1e-4)
     np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
     np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
 
@@ -48,9 +51,11 @@ def test_batchnorm_elu_train_fwd_bwd(be, outer, C, inner, p):
     X, G, Bt, DZ = be.dev(x), be.dev(g), be.dev(b), be.dev(dz)
     SUMS = be.zeros(2 * C, np.float64)
     MU, RS, RM, RV = be.zeros(C), be.zeros(C), be.dev(rm0), be.dev(rv0)
+    NBT = be.dev(np.array([7], np.int64))
     n = outer * inner
     ok(be.lib.eegclip_bn_stats(be.ptr(X), outer, C, inner, be.ptr(SUMS), be.stream))
-    ok(be.lib.eegclip_bn_finalize(be.ptr(SUMS), float(n), 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 1, be.stream))
+    ok(be.lib.eegclip_bn_finalize(be.ptr(SUMS), float(n), 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 1, be.ptr(NBT), be.stream))
+    assert int(be.host(NBT)[0]) == 8
     Y = be.zeros((outer, C, inner))
     ok(be.lib.eegclip_bn_elu_fwd(be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(Bt), be.ptr(Y), outer, C, inner, p, SEED, 5, be.stream))
     keep = keep_mask(SEED, 5, outer * C * inner, p).reshape(outer, C, inner) if p > 0 else np.ones((outer, C, inner), bool)
@@ -70,7 +75,8 @@ def test_batchnorm_elu_train_fwd_bwd(be, outer, C, inner, p):
     np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1, n ** 0.5 / 10))
     np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1, n ** 0.5 / 10))
     # eval mode: statistics come from the running buffers
-    ok(be.lib.eegclip_bn_finalize(None, 0.0, 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 0, be.stream))
+    ok(be.lib.eegclip_bn_finalize(None, 0.0, 1e-5, 0.1, C, be.ptr(MU), be.ptr(RS), be.ptr(RM), be.ptr(RV), 0, be.ptr(NBT), be.stream))
+    assert int(be.host(NBT)[0]) == 8             # eval leaves the step counter alone
     ok(be.lib.eegclip_bn_elu_fwd(be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(Bt), be.ptr(Y), outer, C, inner, 0.0, 0, 0, be.stream))
     ye = F.elu(F.batch_norm(xt.detach(), rm, rv, gt.detach(), bt.detach(), False, 0.1, 1e-5))
     np.testing.assert_allclose(be.host(Y), ye.numpy(), atol=3e-5)
@@ -287,7 +293,7 @@ def test_gemm_silu_epilogue_and_prior_stage_kernels(be):
     np.testing.assert_allclose(be.host(YA), ya.detach().numpy(), atol=3e-5)
     DLN, DX, DG, DB = be.zeros((rows, cols)), be.zeros((rows, cols)), be.zeros(cols), be.zeros(cols)
     ok(be.lib.eegclip_silu_bwd(be.ptr(DY), be.ptr(YL), be.ptr(DLN), rows * cols, 0, p, SEED, 4, be.stream))
-    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DLN), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX), be.ptr(DG), be.ptr(DB), rows, cols, 0, be.stream))
+    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DLN), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX), be.ptr(DG), be.ptr(DB), rows, cols, 0, None, 0.0, 0, 0, be.stream))
     np.testing.assert_allclose(be.host(DX), xt.grad.numpy(), atol=5e-5)
 
 

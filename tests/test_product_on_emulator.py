@@ -64,6 +64,32 @@ def test_atms_train_step_under_emulator_matches_oracle():
         assert d.mean() < 3e-6 and d.max() <= 6.1e-4, (k, d.mean(), d.max())   # elements with |g| ~ round-off may flip by up to 2*lr
 
 
+def test_mixed_clip_loss_equals_the_two_reference_calls():
+    """ClipLoss.forward_mixed (one pass, shared accumulator, accumulated dA GEMM) == alpha*L(z,img) + (1-alpha)*L(z,txt) -- value,
+    d/dz, d/dscale and the gradient of a target that requires it"""
+    rng = np.random.default_rng(3)
+    n, Dm = 6, 16
+    z0, img0, txt0 = [rng.standard_normal((n, Dm)).astype(np.float32) for _ in range(3)]
+    with product_on_emulator():
+        from eeg_image_decode_amd.loss import ClipLoss
+        lf = ClipLoss()
+        outs = []
+        for mixed in (False, True):
+            z, img, txt = T(z0).requires_grad_(), T(img0).requires_grad_(), T(txt0)
+            sc = torch.tensor(2.6593, requires_grad=True)
+            if mixed:
+                loss = lf.forward_mixed(z, [(img, 0.99), (txt, 0.01)], sc)
+            else:
+                loss = 0.99 * lf(z, img, sc) + 0.01 * lf(z, txt, sc)
+            (3.0 * loss).backward()
+            outs.append([loss.detach().clone(), z.grad.clone(), img.grad.clone(), sc.grad.clone()])
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-5, atol=1e-6)
+    ref = oloss.mixed_loss(T(z0), T(img0), T(txt0), torch.tensor(2.6593)) if hasattr(oloss, "mixed_loss") else None
+    if ref is not None:
+        assert abs(float(outs[1][0]) - float(ref)) < 1e-5
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HIPEMU_THREADS"] = "2"
