@@ -48,18 +48,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-// backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.   One wave per row, one row per wave
-// (maximum waves in flight: the row work is tiny, the kernel is latency-bound otherwise).
+// backward, one kernel:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   [+ dx_drop = dropout'(dx)]
+//                        dgamma[c] += sum_rows dy * xhat ;  dbeta[c] += sum_rows dy
+// One wave per row, `rpw` consecutive rows per wave; the lane that owns column c keeps the parameter partial sums of its columns in
+// registers across its rows, the 4 waves of a workgroup combine through LDS and issue one atomic per column.  (The first version
+// read dy and x a second time in a column-parallel kernel: 36 + 14 us per 16 MB tensor; this one streams them once.)
 template <int NC>
-__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
-                                                                int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
-                                                                unsigned long long seed, unsigned site) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
+                                                             int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
+                                                             unsigned long long seed, unsigned site, int rpw) {
+    EEG_LDS_BASE(float, red);            // [2][4][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    float gam[NC], pg[NC], pb[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        gam[i] = c < cols ? gamma[c] : 0.f;
+        pg[i] = 0.f;
+        pb[i] = 0.f;
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * rpw;
+    for (int row = row0; row < row0 + rpw && row < rows; ++row) {
         const float* xr = x + (long long)row * cols;
         const float* dr = dy + (long long)row * cols;
         const float mu = mean[row], rs = rstd[row];
@@ -69,8 +83,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             const bool ok = c < cols;
+            const float d = ok ? dr[c] : 0.f;
             xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
-            g[i] = ok ? dr[c] * gamma[c] : 0.f;
+            g[i] = d * gam[i];
+            pg[i] += d * xh[i];
+            pb[i] += d;
             s1 += g[i];
             s2 += g[i] * xh[i];
         }
@@ -90,31 +107,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
             }
         }
     }
-}
-
-// backward, part 2:  dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy.   Column-parallel: block = 64 columns x 4 row groups,
-// lanes walk columns (coalesced), each thread strides over its share of the rows; LDS combine, one atomic per column per block.
-__global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
-    EEG_LDS_BASE(float, red);   // [2][4][64]
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + lane;
-    float pg = 0.f, pb = 0.f;
-    if (c < cols) {
-#pragma unroll 8
-        for (int r = blockIdx.x * 4 + g; r < rows; r += gridDim.x * 4) {
-            const float d = dy[(long long)r * cols + c];
-            pg += d * (x[(long long)r * cols + c] - mean[r]) * rstd[r];
-            pb += d;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) {
+            red[wave * cols + c] = pg[i];
+            red[(4 + wave) * cols + c] = pb[i];
         }
     }
-    red[g * 64 + lane] = pg;
-    red[256 + g * 64 + lane] = pb;
     __syncthreads();
-    if (g == 0 && c < cols) {
-        atomicAdd(dgamma + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
-        atomicAdd(dbeta + c, (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        atomicAdd(dgamma + c, (red[c] + red[cols + c]) + (red[2 * cols + c] + red[3 * cols + c]));
+        atomicAdd(dbeta + c, (red[4 * cols + c] + red[5 * cols + c]) + (red[6 * cols + c] + red[7 * cols + c]));
     }
 }
 
@@ -276,15 +280,16 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
         return EEGCLIP_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    const dim3 grid(grid_for(rows, 4, 8192));
+    // rows per wave: 4 once that still leaves >= 4 workgroups per CU (each parameter column then takes rows/16 atomics), else 1
+    const int rpw = rows >= 16384 ? 4 : 1;
+    const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
+    const size_t lds = (size_t)8 * cols * sizeof(float);
     if (cols <= 256)
-        EEG_LAUNCH(layernorm_bwd_dx_kernel<4>, grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, drop_p, seed, site);
+        EEG_LAUNCH(layernorm_bwd_kernel<4>, grid, dim3(256), lds, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols, accumulate_dx,
+                   dx_drop, drop_p, seed, site, rpw);
     else
-        EEG_LAUNCH(layernorm_bwd_dx_kernel<LN_MAXC>, grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, drop_p, seed, site);
-    int chunks = (rows + 63) / 64;              // >= 16 rows per thread before the atomics
-    if (chunks > 256) chunks = 256;
-    EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
-               dbeta, rows, cols);
+        EEG_LAUNCH(layernorm_bwd_kernel<LN_MAXC>, grid, dim3(256), lds, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
+                   accumulate_dx, dx_drop, drop_p, seed, site, rpw);
     return (int)hipGetLastError();
 }
 

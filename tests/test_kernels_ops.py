@@ -17,7 +17,7 @@ def rnd(rng, *shape, scale=1.0):
     return (rng.standard_normal(shape) * scale).astype(np.float32)
 
 
-@pytest.mark.parametrize("rows,cols", [(5, 250), (64, 1024), (130, 64), (3, 7)])
+@pytest.mark.parametrize("rows,cols", [(5, 250), (64, 1024), (130, 64), (3, 7), (16391, 6)])
 def test_layernorm_fwd_bwd(be, rows, cols):
     rng = np.random.default_rng(rows * 7 + cols)
     x, g, b, dy = rnd(rng, rows, cols), 1 + 0.1 * rnd(rng, cols), 0.1 * rnd(rng, cols), rnd(rng, rows, cols)
