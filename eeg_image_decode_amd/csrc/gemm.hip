@@ -185,13 +185,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 // =================================================================================================================================
 // fast kernel: plain strides, leading dimensions / contiguous extents even, base pointers 8-byte aligned, offsets < 2^31.
 //
-// LDS images (both conflict free for every access below; ds_*_b64 services 2 x 32 lanes over 64 banks, ds_read_b32 2 x 32 over 32):
-//   k-contiguous operand ("KC", e.g. X and W of Y = X W^T): [row][36]; staged with ds_write_b64 (16 lanes = one 128-byte row),
-//       fetched with ds_read_b64: lane (fr, g) takes k = 8r + 2g + {0,1} of row fr          (row stride 36 = 4 * odd)
-//   row-contiguous operand ("MC", e.g. dY^T and X of dW = dY^T X, W of dX = dY W): [k][64] with column ^ (((k>>1)&1) << 4);
-//       staged with ds_write_b64 along the row, fetched with ds_read_b32 at k = 8r + 2g + e (g and g+1 land in opposite bank halves)
+// LDS images:
+//   k-contiguous operand ("KC", e.g. X and W of Y = X W^T): [row][40]; staged with ds_write_b64 (16 lanes = one 128-byte row),
+//       fetched with ds_read_b128: lane (fr, g) takes k = 16h + 4g + {0..3} of row fr.  Row stride 40 = 4 * 10: in each 16-lane
+//       service group of ds_read_b128 ({0-3,12-15,20-27}, ...) the 16-byte slots fr * 10 + g (mod 16) are all distinct.
+//       (A [row][36] image read with ds_read_b64 pairs -- which the compiler fuses into ds_read2_b64, served 16 lanes at a time over
+//       32 banks -- measured 4 conflict cycles per LDS instruction: SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS on a 4096^3 problem.)
+//   row-contiguous operand ("MC", e.g. dY^T and X of dW = dY^T X, W of dX = dY W): [k][64] with column ^ (((k>>2)&1) << 4);
+//       staged with ds_write_b64 along the row, fetched with ds_read_b32 at k = 16h + 4g + s (g and g+1 land in opposite bank halves)
 // Any bijection between the 4 lane groups x 8 MFMA steps and the 32 k of a tile is a valid contraction order as long as A and B
-// agree; "group g, step 2r+e  <->  k = 8r + 2g + e" is the one that lets the KC side fetch two steps per LDS instruction.
+// agree; "group g, step 4h+s  <->  k = 16h + 4g + s" is the one that lets the KC side fetch four steps per LDS instruction.
 //
 // Staging never branches: rows beyond M / N are clamped to the last valid row (their products only reach accumulator rows that the
 // epilogue never stores), k beyond K loads from a clamped in-bounds address and is replaced by 0.
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
 // Tile order: the dispatcher places workgroup b on XCD b % 8 and every XCD has a private 4 MiB L2; logical tile = (b % 8) * chunk
 // + b / 8 gives each XCD a contiguous run of tiles (n fastest), so the 4..12 column tiles that share one 64-row slab of A hit the
 // same L2 instead of fetching the slab into up to 8 of them.
-constexpr int F_LDK = 36;
-__device__ __forceinline__ int f_swz(int k) { return ((k >> 1) & 1) << 4; }
+constexpr int F_LDK = 40;
+__device__ __forceinline__ int f_swz(int k) { return ((k >> 2) & 1) << 4; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -302,38 +305,40 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
         if (do_rowsum && t < G_BT) {                     // first wave of the n = 0 tiles: row sums of the staged A tile (bias gradients)
             if (A_KC) {
 #pragma unroll
-                for (int k = 0; k < G_BK; k += 2) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(As + t * F_LDK + k);
-                    rowsum += v[0] + v[1];
+                for (int k = 0; k < G_BK; k += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(As + t * F_LDK + k);
+                    rowsum += (v[0] + v[1]) + (v[2] + v[3]);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < G_BK; ++k) rowsum += As[k * G_BT + (t ^ f_swz(k))];
             }
         }
-        const int sw = (g & 1) << 4;                     // f_swz(8r + 2g + e)
+        const int sw = (g & 1) << 4;                     // f_swz(16h + 4g + s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float av[2][2], bv[2][2];
+        for (int h = 0; h < 2; ++h) {
+            float av[2][4], bv[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (A_KC) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(As + (wr * 32 + 16 * i + fr) * F_LDK + 8 * r + 2 * g);
-                    av[i][0] = v[0]; av[i][1] = v[1];
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(As + (wr * 32 + 16 * i + fr) * F_LDK + 16 * h + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[i][e] = v[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) av[i][e] = As[(8 * r + 2 * g + e) * G_BT + ((wr * 32 + 16 * i + fr) ^ sw)];
+                    for (int e = 0; e < 4; ++e) av[i][e] = As[(16 * h + 4 * g + e) * G_BT + ((wr * 32 + 16 * i + fr) ^ sw)];
                 }
                 if (B_KC) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(Bs + (wc * 32 + 16 * i + fr) * F_LDK + 8 * r + 2 * g);
-                    bv[i][0] = v[0]; bv[i][1] = v[1];
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + (wc * 32 + 16 * i + fr) * F_LDK + 16 * h + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[i][e] = v[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) bv[i][e] = Bs[(8 * r + 2 * g + e) * G_BT + ((wc * 32 + 16 * i + fr) ^ sw)];
+                    for (int e = 0; e < 4; ++e) bv[i][e] = Bs[(16 * h + 4 * g + e) * G_BT + ((wc * 32 + 16 * i + fr) ^ sw)];
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
