@@ -31,19 +31,48 @@ __device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
 }
 
 // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 accumulator -----------------------------------------------
+// Three paths, chosen by workgroup-uniform tests BEFORE the element loops: at K ~ 250 a workgroup runs only 8 k-tiles, and a fully
+// general per-element epilogue (eight uniform branches and 64-bit index maps per output) was ~28 % of its instructions.
+//   split-K slices: atomicAdd of alpha*acc (+ bias on slice 0)
+//   plain stride C, nothing but (bias_n, accumulate): pointer-bump stores
+//   everything else: the general form
 template <bool PLAIN>
 __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const f32x4 (&acc)[2][2], int m0, int n0, int wr, int wc,
                                               int lane, bool first_slice) {
     const int nsplit = d.split_k;
+    const int mb = m0 + wr * 32 + (lane >> 4) * 4, nb = n0 + wc * 32 + (lane & 15);
+    if (PLAIN && !d.bias_m && (nsplit > 1 || (!d.Cpre && d.act == EEGCLIP_ACT_NONE && !(d.drop_p > 0.f) && !d.R))) {
+        const long long ldc = d.Cm.si, ldn = d.Cn.si;
+        const bool use_bias = d.bias_n != nullptr && first_slice;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nb + nt * 16;
+            if (n >= d.N) continue;
+            const float bn = use_bias ? d.bias_n[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float* cp = d.C + (long long)(mb + mt * 16) * ldc + (long long)n * ldn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mb + mt * 16 + r < d.M) {
+                        const float v = d.alpha * acc[mt][nt][r] + bn;
+                        if (nsplit > 1) atomicAdd(cp + r * ldc, v);
+                        else cp[r * ldc] = d.accumulate ? cp[r * ldc] + v : v;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wc * 32 + nt * 16 + (lane & 15);
+            const int n = nb + nt * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + mt * 16 + (lane >> 4) * 4 + r;
+                const int m = mb + mt * 16 + r;
                 if (m >= d.M || n >= d.N) continue;
                 float v = d.alpha * acc[mt][nt][r];
                 if (first_slice) {

@@ -5,6 +5,8 @@
 
 namespace eeg {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int LN_MAXC = 16;   // columns per lane: cols <= 1024 (NC = 4 instantiation for cols <= 256: the encoder's 250-wide rows
                               // would otherwise drag 12 dead guarded iterations through every loop)
 
@@ -48,77 +50,124 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-// backward, one kernel:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   [+ dx_drop = dropout'(dx)]
-//                        dgamma[c] += sum_rows dy * xhat ;  dbeta[c] += sum_rows dy
-// One wave per row, `rpw` consecutive rows per wave; the lane that owns column c keeps the parameter partial sums of its columns in
-// registers across its rows, the 4 waves of a workgroup combine through LDS and issue one atomic per column.  (The first version
-// read dy and x a second time in a column-parallel kernel: 36 + 14 us per 16 MB tensor; this one streams them once.)
-template <int NC>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
-                                                             int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
-                                                             unsigned long long seed, unsigned site, int rpw) {
-    EEG_LDS_BASE(float, red);            // [2][4][cols]
+// backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   [+ dx_drop = dropout'(dx)]
+// One wave per row, one row per wave.  Lane l owns the 4 CONSECUTIVE columns 256 i + 4 l .. + 3 of every 256-column group: 8-byte
+// accesses, and the dropout mask of a lane's 4 elements comes from one Philox block (two when row * cols is not a multiple of 4 --
+// a wave-uniform case) instead of four: with a lane-strided column map the 4.1 M Philox evaluations of a (16384, 250) tensor, not
+// HBM, set this kernel's time.  A fused variant that also accumulated dgamma / dbeta (LDS combine + one atomic per column and
+// workgroup) measured slower than this + the column-parallel kernel below: 1024 same-address atomics per parameter.
+template <int NG, bool VEC2>
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
+                                                                int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
+                                                                unsigned long long seed, unsigned site) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    float gam[NC], pg[NC], pb[NC];
+    auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
+        if (VEC2) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        gam[i] = c < cols ? gamma[c] : 0.f;
-        pg[i] = 0.f;
-        pb[i] = 0.f;
-    }
-    const int row0 = (blockIdx.x * 4 + wave) * rpw;
-    for (int row = row0; row < row0 + rpw && row < rows; ++row) {
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = c + 2 * h < cols;                 // cols even: a pair is all in or all out
+                const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
+                v[2 * h] = t[0];
+                v[2 * h + 1] = t[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = c + e < cols ? p[c + e] : 0.f;
+        }
+    };
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (long long)row * cols;
         const float* dr = dy + (long long)row * cols;
         const float mu = mean[row], rs = rstd[row];
-        float xh[NC], g[NC];
+        float xh[NG][4], g[NG][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = lane + 64 * i;
-            const bool ok = c < cols;
-            const float d = ok ? dr[c] : 0.f;
-            xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
-            g[i] = d * gam[i];
-            pg[i] += d * xh[i];
-            pb[i] += d;
-            s1 += g[i];
-            s2 += g[i] * xh[i];
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            float xv[4], dv[4], gv[4];
+            ld4(xr, c, xv);
+            ld4(dr, c, dv);
+            ld4(gamma, c, gv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = c + e < cols ? (xv[e] - mu) * rs : 0.f;
+                g[i][e] = dv[e] * gv[e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
         }
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
         float* dxr = dx + (long long)row * cols;
+        const unsigned long long rbase = (unsigned long long)row * cols;
+        const unsigned off = (unsigned)(rbase & 3ull);            // wave-uniform misalignment of this row against the Philox blocks
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < cols) {
-                float v = rs * (g[i] - c1 - xh[i] * c2);
-                if (accumulate_dx) v += dxr[c];
-                dxr[c] = v;
-                if (dx_drop) {       // second output: the gradient pushed back through the dropout that fed this LayerNorm's residual branch
-                    const unsigned long long idx = (unsigned long long)row * cols + c;
-                    dx_drop[idx] = (drop_p > 0.f && !dropout_keep(seed, site, idx, drop_p)) ? 0.f : v * keep_scale;
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+                if (accumulate_dx && c + e < cols) v[e] += dxr[c + e];
+            }
+            bool keep[4] = {true, true, true, true};
+            if (dx_drop && drop_p > 0.f && c < cols) {
+                const unsigned long long i0 = rbase + c;          // element index of v[0]; block-aligned start is i0 - off
+                bool k0[4], k1[4];
+                dropout_keep4(seed, site, i0 - off, drop_p, k0);
+                if (off) dropout_keep4(seed, site, i0 - off + 4, drop_p, k1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) keep[e] = (off + e < 4) ? k0[(off + e) & 3] : k1[(off + e) & 3];
+            }
+            if (VEC2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (c + 2 * h < cols) {
+                        *reinterpret_cast<f32x2*>(dxr + c + 2 * h) = f32x2{v[2 * h], v[2 * h + 1]};
+                        if (dx_drop)
+                            *reinterpret_cast<f32x2*>(dx_drop + rbase + c + 2 * h) =
+                                f32x2{keep[2 * h] ? v[2 * h] * keep_scale : 0.f, keep[2 * h + 1] ? v[2 * h + 1] * keep_scale : 0.f};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c + e < cols) {
+                        dxr[c + e] = v[e];
+                        if (dx_drop) dx_drop[rbase + c + e] = keep[e] ? v[e] * keep_scale : 0.f;
+                    }
                 }
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < cols) {
-            red[wave * cols + c] = pg[i];
-            red[(4 + wave) * cols + c] = pb[i];
+}
+
+// backward, part 2:  dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy.   Column-parallel: block = 64 columns x 4 row groups,
+// lanes walk columns (coalesced), each thread strides over its share of the rows; LDS combine, one atomic per column per block.
+__global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
+    EEG_LDS_BASE(float, red);   // [2][4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    float pg = 0.f, pb = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int r = blockIdx.x * 4 + g; r < rows; r += gridDim.x * 4) {
+            const float d = dy[(long long)r * cols + c];
+            pg += d * (x[(long long)r * cols + c] - mean[r]) * rstd[r];
+            pb += d;
         }
     }
+    red[g * 64 + lane] = pg;
+    red[256 + g * 64 + lane] = pb;
     __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        atomicAdd(dgamma + c, (red[c] + red[cols + c]) + (red[2 * cols + c] + red[3 * cols + c]));
-        atomicAdd(dbeta + c, (red[4 * cols + c] + red[5 * cols + c]) + (red[6 * cols + c] + red[7 * cols + c]));
+    if (g == 0 && c < cols) {
+        atomicAdd(dgamma + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+        atomicAdd(dbeta + c, (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
     }
 }
 
@@ -280,16 +329,19 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
         return EEGCLIP_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    // rows per wave: 4 once that still leaves >= 4 workgroups per CU (each parameter column then takes rows/16 atomics), else 1
-    const int rpw = rows >= 16384 ? 4 : 1;
-    const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
-    const size_t lds = (size_t)8 * cols * sizeof(float);
-    if (cols <= 256)
-        EEG_LAUNCH(layernorm_bwd_kernel<4>, grid, dim3(256), lds, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols, accumulate_dx,
-                   dx_drop, drop_p, seed, site, rpw);
-    else
-        EEG_LAUNCH(layernorm_bwd_kernel<LN_MAXC>, grid, dim3(256), lds, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, cols,
-                   accumulate_dx, dx_drop, drop_p, seed, site, rpw);
+    const dim3 grid(grid_for(rows, 4, 8192));
+    const bool vec2 = (cols % 2 == 0) && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop)) & 7u);
+#define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
+    EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, \
+               drop_p, seed, site)
+    if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
+    else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
+#undef EEG_LN_BWD_GO
+    int chunks = (rows + 63) / 64;              // >= 16 rows per thread before the atomics
+    if (chunks > 256) chunks = 256;
+    EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
+               dbeta, rows, cols);
     return (int)hipGetLastError();
 }
 
