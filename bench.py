@@ -254,7 +254,7 @@ def main():
 
 
 def _desc_of(plan, idx):
-    fn, a, name = plan.ops[idx]
+    fn, a, name = plan.ops[idx][:3]
     if name == "eegclip_gemm_f32":
         return a[0]._obj
     return None

@@ -470,8 +470,8 @@ class _Engine:
         def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None):
             """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major; bias: G[bias] (Nout) += column sums of dY, taken
             from the A tiles the same launch stages (rowsum_a) instead of a separate pass over dY"""
-            pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
-                    rowsum_a=_p(G[bias]) if bias else None)
+            return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
+                           rowsum_a=_p(G[bias]) if bias else None, side=True)    # nobody reads a weight gradient before the optimizer
 
         pl.memset(b["zb"])                        # BatchNorm backward sums + the split-K accumulators dgu / dfeat
         # head LayerNorm
@@ -490,7 +490,7 @@ class _Engine:
         # 1x1 conv: dfeat is [(b,w)][e]
         pl.gemm(C_TS, C_TS, B * W_TS, _p(b["dfeat"]), D(1), D(C_TS), _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS),
                 _p(G["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1), accumulate=1, split_k=sk(B * W_TS * 8),
-                rowsum_a=_p(G["enc_eeg.0.projection.0.bias"]))
+                rowsum_a=_p(G["enc_eeg.0.projection.0.bias"]), side=True)
         pl.gemm(B * W_TS, C_TS, C_TS, _p(b["dfeat"]), D(C_TS), D(1), _p(P["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1),
                 _p(b["dz2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS))
         # BN2 + ELU + dropout backward
@@ -502,7 +502,7 @@ class _Engine:
         if "scw_ws" not in b:
             b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
-        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH)
+        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, side=True)
         pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]), B, N_CH)
         local1 = None
         if W > 1:
@@ -517,8 +517,9 @@ class _Engine:
                 float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
         if "tsw_ws" not in b:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS)
-        pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]))
+        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS,
+                side=True)
+        pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]), side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(b["weff"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
         pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),

@@ -4,6 +4,12 @@ Building the ctypes argument records costs tens of microseconds per launch in Py
 given shape; replaying a plan is a tight loop of foreign calls on the current HIP stream (and is what gets captured into
 a hipGraph by `torch.cuda.graph`).  Only the dropout seed changes between replays: ops that draw a mask register a
 seed slot that `run()` patches.
+
+Side stream: an op built with ``side=True`` is launched on a second HIP stream after an event that orders it behind everything
+enqueued so far on the main stream; the main stream does NOT wait for it until ``join()`` (implicit at the end of the plan).  The
+backward plans use it for the weight-gradient kernels, whose results nobody reads before the optimizer step: a dW GEMM (512 workgroups
+of 16 k-tiles) and the dX GEMM that follows it on the main stream (1024 workgroups of 8 k-tiles) then share the 256 CUs instead
+of running as two half-empty waves of lock-stepped workgroups.
 """
 import ctypes
 
@@ -22,35 +28,41 @@ class Plan:
         self._seed_slots = []  # (op index, arg index)
         self.L = lib()
         self.timed = {}        # op index -> list of (start, end) torch.cuda.Event pairs (HIP events on the launch stream)
+        self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
+        self.use_side_stream = True
 
     # -- generic positional op; `seed_at` = index of the seed argument (patched at run time)
-    def call(self, fname, *args, seed_at=None):
+    def call(self, fname, *args, seed_at=None, side=False):
         fn = getattr(self.L, fname)
-        self.ops.append((fn, list(args) + [None], fname))
+        self.ops.append((fn, list(args) + [None], fname, side))
         if seed_at is not None:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
     def gemm(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None):
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, side=False):
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
                           drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a)
         self._keep.append(d)
         if drop_p > 0.0:
             self._seed_descs.append(d)
-        self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32"))
+        self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", side))
         return d
 
     def callback(self, fn, name="callback"):
         """run a host callable in stream order (collectives between kernels: SyncBN statistics)"""
-        self.ops.append((None, [fn], name))
+        self.ops.append((None, [fn], name, False))
 
     def memset(self, tensor):
         """zero a torch tensor as part of the plan (stream-ordered)"""
-        self.ops.append((None, [tensor], "memset"))
+        self.ops.append((None, [tensor], "memset", False))
+
+    def join(self):
+        """the main stream waits for everything launched on the side stream so far"""
+        self.ops.append((None, [None], "join", False))
 
     def op_names(self):
-        return [name for _, _, name in self.ops]
+        return [op[2] for op in self.ops]
 
     def time_ops(self, indices):
         """record a HIP event pair around the given ops on every run (bench.py roofline / per-kernel breakdown)"""
@@ -67,23 +79,44 @@ class Plan:
         for i, j in self._seed_slots:
             self.ops[i][1][j] = seed
         timed = self.timed
-        if timed:
-            import torch
-            ts = torch.cuda.current_stream()
-        for idx, (fn, args, name) in enumerate(self.ops):
+        import torch
+        side = None
+        if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
+            if self._side is None:
+                self._side = (torch.cuda.Stream(), {i: torch.cuda.Event() for i, op in enumerate(self.ops) if op[3]}, torch.cuda.Event())
+            side = self._side
+        ts = torch.cuda.current_stream() if (timed or side) else None
+        dirty = False                                    # side stream has work the main stream has not waited for
+        for idx, (fn, args, name, on_side) in enumerate(self.ops):
+            use_side = on_side and side is not None
             if timed and idx in timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(ts)
+                e0.record(side[0] if use_side else ts)
             if fn is None:
                 if name == "memset":
                     args[0].zero_()
+                elif name == "join":
+                    if dirty:
+                        side[2].record(side[0])
+                        ts.wait_event(side[2])
+                        dirty = False
                 else:
                     args[0]()
             else:
-                args[-1] = stream
+                if use_side:
+                    ev = side[1][idx]
+                    ev.record(ts)                        # order the side op behind everything enqueued on the main stream so far
+                    side[0].wait_event(ev)
+                    args[-1] = side[0].cuda_stream
+                    dirty = True
+                else:
+                    args[-1] = stream
                 rc = fn(*args)
                 if rc:
                     check(rc, f"{self.name}:{name}")
             if timed and idx in timed:
-                e1.record(ts)
+                e1.record(side[0] if use_side else ts)
                 timed[idx].append((e0, e1))
+        if dirty:
+            side[2].record(side[0])
+            ts.wait_event(side[2])
