@@ -351,7 +351,7 @@ class _Engine:
         b = dict(
             h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
             f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
-            weff=f(C_TS, 75), y1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
+            y1=f(B, C_TS, N_CH, W_TS), y2=f(B, C_TS, W_TS), z2=f(B, C_TS, W_TS),
             feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
             bn=f(4, C_TS), ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
@@ -373,7 +373,7 @@ class _Engine:
 
         R = B * L_TOK
         b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
-                 dy1=f(B, C_TS, N_CH, W_TS), dweff=f(C_TS, 75),
+                 dy1=f(B, C_TS, N_CH, W_TS),
                  # tsconv_bwd_x writes token rows 0..62 of every sample; row 63 (EEG channel 62, dropped by the reference's [:, :63]
                  # slice) never receives a gradient from the conv path: zeroed once here, nothing else ever writes dn3
                  dn3=torch.zeros(B, L_TOK, D_MODEL, dtype=torch.float32, device=dev),
@@ -412,11 +412,10 @@ class _Engine:
                 _p(b["rs2"]), R, D_MODEL, EPS)
         pl.call("eegclip_layernorm_fwd", _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]),
                 _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS)
-        # A4+A5: tokens 0..62 -> fused conv+pool (75 taps, stride 5) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
+        # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
-        pl.call("eegclip_tsconv_fold", _p(P[_TS + "0.weight"]), _p(b["weff"]))
         pl.memset(b["zf"])
-        pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["weff"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
+        pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
                 C_TS, _p(sums[0]) if train else None)
         W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
         if W > 1:
@@ -517,10 +516,9 @@ class _Engine:
                 float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
         if "tsw_ws" not in b:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(b["dweff"]), _p(b["tsw_ws"]), B, N_CH, T_LEN, C_TS,
-                side=True)
-        pl.call("eegclip_tsconv_unfold_grad", _p(b["dweff"]), _p(G[_TS + "0.weight"]), side=True)
-        pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(b["weff"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
+        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
+                C_TS, side=True)
+        pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
         pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
                 _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0)

@@ -39,6 +39,27 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// all lanes of the calling wave have executed everything before this point (LDS traffic included) before any lane goes on: on the
+// hardware a wavefront IS in lockstep and LDS operations of one wave retire in order, so this only pins the compiler's schedule
+__device__ __forceinline__ void wave_sync() {
+#if defined(EEG_EMU)
+    hipemu::wave_sync();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ float wave_inclusive_scan(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
 // ---- wave-level reductions (64 lanes, xor butterfly) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

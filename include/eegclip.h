@@ -164,19 +164,20 @@ int eegclip_attention_fwd(const float* qkv, float* ctx, int B, int L, int H, int
 int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream);
 
-/* ---- tsconv front: Conv2d(1,40,(1,25)) + AvgPool2d((1,51),(1,5)) folded into one 75-tap stride-5 filter.  ATMS_retrieval.py:102-103
- * x: token rows of T=250 floats at x + b*xs_b + h*xs_h (h < H); y/dy: (B,40,H,36).  fold: (40,25) taps -> weff (40,75).
+/* ---- tsconv front: Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)).  ATMS_retrieval.py:102-103
+ * Computed as a 51-sample box filter of every token row (one wave-level prefix sum, shared by the 40 filters) followed by the 25-tap
+ * convolution at stride 5 -- the two commute, and K = 25 on the matrix cores instead of 75 for the folded filter; the (B,40,H,226)
+ * intermediate of the reference never exists.
+ * x: token rows of T=250 floats at x + b*xs_b + h*xs_h (h < H); w25: the (40,25) conv taps; y/dy: (B,40,H,36).
  * fwd optionally accumulates the BatchNorm batch sums of y into sums (double[80], zeroed by the caller).
- * bwd_w: dweff = sum over workgroup partials (deterministic two-stage reduction through `workspace`); unfold_grad: dw25 += fold^T(dweff).
+ * bwd_w: dw25 += sum over workgroup partials (two-stage reduction through the caller's `workspace`).
  * bwd_x overwrites dx rows h < H. */
-int eegclip_tsconv_fold(const float* w25, float* weff, void* stream);
-int eegclip_tsconv_unfold_grad(const float* dweff, float* dw25, void* stream);
-int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* weff, const float* bias, float* y, int B, int H,
+int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, float* y, int B, int H,
                        int T, int C, double* sums, void* stream);
 long long eegclip_tsconv_bwd_w_workspace_floats(int B, int H);   /* size of `workspace` below (per-workgroup partial tap gradients) */
-int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dweff, float* workspace, int B, int H,
+int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dw25, float* workspace, int B, int H,
                          int T, int C, void* stream);
-int eegclip_tsconv_bwd_x(const float* dy, const float* weff, float* dx, long long xs_b, long long xs_h, int B, int H, int T, int C,
+int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx, long long xs_b, long long xs_h, int B, int H, int T, int C,
                          void* stream);
 
 /* ---- fused spatial stage of tsconv: BatchNorm2d(40) -> ELU -> Conv2d(40,40,(H,1)) and its backward (ATMS_retrieval.py:104-106).

@@ -105,6 +105,7 @@ float atomic_max(float* p, float v);
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl_idx(v, hipemu::cur->lane ^ mask); }
 template <class T> inline T __shfl_down(T v, int d, int = 64) { int s = hipemu::cur->lane + d; return hipemu::shfl_idx(v, s < 64 ? s : hipemu::cur->lane); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hipemu::shfl_idx(v, src); }
+template <class T> inline T __shfl_up(T v, int d, int = 64) { int s = hipemu::cur->lane - d; return hipemu::shfl_idx(v, s >= 0 ? s : hipemu::cur->lane); }
 inline float atomicAdd(float* p, float v) { return hipemu::atomic_add(p, v); }
 inline double atomicAdd(double* p, double v) { return hipemu::atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return hipemu::atomic_add(p, v); }

@@ -184,15 +184,13 @@ def test_attention_fwd_bwd(be, B, H, E, p):
 
 
 @pytest.mark.parametrize("B,H", [(2, 63), (3, 5), (5, 63)])
-def test_tsconv_fold_fwd_bwd(be, B, H):
+def test_tsconv_fwd_bwd(be, B, H):
     rng = np.random.default_rng(B + H)
     w25, bias = rnd(rng, 40, 25, scale=0.2), rnd(rng, 40, scale=0.1)
     xfull = rnd(rng, B, 64, 250)                       # encoder output; rows h < H are convolved in place
     W25, BIAS, X = be.dev(w25), be.dev(bias), be.dev(xfull)
-    WEFF = be.zeros((40, 75))
-    ok(be.lib.eegclip_tsconv_fold(be.ptr(W25), be.ptr(WEFF), be.stream))
     Y, SUMS = be.zeros((B, 40, H, 36)), be.zeros(80, np.float64)
-    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(WEFF), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS), be.stream))
+    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS), be.stream))
     xt = torch.tensor(xfull, dtype=torch.float64, requires_grad=True)
     wt = torch.tensor(w25, dtype=torch.float64, requires_grad=True)
     bt = torch.tensor(bias, dtype=torch.float64)
@@ -204,13 +202,12 @@ def test_tsconv_fold_fwd_bwd(be, B, H):
     np.testing.assert_allclose(s[40:], (yt.detach() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-5)
     dy = rnd(rng, B, 40, H, 36)
     yt.backward(torch.tensor(dy, dtype=torch.float64))
-    DY, DWEFF, DW25 = be.dev(dy), be.zeros((40, 75)), be.dev(np.ones((40, 25), np.float32))
+    DY, DW25 = be.dev(dy), be.dev(np.ones((40, 25), np.float32))
     WS = be.zeros(int(be.lib.eegclip_tsconv_bwd_w_workspace_floats(B, H)))
-    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY), be.ptr(DWEFF), be.ptr(WS), B, H, 250, 40, be.stream))
-    ok(be.lib.eegclip_tsconv_unfold_grad(be.ptr(DWEFF), be.ptr(DW25), be.stream))
+    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY), be.ptr(DW25), be.ptr(WS), B, H, 250, 40, be.stream))
     np.testing.assert_allclose(be.host(DW25) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
     DX = be.dev(np.full((B, 64, 250), 7.0, np.float32))
-    ok(be.lib.eegclip_tsconv_bwd_x(be.ptr(DY), be.ptr(WEFF), be.ptr(DX), 64 * 250, 250, B, H, 250, 40, be.stream))
+    ok(be.lib.eegclip_tsconv_bwd_x(be.ptr(DY), be.ptr(W25), be.ptr(DX), 64 * 250, 250, B, H, 250, 40, be.stream))
     dx = be.host(DX)
     np.testing.assert_allclose(dx[:, :H], xt.grad.numpy()[:, :H], atol=3e-5)
     assert (dx[:, H:] == 7.0).all()                   # rows beyond H are not touched
