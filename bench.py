@@ -170,13 +170,17 @@ def main():
     timed_sel = {}
     if args.breakdown:
         for k, pl in plans.items():
+            pl.use_side_stream = False          # one stream: per-kernel times that add up (the headline run overlaps the weight-gradient kernels)
             pl.time_ops(range(len(pl.ops)))
     else:
-        # pass 0 (untimed by the headline clock): 3 instrumented steps to find the dominant kernel, unless one is named
+        # pass 0 (untimed by the headline clock): 3 instrumented single-stream steps to find the dominant kernel, unless one is named
         for k, pl in plans.items():
+            pl.use_side_stream = False
             pl.time_ops(range(len(pl.ops)))
         for i in range(3):
             step(i)
+        for k, pl in plans.items():
+            pl.use_side_stream = True
         tot = {}
         for k, pl in plans.items():
             for idx, v in pl.timings_ms().items():

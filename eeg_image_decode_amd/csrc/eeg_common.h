@@ -39,13 +39,17 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// all lanes of the calling wave have executed everything before this point (LDS traffic included) before any lane goes on: on the
-// hardware a wavefront IS in lockstep and LDS operations of one wave retire in order, so this only pins the compiler's schedule
+// all lanes of the calling wave have executed everything before this point (LDS traffic included) before any lane goes on.  On the
+// hardware a wavefront IS in lockstep and LDS operations of one wave retire in order; what has to be pinned is the COMPILER, which
+// otherwise moves a lane's LDS load above its own earlier store to a provably different address (the value another lane wrote
+// there is invisible to single-thread alias analysis): wavefront-scope release / acquire fences around the scheduling barrier.
 __device__ __forceinline__ void wave_sync() {
 #if defined(EEG_EMU)
     hipemu::wave_sync();
 #else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
 
