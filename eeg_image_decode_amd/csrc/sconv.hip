@@ -25,18 +25,22 @@ struct bn_affine {            // per-channel BatchNorm as y -> xhat -> u: xhat =
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = (sample, K slice); K = (c,h) = 40*H is cut into SCF_KS slices (a whole sample per workgroup left ONE workgroup
-// of 4 waves per CU: 126 us for a 93 MB read); each slice is streamed in chunks of 128 k; the 4 waves split a chunk's 32 k-steps and
-// keep private 3x3 accumulator tiles (o x w), combined through LDS at the end and added atomically into y2 (zeroed by the launcher).
+// of 4 waves per CU: 126 us for a 93 MB read); each slice is streamed in chunks of 128 k, wave v owning k = 32v .. 32v+31 of a chunk.
+//   B operand (activations): y1 chunk -> registers -> ELU(BN(.)) -> LDS [128][52] (16-byte stores; rows 4 apart land 16 banks apart)
+//   A operand (weights):     straight from global/L2 into registers in MFMA order -- lane (fr, g) fetches Ws[o = 16i + fr][k .. k+3] as
+//       one 16-byte load and feeds four k-steps (the k-slot <-> lane-group assignment is free as long as both operands agree).  A staged
+//       [48][129] weight tile cost 3.2 LDS conflict cycles per LDS instruction (SQ_LDS_BANK_CONFLICT) and half the LDS traffic.
+// The 4 waves keep private 3x3 accumulator tiles (o x w), combined through LDS at the end and added atomically into y2 (zeroed by
+// the launcher).
 constexpr int SCF_KC = 128;
 constexpr int SCF_KS = 4;
-constexpr int SCF_LW = SCF_KC + 1;     // weight tile row stride (odd: the 16 out-channel rows of an operand read hit distinct banks)
+constexpr int SCF_LZ = 52;             // activation tile row stride
 __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
                                                          const float* __restrict__ bs, float* __restrict__ y2, int B, int H, int kper) {
     EEG_LDS_BASE(float, lds);
-    float* wl = lds;                          // [48][SCF_LW]   Ws[o][k0 + kk]   (rows >= 40 zero)
-    float* zl = wl + SC_OP * SCF_LW;          // [128][48]      z1[k0 + kk][w]   (cols >= 36 zero)
-    float* aff = zl + SCF_KC * SC_OP;         // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
-    float* red = lds;                         // 2 x [48][52] cross-wave reduction scratch, aliases the operand tiles after the last chunk
+    float* zl = lds;                          // [128][52]      z1[k0 + kk][w]   (cols >= 36 zero)
+    float* aff = zl + SCF_KC * SCF_LZ;        // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
+    float* red = lds;                         // 2 x [48][52] cross-wave reduction scratch, aliases the activation tile after the last chunk
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
@@ -47,24 +51,25 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
         aff[t] = sc;
         aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
     }
-    for (int i = t; i < SC_OP * SCF_LW; i += 256) wl[i] = 0.f;
-    for (int i = t; i < SCF_KC * SC_OP; i += 256) zl[i] = 0.f;
+    for (int i = t; i < SCF_KC * SCF_LZ; i += 256) zl[i] = 0.f;
     f32x4 acc[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* yb = y1 + (long long)b * K * SC_W;
-    // software pipeline: the global loads of chunk k0+128 (5 weight + 5 activation float4 per thread; kbeg, K and 36 are multiples of 4,
+    // software pipeline: the global loads of chunk k0+128 (6 weight + 5 activation float4 per thread; kbeg, K and 36 are multiples of 4,
     // so a float4 never straddles a row of either operand) are issued before the MFMAs of chunk k0 and land under them
-    f32x4 vw[5], vy[5];
+    f32x4 va[3][2], vy[5];
     const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
     auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = t + 256 * j, o = i >> 5, kk = 4 * (i & 31);               // 40 rows x 32 float4
-            vw[j] = (k0 + kk < kend) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k0 + kk) : zero4v;
-        }
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int o = 16 * i + fr, k = k0 + 32 * wv + 16 * h + 4 * g;
+                va[i][h] = (o < SC_C && k < kend) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
+            }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int e = 4 * (t + 256 * j), kk = e / SC_W;                          // 128 rows x 9 float4
@@ -72,12 +77,6 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
         }
     };
     auto store_chunk = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = t + 256 * j, o = i >> 5, kk = 4 * (i & 31);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wl[o * SCF_LW + kk + q] = vw[j][q];
-        }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int e = 4 * (t + 256 * j), kk = e / SC_W, w = e % SC_W;
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 #pragma unroll
                     for (int q = 0; q < 4; ++q) z[q] = elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
                 }
-                *reinterpret_cast<f32x4*>(zl + kk * SC_OP + w) = z;
+                *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
             }
         }
     };
@@ -97,21 +96,26 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     for (int k0 = kbeg; k0 < kend; k0 += SCF_KC) {
         __syncthreads();
         store_chunk(k0);
+        f32x4 a[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) a[i][h] = va[i][h];
         __syncthreads();
         if (k0 + SCF_KC < kend) load_chunk(k0 + SCF_KC);
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const int kq = 4 * (wv * 8 + s8) + g;
-            float av[3], bv[3];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) av[i] = wl[(16 * i + fr) * SCF_LW + kq];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float* zp = zl + (32 * wv + 16 * h + 4 * g + s4) * SCF_LZ + fr;
+                float bv[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bv[j] = zl[kq * SC_OP + 16 * j + fr];
+                for (int j = 0; j < 3; ++j) bv[j] = zp[16 * j];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f32_16x16x4(av[i], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
-        }
+                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+            }
     }
     // cross-wave sum of the four k-partial accumulator sets: a two-level tree through LDS with plain stores (waves 2,3 -> 0,1, then
     // 1 -> 0).  The first version used 36 ds_add_f32 per lane into one tile: LDS float atomics retire at ~170 cycles per wave
@@ -393,7 +397,7 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
     if (!sc_aligned16(y1) || !sc_aligned16(Ws)) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H, kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;       // slices start on 16-byte boundaries of both operands
-    const size_t lds = (SC_OP * SCF_LW + SCF_KC * SC_OP + 2 * SC_C) * sizeof(float);
+    const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
     hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
     EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
     if (sums2) EEG_LAUNCH(sconv_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, y2, sums2, B);
