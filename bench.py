@@ -189,6 +189,10 @@ def main():
         cands = sorted(tot.items(), key=lambda kv: -kv[1])
         for (k, idx), ms in cands:
             name = plans[k].ops[idx][2]
+            # auto: the largest launch whose LIVE duration is its own -- plans with side-stream ops (the backward) overlap kernels of two
+            # streams inside the timed region, which stretches every per-launch duration there; name an op explicitly to time one anyway
+            if args.roofline_kernel == "auto" and any(op[3] for op in plans[k].ops):
+                continue
             if args.roofline_kernel in ("auto", name) and algorithmic_cost(name, _desc_of(plans[k], idx), B) is not None:
                 timed_sel = {(k, idx): name}
                 plans[k].time_ops([idx])

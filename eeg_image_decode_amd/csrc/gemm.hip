@@ -236,34 +236,55 @@ __device__ __forceinline__ int f_swz(int k) { return ((k >> 2) & 1) << 4; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool A_KC, bool B_KC, bool C_PLAIN>
+template <bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false>
 __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
     constexpr int A_FLOATS = A_KC ? G_BT * F_LDK : G_BK * G_BT;
     EEG_LDS_BASE(float, lds);
     float* As = lds;
     float* Bs = lds + A_FLOATS;
 
-    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (logical >= ntiles) return;                       // whole workgroup leaves before any barrier
+    int logical, slice = 0;
+    if (d.split_k == 1) {
+        logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if (logical >= ntiles) return;                   // whole workgroup leaves before any barrier
+    } else {
+        // split-K (weight gradients: few output tiles, K = all rows of the batch): ALL tiles of one K slice go to ONE XCD, so the
+        // slice of A and B is fetched from HBM once and re-read from that XCD's L2 by the other tiles (a tile-major order spread the
+        // 16 tiles of a 250 x 256 gradient over all 8 XCDs: 114 MB of HBM traffic for 33 MB of operands, rocprofv3 FETCH_SIZE)
+        const int slot = (int)(blockIdx.x >> 3);
+        slice = (int)(blockIdx.x & 7) + 8 * (slot / ntiles);
+        logical = slot % ntiles;
+        if (slice >= d.split_k) return;
+    }
     const int m0 = (logical / gx) * G_BT, n0 = (logical % gx) * G_BT;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
     int kt_begin, kt_end;
-    gemm_k_slice(d, blockIdx.y, kt_begin, kt_end);
+    gemm_k_slice(d, slice, kt_begin, kt_end);
 
     // staging roles: KC operand -> thread (row = r0 + 16 i, k pair kp);  MC operand -> thread (k = kr0 + 8 i, row pair mp)
     const int kp = t & 15, r0 = t >> 4, mp = t & 31, kr0 = t >> 5;
     const int a_ld = A_KC ? (int)d.Am.si : (int)d.Ak.si, b_ld = B_KC ? (int)d.Bn.si : (int)d.Bk.si;
     int a_fix[4], b_fix[4];          // KC: element offset of the (clamped) row;  MC: running element offset of the k row
     int a_col = 0, b_col = 0;        // MC: clamped first row of the pair
+    // K2 (both operands row-contiguous, k through a two-level map {div, so, si}: the value-embedding weight gradient contracts over
+    // the 63 channel rows of every 64-row sample): the k row advances by 32 per tile, so (offset, remainder) are carried along and
+    // wrapped by subtraction -- no division in the loop
+    int a_rem[K2 ? 4 : 1], b_rem[K2 ? 4 : 1];
+    const int a_div = K2 ? (d.Ak.div > 0x7fffffffLL ? 0x7fffffff : (int)d.Ak.div) : 0;      // plain map: one block that never wraps
+    const int b_div = K2 ? (d.Bk.div > 0x7fffffffLL ? 0x7fffffff : (int)d.Bk.div) : 0;
+    const int a_wrap = K2 ? (int)(d.Ak.so - d.Ak.div * d.Ak.si) : 0, b_wrap = K2 ? (int)(d.Bk.so - d.Bk.div * d.Bk.si) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int kfirst = kt_begin * G_BK + kr0 + 8 * i;
         if (A_KC) { const int m = m0 + r0 + 16 * i; a_fix[i] = (m < d.M ? m : d.M - 1) * a_ld; }
-        else      a_fix[i] = (kt_begin * G_BK + kr0 + 8 * i) * a_ld;
+        else if (K2) { a_rem[i] = kfirst % a_div; a_fix[i] = (kfirst / a_div) * (int)d.Ak.so + a_rem[i] * a_ld; }
+        else      a_fix[i] = kfirst * a_ld;
         if (B_KC) { const int n = n0 + r0 + 16 * i; b_fix[i] = (n < d.N ? n : d.N - 1) * b_ld; }
-        else      b_fix[i] = (kt_begin * G_BK + kr0 + 8 * i) * b_ld;
+        else if (K2) { b_rem[i] = kfirst % b_div; b_fix[i] = (kfirst / b_div) * (int)d.Bk.so + b_rem[i] * b_ld; }
+        else      b_fix[i] = kfirst * b_ld;
     }
     if (!A_KC) { const int m = m0 + 2 * mp; a_col = m < d.M ? m : d.M - 2; }
     if (!B_KC) { const int n = n0 + 2 * mp; b_col = n < d.N ? n : d.N - 2; }
@@ -287,6 +308,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
                 ra[i] = *reinterpret_cast<const f32x2*>(d.A + (ok ? a_fix[i] : 0) + a_col);
                 okbits |= (ok ? 1u : 0u) << i;
                 a_fix[i] += G_BK * a_ld;
+                if (K2) {
+                    a_rem[i] += G_BK;
+                    while (a_rem[i] >= a_div) { a_rem[i] -= a_div; a_fix[i] += a_wrap; }
+                }
             }
         }
 #pragma unroll
@@ -299,6 +324,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
                 rb[i] = *reinterpret_cast<const f32x2*>(d.B + (ok ? b_fix[i] : 0) + b_col);
                 okbits |= (ok ? 1u : 0u) << (4 + i);
                 b_fix[i] += G_BK * b_ld;
+                if (K2) {
+                    b_rem[i] += G_BK;
+                    while (b_rem[i] >= b_div) { b_rem[i] -= b_div; b_fix[i] += b_wrap; }
+                }
             }
         }
     };
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
         __syncthreads();
     }
     if (do_rowsum && t < G_BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-    gemm_epilogue<C_PLAIN>(d, acc, m0, n0, wr, wc, lane, blockIdx.y == 0);
+    gemm_epilogue<C_PLAIN>(d, acc, m0, n0, wr, wc, lane, slice == 0);
 }
 
 static inline bool is_plain(const eegclip_dim& x) { return x.div > (1LL << 40); }
@@ -392,6 +421,14 @@ static bool fast_operand_ok(const float* p, long long row_si, long long k_si, in
     return false;
 }
 
+// row-contiguous operand whose k index goes through a (possibly two-level) map: even strides, even row count, 32-bit reach
+static bool fast_k2_ok(const float* p, const eegclip_dim& kd, int rows, int K) {
+    if (!aligned8(p) || kd.si < 0 || kd.so < 0 || (kd.si & 1) || (kd.so & 1) || (rows & 1) || rows < 2) return false;
+    const long long div = kd.div > (1LL << 30) ? (1LL << 30) : kd.div;                 // plain map: never wraps
+    const long long reach = ((K - 1) / div) * kd.so + ((K - 1) % div) * kd.si + rows + 2;
+    return kd.div >= 1 && reach < (1LL << 31) && (kd.div > (1LL << 30) || kd.so - kd.div * kd.si < (1LL << 31));
+}
+
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const int gx = (d.N + G_BT - 1) / G_BT, gy = (d.M + G_BT - 1) / G_BT;
     const dim3 block(G_THREADS);
@@ -399,24 +436,32 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const bool c_plain = is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn)));
     const bool plain = ab_plain && c_plain;
     static const bool allow_fast = !(getenv("EEGCLIP_GEMM_FAST") && atoi(getenv("EEGCLIP_GEMM_FAST")) == 0);   // tuning aid
+    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                           // tuning aid
     bool akc = false, bkc = false;
+    const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
+    const dim3 fgrid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles);
     if (allow_fast && ab_plain && d.K >= 2 && (long long)gx * gy < (1LL << 28) && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) &&
         fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) {
-        const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
-        const dim3 grid(8 * chunk, d.split_k);
-        static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                       // tuning aid
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
         const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
 #define EEG_FAST_GO(AK, BK_)                                                                                                         \
     do {                                                                                                                             \
-        if (c_plain) EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);             \
-        else         EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);            \
+        if (c_plain) EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, true>), fgrid, block, lds, stream, d, gx, ntiles, chunk);            \
+        else         EEG_LAUNCH((gemm_f32_fast_kernel<AK, BK_, false>), fgrid, block, lds, stream, d, gx, ntiles, chunk);           \
     } while (0)
         if (akc && bkc)        EEG_FAST_GO(true, true);
         else if (akc && !bkc)  EEG_FAST_GO(true, false);
         else if (!akc && bkc)  EEG_FAST_GO(false, true);
         else                   EEG_FAST_GO(false, false);
 #undef EEG_FAST_GO
+        return (int)hipGetLastError();
+    }
+    // both operands row-contiguous with k running through two-level maps (plain row maps, plain C): the K2 instantiation
+    if (allow_fast && c_plain && is_plain(d.Am) && is_plain(d.Bn) && d.Am.si == 1 && d.Bn.si == 1 && d.K >= 2 && (long long)gx * gy < (1LL << 28) &&
+        fast_k2_ok(d.A, d.Ak, d.M, d.K) && fast_k2_ok(d.B, d.Bk, d.N, d.K)) {
+        if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<0,0,1,K2> %dx%dx%d sk%d\n", d.M, d.N, d.K, d.split_k);
+        const size_t lds = 2 * G_BK * G_BT * sizeof(float);
+        EEG_LAUNCH((gemm_f32_fast_kernel<false, false, true, true>), fgrid, block, lds, stream, d, gx, ntiles, chunk);
         return (int)hipGetLastError();
     }
     const dim3 grid(gx, gy, d.split_k);

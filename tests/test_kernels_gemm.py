@@ -185,6 +185,23 @@ def test_gemm_gelu_grad_epilogue(be):
     assert be.lib.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0      # needs the pre-activation in R
 
 
+@pytest.mark.parametrize("split", [1, 3])
+def test_gemm_value_embedding_weight_gradient_view(be, split):
+    """dW = dOut[:, 1:, :]^T X: the contraction index k = (sample, channel) runs through a two-level map on the gradient side (63 of
+    every 64 token rows) and a plain one on the EEG side -- the K2 instantiation of the fast kernel (Embed.py:146-149 backward)"""
+    rng = np.random.default_rng(14 + split)
+    Bt, Cc, Dm, T = 5, 63, 50, 70
+    dout, x, w0 = f32(rng, Bt, Cc + 1, Dm), f32(rng, Bt, Cc, T), f32(rng, Dm, T)
+    DO, X, W, RS = be.dev(dout), be.dev(x), be.dev(w0), be.zeros(Dm)
+    d = mk(be, Dm, T, Bt * Cc, DO, D(1), D(Dm, div=Cc, so=(Cc + 1) * Dm), X, D(T), D(1), W, D(T), D(1), accumulate=1, split_k=split,
+           rowsum_a=be.ptr(RS))
+    d.A = be.ptr(DO) + 4 * Dm                     # skip token row 0 of sample 0
+    run(be, d)
+    g = dout[:, 1:, :].reshape(-1, Dm).astype(np.float64)
+    np.testing.assert_allclose(be.host(W), w0 + g.T @ x.reshape(-1, T), atol=2e-4)
+    np.testing.assert_allclose(be.host(RS), g.sum(0), atol=2e-4)
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0
