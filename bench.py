@@ -54,21 +54,30 @@ def algorithmic_cost(name, desc, B):
     return None
 
 
-_KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel", "eegclip_attention_fwd": "eeg::attention_fwd_kernel",
-              "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel",
+_KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegclip_attention_fwd": "eeg::attention_fwd_kernel<true>",
+              "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel<7>",
               "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
-              "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_kernel", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false>",
+              "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false>",
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true>"}
 
 
-def pmc_traffic(op_name, B):
+_GEMM_KERNEL = "eeg::gemm_f32_fast_kernel<true, true, true>"      # Y = X W^T launches (forward Linears); f02 is the largest of them
+
+
+def pmc_traffic(op_name, B, desc=None):
     """HBM bytes per launch of the op's kernel from the committed rocprofv3 PMC summary (profiles/r1_pmc_hbm_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH doubled per the gfx950 correction).  Only valid for the profiled B=256."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-    if B != 256 or op_name not in _KERNEL_OF or not os.path.exists(path):
+    if B != 256 or not os.path.exists(path):
         return None
     with open(path) as f:
-        d = json.load(f).get(_KERNEL_OF[op_name])
+        table = json.load(f)
+    if op_name == "eegclip_gemm_f32" and desc is not None and (desc.M, desc.N, desc.K) == (B * 64, 744, 250):
+        d = table.get(_GEMM_KERNEL)                       # the QKV projection is the largest launch of this instantiation
+        return round(d["hbm_bytes_largest_launch"]) if d and "hbm_bytes_largest_launch" in d else None
+    if op_name not in _KERNEL_OF:
+        return None
+    d = table.get(_KERNEL_OF[op_name])
     return round(d["hbm_bytes_per_launch"]) if d and "hbm_bytes_per_launch" in d else None
 
 
@@ -239,7 +248,7 @@ def main():
                 ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             d = _desc_of(plans[k], idx)
             roof = {"kernel": name + (f"[{d.M}x{d.N}x{d.K}]" if d is not None else ""), "bound": bound, "achieved": round(ach, 2),
-                    "peak": peak, "unit": u, "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B), "avg_launch_ms": round(ms, 5),
+                    "peak": peak, "unit": u, "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, d), "avg_launch_ms": round(ms, 5),
                     "algorithmic_work_per_launch": work, "work_unit": unit}
 
     out = {

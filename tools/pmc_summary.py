@@ -5,17 +5,21 @@ import collections, csv, glob, json, sys
 
 def summarise(paths):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    mx = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     for p in paths:
         for r in csv.DictReader(open(p)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            mx[k][r["Counter_Name"]] = max(mx[k][r["Counter_Name"]], float(r["Counter_Value"]))
             cnt[(k, r["Counter_Name"])] += 1
     out = {}
     for k, v in agg.items():
         d = {c: val / cnt[(k, c)] for c, val in v.items()}
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+            # kernels launched on several problem shapes (the GEMMs): the largest launch
+            d["hbm_bytes_largest_launch"] = (2.0 * mx[k].get("FETCH_SIZE", 0.0) + mx[k].get("WRITE_SIZE", 0.0)) * 1024.0
         d["launches_sampled"] = max(cnt[(k, c)] for c in v)
         out[k] = d
     return out
