@@ -211,6 +211,13 @@ int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, i
 int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
                          float* loss, void* stream);
 
+/* ---- large-batch InfoNCE logits on the bf16 matrix cores (models/loss.py:122-123 at global batch 2048, D = 1024):
+ *   c[m][n] = (*scale) * sum_k a[m][k] * b[n][k]     a (M,K), b (N,K) bf16 row-major (eegclip_cast_bf16 of the fp32 features), c fp32.
+ * fp32 accumulation and fp32 logits; M, N multiples of 128, K multiple of 64, ldc multiple of 4, 16-byte aligned pointers
+ * (other sizes: eegclip_gemm_f32).  cast_bf16: n multiple of 8. */
+int eegclip_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
+int eegclip_logits_bf16(const void* a_bf16, const void* b_bf16, float* c, int M, int N, int K, long long ldc, const float* scale, void* stream);
+
 /* ---- SDXL UNet cross-attention with the IP-Adapter image branch fused (call site Generation/custom_pipeline.py:365-373; arithmetic =
  * diffusers 0.30.0 AttnProcessor2_0 / IPAdapterAttnProcessor2_0, restated -- parity unpinned):
  *   out = softmax(q k^T / sqrt(64)) v + ip_scale * softmax(q k_ip^T / 8) v_ip

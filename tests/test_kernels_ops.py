@@ -394,3 +394,27 @@ def test_fused_spatial_stage(be, B, H):
     np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
     np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
     np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
+
+
+def _bf16_round(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 192)])
+def test_logits_bf16(be, M, N, K):
+    """csrc/logits_bf16.hip: features rounded to bf16 once, fp32 accumulate on v_mfma_f32_16x16x32_bf16, fp32 logits * scale"""
+    rng = np.random.default_rng(M + N + K)
+    a, b = rnd(rng, M, K), rnd(rng, N, K)
+    A, B, SC = be.dev(a), be.dev(b), be.dev(np.array([2.6593], np.float32))
+    A16, B16 = be.zeros((M, K // 2)), be.zeros((N, K // 2))          # bf16 storage viewed as float32 pairs
+    ok(be.lib.eegclip_cast_bf16(be.ptr(A), be.ptr(A16), M * K, be.stream))
+    ok(be.lib.eegclip_cast_bf16(be.ptr(B), be.ptr(B16), N * K, be.stream))
+    got16 = be.host(A16).view(np.uint16).reshape(M, K)
+    np.testing.assert_array_equal(got16, (_bf16_round(a).view(np.uint32) >> 16).astype(np.uint16))
+    C = be.dev(np.full((M, N), np.nan, np.float32))
+    ok(be.lib.eegclip_logits_bf16(be.ptr(A16), be.ptr(B16), be.ptr(C), M, N, K, N, be.ptr(SC), be.stream))
+    ref = 2.6593 * _bf16_round(a).astype(np.float64) @ _bf16_round(b).astype(np.float64).T
+    np.testing.assert_allclose(be.host(C), ref, atol=2e-4 * max(1.0, np.abs(ref).max()))
+    assert be.lib.eegclip_logits_bf16(be.ptr(A16), be.ptr(B16), be.ptr(C), M, N - 1, K, N, be.ptr(SC), be.stream) < 0      # whole tiles only
