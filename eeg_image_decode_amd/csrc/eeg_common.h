@@ -53,6 +53,38 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// LDS-DMA: every lane copies 16 bytes global -> LDS without passing through VGPRs; the destination is wave-uniform base + 16 * lane
+// (NOT a per-lane scatter), the source address is per lane.  Asynchronous: tracked by vmcnt; a ds_read may only follow a counted
+// s_waitcnt vmcnt AND a workgroup barrier (MI355X_MICROARCH.md, LDS-DMA ordering).  Inline asm on purpose: with the builtin the compiler
+// drains vmcnt(0) at every barrier / LDS read, which serialises the pipeline this is used for.
+__device__ __forceinline__ void lds_dma16(void* lds_wave_base, const void* gsrc) {
+#if defined(EEG_EMU)
+    memcpy(static_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63), gsrc, 16);
+#else
+    // LDS byte address = low 32 bits of the generic pointer; wave-uniform by contract, pinned into an SGPR for M0
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {      // at most N vector-memory operations of this wave still in flight
+#if !defined(EEG_EMU)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// workgroup barrier WITHOUT the memory waits __syncthreads() implies (LDS-DMA pipelines count their own vmcnt)
+__device__ __forceinline__ void raw_barrier() {
+#if defined(EEG_EMU)
+    hipemu::syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ float wave_inclusive_scan(float v) {
     const int lane = threadIdx.x & 63;

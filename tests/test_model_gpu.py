@@ -181,6 +181,24 @@ def test_clip_loss_matches_reference_fixture(golden):
             assert abs(float(ClipLoss()(a.detach(), b.detach(), s.detach())) - float(g[f"loss_{n}"])) < 2e-5
 
 
+def test_clip_loss_bf16_logits_option_tracks_the_f32_loss():
+    """ClipLoss(logits_dtype="bf16"): logits of the N x N block on the bf16 matrix cores (opt-in, large-batch configuration); value and
+    gradients stay within bf16-rounding distance of the fp32-exact path"""
+    from eeg_image_decode_amd.loss import ClipLoss
+    n = 256
+    outs = []
+    for dt in ("f32", "bf16"):
+        a = T(syn.unit_features(SEED + 5, n, tag="a") * 32.0).cuda().requires_grad_(True)
+        b = T(syn.unit_features(SEED + 5, n, tag="b")).cuda()
+        s = torch.tensor(float(np.log(1 / 0.07)), device="cuda", requires_grad=True)
+        l = ClipLoss(logits_dtype=dt)(a, b, s)
+        l.backward()
+        outs.append((float(l), a.grad.cpu().numpy(), float(s.grad)))
+    assert abs(outs[0][0] - outs[1][0]) < 5e-3 * abs(outs[0][0])
+    np.testing.assert_allclose(outs[1][1], outs[0][1], atol=2e-2 * np.abs(outs[0][1]).max())
+    assert abs(outs[0][2] - outs[1][2]) < 2e-2 * max(1.0, abs(outs[0][2]))
+
+
 def test_topk_indices_bit_exact_vs_reference(state_np, golden):
     """200-way retrieval: top-5 index lists must equal the reference's exactly (north_star: bit-exact top-k indices)."""
     from eeg_image_decode_amd import retrieval
