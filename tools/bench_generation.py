@@ -1,0 +1,76 @@
+"""Generation-side measurements (BASELINE configs[3] and configs[4]) on one MI355X, HIP-event timed:
+  * diffusion-prior training step at batch 1024 (forward, MSE, backward, grad-norm clip, Adam) -> samples/s
+  * diffusion-prior sampling: 50 DDPM steps with classifier-free guidance for 8 embeddings -> ms per chain
+  * SDXL cross-attention (+ IP-Adapter branch) kernel at the UNet's two attention resolutions, 8 images x CFG -> GB/s vs the HBM roofline
+Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.utils.data import DataLoader
+from eeg_image_decode_amd.prior import DiffusionPriorUNet, Pipe, EmbeddingDataset
+from eeg_image_decode_amd.sdxl import cross_attention
+
+HBM_PEAK_GBS = 8000.0
+
+
+def ev_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def prior_train(B=1024, batches=20):
+    g = torch.Generator().manual_seed(0)
+    n = B * batches
+    ds = EmbeddingDataset(torch.randn(n, 1024, generator=g), torch.randn(n, 1024, generator=g))
+    ds.c_embeddings, ds.h_embeddings = ds.c_embeddings.cuda(), ds.h_embeddings.cuda()
+    pipe = Pipe(DiffusionPriorUNet(cond_dim=1024, dropout=0.1), device="cuda")
+    dl = DataLoader(ds, batch_size=B, shuffle=False)
+    pipe.train(dl, num_epochs=1, learning_rate=1e-3)               # warm-up: builds the plans
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.train(dl, num_epochs=3, learning_rate=1e-3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return pipe, {"batch": B, "steps": 3 * batches, "ms_per_step": round(1e3 * dt / (3 * batches), 3), "samples_per_s": round(3 * n / dt, 1)}
+
+
+def prior_sample(pipe, n=8, steps=50):
+    c = torch.randn(n, 1024, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    return {"embeddings": n, "ddpm_steps": steps, "cfg": True, "ms_per_chain": round(1e3 * (time.perf_counter() - t0) / reps, 2)}
+
+
+def cross_attn(images=8):
+    out = []
+    for HW, heads in ((4096, 10), (1024, 20)):                    # SDXL-base attention blocks at 64x64 (C=640) and 32x32 (C=1280) latents
+        B, C = 2 * images, heads * 64                             # classifier-free guidance doubles the batch
+        for dt in (torch.float16, torch.bfloat16):
+            q = torch.randn(B, HW, C, device="cuda", dtype=dt)
+            k, v = torch.randn(B, 77, C, device="cuda", dtype=dt), torch.randn(B, 77, C, device="cuda", dtype=dt)
+            ki, vi = torch.randn(B, 4, C, device="cuda", dtype=dt), torch.randn(B, 4, C, device="cuda", dtype=dt)
+            ms = ev_ms(lambda: cross_attention(q, k, v, heads, ki, vi, 1.0), 50)
+            byts = 2 * q.numel() * 2 + 2 * (k.numel() + ki.numel()) * 2          # Q in + O out + K/V (+ip) in, 16-bit
+            flop = 4.0 * B * HW * C * 81
+            out.append({"HW": HW, "heads": heads, "dtype": str(dt).split(".")[-1], "us": round(ms * 1e3, 1), "GBs": round(byts / ms / 1e6, 1),
+                        "frac_of_hbm_peak": round(byts / ms / 1e6 / HBM_PEAK_GBS, 3), "TFLOPs": round(flop / ms / 1e9, 1)})
+    return out
+
+
+if __name__ == "__main__":
+    pipe, tr = prior_train()
+    res = {"prior_train_configs3_1gpu": tr, "prior_sample": prior_sample(pipe), "sdxl_cross_attn_configs4": cross_attn()}
+    print(json.dumps(res))
