@@ -15,8 +15,9 @@ namespace eeg {
 
 constexpr int CA_D = 64;          // head_dim
 constexpr int CA_MAXT = 8;        // key tiles of 16 -> S <= 128
-constexpr int CA_KLD = CA_D + 8;  // K row stride in halfs (144 B: 16-B aligned, spreads ds_read_b128 over banks)
-constexpr int CA_QB = 256;        // queries per workgroup (4 waves x 4 tiles of 16)
+constexpr int CA_KLD = CA_D + 16; // K row stride in halfs (160 B = 16 B * 10: the 16 lanes of a ds_read_b128 service group hit 16 distinct slots;
+                                  // 144 B measured 5.8 conflict cycles per LDS instruction)
+constexpr int CA_QB = 512;        // queries per workgroup (4 waves x 8 tiles of 16): the K / V^T staging of a (sample, head) is amortised over them
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -58,9 +59,40 @@ __device__ __forceinline__ unsigned short to_h(float v) {
     }
     return f32_to_bf16_bits(v);
 }
+// two fp32 -> one dword of two 16-bit floats (round to nearest even): one v_cvt_pk_{f16,bf16}_f32 on gfx950
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+#if defined(EEG_EMU)
+    return (unsigned)to_h<F16>(a) | ((unsigned)to_h<F16>(b) << 16);
+#else
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 b16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v{a, b};
+    if (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b16x2_));
+#endif
+}
+__device__ __forceinline__ float fast_exp2(float x) {
+#if defined(EEG_EMU)
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);        // v_exp_f32
+#endif
+}
+typedef unsigned int ca_u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool F16>
 __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
     return F16 ? mfma_f16_16x16x32(a, b, c) : mfma_bf16_16x16x32(a, b, c);
+}
+
+// V^T row stride in halfs for nt key tiles: >= 32 * ceil(nt / 2) keys and = 4 (mod 64), i.e. 2 dwords (mod 32): the 16 lanes of a
+// service group of the paired 8-byte reads (ds_read2_b64, 32 banks) then walk all 32 banks (a 208-byte stride measured 4.7 conflict
+// cycles per LDS instruction)
+__host__ __device__ inline int ca_ldv(int nt) {
+    const int need = ((nt + 1) / 2) * 32;
+    return need <= 4 ? 4 : ((need - 4 + 63) / 64) * 64 + 4;
 }
 
 struct ca_args {
@@ -80,16 +112,25 @@ __device__ __forceinline__ void stage_kv(unsigned short* Ks, unsigned short* Vt,
         if (r < S) val = *reinterpret_cast<const uint4*>(k + r * row_stride + c8 * 8);
         *reinterpret_cast<uint4*>(Ks + r * CA_KLD + c8 * 8) = val;
     }
-    for (int i = t; i < ldv * CA_D; i += blockDim.x) {              // V^T[d][key], zero padded along keys
-        const int key = i / CA_D, d = i % CA_D;                     // consecutive lanes -> consecutive d (coalesced global read)
-        Vt[d * ldv + key] = key < S ? v[key * row_stride + d] : (unsigned short)0;
+    for (int i = t; i < ldv * (CA_D / 8); i += blockDim.x) {        // V^T[d][key], zero padded along keys: 16-byte reads of V rows, transposed stores
+        const int key = i / (CA_D / 8), d8 = 8 * (i % (CA_D / 8));
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (key < S) val = *reinterpret_cast<const uint4*>(v + key * row_stride + d8);
+        const unsigned w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vt[(d8 + 2 * e) * ldv + key] = (unsigned short)(w[e] & 0xffffu);
+            Vt[(d8 + 2 * e + 1) * ldv + key] = (unsigned short)(w[e] >> 16);
+        }
     }
 }
 
-// one branch (text or ip) for a 16-query tile: scores^T, softmax over keys, P V accumulated into acc[4]
+// one branch (text or ip) for a 16-query tile: scores^T, softmax over keys, P V accumulated into acc[4].  `scale2` = scale * log2(e):
+// the softmax runs in base 2 (v_exp_f32); only the last key tile can hold padding keys and is the only one masked.  (The kernel was
+// VALU-bound, not HBM-bound: 880 VALU instructions per 16-query tile -- libm expf, element-wise 16-bit packing and unpacking.)
 template <bool F16>
 __device__ __forceinline__ void branch(const unsigned short* Ks, const unsigned short* Vt, int ldv, int S, int ntile, const bf16x8 (&bq)[2],
-                                       float scale, float pscale, f32x4 (&acc)[4], int lane) {
+                                       float scale2, float pscale, f32x4 (&acc)[4], int lane) {
     const int fr = lane & 15, g = lane >> 4;
     f32x4 s[CA_MAXT];
     float mx = -INFINITY;
@@ -102,12 +143,14 @@ __device__ __forceinline__ void branch(const unsigned short* Ks, const unsigned 
             const bf16x8 ak = *reinterpret_cast<const bf16x8*>(Ks + (16 * t + fr) * CA_KLD + 32 * st + 8 * g);
             c = mma<F16>(ak, bq[st], c);                               // S^T[key = 16t + 4g + r][query = fr]
         }
+        if (t == ntile - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * t + 4 * g + r;
-            c[r] = key < S ? c[r] * scale : -INFINITY;
-            mx = fmaxf(mx, c[r]);
+            for (int r = 0; r < 4; ++r) c[r] = (16 * t + 4 * g + r) < S ? c[r] * scale2 : -INFINITY;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] *= scale2;
         }
+        mx = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), mx);
         s[t] = c;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -118,7 +161,7 @@ __device__ __forceinline__ void branch(const unsigned short* Ks, const unsigned 
         if (t >= ntile) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = expf(s[t][r] - mx);
+            const float p = fast_exp2(s[t][r] - mx);
             s[t][r] = p;
             sum += p;
         }
@@ -130,21 +173,18 @@ __device__ __forceinline__ void branch(const unsigned short* Ks, const unsigned 
 #pragma unroll
     for (int u = 0; u < CA_MAXT / 2; ++u) {
         if (2 * u >= ntile) break;
-        bf16x8 pa;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pa[r] = (short)to_h<F16>(s[2 * u][r] * nrm);
-            pa[4 + r] = (2 * u + 1 < ntile) ? (short)to_h<F16>(s[2 * u + 1][r] * nrm) : (short)0;
-        }
+        const bool two = 2 * u + 1 < ntile;
+        const f32x4 lo4 = s[2 * u], hi4 = two ? s[2 * u + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const ca_u32x4 pw{pack2<F16>(lo4[0] * nrm, lo4[1] * nrm), pack2<F16>(lo4[2] * nrm, lo4[3] * nrm),
+                          pack2<F16>(hi4[0] * nrm, hi4[1] * nrm), pack2<F16>(hi4[2] * nrm, hi4[3] * nrm)};
+        const bf16x8 pa = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
         for (int dn = 0; dn < 4; ++dn) {
             const unsigned short* vp = Vt + (16 * dn + fr) * ldv + 32 * u + 4 * g;
             const uint2 lo = *reinterpret_cast<const uint2*>(vp);
             const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
-            bf16x8 bv;
-            bv[0] = (short)(lo.x & 0xffff); bv[1] = (short)(lo.x >> 16); bv[2] = (short)(lo.y & 0xffff); bv[3] = (short)(lo.y >> 16);
-            bv[4] = (short)(hi.x & 0xffff); bv[5] = (short)(hi.x >> 16); bv[6] = (short)(hi.y & 0xffff); bv[7] = (short)(hi.y >> 16);
-            acc[dn] = mma<F16>(pa, bv, acc[dn]);                       // O[query = 4g + r][d = 16dn + fr]
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, (ca_u32x4{lo.x, lo.y, hi.x, hi.y}));
+            acc[dn] = mma<F16>(bv, pa, acc[dn]);                       // O^T[d = 16dn + 4g + r][query = fr]: 4 consecutive d per lane
         }
     }
 }
@@ -153,7 +193,7 @@ template <bool F16>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const ca_args a) {
     EEG_LDS_BASE(unsigned short, lds);
     const int nt = (a.S + 15) / 16, nt_ip = (a.S_ip + 15) / 16;
-    const int ldv = ((nt + 1) / 2) * 32 + 8, ldv_ip = ((nt_ip + 1) / 2) * 32 + 8;
+    const int ldv = ca_ldv(nt), ldv_ip = ca_ldv(nt_ip);
     unsigned short* Ks = lds;                                    // [nt*16][CA_KLD]
     unsigned short* Vt = Ks + nt * 16 * CA_KLD;                  // [64][ldv]
     unsigned short* Kip = Vt + CA_D * ldv;                       // [nt_ip*16][CA_KLD]
@@ -182,13 +222,14 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const ca_args a) {
         for (int dn = 0; dn < 4; ++dn) acc[dn] = f32x4{0.f, 0.f, 0.f, 0.f};
         branch<F16>(Ks, Vt, ldv, a.S, nt, bq, a.scale, 1.0f, acc, lane);
         if (nt_ip > 0) branch<F16>(Kip, Vip, ldv_ip, a.S_ip, nt_ip, bq, a.scale, a.ip_scale, acc, lane);
+        if (qrow < a.HW) {                                       // the output tile was formed transposed: 8-byte stores of 4 consecutive d
+            unsigned short* op = a.out + ((long long)b * a.HW + qrow) * rs + h * CA_D + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = q0 + 4 * g + r;
-            if (q < a.HW) {
-                unsigned short* op = a.out + ((long long)b * a.HW + q) * rs + h * CA_D + fr;
-#pragma unroll
-                for (int dn = 0; dn < 4; ++dn) op[16 * dn] = to_h<F16>(acc[dn][r]);
+            for (int dn = 0; dn < 4; ++dn) {
+                uint2 w;
+                w.x = pack2<F16>(acc[dn][0], acc[dn][1]);
+                w.y = pack2<F16>(acc[dn][2], acc[dn][3]);
+                *reinterpret_cast<uint2*>(op + 16 * dn) = w;
             }
         }
     }
@@ -204,11 +245,11 @@ extern "C" int eegclip_cross_attn_fwd(const void* q, const void* k, const void* 
         return EEGCLIP_EINVAL;
     if (S_ip > 0 && (!k_ip || !v_ip)) return EEGCLIP_EINVAL;
     if (dtype != EEGCLIP_DT_BF16 && dtype != EEGCLIP_DT_F16) return EEGCLIP_EINVAL;
-    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)k_ip | (uintptr_t)v_ip) & 15) != 0) return EEGCLIP_EALIGN;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)k_ip | (uintptr_t)v_ip | (uintptr_t)out) & 15) != 0) return EEGCLIP_EALIGN;
     ca_args a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (const unsigned short*)k_ip, (const unsigned short*)v_ip,
-              (unsigned short*)out, B, HW, heads, S, S_ip, 0.125f, ip_scale};
+              (unsigned short*)out, B, HW, heads, S, S_ip, 0.125f * 1.44269504088896340736f, ip_scale};      // scale * log2(e): base-2 softmax
     const int nt = (S + 15) / 16, nt_ip = (S_ip + 15) / 16;
-    const int ldv = ((nt + 1) / 2) * 32 + 8, ldv_ip = ((nt_ip + 1) / 2) * 32 + 8;
+    const int ldv = ca_ldv(nt), ldv_ip = ca_ldv(nt_ip);
     const size_t lds = sizeof(unsigned short) * ((size_t)nt * 16 * CA_KLD + CA_D * ldv + (size_t)nt_ip * 16 * CA_KLD + (nt_ip ? CA_D * ldv_ip : 0));
     const dim3 grid((HW + CA_QB - 1) / CA_QB, heads, B);
     if (dtype == EEGCLIP_DT_F16) EEG_LAUNCH((cross_attn_kernel<true>), grid, dim3(256), lds, stream, a);

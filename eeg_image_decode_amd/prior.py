@@ -176,7 +176,7 @@ class _PriorEngine:
                       f"dt1{s}": f(N, hi)})
         return b
 
-    def _build_fwd(self, N, cond, p):
+    def _build_fwd(self, N, cond, p, cond_rows=None):
         P, b, m = self.P, self.bufs[N], self.model
         pl = Plan(f"prior_fwd[N={N}]")
         E, Td, Cd, h0 = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0]
@@ -197,8 +197,8 @@ class _PriorEngine:
             pl.gemm(N, hi, hi, _p(b[f"t1act{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(1), D(hi), _p(b[f"xin{s}"]), D(hi), D(1),
                     bias_n=_p(P[st["t"] + "linear_2.bias"]), R=_p(b[cur]), Rm=D(hi), Rn=D(1))
             if cond:
-                pl.c_gemms.append(pl.gemm(N, hi, Cd, 0, D(Cd), D(1), _p(P[st["c"] + "weight"]), D(1), D(Cd), _p(b[f"xin{s}"]), D(hi), D(1),
-                                          bias_n=_p(P[st["c"] + "bias"]), accumulate=1))
+                pl.c_gemms.append(pl.gemm(N if cond_rows is None else cond_rows, hi, Cd, 0, D(Cd), D(1), _p(P[st["c"] + "weight"]), D(1), D(Cd),
+                                          _p(b[f"xin{s}"]), D(hi), D(1), bias_n=_p(P[st["c"] + "bias"]), accumulate=1))
             pl.gemm(N, ho, hi, _p(b[f"xin{s}"]), D(hi), D(1), _p(P[st["l"] + "0.weight"]), D(1), D(hi), _p(b[f"lin{s}"]), D(ho), D(1),
                     bias_n=_p(P[st["l"] + "0.bias"]))
             pl.call("eegclip_layernorm_silu_fwd", _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(P[st["l"] + "1.bias"]), _p(b[f"ln{s}"]), _p(b[f"act{s}"]),
@@ -263,16 +263,19 @@ class _PriorEngine:
         pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False)
         return pl
 
-    def forward(self, x, t, c, p):
+    def forward(self, x, t, c, p, cond_rows=None):
+        """cond_rows (inference only): the condition embeddings `c` (cond_rows, cond_dim) apply to the FIRST cond_rows rows of x, the rest run
+        unconditioned -- a classifier-free-guidance pair in one pass of 2N rows (the condition term is a separate accumulate-GEMM,
+        so it simply covers fewer rows)"""
         N = x.shape[0]
         if N not in self.bufs:
             self.bufs[N] = self._alloc(N)
         b = self.bufs[N]
         cond = c is not None
-        key = (N, cond, p)
+        key = (N, cond, p) if cond_rows is None else (N, cond, p, cond_rows)
         pk = ("f",) + key
         if pk not in self.plans:
-            self.plans[pk] = self._build_fwd(N, cond, p)
+            self.plans[pk] = self._build_fwd(N, cond, p, cond_rows)
         pl = self.plans[pk]
         b["tt"].copy_(t)
         pl.x_gemm.A = x.data_ptr()
@@ -488,7 +491,8 @@ class Pipe:
                     eps = eng.forward(h_t, tt, None, 0.0)
                     h_t = self.scheduler.step(eps, t, h_t, generator=generator).prev_sample
                 else:
-                    eps_c = eng.forward(h_t, tt, c_embeds, 0.0).clone()
-                    eps_u = eng.forward(h_t, tt, None, 0.0)
-                    h_t = self.scheduler.step(eps_c, t, h_t, generator=generator, model_output_uncond=eps_u, guidance_scale=guidance_scale).prev_sample
+                    # conditional and unconditional prediction (diffusion_prior.py:362-367) as ONE pass over 2N rows: half the launches of a
+                    # loop that is launch-bound at these sizes
+                    eps = eng.forward(torch.cat([h_t, h_t]), torch.cat([tt, tt]), c_embeds, 0.0, cond_rows=N)
+                    h_t = self.scheduler.step(eps[:N], t, h_t, generator=generator, model_output_uncond=eps[N:], guidance_scale=guidance_scale).prev_sample
         return h_t
