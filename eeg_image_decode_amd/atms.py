@@ -294,6 +294,14 @@ def _p(t):
     return t.data_ptr()
 
 
+def _head_split(B):
+    """split-K factor of the projection-head GEMMs (M = B is small: a 4 x 16 tile grid cannot fill 256 CUs).  Every slice adds its
+    partial tile with atomics, so the factor trades workgroups against B * 1024 * split float atomics."""
+    import os
+    cap = int(os.environ.get("EEGCLIP_HEAD_SK", "8"))        # tuning aid; measured at B = 256: 16 -> 101 us, 8 -> 80 us, 4 -> 103 us for the four GEMMs
+    return max(1, min(cap, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
+
+
 class _Engine:
     """Flat parameter/gradient storage + per-batch-size activation buffers and launch plans."""
 
@@ -432,14 +440,13 @@ class _Engine:
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
                 _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train),
                 _p(self.buffers[_TS + "5.num_batches_tracked"]))
-        pl.call("eegclip_bn_elu_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["z2"]), B, C_TS,
-                W_TS, pc_, 0, SITE_CONV, seed_at=10)
-        # 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e]      (:113-114,145)
-        pl.gemm(B * W_TS, C_TS, C_TS, _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS), _p(P["enc_eeg.0.projection.0.weight"]), D(1), D(C_TS),
-                _p(b["feat"]), D(C_TS, div=W_TS, so=F_TS), D(1), bias_n=_p(P["enc_eeg.0.projection.0.bias"]))
+        # BN2 -> ELU -> dropout -> 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e], one workgroup per sample      (:107-114,145)
+        pl.call("eegclip_proj1x1_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
+                seed_at=11)
         # A6: projection head      (:157-167).  M = B is small (256): a 4 x 16 tile grid cannot fill 256 CUs and each workgroup walks K = 1440
         # serially, so the products are split over K (atomics into a zeroed buffer) and bias/GELU/dropout/residual run as a tiny epilogue.
-        skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
+        skh = _head_split(B)
         if skh > 1:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
                     accumulate=1, split_k=skh)
@@ -479,22 +486,32 @@ class _Engine:
         pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
                 _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
-        skh = max(1, min(16, 2048 // max(1, ((B + 63) // 64) * (P_DIM // 64))))
+        skh = _head_split(B)
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
                 accumulate=int(skh > 1), split_k=skh)
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
         wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
         pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
                 accumulate=int(skh > 1), split_k=skh)
-        # 1x1 conv: dfeat is [(b,w)][e]
-        pl.gemm(C_TS, C_TS, B * W_TS, _p(b["dfeat"]), D(1), D(C_TS), _p(b["z2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS),
-                _p(G["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1), accumulate=1, split_k=sk(B * W_TS * 8),
-                rowsum_a=_p(G["enc_eeg.0.projection.0.bias"]), side=True)
-        pl.gemm(B * W_TS, C_TS, C_TS, _p(b["dfeat"]), D(C_TS), D(1), _p(P["enc_eeg.0.projection.0.weight"]), D(C_TS), D(1),
-                _p(b["dz2"]), D(1, div=W_TS, so=C_TS * W_TS), D(W_TS))
-        # BN2 + ELU + dropout backward
+        # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
+        # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
+        # mean-all-reduce of the flat gradient (every rank's gradient is W x its share, SURVEY.md 8e) reproduces the single-process value.
         W = self._world()
-        self._bn_bwd(pl, W, b["dz2"], b["y2"], bn[2], bn[3], _TS + "5.", sums[2], b["dy2"], B, W_TS, pc_, SITE_CONV)
+        pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
+                _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), B, pc_, 0, SITE_CONV, seed_at=14)
+        local2 = None
+        if W > 1:
+            local2 = torch.zeros_like(sums[2])
+            pl._keep.append(local2)
+
+            def exchange2():
+                local2.copy_(sums[2])
+                self._allreduce(sums[2])
+            pl.callback(exchange2, "allreduce_bn2_bwd")
+        pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(sums[2]),
+                _p(local2) if local2 is not None else None, float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
+                W_TS, pc_, 0, SITE_CONV, seed_at=16)
         # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
         # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
         # (d(conv bias) in front of a train-mode BatchNorm is identically zero: tsconv.0.bias / tsconv.4.bias keep the cleared zero.)
@@ -556,26 +573,6 @@ class _Engine:
             pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1),
                     _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
         return pl
-
-    def _bn_bwd(self, pl, W, dz, x, mean, rstd, prefix, sums, dx, B, inner, p, site):
-        P, G = self.P, self.G
-        if W == 1:
-            pl.call("eegclip_bn_elu_bwd", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), _p(dx),
-                    _p(G[prefix + "weight"]), _p(G[prefix + "bias"]), B, C_TS, inner, p, 0, site, seed_at=14)
-            return
-        # SyncBN backward: dx needs the GLOBAL channel sums (all-reduced); dgamma/dbeta take this rank's LOCAL sums, so the later
-        # mean-all-reduce of the flat gradient (every rank's gradient is W x its share, SURVEY.md 8e) reproduces the single-process value.
-        pl.call("eegclip_bn_elu_bwd_stats", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), B, C_TS,
-                inner, p, 0, site, seed_at=11)
-        local = torch.zeros_like(sums)
-        pl._keep.append(local)
-
-        def exchange():
-            local.copy_(sums)
-            self._allreduce(sums)
-        pl.callback(exchange, "allreduce_bn_bwd")
-        pl.call("eegclip_bn_elu_bwd_apply", _p(dz), _p(x), _p(mean), _p(rstd), _p(P[prefix + "weight"]), _p(P[prefix + "bias"]), _p(sums), _p(local),
-                float(W * B * inner), _p(dx), _p(G[prefix + "weight"]), _p(G[prefix + "bias"]), B, C_TS, inner, p, 0, site, seed_at=16)
 
     def _world(self):
         import torch.distributed as dist

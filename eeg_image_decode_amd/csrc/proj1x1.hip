@@ -1,0 +1,145 @@
+// Tail of tsconv + the Enc_eeg projection (Retrieval/ATMS_retrieval.py:107-109,113-114,145), one workgroup per sample:
+//       z2 = dropout(ELU(BatchNorm2(y2)))            y2, z2 (B,40,36)
+//       feat[b, w*40 + e] = bias[e] + sum_c W[e,c] * z2[b,c,w]          1x1 conv + 'b e h w -> b (h w) e' + flatten -> (B,1440)
+// and its backward up to the BatchNorm statistics.  The work is tiny (58 k MACs per sample); as three launches (BN+ELU elementwise, a
+// 9216 x 40 x 40 GEMM through two-level index maps, split-K weight gradient) it cost 29 + 7 us forward and 22 + 23 + 8 us backward,
+// almost all of it launch latency and index arithmetic.  Here a sample's 40 x 36 tile, its gradient and the 40 x 40 weights sit in LDS.
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int PJ_C = 40;       // channels in and out
+constexpr int PJ_W = 36;       // positions
+constexpr int PJ_N = PJ_C * PJ_W;
+constexpr int PJ_LW = 41;      // padded row stride of the [e][c] / [w][e] images
+
+__global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ z2,
+                                                           float* __restrict__ feat, int B, float drop_p, unsigned long long seed, unsigned site) {
+    EEG_LDS_BASE(float, lds);
+    float* zs = lds;                      // [40][36]  z2 of this sample
+    float* ws = zs + PJ_N;                // [40][41]  W[e][c]
+    const int t = threadIdx.x, b = blockIdx.x;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int i = t; i < PJ_C * PJ_C; i += 256) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = Wt[i];
+    for (int i = t; i < PJ_N; i += 256) {
+        const int c = i / PJ_W;
+        const long long idx = (long long)b * PJ_N + i;
+        float v = elu1(gamma[c] * (y2[idx] - mean[c]) * rstd[c] + beta[c]);
+        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? v * ks : 0.f;
+        z2[idx] = v;
+        zs[i] = v;
+    }
+    __syncthreads();
+    for (int o = t; o < PJ_N; o += 256) {
+        const int w = o / PJ_C, e = o % PJ_C;
+        float acc = bias[e];
+#pragma unroll 8
+        for (int c = 0; c < PJ_C; ++c) acc += ws[e * PJ_LW + c] * zs[c * PJ_W + w];
+        feat[(long long)b * PJ_N + o] = acc;
+    }
+}
+
+// backward, first half (everything before the BatchNorm batch sums are known); one workgroup walks `spw` samples:
+//   dW[e,c] += sum_{b,w} dfeat[b,w,e] z2[b,c,w] ;  dbias[e] += sum_{b,w} dfeat[b,w,e]
+//   dz2[b,c,w] = sum_e W[e,c] dfeat[b,w,e]                                     (written: the apply pass re-derives da from it)
+//   da = dz2 * mask/(1-p) * ELU'(BN(y2)) ;  sums[c] += da ;  sums[40 + c] += da * xhat        (fp64 atomics, 80 per workgroup)
+__global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ z2, const float* __restrict__ Wt,
+                                                           const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dz2,
+                                                           float* __restrict__ dW, float* __restrict__ dbias, double* __restrict__ sums, int B, int spw,
+                                                           float drop_p, unsigned long long seed, unsigned site) {
+    EEG_LDS_BASE(float, lds);
+    float* zs = lds;                      // [40][36]  z2[c][w]
+    float* ds = zs + PJ_N;                // [36][41]  dfeat[w][e]
+    float* ws = ds + PJ_W * PJ_LW;        // [40][41]  W[e][c]
+    float* das = ws + PJ_C * PJ_LW;       // [2][40][36]  da and da * xhat of this sample (reduced per channel by 80 threads: no LDS atomics)
+    const int t = threadIdx.x;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int i = t; i < PJ_C * PJ_C; i += 256) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = Wt[i];
+    double csum = 0.0;                                  // threads < 80: running channel sum (t < 40: da, else da * xhat)
+    constexpr int NWO = (PJ_C * PJ_C + 255) / 256;      // weight-gradient entries per thread
+    float dwp[NWO];
+#pragma unroll
+    for (int j = 0; j < NWO; ++j) dwp[j] = 0.f;
+    float dbp = 0.f;                                    // threads < 40: bias gradient of channel t
+    const int b0 = blockIdx.x * spw;
+    for (int b = b0; b < b0 + spw && b < B; ++b) {
+        __syncthreads();                                // previous sample consumed (first pass: orders the weight staging)
+        for (int i = t; i < PJ_N; i += 256) {
+            zs[i] = z2[(long long)b * PJ_N + i];
+            ds[(i / PJ_C) * PJ_LW + i % PJ_C] = dfeat[(long long)b * PJ_N + i];
+        }
+        __syncthreads();
+        for (int i = t; i < PJ_N; i += 256) {           // input gradient of the 1x1 conv + BatchNorm-backward statistics
+            const int c = i / PJ_W, w = i % PJ_W;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < PJ_C; ++e) acc += ws[e * PJ_LW + c] * ds[w * PJ_LW + e];
+            const long long idx = (long long)b * PJ_N + i;
+            dz2[idx] = acc;
+            const float xh = (y2[idx] - mean[c]) * rstd[c];
+            const float u = gamma[c] * xh + beta[c];
+            float d = acc;
+            if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? d * ks : 0.f;
+            const float da = u > 0.f ? d : d * expf(u);
+            das[i] = da;
+            das[PJ_N + i] = da * xh;
+        }
+#pragma unroll
+        for (int j = 0; j < NWO; ++j) {                 // weight gradient
+            const int o = t + 256 * j;
+            if (o < PJ_C * PJ_C) {
+                const int e = o / PJ_C, c = o % PJ_C;
+                float acc = 0.f;
+#pragma unroll 6
+                for (int w = 0; w < PJ_W; ++w) acc += ds[w * PJ_LW + e] * zs[c * PJ_W + w];
+                dwp[j] += acc;
+            }
+        }
+        if (t < PJ_C) {
+            float acc = 0.f;
+            for (int w = 0; w < PJ_W; ++w) acc += ds[w * PJ_LW + t];
+            dbp += acc;
+        }
+        __syncthreads();                                // da tiles complete
+        if (t < 2 * PJ_C) {
+            float acc = 0.f;
+            for (int w = 0; w < PJ_W; ++w) acc += das[t * PJ_W + w];
+            csum += acc;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NWO; ++j) {
+        const int o = t + 256 * j;
+        if (o < PJ_C * PJ_C) atomicAdd(dW + o, dwp[j]);
+    }
+    if (t < PJ_C) atomicAdd(dbias + t, dbp);
+    if (t < 2 * PJ_C) atomicAdd(sums + t, csum);
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_proj1x1_fwd(const float* y2, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                                   const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site,
+                                   void* stream) {
+    if (!y2 || !mean || !rstd || !gamma || !beta || !W || !bias || !z2 || !feat || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    const size_t lds = (PJ_N + PJ_C * PJ_LW) * sizeof(float);
+    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), lds, stream, y2, mean, rstd, gamma, beta, W, bias, z2, feat, B, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const float* W, const float* y2, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, int B, float drop_p,
+                                   unsigned long long seed, unsigned int site, void* stream) {
+    if (!dfeat || !z2 || !W || !y2 || !mean || !rstd || !gamma || !beta || !dz2 || !dW || !dbias || !sums || B < 1 || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    const int spw = B >= 512 ? 4 : (B >= 128 ? 2 : 1);           // samples per workgroup: fewer, fatter atomics once the grid still fills the chip
+    const size_t lds = (PJ_N + PJ_W * PJ_LW + PJ_C * PJ_LW + 2 * PJ_N) * sizeof(float);
+    EEG_LAUNCH(proj1x1_bwd_kernel, dim3((B + spw - 1) / spw), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, B,
+               spw, drop_p, seed, site);
+    return (int)hipGetLastError();
+}

@@ -211,6 +211,16 @@ int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, i
 int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
                          float* loss, void* stream);
 
+/* ---- tail of tsconv + Enc_eeg projection, one workgroup per sample (ATMS_retrieval.py:107-109,113-114,145):
+ *   fwd: z2 = dropout(ELU(BatchNorm2(y2)))  (B,40,36);  feat[b, w*40+e] = bias[e] + sum_c W[e,c] z2[b,c,w]   (B,1440)
+ *   bwd: dW += dfeat^T z2 ; dbias += sum dfeat ; dz2 = W^T dfeat (written) ; sums[2*40] += BatchNorm-backward statistics of
+ *        da = dz2 * mask/(1-p) * ELU'(BN(y2)) -- followed (after the SyncBN all-reduce of sums, if any) by eegclip_bn_elu_bwd_apply(dz2, y2, ...). */
+int eegclip_proj1x1_fwd(const float* y2, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                        const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const float* W, const float* y2, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, int B, float drop_p,
+                        unsigned long long seed, unsigned int site, void* stream);
+
 /* ---- large-batch InfoNCE logits on the bf16 matrix cores (models/loss.py:122-123 at global batch 2048, D = 1024):
  *   c[m][n] = (*scale) * sum_k a[m][k] * b[n][k]     a (M,K), b (N,K) bf16 row-major (eegclip_cast_bf16 of the fp32 features), c fp32.
  * fp32 accumulation and fp32 logits; M, N multiples of 128, K multiple of 64, ldc multiple of 4, 16-byte aligned pointers

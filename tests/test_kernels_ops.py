@@ -418,3 +418,40 @@ def test_logits_bf16(be, M, N, K):
     ref = 2.6593 * _bf16_round(a).astype(np.float64) @ _bf16_round(b).astype(np.float64).T
     np.testing.assert_allclose(be.host(C), ref, atol=2e-4 * max(1.0, np.abs(ref).max()))
     assert be.lib.eegclip_logits_bf16(be.ptr(A16), be.ptr(B16), be.ptr(C), M, N - 1, K, N, be.ptr(SC), be.stream) < 0      # whole tiles only
+
+
+@pytest.mark.parametrize("B,p", [(3, 0.0), (5, 0.5), (130, 0.25)])
+def test_proj1x1_fused_stage(be, B, p):
+    """csrc/proj1x1.hip: BN2 -> ELU -> dropout -> 1x1 conv -> (b, w*40+e) flatten, and the backward up to the BatchNorm statistics +
+    bn_elu_bwd_apply, against autograd of the same torch ops with the Philox mask"""
+    rng = np.random.default_rng(B)
+    C, Wd = 40, 36
+    y2 = rnd(rng, B, C, Wd) * 1.2 + 0.1
+    g, bt, Wc, bc = 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C), rnd(rng, C, C, scale=0.2), 0.1 * rnd(rng, C)
+    dfeat = rnd(rng, B, Wd * C)
+    mean, var = y2.astype(np.float64).mean((0, 2)), y2.astype(np.float64).var((0, 2))
+    keep = keep_mask(SEED, 2, B * C * Wd, p).reshape(B, C, Wd) if p > 0 else np.ones((B, C, Wd), bool)
+    yt = torch.tensor(y2, dtype=torch.float64, requires_grad=True)
+    gt, btt = torch.tensor(g, dtype=torch.float64, requires_grad=True), torch.tensor(bt, dtype=torch.float64, requires_grad=True)
+    wt, bct = torch.tensor(Wc, dtype=torch.float64, requires_grad=True), torch.tensor(bc, dtype=torch.float64, requires_grad=True)
+    z = F.elu(F.batch_norm(yt, None, None, gt, btt, True, 0.1, 1e-5)) * torch.tensor(keep) / (1 - p)
+    ft = (torch.einsum("ec,bcw->bwe", wt, z) + bct).reshape(B, Wd * C)
+    ft.backward(torch.tensor(dfeat, dtype=torch.float64))
+    Y2, MU, RS = be.dev(y2), be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
+    G, BT, WC, BC, DF = be.dev(g), be.dev(bt), be.dev(Wc), be.dev(bc), be.dev(dfeat)
+    Z2, FEAT = be.zeros((B, C, Wd)), be.zeros((B, Wd * C))
+    ok(be.lib.eegclip_proj1x1_fwd(be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(WC), be.ptr(BC), be.ptr(Z2), be.ptr(FEAT), B, p,
+                                  SEED, 2, be.stream))
+    np.testing.assert_allclose(be.host(Z2), z.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(be.host(FEAT), ft.detach().numpy(), atol=5e-5)
+    DZ2, DW, DBC, SUMS = be.zeros((B, C, Wd)), be.dev(np.ones((C, C), np.float32)), be.zeros(C), be.zeros(2 * C, np.float64)
+    ok(be.lib.eegclip_proj1x1_bwd(be.ptr(DF), be.ptr(Z2), be.ptr(WC), be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(DZ2), be.ptr(DW),
+                                  be.ptr(DBC), be.ptr(SUMS), B, p, SEED, 2, be.stream))
+    np.testing.assert_allclose(be.host(DW) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+    np.testing.assert_allclose(be.host(DBC), bct.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bct.grad.numpy()).max()))
+    DY2, DG, DB = be.zeros((B, C, Wd)), be.zeros(C), be.zeros(C)
+    ok(be.lib.eegclip_bn_elu_bwd_apply(be.ptr(DZ2), be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(SUMS), None, float(B * Wd),
+                                       be.ptr(DY2), be.ptr(DG), be.ptr(DB), B, C, Wd, p, SEED, 2, be.stream))
+    np.testing.assert_allclose(be.host(DY2), yt.grad.numpy(), atol=1e-6 + 3e-4 * np.abs(yt.grad.numpy()).max())
+    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=3e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
+    np.testing.assert_allclose(be.host(DB), btt.grad.numpy(), atol=3e-4 * max(1.0, np.abs(btt.grad.numpy()).max()))
