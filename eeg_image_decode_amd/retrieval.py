@@ -65,6 +65,17 @@ def _uniform_ids(batch_size, subject_id, device):
     return ids
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """second HIP stream per device for work nobody waits for inside the step (the running train-accuracy readout)"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
                      alpha=0.99):
     """One iteration of the reference batch loop (ATMS_retrieval.py:209-250) with every tensor already on the device:
@@ -76,6 +87,14 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
     eeg_features = eeg_model(eeg_data, subject_ids).float()
     logit_scale = eeg_model.logit_scale
+    # running train accuracy (ATMS_retrieval.py:241-250: logits against all class features, argmax, count): it only needs the
+    # forward output, so it runs on a second stream underneath the loss / backward / optimizer kernels instead of after them
+    side = _side_stream(eeg_data.device) if torch.cuda.is_available() else None
+    main = torch.cuda.current_stream() if side is not None else None
+    if side is not None:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
     loss_func = eeg_model.loss_func
     if hasattr(loss_func, "forward_mixed"):          # both targets in one pass: one gradient w.r.t. the EEG features, one accumulator
         loss = loss_func.forward_mixed(eeg_features, [(img_features, alpha), (text_features, 1 - alpha)], logit_scale)
@@ -84,11 +103,18 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     loss.backward()
     if edist.world_size() > 1:
         edist.average_flat_grads(eeg_model.flat_parameters()[1])
+    if side is not None:
+        main.wait_stream(side)             # join BEFORE the optimizer rewrites logit_scale, which the readout's ranking kernel reads
+    else:
+        _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
     optimizer.step()
     loss_acc += loss.detach()
+    return eeg_features.detach()
+
+
+def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct):
     pred = topk_retrieval(eeg_features, class_feats, logit_scale, 1)
     check(lib().eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
-    return eeg_features.detach()
 
 
 def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config):
