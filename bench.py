@@ -61,7 +61,7 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true>"}
 
 
-_GEMM_KERNEL = "eeg::gemm_f32_fast_kernel<true, true, true>"      # Y = X W^T launches (forward Linears); f02 is the largest of them
+_GEMM_KERNEL = "eeg::gemm_f32_fast_kernel<true, true, true, false>"      # Y = X W^T launches (forward Linears); f02 is the largest of them
 
 
 def pmc_traffic(op_name, B, desc=None):
