@@ -40,30 +40,55 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(float* __restrict__ h
 }
 
 // backward of the above: dh *= mask/(1-p) in place; dtokens[id] += sum_b dh[b,0,:]
+// The first `tok_blocks` workgroups own the token rows (l = 0) exclusively -- scale them, and sum them over the batch in registers with ONE
+// atomic per (workgroup, column) on the shared-token path (ids == NULL); the streaming workgroups skip those rows.  (Per-element atomics
+// from the streaming loop put 256 same-address atomics on each of the 250 columns in the middle of a bandwidth kernel: 36 us for 32 MB.)
 __global__ __launch_bounds__(256) void embed_finish_bwd_kernel(float* __restrict__ dh, float* __restrict__ dtokens,
                                                                 const long long* __restrict__ ids, int B, int L, int D, float drop_p,
-                                                                unsigned long long seed, unsigned site) {
-    const long long n4 = (long long)B * L * D / 4;
+                                                                unsigned long long seed, unsigned site, int tok_blocks) {
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
-        const long long i0 = 4 * q;
-        f32x4 v = *reinterpret_cast<const f32x4*>(dh + i0);
-        if (drop_p > 0.f) {
-            bool keep[4];
-            dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ks : 0.f;
-            *reinterpret_cast<f32x4*>(dh + i0) = v;
-        }
-        if (dtokens) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long long i = i0 + e;
-                if ((int)((i / D) % L) == 0) {
-                    const int b = (int)(i / ((long long)D * L));
-                    atomicAdd(dtokens + (ids ? ids[b] : 0) * D + (int)(i % D), v[e]);
+    if ((int)blockIdx.x < tok_blocks) {
+        // thread -> column d (and a slice of the batch): rows b = blockIdx.x, blockIdx.x + tok_blocks, ...
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            float acc = 0.f;
+            for (int b = blockIdx.x; b < B; b += tok_blocks) {
+                const long long i = (long long)b * L * D + d;
+                float v = dh[i];
+                if (drop_p > 0.f) {
+                    v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+                    dh[i] = v;
+                }
+                if (dtokens) {
+                    if (ids) atomicAdd(dtokens + ids[b] * D + d, v);
+                    else acc += v;
                 }
             }
+            if (dtokens && !ids) atomicAdd(dtokens + d, acc);
+        }
+        return;
+    }
+    if (!(drop_p > 0.f)) return;                              // nothing to scale: the token blocks did the reduction
+    const long long n4 = (long long)B * L * D / 4;
+    const long long stride = (long long)(gridDim.x - tok_blocks) * blockDim.x;
+    for (long long q = (long long)(blockIdx.x - tok_blocks) * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const long long i0 = 4 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(dh + i0);
+        bool keep[4];
+        dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
+        bool tok[4];
+        bool any_tok = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tok[e] = (int)(((i0 + e) / D) % L) == 0;          // token-row elements belong to the token blocks
+            any_tok |= tok[e];
+            v[e] = keep[e] ? v[e] * ks : 0.f;
+        }
+        if (!any_tok) {
+            *reinterpret_cast<f32x4*>(dh + i0) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!tok[e]) dh[i0 + e] = v[e];
         }
     }
 }
@@ -228,8 +253,9 @@ extern "C" int eegclip_embed_finish_bwd(float* dh, float* dtokens, const long lo
     if (!dh || B < 1 || L < 1 || D < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (((long long)L * D) % 4 != 0) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(dh) & 15u) return EEGCLIP_EALIGN;
-    EEG_LAUNCH(embed_finish_bwd_kernel, dim3(ew_grid((long long)B * L * D / 4)), dim3(256), 0, stream, dh, dtokens, ids, B, L, D, drop_p,
-               seed, site);
+    const int tok_blocks = B < 32 ? B : 32;
+    EEG_LAUNCH(embed_finish_bwd_kernel, dim3(tok_blocks + ew_grid((long long)B * L * D / 4)), dim3(256), 0, stream, dh, dtokens, ids, B, L, D,
+               drop_p, seed, site, tok_blocks);
     return (int)hipGetLastError();
 }
 
