@@ -218,3 +218,29 @@ class ClipLoss(nn.Module):
         if features.dtype != torch.float32:
             raise TypeError("ClipLoss expects float32 features (the reference casts with .float())")
         return _ClipLossFn.apply(features, logit_scale, self, tuple(float(w) for _, w in targets), *[b for b, _ in targets])
+
+
+class _MseFn(torch.autograd.Function):
+    """weight * mean((pred - target)^2) and its gradient w.r.t. pred in one kernel pass (nn.MSELoss of
+    Generation/ATMS_reconstruction.py:201,227; also the diffusion prior's objective)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        require_cuda(pred, "pred")
+        p, t = pred.detach().contiguous(), target.detach().contiguous()
+        acc = torch.zeros(1, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p) if pred.requires_grad else None
+        check(lib().eegclip_mse_loss_grad(p.data_ptr(), t.data_ptr(), p.numel(), acc.data_ptr(), grad.data_ptr() if grad is not None else None,
+                                          _stream()), "mse_loss_grad")
+        ctx.grad, ctx.weight = grad, float(weight)
+        return acc.reshape(()) * float(weight)
+
+    @staticmethod
+    def backward(ctx, go):
+        return (ctx.grad * (go * ctx.weight) if ctx.grad is not None else None), None, None
+
+
+def mse_loss(pred, target, weight=1.0):
+    if pred.dtype != torch.float32 or target.dtype != torch.float32 or pred.shape != target.shape:
+        raise TypeError("mse_loss expects two float32 tensors of the same shape")
+    return _MseFn.apply(pred, target, weight)

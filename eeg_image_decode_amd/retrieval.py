@@ -77,7 +77,7 @@ def _side_stream(device):
 
 
 def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
-                     alpha=0.99):
+                     alpha=0.99, objective="retrieval"):
     """One iteration of the reference batch loop (ATMS_retrieval.py:209-250) with every tensor already on the device:
     forward, image + text InfoNCE (0.99/0.01), backward, optimizer step, running loss and train-accuracy -- no host sync.
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
@@ -96,7 +96,12 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
         with torch.cuda.stream(side):
             _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
     loss_func = eeg_model.loss_func
-    if hasattr(loss_func, "forward_mixed"):          # both targets in one pass: one gradient w.r.t. the EEG features, one accumulator
+    if objective == "reconstruction":
+        # Generation/ATMS_reconstruction.py:222-228 (alpha = 0.9 there): 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img)); the text
+        # loss the reference also evaluates never enters the objective
+        from .loss import mse_loss
+        loss = mse_loss(eeg_features, img_features, 10.0 * alpha) + 10.0 * (1 - alpha) * loss_func(eeg_features, img_features, logit_scale)
+    elif hasattr(loss_func, "forward_mixed"):        # both targets in one pass: one gradient w.r.t. the EEG features, one accumulator
         loss = loss_func.forward_mixed(eeg_features, [(img_features, alpha), (text_features, 1 - alpha)], logit_scale)
     else:                                            # a user-supplied loss module: the reference's two calls (ATMS_retrieval.py:224-229)
         loss = alpha * loss_func(eeg_features, img_features, logit_scale) + (1 - alpha) * loss_func(eeg_features, text_features, logit_scale)
@@ -117,7 +122,7 @@ def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_s
     check(lib().eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
 
 
-def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config):
+def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config, objective="retrieval", alpha=0.99):
     eeg_model.train()
     text_features_all = text_features_all.to(device).float()
     img_features_all = (img_features_all[::10]).to(device).float().contiguous()
@@ -132,7 +137,7 @@ def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all
         img_features = img_features.to(device, non_blocking=True).float()
         labels = labels.to(device, non_blocking=True).long()
         features_list.append(contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels,
-                                              img_features_all, loss_acc, correct))
+                                              img_features_all, loss_acc, correct, alpha=alpha, objective=objective))
         total += eeg_data.size(0)
         n_batches += 1
     average_loss = float(loss_acc) / n_batches            # the only host syncs of the epoch

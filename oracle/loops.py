@@ -6,6 +6,8 @@ tests/golden/eval.npz.  Also the ``cpu_baseline`` ("port") leg of bench.py.
 Reference lines restated (under /root/reference/Retrieval/ATMS_retrieval.py):
   :199-254  train_model   (fwd, img+text ClipLoss mix 0.99/0.01, bwd, AdamW, running accuracy)
   :258-362  evaluate_model (bs=1, k-way candidates = random.sample(others,k-1)+[label], argmax/top-5)
+and the reconstruction-objective variant of the same loop, Generation/ATMS_reconstruction.py:191-249 (pinned by
+tests/golden/recon_loop.npz).
 """
 import random
 
@@ -46,7 +48,10 @@ def torch_state(state_np, dtype=torch.float32):
 class OracleTrainer:
     """Holds a state dict + AdamW moments; ``step`` = one iteration of the reference batch loop."""
 
-    def __init__(self, state, lr=3e-4, p_scale=1.0):
+    def __init__(self, state, lr=3e-4, p_scale=1.0, objective="retrieval"):
+        """objective: "retrieval" = 0.99/0.01 image/text InfoNCE mix (Retrieval/ATMS_retrieval.py:224-229);
+        "reconstruction" = 10 * (0.9 MSE + 0.1 image InfoNCE) (Generation/ATMS_reconstruction.py:222-228)"""
+        self.objective = objective
         self.P = {k: v.clone() for k, v in state.items()}
         self.lr = lr
         self.p_scale = p_scale
@@ -61,7 +66,7 @@ class OracleTrainer:
         want = {}
         z = oatms.atms_forward(self.P, x, subject_ids, train=train, masks=masks, p_scale=self.p_scale, want=want)
         s = self.P["logit_scale"]
-        loss = oloss.mixed_loss(z, img, txt, s)
+        loss = oloss.mixed_loss(z, img, txt, s) if self.objective == "retrieval" else oloss.reconstruction_loss(z, img, s)
         grads = torch.autograd.grad(loss, [self.P[k] for k in self.params], allow_unused=True)
         for k, g in zip(self.params, grads):
             live[k] = g

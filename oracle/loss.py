@@ -57,6 +57,12 @@ def mixed_loss(z, img, txt, logit_scale, alpha=0.99):
     return alpha * clip_loss(z, img, logit_scale) + (1 - alpha) * clip_loss(z, txt, logit_scale)
 
 
+def reconstruction_loss(z, img, logit_scale, alpha=0.90):
+    """Generation/ATMS_reconstruction.py:222-228: 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img)); the text loss is computed
+    by the reference but does not enter the objective."""
+    return alpha * torch.nn.functional.mse_loss(z, img) * 10 + (1 - alpha) * clip_loss(z, img, logit_scale) * 10
+
+
 def train_accuracy_predictions(z, class_feats, logit_scale):
     """argmax over logit_scale * z @ class_feats.T (ATMS_retrieval.py:241-246); ties -> lowest index."""
     return torch.argmax(logit_scale * z @ class_feats.T, dim=1)

@@ -270,6 +270,36 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
             assert int(sd[k]) == 6
 
 
+def test_reconstruction_train_model_matches_reference_fixture(state_np, golden):
+    """reconstruction.train_model == the reference's Generation/ATMS_reconstruction.py:train_model (10 * (0.9 MSE + 0.1 image
+    InfoNCE)) on the same 3-batch loader, 2 epochs of AdamW"""
+    from eeg_image_decode_amd import optim, reconstruction
+    g = golden("recon_loop.npz")
+    n_classes, B = 20, 16
+    img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
+    txt_all = T(syn.unit_features(SEED + 4, n_classes, tag="txtall"))
+    m = make_model(state_np)
+    zero_dropout(m)
+    opt = optim.AdamW(m.parameters(), lr=3e-4)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    losses, accs = [], []
+    for ep in range(2):
+        l, a, feats = reconstruction.train_model("sub-01", m, _ListLoader(_make_batches(SEED + 4, 3, B, n_classes, img_all, txt_all)), opt, "cuda",
+                                                 txt_all, img_all, None)
+        losses.append(l)
+        accs.append(a)
+        if ep == 0:
+            np.testing.assert_allclose(feats.cpu().numpy()[:, :64], g["feats_ep0"], atol=1e-3)
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-3)
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k, p in m.named_parameters():
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue
+        d = float((p.detach() - before[k]).norm())
+        ref = float(g["dnorm:" + k])
+        assert abs(d - ref) <= 5e-3 * max(ref, 1e-3) + 1e-6, (k, d, ref)
+
+
 def test_evaluate_model_matches_reference_fixture(state_np, golden):
     """C2: same (loss, acc, top5) as the reference when python's `random` is seeded identically."""
     import random

@@ -134,6 +134,30 @@ def test_train_loop_matches_reference(state, golden):
             assert int(tr.P[k]) == int(g["bn:" + k]) == 6
 
 
+def test_reconstruction_train_loop_matches_reference(state, golden):
+    """Generation/ATMS_reconstruction.py:train_model (10 * (0.9 MSE + 0.1 image InfoNCE)) on the same loader"""
+    g = golden("recon_loop.npz")
+    n_classes, B = 20, 16
+    img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
+    txt_all = T(syn.unit_features(SEED + 4, n_classes, tag="txtall"))
+    tr = oloops.OracleTrainer(state, lr=3e-4, p_scale=0.0, objective="reconstruction")
+    before = {k: v.clone() for k, v in tr.P.items()}
+    losses, accs = [], []
+    for ep in range(2):
+        l, a, feats = oloops.train_epoch(tr, 1, _make_batches(SEED + 4, 3, B, n_classes, img_all, txt_all), img_all)
+        losses.append(l)
+        accs.append(a)
+        if ep == 0:
+            np.testing.assert_allclose(feats.numpy()[:, :64], g["feats_ep0"], atol=5e-4)
+    np.testing.assert_allclose(losses, g["losses"], atol=1e-3)
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k in tr.params:
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue
+        d = float((tr.P[k] - before[k]).norm())
+        assert abs(d - float(g["dnorm:" + k])) <= 2e-3 * max(float(g["dnorm:" + k]), 1e-3) + 1e-6, k
+
+
 def test_evaluate_matches_reference(state, golden):
     g = golden("eval.npz")
     n_test = 200

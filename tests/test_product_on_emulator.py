@@ -90,6 +90,29 @@ def test_mixed_clip_loss_equals_the_two_reference_calls():
         assert abs(float(outs[1][0]) - float(ref)) < 1e-5
 
 
+def test_reconstruction_objective_step_under_emulator_matches_oracle():
+    """10 * (0.9 MSE + 0.1 image InfoNCE) through contrastive_step(objective="reconstruction"): loss and parameters after one AdamW step"""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B = 3
+    x = T(syn.eeg_batch(SEED + 41, B))
+    img, txt = T(syn.unit_features(SEED + 41, B, tag="img")), T(syn.unit_features(SEED + 41, B, tag="txt"))
+    labels = torch.arange(B)
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim, retrieval
+        m = make_model(state_np).train()
+        opt = optim.AdamW(m.parameters(), lr=3e-4)
+        loss_acc, correct = torch.zeros(()), torch.zeros(1, dtype=torch.int32)
+        retrieval.contrastive_step(m, opt, x, 1, img, txt, labels, img, loss_acc, correct, alpha=0.90, objective="reconstruction")
+        after = {k: p.detach().clone() for k, p in m.named_parameters()}
+    tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0, objective="reconstruction")
+    lo, _ = tr.step(x, torch.full((B,), 1).long(), img, txt)
+    assert abs(float(loss_acc) - float(lo)) < 2e-4 * max(1.0, abs(float(lo)))
+    for k in ("proj_eeg.0.weight", "encoder.encoder.attn_layers.0.attention.query_projection.weight", "enc_eeg.0.tsconv.0.weight", "logit_scale"):
+        d = np.abs(after[k].numpy() - tr.P[k].numpy())
+        # the first Adam step is lr * g / (|g| + eps): an element whose gradient is round-off-sized moves by up to +-lr in either direction
+        assert d.max() <= 2 * 3e-4 + 1e-6 and (d > 2e-5).mean() < 1e-4, (k, float(d.max()), float((d > 2e-5).mean()))
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HIPEMU_THREADS"] = "2"
