@@ -89,9 +89,13 @@ class SubjectEmbedding(_Holder):
 
 
 class DataEmbedding(_Holder):
-    def __init__(self, c_in, d_model, dropout, num_subjects):
+    def __init__(self, c_in, d_model, dropout, num_subjects, joint_train=False):
         super().__init__()
-        self.value_embedding = nn.Linear(c_in, d_model)
+        self.joint_train = bool(joint_train and num_subjects is not None)
+        if self.joint_train:      # one value embedding per subject, chosen per sample (Embed.py:127-131,142-144)
+            self.value_embedding = nn.ModuleDict({str(s): nn.Linear(c_in, d_model) for s in range(num_subjects)})
+        else:
+            self.value_embedding = nn.Linear(c_in, d_model)
         self.position_embedding = PositionalEmbedding(d_model)
         self.temporal_embedding = TimeFeatureEmbedding(d_model)
         self.dropout = nn.Dropout(p=dropout)
@@ -138,7 +142,7 @@ class Encoder(_Holder):
 class iTransformer(_Holder):
     def __init__(self, configs, joint_train=False, num_subjects=10):
         super().__init__()
-        self.enc_embedding = DataEmbedding(configs.seq_len, configs.d_model, configs.dropout, num_subjects)
+        self.enc_embedding = DataEmbedding(configs.seq_len, configs.d_model, configs.dropout, num_subjects, joint_train)
         self.encoder = Encoder(
             [EncoderLayer(AttentionLayer(FullAttention(configs.dropout), configs.d_model, configs.n_heads),
                           configs.d_model, configs.d_ff, configs.dropout) for _ in range(configs.e_layers)],
@@ -202,12 +206,18 @@ _TOK_SHARED = _E + "subject_embedding.shared_embedding"
 
 
 class ATMS(nn.Module):
-    def __init__(self, num_channels=63, sequence_length=250, num_subjects=2, num_features=64, num_latents=1024, num_blocks=1):
+    def __init__(self, num_channels=63, sequence_length=250, num_subjects=2, num_features=64, num_latents=1024, num_blocks=1, *,
+                 joint_train=False, table_subjects=10):
+        """Positional signature = Retrieval/ATMS_retrieval.py:170 (num_subjects only sizes the dead subject_wise_linear list there; the subject-token
+        table always has 10 rows).  Keyword-only extensions for the joint-subject script (retrieval_joint.ATMS wraps them with that script's
+        signature): joint_train = one value-embedding Linear per subject, table_subjects = rows of the subject-token table."""
         super().__init__()
         if num_channels != N_CH or sequence_length != T_LEN:
             raise EegclipError("the HIP kernels are specialised for 63 channels x 250 samples (the reference's only configuration)")
         cfg = Config()
-        self.encoder = iTransformer(cfg)
+        self.joint_train = bool(joint_train)
+        self.table_subjects = int(table_subjects)
+        self.encoder = iTransformer(cfg, joint_train, table_subjects)
         self.subject_wise_linear = nn.ModuleList([nn.Linear(cfg.d_model, sequence_length) for _ in range(num_subjects)])
         self.enc_eeg = Enc_eeg()
         self.proj_eeg = Proj_eeg()
@@ -242,7 +252,27 @@ class ATMS(nn.Module):
         require_cuda(x, "x")
         if x.dtype != torch.float32 or x.dim() != 3 or x.shape[1] != N_CH or x.shape[2] != T_LEN:
             raise EegclipError(f"x must be float32 (B,{N_CH},{T_LEN}); got {x.dtype} {tuple(x.shape)}")
-        if subject_ids is None:
+        host_ids = None
+        if self.joint_train:
+            # one value embedding per subject: the subject of every sample must be known on the host (the reference reads subject_id.item() per
+            # sample, Embed.py:144; an id without an embedding is a KeyError there).  Our loops attach the host copy they built the tensor from.
+            if subject_ids is None:
+                raise EegclipError("joint_train model: subject_ids is required (one value embedding per subject)")
+            if isinstance(subject_ids, int):
+                host_ids = [subject_ids] * x.shape[0]
+                subject_ids = torch.full((x.shape[0],), subject_ids, dtype=torch.long, device=x.device)
+            else:
+                hint = getattr(subject_ids, "_eegclip_uniform_id", None)
+                host_ids = getattr(subject_ids, "_eegclip_host_ids", None)
+                if host_ids is None:
+                    host_ids = [hint] * x.shape[0] if hint is not None else subject_ids.tolist()
+            if len(host_ids) != x.shape[0]:
+                raise EegclipError(f"subject_ids has {len(host_ids)} entries for a batch of {x.shape[0]}")
+            bad = [i for i in host_ids if not 0 <= i < self.table_subjects]
+            if bad:
+                raise EegclipError(f"joint_train model has value embeddings for subjects 0..{self.table_subjects - 1}; got id {bad[0]}")
+            ids, shared = subject_ids.to(device=x.device, dtype=torch.long), False
+        elif subject_ids is None:
             ids, shared = None, True
         elif isinstance(subject_ids, int):
             shared = subject_ids >= 10
@@ -250,15 +280,21 @@ class ATMS(nn.Module):
         else:
             ids = subject_ids.to(device=x.device, dtype=torch.long)
             hint = getattr(subject_ids, "_eegclip_uniform_id", None)        # set by our train/eval loops: no host sync
-            shared = (hint >= 10) if hint is not None else bool((ids >= 10).any())   # the reference syncs here too
+            host = getattr(subject_ids, "_eegclip_host_ids", None)          # per-sample ids our loops built the tensor from
+            if hint is not None:
+                shared = hint >= 10
+            elif host is not None:
+                shared = any(i >= 10 for i in host)
+            else:
+                shared = bool((ids >= 10).any())                            # the reference syncs here too
             if shared:
                 ids = None
         x = x.contiguous()
         train = self.training
         need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if need_grad:
-            return _AtmsFn.apply(x, eng.anchor, self, ids, shared, train)
-        return eng.forward(x, ids, shared, train).clone()
+            return _AtmsFn.apply(x, eng.anchor, self, ids, shared, train, host_ids)
+        return eng.forward(x, ids, shared, train, host_ids).clone()
 
     def drop_probs(self, train):
         if not train:
@@ -272,9 +308,9 @@ class ATMS(nn.Module):
 
 class _AtmsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, model, ids, shared, train):
+    def forward(ctx, x, anchor, model, ids, shared, train, host_ids=None):
         eng = model._engine()
-        out = eng.forward(x, ids, shared, train)
+        out = eng.forward(x, ids, shared, train, host_ids)
         ctx.eng, ctx.key, ctx.version = eng, eng.last_key, eng.version[eng.last_key]
         ctx.x = x
         ctx.want_dx = x.requires_grad
@@ -287,7 +323,7 @@ class _AtmsFn(torch.autograd.Function):
             raise EegclipError("ATMS activations were overwritten by a later forward at the same batch size; "
                                "run backward before the next forward (persistent activation buffers).")
         dx = eng.backward(ctx.key, ctx.x, dout.contiguous(), ctx.want_dx)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def _p(t):
@@ -310,8 +346,18 @@ class _Engine:
         dev = model.logit_scale.device
         self.device = dev
         self.model = model
-        dead = [k for k in sd_params if k not in _LIVE and k not in (_TOK_TABLE, _TOK_SHARED)]
-        order = _LIVE + [_TOK_TABLE, _TOK_SHARED] + dead
+        # joint-subject model: the single value embedding is replaced by one Linear per subject, each live only in steps whose batch holds
+        # that subject (the reference never touches the others: their .grad stays None and AdamW skips them)
+        self.joint = bool(model.joint_train)
+        self.n_subj = model.table_subjects if self.joint else 0
+        self.ve_keys = [(_E + f"value_embedding.{s}.weight", _E + f"value_embedding.{s}.bias") for s in range(self.n_subj)]
+        if self.joint:
+            self.live_base = [k for k in _LIVE if ".value_embedding." not in k]
+            live = self.live_base + [k for pair in self.ve_keys for k in pair]
+        else:
+            live = self.live_base = list(_LIVE)
+        dead = [k for k in sd_params if k not in live and k not in (_TOK_TABLE, _TOK_SHARED)]
+        order = live + [_TOK_TABLE, _TOK_SHARED] + dead
         assert sorted(order) == sorted(sd_params), "parameter list drifted from the reference state_dict"
         offs, off = {}, 0
         for k in order:
@@ -331,7 +377,7 @@ class _Engine:
             self.G[k] = self.gflat[offs[k]:offs[k] + n].view(p.shape)
             self.params[k] = p
         n_live = offs[_TOK_TABLE]
-        self.segments = [(0, n_live, list(_LIVE)),
+        self.segments = [(0, n_live, list(live)),
                          (offs[_TOK_TABLE], sd_params[_TOK_TABLE].numel(), [_TOK_TABLE]),
                          (offs[_TOK_SHARED], sd_params[_TOK_SHARED].numel(), [_TOK_SHARED]),
                          (offs[dead[0]] if dead else off, off - (offs[dead[0]] if dead else off), dead)]
@@ -363,6 +409,8 @@ class _Engine:
             feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
             bn=f(4, C_TS), ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
+        if self.joint:         # subject-ordered copies for batches that arrive in another order (see _build_fwd)
+            b.update(xs=f(B, N_CH, T_LEN), hs=f(B, L_TOK, D_MODEL), perm=torch.zeros(B, dtype=torch.int32, device=dev))
         # everything a plan must clear before use lives in two arenas (forward / backward): ONE memset each instead of five
         nsum = 2 * 2 * C_TS                                        # two BatchNorm sum rows of 2C doubles per direction
         zf = torch.zeros(nsum + B * P_DIM, dtype=torch.float64, device=dev)              # fwd: sums[0..1] | hacc (2,B,P_DIM) f32
@@ -396,9 +444,24 @@ class _Engine:
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
         # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
-        pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
-                _p(b["h"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
-                R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1))
+        hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
+        if not self.joint:
+            pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
+                    _p(b["h"]) + 4 * D_MODEL, hmap, D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
+                    R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1))
+        else:
+            # joint-subject model (Embed.py:142-144): one GEMM per subject over that subject's block of the subject-ordered batch.  A batch
+            # that is not already in subject order is gathered into xs first and the token rows are scattered back to batch order after
+            # (ops skipped otherwise); M and the A / C pointers of each GEMM are patched per call (_joint_layout), absent subjects skipped.
+            XR = N_CH * T_LEN
+            pl.j_gather = len(pl.ops)
+            pl.call("eegclip_gather_rows", _p(b["xs"]), XR, 0, XR, _p(b["perm"]), B, XR, 0)
+            pl.j_first = len(pl.ops)
+            pl.j_gemm = [pl.gemm(N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[w]), D(1), D(T_LEN), 0, hmap, D(1), bias_n=_p(P[bk]),
+                                 R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1)) for w, bk in self.ve_keys]
+            pl.j_scatter = len(pl.ops)
+            pl.call("eegclip_gather_rows", _p(b["h"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
+                    N_CH * D_MODEL, 1)
         tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
         pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
         # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
@@ -565,13 +628,32 @@ class _Engine:
         # embedding: dropout + token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
         pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
-        pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), 0, D(T_LEN), D(1),
-                _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH),
-                rowsum_a=_p(G[_E + "value_embedding.bias"]))      # bias gradient = sum of the 63 channel rows of every sample
+        hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
-            pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL), D(1),
-                    _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
+        if not self.joint:
+            pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), hmap, 0, D(T_LEN), D(1),
+                    _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH),
+                    rowsum_a=_p(G[_E + "value_embedding.bias"]))      # bias gradient = sum of the 63 channel rows of every sample
+            if want_dx:
+                pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, hmap, D(1),
+                        _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
+        else:
+            # per-subject weight gradients over the subject-ordered batch (mirror of the forward: gather the token-row gradients into
+            # subject order first when the batch is not; xs still holds the gathered EEG)
+            XR = N_CH * T_LEN
+            pl.j_gather = len(pl.ops)
+            pl.call("eegclip_gather_rows", _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
+                    N_CH * D_MODEL, 0)
+            pl.j_first = len(pl.ops)
+            pl.j_gemm = [pl.gemm(D_MODEL, T_LEN, N_CH, 0, D(1), hmap, 0, D(T_LEN), D(1), _p(G[w]), D(T_LEN), D(1), accumulate=1, split_k=1,
+                                 rowsum_a=_p(G[bk])) for w, bk in self.ve_keys]
+            if want_dx:
+                b["dxs"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
+                pl.j_dx_first = len(pl.ops)
+                pl.j_dx = [pl.gemm(N_CH, T_LEN, D_MODEL, 0, hmap, D(1), _p(P[w]), D(T_LEN), D(1), 0, D(T_LEN), D(1)) for w, _ in self.ve_keys]
+                pl.j_scatter = len(pl.ops)
+                pl.call("eegclip_gather_rows", _p(b["dx"]), XR, _p(b["dxs"]), XR, _p(b["perm"]), B, XR, 1)
         return pl
 
     def _world(self):
@@ -584,7 +666,49 @@ class _Engine:
         dist.all_reduce(t)
 
     # ---- execution -----------------------------------------------------------------------------------------------
-    def forward(self, x, ids, shared, train):
+    def _joint_layout(self, pl, b, B, host_ids, x_ptr, backward):
+        """Point the per-subject GEMMs of a joint-model plan at this batch: subject blocks of the subject-ordered batch (the batch itself if its
+        ids are already non-decreasing, else the gathered copy xs / hs)."""
+        if not backward:
+            a = np.asarray(host_ids, dtype=np.int64)
+            in_order = bool((a[1:] >= a[:-1]).all())
+            if not in_order:
+                perm = np.argsort(a, kind="stable")
+                b["perm"].copy_(torch.from_numpy(perm.astype(np.int32)))
+                a = a[perm]
+            starts = np.flatnonzero(np.r_[True, a[1:] != a[:-1]])
+            ends = np.r_[starts[1:], B]
+            b["segs"] = [(int(a[i]), int(i), int(j - i)) for i, j in zip(starts, ends)]
+            b["in_order"] = in_order
+        segs, in_order = b["segs"], b["in_order"]
+        XR, HR = 4 * N_CH * T_LEN, 4 * L_TOK * D_MODEL
+        present = {s for s, _, _ in segs}
+        skip = {pl.j_first + s for s in range(self.n_subj) if s not in present}
+        has_dx = hasattr(pl, "j_dx")
+        if has_dx:
+            skip |= {pl.j_dx_first + s for s in range(self.n_subj) if s not in present}
+        if in_order:
+            skip.add(pl.j_gather)
+            if not backward or has_dx:
+                skip.add(pl.j_scatter)
+        if not backward:
+            pl.ops[pl.j_gather][1][2] = x_ptr
+            xb, hb = (x_ptr, _p(b["h"])) if in_order else (_p(b["xs"]), _p(b["hs"]))
+            for s, st, n in segs:
+                d = pl.j_gemm[s]
+                d.M, d.A, d.C = n * N_CH, xb + st * XR, hb + st * HR + 4 * D_MODEL
+        else:
+            xb, gb = (x_ptr, _p(b["dr1"])) if in_order else (_p(b["xs"]), _p(b["hs"]))
+            for s, st, n in segs:
+                d = pl.j_gemm[s]
+                d.K, d.A, d.B = n * N_CH, gb + st * HR + 4 * D_MODEL, xb + st * XR
+                d.split_k = max(1, min(16, n * N_CH // 256))
+                if has_dx:
+                    d = pl.j_dx[s]
+                    d.M, d.A, d.C = n * N_CH, gb + st * HR + 4 * D_MODEL, (_p(b["dx"]) if in_order else _p(b["dxs"])) + st * XR
+        pl.skip = frozenset(skip)
+
+    def forward(self, x, ids, shared, train, host_ids=None):
         B = x.shape[0]
         probs = self.model.drop_probs(train)
         if B not in self.bufs:
@@ -597,7 +721,10 @@ class _Engine:
         b = self.bufs[B]
         if not shared:
             b["ids"].copy_(ids)
-        pl.x_gemm.A = x.data_ptr()              # the only per-call pointer: the EEG batch itself
+        if self.joint:
+            self._joint_layout(pl, b, B, host_ids, x.data_ptr(), False)
+        else:
+            pl.x_gemm.A = x.data_ptr()          # the only per-call pointer: the EEG batch itself
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and max(probs) > 0 else 0
         b["seed"] = seed
         pl.run(torch.cuda.current_stream().cuda_stream, seed)
@@ -605,10 +732,14 @@ class _Engine:
         self.version[key] = self.version.get(key, 0) + 1
         return b["out"]
 
-    def attach_grads(self, shared):
+    def attach_grads(self, shared, subjects=()):
         """Make p.grad views of the flat gradient buffer for every parameter that receives a gradient; zero the
         buffer if the optimizer cleared the grads (zero_grad(set_to_none=True) is torch's default)."""
-        live = list(_LIVE) + [_TOK_SHARED if shared else _TOK_TABLE]
+        live = self.live_base + [_TOK_SHARED if shared else _TOK_TABLE]
+        if self.joint:
+            import torch.distributed as dist
+            everyone = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1     # ranks must step the same parameters
+            live = live + [k for s in (range(self.n_subj) if everyone else sorted(subjects)) for k in self.ve_keys[s]]
         mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
         if all(mine(k) for k in live):
             return False                                   # accumulating onto existing gradients
@@ -634,9 +765,12 @@ class _Engine:
         if pk not in self.plans:
             self.plans[pk] = self._build_bwd(B, shared, probs, want_dx)
         pl = self.plans[pk]
-        self.attach_grads(shared)
+        self.attach_grads(shared, {s for s, _, _ in b["segs"]} if self.joint else ())
         pl.ops[pl.dout_op][1][0] = dout.data_ptr()
         pl._keep_x = (x, dout)
-        pl.x_gemm.B = x.data_ptr()              # the value-embedding weight-gradient GEMM reads the EEG batch
+        if self.joint:
+            self._joint_layout(pl, b, B, None, x.data_ptr(), True)
+        else:
+            pl.x_gemm.B = x.data_ptr()          # the value-embedding weight-gradient GEMM reads the EEG batch
         pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
         return b["dx"].clone() if want_dx else None

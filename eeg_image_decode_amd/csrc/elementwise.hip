@@ -227,9 +227,32 @@ __global__ void clip_scale_kernel(const double* __restrict__ sumsq, float max_no
     }
 }
 
+// sample-block gather / scatter for the joint-subject value embedding (Embed.py:142-144 picks a Linear per sample; the product sorts the
+// batch by subject so that every subject is one GEMM over a contiguous block).  One "row" is a sample's `row_floats` contiguous floats:
+//   scatter == 0:  dst[j*dst_stride + e] = src[idx[j]*src_stride + e]        scatter != 0:  dst[idx[j]*dst_stride + e] = src[j*src_stride + e]
+__global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ dst, long long dst_stride, const float* __restrict__ src,
+                                                          long long src_stride, const int* __restrict__ idx, int n, int row2, int scatter) {
+    const long long total = (long long)n * row2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i / row2), e = (int)(i % row2);       // 8-byte pieces: a 63 x 250 sample is not a multiple of 16 bytes
+        const int k = idx[j];
+        const long long so = (scatter ? (long long)j : (long long)k) * src_stride, dd = (scatter ? (long long)k : (long long)j) * dst_stride;
+        reinterpret_cast<float2*>(dst + dd)[e] = reinterpret_cast<const float2*>(src + so)[e];
+    }
+}
+
 }  // namespace eeg
 
 using namespace eeg;
+
+extern "C" int eegclip_gather_rows(float* dst, long long dst_stride, const float* src, long long src_stride, const int* idx, int n,
+                                   int row_floats, int scatter, void* stream) {
+    if (!dst || !src || !idx || n < 1 || row_floats < 2 || (row_floats & 1) || (dst_stride & 1) || (src_stride & 1)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(gather_rows_kernel, dim3(ew_grid((long long)n * (row_floats / 2))), dim3(256), 0, stream, dst, dst_stride, src, src_stride, idx, n,
+               row_floats / 2, scatter);
+    return (int)hipGetLastError();
+}
 
 extern "C" int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, void* stream) {
     if (!sumsq || !scale_out || max_norm <= 0.f) return EEGCLIP_EINVAL;

@@ -398,7 +398,7 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H, kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;       // slices start on 16-byte boundaries of both operands
     const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
-    hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
+    (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
     EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
     if (sums2) EEG_LAUNCH(sconv_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, y2, sums2, B);
     return (int)hipGetLastError();

@@ -30,6 +30,7 @@ class Plan:
         self.timed = {}        # op index -> list of (start, end) torch.cuda.Event pairs (HIP events on the launch stream)
         self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
         self.use_side_stream = True
+        self.skip = ()         # op indices left out of the next run()s (e.g. the value-embedding GEMMs of subjects absent from the batch)
 
     # -- generic positional op; `seed_at` = index of the seed argument (patched at run time)
     def call(self, fname, *args, seed_at=None, side=False):
@@ -87,7 +88,10 @@ class Plan:
             side = self._side
         ts = torch.cuda.current_stream() if (timed or side) else None
         dirty = False                                    # side stream has work the main stream has not waited for
+        skip = self.skip
         for idx, (fn, args, name, on_side) in enumerate(self.ops):
+            if skip and idx in skip:
+                continue
             use_side = on_side and side is not None
             if timed and idx in timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

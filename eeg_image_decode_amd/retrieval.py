@@ -60,6 +60,11 @@ def topk_retrieval(z, class_feats, logit_scale, k):
 
 
 def _uniform_ids(batch_size, subject_id, device):
+    if not isinstance(subject_id, int):           # a per-sample id list (batches that mix subjects: the joint-subject model's general case)
+        host = [int(i) for i in subject_id]
+        ids = torch.tensor(host, dtype=torch.long).to(device, non_blocking=True)
+        ids._eegclip_host_ids = host              # ATMS.forward lays the batch out by subject from the host copy: no device->host sync
+        return ids
     ids = torch.full((batch_size,), subject_id, dtype=torch.long, device=device)
     ids._eegclip_uniform_id = subject_id          # lets ATMS.forward pick the token branch without a device->host sync
     return ids

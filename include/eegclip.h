@@ -135,6 +135,11 @@ int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out
 /* out[c] += sum over blocks and rows r in [row0, blk_rows) of x[blk*blk_stride + r*cols + c] */
 int eegclip_colsum_blocks(const float* x, int nblk, int blk_rows, int row0, int cols, long long blk_stride, float* out, void* stream);
 int eegclip_sumsq(const float* x, long long n, double* out, void* stream);              /* *out += sum x^2 */
+/* sample-block gather (scatter = 0: dst[j] = src[idx[j]]) / scatter (dst[idx[j]] = src[j]); a block = row_floats contiguous floats at
+ * j*stride.  Used by the joint-subject model (Retrieval/ATMS_retrieval_joint_train.py:172-192, models/subject_layers/Embed.py:142-144) to
+ * bring a mixed-subject batch into subject order, so that each subject's value-embedding Linear is one GEMM over a contiguous block. */
+int eegclip_gather_rows(float* dst, long long dst_stride, const float* src, long long src_stride, const int* idx, int n, int row_floats,
+                        int scatter, void* stream);
 
 /* ---- fused AdamW / Adam step on a flat fp32 segment (torch.optim.AdamW math; ATMS_retrieval.py:548, diffusion_prior.py:286)
  * `step` is the 1-based step count of this update.  g is multiplied by grad_scale and, if grad_scale_dev != NULL, by

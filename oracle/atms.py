@@ -96,7 +96,12 @@ def atms_forward(P, x, subject_ids, train=False, masks=None, p_scale=1.0, want=N
     p_enc, p_conv, p_proj = P_DROP_ENC * p_scale, P_DROP_CONV * p_scale, P_DROP_PROJ * p_scale
 
     # --- A1: DataEmbedding (Embed.py:141-162): each EEG channel is one token of width 250
-    h = F.linear(x, P[pre + "value_embedding.weight"], P[pre + "value_embedding.bias"])
+    if pre + "value_embedding.weight" in P:
+        h = F.linear(x, P[pre + "value_embedding.weight"], P[pre + "value_embedding.bias"])
+    else:
+        # joint-subject model (Embed.py:127-131,142-144; ATMS_retrieval_joint_train.py:172-192): one Linear per subject, chosen per sample
+        h = torch.stack([F.linear(x[i], P[pre + f"value_embedding.{int(s)}.weight"], P[pre + f"value_embedding.{int(s)}.bias"])
+                         for i, s in enumerate(subject_ids)])
     h = h + P[pre + "position_embedding.pe"][0, : x.shape[1]].to(dt)
     h = torch.cat([subject_token(P, subject_ids, B).to(dt), h], dim=1)       # (B,64,250) token 0 = subject
     keep["h0"] = h
@@ -183,14 +188,20 @@ def fused_temporal_filter(w25):
     return weff
 
 
-def state_spec():
+def state_spec(joint_train=False, num_subjects=2):
     """(key, shape, kind) for every entry of the reference ``ATMS().state_dict()``
-    (pinned by tests/golden/atms_keys.json).  kind drives the synthetic weight recipe."""
+    (pinned by tests/golden/atms_keys.json).  kind drives the synthetic weight recipe.
+    joint_train / num_subjects: the ATMS of Retrieval/ATMS_retrieval_joint_train.py:172-192 (num_subjects = 10 there: one value-embedding
+    Linear per subject when joint_train, and as many dead subject_wise_linear layers; pinned by tests/golden/joint_keys.json)."""
     e, l, ts = "encoder.enc_embedding.", "encoder.encoder.attn_layers.0.", "enc_eeg.0.tsconv."
     S = [("logit_scale", (), "logit_scale"),
-         (e + "mask_token", (1, 250), "token"),
-         (e + "value_embedding.weight", (250, 250), "w"), (e + "value_embedding.bias", (250,), "b"),
-         (e + "position_embedding.pe", (1, 5000, 250), "pe"),
+         (e + "mask_token", (1, 250), "token")]
+    if joint_train:
+        for i in range(num_subjects):
+            S += [(e + f"value_embedding.{i}.weight", (250, 250), "w"), (e + f"value_embedding.{i}.bias", (250,), "b")]
+    else:
+        S += [(e + "value_embedding.weight", (250, 250), "w"), (e + "value_embedding.bias", (250,), "b")]
+    S += [(e + "position_embedding.pe", (1, 5000, 250), "pe"),
          (e + "temporal_embedding.embed.weight", (250, 4), "w"),
          (e + "subject_embedding.shared_embedding", (1, 250), "token"),
          (e + "subject_embedding.mask_embedding", (1, 250), "token"),
@@ -202,7 +213,7 @@ def state_spec():
           (l + "norm1.weight", (250,), "g"), (l + "norm1.bias", (250,), "b"),
           (l + "norm2.weight", (250,), "g"), (l + "norm2.bias", (250,), "b"),
           ("encoder.encoder.norm.weight", (250,), "g"), ("encoder.encoder.norm.bias", (250,), "b")]
-    for i in range(2):
+    for i in range(num_subjects):
         S += [(f"subject_wise_linear.{i}.weight", (250, 250), "w"), (f"subject_wise_linear.{i}.bias", (250,), "b")]
     S += [(ts + "0.weight", (40, 1, 1, 25), "w"), (ts + "0.bias", (40,), "b"),
           (ts + "2.weight", (40,), "g"), (ts + "2.bias", (40,), "b"),

@@ -130,6 +130,25 @@ def test_elementwise_helpers(be):
     assert abs(be.host(SC)[0] - min(1.0, 1.0 / (np.sqrt((x.astype(np.float64) ** 2).sum()) + 1e-6))) < 1e-7
 
 
+@pytest.mark.parametrize("n,row,ds,ss", [(7, 15750, 16000, 15750), (1, 2, 2, 2), (33, 250, 250, 1000)])
+def test_gather_scatter_rows_bit_exact(be, n, row, ds, ss):
+    """sample-block gather (dst[j] = src[idx[j]]) and scatter (dst[idx[j]] = src[j]) with independent strides: pure data movement, bit exact"""
+    rng = np.random.default_rng(12)
+    perm = rng.permutation(n).astype(np.int32)
+    src = rnd(rng, n * ss)
+    dst0 = rnd(rng, n * ds)
+    IDX, SRC = be.dev(perm), be.dev(src)
+    for scatter in (0, 1):
+        DST = be.dev(dst0)
+        ok(be.lib.eegclip_gather_rows(be.ptr(DST), ds, be.ptr(SRC), ss, be.ptr(IDX), n, row, scatter, be.stream))
+        want = dst0.copy()
+        for j in range(n):
+            a, b_ = (perm[j], j) if scatter else (j, perm[j])
+            want[a * ds:a * ds + row] = src[b_ * ss:b_ * ss + row]
+        assert np.array_equal(be.host(DST), want)                     # elements between blocks untouched
+    assert be.lib.eegclip_gather_rows(be.ptr(DST), ds, be.ptr(DST), ss, be.ptr(IDX), n, 3, 0, be.stream) < 0       # odd row length
+
+
 @pytest.mark.parametrize("outer,mid,inner", [(1000, 250, 1), (7, 40, 36), (3, 1024, 1), (1, 5, 1)])
 def test_reduce_mid(be, outer, mid, inner):
     rng = np.random.default_rng(outer)

@@ -316,3 +316,65 @@ def test_evaluate_model_matches_reference_fixture(state_np, golden):
         l, a, t5 = retrieval.evaluate_model("sub-08", m, _ListLoader(batches), "cuda", txt_all, img_all, k, None)
         ref = g[f"k{k}"]
         assert abs(l - ref[0]) < 1e-4 and a == ref[1] and t5 == ref[2], (k, l, a, t5, ref)
+
+
+def test_joint_subject_model_matches_reference_fixture(golden):
+    """retrieval_joint.ATMS(joint_train=True) against outputs of the reference's ATMS_retrieval_joint_train.py:ATMS
+    (tests/golden/make_golden_joint.py): eval embeddings for a uniform and a mixed-subject batch, train-mode (p = 0) loss, embeddings,
+    gradient norms of every parameter, gradient slices of the per-subject embeddings, and which parameters get no gradient at all."""
+    from eeg_image_decode_amd.retrieval_joint import ATMS
+    g = golden("joint.npz")
+    state_np = syn.make_state(SEED + 30, oatms.state_spec(True, 10))
+    m = ATMS(joint_train=True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state_np.items()})
+    m = m.cuda().eval()
+    x = T(syn.eeg_batch(SEED + 31, 8)).cuda()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x, torch.full((8,), 4, dtype=torch.long).cuda()).cpu().numpy(), g["emb_uniform4"], atol=1e-4)
+        np.testing.assert_allclose(m(x, 4).cpu().numpy(), g["emb_uniform4"], atol=1e-4)
+        np.testing.assert_allclose(m(x, T(g["ids_mixed"]).cuda()).cpu().numpy(), g["emb_mixed"], atol=1e-4)
+        with pytest.raises(Exception, match="value embeddings for subjects"):
+            m(x, 10)                                   # 'sub-10' has no embedding in the joint model: a KeyError in the reference
+    zero_dropout(m)
+    m.train()
+    B = 12
+    xb = T(syn.eeg_batch(SEED + 32, B)).cuda()
+    img, txt = T(syn.unit_features(SEED + 32, B, tag="img")).cuda(), T(syn.unit_features(SEED + 32, B, tag="txt")).cuda()
+    z = m(xb, T(g["train_ids"]).cuda())
+    loss = 0.99 * m.loss_func(z, img, m.logit_scale) + 0.01 * m.loss_func(z, txt, m.logit_scale)
+    loss.backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["train_z"], atol=1e-4)
+    assert abs(float(loss.detach()) - float(g["train_loss"])) < 1e-4
+    none_keys = set(g["none_grad_keys"].tolist())
+    for k, p in m.named_parameters():
+        if k in none_keys:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        if k in oloops.ZERO_GRAD_KEYS:
+            continue
+        gn = float(g["gnorm:" + k])
+        assert abs(float(p.grad.norm()) - gn) <= 2e-3 * gn + 1e-7, (k, float(p.grad.norm()), gn)
+        if "grad:" + k in g.files:
+            r = g["grad:" + k]
+            np.testing.assert_allclose(p.grad.detach().cpu().numpy().reshape(-1)[:512], r, atol=2e-3 * float(np.abs(r).max()) + 1e-7, err_msg=k)
+
+
+def test_joint_subject_large_mixed_batch_equals_per_subject_passes():
+    """size-independent property at the headline batch: a shuffled 256-sample batch over 10 subjects (eval mode: samples are independent)
+    == the per-subject uniform-id passes stitched back, and the ordered / unordered layouts agree bit for bit"""
+    from eeg_image_decode_amd.retrieval_joint import ATMS
+    torch.manual_seed(5)
+    m = ATMS(joint_train=True).cuda().eval()
+    B = 256
+    x = T(syn.eeg_batch(SEED + 33, B)).cuda()
+    ids = torch.from_numpy(np.random.default_rng(8).integers(0, 10, B))
+    with torch.no_grad():
+        z = m(x, ids.cuda()).clone()
+        order = torch.argsort(ids, stable=True)
+        zs = m(x[order.cuda()].contiguous(), ids[order].cuda()).clone()
+        assert torch.equal(z[order.cuda()], zs)
+        for s in range(10):
+            sel = (ids == s).nonzero().flatten().cuda()
+            if len(sel):
+                np.testing.assert_allclose(m(x[sel].contiguous(), s).cpu().numpy(), z[sel].cpu().numpy(), atol=2e-5)

@@ -158,6 +158,39 @@ def test_reconstruction_train_loop_matches_reference(state, golden):
         assert abs(d - float(g["dnorm:" + k])) <= 2e-3 * max(float(g["dnorm:" + k]), 1e-3) + 1e-6, k
 
 
+def test_joint_subject_model_matches_reference(golden):
+    """ATMS(joint_train=True) of Retrieval/ATMS_retrieval_joint_train.py -- keys, eval embeddings for uniform and mixed
+    subject ids, train-mode loss / gradients with mixed subjects and the set of parameters that receive no gradient"""
+    with open(os.path.join(GOLDEN, "joint_keys.json")) as f:
+        ref = json.load(f)
+    spec = oatms.state_spec(True, 10)
+    assert [k for k, _, _ in spec] == list(ref["keys"]) and {k: list(s) for k, s, _ in spec} == ref["keys"]
+    assert sum(int(np.prod(s)) for k, s, _ in spec if not oloops.is_buffer(k)) == ref["n_params"]
+    g = golden("joint.npz")
+    st = oloops.torch_state(syn.make_state(SEED + 30, spec))
+    x = T(syn.eeg_batch(SEED + 31, 8))
+    np.testing.assert_allclose(oatms.atms_forward(st, x, torch.full((8,), 4).long(), train=False).numpy(), g["emb_uniform4"], atol=2e-5)
+    np.testing.assert_allclose(oatms.atms_forward(st, x, T(g["ids_mixed"]).long(), train=False).numpy(), g["emb_mixed"], atol=2e-5)
+    B = 12
+    xb = T(syn.eeg_batch(SEED + 32, B))
+    img, txt = T(syn.unit_features(SEED + 32, B, tag="img")), T(syn.unit_features(SEED + 32, B, tag="txt"))
+    tr = oloops.OracleTrainer(st, p_scale=0.0)
+    loss, z, grads, _ = tr.loss_and_grads(xb, T(g["train_ids"]).long(), img, txt, train=True)
+    assert abs(float(loss) - float(g["train_loss"])) < 2e-5
+    np.testing.assert_allclose(z.numpy(), g["train_z"], atol=5e-5)
+    none_ref = set(g["none_grad_keys"].tolist())
+    for k in tr.params:
+        if k in none_ref:
+            assert grads[k] is None or float(grads[k].abs().max()) == 0.0, k
+        else:
+            assert grads[k] is not None, k
+            if k not in oloops.ZERO_GRAD_KEYS:
+                ref_n = float(g["gnorm:" + k])
+                assert abs(float(grads[k].norm()) - ref_n) <= 2e-3 * max(ref_n, 1e-6) + 1e-7, k
+            if "grad:" + k in g:
+                np.testing.assert_allclose(grads[k].reshape(-1)[:512].numpy(), g["grad:" + k], atol=1e-6 + 2e-3 * np.abs(g["grad:" + k]).max())
+
+
 def test_evaluate_matches_reference(state, golden):
     g = golden("eval.npz")
     n_test = 200

@@ -113,6 +113,54 @@ def test_reconstruction_objective_step_under_emulator_matches_oracle():
         assert d.max() <= 2 * 3e-4 + 1e-6 and (d > 2e-5).mean() < 1e-4, (k, float(d.max()), float((d > 2e-5).mean()))
 
 
+@pytest.mark.parametrize("ids", [[3, 0, 3, 7], [0, 3, 3, 7], [5, 5, 5, 5]], ids=["mixed-unordered", "mixed-ordered", "uniform"])
+def test_joint_subject_model_under_emulator_matches_oracle(ids):
+    """one value embedding per subject (retrieval_joint.ATMS(joint_train=True)).  Batches that mix subjects (gathered into
+    subject order / already ordered) and the reference loops' uniform-id case: embeddings, loss, every parameter gradient (None for the
+    subjects absent from the batch, as in the reference) and the input gradient."""
+    state_np = syn.make_state(SEED, oatms.state_spec(joint_train=True, num_subjects=10))
+    B = len(ids)
+    x0 = syn.eeg_batch(SEED + 42, B)
+    img, txt = T(syn.unit_features(SEED + 42, B, tag="img")), T(syn.unit_features(SEED + 42, B, tag="txt"))
+    idt = torch.tensor(ids)
+    with product_on_emulator():
+        from eeg_image_decode_amd.retrieval_joint import ATMS
+        m = ATMS(joint_train=True)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state_np.items()})
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        with torch.no_grad():
+            z_eval = m.eval()(T(x0), idt).clone()         # before the train-mode forward moves the BatchNorm running statistics
+        m.train()
+        x = T(x0).requires_grad_()
+        z = m(x, idt)
+        loss = 0.99 * m.loss_func(z, img, m.logit_scale) + 0.01 * m.loss_func(z, txt, m.logit_scale)
+        loss.backward()
+        grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+        dx = x.grad.clone()
+        with pytest.raises(Exception, match="value embeddings for subjects"):
+            m(T(x0), torch.tensor([0, 1, 2, 10][:B]))
+    tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
+    lo, zo, og, _ = tr.loss_and_grads(T(x0), idt, img, txt, train=True)
+    xo = T(x0).requires_grad_()
+    oloss.mixed_loss(oatms.atms_forward(tr.P, xo, idt, train=True, p_scale=0.0), img, txt, tr.P["logit_scale"]).backward()
+    np.testing.assert_allclose(z.detach().numpy(), zo.detach().numpy(), atol=1e-4)
+    assert abs(float(loss.detach()) - float(lo)) < 1e-4
+    present = set(ids)
+    for k, g in grads.items():
+        if og[k] is None:
+            assert g is None, k
+        elif k not in oloops.ZERO_GRAD_KEYS:
+            assert g is not None, k
+            np.testing.assert_allclose(g.numpy(), og[k].numpy(), atol=1e-7 + 3e-3 * float(og[k].abs().max()), err_msg=k)
+    for s in range(10):
+        assert (grads[f"encoder.enc_embedding.value_embedding.{s}.weight"] is not None) == (s in present)
+    np.testing.assert_allclose(dx.numpy(), xo.grad.numpy(), atol=1e-7 + 3e-3 * float(xo.grad.abs().max()))
+    zo_eval = oatms.atms_forward(tr.P, T(x0), idt, train=False)
+    np.testing.assert_allclose(z_eval.numpy(), zo_eval.detach().numpy(), atol=1e-4)
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HIPEMU_THREADS"] = "2"
