@@ -362,7 +362,8 @@ def test_joint_subject_model_matches_reference_fixture(golden):
 
 def test_joint_subject_large_mixed_batch_equals_per_subject_passes():
     """size-independent property at the headline batch: a shuffled 256-sample batch over 10 subjects (eval mode: samples are independent)
-    == the per-subject uniform-id passes stitched back, and the ordered / unordered layouts agree bit for bit"""
+    == the per-subject uniform-id passes stitched back, and the ordered / unordered layouts agree (to round-off: the K-split spatial stage and
+    the split-K head GEMMs add partial tiles with float atomics, whose order differs from run to run)"""
     from eeg_image_decode_amd.retrieval_joint import ATMS
     torch.manual_seed(5)
     m = ATMS(joint_train=True).cuda().eval()
@@ -373,7 +374,7 @@ def test_joint_subject_large_mixed_batch_equals_per_subject_passes():
         z = m(x, ids.cuda()).clone()
         order = torch.argsort(ids, stable=True)
         zs = m(x[order.cuda()].contiguous(), ids[order].cuda()).clone()
-        assert torch.equal(z[order.cuda()], zs)
+        np.testing.assert_allclose(z[order.cuda()].cpu().numpy(), zs.cpu().numpy(), atol=2e-5)
         for s in range(10):
             sel = (ids == s).nonzero().flatten().cuda()
             if len(sel):
