@@ -37,6 +37,7 @@ _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c
 PROTOTYPES = {
     "eegclip_abi_version": [],
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
+    "eegclip_gemm_f32_grouped": [_P, _I, _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P],
     "eegclip_layernorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],

@@ -456,9 +456,9 @@ class _Engine:
             XR = N_CH * T_LEN
             pl.j_gather = len(pl.ops)
             pl.call("eegclip_gather_rows", _p(b["xs"]), XR, 0, XR, _p(b["perm"]), B, XR, 0)
-            pl.j_first = len(pl.ops)
-            pl.j_gemm = [pl.gemm(N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[w]), D(1), D(T_LEN), 0, hmap, D(1), bias_n=_p(P[bk]),
+            pl.j_gemm = [pl.desc(N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[w]), D(1), D(T_LEN), 0, hmap, D(1), bias_n=_p(P[bk]),
                                  R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1)) for w, bk in self.ve_keys]
+            pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)             # ONE launch for all subjects of the batch
             pl.j_scatter = len(pl.ops)
             pl.call("eegclip_gather_rows", _p(b["h"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
                     N_CH * D_MODEL, 1)
@@ -645,13 +645,13 @@ class _Engine:
             pl.j_gather = len(pl.ops)
             pl.call("eegclip_gather_rows", _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
                     N_CH * D_MODEL, 0)
-            pl.j_first = len(pl.ops)
-            pl.j_gemm = [pl.gemm(D_MODEL, T_LEN, N_CH, 0, D(1), hmap, 0, D(T_LEN), D(1), _p(G[w]), D(T_LEN), D(1), accumulate=1, split_k=1,
+            pl.j_gemm = [pl.desc(D_MODEL, T_LEN, N_CH, 0, D(1), hmap, 0, D(T_LEN), D(1), _p(G[w]), D(T_LEN), D(1), accumulate=1, split_k=1,
                                  rowsum_a=_p(G[bk])) for w, bk in self.ve_keys]
+            pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)
             if want_dx:
                 b["dxs"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
-                pl.j_dx_first = len(pl.ops)
-                pl.j_dx = [pl.gemm(N_CH, T_LEN, D_MODEL, 0, hmap, D(1), _p(P[w]), D(T_LEN), D(1), 0, D(T_LEN), D(1)) for w, _ in self.ve_keys]
+                pl.j_dx = [pl.desc(N_CH, T_LEN, D_MODEL, 0, hmap, D(1), _p(P[w]), D(T_LEN), D(1), 0, D(T_LEN), D(1)) for w, _ in self.ve_keys]
+                pl.j_dx_arr, pl.j_dx_group = pl.gemm_grouped(self.n_subj)
                 pl.j_scatter = len(pl.ops)
                 pl.call("eegclip_gather_rows", _p(b["dx"]), XR, _p(b["dxs"]), XR, _p(b["perm"]), B, XR, 1)
         return pl
@@ -682,11 +682,8 @@ class _Engine:
             b["in_order"] = in_order
         segs, in_order = b["segs"], b["in_order"]
         XR, HR = 4 * N_CH * T_LEN, 4 * L_TOK * D_MODEL
-        present = {s for s, _, _ in segs}
-        skip = {pl.j_first + s for s in range(self.n_subj) if s not in present}
+        skip = set()
         has_dx = hasattr(pl, "j_dx")
-        if has_dx:
-            skip |= {pl.j_dx_first + s for s in range(self.n_subj) if s not in present}
         if in_order:
             skip.add(pl.j_gather)
             if not backward or has_dx:
@@ -706,6 +703,13 @@ class _Engine:
                 if has_dx:
                     d = pl.j_dx[s]
                     d.M, d.A, d.C = n * N_CH, gb + st * HR + 4 * D_MODEL, (_p(b["dx"]) if in_order else _p(b["dxs"])) + st * XR
+        for i, (s, _, _) in enumerate(segs):
+            pl.j_arr[i] = pl.j_gemm[s]                   # struct copy: the members of this batch, in subject order
+        pl.ops[pl.j_group][1][1] = len(segs)
+        if has_dx:
+            for i, (s, _, _) in enumerate(segs):
+                pl.j_dx_arr[i] = pl.j_dx[s]
+            pl.ops[pl.j_dx_group][1][1] = len(segs)
         pl.skip = frozenset(skip)
 
     def forward(self, x, ids, shared, train, host_ids=None):

@@ -236,8 +236,10 @@ __device__ __forceinline__ int f_swz(int k) { return ((k >> 2) & 1) << 4; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false>
-__global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+// `bid` = index of this workgroup within its problem (== blockIdx.x for a single GEMM; the grouped launch below subtracts the first
+// workgroup of the group, always a multiple of 8, so bid % 8 is still the XCD the dispatcher placed the workgroup on)
+template <bool A_KC, bool B_KC, bool C_PLAIN, bool K2>
+__device__ __forceinline__ void gemm_f32_fast_body(const eegclip_gemm_desc& d, int gx, int ntiles, int chunk, int bid) {
     constexpr int A_FLOATS = A_KC ? G_BT * F_LDK : G_BK * G_BT;
     EEG_LDS_BASE(float, lds);
     float* As = lds;
@@ -245,14 +247,14 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
 
     int logical, slice = 0;
     if (d.split_k == 1) {
-        logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        logical = (bid & 7) * chunk + (bid >> 3);
         if (logical >= ntiles) return;                   // whole workgroup leaves before any barrier
     } else {
         // split-K (weight gradients: few output tiles, K = all rows of the batch): ALL tiles of one K slice go to ONE XCD, so the
         // slice of A and B is fetched from HBM once and re-read from that XCD's L2 by the other tiles (a tile-major order spread the
         // 16 tiles of a 250 x 256 gradient over all 8 XCDs: 114 MB of HBM traffic for 33 MB of operands, rocprofv3 FETCH_SIZE)
-        const int slot = (int)(blockIdx.x >> 3);
-        slice = (int)(blockIdx.x & 7) + 8 * (slot / ntiles);
+        const int slot = bid >> 3;
+        slice = (bid & 7) + 8 * (slot / ntiles);
         logical = slot % ntiles;
         if (slice >= d.split_k) return;
     }
@@ -408,6 +410,48 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_
     gemm_epilogue<C_PLAIN>(d, acc, m0, n0, wr, wc, lane, slice == 0);
 }
 
+template <bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false>
+__global__ __launch_bounds__(G_THREADS) void gemm_f32_fast_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+    gemm_f32_fast_body<A_KC, B_KC, C_PLAIN, K2>(d, gx, ntiles, chunk, (int)blockIdx.x);
+}
+
+// Grouped launch: up to GEMM_MAX_GROUPS problems that differ only in M, K, split_k and their pointers (the joint-subject model's
+// per-subject value embeddings: SURVEY 8f row 1, models/subject_layers/Embed.py:142-144) run as ONE grid.  Group g owns workgroups
+// [first[g], first[g+1]); everything else comes from the shared descriptor.  Ten 100-tile launches of 10 us each become one 1000-tile
+// launch that fills the chip.
+constexpr int GEMM_MAX_GROUPS = 16;
+struct gemm_group {
+    int M, K, split_k, pad;
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias_n;
+    float* rowsum_a;
+};
+struct gemm_group_table {
+    int n;
+    int first[GEMM_MAX_GROUPS + 1];
+    gemm_group g[GEMM_MAX_GROUPS];
+};
+
+template <bool A_KC, bool B_KC, bool C_PLAIN, bool K2>
+__global__ __launch_bounds__(G_THREADS) void gemm_f32_grouped_kernel(const eegclip_gemm_desc d0, const gemm_group_table tb) {
+    const int b = (int)blockIdx.x;
+    int gi = 0;
+    for (int i = 1; i < tb.n; ++i) gi += b >= tb.first[i] ? 1 : 0;          // workgroup-uniform
+    eegclip_gemm_desc d = d0;
+    d.M = tb.g[gi].M;
+    d.K = tb.g[gi].K;
+    d.split_k = tb.g[gi].split_k;
+    d.A = tb.g[gi].A;
+    d.B = tb.g[gi].B;
+    d.C = tb.g[gi].C;
+    d.bias_n = tb.g[gi].bias_n;
+    d.rowsum_a = tb.g[gi].rowsum_a;
+    const int gx = (d.N + G_BT - 1) / G_BT, ntiles = gx * ((d.M + G_BT - 1) / G_BT);
+    gemm_f32_fast_body<A_KC, B_KC, C_PLAIN, K2>(d, gx, ntiles, (ntiles + 7) / 8, b - tb.first[gi]);
+}
+
 static inline bool is_plain(const eegclip_dim& x) { return x.div > (1LL << 40); }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
@@ -427,6 +471,75 @@ static bool fast_k2_ok(const float* p, const eegclip_dim& kd, int rows, int K) {
     const long long div = kd.div > (1LL << 30) ? (1LL << 30) : kd.div;                 // plain map: never wraps
     const long long reach = ((K - 1) / div) * kd.so + ((K - 1) % div) * kd.si + rows + 2;
     return kd.div >= 1 && reach < (1LL << 31) && (kd.div > (1LL << 30) || kd.so - kd.div * kd.si < (1LL << 31));
+}
+
+// which fast instantiation (if any) a problem can use: 0 = none, 1 = plain k maps (akc / bkc say which operands are k-contiguous),
+// 2 = K2 (row-contiguous operands, two-level k maps)
+static int fast_class(const eegclip_gemm_desc& d, bool& akc, bool& bkc, bool& c_plain) {
+    const int gx = (d.N + G_BT - 1) / G_BT, gy = (d.M + G_BT - 1) / G_BT;
+    const bool ab_plain = is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) && is_plain(d.Bn);
+    c_plain = is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn)));
+    akc = bkc = false;
+    if (d.K < 2 || (long long)gx * gy >= (1LL << 28)) return 0;
+    if (ab_plain && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) && fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) return 1;
+    akc = bkc = false;
+    if (c_plain && is_plain(d.Am) && is_plain(d.Bn) && d.Am.si == 1 && d.Bn.si == 1 && fast_k2_ok(d.A, d.Ak, d.M, d.K) && fast_k2_ok(d.B, d.Bk, d.N, d.K))
+        return 2;
+    return 0;
+}
+
+static int launch_gemm(const eegclip_gemm_desc& d, void* stream);
+
+// everything a group cannot override must be the same in all members (Cpre / bias_m are per-problem buffers: not groupable when set)
+static bool same_dim(const eegclip_dim& a, const eegclip_dim& b) { return a.div == b.div && a.so == b.so && a.si == b.si; }
+static bool same_shared(const eegclip_gemm_desc& a, const eegclip_gemm_desc& b) {
+    return a.N == b.N && same_dim(a.Am, b.Am) && same_dim(a.Ak, b.Ak) && same_dim(a.Bk, b.Bk) && same_dim(a.Bn, b.Bn) && same_dim(a.Cm, b.Cm) &&
+           same_dim(a.Cn, b.Cn) && !a.Cpre && !b.Cpre && !a.bias_m && !b.bias_m && a.R == b.R && (!a.R || (same_dim(a.Rm, b.Rm) && same_dim(a.Rn, b.Rn))) &&
+           a.alpha == b.alpha && a.accumulate == b.accumulate && a.act == b.act && a.drop_p == b.drop_p && a.seed == b.seed &&
+           a.drop_site == b.drop_site && (a.bias_n == nullptr) == (b.bias_n == nullptr) && (a.rowsum_a == nullptr) == (b.rowsum_a == nullptr);
+}
+
+static int launch_gemm_grouped(const eegclip_gemm_desc* ds, int n, void* stream) {
+    static const bool allow = !(getenv("EEGCLIP_GEMM_GROUPED") && atoi(getenv("EEGCLIP_GEMM_GROUPED")) == 0);        // tuning aid
+    bool akc = false, bkc = false, cpl = false;
+    int cls = (allow && n >= 2 && n <= GEMM_MAX_GROUPS) ? fast_class(ds[0], akc, bkc, cpl) : 0;
+    gemm_group_table tb;
+    tb.n = 0;
+    tb.first[0] = 0;
+    for (int i = 0; cls && i < n; ++i) {
+        bool a2, b2, c2;
+        if (fast_class(ds[i], a2, b2, c2) != cls || a2 != akc || b2 != bkc || c2 != cpl || !same_shared(ds[i], ds[0])) cls = 0;   // same instantiation
+        const long long ntiles = (long long)((ds[i].N + G_BT - 1) / G_BT) * ((ds[i].M + G_BT - 1) / G_BT);
+        const long long wgs = ds[i].split_k == 1 ? 8 * ((ntiles + 7) / 8) : 8LL * ((ds[i].split_k + 7) / 8) * ntiles;
+        if (tb.first[i] + wgs >= (1LL << 30)) cls = 0;
+        if (!cls) break;
+        tb.first[i + 1] = tb.first[i] + (int)wgs;
+        tb.g[i] = gemm_group{ds[i].M, ds[i].K, ds[i].split_k, 0, ds[i].A, ds[i].B, ds[i].C, ds[i].bias_n, ds[i].rowsum_a};
+    }
+    if (!cls) {                                           // not groupable: the same work as n launches
+        for (int i = 0; i < n; ++i) {
+            const int rc = launch_gemm(ds[i], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    tb.n = n;
+    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                           // tuning aid
+    if (trace) fprintf(stderr, "eegclip_gemm_f32_grouped: %d members, class %d <%d,%d,%d>, %d workgroups\n", n, cls, (int)akc, (int)bkc, (int)cpl, tb.first[n]);
+    const dim3 grid(tb.first[n]), block(G_THREADS);
+    const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
+#define EEG_GROUP_GO(AK, BK_, CP, K2_) EEG_LAUNCH((gemm_f32_grouped_kernel<AK, BK_, CP, K2_>), grid, block, lds, stream, ds[0], tb)
+    if (cls == 2)                EEG_GROUP_GO(false, false, true, true);
+    else if (akc && bkc && cpl)  EEG_GROUP_GO(true, true, true, false);
+    else if (akc && bkc)         EEG_GROUP_GO(true, true, false, false);
+    else if (akc && cpl)         EEG_GROUP_GO(true, false, true, false);
+    else if (akc)                EEG_GROUP_GO(true, false, false, false);
+    else if (bkc && cpl)         EEG_GROUP_GO(false, true, true, false);
+    else if (bkc)                EEG_GROUP_GO(false, true, false, false);
+    else if (cpl)                EEG_GROUP_GO(false, false, true, false);
+    else                         EEG_GROUP_GO(false, false, false, false);
+#undef EEG_GROUP_GO
+    return (int)hipGetLastError();
 }
 
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
@@ -483,12 +596,41 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
 
 }  // namespace eeg
 
+static int gemm_desc_check(const eegclip_gemm_desc& d);
+
 extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     using namespace eeg;
     if (!dp) return EEGCLIP_EINVAL;
     const eegclip_gemm_desc d = *dp;
+    const int rc = gemm_desc_check(d);
+    if (rc || d.M == 0 || d.N == 0) return rc;
+    return launch_gemm(d, stream);
+}
+
+extern "C" int eegclip_gemm_f32_grouped(const eegclip_gemm_desc* descs, int n, void* stream) {
+    using namespace eeg;
+    if (!descs || n < 0) return EEGCLIP_EINVAL;
+    bool empty = false;
+    for (int i = 0; i < n; ++i) {
+        const int rc = gemm_desc_check(descs[i]);
+        if (rc) return rc;
+        empty = empty || descs[i].M == 0 || descs[i].N == 0;
+    }
+    if (n == 0) return 0;
+    if (empty || n == 1) {                               // degenerate members: plain launches of the non-empty ones
+        for (int i = 0; i < n; ++i) {
+            if (descs[i].M == 0 || descs[i].N == 0) continue;
+            const int rc = launch_gemm(descs[i], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    return launch_gemm_grouped(descs, n, stream);
+}
+
+static int gemm_desc_check(const eegclip_gemm_desc& d) {
     if (d.M < 0 || d.N < 0 || d.K < 0 || !d.C) return EEGCLIP_EINVAL;
-    if (d.M == 0 || d.N == 0) return 0;
+    if (d.M == 0 || d.N == 0) return 0;                  /* nothing to compute (callers skip the launch) */
     if (d.K > 0 && (!d.A || !d.B)) return EEGCLIP_EINVAL;
     if (d.split_k < 1) return EEGCLIP_EINVAL;
     if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre)) return EEGCLIP_EINVAL;
@@ -496,7 +638,7 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     if (d.act == EEGCLIP_ACT_GELU_GRAD && (!d.R || d.split_k > 1)) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;
-    return launch_gemm(d, stream);
+    return 0;
 }
 
 extern "C" int eegclip_abi_version(void) { return EEGCLIP_ABI_VERSION; }

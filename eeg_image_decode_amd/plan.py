@@ -39,16 +39,29 @@ class Plan:
         if seed_at is not None:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
-    def gemm(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, side=False):
+    def desc(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None):
+        """a GEMM descriptor owned by the plan but not (yet) an op: member template of a grouped launch"""
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
                           drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a)
         self._keep.append(d)
-        if drop_p > 0.0:
+        return d
+
+    def gemm(self, *a, side=False, **k):
+        d = self.desc(*a, **k)
+        if d.drop_p > 0.0:
             self._seed_descs.append(d)
         self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", side))
         return d
+
+    def gemm_grouped(self, n_max, side=False):
+        """one eegclip_gemm_f32_grouped op over a descriptor array the caller fills before each run: returns (array, op index); the member
+        count is op argument 1"""
+        arr = (_abi.GemmDesc * n_max)()
+        self._keep.append(arr)
+        self.ops.append((self.L.eegclip_gemm_f32_grouped, [arr, 0, None], "eegclip_gemm_f32_grouped", side))
+        return arr, len(self.ops) - 1
 
     def callback(self, fn, name="callback"):
         """run a host callable in stream order (collectives between kernels: SyncBN statistics)"""

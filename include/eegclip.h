@@ -74,6 +74,11 @@ typedef struct {
 } eegclip_gemm_desc;
 
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);
+/* n independent problems (outputs must not overlap) with the result of n eegclip_gemm_f32 calls.  Members that differ only in M, K, split_k,
+ * A, B, C, bias_n and rowsum_a (at most 16 of them) run as ONE grid: the joint-subject model's per-subject value embeddings -- the
+ * reference's Python loop of B Linear calls, models/subject_layers/Embed.py:144 -- and their weight gradients.  Anything else is launched
+ * member by member. */
+int eegclip_gemm_f32_grouped(const eegclip_gemm_desc* descs, int n, void* stream);
 
 /* ---- LayerNorm (rows of <= 1024 floats).  Transformer_EncDec.py:47,51,77-78 ; ATMS_retrieval.py:166 ; diffusion_prior.py:120,140,155
  * fwd: y = (x-mean)*rstd*gamma+beta, mean/rstd[rows] saved (may be NULL).  bwd: dx (+)= ..., dgamma/dbeta += (atomic);

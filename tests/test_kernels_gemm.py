@@ -202,6 +202,91 @@ def test_gemm_value_embedding_weight_gradient_view(be, split):
     np.testing.assert_allclose(be.host(RS), g.sum(0), atol=2e-4)
 
 
+def _grouped(be, descs, n=None):
+    arr = (_abi.GemmDesc * len(descs))(*descs)
+    rc = be.lib.eegclip_gemm_f32_grouped(arr, len(descs) if n is None else n, be.stream)
+    assert rc == 0, rc
+
+
+@pytest.mark.parametrize("counts", [[2, 1, 4], [1, 1], [3], [1] * 16, [1] * 17])
+def test_grouped_gemm_per_subject_value_embedding(be, counts):
+    """SURVEY 8f row 1 (models/subject_layers/Embed.py:142-144): a subject-ordered batch, one Linear per subject.  The grouped launch must
+    equal the member-by-member launches bit for bit (split_k = 1: no atomics) and the fp64 reference; 17 members exceed the group table and
+    take the member-by-member route inside the library.  Forward view: rows = (sample, channel) -> token rows 1..63 of (B,64,D) + bias + PE."""
+    rng = np.random.default_rng(100 + len(counts))
+    Cc, Dm, T = 63, 50, 70
+    Bt, S = sum(counts), len(counts)
+    x, w, bias, pe = f32(rng, Bt, Cc, T), f32(rng, S, Dm, T), f32(rng, S, Dm), f32(rng, Cc, Dm)
+    X, W, BI, PE = be.dev(x), be.dev(w), be.dev(bias), be.dev(pe)
+    outs = []
+    for grouped in (False, True):
+        H = be.dev(np.full((Bt, Cc + 1, Dm), 7.0, np.float32))
+        ds, st = [], 0
+        for s, n in enumerate(counts):
+            d = mk(be, n * Cc, Dm, T, X, D(T), D(1), W, D(1), D(T), H, D(Dm, div=Cc, so=(Cc + 1) * Dm), D(1), R=be.ptr(PE),
+                   Rm=D(Dm, div=Cc, so=0), Rn=D(1))
+            d.A, d.B, d.bias_n = be.ptr(X) + 4 * st * Cc * T, be.ptr(W) + 4 * s * Dm * T, be.ptr(BI) + 4 * s * Dm
+            d.C = be.ptr(H) + 4 * (st * (Cc + 1) * Dm + Dm)
+            ds.append(d)
+            st += n
+        if grouped:
+            _grouped(be, ds)
+        else:
+            for d in ds:
+                run(be, d)
+        outs.append(be.host(H))
+    assert np.array_equal(outs[0], outs[1])
+    st = 0
+    for s, n in enumerate(counts):
+        ref = x[st:st + n].astype(np.float64) @ w[s].T + bias[s] + pe
+        np.testing.assert_allclose(outs[1][st:st + n, 1:], ref, atol=1e-4)
+        st += n
+    assert (outs[1][:, 0] == 7.0).all()                               # token row 0 is not the GEMM's to write
+
+
+@pytest.mark.parametrize("splits", [[1, 1, 1], [2, 1, 3]])
+def test_grouped_gemm_per_subject_weight_gradients(be, splits):
+    """backward of the above: dW_s += dOut_s[:, 1:, :]^T X_s with the bias gradient as rowsum_a -- K2 instantiation, per-member K and split_k"""
+    rng = np.random.default_rng(7 + sum(splits))
+    Cc, Dm, T = 63, 50, 70
+    counts = [2, 5, 1]
+    Bt, S = sum(counts), len(counts)
+    dout, x, w0 = f32(rng, Bt, Cc + 1, Dm), f32(rng, Bt, Cc, T), f32(rng, S, Dm, T)
+    DO, X, W, RS = be.dev(dout), be.dev(x), be.dev(w0), be.zeros((S, Dm))
+    ds, st = [], 0
+    for s, n in enumerate(counts):
+        d = mk(be, Dm, T, n * Cc, DO, D(1), D(Dm, div=Cc, so=(Cc + 1) * Dm), X, D(T), D(1), W, D(T), D(1), accumulate=1, split_k=splits[s],
+               rowsum_a=be.ptr(RS) + 4 * s * Dm)
+        d.A, d.B, d.C = be.ptr(DO) + 4 * (st * (Cc + 1) * Dm + Dm), be.ptr(X) + 4 * st * Cc * T, be.ptr(W) + 4 * s * Dm * T
+        ds.append(d)
+        st += n
+    _grouped(be, ds)
+    st = 0
+    for s, n in enumerate(counts):
+        g = dout[st:st + n, 1:, :].reshape(-1, Dm).astype(np.float64)
+        np.testing.assert_allclose(be.host(W)[s], w0[s] + g.T @ x[st:st + n].reshape(-1, T), atol=2e-4)
+        np.testing.assert_allclose(be.host(RS)[s], g.sum(0), atol=2e-4)
+        st += n
+
+
+def test_grouped_gemm_mixed_members_and_errors(be):
+    """members that do not share a kernel instantiation (different N / layouts) still give the n-launch result; bad members are rejected
+    before anything is launched"""
+    rng = np.random.default_rng(3)
+    a1, b1, a2, b2 = f32(rng, 40, 30), f32(rng, 30, 20), f32(rng, 16, 66), f32(rng, 10, 16)
+    A1, B1, A2, B2, C1, C2 = be.dev(a1), be.dev(b1), be.dev(a2), be.dev(b2), be.zeros((40, 20)), be.zeros((66, 10))
+    d1 = mk(be, 40, 20, 30, A1, D(30), D(1), B1, D(20), D(1), C1, D(20), D(1))
+    d2 = mk(be, 66, 10, 16, A2, D(1), D(66), B2, D(1), D(16), C2, D(10), D(1))
+    _grouped(be, [d1, d2])
+    np.testing.assert_allclose(be.host(C1), a1.astype(np.float64) @ b1, atol=1e-4)
+    np.testing.assert_allclose(be.host(C2), a2.T.astype(np.float64) @ b2.T, atol=1e-4)
+    _grouped(be, [d1, d2], n=0)                                       # nothing to do
+    bad = mk(be, 40, 20, 30, A1, D(30), D(1), B1, D(20), D(1), C1, D(20), D(1), split_k=0)
+    arr = (_abi.GemmDesc * 2)(d1, bad)
+    assert be.lib.eegclip_gemm_f32_grouped(arr, 2, be.stream) < 0
+    assert be.lib.eegclip_gemm_f32_grouped(None, 2, be.stream) < 0
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0
