@@ -12,6 +12,7 @@ scheduler pieces the reference takes from diffusers==0.30.0 (restated: diffusers
   independent chain; with a seeded CPU generator it reproduces the reference's noise stream exactly.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -390,15 +391,21 @@ class DDPMScheduler:
         var = max(bp / bt * cb, 1e-20)
         return acp_t ** 0.5, bt ** 0.5, (acp_prev ** 0.5 * cb) / bt, ca ** 0.5 * bp / bt, (var ** 0.5 if t > 0 else 0.0)
 
-    def step(self, model_output, timestep, sample, generator=None, return_dict=True, model_output_uncond=None, guidance_scale=0.0):
-        """x_t -> x_{t-1}.  `model_output_uncond` (+ guidance_scale) fuses the classifier-free-guidance mix into the same kernel."""
+    def draw_noise(self, shape, device, generator=None):
+        """the variance noise of one step, drawn exactly like step() draws it (Pipe.generate pre-draws the whole chain in step order)"""
+        gdev = generator.device if generator is not None else device
+        return torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, model_output_uncond=None, guidance_scale=0.0, noise=None):
+        """x_t -> x_{t-1}.  `model_output_uncond` (+ guidance_scale) fuses the classifier-free-guidance mix into the same kernel.
+        `noise`: the step's variance noise if the caller has drawn it already (ignored at t = 0, like the generator)."""
         t = int(timestep)
         sa, sb, c0, ct, sigma = self.step_coeffs(t)
         x = sample.contiguous()
-        noise = None
-        if t > 0:
-            gdev = generator.device if generator is not None else x.device
-            noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32).to(x.device)
+        if t == 0:
+            noise = None
+        elif noise is None:
+            noise = self.draw_noise(x.shape, x.device, generator)
         out = torch.empty_like(x)
         eu = model_output_uncond
         check(lib().eegclip_ddpm_step(x.data_ptr(), model_output.contiguous().data_ptr(), eu.contiguous().data_ptr() if eu is not None else None,
@@ -483,16 +490,54 @@ class Pipe:
             c_embeds = c_embeds.to(self.device).float().contiguous()
         gdev = generator.device if generator is not None else self.device
         h_t = torch.randn(N, prior.embed_dim, generator=generator, device=gdev).to(self.device)
+        steps = timesteps.tolist()                                         # host-side schedule: no device->host sync in the loop
+        # the chain's variance noise, drawn up front in step order (the same generator calls, in the same order, as drawing inside step())
+        noise = [self.scheduler.draw_noise(h_t.shape, h_t.device, generator) for t in steps if t > 0]
+        noise = torch.stack(noise) if noise else torch.zeros(0, *h_t.shape, device=h_t.device)
         eng = prior._engine()
+        use_cfg = not (guidance_scale == 0 or c_embeds is None)
+        graphs = h_t.is_cuda and os.environ.get("EEGCLIP_PRIOR_GRAPH", "1") != "0"
         with torch.no_grad():
-            for t in timesteps.tolist():                                   # host-side schedule: no device->host sync in the loop
-                tt = torch.full((N,), float(t), dtype=torch.float32, device=self.device)
-                if guidance_scale == 0 or c_embeds is None:
-                    eps = eng.forward(h_t, tt, None, 0.0)
-                    h_t = self.scheduler.step(eps, t, h_t, generator=generator).prev_sample
-                else:
-                    # conditional and unconditional prediction (diffusion_prior.py:362-367) as ONE pass over 2N rows: half the launches of a
-                    # loop that is launch-bound at these sizes
-                    eps = eng.forward(torch.cat([h_t, h_t]), torch.cat([tt, tt]), c_embeds, 0.0, cond_rows=N)
-                    h_t = self.scheduler.step(eps[:N], t, h_t, generator=generator, model_output_uncond=eps[N:], guidance_scale=guidance_scale).prev_sample
+            if not graphs:
+                return self._chain(eng, h_t, c_embeds if use_cfg else None, noise, steps, guidance_scale)
+            # The loop is launch-bound (about 50 small launches per DDPM step, 16 us of host time each, for 0.2 ms of GPU work): the WHOLE chain
+            # is captured once into a HIP graph over static buffers (start latent, condition, noise) and replayed with one launch.  Weights are
+            # read through the flat parameter buffer at replay time, so a trained / reloaded prior needs no re-capture.
+            key = (N, tuple(steps), float(guidance_scale), use_cfg, id(eng), eng.flat.data_ptr())
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            g = self._graphs.get(key)
+            if g is None:
+                if len(self._graphs) >= 8:
+                    self._graphs.clear()
+                st = dict(h0=torch.empty_like(h_t), noise=torch.empty_like(noise), c=torch.empty_like(c_embeds) if use_cfg else None)
+                self._chain(eng, h_t, c_embeds if use_cfg else None, noise[:1], steps[-2:] if len(steps) > 1 else steps, guidance_scale)   # builds the plans
+                torch.cuda.synchronize()
+                st["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st["graph"]):
+                    st["out"] = self._chain(eng, st["h0"], st["c"], st["noise"], steps, guidance_scale)
+                g = self._graphs[key] = st
+            g["h0"].copy_(h_t)
+            g["noise"].copy_(noise)
+            if use_cfg:
+                g["c"].copy_(c_embeds)
+            g["graph"].replay()
+            return g["out"].clone()
+
+    def _chain(self, eng, h_t, c_embeds, noise, steps, guidance_scale):
+        """the DDPM ancestral chain (diffusion_prior.py:358-377) from latent h_t; c_embeds None = no classifier-free guidance"""
+        N = h_t.shape[0]
+        j = 0
+        for t in steps:
+            tt = torch.full((N,), float(t), dtype=torch.float32, device=h_t.device)
+            nz = None
+            if t > 0:
+                nz, j = noise[j], j + 1
+            if c_embeds is None:
+                eps = eng.forward(h_t, tt, None, 0.0)
+                h_t = self.scheduler.step(eps, t, h_t, noise=nz).prev_sample
+            else:
+                # conditional and unconditional prediction (diffusion_prior.py:362-367) as ONE pass over 2N rows
+                eps = eng.forward(torch.cat([h_t, h_t]), torch.cat([tt, tt]), c_embeds, 0.0, cond_rows=N)
+                h_t = self.scheduler.step(eps[:N], t, h_t, noise=nz, model_output_uncond=eps[N:], guidance_scale=guidance_scale).prev_sample
         return h_t

@@ -155,3 +155,26 @@ def test_generate_matches_reference_fixture_and_batches_are_independent(golden):
     finally:
         pp.torch.randn = real_randn
     np.testing.assert_allclose(hb.cpu().numpy(), torch.cat(outs).cpu().numpy(), atol=2e-4)
+
+
+def test_generate_graph_replay_equals_eager_chain(monkeypatch):
+    """Pipe.generate replays the whole DDPM chain from one captured HIP graph; the launch-by-launch path (EEGCLIP_PRIOR_GRAPH=0) must give
+    the same latents, a replay must follow new inputs (condition, start latent, noise) and new WEIGHTS without re-capture."""
+    from eeg_image_decode_amd.prior import Pipe
+    m, _ = make_prior()
+    _, cc, _, _ = _train_inputs()
+    pipe = Pipe(m, device="cuda")
+    run = lambda c, seed: pipe.generate(c_embeds=c, num_inference_steps=12, guidance_scale=5.0, generator=torch.Generator().manual_seed(seed))
+    a1, a2 = run(cc[:4], 1), run(cc[4:8], 2)                   # capture + replay, then replay with other inputs
+    assert len(pipe._graphs) == 1
+    with torch.no_grad():
+        m.output_layer.bias.add_(0.25)                          # parameters live in the flat buffer the graph reads
+    a3 = run(cc[:4], 1)
+    monkeypatch.setenv("EEGCLIP_PRIOR_GRAPH", "0")
+    e3 = run(cc[:4], 1)
+    with torch.no_grad():
+        m.output_layer.bias.sub_(0.25)
+    e1, e2 = run(cc[:4], 1), run(cc[4:8], 2)
+    for a, e in ((a1, e1), (a2, e2), (a3, e3)):
+        np.testing.assert_allclose(a.cpu().numpy(), e.cpu().numpy(), atol=1e-5)
+    assert float((a1 - a3).abs().max()) > 1e-3 and float((a1 - a2).abs().max()) > 1e-3
