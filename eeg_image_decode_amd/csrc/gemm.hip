@@ -36,6 +36,29 @@ __device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
 //   split-K slices: atomicAdd of alpha*acc (+ bias on slice 0)
 //   plain stride C, nothing but (bias_n, accumulate): pointer-bump stores
 //   everything else: the general form
+// the general form for one output element: v = alpha * acc on entry
+template <bool PLAIN>
+__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, bool first_slice, float keep_scale) {
+    if (first_slice) {
+        if (d.bias_n) v += d.bias_n[n];
+        if (d.bias_m) v += d.bias_m[m];
+    }
+    const long long coff = goff<PLAIN>(d.Cm, m) + goff<PLAIN>(d.Cn, n);
+    if (d.split_k > 1) {
+        atomicAdd(d.C + coff, v);
+        return;
+    }
+    if (d.Cpre) d.Cpre[coff] = v;
+    if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
+    else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
+    if (d.drop_p > 0.f)
+        v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
+    if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)]);
+    else if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
+    if (d.accumulate) v += d.C[coff];
+    d.C[coff] = v;
+}
+
 template <bool PLAIN>
 __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const f32x4 (&acc)[2][2], int m0, int n0, int wr, int wc,
                                               int lane, bool first_slice) {
@@ -74,25 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
             for (int r = 0; r < 4; ++r) {
                 const int m = mb + mt * 16 + r;
                 if (m >= d.M || n >= d.N) continue;
-                float v = d.alpha * acc[mt][nt][r];
-                if (first_slice) {
-                    if (d.bias_n) v += d.bias_n[n];
-                    if (d.bias_m) v += d.bias_m[m];
-                }
-                const long long coff = goff<PLAIN>(d.Cm, m) + goff<PLAIN>(d.Cn, n);
-                if (nsplit > 1) {
-                    atomicAdd(d.C + coff, v);
-                    continue;
-                }
-                if (d.Cpre) d.Cpre[coff] = v;
-                if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
-                else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
-                if (d.drop_p > 0.f)
-                    v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
-                if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)]);
-                else if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
-                if (d.accumulate) v += d.C[coff];
-                d.C[coff] = v;
+                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, first_slice, keep_scale);
             }
         }
     }
@@ -452,6 +457,68 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_grouped_kernel(const eegcl
     gemm_f32_fast_body<A_KC, B_KC, C_PLAIN, K2>(d, gx, ntiles, (ntiles + 7) / 8, b - tb.first[gi]);
 }
 
+// =================================================================================================================================
+// skinny kernel: M <= 32 rows against a k-contiguous weight matrix (the diffusion prior's sampling chain, Generation/diffusion_prior.py:
+// 340-378: 16 rows -- 8 embeddings x the classifier-free-guidance pair -- through ~34 Linear layers per DDPM step, 50 steps).  With
+// 64 x 64 tiles such a GEMM is at most 16 workgroups walking K = 1024 in 32 dependent k-tiles: 22 us each, 87 % of the chain
+// (rocprofv3), on a chip that could stream the 4 MB of weights in a microsecond.  Here one workgroup owns 16 output columns and its
+// 16 waves split K into interleaved 32-element chunks; each lane feeds the MFMA straight from two 16-byte global loads (lane (n, g)
+// holds W[n][k + 4g .. 4g+3], the A lane X[m][same k]: MFMA step e contracts k + 4g + e over the four lane groups), no LDS staging.
+// The 16 partial tiles are summed through LDS and one wave per 16-row block runs the general epilogue.
+constexpr int SK_WAVES = 16;
+constexpr int SK_N = 16;
+
+template <int MB>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_f32_skinny_kernel(const eegclip_gemm_desc d) {
+    EEG_LDS_BASE(float, lds);                                   // [wave][MB][lane] float4 partial accumulators
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * SK_N;
+    const int nrow = n0 + fr < d.N ? n0 + fr : d.N - 1;         // clamped rows: their products land in columns / rows nobody stores
+    const float* bp = d.B + (long long)nrow * d.Bn.si + 4 * g;
+    const float* ap[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = 16 * i + fr < d.M ? 16 * i + fr : d.M - 1;
+        ap[i] = d.A + (long long)m * d.Am.si + 4 * g;
+    }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = wave * 32; k0 < d.K; k0 += SK_WAVES * 32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + 16 * h;
+            const bool ok = k + 4 * g < d.K;                    // K % 4 == 0: a lane's four k are in range together
+            const int kk = ok ? k : 0;
+            f32x4 bv = *reinterpret_cast<const f32x4*>(bp + kk);
+            bv = ok ? bv : zero;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                f32x4 av = *reinterpret_cast<const f32x4*>(ap[i] + kk);
+                av = ok ? av : zero;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = mfma_f32_16x16x4(av[e], bv[e], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(lds + ((wave * MB + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    if (wave >= MB) return;
+    f32x4 sum = zero;                                           // wave i finishes 16-row block i
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) sum += *reinterpret_cast<const f32x4*>(lds + ((w * MB + wave) * 64 + lane) * 4);
+    const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    const int n = n0 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * wave + 4 * g + r;
+        if (m < d.M && n < d.N) gemm_epilogue_element<true>(d, d.alpha * sum[r], m, n, true, keep_scale);
+    }
+}
+
 static inline bool is_plain(const eegclip_dim& x) { return x.div > (1LL << 40); }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
@@ -542,7 +609,21 @@ static int launch_gemm_grouped(const eegclip_gemm_desc* ds, int n, void* stream)
     return (int)hipGetLastError();
 }
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
+    static const bool allow_skinny = !(getenv("EEGCLIP_GEMM_SKINNY") && atoi(getenv("EEGCLIP_GEMM_SKINNY")) == 0);   // tuning aid
+    // skinny: few rows against k-contiguous operands, every map a plain stride, 16-byte loads legal, K long enough for the 16-way split
+    if (allow_skinny && d.M <= 32 && d.split_k == 1 && d.K >= 64 && (d.K & 3) == 0 && is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) &&
+        is_plain(d.Bn) && is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn))) && d.Ak.si == 1 && d.Bk.si == 1 &&
+        d.Am.si >= 0 && d.Bn.si >= 0 && (d.Am.si & 3) == 0 && (d.Bn.si & 3) == 0 && aligned16(d.A) && aligned16(d.B)) {
+        static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "eegclip_gemm_f32: skinny %dx%dx%d\n", d.M, d.N, d.K);
+        const dim3 grid((d.N + SK_N - 1) / SK_N), block(SK_WAVES * 64);
+        if (d.M <= 16) EEG_LAUNCH((gemm_f32_skinny_kernel<1>), grid, block, SK_WAVES * 1 * 64 * 4 * sizeof(float), stream, d);
+        else           EEG_LAUNCH((gemm_f32_skinny_kernel<2>), grid, block, SK_WAVES * 2 * 64 * 4 * sizeof(float), stream, d);
+        return (int)hipGetLastError();
+    }
     const int gx = (d.N + G_BT - 1) / G_BT, gy = (d.M + G_BT - 1) / G_BT;
     const dim3 block(G_THREADS);
     const bool ab_plain = is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) && is_plain(d.Bn);

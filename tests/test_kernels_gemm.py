@@ -287,6 +287,28 @@ def test_grouped_gemm_mixed_members_and_errors(be):
     assert be.lib.eegclip_gemm_f32_grouped(None, 2, be.stream) < 0
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (8, 1024, 1024), (16, 1000, 512), (17, 70, 68), (32, 512, 1000), (16, 5, 2048)])
+def test_gemm_skinny_rows_kernel(be, M, N, K):
+    """M <= 32 against k-contiguous weights (the prior's sampling chain, diffusion_prior.py:340-378): the 16-wave split-K-in-workgroup kernel,
+    plain and with every epilogue stage (bias, SiLU, dropout, residual, accumulate, Cpre)"""
+    rng = np.random.default_rng(M * 7 + N + K)
+    a, w, bn, r, c0 = f32(rng, M, K), f32(rng, N, K), f32(rng, N), f32(rng, M, N), f32(rng, M, N)
+    A, W, BN, R = be.dev(a), be.dev(w), be.dev(bn), be.dev(r)
+    ref = a.astype(np.float64) @ w.T.astype(np.float64)
+    C = be.dev(np.full((M, N), np.nan, np.float32))
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1), alpha=0.5))
+    np.testing.assert_allclose(be.host(C), 0.5 * ref, atol=3e-5 * max(1, np.abs(ref).max()))
+    C, CP = be.dev(c0), be.zeros((M, N))
+    p = 0.25
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1), bias_n=be.ptr(BN), act=_abi.ACT_SILU, R=be.ptr(R), Rm=D(N), Rn=D(1),
+               accumulate=1, Cpre=be.ptr(CP), drop_p=p, seed=77, drop_site=3))
+    pre = ref + bn
+    keep = keep_mask(77, 3, M * N, p).reshape(M, N)
+    want = pre / (1 + np.exp(-pre)) * keep / (1 - p) + r + c0
+    np.testing.assert_allclose(be.host(CP), pre, atol=3e-5 * max(1, np.abs(ref).max()))
+    np.testing.assert_allclose(be.host(C), want, atol=5e-5 * max(1, np.abs(ref).max()))
+
+
 def test_gemm_rejects_bad_arguments(be):
     L = be.lib
     assert L.eegclip_gemm_f32(None, be.stream) < 0

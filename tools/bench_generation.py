@@ -52,7 +52,26 @@ def prior_sample(pipe, n=8, steps=50):
     for _ in range(reps):
         pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
     torch.cuda.synchronize()
-    return {"embeddings": n, "ddpm_steps": steps, "cfg": True, "ms_per_chain": round(1e3 * (time.perf_counter() - t0) / reps, 2)}
+    graph_ms = 1e3 * (time.perf_counter() - t0) / reps
+    os.environ["EEGCLIP_PRIOR_GRAPH"] = "0"                        # the launch-by-launch chain, for comparison
+    pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    eager_ms = 1e3 * (time.perf_counter() - t0) / reps
+    del os.environ["EEGCLIP_PRIOR_GRAPH"]
+    # the replay alone (inputs already staged): GPU time of the captured chain
+    g = next(iter(pipe._graphs.values()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g["graph"].replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return {"embeddings": n, "ddpm_steps": steps, "cfg": True, "ms_per_chain": round(graph_ms, 2), "ms_per_chain_launch_by_launch": round(eager_ms, 2),
+            "ms_graph_replay_only": round(e0.elapsed_time(e1) / reps, 2)}
 
 
 def cross_attn(images=8):
