@@ -53,6 +53,56 @@ __global__ __launch_bounds__(256) void layernorm_silu_fwd_kernel(const float* __
     }
 }
 
+// Inference form of a prior stage's tail for the sampling chain (Generation/diffusion_prior.py:186-199 inside :358-377).  Every row of a
+// sampling batch shares the timestep and the condition never changes along the chain, so the time / condition embeddings of all stages are
+// computed once per chain; what is left per stage and DDPM step is
+//     y = SiLU(LayerNorm(x)) (+ skip)                 -> act_out   (kept for the decoder's skip additions and the output layer)
+//     y + te[c] + (row < ce_rows ? ce[row][c] : 0)    -> xin_out   (the next stage's input: x + time embedding + condition embedding)
+// in one launch instead of LayerNorm-SiLU, two time-embedding GEMMs, a condition GEMM and the skip axpby.
+__global__ __launch_bounds__(256) void prior_stage_infer_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ skip,
+                                                                 float* __restrict__ act_out, const float* __restrict__ te,
+                                                                 const float* __restrict__ ce, int ce_rows, float* __restrict__ xin_out, int rows,
+                                                                 int cols, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (long long)row * cols;
+        float v[LNS_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? xr[c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = c < cols ? v[i] - mean : 0.f;
+            q += dlt * dlt;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) {
+                const long long idx = (long long)row * cols + c;
+                float a = silu((v[i] - mean) * rstd * gamma[c] + beta[c]);
+                if (skip) a += skip[idx];
+                if (act_out) act_out[idx] = a;
+                if (xin_out) {
+                    float w = a + te[c];
+                    if (row < ce_rows) w += ce[idx];
+                    xin_out[idx] = w;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx,
                                                         long long n, int accumulate, float drop_p, unsigned long long seed, unsigned site) {
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -88,7 +138,8 @@ __global__ __launch_bounds__(256) void ddpm_add_noise_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
                                                          const float* __restrict__ eps_u, float g, float sa, float sb, float c0, float ct,
-                                                         float sigma, const float* __restrict__ noise, float* __restrict__ out, long long n) {
+                                                         float sigma, const float* __restrict__ noise, float* __restrict__ out, float* __restrict__ out_dup,
+                                                         long long n) {
     const float inv_sa = 1.0f / sa;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float e = eps_c[i];
@@ -99,6 +150,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
         float v = c0 * x0 + ct * xi;
         if (noise && sigma != 0.f) v += sigma * noise[i];
         out[i] = v;
+        if (out_dup) out_dup[i] = v;                    // second copy: the conditional / unconditional halves of the next step's 2N-row input
     }
 }
 
@@ -139,6 +191,17 @@ extern "C" int eegclip_layernorm_silu_fwd(const float* x, const float* gamma, co
     return (int)hipGetLastError();
 }
 
+extern "C" int eegclip_prior_stage_infer(const float* x, const float* gamma, const float* beta, const float* skip, float* act_out, const float* te,
+                                         const float* ce, int ce_rows, float* xin_out, int rows, int cols, float eps, void* stream) {
+    if (!x || !gamma || !beta || rows < 0 || cols < 1 || cols > 64 * LNS_MAXC || (!act_out && !xin_out)) return EEGCLIP_EINVAL;
+    if (xin_out && (!te || ce_rows < 0 || (ce_rows > 0 && !ce))) return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    EEG_LAUNCH(prior_stage_infer_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, skip, act_out, te, ce, ce_rows, xin_out, rows, cols, eps);
+    return (int)hipGetLastError();
+}
+
 extern "C" int eegclip_silu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
                                 unsigned long long seed, unsigned site, void* stream) {
     if (!dy || !pre || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
@@ -161,9 +224,9 @@ extern "C" int eegclip_ddpm_add_noise(const float* h, const float* noise, const 
 }
 
 extern "C" int eegclip_ddpm_step(const float* x, const float* eps_c, const float* eps_u, float guidance, float sa, float sb, float c0, float ct,
-                                 float sigma, const float* noise, float* out, long long n, void* stream) {
+                                 float sigma, const float* noise, float* out, float* out_dup, long long n, void* stream) {
     if (!x || !eps_c || !out || n < 1 || sa == 0.f) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(ddpm_step_kernel, dim3(pgrid(n)), dim3(256), 0, stream, x, eps_c, eps_u, guidance, sa, sb, c0, ct, sigma, noise, out, n);
+    EEG_LAUNCH(ddpm_step_kernel, dim3(pgrid(n)), dim3(256), 0, stream, x, eps_c, eps_u, guidance, sa, sb, c0, ct, sigma, noise, out, out_dup, n);
     return (int)hipGetLastError();
 }
 

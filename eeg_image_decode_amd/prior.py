@@ -210,6 +210,65 @@ class _PriorEngine:
         pl.gemm(N, E, h0, _p(b[cur]), D(h0), D(1), _p(P["output_layer.weight"]), D(1), D(h0), _p(b["out"]), D(E), D(1), bias_n=_p(P["output_layer.bias"]))
         return pl
 
+    # ---- sampling chain (Pipe.generate): chain-invariant embeddings hoisted, 20 launches per DDPM step ---------------------------------
+    def sampling(self, N, S, cond_rows):
+        """Plans + buffers for a sampling chain of S steps over N rows (2 x embeddings under classifier-free guidance), the first cond_rows of
+        them conditioned.  In Pipe.generate every row shares the timestep and the condition is fixed, so
+          * hoist plan (once per chain): time embeddings of all S timesteps for all 8 stages, TE_s (S, h_s), and the condition embeddings
+            CE_s (cond_rows, h_s)  -- diffusion_prior.py:188-189,196-197 for every t of the schedule at once;
+          * step plan (per DDPM step j): input Linear, then per stage ONE skinny GEMM + ONE eegclip_prior_stage_infer (LayerNorm, SiLU, skip
+            add, + TE_s[j] + CE_s for the next stage), output Linear.
+        The reference evaluates 2 x 34 Linear layers + 18 small elementwise ops per step (diffusion_prior.py:362-367)."""
+        key = ("s", N, S, cond_rows)
+        if key in self.plans:
+            return self.plans[key]
+        P, m, dev = self.P, self.model, self.device
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        E, Td, Cd, h0 = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0]
+        b = dict(ts=f(S), temb=f(S, Td), x=f(N, E), linI=f(N, h0), actI=f(N, h0), out=f(N, E), c=f(max(cond_rows, 1), Cd))
+        for s, st in enumerate(self.stages):
+            hi, ho = st["hin"], st["hout"]
+            b.update({f"t1{s}": f(S, hi), f"te{s}": f(S, hi), f"ce{s}": f(max(cond_rows, 1), hi), f"xin{s}": f(N, hi), f"lin{s}": f(N, ho), f"act{s}": f(N, ho)})
+        hoist = Plan(f"prior_hoist[S={S}]")
+        hoist.call("eegclip_timestep_embedding", _p(b["ts"]), S, Td, _p(b["temb"]))
+        for s, st in enumerate(self.stages):
+            hi = st["hin"]
+            hoist.gemm(S, hi, Td, _p(b["temb"]), D(Td), D(1), _p(P[st["t"] + "linear_1.weight"]), D(1), D(Td), _p(b[f"t1{s}"]), D(hi), D(1),
+                       bias_n=_p(P[st["t"] + "linear_1.bias"]), act=ACT_SILU)
+            hoist.gemm(S, hi, hi, _p(b[f"t1{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(1), D(hi), _p(b[f"te{s}"]), D(hi), D(1),
+                       bias_n=_p(P[st["t"] + "linear_2.bias"]))
+            if cond_rows:
+                hoist.gemm(cond_rows, hi, Cd, _p(b["c"]), D(Cd), D(1), _p(P[st["c"] + "weight"]), D(1), D(Cd), _p(b[f"ce{s}"]), D(hi), D(1),
+                           bias_n=_p(P[st["c"] + "bias"]))
+        step = Plan(f"prior_step[N={N}]")
+        step.te_slots = []                   # (op index, stage, width): argument 5 of these ops is TE_stage + j * width floats
+        n_st, n_enc = len(self.stages), m.num_layers - 1
+
+        def finish(lin, gamma, beta, skip, act, nxt, rows_h):
+            idx = len(step.ops)
+            if nxt is None:
+                step.call("eegclip_prior_stage_infer", lin, gamma, beta, skip, act, None, None, 0, None, N, rows_h, 1e-5)
+            else:
+                step.call("eegclip_prior_stage_infer", lin, gamma, beta, skip, act, _p(b[f"te{nxt}"]), _p(b[f"ce{nxt}"]) if cond_rows else None,
+                          cond_rows, _p(b[f"xin{nxt}"]), N, rows_h, 1e-5)
+                step.te_slots.append((idx, nxt, self.stages[nxt]["hin"]))
+
+        step.gemm(N, h0, E, _p(b["x"]), D(E), D(1), _p(P["input_layer.0.weight"]), D(1), D(E), _p(b["linI"]), D(h0), D(1), bias_n=_p(P["input_layer.0.bias"]))
+        finish(_p(b["linI"]), _p(P["input_layer.1.weight"]), _p(P["input_layer.1.bias"]), None, _p(b["actI"]), 0, h0)
+        cur, skips = "actI", []
+        for s, st in enumerate(self.stages):
+            hi, ho = st["hin"], st["hout"]
+            if st["dec"] is None:
+                skips.append(cur)
+            step.gemm(N, ho, hi, _p(b[f"xin{s}"]), D(hi), D(1), _p(P[st["l"] + "0.weight"]), D(1), D(hi), _p(b[f"lin{s}"]), D(ho), D(1),
+                      bias_n=_p(P[st["l"] + "0.bias"]))
+            skip = _p(b[skips[n_enc - 1 - st["dec"]]]) if st["dec"] is not None else None          # x += hidden_activations[-1-j]
+            finish(_p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(P[st["l"] + "1.bias"]), skip, _p(b[f"act{s}"]), s + 1 if s + 1 < n_st else None, ho)
+            cur = f"act{s}"
+        step.gemm(N, E, h0, _p(b[cur]), D(h0), D(1), _p(P["output_layer.weight"]), D(1), D(h0), _p(b["out"]), D(E), D(1), bias_n=_p(P["output_layer.bias"]))
+        self.plans[key] = (hoist, step, b)
+        return self.plans[key]
+
     def _build_bwd(self, N, cond, p):
         P, G, b, m = self.P, self.G, self.bufs[N], self.model
         pl = Plan(f"prior_bwd[N={N}]")
@@ -396,9 +455,11 @@ class DDPMScheduler:
         gdev = generator.device if generator is not None else device
         return torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32).to(device)
 
-    def step(self, model_output, timestep, sample, generator=None, return_dict=True, model_output_uncond=None, guidance_scale=0.0, noise=None):
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, model_output_uncond=None, guidance_scale=0.0, noise=None,
+             out=None, out_dup=None):
         """x_t -> x_{t-1}.  `model_output_uncond` (+ guidance_scale) fuses the classifier-free-guidance mix into the same kernel.
-        `noise`: the step's variance noise if the caller has drawn it already (ignored at t = 0, like the generator)."""
+        `noise`: the step's variance noise if the caller has drawn it already (ignored at t = 0, like the generator); `out` / `out_dup`:
+        where to write x_{t-1} (out may be `sample` itself) and an optional second copy."""
         t = int(timestep)
         sa, sb, c0, ct, sigma = self.step_coeffs(t)
         x = sample.contiguous()
@@ -406,11 +467,12 @@ class DDPMScheduler:
             noise = None
         elif noise is None:
             noise = self.draw_noise(x.shape, x.device, generator)
-        out = torch.empty_like(x)
+        out = torch.empty_like(x) if out is None else out
         eu = model_output_uncond
         check(lib().eegclip_ddpm_step(x.data_ptr(), model_output.contiguous().data_ptr(), eu.contiguous().data_ptr() if eu is not None else None,
                                       float(guidance_scale), sa, sb, c0, ct, sigma, noise.data_ptr() if noise is not None else None, out.data_ptr(),
-                                      x.numel(), torch.cuda.current_stream().cuda_stream), "ddpm_step")
+                                      out_dup.data_ptr() if out_dup is not None else None, x.numel(), torch.cuda.current_stream().cuda_stream),
+              "ddpm_step")
         return self._Out(out)
 
 
@@ -497,12 +559,14 @@ class Pipe:
         eng = prior._engine()
         use_cfg = not (guidance_scale == 0 or c_embeds is None)
         graphs = h_t.is_cuda and os.environ.get("EEGCLIP_PRIOR_GRAPH", "1") != "0"
+        # the schedule's timesteps feed the hoisted time embeddings (read at run / replay time: uploaded before either)
+        eng.sampling(2 * N if use_cfg else N, len(steps), N if use_cfg else 0)[2]["ts"].copy_(torch.tensor(steps, dtype=torch.float32))
         with torch.no_grad():
             if not graphs:
                 return self._chain(eng, h_t, c_embeds if use_cfg else None, noise, steps, guidance_scale)
-            # The loop is launch-bound (about 50 small launches per DDPM step, 16 us of host time each, for 0.2 ms of GPU work): the WHOLE chain
-            # is captured once into a HIP graph over static buffers (start latent, condition, noise) and replayed with one launch.  Weights are
-            # read through the flat parameter buffer at replay time, so a trained / reloaded prior needs no re-capture.
+            # 20 small dependent launches per DDPM step: the WHOLE chain (hoisted embeddings + every step) is captured once into a HIP graph over
+            # static buffers (start latent, condition, noise, timesteps) and replayed with one launch, so the host never paces the chain.
+            # Weights are read through the flat parameter buffer at replay time: a trained / reloaded prior needs no re-capture.
             key = (N, tuple(steps), float(guidance_scale), use_cfg, id(eng), eng.flat.data_ptr())
             if not hasattr(self, "_graphs"):
                 self._graphs = {}
@@ -511,7 +575,7 @@ class Pipe:
                 if len(self._graphs) >= 8:
                     self._graphs.clear()
                 st = dict(h0=torch.empty_like(h_t), noise=torch.empty_like(noise), c=torch.empty_like(c_embeds) if use_cfg else None)
-                self._chain(eng, h_t, c_embeds if use_cfg else None, noise[:1], steps[-2:] if len(steps) > 1 else steps, guidance_scale)   # builds the plans
+                self._chain(eng, h_t, c_embeds if use_cfg else None, noise, steps, guidance_scale)      # launch by launch once: builds the plans
                 torch.cuda.synchronize()
                 st["graph"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(st["graph"]):
@@ -525,19 +589,29 @@ class Pipe:
             return g["out"].clone()
 
     def _chain(self, eng, h_t, c_embeds, noise, steps, guidance_scale):
-        """the DDPM ancestral chain (diffusion_prior.py:358-377) from latent h_t; c_embeds None = no classifier-free guidance"""
-        N = h_t.shape[0]
+        """the DDPM ancestral chain (diffusion_prior.py:358-377) from latent h_t; c_embeds None = no classifier-free guidance.  Both
+        predictions of a guided step are ONE pass over 2N rows (rows < N conditioned); see _PriorEngine.sampling for what is hoisted."""
+        N, S = h_t.shape[0], len(steps)
+        cfg = c_embeds is not None
+        rows = 2 * N if cfg else N
+        hoist, step, b = eng.sampling(rows, S, N if cfg else 0)
+        stream = torch.cuda.current_stream().cuda_stream
+        if cfg:
+            b["c"].copy_(c_embeds)
+        hoist.run(stream)
+        x = b["x"]
+        x[:N].copy_(h_t)
+        if cfg:
+            x[N:].copy_(h_t)
         j = 0
-        for t in steps:
-            tt = torch.full((N,), float(t), dtype=torch.float32, device=h_t.device)
+        for i, t in enumerate(steps):
+            for idx, st, width in step.te_slots:
+                step.ops[idx][1][5] = b[f"te{st}"].data_ptr() + 4 * width * i
+            step.run(stream)
             nz = None
             if t > 0:
                 nz, j = noise[j], j + 1
-            if c_embeds is None:
-                eps = eng.forward(h_t, tt, None, 0.0)
-                h_t = self.scheduler.step(eps, t, h_t, noise=nz).prev_sample
-            else:
-                # conditional and unconditional prediction (diffusion_prior.py:362-367) as ONE pass over 2N rows
-                eps = eng.forward(torch.cat([h_t, h_t]), torch.cat([tt, tt]), c_embeds, 0.0, cond_rows=N)
-                h_t = self.scheduler.step(eps[:N], t, h_t, noise=nz, model_output_uncond=eps[N:], guidance_scale=guidance_scale).prev_sample
-        return h_t
+            eps = b["out"]
+            self.scheduler.step(eps[:N], t, x[:N], noise=nz, model_output_uncond=eps[N:] if cfg else None, guidance_scale=guidance_scale if cfg else 0.0,
+                                out=x[:N], out_dup=x[N:] if cfg else None)
+        return x[:N].clone()

@@ -157,13 +157,19 @@ int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, vo
  * timestep_embedding: out[n] = [cos(t_n f_i) | sin(t_n f_i)], f_i = exp(-ln(1e4) i/(dim/2))      (Timesteps(dim, True, 0))
  * ddpm_add_noise:     out = sqrt_acp[t_n]*h + sqrt_1macp[t_n]*noise        (tables: float[1000] on the device)
  * ddpm_step:          eps = eps_u + g*(eps_c-eps_u) (eps_u NULL: eps = eps_c); x0 = clamp((x - sb*eps)/sa, -1, 1);
- *                     out = c0*x0 + ct*x + sigma*noise (noise NULL or sigma 0: none).  out may alias x.
+ *                     out = c0*x0 + ct*x + sigma*noise (noise NULL or sigma 0: none).  out may alias x; out_dup (optional) gets a second copy
+ *                     (the conditional / unconditional halves of the next step's classifier-free-guidance input).
+ * prior_stage_infer:  the tail of a prior stage in the SAMPLING chain (diffusion_prior.py:186-199 inside :358-377), where the time and
+ *                     condition embeddings are chain invariants computed up front:  y = SiLU(LayerNorm(x; gamma, beta, eps)) (+ skip);
+ *                     act_out = y (optional); xin_out = y + te[col] + (row < ce_rows ? ce[row][col] : 0) (optional, the next stage's input).
  * mse_loss_grad:      *loss += mean((pred-target)^2); dpred = 2*(pred-target)/n */
 int eegclip_timestep_embedding(const float* t, int n, int dim, float* out, void* stream);
 int eegclip_ddpm_add_noise(const float* h, const float* noise, const long long* t, const float* sqrt_acp, const float* sqrt_1macp,
                            float* out, int n, int d, void* stream);
 int eegclip_ddpm_step(const float* x, const float* eps_c, const float* eps_u, float guidance, float sa, float sb, float c0, float ct,
-                      float sigma, const float* noise, float* out, long long n, void* stream);
+                      float sigma, const float* noise, float* out, float* out_dup, long long n, void* stream);
+int eegclip_prior_stage_infer(const float* x, const float* gamma, const float* beta, const float* skip, float* act_out, const float* te,
+                              const float* ce, int ce_rows, float* xin_out, int rows, int cols, float eps, void* stream);
 int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream);
 
 /* ---- 64-token multi-head self-attention.  SelfAttention_Family.py:56-75

@@ -334,8 +334,9 @@ def test_timestep_embedding_ddpm_and_mse(be):
     x, ec, eu, noise = rnd(rng, n, d), rnd(rng, n, d), rnd(rng, n, d), rnd(rng, n, d)
     for tstep in (980, 20, 0):
         sa, sb, c0, ct, sg = sch.step_coeffs(tstep)
-        X, EC, EU, NO, O3 = be.dev(x), be.dev(ec), be.dev(eu), be.dev(noise), be.zeros((n, d))
-        ok(be.lib.eegclip_ddpm_step(be.ptr(X), be.ptr(EC), be.ptr(EU), 5.0, sa, sb, c0, ct, sg, be.ptr(NO), be.ptr(O3), n * d, be.stream))
+        X, EC, EU, NO, O3, O4 = be.dev(x), be.dev(ec), be.dev(eu), be.dev(noise), be.zeros((n, d)), be.zeros((n, d))
+        ok(be.lib.eegclip_ddpm_step(be.ptr(X), be.ptr(EC), be.ptr(EU), 5.0, sa, sb, c0, ct, sg, be.ptr(NO), be.ptr(O3), be.ptr(O4), n * d, be.stream))
+        assert np.array_equal(be.host(O3), be.host(O4))               # out_dup: the second half of the next step's 2N-row input
         eps = torch.tensor(eu) + 5.0 * (torch.tensor(ec) - torch.tensor(eu))
         x0 = ((torch.tensor(x) - sb * eps) / sa).clamp(-1, 1)
         ref = c0 * x0 + ct * torch.tensor(x) + sg * torch.tensor(noise)
@@ -351,6 +352,28 @@ def _to16(a, f16):
     t = torch.tensor(a)
     t16 = t.to(torch.float16 if f16 else torch.bfloat16)
     return t16.view(torch.int16).numpy().copy(), t16.float().numpy()
+
+@pytest.mark.parametrize("rows,cols,ce_rows", [(16, 1024, 8), (5, 64, 0), (3, 130, 3)])
+def test_prior_stage_infer(be, rows, cols, ce_rows):
+    """sampling-chain stage tail: SiLU(LayerNorm(x)) (+ skip) -> act_out; + time-embedding row + condition rows -> xin_out"""
+    rng = np.random.default_rng(rows + cols)
+    x, g, b_, sk, te, ce = rnd(rng, rows, cols), rnd(rng, cols), rnd(rng, cols), rnd(rng, rows, cols), rnd(rng, cols), rnd(rng, max(ce_rows, 1), cols)
+    X, G, Bt, SK, TE, CE = be.dev(x), be.dev(g), be.dev(b_), be.dev(sk), be.dev(te), be.dev(ce)
+    xt = torch.tensor(x, dtype=torch.float64)
+    y = F.silu(F.layer_norm(xt, (cols,), torch.tensor(g, dtype=torch.float64), torch.tensor(b_, dtype=torch.float64), 1e-5)).numpy()
+    for use_skip in (False, True):
+        ACT, XIN = be.zeros((rows, cols)), be.zeros((rows, cols))
+        ok(be.lib.eegclip_prior_stage_infer(be.ptr(X), be.ptr(G), be.ptr(Bt), be.ptr(SK) if use_skip else None, be.ptr(ACT), be.ptr(TE),
+                                            be.ptr(CE) if ce_rows else None, ce_rows, be.ptr(XIN), rows, cols, 1e-5, be.stream))
+        a = y + (sk if use_skip else 0)
+        w = a + te
+        w[:ce_rows] += ce[:ce_rows]
+        np.testing.assert_allclose(be.host(ACT), a, atol=2e-5)
+        np.testing.assert_allclose(be.host(XIN), w, atol=2e-5)
+    ACT = be.zeros((rows, cols))
+    ok(be.lib.eegclip_prior_stage_infer(be.ptr(X), be.ptr(G), be.ptr(Bt), None, be.ptr(ACT), None, None, 0, None, rows, cols, 1e-5, be.stream))
+    np.testing.assert_allclose(be.host(ACT), y, atol=2e-5)
+    assert be.lib.eegclip_prior_stage_infer(be.ptr(X), be.ptr(G), be.ptr(Bt), None, None, None, None, 0, None, rows, cols, 1e-5, be.stream) < 0
 
 
 @pytest.mark.parametrize("f16", [False, True])

@@ -239,3 +239,27 @@ def test_clip_loss_gather_modes_match_reference_gloo_fixture(mode, golden):
         assert abs(ret[r][0] - g[tag + "_loss"][r]) < 2e-5
         np.testing.assert_allclose(ret[r][1], g[tag + "_da"][r], atol=3e-6)
         np.testing.assert_allclose(ret[r][2], g[tag + "_db"][r], atol=6e-5)
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_prior_sampling_chain_under_emulator_matches_oracle(guided):
+    """Pipe.generate's restructured chain (time / condition embeddings hoisted out of the DDPM loop, skinny GEMM + fused stage tail per stage,
+    classifier-free-guidance pair as one 2N-row pass) against the oracle's layer-by-layer chain with the same noise stream"""
+    from oracle import prior as oprior
+    state = syn.make_state(SEED + 20, oprior.prior_state_spec())
+    P = oloops.torch_state(state)
+    rng = np.random.default_rng(9)
+    c = T(rng.standard_normal((2, 1024)).astype(np.float32)) if guided else None
+    steps = 4
+    with product_on_emulator():
+        from eeg_image_decode_amd.prior import DiffusionPriorUNet, Pipe
+        m = DiffusionPriorUNet(cond_dim=1024)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        pipe = Pipe(m, device="cpu")
+        h = pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=torch.Generator().manual_seed(3))
+    n = 2 if guided else 1
+    hT = torch.randn(n, 1024, generator=torch.Generator().manual_seed(3))
+    gen = torch.Generator().manual_seed(3)
+    torch.randn(n, 1024, generator=gen)                     # the start latent comes first in the stream
+    ho, _ = oprior.generate(P, oprior.DDPMSchedulerOracle(), c, steps, 5.0, generator=gen, h_T=hT)
+    np.testing.assert_allclose(h.numpy(), ho.numpy(), atol=2e-4)
