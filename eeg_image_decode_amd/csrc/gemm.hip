@@ -486,7 +486,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_f32_skinny_kernel(const ee
 #pragma unroll
     for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = wave * 32; k0 < d.K; k0 += SK_WAVES * 32) {
+    for (int k0 = wave * 32; k0 < d.K; k0 += SK_WAVES * 32) {   // (requesting two chunks before the first MFMA measured slower: 6.3 vs 5.3 us)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + 16 * h;

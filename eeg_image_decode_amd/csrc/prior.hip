@@ -64,41 +64,49 @@ __global__ __launch_bounds__(256) void prior_stage_infer_kernel(const float* __r
                                                                  float* __restrict__ act_out, const float* __restrict__ te,
                                                                  const float* __restrict__ ce, int ce_rows, float* __restrict__ xin_out, int rows,
                                                                  int cols, float eps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float inv = 1.0f / (float)cols;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float* xr = x + (long long)row * cols;
-        float v[LNS_MAXC];
-        float s = 0.f;
+    // one workgroup per row, <= 4 columns per thread: a sampling batch has 16 rows, so a wave-per-row kernel is 16 waves walking 16 dependent
+    // loads each (6.5 us, rocprofv3); here every operand of a row is requested in one round trip before the first reduction
+    EEG_LDS_BASE(float, red);                                   // [0..3] sums, [4..7] squared deviations, one per wave
+    constexpr int PC = LNS_MAXC / 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = blockIdx.x;
+    const long long base = (long long)row * cols;
+    const bool has_ce = xin_out && row < ce_rows;
+    float v[PC], gm[PC], bt[PC], sk[PC], tv[PC], cv[PC];
+    float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LNS_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < cols ? xr[c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) * inv;
-        float q = 0.f;
+    for (int i = 0; i < PC; ++i) {
+        const int c = t + 256 * i;
+        const bool ok = c < cols;
+        v[i] = ok ? x[base + c] : 0.f;
+        gm[i] = ok ? gamma[c] : 0.f;
+        bt[i] = ok ? beta[c] : 0.f;
+        sk[i] = ok && skip ? skip[base + c] : 0.f;
+        tv[i] = ok && xin_out ? te[c] : 0.f;
+        cv[i] = ok && has_ce ? ce[base + c] : 0.f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)cols;
+    float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LNS_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            const float dlt = c < cols ? v[i] - mean : 0.f;
-            q += dlt * dlt;
-        }
-        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+    for (int i = 0; i < PC; ++i) {
+        const float dlt = t + 256 * i < cols ? v[i] - mean : 0.f;
+        q += dlt * dlt;
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)cols + eps);
 #pragma unroll
-        for (int i = 0; i < LNS_MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < cols) {
-                const long long idx = (long long)row * cols + c;
-                float a = silu((v[i] - mean) * rstd * gamma[c] + beta[c]);
-                if (skip) a += skip[idx];
-                if (act_out) act_out[idx] = a;
-                if (xin_out) {
-                    float w = a + te[c];
-                    if (row < ce_rows) w += ce[idx];
-                    xin_out[idx] = w;
-                }
-            }
+    for (int i = 0; i < PC; ++i) {
+        const int c = t + 256 * i;
+        if (c < cols) {
+            const float a = silu((v[i] - mean) * rstd * gm[i] + bt[i]) + sk[i];
+            if (act_out) act_out[base + c] = a;
+            if (xin_out) xin_out[base + c] = a + tv[i] + cv[i];
         }
     }
 }
@@ -196,9 +204,7 @@ extern "C" int eegclip_prior_stage_infer(const float* x, const float* gamma, con
     if (!x || !gamma || !beta || rows < 0 || cols < 1 || cols > 64 * LNS_MAXC || (!act_out && !xin_out)) return EEGCLIP_EINVAL;
     if (xin_out && (!te || ce_rows < 0 || (ce_rows > 0 && !ce))) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    int grid = (rows + 3) / 4;
-    if (grid > 2048) grid = 2048;
-    EEG_LAUNCH(prior_stage_infer_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, skip, act_out, te, ce, ce_rows, xin_out, rows, cols, eps);
+    EEG_LAUNCH(prior_stage_infer_kernel, dim3(rows), dim3(256), 8 * sizeof(float), stream, x, gamma, beta, skip, act_out, te, ce, ce_rows, xin_out, rows, cols, eps);
     return (int)hipGetLastError();
 }
 
