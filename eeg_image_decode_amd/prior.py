@@ -275,18 +275,17 @@ class _PriorEngine:
         E, Td, Cd, h0 = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0]
         sk = lambda k: max(1, min(16, k // 256))
 
-        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, small):
-            g = pl.gemm(Nout, Nin, N, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(N) if small else 1)
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, small, bias=None):
+            # weight gradients are off the dX chain: they run on the plan's second stream underneath it (the prior's GEMMs are small -- a
+            # 1024 x 128 gradient is 32 tiles on 256 CUs); the bias gradient is the row sum of dY^T the same launch already streams (rowsum_a)
+            g = pl.gemm(Nout, Nin, N, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(N) if small else 1,
+                        rowsum_a=_p(G[bias]) if bias else None, side=True)
             return g
-
-        def bgrad(name, dY, cols):
-            pl.call("eegclip_reduce_mid", dY, N, cols, 1, _p(G[name]))
 
         n_st = len(self.stages)
         n_enc = m.num_layers - 1
         last = f"act{n_st - 1}"
-        bgrad("output_layer.bias", _p(b["dout"]), E)
-        wgrad("output_layer.weight", _p(b["dout"]), E, _p(b[last]), h0, E, h0, False)
+        wgrad("output_layer.weight", _p(b["dout"]), E, _p(b[last]), h0, E, h0, False, bias="output_layer.bias")
         pl.gemm(N, h0, E, _p(b["dout"]), D(E), D(1), _p(P["output_layer.weight"]), D(h0), D(1), _p(b[f"dact{n_st - 1}"]), D(h0), D(1))
         pl.c_gemms = []
         for s in range(n_st - 1, -1, -1):
@@ -296,31 +295,25 @@ class _PriorEngine:
             pl.call("eegclip_silu_bwd", _p(b[f"dact{s}"]), _p(b[f"ln{s}"]), _p(b[f"dln{s}"]), N * ho, 0, p, 0, s, seed_at=6)
             pl.call("eegclip_layernorm_bwd", _p(b[f"dln{s}"]), _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), _p(b[f"dlin{s}"]),
                     _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), N, ho, 0, None, 0.0, 0, 0)
-            bgrad(st["l"] + "0.bias", _p(b[f"dlin{s}"]), ho)
-            wgrad(st["l"] + "0.weight", _p(b[f"dlin{s}"]), ho, _p(b[f"xin{s}"]), hi, ho, hi, small)
+            wgrad(st["l"] + "0.weight", _p(b[f"dlin{s}"]), ho, _p(b[f"xin{s}"]), hi, ho, hi, small, bias=st["l"] + "0.bias")
             pl.gemm(N, hi, ho, _p(b[f"dlin{s}"]), D(ho), D(1), _p(P[st["l"] + "0.weight"]), D(hi), D(1), _p(b[f"dxin{s}"]), D(hi), D(1))
             if cond:
-                bgrad(st["c"] + "bias", _p(b[f"dxin{s}"]), hi)
-                pl.c_gemms.append(wgrad(st["c"] + "weight", _p(b[f"dxin{s}"]), hi, 0, Cd, hi, Cd, hi < 256))
-            bgrad(st["t"] + "linear_2.bias", _p(b[f"dxin{s}"]), hi)
-            wgrad(st["t"] + "linear_2.weight", _p(b[f"dxin{s}"]), hi, _p(b[f"t1act{s}"]), hi, hi, hi, hi < 256)
+                pl.c_gemms.append(wgrad(st["c"] + "weight", _p(b[f"dxin{s}"]), hi, 0, Cd, hi, Cd, hi < 256, bias=st["c"] + "bias"))
+            wgrad(st["t"] + "linear_2.weight", _p(b[f"dxin{s}"]), hi, _p(b[f"t1act{s}"]), hi, hi, hi, hi < 256, bias=st["t"] + "linear_2.bias")
             pl.gemm(N, hi, hi, _p(b[f"dxin{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(hi), D(1), _p(b[f"dt1{s}"]), D(hi), D(1))
             pl.call("eegclip_silu_bwd", _p(b[f"dt1{s}"]), _p(b[f"t1pre{s}"]), _p(b[f"dt1{s}"]), N * hi, 0, 0.0, 0, 0)
-            bgrad(st["t"] + "linear_1.bias", _p(b[f"dt1{s}"]), hi)
-            wgrad(st["t"] + "linear_1.weight", _p(b[f"dt1{s}"]), hi, _p(b["temb"]), Td, hi, Td, hi < 256)
+            wgrad(st["t"] + "linear_1.weight", _p(b[f"dt1{s}"]), hi, _p(b["temb"]), Td, hi, Td, hi < 256, bias=st["t"] + "linear_1.bias")
             # gradient w.r.t. the stage input x: dxin, plus the skip branch for encoder stages (decode stage j = n_enc-1-i adds skips[i])
+            # (the skip gradient is added into the DESTINATION, never into dxin: the weight-gradient GEMMs on the second stream still read dxin)
+            dst = _p(b[f"dact{s - 1}"]) if s > 0 else _p(b["dactI"])
+            pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), dst, N * hi, 1.0, 0.0)
             if st["dec"] is None:
                 dec_s = n_enc + (n_enc - 1 - s)
-                pl.call("eegclip_axpby", _p(b[f"dact{dec_s}"]), _p(b[f"dxin{s}"]), N * hi, 1.0, 1.0)
-            if s > 0:
-                pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), _p(b[f"dact{s - 1}"]), N * hi, 1.0, 0.0)
-            else:
-                pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), _p(b["dactI"]), N * hi, 1.0, 0.0)
+                pl.call("eegclip_axpby", _p(b[f"dact{dec_s}"]), dst, N * hi, 1.0, 1.0)
         pl.call("eegclip_silu_bwd", _p(b["dactI"]), _p(b["lnI"]), _p(b["dlnI"]), N * h0, 0, 0.0, 0, 0)
         pl.call("eegclip_layernorm_bwd", _p(b["dlnI"]), _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(b["muI"]), _p(b["rsI"]), _p(b["dlinI"]),
                 _p(G["input_layer.1.weight"]), _p(G["input_layer.1.bias"]), N, h0, 0, None, 0.0, 0, 0)
-        bgrad("input_layer.0.bias", _p(b["dlinI"]), h0)
-        pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False)
+        pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False, bias="input_layer.0.bias")
         return pl
 
     def forward(self, x, t, c, p, cond_rows=None):
