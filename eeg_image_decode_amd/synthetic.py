@@ -83,3 +83,53 @@ def learnable_pairs(seed, n_classes, per_class, noise=1.0, dim=1024, channels=63
     base = (protos @ m1) @ m2 * np.float32(math.sqrt(dim))          # ~unit variance per element
     eeg = base[labels] + noise * _rng(seed, "pairnoise").standard_normal((labels.size, channels * time), dtype=np.float32)
     return eeg.reshape(-1, channels, time).astype(np.float32), labels, protos
+
+
+def write_things_eeg_tree(root, seed, subjects=("sub-01", "sub-02"), channels=4, n_times=110, train_classes=1654, imgs_per_class=10,
+                          train_reps=4, test_classes=200, test_reps=5, feat_dim=1024):
+    """A synthetic stand-in for the THINGS-EEG2 tree the reference's EEGDataset reads (Retrieval/eegdatasets_leaveone.py:24-34,151-156,
+    199-203, preprocessing_utils.py:240-300), in the reference's ON-DISK FORMAT, with small channel / time extents so it is cheap to write:
+
+      <root>/data/<sub>/preprocessed_eeg_training.npy   pickled dict {'preprocessed_eeg_data' (classes*imgs, reps, C, T) float64,
+                                                                      'ch_names' list[str], 'times' (n_times,) float64}
+      <root>/data/<sub>/preprocessed_eeg_test.npy       same keys, (test_classes, test_reps, C, T)
+      <root>/images/training_images/00001_<name>/<name>_01b.jpg ...   (empty files: only the directory listing is read when the cached
+      <root>/images/test_images/00001_<name>/...                       features exist)
+      <root>/ViT-H-14_features_{train,test}.pt          {'text_features' (classes, D), 'img_features' (classes*imgs, D)} float32
+      <root>/data_config.json                           {'data_path', 'img_directory_training', 'img_directory_test'}
+
+    `times` has n_times entries from -0.2 s at 100 Hz steps of 0.01; the reference drops the first 50 (`times[50:]`), so the stored EEG has
+    T = n_times - 50 samples.  Returns the dict written to data_config.json."""
+    import json
+    import os
+    import pickle
+
+    import torch
+    T = n_times - 50
+    times = np.round(-0.2 + 0.01 * np.arange(n_times), 10) - 0.3          # times[50:] starts at 0.0
+    ch_names = [f"CH{i}" for i in range(channels)]
+    data_dir = os.path.join(root, "data")
+    for sub in subjects:
+        os.makedirs(os.path.join(data_dir, sub), exist_ok=True)
+        for split, shape in (("training", (train_classes * imgs_per_class, train_reps, channels, T)), ("test", (test_classes, test_reps, channels, T))):
+            arr = _rng(seed, f"eegfile:{sub}:{split}").standard_normal(shape)                 # float64, like the MVNN-whitened data
+            with open(os.path.join(data_dir, sub, f"preprocessed_eeg_{split}.npy"), "wb") as f:
+                # a plain pickle (protocol 4) under an .npy name, as EEG-preprocessing/preprocessing_utils.py:254-257,295-299 writes it:
+                # np.load(allow_pickle=True) falls back to pickle.load for a file without the npy magic and returns the dict itself
+                pickle.dump({"preprocessed_eeg_data": arr, "ch_names": ch_names, "times": times}, f, protocol=4)
+    cfg = {"data_path": data_dir, "img_directory_training": os.path.join(root, "images", "training_images"),
+           "img_directory_test": os.path.join(root, "images", "test_images")}
+    for key, n_cls, per in (("img_directory_training", train_classes, imgs_per_class), ("img_directory_test", test_classes, 1)):
+        for c in range(n_cls):
+            name = f"thing{c:04d}" + ("_big" if c % 7 == 0 else "")            # some names carry a second '_' (only the first one splits)
+            d = os.path.join(cfg[key], f"{c + 1:05d}_{name}")
+            os.makedirs(d, exist_ok=True)
+            for j in range(per):
+                open(os.path.join(d, f"{name}_{j + 1:02d}{'s' if key.endswith('test') else 'b'}.jpg"), "wb").close()
+    for split, n_cls, per in (("train", train_classes, imgs_per_class), ("test", test_classes, 1)):
+        torch.save({"text_features": torch.from_numpy(unit_features(seed, n_cls, feat_dim, tag=f"ds-text-{split}")),
+                    "img_features": torch.from_numpy(unit_features(seed, n_cls * per, feat_dim, tag=f"ds-img-{split}"))},
+                   os.path.join(root, f"ViT-H-14_features_{split}.pt"))
+    with open(os.path.join(root, "data_config.json"), "w") as f:
+        json.dump(cfg, f)
+    return cfg

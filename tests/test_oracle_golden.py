@@ -233,3 +233,42 @@ def test_distributed_loss_modes_closed_form(golden):
         assert abs(np.mean(ll) - glob) < 1e-5
         np.testing.assert_allclose(g[f"w{W}_ll1_gwg1_da"], W * da.numpy(), atol=2e-6)
         np.testing.assert_allclose(g[f"w{W}_ll1_gwg1_db"], W * db.numpy(), atol=5e-5)
+
+
+# ---- input pipeline: oracle.dataset against the reference's EEGDataset on the synthetic THINGS-EEG tree ----------------
+DATASET_CONFIGS = {
+    "train_two_subjects": dict(subjects=["sub-01", "sub-02"], train=True),
+    "train_leave_sub02_out": dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02", train=True),
+    "test_sub01": dict(subjects=["sub-01"], train=False),
+    "test_leave_sub02_out": dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02", train=False),
+    "train_window": dict(subjects=["sub-02"], train=True, time_window=[0.1, 0.35]),
+}
+
+
+@pytest.fixture(scope="module")
+def things_tree(tmp_path_factory):
+    from eeg_image_decode_amd import synthetic as syn
+    root = str(tmp_path_factory.mktemp("things_eeg"))
+    return root, syn.write_things_eeg_tree(root, 20260927)
+
+
+@pytest.mark.parametrize("name", list(DATASET_CONFIGS))
+def test_dataset_restatement_matches_reference_fixture(name, things_tree, golden):
+    from oracle import dataset as ods
+    g = golden("dataset.npz")
+    root, cfg = things_tree
+    kw = dict(DATASET_CONFIGS[name])
+    train = kw.pop("train")
+    data, lab, texts, images, _, _ = ods.load_split(cfg["data_path"], cfg["img_directory_training" if train else "img_directory_test"], train=train, **kw)
+    assert len(data) == int(g[f"{name}:len"]) and list(data.shape) == g[f"{name}:data_shape"].tolist()
+    assert np.array_equal(lab, g[f"{name}:labels"])
+    assert len(texts) == int(g[f"{name}:n_text"]) and len(images) == int(g[f"{name}:n_img"])
+    idx = g[f"{name}:idx"]
+    np.testing.assert_array_equal(data[idx], g[f"{name}:x"]) if train else np.testing.assert_allclose(data[idx], g[f"{name}:x"], atol=1e-6)
+    rows = [ods.item_rows(int(i), train, 1654 if train else 200) for i in idx]
+    assert [r[0] for r in rows] == g[f"{name}:text_row"].tolist() and [r[1] for r in rows] == g[f"{name}:img_row"].tolist()
+    assert [texts[r[0]] for r in rows] == g[f"{name}:text"].tolist()
+    assert [os.path.relpath(images[r[1]], root) for r in rows] == g[f"{name}:img"].tolist()
+    assert abs(float(data.astype(np.float64).sum()) - float(g[f"{name}:data_sum"])) < 1e-3
+    if not train:
+        np.testing.assert_allclose(data, g[f"{name}:data"], atol=1e-6)
