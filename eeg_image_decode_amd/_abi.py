@@ -62,6 +62,7 @@ PROTOTYPES = {
     "eegclip_reduce_mid": [_P, _I, _I, _I, _P, _P],
     "eegclip_colsum_blocks": [_P, _I, _I, _I, _I, _L, _P, _P],
     "eegclip_sumsq": [_P, _L, _P, _P],
+    "eegclip_stage_eeg": [_P, _P, _L, _I, _I, _I, _P, _I, _I, _P],
     "eegclip_gather_rows": [_P, _L, _P, _L, _P, _I, _I, _I, _P],
     "eegclip_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
     "eegclip_clip_scale": [_P, _F, _P, _P],

@@ -241,9 +241,42 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ ds
     }
 }
 
+// Dataset staging (Retrieval/eegdatasets_leaveone.py:157,203 `.float()`, :220 mean over repetitions, :293-306 time-window mask): the
+// reference's on-disk trials are float64 (images, repetitions, channels, T); one pass turns a chunk of them into the float32 training
+// layout in HBM.  row = (image, repetition, channel) [or (image, channel) when averaging]; a thread owns one output sample, so a wave
+// reads Tw consecutive doubles of a row (the mask of a contiguous window is a contiguous index list).
+//   mean_reps == 0:  dst[(i*reps + r)*C + c][j] = (float) src[i][r][c][tidx[j]]
+//   mean_reps != 0:  dst[i*C + c][j] = (sum_r (float) src[i][r][c][tidx[j]]) / reps         float32 accumulation in repetition order
+__global__ __launch_bounds__(256) void stage_eeg_kernel(const double* __restrict__ src, float* __restrict__ dst, long long n_items, int reps,
+                                                        int C, int T, const int* __restrict__ tidx, int Tw, int mean_reps) {
+    const long long rows = mean_reps ? n_items * C : n_items * reps * C;
+    const long long total = rows * Tw;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / Tw;
+        const int t = tidx[(int)(e % Tw)];
+        if (!mean_reps) {
+            dst[e] = (float)src[row * T + t];
+        } else {
+            const long long i = row / C;
+            const int c = (int)(row % C);
+            float acc = 0.f;
+            for (int r = 0; r < reps; ++r) acc += (float)src[((i * reps + r) * C + c) * T + t];
+            dst[e] = acc / (float)reps;
+        }
+    }
+}
+
 }  // namespace eeg
 
 using namespace eeg;
+
+extern "C" int eegclip_stage_eeg(const double* src, float* dst, long long n_items, int reps, int channels, int T, const int* tidx, int Tw,
+                                 int mean_reps, void* stream) {
+    if (!src || !dst || !tidx || n_items < 1 || reps < 1 || channels < 1 || T < 1 || Tw < 1 || Tw > T) return EEGCLIP_EINVAL;
+    const long long total = (mean_reps ? n_items * channels : n_items * reps * channels) * Tw;
+    EEG_LAUNCH(stage_eeg_kernel, dim3(ew_grid(total, 256, 16384)), dim3(256), 0, stream, src, dst, n_items, reps, channels, T, tidx, Tw, mean_reps);
+    return (int)hipGetLastError();
+}
 
 extern "C" int eegclip_gather_rows(float* dst, long long dst_stride, const float* src, long long src_stride, const int* idx, int n,
                                    int row_floats, int scatter, void* stream) {

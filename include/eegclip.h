@@ -140,9 +140,16 @@ int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out
 /* out[c] += sum over blocks and rows r in [row0, blk_rows) of x[blk*blk_stride + r*cols + c] */
 int eegclip_colsum_blocks(const float* x, int nblk, int blk_rows, int row0, int cols, long long blk_stride, float* out, void* stream);
 int eegclip_sumsq(const float* x, long long n, double* out, void* stream);              /* *out += sum x^2 */
+/* dataset staging: a chunk of the reference's on-disk trials -- float64 (n_items, reps, channels, T), Retrieval/eegdatasets_leaveone.py:151-157,
+ * 199-203 -- to the float32 layout the loops consume, time window applied (tidx: the Tw selected sample indices, :293-306).
+ * mean_reps = 0: every repetition is a sample, dst (n_items*reps, channels, Tw) (training split, :255); mean_reps = 1: the mean over
+ * repetitions taken after the float32 cast, dst (n_items, channels, Tw) (test split, :220). */
+int eegclip_stage_eeg(const double* src, float* dst, long long n_items, int reps, int channels, int T, const int* tidx, int Tw, int mean_reps,
+                      void* stream);
 /* sample-block gather (scatter = 0: dst[j] = src[idx[j]]) / scatter (dst[idx[j]] = src[j]); a block = row_floats contiguous floats at
  * j*stride.  Used by the joint-subject model (Retrieval/ATMS_retrieval_joint_train.py:172-192, models/subject_layers/Embed.py:142-144) to
- * bring a mixed-subject batch into subject order, so that each subject's value-embedding Linear is one GEMM over a contiguous block. */
+ * bring a mixed-subject batch into subject order, so that each subject's value-embedding Linear is one GEMM over a contiguous block, and by the
+ * HBM-resident dataset loader to assemble a shuffled batch (EEG windows, labels as 8-byte rows, feature rows). */
 int eegclip_gather_rows(float* dst, long long dst_stride, const float* src, long long src_stride, const int* idx, int n, int row_floats,
                         int scatter, void* stream);
 

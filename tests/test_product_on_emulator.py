@@ -263,3 +263,48 @@ def test_prior_sampling_chain_under_emulator_matches_oracle(guided):
     torch.randn(n, 1024, generator=gen)                     # the start latent comes first in the stream
     ho, _ = oprior.generate(P, oprior.DDPMSchedulerOracle(), c, steps, 5.0, generator=gen, h_T=hT)
     np.testing.assert_allclose(h.numpy(), ho.numpy(), atol=2e-4)
+
+
+@pytest.fixture(scope="module")
+def small_things_tree(tmp_path_factory):
+    """the synthetic THINGS-EEG tree with the reference's class counts (they are hard-coded in its loader) but one channel pair and few samples"""
+    root = str(tmp_path_factory.mktemp("things_small"))
+    return root, syn.write_things_eeg_tree(root, 7, channels=2, n_times=58, feat_dim=8)
+
+
+@pytest.mark.parametrize("train,kw", [(True, dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02")), (False, dict(subjects=["sub-02"])),
+                                      (True, dict(subjects=["sub-02", "sub-01"], time_window=[0.02, 0.05]))])
+def test_dataset_staging_and_device_loader_under_emulator_match_oracle(train, kw, small_things_tree):
+    """datasets.EEGDataset (float64 file -> eegclip_stage_eeg -> resident float32 split) and its batch loader (eegclip_gather_rows) against the
+    oracle's restatement of the reference class: whole data tensor, labels, texts, image paths, item tuples and shuffled batches"""
+    from oracle import dataset as ods
+    root, cfg = small_things_tree
+    data, lab, texts, images, _, _ = ods.load_split(cfg["data_path"], cfg["img_directory_training" if train else "img_directory_test"], train=train, **kw)
+    with product_on_emulator():
+        from eeg_image_decode_amd.datasets import EEGDataset
+        ds = EEGDataset(cfg["data_path"], train=train, config=cfg, features_dir=root, device="cpu", **kw)
+        assert len(ds) == len(data) and ds.text == texts and ds.img == images
+        np.testing.assert_array_equal(ds.labels.numpy(), lab)
+        if train:
+            np.testing.assert_array_equal(ds.data.numpy(), data)                          # a cast and a copy: bit exact
+        else:
+            np.testing.assert_allclose(ds.data.numpy(), data, atol=1e-6)                  # mean over repetitions: float32 summation order
+        for i in (0, 41, len(ds) - 1):
+            x, label, text, tf, img, imf = ds[i]
+            ti, ii = ods.item_rows(i, train, 1654 if train else 200)
+            assert int(label) == lab[i] and text == texts[ti] and img == images[ii]
+            assert torch.equal(tf, ds.text_features[ti]) and torch.equal(imf, ds.img_features[ii]) and torch.equal(x, ds.data[i])
+        ld = ds.loader(batch_size=64, shuffle=True, drop_last=train, generator=torch.Generator().manual_seed(5))
+        order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5)).numpy()
+        assert len(ld) == (len(ds) // 64 if train else (len(ds) + 63) // 64)
+        seen = 0
+        for bi, (x, y, text, tf, img, imf) in enumerate(ld):
+            idx = order[bi * 64:bi * 64 + 64]
+            assert torch.equal(x, ds.data[idx]) and torch.equal(y, ds.labels[idx])
+            rows = [ods.item_rows(int(i), train, 1654 if train else 200) for i in idx]
+            assert text == [texts[r[0]] for r in rows] and img == [images[r[1]] for r in rows]
+            assert torch.equal(tf, ds.text_features[[r[0] for r in rows]]) and torch.equal(imf, ds.img_features[[r[1] for r in rows]])
+            seen += len(idx)
+            if bi == 2:
+                break
+        assert seen == min(len(ds), 192)
