@@ -86,7 +86,7 @@ def learnable_pairs(seed, n_classes, per_class, noise=1.0, dim=1024, channels=63
 
 
 def write_things_eeg_tree(root, seed, subjects=("sub-01", "sub-02"), channels=4, n_times=110, train_classes=1654, imgs_per_class=10,
-                          train_reps=4, test_classes=200, test_reps=5, feat_dim=1024):
+                          train_reps=4, test_classes=200, test_reps=5, feat_dim=1024, dt=0.01):
     """A synthetic stand-in for the THINGS-EEG2 tree the reference's EEGDataset reads (Retrieval/eegdatasets_leaveone.py:24-34,151-156,
     199-203, preprocessing_utils.py:240-300), in the reference's ON-DISK FORMAT, with small channel / time extents so it is cheap to write:
 
@@ -98,15 +98,16 @@ def write_things_eeg_tree(root, seed, subjects=("sub-01", "sub-02"), channels=4,
       <root>/ViT-H-14_features_{train,test}.pt          {'text_features' (classes, D), 'img_features' (classes*imgs, D)} float32
       <root>/data_config.json                           {'data_path', 'img_directory_training', 'img_directory_test'}
 
-    `times` has n_times entries from -0.2 s at 100 Hz steps of 0.01; the reference drops the first 50 (`times[50:]`), so the stored EEG has
-    T = n_times - 50 samples.  Returns the dict written to data_config.json."""
+    `times` has n_times entries `dt` apart with times[50] = 0 s; the reference drops the first 50 (`times[50:]`), so the stored EEG has
+    T = n_times - 50 samples (the real data: 250 Hz, n_times = 300, dt = 0.004 -> 250 samples in [0, 1] s).  Returns the dict written to
+    data_config.json."""
     import json
     import os
     import pickle
 
     import torch
     T = n_times - 50
-    times = np.round(-0.2 + 0.01 * np.arange(n_times), 10) - 0.3          # times[50:] starts at 0.0
+    times = np.round(-0.2 + dt * np.arange(n_times), 10) - (0.3 if dt == 0.01 else 50 * dt - 0.2)          # times[50:] starts at 0.0
     ch_names = [f"CH{i}" for i in range(channels)]
     data_dir = os.path.join(root, "data")
     for sub in subjects:

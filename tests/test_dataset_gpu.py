@@ -66,7 +66,7 @@ def test_loader_feeds_train_and_evaluate_loops(tmp_path):
     from eeg_image_decode_amd.atms import ATMS
     from eeg_image_decode_amd.datasets import EEGDataset
     root = str(tmp_path)
-    cfg = syn.write_things_eeg_tree(root, 11, subjects=("sub-01",), channels=63, n_times=300, train_classes=12, test_classes=200, test_reps=3)
+    cfg = syn.write_things_eeg_tree(root, 11, subjects=("sub-01",), channels=63, n_times=300, dt=0.004, train_classes=12, test_classes=200, test_reps=3)
     tr = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=True, config=cfg, features_dir=root)
     te = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=False, config=cfg, features_dir=root)
     assert tuple(tr.data.shape) == (12 * 10 * 4, 63, 250) and tuple(te.data.shape) == (200, 63, 250)

@@ -35,7 +35,7 @@ def main():
                                                                                 "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3)}
     root = tempfile.mkdtemp(prefix="things_bench_")
     try:
-        cfg = syn.write_things_eeg_tree(root, 3, subjects=("sub-01",), channels=63, n_times=300, train_classes=100, test_classes=200, test_reps=4)
+        cfg = syn.write_things_eeg_tree(root, 3, subjects=("sub-01",), channels=63, n_times=300, dt=0.004, train_classes=100, test_classes=200, test_reps=4)
         t0 = time.perf_counter()
         ds = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=True, config=cfg, features_dir=root)
         torch.cuda.synchronize()
