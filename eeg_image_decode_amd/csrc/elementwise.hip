@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void stage_eeg_kernel(const double* __restrict
     const long long total = rows * Tw;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long row = e / Tw;
-        const int t = tidx[(int)(e % Tw)];
+        const int t = tidx ? tidx[(int)(e % Tw)] : (int)(e % Tw);
         if (!mean_reps) {
             dst[e] = (float)src[row * T + t];
         } else {
@@ -266,14 +266,29 @@ __global__ __launch_bounds__(256) void stage_eeg_kernel(const double* __restrict
     }
 }
 
+// whole-window cast (tidx == NULL: every stored sample is kept -- the real data's [0, 1] s window): a flat float64 -> float32 stream, four values
+// per thread (two 16-byte loads, one 16-byte store)
+__global__ __launch_bounds__(256) void stage_eeg_flat_kernel(const double* __restrict__ src, float* __restrict__ dst, long long n4, long long n) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const f64x2 a = reinterpret_cast<const f64x2*>(src)[2 * q], b = reinterpret_cast<const f64x2*>(src)[2 * q + 1];
+        reinterpret_cast<float4*>(dst)[q] = make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) dst[4 * n4 + threadIdx.x] = (float)src[4 * n4 + threadIdx.x];
+}
+
 }  // namespace eeg
 
 using namespace eeg;
 
 extern "C" int eegclip_stage_eeg(const double* src, float* dst, long long n_items, int reps, int channels, int T, const int* tidx, int Tw,
                                  int mean_reps, void* stream) {
-    if (!src || !dst || !tidx || n_items < 1 || reps < 1 || channels < 1 || T < 1 || Tw < 1 || Tw > T) return EEGCLIP_EINVAL;
+    if (!src || !dst || n_items < 1 || reps < 1 || channels < 1 || T < 1 || Tw < 1 || Tw > T || (!tidx && Tw != T)) return EEGCLIP_EINVAL;
     const long long total = (mean_reps ? n_items * channels : n_items * reps * channels) * Tw;
+    if (!tidx && !mean_reps && !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u)) {
+        EEG_LAUNCH(stage_eeg_flat_kernel, dim3(ew_grid(total / 4, 256, 16384)), dim3(256), 0, stream, src, dst, total / 4, total);
+        return (int)hipGetLastError();
+    }
     EEG_LAUNCH(stage_eeg_kernel, dim3(ew_grid(total, 256, 16384)), dim3(256), 0, stream, src, dst, n_items, reps, channels, T, tidx, Tw, mean_reps);
     return (int)hipGetLastError();
 }

@@ -114,7 +114,7 @@ class EEGDataset:
             Tw = int(tidx.numel())
             if Tw == 0:
                 raise EegclipError(f"time_window {self.time_window} selects no sample")
-            tidx_d = tidx.to(dev)
+            tidx_d = tidx.to(dev) if Tw != T else None             # whole window kept (the real data): the flat cast path
             rows_out = n_items if not self.train else n_items * reps
             out = torch.empty(rows_out, C, Tw, dtype=torch.float32, device=dev)
             step = max(1, _CHUNK_BYTES // (reps * C * T * 8))
@@ -122,7 +122,8 @@ class EEGDataset:
                 n = min(step, n_items - i0)
                 chunk = torch.from_numpy(eeg[i0:i0 + n]).to(dev)                                  # float64, resident only for this chunk
                 dst = out[i0:i0 + n] if not self.train else out[i0 * reps:(i0 + n) * reps]
-                check(L.eegclip_stage_eeg(chunk.data_ptr(), dst.data_ptr(), n, reps, C, T, tidx_d.data_ptr(), Tw, 0 if self.train else 1, _stream()),
+                check(L.eegclip_stage_eeg(chunk.data_ptr(), dst.data_ptr(), n, reps, C, T, tidx_d.data_ptr() if tidx_d is not None else None, Tw,
+                                          0 if self.train else 1, _stream()),
                       "stage_eeg")
                 del chunk
             blocks.append(out)

@@ -141,7 +141,8 @@ int eegclip_reduce_mid(const float* x, int outer, int mid, int inner, float* out
 int eegclip_colsum_blocks(const float* x, int nblk, int blk_rows, int row0, int cols, long long blk_stride, float* out, void* stream);
 int eegclip_sumsq(const float* x, long long n, double* out, void* stream);              /* *out += sum x^2 */
 /* dataset staging: a chunk of the reference's on-disk trials -- float64 (n_items, reps, channels, T), Retrieval/eegdatasets_leaveone.py:151-157,
- * 199-203 -- to the float32 layout the loops consume, time window applied (tidx: the Tw selected sample indices, :293-306).
+ * 199-203 -- to the float32 layout the loops consume, time window applied (tidx: the Tw selected sample indices, :293-306;
+ * NULL = all T of them, Tw == T).
  * mean_reps = 0: every repetition is a sample, dst (n_items*reps, channels, Tw) (training split, :255); mean_reps = 1: the mean over
  * repetitions taken after the float32 cast, dst (n_items, channels, Tw) (test split, :220). */
 int eegclip_stage_eeg(const double* src, float* dst, long long n_items, int reps, int channels, int T, const int* tidx, int Tw, int mean_reps,

@@ -149,6 +149,32 @@ def test_gather_scatter_rows_bit_exact(be, n, row, ds, ss):
     assert be.lib.eegclip_gather_rows(be.ptr(DST), ds, be.ptr(DST), ss, be.ptr(IDX), n, 3, 0, be.stream) < 0       # odd row length
 
 
+@pytest.mark.parametrize("n,reps,C,T,win", [(7, 4, 3, 10, (2, 9)), (5, 3, 2, 6, None), (33, 4, 63, 26, None), (4, 5, 3, 8, (0, 8))])
+def test_stage_eeg_cast_window_and_mean(be, n, reps, C, T, win):
+    """dataset staging (eegdatasets_leaveone.py:157,220,293-306): float64 trials -> float32, time window, optional mean over repetitions taken
+    AFTER the float32 cast; tidx = NULL keeps every sample (flat vectorised cast)"""
+    rng = np.random.default_rng(n + T)
+    src = rng.standard_normal((n, reps, C, T))
+    cols = np.arange(T) if win is None else np.arange(win[0], win[1])
+    SRC = be.dev(src)
+    TI = None if win is None else be.dev(cols.astype(np.int32))
+    Tw = len(cols)
+    DST = be.zeros((n * reps, C, Tw))
+    ok(be.lib.eegclip_stage_eeg(be.ptr(SRC), be.ptr(DST), n, reps, C, T, be.ptr(TI), Tw, 0, be.stream))
+    assert np.array_equal(be.host(DST), src.astype(np.float32)[..., cols].reshape(n * reps, C, Tw))
+    if win is None:
+        TI = be.dev(cols.astype(np.int32))                           # the mean path always takes an index list or NULL; exercise both
+    for ti in (TI, None) if win is None else (TI,):
+        DM = be.zeros((n, C, Tw))
+        ok(be.lib.eegclip_stage_eeg(be.ptr(SRC), be.ptr(DM), n, reps, C, T, be.ptr(ti), Tw, 1, be.stream))
+        f = src.astype(np.float32)[..., cols]
+        acc = np.zeros((n, C, Tw), np.float32)
+        for r in range(reps):
+            acc += f[:, r]
+        assert np.array_equal(be.host(DM), acc / np.float32(reps))          # float32 accumulation in repetition order, bit for bit
+    assert be.lib.eegclip_stage_eeg(be.ptr(SRC), be.ptr(DST), n, reps, C, T, None, Tw - 1 if Tw > 1 else 0, 0, be.stream) < 0
+
+
 @pytest.mark.parametrize("outer,mid,inner", [(1000, 250, 1), (7, 40, 36), (3, 1024, 1), (1, 5, 1)])
 def test_reduce_mid(be, outer, mid, inner):
     rng = np.random.default_rng(outer)

@@ -20,7 +20,7 @@ def main():
     tidx = torch.arange(T, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for mean in (0, 1):
-        run = lambda: check(lib().eegclip_stage_eeg(src.data_ptr(), dst.data_ptr(), n, reps, C, T, tidx.data_ptr(), T, mean, st), "stage")
+        run = lambda: check(lib().eegclip_stage_eeg(src.data_ptr(), dst.data_ptr(), n, reps, C, T, None if not mean else tidx.data_ptr(), T, mean, st), "stage")
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
