@@ -11,6 +11,8 @@
 // 8-byte LDS reads per lane.  Both branches accumulate into the same fp32 accumulators (ip probabilities pre-scaled).
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
 constexpr int CA_D = 64;          // head_dim
@@ -102,25 +104,50 @@ struct ca_args {
     float scale, ip_scale;
 };
 
-// stage K rows [S][64] (padded stride) and V transposed [64][ldv] for one (b, head); rows >= S are zero
-__device__ __forceinline__ void stage_kv(unsigned short* Ks, unsigned short* Vt, int ldv, const unsigned short* k, const unsigned short* v,
-                                         int S, int S_pad, long long row_stride) {
+// stage K rows [S][64] (padded stride) and V transposed [64][ldv] for one (b, head); rows >= S are zero.  Two phases: every global load of
+// BOTH branches is issued before the first LDS store (kv_issue ... kv_issue, kv_commit ... kv_commit).  As one load-then-store loop per
+// operand each iteration waited for its own load: ~10 dependent HBM round trips per workgroup, about half of the launch (the 1280
+// workgroups of a UNet attention call each stage their own 20 KB of keys and values).
+constexpr int CA_KIT = (CA_MAXT * 16 * (CA_D / 8) + 255) / 256;       // 16-byte pieces of K per thread
+constexpr int CA_VIT = (132 * (CA_D / 8) + 255) / 256;                // ... of V (ca_ldv() never exceeds 132 keys)
+struct kv_stage {
+    uint4 k[CA_KIT], v[CA_VIT];
+};
+
+__device__ __forceinline__ void kv_issue(kv_stage& r, int ldv, const unsigned short* k, const unsigned short* v, int S, int S_pad,
+                                         long long row_stride) {
     const int t = threadIdx.x;
-    for (int i = t; i < S_pad * (CA_D / 8); i += blockDim.x) {      // 16-byte pieces of K rows
-        const int r = i / (CA_D / 8), c8 = i % (CA_D / 8);
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (r < S) val = *reinterpret_cast<const uint4*>(k + r * row_stride + c8 * 8);
-        *reinterpret_cast<uint4*>(Ks + r * CA_KLD + c8 * 8) = val;
-    }
-    for (int i = t; i < ldv * (CA_D / 8); i += blockDim.x) {        // V^T[d][key], zero padded along keys: 16-byte reads of V rows, transposed stores
-        const int key = i / (CA_D / 8), d8 = 8 * (i % (CA_D / 8));
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (key < S) val = *reinterpret_cast<const uint4*>(v + key * row_stride + d8);
-        const unsigned w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            Vt[(d8 + 2 * e) * ldv + key] = (unsigned short)(w[e] & 0xffffu);
-            Vt[(d8 + 2 * e + 1) * ldv + key] = (unsigned short)(w[e] >> 16);
+    for (int j = 0; j < CA_KIT; ++j) {
+        const int i = t + 256 * j, row = i / (CA_D / 8), c8 = i % (CA_D / 8);
+        r.k[j] = make_uint4(0, 0, 0, 0);
+        if (i < S_pad * (CA_D / 8) && row < S) r.k[j] = *reinterpret_cast<const uint4*>(k + row * row_stride + c8 * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < CA_VIT; ++j) {
+        const int i = t + 256 * j, key = i / (CA_D / 8), d8 = 8 * (i % (CA_D / 8));
+        r.v[j] = make_uint4(0, 0, 0, 0);
+        if (i < ldv * (CA_D / 8) && key < S) r.v[j] = *reinterpret_cast<const uint4*>(v + key * row_stride + d8);
+    }
+}
+
+__device__ __forceinline__ void kv_commit(const kv_stage& r, unsigned short* Ks, unsigned short* Vt, int ldv, int S_pad) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < CA_KIT; ++j) {
+        const int i = t + 256 * j, row = i / (CA_D / 8), c8 = i % (CA_D / 8);
+        if (i < S_pad * (CA_D / 8)) *reinterpret_cast<uint4*>(Ks + row * CA_KLD + c8 * 8) = r.k[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CA_VIT; ++j) {                                 // V^T[d][key], zero padded along keys: transposed 2-byte stores
+        const int i = t + 256 * j, key = i / (CA_D / 8), d8 = 8 * (i % (CA_D / 8));
+        if (i < ldv * (CA_D / 8)) {
+            const unsigned w[4] = {r.v[j].x, r.v[j].y, r.v[j].z, r.v[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(d8 + 2 * e) * ldv + key] = (unsigned short)(w[e] & 0xffffu);
+                Vt[(d8 + 2 * e + 1) * ldv + key] = (unsigned short)(w[e] >> 16);
+            }
         }
     }
 }
@@ -145,23 +172,21 @@ __device__ __forceinline__ void branch(const unsigned short* Ks, const unsigned 
         }
         if (t == ntile - 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = (16 * t + 4 * g + r) < S ? c[r] * scale2 : -INFINITY;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] *= scale2;
+            for (int r = 0; r < 4; ++r) c[r] = (16 * t + 4 * g + r) < S ? c[r] : -INFINITY;
         }
-        mx = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), mx);
-        s[t] = c;
+        mx = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), mx);          // max of the RAW scores: the (positive) scale is folded into
+        s[t] = c;                                                             // the exponent's FMA below, one instruction per score less
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * scale2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < CA_MAXT; ++t) {
         if (t >= ntile) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(s[t][r] - mx);
+            const float p = fast_exp2(fmaf(s[t][r], scale2, -mxs));
             s[t][r] = p;
             sum += p;
         }
@@ -201,10 +226,14 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const ca_args a) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int C = a.heads * CA_D;
     const long long rs = C;
-    stage_kv(Ks, Vt, ldv, a.k + ((long long)b * a.S) * rs + h * CA_D, a.v + ((long long)b * a.S) * rs + h * CA_D, a.S, nt * 16, rs);
-    if (nt_ip > 0)
-        stage_kv(Kip, Vip, ldv_ip, a.k_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.v_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.S_ip,
-                 nt_ip * 16, rs);
+    {
+        kv_stage rt, ri;
+        kv_issue(rt, ldv, a.k + ((long long)b * a.S) * rs + h * CA_D, a.v + ((long long)b * a.S) * rs + h * CA_D, a.S, nt * 16, rs);
+        if (nt_ip > 0)
+            kv_issue(ri, ldv_ip, a.k_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.v_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.S_ip, nt_ip * 16, rs);
+        kv_commit(rt, Ks, Vt, ldv, nt * 16);
+        if (nt_ip > 0) kv_commit(ri, Kip, Vip, ldv_ip, nt_ip * 16);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -235,6 +264,182 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const ca_args a) {
     }
 }
 
+// ---- SDXL's own shape (77 text tokens = 5 key tiles, 0 or 4 image tokens = 0 / 1 tile): K and V^T fragments live in REGISTERS -----------
+// A wave walks 8 query tiles against the same keys.  Re-reading the K / V^T fragments from LDS for every tile cost 28 LDS instructions and
+// their address arithmetic per tile on top of a VALU-heavy softmax (wave64 VALU issues over 4 cycles: ~400 instructions per tile were
+// ~27 us of the 66 us launch, the MFMAs 7.5 us, the HBM roofline 28 us).  With the tile counts as template parameters the fragments are
+// loaded once per wave (112 VGPRs) and the tile loop touches LDS not at all.
+template <int NT>
+struct kv_frag {
+    bf16x8 k[NT > 0 ? NT : 1][2];
+    bf16x8 v[NT > 0 ? (NT + 1) / 2 : 1][4];
+};
+
+template <int NT, bool VREG>
+__device__ __forceinline__ void load_frag(kv_frag<NT>& f, const unsigned short* Ks, const unsigned short* Vt, int ldv, int lane) {
+    const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) f.k[t][st] = *reinterpret_cast<const bf16x8*>(Ks + (16 * t + fr) * CA_KLD + 32 * st + 8 * g);
+    if (!VREG) return;
+#pragma unroll
+    for (int u = 0; u < (NT + 1) / 2; ++u)
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) {
+            const unsigned short* vp = Vt + (16 * dn + fr) * ldv + 32 * u + 4 * g;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+            f.v[u][dn] = __builtin_bit_cast(bf16x8, (ca_u32x4{lo.x, lo.y, hi.x, hi.y}));
+        }
+}
+
+// same arithmetic, in the same order, as branch() -- the two are interchangeable bit for bit.  TWO query tiles advance in lockstep through
+// every phase (scores, max, exp, sum, P V): the phases of one tile are a dependent chain through MFMA results and cross-lane shuffles, and
+// at 2 waves per SIMD nothing else hides those latencies.
+template <bool F16, int NT, bool VREG>
+__device__ __forceinline__ void branch_reg2(const kv_frag<NT>& f, const unsigned short* Vt, int ldv, int S, const bf16x8 (&bq)[2][2], float scale2,
+                                            float pscale, f32x4 (&acc)[2][4], int lane) {
+    const int g = lane >> 4, fr = lane & 15;
+    f32x4 s[2][NT];
+    float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) c = mma<F16>(f.k[t][st], bq[p][st], c);
+            if (t == NT - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = (16 * t + 4 * g + r) < S ? c[r] : -INFINITY;
+            }
+            mx[p] = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), mx[p]);
+            s[p][t] = c;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) mx[p] = fmaxf(mx[p], __shfl_xor(mx[p], 16, 64));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) mx[p] = fmaxf(mx[p], __shfl_xor(mx[p], 32, 64));
+    const float mxs[2] = {mx[0] * scale2, mx[1] * scale2};
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp2(fmaf(s[p][t][r], scale2, -mxs[p]));
+                s[p][t][r] = e;
+                sum[p] += e;
+            }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) sum[p] += __shfl_xor(sum[p], 16, 64);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) sum[p] += __shfl_xor(sum[p], 32, 64);
+    const float nrm[2] = {pscale / sum[0], pscale / sum[1]};
+#pragma unroll
+    for (int u = 0; u < (NT + 1) / 2; ++u) {
+        const bool two = 2 * u + 1 < NT;
+        bf16x8 pa[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 lo4 = s[p][2 * u], hi4 = two ? s[p][two ? 2 * u + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const ca_u32x4 pw{pack2<F16>(lo4[0] * nrm[p], lo4[1] * nrm[p]), pack2<F16>(lo4[2] * nrm[p], lo4[3] * nrm[p]),
+                              pack2<F16>(hi4[0] * nrm[p], hi4[1] * nrm[p]), pack2<F16>(hi4[2] * nrm[p], hi4[3] * nrm[p])};
+            pa[p] = __builtin_bit_cast(bf16x8, pw);
+        }
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) {
+            bf16x8 bv;
+            if (VREG) {
+                bv = f.v[u][dn];
+            } else {                                     // V^T fragment from LDS, shared by the two tiles
+                const unsigned short* vp = Vt + (16 * dn + fr) * ldv + 32 * u + 4 * g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+                bv = __builtin_bit_cast(bf16x8, (ca_u32x4{lo.x, lo.y, hi.x, hi.y}));
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) acc[p][dn] = mma<F16>(bv, pa[p], acc[p][dn]);
+        }
+    }
+}
+
+template <bool F16, int NT, int NT_IP, bool VREG>
+__global__ __launch_bounds__(256, VREG ? 2 : 3) void cross_attn_reg_kernel(const ca_args a) {
+    EEG_LDS_BASE(unsigned short, lds);
+    const int ldv = ca_ldv(NT), ldv_ip = ca_ldv(NT_IP);
+    unsigned short* Ks = lds;
+    unsigned short* Vt = Ks + NT * 16 * CA_KLD;
+    unsigned short* Kip = Vt + CA_D * ldv;
+    unsigned short* Vip = Kip + NT_IP * 16 * CA_KLD;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long long rs = a.heads * CA_D;
+    {
+        kv_stage rt, ri;
+        kv_issue(rt, ldv, a.k + ((long long)b * a.S) * rs + h * CA_D, a.v + ((long long)b * a.S) * rs + h * CA_D, a.S, NT * 16, rs);
+        if (NT_IP > 0)
+            kv_issue(ri, ldv_ip, a.k_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.v_ip + ((long long)b * a.S_ip) * rs + h * CA_D, a.S_ip, NT_IP * 16, rs);
+        kv_commit(rt, Ks, Vt, ldv, NT * 16);
+        if (NT_IP > 0) kv_commit(ri, Kip, Vip, ldv_ip, NT_IP * 16);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    kv_frag<NT> ft;
+    kv_frag<NT_IP> fi;
+    load_frag<NT, VREG>(ft, Ks, Vt, ldv, lane);
+    if (NT_IP > 0) load_frag<NT_IP, VREG>(fi, Kip, Vip, ldv_ip, lane);
+    // a wave owns query tiles (it*4 + wave), it = 0..7, taken two at a time (it, it + 1); rows beyond HW are clamped on load, skipped on store
+    auto q_ptr = [&](int it) {
+        const int qrow = blockIdx.x * CA_QB + (it * 4 + wave) * 16 + fr;
+        return a.q + ((long long)b * a.HW + (qrow < a.HW ? qrow : a.HW - 1)) * rs + h * CA_D + 8 * g;
+    };
+    bf16x8 nq[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        nq[p][0] = *reinterpret_cast<const bf16x8*>(q_ptr(p));
+        nq[p][1] = *reinterpret_cast<const bf16x8*>(q_ptr(p) + 32);
+    }
+    for (int it = 0; it < CA_QB / 64; it += 2) {
+        const int q0 = blockIdx.x * CA_QB + (it * 4 + wave) * 16;
+        if (q0 >= a.HW) break;                                   // wave-uniform
+        const bf16x8 bq[2][2] = {{nq[0][0], nq[0][1]}, {nq[1][0], nq[1][1]}};
+        if (it + 2 < CA_QB / 64) {                               // the next pair's queries are in flight while this pair is computed
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                nq[p][0] = *reinterpret_cast<const bf16x8*>(q_ptr(it + 2 + p));
+                nq[p][1] = *reinterpret_cast<const bf16x8*>(q_ptr(it + 2 + p) + 32);
+            }
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int dn = 0; dn < 4; ++dn) acc[p][dn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        branch_reg2<F16, NT, VREG>(ft, Vt, ldv, a.S, bq, a.scale, 1.0f, acc, lane);
+        if (NT_IP > 0)
+            branch_reg2<F16, (NT_IP > 0 ? NT_IP : 1), VREG>(reinterpret_cast<const kv_frag<(NT_IP > 0 ? NT_IP : 1)>&>(fi), Vip, ldv_ip, a.S_ip, bq, a.scale,
+                                                            a.ip_scale, acc, lane);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int qrow = q0 + 64 * p + fr;
+            if (qrow < a.HW) {
+                unsigned short* op = a.out + ((long long)b * a.HW + qrow) * rs + h * CA_D + 4 * g;
+#pragma unroll
+                for (int dn = 0; dn < 4; ++dn) {
+                    uint2 w;
+                    w.x = pack2<F16>(acc[p][dn][0], acc[p][dn][1]);
+                    w.y = pack2<F16>(acc[p][dn][2], acc[p][dn][3]);
+                    *reinterpret_cast<uint2*>(op + 16 * dn) = w;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace eeg
 
 using namespace eeg;
@@ -252,6 +457,21 @@ extern "C" int eegclip_cross_attn_fwd(const void* q, const void* k, const void* 
     const int ldv = ca_ldv(nt), ldv_ip = ca_ldv(nt_ip);
     const size_t lds = sizeof(unsigned short) * ((size_t)nt * 16 * CA_KLD + CA_D * ldv + (size_t)nt_ip * 16 * CA_KLD + (nt_ip ? CA_D * ldv_ip : 0));
     const dim3 grid((HW + CA_QB - 1) / CA_QB, heads, B);
+    static const bool allow_reg = !(getenv("EEGCLIP_CA_REG") && atoi(getenv("EEGCLIP_CA_REG")) == 0);        // tuning aid
+    if (allow_reg && nt == 5 && nt_ip <= 1) {            // SDXL: 77 text tokens, 0 / 4 image tokens -- K (and optionally V^T) fragments in registers
+        static const bool vreg = getenv("EEGCLIP_CA_VREG") && atoi(getenv("EEGCLIP_CA_VREG")) != 0;            // tuning aid
+        const bool f16 = dtype == EEGCLIP_DT_F16;
+#define EEG_CA_GO(F, I, V) EEG_LAUNCH((cross_attn_reg_kernel<F, 5, I, V>), grid, dim3(256), lds, stream, a)
+        if (vreg) {
+            if (nt_ip == 1) { if (f16) EEG_CA_GO(true, 1, true); else EEG_CA_GO(false, 1, true); }
+            else            { if (f16) EEG_CA_GO(true, 0, true); else EEG_CA_GO(false, 0, true); }
+        } else {
+            if (nt_ip == 1) { if (f16) EEG_CA_GO(true, 1, false); else EEG_CA_GO(false, 1, false); }
+            else            { if (f16) EEG_CA_GO(true, 0, false); else EEG_CA_GO(false, 0, false); }
+        }
+#undef EEG_CA_GO
+        return (int)hipGetLastError();
+    }
     if (dtype == EEGCLIP_DT_F16) EEG_LAUNCH((cross_attn_kernel<true>), grid, dim3(256), lds, stream, a);
     else                         EEG_LAUNCH((cross_attn_kernel<false>), grid, dim3(256), lds, stream, a);
     return (int)hipGetLastError();
