@@ -542,12 +542,18 @@ class _Engine:
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
                            rowsum_a=_p(G[bias]) if bias else None, side=True)    # nobody reads a weight gradient before the optimizer
 
+        import os
+        ln_side = os.environ.get("EEGCLIP_LN_SIDE", "1") != "0"        # tuning aid: LayerNorm parameter-gradient kernels on the second stream
         pl.memset(b["zb"])                        # BatchNorm backward sums + the split-K accumulators dgu / dfeat
         # head LayerNorm
         pl.dout_op = len(pl.ops)
         # s = u + dropout(W4 gelu(u) + b4): the LayerNorm backward writes ds and dv = ds * mask / (1 - p) in one pass
         pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
-                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
+                None, None, B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
+        # (the gamma / beta gradients of every LayerNorm are a second, independent kernel: it runs on the side stream, off the dX chain)
+        pl.dout_par_op = len(pl.ops)
+        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
+                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
         skh = _head_split(B)
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
@@ -601,12 +607,16 @@ class _Engine:
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
         pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
-                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0)
+                None, None, R, D_MODEL, 0, None, 0.0, 0, 0)
+        pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), None, _p(b["mu3"]), _p(b["rs3"]), None,
+                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, side=ln_side)
         # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2).  LN2 backward emits dr2 (residual path) and df2 = dropout'(dr2);
         # bias gradients ride on the weight-gradient GEMMs; dropout' and gelu' of the hidden activation are the epilogue of the GEMM
         # that produces its gradient -- 5 elementwise / reduction passes over (B*64, 250..256) tensors gone
         pl.call("eegclip_layernorm_bwd", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
-                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, seed_at=13)
+                None, None, R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, seed_at=13)
+        pl.call("eegclip_layernorm_bwd", _p(b["dn2"]), _p(b["r2"]), None, _p(b["mu2"]), _p(b["rs2"]), None,
+                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, side=ln_side)
         wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
         pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
                 act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT)                  # dg1 := df1
@@ -615,7 +625,9 @@ class _Engine:
                 accumulate=1)                                                                  # dr2 := dn1
         # attention block: r1 = h + dropout(Wo ctx + bo)
         pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
-                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, seed_at=13)
+                None, None, R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, seed_at=13)
+        pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), None, _p(b["mu1"]), _p(b["rs1"]), None,
+                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, side=ln_side)
         wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
               bias=_LY + "attention.out_projection.bias")
         pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1))
@@ -770,7 +782,7 @@ class _Engine:
             self.plans[pk] = self._build_bwd(B, shared, probs, want_dx)
         pl = self.plans[pk]
         self.attach_grads(shared, {s for s, _, _ in b["segs"]} if self.joint else ())
-        pl.ops[pl.dout_op][1][0] = dout.data_ptr()
+        pl.ops[pl.dout_op][1][0] = pl.ops[pl.dout_par_op][1][0] = dout.data_ptr()
         pl._keep_x = (x, dout)
         if self.joint:
             self._joint_layout(pl, b, B, None, x.data_ptr(), True)

@@ -325,9 +325,13 @@ extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const f
 extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                      float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop,
                                      float drop_p, unsigned long long seed, unsigned int site, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols < 1 || cols > 64 * LN_MAXC)
+    // either half may be left out: dx == NULL -> parameter gradients only, dgamma == dbeta == NULL -> input gradient only (the two are
+    // independent kernels; the encoder's backward runs the parameter half on its second stream, off the dX chain)
+    const bool want_dx = dx != nullptr, want_par = dgamma != nullptr || dbeta != nullptr;
+    if (!dy || !x || !mean || !rstd || (!want_dx && !want_par) || (want_par && (!dgamma || !dbeta)) || (want_dx && !gamma) || rows < 0 || cols < 1 ||
+        cols > 64 * LN_MAXC)
         return EEGCLIP_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || (!want_dx && dx_drop)) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
     const dim3 grid(grid_for(rows, 4, 8192));
     const bool vec2 = (cols % 2 == 0) && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
@@ -335,13 +339,17 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
 #define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
     EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, \
                drop_p, seed, site)
-    if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
-    else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
+    if (want_dx) {
+        if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
+        else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
+    }
 #undef EEG_LN_BWD_GO
-    int chunks = (rows + 63) / 64;              // >= 16 rows per thread before the atomics
-    if (chunks > 256) chunks = 256;
-    EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
-               dbeta, rows, cols);
+    if (want_par) {
+        int chunks = (rows + 63) / 64;              // >= 16 rows per thread before the atomics
+        if (chunks > 256) chunks = 256;
+        EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
+                   dbeta, rows, cols);
+    }
     return (int)hipGetLastError();
 }
 

@@ -83,7 +83,9 @@ int eegclip_gemm_f32_grouped(const eegclip_gemm_desc* descs, int n, void* stream
 /* ---- LayerNorm (rows of <= 1024 floats).  Transformer_EncDec.py:47,51,77-78 ; ATMS_retrieval.py:166 ; diffusion_prior.py:120,140,155
  * fwd: y = (x-mean)*rstd*gamma+beta, mean/rstd[rows] saved (may be NULL).  bwd: dx (+)= ..., dgamma/dbeta += (atomic);
  * dx_drop (optional): second output dx * mask/(1-p), mask = Philox(seed, site, row*cols+c) -- the gradient entering the
- * dropout(sublayer(.)) branch of the residual that fed this LayerNorm (Transformer_EncDec.py:45,51), saving a copy + a mask pass. */
+ * dropout(sublayer(.)) branch of the residual that fed this LayerNorm (Transformer_EncDec.py:45,51), saving a copy + a mask pass.
+ * bwd runs two independent kernels; either may be left out: dx = NULL (and gamma may then be NULL) -> parameter gradients only,
+ * dgamma = dbeta = NULL -> input gradient only. */
 int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           int rows, int cols, float eps, void* stream);
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

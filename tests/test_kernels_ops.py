@@ -40,6 +40,17 @@ def test_layernorm_fwd_bwd(be, rows, cols):
     np.testing.assert_allclose(be.host(DXD), (dx0 + xt.grad.numpy()) * keep / 0.75, atol=1e-4)
     np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
     np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
+    # the two halves on their own (the encoder's backward runs the parameter half on its second stream)
+    DX2, DG2, DB2 = be.dev(dx0), be.zeros(cols), be.zeros(cols)
+    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX2), None, None, rows, cols, 1, None, 0.0, 0, 0,
+                                    be.stream))
+    ok(be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), None, be.ptr(MU), be.ptr(RS), None, be.ptr(DG2), be.ptr(DB2), rows, cols, 0, None, 0.0, 0, 0,
+                                    be.stream))
+    assert np.array_equal(be.host(DX2), be.host(DX))
+    np.testing.assert_allclose(be.host(DG2), be.host(DG), atol=1e-4 * max(1, rows ** 0.5))         # atomics: summation order varies
+    np.testing.assert_allclose(be.host(DB2), be.host(DB), atol=1e-4 * max(1, rows ** 0.5))
+    assert be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), None, None, None, rows, cols, 0, None, 0.0, 0, 0,
+                                        be.stream) < 0
 
 
 @pytest.mark.parametrize("outer,C,inner,p", [(6, 40, 63 * 36, 0.0), (9, 40, 36, 0.5), (2, 3, 5, 0.0)])
