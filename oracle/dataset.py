@@ -50,14 +50,16 @@ def list_texts_and_images(directory, classes=None, pictures=None):
     return texts, images
 
 
-def load_split(data_path, img_dir, subjects, exclude_subject=None, train=True, time_window=(0, 1.0), classes=None, pictures=None):
-    """-> data (n, C, Tw) float32, labels (n,) int64, texts, images, times (after [50:]), ch_names"""
+def load_split(data_path, img_dir, subjects, exclude_subject=None, train=True, time_window=(0, 1.0), classes=None, pictures=None, joint=False):
+    """-> data (n, C, Tw) float32, labels (n,) int64, texts, images, times (after [50:]), ch_names
+    joint=True: Retrieval/eegdatasets_joint_subjects.py, whose `adap_subject` (passed here as exclude_subject) never drops a TRAINING subject
+    (:153-154 commented out) and selects the test subject exactly like exclude_subject does (:195)."""
     texts, images = list_texts_and_images(img_dir, classes, pictures)
     blocks, labels = [], []
     times = ch_names = None
     for sub in subjects:
         if train:
-            if sub == exclude_subject:
+            if sub == exclude_subject and not joint:
                 continue
             d = read_subject_file(os.path.join(data_path, sub, "preprocessed_eeg_training.npy"))
             eeg = d["preprocessed_eeg_data"].astype(np.float32)

@@ -3,7 +3,7 @@
 Retrieval/eegdatasets_leaveone.py:EEGDataset (imported in place; clip / open_clip / torchvision stubbed -- the cached-feature path never calls
 them) on the synthetic THINGS-EEG tree of eeg_image_decode_amd.synthetic.write_things_eeg_tree and stores OUTPUTS only:
 
-    tests/golden/dataset.npz     per configuration: len, the whole label tensor, and for a spread of indices the item tuple
+    tests/golden/dataset.npz, dataset_joint.npz (the joint-subject variant, eegdatasets_joint_subjects.py)     per configuration: len, the whole label tensor, and for a spread of indices the item tuple
                                  (EEG window, label, text, image path relative to the tree, rows of the feature tables)
 
     python tests/golden/make_golden_dataset.py
@@ -25,6 +25,13 @@ REF = "/root/reference"
 from eeg_image_decode_amd import synthetic as syn  # noqa: E402
 
 SEED = 20260927
+JOINT_CONFIGS = {
+    # Retrieval/eegdatasets_joint_subjects.py: adap_subject never drops a training subject; it selects the test subject
+    "joint_train_adapt_sub02": dict(subjects=["sub-01", "sub-02"], adap_subject="sub-02", train=True),
+    "joint_test_adapt_sub02": dict(subjects=["sub-01", "sub-02"], adap_subject="sub-02", train=False),
+    # (adap_subject=None with several subjects concatenates their test sets, but __getitem__ indexes the 200 texts with index % 16000 and
+    #  raises IndexError from item 200 on -- in both dataset modules; not a usable configuration)
+}
 CONFIGS = {
     # name: EEGDataset kwargs (data_path is filled in)
     "train_two_subjects": dict(subjects=["sub-01", "sub-02"], train=True),
@@ -52,8 +59,20 @@ def main():
         spec = importlib.util.spec_from_file_location("ref_ds", os.path.join(REF, "Retrieval", "eegdatasets_leaveone.py"))
         ref = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(ref)
+        spec = importlib.util.spec_from_file_location("ref_ds_joint", os.path.join(REF, "Retrieval", "eegdatasets_joint_subjects.py"))
+        refj = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(refj)
+        for which, (mod, configs) in {"dataset.npz": (ref, CONFIGS), "dataset_joint.npz": (refj, JOINT_CONFIGS)}.items():
+            record(mod, configs, root, os.path.join(HERE, which))
+    finally:
+        os.chdir(HERE)
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def record(ref, configs, root, path):
+    if True:
         out = {}
-        for name, kw in CONFIGS.items():
+        for name, kw in configs.items():
             ds = ref.EEGDataset(ref.data_path, **kw)
             n = len(ds)
             out[f"{name}:len"] = np.int64(n)
@@ -73,12 +92,8 @@ def main():
             if not kw["train"]:
                 out[f"{name}:data"] = ds.data.numpy()                  # the averaged test set is small: keep all of it
             out[f"{name}:data_sum"] = np.float64(ds.data.double().sum().item())
-        os.chdir(HERE)
-        np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
-        print("wrote dataset.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith(("len", "data_shape"))})
-    finally:
-        os.chdir(HERE)
-        shutil.rmtree(root, ignore_errors=True)
+        np.savez_compressed(path, **out)
+        print("wrote", os.path.basename(path), {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith(("len", "data_shape"))})
 
 
 if __name__ == "__main__":

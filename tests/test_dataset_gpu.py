@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from eeg_image_decode_amd import synthetic as syn
-from test_oracle_golden import DATASET_CONFIGS
+from test_oracle_golden import DATASET_CONFIGS, JOINT_DATASET_CONFIGS
 
 pytestmark = pytest.mark.gpu
 
@@ -18,12 +18,18 @@ def things_tree(tmp_path_factory):
     return root, syn.write_things_eeg_tree(root, 20260927)
 
 
-@pytest.mark.parametrize("name", list(DATASET_CONFIGS))
+@pytest.mark.parametrize("name", list(DATASET_CONFIGS) + list(JOINT_DATASET_CONFIGS))
 def test_device_dataset_matches_reference_fixture(name, things_tree, golden):
-    from eeg_image_decode_amd.datasets import EEGDataset
-    g = golden("dataset.npz")
+    joint = name in JOINT_DATASET_CONFIGS
+    g = golden("dataset_joint.npz" if joint else "dataset.npz")
     root, cfg = things_tree
-    kw = dict(DATASET_CONFIGS[name])
+    if joint:                                                   # Retrieval/eegdatasets_joint_subjects.py: adap_subject instead of exclude_subject
+        from eeg_image_decode_amd.datasets_joint import EEGDataset
+        kw = dict(JOINT_DATASET_CONFIGS[name])
+        kw["adap_subject"] = kw.pop("exclude_subject")
+    else:
+        from eeg_image_decode_amd.datasets import EEGDataset
+        kw = dict(DATASET_CONFIGS[name])
     train = kw["train"]
     ds = EEGDataset(cfg["data_path"], config=cfg, features_dir=root, **kw)
     assert ds.data.is_cuda and len(ds) == int(g[f"{name}:len"]) and list(ds.data.shape) == g[f"{name}:data_shape"].tolist()

@@ -252,12 +252,19 @@ def things_tree(tmp_path_factory):
     return root, syn.write_things_eeg_tree(root, 20260927)
 
 
-@pytest.mark.parametrize("name", list(DATASET_CONFIGS))
+JOINT_DATASET_CONFIGS = {
+    "joint_train_adapt_sub02": dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02", train=True),
+    "joint_test_adapt_sub02": dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02", train=False),
+}
+
+
+@pytest.mark.parametrize("name", list(DATASET_CONFIGS) + list(JOINT_DATASET_CONFIGS))
 def test_dataset_restatement_matches_reference_fixture(name, things_tree, golden):
     from oracle import dataset as ods
-    g = golden("dataset.npz")
+    joint = name in JOINT_DATASET_CONFIGS
+    g = golden("dataset_joint.npz" if joint else "dataset.npz")
     root, cfg = things_tree
-    kw = dict(DATASET_CONFIGS[name])
+    kw = dict(JOINT_DATASET_CONFIGS[name] if joint else DATASET_CONFIGS[name], joint=joint)
     train = kw.pop("train")
     data, lab, texts, images, _, _ = ods.load_split(cfg["data_path"], cfg["img_directory_training" if train else "img_directory_test"], train=train, **kw)
     assert len(data) == int(g[f"{name}:len"]) and list(data.shape) == g[f"{name}:data_shape"].tolist()

@@ -272,16 +272,25 @@ def small_things_tree(tmp_path_factory):
     return root, syn.write_things_eeg_tree(root, 7, channels=2, n_times=58, feat_dim=8)
 
 
-@pytest.mark.parametrize("train,kw", [(True, dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02")), (False, dict(subjects=["sub-02"])),
-                                      (True, dict(subjects=["sub-02", "sub-01"], time_window=[0.02, 0.05]))])
-def test_dataset_staging_and_device_loader_under_emulator_match_oracle(train, kw, small_things_tree):
+@pytest.mark.parametrize("train,kw,joint", [(True, dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02"), False),
+                                            (False, dict(subjects=["sub-02"]), False),
+                                            (True, dict(subjects=["sub-02", "sub-01"], time_window=[0.02, 0.05]), False),
+                                            (True, dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02"), True),
+                                            (False, dict(subjects=["sub-01", "sub-02"], exclude_subject="sub-02"), True)])
+def test_dataset_staging_and_device_loader_under_emulator_match_oracle(train, kw, joint, small_things_tree):
     """datasets.EEGDataset (float64 file -> eegclip_stage_eeg -> resident float32 split) and its batch loader (eegclip_gather_rows) against the
     oracle's restatement of the reference class: whole data tensor, labels, texts, image paths, item tuples and shuffled batches"""
     from oracle import dataset as ods
     root, cfg = small_things_tree
-    data, lab, texts, images, _, _ = ods.load_split(cfg["data_path"], cfg["img_directory_training" if train else "img_directory_test"], train=train, **kw)
+    data, lab, texts, images, _, _ = ods.load_split(cfg["data_path"], cfg["img_directory_training" if train else "img_directory_test"], train=train,
+                                                    joint=joint, **kw)
     with product_on_emulator():
-        from eeg_image_decode_amd.datasets import EEGDataset
+        if joint:                                     # eegdatasets_joint_subjects.py: adap_subject keeps every training subject
+            from eeg_image_decode_amd.datasets_joint import EEGDataset
+            kw = dict(kw, adap_subject=kw["exclude_subject"])
+            del kw["exclude_subject"]
+        else:
+            from eeg_image_decode_amd.datasets import EEGDataset
         ds = EEGDataset(cfg["data_path"], train=train, config=cfg, features_dir=root, device="cpu", **kw)
         assert len(ds) == len(data) and ds.text == texts and ds.img == images
         np.testing.assert_array_equal(ds.labels.numpy(), lab)
