@@ -9,7 +9,8 @@
 // Tiling (CDNA4): 64 x 64 output tile per 256-thread workgroup = 4 wavefronts in a 2x2 grid, each wave owning 32x32 as 2x2 MFMA
 // 16x16 accumulators; BK = 32 (128x128 / 128x64 tiles and an LDS double buffer were built and measured slower on every shape of
 // this path: at K ~ 250 occupancy, not per-wave reuse, hides the latency).  Global->register prefetch of k-tile t+1 overlaps the
-// MFMAs of tile t.  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile aligned: padding lives only in LDS
+// MFMAs of tile t (a second register stage -- tile t+2 in flight as well -- costs 32 VGPRs and two waves/SIMD: 94 vs 84 us on
+// 16384x744x250, measured).  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile aligned: padding lives only in LDS
 // (zeros) or in clamped addresses, never in HBM.
 #include "eeg_common.h"
 
