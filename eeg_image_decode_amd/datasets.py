@@ -52,9 +52,8 @@ def _listing(directory):
 
 
 class EEGDataset:
-    """
-    subjects = ['sub-01', 'sub-02', 'sub-05', 'sub-04', 'sub-03', 'sub-06', 'sub-07', 'sub-08', 'sub-09', 'sub-10']
-    """
+    """One split (training or test) of one or several THINGS-EEG subjects, resident in HBM; constructor, attributes and item tuple of
+    Retrieval/eegdatasets_leaveone.py:36-375 (keyword-only extras: config, features_dir, device)."""
 
     def __init__(self, data_path, exclude_subject=None, subjects=None, train=True, time_window=[0, 1.0], classes=None, pictures=None, val_size=None,
                  *, config=None, features_dir=".", device="cuda"):

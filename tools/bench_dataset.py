@@ -54,6 +54,19 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["device_loader_b256"] = {"batches": nb, "us_per_batch": round(dt / nb * 1e6, 1), "samples_per_s": round(nb * 256 / dt, 1)}
+        # the feature dump that feeds the diffusion prior (Generation notebooks: eval-mode embeddings of the whole training split)
+        from eeg_image_decode_amd import retrieval
+        from eeg_image_decode_amd.atms import ATMS
+        m = ATMS().cuda()
+        retrieval.get_eegfeatures("sub-01", m, ds.loader(batch_size=1000), "cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            feats = retrieval.get_eegfeatures("sub-01", m, ds.loader(batch_size=1000), "cuda")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["feature_dump_b1000"] = {"samples": len(ds), "ms_per_pass": round(dt / 5 * 1e3, 2), "samples_per_s": round(5 * len(ds) / dt, 1),
+                                     "whole_subject_66160_s": round(66160 / (5 * len(ds) / dt), 3)}
     finally:
         shutil.rmtree(root, ignore_errors=True)
     print(json.dumps(out))
