@@ -382,6 +382,11 @@ class _Engine:
                          (offs[_TOK_SHARED], sd_params[_TOK_SHARED].numel(), [_TOK_SHARED]),
                          (offs[dead[0]] if dead else off, off - (offs[dead[0]] if dead else off), dead)]
         self.offs = offs
+        # gradient bucket that is complete early in the backward (conv stack + projection head: 10.5 of the 12.8 MB), contiguous in the flat
+        # buffer; under data parallelism its all-reduce is started from inside the backward plan and hidden under the transformer's backward
+        a0, a1 = offs[_TS + "0.weight"], offs["proj_eeg.2.bias"] + (sd_params["proj_eeg.2.bias"].numel() + 3) // 4 * 4
+        self.early_bucket = (a0, a1)
+        self.early_work = None
         self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])
         self.buffers = dict(model.named_buffers())
         self.bufs, self.plans, self.version = {}, {}, {}
@@ -528,7 +533,7 @@ class _Engine:
         return pl
 
     # ---- backward plan -----------------------------------------------------------------------------------------
-    def _build_bwd(self, B, shared, probs, want_dx):
+    def _build_bwd(self, B, shared, probs, want_dx, early_reduce=False):
         P, G, b = self.P, self.G, self.bufs[B]
         pe_, pc_, pp_ = probs
         pl = Plan(f"atms_bwd[B={B}]")
@@ -604,6 +609,10 @@ class _Engine:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
                 C_TS, side=True)
+        if early_reduce:
+            # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
+            # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
+            pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
         pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
@@ -676,6 +685,11 @@ class _Engine:
     def _allreduce(t):
         import torch.distributed as dist
         dist.all_reduce(t)
+
+    def _start_early_reduce(self):
+        import torch.distributed as dist
+        a0, a1 = self.early_bucket
+        self.early_work = dist.all_reduce(self.gflat[a0:a1], op=dist.ReduceOp.SUM, async_op=True)
 
     # ---- execution -----------------------------------------------------------------------------------------------
     def _joint_layout(self, pl, b, B, host_ids, x_ptr, backward):
@@ -777,9 +791,10 @@ class _Engine:
         b = self.bufs[B]
         if "ds" not in b:
             self._alloc_bwd(B, b)
-        pk = ("b", B, shared, probs, want_dx, W)
+        early = bool(getattr(self.model, "overlap_grad_allreduce", False)) and W > 1
+        pk = ("b", B, shared, probs, want_dx, W, early)
         if pk not in self.plans:
-            self.plans[pk] = self._build_bwd(B, shared, probs, want_dx)
+            self.plans[pk] = self._build_bwd(B, shared, probs, want_dx, early)
         pl = self.plans[pk]
         self.attach_grads(shared, {s for s, _, _ in b["segs"]} if self.joint else ())
         pl.ops[pl.dout_op][1][0] = pl.ops[pl.dout_par_op][1][0] = dout.data_ptr()

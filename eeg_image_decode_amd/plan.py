@@ -63,9 +63,11 @@ class Plan:
         self.ops.append((self.L.eegclip_gemm_f32_grouped, [arr, 0, None], "eegclip_gemm_f32_grouped", side))
         return arr, len(self.ops) - 1
 
-    def callback(self, fn, name="callback"):
-        """run a host callable in stream order (collectives between kernels: SyncBN statistics)"""
-        self.ops.append((None, [fn], name, False))
+    def callback(self, fn, name="callback", side=False):
+        """run a host callable in stream order (collectives between kernels: SyncBN statistics).  side=True: the callable runs with the plan's
+        second stream current, behind everything enqueued on both streams so far (an asynchronous collective over gradients that kernels of
+        either stream have produced)"""
+        self.ops.append((None, [fn], name, side))
 
     def memset(self, tensor):
         """zero a torch tensor as part of the plan (stream-ordered)"""
@@ -117,6 +119,13 @@ class Plan:
                         side[2].record(side[0])
                         ts.wait_event(side[2])
                         dirty = False
+                elif use_side:
+                    ev = side[1][idx]
+                    ev.record(ts)
+                    side[0].wait_event(ev)
+                    with torch.cuda.stream(side[0]):
+                        args[0]()
+                    dirty = True
                 else:
                     args[0]()
             else:

@@ -88,6 +88,8 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
     from . import dist as edist
     optimizer.zero_grad()
+    if edist.world_size() > 1 and hasattr(eeg_model, "_engine") and os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0":
+        eeg_model.overlap_grad_allreduce = True          # one backward per step here: its early gradient bucket may be reduced while it still runs
     batch_size = eeg_data.size(0)
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
     eeg_features = eeg_model(eeg_data, subject_ids).float()
@@ -112,7 +114,7 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
         loss = alpha * loss_func(eeg_features, img_features, logit_scale) + (1 - alpha) * loss_func(eeg_features, text_features, logit_scale)
     loss.backward()
     if edist.world_size() > 1:
-        edist.average_flat_grads(eeg_model.flat_parameters()[1])
+        edist.average_flat_grads(eeg_model.flat_parameters()[1], eeg_model._engine() if hasattr(eeg_model, "_engine") else None)
     if side is not None:
         main.wait_stream(side)             # join BEFORE the optimizer rewrites logit_scale, which the readout's ranking kernel reads
     else:

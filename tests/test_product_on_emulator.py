@@ -181,6 +181,10 @@ def _dp_worker(rank, world, port, ret):
         classes = T(syn.unit_features(SEED + 42, 7, tag="cls"))
         retrieval.contrastive_step(m, opt, x_all[sl].contiguous(), 1, img_all[sl].contiguous(), txt_all[sl].contiguous(),
                                    torch.zeros(n, dtype=torch.long), classes, loss_acc, correct)
+        eng = m._engine()
+        # the conv-stack + head gradient bucket was all-reduced from INSIDE the backward plan (asynchronously) and collected afterwards
+        early = [pl for k, pl in eng.plans.items() if k[0] == "b" and "allreduce_early_bucket" in pl.op_names()]
+        assert bool(early) == (os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0") and eng.early_work is None
         ret[rank] = ({k: p.detach().clone().numpy() for k, p in m.named_parameters()}, float(loss_acc),
                      {k: v.clone().numpy() for k, v in m.state_dict().items() if "running" in k})
     dist.destroy_process_group()
