@@ -330,6 +330,12 @@ def _p(t):
     return t.data_ptr()
 
 
+def _dp_world():
+    """ranks that share the parameters (1 without torch.distributed)"""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def _head_split(B):
     """split-K factor of the projection-head GEMMs (M = B is small: a 4 x 16 tile grid cannot fill 256 CUs).  Every slice adds its
     partial tile with atomics, so the factor trades workgroups against B * 1024 * split float atomics."""
@@ -767,8 +773,7 @@ class _Engine:
         buffer if the optimizer cleared the grads (zero_grad(set_to_none=True) is torch's default)."""
         live = self.live_base + [_TOK_SHARED if shared else _TOK_TABLE]
         if self.joint:
-            import torch.distributed as dist
-            everyone = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1     # ranks must step the same parameters
+            everyone = _dp_world() > 1     # ranks must step the same parameters
             live = live + [k for s in (range(self.n_subj) if everyone else sorted(subjects)) for k in self.ve_keys[s]]
         mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
         if all(mine(k) for k in live):
@@ -791,7 +796,7 @@ class _Engine:
         b = self.bufs[B]
         if "ds" not in b:
             self._alloc_bwd(B, b)
-        early = bool(getattr(self.model, "overlap_grad_allreduce", False)) and W > 1
+        early = bool(getattr(self.model, "overlap_grad_allreduce", False)) and _dp_world() > 1
         pk = ("b", B, shared, probs, want_dx, W, early)
         if pk not in self.plans:
             self.plans[pk] = self._build_bwd(B, shared, probs, want_dx, early)

@@ -379,3 +379,45 @@ def test_joint_subject_large_mixed_batch_equals_per_subject_passes():
             sel = (ids == s).nonzero().flatten().cuda()
             if len(sel):
                 np.testing.assert_allclose(m(x[sel].contiguous(), s).cpu().numpy(), z[sel].cpu().numpy(), atol=2e-5)
+
+
+def test_early_gradient_bucket_allreduce_runs_on_rccl(monkeypatch):
+    """mechanism check on the real backend: a 1-rank "nccl" (= RCCL) process group, the engine told it is one of two ranks, so the backward
+    plan takes the data-parallel route -- the early gradient bucket all-reduced asynchronously from the plan's second stream, the remainder
+    afterwards.  With one real rank every collective is the identity, so only the 1/W scaling differs: the step must leave exactly half the
+    single-process gradient."""
+    import os
+    import torch.distributed as dist
+    from eeg_image_decode_amd import atms, dist as edist, optim, retrieval
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29741")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        state_np = syn.make_state(SEED, oatms.state_spec())
+        B = 8
+        x = T(syn.eeg_batch(SEED + 50, B)).cuda()
+        img, txt = T(syn.unit_features(SEED + 50, B, tag="img")).cuda(), T(syn.unit_features(SEED + 50, B, tag="txt")).cuda()
+        labels, classes = torch.zeros(B, dtype=torch.long, device="cuda"), T(syn.unit_features(SEED + 51, 7, tag="cls")).cuda()
+        grads = []
+        for fake_world in (1, 2):
+            m = make_model(state_np)
+            zero_dropout(m)
+            m.train()
+            opt = optim.AdamW(m.parameters(), lr=0.0)                      # lr 0: the step leaves the gradients in place for inspection
+            if fake_world == 2:
+                monkeypatch.setattr(edist, "world_size", lambda: 2)
+                monkeypatch.setattr(atms, "_dp_world", lambda: 2)
+            loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+            retrieval.contrastive_step(m, opt, x, 1, img, txt, labels, classes, loss_acc, correct)
+            torch.cuda.synchronize()
+            eng = m._engine()
+            if fake_world == 2:
+                assert any("allreduce_early_bucket" in pl.op_names() for k, pl in eng.plans.items() if k[0] == "b") and eng.early_work is None
+            grads.append(eng.gflat.clone())
+        assert torch.isfinite(grads[1]).all() and (grads[0].abs() > 0).any()
+        g0, g1 = grads[0].cpu().numpy(), grads[1].cpu().numpy()
+        np.testing.assert_allclose(g1, 0.5 * g0, atol=2e-5 * float(np.abs(g0).max()))            # (atomics: summation order varies run to run)
+    finally:
+        dist.destroy_process_group()
