@@ -417,6 +417,16 @@ def test_early_gradient_bucket_allreduce_runs_on_rccl(monkeypatch):
                 assert any("allreduce_early_bucket" in pl.op_names() for k, pl in eng.plans.items() if k[0] == "b") and eng.early_work is None
             grads.append(eng.gflat.clone())
         assert torch.isfinite(grads[1]).all() and (grads[0].abs() > 0).any()
+        # the SyncBN route as well (float64 statistics all-reduced from plan callbacks, forward and backward): told W = 2 the batch count is
+        # doubled, so the numbers are not the single-process ones -- this only checks that the collectives run on RCCL and stay finite
+        monkeypatch.setattr(atms._Engine, "_world", lambda self: 2)
+        m = make_model(state_np).train()
+        opt = optim.AdamW(m.parameters(), lr=0.0)
+        loss_acc = torch.zeros((), device="cuda")
+        retrieval.contrastive_step(m, opt, x, 1, img, txt, labels, classes, loss_acc, correct)
+        torch.cuda.synchronize()
+        assert any("allreduce_bn1" in pl.op_names() for pl in m._engine().plans.values())
+        assert torch.isfinite(m._engine().gflat).all() and np.isfinite(float(loss_acc))
         g0, g1 = grads[0].cpu().numpy(), grads[1].cpu().numpy()
         np.testing.assert_allclose(g1, 0.5 * g0, atol=2e-5 * float(np.abs(g0).max()))            # (atomics: summation order varies run to run)
     finally:
