@@ -431,3 +431,41 @@ def test_early_gradient_bucket_allreduce_runs_on_rccl(monkeypatch):
         np.testing.assert_allclose(g1, 0.5 * g0, atol=2e-5 * float(np.abs(g0).max()))            # (atomics: summation order varies run to run)
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_batch_rows_are_independent_in_eval_mode(state_np):
+    """BASELINE configs[1] size (and beyond) through a size-independent property: in eval mode every sample is independent, so a 1024-sample
+    batch must reproduce the rows of 8-sample batches (the oracle takes minutes at this size; it pins the small batches above)"""
+    m = make_model(state_np).eval()
+    x = T(syn.eeg_batch(SEED + 60, 1024)).cuda()
+    with torch.no_grad():
+        big = m(x, 1).clone()
+        for i0 in (0, 504, 1016):
+            small = m(x[i0:i0 + 8].contiguous(), 1)
+            np.testing.assert_allclose(big[i0:i0 + 8].cpu().numpy(), small.cpu().numpy(), atol=2e-5)
+        z256 = m(x[:256].contiguous(), 1)
+        np.testing.assert_allclose(big[:256].cpu().numpy(), z256.cpu().numpy(), atol=2e-5)
+
+
+def test_clip_loss_at_global_batch_2048_matches_torch_fp32_and_its_gradients():
+    """BASELINE configs[2] size (8 x 256 gathered): value, d/dz, d/dscale against a plain torch fp32 evaluation of models/loss.py:122-140 on
+    the GPU (the CPU oracle pins N = 32 / 256 through the reference fixtures)"""
+    from eeg_image_decode_amd.loss import ClipLoss
+    N, Dm = 2048, 1024
+    a0 = T(syn.unit_features(SEED + 61, N, Dm, tag="a")).cuda()
+    b0 = T(syn.unit_features(SEED + 61, N, Dm, tag="b")).cuda()
+    outs = []
+    for ours in (True, False):
+        a = (a0 * 3.0).clone().requires_grad_()
+        sc = torch.tensor(2.6593, device="cuda", requires_grad=True)
+        if ours:
+            loss = ClipLoss()(a, b0, sc)
+        else:
+            logits = sc * a @ b0.T
+            lab = torch.arange(N, device="cuda")
+            loss = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.T, lab))
+        loss.backward()
+        outs.append((float(loss.detach()), a.grad.clone(), float(sc.grad)))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-4 * abs(outs[1][0])
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), atol=2e-3 * float(outs[1][1].abs().max()))
+    assert abs(outs[0][2] - outs[1][2]) < 2e-3 * abs(outs[1][2]) + 1e-6
