@@ -469,3 +469,42 @@ def test_clip_loss_at_global_batch_2048_matches_torch_fp32_and_its_gradients():
     assert abs(outs[0][0] - outs[1][0]) < 1e-4 * abs(outs[1][0])
     np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), atol=2e-3 * float(outs[1][1].abs().max()))
     assert abs(outs[0][2] - outs[1][2]) < 2e-3 * abs(outs[1][2]) + 1e-6
+
+
+def test_retrieval_accuracy_after_training_matches_the_oracle():
+    """north_star: top-1 / top-5 retrieval accuracy on held-out synthetic pairs.  A short version of tools/accuracy_parity.py (whose full run --
+    150 steps, identical accuracies for every k, profiles/r1_accuracy_parity.json -- takes two minutes of host time): same weights, same
+    batches, dropout off; after 40 AdamW steps the held-out 200-way scores of the HIP path and of the CPU oracle must agree."""
+    from eeg_image_decode_amd import optim, retrieval
+    n_train, per, n_test, B, steps = 400, 2, 200, 64, 40
+    eeg, lab, protos = syn.learnable_pairs(5, n_train + n_test, per, noise=0.5)
+    tr = lab < n_train
+    xtr, ltr = T(eeg[tr]), T(lab[tr])
+    xte = T(eeg[~tr].reshape(n_test, per, 63, 250).mean(1))
+    p_tr, p_te = T(protos[:n_train]), T(protos[n_train:])
+    state_np = syn.make_state(1, oatms.state_spec())
+    rng = np.random.default_rng(0)
+    batches = [rng.permutation(len(xtr))[:B] for _ in range(steps)]
+    m = make_model(state_np)
+    zero_dropout(m)
+    m.train()
+    opt = optim.AdamW(m.parameters(), lr=3e-4)
+    loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    xg, pg, lg = xtr.cuda(), p_tr.cuda(), ltr.cuda()
+    for idx in batches:
+        i = T(idx).cuda()
+        retrieval.contrastive_step(m, opt, xg[i].contiguous(), 1, pg[lg[i]], pg[lg[i]], lg[i], pg, loss_acc, correct)
+    tr_o = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
+    for idx in batches:
+        tr_o.step(xtr[idx], torch.full((B,), 1).long(), p_tr[ltr[idx]], p_tr[ltr[idx]])
+    with torch.no_grad():
+        zg = m.eval()(xte.cuda(), 1).cpu()
+    zo = oatms.atms_forward(tr_o.P, xte, torch.full((n_test,), 1).long(), train=False)
+    assert float(torch.nn.functional.cosine_similarity(zg, zo).min()) > 0.9999
+    tg, to = (zg @ p_te.T).topk(5, 1).indices, (zo @ p_te.T).topk(5, 1).indices
+    want = torch.arange(n_test)
+    acc = lambda t: (float((t[:, 0] == want).float().mean()), float((t == want[:, None]).any(1).float().mean()))
+    (g1, g5), (o1, o5) = acc(tg), acc(to)
+    assert o5 > 3 * 5 / n_test                                    # the model has learnt something: well above the 2.5 % chance level
+    assert abs(g1 - o1) <= 1.0 / n_test + 1e-9 and abs(g5 - o5) <= 1.0 / n_test + 1e-9, ((g1, g5), (o1, o5))
+    assert int((tg[:, 0] != to[:, 0]).sum()) <= 2
