@@ -23,7 +23,9 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        # EEGCLIP_DIST_BACKEND=gloo: several ranks on ONE GPU (functional check of the data-parallel step where RCCL would refuse duplicate devices)
+        backend = backend or os.environ.get("EEGCLIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

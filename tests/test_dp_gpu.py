@@ -1,0 +1,78 @@
+"""The data-parallel step with the REAL HIP kernels and two processes: both ranks share the one GPU of the test box through the gloo backend
+(RCCL refuses duplicate devices), so everything but the transport is the production path -- all-gathered negatives + reduce-scattered
+embedding gradients in ClipLoss, SyncBN statistics all-reduced from inside the launch plans, the early gradient bucket reduced asynchronously
+from the backward plan's second stream, the remainder after it.  Result must equal ONE process stepping on the global batch (the oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import SEED
+from eeg_image_decode_amd import synthetic as syn
+from oracle import atms as oatms
+from oracle import loops as oloops
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), str(rank), str(world)
+    os.environ["EEGCLIP_DIST_BACKEND"] = "gloo"
+    from eeg_image_decode_amd import dist as edist
+    from eeg_image_decode_amd import optim, retrieval
+    from eeg_image_decode_amd.atms import ATMS
+    edist.init_from_env()
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    x_all = T(syn.eeg_batch(SEED + 41, n * world)).cuda()
+    img_all = T(syn.unit_features(SEED + 41, n * world, tag="img")).cuda()
+    txt_all = T(syn.unit_features(SEED + 41, n * world, tag="txt")).cuda()
+    sl = slice(rank * n, (rank + 1) * n)
+    m = ATMS()
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state_np.items()})
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m = m.cuda().train()
+    edist.configure_loss_for_world(m.loss_func, rank, world)
+    opt = optim.AdamW(m.parameters(), lr=3e-4)
+    loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    classes = T(syn.unit_features(SEED + 42, 7, tag="cls")).cuda()
+    retrieval.contrastive_step(m, opt, x_all[sl].contiguous(), 1, img_all[sl].contiguous(), txt_all[sl].contiguous(),
+                               torch.zeros(n, dtype=torch.long, device="cuda"), classes, loss_acc, correct)
+    torch.cuda.synchronize()
+    eng = m._engine()
+    early = any("allreduce_early_bucket" in pl.op_names() for k, pl in eng.plans.items() if k[0] == "b")
+    ret[rank] = ({k: p.detach().cpu().numpy() for k, p in m.named_parameters()}, float(loss_acc), early,
+                 {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k})
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_global_batch_step():
+    world, n = 2, 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29747, n, ret), nprocs=world, join=True)
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    x_all = T(syn.eeg_batch(SEED + 41, n * world))
+    img_all, txt_all = T(syn.unit_features(SEED + 41, n * world, tag="img")), T(syn.unit_features(SEED + 41, n * world, tag="txt"))
+    tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
+    lo, _ = tr.step(x_all, torch.full((n * world,), 1).long(), img_all, txt_all)
+    (p0, l0, e0, bn0), (p1, l1, e1, _) = ret[0], ret[1]
+    assert e0 and e1                                                     # the asynchronous early-bucket route was taken
+    assert abs(0.5 * (l0 + l1) - float(lo)) < 1e-4
+    for k in p0:
+        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)          # ranks stay bit-identical
+        if k in oloops.ZERO_GRAD_KEYS or tr.P[k].shape != p0[k].shape:
+            continue
+        d = np.abs(p0[k] - tr.P[k].numpy())
+        assert d.mean() < 6e-6 and d.max() <= 6.1e-4, (k, d.mean(), d.max())       # Adam step 1 = lr * sign(g): round-off-sized g may flip
+    for k in bn0:
+        np.testing.assert_allclose(bn0[k], tr.P[k].numpy(), atol=2e-5, err_msg=k)
