@@ -39,6 +39,7 @@ PROTOTYPES = {
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
     "eegclip_gemm_f32_grouped": [_P, _I, _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "eegclip_residual_layernorm_fwd": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P],
     "eegclip_layernorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_silu_bwd": [_P, _P, _P, _L, _I, _F, _U64, _U, _P],

@@ -480,20 +480,21 @@ class _Engine:
                 _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]))
         pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
                 SITE_ATTN, seed_at=9)
+        # (dropout + residual of both sublayers live in the LayerNorm kernel that follows, not in the GEMM epilogue: one Philox block per 4
+        #  consecutive columns there, one per ELEMENT in an MFMA accumulator layout -- 12 us per GEMM)
         pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
-                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), drop_p=pe_, drop_site=SITE_ATTN_OUT,
-                R=_p(b["h"]), Rm=D(D_MODEL), Rn=D(1))
+                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]))
         # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
-        pl.call("eegclip_layernorm_fwd", _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]),
-                _p(b["rs1"]), R, D_MODEL, EPS)
+        pl.call("eegclip_residual_layernorm_fwd", _p(b["r1"]), _p(b["h"]), _p(b["r1"]), pe_, 0, SITE_ATTN_OUT, _p(P[_LY + "norm1.weight"]),
+                _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]), _p(b["rs1"]), None, None, None, None, None, R, D_MODEL, EPS, seed_at=4)
         pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
                 Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT)
         pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
-                bias_n=_p(P[_LY + "conv2.bias"]), drop_p=pe_, drop_site=SITE_FFN_OUT, R=_p(b["n1"]), Rm=D(D_MODEL), Rn=D(1))
-        pl.call("eegclip_layernorm_fwd", _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]),
-                _p(b["rs2"]), R, D_MODEL, EPS)
-        pl.call("eegclip_layernorm_fwd", _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]),
-                _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS)
+                bias_n=_p(P[_LY + "conv2.bias"]))
+        # norm2 and the encoder's final norm back to back in one launch
+        pl.call("eegclip_residual_layernorm_fwd", _p(b["r2"]), _p(b["n1"]), _p(b["r2"]), pe_, 0, SITE_FFN_OUT, _p(P[_LY + "norm2.weight"]),
+                _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]), _p(b["rs2"]), _p(P["encoder.encoder.norm.weight"]),
+                _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
         pl.memset(b["zf"])

@@ -50,6 +50,135 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// Residual + LayerNorm, the post-LN sublayer tail of the encoder (Transformer_EncDec.py:45-51):  v = resid + dropout(x);  y = LN(v)
+// [;  y2 = LN2(y): the layer's norm2 followed directly by the encoder's final norm, :77-78].  The dropout and the residual used to be
+// the epilogue of the GEMM that produces x; there every output element costs a whole Philox block (a lane's 16 accumulator values
+// sit in 16 different blocks: +12 us on a 32 us GEMM), here a lane owns 4 consecutive columns and one block serves all four.
+// Same mask (Philox(seed, site, row * cols + c)) and the same arithmetic order, so results are bit-identical to the epilogue form.
+template <int NG, bool VEC2, bool DOUBLE>
+__global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                                      float* __restrict__ x_out, float drop_p, unsigned long long seed, unsigned site,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                      const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                                      float* __restrict__ y2, float* __restrict__ mean2_out, float* __restrict__ rstd2_out,
+                                                                      int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
+        if (VEC2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = c + 2 * h < cols;
+                const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
+                v[2 * h] = t[0];
+                v[2 * h + 1] = t[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = c + e < cols ? p[c + e] : 0.f;
+        }
+    };
+    auto st4 = [&](float* p, int c, const float (&v)[4]) {
+        if (VEC2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (c + 2 * h < cols) *reinterpret_cast<f32x2*>(p + c + 2 * h) = f32x2{v[2 * h], v[2 * h + 1]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cols) p[c + e] = v[e];
+        }
+    };
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const unsigned long long rbase = (unsigned long long)row * cols;
+        const unsigned off = (unsigned)(rbase & 3ull);            // wave-uniform misalignment of this row against the Philox blocks
+        float v[NG][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            ld4(x + rbase, c, v[i]);
+            if (resid) {
+                float rv[4];
+                ld4(resid + rbase, c, rv);
+                bool keep[4] = {true, true, true, true};
+                if (drop_p > 0.f && c < cols) {
+                    bool k0[4], k1[4];
+                    dropout_keep4(seed, site, rbase + c - off, drop_p, k0);
+                    if (off) dropout_keep4(seed, site, rbase + c - off + 4, drop_p, k1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keep[e] = (off + e < 4) ? k0[(off + e) & 3] : k1[(off + e) & 3];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = v[i][e];
+                    if (drop_p > 0.f) d = keep[e] ? d * keep_scale : 0.f;
+                    v[i][e] = c + e < cols ? d + rv[e] : 0.f;
+                }
+                if (x_out) st4(x_out + rbase, c, v[i]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += v[i][e];
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = 256 * i + 4 * lane + e < cols ? v[i][e] - mean : 0.f;
+                q += dlt * dlt;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            float gv[4], bv[4];
+            ld4(gamma, c, gv);
+            ld4(beta, c, bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = c + e < cols ? (v[i][e] - mean) * rstd * gv[e] + bv[e] : 0.f;
+                s2 += v[i][e];
+            }
+            st4(y + rbase, c, v[i]);
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        if (DOUBLE) {
+            const float m2 = wave_sum(s2) * inv;
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = 256 * i + 4 * lane + e < cols ? v[i][e] - m2 : 0.f;
+                    q2 += dlt * dlt;
+                }
+            const float r2 = rsqrtf(wave_sum(q2) * inv + eps);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int c = 256 * i + 4 * lane;
+                float gv[4], bv[4], o[4];
+                ld4(gamma2, c, gv);
+                ld4(beta2, c, bv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - m2) * r2 * gv[e] + bv[e];
+                st4(y2 + rbase, c, o);
+            }
+            if (lane == 0) {
+                if (mean2_out) mean2_out[row] = m2;
+                if (rstd2_out) rstd2_out[row] = r2;
+            }
+        }
+    }
+}
+
 // backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   [+ dx_drop = dropout'(dx)]
 // One wave per row, one row per wave.  Lane l owns the 4 CONSECUTIVE columns 256 i + 4 l .. + 3 of every 256-column group: 8-byte
 // accesses, and the dropout mask of a lane's 4 elements comes from one Philox block (two when row * cols is not a multiple of 4 --
@@ -319,6 +448,34 @@ extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const f
     const int grid = grid_for(rows, 4, 8192);
     if (cols <= 256) EEG_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
     else             EEG_LAUNCH(layernorm_fwd_kernel<LN_MAXC>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
+                                              unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                              const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
+                                              float eps, void* stream) {
+    const bool dbl = gamma2 != nullptr;
+    if (!x || !gamma || !beta || !y || rows < 0 || cols < 1 || cols > 64 * LN_MAXC || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if ((x_out || drop_p > 0.f) && !resid) return EEGCLIP_EINVAL;
+    if (dbl && (!beta2 || !y2)) return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const int grid = grid_for(rows, 4, 8192);
+    const bool vec2 = (cols % 2 == 0) &&
+                      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(x_out) |
+                         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2) | reinterpret_cast<uintptr_t>(y2)) & 7u);
+#define EEG_RLN_GO(NG, V2, DB)                                                                                                              \
+    EEG_LAUNCH((residual_layernorm_fwd_kernel<NG, V2, DB>), dim3(grid), dim3(256), 0, stream, x, resid, x_out, drop_p, seed, site, gamma, beta, y, \
+               mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps)
+    if (cols <= 256) {
+        if (vec2) { if (dbl) EEG_RLN_GO(1, true, true); else EEG_RLN_GO(1, true, false); }
+        else      { if (dbl) EEG_RLN_GO(1, false, true); else EEG_RLN_GO(1, false, false); }
+    } else {
+        if (vec2) { if (dbl) EEG_RLN_GO(4, true, true); else EEG_RLN_GO(4, true, false); }
+        else      { if (dbl) EEG_RLN_GO(4, false, true); else EEG_RLN_GO(4, false, false); }
+    }
+#undef EEG_RLN_GO
     return (int)hipGetLastError();
 }
 

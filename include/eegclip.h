@@ -88,6 +88,12 @@ int eegclip_gemm_f32_grouped(const eegclip_gemm_desc* descs, int n, void* stream
  * dgamma = dbeta = NULL -> input gradient only. */
 int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           int rows, int cols, float eps, void* stream);
+/* the post-LN sublayer tail in one pass (Transformer_EncDec.py:45-51,77-78): v = resid + dropout(x) (resid NULL: v = x), x_out = v (optional, may
+ * alias x), y = LN(v; gamma, beta), and optionally a second LayerNorm of y straight after (gamma2 != NULL: y2 = LN(y; gamma2, beta2) -- the
+ * layer's norm2 followed by the encoder's final norm).  Mask = Philox(seed, site, row*cols + c): identical to the GEMM dropout epilogue. */
+int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed, unsigned int site,
+                                   const float* gamma, const float* beta, float* y, float* mean, float* rstd, const float* gamma2,
+                                   const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols, float eps, void* stream);
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p,
                           unsigned long long seed, unsigned int site, void* stream);

@@ -53,6 +53,41 @@ def test_layernorm_fwd_bwd(be, rows, cols):
                                         be.stream) < 0
 
 
+@pytest.mark.parametrize("rows,cols,p,double", [(5, 250, 0.25, True), (130, 250, 0.25, False), (7, 64, 0.0, True), (3, 1024, 0.5, False), (4, 7, 0.25, True)])
+def test_residual_layernorm_fwd(be, rows, cols, p, double):
+    """v = resid + dropout(x) -> x_out (in place over x); y = LN(v); optionally y2 = LN2(y): the encoder's post-LN sublayer tail with the
+    dropout mask of the GEMM epilogue it replaces (Philox(seed, site, row*cols + c))"""
+    rng = np.random.default_rng(rows + cols)
+    x, r = rnd(rng, rows, cols), rnd(rng, rows, cols)
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(rng, cols), 0.1 * rnd(rng, cols), 1 + 0.1 * rnd(rng, cols), 0.1 * rnd(rng, cols)
+    X, Rz, G1, B1, G2, B2 = be.dev(x), be.dev(r), be.dev(g1), be.dev(b1), be.dev(g2), be.dev(b2)
+    Y, Y2, MU, RS, MU2, RS2 = be.zeros((rows, cols)), be.zeros((rows, cols)), be.zeros(rows), be.zeros(rows), be.zeros(rows), be.zeros(rows)
+    ok(be.lib.eegclip_residual_layernorm_fwd(be.ptr(X), be.ptr(Rz), be.ptr(X), p, SEED, 6, be.ptr(G1), be.ptr(B1), be.ptr(Y), be.ptr(MU), be.ptr(RS),
+                                             be.ptr(G2) if double else None, be.ptr(B2) if double else None, be.ptr(Y2) if double else None,
+                                             be.ptr(MU2) if double else None, be.ptr(RS2) if double else None, rows, cols, 1e-5, be.stream))
+    keep = keep_mask(SEED, 6, rows * cols, p).reshape(rows, cols) if p > 0 else np.ones((rows, cols), bool)
+    ks = np.float32(1.0) / (np.float32(1.0) - np.float32(p))               # the kernels multiply by the fp32 reciprocal
+    v = np.where(keep, x * ks, np.float32(0)).astype(np.float32) + r
+    assert np.array_equal(be.host(X), v)                                   # same arithmetic order as the GEMM epilogue: bit exact
+    vt = torch.tensor(v, dtype=torch.float64)
+    y = F.layer_norm(vt, (cols,), torch.tensor(g1, dtype=torch.float64), torch.tensor(b1, dtype=torch.float64), 1e-5)
+    np.testing.assert_allclose(be.host(Y), y.numpy(), atol=3e-5)
+    np.testing.assert_allclose(be.host(MU), v.astype(np.float64).mean(1), atol=1e-5)
+    np.testing.assert_allclose(be.host(RS), 1 / np.sqrt(v.astype(np.float64).var(1) + 1e-5), rtol=1e-4)
+    if double:
+        y2 = F.layer_norm(y, (cols,), torch.tensor(g2, dtype=torch.float64), torch.tensor(b2, dtype=torch.float64), 1e-5)
+        np.testing.assert_allclose(be.host(Y2), y2.numpy(), atol=5e-5)
+        np.testing.assert_allclose(be.host(MU2), y.numpy().mean(1), atol=2e-5)
+    # plain LayerNorm form (no residual) and argument errors
+    Y3 = be.zeros((rows, cols))
+    ok(be.lib.eegclip_residual_layernorm_fwd(be.ptr(Rz), None, None, 0.0, 0, 0, be.ptr(G1), be.ptr(B1), be.ptr(Y3), None, None, None, None, None, None, None,
+                                             rows, cols, 1e-5, be.stream))
+    y3 = F.layer_norm(torch.tensor(r, dtype=torch.float64), (cols,), torch.tensor(g1, dtype=torch.float64), torch.tensor(b1, dtype=torch.float64), 1e-5)
+    np.testing.assert_allclose(be.host(Y3), y3.numpy(), atol=3e-5)
+    assert be.lib.eegclip_residual_layernorm_fwd(be.ptr(Rz), None, None, 0.25, 0, 0, be.ptr(G1), be.ptr(B1), be.ptr(Y3), None, None, None, None, None,
+                                                 None, None, rows, cols, 1e-5, be.stream) < 0
+
+
 @pytest.mark.parametrize("outer,C,inner,p", [(6, 40, 63 * 36, 0.0), (9, 40, 36, 0.5), (2, 3, 5, 0.0)])
 def test_batchnorm_elu_train_fwd_bwd(be, outer, C, inner, p):
     rng = np.random.default_rng(outer + C + inner)
