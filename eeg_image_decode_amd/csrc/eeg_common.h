@@ -238,6 +238,24 @@ __device__ __forceinline__ void dropout_keep_quad(unsigned long long seed, unsig
     for (int t = 0; t < 4; ++t) keep[t] = (float)(bits[t] >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// the same trade for four elements that share the quad's lane-in-quad word: lane j hands in the Philox block of ITS element t = j
+// (`my_block`), gets back keep[t] = decision of word j in the block lane t handed in.  (GEMM epilogue: a lane's 4 accumulator rows at one
+// column; with N % 4 == 0 the four lanes of a quad sit in the same block of every row.)
+__device__ __forceinline__ void dropout_keep_quad_blocks(unsigned long long seed, unsigned site, unsigned long long my_block, int j, float p,
+                                                         bool (&keep)[4]) {
+    const philox4 r = philox4x32_10(seed, my_block, site);
+    unsigned bits[4];
+#define EEG_QUAD_PICK(T)                                                                                      \
+    {                                                                                                         \
+        const unsigned x = quad_bcast<T>(r.x), y = quad_bcast<T>(r.y), z = quad_bcast<T>(r.z), w = quad_bcast<T>(r.w); \
+        bits[T] = j == 0 ? x : j == 1 ? y : j == 2 ? z : w;                                                   \
+    }
+    EEG_QUAD_PICK(0) EEG_QUAD_PICK(1) EEG_QUAD_PICK(2) EEG_QUAD_PICK(3)
+#undef EEG_QUAD_PICK
+#pragma unroll
+    for (int t = 0; t < 4; ++t) keep[t] = (float)(bits[t] >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -38,8 +38,10 @@ __device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
 //   plain stride C, nothing but (bias_n, accumulate): pointer-bump stores
 //   everything else: the general form
 // the general form for one output element: v = alpha * acc on entry
+// keep_known: -1 = evaluate the dropout mask here, 0 / 1 = the caller already has this element's decision (quad-shared Philox blocks)
 template <bool PLAIN>
-__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, bool first_slice, float keep_scale) {
+__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, bool first_slice, float keep_scale,
+                                                      int keep_known = -1) {
     if (first_slice) {
         if (d.bias_n) v += d.bias_n[n];
         if (d.bias_m) v += d.bias_m[m];
@@ -52,8 +54,10 @@ __device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d
     if (d.Cpre) d.Cpre[coff] = v;
     if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
     else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
-    if (d.drop_p > 0.f)
-        v = dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p) ? v * keep_scale : 0.f;
+    if (d.drop_p > 0.f) {
+        const bool keep = keep_known >= 0 ? keep_known != 0 : dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p);
+        v = keep ? v * keep_scale : 0.f;
+    }
     if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)]);
     else if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
     if (d.accumulate) v += d.C[coff];
@@ -89,16 +93,26 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
         return;
     }
     const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    // dropout with N % 4 == 0: the 4 lanes of a quad (4 consecutive columns) sit in the same Philox block of every row, so for a lane's 4
+    // accumulator rows the quad evaluates 4 blocks instead of 16 (a lane's 16 outputs otherwise need 16 whole blocks: ~1400 VALU
+    // instructions per wave tile, +12 us on a 32 us GEMM)
+    const bool quad_mask = d.drop_p > 0.f && nsplit == 1 && (d.N & 3) == 0;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = nb + nt * 16;
+            bool kq[4] = {true, true, true, true};
+            if (quad_mask) {
+                const int j = lane & 3;
+                const unsigned long long blk = ((unsigned long long)(mb + mt * 16 + j) * (unsigned)d.N + (unsigned)(n - j)) >> 2;
+                dropout_keep_quad_blocks(d.seed, d.drop_site, blk, j, d.drop_p, kq);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mb + mt * 16 + r;
                 if (m >= d.M || n >= d.N) continue;
-                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, first_slice, keep_scale);
+                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, first_slice, keep_scale, quad_mask ? (int)kq[r] : -1);
             }
         }
     }

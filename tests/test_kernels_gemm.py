@@ -58,9 +58,11 @@ def test_gemm_epilogue_bias_gelu_pre_residual_accumulate(be):
     np.testing.assert_allclose(be.host(C), ref, atol=3e-5)
 
 
-def test_gemm_dropout_mask_is_philox_of_logical_index(be):
-    rng = np.random.default_rng(6)
-    M, N, K = 65, 67, 8
+@pytest.mark.parametrize("M,N,K", [(65, 67, 8), (70, 72, 8), (130, 256, 34), (33, 4, 6)])
+def test_gemm_dropout_mask_is_philox_of_logical_index(be, M, N, K):
+    """(N % 4 == 0 takes the quad-shared Philox route of the epilogue, other N the per-element one: the mask must be the same function of
+    the logical element index either way)"""
+    rng = np.random.default_rng(6 + N)
     a, w = f32(rng, M, K), f32(rng, N, K)
     A, W, C = be.dev(a), be.dev(w), be.zeros((M, N))
     p, seed, site = 0.25, 0x1234567890ABCDEF, 3
