@@ -39,14 +39,15 @@ __device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
 //   everything else: the general form
 // the general form for one output element: v = alpha * acc on entry
 // keep_known: -1 = evaluate the dropout mask here, 0 / 1 = the caller already has this element's decision (quad-shared Philox blocks)
+// coff / roff: element offsets into C (and Cpre) / R, formed by the caller from per-row and per-column parts (a two-level map costs an integer
+// division: a lane's 16 outputs share 8 rows and 2 columns)
 template <bool PLAIN>
-__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, bool first_slice, float keep_scale,
-                                                      int keep_known = -1) {
+__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, long long coff, long long roff,
+                                                      bool first_slice, float keep_scale, int keep_known = -1) {
     if (first_slice) {
         if (d.bias_n) v += d.bias_n[n];
         if (d.bias_m) v += d.bias_m[m];
     }
-    const long long coff = goff<PLAIN>(d.Cm, m) + goff<PLAIN>(d.Cn, n);
     if (d.split_k > 1) {
         atomicAdd(d.C + coff, v);
         return;
@@ -58,8 +59,8 @@ __device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d
         const bool keep = keep_known >= 0 ? keep_known != 0 : dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p);
         v = keep ? v * keep_scale : 0.f;
     }
-    if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)]);
-    else if (d.R) v += d.R[goff<PLAIN>(d.Rm, m) + goff<PLAIN>(d.Rn, n)];
+    if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[roff]);
+    else if (d.R) v += d.R[roff];
     if (d.accumulate) v += d.C[coff];
     d.C[coff] = v;
 }
@@ -97,8 +98,22 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
     // accumulator rows the quad evaluates 4 blocks instead of 16 (a lane's 16 outputs otherwise need 16 whole blocks: ~1400 VALU
     // instructions per wave tile, +12 us on a 32 us GEMM)
     const bool quad_mask = d.drop_p > 0.f && nsplit == 1 && (d.N & 3) == 0;
+    long long ccol[2], rcol[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nb + nt * 16 < d.N ? nb + nt * 16 : 0;
+        ccol[nt] = goff<PLAIN>(d.Cn, n);
+        rcol[nt] = d.R ? goff<PLAIN>(d.Rn, n) : 0;
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        long long crow[4], rrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + mt * 16 + r < d.M ? mb + mt * 16 + r : 0;
+            crow[r] = goff<PLAIN>(d.Cm, m);
+            rrow[r] = d.R ? goff<PLAIN>(d.Rm, m) : 0;
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = nb + nt * 16;
@@ -112,7 +127,8 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
             for (int r = 0; r < 4; ++r) {
                 const int m = mb + mt * 16 + r;
                 if (m >= d.M || n >= d.N) continue;
-                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, first_slice, keep_scale, quad_mask ? (int)kq[r] : -1);
+                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, crow[r] + ccol[nt], rrow[r] + rcol[nt], first_slice, keep_scale,
+                                             quad_mask ? (int)kq[r] : -1);
             }
         }
     }
@@ -530,7 +546,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_f32_skinny_kernel(const ee
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = 16 * wave + 4 * g + r;
-        if (m < d.M && n < d.N) gemm_epilogue_element<true>(d, d.alpha * sum[r], m, n, true, keep_scale);
+        if (m < d.M && n < d.N)
+            gemm_epilogue_element<true>(d, d.alpha * sum[r], m, n, (long long)m * d.Cm.si + (long long)n * d.Cn.si,
+                                        d.R ? (long long)m * d.Rm.si + (long long)n * d.Rn.si : 0, true, keep_scale);
     }
 }
 
