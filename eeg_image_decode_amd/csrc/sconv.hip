@@ -391,14 +391,16 @@ static bool sc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 static int sc_check(int B, int H) { return (B < 1 || H < 1 || H > 64) ? EEGCLIP_EINVAL : 0; }
 
 extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                                 const float* bs, float* y2, double* sums2, int B, int H, void* stream) {
+                                 const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
     if (!sc_aligned16(y1) || !sc_aligned16(Ws)) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H, kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;       // slices start on 16-byte boundaries of both operands
     const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
-    (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
+    // the K slices add their partial tiles into y2 with atomics: it must start at zero (callers that clear it together with their other
+    // accumulators pass y2_is_zero != 0 and save the extra memset launch)
+    if (!y2_is_zero) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
     EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
     if (sums2) EEG_LAUNCH(sconv_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, y2, sums2, B);
     return (int)hipGetLastError();

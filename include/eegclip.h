@@ -220,9 +220,10 @@ int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx, long long
  *   bwd_w       dWs += sum_{b,w} dy2 (x) z1       (two-stage reduction through `workspace`, size from ..._workspace_floats)
  *   bwd_x_stats sums[c] += sum da, sums[40+c] += sum da*xhat,  da = (Ws^T dy2) * ELU'(BN(y1))     (double[80], zeroed by the caller)
  *   bwd_x_apply dy1 = gamma*rstd*(da - sums/count - xhat*sums'/count); dgamma/dbeta += sums_local (NULL = sums) -- SyncBN: all-reduce
- *               sums between the two calls and pass the global count. */
+ *               sums between the two calls and pass the global count.  sconv_fwd adds K-slice partial tiles into y2 with atomics:
+ * y2_is_zero = 0 lets it clear y2 itself, != 0 says the caller already did. */
 int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                      const float* bs, float* y2, double* sums2, int B, int H, void* stream);
+                      const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, void* stream);
 long long eegclip_sconv_bwd_w_workspace_floats(int B, int H);
 int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
                         float* dWs, float* workspace, int B, int H, void* stream);

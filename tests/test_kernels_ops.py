@@ -493,7 +493,7 @@ def test_fused_spatial_stage(be, B, H):
     Y1, G1, B1, WS, BS, DY2 = be.dev(y1), be.dev(g1), be.dev(b1), be.dev(Ws), be.dev(bs), be.dev(dy2)
     MU, RS = be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
     Y2, S2 = be.zeros((B, C, Wd)), be.zeros(80, np.float64)
-    ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(BS), be.ptr(Y2), be.ptr(S2), B, H, be.stream))
+    ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(BS), be.ptr(Y2), be.ptr(S2), B, H, 0, be.stream))
     np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
     np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3)
     np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
