@@ -26,10 +26,13 @@ class GemmDesc(C.Structure):
         ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("drop_site", C.c_uint),
         ("split_k", C.c_int),
         ("rowsum_a", C.c_void_p),
+        ("precision", C.c_int),
     ]
 
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3 = 0, 1
+ABI_VERSION = 2
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 

@@ -26,8 +26,8 @@ def lib():
         l = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         _abi.declare(l)
         v = l.eegclip_abi_version()
-        if v != 1:
-            raise EegclipError(f"ABI version mismatch: library {v}, python binding 1")
+        if v != _abi.ABI_VERSION:
+            raise EegclipError(f"ABI version mismatch: library {v}, python binding {_abi.ABI_VERSION}")
         _lib = l
     return _lib
 

@@ -13,6 +13,7 @@
 // 16384x744x250, measured).  None of the encoder's dimensions (250, 248, 63, 36, 1440, 2520) is tile aligned: padding lives only in LDS
 // (zeros) or in clamped addresses, never in HBM.
 #include "eeg_common.h"
+#include "gemm_epilogue.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,125 +23,6 @@ namespace eeg {
 constexpr int G_BK = 32;
 constexpr int G_BT = 64;        // tile edge (M and N)
 constexpr int G_THREADS = 256;
-
-// PLAIN = every index map is a plain stride (div = 2^62): offsets are one multiply, and the integer-division path of the two-level
-// maps is not even instantiated (it was >1000 instructions of the unrolled staging/epilogue code)
-template <bool PLAIN>
-__device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
-    if (PLAIN) return (long long)i * d.si;
-    return dim_off(d, i);
-}
-
-// ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 accumulator -----------------------------------------------
-// Three paths, chosen by workgroup-uniform tests BEFORE the element loops: at K ~ 250 a workgroup runs only 8 k-tiles, and a fully
-// general per-element epilogue (eight uniform branches and 64-bit index maps per output) was ~28 % of its instructions.
-//   split-K slices: atomicAdd of alpha*acc (+ bias on slice 0)
-//   plain stride C, nothing but (bias_n, accumulate): pointer-bump stores
-//   everything else: the general form
-// the general form for one output element: v = alpha * acc on entry
-// keep_known: -1 = evaluate the dropout mask here, 0 / 1 = the caller already has this element's decision (quad-shared Philox blocks)
-// coff / roff: element offsets into C (and Cpre) / R, formed by the caller from per-row and per-column parts (a two-level map costs an integer
-// division: a lane's 16 outputs share 8 rows and 2 columns)
-template <bool PLAIN>
-__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, long long coff, long long roff,
-                                                      bool first_slice, float keep_scale, int keep_known = -1) {
-    if (first_slice) {
-        if (d.bias_n) v += d.bias_n[n];
-        if (d.bias_m) v += d.bias_m[m];
-    }
-    if (d.split_k > 1) {
-        atomicAdd(d.C + coff, v);
-        return;
-    }
-    if (d.Cpre) d.Cpre[coff] = v;
-    if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
-    else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
-    if (d.drop_p > 0.f) {
-        const bool keep = keep_known >= 0 ? keep_known != 0 : dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p);
-        v = keep ? v * keep_scale : 0.f;
-    }
-    if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[roff]);
-    else if (d.R) v += d.R[roff];
-    if (d.accumulate) v += d.C[coff];
-    d.C[coff] = v;
-}
-
-template <bool PLAIN>
-__device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const f32x4 (&acc)[2][2], int m0, int n0, int wr, int wc,
-                                              int lane, bool first_slice) {
-    const int nsplit = d.split_k;
-    const int mb = m0 + wr * 32 + (lane >> 4) * 4, nb = n0 + wc * 32 + (lane & 15);
-    if (PLAIN && !d.bias_m && (nsplit > 1 || (!d.Cpre && d.act == EEGCLIP_ACT_NONE && !(d.drop_p > 0.f) && !d.R))) {
-        const long long ldc = d.Cm.si, ldn = d.Cn.si;
-        const bool use_bias = d.bias_n != nullptr && first_slice;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = nb + nt * 16;
-            if (n >= d.N) continue;
-            const float bn = use_bias ? d.bias_n[n] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float* cp = d.C + (long long)(mb + mt * 16) * ldc + (long long)n * ldn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (mb + mt * 16 + r < d.M) {
-                        const float v = d.alpha * acc[mt][nt][r] + bn;
-                        if (nsplit > 1) atomicAdd(cp + r * ldc, v);
-                        else cp[r * ldc] = d.accumulate ? cp[r * ldc] + v : v;
-                    }
-                }
-            }
-        }
-        return;
-    }
-    const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
-    // dropout with N % 4 == 0: the 4 lanes of a quad (4 consecutive columns) sit in the same Philox block of every row, so for a lane's 4
-    // accumulator rows the quad evaluates 4 blocks instead of 16 (a lane's 16 outputs otherwise need 16 whole blocks: ~1400 VALU
-    // instructions per wave tile, +12 us on a 32 us GEMM)
-    const bool quad_mask = d.drop_p > 0.f && nsplit == 1 && (d.N & 3) == 0;
-    long long ccol[2], rcol[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = nb + nt * 16 < d.N ? nb + nt * 16 : 0;
-        ccol[nt] = goff<PLAIN>(d.Cn, n);
-        rcol[nt] = d.R ? goff<PLAIN>(d.Rn, n) : 0;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        long long crow[4], rrow[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mb + mt * 16 + r < d.M ? mb + mt * 16 + r : 0;
-            crow[r] = goff<PLAIN>(d.Cm, m);
-            rrow[r] = d.R ? goff<PLAIN>(d.Rm, m) : 0;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = nb + nt * 16;
-            bool kq[4] = {true, true, true, true};
-            if (quad_mask) {
-                const int j = lane & 3;
-                const unsigned long long blk = ((unsigned long long)(mb + mt * 16 + j) * (unsigned)d.N + (unsigned)(n - j)) >> 2;
-                dropout_keep_quad_blocks(d.seed, d.drop_site, blk, j, d.drop_p, kq);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mb + mt * 16 + r;
-                if (m >= d.M || n >= d.N) continue;
-                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, crow[r] + ccol[nt], rrow[r] + rcol[nt], first_slice, keep_scale,
-                                             quad_mask ? (int)kq[r] : -1);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int slice, int& kt_begin, int& kt_end) {
-    const int ktiles = (d.K + G_BK - 1) / G_BK;
-    const int tiles_per = (ktiles + d.split_k - 1) / d.split_k;
-    kt_begin = slice * tiles_per;
-    kt_end = kt_begin + tiles_per;
-    if (kt_end > ktiles) kt_end = ktiles;
-}
 
 // =================================================================================================================================
 // general kernel.  LDS image: element (k, m) of a BK x 64 operand tile lives at k*64 + (m ^ swz(k)), swz(k) = ((k&1)<<4) | (k>>1):
@@ -163,7 +45,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * G_BT, n0 = blockIdx.x * G_BT;
     int kt_begin, kt_end;
-    gemm_k_slice(d, blockIdx.z, kt_begin, kt_end);
+    gemm_k_slice<G_BK>(d, blockIdx.z, kt_begin, kt_end);
 
     // ---- per-thread staging coordinates -------------------------------------------------------------
     // m-contiguous operand: lane walks m (coalesced), k = t / 64 + 4 i.   k-contiguous: lane walks k, m = (t>>5) + 8 i.
@@ -300,7 +182,7 @@ __device__ __forceinline__ void gemm_f32_fast_body(const eegclip_gemm_desc& d, i
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
     int kt_begin, kt_end;
-    gemm_k_slice(d, slice, kt_begin, kt_end);
+    gemm_k_slice<G_BK>(d, slice, kt_begin, kt_end);
 
     // staging roles: KC operand -> thread (row = r0 + 16 i, k pair kp);  MC operand -> thread (k = kr0 + 8 i, row pair mp)
     const int kp = t & 15, r0 = t >> 4, mp = t & 31, kr0 = t >> 5;
@@ -669,6 +551,7 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const dim3 fgrid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles);
     if (allow_fast && ab_plain && d.K >= 2 && (long long)gx * gy < (1LL << 28) && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) &&
         fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) {
+        if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, akc, bkc, c_plain, stream);
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
         const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
 #define EEG_FAST_GO(AK, BK_)                                                                                                         \
@@ -749,6 +632,8 @@ static int gemm_desc_check(const eegclip_gemm_desc& d) {
     if (d.split_k < 1) return EEGCLIP_EINVAL;
     if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre)) return EEGCLIP_EINVAL;
     if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_GELU_GRAD) return EEGCLIP_EINVAL;
+    if ((d.precision & 0xff) != EEGCLIP_PREC_F32 && (d.precision & 0xff) != EEGCLIP_PREC_BF16X3) return EEGCLIP_EINVAL;
+    if ((d.precision >> 8) < 0 || (d.precision >> 8) > 6) return EEGCLIP_EINVAL;
     if (d.act == EEGCLIP_ACT_GELU_GRAD && (!d.R || d.split_k > 1)) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;

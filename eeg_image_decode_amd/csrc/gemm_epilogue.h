@@ -1,0 +1,131 @@
+// Shared pieces of the GEMM kernels (gemm.hip: exact-f32 MFMA; gemm_x3.hip: split-bf16 MFMA): index maps, the fused epilogue over
+// 16x16 MFMA accumulator tiles (the C/D fragment layout is the same for every MFMA shape x dtype on gfx950) and the split-K slice bounds.
+#pragma once
+#include "eeg_common.h"
+
+namespace eeg {
+
+// PLAIN = every index map is a plain stride (div = 2^62): offsets are one multiply, and the integer-division path of the two-level
+// maps is not even instantiated (it was >1000 instructions of the unrolled staging/epilogue code)
+template <bool PLAIN>
+__device__ __forceinline__ long long goff(const eegclip_dim& d, int i) {
+    if (PLAIN) return (long long)i * d.si;
+    return dim_off(d, i);
+}
+
+// ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 accumulator -----------------------------------------------
+// Three paths, chosen by workgroup-uniform tests BEFORE the element loops: at K ~ 250 a workgroup runs only 8 k-tiles, and a fully
+// general per-element epilogue (eight uniform branches and 64-bit index maps per output) was ~28 % of its instructions.
+//   split-K slices: atomicAdd of alpha*acc (+ bias on slice 0)
+//   plain stride C, nothing but (bias_n, accumulate): pointer-bump stores
+//   everything else: the general form
+// the general form for one output element: v = alpha * acc on entry
+// keep_known: -1 = evaluate the dropout mask here, 0 / 1 = the caller already has this element's decision (quad-shared Philox blocks)
+// coff / roff: element offsets into C (and Cpre) / R, formed by the caller from per-row and per-column parts (a two-level map costs an integer
+// division: a lane's 16 outputs share 8 rows and 2 columns)
+template <bool PLAIN>
+__device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d, float v, int m, int n, long long coff, long long roff,
+                                                      bool first_slice, float keep_scale, int keep_known = -1) {
+    if (first_slice) {
+        if (d.bias_n) v += d.bias_n[n];
+        if (d.bias_m) v += d.bias_m[m];
+    }
+    if (d.split_k > 1) {
+        atomicAdd(d.C + coff, v);
+        return;
+    }
+    if (d.Cpre) d.Cpre[coff] = v;
+    if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
+    else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
+    if (d.drop_p > 0.f) {
+        const bool keep = keep_known >= 0 ? keep_known != 0 : dropout_keep(d.seed, d.drop_site, (unsigned long long)m * (unsigned)d.N + (unsigned)n, d.drop_p);
+        v = keep ? v * keep_scale : 0.f;
+    }
+    if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[roff]);
+    else if (d.R) v += d.R[roff];
+    if (d.accumulate) v += d.C[coff];
+    d.C[coff] = v;
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const f32x4 (&acc)[2][2], int m0, int n0, int wr, int wc,
+                                              int lane, bool first_slice) {
+    const int nsplit = d.split_k;
+    const int mb = m0 + wr * 32 + (lane >> 4) * 4, nb = n0 + wc * 32 + (lane & 15);
+    if (PLAIN && !d.bias_m && (nsplit > 1 || (!d.Cpre && d.act == EEGCLIP_ACT_NONE && !(d.drop_p > 0.f) && !d.R))) {
+        const long long ldc = d.Cm.si, ldn = d.Cn.si;
+        const bool use_bias = d.bias_n != nullptr && first_slice;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nb + nt * 16;
+            if (n >= d.N) continue;
+            const float bn = use_bias ? d.bias_n[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float* cp = d.C + (long long)(mb + mt * 16) * ldc + (long long)n * ldn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mb + mt * 16 + r < d.M) {
+                        const float v = d.alpha * acc[mt][nt][r] + bn;
+                        if (nsplit > 1) atomicAdd(cp + r * ldc, v);
+                        else cp[r * ldc] = d.accumulate ? cp[r * ldc] + v : v;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    // dropout with N % 4 == 0: the 4 lanes of a quad (4 consecutive columns) sit in the same Philox block of every row, so for a lane's 4
+    // accumulator rows the quad evaluates 4 blocks instead of 16 (a lane's 16 outputs otherwise need 16 whole blocks: ~1400 VALU
+    // instructions per wave tile, +12 us on a 32 us GEMM)
+    const bool quad_mask = d.drop_p > 0.f && nsplit == 1 && (d.N & 3) == 0;
+    long long ccol[2], rcol[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nb + nt * 16 < d.N ? nb + nt * 16 : 0;
+        ccol[nt] = goff<PLAIN>(d.Cn, n);
+        rcol[nt] = d.R ? goff<PLAIN>(d.Rn, n) : 0;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        long long crow[4], rrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + mt * 16 + r < d.M ? mb + mt * 16 + r : 0;
+            crow[r] = goff<PLAIN>(d.Cm, m);
+            rrow[r] = d.R ? goff<PLAIN>(d.Rm, m) : 0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nb + nt * 16;
+            bool kq[4] = {true, true, true, true};
+            if (quad_mask) {
+                const int j = lane & 3;
+                const unsigned long long blk = ((unsigned long long)(mb + mt * 16 + j) * (unsigned)d.N + (unsigned)(n - j)) >> 2;
+                dropout_keep_quad_blocks(d.seed, d.drop_site, blk, j, d.drop_p, kq);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + mt * 16 + r;
+                if (m >= d.M || n >= d.N) continue;
+                gemm_epilogue_element<PLAIN>(d, d.alpha * acc[mt][nt][r], m, n, crow[r] + ccol[nt], rrow[r] + rcol[nt], first_slice, keep_scale,
+                                             quad_mask ? (int)kq[r] : -1);
+            }
+        }
+    }
+}
+
+template <int BK>
+__device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int slice, int& kt_begin, int& kt_end) {
+    const int ktiles = (d.K + BK - 1) / BK;
+    const int tiles_per = (ktiles + d.split_k - 1) / d.split_k;
+    kt_begin = slice * tiles_per;
+    kt_end = kt_begin + tiles_per;
+    if (kt_end > ktiles) kt_end = ktiles;
+}
+
+// gemm_x3.hip: the split-bf16 kernel for the plain-stride operand classes (akc / bkc: operand is k-contiguous)
+int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream);
+
+}  // namespace eeg

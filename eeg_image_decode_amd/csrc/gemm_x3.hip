@@ -1,0 +1,316 @@
+// Split-precision fp32 GEMM on the bf16 matrix cores (eegclip_gemm_desc.precision = EEGCLIP_PREC_BF16X3).
+//
+//   C[m,n] (+)= epilogue(alpha * sum_k A[m,k] B[k,n]),   a*b  :=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   (fp32 accumulate)
+//
+// with a = a_hi + a_lo, a_hi = bf16(a), a_lo = bf16(a - a_hi) (a - a_hi is exact in fp32).  v_mfma_f32_16x16x4_f32 runs at 1/16 of
+// the bf16 rate (157 TF vs 2.5 PF); three bf16 products cost 3/16 of an exact one, and the GEMMs of this path (K ~ 250, N ~ 250..1024)
+// stop being bound by the matrix pipe at all: what is left is operand staging, which this kernel shares with gemm.hip's fast kernel.
+// Same operand classes as that kernel (plain strides, even leading dimensions, 8-byte aligned bases, 32-bit reach), same XCD-aware
+// tile order, same split-K scheme, same epilogue (gemm_epilogue.h) -- the C/D fragment layout of a 16x16 MFMA does not depend on dtype.
+//
+// The split happens ONCE per staged element, in registers, between the global load and the LDS store (v_cvt_pk_bf16_f32 x2, one
+// shift / and, one subtract per element): HBM and L2 only ever see fp32, and the LDS image costs the same 4 bytes per element.
+//
+// LDS image of a BT x BK operand tile (both operand classes end up in the SAME image, so the MFMA loop has one form):
+//     row r (= m or n within the tile):  [ hi plane: BK bf16 | lo plane: BK bf16 | 32 bytes pad ]        row stride RS = 4 BK + 32
+//     inside a plane the 16-byte chunk c (8 consecutive k) sits at chunk slot c ^ ((r >> 2) & (BK/8 - 1))
+//   * MFMA operand fetch: lane (fr = lane & 15, g = lane >> 4) of k-step s reads the 16 bytes of row fr, chunk 4 s + g with one
+//     ds_read_b128 per plane -- conflict free (tools/micro/lds_layout_search.py enumerates the lane groups of MI355X_MICROARCH.md)
+//   * k-contiguous operand ("KC": X and W of Y = X W^T): a thread loads 4 consecutive k of one row (two 8-byte loads: rows of 250 floats
+//     are only 8-byte aligned), splits them and writes 8 bytes per plane (ds_write_b64, 2-way at worst)
+//   * row-contiguous operand ("MC": dY^T and X of dW = dY^T X; W of dX = dY W): a thread loads 4 consecutive k ROWS x 2 adjacent m
+//     (coalesced along m), i.e. a 4 x 2 block -- the transpose the k-contiguous image needs happens in registers -- and writes 8 bytes
+//     per (m, plane)
+//
+// Tile shapes (template): BT x BT output per 256-thread workgroup, 2 x 2 wavefronts, each wave (BT/32)^2 MFMA 16x16x32 tiles;
+// BK = 32 or 64; DB = two LDS images (one barrier per k-tile: the next tile is converted and stored behind the current tile's MFMAs)
+// or one (two barriers).  launch_gemm_x3() picks per problem; EEGCLIP_X3_CFG overrides for tuning.
+#include "eeg_common.h"
+#include "gemm_epilogue.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace eeg {
+
+constexpr int X3_THREADS = 256;
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed bf16 pair (round to nearest even), low half = first
+__device__ __forceinline__ unsigned x3_pack2(float a, float b) {
+#if defined(EEG_EMU)
+    return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+#else
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const f32x2_t v{a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));          // v_cvt_pk_bf16_f32
+#endif
+}
+// 4 consecutive-k values -> hi / lo planes (4 bf16 = 8 bytes each)
+__device__ __forceinline__ void x3_split4(float v0, float v1, float v2, float v3, u32x2_t& hi, u32x2_t& lo) {
+    const unsigned h01 = x3_pack2(v0, v1), h23 = x3_pack2(v2, v3);
+    const float r0 = v0 - __uint_as_float(h01 << 16), r1 = v1 - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = v2 - __uint_as_float(h23 << 16), r3 = v3 - __uint_as_float(h23 & 0xffff0000u);
+    hi = u32x2_t{h01, h23};
+    lo = u32x2_t{x3_pack2(r0, r1), x3_pack2(r2, r3)};
+}
+
+template <int BK>
+struct x3_geom {
+    static constexpr int RS = 4 * BK + 32;       // row stride in bytes
+    static constexpr int NCH = BK / 8;           // 16-byte chunks per plane
+    // byte offset of k-quad kq (4 consecutive k = 8 bytes) of row r in plane p
+    __device__ static __forceinline__ int quad(int r, int p, int kq) {
+        return r * RS + p * (2 * BK) + ((((kq >> 1) ^ (r >> 2)) & (NCH - 1)) << 4) + ((kq & 1) << 3);
+    }
+    // byte offset of 16-byte chunk c of row r in plane p
+    __device__ static __forceinline__ int chunk(int r, int p, int c) { return r * RS + p * (2 * BK) + (((c ^ (r >> 2)) & (NCH - 1)) << 4); }
+};
+
+template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN>
+__global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+    using G = x3_geom<BK>;
+    constexpr int WT = BT / 32;                  // MFMA tiles per wave and dimension
+    constexpr int IMG = BT * G::RS;              // bytes of one operand image
+    constexpr int NQ = BK / 4;                   // k-quads per row
+    // KC staging: thread -> (k-quad t % NQ, row t / NQ + RPP i)
+    constexpr int RPP = X3_THREADS / NQ, KC_PASS = BT / RPP;
+    // MC staging: thread -> (m-pair t % NP, k-quad t / NP + QPP i)
+    constexpr int NP = BT / 2, QPP = X3_THREADS / NP, MC_PASS = NQ / QPP;
+    static_assert(KC_PASS >= 1 && MC_PASS >= 1 && BT % RPP == 0 && NQ % QPP == 0, "tile shape");
+    EEG_LDS_BASE(unsigned char, lds);            // [DB ? 2 : 1][A image | B image]
+
+    const int bid = (int)blockIdx.x;
+    int logical, slice = 0;
+    if (d.split_k == 1) {
+        logical = (bid & 7) * chunk + (bid >> 3);                   // XCD b % 8 owns a contiguous run of tiles (n fastest)
+        if (logical >= ntiles) return;
+    } else {
+        const int slot = bid >> 3;                                  // all tiles of one K slice on one XCD (see gemm.hip)
+        slice = (bid & 7) + 8 * (slot / ntiles);
+        logical = slot % ntiles;
+        if (slice >= d.split_k) return;
+    }
+    const int m0 = (logical / gx) * BT, n0 = (logical % gx) * BT;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+    int kt_begin, kt_end;
+    gemm_k_slice<BK>(d, slice, kt_begin, kt_end);
+
+    const int a_ld = A_KC ? (int)d.Am.si : (int)d.Ak.si, b_ld = B_KC ? (int)d.Bn.si : (int)d.Bk.si;
+    const int kc_kq = t % NQ, kc_r0 = t / NQ, mc_mp = t % NP, mc_q0 = t / NP;
+    int a_fix[A_KC ? KC_PASS : 1], b_fix[B_KC ? KC_PASS : 1];      // KC: element offset of the (clamped) row
+    int a_col = 0, b_col = 0;                                      // MC: clamped first row of the pair
+    if (A_KC) {
+#pragma unroll
+        for (int i = 0; i < KC_PASS; ++i) { const int m = m0 + kc_r0 + RPP * i; a_fix[i] = (m < d.M ? m : d.M - 1) * a_ld; }
+    } else { const int m = m0 + 2 * mc_mp; a_col = m < d.M ? m : d.M - 2; a_fix[0] = 0; }
+    if (B_KC) {
+#pragma unroll
+        for (int i = 0; i < KC_PASS; ++i) { const int n = n0 + kc_r0 + RPP * i; b_fix[i] = (n < d.N ? n : d.N - 1) * b_ld; }
+    } else { const int n = n0 + 2 * mc_mp; b_col = n < d.N ? n : d.N - 2; b_fix[0] = 0; }
+
+    // registers of the tile in flight; the "k beyond K -> 0" select is applied at LDS-store time (a select next to the load would
+    // make the wave wait for its prefetch before the MFMAs it overlaps with)
+    constexpr int A_REGS = A_KC ? KC_PASS * 2 : MC_PASS * 4, B_REGS = B_KC ? KC_PASS * 2 : MC_PASS * 4;
+    f32x2_t ra[A_REGS], rb[B_REGS];
+    unsigned a_ok = 0, b_ok = 0;
+
+    auto load_op = [&](auto kc_tag, const float* P, const int* fix, int col, int ld, f32x2_t* r, unsigned& ok, int k0) {
+        constexpr bool KC = decltype(kc_tag)::value;
+        ok = 0;
+        if (KC) {
+            const int ka = k0 + 4 * kc_kq;
+            const bool ok0 = ka < d.K, ok1 = ka + 2 < d.K;          // K is even: a pair is in or out as a whole
+            const int k_0 = ok0 ? ka : 0, k_1 = ok1 ? ka + 2 : 0;
+            ok = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
+#pragma unroll
+            for (int i = 0; i < KC_PASS; ++i) {
+                r[2 * i] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_0);
+                r[2 * i + 1] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MC_PASS; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 4 * (mc_q0 + QPP * i) + j;
+                    const bool okk = k < d.K;
+                    r[4 * i + j] = *reinterpret_cast<const f32x2_t*>(P + (okk ? k : 0) * ld + col);
+                    ok |= (okk ? 1u : 0u) << (4 * i + j);
+                }
+        }
+    };
+    auto store_op = [&](auto kc_tag, unsigned char* img, const f32x2_t* r, unsigned ok) {
+        constexpr bool KC = decltype(kc_tag)::value;
+        const f32x2_t zero{0.f, 0.f};
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < KC_PASS; ++i) {
+                const f32x2_t p0 = ok & 1u ? r[2 * i] : zero, p1 = ok & 2u ? r[2 * i + 1] : zero;
+                u32x2_t hi, lo;
+                x3_split4(p0[0], p0[1], p1[0], p1[1], hi, lo);
+                const int row = kc_r0 + RPP * i;
+                *reinterpret_cast<u32x2_t*>(img + G::quad(row, 0, kc_kq)) = hi;
+                *reinterpret_cast<u32x2_t*>(img + G::quad(row, 1, kc_kq)) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MC_PASS; ++i) {
+                f32x2_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (ok >> (4 * i + j)) & 1u ? r[4 * i + j] : zero;
+                const int kq = mc_q0 + QPP * i;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    u32x2_t hi, lo;
+                    x3_split4(v[0][e], v[1][e], v[2][e], v[3][e], hi, lo);
+                    *reinterpret_cast<u32x2_t*>(img + G::quad(2 * mc_mp + e, 0, kq)) = hi;
+                    *reinterpret_cast<u32x2_t*>(img + G::quad(2 * mc_mp + e, 1, kq)) = lo;
+                }
+            }
+        }
+    };
+    using akc_t = std::integral_constant<bool, A_KC>;
+    using bkc_t = std::integral_constant<bool, B_KC>;
+    auto load_tile = [&](int kt) {
+        load_op(akc_t{}, d.A, a_fix, a_col, a_ld, ra, a_ok, kt * BK);
+        load_op(bkc_t{}, d.B, b_fix, b_col, b_ld, rb, b_ok, kt * BK);
+    };
+    auto store_tile = [&](unsigned char* buf) {
+        store_op(akc_t{}, buf, ra, a_ok);
+        store_op(bkc_t{}, buf + IMG, rb, b_ok);
+    };
+
+    f32x4 acc[WT][WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool do_rowsum = d.rowsum_a != nullptr && n0 == 0;
+    float rowsum = 0.f;
+    auto compute = [&](const unsigned char* buf) {
+        if (do_rowsum && t < BT) {                               // bias gradients: row sums of the staged A tile (hi + lo = a to 2^-17)
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c) {
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(buf + G::chunk(t, 0, c));
+                const bf16x8 l = *reinterpret_cast<const bf16x8*>(buf + G::chunk(t, 1, c));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rowsum += bf16_bits_to_f32((unsigned short)h[e]) + bf16_bits_to_f32((unsigned short)l[e]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            bf16x8 bh[WT], bl[WT];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int row = wc * (BT / 2) + 16 * j + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(buf + IMG + G::chunk(row, 0, 4 * s + g));
+                bl[j] = *reinterpret_cast<const bf16x8*>(buf + IMG + G::chunk(row, 1, 4 * s + g));
+            }
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                const int row = wr * (BT / 2) + 16 * i + fr;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(buf + G::chunk(row, 0, 4 * s + g));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::chunk(row, 1, 4 * s + g));
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    acc[i][j] = mfma_bf16_16x16x32(al, bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah, bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah, bh[j], acc[i][j]);
+                }
+            }
+        }
+    };
+
+    if (DB) {
+        int cur = 0;
+        if (kt_begin < kt_end) {
+            load_tile(kt_begin);
+            store_tile(lds);
+        }
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) load_tile(kt + 1);                         // global -> registers, in flight under this tile's MFMAs
+            compute(lds + cur * 2 * IMG);
+            if (more) store_tile(lds + (cur ^ 1) * 2 * IMG);     // split + store into the OTHER image: one barrier per k-tile
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        if (kt_begin < kt_end) load_tile(kt_begin);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            store_tile(lds);
+            __syncthreads();
+            if (kt + 1 < kt_end) load_tile(kt + 1);
+            compute(lds);
+            __syncthreads();
+        }
+    }
+    if (do_rowsum && t < BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
+    // (explicit 32x32 sub-blocks: a loop over them is too large for the unroller and would index `acc` at run time -> scratch)
+#define EEG_X3_EPI(SI, SJ)                                                                                                          \
+    {                                                                                                                               \
+        f32x4 a2[2][2] = {{acc[2 * SI][2 * SJ], acc[2 * SI][2 * SJ + 1]}, {acc[2 * SI + 1][2 * SJ], acc[2 * SI + 1][2 * SJ + 1]}};  \
+        gemm_epilogue<C_PLAIN>(d, a2, m0 + wr * (BT / 2) + 32 * SI, n0 + wc * (BT / 2) + 32 * SJ, 0, 0, lane, slice == 0);          \
+    }
+    EEG_X3_EPI(0, 0)
+    if constexpr (WT == 4) {
+        EEG_X3_EPI(0, 1)
+        EEG_X3_EPI(1, 0)
+        EEG_X3_EPI(1, 1)
+    }
+#undef EEG_X3_EPI
+}
+
+template <int BT, int BK, bool DB>
+static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream) {
+    const int gx = (d.N + BT - 1) / BT, gy = (d.M + BT - 1) / BT;
+    const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
+    const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
+    const size_t lds = (size_t)(DB ? 2 : 1) * 2 * BT * x3_geom<BK>::RS;
+#define EEG_X3_GO(AK, BK_)                                                                                                        \
+    do {                                                                                                                          \
+        if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);     \
+        else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);    \
+    } while (0)
+    if (akc && bkc)        EEG_X3_GO(true, true);
+    else if (akc && !bkc)  EEG_X3_GO(true, false);
+    else if (!akc && bkc)  EEG_X3_GO(false, true);
+    else                   EEG_X3_GO(false, false);
+#undef EEG_X3_GO
+    return (int)hipGetLastError();
+}
+
+// Problem -> tile shape.  cfg: 0 = 64x64x32, 1 = 64x64x32 double-buffered, 2 = 64x64x64, 3 = 64x64x64 double-buffered,
+// 4 = 128x128x32, 5 = 128x128x32 double-buffered.  EEGCLIP_X3_CFG pins one for tuning.
+int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream) {
+    static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
+    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
+    int cfg = ((d.precision >> 8) & 0xff) - 1;                  // explicit tile configuration in the descriptor (tuning / tests)
+    if (cfg < 0) cfg = pinned;
+    if (cfg < 0) {
+        // large tiles only when they still give every CU several workgroups; split-K weight gradients (few output tiles) keep 64x64
+        const long long big_tiles = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+        cfg = (d.split_k == 1 && big_tiles >= 1024) ? 5 : 1;
+    }
+    if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 cfg %d <%d,%d,%d> %dx%dx%d sk%d\n", cfg, (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
+    switch (cfg) {
+        case 0: return x3_launch_cfg<64, 32, false>(d, akc, bkc, c_plain, stream);
+        case 2: return x3_launch_cfg<64, 64, false>(d, akc, bkc, c_plain, stream);
+        case 3: return x3_launch_cfg<64, 64, true>(d, akc, bkc, c_plain, stream);
+        case 4: return x3_launch_cfg<128, 32, false>(d, akc, bkc, c_plain, stream);
+        case 5: return x3_launch_cfg<128, 32, true>(d, akc, bkc, c_plain, stream);
+        default: return x3_launch_cfg<64, 32, true>(d, akc, bkc, c_plain, stream);
+    }
+}
+
+}  // namespace eeg

@@ -12,6 +12,7 @@ of 16 k-tiles) and the dX GEMM that follows it on the main stream (1024 workgrou
 of running as two half-empty waves of lock-stepped workgroups.
 """
 import ctypes
+import os
 
 from . import _abi
 from ._lib import check, lib
@@ -19,9 +20,20 @@ from ._lib import check, lib
 D = _abi.dim
 
 
+def default_gemm_precision():
+    """Arithmetic of the plan GEMMs (every Linear of the encoder / head / prior, forward and backward): split-bf16 products on the bf16 matrix
+    cores by default (include/eegclip.h: EEGCLIP_PREC_BF16X3; embeddings move by <= 3e-5 against exact fp32 products, parity budget 1e-3);
+    EEGCLIP_GEMM_PRECISION=f32 restores exact fp32 products (v_mfma_f32_16x16x4_f32, 1/16 of the rate)."""
+    v = os.environ.get("EEGCLIP_GEMM_PRECISION", "bf16x3").lower()
+    if v not in ("bf16x3", "f32"):
+        raise ValueError("EEGCLIP_GEMM_PRECISION must be 'bf16x3' or 'f32'")
+    return _abi.PREC_BF16X3 if v == "bf16x3" else _abi.PREC_F32
+
+
 class Plan:
-    def __init__(self, name=""):
+    def __init__(self, name="", precision=None):
         self.name = name
+        self.precision = default_gemm_precision() if precision is None else precision
         self.ops = []          # [fn, [args..., stream]]
         self._keep = []        # keep ctypes structs / tensors alive
         self._seed_descs = []
@@ -40,11 +52,12 @@ class Plan:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
     def desc(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None):
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None):
         """a GEMM descriptor owned by the plan but not (yet) an op: member template of a grouped launch"""
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
-                          drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a)
+                          drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a,
+                          precision=self.precision if precision is None else precision)
         self._keep.append(d)
         return d
 

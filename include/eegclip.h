@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 1
+#define EEGCLIP_ABI_VERSION 2
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -38,7 +38,17 @@ typedef struct {
 #define EEGCLIP_ACT_SILU 2 /* x * sigmoid(x) (nn.SiLU: diffusion prior) */
 #define EEGCLIP_ACT_GELU_GRAD 3 /* backward of GELU: v *= gelu'(R[m,n]) -- R holds the forward PRE-activation and is not added */
 
-/* C[m,n] (+)= epilogue( alpha * sum_k A[m,k] * B[k,n] )          fp32 in, fp32 MFMA (exact f32), fp32 out.
+/* Arithmetic of the contraction (eegclip_gemm_desc.precision).  Inputs, accumulation and outputs are fp32 in both modes.
+ *   F32     v_mfma_f32_16x16x4_f32: every product and sum rounded once in fp32 (bit-equal to an fmaf chain); 157 TF peak.
+ *   BF16X3  split precision on the bf16 matrix cores (2.5 PF peak): each operand is split while it is staged into LDS as
+ *           a = a_hi + a_lo (a_hi = bf16(a), a_lo = bf16(a - a_hi)) and a*b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32
+ *           accumulation; the dropped a_lo*b_lo term and the rounding of a_lo bound the error of a product by ~2^-16 |a||b| (fp32: 2^-24).
+ *           Measured on the encoder: embeddings move by <= 3e-5 (parity budget 1e-3).  Needs the plain-stride operand class (every
+ *           Linear of the path, forward and backward); other index maps run as F32. */
+#define EEGCLIP_PREC_F32 0
+#define EEGCLIP_PREC_BF16X3 1
+
+/* C[m,n] (+)= epilogue( alpha * sum_k A[m,k] * B[k,n] )          fp32 in, fp32 accumulate, fp32 out; products per `precision`.
  * epilogue order: +bias_n[n] +bias_m[m] -> (store Cpre) -> act -> dropout(p, Philox(seed, site, m*N+n)) -> +R[m,n]
  * (act = EEGCLIP_ACT_GELU_GRAD: no forward activation; after the dropout stage v *= gelu'(R[m,n]) instead of v += R[m,n] -- the
  *  gradient of dropout(gelu(pre)) w.r.t. pre fused into the GEMM that produces the upstream gradient, Transformer_EncDec.py:48).
@@ -71,6 +81,8 @@ typedef struct {
     unsigned int drop_site;
     int split_k;          /* >= 1 */
     float* rowsum_a;      /* [M] or NULL: += sum_k A[m,k] */
+    int precision;        /* EEGCLIP_PREC_* (0 = exact fp32 products); bits 8..15: BF16X3 tile configuration, 0 = chosen by the library,
+                             1..6 = 64x64x32 | same, two LDS images | 64x64x64 | same, two images | 128x128x32 | same, two images (tuning aid) */
 } eegclip_gemm_desc;
 
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);

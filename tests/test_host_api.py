@@ -36,7 +36,7 @@ def test_header_abi_and_library_agree():
     exported = set(re.findall(r" T (eegclip_\w+)", out))
     assert declared <= exported, declared - exported
     lib = _abi.declare(ctypes.CDLL(libpath))                        # loads without a GPU; no compute call here
-    assert lib.eegclip_abi_version() == 1
+    assert lib.eegclip_abi_version() == _abi.ABI_VERSION
     # every header entry cites the reference lines it replaces
     assert hdr.count(".py:") >= 12
 
