@@ -311,7 +311,7 @@ class _AtmsFn(torch.autograd.Function):
     def forward(ctx, x, anchor, model, ids, shared, train, host_ids=None):
         eng = model._engine()
         out = eng.forward(x, ids, shared, train, host_ids)
-        ctx.eng, ctx.key, ctx.version = eng, eng.last_key, eng.version[eng.last_key]
+        ctx.eng, ctx.key, ctx.version = eng, eng.last_key, eng.version[x.shape[0]]
         ctx.x = x
         ctx.want_dx = x.requires_grad
         return out
@@ -319,7 +319,7 @@ class _AtmsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.eng
-        if eng.version.get(ctx.key) != ctx.version:
+        if eng.version.get(ctx.key[0]) != ctx.version:        # the buffers are shared by EVERY plan of this batch size (train / eval / token branch)
             raise EegclipError("ATMS activations were overwritten by a later forward at the same batch size; "
                                "run backward before the next forward (persistent activation buffers).")
         dx = eng.backward(ctx.key, ctx.x, dout.contiguous(), ctx.want_dx)
@@ -545,7 +545,10 @@ class _Engine:
         return pl
 
     # ---- backward plan -----------------------------------------------------------------------------------------
-    def _build_bwd(self, B, shared, probs, want_dx, early_reduce=False):
+    def _build_bwd(self, B, shared, probs, want_dx, early_reduce=False, train=True):
+        """train=False: backward of an eval-mode forward (frozen-BatchNorm fine-tuning, saliency).  BatchNorm then normalises with the
+        running statistics, which do not depend on the batch: dx = gamma*rstd*da with no batch-mean terms, and the conv biases in front of
+        the two BatchNorms get real gradients (in train mode the mean subtraction cancels them exactly)."""
         P, G, b = self.P, self.G, self.bufs[B]
         pe_, pc_, pp_ = probs
         pl = Plan(f"atms_bwd[B={B}]")
@@ -582,7 +585,17 @@ class _Engine:
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
         # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.
-        W = self._world()
+        W = self._world() if train else 1
+        zsum = None
+        if not train:
+            # eval-mode BatchNorm backward through the SAME apply kernels: they form dx = gamma*rstd*(da - S0/count - xhat*S1/count) from the
+            # `sums` argument and dgamma / dbeta from `sums_local`; a zero `sums` drops the batch-mean terms (= the running-statistics formula)
+            zsum = torch.zeros(2 * C_TS, dtype=torch.float64, device=self.device)
+            pl._keep.append(zsum)
+
+            def conv_bias_grad(bias_key, gamma_key, rstd, s):
+                # d bias[c] = sum over (b,h,w) of the gradient entering the BatchNorm input = gamma[c]*rstd[c]*sum(da)[c]   (40 values)
+                return lambda: G[bias_key].add_((P[gamma_key] * rstd * s[:C_TS].to(torch.float32)))
         pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
                 _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
                 _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), B, pc_, 0, SITE_CONV, seed_at=14)
@@ -595,8 +608,10 @@ class _Engine:
                 local2.copy_(sums[2])
                 self._allreduce(sums[2])
             pl.callback(exchange2, "allreduce_bn2_bwd")
-        pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(sums[2]),
-                _p(local2) if local2 is not None else None, float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
+        if not train:
+            pl.callback(conv_bias_grad(_TS + "4.bias", _TS + "5.weight", bn[3], sums[2]), "conv2_bias_grad_eval")
+        pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                _p(sums[2]) if train else _p(zsum), (_p(local2) if local2 is not None else None) if train else _p(sums[2]), float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
                 W_TS, pc_, 0, SITE_CONV, seed_at=16)
         # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
         # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
@@ -615,8 +630,10 @@ class _Engine:
                 local1.copy_(sums[3])
                 self._allreduce(sums[3])
             pl.callback(exchange1, "allreduce_bn1_bwd")
-        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]), _p(local1) if local1 is not None else None,
-                float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
+        if not train:
+            pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
+        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]) if train else _p(zsum),
+                (_p(local1) if local1 is not None else None) if train else _p(sums[3]), float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
         if "tsw_ws" not in b:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
@@ -776,7 +793,7 @@ class _Engine:
         pl.ops[pl.out_op][1][8] = out.data_ptr()
         pl.run(torch.cuda.current_stream().cuda_stream, seed)
         self.last_key = key
-        self.version[key] = self.version.get(key, 0) + 1
+        self.version[B] = self.version.get(B, 0) + 1
         return out
 
     def attach_grads(self, shared, subjects=()):
@@ -808,9 +825,9 @@ class _Engine:
         if "ds" not in b:
             self._alloc_bwd(B, b)
         early = bool(getattr(self.model, "overlap_grad_allreduce", False)) and _dp_world() > 1
-        pk = ("b", B, shared, probs, want_dx, W, early)
+        pk = ("b", B, train, shared, probs, want_dx, W, early)
         if pk not in self.plans:
-            self.plans[pk] = self._build_bwd(B, shared, probs, want_dx, early)
+            self.plans[pk] = self._build_bwd(B, shared, probs, want_dx, early, train)
         pl = self.plans[pk]
         self.attach_grads(shared, {s for s, _, _ in b["segs"]} if self.joint else ())
         pl.ops[pl.dout_op][1][0] = pl.ops[pl.dout_par_op][1][0] = dout.data_ptr()

@@ -5,6 +5,10 @@ Parameters of ATMS / DiffusionPriorUNet are views into one flat fp32 buffer and 
 the parameters that received a gradient into maximal contiguous runs and issues ONE eegclip_adamw_step launch per run
 (normally 2 per step instead of ~45 tiny foreach kernels).  Semantics are torch's: decoupled weight decay, bias
 correction with a per-parameter step count, parameters whose grad is None are skipped entirely (no decay, no step).
+
+The moments live in two flat buffers shaped like the parameter storage; ``state[p]["exp_avg"]`` / ``["exp_avg_sq"]`` are VIEWS of
+them, so ``state_dict()`` / ``load_state_dict()`` carry step, exp_avg and exp_avg_sq per parameter exactly like torch.optim.AdamW
+(loaded tensors are copied into the flat buffers at the next step; so are the old moments after the model was re-flattened).
 """
 import torch
 
@@ -25,6 +29,27 @@ class AdamW(torch.optim.Optimizer):
             n = st.nbytes() // 4
             self._moments[key] = (torch.zeros(n, dtype=torch.float32, device=p.device), torch.zeros(n, dtype=torch.float32, device=p.device))
         return self._moments[key]
+
+    def _link_state(self, live):
+        """make state[p]["exp_avg"/"exp_avg_sq"] views of the flat moment buffers; moments that live elsewhere (loaded by load_state_dict, or
+        views of the buffers of a storage the model has since left) are copied in first.  Runs only when the set of live tensors changes."""
+        for p in live:
+            m, v = self._moments_for(p)
+            off = (p.data_ptr() - p.untyped_storage().data_ptr()) // 4
+            st = self.state[p]
+            for name, buf in (("exp_avg", m), ("exp_avg_sq", v)):
+                view = buf[off:off + p.numel()].view(p.shape)
+                old = st.get(name)
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old.to(device=view.device, dtype=torch.float32).reshape(p.shape))
+                st[name] = view
+        alive = {p.untyped_storage().data_ptr() for g in self.param_groups for p in g["params"]}
+        for key in [k for k in self._moments if k not in alive]:
+            del self._moments[key]                        # buffers of storages no parameter lives in any more
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._runs_cache.clear()                          # the loaded moments are linked (copied into the flat buffers) at the next step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,7 +72,10 @@ class AdamW(torch.optim.Optimizer):
                 st = steps.pop()
                 runs = [(p0, n, st) for (p0, n) in self._runs_cache[ck]]
             else:
+                self._link_state(live)
                 runs = self._make_runs(live)
+                if len(self._runs_cache) >= 64:           # (joint-subject training: the live set changes with the subjects of the batch)
+                    self._runs_cache.clear()
                 if len(steps) == 1:
                     self._runs_cache[ck] = [(p0, n) for (p0, n, _) in runs]
             b1, b2 = group["betas"]

@@ -513,6 +513,8 @@ class Pipe:
         self.scheduler = scheduler if scheduler is not None else DDPMScheduler()
         self.device = device
         self.lr_history = []
+        self.cond_drop_prob = 0.1            # whole-batch condition drop of the training loop (diffusion_prior.py:304)
+        self.cond_dropped = []               # the decision taken at every update (diagnostics / tests)
 
     def train(self, dataloader, num_epochs=10, learning_rate=1e-4):
         from . import dist as edist
@@ -529,14 +531,25 @@ class Pipe:
         clip = torch.ones(1, dtype=torch.float32, device=device)
         optimizer.grad_scale_dev = clip
         step = 0
+        drop_gen = None
+        if edist.world_size() > 1:
+            # data parallel: the whole-batch condition drop must be ONE decision for all ranks -- a rank that dropped the condition has no
+            # gradient for the condition layers, Adam would skip them there and step them elsewhere, and the replicas would drift apart for
+            # good.  One seed from rank 0 (its global RNG stream, like the single-process draw), then every rank draws the same sequence.
+            import torch.distributed as dist
+            seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+            seed = seed.to(device) if dist.get_backend() == "nccl" else seed
+            dist.broadcast(seed, 0)
+            drop_gen = torch.Generator().manual_seed(int(seed))
         for epoch in range(num_epochs):
             loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
             for batch in dataloader:
                 c_embeds = batch['c_embedding'].to(device) if 'c_embedding' in batch.keys() else None
                 h_embeds = batch['h_embedding'].to(device).float()
                 N = h_embeds.shape[0]
-                if torch.rand(1) < 0.1:                                   # whole-batch condition drop (diffusion_prior.py:304)
+                if (torch.rand(1, generator=drop_gen) if drop_gen is not None else torch.rand(1)) < self.cond_drop_prob:      # (:304)
                     c_embeds = None
+                self.cond_dropped.append(c_embeds is None)
                 noise = torch.randn_like(h_embeds)
                 timesteps = torch.randint(0, T, (N,), device=device)
                 perturbed = self.scheduler.add_noise(h_embeds, noise, timesteps)

@@ -88,8 +88,20 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
     from . import dist as edist
     optimizer.zero_grad()
-    if edist.world_size() > 1 and hasattr(eeg_model, "_engine") and os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0":
-        eeg_model.overlap_grad_allreduce = True          # one backward per step here: its early gradient bucket may be reduced while it still runs
+    overlap = edist.world_size() > 1 and hasattr(eeg_model, "_engine") and os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0"
+    prev_overlap = getattr(eeg_model, "overlap_grad_allreduce", False)
+    if overlap:
+        eeg_model.overlap_grad_allreduce = True          # one backward per step HERE: its early gradient bucket may be reduced while it still runs
+    try:
+        return _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
+                                 alpha, objective)
+    finally:
+        if overlap:
+            eeg_model.overlap_grad_allreduce = prev_overlap      # (a caller accumulating gradients over several backwards must not inherit it)
+
+
+def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct, alpha, objective):
+    from . import dist as edist
     batch_size = eeg_data.size(0)
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
     eeg_features = eeg_model(eeg_data, subject_ids).float()
@@ -160,6 +172,12 @@ def evaluate_model(sub, eeg_model, dataloader, device, text_features_all, img_fe
     all_labels = set(range(text_features_all.size(0)))
     subject_id = extract_id_from_string(sub)
     loss_acc = torch.zeros((), dtype=torch.float32, device=device)
+    # evaluation is per process (the reference evaluates in one process): a loss module configured for data-parallel TRAINING would all-gather
+    # here -- a hang if only rank 0 evaluates, duplicated positives scored as negatives if every rank evaluates the same test set
+    loss_func = eeg_model.loss_func
+    if getattr(loss_func, "world_size", 1) > 1:
+        from .loss import ClipLoss
+        loss_func = ClipLoss(logits_dtype=getattr(loss_func, "logits_dtype", "f32"))
     feats, labs, cands = [], [], []
     n_batches = 0
     with torch.no_grad():
@@ -171,8 +189,8 @@ def evaluate_model(sub, eeg_model, dataloader, device, text_features_all, img_fe
             batch_size = eeg_data.size(0)
             eeg_features = eeg_model(eeg_data, _uniform_ids(batch_size, subject_id, device))
             logit_scale = eeg_model.logit_scale
-            img_loss = eeg_model.loss_func(eeg_features, img_features, logit_scale)
-            text_loss = eeg_model.loss_func(eeg_features, text_features, logit_scale)
+            img_loss = loss_func(eeg_features, img_features, logit_scale)
+            text_loss = loss_func(eeg_features, text_features, logit_scale)
             loss_acc += img_loss * alpha + text_loss * (1 - alpha)
             n_batches += 1
             for label in labels_host:

@@ -321,3 +321,149 @@ def test_dataset_staging_and_device_loader_under_emulator_match_oracle(train, kw
             if bi == 2:
                 break
         assert seen == min(len(ds), 192)
+
+
+def test_eval_mode_backward_uses_running_statistics():
+    """model.eval() with grad enabled (frozen-BatchNorm fine-tuning, saliency).  BatchNorm normalises with the running statistics,
+    so its backward has no batch-mean terms and the conv biases in front of it get real gradients -- against autograd through the oracle's
+    eval-mode forward, input gradient included."""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    rng = np.random.default_rng(5)
+    for k in list(state_np):                      # non-trivial running statistics (the synthetic state has mean 0 / var 1)
+        if k.endswith("running_mean"):
+            state_np[k] = (0.1 * rng.standard_normal(state_np[k].shape)).astype(np.float32)
+        if k.endswith("running_var"):
+            state_np[k] = (0.5 + rng.random(state_np[k].shape)).astype(np.float32)
+    B = 3
+    x0 = syn.eeg_batch(SEED + 43, B)
+    img, txt = T(syn.unit_features(SEED + 43, B, tag="img")), T(syn.unit_features(SEED + 43, B, tag="txt"))
+    with product_on_emulator():
+        m = make_model(state_np).eval()
+        x = T(x0).requires_grad_()
+        z = m(x, 1)
+        loss = 0.99 * m.loss_func(z, img, m.logit_scale) + 0.01 * m.loss_func(z, txt, m.logit_scale)
+        loss.backward()
+        grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+        dx = x.grad.clone()
+    tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
+    xo = T(x0).requires_grad_()
+    zo = oatms.atms_forward(tr.P, xo, torch.full((B,), 1).long(), train=False)
+    lo = oloss.mixed_loss(zo, img, txt, tr.P["logit_scale"])
+    (dxo,) = torch.autograd.grad(lo, [xo])
+    _, _, og, _ = tr.loss_and_grads(T(x0), torch.full((B,), 1).long(), img, txt, train=False)
+    np.testing.assert_allclose(z.detach().numpy(), zo.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(dx.numpy(), dxo.numpy(), atol=3e-3 * float(dxo.abs().max()))
+    for k, g in grads.items():
+        if og[k] is None:
+            assert g is None, k
+        elif k != "encoder.encoder.attn_layers.0.attention.key_projection.bias":       # identically zero (softmax shift invariance)
+            np.testing.assert_allclose(g.numpy(), og[k].numpy(), atol=1e-7 + 3e-3 * float(og[k].abs().max()), err_msg=k)
+    for k in ("enc_eeg.0.tsconv.0.bias", "enc_eeg.0.tsconv.4.bias"):                    # not zero in eval mode
+        assert float(og[k].abs().max()) > 1e-6 and float(grads[k].abs().max()) > 1e-6
+
+
+def test_any_later_forward_at_the_same_batch_size_invalidates_a_pending_backward():
+    """the activation buffers are shared by every plan of a batch size -- a no-grad / eval / other-token-branch forward between
+    a training forward and its backward must make that backward raise, not produce silently wrong gradients"""
+    from eeg_image_decode_amd._lib import EegclipError
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B = 2
+    x = T(syn.eeg_batch(SEED + 44, B))
+    img = T(syn.unit_features(SEED + 44, B, tag="img"))
+    with product_on_emulator():
+        m = make_model(state_np).train()
+        for later in ("eval", "shared_token", "same"):
+            m.train()
+            z = m(x, 1)
+            loss = m.loss_func(z, img, m.logit_scale)
+            if later == "eval":
+                with torch.no_grad():
+                    m.eval()(x, 1)
+            elif later == "shared_token":
+                with torch.no_grad():
+                    m(x, 10)
+            else:
+                with torch.no_grad():
+                    m(x, 1)
+            with pytest.raises(EegclipError):
+                loss.backward()
+        m.train()
+        z = m(x, 1)                                   # a different batch size does not interfere
+        with torch.no_grad():
+            m(torch.cat([x, x]), 1)
+        m.loss_func(z, img, m.logit_scale).backward()
+
+
+def _prior_dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import prior as oprior
+    state = syn.make_state(SEED + 20, oprior.prior_state_spec())
+    rng = np.random.default_rng(100 + rank)                       # every rank trains on its own shard
+    data = [{"c_embedding": T(rng.standard_normal((4, 1024)).astype(np.float32)), "h_embedding": T(rng.standard_normal((4, 1024)).astype(np.float32))}
+            for _ in range(3)]
+    torch.manual_seed(1000 + rank)                                # ... with its own noise / timestep stream
+    with product_on_emulator():
+        from eeg_image_decode_amd.prior import DiffusionPriorUNet, Pipe
+        m = DiffusionPriorUNet(cond_dim=1024)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        pipe = Pipe(m, device="cpu")
+        pipe.cond_drop_prob = 0.5
+        pipe.train(data, num_epochs=2, learning_rate=1e-3)
+        flat = m._engine().flat.clone()
+    ret[rank] = (flat.numpy(), list(pipe.cond_dropped))
+    dist.destroy_process_group()
+
+
+def test_two_rank_prior_training_keeps_replicas_identical_through_condition_drops():
+    """Pipe.train under data parallelism.  The whole-batch condition drop (diffusion_prior.py:304) is one shared decision: with
+    per-rank draws a rank that dropped the condition would skip the Adam update of the condition layers while the others step them."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_prior_dp_worker, args=(world, 29761, ret), nprocs=world, join=True)
+    (p0, d0), (p1, d1) = ret[0], ret[1]
+    assert d0 == d1 and len(d0) == 6
+    assert any(d0) and not all(d0), d0                               # both branches were exercised (p = 0.5, 6 updates, fixed seeds)
+    np.testing.assert_array_equal(p0, p1)
+
+
+def test_fused_adamw_state_dict_round_trip_and_reflatten():
+    """optimizer.state_dict() carries exp_avg / exp_avg_sq per parameter (views of the flat moment buffers); a resumed optimizer and
+    an optimizer whose model was re-flattened (model.float() re-creates the storage) continue exactly like the uninterrupted one"""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B = 2
+    xs = [T(syn.eeg_batch(SEED + 50 + i, B)) for i in range(3)]
+    img = T(syn.unit_features(SEED + 50, B, tag="img"))
+
+    def one(m, opt, x):
+        opt.zero_grad()
+        m.loss_func(m(x, 1), img, m.logit_scale).backward()
+        opt.step()
+
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim
+        ref = make_model(state_np).train()
+        opt_ref = optim.AdamW(ref.parameters(), lr=3e-4)
+        for x in xs:
+            one(ref, opt_ref, x)
+        want = {k: p.detach().clone() for k, p in ref.named_parameters()}
+
+        a = make_model(state_np).train()
+        opt_a = optim.AdamW(a.parameters(), lr=3e-4)
+        one(a, opt_a, xs[0])
+        sd_model, sd_opt = {k: v.clone() for k, v in a.state_dict().items()}, opt_a.state_dict()
+        st = sd_opt["state"]
+        assert all("exp_avg" in v and "exp_avg_sq" in v and "step" in v for v in st.values()) and len(st) > 30
+        b = make_model(state_np).train()                 # resume in a fresh model / optimizer
+        b.load_state_dict(sd_model)
+        opt_b = optim.AdamW(b.parameters(), lr=3e-4)
+        opt_b.load_state_dict(sd_opt)
+        one(b, opt_b, xs[1])
+        b.float()                                        # nn.Module._apply: the engine re-flattens into a NEW storage on the next forward
+        one(b, opt_b, xs[2])
+        # (not bit-equal: split-K GEMMs add with atomics and Adam turns round-off-sized gradients into +-lr steps.  Run-to-run L1 distance of
+        #  the whole parameter vector after these three steps: ~0.1; with the moments dropped at the resume: ~400)
+        l1 = sum(float((p.detach() - want[k]).abs().sum()) for k, p in b.named_parameters())
+        assert l1 < 4.0, l1
+        assert len(opt_b._moments) == 1                  # the buffers of the abandoned storage are gone
