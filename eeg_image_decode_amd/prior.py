@@ -537,7 +537,7 @@ class Pipe:
             # gradient for the condition layers, Adam would skip them there and step them elsewhere, and the replicas would drift apart for
             # good.  One seed from rank 0 (its global RNG stream, like the single-process draw), then every rank draws the same sequence.
             import torch.distributed as dist
-            seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+            seed = torch.empty(1, dtype=torch.int64).random_(0, 2 ** 31 - 1)
             seed = seed.to(device) if dist.get_backend() == "nccl" else seed
             dist.broadcast(seed, 0)
             drop_gen = torch.Generator().manual_seed(int(seed))

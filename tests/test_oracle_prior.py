@@ -96,3 +96,20 @@ def test_ddpm_scheduler_identities():
     out = s.step(n, 0, xt).prev_sample
     sa, sb, c0, ct, sig = s.step_coeffs(0)
     assert sig == 0.0 and abs(ct) < 1e-7 and abs(c0 - 1.0) < 1e-6
+
+
+def test_cosine_warmup_schedule_is_pinned_by_the_transformers_implementation():
+    """diffusers' get_cosine_schedule_with_warmup (diffusion_prior.py:287) is a copy of transformers' function of the same name, and
+    transformers IS installed here: the oracle's and the product's restatements must reproduce it for every update of a 1200-step run, with
+    the reference's order of calls (scheduler.step() before optimizer.step(), :331-332)."""
+    from transformers.optimization import get_cosine_schedule_with_warmup
+    from eeg_image_decode_amd.prior import cosine_with_warmup_lr as product_lr
+    for total in (600, 1200, 400):
+        dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sch = get_cosine_schedule_with_warmup(dummy, num_warmup_steps=500, num_training_steps=total)
+        for step in range(1, total + 1):
+            sch.step()
+            want = dummy.param_groups[0]["lr"]
+            dummy.step()
+            assert abs(oprior.cosine_with_warmup_lr(step, 1e-3, 500, total) - want) <= 1e-18 + 1e-12 * want, (total, step)
+            assert abs(product_lr(step, 1e-3, 500, total) - want) <= 1e-18 + 1e-12 * want, (total, step)
