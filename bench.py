@@ -26,7 +26,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TF = 157.3       # v_mfma_f32_*_f32 dense peak (f32 in / f32 acc)
+PEAK_BF16_MFMA_TF = 2500.0     # v_mfma_f32_*_bf16 dense peak
 N_CLASSES = 1654
+PREC_BF16X3 = 1
 
 
 def algorithmic_cost(name, desc, B):
@@ -61,24 +63,30 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true>"}
 
 
-_GEMM_KERNEL = "eeg::gemm_f32_fast_kernel<true, true, true, false>"      # Y = X W^T launches (forward Linears); f02 is the largest of them
+PMC_SUMMARY = os.path.join("profiles", "r2_pmc_hbm_traffic.json")
 
 
-def pmc_traffic(op_name, B, desc=None):
-    """HBM bytes per launch of the op's kernel from the committed rocprofv3 PMC summary (profiles/r1_pmc_hbm_traffic.json: separate
-    FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH doubled per the gfx950 correction).  Only valid for the profiled B=256."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-    if B != 256 or not os.path.exists(path):
-        return None
+def pmc_traffic(family, B):
+    """(HBM bytes per launch averaged over the family's launches of one step, source) from the COMMITTED rocprofv3 PMC summary of this very
+    command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 correction; tools/pmc_summary.py): PMC counters cannot
+    be collected from inside the process, so this is a stored number next to the live ones -- `traffic_source` says so.  Only for the profiled
+    batch size; (None, None) otherwise."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None, None
     with open(path) as f:
         table = json.load(f)
-    if op_name == "eegclip_gemm_f32" and desc is not None and (desc.M, desc.N, desc.K) == (B * 64, 744, 250):
-        d = table.get(_GEMM_KERNEL)                       # the QKV projection is the largest launch of this instantiation
-        return round(d["hbm_bytes_largest_launch"]) if d and "hbm_bytes_largest_launch" in d else None
-    if op_name not in _KERNEL_OF:
-        return None
-    d = table.get(_KERNEL_OF[op_name])
-    return round(d["hbm_bytes_per_launch"]) if d and "hbm_bytes_per_launch" in d else None
+    if table.get("batch") != B:
+        return None, None
+    d = table.get("families", {}).get(family)
+    return (round(d["hbm_bytes_per_launch"]), PMC_SUMMARY) if d and "hbm_bytes_per_launch" in d else (None, None)
+
+
+def family_of(name, desc):
+    """kernels are grouped for the roofline: every GEMM launch of one arithmetic (they are one kernel template), each other op on its own"""
+    if name == "eegclip_gemm_f32":
+        return "gemm_bf16x3" if (desc.precision & 0xff) == PREC_BF16X3 else "gemm_f32"
+    return name
 
 
 def build(world, rank, B, seed=0):
@@ -141,6 +149,159 @@ def cpu_baseline(B, seconds=12.0):
                       f"{dt:.1f}s after 1 warm-up"}
 
 
+def _ev_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary():
+    """The other rows of SURVEY.md section 8, timed by this process so that they are driver-run numbers, not builder-run ones: InfoNCE at global
+    batch 2048 (north_star's kernel target), diffusion-prior training at batch 1024 (configs[3]), the 50-step prior sampling chain, the SDXL
+    cross-attention kernel at 8 images x CFG (configs[4]), the SDXL-shaped sampling loop, and one end-to-end pass dataset files -> loader -> train_model."""
+    out = {}
+
+    def section(name, fn):
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn()
+            out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:                                # a secondary line must never take the headline down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    section("infonce_global_batch_2048", _sec_infonce)
+    section("prior_train_batch_1024", _sec_prior_train)
+    section("prior_sampling_chain", _sec_prior_chain)
+    section("sdxl_cross_attention", _sec_cross_attn)
+    section("sdxl_sampling_loop", _sec_sdxl_loop)
+    section("end_to_end_dataset_loader_train_model", _sec_end_to_end)
+    return out
+
+
+def _sec_infonce(N=2048, Dm=1024):
+    from eeg_image_decode_amd.loss import ClipLoss
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.nn.functional.layer_norm(torch.randn(N, Dm, device="cuda", generator=g), (Dm,))        # EEG embeddings leave a LayerNorm
+    b = torch.nn.functional.normalize(torch.randn(N, Dm, device="cuda", generator=g), dim=1)          # CLIP targets are unit norm
+    sc = torch.tensor(2.6593, device="cuda")
+    flop = 2.0 * N * N * Dm
+    res = {"workload": f"CLIP-symmetric InfoNCE, N = {N} (8 x 256 gathered), D = {Dm}; fraction = 2*N^2*D / time over the dense bf16 MFMA peak"}
+    ref = None
+    for mode in ("f32", "bf16"):
+        lf = ClipLoss(logits_dtype=mode)
+        with torch.no_grad():
+            ms_f = _ev_ms(lambda: lf(a, b, sc), 30)
+            loss = float(lf(a, b, sc))
+        ar = a.clone().requires_grad_()
+        ms_fb = _ev_ms(lambda: lf(ar, b, sc), 20)            # ClipLoss computes the gradients in its forward (one pass over the logits)
+        ref = loss if ref is None else ref
+        res["parity_mode" if mode == "f32" else "throughput_mode"] = {
+            "logits_dtype": mode, "forward_us": round(ms_f * 1e3, 1), "forward_TFLOPs": round(flop / ms_f / 1e9, 1),
+            "forward_frac_of_bf16_mfma_peak": round(flop / ms_f / 1e9 / PEAK_BF16_MFMA_TF, 4), "forward_backward_us": round(ms_fb * 1e3, 1),
+            "loss": round(loss, 6), "abs_loss_difference_to_parity_mode": round(abs(loss - ref), 7)}
+    return res
+
+
+def _sec_prior_train(B=1024, batches=6):
+    from eeg_image_decode_amd.prior import DiffusionPriorUNet, Pipe
+    g = torch.Generator().manual_seed(0)
+    n = B * batches
+    c, h = torch.randn(n, 1024, generator=g).cuda(), torch.randn(n, 1024, generator=g).cuda()
+    pipe = Pipe(DiffusionPriorUNet(cond_dim=1024, dropout=0.1), device="cuda")
+    dl = [{"c_embedding": c[i:i + B], "h_embedding": h[i:i + B]} for i in range(0, n, B)]       # batches resident in HBM, like the headline
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        pipe.train(dl, num_epochs=1, learning_rate=1e-3)                                        # builds the plans
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.train(dl, num_epochs=4, learning_rate=1e-3)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "configs[3]: diffusion-prior training step (add_noise, forward, MSE, backward, grad-norm clip, Adam) at batch 1024, 1 GPU",
+            "steps": 4 * batches, "ms_per_step": round(1e3 * dt / (4 * batches), 3), "samples_per_s": round(4 * n / dt, 1)}
+
+
+def _sec_prior_chain(n=8, steps=50):
+    from eeg_image_decode_amd.prior import DiffusionPriorUNet, Pipe
+    pipe = Pipe(DiffusionPriorUNet(cond_dim=1024), device="cuda")
+    c = torch.randn(n, 1024, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        pipe.generate(c_embeds=c, num_inference_steps=steps, guidance_scale=5.0, generator=gen)
+    torch.cuda.synchronize()
+    return {"workload": f"Pipe.generate: {steps} DDPM steps with classifier-free guidance for {n} EEG embeddings (one captured HIP graph)",
+            "ms_per_chain": round(1e3 * (time.perf_counter() - t0) / reps, 2)}
+
+
+def _sec_cross_attn(images=8):
+    from eeg_image_decode_amd.sdxl import cross_attention
+    rows = []
+    for HW, heads in ((4096, 10), (1024, 20)):
+        Bc, C = 2 * images, heads * 64
+        q = torch.randn(Bc, HW, C, device="cuda", dtype=torch.float16)
+        k, v = torch.randn(Bc, 77, C, device="cuda", dtype=torch.float16), torch.randn(Bc, 77, C, device="cuda", dtype=torch.float16)
+        ki, vi = torch.randn(Bc, 4, C, device="cuda", dtype=torch.float16), torch.randn(Bc, 4, C, device="cuda", dtype=torch.float16)
+        ms = _ev_ms(lambda: cross_attention(q, k, v, heads, ki, vi, 1.0), 50)
+        byts = 2 * q.numel() * 2 + 2 * (k.numel() + ki.numel()) * 2
+        rows.append({"HW": HW, "C": C, "us": round(ms * 1e3, 1), "GBs": round(byts / ms / 1e6, 1), "frac_of_hbm_peak": round(byts / ms / 1e6 / PEAK_HBM_GBS, 3)})
+    return {"workload": f"configs[4]: softmax(QK^T/8)V + IP-Adapter branch, {images} images x CFG pair, 77 + 4 tokens, fp16; bytes = Q in + O out + K/V",
+            "shapes": rows}
+
+
+def _sec_sdxl_loop():
+    from eeg_image_decode_amd import sdxl
+    if not hasattr(sdxl, "bench_sampling_loop"):
+        return {"skipped": "sampling loop not built in this revision"}
+    return sdxl.bench_sampling_loop(images=8, steps=50)
+
+
+def _sec_end_to_end():
+    """the reference's whole input path: THINGS-EEG files on disk -> EEGDataset (float64 -> HBM-resident float32 split) -> shuffled batches of
+    256 -> train_model (per-epoch host syncs included).  A synthetic tree in the reference's on-disk format with the real channel / time extents."""
+    import shutil
+    import tempfile
+    from eeg_image_decode_amd import optim, retrieval, synthetic as syn
+    from eeg_image_decode_amd.atms import ATMS
+    from eeg_image_decode_amd.datasets import EEGDataset
+    root = tempfile.mkdtemp(prefix="things_bench_")
+    try:
+        cfg = syn.write_things_eeg_tree(root, 3, subjects=("sub-01",), channels=63, n_times=300, dt=0.004, train_classes=52, test_classes=200, test_reps=4)
+        t0 = time.perf_counter()
+        ds = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=True, config=cfg, features_dir=root)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        torch.manual_seed(0)
+        model = ATMS().cuda()
+        opt = optim.AdamW(model.parameters(), lr=3e-4)
+        ld = ds.loader(batch_size=256, shuffle=True, drop_last=True)
+        run = lambda: retrieval.train_model("sub-01", model, ld, opt, "cuda", ds.text_features, ds.img_features, None)
+        run()                                                     # first epoch builds the plans
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        epochs = 6
+        for _ in range(epochs):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = epochs * len(ld) * 256
+        return {"workload": "files -> EEGDataset -> DeviceLoader(256, shuffle) -> train_model, B = 256", "samples": len(ds), "dataset_build_s": round(t_build, 3),
+                "epochs": epochs, "batches_per_epoch": len(ld), "samples_per_s": round(n / dt, 1), "ms_per_step": round(1e3 * dt / (epochs * len(ld)), 4)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,8 +309,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU (BASELINE configs[1]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other SURVEY section 8 rows)")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel of the fwd/bwd plans with HIP events and print a table")
-    ap.add_argument("--roofline-kernel", default="auto", help="op name for the roofline object (auto = the op with the largest total time)")
+    ap.add_argument("--roofline-kernel", default="auto", help="kernel family for the roofline object: gemm_bf16x3, gemm_f32 or an op name such as "
+                    "eegclip_sconv_fwd (auto = the family with the largest total time)")
     args = ap.parse_args()
 
     from eeg_image_decode_amd import dist as edist
@@ -185,37 +348,41 @@ def main():
         step(i)
     eng = model._engine()
     plans = {k: v for k, v in eng.plans.items()}
-    # ---- choose the kernels to time live (HIP events on the launch stream, inside the timed region) -----------------
-    timed_sel = {}
+    # ---- the dominant kernel: 3 instrumented single-stream steps (outside the headline clock) time every launch on its own; launches are
+    # grouped into families (all GEMM launches of one arithmetic are one kernel template) and the family with the largest total time is
+    # the one the roofline object describes.  ALL its launches are then timed live inside the timed region (HIP events on the stream each
+    # launch goes to -- the backward overlaps two streams there, which stretches per-launch durations: both figures are reported).
+    for k, pl in plans.items():
+        pl.use_side_stream = False
+        pl.time_ops(range(len(pl.ops)))
+    for i in range(3):
+        step(i)
+    single = {}                                   # (plan key, op index) -> mean ms on one stream
+    for k, pl in plans.items():
+        for idx, v in pl.timings_ms().items():
+            single[(k, idx)] = float(np.mean(v))
+        pl.time_ops([])
+        pl.use_side_stream = True
+    fam_ops, fam_ms = {}, {}
+    for (k, idx), ms in single.items():
+        name = plans[k].ops[idx][2]
+        d = _desc_of(plans[k], idx)
+        if algorithmic_cost(name, d, B) is None:
+            continue
+        fam = family_of(name, d)
+        fam_ops.setdefault(fam, []).append((k, idx))
+        fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
+    dominant = max(fam_ms, key=fam_ms.get) if args.roofline_kernel == "auto" else args.roofline_kernel
     if args.breakdown:
-        for k, pl in plans.items():
-            pl.use_side_stream = False          # one stream: per-kernel times that add up (the headline run overlaps the weight-gradient kernels)
-            pl.time_ops(range(len(pl.ops)))
-    else:
-        # pass 0 (untimed by the headline clock): 3 instrumented single-stream steps to find the dominant kernel, unless one is named
         for k, pl in plans.items():
             pl.use_side_stream = False
             pl.time_ops(range(len(pl.ops)))
-        for i in range(3):
-            step(i)
-        for k, pl in plans.items():
-            pl.use_side_stream = True
-        tot = {}
-        for k, pl in plans.items():
-            for idx, v in pl.timings_ms().items():
-                tot[(k, idx)] = float(np.mean(v))
-            pl.time_ops([])
-        cands = sorted(tot.items(), key=lambda kv: -kv[1])
-        for (k, idx), ms in cands:
-            name = plans[k].ops[idx][2]
-            # auto: the largest launch whose LIVE duration is its own -- plans with side-stream ops (the backward) overlap kernels of two
-            # streams inside the timed region, which stretches every per-launch duration there; name an op explicitly to time one anyway
-            if args.roofline_kernel == "auto" and any(op[3] for op in plans[k].ops):
-                continue
-            if args.roofline_kernel in ("auto", name) and algorithmic_cost(name, _desc_of(plans[k], idx), B) is not None:
-                timed_sel = {(k, idx): name}
-                plans[k].time_ops([idx])
-                break
+    else:
+        by_plan = {}
+        for k, idx in fam_ops.get(dominant, []):
+            by_plan.setdefault(k, []).append(idx)
+        for k, idxs in by_plan.items():
+            plans[k].time_ops(idxs)
 
     barrier()
     t0 = time.perf_counter()
@@ -230,7 +397,7 @@ def main():
         dt = float(tmax)
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
-    final_loss = float(loss_acc) / (i_ramp + args.warmup + args.steps + (0 if args.breakdown else 3))
+    final_loss = float(loss_acc) / (i_ramp + args.warmup + args.steps + 3)
 
     roof = None
     if args.breakdown:
@@ -247,31 +414,59 @@ def main():
             print(f"# per-kernel HIP-event breakdown (ms/step, mean over {args.steps} steps); sum of kernels = {tot:.3f} ms, step = {ms_per_step:.3f} ms", file=sys.stderr)
             for ms, ph, idx, tag in rows:
                 print(f"#  {ms:8.4f} ms  {100 * ms / tot:5.1f}%  {ph}{idx:02d}  {tag}", file=sys.stderr)
-    else:
-        for (k, idx), name in timed_sel.items():
-            v = plans[k].timings_ms()[idx][-args.steps:]
-            ms = float(np.mean(v))
-            bound, work, unit = algorithmic_cost(name, _desc_of(plans[k], idx), B)
-            if bound == "mfma":
-                ach, peak, u = work / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TF, "TFLOP/s"
-            else:
-                ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-            d = _desc_of(plans[k], idx)
-            roof = {"kernel": name + (f"[{d.M}x{d.N}x{d.K}]" if d is not None else ""), "bound": bound, "achieved": round(ach, 2),
-                    "peak": peak, "unit": u, "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, B, d), "avg_launch_ms": round(ms, 5),
-                    "algorithmic_work_per_launch": work, "work_unit": unit}
+    elif dominant in fam_ops:
+        ops = fam_ops[dominant]
+        live = {}
+        for k in {k for k, _ in ops}:
+            for idx, v in plans[k].timings_ms().items():
+                live[(k, idx)] = float(np.mean(v[-args.steps:]))
+        work = {o: algorithmic_cost(plans[o[0]].ops[o[1]][2], _desc_of(plans[o[0]], o[1]), B) for o in ops}
+        bound, unit = work[ops[0]][0], work[ops[0]][2]
+        w_tot = sum(w[1] for w in work.values())
+        ms_live, ms_single = sum(live[o] for o in ops), sum(single[o] for o in ops)
+        if bound == "mfma":
+            # bf16x3: three bf16 MFMA products per algorithmic multiply-add -> the pipe's ceiling for ALGORITHMIC flops is a third of 2.5 PF
+            peak = PEAK_BF16_MFMA_TF / 3.0 if dominant == "gemm_bf16x3" else PEAK_F32_MFMA_TF
+            scale, u = 1e-3 * 1e12, "TFLOP/s"
+        else:
+            peak, scale, u = PEAK_HBM_GBS, 1e-3 * 1e9, "GB/s"
+        ach = w_tot / (ms_live * scale)
+        big = max(ops, key=lambda o: work[o][1])
+        dbig = _desc_of(plans[big[0]], big[1])
+        traffic, tsrc = pmc_traffic(dominant, B)
+        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel (every Linear of the step, forward / dX / dW: fp32 in/out, split-bf16 products)",
+                        "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)"}
+        roof = {"kernel": kernel_names.get(dominant, dominant), "launches_per_step": len(ops), "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": u, "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_ms": round(ms_live / len(ops), 5), "algorithmic_work_per_launch": w_tot / len(ops), "work_unit": unit,
+                "share_of_kernel_time_single_stream": round(fam_ms[dominant] / sum(single.values()), 3),
+                "single_stream": {"achieved": round(w_tot / (ms_single * scale), 2), "frac": round(w_tot / (ms_single * scale) / peak, 4),
+                                  "note": "same launches timed one at a time on one stream (3 instrumented steps before the timed region)"},
+                "largest_launch": {"shape": f"{dbig.M}x{dbig.N}x{dbig.K}" if dbig is not None else None, "avg_ms": round(live[big], 5),
+                                   "achieved": round(work[big][1] / (live[big] * scale), 2), "frac": round(work[big][1] / (live[big] * scale) / peak, 4)}}
+        if bound == "mfma":
+            roof["frac_of_f32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TF, 4)
+        if dominant == "gemm_bf16x3":
+            roof["peak_note"] = "2.5 PFLOP/s dense bf16 MFMA / 3 products per multiply-add; achieved counts algorithmic 2MNK flops"
+        roof["other_families_single_stream_ms"] = {f: round(v, 4) for f, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])[:8]}
 
     out = {
         "metric": "EEG-CLIP contrastive train samples/sec (global batch)", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",        # fp32 tensors end to end; see config.gemm_arithmetic
         "config": {"workload": "configs[1]: full ATM-S EEG encoder (63ch x 250t -> 1024-d) contrastive train step vs frozen 1024-d CLIP "
                                "embeddings, 256 samples/GPU" + (f", global batch {world * B} with RCCL all-gather negatives (configs[2])" if world > 1 else ""),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "n_classes_for_accuracy": N_CLASSES,
                    "optimizer": "AdamW lr 3e-4 (fused)", "final_mean_loss": round(final_loss, 4),
+                   "gemm_arithmetic": "bf16x3 split products, fp32 accumulate (embeddings within 3e-5 of exact fp32 products)"
+                   if os.environ.get("EEGCLIP_GEMM_PRECISION", "bf16x3") != "f32" else "exact fp32 products (v_mfma_f32_16x16x4_f32)",
                    "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4)},
         "roofline": roof,
     }
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del model, opt, pool
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:
