@@ -278,8 +278,10 @@ def _sec_end_to_end():
     root = tempfile.mkdtemp(prefix="things_bench_")
     try:
         cfg = syn.write_things_eeg_tree(root, 3, subjects=("sub-01",), channels=63, n_times=300, dt=0.004, train_classes=52, test_classes=200, test_reps=4)
+        import contextlib, io
         t0 = time.perf_counter()
-        ds = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=True, config=cfg, features_dir=root)
+        with contextlib.redirect_stdout(io.StringIO()):           # (the dataset class prints its shapes like the reference; stdout carries ONE json line)
+            ds = EEGDataset(cfg["data_path"], subjects=["sub-01"], train=True, config=cfg, features_dir=root)
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
         torch.manual_seed(0)

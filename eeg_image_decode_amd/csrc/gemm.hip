@@ -551,7 +551,7 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const dim3 fgrid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles);
     if (allow_fast && ab_plain && d.K >= 2 && (long long)gx * gy < (1LL << 28) && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) &&
         fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) {
-        if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, akc, bkc, c_plain, stream);
+        if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, akc, bkc, c_plain, false, stream);
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
         const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
 #define EEG_FAST_GO(AK, BK_)                                                                                                         \
@@ -569,6 +569,7 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     // both operands row-contiguous with k running through two-level maps (plain row maps, plain C): the K2 instantiation
     if (allow_fast && c_plain && is_plain(d.Am) && is_plain(d.Bn) && d.Am.si == 1 && d.Bn.si == 1 && d.K >= 2 && (long long)gx * gy < (1LL << 28) &&
         fast_k2_ok(d.A, d.Ak, d.M, d.K) && fast_k2_ok(d.B, d.Bk, d.N, d.K)) {
+        if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, false, false, true, true, stream);
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<0,0,1,K2> %dx%dx%d sk%d\n", d.M, d.N, d.K, d.split_k);
         const size_t lds = 2 * G_BK * G_BT * sizeof(float);
         EEG_LAUNCH((gemm_f32_fast_kernel<false, false, true, true>), fgrid, block, lds, stream, d, gx, ntiles, chunk);

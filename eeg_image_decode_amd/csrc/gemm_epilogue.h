@@ -126,6 +126,7 @@ __device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int sli
 }
 
 // gemm_x3.hip: the split-bf16 kernel for the plain-stride operand classes (akc / bkc: operand is k-contiguous)
-int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream);
+// k2: both operands row-contiguous, k through two-level maps (akc = bkc = false, c_plain = true)
+int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream);
 
 }  // namespace eeg

@@ -71,8 +71,14 @@ struct x3_geom {
     __device__ static __forceinline__ int chunk(int r, int p, int c) { return r * RS + p * (2 * BK) + (((c ^ (r >> 2)) & (NCH - 1)) << 4); }
 };
 
-template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN>
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte global load from a dword-aligned address
+
+// K2: both operands row-contiguous with k running through two-level maps {div, so, si} (the value-embedding weight gradient contracts over
+// the 63 channel rows of every 64-row sample): a thread's k rows advance by BK per tile, so (offset, remainder) are carried along and
+// wrapped by subtraction -- no division in the loop (same scheme as gemm.hip's K2 instantiation)
+template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false>
 __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+    static_assert(!K2 || (!A_KC && !B_KC), "two-level k maps are implemented for row-contiguous operands");
     using G = x3_geom<BK>;
     constexpr int WT = BT / 32;                  // MFMA tiles per wave and dimension
     constexpr int IMG = BT * G::RS;              // bytes of one operand image
@@ -115,6 +121,24 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
 #pragma unroll
         for (int i = 0; i < KC_PASS; ++i) { const int n = n0 + kc_r0 + RPP * i; b_fix[i] = (n < d.N ? n : d.N - 1) * b_ld; }
     } else { const int n = n0 + 2 * mc_mp; b_col = n < d.N ? n : d.N - 2; b_fix[0] = 0; }
+    // K2: element offset / remainder of each k row this thread stages (MC_PASS x 4 rows per operand), for the FIRST tile of the slice
+    constexpr int K2R = K2 ? MC_PASS * 4 : 1;
+    int a_koff[K2R], a_rem[K2R], b_koff[K2R], b_rem[K2R];
+    const int a_div = K2 ? (d.Ak.div > 0x7fffffffLL ? 0x7fffffff : (int)d.Ak.div) : 1;      // plain map: one block that never wraps
+    const int b_div = K2 ? (d.Bk.div > 0x7fffffffLL ? 0x7fffffff : (int)d.Bk.div) : 1;
+    const int a_wrap = K2 ? (int)(d.Ak.so - d.Ak.div * d.Ak.si) : 0, b_wrap = K2 ? (int)(d.Bk.so - d.Bk.div * d.Bk.si) : 0;
+    if (K2) {
+#pragma unroll
+        for (int i = 0; i < MC_PASS; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt_begin * BK + 4 * (mc_q0 + QPP * i) + j;
+                a_rem[4 * i + j] = k % a_div;
+                a_koff[4 * i + j] = (k / a_div) * (int)d.Ak.so + a_rem[4 * i + j] * a_ld;
+                b_rem[4 * i + j] = k % b_div;
+                b_koff[4 * i + j] = (k / b_div) * (int)d.Bk.so + b_rem[4 * i + j] * b_ld;
+            }
+    }
 
     // registers of the tile in flight; the "k beyond K -> 0" select is applied at LDS-store time (a select next to the load would
     // make the wave wait for its prefetch before the MFMAs it overlaps with)
@@ -122,18 +146,31 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
     f32x2_t ra[A_REGS], rb[B_REGS];
     unsigned a_ok = 0, b_ok = 0;
 
-    auto load_op = [&](auto kc_tag, const float* P, const int* fix, int col, int ld, f32x2_t* r, unsigned& ok, int k0) {
+    auto load_op = [&](auto kc_tag, const float* P, const int* fix, int col, int ld, f32x2_t* r, unsigned& ok, int k0, int* koff, int* rem,
+                       int div, int wrap) {
         constexpr bool KC = decltype(kc_tag)::value;
         ok = 0;
         if (KC) {
             const int ka = k0 + 4 * kc_kq;
-            const bool ok0 = ka < d.K, ok1 = ka + 2 < d.K;          // K is even: a pair is in or out as a whole
-            const int k_0 = ok0 ? ka : 0, k_1 = ok1 ? ka + 2 : 0;
-            ok = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
+            if (k0 + BK <= d.K) {
+                // interior tile (workgroup-uniform test): one 16-byte load per 4 consecutive k.  Rows of 250 floats are only 8-byte
+                // aligned; the hardware needs dword alignment for global_load_dwordx4, and half the vector-memory instructions go away
+                ok = 3u;
 #pragma unroll
-            for (int i = 0; i < KC_PASS; ++i) {
-                r[2 * i] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_0);
-                r[2 * i + 1] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_1);
+                for (int i = 0; i < KC_PASS; ++i) {
+                    const f32x4u_t v = *reinterpret_cast<const f32x4u_t*>(P + fix[i] + ka);
+                    r[2 * i] = f32x2_t{v[0], v[1]};
+                    r[2 * i + 1] = f32x2_t{v[2], v[3]};
+                }
+            } else {
+                const bool ok0 = ka < d.K, ok1 = ka + 2 < d.K;      // K is even: a pair is in or out as a whole
+                const int k_0 = ok0 ? ka : 0, k_1 = ok1 ? ka + 2 : 0;
+                ok = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
+#pragma unroll
+                for (int i = 0; i < KC_PASS; ++i) {
+                    r[2 * i] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_0);
+                    r[2 * i + 1] = *reinterpret_cast<const f32x2_t*>(P + fix[i] + k_1);
+                }
             }
         } else {
 #pragma unroll
@@ -142,8 +179,14 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
                 for (int j = 0; j < 4; ++j) {
                     const int k = k0 + 4 * (mc_q0 + QPP * i) + j;
                     const bool okk = k < d.K;
-                    r[4 * i + j] = *reinterpret_cast<const f32x2_t*>(P + (okk ? k : 0) * ld + col);
+                    const int off = K2 ? koff[4 * i + j] : k * ld;
+                    r[4 * i + j] = *reinterpret_cast<const f32x2_t*>(P + (okk ? off : 0) + col);
                     ok |= (okk ? 1u : 0u) << (4 * i + j);
+                    if (K2) {
+                        koff[4 * i + j] += BK * ld;
+                        rem[4 * i + j] += BK;
+                        while (rem[4 * i + j] >= div) { rem[4 * i + j] -= div; koff[4 * i + j] += wrap; }
+                    }
                 }
         }
     };
@@ -180,8 +223,8 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
     using akc_t = std::integral_constant<bool, A_KC>;
     using bkc_t = std::integral_constant<bool, B_KC>;
     auto load_tile = [&](int kt) {
-        load_op(akc_t{}, d.A, a_fix, a_col, a_ld, ra, a_ok, kt * BK);
-        load_op(bkc_t{}, d.B, b_fix, b_col, b_ld, rb, b_ok, kt * BK);
+        load_op(akc_t{}, d.A, a_fix, a_col, a_ld, ra, a_ok, kt * BK, a_koff, a_rem, a_div, a_wrap);
+        load_op(bkc_t{}, d.B, b_fix, b_col, b_ld, rb, b_ok, kt * BK, b_koff, b_rem, b_div, b_wrap);
     };
     auto store_tile = [&](unsigned char* buf) {
         store_op(akc_t{}, buf, ra, a_ok);
@@ -272,7 +315,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
 }
 
 template <int BT, int BK, bool DB>
-static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream) {
+static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
     const int gx = (d.N + BT - 1) / BT, gy = (d.M + BT - 1) / BT;
     const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
     const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
@@ -282,7 +325,8 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_
         if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);     \
         else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);    \
     } while (0)
-    if (akc && bkc)        EEG_X3_GO(true, true);
+    if (k2)                EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, false, false, true, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
+    else if (akc && bkc)   EEG_X3_GO(true, true);
     else if (akc && !bkc)  EEG_X3_GO(true, false);
     else if (!akc && bkc)  EEG_X3_GO(false, true);
     else                   EEG_X3_GO(false, false);
@@ -292,24 +336,26 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_
 
 // Problem -> tile shape.  cfg: 0 = 64x64x32, 1 = 64x64x32 double-buffered, 2 = 64x64x64, 3 = 64x64x64 double-buffered,
 // 4 = 128x128x32, 5 = 128x128x32 double-buffered.  EEGCLIP_X3_CFG pins one for tuning.
-int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, void* stream) {
+int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
     static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
     static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
     int cfg = ((d.precision >> 8) & 0xff) - 1;                  // explicit tile configuration in the descriptor (tuning / tests)
     if (cfg < 0) cfg = pinned;
     if (cfg < 0) {
-        // large tiles only when they still give every CU several workgroups; split-K weight gradients (few output tiles) keep 64x64
+        // measured on the shapes of a training step (profiles/r2_gemm_x3_sweep_*.json): 64x64x64 with one LDS image is the best or within 3 % of
+        // the best everywhere at K ~ 250 and for the split-K weight gradients; 128x128 tiles only pay once K is long and the grid is large (4096^3:
+        // 510 vs 733 us)
         const long long big_tiles = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-        cfg = (d.split_k == 1 && big_tiles >= 1024) ? 5 : 1;
+        cfg = (d.split_k == 1 && big_tiles >= 1024 && d.K >= 1024) ? 5 : 2;
     }
-    if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 cfg %d <%d,%d,%d> %dx%dx%d sk%d\n", cfg, (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
+    if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 cfg %d <%d,%d,%d%s> %dx%dx%d sk%d\n", cfg, (int)akc, (int)bkc, (int)c_plain, k2 ? ",K2" : "", d.M, d.N, d.K, d.split_k);
     switch (cfg) {
-        case 0: return x3_launch_cfg<64, 32, false>(d, akc, bkc, c_plain, stream);
-        case 2: return x3_launch_cfg<64, 64, false>(d, akc, bkc, c_plain, stream);
-        case 3: return x3_launch_cfg<64, 64, true>(d, akc, bkc, c_plain, stream);
-        case 4: return x3_launch_cfg<128, 32, false>(d, akc, bkc, c_plain, stream);
-        case 5: return x3_launch_cfg<128, 32, true>(d, akc, bkc, c_plain, stream);
-        default: return x3_launch_cfg<64, 32, true>(d, akc, bkc, c_plain, stream);
+        case 0: return x3_launch_cfg<64, 32, false>(d, akc, bkc, c_plain, k2, stream);
+        case 2: return x3_launch_cfg<64, 64, false>(d, akc, bkc, c_plain, k2, stream);
+        case 3: return x3_launch_cfg<64, 64, true>(d, akc, bkc, c_plain, k2, stream);
+        case 4: return x3_launch_cfg<128, 32, false>(d, akc, bkc, c_plain, k2, stream);
+        case 5: return x3_launch_cfg<128, 32, true>(d, akc, bkc, c_plain, k2, stream);
+        default: return x3_launch_cfg<64, 32, true>(d, akc, bkc, c_plain, k2, stream);
     }
 }
 

@@ -139,3 +139,21 @@ def test_x3_falls_back_to_f32_products_for_other_operand_classes(be):
     np.testing.assert_allclose(be.host(C), a.astype(np.float64) @ b, atol=2e-5)
     d = mk(be, M, N, K, A, D(K), D(1), B, D(N), D(1), C, D(N), D(1), precision=7)
     assert be.lib.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5])
+@pytest.mark.parametrize("split_k", [1, 3])
+def test_x3_value_embedding_weight_gradient_view(be, cfg, split_k):
+    """dW = dOut[:, 1:, :]^T X with k = (sample, channel) through a two-level map on the gradient side (63 of every 64 token rows) and a
+    plain one on the EEG side: the K2 form of the split kernel (Embed.py:146-149 backward), bias gradient as rowsum_a"""
+    rng = np.random.default_rng(14 + split_k)
+    Bt, Cc, Dm, T = 5, 63, 50, 70
+    dout, x, w0 = f32(rng, Bt, Cc + 1, Dm), f32(rng, Bt, Cc, T), f32(rng, Dm, T)
+    DO, X, W, RS = be.dev(dout), be.dev(x), be.dev(w0), be.zeros(Dm)
+    d = mk(be, Dm, T, Bt * Cc, DO, D(1), D(Dm, div=Cc, so=(Cc + 1) * Dm), X, D(T), D(1), W, D(T), D(1), accumulate=1, split_k=split_k,
+           rowsum_a=be.ptr(RS), precision=prec(cfg))
+    d.A = be.ptr(DO) + 4 * Dm                     # skip token row 0 of sample 0
+    run(be, d)
+    g = dout[:, 1:, :].reshape(-1, Dm)
+    np.testing.assert_allclose(be.host(W), w0 + x3_ref(g.T, x.reshape(-1, T)), atol=2e-4)        # fp32 accumulation over K = 315
+    np.testing.assert_allclose(be.host(RS), g.astype(np.float64).sum(0), atol=2e-4)
