@@ -187,25 +187,45 @@ def secondary():
 
 
 def _sec_infonce(N=2048, Dm=1024):
-    from eeg_image_decode_amd.loss import ClipLoss
+    """north_star's kernel target: the InfoNCE logits at global batch 2048 on the bf16 matrix cores.  `logits_block` = ONE fused launch over one
+    N x N block (tile kernel + the small finalize kernel): 2 N^2 D algorithmic flops, the logits never leave the chip.  `clip_loss_*` = the whole
+    ClipLoss call (feature split, both blocks of the symmetric loss = 4 N^2 D flops, and for forward_backward the gradient matrix + dA GEMM)."""
+    import ctypes
+    from eeg_image_decode_amd import _abi
+    from eeg_image_decode_amd._lib import lib
+    from eeg_image_decode_amd.loss import ClipLoss, split_planes
+    L = lib()
     g = torch.Generator(device="cuda").manual_seed(0)
     a = torch.nn.functional.layer_norm(torch.randn(N, Dm, device="cuda", generator=g), (Dm,))        # EEG embeddings leave a LayerNorm
     b = torch.nn.functional.normalize(torch.randn(N, Dm, device="cuda", generator=g), dim=1)          # CLIP targets are unit norm
     sc = torch.tensor(2.6593, device="cuda")
     flop = 2.0 * N * N * Dm
-    res = {"workload": f"CLIP-symmetric InfoNCE, N = {N} (8 x 256 gathered), D = {Dm}; fraction = 2*N^2*D / time over the dense bf16 MFMA peak"}
+    res = {"workload": f"CLIP-symmetric InfoNCE, N = {N} (8 x 256 gathered), D = {Dm}; fractions are of the dense bf16 MFMA peak (2.5 PFLOP/s)"}
+    st = torch.cuda.current_stream().cuda_stream
+    ws = int(L.eegclip_infonce_fused_workspace_floats(N, N))
     ref = None
-    for mode in ("f32", "bf16"):
+    for mode, planes in (("f32", 2), ("bf16", 1)):
+        ap, bp = split_planes(a, planes), split_planes(b, planes)
+        buf = torch.empty(ws + 2 * N, device="cuda")
+        acc = torch.zeros(2, device="cuda")
+        pr = (_abi.InfonceProblem * 1)(_abi.InfonceProblem(q_hi=ap[0].data_ptr(), q_lo=ap[1].data_ptr() if planes == 2 else None, k_hi=bp[0].data_ptr(),
+                                                           k_lo=bp[1].data_ptr() if planes == 2 else None, col0=0, weight=0.5, part=buf.data_ptr(),
+                                                           diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=None, ldg=0))
+        ms_blk = _ev_ms(lambda: L.eegclip_infonce_fused_fwd(pr, 1, N, N, Dm, planes, N, sc.data_ptr(), acc.data_ptr(), st), 100, warm=10)
+        mult = 3.0 if planes == 2 else 1.0                 # MFMA products per algorithmic multiply-add
         lf = ClipLoss(logits_dtype=mode)
         with torch.no_grad():
             ms_f = _ev_ms(lambda: lf(a, b, sc), 30)
             loss = float(lf(a, b, sc))
         ar = a.clone().requires_grad_()
-        ms_fb = _ev_ms(lambda: lf(ar, b, sc), 20)            # ClipLoss computes the gradients in its forward (one pass over the logits)
+        ms_fb = _ev_ms(lambda: lf(ar, b, sc), 20)            # ClipLoss computes the gradients in its forward (one pass)
         ref = loss if ref is None else ref
         res["parity_mode" if mode == "f32" else "throughput_mode"] = {
-            "logits_dtype": mode, "forward_us": round(ms_f * 1e3, 1), "forward_TFLOPs": round(flop / ms_f / 1e9, 1),
-            "forward_frac_of_bf16_mfma_peak": round(flop / ms_f / 1e9 / PEAK_BF16_MFMA_TF, 4), "forward_backward_us": round(ms_fb * 1e3, 1),
+            "arithmetic": "bf16x3 split products (logits within ~5e-5 of fp32)" if planes == 2 else "one bf16 product (features rounded to bf16)",
+            "logits_block_us": round(ms_blk * 1e3, 2), "logits_block_algorithmic_TFLOPs": round(flop / ms_blk / 1e9, 1),
+            "logits_block_frac_of_bf16_mfma_peak": round(flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
+            "logits_block_mfma_work_frac_of_peak": round(mult * flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
+            "clip_loss_forward_us": round(ms_f * 1e3, 1), "clip_loss_forward_backward_us": round(ms_fb * 1e3, 1),
             "loss": round(loss, 6), "abs_loss_difference_to_parity_mode": round(abs(loss - ref), 7)}
     return res
 

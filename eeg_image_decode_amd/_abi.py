@@ -30,6 +30,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class InfonceProblem(C.Structure):
+    _fields_ = [("q_hi", C.c_void_p), ("q_lo", C.c_void_p), ("k_hi", C.c_void_p), ("k_lo", C.c_void_p), ("col0", C.c_int), ("weight", C.c_float),
+                ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong)]
+
+
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
 ABI_VERSION = 2
@@ -90,6 +95,11 @@ PROTOTYPES = {
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],
     "eegclip_infonce_loss": [_P, _I, _L, _P, _P, _P, _F, _P, _P],
+    "eegclip_split_bf16": [_P, _P, _P, _L, _P],
+    "eegclip_infonce_fused_supported": [_I, _I, _I],
+    "eegclip_infonce_fused_workspace_floats": [_I, _I],
+    "eegclip_infonce_fused_fwd": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
 }

@@ -169,6 +169,31 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c)
 #endif
 }
 
+// 32x32x16 bf16: lane l supplies A[i=l&31][k=8*(l>>5)..+7], B[k=8*(l>>5)..+7][j=l&31]; D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] in reg r (16 regs).
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(EEG_EMU)
+    struct AB { bf16x8 a, b; } in{a, b};
+    auto all = hipemu::wave_allgather(&in, sizeof(in));
+    const int l = hipemu::cur->lane, col = l & 31, hb = 4 * (l >> 5);
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + hb;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            AB ra, rbv;
+            memcpy(&ra, all[row + 32 * h], sizeof(AB));
+            memcpy(&rbv, all[col + 32 * h], sizeof(AB));
+            for (int e = 0; e < 8; ++e)
+                acc += bf16_bits_to_f32((unsigned short)ra.a[e]) * bf16_bits_to_f32((unsigned short)rbv.b[e]);
+        }
+        d[r] = acc;
+    }
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // ---- two-level index -> element offset  (eegclip_dim: offset(i) = (i / div) * so + (i % div) * si) ----
 __device__ __forceinline__ long long dim_off(const eegclip_dim& d, int i) {
     if ((long long)i < d.div) return (long long)i * d.si;      // plain strided dimension (div = 2^62) or first run

@@ -1,0 +1,362 @@
+// Fused CLIP-symmetric InfoNCE (models/loss.py:100-141): the N x N logits never exist in HBM on the forward.
+//
+// One "block" is S = s * Q K^T with Q (n, D) the rows that are scored and K (N, D) what they are scored against; its loss term is the
+// cross-entropy of every row against column col0 + row (loss.py:129-130: labels = arange(n) + n * rank).  The reference's symmetric loss is
+// two such blocks, (Q, K) = (A, B) and (B, A) -- it literally computes both logit matrices (loss.py:122-123); the row-sharded data-parallel
+// form is the same two blocks with K = the gathered features (loss.py:113-115).  So ONE kernel shape covers everything:
+//
+//   infonce_tile_kernel<FWD>   logits tile on the bf16 matrix cores -> per-row (max, sum exp) partial of the tile, the positive logit
+//   infonce_finalize_kernel    partials -> log-sum-exp per row, loss += w / n_total * sum_rows (lse - positive)
+//   infonce_tile_kernel<GRAD>  recomputes the tile, writes G = s * w / n_total * (exp(S - lse_row) [+ exp(S - lse_key)] - [1|2] delta) in fp32 --
+//                              the ONLY N x N array of the step, written once and read once by the dQ = G K GEMM -- and d loss / d s
+//
+// Arithmetic (template NP): NP = 1 "throughput": features rounded to bf16, one product; NP = 2 "parity": features split hi + lo
+// (eegclip_split_bf16), q*k = q_hi k_hi + q_hi k_lo + q_lo k_hi with fp32 accumulation -- logits within ~5e-5 of exact fp32 products
+// (budget 1e-3), like gemm_x3.hip.
+//
+// Tile = TM x TM logits per 256-thread workgroup (TM = 128, or 64 when the block has few tiles: a rank's 256 x 2048 block is 128 workgroups of
+// 64 x 64), 2 x 2 wavefronts, each wave (TM/2)^2 as 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16).  The product is formed TRANSPOSED
+// (MFMA rows = keys, columns = queries): a lane then owns ONE query row and its 16 accumulator registers per tile run over keys, so the
+// row max / row sum are in-lane reductions plus one exchange with lane ^ 32 -- no cross-lane reduction trees.  (The column statistics of the
+// same tile would need them; they are the row statistics of the swapped block, which is a second block of the same launch.)
+// Operand tiles go global -> LDS by LDS-DMA (16 bytes per lane, no VGPRs), 4 stages deep with counted vmcnt, exactly the pipeline of
+// logits_bf16.hip; LDS rows are unpadded (DMA deposits lane-linear), bank conflicts are avoided by XOR-swizzling the 16-byte chunk index on
+// the DMA SOURCE address and on the ds_read address: f(row) = (row >> 1) & 7 for 128-byte rows (BK = 64), (row >> 2) & 3 for 64-byte rows
+// (BK = 32) -- conflict free for the 32x32x16 fragment fetch "lane (r = lane & 31, h = lane >> 5) <- chunk 2 step + h of row r".
+#include "eeg_common.h"
+
+#include <stdlib.h>
+
+namespace eeg {
+
+constexpr int IF_NS = 4;                 // LDS stages
+constexpr int IF_MAX_PROB = 8;
+
+struct if_problem {                      // device copy of eegclip_infonce_problem (pointers only what the kernels use)
+    const unsigned short* q_hi;
+    const unsigned short* q_lo;
+    const unsigned short* k_hi;
+    const unsigned short* k_lo;
+    float* part;                         // [2][P][n]: max plane, sum plane
+    float* diag;                         // [n]
+    float* lse;                          // [n]
+    const float* lse_k;                  // [N] or null
+    float* G;
+    long long ldg;
+    int col0;
+    float weight;
+};
+struct if_table {
+    if_problem p[IF_MAX_PROB];
+};
+
+template <int NP>
+struct if_geom {
+    static constexpr int BK = NP == 1 ? 64 : 32;              // bf16 elements per row of a stage tile
+    static constexpr int ROWB = 2 * BK;                       // bytes per LDS row
+    static constexpr int NCH = BK / 8;                        // 16-byte chunks per row
+    static constexpr int RPI = 1024 / ROWB;                   // rows one DMA instruction deposits
+    __device__ static __forceinline__ int swz(int row) { return NP == 1 ? (row >> 1) & 7 : (row >> 2) & 3; }
+};
+
+// MODE 0 = forward partials, 1 = gradient tile
+template <int NP, int TM, int MODE>
+__global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
+                                                            float inv_total, float* __restrict__ dscale) {
+    using Gm = if_geom<NP>;
+    constexpr int BK = Gm::BK, ROWB = Gm::ROWB, NCH = Gm::NCH, RPI = Gm::RPI;
+    constexpr int WT = TM / 64;                               // 32x32 MFMA tiles per wave and dimension
+    constexpr int TILE_B = TM * ROWB;                         // bytes of one operand-plane tile
+    constexpr int STAGE_B = 2 * NP * TILE_B;                  // q_hi | k_hi | (q_lo | k_lo)
+    constexpr int IPT = TM / RPI / 4;                         // DMA instructions per wave, tile and operand plane
+    constexpr int DPT = 2 * NP * IPT;                         // ... per wave and k-tile (what vmcnt counts)
+    static_assert(IPT >= 1, "tile too small for the 4-wave DMA split");
+    EEG_LDS_BASE(unsigned char, lds);
+
+    const int tiles = tiles_q * tiles_k;
+    const int prob = (int)blockIdx.x / tiles;
+    const int rem = (int)blockIdx.x - prob * tiles;
+    const if_problem& P = tb.p[prob];
+    const int q0 = (rem / tiles_k) * TM, k0r = (rem % tiles_k) * TM;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wq = wave >> 1, wk = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // ---- DMA roles: wave w deposits rows [w * TM/4, +TM/4) of every operand-plane tile, instruction i = rows + RPI * i
+    const int drow = lane / NCH, dpos = lane % NCH;
+    const unsigned short* src[2 * NP][IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int row = wave * (TM / 4) + RPI * i + drow;
+        const int col = 8 * (dpos ^ Gm::swz(row));
+        src[0][i] = P.q_hi + (long long)(q0 + row) * D + col;
+        src[1][i] = P.k_hi + (long long)(k0r + row) * D + col;
+        if (NP == 2) {
+            src[2 * NP - 2][i] = P.q_lo + (long long)(q0 + row) * D + col;
+            src[2 * NP - 1][i] = P.k_lo + (long long)(k0r + row) * D + col;
+        }
+    }
+    auto issue_tile = [&](int kt) {
+        unsigned char* st = lds + (kt % IF_NS) * STAGE_B + wave * (TM / 4) * ROWB;
+#pragma unroll
+        for (int o = 0; o < 2 * NP; ++o)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) lds_dma16(st + o * TILE_B + RPI * i * ROWB, src[o][i] + kt * BK);
+    };
+
+    f32x16 acc[WT][WT];                                       // acc[j][i]: key tile j (MFMA rows), query tile i (MFMA columns)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+    const int ktiles = D / BK;
+#pragma unroll
+    for (int p = 0; p < IF_NS - 1; ++p)
+        if (p < ktiles) issue_tile(p);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int newer = ktiles - 1 - kt < IF_NS - 2 ? ktiles - 1 - kt : IF_NS - 2;      // tiles issued after kt that may stay in flight
+        if (newer >= 2) wait_vmcnt<2 * DPT>();
+        else if (newer == 1) wait_vmcnt<DPT>();
+        else wait_vmcnt<0>();
+        raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
+        if (kt + IF_NS - 1 < ktiles) issue_tile(kt + IF_NS - 1);
+        const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
+        bf16x8 qh[BK / 16][WT], kh[BK / 16][WT], ql[NP == 2 ? BK / 16 : 1][WT], kl[NP == 2 ? BK / 16 : 1][WT];
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                const int rq = wq * (TM / 2) + 32 * i + r32, rk = wk * (TM / 2) + 32 * i + r32;
+                const int oq = rq * ROWB + (((2 * s + h) ^ Gm::swz(rq)) & (NCH - 1)) * 16;
+                const int ok = rk * ROWB + (((2 * s + h) ^ Gm::swz(rk)) & (NCH - 1)) * 16;
+                qh[s][i] = *reinterpret_cast<const bf16x8*>(st + oq);
+                kh[s][i] = *reinterpret_cast<const bf16x8*>(st + TILE_B + ok);
+                if (NP == 2) {
+                    ql[s][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + oq);
+                    kl[s][i] = *reinterpret_cast<const bf16x8*>(st + 3 * TILE_B + ok);
+                }
+            }
+#if !defined(EEG_EMU)
+        __builtin_amdgcn_sched_barrier(0);                    // all fragment reads of the tile ahead of its MFMAs (see logits_bf16.hip)
+#endif
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    if (NP == 2) {
+                        acc[j][i] = mfma_bf16_32x32x16(kl[s][j], qh[s][i], acc[j][i]);
+                        acc[j][i] = mfma_bf16_32x32x16(kh[s][j], ql[s][i], acc[j][i]);
+                    }
+                    acc[j][i] = mfma_bf16_32x32x16(kh[s][j], qh[s][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
+                }
+    }
+
+    // ---- epilogue: lane (r32, h) owns query row q = q0 + wq TM/2 + 32 i + r32 of tile i; register e of key tile j is key
+    //      k = k0r + wk TM/2 + 32 j + (e & 3) + 8 (e >> 2) + 4 h
+    const float s = *scale;
+    if (MODE == 0) {
+        const int Pn = 2 * tiles_k;                           // partial slots per row: (key tile, wk)
+        const int slot = 2 * (rem % tiles_k) + wk;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+            const int q = q0 + wq * (TM / 2) + 32 * i + r32;
+            const int pos = P.col0 + q - (k0r + wk * (TM / 2));      // key index of the positive inside this wave's key range, if any
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[j][i][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // the other half-wave holds the other 16 keys of every 32-key tile
+            // (s may be negative in principle -- it is a trained raw multiplier: take the max of s * x over both extremes)
+            float mn = 3.0e38f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mn = fminf(mn, acc[j][i][e]);
+            mn = fminf(mn, __shfl_xor(mn, 32, 64));
+            const float m = fmaxf(s * mx, s * mn);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = s * acc[j][i][e];
+                    sum += expf(v - m);
+                    if (32 * j + (e & 3) + 8 * (e >> 2) + 4 * h == pos) P.diag[q] = v;      // exactly one lane / register of the launch per row
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            if (h == 0) {
+                P.part[(long long)slot * n + q] = m;
+                P.part[(long long)(Pn + slot) * n + q] = sum;
+            }
+        }
+    } else {
+        const float two = P.lse_k ? 2.f : 1.f;
+        const float c = P.weight * inv_total;
+        float ds = 0.f;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+            const int q = q0 + wq * (TM / 2) + 32 * i + r32;
+            const float lq = P.lse[q];
+            const int kb = k0r + wk * (TM / 2);
+            const int pos = P.col0 + q - kb;
+            float* grow = P.G + (long long)q * P.ldg + kb;
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int eq = 0; eq < 4; ++eq) {              // registers 4 eq .. 4 eq + 3 are 4 CONSECUTIVE keys: one 16-byte store
+                    const int kk = 32 * j + 8 * eq + 4 * h;
+                    f32x4 lk = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (P.lse_k) lk = *reinterpret_cast<const f32x4*>(P.lse_k + kb + kk);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float raw = acc[j][i][4 * eq + e];
+                        const float v = s * raw;
+                        float g = expf(v - lq);
+                        if (P.lse_k) g += expf(v - lk[e]);
+                        if (kk + e == pos) g -= two;
+                        g *= c;
+                        ds += g * raw;
+                        o[e] = g * s;
+                    }
+                    *reinterpret_cast<f32x4*>(grow + kk) = o;
+                }
+        }
+        ds = wave_sum(ds);
+        if (lane == 0) atomicAdd(dscale, ds);
+    }
+}
+
+// partials -> lse; loss.  One thread per row; grid.y = problem
+__global__ __launch_bounds__(256) void infonce_finalize_kernel(const if_table tb, int n, int Pn, float inv_total, float* __restrict__ loss) {
+    const if_problem& P = tb.p[blockIdx.y];
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    float contrib = 0.f;
+    if (q < n) {
+        float m = -3.0e38f;
+        for (int p = 0; p < Pn; ++p) m = fmaxf(m, P.part[(long long)p * n + q]);
+        float l = 0.f;
+        for (int p = 0; p < Pn; ++p) l += P.part[(long long)(Pn + p) * n + q] * expf(P.part[(long long)p * n + q] - m);
+        const float lse = m + logf(l);
+        P.lse[q] = lse;
+        contrib = (lse - P.diag[q]) * P.weight * inv_total;
+    }
+    contrib = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(loss, contrib);
+}
+
+// fp32 -> bf16 hi (+ lo = bf16(x - hi)) planes, 8 elements per thread
+typedef unsigned int ifu32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                          long long n8) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n8; q += (long long)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 8 * q), b = *reinterpret_cast<const f32x4*>(x + 8 * q + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        unsigned short hb[8], lb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hb[e] = f32_to_bf16_bits(v[e]);
+            lb[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(hb[e]));
+        }
+        ifu32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hb[2 * e] | ((unsigned)hb[2 * e + 1] << 16);
+        *reinterpret_cast<ifu32x4*>(hi + 8 * q) = o;
+        if (lo) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = lb[2 * e] | ((unsigned)lb[2 * e + 1] << 16);
+            *reinterpret_cast<ifu32x4*>(lo + 8 * q) = o;
+        }
+    }
+}
+
+// `force`: bits 8..15 of the `planes` argument (tuning / tests): 0 = chosen here, 64 or 128
+static inline int if_tile(int n, int N, int force = 0) {
+    if (force == 128 && n % 128 == 0 && N % 128 == 0) return 128;
+    if (force == 64) return 64;
+    // 128 x 128 tiles once they fill the chip on their own; 64 x 64 otherwise (a rank's 256 x 2048 block: 128 workgroups per block)
+    return (n % 128 == 0 && N % 128 == 0 && (long long)(n / 128) * (N / 128) >= 256) ? 128 : 64;
+}
+
+static int if_table_from(const eegclip_infonce_problem* probs, int nprob, int planes, bool grad, if_table& tb) {
+    if (!probs || nprob < 1 || nprob > IF_MAX_PROB) return EEGCLIP_EINVAL;
+    for (int i = 0; i < nprob; ++i) {
+        const eegclip_infonce_problem& p = probs[i];
+        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || !p.lse || (!grad && (!p.part || !p.diag)) || (grad && (!p.G || (p.ldg & 3))))
+            return EEGCLIP_EINVAL;
+        uintptr_t al = reinterpret_cast<uintptr_t>(p.q_hi) | reinterpret_cast<uintptr_t>(p.k_hi) | reinterpret_cast<uintptr_t>(p.q_lo) |
+                       reinterpret_cast<uintptr_t>(p.k_lo) | reinterpret_cast<uintptr_t>(p.G) | reinterpret_cast<uintptr_t>(p.lse_k);
+        if (al & 15u) return EEGCLIP_EALIGN;
+        tb.p[i] = if_problem{static_cast<const unsigned short*>(p.q_hi), static_cast<const unsigned short*>(p.q_lo), static_cast<const unsigned short*>(p.k_hi),
+                             static_cast<const unsigned short*>(p.k_lo), p.part, p.diag, p.lse, p.lse_k, p.G, p.ldg, p.col0, p.weight};
+    }
+    return 0;
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_split_bf16(const float* x, void* hi, void* lo, long long n, void* stream) {
+    if (!x || !hi || n < 0 || (n & 7)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15u) return EEGCLIP_EALIGN;
+    if (n == 0) return 0;
+    long long g = (n / 8 + 255) / 256;
+    if (g > 4096) g = 4096;
+    EEG_LAUNCH(split_bf16_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, static_cast<unsigned short*>(hi), static_cast<unsigned short*>(lo), n / 8);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_infonce_fused_supported(int n, int N, int D) { return n >= 64 && N >= 64 && n % 64 == 0 && N % 64 == 0 && D >= 64 && D % 64 == 0; }
+
+extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
+    if (n < 1 || N < 1) return 0;
+    return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
+}
+
+#define EEG_IF_GO(NP_, TM_, MODE_)                                                                                                              \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_>), dim3((unsigned)(nprob * tq * tk)), dim3(256), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
+               stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+
+static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
+                           void* stream) {
+    const int TM = if_tile(n, N, planes >> 8), tq = n / TM, tk = N / TM;
+    planes &= 0xff;
+    if (planes == 1) {
+        if (TM == 128) { if (mode == 0) EEG_IF_GO(1, 128, 0); else EEG_IF_GO(1, 128, 1); }
+        else           { if (mode == 0) EEG_IF_GO(1, 64, 0);  else EEG_IF_GO(1, 64, 1); }
+    } else {
+        if (TM == 128) { if (mode == 0) EEG_IF_GO(2, 128, 0); else EEG_IF_GO(2, 128, 1); }
+        else           { if (mode == 0) EEG_IF_GO(2, 64, 0);  else EEG_IF_GO(2, 64, 1); }
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, int nprob, int n, int N, int D, int planes, int n_total,
+                                         const float* scale, float* loss, void* stream) {
+    if (!eegclip_infonce_fused_supported(n, N, D) || ((planes & 0xff) != 1 && (planes & 0xff) != 2) || !scale || !loss || n_total < 1) return EEGCLIP_EINVAL;
+    if_table tb;
+    int rc = if_table_from(probs, nprob, planes & 0xff, false, tb);
+    if (rc) return rc;
+    const float inv_total = 1.0f / (float)n_total;
+    rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
+    if (rc) return rc;
+    const int Pn = 2 * (N / if_tile(n, N, planes >> 8));
+    EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nprob), dim3(256), 0, stream, tb, n, Pn, inv_total, loss);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_infonce_fused_grad(const eegclip_infonce_problem* probs, int nprob, int n, int N, int D, int planes, int n_total,
+                                          const float* scale, float* dscale, void* stream) {
+    if (!eegclip_infonce_fused_supported(n, N, D) || ((planes & 0xff) != 1 && (planes & 0xff) != 2) || !scale || !dscale || n_total < 1) return EEGCLIP_EINVAL;
+    if_table tb;
+    const int rc = if_table_from(probs, nprob, planes & 0xff, true, tb);
+    if (rc) return rc;
+    return if_launch_tiles(tb, nprob, n, N, D, planes, 1, scale, 1.0f / (float)n_total, dscale, stream);
+}

@@ -3,12 +3,16 @@
     loss = ClipLoss(local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1)(z_eeg, z_tgt, logit_scale)
 
 `logit_scale` multiplies the logits RAW (no exp) exactly like the reference.  The N x N
-logits are produced by the fp32-MFMA GEMM, row/column log-sum-exp and the gradient matrix by the loss kernels
-(csrc/loss.hip); gradients w.r.t. both feature matrices and the scale are computed in the same pass and handed to
-autograd.  world_size > 1 reproduces the three gather modes of models/loss.py:20-75 over torch.distributed (RCCL on
-ROCm): all-gather forward, reduce-scatter of the gathered-feature gradients when gather_with_grad is set.
+logits are never written on the forward: csrc/infonce_fused.hip forms logits tiles on the bf16 matrix cores (split-bf16 products,
+fp32 accumulate: logits within ~5e-5 of exact fp32 products) and keeps only per-row log-sum-exp partials; the backward recomputes
+the tiles, writes the gradient matrix G once and the feature gradients are GEMMs over it.  Shapes the fused kernels do not take
+(n, N or D not a multiple of 64) use the fp32-MFMA GEMM + row/column log-sum-exp kernels of csrc/loss.hip.  Gradients w.r.t. both
+feature matrices and the scale are computed in the forward pass and handed to autograd.  world_size > 1 reproduces the three gather
+modes of models/loss.py:20-75 over torch.distributed (RCCL on ROCm): all-gather forward, reduce-scatter of the gathered-feature
+gradients when gather_with_grad is set.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -23,10 +27,59 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _gemm(M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, alpha=1.0, accumulate=0, split_k=1):
+def _gemm(M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, alpha=1.0, accumulate=0, split_k=1, precision=0):
     d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=None, bias_n=None, bias_m=None,
-                      R=None, Rm=D(0), Rn=D(0), alpha=alpha, accumulate=accumulate, act=0, drop_p=0.0, seed=0, drop_site=0, split_k=split_k)
+                      R=None, Rm=D(0), Rn=D(0), alpha=alpha, accumulate=accumulate, act=0, drop_p=0.0, seed=0, drop_site=0, split_k=split_k,
+                      precision=precision)
     check(lib().eegclip_gemm_f32(ctypes.byref(d), _stream()), "gemm")
+
+
+def fused_enabled(n, N, Dm):
+    """the fused kernels take whole 64-tiles (every training configuration of the path: 256 per GPU, D = 1024); EEGCLIP_INFONCE_FUSED=0 pins
+    the GEMM + log-sum-exp route (diagnosis)"""
+    return os.environ.get("EEGCLIP_INFONCE_FUSED", "1") != "0" and bool(lib().eegclip_infonce_fused_supported(int(n), int(N), int(Dm)))
+
+
+def split_planes(x, planes):
+    """fp32 features -> bf16 planes (hi, lo): x ~ hi + lo; lo is None in the one-product (throughput) mode"""
+    n, Dm = x.shape
+    hi = torch.empty(n, Dm, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(n, Dm, dtype=torch.bfloat16, device=x.device) if planes == 2 else None
+    check(lib().eegclip_split_bf16(x.data_ptr(), hi.data_ptr(), lo.data_ptr() if lo is not None else None, n * Dm, _stream()), "split_bf16")
+    return hi, lo
+
+
+def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
+    """blocks = [(q planes, k planes, col0, weight)]: adds sum_blocks weight / n_total * sum_rows (lse_row - positive) to acc[0].
+    want_grad = [(block index, index of the block whose lse is the second (per-key) normaliser, or None)]: for each, the gradient matrix
+    G = s * dL/dS of that block ((n, N) fp32, written once) is returned and d loss / d s is added to acc[1]."""
+    L = lib()
+    dev = sc.device
+    nb = len(blocks)
+    ws = int(L.eegclip_infonce_fused_workspace_floats(n, N))
+    buf = torch.empty(nb * (ws + 2 * n), dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    arr = (_abi.InfonceProblem * nb)()
+    for i, ((qh, ql), (kh, kl), col0, w) in enumerate(blocks):
+        o = base + 4 * i * (ws + 2 * n)
+        arr[i] = _abi.InfonceProblem(q_hi=qh.data_ptr(), q_lo=ql.data_ptr() if ql is not None else None, k_hi=kh.data_ptr(),
+                                     k_lo=kl.data_ptr() if kl is not None else None, col0=int(col0), weight=float(w), part=o, diag=o + 4 * ws,
+                                     lse=o + 4 * (ws + n), lse_k=None, G=None, ldg=0)
+    st = _stream()
+    check(L.eegclip_infonce_fused_fwd(arr, nb, n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr(), st), "infonce_fused_fwd")
+    if not want_grad:
+        return []
+    garr = (_abi.InfonceProblem * len(want_grad))()
+    Gs = []
+    for j, (bi, ki) in enumerate(want_grad):
+        G = torch.empty(n, N, dtype=torch.float32, device=dev)
+        Gs.append(G)
+        garr[j] = arr[bi]
+        garr[j].G, garr[j].ldg = G.data_ptr(), N
+        garr[j].lse_k = arr[ki].lse if ki is not None else None
+    check(L.eegclip_infonce_fused_grad(garr, len(want_grad), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
+    Gs[0]._eegclip_keep = buf                      # the lse vectors must outlive the launch (stream-ordered allocator: already safe; explicit)
+    return Gs
 
 
 def _scale_ptr(logit_scale, device):
@@ -81,25 +134,27 @@ def infonce_block(a_rows, b_cols, sc, col0, n_total, weight, row_term, col_term,
     return acc[0:1], acc[1:2], X
 
 
-def _grad_rows(X, b_cols, out=None):
+def _grad_rows(X, b_cols, out=None, precision=0):
     """dA (+)= (s G) B  -> (n, D)"""
     n, N = X.shape
     Dm = b_cols.shape[1]
     accumulate = out is not None
     if out is None:
         out = torch.empty(n, Dm, dtype=torch.float32, device=X.device)
-    _gemm(n, Dm, N, X.data_ptr(), D(N), D(1), b_cols.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate))
+    _gemm(n, Dm, N, X.data_ptr(), D(X.stride(0)), D(1), b_cols.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate),
+          precision=precision)
     return out
 
 
-def _grad_cols(X, a_rows, out=None):
+def _grad_cols(X, a_rows, out=None, precision=0):
     """dB (+)= (s G)^T A -> (N, D)"""
     n, N = X.shape
     Dm = a_rows.shape[1]
     accumulate = out is not None
     if out is None:
         out = torch.empty(N, Dm, dtype=torch.float32, device=X.device)
-    _gemm(N, Dm, n, X.data_ptr(), D(1), D(N), a_rows.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate))
+    _gemm(N, Dm, n, X.data_ptr(), D(1), D(X.stride(0)), a_rows.data_ptr(), D(Dm), D(1), out.data_ptr(), D(Dm), D(1), accumulate=int(accumulate),
+          precision=precision)
     return out
 
 
@@ -124,7 +179,24 @@ class _ClipLossFn(torch.autograd.Function):
         acc = torch.zeros(2, dtype=torch.float32, device=dev)
         da = None
         dbs = [None] * len(bs)
-        if W == 1:
+        planes = 2 if mod.logits_dtype == "f32" else 1
+        PX3 = _abi.PREC_BF16X3                              # the dQ = G K / dK = G^T Q GEMMs behind the fused kernels: split-bf16 products too
+        Dm = a_.shape[1]
+        if W == 1 and fused_enabled(n, n, Dm) and all(b.shape == a_.shape for b in bs):
+            # blocks (A, B_t) and (B_t, A) of every target in ONE launch; one gradient matrix per target with both normalisers
+            ap = split_planes(a_, planes)
+            bps = [split_planes(b_, planes) for b_ in bs]
+            blocks, want = [], []
+            for t, w in enumerate(weights):
+                blocks += [(ap, bps[t], 0, 0.5 * w), (bps[t], ap, 0, 0.5 * w)]
+                want.append((2 * t, 2 * t + 1))
+            Gs = fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want if need else [])
+            for t, b_ in enumerate(bs):
+                if need_a:
+                    da = _grad_rows(Gs[t], b_, da, PX3)
+                if need_b[t]:
+                    dbs[t] = _grad_cols(Gs[t], a_, None, PX3)
+        elif W == 1:
             for t, (b_, w) in enumerate(zip(bs, weights)):
                 _, _, X = infonce_block(a_, b_, sc, 0, n, w, True, True, need, acc, mod.logits_dtype == "bf16")
                 if need_a:
@@ -137,9 +209,50 @@ class _ClipLossFn(torch.autograd.Function):
             dist.all_gather_into_tensor(a_all, a_)
             ga = None                                              # gradient w.r.t. the gathered copies of a (local_loss + gather_with_grad)
             sl = slice(rank * n, (rank + 1) * n)
+            N = W * n
+            fused = fused_enabled(n, N, Dm) and all(b.shape == a_.shape for b in bs)
+            if fused:
+                a_all_p = split_planes(a_all, planes)
+                ap = (a_all_p[0][sl], a_all_p[1][sl] if planes == 2 else None)        # this rank's rows of the gathered planes
             for t, (b_, w) in enumerate(zip(bs, weights)):
                 b_all = torch.empty(W * n, b_.shape[1], dtype=torch.float32, device=dev)
                 dist.all_gather_into_tensor(b_all, b_)
+                if fused:
+                    b_all_p = split_planes(b_all, planes)
+                    bp = (b_all_p[0][sl], b_all_p[1][sl] if planes == 2 else None)
+                    if not mod.local_loss:
+                        # every rank scores the full N x N matrix (models/loss.py:117-121): both terms from one gradient matrix
+                        Gs = fused_infonce([(a_all_p, b_all_p, 0, 0.5 * w), (b_all_p, a_all_p, 0, 0.5 * w)], N, N, Dm, planes, N, sc, acc,
+                                           [(0, 1)] if need else [])
+                        if not need:
+                            continue
+                        G = Gs[0]
+                        mult = float(W) if mod.gather_with_grad else 1.0
+                        if need_a:
+                            part = _grad_rows(G[sl], b_all, None, PX3) * mult
+                            da = part if da is None else da + part
+                        if need_b[t]:
+                            dbs[t] = _grad_cols(G, a_all, None, PX3)[sl] * mult
+                    else:
+                        # row-sharded (models/loss.py:113-115,129-130): this rank's rows against everybody's, positives at column i + n*rank
+                        Gs = fused_infonce([(ap, b_all_p, rank * n, 0.5 * w), (bp, a_all_p, rank * n, 0.5 * w)], n, N, Dm, planes, n, sc, acc,
+                                           [(0, None), (1, None)] if need else [])
+                        if not need:
+                            continue
+                        G1, G2 = Gs
+                        if need_a:
+                            da = _grad_rows(G1, b_all, da, PX3)
+                        if need_b[t]:
+                            dbs[t] = _grad_rows(G2, a_all, None, PX3)
+                        if mod.gather_with_grad:
+                            if need_a:
+                                ga = _grad_cols(G2, b_, ga, PX3)
+                            if need_b[t]:
+                                gb = _grad_cols(G1, a_, None, PX3)
+                                part = torch.empty_like(b_)
+                                dist.reduce_scatter_tensor(part, gb)
+                                dbs[t] = dbs[t] + part
+                    continue
                 if not mod.local_loss:
                     # every rank scores the full N x N matrix (models/loss.py:117-121)
                     _, _, X = infonce_block(a_all, b_all, sc, 0, W * n, w, True, True, need, acc, mod.logits_dtype == "bf16")

@@ -256,6 +256,41 @@ int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, i
 int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
                          float* loss, void* stream);
 
+/* ---- fused InfoNCE (models/loss.py:100-141) on the bf16 matrix cores: the N x N logits are never written on the forward.
+ * A "block" is S = s * Q K^T (Q: the n rows that are scored, K: the N rows they are scored against, both (., D) row-major) with the positive of
+ * row i at column col0 + i (loss.py:129-130).  The symmetric loss of the reference is two blocks, (A, B) and (B, A) -- it computes both logit
+ * matrices, loss.py:122-123; the row-sharded data-parallel form (loss.py:113-115) is the same two blocks against the gathered features.
+ *   split_bf16   x -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL); n % 8 == 0, 16-byte aligned pointers
+ *   fused_fwd    per block: row log-sum-exp -> lse[n]; *loss += sum_blocks weight / n_total * sum_rows (lse - S[i, col0 + i])
+ *                (`part` = workspace of eegclip_infonce_fused_workspace_floats(n, N) floats, `diag` = n floats; both written here)
+ *   fused_grad   per block: G[i, j] = s * weight / n_total * (exp(S_ij - lse[i]) + (lse_k ? exp(S_ij - lse_k[j]) : 0) - (lse_k ? 2 : 1) [j == col0 + i])
+ *                in fp32 (n x N, leading dimension ldg, ldg % 4 == 0) and *dscale += d loss / d s: then dQ = G K and dK = G^T Q are plain GEMMs.
+ *                lse_k = the lse of the SWAPPED block (the column normaliser of the square single-process case: one G for both CE terms).
+ * planes = 1: one bf16 product (features rounded to bf16: logit error ~2^-9 |q||k|, the throughput mode); planes = 2: q k = q_hi k_hi + q_hi k_lo +
+ * q_lo k_hi, fp32 accumulate (logits within ~5e-5 of exact fp32 products: the parity mode).  All blocks of one call share n, N, D; at most 8.
+ * Supported shapes: n, N, D multiples of 64 (eegclip_infonce_fused_supported); anything else takes the GEMM + lse_rows/lse_cols route. */
+typedef struct {
+    const void* q_hi;     /* (n, D) bf16 */
+    const void* q_lo;     /* (n, D) bf16 or NULL (planes = 1) */
+    const void* k_hi;     /* (N, D) bf16 */
+    const void* k_lo;
+    int col0;             /* positive of row i = column col0 + i */
+    float weight;         /* loss weight of this block (the 1/2 of the symmetric loss and the target mix included) */
+    float* part;          /* workspace (fwd) */
+    float* diag;          /* [n] positives (fwd out) */
+    float* lse;           /* [n] (fwd out, grad in) */
+    const float* lse_k;   /* [N] or NULL (grad in) */
+    float* G;             /* (n, ldg) fp32 (grad out) */
+    long long ldg;
+} eegclip_infonce_problem;
+int eegclip_split_bf16(const float* x, void* hi, void* lo, long long n, void* stream);
+int eegclip_infonce_fused_supported(int n, int N, int D);
+long long eegclip_infonce_fused_workspace_floats(int n, int N);
+int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* blocks, int n_blocks, int n, int N, int D, int planes, int n_total,
+                              const float* scale, float* loss, void* stream);
+int eegclip_infonce_fused_grad(const eegclip_infonce_problem* blocks, int n_blocks, int n, int N, int D, int planes, int n_total,
+                               const float* scale, float* dscale, void* stream);
+
 /* ---- tail of tsconv + Enc_eeg projection, one workgroup per sample (ATMS_retrieval.py:107-109,113-114,145):
  *   fwd: z2 = dropout(ELU(BatchNorm2(y2)))  (B,40,36);  feat[b, w*40+e] = bias[e] + sum_c W[e,c] z2[b,c,w]   (B,1440)
  *   bwd: dW += dfeat^T z2 ; dbias += sum dfeat ; dz2 = W^T dfeat (written) ; sums[2*40] += BatchNorm-backward statistics of

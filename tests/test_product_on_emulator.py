@@ -467,3 +467,72 @@ def test_fused_adamw_state_dict_round_trip_and_reflatten():
         l1 = sum(float((p.detach() - want[k]).abs().sum()) for k, p in b.named_parameters())
         assert l1 < 4.0, l1
         assert len(opt_b._moments) == 1                  # the buffers of the abandoned storage are gone
+
+
+@pytest.mark.parametrize("logits_dtype", ["f32", "bf16"])
+def test_fused_clip_loss_matches_the_oracle_and_the_unfused_route(logits_dtype, monkeypatch):
+    """ClipLoss on the fused kernels (n, D multiples of 64): value, d/dz, d/dtarget, d/dscale against the oracle's autograd (models/loss.py:
+    122-140) -- parity mode within fp32 round-off class, throughput mode within its bf16 budget -- and the mixed two-target form"""
+    rng = np.random.default_rng(11)
+    n, Dm = 64, 128
+    z0 = rng.standard_normal((n, Dm)).astype(np.float32)
+    z0 = (z0 - z0.mean(1, keepdims=True)) / z0.std(1, keepdims=True)
+    img0, txt0 = syn.unit_features(3, n, Dm, tag="fi"), syn.unit_features(3, n, Dm, tag="ft")
+    tol = 3e-5 if logits_dtype == "f32" else 2e-2
+    with product_on_emulator():
+        from eeg_image_decode_amd import loss as ploss
+        lf = ploss.ClipLoss(logits_dtype=logits_dtype)
+        z, img, txt = T(z0).requires_grad_(), T(img0).requires_grad_(), T(txt0)
+        sc = torch.tensor(2.6593, requires_grad=True)
+        calls = []
+        real = ploss.fused_infonce
+        monkeypatch.setattr(ploss, "fused_infonce", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        loss = lf.forward_mixed(z, [(img, 0.99), (txt, 0.01)], sc)
+        (3.0 * loss).backward()
+        assert calls, "the fused route was not taken"
+        got = [loss.detach().clone(), z.grad.clone(), img.grad.clone(), sc.grad.clone()]
+    zo, io, to = T(z0).requires_grad_(), T(img0).requires_grad_(), T(txt0)
+    so = torch.tensor(2.6593, requires_grad=True)
+    lo = oloss.mixed_loss(zo, io, to, so)
+    (3.0 * lo).backward()
+    assert abs(float(got[0]) - float(lo)) < tol * max(1.0, abs(float(lo)))
+    for g, r in ((got[1], zo.grad), (got[2], io.grad), (got[3], so.grad)):
+        np.testing.assert_allclose(g.numpy(), r.numpy(), atol=(2e-3 if logits_dtype == "f32" else 5e-2) * float(r.abs().max()) + 1e-8)
+
+
+def _fused_dp_worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, Dm = 64, 64
+    a_all = T(syn.unit_features(SEED + 9, n * world, Dm, tag="da") * 8.0)
+    b_all = T(syn.unit_features(SEED + 9, n * world, Dm, tag="db"))
+    outs = []
+    with product_on_emulator():
+        from eeg_image_decode_amd.loss import ClipLoss
+        for fused in ("1", "0"):
+            os.environ["EEGCLIP_INFONCE_FUSED"] = fused
+            a = a_all[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+            b = b_all[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+            sc = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+            l = ClipLoss(local_loss=mode[0], gather_with_grad=mode[1], rank=rank, world_size=world)(a, b, sc)
+            l.backward()
+            outs.append((float(l), a.grad.numpy().copy(), b.grad.numpy().copy(), float(sc.grad)))
+    os.environ.pop("EEGCLIP_INFONCE_FUSED", None)
+    ret[rank] = outs
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", [(False, False), (False, True), (True, True)])
+def test_fused_clip_loss_gather_modes_equal_the_unfused_route_on_two_ranks(mode):
+    """the three gather modes of models/loss.py:20-75 on the fused kernels (row-sharded blocks with the rank offset; full N x N on every rank)
+    == the GEMM + log-sum-exp route, which the reference gloo fixture pins (test_clip_loss_gather_modes_match_reference_gloo_fixture)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_fused_dp_worker, args=(world, 29801 + 2 * int(mode[0]) + int(mode[1]), mode, ret), nprocs=world, join=True)
+    for r in range(world):
+        (lf, daf, dbf, dsf), (lu, dau, dbu, dsu) = ret[r]
+        assert abs(lf - lu) < 3e-5 * max(1.0, abs(lu))
+        np.testing.assert_allclose(daf, dau, atol=2e-3 * np.abs(dau).max())
+        np.testing.assert_allclose(dbf, dbu, atol=2e-3 * np.abs(dbu).max())
+        assert abs(dsf - dsu) < 2e-3 * abs(dsu) + 1e-7
