@@ -96,12 +96,14 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
             src[2 * NP - 1][i] = P.k_lo + (long long)(k0r + row) * D + col;
         }
     }
-    auto issue_tile = [&](int kt) {
+    auto issue_one = [&](int kt, int dnum) {                  // DMA instruction `dnum` (0 .. DPT-1) of k-tile kt
+        const int o = dnum / IPT, i = dnum % IPT;
         unsigned char* st = lds + (kt % IF_NS) * STAGE_B + wave * (TM / 4) * ROWB;
+        lds_dma16(st + o * TILE_B + RPI * i * ROWB, src[o][i] + kt * BK);
+    };
+    auto issue_tile = [&](int kt) {
 #pragma unroll
-        for (int o = 0; o < 2 * NP; ++o)
-#pragma unroll
-            for (int i = 0; i < IPT; ++i) lds_dma16(st + o * TILE_B + RPI * i * ROWB, src[o][i] + kt * BK);
+        for (int dnum = 0; dnum < DPT; ++dnum) issue_one(kt, dnum);
     };
 
     f32x16 acc[WT][WT];                                       // acc[j][i]: key tile j (MFMA rows), query tile i (MFMA columns)
@@ -112,6 +114,24 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
+    // fragment addresses (do not depend on the k-tile): byte offset of chunk 2 s + h of this lane's row in a q / k tile
+    int foq[BK / 16][WT], fok[BK / 16][WT];
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+            const int rq = wq * (TM / 2) + 32 * i + r32, rk = wk * (TM / 2) + 32 * i + r32;
+            foq[s][i] = rq * ROWB + (((2 * s + h) ^ Gm::swz(rq)) & (NCH - 1)) * 16;
+            fok[s][i] = TILE_B + rk * ROWB + (((2 * s + h) ^ Gm::swz(rk)) & (NCH - 1)) * 16;
+        }
+
+    // One k-tile = NSTEP MFMA k-steps.  With ONE wave per SIMD nothing else covers this wave's issue slots, so the order inside the tile
+    // is what overlaps the three pipes (first version: barrier -> 8 DMA issues -> 16 fragment reads -> wait -> 16 MFMAs, strictly one after
+    // the other: 0.9 us per k-tile, of which the DMA issues alone ~0.4 -- MI355X_MICROARCH.md prices an LDS-DMA issue at 60-185 cycles):
+    //   * the fragment reads of step s + 1 are issued BEFORE the MFMAs of step s (two register sets),
+    //   * the DMA instructions of tile kt + 3 are spread between the MFMAs of the whole tile (the matrix pipe works through its queue
+    //     while the wave issues them).
+    constexpr int NSTEP = BK / 16, MPS = WT * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
     const int ktiles = D / BK;
 #pragma unroll
     for (int p = 0; p < IF_NS - 1; ++p)
@@ -122,105 +142,126 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
         else if (newer == 1) wait_vmcnt<DPT>();
         else wait_vmcnt<0>();
         raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
-        if (kt + IF_NS - 1 < ktiles) issue_tile(kt + IF_NS - 1);
+        const bool refill = kt + IF_NS - 1 < ktiles;          // (workgroup-uniform)
         const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
-        bf16x8 qh[BK / 16][WT], kh[BK / 16][WT], ql[NP == 2 ? BK / 16 : 1][WT], kl[NP == 2 ? BK / 16 : 1][WT];
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s)
+        bf16x8 qh[2][WT], kh[2][WT], ql[2][WT], kl[2][WT];
+        auto read_step = [&](int s, int set) {
 #pragma unroll
             for (int i = 0; i < WT; ++i) {
-                const int rq = wq * (TM / 2) + 32 * i + r32, rk = wk * (TM / 2) + 32 * i + r32;
-                const int oq = rq * ROWB + (((2 * s + h) ^ Gm::swz(rq)) & (NCH - 1)) * 16;
-                const int ok = rk * ROWB + (((2 * s + h) ^ Gm::swz(rk)) & (NCH - 1)) * 16;
-                qh[s][i] = *reinterpret_cast<const bf16x8*>(st + oq);
-                kh[s][i] = *reinterpret_cast<const bf16x8*>(st + TILE_B + ok);
+                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
+                kh[set][i] = *reinterpret_cast<const bf16x8*>(st + fok[s][i]);
                 if (NP == 2) {
-                    ql[s][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + oq);
-                    kl[s][i] = *reinterpret_cast<const bf16x8*>(st + 3 * TILE_B + ok);
+                    ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+                    kl[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][i]);
                 }
             }
-#if !defined(EEG_EMU)
-        __builtin_amdgcn_sched_barrier(0);                    // all fragment reads of the tile ahead of its MFMAs (see logits_bf16.hip)
-#endif
+        };
+        read_step(0, 0);
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s)
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
+#endif
+            const int set = s & 1;
 #pragma unroll
             for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
+                    const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
                     if (NP == 2) {
-                        acc[j][i] = mfma_bf16_32x32x16(kl[s][j], qh[s][i], acc[j][i]);
-                        acc[j][i] = mfma_bf16_32x32x16(kh[s][j], ql[s][i], acc[j][i]);
+                        acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
+                        if (refill && ((m0_ + 1) * DPT) / TOTAL > (m0_ * DPT) / TOTAL) issue_one(kt + IF_NS - 1, (m0_ * DPT) / TOTAL);
+                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
+                        if (refill && ((m0_ + 2) * DPT) / TOTAL > ((m0_ + 1) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + 1) * DPT) / TOTAL);
                     }
-                    acc[j][i] = mfma_bf16_32x32x16(kh[s][j], qh[s][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
+                    constexpr int last = NP == 2 ? 2 : 0;
+                    acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
+                    if (refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
                 }
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
     }
 
     // ---- epilogue: lane (r32, h) owns query row q = q0 + wq TM/2 + 32 i + r32 of tile i; register e of key tile j is key
-    //      k = k0r + wk TM/2 + 32 j + (e & 3) + 8 (e >> 2) + 4 h
+    //      k = k0r + wk TM/2 + 32 j + (e & 3) + 8 (e >> 2) + 4 h.
+    // (every field of the block descriptor is read into a register HERE: `tb.p[prob]` is a dynamically indexed kernel argument, and a use
+    //  inside a conditional costs a scalar load + wait per use -- 64 of them per lane in the first version, ~5 us of a 17 us kernel)
     const float s = *scale;
+    float* const p_part = P.part;
+    float* const p_diag = P.diag;
+    const float* const p_lse = P.lse;
+    const float* const p_lse_k = P.lse_k;
+    float* const p_G = P.G;
+    const long long p_ldg = P.ldg;
+    const int p_col0 = P.col0;
+    const float p_weight = P.weight;
     if (MODE == 0) {
         const int Pn = 2 * tiles_k;                           // partial slots per row: (key tile, wk)
         const int slot = 2 * (rem % tiles_k) + wk;
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const int pos = P.col0 + q - (k0r + wk * (TM / 2));      // key index of the positive inside this wave's key range, if any
-            float mx = -3.0e38f;
+            const int pos = p_col0 + q - (k0r + wk * (TM / 2)) - 4 * h;      // key index of the positive in this lane's register numbering, if any
+            float mx = -3.0e38f, mn = 3.0e38f;
 #pragma unroll
             for (int j = 0; j < WT; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[j][i][e]);
+                for (int e = 0; e < 16; ++e) {
+                    mx = fmaxf(mx, acc[j][i][e]);
+                    mn = fminf(mn, acc[j][i][e]);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // the other half-wave holds the other 16 keys of every 32-key tile
-            // (s may be negative in principle -- it is a trained raw multiplier: take the max of s * x over both extremes)
-            float mn = 3.0e38f;
-#pragma unroll
-            for (int j = 0; j < WT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mn = fminf(mn, acc[j][i][e]);
             mn = fminf(mn, __shfl_xor(mn, 32, 64));
-            const float m = fmaxf(s * mx, s * mn);
-            float sum = 0.f;
+            const float m = fmaxf(s * mx, s * mn);            // (s is a trained raw multiplier: it may be negative in principle)
+            float sum = 0.f, dv = 0.f;
+            bool have = false;
 #pragma unroll
             for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float v = s * acc[j][i][e];
-                    sum += expf(v - m);
-                    if (32 * j + (e & 3) + 8 * (e >> 2) + 4 * h == pos) P.diag[q] = v;      // exactly one lane / register of the launch per row
+                    sum += fast_exp(v - m);
+                    const bool hit = 32 * j + (e & 3) + 8 * (e >> 2) == pos;
+                    dv = hit ? v : dv;
+                    have = have || hit;
                 }
             sum += __shfl_xor(sum, 32, 64);
+            if (have) p_diag[q] = dv;                         // exactly one lane of the launch per row
             if (h == 0) {
-                P.part[(long long)slot * n + q] = m;
-                P.part[(long long)(Pn + slot) * n + q] = sum;
+                p_part[(long long)slot * n + q] = m;
+                p_part[(long long)(Pn + slot) * n + q] = sum;
             }
         }
     } else {
-        const float two = P.lse_k ? 2.f : 1.f;
-        const float c = P.weight * inv_total;
+        const bool two_norm = p_lse_k != nullptr;
+        const float two = two_norm ? 2.f : 1.f;
+        const float c = p_weight * inv_total;
         float ds = 0.f;
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const float lq = P.lse[q];
+            const float lq = p_lse[q];
             const int kb = k0r + wk * (TM / 2);
-            const int pos = P.col0 + q - kb;
-            float* grow = P.G + (long long)q * P.ldg + kb;
+            const int pos = p_col0 + q - kb;
+            float* grow = p_G + (long long)q * p_ldg + kb;
 #pragma unroll
             for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int eq = 0; eq < 4; ++eq) {              // registers 4 eq .. 4 eq + 3 are 4 CONSECUTIVE keys: one 16-byte store
                     const int kk = 32 * j + 8 * eq + 4 * h;
                     f32x4 lk = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (P.lse_k) lk = *reinterpret_cast<const f32x4*>(P.lse_k + kb + kk);
+                    if (two_norm) lk = *reinterpret_cast<const f32x4*>(p_lse_k + kb + kk);
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float raw = acc[j][i][4 * eq + e];
                         const float v = s * raw;
-                        float g = expf(v - lq);
-                        if (P.lse_k) g += expf(v - lk[e]);
-                        if (kk + e == pos) g -= two;
+                        float g = fast_exp(v - lq);
+                        if (two_norm) g += fast_exp(v - lk[e]);
+                        g -= (kk + e == pos) ? two : 0.f;
                         g *= c;
                         ds += g * raw;
                         o[e] = g * s;
@@ -228,27 +269,48 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
                     *reinterpret_cast<f32x4*>(grow + kk) = o;
                 }
         }
+        // one atomic per WORKGROUP (same-address atomics retire at ~12 ns each: one per wave was 1024 of them = ~13 us at N = 2048);
+        // the operand stages are dead here, the partial sums go through the first bytes of the LDS
         ds = wave_sum(ds);
-        if (lane == 0) atomicAdd(dscale, ds);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);
+        if (lane == 0) red[wave] = ds;
+        __syncthreads();
+        if (t == 0) atomicAdd(dscale, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
 
-// partials -> lse; loss.  One thread per row; grid.y = problem
+// partials -> lse; loss.  32 lanes per row (lane p takes partial slots p, p + 32, ...: one round of loads, then two 5-step shuffle
+// reductions; one thread per row walked its 2 x Pn loads in sequence: 17-23 us for 2048 rows).  grid.x <= 32 workgroups stride over the rows
+// and add ONE value each to the loss (one atomic per wave was 1024 same-address atomics = ~13 us); grid.y = problem
 __global__ __launch_bounds__(256) void infonce_finalize_kernel(const if_table tb, int n, int Pn, float inv_total, float* __restrict__ loss) {
+    EEG_LDS_BASE(float, red);
     const if_problem& P = tb.p[blockIdx.y];
-    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const float* const part = P.part;
+    const float* const diag = P.diag;
+    float* const lse_out = P.lse;
+    const float w = P.weight * inv_total;
+    const int lane = threadIdx.x & 63, sub = lane & 31, wave = threadIdx.x >> 6;
     float contrib = 0.f;
-    if (q < n) {
+    for (int q = (int)(blockIdx.x * 8 + (threadIdx.x >> 5)); q < n; q += (int)gridDim.x * 8) {      // (uniform per half-wave)
         float m = -3.0e38f;
-        for (int p = 0; p < Pn; ++p) m = fmaxf(m, P.part[(long long)p * n + q]);
+        for (int p = sub; p < Pn; p += 32) m = fmaxf(m, part[(long long)p * n + q]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         float l = 0.f;
-        for (int p = 0; p < Pn; ++p) l += P.part[(long long)(Pn + p) * n + q] * expf(P.part[(long long)p * n + q] - m);
-        const float lse = m + logf(l);
-        P.lse[q] = lse;
-        contrib = (lse - P.diag[q]) * P.weight * inv_total;
+        for (int p = sub; p < Pn; p += 32) l += part[(long long)(Pn + p) * n + q] * fast_exp(part[(long long)p * n + q] - m);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o, 64);
+        if (sub == 0) {
+            const float lse = m + logf(l);
+            lse_out[q] = lse;
+            contrib += (lse - diag[q]) * w;
+        }
     }
     contrib = wave_sum(contrib);
-    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(loss, contrib);
+    if (lane == 0) red[wave] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // fp32 -> bf16 hi (+ lo = bf16(x - hi)) planes, 8 elements per thread
@@ -348,7 +410,8 @@ extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, i
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
     if (rc) return rc;
     const int Pn = 2 * (N / if_tile(n, N, planes >> 8));
-    EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nprob), dim3(256), 0, stream, tb, n, Pn, inv_total, loss);
+    const int fgrid = (n + 7) / 8 < 32 ? (n + 7) / 8 : 32;
+    EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)fgrid, (unsigned)nprob), dim3(256), 4 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
     return (int)hipGetLastError();
 }
 

@@ -265,7 +265,7 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
     sd = m.state_dict()
     for k in sd:
         if "running_var" in k:
-            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=2e-4, err_msg=k)
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=4e-4, err_msg=k)      # 6 AdamW steps at B = 16 (round-off-sized gradients flip +-lr)
         if "num_batches" in k:
             assert int(sd[k]) == 6
 
