@@ -95,6 +95,8 @@ PROTOTYPES = {
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],
     "eegclip_infonce_loss": [_P, _I, _L, _P, _P, _P, _F, _P, _P],
+    "eegclip_gemm16": [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "eegclip_sampler_step": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _I, _P],
     "eegclip_split_bf16": [_P, _P, _P, _L, _P],
     "eegclip_infonce_fused_supported": [_I, _I, _I],
     "eegclip_infonce_fused_workspace_floats": [_I, _I],

@@ -1,0 +1,287 @@
+// 16-bit Linear layers of the SDXL sampling path (call site Generation/custom_pipeline.py:365-373: the UNet's
+// attention projections to_q / to_k / to_v / to_out, to_k_ip / to_v_ip, and the stand-in UNet's stage transitions):
+//
+//     C[m, n] = sum_k A[m, k] W[n, k]  (+ bias[n])  (+ R[row(m), n])          A (M, K), W (N, K) = nn.Linear weight, C (M, N)
+//
+// fp16 or bf16 in and out, fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16}.  row(m) = m (a residual shaped like C) or m / r_div (one
+// row per sample: the time / condition embedding added to every token of a sample).
+//
+// Same structure as csrc/infonce_fused.hip, which documents it: 128 x 128 output tile per 256-thread workgroup, 2 x 2 waves x (2 x 2) MFMA
+// 32x32 tiles, BK = 64, both operands are 16-bit in HBM so the tiles go global -> LDS by LDS-DMA with no VGPR staging and no conversion,
+// 4 stages with counted vmcnt, XOR-swizzled chunks (source address and ds_read address), fragment reads one k-step ahead of the MFMAs and
+// the DMA issues spread between them.  The product is formed transposed (MFMA rows = n, columns = m): a lane owns one output row and each
+// quad of accumulator registers is 4 consecutive n -> 8-byte stores, bias / residual fetched as 8 bytes.
+// Requirements: N % 128 == 0, K % 64 == 0, leading dimensions multiples of 8, 16-byte aligned pointers; any M (rows are clamped on the
+// load side and predicated on the store side).  XCD-aware tile order (n fastest inside an XCD's run: the A panel is shared).
+#include "eeg_common.h"
+
+#include <stdlib.h>
+
+namespace eeg {
+
+constexpr int G16_T = 128, G16_K = 64, G16_NS = 4;
+constexpr int G16_ROWB = 2 * G16_K;                       // 128-byte LDS rows
+constexpr int G16_TILE_B = G16_T * G16_ROWB;              // one operand tile
+constexpr int G16_STAGE_B = 2 * G16_TILE_B;
+
+typedef _Float16 g16_f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_f16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(EEG_EMU)
+    struct AB { bf16x8 a, b; } in{a, b};
+    auto all = hipemu::wave_allgather(&in, sizeof(in));
+    const int l = hipemu::cur->lane, col = l & 31, hb = 4 * (l >> 5);
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + hb;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            AB ra, rbv;
+            memcpy(&ra, all[row + 32 * h], sizeof(AB));
+            memcpy(&rbv, all[col + 32 * h], sizeof(AB));
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                short sx = ra.a[e], sy = rbv.b[e];
+                memcpy(&x, &sx, 2);
+                memcpy(&y, &sy, 2);
+                acc += (float)x * (float)y;
+            }
+        }
+        d[r] = acc;
+    }
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(g16_f16x8, a), __builtin_bit_cast(g16_f16x8, b), c, 0, 0, 0);
+#endif
+}
+
+template <bool F16>
+__device__ __forceinline__ float g16_to_f32(unsigned short u) {
+    if (F16) {
+        _Float16 h;
+        memcpy(&h, &u, 2);
+        return (float)h;
+    }
+    return bf16_bits_to_f32(u);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned short g16_from_f32(float v) {
+    if (F16) {
+        const _Float16 h = (_Float16)v;
+        unsigned short u;
+        memcpy(&u, &h, 2);
+        return u;
+    }
+    return f32_to_bf16_bits(v);
+}
+
+struct g16_args {
+    const unsigned short* A;
+    const unsigned short* W;
+    unsigned short* C;
+    const unsigned short* bias;
+    const unsigned short* R;
+    long long lda, ldw, ldc, ldr;
+    int M, N, K, r_div;
+    int tiles_n, ntiles, chunk;
+};
+
+typedef unsigned short g16_u16x4 __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+__global__ __launch_bounds__(256) void gemm16_kernel(const g16_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    const int logical = (int)(blockIdx.x & 7) * a.chunk + (int)(blockIdx.x >> 3);
+    if (logical >= a.ntiles) return;
+    const int m0 = (logical / a.tiles_n) * G16_T, n0 = (logical % a.tiles_n) * G16_T;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    // DMA roles: wave w deposits rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per instruction
+    const int drow = lane >> 3, dpos = lane & 7;
+    const unsigned short* src[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 32 * wave + 8 * i + drow;
+        const int col = 8 * (dpos ^ swz(row));
+        const int m = m0 + row < a.M ? m0 + row : a.M - 1;          // rows beyond M: a clamped copy that nobody stores
+        src[0][i] = a.A + (long long)m * a.lda + col;
+        src[1][i] = a.W + (long long)(n0 + row) * a.ldw + col;
+    }
+    auto issue_one = [&](int kt, int dnum) {
+        const int o = dnum >> 2, i = dnum & 3;
+        unsigned char* st = lds + (kt % G16_NS) * G16_STAGE_B + 32 * wave * G16_ROWB;
+        lds_dma16(st + o * G16_TILE_B + 8 * i * G16_ROWB, src[o][i] + kt * G16_K);
+    };
+    f32x16 acc[2][2];                                         // acc[j][i]: n tile j (MFMA rows), m tile i (MFMA columns)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    int fom[4][2], fon[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rm = wm * 64 + 32 * i + r32, rn = wn * 64 + 32 * i + r32;
+            fom[s][i] = rm * G16_ROWB + (((2 * s + h) ^ swz(rm)) & 7) * 16;
+            fon[s][i] = G16_TILE_B + rn * G16_ROWB + (((2 * s + h) ^ swz(rn)) & 7) * 16;
+        }
+    const int ktiles = a.K / G16_K;
+#pragma unroll
+    for (int p = 0; p < G16_NS - 1; ++p)
+        if (p < ktiles) {
+#pragma unroll
+            for (int dnum = 0; dnum < 8; ++dnum) issue_one(p, dnum);
+        }
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int newer = ktiles - 1 - kt < G16_NS - 2 ? ktiles - 1 - kt : G16_NS - 2;
+        if (newer >= 2) wait_vmcnt<16>();
+        else if (newer == 1) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+        raw_barrier();
+        const bool refill = kt + G16_NS - 1 < ktiles;
+        const unsigned char* st = lds + (kt % G16_NS) * G16_STAGE_B;
+        bf16x8 am[2][2], wf[2][2];
+        auto read_step = [&](int s, int set) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                am[set][i] = *reinterpret_cast<const bf16x8*>(st + fom[s][i]);
+                wf[set][i] = *reinterpret_cast<const bf16x8*>(st + fon[s][i]);
+            }
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) read_step(s + 1, (s + 1) & 1);
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            const int set = s & 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[j][i] = F16 ? mfma_f16_32x32x16(wf[set][j], am[set][i], acc[j][i]) : mfma_bf16_32x32x16(wf[set][j], am[set][i], acc[j][i]);
+                    const int mi = 4 * s + 2 * j + i;          // one DMA instruction after every second MFMA
+                    if (refill && (mi & 1)) issue_one(kt + G16_NS - 1, mi >> 1);
+                }
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+    // ---- epilogue: lane (r32, h) owns row m = m0 + 64 wm + 32 i + r32; registers 4 eq .. 4 eq + 3 of n tile j are the 4 consecutive columns
+    //      n = n0 + 64 wn + 32 j + 8 eq + 4 h
+    const unsigned short* const bias = a.bias;
+    const unsigned short* const R = a.R;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + 32 * i + r32;
+        if (m >= a.M) continue;
+        unsigned short* crow = a.C + (long long)m * a.ldc;
+        const unsigned short* rrow = R ? R + (long long)(a.r_div > 0 ? m / a.r_div : m) * a.ldr : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int eq = 0; eq < 4; ++eq) {
+                const int n = n0 + wn * 64 + 32 * j + 8 * eq + 4 * h;
+                g16_u16x4 bv = g16_u16x4{0, 0, 0, 0}, rv = g16_u16x4{0, 0, 0, 0};
+                if (bias) bv = *reinterpret_cast<const g16_u16x4*>(bias + n);
+                if (rrow) rv = *reinterpret_cast<const g16_u16x4*>(rrow + n);
+                g16_u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[j][i][4 * eq + e];
+                    if (bias) v += g16_to_f32<F16>(bv[e]);
+                    if (rrow) v += g16_to_f32<F16>(rv[e]);
+                    o[e] = g16_from_f32<F16>(v);
+                }
+                *reinterpret_cast<g16_u16x4*>(crow + n) = o;
+            }
+    }
+}
+
+// ---- one step of the sampling loop over the latents (Generation/custom_pipeline.py:376-385), fused: classifier-free-guidance mix of the two
+// noise predictions, then the scheduler update x_t -> x_{t-1} in the general linear form both schedulers of this path reduce to
+//     eps = eps_u + g (eps_c - eps_u);   x' = cx * x + ce * eps + cn * noise          (16-bit in / out, fp32 arithmetic)
+// DDIM (eta = 0): cx = sqrt(ab_prev / ab_t), ce = sqrt(1 - ab_prev) - sqrt(ab_prev (1 - ab_t) / ab_t), cn = 0;
+// Euler ancestral: cx = 1, ce = sigma_down - sigma, cn = sigma_up.  `scaled` (optional) = x' * in_scale: the next step's model input
+// (Euler: 1 / sqrt(sigma_next^2 + 1), scheduler.scale_model_input) written in the same pass.
+template <bool F16>
+__global__ __launch_bounds__(256) void sampler_step_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ eps_u,
+                                                            const unsigned short* __restrict__ eps_c, const unsigned short* __restrict__ noise,
+                                                            unsigned short* __restrict__ out, unsigned short* __restrict__ scaled, float g, float cx, float ce,
+                                                            float cn, float in_scale, long long n4) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const g16_u16x4 xv = *reinterpret_cast<const g16_u16x4*>(x + 4 * q);
+        const g16_u16x4 eu = *reinterpret_cast<const g16_u16x4*>(eps_u + 4 * q);
+        g16_u16x4 ec = eu, nz = g16_u16x4{0, 0, 0, 0};
+        if (eps_c) ec = *reinterpret_cast<const g16_u16x4*>(eps_c + 4 * q);
+        if (noise) nz = *reinterpret_cast<const g16_u16x4*>(noise + 4 * q);
+        g16_u16x4 o, so;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = g16_to_f32<F16>(eu[e]);
+            float eps = u;
+            if (eps_c) eps = u + g * (g16_to_f32<F16>(ec[e]) - u);
+            float v = cx * g16_to_f32<F16>(xv[e]) + ce * eps;
+            if (noise) v += cn * g16_to_f32<F16>(nz[e]);
+            o[e] = g16_from_f32<F16>(v);
+            so[e] = g16_from_f32<F16>(g16_to_f32<F16>(o[e]) * in_scale);      // the model sees the ROUNDED latent, like the reference's 16-bit tensors
+        }
+        *reinterpret_cast<g16_u16x4*>(out + 4 * q) = o;
+        if (scaled) *reinterpret_cast<g16_u16x4*>(scaled + 4 * q) = so;
+    }
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_gemm16(const void* A, long long lda, const void* W, long long ldw, void* C, long long ldc, const void* bias, const void* R,
+                              long long ldr, int r_div, int M, int N, int K, int dtype, void* stream) {
+    if (!A || !W || !C || M < 0 || N < 1 || K < 1 || (dtype != EEGCLIP_DT_BF16 && dtype != EEGCLIP_DT_F16)) return EEGCLIP_EINVAL;
+    if (N % G16_T || K % G16_K || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K || ldc < N || r_div < 0 || (R && (ldr < N || (ldr & 3)))) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15u) return EEGCLIP_EALIGN;
+    if ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(R)) & 7u) return EEGCLIP_EALIGN;
+    if (M == 0) return 0;
+    g16_args a;
+    a.A = static_cast<const unsigned short*>(A);
+    a.W = static_cast<const unsigned short*>(W);
+    a.C = static_cast<unsigned short*>(C);
+    a.bias = static_cast<const unsigned short*>(bias);
+    a.R = static_cast<const unsigned short*>(R);
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K; a.r_div = r_div;
+    a.tiles_n = N / G16_T;
+    a.ntiles = a.tiles_n * ((M + G16_T - 1) / G16_T);
+    a.chunk = (a.ntiles + 7) / 8;
+    const size_t lds = (size_t)G16_NS * G16_STAGE_B;
+    if (dtype == EEGCLIP_DT_F16) EEG_LAUNCH((gemm16_kernel<true>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
+    else                         EEG_LAUNCH((gemm16_kernel<false>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_sampler_step(const void* x, const void* eps_u, const void* eps_c, const void* noise, void* out, void* scaled, float guidance,
+                                    float cx, float ce, float cn, float in_scale, long long n, int dtype, void* stream) {
+    if (!x || !eps_u || !out || n < 0 || (n & 3) || (dtype != EEGCLIP_DT_BF16 && dtype != EEGCLIP_DT_F16)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(eps_u) | reinterpret_cast<uintptr_t>(eps_c) | reinterpret_cast<uintptr_t>(noise) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scaled)) & 7u)
+        return EEGCLIP_EALIGN;
+    if (n == 0) return 0;
+    long long g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+#define EEG_SS_GO(F)                                                                                                                              \
+    EEG_LAUNCH((sampler_step_kernel<F>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const unsigned short*>(x),                          \
+               static_cast<const unsigned short*>(eps_u), static_cast<const unsigned short*>(eps_c), static_cast<const unsigned short*>(noise),   \
+               static_cast<unsigned short*>(out), static_cast<unsigned short*>(scaled), guidance, cx, ce, cn, in_scale, n / 4)
+    if (dtype == EEGCLIP_DT_F16) EEG_SS_GO(true);
+    else                         EEG_SS_GO(false);
+#undef EEG_SS_GO
+    return (int)hipGetLastError();
+}

@@ -256,6 +256,23 @@ int eegclip_infonce_grad(float* X, int rows, int cols, long long ld, int col0, i
 int eegclip_infonce_loss(const float* X, int n, long long ld, const float* scale, const float* lse_r, const float* lse_c, float weight,
                          float* loss, void* stream);
 
+#define EEGCLIP_DT_BF16 0
+#define EEGCLIP_DT_F16 1
+
+/* ---- 16-bit Linear layers of the SDXL sampling path (row F2: the UNet's to_q / to_k / to_v / to_out and to_k_ip / to_v_ip projections around
+ * the cross-attention of Generation/custom_pipeline.py:365-373, which diffusers runs as library GEMMs):
+ *     C[m, n] = sum_k A[m, k] W[n, k] + bias[n] + R[r_div ? m / r_div : m, n]        A (M, K), W (N, K) = nn.Linear weight layout, C (M, N)
+ * fp16 / bf16 (dtype = EEGCLIP_DT_*) in and out, fp32 accumulate on the 16-bit matrix cores; bias, R optional (NULL).  r_div > 0: R has one row per
+ * block of r_div consecutive rows (a per-sample embedding added to every token).  N % 128 == 0, K % 64 == 0, lda / ldw multiples of 8, ldc / ldr
+ * multiples of 4, A / W 16-byte and C / bias / R 8-byte aligned; any M.
+ * sampler_step: one step of the denoising loop over the latents (custom_pipeline.py:376-385), fused: eps = eps_u + guidance * (eps_c - eps_u)
+ * (eps_c NULL: eps = eps_u), x' = cx * x + ce * eps + cn * noise (noise NULL: no noise term), out = x' and optionally scaled = x' * in_scale (the
+ * next model input: scheduler.scale_model_input).  cx / ce / cn come from the scheduler (DDIM eta = 0, Euler ancestral).  n % 4 == 0. */
+int eegclip_gemm16(const void* A, long long lda, const void* W, long long ldw, void* C, long long ldc, const void* bias, const void* R, long long ldr,
+                   int r_div, int M, int N, int K, int dtype, void* stream);
+int eegclip_sampler_step(const void* x, const void* eps_u, const void* eps_c, const void* noise, void* out, void* scaled, float guidance, float cx,
+                         float ce, float cn, float in_scale, long long n, int dtype, void* stream);
+
 /* ---- fused InfoNCE (models/loss.py:100-141) on the bf16 matrix cores: the N x N logits are never written on the forward.
  * A "block" is S = s * Q K^T (Q: the n rows that are scored, K: the N rows they are scored against, both (., D) row-major) with the positive of
  * row i at column col0 + i (loss.py:129-130).  The symmetric loss of the reference is two blocks, (A, B) and (B, A) -- it computes both logit
@@ -313,8 +330,6 @@ int eegclip_logits_bf16(const void* a_bf16, const void* b_bf16, float* c, int M,
  *   out = softmax(q k^T / sqrt(64)) v + ip_scale * softmax(q k_ip^T / 8) v_ip
  * q/out (B, HW, heads*64); k/v (B, S, heads*64); k_ip/v_ip (B, S_ip, heads*64) or NULL with S_ip = 0.  16-bit I/O (dtype), fp32 accumulate.
  * head_dim must be 64, S and S_ip <= 128, pointers 16-byte aligned. */
-#define EEGCLIP_DT_BF16 0
-#define EEGCLIP_DT_F16 1
 int eegclip_cross_attn_fwd(const void* q, const void* k, const void* v, const void* k_ip, const void* v_ip, void* out, int B, int HW, int heads,
                            int head_dim, int S, int S_ip, float ip_scale, int dtype, void* stream);
 
