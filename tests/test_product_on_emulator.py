@@ -536,3 +536,49 @@ def test_fused_clip_loss_gather_modes_equal_the_unfused_route_on_two_ranks(mode)
         np.testing.assert_allclose(daf, dau, atol=2e-3 * np.abs(dau).max())
         np.testing.assert_allclose(dbf, dbu, atol=2e-3 * np.abs(dbu).max())
         assert abs(dsf - dsu) < 2e-3 * abs(dsu) + 1e-7
+
+
+def test_sdxl_sampling_loop_under_emulator_matches_the_oracle():
+    """F1 without a GPU: generate_ip_adapter_embeds on the smallest SDXL-shaped stand-in (8 x 8 latents, one layer per stage), 2 DDIM steps with
+    classifier-free guidance -- gemm16, cross-attention, image projection, sampler step and the host loop together against oracle/sdxl_pipeline.py"""
+    from sdxl_common import oracle_loop, small_pipe
+    with product_on_emulator():
+        pipe, W, cfg = small_pipe("ddim", "cpu", latent=8)
+        emb = torch.randn(1, 1024, generator=torch.Generator().manual_seed(3)).half()
+        out = pipe.generate_ip_adapter_embeds(prompt="", ip_adapter_embeds=emb, num_inference_steps=2, guidance_scale=5.0,
+                                              generator=torch.Generator().manual_seed(11)).images
+    ref = oracle_loop(pipe, W, cfg, "ddim", 2, 5.0, emb.float().numpy().astype(np.float64), seed=11)
+    assert out.shape == (1, 4, 8, 8)
+    d = np.abs(out.float().numpy() - ref)
+    assert d.max() < 1e-2 * max(1.0, np.abs(ref).max()), (d.max(), np.abs(ref).max())
+
+
+def test_sdxl_schedulers_reproduce_their_defining_identities():
+    """host-side coefficients of the two schedulers (product) against the oracle's step on random data, plus the DDIM identity: a latent built from
+    (x0, eps) at timestep t steps to the same (x0, eps) mixture at the previous timestep"""
+    from eeg_image_decode_amd.sdxl import DDIMScheduler, EulerAncestralDiscreteScheduler
+    from oracle import sdxl_pipeline as osp
+    rng = np.random.default_rng(0)
+    x, eps, nz = rng.standard_normal(64), rng.standard_normal(64), rng.standard_normal(64)
+    d, od = DDIMScheduler(), osp.DDIM(50)
+    d.set_timesteps(50)
+    assert d.timesteps.tolist() == od.timesteps.tolist() == list(range(981, 0, -20))
+    for i, t in enumerate(d.timesteps.tolist()):
+        cx, ce, cn = d.coefficients(t)
+        od.i = i
+        np.testing.assert_allclose(cx * x + ce * eps, od.step(eps, x), rtol=1e-12, atol=1e-12)
+        a_t = od.acp[t]
+        a_p = od.acp[t - 20] if t - 20 >= 0 else od.acp[0]
+        x0 = rng.standard_normal(64)
+        xt = np.sqrt(a_t) * x0 + np.sqrt(1 - a_t) * eps
+        np.testing.assert_allclose(cx * xt + ce * eps, np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * eps, atol=1e-12)
+    for n in (1, 4):
+        e, oe = EulerAncestralDiscreteScheduler(), osp.EulerAncestral(n)
+        e.set_timesteps(n)
+        assert e.timesteps.tolist() == oe.timesteps.tolist() and e.timesteps[0] == 999
+        assert abs(e.init_noise_sigma - oe.init_noise_sigma) < 1e-12
+        for i in range(n):
+            cx, ce, cn = e.coefficients(i)
+            oe.i = i
+            np.testing.assert_allclose(cx * x + ce * eps + cn * nz, oe.step(eps, x, nz), rtol=1e-10, atol=1e-10)
+        assert e.coefficients(n - 1)[2] == 0.0                    # the last step lands on sigma = 0: no noise is added
