@@ -647,6 +647,8 @@ class Generator4Embeds:
 
     def generate(self, image_embeds, text_prompt='', generator=None):
         image_embeds = image_embeds.to(device=self.device, dtype=self.dtype)
+        if image_embeds.dim() == 1:
+            image_embeds = image_embeds[None]
         if not self._stand_in:
             return self.pipe(prompt=text_prompt, ip_adapter_image_embeds=[image_embeds.unsqueeze(1)], num_inference_steps=self.num_inference_steps,
                              guidance_scale=0.0, generator=generator).images[0]
