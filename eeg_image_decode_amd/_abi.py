@@ -35,6 +35,18 @@ class InfonceProblem(C.Structure):
                 ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong)]
 
 
+PLAN_MAX_ARGS = 24
+PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP = -2, -3, 1, 2
+
+
+class PlanArg(C.Union):
+    _fields_ = [("p", C.c_void_p), ("i", C.c_longlong), ("u", C.c_ulonglong), ("d", C.c_double), ("f", C.c_float), ("i32", C.c_int), ("u32", C.c_uint)]
+
+
+class PlanOp(C.Structure):
+    _fields_ = [("fn", C.c_int), ("flags", C.c_int), ("a", PlanArg * PLAN_MAX_ARGS)]
+
+
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
 ABI_VERSION = 2
@@ -102,9 +114,23 @@ PROTOTYPES = {
     "eegclip_infonce_fused_workspace_floats": [_I, _I],
     "eegclip_infonce_fused_fwd": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "eegclip_plan_fn_id": [C.c_char_p],
+    "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
+    "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
 }
+
+
+def plan_functions():
+    """entry points the plan executor can dispatch: int f(..., void* stream) -- name -> argument ctypes WITHOUT the trailing stream"""
+    skip = {"eegclip_plan_run"}
+    return {n: a[:-1] for n, a in PROTOTYPES.items() if a and a[-1] is _P and not n.endswith("_floats") and n not in skip}
+
+
+def plan_slot(t):
+    """PlanArg field for a ctypes parameter type"""
+    return {C.c_int: "i32", C.c_uint: "u32", C.c_longlong: "i", C.c_ulonglong: "u", C.c_float: "f", C.c_double: "d"}.get(t, "p")
 
 
 def declare(lib):

@@ -744,7 +744,7 @@ class _Engine:
             if not backward or has_dx:
                 skip.add(pl.j_scatter)
         if not backward:
-            pl.ops[pl.j_gather][1][2] = x_ptr
+            pl.set_arg(pl.j_gather, 2, x_ptr)
             xb, hb = (x_ptr, _p(b["h"])) if in_order else (_p(b["xs"]), _p(b["hs"]))
             for s, st, n in segs:
                 d = pl.j_gemm[s]
@@ -760,11 +760,11 @@ class _Engine:
                     d.M, d.A, d.C = n * N_CH, gb + st * HR + 4 * D_MODEL, (_p(b["dx"]) if in_order else _p(b["dxs"])) + st * XR
         for i, (s, _, _) in enumerate(segs):
             pl.j_arr[i] = pl.j_gemm[s]                   # struct copy: the members of this batch, in subject order
-        pl.ops[pl.j_group][1][1] = len(segs)
+        pl.set_arg(pl.j_group, 1, len(segs))
         if has_dx:
             for i, (s, _, _) in enumerate(segs):
                 pl.j_dx_arr[i] = pl.j_dx[s]
-            pl.ops[pl.j_dx_group][1][1] = len(segs)
+            pl.set_arg(pl.j_dx_group, 1, len(segs))
         pl.skip = frozenset(skip)
 
     def forward(self, x, ids, shared, train, host_ids=None):
@@ -790,7 +790,7 @@ class _Engine:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and max(probs) > 0 else 0
         b["seed"] = seed
         out = torch.empty(B, P_DIM, dtype=torch.float32, device=self.device)
-        pl.ops[pl.out_op][1][8] = out.data_ptr()
+        pl.set_arg(pl.out_op, 8, out.data_ptr())
         pl.run(torch.cuda.current_stream().cuda_stream, seed)
         self.last_key = key
         self.version[B] = self.version.get(B, 0) + 1
@@ -830,7 +830,8 @@ class _Engine:
             self.plans[pk] = self._build_bwd(B, shared, probs, want_dx, early, train)
         pl = self.plans[pk]
         self.attach_grads(shared, {s for s, _, _ in b["segs"]} if self.joint else ())
-        pl.ops[pl.dout_op][1][0] = pl.ops[pl.dout_par_op][1][0] = dout.data_ptr()
+        pl.set_arg(pl.dout_op, 0, dout.data_ptr())
+        pl.set_arg(pl.dout_par_op, 0, dout.data_ptr())
         pl._keep_x = (x, dout)
         if self.joint:
             self._joint_layout(pl, b, B, None, x.data_ptr(), True)

@@ -43,6 +43,9 @@ class Plan:
         self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
         self.use_side_stream = True
         self.skip = ()         # op indices left out of the next run()s (e.g. the value-embedding GEMMs of subjects absent from the batch)
+        self._c = None         # compiled form for the C executor (eegclip_plan_run): built on the first untimed run
+        self._c_skip = ()
+        self.use_c_executor = os.environ.get("EEGCLIP_PLAN_EXEC", "c") != "python"
 
     # -- generic positional op; `seed_at` = index of the seed argument (patched at run time)
     def call(self, fname, *args, seed_at=None, side=False):
@@ -93,6 +96,121 @@ class Plan:
     def op_names(self):
         return [op[2] for op in self.ops]
 
+    def set_arg(self, idx, j, value):
+        """patch argument j of op idx for the following runs (the per-call pointers: input batch, output tensor, upstream gradient)"""
+        self.ops[idx][1][j] = value
+        if self._c is not None:
+            self._c_write(idx, j, value)
+
+    # ---- C executor -----------------------------------------------------------------------------------------------------------------
+    def _c_write(self, idx, j, value):
+        arr, slots = self._c["arr"], self._c["slots"]
+        if slots[idx] is None or j >= len(slots[idx]):
+            return
+        setattr(arr[idx].a[j], slots[idx][j], 0 if value is None else value)
+
+    def _compile(self):
+        """the op list as an eegclip_plan_op array: replayed by ONE foreign call (eegclip_plan_run) instead of one ctypes call per launch --
+        the Python loop costs ~5 us per op, more than most of these kernels run for.  Host callbacks (collectives under data parallelism) cut the
+        array into segments that are run one call each."""
+        L = self.L
+        fns = _abi.plan_functions()
+        n = len(self.ops)
+        arr = (_abi.PlanOp * n)()
+        slots, segments, start = [], [], 0
+        for i, (fn, args, name, on_side) in enumerate(self.ops):
+            if fn is None and name == "memset":
+                t = args[0]
+                arr[i].fn = _abi.PLAN_MEMSET
+                arr[i].a[0].p, arr[i].a[1].i = t.data_ptr(), t.numel() * t.element_size()
+                slots.append(None)
+            elif fn is None and name == "join":
+                arr[i].fn = _abi.PLAN_JOIN
+                slots.append(None)
+            elif fn is None:                                      # host callback: a segment boundary
+                arr[i].fn = -1
+                slots.append(None)
+                if i > start:
+                    segments.append(("c", start, i))
+                segments.append(("py", i, on_side))
+                start = i + 1
+            else:
+                fid = L.eegclip_plan_fn_id(name.encode())
+                if fid < 0:
+                    raise RuntimeError(f"{name} is not dispatchable by the plan executor")
+                arr[i].fn = fid
+                arr[i].flags = _abi.PLAN_SIDE if on_side else 0
+                sl = [_abi.plan_slot(t) for t in fns[name]]
+                slots.append(sl)
+                for j, s_ in enumerate(sl):
+                    v = args[j]
+                    if hasattr(v, "_obj"):                        # ctypes.byref(struct): the struct is owned by the plan (self._keep)
+                        v = ctypes.addressof(v._obj)
+                    elif isinstance(v, ctypes.Array):
+                        v = ctypes.addressof(v)
+                    setattr(arr[i].a[j], s_, 0 if v is None else v)
+        if start < n:
+            segments.append(("c", start, n))
+        n_side = sum(1 for op in self.ops if op[3])
+        ev = (ctypes.c_void_p * n)()
+        join = ctypes.c_void_p()
+        if n_side:
+            tmp = (ctypes.c_void_p * (n_side + 1))()
+            check(L.eegclip_plan_events(n_side + 1, tmp), f"{self.name}:plan_events")
+            k = 0
+            for i, op in enumerate(self.ops):
+                if op[3]:
+                    ev[i] = tmp[k]
+                    k += 1
+            join = ctypes.c_void_p(tmp[n_side])
+        self._c = dict(arr=arr, slots=slots, segments=segments, events=ev, join=join, n=n, dirty=ctypes.c_int(0), failed=ctypes.c_int(-1))
+        self._c_skip = ()
+
+    def _run_c(self, stream, seed):
+        import torch
+        c = self._c
+        arr = c["arr"]
+        for i, j in self._seed_slots:
+            arr[i].a[j].u = seed
+        if self.skip != self._c_skip:
+            for i in self._c_skip:
+                arr[i].flags &= ~_abi.PLAN_SKIP
+            for i in self.skip:
+                arr[i].flags |= _abi.PLAN_SKIP
+            self._c_skip = self.skip
+        side = None
+        if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
+            if self._side is None:
+                self._side = (torch.cuda.Stream(), None, None)
+            side = self._side[0]
+        c["dirty"].value = 0
+        for seg in c["segments"]:
+            if seg[0] == "c":
+                rc = self.L.eegclip_plan_run(arr, seg[1], seg[2], c["n"], stream, side.cuda_stream if side is not None else None, c["events"], c["join"],
+                                             ctypes.byref(c["dirty"]), ctypes.byref(c["failed"]))
+                if rc:
+                    check(rc, f"{self.name}:{self.ops[c['failed'].value][2]}")
+            else:
+                idx, on_side = seg[1], seg[2]
+                if idx in self.skip:
+                    continue
+                fn = self.ops[idx][1][0]
+                if on_side and side is not None:                  # behind everything enqueued on BOTH streams so far
+                    ts = torch.cuda.current_stream()
+                    e = torch.cuda.Event()
+                    e.record(ts)
+                    side.wait_event(e)
+                    with torch.cuda.stream(side):
+                        fn()
+                    c["dirty"].value = 1
+                else:
+                    fn()
+        if c["dirty"].value and side is not None:                 # (a trailing side-stream callback: join here)
+            e = torch.cuda.Event()
+            e.record(side)
+            torch.cuda.current_stream().wait_event(e)
+            c["dirty"].value = 0
+
     def time_ops(self, indices):
         """record a HIP event pair around the given ops on every run (bench.py roofline / per-kernel breakdown)"""
         self.timed = {i: [] for i in indices}
@@ -105,14 +223,19 @@ class Plan:
     def run(self, stream, seed=0):
         for d in self._seed_descs:
             d.seed = seed
+        if self.use_c_executor and not self.timed:
+            if self._c is None:
+                self._compile()
+            return self._run_c(stream, seed)
         for i, j in self._seed_slots:
             self.ops[i][1][j] = seed
         timed = self.timed
         import torch
         side = None
         if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
-            if self._side is None:
-                self._side = (torch.cuda.Stream(), {i: torch.cuda.Event() for i, op in enumerate(self.ops) if op[3]}, torch.cuda.Event())
+            if self._side is None or self._side[1] is None:        # (the C executor keeps only the stream: it owns its own events)
+                st_side = self._side[0] if self._side is not None else torch.cuda.Stream()
+                self._side = (st_side, {i: torch.cuda.Event() for i, op in enumerate(self.ops) if op[3]}, torch.cuda.Event())
             side = self._side
         ts = torch.cuda.current_stream() if (timed or side) else None
         dirty = False                                    # side stream has work the main stream has not waited for

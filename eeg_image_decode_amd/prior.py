@@ -638,7 +638,7 @@ class Pipe:
         j = 0
         for i, t in enumerate(steps):
             for idx, st, width in step.te_slots:
-                step.ops[idx][1][5] = b[f"te{st}"].data_ptr() + 4 * width * i
+                step.set_arg(idx, 5, b[f"te{st}"].data_ptr() + 4 * width * i)
             step.run(stream)
             nz = None
             if t > 0:

@@ -338,6 +338,43 @@ int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, c
                       long long* out_idx, void* stream);
 int eegclip_count_equal(const long long* pred, int stride, const long long* labels, int n, int* count, void* stream);
 
+/* ---- launch-plan executor: the forward / backward of the encoder are fixed sequences of the entry points above (~50 per direction).  Issuing
+ * them one foreign call at a time from Python costs ~5 us each -- more than the GPU needs for most of them -- so a sequence is described ONCE as an
+ * array of (function id, argument slots) and replayed by one call that loops in C.  (The reference's step is paced by the Python interpreter in the
+ * same way: Retrieval/ATMS_retrieval.py:209-250 issues every torch op of the step from its batch loop.)
+ *   fn      id from eegclip_plan_fn_id("eegclip_...") (every entry point whose last parameter is the stream), or a pseudo op:
+ *           EEGCLIP_PLAN_MEMSET (a[0].p = device pointer, a[1].i = bytes: hipMemsetAsync to 0), EEGCLIP_PLAN_JOIN (main stream waits for the side stream)
+ *   flags   EEGCLIP_PLAN_SIDE: launch on `side_stream`, ordered behind everything enqueued on the main stream so far (fork event `events[index]`);
+ *           EEGCLIP_PLAN_SKIP: leave the op out of this run
+ *   a[k]    the k-th argument in its natural C type (pointers .p, int .i32, unsigned .u32, long long .i, unsigned long long .u, float .f, double .d);
+ *           the trailing stream argument is supplied by the executor.
+ * plan_run executes ops [begin, end); *dirty carries "the side stream holds work the main stream has not waited for" between calls (a plan with
+ * host callbacks is run in segments); a trailing join is issued when end == n_total.  Returns 0 or the first failing op's code (*failed = its index).
+ * plan_events fills `out[n]` with hipEvent_t handles (timing disabled) for the fork / join events of one plan. */
+typedef union {
+    void* p;
+    long long i;
+    unsigned long long u;
+    double d;
+    float f;
+    int i32;
+    unsigned int u32;
+} eegclip_plan_arg;
+#define EEGCLIP_PLAN_MAX_ARGS 24
+typedef struct {
+    int fn;
+    int flags;
+    eegclip_plan_arg a[EEGCLIP_PLAN_MAX_ARGS];
+} eegclip_plan_op;
+#define EEGCLIP_PLAN_MEMSET (-2)
+#define EEGCLIP_PLAN_JOIN (-3)
+#define EEGCLIP_PLAN_SIDE 1
+#define EEGCLIP_PLAN_SKIP 2
+int eegclip_plan_fn_id(const char* name);
+int eegclip_plan_events(int n, void** out);
+int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* const* events,
+                     void* join_event, int* dirty, int* failed);
+
 #ifdef __cplusplus
 }
 #endif

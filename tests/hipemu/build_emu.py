@@ -16,8 +16,11 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DEEG_EMU", "-I", HERE, "-f
 
 def build(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    from eeg_image_decode_amd import build as product_build
+    product_build.generate_plan_dispatch()                       # csrc/plan_exec_gen.inc (generated from the ctypes prototypes)
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")) + [os.path.join(HERE, "hipemu.cpp")]
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "hipemu.h"), os.path.join(ROOT, "include", "eegclip.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(HERE, "hipemu.h"), os.path.join(ROOT, "include", "eegclip.h")]
     hm = max(os.path.getmtime(h) for h in hdrs)
     objs, jobs = [], []
     for s in srcs:
