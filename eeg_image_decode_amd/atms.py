@@ -395,10 +395,38 @@ class _Engine:
         self.early_work = None
         self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])
         self.buffers = dict(model.named_buffers())
+        self._init_weight_planes()
         self.bufs, self.plans, self.version = {}, {}, {}
         self.last_key = None
         self.grad_fresh = True               # gflat holds zeros / stale values that must be cleared before accumulation
         lib()
+
+    def _init_weight_planes(self):
+        """bf16 hi / lo planes of every Linear weight, in both orientations (W for Y = X W^T, W^T for dX = dY W), refreshed by ONE
+        eegclip_split_rows launch at the head of every forward plan: the split of a weight element is then done once per step instead of once
+        per workgroup tile that stages it (csrc/gemm_x3.hip, planes variant)."""
+        if self.joint:
+            base = []                                                # (the per-subject value embeddings run as a grouped fp32 launch)
+        else:
+            base = [("embed", _E + "value_embedding.weight", D_MODEL, T_LEN)]
+        base += [("qkv", _LY + "attention.query_projection.weight", 3 * HE, D_MODEL), ("out", _LY + "attention.out_projection.weight", D_MODEL, HE),
+                 ("ffn1", _LY + "conv1.weight", D_FF, D_MODEL), ("ffn2", _LY + "conv2.weight", D_MODEL, D_FF),
+                 ("head0", "proj_eeg.0.weight", P_DIM, F_TS), ("head1", "proj_eeg.1.fn.1.weight", P_DIM, P_DIM)]
+        pad = lambda n: (n + 63) // 64 * 64
+        total = sum(r * pad(c) + c * pad(r) for _, _, r, c in base)
+        self.plane_buf = torch.zeros(2 * total, dtype=torch.bfloat16, device=self.device)
+        items = (_abi.SplitItem * (2 * len(base)))()
+        self.planes, self.planesT = {}, {}
+        off, ptr = 0, self.plane_buf.data_ptr()
+        for i, (name, key, rows, cols) in enumerate(base):
+            src = self.P[key].data_ptr()                             # (rows, cols) row-major view of the flat buffer (q|k|v: three adjacent weights)
+            for tr in (0, 1):
+                orow, ld = (cols, pad(rows)) if tr else (rows, pad(cols))
+                hi, lo = ptr + 2 * off, ptr + 2 * (off + orow * ld)
+                items[2 * i + tr] = _abi.SplitItem(src=src, hi=hi, lo=lo, rows=rows, cols=cols, ld_src=cols, ld_out=ld, transpose=tr)
+                (self.planesT if tr else self.planes)[name] = (hi, lo, ld)
+                off += 2 * orow * ld
+        self.plane_items, self.n_plane_items = items, 2 * len(base)
 
     def stale(self, model):
         a, b = self._check
@@ -456,12 +484,14 @@ class _Engine:
         pl = Plan(f"atms_fwd[B={B}]")
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
+        PL, PLT = self.planes, self.planesT
+        pl.call("eegclip_split_rows", self.plane_items, self.n_plane_items)          # weight planes of this step (both orientations)
         # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
         if not self.joint:
             pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
                     _p(b["h"]) + 4 * D_MODEL, hmap, D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
-                    R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1))
+                    R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1), planes=PL["embed"])
         else:
             # joint-subject model (Embed.py:142-144): one GEMM per subject over that subject's block of the subject-ordered batch.  A batch
             # that is not already in subject order is gathered into xs first and the token rows are scattered back to batch order after
@@ -479,20 +509,20 @@ class _Engine:
         pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
         # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
         pl.gemm(R, 3 * HE, D_MODEL, _p(b["h"]), D(D_MODEL), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(1), D(D_MODEL),
-                _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]))
+                _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]), planes=PL["qkv"])
         pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
                 SITE_ATTN, seed_at=9)
         # (dropout + residual of both sublayers live in the LayerNorm kernel that follows, not in the GEMM epilogue: one Philox block per 4
         #  consecutive columns there, one per ELEMENT in an MFMA accumulator layout -- 12 us per GEMM)
         pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
-                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]))
+                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), planes=PL["out"])
         # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
         pl.call("eegclip_residual_layernorm_fwd", _p(b["r1"]), _p(b["h"]), _p(b["r1"]), pe_, 0, SITE_ATTN_OUT, _p(P[_LY + "norm1.weight"]),
                 _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]), _p(b["rs1"]), None, None, None, None, None, R, D_MODEL, EPS, seed_at=4)
         pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
-                Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT)
+                Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PL["ffn1"])
         pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
-                bias_n=_p(P[_LY + "conv2.bias"]))
+                bias_n=_p(P[_LY + "conv2.bias"]), planes=PL["ffn2"])
         # norm2 and the encoder's final norm back to back in one launch
         pl.call("eegclip_residual_layernorm_fwd", _p(b["r2"]), _p(b["n1"]), _p(b["r2"]), pe_, 0, SITE_FFN_OUT, _p(P[_LY + "norm2.weight"]),
                 _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]), _p(b["rs2"]), _p(P["encoder.encoder.norm.weight"]),
@@ -526,16 +556,16 @@ class _Engine:
         skh = _head_split(B)
         if skh > 1:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
-                    accumulate=1, split_k=skh)
+                    accumulate=1, split_k=skh, planes=PL["head0"])
             pl.call("eegclip_bias_act", _p(b["hacc"][0]), _p(P["proj_eeg.0.bias"]), _p(b["u"]), None, _p(b["gu"]), B, P_DIM, ACT_GELU, 0.0, 0, 0)
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["hacc"][1]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh)             # (slice 0 adds the bias)
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh, planes=PL["head1"])             # (slice 0 adds the bias)
             w_lin = b["hacc"][1]
         else:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
-                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU)
+                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU, planes=PL["head0"])
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]))
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), planes=PL["head1"])
             w_lin = b["s"]
         # s = u + dropout(W gelu(u) + b), out = LayerNorm(s): ResidualAdd + LayerNorm of Proj_eeg in one launch; `out` is a fresh tensor per
         # call (argument 8 is patched by forward()), so callers keep what they are handed and no copy is made
@@ -552,6 +582,7 @@ class _Engine:
         P, G, b = self.P, self.G, self.bufs[B]
         pe_, pc_, pp_ = probs
         pl = Plan(f"atms_bwd[B={B}]")
+        PLT = self.planesT                        # W^T planes of this step's weights (refreshed by the forward plan)
         R = B * L_TOK
         sums, bn = b["sums"], b["bn"]
         sk = lambda k: max(1, min(64, k // 512))      # split-K for the reduce-over-batch weight-gradient GEMMs
@@ -577,11 +608,11 @@ class _Engine:
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
         skh = _head_split(B)
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
-                accumulate=int(skh > 1), split_k=skh)
+                accumulate=int(skh > 1), split_k=skh, planes=PLT["head1"])
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
         wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
         pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
-                accumulate=int(skh > 1), split_k=skh)
+                accumulate=int(skh > 1), split_k=skh, planes=PLT["head0"])
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
         # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.
@@ -657,10 +688,10 @@ class _Engine:
                 _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, side=ln_side)
         wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
         pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
-                act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT)                  # dg1 := df1
+                act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PLT["ffn2"])                  # dg1 := df1
         wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
         pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
-                accumulate=1)                                                                  # dr2 := dn1
+                accumulate=1, planes=PLT["ffn1"])                                              # dr2 := dn1
         # attention block: r1 = h + dropout(Wo ctx + bo)
         pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
                 None, None, R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, seed_at=13)
@@ -668,13 +699,14 @@ class _Engine:
                 _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, side=ln_side)
         wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
               bias=_LY + "attention.out_projection.bias")
-        pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1))
+        pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
+                planes=PLT["out"])
         pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                 pe_, 0, SITE_ATTN, seed_at=10)
         wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
               bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
         pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
-                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=1)                                   # dr1 := dh
+                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=1, planes=PLT["qkv"])                # dr1 := dh
         # embedding: dropout + token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
         pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
@@ -687,7 +719,7 @@ class _Engine:
                     rowsum_a=_p(G[_E + "value_embedding.bias"]))      # bias gradient = sum of the 63 channel rows of every sample
             if want_dx:
                 pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, hmap, D(1),
-                        _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
+                        _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1), planes=PLT["embed"])
         else:
             # per-subject weight gradients over the subject-ordered batch (mirror of the forward: gather the token-row gradients into
             # subject order first when the batch is not; xs still holds the gathered EEG)

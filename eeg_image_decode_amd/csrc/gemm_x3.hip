@@ -314,6 +314,193 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
 #undef EEG_X3_EPI
 }
 
+// =================================================================================================================================
+// Pre-split B ("planes") variant.  PMC on the kernel above at the step's shapes (profiles/r2_pmc_gemm_x3.json): ~1000 VALU instructions
+// per wave, half of them the hi/lo split, VALU issue = 46 % of the kernel's SIMD time, MFMA pipe 17 % -- and the split of one operand
+// element is repeated by every tile that stages it: a weight element by all 256 row tiles, an activation element by every column tile.
+// Weights change once per optimizer step, so their split is hoisted out of the GEMMs altogether (eegclip_split_rows: bf16 planes
+// hi / lo, [N][Kpad] with zero padding, plus the transposed planes for the dX = dY W form), and the output tile becomes 64 x 256 -- every
+// Linear of the encoder has N <= 256 except the fused QKV projection (3 tiles) -- so an activation element is split by ONE workgroup
+// (N <= 256) instead of four.  Per k-tile a workgroup then converts 64 x BK activations, copies 256 x BK x 2 plane bytes with 16-byte
+// loads / ds_write_b128 and issues 4 x 48 MFMAs: the matrix pipe is the long pole again.
+//   A: k-contiguous fp32 rows (the layer input, or dY), converted while staged, as above.   B: planes, rows = output columns n.
+//   4 waves side by side, each 64 rows x 64 columns (4 x 4 MFMA tiles); same LDS geometry, same epilogue, same split-K scheme.
+constexpr int XP_BM = 64, XP_BN = 256;
+typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BK, bool C_PLAIN>
+__global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+    using G = x3_geom<BK>;
+    constexpr int IMG_A = XP_BM * G::RS, NQ = BK / 4, RPP = X3_THREADS / NQ, KC_PASS = XP_BM / RPP;
+    constexpr int NCH = BK / 8, BRP = X3_THREADS / NCH, B_PASS = XP_BN / BRP;        // B: thread -> (chunk t % NCH, row t / NCH + BRP i)
+    EEG_LDS_BASE(unsigned char, lds);
+    const int bid = (int)blockIdx.x;
+    int logical, slice = 0;
+    if (d.split_k == 1) {
+        logical = (bid & 7) * chunk + (bid >> 3);
+        if (logical >= ntiles) return;
+    } else {
+        const int slot = bid >> 3;
+        slice = (bid & 7) + 8 * (slot / ntiles);
+        logical = slot % ntiles;
+        if (slice >= d.split_k) return;
+    }
+    const int m0 = (logical / gx) * XP_BM, n0 = (logical % gx) * XP_BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    int kt_begin, kt_end;
+    gemm_k_slice<BK>(d, slice, kt_begin, kt_end);
+    const int a_ld = (int)d.Am.si;
+    const int kc_kq = t % NQ, kc_r0 = t / NQ;
+    int a_fix[KC_PASS];
+#pragma unroll
+    for (int i = 0; i < KC_PASS; ++i) { const int m = m0 + kc_r0 + RPP * i; a_fix[i] = (m < d.M ? m : d.M - 1) * a_ld; }
+    const int b_c = t % NCH, b_r0 = t / NCH;
+    const unsigned short* const Bh = static_cast<const unsigned short*>(d.B_hi);
+    const unsigned short* const Bl = static_cast<const unsigned short*>(d.B_lo);
+    long long b_fix[B_PASS];
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) { const int n = n0 + b_r0 + BRP * i; b_fix[i] = (long long)(n < d.N ? n : d.N - 1) * d.ldb_planes + 8 * b_c; }
+
+    f32x2_t ra[KC_PASS * 2];
+    xp_u32x4 rbh[B_PASS], rbl[B_PASS];
+    unsigned a_ok = 0;
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK, ka = k0 + 4 * kc_kq;
+        if (k0 + BK <= d.K) {
+            a_ok = 3u;
+#pragma unroll
+            for (int i = 0; i < KC_PASS; ++i) {
+                const f32x4u_t v = *reinterpret_cast<const f32x4u_t*>(d.A + a_fix[i] + ka);
+                ra[2 * i] = f32x2_t{v[0], v[1]};
+                ra[2 * i + 1] = f32x2_t{v[2], v[3]};
+            }
+        } else {
+            const bool ok0 = ka < d.K, ok1 = ka + 2 < d.K;
+            const int k_0 = ok0 ? ka : 0, k_1 = ok1 ? ka + 2 : 0;
+            a_ok = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
+#pragma unroll
+            for (int i = 0; i < KC_PASS; ++i) {
+                ra[2 * i] = *reinterpret_cast<const f32x2_t*>(d.A + a_fix[i] + k_0);
+                ra[2 * i + 1] = *reinterpret_cast<const f32x2_t*>(d.A + a_fix[i] + k_1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {                          // the planes are zero padded to a multiple of 64 in k: no tail handling
+            rbh[i] = *reinterpret_cast<const xp_u32x4*>(Bh + b_fix[i] + k0);
+            rbl[i] = *reinterpret_cast<const xp_u32x4*>(Bl + b_fix[i] + k0);
+        }
+    };
+    auto store_tile = [&]() {
+        const f32x2_t zero{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KC_PASS; ++i) {
+            const f32x2_t p0 = a_ok & 1u ? ra[2 * i] : zero, p1 = a_ok & 2u ? ra[2 * i + 1] : zero;
+            u32x2_t hi, lo;
+            x3_split4(p0[0], p0[1], p1[0], p1[1], hi, lo);
+            const int row = kc_r0 + RPP * i;
+            *reinterpret_cast<u32x2_t*>(lds + G::quad(row, 0, kc_kq)) = hi;
+            *reinterpret_cast<u32x2_t*>(lds + G::quad(row, 1, kc_kq)) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int row = b_r0 + BRP * i;
+            *reinterpret_cast<xp_u32x4*>(lds + IMG_A + G::chunk(row, 0, b_c)) = rbh[i];
+            *reinterpret_cast<xp_u32x4*>(lds + IMG_A + G::chunk(row, 1, b_c)) = rbl[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = d.rowsum_a != nullptr && n0 == 0;
+    float rowsum = 0.f;
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        if (do_rowsum && t < XP_BM) {
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c) {
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(lds + G::chunk(t, 0, c));
+                const bf16x8 l = *reinterpret_cast<const bf16x8*>(lds + G::chunk(t, 1, c));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rowsum += bf16_bits_to_f32((unsigned short)h[e]) + bf16_bits_to_f32((unsigned short)l[e]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            bf16x8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 64 * wave + 16 * j + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 0, 4 * s + g));
+                bl[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 1, 4 * s + g));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * i + fr;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 0, 4 * s + g));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 1, 4 * s + g));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = mfma_bf16_16x16x32(al, bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah, bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah, bh[j], acc[i][j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (do_rowsum && t < XP_BM && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
+#define EEG_XP_EPI(SI, SJ)                                                                                                          \
+    {                                                                                                                               \
+        f32x4 a2[2][2] = {{acc[2 * SI][2 * SJ], acc[2 * SI][2 * SJ + 1]}, {acc[2 * SI + 1][2 * SJ], acc[2 * SI + 1][2 * SJ + 1]}};  \
+        gemm_epilogue<C_PLAIN>(d, a2, m0 + 32 * SI, n0 + 64 * wave + 32 * SJ, 0, 0, lane, slice == 0);                              \
+    }
+    EEG_XP_EPI(0, 0)
+    EEG_XP_EPI(0, 1)
+    EEG_XP_EPI(1, 0)
+    EEG_XP_EPI(1, 1)
+#undef EEG_XP_EPI
+}
+
+// rows of an fp32 matrix -> bf16 planes hi / lo, [rows][ld_out] with zeros beyond `cols`; TRANSPOSE: the planes of the transposed matrix.
+// A table of up to 24 matrices per launch (every Linear weight of the encoder, both orientations, in ONE launch per step).
+struct xp_split_entry {
+    const float* src;
+    unsigned short* hi;
+    unsigned short* lo;
+    int rows, cols;                  // of the SOURCE matrix
+    long long ld_src, ld_out;
+    int transpose, first_block;      // workgroups [first_block, next first_block) belong to this entry
+};
+constexpr int XP_SPLIT_MAX = 24;
+struct xp_split_table {
+    int n;
+    xp_split_entry e[XP_SPLIT_MAX];
+};
+__global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb) {
+    int ei = 0;
+    for (int i = 1; i < tb.n; ++i) ei += (int)blockIdx.x >= tb.e[i].first_block ? 1 : 0;
+    const xp_split_entry& E = tb.e[ei];
+    const int orow_n = E.transpose ? E.cols : E.rows, ocol_n = E.transpose ? E.rows : E.cols;
+    const long long per_row = E.ld_out;                              // output elements per row incl. padding
+    const long long total = (long long)orow_n * per_row;
+    for (long long q = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; q < total;
+         q += 256LL * ((ei + 1 < tb.n ? tb.e[ei + 1].first_block : (int)gridDim.x) - E.first_block)) {
+        const int r = (int)(q / per_row), c = (int)(q % per_row);
+        float v = 0.f;
+        if (c < ocol_n) v = E.transpose ? E.src[(long long)c * E.ld_src + r] : E.src[(long long)r * E.ld_src + c];
+        const unsigned short h = f32_to_bf16_bits(v);
+        E.hi[q] = h;
+        E.lo[q] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+    }
+}
+
 template <int BT, int BK, bool DB>
 static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
     const int gx = (d.N + BT - 1) / BT, gy = (d.M + BT - 1) / BT;
@@ -336,9 +523,25 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_
 
 // Problem -> tile shape.  cfg: 0 = 64x64x32, 1 = 64x64x32 double-buffered, 2 = 64x64x64, 3 = 64x64x64 double-buffered,
 // 4 = 128x128x32, 5 = 128x128x32 double-buffered.  EEGCLIP_X3_CFG pins one for tuning.
+static bool xp_planes_ok(const eegclip_gemm_desc& d) {
+    return d.B_hi && d.B_lo && d.ldb_planes >= ((d.K + 63) / 64) * 64 && (d.ldb_planes & 7) == 0 &&
+           ((reinterpret_cast<uintptr_t>(d.B_hi) | reinterpret_cast<uintptr_t>(d.B_lo)) & 15u) == 0;
+}
+
 int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
     static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
     static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
+    static const bool allow_planes = !(getenv("EEGCLIP_X3_PLANES") && atoi(getenv("EEGCLIP_X3_PLANES")) == 0);      // tuning aid
+    if (allow_planes && akc && !k2 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
+        const int gx = (d.N + XP_BN - 1) / XP_BN, gy = (d.M + XP_BM - 1) / XP_BM;
+        const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
+        const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
+        if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 planes <%d> %dx%dx%d sk%d\n", (int)c_plain, d.M, d.N, d.K, d.split_k);
+        const size_t lds = (size_t)(XP_BM + XP_BN) * x3_geom<32>::RS;
+        if (c_plain) EEG_LAUNCH((gemm_x3p_kernel<32, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
+        else         EEG_LAUNCH((gemm_x3p_kernel<32, false>), grid, block, lds, stream, d, gx, ntiles, chunk);
+        return (int)hipGetLastError();
+    }
     int cfg = ((d.precision >> 8) & 0xff) - 1;                  // explicit tile configuration in the descriptor (tuning / tests)
     if (cfg < 0) cfg = pinned;
     if (cfg < 0) {
@@ -360,3 +563,25 @@ int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain,
 }
 
 }  // namespace eeg
+
+using namespace eeg;
+
+extern "C" int eegclip_split_rows(const eegclip_split_item* items, int n, void* stream) {
+    if (!items || n < 0 || n > XP_SPLIT_MAX) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    xp_split_table tb;
+    tb.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const eegclip_split_item& it = items[i];
+        const int orow = it.transpose ? it.cols : it.rows, ocol = it.transpose ? it.rows : it.cols;
+        if (!it.src || !it.hi || !it.lo || it.rows < 1 || it.cols < 1 || it.ld_src < it.cols || it.ld_out < ocol) return EEGCLIP_EINVAL;
+        tb.e[i] = xp_split_entry{it.src, static_cast<unsigned short*>(it.hi), static_cast<unsigned short*>(it.lo), it.rows, it.cols, it.ld_src, it.ld_out,
+                                 it.transpose, blocks};
+        long long b = ((long long)orow * it.ld_out + 1023) / 1024;          // ~4 elements per thread
+        if (b > 256) b = 256;
+        blocks += (int)b;
+    }
+    EEG_LAUNCH(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tb);
+    return (int)hipGetLastError();
+}

@@ -55,12 +55,14 @@ class Plan:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
     def desc(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None):
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None, planes=None):
         """a GEMM descriptor owned by the plan but not (yet) an op: member template of a grouped launch"""
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
                           drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a,
                           precision=self.precision if precision is None else precision)
+        if planes is not None:                                   # B pre-split into bf16 planes (hi pointer, lo pointer, elements per row)
+            d.B_hi, d.B_lo, d.ldb_planes = planes
         self._keep.append(d)
         return d
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 2
+#define EEGCLIP_ABI_VERSION 3
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -83,8 +83,25 @@ typedef struct {
     float* rowsum_a;      /* [M] or NULL: += sum_k A[m,k] */
     int precision;        /* EEGCLIP_PREC_* (0 = exact fp32 products); bits 8..15: BF16X3 tile configuration, 0 = chosen by the library,
                              1..6 = 64x64x32 | same, two LDS images | 64x64x64 | same, two images | 128x128x32 | same, two images (tuning aid) */
+    const void* B_hi;     /* optional (BF16X3, k-contiguous A): B already split into bf16 planes by eegclip_split_rows -- row n of each plane = B[:, n]
+                             (N rows of ldb_planes elements, k contiguous, zero padded to a multiple of 64).  Weights are split once per optimizer
+                             step instead of once per tile that stages them; B must still be valid (other operand classes fall back to it). */
+    const void* B_lo;
+    long long ldb_planes;
 } eegclip_gemm_desc;
 
+/* fp32 matrices -> bf16 planes hi = bf16(x), lo = bf16(x - hi), [rows][ld_out] with zeros beyond the source columns; transpose != 0: the planes
+ * of the transposed matrix ([cols][ld_out]).  Up to 24 matrices per launch: every Linear weight of the encoder, both orientations (W for
+ * Y = X W^T, W^T for dX = dY W), once per step. */
+typedef struct {
+    const float* src;
+    void* hi;
+    void* lo;
+    int rows, cols;       /* of the source */
+    long long ld_src, ld_out;
+    int transpose;
+} eegclip_split_item;
+int eegclip_split_rows(const eegclip_split_item* items, int n, void* stream);
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);
 /* n independent problems (outputs must not overlap) with the result of n eegclip_gemm_f32 calls.  Members that differ only in M, K, split_k,
  * A, B, C, bias_n and rowsum_a (at most 16 of them) run as ONE grid: the joint-subject model's per-subject value embeddings -- the

@@ -32,7 +32,7 @@ SHAPES = [
     ("w_head0 1024x1440x256", 1024, 1440, 256, "tn", 1), ("w_head1 1024x1024x256", 1024, 1024, 256, "tn", 1),
     ("prior 1024x1024x1024", 1024, 1024, 1024, "nt", 1), ("sq 4096^3", 4096, 4096, 4096, "nt", 1),
 ]
-CFGS = [("f32", 0), ("x3 auto", 1)] + [(f"x3 cfg{c}", 1 | ((c + 1) << 8)) for c in range(6)]
+CFGS = [("f32", 0), ("x3 auto", 1), ("x3 planes", "planes")] + [(f"x3 cfg{c}", 1 | ((c + 1) << 8)) for c in range(6)]
 
 
 def make(M, N, K, kind, split):
@@ -47,7 +47,15 @@ def make(M, N, K, kind, split):
     d = _abi.GemmDesc(M=M, N=N, K=K, A=A.data_ptr(), Am=Am, Ak=Ak, B=B.data_ptr(), Bk=Bk, Bn=Bn, C=C.data_ptr(), Cm=D(N), Cn=D(1), Cpre=None,
                       bias_n=bias.data_ptr(), bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=int(split > 1), act=0, drop_p=0.0, seed=1,
                       drop_site=0, split_k=split)
-    return d, (A, B, C, bias)
+    planes = None
+    if kind in ("nt", "nn"):                                      # weights pre-split into bf16 planes (rows = output columns)
+        Wm = B if kind == "nt" else B.t().contiguous()            # (N, K)
+        ld = (K + 63) // 64 * 64
+        hi = torch.zeros(N, ld, dtype=torch.bfloat16, device="cuda"); lo = torch.zeros(N, ld, dtype=torch.bfloat16, device="cuda")
+        it = (_abi.SplitItem * 1)(_abi.SplitItem(src=Wm.data_ptr(), hi=hi.data_ptr(), lo=lo.data_ptr(), rows=N, cols=K, ld_src=K, ld_out=ld, transpose=0))
+        assert lib().eegclip_split_rows(it, 1, torch.cuda.current_stream().cuda_stream) == 0
+        planes = (hi, lo, ld, Wm)
+    return d, (A, B, C, bias, planes)
 
 
 def main():
@@ -62,14 +70,24 @@ def main():
     for name, M, N, K, kind, split in SHAPES:
         d, keep = make(M, N, K, kind, split)
         reps = max(2, args.reps // 4) if M * N * K > 1e10 else args.reps
-        times = {c: [] for c, _ in CFGS}
-        for c, p in CFGS:                                             # warm-up: code objects, clocks
-            d.precision = p
+        times = {c: [] for c, _ in CFGS if _ != "planes" or keep[4] is not None}
+        planes = keep[4]
+
+        def setp(p):
+            if p == "planes":
+                d.precision = 1
+                d.B_hi, d.B_lo, d.ldb_planes = planes[0].data_ptr(), planes[1].data_ptr(), planes[2]
+            else:
+                d.precision = p
+                d.B_hi, d.B_lo, d.ldb_planes = None, None, 0
+        cfgs = [c for c in CFGS if c[1] != "planes" or planes is not None]
+        for c, p in cfgs:                                             # warm-up: code objects, clocks
+            setp(p)
             for _ in range(2):
                 assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0
         for _ in range(args.rounds):
-            for c, p in CFGS:
-                d.precision = p
+            for c, p in cfgs:
+                setp(p)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
