@@ -13,6 +13,7 @@ arithmetic in hand-written HIP kernels reached through the C ABI (include/eegcli
   backward of a batch must run before the next forward at the same batch size (the training loop does exactly that).
 * There is no CPU / eager-PyTorch fallback: a CPU tensor or a missing library raises.
 """
+import os
 import math
 
 import numpy as np
@@ -404,7 +405,16 @@ class _Engine:
     def _init_weight_planes(self):
         """bf16 hi / lo planes of every Linear weight, in both orientations (W for Y = X W^T, W^T for dX = dY W), refreshed by ONE
         eegclip_split_rows launch at the head of every forward plan: the split of a weight element is then done once per step instead of once
-        per workgroup tile that stages it (csrc/gemm_x3.hip, planes variant)."""
+        per workgroup tile that stages it (csrc/gemm_x3.hip, planes variant).
+
+        OFF unless EEGCLIP_WEIGHT_PLANES=1: measured at B = 256 the 64x256-tile planes kernel is SLOWER than the 64x64x64 kernel that splits both
+        operands in registers (K ~ 250 GEMMs 24 vs 17 us, the step 1.60 vs 1.41 ms, profiles/r2_gemm_x3_sweep_v3.json): its 255-VGPR waves leave
+        one workgroup per SIMD, and the saved VALU work does not pay for the lost latency hiding."""
+        import collections
+        if os.environ.get("EEGCLIP_WEIGHT_PLANES", "0") != "1":
+            self.planes = self.planesT = collections.defaultdict(lambda: None)
+            self.plane_items, self.n_plane_items = None, 0
+            return
         if self.joint:
             base = []                                                # (the per-subject value embeddings run as a grouped fp32 launch)
         else:
@@ -485,7 +495,8 @@ class _Engine:
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
         PL, PLT = self.planes, self.planesT
-        pl.call("eegclip_split_rows", self.plane_items, self.n_plane_items)          # weight planes of this step (both orientations)
+        if self.n_plane_items:
+            pl.call("eegclip_split_rows", self.plane_items, self.n_plane_items)      # weight planes of this step (both orientations)
         # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
         if not self.joint:

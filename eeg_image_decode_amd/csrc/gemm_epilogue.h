@@ -116,6 +116,150 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
     }
 }
 
+// ---- epilogue over TRANSPOSED accumulator tiles: the product was formed as D' = B_tile A_tile^T (MFMA rows = n, columns = m), so lane
+// (fr = lane & 15, g = lane >> 4) holds, in the 4 registers of tile (mt, nt), the 4 CONSECUTIVE columns n = nb + 16 nt + 4 g + {0..3} of ONE
+// output row m = mb + 16 mt + fr.  Everything per-row is then per-lane and everything along n is a 16-byte access: bias / residual / C are
+// read and written as f32x4 (a dword-aligned address is enough for global 16-byte accesses), one Philox block covers the lane's 4 outputs.
+// Two measured reasons (tools/xp_abl.py, a 16384 x 256 x 250 launch: 27 us, of which an EMPTY k-loop left 16, no epilogue 6, plain 16-byte
+// stores of the tile 8): (1) with the standard layout a lane's 16 outputs are 16 separate 4-byte stores; (2) the epilogue was a chain of
+// "load bias -> wait -> compute -> store" blocks, one per 16x16 tile, each behind its own uniform branches: every block paid a full memory
+// latency.  Here ALL loads of a wave tile row are issued before the first use: the bias vectors once per call, residual / accumulate operands
+// per row of tiles.
+typedef float f32x4a4_t __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool PLAIN, int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, const f32x4 (&acc)[MT][NT], int mb, int nb, int lane, bool first_slice) {
+    const int fr = lane & 15, g = lane >> 4;
+    const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    const bool vec_c = PLAIN ? d.Cn.si == 1 : (d.Cn.si == 1 && d.Cn.div > (1LL << 40));          // columns contiguous in C (and Cpre)
+    const bool vec_r = d.R != nullptr && (PLAIN ? d.Rn.si == 1 : (d.Rn.si == 1 && d.Rn.div > (1LL << 40)));
+    const bool use_bias = first_slice && d.bias_n != nullptr;
+    const bool split = d.split_k > 1;
+    // wave-uniform: does the 16-column tile nt lie inside N entirely (vector accesses) or is it the ragged last tile (per-element, clamped)?
+    bool tile_full[NT];
+    int ncol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        tile_full[nt] = nb + 16 * nt + 16 <= d.N;
+        ncol[nt] = nb + 16 * nt + 4 * g;
+    }
+    auto load4 = [&](const float* base, long long row_off, const eegclip_dim& cn, int nt, bool vec) -> f32x4a4_t {
+        const int n = ncol[nt];
+        if (vec && tile_full[nt]) return *reinterpret_cast<const f32x4a4_t*>(base + row_off + n);
+        f32x4a4_t r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ne = n + e < d.N ? n + e : d.N - 1;          // clamped: never dereferenced out of range, never stored
+            r[e] = base[row_off + goff<PLAIN>(cn, ne)];
+        }
+        return r;
+    };
+    f32x4a4_t bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = f32x4a4_t{0.f, 0.f, 0.f, 0.f};
+    if (use_bias) {
+        const eegclip_dim unit{1LL << 62, 0, 1};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nb + 16 * nt < d.N) {
+                const int n = ncol[nt];
+                if (tile_full[nt]) bias[nt] = *reinterpret_cast<const f32x4a4_t*>(d.bias_n + n);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bias[nt][e] = d.bias_n[n + e < d.N ? n + e : d.N - 1];
+                }
+            }
+        }
+        (void)unit;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mm = mb + 16 * mt + fr;
+        const bool row_ok = mm < d.M;
+        const int m = row_ok ? mm : d.M - 1;                       // clamped row: loads stay in range, stores are predicated
+        const long long crow = goff<PLAIN>(d.Cm, m);
+        const long long rrow = d.R ? goff<PLAIN>(d.Rm, m) : 0;
+        const float bm = (first_slice && d.bias_m) ? d.bias_m[m] : 0.f;
+        // phase 1: every load of this row of tiles
+        f32x4a4_t rr[NT], oo[NT];
+        if (d.R && !split) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nb + 16 * nt < d.N) rr[nt] = load4(d.R, rrow, d.Rn, nt, vec_r);
+        }
+        if (d.accumulate && !split) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nb + 16 * nt < d.N) oo[nt] = load4(d.C, crow, d.Cn, nt, vec_c);
+        }
+        // phase 2: arithmetic and stores
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nb + 16 * nt >= d.N) continue;                     // (wave uniform)
+            const int n = ncol[nt];
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = d.alpha * acc[mt][nt][e] + bm + bias[nt][e];
+            const bool vc = vec_c && tile_full[nt];
+            const long long c0 = crow + goff<PLAIN>(d.Cn, n < d.N ? n : d.N - 1);
+            if (split) {
+                if (row_ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) atomicAdd(d.C + (vc ? c0 + e : crow + goff<PLAIN>(d.Cn, n + e)), v[e]);
+                }
+                continue;
+            }
+            if (d.Cpre && row_ok) {
+                if (vc) *reinterpret_cast<f32x4a4_t*>(d.Cpre + c0) = f32x4a4_t{v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) d.Cpre[crow + goff<PLAIN>(d.Cn, n + e)] = v[e];
+                }
+            }
+            if (d.act == EEGCLIP_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (d.act == EEGCLIP_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+            }
+            if (d.drop_p > 0.f) {
+                const unsigned long long idx = (unsigned long long)mm * (unsigned)d.N + (unsigned)n;
+                bool keep[4];
+                if ((d.N & 3) == 0) dropout_keep4(d.seed, d.drop_site, idx, d.drop_p, keep);       // the lane's 4 outputs are ONE Philox block
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keep[e] = dropout_keep(d.seed, d.drop_site, idx + e, d.drop_p);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * keep_scale : 0.f;
+            }
+            if (d.R) {
+                if (d.act == EEGCLIP_ACT_GELU_GRAD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(rr[nt][e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[nt][e];
+                }
+            }
+            if (d.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += oo[nt][e];
+            }
+            if (!row_ok) continue;
+            if (vc) *reinterpret_cast<f32x4a4_t*>(d.C + c0) = f32x4a4_t{v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < d.N) d.C[crow + goff<PLAIN>(d.Cn, n + e)] = v[e];
+            }
+        }
+    }
+}
+
 template <int BK>
 __device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int slice, int& kt_begin, int& kt_end) {
     const int ktiles = (d.K + BK - 1) / BK;

@@ -76,7 +76,10 @@ typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 
 // K2: both operands row-contiguous with k running through two-level maps {div, so, si} (the value-embedding weight gradient contracts over
 // the 63 channel rows of every 64-row sample): a thread's k rows advance by BK per tile, so (offset, remainder) are carried along and
 // wrapped by subtraction -- no division in the loop (same scheme as gemm.hip's K2 instantiation)
-template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false>
+// TRANS: the product is formed transposed (MFMA rows = n) and finished by gemm_epilogue_t (16-byte accesses along n); the split-K launches keep
+// the standard orientation: their epilogue is atomics only, and a wave's atomic instruction over 4 rows x 16 consecutive words coalesces where
+// 16 rows x 4 strided words does not (measured: the weight-gradient GEMMs 62 -> 174 us with the transposed layout).
+template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false, bool TRANS = false>
 __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
     static_assert(!K2 || (!A_KC && !B_KC), "two-level k maps are implemented for row-contiguous operands");
     using G = x3_geom<BK>;
@@ -265,9 +268,15 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(buf + G::chunk(row, 1, 4 * s + g));
 #pragma unroll
                 for (int j = 0; j < WT; ++j) {
-                    acc[i][j] = mfma_bf16_16x16x32(al, bh[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(ah, bl[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(ah, bh[j], acc[i][j]);
+                    if (TRANS) {
+                        acc[i][j] = mfma_bf16_16x16x32(bh[j], al, acc[i][j]);
+                        acc[i][j] = mfma_bf16_16x16x32(bl[j], ah, acc[i][j]);
+                        acc[i][j] = mfma_bf16_16x16x32(bh[j], ah, acc[i][j]);
+                    } else {
+                        acc[i][j] = mfma_bf16_16x16x32(al, bh[j], acc[i][j]);
+                        acc[i][j] = mfma_bf16_16x16x32(ah, bl[j], acc[i][j]);
+                        acc[i][j] = mfma_bf16_16x16x32(ah, bh[j], acc[i][j]);
+                    }
                 }
             }
         }
@@ -299,19 +308,23 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
         }
     }
     if (do_rowsum && t < BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-    // (explicit 32x32 sub-blocks: a loop over them is too large for the unroller and would index `acc` at run time -> scratch)
+    if constexpr (TRANS) {
+        gemm_epilogue_t<C_PLAIN, WT, WT>(d, acc, m0 + wr * (BT / 2), n0 + wc * (BT / 2), lane, slice == 0);
+    } else {
+        // (explicit 32x32 sub-blocks: a loop over them is too large for the unroller and would index `acc` at run time -> scratch)
 #define EEG_X3_EPI(SI, SJ)                                                                                                          \
     {                                                                                                                               \
         f32x4 a2[2][2] = {{acc[2 * SI][2 * SJ], acc[2 * SI][2 * SJ + 1]}, {acc[2 * SI + 1][2 * SJ], acc[2 * SI + 1][2 * SJ + 1]}};  \
         gemm_epilogue<C_PLAIN>(d, a2, m0 + wr * (BT / 2) + 32 * SI, n0 + wc * (BT / 2) + 32 * SJ, 0, 0, lane, slice == 0);          \
     }
-    EEG_X3_EPI(0, 0)
-    if constexpr (WT == 4) {
-        EEG_X3_EPI(0, 1)
-        EEG_X3_EPI(1, 0)
-        EEG_X3_EPI(1, 1)
-    }
+        EEG_X3_EPI(0, 0)
+        if constexpr (WT == 4) {
+            EEG_X3_EPI(0, 1)
+            EEG_X3_EPI(1, 0)
+            EEG_X3_EPI(1, 1)
+        }
 #undef EEG_X3_EPI
+    }
 }
 
 // =================================================================================================================================
@@ -447,25 +460,16 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 1, 4 * s + g));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = mfma_bf16_16x16x32(al, bh[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(ah, bl[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(ah, bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(bh[j], al, acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(bl[j], ah, acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(bh[j], ah, acc[i][j]);
                 }
             }
         }
         __syncthreads();
     }
     if (do_rowsum && t < XP_BM && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-#define EEG_XP_EPI(SI, SJ)                                                                                                          \
-    {                                                                                                                               \
-        f32x4 a2[2][2] = {{acc[2 * SI][2 * SJ], acc[2 * SI][2 * SJ + 1]}, {acc[2 * SI + 1][2 * SJ], acc[2 * SI + 1][2 * SJ + 1]}};  \
-        gemm_epilogue<C_PLAIN>(d, a2, m0 + 32 * SI, n0 + 64 * wave + 32 * SJ, 0, 0, lane, slice == 0);                              \
-    }
-    EEG_XP_EPI(0, 0)
-    EEG_XP_EPI(0, 1)
-    EEG_XP_EPI(1, 0)
-    EEG_XP_EPI(1, 1)
-#undef EEG_XP_EPI
+    gemm_epilogue_t<C_PLAIN, 4, 4>(d, acc, m0, n0 + 64 * wave, lane, slice == 0);
 }
 
 // rows of an fp32 matrix -> bf16 planes hi / lo, [rows][ld_out] with zeros beyond `cols`; TRANSPOSE: the planes of the transposed matrix.
@@ -509,8 +513,13 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_
     const size_t lds = (size_t)(DB ? 2 : 1) * 2 * BT * x3_geom<BK>::RS;
 #define EEG_X3_GO(AK, BK_)                                                                                                        \
     do {                                                                                                                          \
-        if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);     \
-        else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);    \
+        if (d.split_k > 1) {                                                                                                      \
+            if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true, false, false>), grid, block, lds, stream, d, gx, ntiles, chunk);   \
+            else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false, false, false>), grid, block, lds, stream, d, gx, ntiles, chunk);  \
+        } else {                                                                                                                  \
+            if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true, false, true>), grid, block, lds, stream, d, gx, ntiles, chunk);    \
+            else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false, false, true>), grid, block, lds, stream, d, gx, ntiles, chunk);   \
+        }                                                                                                                         \
     } while (0)
     if (k2)                EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, false, false, true, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
     else if (akc && bkc)   EEG_X3_GO(true, true);
@@ -532,7 +541,7 @@ int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain,
     static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
     static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
     static const bool allow_planes = !(getenv("EEGCLIP_X3_PLANES") && atoi(getenv("EEGCLIP_X3_PLANES")) == 0);      // tuning aid
-    if (allow_planes && akc && !k2 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
+    if (allow_planes && akc && !k2 && d.split_k == 1 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
         const int gx = (d.N + XP_BN - 1) / XP_BN, gy = (d.M + XP_BM - 1) / XP_BM;
         const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
         const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
