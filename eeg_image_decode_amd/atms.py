@@ -190,7 +190,12 @@ class Proj_eeg(nn.Sequential):
 # flat-buffer order: the always-live group first (QKV adjacent), then the two conditionally-live token tensors, then dead
 _E, _LY, _TS = "encoder.enc_embedding.", "encoder.encoder.attn_layers.0.", "enc_eeg.0.tsconv."
 _LIVE = [
+    # gradients that are complete EARLY in the backward first (loss -> head -> conv stack: 10.5 of the 12.8 MB), the transformer's after them: under
+    # data parallelism the flat gradient is then exactly TWO all-reduces, the first one started inside the backward plan (Engine.early_bucket)
     "logit_scale",
+    _TS + "0.weight", _TS + "0.bias", _TS + "2.weight", _TS + "2.bias", _TS + "4.weight", _TS + "4.bias", _TS + "5.weight", _TS + "5.bias",
+    "enc_eeg.0.projection.0.weight", "enc_eeg.0.projection.0.bias",
+    "proj_eeg.0.weight", "proj_eeg.0.bias", "proj_eeg.1.fn.1.weight", "proj_eeg.1.fn.1.bias", "proj_eeg.2.weight", "proj_eeg.2.bias",
     _E + "value_embedding.weight", _E + "value_embedding.bias",
     _LY + "attention.query_projection.weight", _LY + "attention.key_projection.weight", _LY + "attention.value_projection.weight",
     _LY + "attention.query_projection.bias", _LY + "attention.key_projection.bias", _LY + "attention.value_projection.bias",
@@ -198,9 +203,6 @@ _LIVE = [
     _LY + "conv1.weight", _LY + "conv1.bias", _LY + "conv2.weight", _LY + "conv2.bias",
     _LY + "norm1.weight", _LY + "norm1.bias", _LY + "norm2.weight", _LY + "norm2.bias",
     "encoder.encoder.norm.weight", "encoder.encoder.norm.bias",
-    _TS + "0.weight", _TS + "0.bias", _TS + "2.weight", _TS + "2.bias", _TS + "4.weight", _TS + "4.bias", _TS + "5.weight", _TS + "5.bias",
-    "enc_eeg.0.projection.0.weight", "enc_eeg.0.projection.0.bias",
-    "proj_eeg.0.weight", "proj_eeg.0.bias", "proj_eeg.1.fn.1.weight", "proj_eeg.1.fn.1.bias", "proj_eeg.2.weight", "proj_eeg.2.bias",
 ]
 _TOK_TABLE = _E + "subject_embedding.subject_embedding.weight"
 _TOK_SHARED = _E + "subject_embedding.shared_embedding"
@@ -391,7 +393,8 @@ class _Engine:
         self.offs = offs
         # gradient bucket that is complete early in the backward (conv stack + projection head: 10.5 of the 12.8 MB), contiguous in the flat
         # buffer; under data parallelism its all-reduce is started from inside the backward plan and hidden under the transformer's backward
-        a0, a1 = offs[_TS + "0.weight"], offs["proj_eeg.2.bias"] + (sd_params["proj_eeg.2.bias"].numel() + 3) // 4 * 4
+        a0, a1 = 0, offs["proj_eeg.2.bias"] + (sd_params["proj_eeg.2.bias"].numel() + 3) // 4 * 4
+        assert offs["logit_scale"] == 0 and a1 == offs[self.live_base[self.live_base.index("proj_eeg.2.bias") + 1]]
         self.early_bucket = (a0, a1)
         self.early_work = None
         self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])

@@ -214,9 +214,9 @@ class _ClipLossFn(torch.autograd.Function):
             if fused:
                 a_all_p = split_planes(a_all, planes)
                 ap = (a_all_p[0][sl], a_all_p[1][sl] if planes == 2 else None)        # this rank's rows of the gathered planes
+            b_alls = mod._gathered_targets(bs)                     # ONE all-gather for every target (usually started at step start)
             for t, (b_, w) in enumerate(zip(bs, weights)):
-                b_all = torch.empty(W * n, b_.shape[1], dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(b_all, b_)
+                b_all = b_alls[t]
                 if fused:
                     b_all_p = split_planes(b_all, planes)
                     bp = (b_all_p[0][sl], b_all_p[1][sl] if planes == 2 else None)
@@ -312,6 +312,51 @@ class ClipLoss(nn.Module):
         self.rank = rank
         self.world_size = world_size
         self.use_horovod = use_horovod
+
+    # ---- data parallel: the targets are INPUTS of the step (frozen CLIP features), so their all-gather does not have to wait for the encoder ----
+    @staticmethod
+    def _target_key(ts):
+        return tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ts)
+
+    def gather_targets(self, *targets):
+        """Start ONE asynchronous all-gather of all the step's target matrices ([img | txt] stacked, (T, n, D) per rank -> (W, T, n, D)) -- call it
+        before the encoder forward; the next forward / forward_mixed on the SAME tensors picks the result up and only then waits for it.  No-op
+        for a single process.  (The reference gathers inside the loss, models/loss.py:20-75: same values, issued earlier.)"""
+        if self.world_size <= 1:
+            return None
+        import torch.distributed as dist
+        ts = [t.detach().contiguous() for t in targets]
+        if any(t.shape != ts[0].shape or t.dtype != torch.float32 for t in ts):
+            return None                                           # (ragged targets: gathered one by one inside the loss)
+        send = ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
+        out = torch.empty((self.world_size * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.float32, device=send.device)
+        work = dist.all_gather_into_tensor(out, send, async_op=True)
+        self._pending_targets = (self._target_key(ts), work, out, send)
+        return work
+
+    def _gathered_targets(self, bs):
+        """[(W n, D) gathered copy of every target]: the prefetched gather if it was started for exactly these tensors, else one gather now."""
+        import torch.distributed as dist
+        pend, self._pending_targets = getattr(self, "_pending_targets", None), None
+        if pend is not None and pend[0] == self._target_key(bs):
+            pend[1].wait()
+            out = pend[2]
+        elif all(b.shape == bs[0].shape for b in bs):
+            send = bs[0].unsqueeze(0) if len(bs) == 1 else torch.stack(bs)
+            out = torch.empty((self.world_size * send.shape[0],) + tuple(send.shape[1:]), dtype=torch.float32, device=send.device)
+            dist.all_gather_into_tensor(out, send)
+        else:
+            res = []
+            for b in bs:
+                b_all = torch.empty(self.world_size * b.shape[0], b.shape[1], dtype=torch.float32, device=b.device)
+                dist.all_gather_into_tensor(b_all, b)
+                res.append(b_all)
+            return res
+        W, n = self.world_size, bs[0].shape[0]
+        if len(bs) == 1:
+            return [out.view(W * n, -1)]
+        out = out.view(W, len(bs), n, -1)                       # (rank, target, sample, feature)
+        return [out[:, t].reshape(W * n, -1) for t in range(len(bs))]        # (rank, sample) rows of target t, contiguous
 
     def forward(self, image_features, text_features, logit_scale):
         require_cuda(image_features, "image_features")

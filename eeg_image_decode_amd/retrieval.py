@@ -104,6 +104,10 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
     from . import dist as edist
     batch_size = eeg_data.size(0)
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
+    loss_func = eeg_model.loss_func
+    if edist.world_size() > 1 and hasattr(loss_func, "gather_targets"):
+        # the targets are inputs: their all-gather ([img | txt] in ONE collective) runs under the encoder forward instead of after it
+        loss_func.gather_targets(*((img_features,) if objective == "reconstruction" else (img_features, text_features)))
     eeg_features = eeg_model(eeg_data, subject_ids).float()
     logit_scale = eeg_model.logit_scale
     # running train accuracy (ATMS_retrieval.py:241-250: logits against all class features, argmax, count): it only needs the
@@ -114,7 +118,6 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
         side.wait_stream(main)
         with torch.cuda.stream(side):
             _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
-    loss_func = eeg_model.loss_func
     if objective == "reconstruction":
         # Generation/ATMS_reconstruction.py:222-228 (alpha = 0.9 there): 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img)); the text
         # loss the reference also evaluates never enters the objective

@@ -179,8 +179,28 @@ def _dp_worker(rank, world, port, ret):
         opt = optim.AdamW(m.parameters(), lr=3e-4)
         loss_acc, correct = torch.zeros(()), torch.zeros(1, dtype=torch.int32)
         classes = T(syn.unit_features(SEED + 42, 7, tag="cls"))
-        retrieval.contrastive_step(m, opt, x_all[sl].contiguous(), 1, img_all[sl].contiguous(), txt_all[sl].contiguous(),
-                                   torch.zeros(n, dtype=torch.long), classes, loss_acc, correct)
+        calls = {}
+
+        def counted(name):
+            fn = getattr(dist, name)
+
+            def wrapper(*a, **k):
+                calls[name] = calls.get(name, 0) + 1
+                return fn(*a, **k)
+            return wrapper
+        saved = {nm: getattr(dist, nm) for nm in ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor", "broadcast", "all_gather")}
+        for nm in saved:
+            setattr(dist, nm, counted(nm))
+        try:
+            retrieval.contrastive_step(m, opt, x_all[sl].contiguous(), 1, img_all[sl].contiguous(), txt_all[sl].contiguous(),
+                                       torch.zeros(n, dtype=torch.long), classes, loss_acc, correct)
+        finally:
+            for nm, fn in saved.items():
+                setattr(dist, nm, fn)
+        # collectives of ONE data-parallel step: [img|txt] targets in one all-gather (started before the encoder), Z in one, one reduce-scatter of
+        # the gathered-copy gradients, the flat gradient in two all-reduces (early bucket + rest), and the four data-dependent 640-byte SyncBN sums
+        if os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0":
+            assert calls == {"all_gather_into_tensor": 2, "reduce_scatter_tensor": 1, "all_reduce": 2 + 4}, calls
         eng = m._engine()
         # the conv-stack + head gradient bucket was all-reduced from INSIDE the backward plan (asynchronously) and collected afterwards
         early = [pl for k, pl in eng.plans.items() if k[0] == "b" and "allreduce_early_bucket" in pl.op_names()]
