@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int),
         ("rowsum_a", C.c_void_p),
         ("precision", C.c_int),
-        ("B_hi", C.c_void_p), ("B_lo", C.c_void_p), ("ldb_planes", C.c_longlong),
+        ("B_hi", C.c_void_p), ("B_lo", C.c_void_p), ("ldb_planes", C.c_longlong), ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
     ]
 
 
@@ -55,7 +55,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -63,6 +63,7 @@ _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c
 PROTOTYPES = {
     "eegclip_abi_version": [],
     "eegclip_gemm_f32": [C.POINTER(GemmDesc), _P],
+    "eegclip_gemm_workspace_bytes": [C.POINTER(GemmDesc)],
     "eegclip_split_rows": [C.POINTER(SplitItem), _I, _P],
     "eegclip_gemm_f32_grouped": [_P, _I, _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
@@ -144,6 +145,6 @@ def declare(lib):
     """Attach prototypes; raises AttributeError if the library lacks a symbol the header declares."""
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
-        fn.restype = C.c_longlong if name.endswith("_floats") else C.c_int
+        fn.restype = C.c_longlong if name.endswith(("_floats", "_bytes")) else C.c_int
         fn.argtypes = args
     return lib

@@ -470,7 +470,7 @@ static int fast_class(const eegclip_gemm_desc& d, bool& akc, bool& bkc, bool& c_
     return 0;
 }
 
-static int launch_gemm(const eegclip_gemm_desc& d, void* stream);
+static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_query = nullptr);
 
 // everything a group cannot override must be the same in all members (Cpre / bias_m are per-problem buffers: not groupable when set)
 static bool same_dim(const eegclip_dim& a, const eegclip_dim& b) { return a.div == b.div && a.so == b.so && a.si == b.si; }
@@ -526,12 +526,15 @@ static int launch_gemm_grouped(const eegclip_gemm_desc* ds, int n, void* stream)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
+// ws_query: do not launch; report the split-K workspace the launch would use (0 unless it is routed to the BF16X3 kernels)
+static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_query) {
+    if (ws_query) *ws_query = 0;
     static const bool allow_skinny = !(getenv("EEGCLIP_GEMM_SKINNY") && atoi(getenv("EEGCLIP_GEMM_SKINNY")) == 0);   // tuning aid
     // skinny: few rows against k-contiguous operands, every map a plain stride, 16-byte loads legal, K long enough for the 16-way split
     if (allow_skinny && d.M <= 32 && d.split_k == 1 && d.K >= 64 && (d.K & 3) == 0 && is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) &&
         is_plain(d.Bn) && is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn))) && d.Ak.si == 1 && d.Bk.si == 1 &&
         d.Am.si >= 0 && d.Bn.si >= 0 && (d.Am.si & 3) == 0 && (d.Bn.si & 3) == 0 && aligned16(d.A) && aligned16(d.B)) {
+        if (ws_query) return 0;
         static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
         if (trace) fprintf(stderr, "eegclip_gemm_f32: skinny %dx%dx%d\n", d.M, d.N, d.K);
         const dim3 grid((d.N + SK_N - 1) / SK_N), block(SK_WAVES * 64);
@@ -551,6 +554,10 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     const dim3 fgrid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles);
     if (allow_fast && ab_plain && d.K >= 2 && (long long)gx * gy < (1LL << 28) && fast_operand_ok(d.A, d.Am.si, d.Ak.si, d.M, d.K, akc) &&
         fast_operand_ok(d.B, d.Bn.si, d.Bk.si, d.N, d.K, bkc)) {
+        if (ws_query) {
+            if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) *ws_query = gemm_x3_workspace_bytes(d);
+            return 0;
+        }
         if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, akc, bkc, c_plain, false, stream);
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
         const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
@@ -569,12 +576,17 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream) {
     // both operands row-contiguous with k running through two-level maps (plain row maps, plain C): the K2 instantiation
     if (allow_fast && c_plain && is_plain(d.Am) && is_plain(d.Bn) && d.Am.si == 1 && d.Bn.si == 1 && d.K >= 2 && (long long)gx * gy < (1LL << 28) &&
         fast_k2_ok(d.A, d.Ak, d.M, d.K) && fast_k2_ok(d.B, d.Bk, d.N, d.K)) {
+        if (ws_query) {
+            if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) *ws_query = gemm_x3_workspace_bytes(d);
+            return 0;
+        }
         if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, false, false, true, true, stream);
         if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<0,0,1,K2> %dx%dx%d sk%d\n", d.M, d.N, d.K, d.split_k);
         const size_t lds = 2 * G_BK * G_BT * sizeof(float);
         EEG_LAUNCH((gemm_f32_fast_kernel<false, false, true, true>), fgrid, block, lds, stream, d, gx, ntiles, chunk);
         return (int)hipGetLastError();
     }
+    if (ws_query) return 0;
     const dim3 grid(gx, gy, d.split_k);
     const size_t lds = 2 * G_BK * G_BT * sizeof(float);
     akc = (d.Ak.si == 1);
@@ -603,6 +615,16 @@ extern "C" int eegclip_gemm_f32(const eegclip_gemm_desc* dp, void* stream) {
     const int rc = gemm_desc_check(d);
     if (rc || d.M == 0 || d.N == 0) return rc;
     return launch_gemm(d, stream);
+}
+
+extern "C" long long eegclip_gemm_workspace_bytes(const eegclip_gemm_desc* dp) {
+    using namespace eeg;
+    if (!dp) return 0;
+    const eegclip_gemm_desc d = *dp;
+    if (gemm_desc_check(d) || d.M == 0 || d.N == 0 || d.split_k <= 1) return 0;
+    long long bytes = 0;
+    launch_gemm(d, nullptr, &bytes);
+    return bytes;
 }
 
 extern "C" int eegclip_gemm_f32_grouped(const eegclip_gemm_desc* descs, int n, void* stream) {
@@ -635,6 +657,7 @@ static int gemm_desc_check(const eegclip_gemm_desc& d) {
     if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_GELU_GRAD) return EEGCLIP_EINVAL;
     if ((d.precision & 0xff) != EEGCLIP_PREC_F32 && (d.precision & 0xff) != EEGCLIP_PREC_BF16X3) return EEGCLIP_EINVAL;
     if ((d.precision >> 8) < 0 || (d.precision >> 8) > 6) return EEGCLIP_EINVAL;
+    if (d.workspace && d.workspace_bytes < 0) return EEGCLIP_EINVAL;
     if (d.act == EEGCLIP_ACT_GELU_GRAD && (!d.R || d.split_k > 1)) return EEGCLIP_EINVAL;
     if (d.Am.div <= 0 || d.Ak.div <= 0 || d.Bk.div <= 0 || d.Bn.div <= 0 || d.Cm.div <= 0 || d.Cn.div <= 0) return EEGCLIP_EINVAL;
     if (d.R && (d.Rm.div <= 0 || d.Rn.div <= 0)) return EEGCLIP_EINVAL;

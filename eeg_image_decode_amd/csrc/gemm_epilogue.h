@@ -128,13 +128,14 @@ __device__ __forceinline__ void gemm_epilogue(const eegclip_gemm_desc& d, const 
 typedef float f32x4a4_t __attribute__((ext_vector_type(4), aligned(4)));
 
 template <bool PLAIN, int MT, int NT>
-__device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, const f32x4 (&acc)[MT][NT], int mb, int nb, int lane, bool first_slice) {
+__device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, const f32x4 (&acc)[MT][NT], int mb, int nb, int lane, bool first_slice,
+                                                bool split, float* __restrict__ C) {
     const int fr = lane & 15, g = lane >> 4;
     const float keep_scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
     const bool vec_c = PLAIN ? d.Cn.si == 1 : (d.Cn.si == 1 && d.Cn.div > (1LL << 40));          // columns contiguous in C (and Cpre)
     const bool vec_r = d.R != nullptr && (PLAIN ? d.Rn.si == 1 : (d.Rn.si == 1 && d.Rn.div > (1LL << 40)));
     const bool use_bias = first_slice && d.bias_n != nullptr;
-    const bool split = d.split_k > 1;
+    // (split: this call adds one K slice's share atomically; false also for the workspace reduction, whose last workgroup owns the tile)
     // wave-uniform: does the 16-column tile nt lie inside N entirely (vector accesses) or is it the ragged last tile (per-element, clamped)?
     bool tile_full[NT];
     int ncol[NT];
@@ -190,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
         if (d.accumulate && !split) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                if (nb + 16 * nt < d.N) oo[nt] = load4(d.C, crow, d.Cn, nt, vec_c);
+                if (nb + 16 * nt < d.N) oo[nt] = load4(C, crow, d.Cn, nt, vec_c);
         }
         // phase 2: arithmetic and stores
 #pragma unroll
@@ -206,7 +207,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
                 if (row_ok) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < d.N) atomicAdd(d.C + (vc ? c0 + e : crow + goff<PLAIN>(d.Cn, n + e)), v[e]);
+                        if (n + e < d.N) atomicAdd(C + (vc ? c0 + e : crow + goff<PLAIN>(d.Cn, n + e)), v[e]);
                 }
                 continue;
             }
@@ -250,11 +251,11 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
                 for (int e = 0; e < 4; ++e) v[e] += oo[nt][e];
             }
             if (!row_ok) continue;
-            if (vc) *reinterpret_cast<f32x4a4_t*>(d.C + c0) = f32x4a4_t{v[0], v[1], v[2], v[3]};
+            if (vc) *reinterpret_cast<f32x4a4_t*>(C + c0) = f32x4a4_t{v[0], v[1], v[2], v[3]};
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < d.N) d.C[crow + goff<PLAIN>(d.Cn, n + e)] = v[e];
+                    if (n + e < d.N) C[crow + goff<PLAIN>(d.Cn, n + e)] = v[e];
             }
         }
     }
@@ -272,5 +273,6 @@ __device__ __forceinline__ void gemm_k_slice(const eegclip_gemm_desc& d, int sli
 // gemm_x3.hip: the split-bf16 kernel for the plain-stride operand classes (akc / bkc: operand is k-contiguous)
 // k2: both operands row-contiguous, k through two-level maps (akc = bkc = false, c_plain = true)
 int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream);
+long long gemm_x3_workspace_bytes(const eegclip_gemm_desc& d);
 
 }  // namespace eeg

@@ -73,6 +73,33 @@ struct x3_geom {
 
 typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte global load from a dword-aligned address
 
+// split-K workspace: split_k plain [M][ld] slabs of partial products, ld = N rounded up to 4 floats
+static inline long long x3_ws_ld(int N) { return ((long long)N + 3) & ~3LL; }
+static inline long long x3_workspace_bytes(int M, int N, int split_k) { return 4LL * split_k * M * x3_ws_ld(N); }
+
+// C[m,n] (+)= sum_s slab_s[m,n] + bias_n[n] + bias_m[m], slabs added in slice order (a result independent of scheduling); one thread per 4 columns
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const eegclip_gemm_desc d, const float* __restrict__ slabs, int ld) {
+    const int q = ld >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)d.M * q) return;
+    const int m = (int)(idx / q), n = (int)(idx % q) * 4;
+    const size_t slab = (size_t)d.M * ld;
+    const float* p = slabs + (size_t)m * ld + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < d.split_k; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slab);
+    const float bm = d.bias_m ? d.bias_m[m] : 0.f;
+    const long long crow = goff<PLAIN>(d.Cm, m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e >= d.N) break;
+        float o = v[e] + bm + (d.bias_n ? d.bias_n[n + e] : 0.f);
+        float* c = d.C + crow + goff<PLAIN>(d.Cn, n + e);
+        if (d.accumulate) o += *c;
+        *c = o;
+    }
+}
+
 // K2: both operands row-contiguous with k running through two-level maps {div, so, si} (the value-embedding weight gradient contracts over
 // the 63 channel rows of every 64-row sample): a thread's k rows advance by BK per tile, so (offset, remainder) are carried along and
 // wrapped by subtraction -- no division in the loop (same scheme as gemm.hip's K2 instantiation)
@@ -309,7 +336,10 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
     }
     if (do_rowsum && t < BT && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
     if constexpr (TRANS) {
-        gemm_epilogue_t<C_PLAIN, WT, WT>(d, acc, m0 + wr * (BT / 2), n0 + wc * (BT / 2), lane, slice == 0);
+        // split_k > 1 here = the workspace route: the launcher pointed C at a stack of split_k plain [M][ld] slabs, slice s fills slab s with
+        // its partial product (no bias, no accumulate) and eegclip's reduce kernel adds the slabs in slice order afterwards
+        float* cbase = d.C + (d.split_k > 1 ? (size_t)slice * (size_t)d.M * (size_t)d.Cm.si : (size_t)0);
+        gemm_epilogue_t<C_PLAIN, WT, WT>(d, acc, m0 + wr * (BT / 2), n0 + wc * (BT / 2), lane, slice == 0, false, cbase);
     } else {
         // (explicit 32x32 sub-blocks: a loop over them is too large for the unroller and would index `acc` at run time -> scratch)
 #define EEG_X3_EPI(SI, SJ)                                                                                                          \
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
         __syncthreads();
     }
     if (do_rowsum && t < XP_BM && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-    gemm_epilogue_t<C_PLAIN, 4, 4>(d, acc, m0, n0 + 64 * wave, lane, slice == 0);
+    gemm_epilogue_t<C_PLAIN, 4, 4>(d, acc, m0, n0 + 64 * wave, lane, slice == 0, d.split_k > 1, d.C);
 }
 
 // rows of an fp32 matrix -> bf16 planes hi / lo, [rows][ld_out] with zeros beyond `cols`; TRANSPOSE: the planes of the transposed matrix.
@@ -506,14 +536,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
 }
 
 template <int BT, int BK, bool DB>
-static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
-    const int gx = (d.N + BT - 1) / BT, gy = (d.M + BT - 1) / BT;
+static int x3_launch_cfg(const eegclip_gemm_desc& d_in, bool akc, bool bkc, bool c_plain_in, bool k2, void* stream) {
+    bool c_plain = c_plain_in;
+    const int gx = (d_in.N + BT - 1) / BT, gy = (d_in.M + BT - 1) / BT;
     const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
-    const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
+    const dim3 grid(d_in.split_k == 1 ? 8 * chunk : 8 * ((d_in.split_k + 7) / 8) * ntiles), block(X3_THREADS);
     const size_t lds = (size_t)(DB ? 2 : 1) * 2 * BT * x3_geom<BK>::RS;
+    // split-K: through the workspace (transposed product into per-slice slabs + one ordered reduction) when the caller gave one, else atomics
+    const bool ws = d_in.split_k > 1 && d_in.workspace != nullptr && d_in.workspace_bytes >= x3_workspace_bytes(d_in.M, d_in.N, d_in.split_k) &&
+                    (reinterpret_cast<uintptr_t>(d_in.workspace) & 15u) == 0;
+    eegclip_gemm_desc d = d_in;
+    if (ws) {
+        d.C = d_in.workspace;
+        d.Cm = eegclip_dim{1LL << 62, 0, x3_ws_ld(d_in.N)};
+        d.Cn = eegclip_dim{1LL << 62, 0, 1};
+        d.bias_n = d.bias_m = nullptr;
+        d.accumulate = 0;
+        c_plain = true;
+    }
+    const bool trans = d.split_k == 1 || ws;
 #define EEG_X3_GO(AK, BK_)                                                                                                        \
     do {                                                                                                                          \
-        if (d.split_k > 1) {                                                                                                      \
+        if (!trans) {                                                                                                             \
             if (c_plain) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, true, false, false>), grid, block, lds, stream, d, gx, ntiles, chunk);   \
             else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false, false, false>), grid, block, lds, stream, d, gx, ntiles, chunk);  \
         } else {                                                                                                                  \
@@ -521,12 +565,22 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_
             else         EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, AK, BK_, false, false, true>), grid, block, lds, stream, d, gx, ntiles, chunk);   \
         }                                                                                                                         \
     } while (0)
-    if (k2)                EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, false, false, true, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
+    if (k2) {
+        if (ws) EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, false, false, true, true, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
+        else    EEG_LAUNCH((gemm_x3_kernel<BT, BK, DB, false, false, true, true, false>), grid, block, lds, stream, d, gx, ntiles, chunk);
+    }
     else if (akc && bkc)   EEG_X3_GO(true, true);
     else if (akc && !bkc)  EEG_X3_GO(true, false);
     else if (!akc && bkc)  EEG_X3_GO(false, true);
     else                   EEG_X3_GO(false, false);
 #undef EEG_X3_GO
+    if (ws) {
+        const int ld = (int)x3_ws_ld(d_in.N);
+        const long long threads = (long long)d_in.M * (ld >> 2);
+        const dim3 rgrid((unsigned)((threads + 255) / 256));
+        if (c_plain_in) EEG_LAUNCH((x3_splitk_reduce_kernel<true>), rgrid, dim3(256), 0, stream, d_in, (const float*)d_in.workspace, ld);
+        else            EEG_LAUNCH((x3_splitk_reduce_kernel<false>), rgrid, dim3(256), 0, stream, d_in, (const float*)d_in.workspace, ld);
+    }
     return (int)hipGetLastError();
 }
 
@@ -536,6 +590,8 @@ static bool xp_planes_ok(const eegclip_gemm_desc& d) {
     return d.B_hi && d.B_lo && d.ldb_planes >= ((d.K + 63) / 64) * 64 && (d.ldb_planes & 7) == 0 &&
            ((reinterpret_cast<uintptr_t>(d.B_hi) | reinterpret_cast<uintptr_t>(d.B_lo)) & 15u) == 0;
 }
+
+long long gemm_x3_workspace_bytes(const eegclip_gemm_desc& d) { return d.split_k > 1 ? x3_workspace_bytes(d.M, d.N, d.split_k) : 0; }
 
 int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
     static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;

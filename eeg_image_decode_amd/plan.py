@@ -20,6 +20,11 @@ from ._lib import check, lib
 D = _abi.dim
 
 
+# split-K through per-slice slabs + an ordered reduction instead of atomics on C: run-to-run bit-reproducible weight gradients.  Measured equal in
+# time at the step's split (256 x 250 x 16384 / 32 slices: 31.4 us atomics, 32.3 us slabs; tools/wgrad_probe.py), so it is opt-in.
+_SPLITK_WORKSPACE = os.environ.get("EEGCLIP_SPLITK_WORKSPACE", "0") == "1"
+
+
 def default_gemm_precision():
     """Arithmetic of the plan GEMMs (every Linear of the encoder / head / prior, forward and backward): split-bf16 products on the bf16 matrix
     cores by default (include/eegclip.h: EEGCLIP_PREC_BF16X3; embeddings move by <= 3e-5 against exact fp32 products, parity budget 1e-3);
@@ -68,6 +73,15 @@ class Plan:
 
     def gemm(self, *a, side=False, **k):
         d = self.desc(*a, **k)
+        if d.split_k > 1 and _SPLITK_WORKSPACE:
+            # split-K through a scratch buffer of this op's own (ops of one plan may overlap on its two streams): partial tiles + one ordered
+            # reduction instead of split_k atomic adds per output element
+            nbytes = int(self.L.eegclip_gemm_workspace_bytes(ctypes.byref(d)))
+            if nbytes > 0:
+                import torch
+                ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda" if torch.cuda.is_available() else "cpu")   # (cpu: the test emulator)
+                self._keep.append(ws)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
         if d.drop_p > 0.0:
             self._seed_descs.append(d)
         self.ops.append((self.L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", side))

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 3
+#define EEGCLIP_ABI_VERSION 4
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -59,7 +59,11 @@ typedef struct {
  *   Transformer_EncDec.py:48-51 (FFN), Retrieval/ATMS_retrieval.py:106,113 (spatial / 1x1 conv), :157-167 (head),
  *   models/loss.py:122-123 (logits), Generation/diffusion_prior.py:167-203 (prior MLP).
  * split_k > 1: K is cut into split_k slices whose partial products are atomically added into C (C must be
- * zero or hold the value to accumulate onto); bias is added by slice 0; act/dropout/R/Cpre are not allowed. */
+ * zero or hold the value to accumulate onto); bias is added by slice 0; act/dropout/R/Cpre are not allowed.
+ * With `workspace` (BF16X3 launches; at least eegclip_gemm_workspace_bytes(d) bytes, contents irrelevant, not shared by launches that may run
+ * concurrently) slice s writes its partial product into slab s of the workspace instead and a second kernel of the same call adds the slabs
+ * IN SLICE ORDER (+ bias, + C when accumulating) and stores C once: no atomics on C (measured: the 2.1 M device-scope atomics of a
+ * 256 x 250 x 16384 / 32-slice weight gradient cost ~15 of its 31 us) and a result that does not depend on the arrival order. */
 typedef struct {
     int M, N, K;
     const float* A;
@@ -88,6 +92,8 @@ typedef struct {
                              step instead of once per tile that stages them; B must still be valid (other operand classes fall back to it). */
     const void* B_lo;
     long long ldb_planes;
+    float* workspace;     /* optional split-K scratch (see above); NULL = atomics */
+    long long workspace_bytes;
 } eegclip_gemm_desc;
 
 /* fp32 matrices -> bf16 planes hi = bf16(x), lo = bf16(x - hi), [rows][ld_out] with zeros beyond the source columns; transpose != 0: the planes
@@ -103,6 +109,9 @@ typedef struct {
 } eegclip_split_item;
 int eegclip_split_rows(const eegclip_split_item* items, int n, void* stream);
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);
+/* bytes of split-K workspace this launch can use (0: it would not use one -- split_k == 1, exact-fp32 products or an operand class outside the
+ * BF16X3 kernels) */
+long long eegclip_gemm_workspace_bytes(const eegclip_gemm_desc* d);
 /* n independent problems (outputs must not overlap) with the result of n eegclip_gemm_f32 calls.  Members that differ only in M, K, split_k,
  * A, B, C, bias_n and rowsum_a (at most 16 of them) run as ONE grid: the joint-subject model's per-subject value embeddings -- the
  * reference's Python loop of B Linear calls, models/subject_layers/Embed.py:144 -- and their weight gradients.  Anything else is launched

@@ -110,6 +110,7 @@ inline float atomicAdd(float* p, float v) { return hipemu::atomic_add(p, v); }
 inline double atomicAdd(double* p, double v) { return hipemu::atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return hipemu::atomic_add(p, v); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return hipemu::atomic_add(p, v); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }

@@ -237,3 +237,73 @@ def test_x3_planes_variant_full_epilogue_and_embedding_map(be):
     out = be.host(OUT)
     np.testing.assert_allclose(out[:, 1:], x3_ref(xe.reshape(-1, T), we.T).reshape(Bt, Cc, T) + b_ + pe, atol=2e-5)
     assert (out[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5])
+@pytest.mark.parametrize("M,N,K,split_k", [(72, 66, 330, 3), (200, 130, 70, 2), (130, 250, 1100, 8), (2, 2, 40, 5)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1)])
+def test_x3_split_k_through_the_workspace(be, cfg, M, N, K, split_k, ta, tb):
+    """split-K with eegclip_gemm_desc.workspace: every slice writes its partial product into its own slab, a second kernel adds the slabs in
+    slice order.  Same sums as the atomic route, bit-equal from run to run, bias / alpha / accumulate / bias_m applied once, workspace contents
+    irrelevant on entry (NaN filled here)."""
+    if be.name == "emu" and cfg in (2, 3) and (M, N, K) != (72, 66, 330):
+        pytest.skip("emulator time")
+    rng = np.random.default_rng(M + N + K + 5 * ta + 3 * tb)
+    a = f32(rng, *((K, M) if ta else (M, K)))
+    b = f32(rng, *((N, K) if tb else (K, N)))
+    bias, bm, c0 = f32(rng, N), f32(rng, M), f32(rng, M, N)
+    A, B, BI, BM = be.dev(a), be.dev(b), be.dev(bias), be.dev(bm)
+    Am, Ak = (D(1), D(M)) if ta else (D(K), D(1))
+    Bk, Bn = (D(1), D(K)) if tb else (D(N), D(1))
+    outs = []
+    ws = None
+    for rep in range(2):
+        C = be.dev(c0)
+        d = mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), bias_n=be.ptr(BI), bias_m=be.ptr(BM), alpha=0.5, accumulate=1, split_k=split_k,
+               precision=prec(cfg))
+        need = be.lib.eegclip_gemm_workspace_bytes(ctypes.byref(d))
+        assert need == 4 * split_k * M * ((N + 3) // 4 * 4)
+        if ws is None:
+            ws = be.dev(np.full(need // 4, np.nan, np.float32))
+        d.workspace, d.workspace_bytes = be.ptr(ws), need
+        run(be, d)
+        outs.append(be.host(C).copy())
+    am, bmat = (a.T if ta else a), (b.T if tb else b)
+    want = 0.5 * x3_ref(am, bmat) + bias + bm[:, None] + c0
+    np.testing.assert_allclose(outs[0], want, atol=6e-6 * max(1.0, np.abs(want).max()))
+    assert (outs[0] == outs[1]).all()
+    # too small a workspace: the atomic route, same sums
+    C = be.dev(c0)
+    d = mk(be, M, N, K, A, Am, Ak, B, Bk, Bn, C, D(N), D(1), bias_n=be.ptr(BI), bias_m=be.ptr(BM), alpha=0.5, accumulate=1, split_k=split_k,
+           precision=prec(cfg))
+    d.workspace, d.workspace_bytes = be.ptr(ws), need - 4
+    run(be, d)
+    np.testing.assert_allclose(be.host(C), want, atol=6e-6 * max(1.0, np.abs(want).max()))
+
+
+def test_x3_split_k_workspace_query_is_zero_where_no_workspace_is_used(be):
+    rng = np.random.default_rng(3)
+    a, b = f32(rng, 40, 30), f32(rng, 30, 20)
+    A, B, C = be.dev(a), be.dev(b), be.zeros((40, 20))
+    for split_k, precision, want_ws in [(1, prec(), False), (4, 0, False), (4, prec(), True)]:
+        d = mk(be, 40, 20, 30, A, D(30), D(1), B, D(20), D(1), C, D(20), D(1), accumulate=1, split_k=split_k, precision=precision)
+        assert (be.lib.eegclip_gemm_workspace_bytes(ctypes.byref(d)) > 0) == want_ws
+
+
+@pytest.mark.parametrize("split_k", [3, 7])
+def test_x3_value_embedding_weight_gradient_through_the_workspace(be, split_k):
+    rng = np.random.default_rng(40 + split_k)
+    Bt, Cc, Dm, T = 5, 63, 50, 70
+    dout, x, w0 = f32(rng, Bt, Cc + 1, Dm), f32(rng, Bt, Cc, T), f32(rng, Dm, T)
+    DO, X, W, RS = be.dev(dout), be.dev(x), be.dev(w0), be.zeros(Dm)
+    d = mk(be, Dm, T, Bt * Cc, DO, D(1), D(Dm, div=Cc, so=(Cc + 1) * Dm), X, D(T), D(1), W, D(T), D(1), accumulate=1, split_k=split_k,
+           rowsum_a=be.ptr(RS), precision=prec())
+    d.A = be.ptr(DO) + 4 * Dm
+    need = be.lib.eegclip_gemm_workspace_bytes(ctypes.byref(d))
+    assert need > 0
+    ws = be.zeros(need // 4)
+    d.workspace, d.workspace_bytes = be.ptr(ws), need
+    run(be, d)
+    g = dout[:, 1:, :].reshape(-1, Dm)
+    np.testing.assert_allclose(be.host(W), w0 + x3_ref(g.T, x.reshape(-1, T)), atol=2e-4)
+    np.testing.assert_allclose(be.host(RS), g.astype(np.float64).sum(0), atol=2e-4)
