@@ -106,11 +106,11 @@ PROTOTYPES = {
     "eegclip_tsconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
     "eegclip_cross_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_sconv_bwd_w_workspace_floats": [_I, _I],
-    "eegclip_sconv_bwd_w": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "eegclip_sconv_bwd_x_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _P],
+    "eegclip_sconv_bwd_w": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "eegclip_sconv_bwd_x_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_infonce_grad": [_P, _I, _I, _L, _I, _I, _P, _P, _P, _F, _P, _P, _P],

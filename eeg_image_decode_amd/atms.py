@@ -405,6 +405,31 @@ class _Engine:
         self.grad_fresh = True               # gflat holds zeros / stale values that must be cleared before accumulation
         lib()
 
+    def _spatial_weight_planes(self, pl):
+        """bf16 hi / lo planes of the spatial conv weights for the split-bf16 conv kernels (csrc/sconv.hip), refreshed by ONE eegclip_split_rows
+        launch in the forward plan: Ws as [40][ld] (k contiguous: forward) and Ws^T as [(c,h)][64] (both BN1-backward passes).  Returns the
+        forward kernel's (hi, lo, ld) arguments; (None, None, 0) = exact fp32 products."""
+        if pl.precision != _abi.PREC_BF16X3:
+            return (None, None, 0)
+        Kc = C_TS * N_CH
+        ld = (Kc + 128 + 63) // 64 * 64             # a forward chunk may read up to 127 k past the end of its K slice
+        if not hasattr(self, "sc_planes"):
+            self.sc_planes = torch.zeros(2, C_TS, ld, dtype=torch.bfloat16, device=self.device)
+            self.sc_planes_t = torch.zeros(2, Kc, 64, dtype=torch.bfloat16, device=self.device)
+        f, tr = self.sc_planes, self.sc_planes_t
+        src = _p(self.P[_TS + "4.weight"])
+        items = (_abi.SplitItem * 2)(
+            _abi.SplitItem(src=src, hi=f[0].data_ptr(), lo=f[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=ld, transpose=0),
+            _abi.SplitItem(src=src, hi=tr[0].data_ptr(), lo=tr[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=64, transpose=1))
+        pl._keep.append(items)
+        pl.call("eegclip_split_rows", items, 2)
+        # measured at B = 256 (single-stream HIP events, profiles/r2_conv_x3_vs_f32.json): the split-bf16 FORWARD kernel is not faster than the exact
+        # fp32 one (61 vs 59 us: both are bound by occupancy and the L1 tag rate of their strided 16-byte accesses, not by the MFMA pipe), so the
+        # forward keeps exact products unless EEGCLIP_SCONV_FWD_X3=1; the backward kernels (apply -4 us, dW -4 us) use the planes
+        if os.environ.get("EEGCLIP_SCONV_FWD_X3", "0") != "1":
+            return (None, None, 0)
+        return (f[0].data_ptr(), f[1].data_ptr(), ld)
+
     def _init_weight_planes(self):
         """bf16 hi / lo planes of every Linear weight, in both orientations (W for Y = X W^T, W^T for dX = dY W), refreshed by ONE
         eegclip_split_rows launch at the head of every forward plan: the split of a weight element is then done once per step instead of once
@@ -554,8 +579,9 @@ class _Engine:
                 _p(self.buffers[_TS + "2.num_batches_tracked"]))
         # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
         # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
+        fw = self._spatial_weight_planes(pl)
         pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
-                _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1)      # y2 lives in the arena cleared above
+                *fw, _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1)      # y2 lives in the arena cleared above
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
@@ -664,8 +690,13 @@ class _Engine:
         if "scw_ws" not in b:
             b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
-        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, side=True)
-        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]), B, N_CH)
+        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
+        # split-bf16 products for the K = 40 contraction of both BN1-backward passes (the plan's GEMM precision): Ws^T as bf16 planes
+        # [(c,h)][64 o], split by the forward plan of this step
+        wt = (None, None)
+        if pl.precision == _abi.PREC_BF16X3:
+            wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
+        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), B, N_CH)
         local1 = None
         if W > 1:
             local1 = torch.zeros_like(sums[3])
@@ -677,7 +708,7 @@ class _Engine:
             pl.callback(exchange1, "allreduce_bn1_bwd")
         if not train:
             pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
-        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), _p(b["y1"]), *bnp, _p(sums[3]) if train else _p(zsum),
+        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]) if train else _p(zsum),
                 (_p(local1) if local1 is not None else None) if train else _p(sums[3]), float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
         if "tsw_ws" not in b:
             b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)

@@ -304,4 +304,28 @@ __device__ __forceinline__ float fast_exp(float x) {
 }
 __device__ __forceinline__ float elu1_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.0f; }
 
+// ---- split-bf16 staging helpers (shared by csrc/gemm_x3.hip and the bf16x3 conv kernels) ----
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed bf16 pair (round to nearest even), low half = first
+__device__ __forceinline__ unsigned x3_pack2(float a, float b) {
+#if defined(EEG_EMU)
+    return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+#else
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const f32x2_t v{a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));          // v_cvt_pk_bf16_f32
+#endif
+}
+// 4 consecutive-k values -> hi / lo planes (4 bf16 = 8 bytes each)
+__device__ __forceinline__ void x3_split4(float v0, float v1, float v2, float v3, u32x2_t& hi, u32x2_t& lo) {
+    const unsigned h01 = x3_pack2(v0, v1), h23 = x3_pack2(v2, v3);
+    const float r0 = v0 - __uint_as_float(h01 << 16), r1 = v1 - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = v2 - __uint_as_float(h23 << 16), r3 = v3 - __uint_as_float(h23 & 0xffff0000u);
+    hi = u32x2_t{h01, h23};
+    lo = u32x2_t{x3_pack2(r0, r1), x3_pack2(r2, r3)};
+}
+
+
 }  // namespace eeg

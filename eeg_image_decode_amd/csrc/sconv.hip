@@ -8,7 +8,8 @@
 //   sconv_bwd_w        dWs[o,c,h] += sum_{b,w} dy2[b,o,w] * z1[b,c,h,w]                  reads y1 once
 //   sconv_bwd_x<false> BN1 backward sums of da = (Ws^T dy2) * ELU'(BN(y1))               reads y1 once
 //   sconv_bwd_x<true>  dy1 = BN1 backward(da)                                            reads y1 once, writes dy1 once
-// All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32).  HBM traffic: 5 passes over the 93 MB tensor per step instead of 14.
+// Contractions: v_mfma_f32_16x16x4_f32 (exact fp32), or -- sconv_bwd_x with pre-split weight planes -- split-bf16 products on
+// v_mfma_f32_16x16x32_bf16.  HBM traffic: 5 passes over the 93 MB tensor per step instead of 14.
 #include "eeg_common.h"
 
 #include <stdlib.h>
@@ -159,6 +160,151 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     }
 }
 
+// forward with split-bf16 products (weights pre-split into bf16 planes [40][ldp], k contiguous, by eegclip_split_rows): same decomposition
+// (workgroup = sample x K slice, 128-k chunks, wave v owns k = 32v .. 32v+31 of a chunk = ONE 16x16x32 k-step), but 27 MFMAs of 16 cycles per
+// chunk and wave instead of 72 exact-fp32 ones of 32 cycles.  The activation operand needs 8 consecutive k per lane at a fixed position w while
+// y1 is [k][w]: a thread loads a 4 k x 4 w block (four 16-byte loads), evaluates ELU(BN(.)), splits, and writes 4 k of one w as ONE 8-byte LDS
+// store per plane into z^T [48 w][128 k] (row stride 272 bytes: the 16 rows of a fragment read are 4 banks apart).  Weight fragments come
+// straight from global memory (16 bytes = 8 k of one output channel per lane, plane and tile).
+constexpr int SFX_RS = 272;
+constexpr int SFX_PLANE = SC_OP * SFX_RS;
+__global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const unsigned short* __restrict__ wp_hi,
+                                                            const unsigned short* __restrict__ wp_lo, long long ldp, const float* __restrict__ bs,
+                                                            float* __restrict__ y2, int B, int H, int kper) {
+    EEG_LDS_BASE(float, lds);
+    unsigned char* zp = reinterpret_cast<unsigned char*>(lds);     // planes hi | lo of z1^T[w][k0 + kk]
+    float* aff = lds + 2 * SFX_PLANE / 4;                           // [2][40]
+    float* red = lds;                                               // 2 x [48][52] reduction scratch, aliases the planes after the last chunk
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int K = SC_C * H;
+    const int kbeg = blockIdx.y * kper, kend = kbeg + kper < K ? kbeg + kper : K;
+    if (t < SC_C) {
+        const float sc = bn.gamma[t] * bn.rstd[t];
+        aff[t] = sc;
+        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
+    }
+    for (int i = t; i < 2 * SFX_PLANE / 16; i += 256) reinterpret_cast<f32x4*>(zp)[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // rows w >= 36 stay zero
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* yb = y1 + (long long)b * K * SC_W;
+    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wh[3], wl[3];
+    f32x4 vy[2][4];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int o = 16 * i + fr < SC_C ? 16 * i + fr : SC_C - 1;       // (rows 40..47 of the product are never stored)
+            const long long off = (long long)o * ldp + k0 + 32 * wv + 8 * g;  // k beyond kend: multiplied by the zeros staged on the activation side
+            wh[i] = *reinterpret_cast<const bf16x8*>(wp_hi + off);
+            wl[i] = *reinterpret_cast<const bf16x8*>(wp_lo + off);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int u = t + 256 * ps, kq = u / 9, wq = u % 9;              // 32 k-quads x 9 w-quads = 288 blocks of 4 k x 4 w
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 4 * kq + r;
+                vy[ps][r] = (u < 288 && k < kend) ? *reinterpret_cast<const f32x4*>(yb + (long long)k * SC_W + 4 * wq) : zero4v;
+            }
+        }
+    };
+    auto store_chunk = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int u = t + 256 * ps, kq = u / 9, wq = u % 9;
+            if (u >= 288) continue;
+            f32x4 z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 4 * kq + r;
+                z[r] = zero4v;
+                if (k < kend) {
+                    const int c = k / H;
+                    const float sc = aff[c], sh = aff[SC_C + c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[r][q] = elu1_fast(vy[ps][r][q] * sc + sh);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2_t hi, lo;
+                x3_split4(z[0][q], z[1][q], z[2][q], z[3][q], hi, lo);
+                unsigned char* dst = zp + (4 * wq + q) * SFX_RS + 8 * kq;
+                *reinterpret_cast<u32x2_t*>(dst) = hi;
+                *reinterpret_cast<u32x2_t*>(dst + SFX_PLANE) = lo;
+            }
+        }
+    };
+    if (kbeg < kend) load_chunk(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += SCF_KC) {
+        __syncthreads();
+        store_chunk(k0);
+        bf16x8 ah[3], al[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ah[i] = wh[i]; al[i] = wl[i]; }
+        __syncthreads();
+        if (k0 + SCF_KC < kend) load_chunk(k0 + SCF_KC);
+        bf16x8 bh[3], bl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned char* src = zp + (16 * j + fr) * SFX_RS + 2 * (32 * wv + 8 * g);
+            bh[j] = *reinterpret_cast<const bf16x8*>(src);
+            bl[j] = *reinterpret_cast<const bf16x8*>(src + SFX_PLANE);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                     // D[o = 16i + 4g + r][w = 16j + fr]
+                acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
+                acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);
+                acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
+            }
+    }
+    // cross-wave sum of the four k-partial accumulator sets (as in sconv_fwd_kernel)
+    constexpr int RLD = 52;
+    auto put = [&](float* reg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr] = acc[i][j][r];
+    };
+    auto add = [&](const float* reg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr];
+    };
+    __syncthreads();
+    if (wv >= 2) put(red + (wv - 2) * SC_OP * RLD);
+    __syncthreads();
+    if (wv < 2) add(red + wv * SC_OP * RLD);
+    __syncthreads();
+    if (wv == 1) put(red);
+    __syncthreads();
+    if (wv == 0) {
+        add(red);
+        float* yo = y2 + (long long)b * SC_C * SC_W;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * i + 4 * g + r, w = 16 * j + fr;
+                    if (o < SC_C && w < SC_W) atomicAdd(yo + o * SC_W + w, acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f));
+                }
+    }
+}
+
 // BatchNorm2d #2 batch statistics of y2 (B,40,36): workgroup = (channel, slice of samples); fp64 atomics, 2 per workgroup
 __global__ __launch_bounds__(256) void sconv_stats2_kernel(const float* __restrict__ y2, double* __restrict__ sums2, int B) {
     EEG_LDS_BASE(double, sh);                 // [2][4] per-wave partial sums
@@ -274,6 +420,125 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restric
         }
 }
 
+// weight gradient with split-bf16 products: both operands are contiguous along the contraction index (the 36 positions w of one sample), so the
+// staging is a plain split -- 4 consecutive w -> one 8-byte LDS store per plane -- into planes [rows][64 w] (w >= 36 zero; row stride 144
+// bytes: conflict-free 16-byte fragment reads).  Per sample and wave 3 x NT x 2 x 3 MFMAs of 16 cycles (K = 36 padded to 64) instead of
+// 3 x NT x 9 exact-fp32 ones of 32 cycles.
+constexpr int SWX_RS = 144;
+template <int NS>
+__global__ __launch_bounds__(256) void sconv_bwd_w_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
+                                                              float* __restrict__ partials, int B, int H, int bgroups) {
+    constexpr int NT = NS / 64;
+    constexpr int NV = (NS * SC_W / 4 + 255) / 256;
+    constexpr int ZPL = NS * SWX_RS, DPL = SC_OP * SWX_RS;       // bytes per plane
+    EEG_LDS_BASE(float, lds);
+    unsigned char* zp = reinterpret_cast<unsigned char*>(lds);   // z1 planes hi | lo   [NS n][64 w]
+    unsigned char* dp = zp + 2 * ZPL;                            // dy2 planes hi | lo  [48 o][64 w]
+    float* aff = reinterpret_cast<float*>(dp + 2 * DPL);         // [2][40]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int K = SC_C * H;
+    const int n0 = blockIdx.x * NS, bg = blockIdx.y;
+    if (t < SC_C) {
+        const float sc = bn.gamma[t] * bn.rstd[t];
+        aff[t] = sc;
+        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
+    }
+    for (int i = t; i < (2 * ZPL + 2 * DPL) / 16; i += 256) reinterpret_cast<f32x4*>(zp)[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // w >= 36, o >= 40: zero for good
+    f32x4 acc[3][NT];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ncols = K - n0 < NS ? K - n0 : NS;
+    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
+    f32x4 vz[NV], vd[2];
+    auto load_sample = [&](int b) {
+        const float* src = y1 + ((long long)b * K + n0) * SC_W;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 4 * (t + 256 * j);
+            vz[j] = (e < ncols * SC_W) ? *reinterpret_cast<const f32x4*>(src + e) : zero4v;
+        }
+        const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 4 * (t + 256 * j);
+            vd[j] = e < SC_C * SC_W ? *reinterpret_cast<const f32x4*>(dsrc + e) : zero4v;
+        }
+    };
+    auto store_sample = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int e = 4 * (t + 256 * j), n = e / SC_W, w = e % SC_W;
+            if (e >= NS * SC_W) continue;
+            f32x4 z = zero4v;
+            if (n < ncols) {
+                const int c = (n0 + n) / H;
+                const float sc = aff[c], sh = aff[SC_C + c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] = elu1_fast(vz[j][q] * sc + sh);
+            }
+            u32x2_t hi, lo;
+            x3_split4(z[0], z[1], z[2], z[3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(zp + n * SWX_RS + 2 * w) = hi;
+            *reinterpret_cast<u32x2_t*>(zp + ZPL + n * SWX_RS + 2 * w) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 4 * (t + 256 * j), o = e / SC_W, w = e % SC_W;
+            if (e >= SC_C * SC_W) continue;
+            u32x2_t hi, lo;
+            x3_split4(vd[j][0], vd[j][1], vd[j][2], vd[j][3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(dp + o * SWX_RS + 2 * w) = hi;
+            *reinterpret_cast<u32x2_t*>(dp + DPL + o * SWX_RS + 2 * w) = lo;
+        }
+    };
+    if (bg < B) load_sample(bg);
+    for (int b = bg; b < B; b += bgroups) {
+        __syncthreads();
+        store_sample();
+        __syncthreads();
+        if (b + bgroups < B) load_sample(b + bgroups);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ah[3], al[3], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned char* src = dp + (16 * i + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
+                ah[i] = *reinterpret_cast<const bf16x8*>(src);
+                al[i] = *reinterpret_cast<const bf16x8*>(src + DPL);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned char* src = zp + (16 * NT * wv + 16 * j + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
+                bh[j] = *reinterpret_cast<const bf16x8*>(src);
+                bl[j] = *reinterpret_cast<const bf16x8*>(src + ZPL);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {                // D[o = 16i + 4g + r][n = n0 + 16 NT wv + 16j + fr]
+                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
+                }
+        }
+    }
+    float* out = partials + (long long)bg * SC_C * K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 16 * NT * wv + 16 * j + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * i + 4 * g + r;
+                if (o < SC_C && n < K) out[(long long)o * K + n] = acc[i][j][r];
+            }
+        }
+}
+
 __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -290,20 +555,46 @@ __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, in
 // one row: y1 is read and dy1 written as one 16-byte access per lane and tile instead of four 4-byte ones.
 //   APPLY = false: accumulate sum(da), sum(da * xhat) per channel (LDS, then 80 fp64 atomics per workgroup)
 //   APPLY = true : dy1 = gamma * rstd * (da - S1/n - xhat * S2/n)
-template <bool APPLY>
+// X3: the K = 40 contraction as split-bf16 products on v_mfma_f32_16x16x32_bf16 (same arithmetic as csrc/gemm_x3.hip: hi*lo + lo*hi + hi*hi, fp32
+// accumulate) instead of 10 x 3 exact-fp32 MFMAs of 32 cycles each per task: 2 x 3 x 3 MFMAs of 16 cycles.  dy2^T is split once per workgroup
+// into LDS planes [48 w][64 o] (row stride 144 bytes: the 16 rows of a fragment read land 4 banks apart), its fragments do not depend on the
+// task and live in registers; the weights come PRE-SPLIT from eegclip_split_rows(transpose) as planes [(c,h)][64 o]: one 16-byte load per
+// k-step and plane instead of 10 strided 4-byte gathers + a split in registers.
+constexpr int SCX_RS = 144;                  // bytes per row of a dy2^T plane
+constexpr int SCX_GY = 5;                    // workgroups per sample: 20 waves x 2 channels x 4 row blocks
+template <bool APPLY, bool X3>
 __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restrict__ dy2, const float* __restrict__ Ws,
+                                                           const unsigned short* __restrict__ wt_hi, const unsigned short* __restrict__ wt_lo,
                                                            const float* __restrict__ y1, const bn_affine bn, double* __restrict__ sums,
                                                            const double* __restrict__ sums_param, double count, float* __restrict__ dy1,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H) {
     EEG_LDS_BASE(float, lds);
-    float* dl = lds;                          // [40][48]  dy2[o][w]  (cols >= 36 zero)
-    float* sl = dl + SC_C * SC_OP;            // [80] per-workgroup channel sums
+    float* dl = lds;                          // !X3: [40][48] dy2[o][w] (cols >= 36 zero)   X3: two bf16 planes [48 w][144 B] of dy2^T
+    float* sl = dl + (X3 ? 2 * SC_OP * SCX_RS / 4 : SC_C * SC_OP);            // [80] per-workgroup channel sums
+    unsigned char* dplane = reinterpret_cast<unsigned char*>(lds);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
-    for (int i = t; i < SC_C * SC_OP; i += 256) {
-        const int o = i / SC_OP, w = i % SC_OP;
-        dl[i] = w < SC_W ? dy2[((long long)b * SC_C + o) * SC_W + w] : 0.f;
+    if (X3) {
+        for (int i = t; i < SC_OP * 64; i += 256) {               // o >= 40 and w >= 36: zeros
+            const int w = i >> 6, o = i & 63;
+            if (o >= SC_C || w >= SC_W) {
+                *reinterpret_cast<unsigned short*>(dplane + w * SCX_RS + 2 * o) = 0;
+                *reinterpret_cast<unsigned short*>(dplane + SC_OP * SCX_RS + w * SCX_RS + 2 * o) = 0;
+            }
+        }
+        for (int i = t; i < SC_C * SC_W; i += 256) {              // coalesced read of the sample's dy2, transposed 2-byte stores
+            const int o = i / SC_W, w = i % SC_W;
+            const float v = dy2[(long long)b * SC_C * SC_W + i];
+            const unsigned short h = f32_to_bf16_bits(v);
+            *reinterpret_cast<unsigned short*>(dplane + w * SCX_RS + 2 * o) = h;
+            *reinterpret_cast<unsigned short*>(dplane + SC_OP * SCX_RS + w * SCX_RS + 2 * o) = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+        }
+    } else {
+        for (int i = t; i < SC_C * SC_OP; i += 256) {
+            const int o = i / SC_OP, w = i % SC_OP;
+            dl[i] = w < SC_W ? dy2[((long long)b * SC_C + o) * SC_W + w] : 0.f;
+        }
     }
     if (t < 2 * SC_C) sl[t] = 0.f;
     if (APPLY && b == 0 && blockIdx.y == 0 && t < SC_C) {        // parameter gradients from this rank's own sums (see norm.hip: bn_elu_bwd_apply)
@@ -313,14 +604,37 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
     __syncthreads();
     const int MT = (H + 15) / 16;
     const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    // register double-buffer: the 10 weight and 3 x 16-byte y1 loads of the wave's next task are issued before the MFMAs / epilogue of this one
-    float nav[10];
+    // X3: A fragments (dy2^T rows w = 16j + fr, k = o = 32s + 8g ..): the same for every task of the wave
+    bf16x8 ah[X3 ? 3 : 1][2], al[X3 ? 3 : 1][2];
+    if (X3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                ah[j][s2] = *reinterpret_cast<const bf16x8*>(dplane + (16 * j + fr) * SCX_RS + 2 * (32 * s2 + 8 * g));
+                al[j][s2] = *reinterpret_cast<const bf16x8*>(dplane + SC_OP * SCX_RS + (16 * j + fr) * SCX_RS + 2 * (32 * s2 + 8 * g));
+            }
+    }
+    // register double-buffer: the weight and 3 x 16-byte y1 loads of the wave's next task are issued before the MFMAs / epilogue of this one
+    float nav[X3 ? 1 : 10];
+    bf16x8 nbh[X3 ? 2 : 1], nbl[X3 ? 2 : 1];
     f32x4 nyv[3];
+    const bf16x8 zero8{0, 0, 0, 0, 0, 0, 0, 0};
     auto load_task = [&](int p) {
         const int c = p / MT, mt = p % MT;
         const int h = 16 * mt + fr;                           // this lane's row: B-operand column and accumulator column
+        if (X3) {
+            const long long row = ((long long)c * H + (h < H ? h : H - 1)) * 64;
 #pragma unroll
-        for (int kk = 0; kk < 10; ++kk) nav[kk] = h < H ? Ws[((long long)(4 * kk + g) * SC_C + c) * H + h] : 0.f;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                nbh[s2] = *reinterpret_cast<const bf16x8*>(wt_hi + row + 32 * s2 + 8 * g);
+                nbl[s2] = *reinterpret_cast<const bf16x8*>(wt_lo + row + 32 * s2 + 8 * g);
+                if (h >= H) { nbh[s2] = zero8; nbl[s2] = zero8; }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 10; ++kk) nav[kk] = h < H ? Ws[((long long)(4 * kk + g) * SC_C + c) * H + h] : 0.f;
+        }
         const float* yr = y1 + (((long long)b * SC_C + c) * H + h) * SC_W;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -328,30 +642,53 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
             nyv[j] = (h < H && w < SC_W) ? *reinterpret_cast<const f32x4*>(yr + w) : zero4v;
         }
     };
-    const int pstep = 4 * gridDim.y, p0 = 4 * blockIdx.y + wv;      // gridDim.y workgroups share a sample: more waves per CU to overlap
-    if (p0 < SC_C * MT) load_task(p0);                                 // one wave's MFMA phase with another's VALU epilogue
-    for (int p = p0; p < SC_C * MT; p += pstep) {
+    // gridDim.y workgroups share a sample (more waves per CU: one wave's MFMA phase overlaps another's VALU epilogue); a wave owns WHOLE channels
+    // -- all row blocks mt of channel c = wid + wps * i -- so that the statistics pass reduces its per-lane sums across the wave once per
+    // channel instead of once per task (12 ds_bpermute steps per task were ~1000 of its ~2500 cycles)
+    const int wps = 4 * gridDim.y, wid = 4 * blockIdx.y + wv;
+    const int ntask = wid < SC_C ? ((SC_C - 1 - wid) / wps + 1) * MT : 0;
+    auto task_of = [&](int q) { return (wid + wps * (q / MT)) * MT + q % MT; };
+    if (ntask > 0) load_task(task_of(0));
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < ntask; ++q) {
+        const int p = task_of(q);
         const int c = p / MT, mt = p % MT;
-        float av[10];
+        float av[X3 ? 1 : 10];
+        bf16x8 bh[X3 ? 2 : 1], bl[X3 ? 2 : 1];
         f32x4 yv[3];
+        if (X3) {
 #pragma unroll
-        for (int kk = 0; kk < 10; ++kk) av[kk] = nav[kk];
+            for (int s2 = 0; s2 < 2; ++s2) { bh[s2] = nbh[s2]; bl[s2] = nbl[s2]; }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 10; ++kk) av[kk] = nav[kk];
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) yv[j] = nyv[j];
-        if (p + pstep < SC_C * MT) load_task(p + pstep);
+        if (q + 1 < ntask) load_task(task_of(q + 1));
         f32x4 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = zero4v;
+        if (X3) {
 #pragma unroll
-        for (int kk = 0; kk < 10; ++kk) {
-            const float* dp = dl + (4 * kk + g) * SC_OP + fr;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = mfma_f32_16x16x4(dp[16 * j], av[kk], acc[j]);      // D[w = 16j + 4g + r][h = 16mt + fr]
+                for (int j = 0; j < 3; ++j) {                 // D[w = 16j + 4g + r][h = 16mt + fr]
+                    acc[j] = mfma_bf16_16x16x32(ah[j][s2], bl[s2], acc[j]);
+                    acc[j] = mfma_bf16_16x16x32(al[j][s2], bh[s2], acc[j]);
+                    acc[j] = mfma_bf16_16x16x32(ah[j][s2], bh[s2], acc[j]);
+                }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 10; ++kk) {
+                const float* dp = dl + (4 * kk + g) * SC_OP + fr;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = mfma_f32_16x16x4(dp[16 * j], av[kk], acc[j]);      // D[w = 16j + 4g + r][h = 16mt + fr]
+            }
         }
         const float mean = bn.mean[c], rstd = bn.rstd[c], gam = bn.gamma[c], bet = bn.beta[c];
         float m1 = 0.f, m2 = 0.f;
         if (APPLY) { m1 = (float)(sums[c] / count); m2 = (float)(sums[SC_C + c] / count); }
-        float s1 = 0.f, s2 = 0.f;
         const int h = 16 * mt + fr;
         float* dr = APPLY ? dy1 + (((long long)b * SC_C + c) * H + h) * SC_W : nullptr;
 #pragma unroll
@@ -371,10 +708,12 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
                 if (APPLY) *reinterpret_cast<f32x4*>(dr + w) = o4;
             }
         }
-        if (!APPLY) {
+        if (!APPLY && mt == MT - 1) {                          // channel complete
             s1 = wave_sum(s1);
             s2 = wave_sum(s2);
             if (lane == 0) { atomicAdd(sl + c, s1); atomicAdd(sl + SC_C + c, s2); }
+            s1 = 0.f;
+            s2 = 0.f;
         }
     }
     if (!APPLY) {
@@ -391,17 +730,30 @@ static bool sc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 static int sc_check(int B, int H) { return (B < 1 || H < 1 || H > 64) ? EEGCLIP_EINVAL : 0; }
 
 extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                                 const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, void* stream) {
+                                 const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
+                                 int y2_is_zero, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
+    if ((Ws_hi == nullptr) != (Ws_lo == nullptr)) return EEGCLIP_EINVAL;
     if (!sc_aligned16(y1) || !sc_aligned16(Ws)) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
-    const int K = SC_C * H, kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;       // slices start on 16-byte boundaries of both operands
-    const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
+    const int K = SC_C * H;
     // the K slices add their partial tiles into y2 with atomics: it must start at zero (callers that clear it together with their other
     // accumulators pass y2_is_zero != 0 and save the extra memset launch)
     if (!y2_is_zero) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
-    EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
+    if (Ws_hi) {
+        // a chunk may run up to 127 k past the end of its slice (zeros on the activation side): the planes must be readable there
+        if (ld_planes < K + SCF_KC || (ld_planes & 7) != 0) return EEGCLIP_EINVAL;
+        if (!sc_aligned16(Ws_hi) || !sc_aligned16(Ws_lo)) return EEGCLIP_EALIGN;
+        const int kper = ((K + SCF_KS - 1) / SCF_KS + 7) & ~7;                 // slices start on 16-byte boundaries of the bf16 planes
+        const size_t lds = 2 * SFX_PLANE + 2 * SC_C * sizeof(float);
+        EEG_LAUNCH(sconv_fwd_x3_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, (const unsigned short*)Ws_hi, (const unsigned short*)Ws_lo,
+                   ld_planes, bs, y2, B, H, kper);
+    } else {
+        const int kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;                 // slices start on 16-byte boundaries of both operands
+        const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
+        EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
+    }
     if (sums2) EEG_LAUNCH(sconv_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, y2, sums2, B);
     return (int)hipGetLastError();
 }
@@ -421,42 +773,67 @@ static int scw_groups(int B, int H) {
 extern "C" long long eegclip_sconv_bwd_w_workspace_floats(int B, int H) { return (long long)scw_groups(B, H) * SC_C * SC_C * H; }
 
 extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
-                                   float* dWs, float* workspace, int B, int H, void* stream) {
+                                   float* dWs, float* workspace, int B, int H, int precision, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !dy2 || !dWs || !workspace) return EEGCLIP_EINVAL;
-    if (!sc_aligned16(y1)) return EEGCLIP_EALIGN;
+    if (precision != EEGCLIP_PREC_F32 && precision != EEGCLIP_PREC_BF16X3) return EEGCLIP_EINVAL;
+    if (!sc_aligned16(y1) || (precision == EEGCLIP_PREC_BF16X3 && !sc_aligned16(dy2))) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H, groups = scw_groups(B, H), ns = scw_ns();
-    const size_t lds = (ns * SCW_L + SC_OP * SCW_L + 2 * SC_C) * sizeof(float);
     const dim3 grid((K + ns - 1) / ns, groups);
-    if (ns == 256) EEG_LAUNCH(sconv_bwd_w_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
-    else           EEG_LAUNCH(sconv_bwd_w_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+    if (precision == EEGCLIP_PREC_BF16X3) {
+        const size_t lds = (size_t)2 * (ns + SC_OP) * SWX_RS + 2 * SC_C * sizeof(float);
+        if (ns == 256) EEG_LAUNCH(sconv_bwd_w_x3_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+        else           EEG_LAUNCH(sconv_bwd_w_x3_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+    } else {
+        const size_t lds = (ns * SCW_L + SC_OP * SCW_L + 2 * SC_C) * sizeof(float);
+        if (ns == 256) EEG_LAUNCH(sconv_bwd_w_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+        else           EEG_LAUNCH(sconv_bwd_w_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+    }
     const long long n = (long long)SC_C * K;
     EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, groups, n, dWs);
     return (int)hipGetLastError();
 }
 
-extern "C" int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd,
-                                         const float* gamma, const float* beta, double* sums, int B, int H, void* stream) {
+static bool scx_planes_ok(const void* hi, const void* lo) { return hi && lo && sc_aligned16(hi) && sc_aligned16(lo); }
+
+extern "C" int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
+                                         const float* rstd, const float* gamma, const float* beta, double* sums, int B, int H, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums) return EEGCLIP_EINVAL;
-    if (!sc_aligned16(y1)) return EEGCLIP_EALIGN;
+    if ((WsT_hi == nullptr) != (WsT_lo == nullptr)) return EEGCLIP_EINVAL;
+    if (!sc_aligned16(y1) || (WsT_hi && !scx_planes_ok(WsT_hi, WsT_lo))) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
-    const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
-    EEG_LAUNCH((sconv_bwd_x_kernel<false>), dim3(B, 4), dim3(256), lds, stream, dy2, Ws, y1, bn, sums, (const double*)nullptr, 1.0, (float*)nullptr,
-               (float*)nullptr, (float*)nullptr, B, H);
+    const unsigned short *wh = (const unsigned short*)WsT_hi, *wl = (const unsigned short*)WsT_lo;
+    if (wh) {
+        const size_t lds = 2 * SC_OP * SCX_RS + 2 * SC_C * sizeof(float);
+        EEG_LAUNCH((sconv_bwd_x_kernel<false, true>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, sums, (const double*)nullptr, 1.0,
+                   (float*)nullptr, (float*)nullptr, (float*)nullptr, B, H);
+    } else {
+        const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
+        EEG_LAUNCH((sconv_bwd_x_kernel<false, false>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, sums, (const double*)nullptr, 1.0,
+                   (float*)nullptr, (float*)nullptr, (float*)nullptr, B, H);
+    }
     return (int)hipGetLastError();
 }
 
-extern "C" int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd,
-                                         const float* gamma, const float* beta, const double* sums, const double* sums_local, double count,
-                                         float* dy1, float* dgamma, float* dbeta, int B, int H, void* stream) {
+extern "C" int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
+                                         const float* rstd, const float* gamma, const float* beta, const double* sums, const double* sums_local,
+                                         double count, float* dy1, float* dgamma, float* dbeta, int B, int H, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums || !dy1 || !dgamma || !dbeta || count < 1.0) return EEGCLIP_EINVAL;
-    if (!sc_aligned16(y1) || !sc_aligned16(dy1)) return EEGCLIP_EALIGN;
+    if ((WsT_hi == nullptr) != (WsT_lo == nullptr)) return EEGCLIP_EINVAL;
+    if (!sc_aligned16(y1) || !sc_aligned16(dy1) || (WsT_hi && !scx_planes_ok(WsT_hi, WsT_lo))) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
-    const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
-    EEG_LAUNCH((sconv_bwd_x_kernel<true>), dim3(B, 4), dim3(256), lds, stream, dy2, Ws, y1, bn, const_cast<double*>(sums),
-               sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+    const unsigned short *wh = (const unsigned short*)WsT_hi, *wl = (const unsigned short*)WsT_lo;
+    if (wh) {
+        const size_t lds = 2 * SC_OP * SCX_RS + 2 * SC_C * sizeof(float);
+        EEG_LAUNCH((sconv_bwd_x_kernel<true, true>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, const_cast<double*>(sums),
+                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+    } else {
+        const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
+        EEG_LAUNCH((sconv_bwd_x_kernel<true, false>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, const_cast<double*>(sums),
+                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+    }
     return (int)hipGetLastError();
 }

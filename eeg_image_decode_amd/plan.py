@@ -45,6 +45,7 @@ class Plan:
         self._seed_slots = []  # (op index, arg index)
         self.L = lib()
         self.timed = {}        # op index -> list of (start, end) torch.cuda.Event pairs (HIP events on the launch stream)
+        self.time_every, self._time_tick = 1, 0
         self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
         self.use_side_stream = True
         self.skip = ()         # op indices left out of the next run()s (e.g. the value-embedding GEMMs of subjects absent from the batch)
@@ -227,9 +228,11 @@ class Plan:
             torch.cuda.current_stream().wait_event(e)
             c["dirty"].value = 0
 
-    def time_ops(self, indices):
-        """record a HIP event pair around the given ops on every run (bench.py roofline / per-kernel breakdown)"""
+    def time_ops(self, indices, every=1):
+        """record a HIP event pair around the given ops on every `every`-th run (bench.py roofline / per-kernel breakdown); the other runs go
+        through the normal (un-instrumented) path"""
         self.timed = {i: [] for i in indices}
+        self.time_every, self._time_tick = max(1, int(every)), 0
 
     def timings_ms(self):
         import torch
@@ -239,13 +242,17 @@ class Plan:
     def run(self, stream, seed=0):
         for d in self._seed_descs:
             d.seed = seed
-        if self.use_c_executor and not self.timed:
+        timed = self.timed
+        if timed and self.time_every > 1:
+            self._time_tick += 1
+            if self._time_tick % self.time_every:
+                timed = None
+        if self.use_c_executor and not timed:
             if self._c is None:
                 self._compile()
             return self._run_c(stream, seed)
         for i, j in self._seed_slots:
             self.ops[i][1][j] = seed
-        timed = self.timed
         import torch
         side = None
         if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):

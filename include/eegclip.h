@@ -260,16 +260,23 @@ int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx, long long
  *   bwd_x_apply dy1 = gamma*rstd*(da - sums/count - xhat*sums'/count); dgamma/dbeta += sums_local (NULL = sums) -- SyncBN: all-reduce
  *               sums between the two calls and pass the global count.  sconv_fwd adds K-slice partial tiles into y2 with atomics:
  * y2_is_zero = 0 lets it clear y2 itself, != 0 says the caller already did. */
+/* Ws_hi / Ws_lo (both or neither) + ld_planes: bf16 planes of Ws as eegclip_split_rows{src = Ws, rows = 40, cols = 40 H, ld_src = 40 H,
+ * ld_out = ld_planes} writes them, ld_planes >= 40 H + 128 and a multiple of 8, 16-byte aligned: split-bf16 products instead of exact fp32. */
 int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                      const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, void* stream);
+                      const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
+                      int y2_is_zero, void* stream);
 long long eegclip_sconv_bwd_w_workspace_floats(int B, int H);
+/* precision: EEGCLIP_PREC_F32 (exact fp32 products) | EEGCLIP_PREC_BF16X3 (split-bf16 products; dy2 16-byte aligned) */
 int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
-                        float* dWs, float* workspace, int B, int H, void* stream);
-int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, double* sums, int B, int H, void* stream);
-int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const float* y1, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, const double* sums, const double* sums_local, double count, float* dy1, float* dgamma,
-                              float* dbeta, int B, int H, void* stream);
+                        float* dWs, float* workspace, int B, int H, int precision, void* stream);
+/* WsT_hi / WsT_lo (both or neither): bf16 planes of Ws^T, [(c,h)][64 o] -- eegclip_split_rows{src = Ws, rows = 40, cols = 40 H, ld_src = 40 H,
+ * ld_out = 64, transpose = 1}, 16-byte aligned.  Given: the K = 40 contraction runs as split-bf16 products (hi*lo + lo*hi + hi*hi on the bf16
+ * matrix cores, fp32 accumulate: ~2^-16 relative per term, as EEGCLIP_PREC_BF16X3); NULL: exact fp32 products. */
+int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, double* sums, int B, int H, void* stream);
+int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, const double* sums, const double* sums_local,
+                              double count, float* dy1, float* dgamma, float* dbeta, int B, int H, void* stream);
 
 /* ---- InfoNCE around the logits GEMM.  models/loss.py:122-140  (scale = pointer to the RAW logit_scale on the device)
  * lse_rows/cols: log-sum-exp of scale*X along rows / columns.  infonce_grad: X (rows x cols block of raw logits, positives at

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from backends import be, ok  # noqa: F401
+from eeg_image_decode_amd import _abi
 from philox_np import keep_mask
 
 SEED = 0x5EEDC0FFEE
@@ -492,22 +493,43 @@ def test_fused_spatial_stage(be, B, H):
     var = y1.astype(np.float64).var((0, 2, 3))
     Y1, G1, B1, WS, BS, DY2 = be.dev(y1), be.dev(g1), be.dev(b1), be.dev(Ws), be.dev(bs), be.dev(dy2)
     MU, RS = be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
-    Y2, S2 = be.zeros((B, C, Wd)), be.zeros(80, np.float64)
-    ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(BS), be.ptr(Y2), be.ptr(S2), B, H, 0, be.stream))
-    np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
-    np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3)
-    np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
-    DWS = be.dev(np.ones((C, C, H), np.float32))
-    WSP = be.zeros(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)))
-    ok(be.lib.eegclip_sconv_bwd_w(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(DWS), be.ptr(WSP), B, H, be.stream))
-    np.testing.assert_allclose(be.host(DWS) - 1.0, wt.grad.numpy(), atol=1e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
-    SUMS, DY1, DG, DB = be.zeros(80, np.float64), be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
-    ok(be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), B, H, be.stream))
-    ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), None,
-                                        float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
-    np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
-    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
-    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
+    # forward: exact fp32 products, then split-bf16 products with the weights pre-split by eegclip_split_rows
+    Kf = C * H
+    ldp = (Kf + 128 + 63) // 64 * 64
+    FH, FL = be.dev(np.full((C, ldp), 0x7FC0, np.uint16)), be.dev(np.full((C, ldp), 0x7FC0, np.uint16))
+    itf = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(WS), hi=be.ptr(FH), lo=be.ptr(FL), rows=C, cols=Kf, ld_src=Kf, ld_out=ldp, transpose=0))
+    ok(be.lib.eegclip_split_rows(itf, 1, be.stream))
+    for planes in ((None, None, 0), (be.ptr(FH), be.ptr(FL), ldp)):
+        Y2, S2 = be.zeros((B, C, Wd)), be.zeros(80, np.float64)
+        ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), *planes, be.ptr(BS), be.ptr(Y2), be.ptr(S2),
+                                    B, H, 0, be.stream))
+        np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
+        np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3, rtol=2e-5 if planes[0] else 0)   # (sums of ~1e3 terms)
+        np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
+    assert be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(FH), be.ptr(FL), Kf, be.ptr(BS),
+                                    be.ptr(Y2), be.ptr(S2), B, H, 0, be.stream) < 0           # planes too narrow for the chunk overrun
+    for precision in (_abi.PREC_F32, _abi.PREC_BF16X3):
+        DWS = be.dev(np.ones((C, C, H), np.float32))
+        WSP = be.zeros(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)))
+        ok(be.lib.eegclip_sconv_bwd_w(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(DWS), be.ptr(WSP), B, H, precision,
+                                      be.stream))
+        np.testing.assert_allclose(be.host(DWS) - 1.0, wt.grad.numpy(), atol=1e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+    # input gradient: exact fp32 products (no planes), then split-bf16 products with Ws^T pre-split by eegclip_split_rows
+    K = C * H
+    WH, WL = be.dev(np.full((K, 64), 0x7FC0, np.uint16)), be.dev(np.full((K, 64), 0x7FC0, np.uint16))
+    it = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(WS), hi=be.ptr(WH), lo=be.ptr(WL), rows=C, cols=K, ld_src=K, ld_out=64, transpose=1))
+    ok(be.lib.eegclip_split_rows(it, 1, be.stream))
+    for planes in ((None, None), (be.ptr(WH), be.ptr(WL))):
+        SUMS, DY1, DG, DB = be.zeros(80, np.float64), be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
+        ok(be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), *planes, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
+                                            B, H, be.stream))
+        ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), *planes, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
+                                            None, float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
+        np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
+        np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
+        np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
+    assert be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(WH), None, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
+                                            be.ptr(SUMS), B, H, be.stream) < 0
 
 
 def _bf16_round(a):

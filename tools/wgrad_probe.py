@@ -38,7 +38,7 @@ for name, M, N, K, kind, sks in [("w_ffn1", 256, 250, 16384, "tn", (8, 16, 32, 6
             ta = t_of(d)
             need = L.eegclip_gemm_workspace_bytes(ctypes.byref(d))
             tw = float("nan")
-            if need > 0:
+            if need > 0 and os.environ.get("PROBE_WS"):
                 ws = torch.zeros(need // 4, device="cuda")
                 d.workspace, d.workspace_bytes = ws.data_ptr(), need
                 tw = t_of(d)
