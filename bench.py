@@ -59,8 +59,8 @@ def algorithmic_cost(name, desc, B):
 _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegclip_attention_fwd": "eeg::attention_fwd_kernel<true>",
               "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel<7>",
               "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
-              "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false>",
-              "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true>"}
+              "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_x3_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false, true>",
+              "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>"}
 
 
 PMC_SUMMARY = os.path.join("profiles", "r2_pmc_hbm_traffic.json")

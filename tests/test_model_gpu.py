@@ -265,7 +265,10 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
     sd = m.state_dict()
     for k in sd:
         if "running_var" in k:
-            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=4e-4, err_msg=k)      # 6 AdamW steps at B = 16 (round-off-sized gradients flip +-lr)
+            # 6 AdamW steps at B = 16: parameters whose true gradient is zero or round-off sized (the conv biases in front of a train-mode
+            # BatchNorm, a few spatial weights) move by +-lr = 3e-4 per step in a direction set by the LAST BIT of the gradient, so the
+            # running statistics agree to the parity budget (1e-3), not to fp32 round-off
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=1e-3, err_msg=k)
         if "num_batches" in k:
             assert int(sd[k]) == 6
 
