@@ -96,11 +96,31 @@ __device__ __forceinline__ float wave_inclusive_scan(float v) {
     return v;
 }
 
-// ---- wave-level reductions (64 lanes, xor butterfly) ----
+// ---- wave-level reductions (64 lanes) ----
+// float sum / max: DPP data movement inside the VALU (quad_perm xor 1, xor 2, row_ror 4, row_ror 8: every lane of a 16-lane row holds the row's
+// result; row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's; v_readlane broadcasts it) -- 6 VALU
+// instructions instead of the 6 dependent ds_bpermute round trips of a __shfl_xor butterfly (~1000 cycles per pair of sums: it was the
+// longest dependency chain of every LayerNorm row and of the BatchNorm-statistics tasks).
+#if !defined(EEG_EMU)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+#if defined(EEG_EMU)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
+#else
+    v += dpp_mov<0xb1, 0xf>(0.f, v);       // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4e, 0xf>(0.f, v);       // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x124, 0xf>(0.f, v);      // row_ror:4
+    v += dpp_mov<0x128, 0xf>(0.f, v);      // row_ror:8
+    v += dpp_mov<0x142, 0xa>(0.f, v);      // row_bcast:15 -> rows 1, 3 (the others add the `old` operand: 0)
+    v += dpp_mov<0x143, 0xc>(0.f, v);      // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -108,9 +128,19 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+#if defined(EEG_EMU)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
     return v;
+#else
+    v = fmaxf(v, dpp_mov<0xb1, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x4e, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x124, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x128, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(v, v));       // (rows that do not receive keep `old` = their own value)
+    v = fmaxf(v, dpp_mov<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 
 // ---- MFMA wrappers (gfx950 fragment layouts, guide section 3) ----

@@ -3,6 +3,8 @@
 // 64-lane xor-butterfly reductions, statistics kept in fp32 (LN) or fp64 atomics (BN batch sums).
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // the epilogue of the GEMM that produces x; there every output element costs a whole Philox block (a lane's 16 accumulator values
 // sit in 16 different blocks: +12 us on a 32 us GEMM), here a lane owns 4 consecutive columns and one block serves all four.
 // Same mask (Philox(seed, site, row * cols + c)) and the same arithmetic order, so results are bit-identical to the epilogue form.
+typedef float ln_f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte global access from a dword-aligned address
 template <int NG, bool VEC2, bool DOUBLE>
 __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                                       float* __restrict__ x_out, float drop_p, unsigned long long seed, unsigned site,
@@ -68,12 +71,17 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
         if (VEC2) {
+            if (c + 3 < cols) {                                   // one 16-byte access (dword alignment is enough for global_load_dwordx4)
+                const ln_f32x4u t = *reinterpret_cast<const ln_f32x4u*>(p + c);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = c + 2 * h < cols;
-                const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
-                v[2 * h] = t[0];
-                v[2 * h + 1] = t[1];
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = c + 2 * h < cols;
+                    const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
+                    v[2 * h] = t[0];
+                    v[2 * h + 1] = t[1];
+                }
             }
         } else {
 #pragma unroll
@@ -82,9 +90,12 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
     };
     auto st4 = [&](float* p, int c, const float (&v)[4]) {
         if (VEC2) {
+            if (c + 3 < cols) *reinterpret_cast<ln_f32x4u*>(p + c) = ln_f32x4u{v[0], v[1], v[2], v[3]};
+            else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (c + 2 * h < cols) *reinterpret_cast<f32x2*>(p + c + 2 * h) = f32x2{v[2 * h], v[2 * h + 1]};
+                for (int h = 0; h < 2; ++h)
+                    if (c + 2 * h < cols) *reinterpret_cast<f32x2*>(p + c + 2 * h) = f32x2{v[2 * h], v[2 * h + 1]};
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -196,12 +207,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
         if (VEC2) {
+            if (c + 3 < cols) {                                   // one 16-byte access (dword alignment is enough for global_load_dwordx4)
+                const ln_f32x4u t = *reinterpret_cast<const ln_f32x4u*>(p + c);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = c + 2 * h < cols;                 // cols even: a pair is all in or all out
-                const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
-                v[2 * h] = t[0];
-                v[2 * h + 1] = t[1];
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = c + 2 * h < cols;             // cols even: a pair is all in or all out
+                    const f32x2 t = ok ? *reinterpret_cast<const f32x2*>(p + c + 2 * h) : f32x2{0.f, 0.f};
+                    v[2 * h] = t[0];
+                    v[2 * h + 1] = t[1];
+                }
             }
         } else {
 #pragma unroll
@@ -251,7 +267,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) keep[e] = (off + e < 4) ? k0[(off + e) & 3] : k1[(off + e) & 3];
             }
-            if (VEC2) {
+            if (VEC2 && c + 3 < cols) {
+                *reinterpret_cast<ln_f32x4u*>(dxr + c) = ln_f32x4u{v[0], v[1], v[2], v[3]};
+                if (dx_drop)
+                    *reinterpret_cast<ln_f32x4u*>(dx_drop + rbase + c) =
+                        ln_f32x4u{keep[0] ? v[0] * keep_scale : 0.f, keep[1] ? v[1] * keep_scale : 0.f, keep[2] ? v[2] * keep_scale : 0.f,
+                                  keep[3] ? v[3] * keep_scale : 0.f};
+            } else if (VEC2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (c + 2 * h < cols) {
@@ -276,6 +298,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
 
 // backward, part 2:  dgamma[c] += sum_rows dy*xhat ; dbeta[c] += sum_rows dy.   Column-parallel: block = 64 columns x 4 row groups,
 // lanes walk columns (coalesced), each thread strides over its share of the rows; LDS combine, one atomic per column per block.
+// The kernel is bound by its ATOMICS, not by the 33.6 MB it reads: time is proportional to the number of workgroups at any access width
+// (16-byte row-wise variant, 16384 x 250: 128 workgroups 27.6 us, 256 -> 33, 512 -> 55, 1024 -> 103 us = ~5 float atomics per ns device-wide;
+// this version issues 131 K atomics: 19 us).  It runs on the backward's second stream, off the dX chain.
 __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {

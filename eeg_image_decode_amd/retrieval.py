@@ -26,16 +26,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def scaled_logits(z, feats):
-    """raw z @ feats.T on the fp32-MFMA GEMM (the monotone logit_scale factor is irrelevant for argmax / top-k and is
-    applied by the caller where values matter)."""
+def scaled_logits(z, feats, precision=_abi.PREC_F32):
+    """raw z @ feats.T (the monotone logit_scale factor is irrelevant for argmax / top-k and is applied by the caller where values matter).
+    precision: exact fp32 products by default (evaluation: the ranking the reference's fp32 matmul produces); the running TRAIN accuracy of the
+    batch loop passes the step's GEMM arithmetic (split-bf16: logits within ~3e-5, half the time of a launch that shares the GPU with the backward)."""
     z, feats = z.contiguous(), feats.contiguous()
     n, dm = z.shape
     c = feats.shape[0]
     out = torch.empty(n, c, dtype=torch.float32, device=z.device)
     d = _abi.GemmDesc(M=n, N=c, K=dm, A=z.data_ptr(), Am=D(dm), Ak=D(1), B=feats.data_ptr(), Bk=D(1), Bn=D(dm), C=out.data_ptr(),
                       Cm=D(c), Cn=D(1), Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0,
-                      drop_p=0.0, seed=0, drop_site=0, split_k=1)
+                      drop_p=0.0, seed=0, drop_site=0, split_k=1, precision=precision)
     check(lib().eegclip_gemm_f32(ctypes.byref(d), _stream()), "logits gemm")
     return out
 
@@ -50,10 +51,10 @@ def topk_rows(logits, k, scale=None):
     return out
 
 
-def topk_retrieval(z, class_feats, logit_scale, k):
+def topk_retrieval(z, class_feats, logit_scale, k, precision=_abi.PREC_F32):
     """indices of the k best classes per query, ties -> lowest index (ATMS_retrieval.py:246 argmax, :320 topk)."""
     require_cuda(z, "z")
-    logits = scaled_logits(z.detach().float(), class_feats.detach().float())
+    logits = scaled_logits(z.detach().float(), class_feats.detach().float(), precision)
     if not torch.is_tensor(logit_scale):
         logit_scale = torch.full((1,), float(logit_scale), dtype=torch.float32, device=z.device)
     return topk_rows(logits, k, logit_scale)
@@ -140,7 +141,8 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
 
 
 def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct):
-    pred = topk_retrieval(eeg_features, class_feats, logit_scale, 1)
+    from .plan import default_gemm_precision
+    pred = topk_retrieval(eeg_features, class_feats, logit_scale, 1, default_gemm_precision())
     check(lib().eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
 
 
