@@ -407,10 +407,10 @@ class _Engine:
 
     def _spatial_weight_planes(self, pl):
         """bf16 hi / lo planes of the spatial conv weights for the split-bf16 conv kernels (csrc/sconv.hip), refreshed by ONE eegclip_split_rows
-        launch in the forward plan: Ws as [40][ld] (k contiguous: forward) and Ws^T as [(c,h)][64] (both BN1-backward passes).  Returns the
-        forward kernel's (hi, lo, ld) arguments; (None, None, 0) = exact fp32 products."""
+        launch in the forward plan (shared with the Linear weights): Ws^T as [(c,h)][64] (both BN1-backward passes) and, opt-in, Ws as [40][ld]
+        (k contiguous: forward).  Returns the forward kernel's (hi, lo, ld) arguments -- (None, None, 0) = exact fp32 products -- and the split items."""
         if pl.precision != _abi.PREC_BF16X3:
-            return (None, None, 0)
+            return (None, None, 0), []
         Kc = C_TS * N_CH
         ld = (Kc + 128 + 63) // 64 * 64             # a forward chunk may read up to 127 k past the end of its K slice
         if not hasattr(self, "sc_planes"):
@@ -418,53 +418,56 @@ class _Engine:
             self.sc_planes_t = torch.zeros(2, Kc, 64, dtype=torch.bfloat16, device=self.device)
         f, tr = self.sc_planes, self.sc_planes_t
         src = _p(self.P[_TS + "4.weight"])
-        items = (_abi.SplitItem * 2)(
-            _abi.SplitItem(src=src, hi=f[0].data_ptr(), lo=f[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=ld, transpose=0),
-            _abi.SplitItem(src=src, hi=tr[0].data_ptr(), lo=tr[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=64, transpose=1))
-        pl._keep.append(items)
-        pl.call("eegclip_split_rows", items, 2)
+        items = [_abi.SplitItem(src=src, hi=tr[0].data_ptr(), lo=tr[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=64, transpose=1)]
         # measured at B = 256 (single-stream HIP events, profiles/r2_conv_x3_vs_f32.json): the split-bf16 FORWARD kernel is not faster than the exact
         # fp32 one (61 vs 59 us: both are bound by occupancy and the L1 tag rate of their strided 16-byte accesses, not by the MFMA pipe), so the
         # forward keeps exact products unless EEGCLIP_SCONV_FWD_X3=1; the backward kernels (apply -4 us, dW -4 us) use the planes
         if os.environ.get("EEGCLIP_SCONV_FWD_X3", "0") != "1":
-            return (None, None, 0)
-        return (f[0].data_ptr(), f[1].data_ptr(), ld)
+            return (None, None, 0), items
+        items.append(_abi.SplitItem(src=src, hi=f[0].data_ptr(), lo=f[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=ld, transpose=0))
+        return (f[0].data_ptr(), f[1].data_ptr(), ld), items
 
     def _init_weight_planes(self):
-        """bf16 hi / lo planes of every Linear weight, in both orientations (W for Y = X W^T, W^T for dX = dY W), refreshed by ONE
-        eegclip_split_rows launch at the head of every forward plan: the split of a weight element is then done once per step instead of once
-        per workgroup tile that stages it (csrc/gemm_x3.hip, planes variant).
+        """bf16 hi / lo planes of the TRANSPOSED attention / FFN weights (W^T for dX = dY W), refreshed by the eegclip_split_rows launch at the
+        head of every forward plan, for the planes variant of the split-bf16 GEMM (csrc/gemm_x3.hip: B never split in the kernel, 64 x 128 x 64
+        tiles).  OFF by default: EEGCLIP_WEIGHT_PLANES=1 enables it for the plain-epilogue dX GEMMs, =all for every Linear.
 
-        OFF unless EEGCLIP_WEIGHT_PLANES=1: measured at B = 256 the 64x256-tile planes kernel is SLOWER than the 64x64x64 kernel that splits both
-        operands in registers (K ~ 250 GEMMs 24 vs 17 us, the step 1.60 vs 1.41 ms, profiles/r2_gemm_x3_sweep_v3.json): its 255-VGPR waves leave
-        one workgroup per SIMD, and the saved VALU work does not pay for the lost latency hiding."""
+        Which launches use planes is a measured choice (bench.py --breakdown at B = 256, us, both-operands-split kernel -> planes kernel):
+        the dX GEMMs with a plain epilogue gain -- fused QKV (K = 744) 45.7 -> 37.0, FFN 24.4 -> 22.3, out-projection 21.5 -> 20.6 -- while launches
+        with a heavy epilogue (GELU / dropout / pre-activation copy / two-level output map: 8 accumulator tiles per wave at 3 waves per SIMD instead
+        of 4 at 4) lose: value embedding 25.4 -> 37.1, GELU' dX 30.7 -> 36.4, and the forward GEMMs are a wash (44.5 -> 47.9, 20.3 -> 20.8,
+        19.1 -> 18.9).  In the STEP, where these launches share the GPU with the weight-gradient stream, neither setting pays: every Linear on planes
+        1.253 vs 1.218 ms, only the three gaining dX launches 1.204 vs 1.196 ms (same box, alternating runs) -- the 155-VGPR / 55 KB-LDS kernel
+        leaves less of a CU to the co-running kernels than it saves."""
         import collections
-        if os.environ.get("EEGCLIP_WEIGHT_PLANES", "0") != "1":
-            self.planes = self.planesT = collections.defaultdict(lambda: None)
-            self.plane_items, self.n_plane_items = None, 0
+        mode = os.environ.get("EEGCLIP_WEIGHT_PLANES", "0")
+        self.planes, self.planesT = collections.defaultdict(lambda: None), collections.defaultdict(lambda: None)
+        self.plane_items, self.n_plane_items = None, 0
+        if mode == "0":
             return
-        if self.joint:
-            base = []                                                # (the per-subject value embeddings run as a grouped fp32 launch)
-        else:
-            base = [("embed", _E + "value_embedding.weight", D_MODEL, T_LEN)]
-        base += [("qkv", _LY + "attention.query_projection.weight", 3 * HE, D_MODEL), ("out", _LY + "attention.out_projection.weight", D_MODEL, HE),
-                 ("ffn1", _LY + "conv1.weight", D_FF, D_MODEL), ("ffn2", _LY + "conv2.weight", D_MODEL, D_FF),
-                 ("head0", "proj_eeg.0.weight", P_DIM, F_TS), ("head1", "proj_eeg.1.fn.1.weight", P_DIM, P_DIM)]
+        # (name, flat-buffer key, rows, cols, orientations)
+        base = [("qkv", _LY + "attention.query_projection.weight", 3 * HE, D_MODEL, (1,)), ("out", _LY + "attention.out_projection.weight", D_MODEL, HE, (1,)),
+                ("ffn1", _LY + "conv1.weight", D_FF, D_MODEL, (1,))]
+        if mode == "all":
+            base = [(n, k, r, c, (0, 1)) for n, k, r, c, _ in base] + [("ffn2", _LY + "conv2.weight", D_MODEL, D_FF, (0, 1))]
+            if not self.joint:                                       # (the per-subject value embeddings run as a grouped fp32 launch)
+                base.append(("embed", _E + "value_embedding.weight", D_MODEL, T_LEN, (0, 1)))
         pad = lambda n: (n + 63) // 64 * 64
-        total = sum(r * pad(c) + c * pad(r) for _, _, r, c in base)
+        total = sum((r * pad(c) if 0 in o else 0) + (c * pad(r) if 1 in o else 0) for _, _, r, c, o in base)
         self.plane_buf = torch.zeros(2 * total, dtype=torch.bfloat16, device=self.device)
-        items = (_abi.SplitItem * (2 * len(base)))()
-        self.planes, self.planesT = {}, {}
-        off, ptr = 0, self.plane_buf.data_ptr()
-        for i, (name, key, rows, cols) in enumerate(base):
+        n_items = sum(len(o) for *_, o in base)
+        items = (_abi.SplitItem * n_items)()
+        off, ptr, j = 0, self.plane_buf.data_ptr(), 0
+        for name, key, rows, cols, orient in base:
             src = self.P[key].data_ptr()                             # (rows, cols) row-major view of the flat buffer (q|k|v: three adjacent weights)
-            for tr in (0, 1):
+            for tr in orient:
                 orow, ld = (cols, pad(rows)) if tr else (rows, pad(cols))
                 hi, lo = ptr + 2 * off, ptr + 2 * (off + orow * ld)
-                items[2 * i + tr] = _abi.SplitItem(src=src, hi=hi, lo=lo, rows=rows, cols=cols, ld_src=cols, ld_out=ld, transpose=tr)
+                items[j] = _abi.SplitItem(src=src, hi=hi, lo=lo, rows=rows, cols=cols, ld_src=cols, ld_out=ld, transpose=tr)
                 (self.planesT if tr else self.planes)[name] = (hi, lo, ld)
                 off += 2 * orow * ld
-        self.plane_items, self.n_plane_items = items, 2 * len(base)
+                j += 1
+        self.plane_items, self.n_plane_items = items, n_items
 
     def stale(self, model):
         a, b = self._check
@@ -523,8 +526,17 @@ class _Engine:
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
         PL, PLT = self.planes, self.planesT
-        if self.n_plane_items:
-            pl.call("eegclip_split_rows", self.plane_items, self.n_plane_items)      # weight planes of this step (both orientations)
+        # bf16 planes of this step's weights -- every Linear in both orientations + the spatial conv -- in ONE launch
+        fw, conv_items = self._spatial_weight_planes(pl)
+        n_items = self.n_plane_items + len(conv_items)
+        if n_items:
+            items = (_abi.SplitItem * n_items)()
+            for i in range(self.n_plane_items):
+                items[i] = self.plane_items[i]
+            for i, it in enumerate(conv_items):
+                items[self.n_plane_items + i] = it
+            pl._keep.append(items)
+            pl.call("eegclip_split_rows", items, n_items)
         # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
         if not self.joint:
@@ -579,7 +591,6 @@ class _Engine:
                 _p(self.buffers[_TS + "2.num_batches_tracked"]))
         # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
         # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
-        fw = self._spatial_weight_planes(pl)
         pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
                 *fw, _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1)      # y2 lives in the arena cleared above
         if W > 1:
@@ -596,16 +607,16 @@ class _Engine:
         skh = _head_split(B)
         if skh > 1:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
-                    accumulate=1, split_k=skh, planes=PL["head0"])
+                    accumulate=1, split_k=skh, planes=None)
             pl.call("eegclip_bias_act", _p(b["hacc"][0]), _p(P["proj_eeg.0.bias"]), _p(b["u"]), None, _p(b["gu"]), B, P_DIM, ACT_GELU, 0.0, 0, 0)
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["hacc"][1]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh, planes=PL["head1"])             # (slice 0 adds the bias)
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh, planes=None)             # (slice 0 adds the bias)
             w_lin = b["hacc"][1]
         else:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
-                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU, planes=PL["head0"])
+                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU, planes=None)
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), planes=PL["head1"])
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), planes=None)
             w_lin = b["s"]
         # s = u + dropout(W gelu(u) + b), out = LayerNorm(s): ResidualAdd + LayerNorm of Proj_eeg in one launch; `out` is a fresh tensor per
         # call (argument 8 is patched by forward()), so callers keep what they are handed and no copy is made
@@ -648,11 +659,11 @@ class _Engine:
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
         skh = _head_split(B)
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
-                accumulate=int(skh > 1), split_k=skh, planes=PLT["head1"])
+                accumulate=int(skh > 1), split_k=skh, planes=None)
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
         wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
         pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
-                accumulate=int(skh > 1), split_k=skh, planes=PLT["head0"])
+                accumulate=int(skh > 1), split_k=skh, planes=None)
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
         # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.

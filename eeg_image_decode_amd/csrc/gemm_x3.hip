@@ -346,12 +346,15 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
 // loads / ds_write_b128 and issues 4 x 48 MFMAs: the matrix pipe is the long pole again.
 //   A: k-contiguous fp32 rows (the layer input, or dY), converted while staged, as above.   B: planes, rows = output columns n.
 //   4 waves side by side, each 64 rows x 64 columns (4 x 4 MFMA tiles); same LDS geometry, same epilogue, same split-K scheme.
-constexpr int XP_BM = 64, XP_BN = 256;
+constexpr int XP_BM = 64;
 typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BK, bool C_PLAIN>
+// XP_BN = 256: 4 waves side by side, 64 x 64 each (16 accumulator tiles per wave: 255 VGPRs, one workgroup per SIMD);
+// XP_BN = 128: 2 x 2 waves, 32 x 64 each (8 tiles: the occupancy of the base kernel, B never split, an A element split by half as many tiles)
+template <int BK, int XP_BN, bool C_PLAIN>
 __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
     using G = x3_geom<BK>;
+    constexpr int WN = XP_BN / 64, WM = 4 / WN, MT = 4 / WM;          // waves along n / m, MFMA row tiles per wave
     constexpr int IMG_A = XP_BM * G::RS, NQ = BK / 4, RPP = X3_THREADS / NQ, KC_PASS = XP_BM / RPP;
     constexpr int NCH = BK / 8, BRP = X3_THREADS / NCH, B_PASS = XP_BN / BRP;        // B: thread -> (chunk t % NCH, row t / NCH + BRP i)
     EEG_LDS_BASE(unsigned char, lds);
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
     const int m0 = (logical / gx) * XP_BM, n0 = (logical % gx) * XP_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
     int kt_begin, kt_end;
     gemm_k_slice<BK>(d, slice, kt_begin, kt_end);
     const int a_ld = (int)d.Am.si;
@@ -431,9 +435,9 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = d.rowsum_a != nullptr && n0 == 0;
@@ -457,13 +461,13 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
             bf16x8 bh[4], bl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = 64 * wave + 16 * j + fr;
+                const int row = 64 * wn + 16 * j + fr;
                 bh[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 0, 4 * s + g));
                 bl[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 1, 4 * s + g));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 16 * i + fr;
+            for (int i = 0; i < MT; ++i) {
+                const int row = (XP_BM / WM) * wm + 16 * i + fr;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 0, 4 * s + g));
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 1, 4 * s + g));
 #pragma unroll
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
         __syncthreads();
     }
     if (do_rowsum && t < XP_BM && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-    gemm_epilogue_t<C_PLAIN, 4, 4>(d, acc, m0, n0 + 64 * wave, lane, slice == 0, d.split_k > 1, d.C);
+    gemm_epilogue_t<C_PLAIN, MT, 4>(d, acc, m0 + (XP_BM / WM) * wm, n0 + 64 * wn, lane, slice == 0, d.split_k > 1, d.C);
 }
 
 // rows of an fp32 matrix -> bf16 planes hi / lo, [rows][ld_out] with zeros beyond `cols`; TRANSPOSE: the planes of the transposed matrix.
@@ -575,14 +579,27 @@ int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain,
     static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
     static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
     static const bool allow_planes = !(getenv("EEGCLIP_X3_PLANES") && atoi(getenv("EEGCLIP_X3_PLANES")) == 0);      // tuning aid
-    if (allow_planes && akc && !k2 && d.split_k == 1 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
-        const int gx = (d.N + XP_BN - 1) / XP_BN, gy = (d.M + XP_BM - 1) / XP_BM;
+    // (few rows: the 64 x 64 kernel's larger grid wins -- 1024^3: 20 vs 27 us)
+    if (allow_planes && akc && !k2 && d.split_k == 1 && d.M >= 2048 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
+        // variant: output tile width x k-tile depth (EEGCLIP_XP_VARIANT = 0: 256 x 32, 1: 128 x 32, 2: 128 x 64; tuning aid).  Measured at the step's
+        // shapes (16384 rows, K ~ 250; us, 64x64x64 kernel -> variant 2): forward 16.4-18.3 -> 16.3-17.1, dX 17.5-17.9 -> 15.6-16.0,
+        // dX of the fused QKV projection (K = 744) 40.9 -> 31.7; variant 0 (255 VGPRs): 21-24.
+        static const int variant = getenv("EEGCLIP_XP_VARIANT") ? atoi(getenv("EEGCLIP_XP_VARIANT")) : 2;
+        const int bn = variant == 0 ? 256 : 128, bk = variant == 2 ? 64 : 32;
+        const int gx = (d.N + bn - 1) / bn, gy = (d.M + XP_BM - 1) / XP_BM;
         const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
-        const dim3 grid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles), block(X3_THREADS);
-        if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 planes <%d> %dx%dx%d sk%d\n", (int)c_plain, d.M, d.N, d.K, d.split_k);
-        const size_t lds = (size_t)(XP_BM + XP_BN) * x3_geom<32>::RS;
-        if (c_plain) EEG_LAUNCH((gemm_x3p_kernel<32, true>), grid, block, lds, stream, d, gx, ntiles, chunk);
-        else         EEG_LAUNCH((gemm_x3p_kernel<32, false>), grid, block, lds, stream, d, gx, ntiles, chunk);
+        const dim3 grid(8 * chunk), block(X3_THREADS);
+        if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 planes <%d,%d,%d> %dx%dx%d\n", bn, bk, (int)c_plain, d.M, d.N, d.K);
+        const size_t lds = (size_t)(XP_BM + bn) * (bk == 64 ? x3_geom<64>::RS : x3_geom<32>::RS);
+#define EEG_XP_GO(BK_, BN_)                                                                                              \
+    do {                                                                                                                 \
+        if (c_plain) EEG_LAUNCH((gemm_x3p_kernel<BK_, BN_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);      \
+        else         EEG_LAUNCH((gemm_x3p_kernel<BK_, BN_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);     \
+    } while (0)
+        if (variant == 0)      EEG_XP_GO(32, 256);
+        else if (variant == 2) EEG_XP_GO(64, 128);
+        else                   EEG_XP_GO(32, 128);
+#undef EEG_XP_GO
         return (int)hipGetLastError();
     }
     int cfg = ((d.precision >> 8) & 0xff) - 1;                  // explicit tile configuration in the descriptor (tuning / tests)
