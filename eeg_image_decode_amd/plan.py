@@ -25,6 +25,9 @@ D = _abi.dim
 _SPLITK_WORKSPACE = os.environ.get("EEGCLIP_SPLITK_WORKSPACE", "0") == "1"
 
 
+_SIDE_PRIORITY = int(os.environ.get("EEGCLIP_SIDE_PRIORITY", "0"))     # HIP stream priority of a plan's second stream (tuning aid)
+
+
 def default_gemm_precision():
     """Arithmetic of the plan GEMMs (every Linear of the encoder / head / prior, forward and backward): split-bf16 products on the bf16 matrix
     cores by default (include/eegclip.h: EEGCLIP_PREC_BF16X3; embeddings move by <= 3e-5 against exact fp32 products, parity budget 1e-3);
@@ -198,7 +201,7 @@ class Plan:
         side = None
         if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
             if self._side is None:
-                self._side = (torch.cuda.Stream(), None, None)
+                self._side = (torch.cuda.Stream(priority=_SIDE_PRIORITY), None, None)
             side = self._side[0]
         c["dirty"].value = 0
         for seg in c["segments"]:
@@ -257,7 +260,7 @@ class Plan:
         side = None
         if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
             if self._side is None or self._side[1] is None:        # (the C executor keeps only the stream: it owns its own events)
-                st_side = self._side[0] if self._side is not None else torch.cuda.Stream()
+                st_side = self._side[0] if self._side is not None else torch.cuda.Stream(priority=_SIDE_PRIORITY)
                 self._side = (st_side, {i: torch.cuda.Event() for i, op in enumerate(self.ops) if op[3]}, torch.cuda.Event())
             side = self._side
         ts = torch.cuda.current_stream() if (timed or side) else None
