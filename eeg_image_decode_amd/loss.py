@@ -158,6 +158,20 @@ def _grad_cols(X, a_rows, out=None, precision=0):
     return out
 
 
+_ACC_POOL = {}
+
+
+def _zero_pair(dev):
+    """a zeroed (loss, dscale) accumulator pair: slices of a pool that is filled 128 pairs at a time (one fill launch per 128 loss calls instead of
+    one per call; a slice is handed out once, so a loss value that is still referenced is never overwritten)"""
+    key = str(dev)
+    pool, used = _ACC_POOL.get(key, (None, 0))
+    if pool is None or used >= pool.shape[0]:
+        pool, used = torch.zeros(128, 2, dtype=torch.float32, device=dev), 0
+    _ACC_POOL[key] = (pool, used + 1)
+    return pool[used]
+
+
 class _ClipLossFn(torch.autograd.Function):
     """loss = sum_t w_t * ClipLoss(a, b_t, scale) for one or more target matrices b_t that share the query features `a`
     (the training loop mixes an image and a text target, ATMS_retrieval.py:224-229): one (loss, dscale) accumulator, one gradient
@@ -176,7 +190,7 @@ class _ClipLossFn(torch.autograd.Function):
         a_ = a.detach().contiguous()
         bs = [b.detach().contiguous() for b in targets]
         n = a_.shape[0]
-        acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        acc = _zero_pair(dev)
         da = None
         dbs = [None] * len(bs)
         planes = 2 if mod.logits_dtype == "f32" else 1
@@ -284,11 +298,17 @@ class _ClipLossFn(torch.autograd.Function):
                 dist.reduce_scatter_tensor(part, ga)
                 da = da + part
         ctx.grads = (da, acc[1].reshape(()) if need_s else None, dbs)
+        ctx.unit_grad = bool(getattr(mod, "_unit_upstream_grad", False))
         return acc[0].reshape(())
 
     @staticmethod
     def backward(ctx, go):
         da, ds, dbs = ctx.grads
+        if ctx.unit_grad:
+            # the caller guarantees that this loss is the root of the backward pass (upstream gradient == 1: the batch loop of retrieval.py calls
+            # loss.backward() on exactly this scalar): the gradients computed in forward are returned as they are -- two elementwise launches
+            # (dA * 1, dscale * 1) less on the critical path between the loss and the encoder's backward
+            return (da, ds, None, None) + tuple(dbs)
         return (da * go if da is not None else None, ds * go if ds is not None else None, None, None) + \
             tuple(db * go if db is not None else None for db in dbs)
 

@@ -66,9 +66,18 @@ def _uniform_ids(batch_size, subject_id, device):
         ids = torch.tensor(host, dtype=torch.long).to(device, non_blocking=True)
         ids._eegclip_host_ids = host              # ATMS.forward lays the batch out by subject from the host copy: no device->host sync
         return ids
-    ids = torch.full((batch_size,), subject_id, dtype=torch.long, device=device)
-    ids._eegclip_uniform_id = subject_id          # lets ATMS.forward pick the token branch without a device->host sync
+    key = (batch_size, subject_id, str(device))
+    ids = _UNIFORM_IDS.get(key)
+    if ids is None:                               # (one fill per (batch size, subject), not one per step; nobody writes to it)
+        if len(_UNIFORM_IDS) > 64:
+            _UNIFORM_IDS.clear()
+        ids = torch.full((batch_size,), subject_id, dtype=torch.long, device=device)
+        ids._eegclip_uniform_id = subject_id      # lets ATMS.forward pick the token branch without a device->host sync
+        _UNIFORM_IDS[key] = ids
     return ids
+
+
+_UNIFORM_IDS = {}
 
 
 _SIDE = {}
@@ -125,7 +134,11 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
         from .loss import mse_loss
         loss = mse_loss(eeg_features, img_features, 10.0 * alpha) + 10.0 * (1 - alpha) * loss_func(eeg_features, img_features, logit_scale)
     elif hasattr(loss_func, "forward_mixed"):        # both targets in one pass: one gradient w.r.t. the EEG features, one accumulator
-        loss = loss_func.forward_mixed(eeg_features, [(img_features, alpha), (text_features, 1 - alpha)], logit_scale)
+        loss_func._unit_upstream_grad = True         # `loss` IS the scalar backward() is called on three lines below
+        try:
+            loss = loss_func.forward_mixed(eeg_features, [(img_features, alpha), (text_features, 1 - alpha)], logit_scale)
+        finally:
+            loss_func._unit_upstream_grad = False
     else:                                            # a user-supplied loss module: the reference's two calls (ATMS_retrieval.py:224-229)
         loss = alpha * loss_func(eeg_features, img_features, logit_scale) + (1 - alpha) * loss_func(eeg_features, text_features, logit_scale)
     loss.backward()
