@@ -52,23 +52,38 @@ __global__ __launch_bounds__(256) void embed_finish_bwd_kernel(float* __restrict
         for (int d = threadIdx.x; d < D; d += blockDim.x) {
             float acc = 0.f;
             long long row = 0;                                // token row the running sum belongs to (ids == NULL: the shared token, row 0)
-            for (int b = blockIdx.x; b < B; b += tok_blocks) {
-                const long long i = (long long)b * L * D + d;
-                float v = dh[i];
-                if (drop_p > 0.f) {
-                    v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
-                    dh[i] = v;
+            // 8 batch rows at a time: all their loads are issued before the first use (the rows are L*D floats apart: one memory latency per
+            // element when loaded one by one -- this serial chain, not the streaming part, was the kernel's 31 us)
+            for (int b0 = blockIdx.x; b0 < B; b0 += 8 * tok_blocks) {
+                float v8[8];
+                long long r8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u * tok_blocks;
+                    v8[u] = b < B ? dh[(long long)b * L * D + d] : 0.f;
+                    r8[u] = (b < B && ids) ? ids[b] : 0;
                 }
-                if (dtokens) {
-                    // runs of equal ids are summed in a register and flushed with ONE atomic (a single-subject batch -- the reference's
-                    // loops -- is one run: 32 x 250 atomics instead of 256-way contention on each of 250 addresses)
-                    const long long r = ids ? ids[b] : 0;
-                    if (r != row) {
-                        if (acc != 0.f) atomicAdd(dtokens + row * D + d, acc);
-                        acc = 0.f;
-                        row = r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u * tok_blocks;
+                    if (b >= B) break;
+                    const long long i = (long long)b * L * D + d;
+                    float v = v8[u];
+                    if (drop_p > 0.f) {
+                        v = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? v * ks : 0.f;
+                        dh[i] = v;
                     }
-                    acc += v;
+                    if (dtokens) {
+                        // runs of equal ids are summed in a register and flushed with ONE atomic (a single-subject batch -- the reference's
+                        // loops -- is one run: 32 x 250 atomics instead of 256-way contention on each of 250 addresses)
+                        const long long r = r8[u];
+                        if (r != row) {
+                            if (acc != 0.f) atomicAdd(dtokens + row * D + d, acc);
+                            acc = 0.f;
+                            row = r;
+                        }
+                        acc += v;
+                    }
                 }
             }
             if (dtokens && acc != 0.f) atomicAdd(dtokens + row * D + d, acc);

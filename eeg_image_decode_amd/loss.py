@@ -49,6 +49,20 @@ def split_planes(x, planes):
     return hi, lo
 
 
+def split_planes_many(xs, planes):
+    """split_planes of several same-shaped feature matrices in ONE launch (eegclip_split_rows over a table: the query features and both
+    targets of the batch loop -- three 5-us launches of a 1 MB split each, between the encoder's forward and the loss, became one)"""
+    if len(xs) == 1 or any(x.shape != xs[0].shape or not x.is_contiguous() for x in xs) or xs[0].shape[1] % 64 != 0 or len(xs) > 24:
+        return [split_planes(x, planes) for x in xs]
+    n, Dm = xs[0].shape
+    buf = torch.empty(len(xs), 2, n, Dm, dtype=torch.bfloat16, device=xs[0].device)
+    items = (_abi.SplitItem * len(xs))()
+    for i, x in enumerate(xs):
+        items[i] = _abi.SplitItem(src=x.data_ptr(), hi=buf[i, 0].data_ptr(), lo=buf[i, 1].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0)
+    check(lib().eegclip_split_rows(items, len(xs), _stream()), "split_rows")
+    return [(buf[i, 0], buf[i, 1] if planes == 2 else None) for i in range(len(xs))]
+
+
 def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
     """blocks = [(q planes, k planes, col0, weight)]: adds sum_blocks weight / n_total * sum_rows (lse_row - positive) to acc[0].
     want_grad = [(block index, index of the block whose lse is the second (per-key) normaliser, or None)]: for each, the gradient matrix
@@ -198,8 +212,7 @@ class _ClipLossFn(torch.autograd.Function):
         Dm = a_.shape[1]
         if W == 1 and fused_enabled(n, n, Dm) and all(b.shape == a_.shape for b in bs):
             # blocks (A, B_t) and (B_t, A) of every target in ONE launch; one gradient matrix per target with both normalisers
-            ap = split_planes(a_, planes)
-            bps = [split_planes(b_, planes) for b_ in bs]
+            ap, *bps = split_planes_many([a_] + bs, planes)
             blocks, want = [], []
             for t, w in enumerate(weights):
                 blocks += [(ap, bps[t], 0, 0.5 * w), (bps[t], ap, 0, 0.5 * w)]
