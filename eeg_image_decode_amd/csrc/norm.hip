@@ -325,6 +325,103 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* _
     }
 }
 
+// Parameter gradients WITHOUT the atomics: stage 1 streams dy and x once (a wave per row, 16-byte accesses, lane owns 4 consecutive columns of
+// each 256-column group; LNP_ROWS rows per wave: 16384 rows -> 1024 workgroups, every row's loads independent) and writes one partial
+// [dgamma | dbeta] row per workgroup with plain stores; stage 2 sums the partial rows column-wise (a thread per column and slice of partials,
+// LDS combine) and adds into dgamma / dbeta -- 16 partial sums per address instead of 256..1024 contended atomics.
+constexpr int LNP_ROWS = 4;
+template <int NG>
+__global__ __launch_bounds__(256) void layernorm_bwd_param_stage1_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                          float* __restrict__ partials, int rows, int cols) {
+    EEG_LDS_BASE(float, red);   // [3 waves][2][NG * 256]
+    constexpr int W = NG * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[NG][4], pb[NG][4];
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
+    const int r0 = ((int)blockIdx.x * 4 + wave) * LNP_ROWS;
+#pragma unroll
+    for (int k = 0; k < LNP_ROWS; ++k) {
+        const int r = r0 + k;
+        if (r >= rows) break;
+        const float mu = mean[r], rs = rstd[r];
+        const float* xr = x + (long long)r * cols;
+        const float* dr = dy + (long long)r * cols;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            if (c >= cols) continue;
+            float xv[4], dv[4];
+            if (c + 3 < cols) {
+                const ln_f32x4u a = *reinterpret_cast<const ln_f32x4u*>(xr + c), b = *reinterpret_cast<const ln_f32x4u*>(dr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[e] = a[e]; dv[e] = b[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[e] = c + e < cols ? xr[c + e] : 0.f; dv[e] = c + e < cols ? dr[c + e] : 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pg[i][e] += dv[e] * (xv[e] - mu) * rs;
+                pb[i][e] += dv[e];
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[((wave - 1) * 2 + 0) * W + 256 * i + 4 * lane + e] = pg[i][e];
+                red[((wave - 1) * 2 + 1) * W + 256 * i + 4 * lane + e] = pb[i][e];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = partials + (long long)blockIdx.x * 2 * cols;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 256 * i + 4 * lane + e;
+                if (c < cols) {
+                    float g = pg[i][e], bsum = pb[i][e];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) { g += red[(w * 2 + 0) * W + c]; bsum += red[(w * 2 + 1) * W + c]; }
+                    out[c] = g;
+                    out[cols + c] = bsum;
+                }
+            }
+    }
+}
+
+// stage 2: grid (column blocks of 64 over the 2*cols partial columns, LNP_SLICES slices of the partial rows); 4 waves of a workgroup take every
+// 4th row of the slice; one atomic per column and slice (LNP_SLICES per address)
+constexpr int LNP_SLICES = 16;
+__global__ __launch_bounds__(256) void layernorm_bwd_param_stage2_kernel(const float* __restrict__ partials, int nparts, int cols,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    EEG_LDS_BASE(float, red);   // [4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;                    // column of the [dgamma | dbeta] partial row
+    float s = 0.f;
+    if (c < 2 * cols) {
+        const int per = (nparts + LNP_SLICES - 1) / LNP_SLICES;
+        const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+#pragma unroll 8
+        for (int p = p0 + g; p < p1; p += 4) s += partials[(long long)p * 2 * cols + c];
+    }
+    red[g * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0 && c < 2 * cols) {
+        const float t = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        if (c < cols) atomicAdd(dgamma + c, t);
+        else          atomicAdd(dbeta + c - cols, t);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm2d over a (outer, C, inner) view: channel c owns elements x[o][c][i].
 // sums[c] = sum x, sums[C + c] = sum x^2   (fp64 atomics: 5.8e5 terms per channel at B=256)
@@ -532,6 +629,23 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
         EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
                    dbeta, rows, cols);
     }
+    return (int)hipGetLastError();
+}
+
+static long long lnp_parts(int rows) { return ((long long)rows + 4 * LNP_ROWS - 1) / (4 * LNP_ROWS); }
+extern "C" long long eegclip_layernorm_bwd_params_workspace_floats(int rows, int cols) {
+    return rows < 1 || cols < 1 ? 0 : lnp_parts(rows) * 2 * cols;
+}
+
+extern "C" int eegclip_layernorm_bwd_params(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                            int rows, int cols, float* workspace, void* stream) {
+    if (!dy || !x || !mean || !rstd || !dgamma || !dbeta || !workspace || rows < 0 || cols < 1 || cols > 64 * LN_MAXC) return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const int parts = (int)lnp_parts(rows);
+    if (cols <= 256) EEG_LAUNCH(layernorm_bwd_param_stage1_kernel<1>, dim3(parts), dim3(256), 3 * 2 * 256 * sizeof(float), stream, dy, x, mean, rstd, workspace, rows, cols);
+    else             EEG_LAUNCH(layernorm_bwd_param_stage1_kernel<4>, dim3(parts), dim3(256), 3 * 2 * 1024 * sizeof(float), stream, dy, x, mean, rstd, workspace, rows, cols);
+    const int slices = parts < LNP_SLICES ? parts : LNP_SLICES;
+    EEG_LAUNCH(layernorm_bwd_param_stage2_kernel, dim3((2 * cols + 63) / 64, slices), dim3(256), 256 * sizeof(float), stream, workspace, parts, cols, dgamma, dbeta);
     return (int)hipGetLastError();
 }
 

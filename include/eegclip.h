@@ -135,6 +135,12 @@ int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p,
                           unsigned long long seed, unsigned int site, void* stream);
+/* the parameter half of eegclip_layernorm_bwd (dgamma += sum_rows dy*xhat, dbeta += sum_rows dy) through a caller-owned workspace of
+ * eegclip_layernorm_bwd_params_workspace_floats(rows, cols) floats (contents irrelevant): per-workgroup partial rows + a column reduction
+ * instead of hundreds of contended atomics per column (the atomic form is bound by them: 19 us for 16384 x 250; this one streams). */
+long long eegclip_layernorm_bwd_params_workspace_floats(int rows, int cols);
+int eegclip_layernorm_bwd_params(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                 int rows, int cols, float* workspace, void* stream);
 
 /* LayerNorm -> SiLU -> dropout in one pass (prior stage, Generation/diffusion_prior.py:117-121,137-143): y_ln = LN(x) is kept for
  * the backward, y_act = dropout(silu(y_ln)).  silu_bwd: dx (+)= dy*mask/(1-p)*silu'(pre). */

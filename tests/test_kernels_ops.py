@@ -52,6 +52,13 @@ def test_layernorm_fwd_bwd(be, rows, cols):
     np.testing.assert_allclose(be.host(DB2), be.host(DB), atol=1e-4 * max(1, rows ** 0.5))
     assert be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), None, None, None, rows, cols, 0, None, 0.0, 0, 0,
                                         be.stream) < 0
+    # the parameter half without atomics on the inputs' scale: per-workgroup partial rows in a workspace + a column reduction; accumulates
+    nws = int(be.lib.eegclip_layernorm_bwd_params_workspace_floats(rows, cols))
+    assert nws == (rows + 15) // 16 * 2 * cols
+    WS, DG3, DB3 = be.dev(np.full(nws, np.nan, np.float32)), be.dev(np.full(cols, 2.0, np.float32)), be.dev(np.full(cols, -1.0, np.float32))
+    ok(be.lib.eegclip_layernorm_bwd_params(be.ptr(DY), be.ptr(X), be.ptr(MU), be.ptr(RS), be.ptr(DG3), be.ptr(DB3), rows, cols, be.ptr(WS), be.stream))
+    np.testing.assert_allclose(be.host(DG3) - 2.0, gt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
+    np.testing.assert_allclose(be.host(DB3) + 1.0, bt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
 
 
 @pytest.mark.parametrize("rows,cols,p,double", [(5, 250, 0.25, True), (130, 250, 0.25, False), (7, 64, 0.0, True), (3, 1024, 0.5, False), (4, 7, 0.25, True)])

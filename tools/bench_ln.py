@@ -19,3 +19,5 @@ print("fwd        %.1f us" % t(lambda: L.eegclip_layernorm_fwd(P(x), P(g), P(b),
 print("bwd dx     %.1f us" % t(lambda: L.eegclip_layernorm_bwd(P(dy), P(x), P(g), P(mu), P(rs), P(dx), None, None, R, C, 0, None, 0.0, 0, 0, st)))
 print("bwd dx+drop %.1f us" % t(lambda: L.eegclip_layernorm_bwd(P(dy), P(x), P(g), P(mu), P(rs), P(dx), None, None, R, C, 0, P(dxd), 0.25, 1, 2, st)))
 print("bwd param  %.1f us" % t(lambda: L.eegclip_layernorm_bwd(P(dy), P(x), None, P(mu), P(rs), None, P(dg), P(db), R, C, 0, None, 0.0, 0, 0, st)))
+ws = torch.empty(int(L.eegclip_layernorm_bwd_params_workspace_floats(R, C)), device="cuda")
+print("bwd param (partials + reduce) %.1f us" % t(lambda: L.eegclip_layernorm_bwd_params(P(dy), P(x), P(mu), P(rs), P(dg), P(db), R, C, P(ws), st)))
