@@ -100,7 +100,8 @@ PROTOTYPES = {
     "eegclip_attention_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_proj1x1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
-    "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
+    "eegclip_proj1x1_bwd_workspace_floats": [_I],
+    "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_cast_bf16": [_P, _P, _L, _P],
     "eegclip_logits_bf16": [_P, _P, _P, _I, _I, _I, _L, _P, _P],
     "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P],

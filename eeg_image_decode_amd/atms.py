@@ -683,9 +683,11 @@ class _Engine:
             def conv_bias_grad(bias_key, gamma_key, rstd, s):
                 # d bias[c] = sum over (b,h,w) of the gradient entering the BatchNorm input = gamma[c]*rstd[c]*sum(da)[c]   (40 values)
                 return lambda: G[bias_key].add_((P[gamma_key] * rstd * s[:C_TS].to(torch.float32)))
+        if "pj_ws" not in b:
+            b["pj_ws"] = torch.empty(int(lib().eegclip_proj1x1_bwd_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
         pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
                 _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
-                _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), B, pc_, 0, SITE_CONV, seed_at=14)
+                _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=15)
         local2 = None
         if W > 1:
             local2 = torch.zeros_like(sums[2])

@@ -6,12 +6,15 @@
 // almost all of it launch latency and index arithmetic.  Here a sample's 40 x 36 tile, its gradient and the 40 x 40 weights sit in LDS.
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
 constexpr int PJ_C = 40;       // channels in and out
 constexpr int PJ_W = 36;       // positions
 constexpr int PJ_N = PJ_C * PJ_W;
 constexpr int PJ_LW = 41;      // padded row stride of the [e][c] / [w][e] images
+constexpr int PJ_PART = PJ_C * PJ_C + PJ_C + 2 * PJ_C;      // partial row of the backward: dW | dbias | BatchNorm-backward sums
 
 __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ z2, const float* __restrict__ Wt,
                                                            const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dz2,
-                                                           float* __restrict__ dW, float* __restrict__ dbias, double* __restrict__ sums, int B, int spw,
+                                                           float* __restrict__ dW, float* __restrict__ dbias, double* __restrict__ sums, double* __restrict__ partials, int B, int spw,
                                                            float drop_p, unsigned long long seed, unsigned site) {
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2[c][w]
@@ -110,6 +113,19 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
             csum += acc;
         }
     }
+    if (partials) {
+        // one partial row [dW 1600 | dbias 40 | sums 80] per workgroup, reduced column-wise by proj1x1_bwd_reduce_kernel: with one workgroup per
+        // sample the 1720 atomics per workgroup (256-way contention per address) were half of the kernel's 30 us
+        double* row = partials + (long long)blockIdx.x * PJ_PART;
+#pragma unroll
+        for (int j = 0; j < NWO; ++j) {
+            const int o = t + 256 * j;
+            if (o < PJ_C * PJ_C) row[o] = (double)dwp[j];
+        }
+        if (t < PJ_C) row[PJ_C * PJ_C + t] = (double)dbp;
+        if (t < 2 * PJ_C) row[PJ_C * PJ_C + PJ_C + t] = csum;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NWO; ++j) {
         const int o = t + 256 * j;
@@ -117,6 +133,30 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
     }
     if (t < PJ_C) atomicAdd(dbias + t, dbp);
     if (t < 2 * PJ_C) atomicAdd(sums + t, csum);
+}
+
+// column sums of the partial rows: grid (column blocks of 64, PJ_SLICES slices of the rows); one atomic per column and slice
+constexpr int PJ_SLICES = 8;
+__global__ __launch_bounds__(256) void proj1x1_bwd_reduce_kernel(const double* __restrict__ partials, int nparts, float* __restrict__ dW,
+                                                                  float* __restrict__ dbias, double* __restrict__ sums) {
+    EEG_LDS_BASE(double, red);   // [4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (c < PJ_PART) {
+        const int per = (nparts + PJ_SLICES - 1) / PJ_SLICES;
+        const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+#pragma unroll 8
+        for (int p = p0 + g; p < p1; p += 4) s += partials[(long long)p * PJ_PART + c];
+    }
+    red[g * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0 && c < PJ_PART) {
+        const double v = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        if (c < PJ_C * PJ_C)             atomicAdd(dW + c, (float)v);
+        else if (c < PJ_C * PJ_C + PJ_C) atomicAdd(dbias + c - PJ_C * PJ_C, (float)v);
+        else                             atomicAdd(sums + c - PJ_C * PJ_C - PJ_C, v);
+    }
 }
 
 }  // namespace eeg
@@ -132,14 +172,26 @@ extern "C" int eegclip_proj1x1_fwd(const float* y2, const float* mean, const flo
     return (int)hipGetLastError();
 }
 
+extern "C" long long eegclip_proj1x1_bwd_workspace_floats(int B) { return B < 1 ? 0 : 2LL * B * PJ_PART; }      // (doubles, counted in floats)
+
 extern "C" int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const float* W, const float* y2, const float* mean, const float* rstd,
-                                   const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, int B, float drop_p,
-                                   unsigned long long seed, unsigned int site, void* stream) {
+                                   const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
+                                   float drop_p, unsigned long long seed, unsigned int site, void* stream) {
     if (!dfeat || !z2 || !W || !y2 || !mean || !rstd || !gamma || !beta || !dz2 || !dW || !dbias || !sums || B < 1 || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
-    const int spw = B >= 512 ? 4 : (B >= 128 ? 2 : 1);           // samples per workgroup: fewer, fatter atomics once the grid still fills the chip
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7u)) return EEGCLIP_EALIGN;
+    static const int forced = getenv("EEGCLIP_PJ_SPW") ? atoi(getenv("EEGCLIP_PJ_SPW")) : 0;     // tuning aid
+    // samples per workgroup: with a workspace one (the per-sample work is ~11 us of LDS-bound arithmetic: as parallel as possible); with atomics
+    // fewer, fatter ones once the grid still fills the chip
+    const int spw = forced > 0 ? forced : (workspace ? 1 : (B >= 512 ? 4 : (B >= 128 ? 2 : 1)));
     const size_t lds = (PJ_N + PJ_W * PJ_LW + PJ_C * PJ_LW + 2 * PJ_N) * sizeof(float);
-    EEG_LAUNCH(proj1x1_bwd_kernel, dim3((B + spw - 1) / spw), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, B,
-               spw, drop_p, seed, site);
+    const int nwg = (B + spw - 1) / spw;
+    double* parts = reinterpret_cast<double*>(workspace);
+    EEG_LAUNCH(proj1x1_bwd_kernel, dim3(nwg), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, parts, B, spw,
+               drop_p, seed, site);
+    if (parts) {
+        const int slices = nwg < PJ_SLICES ? nwg : PJ_SLICES;
+        EEG_LAUNCH(proj1x1_bwd_reduce_kernel, dim3((PJ_PART + 63) / 64, slices), dim3(256), 256 * sizeof(double), stream, parts, nwg, dW, dbias, sums);
+    }
     return (int)hipGetLastError();
 }

@@ -353,9 +353,12 @@ int eegclip_infonce_fused_grad(const eegclip_infonce_problem* blocks, int n_bloc
  *        da = dz2 * mask/(1-p) * ELU'(BN(y2)) -- followed (after the SyncBN all-reduce of sums, if any) by eegclip_bn_elu_bwd_apply(dz2, y2, ...). */
 int eegclip_proj1x1_fwd(const float* y2, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                         const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+/* workspace (optional, 8-byte aligned, eegclip_proj1x1_bwd_workspace_floats(B) floats, contents irrelevant): dW / dbias / sums are accumulated through
+ * per-workgroup partial rows + a column reduction instead of 1720 contended atomics per workgroup */
+long long eegclip_proj1x1_bwd_workspace_floats(int B);
 int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const float* W, const float* y2, const float* mean, const float* rstd,
-                        const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, int B, float drop_p,
-                        unsigned long long seed, unsigned int site, void* stream);
+                        const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
+                        float drop_p, unsigned long long seed, unsigned int site, void* stream);
 
 /* ---- large-batch InfoNCE logits on the bf16 matrix cores (models/loss.py:122-123 at global batch 2048, D = 1024):
  *   c[m][n] = (*scale) * sum_k a[m][k] * b[n][k]     a (M,K), b (N,K) bf16 row-major (eegclip_cast_bf16 of the fp32 features), c fp32.

@@ -587,11 +587,18 @@ def test_proj1x1_fused_stage(be, B, p):
                                   SEED, 2, be.stream))
     np.testing.assert_allclose(be.host(Z2), z.detach().numpy(), atol=2e-5)
     np.testing.assert_allclose(be.host(FEAT), ft.detach().numpy(), atol=5e-5)
-    DZ2, DW, DBC, SUMS = be.zeros((B, C, Wd)), be.dev(np.ones((C, C), np.float32)), be.zeros(C), be.zeros(2 * C, np.float64)
-    ok(be.lib.eegclip_proj1x1_bwd(be.ptr(DF), be.ptr(Z2), be.ptr(WC), be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(DZ2), be.ptr(DW),
-                                  be.ptr(DBC), be.ptr(SUMS), B, p, SEED, 2, be.stream))
-    np.testing.assert_allclose(be.host(DW) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
-    np.testing.assert_allclose(be.host(DBC), bct.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bct.grad.numpy()).max()))
+    sums_seen = []
+    for use_ws in (False, True):        # atomics on dW / dbias / sums, then per-workgroup partial rows + column reduction
+        DZ2, DW, DBC, SUMS = be.zeros((B, C, Wd)), be.dev(np.ones((C, C), np.float32)), be.zeros(C), be.zeros(2 * C, np.float64)
+        nws = int(be.lib.eegclip_proj1x1_bwd_workspace_floats(B))
+        assert nws == 2 * B * (C * C + 3 * C)
+        WSP = be.dev(np.full(nws // 2, np.nan, np.float64)) if use_ws else None
+        ok(be.lib.eegclip_proj1x1_bwd(be.ptr(DF), be.ptr(Z2), be.ptr(WC), be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(DZ2), be.ptr(DW),
+                                      be.ptr(DBC), be.ptr(SUMS), be.ptr(WSP) if use_ws else None, B, p, SEED, 2, be.stream))
+        np.testing.assert_allclose(be.host(DW) - 1.0, wt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+        np.testing.assert_allclose(be.host(DBC), bct.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bct.grad.numpy()).max()))
+        sums_seen.append(be.host(SUMS).copy())
+    np.testing.assert_allclose(sums_seen[1], sums_seen[0], rtol=1e-9, atol=1e-9)
     DY2, DG, DB = be.zeros((B, C, Wd)), be.zeros(C), be.zeros(C)
     ok(be.lib.eegclip_bn_elu_bwd_apply(be.ptr(DZ2), be.ptr(Y2), be.ptr(MU), be.ptr(RS), be.ptr(G), be.ptr(BT), be.ptr(SUMS), None, float(B * Wd),
                                        be.ptr(DY2), be.ptr(DG), be.ptr(DB), B, C, Wd, p, SEED, 2, be.stream))
