@@ -104,7 +104,8 @@ PROTOTYPES = {
     "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_cast_bf16": [_P, _P, _L, _P],
     "eegclip_logits_bf16": [_P, _P, _P, _I, _I, _I, _L, _P, _P],
-    "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "eegclip_tsconv_fwd_workspace_floats": [_I, _I],
+    "eegclip_tsconv_fwd": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P],
     "eegclip_tsconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
@@ -112,7 +113,8 @@ PROTOTYPES = {
     "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_sconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_sconv_bwd_w": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "eegclip_sconv_bwd_x_stats_workspace_floats": [_I],
+    "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_sconv_bwd_x_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],
     "eegclip_lse_cols": [_P, _I, _I, _L, _P, _P, _P],

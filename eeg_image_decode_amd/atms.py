@@ -581,8 +581,10 @@ class _Engine:
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
         pl.memset(b["zf"])
+        if "tsf_ws" not in b:
+            b["tsf_ws"] = torch.empty(int(lib().eegclip_tsconv_fwd_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
         pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
-                C_TS, _p(sums[0]) if train else None)
+                C_TS, _p(sums[0]) if train else None, _p(b["tsf_ws"]))
         W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
@@ -714,7 +716,9 @@ class _Engine:
         wt = (None, None)
         if pl.precision == _abi.PREC_BF16X3:
             wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
-        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), B, N_CH)
+        if "scx_ws" not in b:
+            b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
+        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
         local1 = None
         if W > 1:
             local1 = torch.zeros_like(sums[3])

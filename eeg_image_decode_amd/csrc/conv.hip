@@ -74,7 +74,8 @@ __device__ __forceinline__ void box_filter_row(float* __restrict__ srow, float* 
 constexpr int TSF_R = 32;                       // token rows per work item: 32*36/16 = 72 position tiles, 18 per wave; 8 rows per wave
 __global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict__ x, long long xs_b, long long xs_h,
                                                           const float* __restrict__ w25, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int B, int H, double* __restrict__ sums, int vec2) {
+                                                          float* __restrict__ y, int B, int H, double* __restrict__ sums, double* __restrict__ partials,
+                                                          int vec2) {
     EEG_LDS_BASE(float, lds);
     float* wl = lds;                             // [28][48]  taps-major: A operand (filters) read = 16 consecutive floats
     float* sl = wl + TS_KP * TS_CP;              // [32][256] box-filtered rows
@@ -157,8 +158,13 @@ __global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict
         if (t < TS_C) {
             double s = 0.0, q = 0.0;
             for (int k = 0; k < 4; ++k) { s += sc[(k * 2 + 0) * TS_CP + t]; q += sc[(k * 2 + 1) * TS_CP + t]; }
-            atomicAdd(sums + t, s);
-            atomicAdd(sums + TS_C + t, q);
+            if (partials) {                       // a partial row per workgroup, column-summed by colsum_f64_kernel (504-way contended atomics otherwise)
+                partials[(long long)blockIdx.x * 2 * TS_C + t] = s;
+                partials[(long long)blockIdx.x * 2 * TS_C + TS_C + t] = q;
+            } else {
+                atomicAdd(sums + t, s);
+                atomicAdd(sums + TS_C + t, q);
+            }
         }
     }
 }
@@ -451,14 +457,22 @@ static int ts_vec2(const float* x, long long xs_b, long long xs_h) {
     return ((reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (xs_b & 1) == 0 && (xs_h & 1) == 0) ? 1 : 0;
 }
 
+static int tsf_grid(int B, int H) {
+    const int nchunks = (B * H + TSF_R - 1) / TSF_R;
+    return nchunks < 1024 ? nchunks : 1024;
+}
+extern "C" long long eegclip_tsconv_fwd_workspace_floats(int B, int H) { return B < 1 || H < 1 ? 0 : 2LL * tsf_grid(B, H) * 2 * TS_C; }   // (doubles, in floats)
+
 extern "C" int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, float* y,
-                                  int B, int H, int T, int C, double* sums, void* stream) {
+                                  int B, int H, int T, int C, double* sums, float* workspace, void* stream) {
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!x || !w25 || !bias || !y) return EEGCLIP_EINVAL;
-    const int nchunks = (B * H + TSF_R - 1) / TSF_R;
-    int grid = nchunks < 1024 ? nchunks : 1024;
+    if (reinterpret_cast<uintptr_t>(workspace) & 7u) return EEGCLIP_EALIGN;
+    const int grid = tsf_grid(B, H);
     const size_t lds = (TS_KP * TS_CP + TSF_R * TS_XS + 4 * TS_XS + 8 * TS_CP) * sizeof(float);
-    EEG_LAUNCH(tsconv_fwd_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, w25, bias, y, B, H, sums, ts_vec2(x, xs_b, xs_h));
+    double* parts = sums ? reinterpret_cast<double*>(workspace) : nullptr;
+    EEG_LAUNCH(tsconv_fwd_kernel, dim3(grid), dim3(256), lds, stream, x, xs_b, xs_h, w25, bias, y, B, H, sums, parts, ts_vec2(x, xs_b, xs_h));
+    if (parts) EEG_COLSUM_F64((const double*)parts, grid, 2 * TS_C, sums, stream);
     return (int)hipGetLastError();
 }
 

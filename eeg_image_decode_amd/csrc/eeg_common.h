@@ -358,4 +358,28 @@ __device__ __forceinline__ void x3_split4(float v0, float v1, float v2, float v3
 }
 
 
+// ---- column sums of per-workgroup partial rows (fp64): out[c] += sum_p partials[p][c].  The BatchNorm-statistics producers used to add their 80
+// per-channel sums with fp64 atomics straight from every workgroup: 500..1300-way contention per address, ~0.2 ns per atomic device-wide, i.e.
+// 8..20 us inside kernels of 45..65 us.  grid (column blocks of 64, COLSUM_SLICES slices of the rows): COLSUM_SLICES atomics per address.
+constexpr int COLSUM_SLICES = 8;
+template <int UNUSED>
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restrict__ partials, int nparts, int ncols, double* __restrict__ out) {
+    EEG_LDS_BASE(double, red);   // [4][64]
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (c < ncols) {
+        const int per = (nparts + COLSUM_SLICES - 1) / COLSUM_SLICES;
+        const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+#pragma unroll 8
+        for (int p = p0 + g; p < p1; p += 4) s += partials[(long long)p * ncols + c];
+    }
+    red[g * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0 && c < ncols) atomicAdd(out + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));
+}
+#define EEG_COLSUM_F64(partials, nparts, ncols, out, stream)                                                                               \
+    EEG_LAUNCH((eeg::colsum_f64_kernel<0>), dim3(((ncols) + 63) / 64, (nparts) < eeg::COLSUM_SLICES ? (nparts) : eeg::COLSUM_SLICES), dim3(256),       \
+               256 * sizeof(double), stream, partials, nparts, ncols, out)
+
 }  // namespace eeg

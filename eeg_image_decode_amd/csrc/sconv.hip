@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
                                                            const unsigned short* __restrict__ wt_hi, const unsigned short* __restrict__ wt_lo,
                                                            const float* __restrict__ y1, const bn_affine bn, double* __restrict__ sums,
                                                            const double* __restrict__ sums_param, double count, float* __restrict__ dy1,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, double* __restrict__ partials, int B, int H) {
     EEG_LDS_BASE(float, lds);
     float* dl = lds;                          // !X3: [40][48] dy2[o][w] (cols >= 36 zero)   X3: two bf16 planes [48 w][144 B] of dy2^T
     float* sl = dl + (X3 ? 2 * SC_OP * SCX_RS / 4 : SC_C * SC_OP);            // [80] per-workgroup channel sums
@@ -718,7 +718,12 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
     }
     if (!APPLY) {
         __syncthreads();
-        if (t < 2 * SC_C) atomicAdd(sums + t, (double)sl[t]);
+        if (t < 2 * SC_C) {
+            // (partials: one row of 80 sums per workgroup, column-summed by colsum_f64_kernel -- 1280 workgroups adding into 80 addresses were
+            // ~20 us of atomics in this 65-us kernel)
+            if (partials) partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * SC_C) + t] = (double)sl[t];
+            else          atomicAdd(sums + t, (double)sl[t]);
+        }
     }
 }
 
@@ -797,23 +802,28 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
 
 static bool scx_planes_ok(const void* hi, const void* lo) { return hi && lo && sc_aligned16(hi) && sc_aligned16(lo); }
 
+extern "C" long long eegclip_sconv_bwd_x_stats_workspace_floats(int B) { return B < 1 ? 0 : 2LL * B * SCX_GY * 2 * SC_C; }     // (doubles, in floats)
+
 extern "C" int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
-                                         const float* rstd, const float* gamma, const float* beta, double* sums, int B, int H, void* stream) {
+                                         const float* rstd, const float* gamma, const float* beta, double* sums, float* workspace, int B, int H,
+                                         void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!dy2 || !Ws || !y1 || !mean || !rstd || !gamma || !beta || !sums) return EEGCLIP_EINVAL;
     if ((WsT_hi == nullptr) != (WsT_lo == nullptr)) return EEGCLIP_EINVAL;
-    if (!sc_aligned16(y1) || (WsT_hi && !scx_planes_ok(WsT_hi, WsT_lo))) return EEGCLIP_EALIGN;
+    if (!sc_aligned16(y1) || (WsT_hi && !scx_planes_ok(WsT_hi, WsT_lo)) || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
     const unsigned short *wh = (const unsigned short*)WsT_hi, *wl = (const unsigned short*)WsT_lo;
+    double* parts = reinterpret_cast<double*>(workspace);
     if (wh) {
         const size_t lds = 2 * SC_OP * SCX_RS + 2 * SC_C * sizeof(float);
         EEG_LAUNCH((sconv_bwd_x_kernel<false, true>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, sums, (const double*)nullptr, 1.0,
-                   (float*)nullptr, (float*)nullptr, (float*)nullptr, B, H);
+                   (float*)nullptr, (float*)nullptr, (float*)nullptr, parts, B, H);
     } else {
         const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
         EEG_LAUNCH((sconv_bwd_x_kernel<false, false>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, sums, (const double*)nullptr, 1.0,
-                   (float*)nullptr, (float*)nullptr, (float*)nullptr, B, H);
+                   (float*)nullptr, (float*)nullptr, (float*)nullptr, parts, B, H);
     }
+    if (parts) EEG_COLSUM_F64((const double*)parts, B * SCX_GY, 2 * SC_C, sums, stream);
     return (int)hipGetLastError();
 }
 
@@ -829,11 +839,11 @@ extern "C" int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, cons
     if (wh) {
         const size_t lds = 2 * SC_OP * SCX_RS + 2 * SC_C * sizeof(float);
         EEG_LAUNCH((sconv_bwd_x_kernel<true, true>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, const_cast<double*>(sums),
-                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, (double*)nullptr, B, H);
     } else {
         const size_t lds = (SC_C * SC_OP + 2 * SC_C) * sizeof(float);
         EEG_LAUNCH((sconv_bwd_x_kernel<true, false>), dim3(B, SCX_GY), dim3(256), lds, stream, dy2, Ws, wh, wl, y1, bn, const_cast<double*>(sums),
-                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, B, H);
+                   sums_local ? sums_local : sums, count, dy1, dgamma, dbeta, (double*)nullptr, B, H);
     }
     return (int)hipGetLastError();
 }

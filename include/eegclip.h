@@ -248,8 +248,11 @@ int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int 
  * fwd optionally accumulates the BatchNorm batch sums of y into sums (double[80], zeroed by the caller).
  * bwd_w: dw25 += sum over workgroup partials (two-stage reduction through the caller's `workspace`).
  * bwd_x overwrites dx rows h < H. */
+/* workspace (optional, 8-byte aligned, eegclip_tsconv_fwd_workspace_floats(B, H) floats): the BatchNorm batch sums leave every workgroup as a
+ * partial row and are column-summed by a second kernel instead of contended fp64 atomics */
+long long eegclip_tsconv_fwd_workspace_floats(int B, int H);
 int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, float* y, int B, int H,
-                       int T, int C, double* sums, void* stream);
+                       int T, int C, double* sums, float* workspace, void* stream);
 long long eegclip_tsconv_bwd_w_workspace_floats(int B, int H);   /* size of `workspace` below (per-workgroup partial tap gradients) */
 int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs_h, const float* dy, float* dw25, float* workspace, int B, int H,
                          int T, int C, void* stream);
@@ -278,8 +281,11 @@ int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, c
 /* WsT_hi / WsT_lo (both or neither): bf16 planes of Ws^T, [(c,h)][64 o] -- eegclip_split_rows{src = Ws, rows = 40, cols = 40 H, ld_src = 40 H,
  * ld_out = 64, transpose = 1}, 16-byte aligned.  Given: the K = 40 contraction runs as split-bf16 products (hi*lo + lo*hi + hi*hi on the bf16
  * matrix cores, fp32 accumulate: ~2^-16 relative per term, as EEGCLIP_PREC_BF16X3); NULL: exact fp32 products. */
+/* workspace (optional, 8-byte aligned, eegclip_sconv_bwd_x_stats_workspace_floats(B) floats): the 80 sums leave every workgroup as a partial row and
+ * are column-summed by a second kernel instead of 1280-way contended fp64 atomics. */
+long long eegclip_sconv_bwd_x_stats_workspace_floats(int B);
 int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
-                              const float* rstd, const float* gamma, const float* beta, double* sums, int B, int H, void* stream);
+                              const float* rstd, const float* gamma, const float* beta, double* sums, float* workspace, int B, int H, void* stream);
 int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, const double* sums, const double* sums_local,
                               double count, float* dy1, float* dgamma, float* dbeta, int B, int H, void* stream);

@@ -289,7 +289,11 @@ def test_tsconv_fwd_bwd(be, B, H):
     xfull = rnd(rng, B, 64, 250)                       # encoder output; rows h < H are convolved in place
     W25, BIAS, X = be.dev(w25), be.dev(bias), be.dev(xfull)
     Y, SUMS = be.zeros((B, 40, H, 36)), be.zeros(80, np.float64)
-    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS), be.stream))
+    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS), None, be.stream))
+    SUMS_W = be.zeros(80, np.float64)           # the same sums through per-workgroup partial rows + a column reduction
+    WSF = be.dev(np.full(int(be.lib.eegclip_tsconv_fwd_workspace_floats(B, H)) // 2, np.nan, np.float64))
+    ok(be.lib.eegclip_tsconv_fwd(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS), be.ptr(Y), B, H, 250, 40, be.ptr(SUMS_W), be.ptr(WSF), be.stream))
+    np.testing.assert_allclose(be.host(SUMS_W), be.host(SUMS), rtol=1e-9, atol=1e-9)
     xt = torch.tensor(xfull, dtype=torch.float64, requires_grad=True)
     wt = torch.tensor(w25, dtype=torch.float64, requires_grad=True)
     bt = torch.tensor(bias, dtype=torch.float64)
@@ -528,15 +532,17 @@ def test_fused_spatial_stage(be, B, H):
     ok(be.lib.eegclip_split_rows(it, 1, be.stream))
     for planes in ((None, None), (be.ptr(WH), be.ptr(WL))):
         SUMS, DY1, DG, DB = be.zeros(80, np.float64), be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
+        nws = int(be.lib.eegclip_sconv_bwd_x_stats_workspace_floats(B))
+        WSX = be.dev(np.full(nws // 2, np.nan, np.float64)) if planes[0] else None       # (partial rows + column sums | atomics)
         ok(be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), *planes, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
-                                            B, H, be.stream))
+                                            be.ptr(WSX) if planes[0] else None, B, H, be.stream))
         ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), *planes, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
                                             None, float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
         np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
         np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
         np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
     assert be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(WH), None, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
-                                            be.ptr(SUMS), B, H, be.stream) < 0
+                                            be.ptr(SUMS), None, B, H, be.stream) < 0
 
 
 def _bf16_round(a):

@@ -15,6 +15,6 @@ def t(fn, n=10):
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-print("fwd   %.1f us" % t(lambda: L.eegclip_tsconv_fwd(x.data_ptr(), 16000, 250, w25.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, 250, 40, sums.data_ptr(), st)))
+print("fwd   %.1f us" % t(lambda: L.eegclip_tsconv_fwd(x.data_ptr(), 16000, 250, w25.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, 250, 40, sums.data_ptr(), None, st)))
 print("bwd_w %.1f us" % t(lambda: L.eegclip_tsconv_bwd_w(x.data_ptr(), 16000, 250, dy.data_ptr(), dw25.data_ptr(), ws.data_ptr(), B, H, 250, 40, st)))
 print("bwd_x %.1f us" % t(lambda: L.eegclip_tsconv_bwd_x(dy.data_ptr(), w25.data_ptr(), dx.data_ptr(), 16000, 250, B, H, 250, 40, st)))
