@@ -363,7 +363,8 @@ def main():
     # and a cold GPU needs a few hundred milliseconds of load to reach its sustained clocks
     t_ramp = time.perf_counter()
     i_ramp = 0
-    while time.perf_counter() - t_ramp < 0.4 or i_ramp < 3:
+    # (several ranks: every step holds collectives, so all ranks must run the SAME number of steps -- a fixed count, not a time-based one)
+    while (time.perf_counter() - t_ramp < 0.4 or i_ramp < 3) if world == 1 else i_ramp < 48:
         step(i_ramp)
         i_ramp += 1
         if i_ramp % 16 == 0:

@@ -76,3 +76,24 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_global_batch_step():
         assert d.mean() < 6e-6 and d.max() <= 6.1e-4, (k, d.mean(), d.max())       # Adam step 1 = lr * sign(g): round-off-sized g may flip
     for k in bn0:
         np.testing.assert_allclose(bn0[k], tr.P[k].numpy(), atol=2e-5, err_msg=k)
+
+
+def test_bench_runs_on_two_ranks_and_prints_one_json_line():
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one process per rank; here both ranks on the one GPU through
+    gloo): every rank must issue the same number of steps -- a time-based warm-up loop once ran a different count on each rank and hung the
+    collectives -- and rank 0 prints exactly one JSON line with the whole-job throughput."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EEGCLIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["global_batch"] == 512 and d["value"] > 0 and d["scaling"] == "weak"
