@@ -773,10 +773,13 @@ class _Engine:
         wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
               bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
         pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
-                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=1, planes=PLT["qkv"])                # dr1 := dh
-        # embedding: dropout + token row + value embedding
+                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=2, drop_p=pe_, drop_site=SITE_EMBED, planes=PLT["qkv"])
+        # ^ dr1 := dropout'(dh): the embedding dropout's backward (Embed.py:162) is the epilogue of the GEMM that completes dh -- accumulate FIRST
+        #   (residual-path gradient already in dr1), then the mask of the (B,64,250) element index = m * 250 + n -- instead of a separate in-place
+        #   pass over the 16 MB tensor (35 us in the step)
+        # embedding: token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
-        pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
+        pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, 0.0, 0, SITE_EMBED)
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)

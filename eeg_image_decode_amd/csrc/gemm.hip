@@ -653,7 +653,8 @@ static int gemm_desc_check(const eegclip_gemm_desc& d) {
     if (d.M == 0 || d.N == 0) return 0;                  /* nothing to compute (callers skip the launch) */
     if (d.K > 0 && (!d.A || !d.B)) return EEGCLIP_EINVAL;
     if (d.split_k < 1) return EEGCLIP_EINVAL;
-    if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre)) return EEGCLIP_EINVAL;
+    if (d.split_k > 1 && (d.act != EEGCLIP_ACT_NONE || d.drop_p > 0.f || d.R || d.Cpre || d.accumulate == 2)) return EEGCLIP_EINVAL;
+    if (d.accumulate < 0 || d.accumulate > 2) return EEGCLIP_EINVAL;
     if (d.drop_p < 0.f || d.drop_p >= 1.f || d.act < 0 || d.act > EEGCLIP_ACT_GELU_GRAD) return EEGCLIP_EINVAL;
     if ((d.precision & 0xff) != EEGCLIP_PREC_F32 && (d.precision & 0xff) != EEGCLIP_PREC_BF16X3) return EEGCLIP_EINVAL;
     if ((d.precision >> 8) < 0 || (d.precision >> 8) > 6) return EEGCLIP_EINVAL;

@@ -34,6 +34,7 @@ __device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d
         atomicAdd(d.C + coff, v);
         return;
     }
+    if (d.accumulate == 2) v += d.C[coff];               // accumulate FIRST: the old C goes through the rest of the chain (dropout of a sum)
     if (d.Cpre) d.Cpre[coff] = v;
     if (d.act == EEGCLIP_ACT_GELU) v = gelu_erf(v);
     else if (d.act == EEGCLIP_ACT_SILU) v = silu(v);
@@ -43,7 +44,7 @@ __device__ __forceinline__ void gemm_epilogue_element(const eegclip_gemm_desc& d
     }
     if (d.act == EEGCLIP_ACT_GELU_GRAD) v *= gelu_erf_grad(d.R[roff]);
     else if (d.R) v += d.R[roff];
-    if (d.accumulate) v += d.C[coff];
+    if (d.accumulate == 1) v += d.C[coff];
     d.C[coff] = v;
 }
 
@@ -211,6 +212,10 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
                 }
                 continue;
             }
+            if (d.accumulate == 2) {                               // accumulate FIRST (see gemm_epilogue_element)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += oo[nt][e];
+            }
             if (d.Cpre && row_ok) {
                 if (vc) *reinterpret_cast<f32x4a4_t*>(d.Cpre + c0) = f32x4a4_t{v[0], v[1], v[2], v[3]};
                 else {
@@ -230,9 +235,13 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
                 const unsigned long long idx = (unsigned long long)mm * (unsigned)d.N + (unsigned)n;
                 bool keep[4];
                 if ((d.N & 3) == 0) dropout_keep4(d.seed, d.drop_site, idx, d.drop_p, keep);       // the lane's 4 outputs are ONE Philox block
-                else {
+                else {                                                                             // rows start off a block boundary: at most two blocks
+                    const unsigned off = (unsigned)(idx & 3ull);
+                    bool k0[4], k1[4];
+                    dropout_keep4(d.seed, d.drop_site, idx - off, d.drop_p, k0);
+                    if (off) dropout_keep4(d.seed, d.drop_site, idx - off + 4, d.drop_p, k1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) keep[e] = dropout_keep(d.seed, d.drop_site, idx + e, d.drop_p);
+                    for (int e = 0; e < 4; ++e) keep[e] = (off + e < 4) ? k0[(off + e) & 3] : k1[(off + e) & 3];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * keep_scale : 0.f;
@@ -246,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const eegclip_gemm_desc& d, cons
                     for (int e = 0; e < 4; ++e) v[e] += rr[nt][e];
                 }
             }
-            if (d.accumulate) {
+            if (d.accumulate == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += oo[nt][e];
             }

@@ -78,7 +78,8 @@ typedef struct {
     const float* R;       /* residual or NULL */
     eegclip_dim Rm, Rn;
     float alpha;
-    int accumulate;       /* 1: C += result */
+    int accumulate;       /* 1: C += result (after the epilogue chain).  2: the old C is added FIRST and goes through the chain with the product:
+                             C = epilogue(alpha * A B + bias + C_old) -- dropout of a sum of two gradient contributions in one pass */
     int act;              /* EEGCLIP_ACT_* */
     float drop_p;         /* 0 = no dropout */
     unsigned long long seed;

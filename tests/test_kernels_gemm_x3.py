@@ -307,3 +307,21 @@ def test_x3_value_embedding_weight_gradient_through_the_workspace(be, split_k):
     g = dout[:, 1:, :].reshape(-1, Dm)
     np.testing.assert_allclose(be.host(W), w0 + x3_ref(g.T, x.reshape(-1, T)), atol=2e-4)
     np.testing.assert_allclose(be.host(RS), g.astype(np.float64).sum(0), atol=2e-4)
+
+
+@pytest.mark.parametrize("prec_", [0, _abi.PREC_BF16X3])
+@pytest.mark.parametrize("N", [92, 250])
+def test_gemm_accumulate_first_then_dropout(be, prec_, N):
+    """accumulate = 2: C = dropout(alpha A B + bias + C_old) -- the dropout backward of a sum of two gradient contributions as the epilogue of the
+    GEMM that produces the second one (rows of 250 floats start off the 4-element Philox blocks: two blocks per lane)"""
+    rng = np.random.default_rng(7 + N)
+    M, K = 70, 40
+    a, w, bn, c0 = f32(rng, M, K), f32(rng, K, N), f32(rng, N), f32(rng, M, N)
+    A, W, BN, C = be.dev(a), be.dev(w), be.dev(bn), be.dev(c0)
+    p, seed, site = 0.25, 0x0BADC0FFEE123457, 6
+    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(N), D(1), C, D(N), D(1), bias_n=be.ptr(BN), accumulate=2, drop_p=p, seed=seed, drop_site=site, precision=prec_))
+    keep = keep_mask(seed, site, M * N, p).reshape(M, N)
+    prod = x3_ref(a, w) if prec_ else a.astype(np.float64) @ w.astype(np.float64)
+    np.testing.assert_allclose(be.host(C), (prod + bn + c0) * keep / (1 - p), atol=4e-5)
+    d = mk(be, M, N, K, A, D(K), D(1), W, D(N), D(1), C, D(N), D(1), accumulate=2, split_k=2, precision=prec_)
+    assert be.lib.eegclip_gemm_f32(ctypes.byref(d), be.stream) < 0          # (no accumulate-first across K slices)
