@@ -82,7 +82,7 @@ def pmc_traffic(family, B):
     return (round(d["hbm_bytes_per_launch"]), PMC_SUMMARY) if d and "hbm_bytes_per_launch" in d else (None, None)
 
 
-TIME_EVERY = 4
+TIME_EVERY = 8
 
 
 def family_of(name, desc):
@@ -408,7 +408,7 @@ def main():
         for k, idx in fam_ops.get(dominant, []):
             by_plan.setdefault(k, []).append(idx)
         # every launch of the family is timed on every TIME_EVERY-th step of the timed region (two HIP events per launch: ~40 per step for the GEMM
-        # family, ~0.1 ms of a 1.3 ms step if recorded on every step -- instrumentation the product does not carry)
+        # family, ~0.1 ms of a 1.2 ms step if recorded on every step -- instrumentation the product does not carry; 3+ sampled steps x 20 launches)
         for k, idxs in by_plan.items():
             plans[k].time_ops(idxs, every=TIME_EVERY if args.steps >= 2 * TIME_EVERY else 1)
 
