@@ -69,6 +69,8 @@ PROTOTYPES = {
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_residual_layernorm_fwd": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P],
+    "eegclip_layernorm_bwd_full_workspace_floats": [_I, _I],
+    "eegclip_layernorm_bwd_full": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P, _P],
     "eegclip_layernorm_bwd_params_workspace_floats": [_I, _I],
     "eegclip_layernorm_bwd_params": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "eegclip_layernorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],

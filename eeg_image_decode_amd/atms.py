@@ -653,6 +653,10 @@ class _Engine:
         if "lnp_ws" not in b:
             b["lnp_ws"] = torch.empty(int(lib().eegclip_layernorm_bwd_params_workspace_floats(R, D_MODEL)), dtype=torch.float32, device=self.device)
         lnp_ws = _p(b["lnp_ws"])
+        # ... or, fused (default): the input-gradient kernel of those LayerNorms leaves the partial rows itself -- one pass over dy / x instead of two
+        if "lnf_ws" not in b:
+            b["lnf_ws"] = torch.empty(int(lib().eegclip_layernorm_bwd_full_workspace_floats(R, D_MODEL)), dtype=torch.float32, device=self.device)
+        lnf_ws = _p(b["lnf_ws"])
         pl.memset(b["zb"])                        # BatchNorm backward sums + the split-K accumulators dgu / dfeat
         # head LayerNorm
         pl.dout_op = len(pl.ops)
@@ -742,17 +746,13 @@ class _Engine:
             pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         # final LN, LN2
-        pl.call("eegclip_layernorm_bwd", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
-                None, None, R, D_MODEL, 0, None, 0.0, 0, 0)
-        pl.call("eegclip_layernorm_bwd_params", _p(b["dn3"]), _p(b["n2"]), _p(b["mu3"]), _p(b["rs3"]),
-                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, lnp_ws, side=ln_side)
+        pl.call("eegclip_layernorm_bwd_full", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
+                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, lnf_ws)
         # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2).  LN2 backward emits dr2 (residual path) and df2 = dropout'(dr2);
         # bias gradients ride on the weight-gradient GEMMs; dropout' and gelu' of the hidden activation are the epilogue of the GEMM
         # that produces its gradient -- 5 elementwise / reduction passes over (B*64, 250..256) tensors gone
-        pl.call("eegclip_layernorm_bwd", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
-                None, None, R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, seed_at=13)
-        pl.call("eegclip_layernorm_bwd_params", _p(b["dn2"]), _p(b["r2"]), _p(b["mu2"]), _p(b["rs2"]),
-                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, lnp_ws, side=ln_side)
+        pl.call("eegclip_layernorm_bwd_full", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
+                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, lnf_ws, seed_at=13)
         wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
         pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
                 act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PLT["ffn2"])                  # dg1 := df1
@@ -760,10 +760,8 @@ class _Engine:
         pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
                 accumulate=1, planes=PLT["ffn1"])                                              # dr2 := dn1
         # attention block: r1 = h + dropout(Wo ctx + bo)
-        pl.call("eegclip_layernorm_bwd", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
-                None, None, R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, seed_at=13)
-        pl.call("eegclip_layernorm_bwd_params", _p(b["dr2"]), _p(b["r1"]), _p(b["mu1"]), _p(b["rs1"]),
-                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, lnp_ws, side=ln_side)
+        pl.call("eegclip_layernorm_bwd_full", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
+                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, lnf_ws, seed_at=13)
         wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
               bias=_LY + "attention.out_projection.bias")
         pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),

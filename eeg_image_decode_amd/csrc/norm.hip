@@ -196,12 +196,20 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
 // a wave-uniform case) instead of four: with a lane-strided column map the 4.1 M Philox evaluations of a (16384, 250) tensor, not
 // HBM, set this kernel's time.  A fused variant that also accumulated dgamma / dbeta (LDS combine + one atomic per column and
 // workgroup) measured slower than this + the column-parallel kernel below: 1024 same-address atomics per parameter.
-template <int NG, bool VEC2>
+// PART: the kernel also leaves this workgroup's share of the parameter gradients (sum_rows dy * xhat | sum_rows dy, per column) as one partial row
+// in `partials` -- the operands are in registers anyway; layernorm_bwd_param_stage2_kernel sums the rows.  (With atomics instead of partial rows
+// this fusion lost; see the note above.)
+template <int NG, bool VEC2, bool PART = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
                                                                 int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
-                                                                unsigned long long seed, unsigned site) {
+                                                                unsigned long long seed, unsigned site, float* __restrict__ partials) {
+    float pgam[PART ? NG : 1][4], pbet[PART ? NG : 1][4];
+#pragma unroll
+    for (int i = 0; i < (PART ? NG : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pgam[i][e] = 0.f; pbet[i][e] = 0.f; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
                 g[i][e] = dv[e] * gv[e];
                 s1 += g[i][e];
                 s2 += g[i][e] * xh[i][e];
+                if (PART) { pgam[i][e] += dv[e] * xh[i][e]; pbet[i][e] += dv[e]; }
             }
         }
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
@@ -292,6 +301,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
                     }
                 }
             }
+        }
+    }
+    if (PART) {
+        // cross-wave combine through LDS (dynamic: [3][2][NG * 256] floats), wave 0 writes the partial row [dgamma | dbeta]
+        EEG_LDS_BASE(float, red);
+        constexpr int W = NG * 256;
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[((wave - 1) * 2 + 0) * W + 256 * i + 4 * lane + e] = pgam[i][e];
+                    red[((wave - 1) * 2 + 1) * W + 256 * i + 4 * lane + e] = pbet[i][e];
+                }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float* out = partials + (long long)blockIdx.x * 2 * cols;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 256 * i + 4 * lane + e;
+                    if (c < cols) {
+                        float gsum = pgam[i][e], bsum = pbet[i][e];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) { gsum += red[(w * 2 + 0) * W + c]; bsum += red[(w * 2 + 1) * W + c]; }
+                        out[c] = gsum;
+                        out[cols + c] = bsum;
+                    }
+                }
         }
     }
 }
@@ -617,7 +657,7 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
                                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop)) & 7u);
 #define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
     EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, \
-               drop_p, seed, site)
+               drop_p, seed, site, (float*)nullptr)
     if (want_dx) {
         if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
         else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
@@ -629,6 +669,32 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
         EEG_LAUNCH(layernorm_bwd_param_kernel, dim3(chunks, (cols + 63) / 64), dim3(256), 512 * sizeof(float), stream, dy, x, mean, rstd, dgamma,
                    dbeta, rows, cols);
     }
+    return (int)hipGetLastError();
+}
+
+// dx (+ dropout'(dx)) AND the parameter gradients from ONE pass over dy / x: the input-gradient kernel leaves per-workgroup partial rows,
+// stage 2 sums them.  workspace: eegclip_layernorm_bwd_full_workspace_floats(rows, cols) floats.
+static int lnf_grid(int rows) { const int g = (rows + 15) / 16; return g < 1 ? 1 : (g > 1024 ? 1024 : g); }
+extern "C" long long eegclip_layernorm_bwd_full_workspace_floats(int rows, int cols) { return rows < 1 || cols < 1 ? 0 : (long long)lnf_grid(rows) * 2 * cols; }
+
+extern "C" int eegclip_layernorm_bwd_full(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                          float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p,
+                                          unsigned long long seed, unsigned int site, float* workspace, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows < 0 || cols < 1 || cols > 64 * LN_MAXC) return EEGCLIP_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const int parts = lnf_grid(rows);
+    const dim3 grid(parts);
+    const bool vec2 = (cols % 2 == 0) && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop)) & 7u);
+#define EEG_LNF_GO(NG, V2)                                                                                                                         \
+    EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2, true>), grid, dim3(256), 3 * 2 * NG * 256 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, rows, \
+               cols, accumulate_dx, dx_drop, drop_p, seed, site, workspace)
+    if (cols <= 256) { if (vec2) EEG_LNF_GO(1, true); else EEG_LNF_GO(1, false); }
+    else             { if (vec2) EEG_LNF_GO(4, true); else EEG_LNF_GO(4, false); }
+#undef EEG_LNF_GO
+    const int slices = parts < LNP_SLICES ? parts : LNP_SLICES;
+    EEG_LAUNCH(layernorm_bwd_param_stage2_kernel, dim3((2 * cols + 63) / 64, slices), dim3(256), 256 * sizeof(float), stream, workspace, parts, cols, dgamma, dbeta);
     return (int)hipGetLastError();
 }
 

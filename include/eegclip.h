@@ -139,6 +139,12 @@ int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, c
 /* the parameter half of eegclip_layernorm_bwd (dgamma += sum_rows dy*xhat, dbeta += sum_rows dy) through a caller-owned workspace of
  * eegclip_layernorm_bwd_params_workspace_floats(rows, cols) floats (contents irrelevant): per-workgroup partial rows + a column reduction
  * instead of hundreds of contended atomics per column (the atomic form is bound by them: 19 us for 16384 x 250; this one streams). */
+/* eegclip_layernorm_bwd with both halves in ONE pass over dy / x: the input-gradient kernel leaves the parameter-gradient partial rows in
+ * `workspace` (eegclip_layernorm_bwd_full_workspace_floats(rows, cols) floats), a column reduction adds them into dgamma / dbeta. */
+long long eegclip_layernorm_bwd_full_workspace_floats(int rows, int cols);
+int eegclip_layernorm_bwd_full(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+                               float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p, unsigned long long seed,
+                               unsigned int site, float* workspace, void* stream);
 long long eegclip_layernorm_bwd_params_workspace_floats(int rows, int cols);
 int eegclip_layernorm_bwd_params(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                                  int rows, int cols, float* workspace, void* stream);

@@ -52,6 +52,15 @@ def test_layernorm_fwd_bwd(be, rows, cols):
     np.testing.assert_allclose(be.host(DB2), be.host(DB), atol=1e-4 * max(1, rows ** 0.5))
     assert be.lib.eegclip_layernorm_bwd(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), None, None, None, rows, cols, 0, None, 0.0, 0, 0,
                                         be.stream) < 0
+    # both halves in one pass: dx, dropout'(dx) and the parameter gradients (partial rows + column reduction)
+    nwf = int(be.lib.eegclip_layernorm_bwd_full_workspace_floats(rows, cols))
+    WSF, DX4, DXD4 = be.dev(np.full(nwf, np.nan, np.float32)), be.dev(dx0), be.zeros((rows, cols))
+    DG4, DB4 = be.dev(np.full(cols, 0.5, np.float32)), be.dev(np.full(cols, -0.5, np.float32))
+    ok(be.lib.eegclip_layernorm_bwd_full(be.ptr(DY), be.ptr(X), be.ptr(G), be.ptr(MU), be.ptr(RS), be.ptr(DX4), be.ptr(DG4), be.ptr(DB4), rows, cols, 1,
+                                         be.ptr(DXD4), 0.25, SEED, 4, be.ptr(WSF), be.stream))
+    assert np.array_equal(be.host(DX4), be.host(DX)) and np.array_equal(be.host(DXD4), be.host(DXD))
+    np.testing.assert_allclose(be.host(DG4) - 0.5, gt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
+    np.testing.assert_allclose(be.host(DB4) + 0.5, bt.grad.numpy(), atol=1e-4 * max(1, rows ** 0.5))
     # the parameter half without atomics on the inputs' scale: per-workgroup partial rows in a workspace + a column reduction; accumulates
     nws = int(be.lib.eegclip_layernorm_bwd_params_workspace_floats(rows, cols))
     assert nws == (rows + 15) // 16 * 2 * cols
