@@ -134,12 +134,17 @@ PROTOTYPES = {
     "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
+    "eegclip_timing_event_create": [],
+    "eegclip_timing_event_destroy": [_P],
+    "eegclip_time_next_launch": [_P, _P],
+    "eegclip_timing_elapsed_ms": [_P, _P],
 }
+RESTYPES = {"eegclip_timing_event_create": C.c_void_p, "eegclip_timing_elapsed_ms": C.c_float}
 
 
 def plan_functions():
     """entry points the plan executor can dispatch: int f(..., void* stream) -- name -> argument ctypes WITHOUT the trailing stream"""
-    skip = {"eegclip_plan_run"}
+    skip = {"eegclip_plan_run", "eegclip_timing_event_destroy", "eegclip_time_next_launch", "eegclip_timing_elapsed_ms"}
     return {n: a[:-1] for n, a in PROTOTYPES.items() if a and a[-1] is _P and not n.endswith("_floats") and n not in skip}
 
 
@@ -152,6 +157,6 @@ def declare(lib):
     """Attach prototypes; raises AttributeError if the library lacks a symbol the header declares."""
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
-        fn.restype = C.c_longlong if name.endswith(("_floats", "_bytes")) else C.c_int
+        fn.restype = RESTYPES.get(name, C.c_longlong if name.endswith(("_floats", "_bytes")) else C.c_int)
         fn.argtypes = args
     return lib

@@ -9,6 +9,7 @@
 #include "hipemu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #endif
 
 #include <stdint.h>
@@ -16,6 +17,16 @@
 #include "../../include/eegclip.h"
 
 namespace eeg {
+
+#if !defined(EEG_EMU)
+struct launch_events {
+    hipEvent_t start, stop;
+};
+inline launch_events& tls_launch_events() {
+    static thread_local launch_events e{nullptr, nullptr};
+    return e;
+}
+#endif
 
 constexpr int kWave = 64;   // CDNA wavefront width -- hard-coded on purpose (guide section 1)
 
@@ -32,8 +43,19 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define EEG_LDS_BASE(T, name)                                                         \
     extern __shared__ __attribute__((aligned(16))) unsigned char eeg_lds_raw_[];      \
     T* name = reinterpret_cast<T*>(eeg_lds_raw_)
-#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+// eegclip_time_next_launch(start, stop) arms a pair of events for the NEXT kernel this thread launches: the launch then goes through
+// hipExtLaunchKernelGGL, which stamps the events with the kernel's own begin / end timestamps (what rocprofv3 reports) -- no marker packets
+// around the kernel, so neither the dispatch bubbles of an event bracket (~5 us per launch) nor their serialisation end up in the measurement.
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...)                                                                                  \
+    do {                                                                                                                                 \
+        eeg::launch_events& ev_ = eeg::tls_launch_events();                                                                              \
+        if (ev_.start) {                                                                                                                 \
+            hipExtLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), ev_.start, ev_.stop, 0, __VA_ARGS__);            \
+            ev_.start = ev_.stop = nullptr;                                                                                              \
+        } else {                                                                                                                         \
+            hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__);                                       \
+        }                                                                                                                                \
+    } while (0)
 #endif
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -49,6 +49,8 @@ class Plan:
         self.L = lib()
         self.timed = {}        # op index -> list of (start, end) torch.cuda.Event pairs (HIP events on the launch stream)
         self.time_every, self._time_tick = 1, 0
+        self.kernel_timestamps = os.environ.get("EEGCLIP_TIMING", "kernel") != "bracket"      # per-op timing: kernel timestamps | HIP-event brackets
+        self._ev_free, self._ev_used = [], []
         self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
         self.use_side_stream = True
         self.skip = ()         # op indices left out of the next run()s (e.g. the value-embedding GEMMs of subjects absent from the batch)
@@ -236,11 +238,25 @@ class Plan:
         through the normal (un-instrumented) path"""
         self.timed = {i: [] for i in indices}
         self.time_every, self._time_tick = max(1, int(every)), 0
+        self._ev_free.extend(self._ev_used)          # (the previous measurement has been read)
+        self._ev_used = []
+
+    def _timing_event(self):
+        """a library-owned event for eegclip_time_next_launch (recycled across time_ops() calls)"""
+        if self._ev_free:
+            e = self._ev_free.pop()
+        else:
+            e = self.L.eegclip_timing_event_create()
+            if not e:
+                raise RuntimeError("hipEventCreate failed")
+        self._ev_used.append(e)
+        return e
 
     def timings_ms(self):
         import torch
         torch.cuda.synchronize()
-        return {i: [a.elapsed_time(b) for a, b in evs] for i, evs in self.timed.items()}
+        el = self.L.eegclip_timing_elapsed_ms
+        return {i: [(float(el(a, b)) if isinstance(a, int) else a.elapsed_time(b)) for a, b in evs] for i, evs in self.timed.items()}
 
     def run(self, stream, seed=0):
         for d in self._seed_descs:
@@ -270,7 +286,13 @@ class Plan:
             if skip and idx in skip:
                 continue
             use_side = on_side and side is not None
-            if timed and idx in timed:
+            # (single-kernel entry points only: the stamp covers the FIRST kernel a call launches)
+            stamp = timed and idx in timed and name == "eegclip_gemm_f32" and self.kernel_timestamps
+            if stamp:
+                # the kernel's own GPU begin / end timestamps (hipExtLaunchKernel events armed for the next launch): no marker packets around it
+                e0, e1 = self._timing_event(), self._timing_event()
+                self.L.eegclip_time_next_launch(e0, e1)
+            elif timed and idx in timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side[0] if use_side else ts)
             if fn is None:
@@ -302,7 +324,9 @@ class Plan:
                 rc = fn(*args)
                 if rc:
                     check(rc, f"{self.name}:{name}")
-            if timed and idx in timed:
+            if stamp:
+                timed[idx].append((e0, e1))
+            elif timed and idx in timed:
                 e1.record(side[0] if use_side else ts)
                 timed[idx].append((e0, e1))
         if dirty:

@@ -430,6 +430,14 @@ int eegclip_plan_events(int n, void** out);
 int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* const* events,
                      void* join_event, int* dirty, int* failed);
 
+/* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
+ * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
+ * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */
+void* eegclip_timing_event_create(void);
+int eegclip_timing_event_destroy(void* event);
+int eegclip_time_next_launch(void* start, void* stop);
+float eegclip_timing_elapsed_ms(void* start, void* stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ def test_atms_state_dict_matches_reference_keys_and_shapes():
 def test_header_abi_and_library_agree():
     from eeg_image_decode_amd import _abi
     hdr = open(os.path.join(ROOT, "include", "eegclip.h")).read()
-    declared = set(re.findall(r"\b(?:int|long long)\s+(eegclip_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|long long|float|void\s*\*)\s*(eegclip_\w+)\s*\(", hdr))
     assert declared == set(_abi.PROTOTYPES), (declared ^ set(_abi.PROTOTYPES))
     libpath = os.path.join(ROOT, "eeg_image_decode_amd", "csrc", "libeegclip_hip.so")
     if not os.path.exists(libpath):
