@@ -296,3 +296,38 @@ def test_cross_attention_at_the_sdxl_sampling_shapes(dtype, hw, dim, heads):
     no_ip = cross_attention(q, k, v, heads)                                          # text branch alone (no IP-Adapter loaded)
     ref0 = sdxl_attn.cross_attention(f(q[:, rows]), f(k), f(v), heads)
     np.testing.assert_allclose(f(no_ip[:, rows]), ref0, atol=tol)
+
+
+def test_kernel_timestamp_timing_of_one_launch():
+    """eegclip_time_next_launch stamps the next kernel with its own GPU begin / end (hipExtLaunchKernel start / stop events): the figure bench.py's
+    roofline uses.  It must be positive, below a record-around-the-launch bracket of the same launch, and a second launch without arming must
+    leave the events untouched."""
+    import ctypes
+    from eeg_image_decode_amd import _abi
+    from eeg_image_decode_amd._lib import lib
+    L = lib()
+    D = _abi.dim
+    M, N, K = 16384, 256, 250
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    c = torch.empty(M, N, device="cuda")
+    d = _abi.GemmDesc(M=M, N=N, K=K, A=a.data_ptr(), Am=D(K), Ak=D(1), B=w.data_ptr(), Bk=D(1), Bn=D(K), C=c.data_ptr(), Cm=D(N), Cn=D(1), Cpre=None,
+                      bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0, drop_site=0, split_k=1,
+                      precision=_abi.PREC_BF16X3)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0
+    e0, e1 = L.eegclip_timing_event_create(), L.eegclip_timing_event_create()
+    assert e0 and e1
+    assert L.eegclip_time_next_launch(e0, None) < 0                 # both or neither
+    assert L.eegclip_time_next_launch(e0, e1) == 0
+    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0            # not armed: an ordinary launch
+    b1.record()
+    torch.cuda.synchronize()
+    ms = float(L.eegclip_timing_elapsed_ms(e0, e1))
+    assert 0.003 < ms < 0.2, ms                                     # ~17 us for this shape
+    assert ms <= b0.elapsed_time(b1) + 0.002
+    np.testing.assert_allclose(c[:4].cpu().numpy(), (a[:4].double() @ w.double().T).cpu().numpy(), atol=2e-3)
+    assert L.eegclip_timing_event_destroy(e0) == 0 and L.eegclip_timing_event_destroy(e1) == 0
