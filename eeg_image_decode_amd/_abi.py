@@ -55,7 +55,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -131,6 +131,7 @@ PROTOTYPES = {
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
+    "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],

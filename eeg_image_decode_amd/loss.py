@@ -66,6 +66,9 @@ def split_planes_many(xs, planes):
     return [(buf[i, 0], buf[i, 1] if planes == 2 else None) for i in range(len(xs))]
 
 
+MAX_BLOCKS_PER_LAUNCH = 8          # IF_MAX_PROB of csrc/infonce_fused.hip (eegclip_infonce_fused_{fwd,grad} reject more)
+
+
 def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
     """blocks = [(q planes, k planes, col0, weight)]: adds sum_blocks weight / n_total * sum_rows (lse_row - positive) to acc[0].
     want_grad = [(block index, index of the block whose lse is the second (per-key) normaliser, or None)]: for each, the gradient matrix
@@ -83,7 +86,9 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
                                      k_lo=kl.data_ptr() if kl is not None else None, col0=int(col0), weight=float(w), part=o, diag=o + 4 * ws,
                                      lse=o + 4 * (ws + n), lse_k=None, G=None, ldg=0)
     st = _stream()
-    check(L.eegclip_infonce_fused_fwd(arr, nb, n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr(), st), "infonce_fused_fwd")
+    for c0 in range(0, nb, MAX_BLOCKS_PER_LAUNCH):                  # (any number of targets: the launch table holds 8 blocks)
+        chunk = (_abi.InfonceProblem * min(MAX_BLOCKS_PER_LAUNCH, nb - c0))(*arr[c0:c0 + MAX_BLOCKS_PER_LAUNCH])
+        check(L.eegclip_infonce_fused_fwd(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr(), st), "infonce_fused_fwd")
     if not want_grad:
         return []
     garr = (_abi.InfonceProblem * len(want_grad))()
@@ -94,7 +99,9 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
         garr[j] = arr[bi]
         garr[j].G, garr[j].ldg = G.data_ptr(), N
         garr[j].lse_k = arr[ki].lse if ki is not None else None
-    check(L.eegclip_infonce_fused_grad(garr, len(want_grad), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
+    for c0 in range(0, len(want_grad), MAX_BLOCKS_PER_LAUNCH):
+        chunk = (_abi.InfonceProblem * min(MAX_BLOCKS_PER_LAUNCH, len(want_grad) - c0))(*garr[c0:c0 + MAX_BLOCKS_PER_LAUNCH])
+        check(L.eegclip_infonce_fused_grad(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
     Gs[0]._eegclip_keep = buf                      # the lse vectors must outlive the launch (stream-ordered allocator: already safe; explicit)
     return Gs
 
@@ -175,6 +182,83 @@ def _grad_cols(X, a_rows, out=None, precision=0):
     return out
 
 
+def sharded_blocks(local_loss, gather_with_grad, rank, W, a_, bs, a_all, b_alls, weights, sc, acc, need_a, need_b, need, planes, bf16_logits=False):
+    """What ONE rank computes between the collectives of a data-parallel ClipLoss (models/loss.py:100-141 with world_size > 1): the loss / d scale
+    contributions (added to `acc`) and
+        da       (n, D)   gradient w.r.t. this rank's own query rows (the part that does not travel),
+        ga       (N, D)   gradient w.r.t. the GATHERED query copies, summed over the targets (local_loss + gather_with_grad), else None
+        dbs[t]   (n, D)   gradient w.r.t. this rank's rows of target t, gbs[t] (N, D) its gathered-copy part (to be reduce-scattered) or None.
+    No collective is issued here: the caller all-gathers before and reduce-scatters after (tests drive it rank by rank on one GPU)."""
+    n, Dm = a_.shape
+    N = W * n
+    PX3 = _abi.PREC_BF16X3
+    sl = slice(rank * n, (rank + 1) * n)
+    da, ga = None, None
+    dbs, gbs = [None] * len(bs), [None] * len(bs)
+    fused = fused_enabled(n, N, Dm) and all(b.shape == a_.shape for b in bs)
+    if fused:
+        a_all_p = split_planes(a_all, planes)
+        ap = (a_all_p[0][sl], a_all_p[1][sl] if planes == 2 else None)        # this rank's rows of the gathered planes
+    for t, (b_, w) in enumerate(zip(bs, weights)):
+        b_all = b_alls[t]
+        if fused:
+            b_all_p = split_planes(b_all, planes)
+            bp = (b_all_p[0][sl], b_all_p[1][sl] if planes == 2 else None)
+            if not local_loss:
+                # every rank scores the full N x N matrix (models/loss.py:117-121): both terms from one gradient matrix
+                Gs = fused_infonce([(a_all_p, b_all_p, 0, 0.5 * w), (b_all_p, a_all_p, 0, 0.5 * w)], N, N, Dm, planes, N, sc, acc,
+                                   [(0, 1)] if need else [])
+                if not need:
+                    continue
+                G = Gs[0]
+                mult = float(W) if gather_with_grad else 1.0
+                if need_a:
+                    part = _grad_rows(G[sl], b_all, None, PX3) * mult
+                    da = part if da is None else da + part
+                if need_b[t]:
+                    dbs[t] = _grad_cols(G, a_all, None, PX3)[sl] * mult
+            else:
+                # row-sharded (models/loss.py:113-115,129-130): this rank's rows against everybody's, positives at column i + n*rank
+                Gs = fused_infonce([(ap, b_all_p, rank * n, 0.5 * w), (bp, a_all_p, rank * n, 0.5 * w)], n, N, Dm, planes, n, sc, acc,
+                                   [(0, None), (1, None)] if need else [])
+                if not need:
+                    continue
+                G1, G2 = Gs
+                if need_a:
+                    da = _grad_rows(G1, b_all, da, PX3)
+                if need_b[t]:
+                    dbs[t] = _grad_rows(G2, a_all, None, PX3)
+                if gather_with_grad:
+                    if need_a:
+                        ga = _grad_cols(G2, b_, ga, PX3)
+                    if need_b[t]:
+                        gbs[t] = _grad_cols(G1, a_, None, PX3)
+            continue
+        if not local_loss:
+            # every rank scores the full N x N matrix (models/loss.py:117-121)
+            _, _, X = infonce_block(a_all, b_all, sc, 0, W * n, w, True, True, need, acc, bf16_logits)
+            mult = float(W) if gather_with_grad else 1.0     # all_gather backward sums W identical copies
+            if need_a:
+                part = _grad_rows(X[sl].contiguous(), b_all) * mult
+                da = part if da is None else da + part
+            if need_b[t]:
+                dbs[t] = _grad_cols(X, a_all)[sl] * mult
+        else:
+            # row-sharded: n x N blocks, positives at column i + n*rank (models/loss.py:113-115,129-130)
+            _, _, X1 = infonce_block(a_, b_all, sc, rank * n, n, w, True, False, True, acc)
+            _, _, X2 = infonce_block(b_, a_all, sc, rank * n, n, w, True, False, True, acc)
+            if need_a:
+                da = _grad_rows(X1, b_all, da)
+            if need_b[t]:
+                dbs[t] = _grad_rows(X2, a_all)
+            if gather_with_grad:
+                if need_a:
+                    ga = _grad_cols(X2, b_, ga)                   # (N, D): d loss_r / d a_all, summed over the targets
+                if need_b[t]:
+                    gbs[t] = _grad_cols(X1, a_)
+    return da, ga, dbs, gbs
+
+
 _ACC_POOL = {}
 
 
@@ -237,78 +321,15 @@ class _ClipLossFn(torch.autograd.Function):
             import torch.distributed as dist
             a_all = torch.empty(W * n, a_.shape[1], dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(a_all, a_)
-            ga = None                                              # gradient w.r.t. the gathered copies of a (local_loss + gather_with_grad)
-            sl = slice(rank * n, (rank + 1) * n)
-            N = W * n
-            fused = fused_enabled(n, N, Dm) and all(b.shape == a_.shape for b in bs)
-            if fused:
-                a_all_p = split_planes(a_all, planes)
-                ap = (a_all_p[0][sl], a_all_p[1][sl] if planes == 2 else None)        # this rank's rows of the gathered planes
             b_alls = mod._gathered_targets(bs)                     # ONE all-gather for every target (usually started at step start)
-            for t, (b_, w) in enumerate(zip(bs, weights)):
-                b_all = b_alls[t]
-                if fused:
-                    b_all_p = split_planes(b_all, planes)
-                    bp = (b_all_p[0][sl], b_all_p[1][sl] if planes == 2 else None)
-                    if not mod.local_loss:
-                        # every rank scores the full N x N matrix (models/loss.py:117-121): both terms from one gradient matrix
-                        Gs = fused_infonce([(a_all_p, b_all_p, 0, 0.5 * w), (b_all_p, a_all_p, 0, 0.5 * w)], N, N, Dm, planes, N, sc, acc,
-                                           [(0, 1)] if need else [])
-                        if not need:
-                            continue
-                        G = Gs[0]
-                        mult = float(W) if mod.gather_with_grad else 1.0
-                        if need_a:
-                            part = _grad_rows(G[sl], b_all, None, PX3) * mult
-                            da = part if da is None else da + part
-                        if need_b[t]:
-                            dbs[t] = _grad_cols(G, a_all, None, PX3)[sl] * mult
-                    else:
-                        # row-sharded (models/loss.py:113-115,129-130): this rank's rows against everybody's, positives at column i + n*rank
-                        Gs = fused_infonce([(ap, b_all_p, rank * n, 0.5 * w), (bp, a_all_p, rank * n, 0.5 * w)], n, N, Dm, planes, n, sc, acc,
-                                           [(0, None), (1, None)] if need else [])
-                        if not need:
-                            continue
-                        G1, G2 = Gs
-                        if need_a:
-                            da = _grad_rows(G1, b_all, da, PX3)
-                        if need_b[t]:
-                            dbs[t] = _grad_rows(G2, a_all, None, PX3)
-                        if mod.gather_with_grad:
-                            if need_a:
-                                ga = _grad_cols(G2, b_, ga, PX3)
-                            if need_b[t]:
-                                gb = _grad_cols(G1, a_, None, PX3)
-                                part = torch.empty_like(b_)
-                                dist.reduce_scatter_tensor(part, gb)
-                                dbs[t] = dbs[t] + part
-                    continue
-                if not mod.local_loss:
-                    # every rank scores the full N x N matrix (models/loss.py:117-121)
-                    _, _, X = infonce_block(a_all, b_all, sc, 0, W * n, w, True, True, need, acc, mod.logits_dtype == "bf16")
-                    mult = float(W) if mod.gather_with_grad else 1.0     # all_gather backward sums W identical copies
-                    if need_a:
-                        part = _grad_rows(X[sl].contiguous(), b_all) * mult
-                        da = part if da is None else da + part
-                    if need_b[t]:
-                        dbs[t] = _grad_cols(X, a_all)[sl] * mult
-                else:
-                    # row-sharded: n x N blocks, positives at column i + n*rank (models/loss.py:113-115,129-130)
-                    _, _, X1 = infonce_block(a_, b_all, sc, rank * n, n, w, True, False, True, acc)
-                    _, _, X2 = infonce_block(b_, a_all, sc, rank * n, n, w, True, False, True, acc)
-                    if need_a:
-                        da = _grad_rows(X1, b_all, da)
-                    if need_b[t]:
-                        dbs[t] = _grad_rows(X2, a_all)
-                    if mod.gather_with_grad:
-                        # gradients that reached the GATHERED copies flow back through all_gather = reduce-scatter(sum)
-                        if need_a:
-                            ga = _grad_cols(X2, b_, ga)                   # (N, D): d loss_r / d a_all, summed over the targets
-                        if need_b[t]:
-                            gb = _grad_cols(X1, a_)
-                            part = torch.empty_like(b_)
-                            dist.reduce_scatter_tensor(part, gb)
-                            dbs[t] = dbs[t] + part
+            da, ga, dbs, gbs = sharded_blocks(mod.local_loss, mod.gather_with_grad, rank, W, a_, bs, a_all, b_alls, weights, sc, acc, need_a, need_b,
+                                              need, planes, mod.logits_dtype == "bf16")
+            # gradients that reached the GATHERED copies flow back through all_gather = reduce-scatter(sum) (models/loss.py:52-58)
+            for t_, gb in enumerate(gbs):
+                if gb is not None:
+                    part = torch.empty_like(bs[t_])
+                    dist.reduce_scatter_tensor(part, gb)
+                    dbs[t_] = dbs[t_] + part
             if ga is not None:
                 part = torch.empty_like(a_)
                 dist.reduce_scatter_tensor(part, ga)

@@ -185,8 +185,25 @@ class Plan:
                     ev[i] = tmp[k]
                     k += 1
             join = ctypes.c_void_p(tmp[n_side])
-        self._c = dict(arr=arr, slots=slots, segments=segments, events=ev, join=join, n=n, dirty=ctypes.c_int(0), failed=ctypes.c_int(-1))
+        self._c = dict(arr=arr, slots=slots, segments=segments, events=ev, join=join, n=n, dirty=ctypes.c_int(0), failed=ctypes.c_int(-1),
+                       owned=(tmp if n_side else None))
         self._c_skip = ()
+
+    def close(self):
+        """give the plan's HIP events back (fork / join events of the C executor, library-owned timing events); the plan must not run afterwards.
+        Called when an engine drops a plan and from __del__: plans are rebuilt per (batch size, mode, world size ...) key."""
+        c, self._c = self._c, None
+        try:
+            if c is not None and c.get("owned") is not None:
+                self.L.eegclip_plan_events_destroy(len(c["owned"]), c["owned"])
+            for e in self._ev_free + self._ev_used:
+                self.L.eegclip_timing_event_destroy(e)
+        except Exception:                                         # interpreter shutdown: the library may be gone
+            pass
+        self._ev_free, self._ev_used = [], []
+
+    def __del__(self):
+        self.close()
 
     def _run_c(self, stream, seed):
         import torch
@@ -322,6 +339,8 @@ class Plan:
                 else:
                     args[-1] = stream
                 rc = fn(*args)
+                if stamp:
+                    self.L.eegclip_time_next_launch(None, None)      # (a call that returned before launching must not leave the pair armed)
                 if rc:
                     check(rc, f"{self.name}:{name}")
             if stamp:

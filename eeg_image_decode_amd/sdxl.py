@@ -95,14 +95,15 @@ def cross_attention(q, k, v, heads, k_ip=None, v_ip=None, ip_scale=1.0):
 
 
 def _hip_linear_ok(lin, x):
-    return lin.weight.shape[0] % 128 == 0 and lin.weight.shape[1] % 64 == 0 and lin.weight.dtype == x.dtype and x.is_cuda
+    return lin.weight.shape[0] % 128 == 0 and lin.weight.shape[1] % 64 == 0 and lin.weight.dtype == x.dtype      # (linear16 itself rejects CPU tensors)
 
 
 class HIPIPAdapterAttnProcessor(nn.Module):
     """Cross-attention processor with an optional IP-Adapter branch (to_k_ip / to_v_ip: Linear(cross_attention_dim -> hidden_size),
     the non-"plus" adapter with 4 image tokens; scale 1 as in the reference, custom_pipeline.py:476).  Every GEMM of the layer -- attn.to_q,
     to_k, to_v, to_out[0], to_k_ip, to_v_ip -- runs on csrc/gemm16.hip (no library GEMM); the K / V projections of the text and image tokens are
-    cached per (tensor, version): inside a sampling run they are computed on the first denoising step only."""
+    cached: inside a sampling run (begin_sampling_run / end_sampling_run, driven by generate_ip_adapter_embeds) they are computed on the first
+    denoising step only; outside one, only for the very same tensor object."""
 
     def __init__(self, hidden_size, cross_attention_dim=2048, num_tokens=4, scale=1.0, with_ip=True):
         super().__init__()
@@ -118,14 +119,30 @@ class HIPIPAdapterAttnProcessor(nn.Module):
                                "the activations); this processor issues no library GEMM")
         return linear16(x, layer.weight, layer.bias, residual)
 
-    def _projected(self, tag, lin_k, lin_v, tokens):
-        """K, V of a token tensor, cached while the tensor object (and its version counter) stay the same"""
-        key = (tag, tokens.data_ptr(), tuple(tokens.shape), tokens._version, lin_k.weight.data_ptr(), lin_k.weight._version)
+    def begin_sampling_run(self):
+        """Called by the sampling loop before its first UNet forward: inside one run the text / image tokens are constants (custom_pipeline.py:296-373
+        builds them before the loop), so K / V are projected on the first step and reused on the others even when the pipeline hands over a FRESH
+        token tensor every step (diffusers' encoder_hid_proj does).  Nothing cached survives the call: a new run never sees an old run's K / V."""
+        self._kv_cache.clear()
+        self._run_scope = True
+
+    def end_sampling_run(self):
+        self._kv_cache.clear()
+        self._run_scope = False
+
+    def _projected(self, tag, lin_k, lin_v, src, make_tokens):
+        """K, V of the token tensor `src` (make_tokens() -> the (B, S, cross_dim) matrix in the activation dtype).  Outside a sampling run they are
+        reused only for THE SAME tensor object at the same version (the entry holds a reference to it, so its address cannot be recycled for
+        another tensor while the entry lives -- keying on data_ptr() could hand the K / V of a freed tensor to the next one allocated at its
+        address); inside a run (begin_sampling_run) the first projection of the run is reused for any tensor of that shape."""
         hit = self._kv_cache.get(tag)
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
+        wkey = (lin_k.weight.data_ptr(), lin_k.weight._version, lin_v.weight.data_ptr(), lin_v.weight._version)
+        if hit is not None and hit[2] == wkey and hit[0].shape == src.shape and hit[0].dtype == src.dtype:
+            if getattr(self, "_run_scope", False) or (hit[0] is src and hit[1] == src._version):
+                return hit[3], hit[4]
+        tokens = make_tokens()
         k, v = self._lin(lin_k, tokens), self._lin(lin_v, tokens)
-        self._kv_cache[tag] = (key, k, v)
+        self._kv_cache[tag] = (src, src._version, wkey, k, v)
         return k, v
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0, ip_adapter_masks=None, **kw):
@@ -145,15 +162,20 @@ class HIPIPAdapterAttnProcessor(nn.Module):
         elif self.to_k_ip is not None and encoder_hidden_states.shape[1] > 77:   # older layout: image tokens concatenated after the 77 text tokens
             end = encoder_hidden_states.shape[1] - self.num_tokens
             encoder_hidden_states, ip_tokens = encoder_hidden_states[:, :end], encoder_hidden_states[:, end:]
-        if getattr(attn, "norm_cross", None):
-            encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+        text_src = encoder_hidden_states                                      # (identity of what the pipeline handed over: the cache key)
         q = self._lin(attn.to_q, hidden_states)
-        k, v = self._projected("text", attn.to_k, attn.to_v, encoder_hidden_states.to(q.dtype))
+
+        def text_tokens():
+            e = encoder_hidden_states
+            if getattr(attn, "norm_cross", None):
+                e = attn.norm_encoder_hidden_states(e)
+            return e.to(q.dtype)
+        k, v = self._projected("text", attn.to_k, attn.to_v, text_src, text_tokens)
         k_ip = v_ip = None
         if ip_tokens is not None and self.to_k_ip is not None:
-            if ip_tokens.dim() == 4:                                          # (B, n_images, tokens, dim)
-                ip_tokens = ip_tokens.flatten(1, 2)
-            k_ip, v_ip = self._projected("ip", self.to_k_ip, self.to_v_ip, ip_tokens.to(q.dtype))
+            ip_src = ip_tokens
+            k_ip, v_ip = self._projected("ip", self.to_k_ip, self.to_v_ip, ip_src,
+                                         lambda: (ip_src.flatten(1, 2) if ip_src.dim() == 4 else ip_src).to(q.dtype))      # (B, n_images, tokens, dim)
         out = cross_attention(q, k, v, attn.heads, k_ip, v_ip, self.scale)
         fuse_res = bool(getattr(attn, "residual_connection", False)) and shape4 is None and getattr(attn, "rescale_output_factor", 1.0) == 1.0
         out = self._lin(attn.to_out[0], out, residual if fuse_res else None)
@@ -387,15 +409,16 @@ class SDXLShapedUNet(nn.Module):
             if ip is not None:
                 kip, vip = linear16(ip, s.to_k_ip), linear16(ip, s.to_v_ip)
             kv.append((k, v, kip, vip))
-        self._kv = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, None if image_embeds is None else image_embeds.data_ptr(), B, kv)
+        # (the entry keeps the token tensors themselves: identity, not data_ptr(), decides a hit -- an address can be recycled by the allocator)
+        self._kv = (encoder_hidden_states, encoder_hidden_states._version, image_embeds, None if image_embeds is None else image_embeds._version, B, kv)
         return self
 
     def _kv_for(self, encoder_hidden_states, image_embeds):
         c = self._kv
-        if c is None or c[0] != encoder_hidden_states.data_ptr() or c[1] != encoder_hidden_states._version or \
-                c[2] != (None if image_embeds is None else image_embeds.data_ptr()) or c[3] != encoder_hidden_states.shape[0]:
+        if c is None or c[0] is not encoder_hidden_states or c[1] != encoder_hidden_states._version or c[2] is not image_embeds or \
+                c[3] != (None if image_embeds is None else image_embeds._version) or c[4] != encoder_hidden_states.shape[0]:
             self.precompute(encoder_hidden_states, image_embeds)
-        return self._kv[4]
+        return self._kv[5]
 
     # ---- forward
     def embedding(self, timestep, B, added_cond_kwargs):
@@ -593,23 +616,30 @@ def generate_ip_adapter_embeds(self, prompt=None, prompt_2=None, height=None, wi
         timesteps = timesteps[:len([ts for ts in timesteps.tolist() if ts >= cutoff])]
     if hasattr(self.unet, "precompute"):
         self.unet.precompute(prompt_embeds, image_embeds)        # K / V of all layers: once per run, not once per step
+    run_scoped = [p for p in getattr(self.unet, "attn_processors", {}).values() if hasattr(p, "begin_sampling_run")]
+    for p in run_scoped:                                         # (diffusers UNet with the HIP processors installed: per-run K / V caches)
+        p.begin_sampling_run()
     added = {"text_embeds": add_text_embeds, "time_ids": add_time_ids}
     if image_embeds is not None:
         added["image_embeds"] = image_embeds
     # 8. denoising loop
-    for i, t in enumerate(timesteps.tolist()):
-        model_in = torch.cat([latents] * 2) if do_cfg else latents
-        model_in = self.scheduler.scale_model_input(model_in, t)
-        noise_pred = self.unet(model_in, t, encoder_hidden_states=prompt_embeds, timestep_cond=None, cross_attention_kwargs=cross_attention_kwargs,
-                               added_cond_kwargs=added, return_dict=False)[0]
-        if do_cfg:
-            eps_u, eps_c = noise_pred.chunk(2)
-            latents = self.scheduler.step(eps_c, t, latents, generator=generator, model_output_uncond=eps_u, guidance_scale=guidance_scale)[0]
-        else:
-            latents = self.scheduler.step(noise_pred, t, latents, generator=generator)[0]
-        if callback_on_step_end is not None:
-            out = callback_on_step_end(self, i, t, {"latents": latents})
-            latents = out.pop("latents", latents)
+    try:
+        for i, t in enumerate(timesteps.tolist()):
+            model_in = torch.cat([latents] * 2) if do_cfg else latents
+            model_in = self.scheduler.scale_model_input(model_in, t)
+            noise_pred = self.unet(model_in, t, encoder_hidden_states=prompt_embeds, timestep_cond=None, cross_attention_kwargs=cross_attention_kwargs,
+                                   added_cond_kwargs=added, return_dict=False)[0]
+            if do_cfg:
+                eps_u, eps_c = noise_pred.chunk(2)
+                latents = self.scheduler.step(eps_c, t, latents, generator=generator, model_output_uncond=eps_u, guidance_scale=guidance_scale)[0]
+            else:
+                latents = self.scheduler.step(noise_pred, t, latents, generator=generator)[0]
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = out.pop("latents", latents)
+    finally:
+        for p in run_scoped:
+            p.end_sampling_run()
     if output_type == "latent":
         image = latents
     else:

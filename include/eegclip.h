@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 4
+#define EEGCLIP_ABI_VERSION 5
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -427,6 +427,9 @@ typedef struct {
 #define EEGCLIP_PLAN_SKIP 2
 int eegclip_plan_fn_id(const char* name);
 int eegclip_plan_events(int n, void** out);
+/* destroys events made by eegclip_plan_events (null entries are skipped): call when a plan is dropped -- plans are rebuilt per batch size /
+ * mode / world size, so a long-lived process would otherwise leak their fork / join events */
+int eegclip_plan_events_destroy(int n, void* const* events);
 int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* const* events,
                      void* join_event, int* dirty, int* failed);
 
@@ -435,7 +438,7 @@ int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total
  * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */
 void* eegclip_timing_event_create(void);
 int eegclip_timing_event_destroy(void* event);
-int eegclip_time_next_launch(void* start, void* stop);
+int eegclip_time_next_launch(void* start, void* stop);          /* (NULL, NULL) disarms a pair that no launch has consumed */
 float eegclip_timing_elapsed_ms(void* start, void* stop);
 
 #ifdef __cplusplus

@@ -282,10 +282,55 @@ def gen_dist():
     np.savez_compressed(os.path.join(HERE, "dist_loss.npz"), **out)
 
 
+def _dist_worker_big(rank, world, port, mode, n, ret):
+    """the same three gather modes at sizes where the product's FUSED row-sharded InfoNCE runs (n a multiple of 64, D = 1024): query features
+    shaped like the encoder's output (a LayerNorm row: zero mean, unit variance -> |logit| up to ~2.66 * 32), unit-norm targets"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(max(1, 8 // world))
+    sys.path.insert(0, REF)
+    from models.loss import ClipLoss
+    a_all = t(syn.unit_features(SEED + 11, n * world, tag="da") * 32.0)
+    b_all = t(syn.unit_features(SEED + 11, n * world, tag="db"))
+    a = a_all[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+    b = b_all[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+    s = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+    local_loss, gwg = mode
+    l = ClipLoss(local_loss=local_loss, gather_with_grad=gwg, rank=rank, world_size=world)(a, b, s)
+    l.backward()
+    ret[rank] = (float(l.item()), a.grad.numpy()[:, :DIST_COLS].copy(), b.grad.numpy()[:, :DIST_COLS].copy(), float(s.grad))
+    dist.destroy_process_group()
+
+
+DIST_COLS = 24            # feature columns of the per-rank gradients that are stored (all rows)
+
+
+def gen_dist_big():
+    """dist_loss_fused.npz: (world, n per rank) = (2, 64), (4, 64), (8, 256) -- the last one is configs[2] itself: 8 ranks x 256 rows, N = 2048"""
+    import torch.multiprocessing as mp
+    out = {}
+    port = 29651
+    for world, n in ((2, 64), (4, 64), (8, 256)):
+        for mode in ((False, False), (False, True), (True, True)):
+            mgr = mp.Manager()
+            ret = mgr.dict()
+            mp.spawn(_dist_worker_big, args=(world, port, mode, n, ret), nprocs=world, join=True)
+            port += 1
+            tag = f"w{world}_n{n}_ll{int(mode[0])}_gwg{int(mode[1])}"
+            out[tag + "_loss"] = np.asarray([ret[r][0] for r in range(world)], np.float64)
+            out[tag + "_da"] = np.stack([ret[r][1] for r in range(world)])
+            out[tag + "_db"] = np.stack([ret[r][2] for r in range(world)])
+            out[tag + "_ds"] = np.asarray([ret[r][3] for r in range(world)], np.float64)
+            print(tag, out[tag + "_loss"], flush=True)
+    np.savez_compressed(os.path.join(HERE, "dist_loss_fused.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"keys", "eval_enc", "train_p0", "loss", "train_loop", "eval", "dist", "prior"}
+    which = set(sys.argv[1:]) or {"keys", "eval_enc", "train_p0", "loss", "train_loop", "eval", "dist", "dist_big", "prior"}
     ref = import_reference()
     if "keys" in which:
         gen_keys(ref)
@@ -301,6 +346,8 @@ def main():
         gen_eval(ref)
     if "dist" in which:
         gen_dist()
+    if "dist_big" in which:
+        gen_dist_big()
     if "prior" in which:
         from make_golden_prior import gen_prior
         gen_prior()

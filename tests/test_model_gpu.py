@@ -234,10 +234,14 @@ def _make_batches(seed, n_batches, B, n_classes, img_all, txt_all):
     return out
 
 
+@pytest.mark.parametrize("arith,bn_tol", [("bf16x3", 1e-3), ("f32", 2e-4)])
 @pytest.mark.parametrize("which_opt", ["fused", "torch"])
-def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
-    """C1: retrieval.train_model == reference train_model on the same 3-batch loader (dropout p=0), 2 epochs of AdamW."""
+def test_train_model_matches_reference_fixture(state_np, golden, which_opt, arith, bn_tol, monkeypatch):
+    """C1: retrieval.train_model == reference train_model on the same 3-batch loader (dropout p=0), 2 epochs of AdamW -- in the default split-bf16
+    GEMM arithmetic and with exact fp32 products (EEGCLIP_GEMM_PRECISION=f32), where the BatchNorm running statistics are held to 2e-4: a
+    BatchNorm-statistics regression shows there, the looser bound of the split arithmetic is explained below."""
     from eeg_image_decode_amd import optim, retrieval
+    monkeypatch.setenv("EEGCLIP_GEMM_PRECISION", arith)
     g = golden("train_loop.npz")
     n_classes, B = 20, 16
     img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
@@ -268,7 +272,7 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt):
             # 6 AdamW steps at B = 16: parameters whose true gradient is zero or round-off sized (the conv biases in front of a train-mode
             # BatchNorm, a few spatial weights) move by +-lr = 3e-4 per step in a direction set by the LAST BIT of the gradient, so the
             # running statistics agree to the parity budget (1e-3), not to fp32 round-off
-            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=1e-3, err_msg=k)
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g["bn:" + k], atol=bn_tol, err_msg=k)
         if "num_batches" in k:
             assert int(sd[k]) == 6
 

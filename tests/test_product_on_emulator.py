@@ -573,6 +573,12 @@ def test_sdxl_sampling_loop_under_emulator_matches_the_oracle():
     assert d.max() < 1e-2 * max(1.0, np.abs(ref).max()), (d.max(), np.abs(ref).max())
 
 
+def test_processor_kv_cache_never_serves_another_tensors_projections_under_emulator():
+    from sdxl_common import check_processor_kv_cache_never_serves_another_tensors_projections
+    with product_on_emulator():
+        check_processor_kv_cache_never_serves_another_tensors_projections("cpu")
+
+
 def test_sdxl_schedulers_reproduce_their_defining_identities():
     """host-side coefficients of the two schedulers (product) against the oracle's step on random data, plus the DDIM identity: a latent built from
     (x0, eps) at timestep t steps to the same (x0, eps) mixture at the previous timestep"""
