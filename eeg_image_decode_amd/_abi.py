@@ -41,6 +41,14 @@ class InfonceProblem(C.Structure):
                 ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong)]
 
 
+class TokenBlockDesc(C.Structure):
+    _fields_ = ([("B", C.c_int), ("x", C.c_void_p), ("packed", C.c_void_p), ("bv", C.c_void_p), ("pe", C.c_void_p), ("tokens", C.c_void_p), ("ids", C.c_void_p)]
+                + [(k, C.c_void_p) for k in ("bqkv", "bo", "ln1_g", "ln1_b", "b1", "b2", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
+                + [(k, C.c_void_p) for k in ("h", "qkv", "ctx", "r1", "n1", "mu1", "rs1", "f1", "g1", "r2", "n2", "mu2", "rs2", "n3", "mu3", "rs3")]
+                + [("drop_p", C.c_float), ("eps", C.c_float), ("scale", C.c_float), ("seed", C.c_ulonglong)]
+                + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")])
+
+
 PLAN_MAX_ARGS = 24
 PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP = -2, -3, 1, 2
 
@@ -129,6 +137,9 @@ PROTOTYPES = {
     "eegclip_infonce_fused_workspace_floats": [_I, _I],
     "eegclip_infonce_fused_fwd": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "eegclip_token_block_packed_bytes": [],
+    "eegclip_token_block_pack": [_P, _P, _P, _P, _P, _P, _P],
+    "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

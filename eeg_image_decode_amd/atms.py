@@ -469,6 +469,11 @@ class _Engine:
                 j += 1
         self.plane_items, self.n_plane_items = items, n_items
 
+    def _token_block_enabled(self, pl):
+        """the fused transformer-block forward (csrc/token_block.hip): the single-subject model in the default split-bf16 arithmetic;
+        EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan (diagnosis, A/B timing)"""
+        return (not self.joint) and pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
+
     def stale(self, model):
         a, b = self._check
         return (a.data_ptr() != self.flat.data_ptr() or b.data.data_ptr() != self.P[_LIVE[-1]].data_ptr()
@@ -537,47 +542,66 @@ class _Engine:
                 items[self.n_plane_items + i] = it
             pl._keep.append(items)
             pl.call("eegclip_split_rows", items, n_items)
-        # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
-        hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
-        if not self.joint:
-            pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
-                    _p(b["h"]) + 4 * D_MODEL, hmap, D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
-                    R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1), planes=PL["embed"])
+        pl.tb_desc = None
+        if self._token_block_enabled(pl):
+            # A1-A3 in ONE launch, one workgroup per sample (csrc/token_block.hip): the ten launches below it replace were bound by per-launch
+            # prologue / epilogue and activation round trips, not by their K ~ 250 contractions
+            if not hasattr(self, "tb_packed"):
+                self.tb_packed = torch.empty(int(lib().eegclip_token_block_packed_bytes()) // 2, dtype=torch.bfloat16, device=self.device)
+            pl.call("eegclip_token_block_pack", _p(P[_E + "value_embedding.weight"]), _p(P[_LY + "attention.query_projection.weight"]),
+                    _p(P[_LY + "attention.out_projection.weight"]), _p(P[_LY + "conv1.weight"]), _p(P[_LY + "conv2.weight"]), _p(self.tb_packed))
+            tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
+            pl.tb_desc = pl.call_desc("eegclip_token_block_fwd", _abi.TokenBlockDesc(
+                B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[_E + "value_embedding.bias"]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]),
+                bqkv=_p(P[_LY + "attention.query_projection.bias"]), bo=_p(P[_LY + "attention.out_projection.bias"]), ln1_g=_p(P[_LY + "norm1.weight"]),
+                ln1_b=_p(P[_LY + "norm1.bias"]), b1=_p(P[_LY + "conv1.bias"]), b2=_p(P[_LY + "conv2.bias"]), ln2_g=_p(P[_LY + "norm2.weight"]),
+                ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), ln3_b=_p(P["encoder.encoder.norm.bias"]),
+                h=_p(b["h"]), qkv=_p(b["qkv"]), ctx=_p(b["ctx"]), r1=_p(b["r1"]), n1=_p(b["n1"]), mu1=_p(b["mu1"]), rs1=_p(b["rs1"]), f1=_p(b["f1"]),
+                g1=_p(b["g1"]), r2=_p(b["r2"]), n2=_p(b["n2"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), n3=_p(b["n3"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]),
+                drop_p=pe_, eps=EPS, scale=1.0 / math.sqrt(D_HEAD), seed=0, site_embed=SITE_EMBED, site_attn=SITE_ATTN, site_attn_out=SITE_ATTN_OUT,
+                site_ffn_act=SITE_FFN_ACT, site_ffn_out=SITE_FFN_OUT), seeded=pe_ > 0.0)
         else:
-            # joint-subject model (Embed.py:142-144): one GEMM per subject over that subject's block of the subject-ordered batch.  A batch
-            # that is not already in subject order is gathered into xs first and the token rows are scattered back to batch order after
-            # (ops skipped otherwise); M and the A / C pointers of each GEMM are patched per call (_joint_layout), absent subjects skipped.
-            XR = N_CH * T_LEN
-            pl.j_gather = len(pl.ops)
-            pl.call("eegclip_gather_rows", _p(b["xs"]), XR, 0, XR, _p(b["perm"]), B, XR, 0)
-            pl.j_gemm = [pl.desc(N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[w]), D(1), D(T_LEN), 0, hmap, D(1), bias_n=_p(P[bk]),
-                                 R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1)) for w, bk in self.ve_keys]
-            pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)             # ONE launch for all subjects of the batch
-            pl.j_scatter = len(pl.ops)
-            pl.call("eegclip_gather_rows", _p(b["h"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
-                    N_CH * D_MODEL, 1)
-        tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
-        pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
-        # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
-        pl.gemm(R, 3 * HE, D_MODEL, _p(b["h"]), D(D_MODEL), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(1), D(D_MODEL),
-                _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]), planes=PL["qkv"])
-        pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
-                SITE_ATTN, seed_at=9)
-        # (dropout + residual of both sublayers live in the LayerNorm kernel that follows, not in the GEMM epilogue: one Philox block per 4
-        #  consecutive columns there, one per ELEMENT in an MFMA accumulator layout -- 12 us per GEMM)
-        pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
-                _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), planes=PL["out"])
-        # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
-        pl.call("eegclip_residual_layernorm_fwd", _p(b["r1"]), _p(b["h"]), _p(b["r1"]), pe_, 0, SITE_ATTN_OUT, _p(P[_LY + "norm1.weight"]),
-                _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]), _p(b["rs1"]), None, None, None, None, None, R, D_MODEL, EPS, seed_at=4)
-        pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
-                Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PL["ffn1"])
-        pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
-                bias_n=_p(P[_LY + "conv2.bias"]), planes=PL["ffn2"])
-        # norm2 and the encoder's final norm back to back in one launch
-        pl.call("eegclip_residual_layernorm_fwd", _p(b["r2"]), _p(b["n1"]), _p(b["r2"]), pe_, 0, SITE_FFN_OUT, _p(P[_LY + "norm2.weight"]),
-                _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]), _p(b["rs2"]), _p(P["encoder.encoder.norm.weight"]),
-                _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
+            # A1: value embedding + PE into token rows 1..63, then subject token + dropout      (Embed.py:146-162)
+            hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)        # GEMM row m = (sample, channel) -> token row 1 + channel of that sample
+            if not self.joint:
+                pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
+                        _p(b["h"]) + 4 * D_MODEL, hmap, D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
+                        R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1), planes=PL["embed"])
+            else:
+                # joint-subject model (Embed.py:142-144): one GEMM per subject over that subject's block of the subject-ordered batch.  A batch
+                # that is not already in subject order is gathered into xs first and the token rows are scattered back to batch order after
+                # (ops skipped otherwise); M and the A / C pointers of each GEMM are patched per call (_joint_layout), absent subjects skipped.
+                XR = N_CH * T_LEN
+                pl.j_gather = len(pl.ops)
+                pl.call("eegclip_gather_rows", _p(b["xs"]), XR, 0, XR, _p(b["perm"]), B, XR, 0)
+                pl.j_gemm = [pl.desc(N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[w]), D(1), D(T_LEN), 0, hmap, D(1), bias_n=_p(P[bk]),
+                                     R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1)) for w, bk in self.ve_keys]
+                pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)             # ONE launch for all subjects of the batch
+                pl.j_scatter = len(pl.ops)
+                pl.call("eegclip_gather_rows", _p(b["h"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
+                        N_CH * D_MODEL, 1)
+            tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
+            pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
+            # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
+            pl.gemm(R, 3 * HE, D_MODEL, _p(b["h"]), D(D_MODEL), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(1), D(D_MODEL),
+                    _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]), planes=PL["qkv"])
+            pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
+                    SITE_ATTN, seed_at=9)
+            # (dropout + residual of both sublayers live in the LayerNorm kernel that follows, not in the GEMM epilogue: one Philox block per 4
+            #  consecutive columns there, one per ELEMENT in an MFMA accumulator layout -- 12 us per GEMM)
+            pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
+                    _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), planes=PL["out"])
+            # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
+            pl.call("eegclip_residual_layernorm_fwd", _p(b["r1"]), _p(b["h"]), _p(b["r1"]), pe_, 0, SITE_ATTN_OUT, _p(P[_LY + "norm1.weight"]),
+                    _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]), _p(b["rs1"]), None, None, None, None, None, R, D_MODEL, EPS, seed_at=4)
+            pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
+                    Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PL["ffn1"])
+            pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
+                    bias_n=_p(P[_LY + "conv2.bias"]), planes=PL["ffn2"])
+            # norm2 and the encoder's final norm back to back in one launch
+            pl.call("eegclip_residual_layernorm_fwd", _p(b["r2"]), _p(b["n1"]), _p(b["r2"]), pe_, 0, SITE_FFN_OUT, _p(P[_LY + "norm2.weight"]),
+                    _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]), _p(b["rs2"]), _p(P["encoder.encoder.norm.weight"]),
+                    _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
         pl.memset(b["zf"])
@@ -885,6 +909,8 @@ class _Engine:
                 b["ids_uniform"] = uid
         if self.joint:
             self._joint_layout(pl, b, B, host_ids, x.data_ptr(), False)
+        elif pl.tb_desc is not None:
+            pl.tb_desc.x = x.data_ptr()
         else:
             pl.x_gemm.A = x.data_ptr()          # the only per-call pointer: the EEG batch itself
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train and max(probs) > 0 else 0

@@ -1,0 +1,711 @@
+// The transformer block of the ATM-S encoder as ONE workgroup per sample (models/subject_layers/Embed.py:141-162, SelfAttention_Family.py:56-75,
+// 194-213, Transformer_EncDec.py:39-51,61-80): value embedding + positional embedding + subject token + dropout, fused Q|K|V projection, 4-head
+// softmax attention with probability dropout, output projection, dropout + residual + LayerNorm, FFN 250 -> 256 (GELU, dropout) -> 250,
+// dropout + residual + LayerNorm, final LayerNorm.
+//
+// Why one kernel: a sample is 64 tokens x 250 features (64 KB of fp32) -- it fits the 160 KB LDS of a CU with room to spare, and every Linear of
+// the block has K ~ 250: as ten separate launches (round 2) the path was bound by per-launch prologue / epilogue and by ~600 MB per step of
+// activation round trips through HBM, not by the contractions (16 of 27 us of a 16384 x 256 x 250 launch with an EMPTY k-loop).
+// Here activations stay in LDS between the stages; HBM sees the EEG sample once and each tensor the backward needs once (written, never re-read,
+// except the 64 KB residual `h` that comes back from L2).
+//
+// Arithmetic = the plan GEMMs' (csrc/gemm_x3.hip): fp32 in / out / accumulate, products as split bf16 (a = a_hi + a_lo, a b ~ a_hi b_hi + a_hi b_lo
+// + a_lo b_hi on v_mfma_f32_16x16x32_bf16).  Activations are split ONCE by their producer into hi | lo planes in LDS; weights are split once per
+// step by eegclip_token_block_pack into MFMA-fragment order, so a wave's B operand is one coalesced 1 KB load per (16 outputs x 32 k) tile
+// straight into registers (each weight element is used by exactly one wave of a workgroup: LDS staging would be a pure detour).
+//
+// Workgroup = 512 threads = 8 waves (2 per SIMD, 256 VGPRs each).  LDS (128 KB):
+//   AP  [2 planes][64 rows][256 k] bf16   A operand of the current Linear; 512-byte rows, 16-byte chunk index XOR (row & 15): conflict-free
+//                                         ds_read_b128 fragment fetches
+//   XF  [64][256] fp32                    row-wise work (dropout, residual, LayerNorm); 1 KB rows, 16-byte chunk index XOR (row & 15)
+//   during attention both regions hold the q | k | v^T (| P) planes of one head each ([64][64] bf16 hi | lo, 128-byte rows).
+// Dropout masks are Philox(seed, site, flat element index) exactly as in the unfused kernels (csrc/elementwise.hip, norm.hip, attention.hip,
+// gemm_epilogue.h): the backward regenerates them, tests regenerate them in numpy.
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int TB_THREADS = 512;
+constexpr int TB_L = 64, TB_D = 250, TB_T = 250, TB_NCH = 63, TB_H = 4, TB_E = 62, TB_HE = 248, TB_FF = 256;
+constexpr int TB_AP_PLANE = 64 * 512;                       // bytes of one A plane
+constexpr int TB_AP_BYTES = 2 * TB_AP_PLANE;
+constexpr int TB_XF_BYTES = 64 * 1024;
+constexpr int TB_LDS = TB_AP_BYTES + TB_XF_BYTES;
+constexpr int TB_HQ_PLANE = 64 * 128;                       // one [64][64] bf16 plane of a head
+// packed weights: per (n-tile of 16, k-step of 32): 64 lanes x 8 bf16 of the hi plane, then of the lo plane (MFMA B / A fragment order)
+constexpr int TB_KS = 8;
+constexpr int TB_TILE = 1024;                               // bf16 elements per (n-tile, k-step)
+constexpr int TB_NT_V = 16, TB_NT_QKV = 48, TB_NT_O = 16, TB_NT_1 = 16, TB_NT_2 = 16;
+constexpr long long TB_OFF_V = 0;
+constexpr long long TB_OFF_QKV = TB_OFF_V + (long long)TB_NT_V * TB_KS * TB_TILE;
+constexpr long long TB_OFF_O = TB_OFF_QKV + (long long)TB_NT_QKV * TB_KS * TB_TILE;
+constexpr long long TB_OFF_1 = TB_OFF_O + (long long)TB_NT_O * TB_KS * TB_TILE;
+constexpr long long TB_OFF_2 = TB_OFF_1 + (long long)TB_NT_1 * TB_KS * TB_TILE;
+constexpr long long TB_PACKED_ELEMS = TB_OFF_2 + (long long)TB_NT_2 * TB_KS * TB_TILE;
+
+// a value every lane of the wave agrees on, made provably so for the compiler (scalar branches, SGPR addressing)
+__device__ __forceinline__ int wave_uniform(int v) {
+#if defined(EEG_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+typedef float tb_f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte global access from a dword-aligned address
+typedef float tb_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned tb_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int ap_off(int row, int k) { return row * 512 + ((((k >> 3) ^ (row & 15))) << 4) + ((k & 7) << 1); }
+__device__ __forceinline__ int xf_off(int row, int col) { return row * 1024 + ((((col >> 2) ^ (row & 15))) << 4) + ((col & 3) << 2); }
+__device__ __forceinline__ int hq_off(int row, int k) { return row * 128 + ((((k >> 3) ^ ((row >> 1) & 7))) << 4) + ((k & 7) << 1); }
+
+// source element of the packed matrix `mat` at (n, k), or -1 (zero padding)
+//   0  value embedding  (n < 250, k < 250)            Wv[n][k]
+//   1  q | k | v        n = 64 seg + d, seg = 3 head + which, d < 62     Wqkv[which 248 + head 62 + d][k]
+//   2  out projection   (n < 250), k = 64 head + d, d < 62               Wo[n][62 head + d]
+//   3  FFN 1            (n < 256, k < 250)            W1[n][k]
+//   4  FFN 2            (n < 250, k < 256)            W2[n][k]
+__device__ __forceinline__ long long tb_src_index(int mat, int n, int k) {
+    switch (mat) {
+        case 0: return (n < TB_D && k < TB_T) ? (long long)n * TB_T + k : -1;
+        case 1: {
+            const int seg = n >> 6, d = n & 63, head = seg / 3, which = seg - 3 * head;
+            return (seg < 12 && d < TB_E && k < TB_D) ? (long long)(which * TB_HE + head * TB_E + d) * TB_D + k : -1;
+        }
+        case 2: {
+            const int head = k >> 6, d = k & 63;
+            return (n < TB_D && head < TB_H && d < TB_E) ? (long long)n * TB_HE + head * TB_E + d : -1;
+        }
+        case 3: return (n < TB_FF && k < TB_D) ? (long long)n * TB_D + k : -1;
+        default: return (n < TB_D && k < TB_FF) ? (long long)n * TB_FF + k : -1;
+    }
+}
+
+struct tb_pack_args {
+    const float* w[5];
+    unsigned short* out;
+};
+
+// one 64-thread workgroup per (matrix, n-tile, k-step): lane l owns the 8 k of fragment lane l
+__global__ __launch_bounds__(64) void token_block_pack_kernel(const tb_pack_args a) {
+    int tile = blockIdx.x;
+    int mat = 0;
+    const int nts[5] = {TB_NT_V, TB_NT_QKV, TB_NT_O, TB_NT_1, TB_NT_2};
+    while (mat < 4 && tile >= nts[mat] * TB_KS) { tile -= nts[mat] * TB_KS; ++mat; }
+    const int nt = tile / TB_KS, ks = tile % TB_KS;
+    const int lane = threadIdx.x & 63;
+    const int n = 16 * nt + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    const float* src = a.w[mat];
+    unsigned hb[8], lb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const long long si = tb_src_index(mat, n, k0 + e);
+        const float v = si >= 0 ? src[si] : 0.f;
+        const unsigned short h = f32_to_bf16_bits(v);
+        hb[e] = h;
+        lb[e] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+    }
+    unsigned short* dst = a.out + (long long)blockIdx.x * TB_TILE + lane * 8;
+    tb_u4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        oh[e] = hb[2 * e] | (hb[2 * e + 1] << 16);
+        ol[e] = lb[2 * e] | (lb[2 * e + 1] << 16);
+    }
+    *reinterpret_cast<tb_u4*>(dst) = oh;
+    *reinterpret_cast<tb_u4*>(dst + 512) = ol;
+}
+
+// ---- C[64 x 16 NT] of one wave: A = the AP planes (all 64 rows, K = 256), B = NT packed n-tiles starting at `wp`.
+//      bit j of TM set: tile j is formed TRANSPOSED (MFMA rows = n): lane (fr, g) then holds n = 16 j + 4 g + i of row m = 16 mt + fr;
+//      clear: standard, lane holds rows m = 16 mt + 4 g + i of column n = 16 j + fr.
+template <int NT, unsigned TM>
+__device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned short* wp, int lane, f32x4 (&acc)[4][NT]) {
+    const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 bh[2][NT], bl[2][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS) * TB_TILE) + lane;
+        bh[0][j] = p[0];
+        bl[0][j] = p[64];
+    }
+#pragma unroll
+    for (int ks = 0; ks < TB_KS; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < TB_KS) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const bf16x8* p = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + ks + 1) * TB_TILE) + lane;
+                bh[cur ^ 1][j] = p[0];
+                bl[cur ^ 1][j] = p[64];
+            }
+        }
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int off = (16 * mt + fr) * 512 + (((4 * ks + g) ^ fr) << 4);
+            ah[mt] = *reinterpret_cast<const bf16x8*>(AP + off);
+            al[mt] = *reinterpret_cast<const bf16x8*>(AP + TB_AP_PLANE + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if ((TM >> j) & 1u) {
+                    acc[mt][j] = mfma_bf16_16x16x32(bl[cur][j], ah[mt], acc[mt][j]);
+                    acc[mt][j] = mfma_bf16_16x16x32(bh[cur][j], al[mt], acc[mt][j]);
+                    acc[mt][j] = mfma_bf16_16x16x32(bh[cur][j], ah[mt], acc[mt][j]);
+                } else {
+                    acc[mt][j] = mfma_bf16_16x16x32(al[mt], bh[cur][j], acc[mt][j]);
+                    acc[mt][j] = mfma_bf16_16x16x32(ah[mt], bl[cur][j], acc[mt][j]);
+                    acc[mt][j] = mfma_bf16_16x16x32(ah[mt], bh[cur][j], acc[mt][j]);
+                }
+            }
+    }
+}
+
+// 4 consecutive-k fp32 -> hi | lo bf16 (8 bytes each) at the same offset of both planes
+__device__ __forceinline__ void tb_store_planes4(unsigned char* hi_plane, int plane_stride, int off, float v0, float v1, float v2, float v3) {
+    u32x2_t h, l;
+    x3_split4(v0, v1, v2, v3, h, l);
+    *reinterpret_cast<u32x2_t*>(hi_plane + off) = h;
+    *reinterpret_cast<u32x2_t*>(hi_plane + plane_stride + off) = l;
+}
+__device__ __forceinline__ void tb_store_planes2(unsigned char* hi_plane, int plane_stride, int off, float v0, float v1) {
+    const unsigned h = x3_pack2(v0, v1);
+    const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+    *reinterpret_cast<unsigned*>(hi_plane + off) = h;
+    *reinterpret_cast<unsigned*>(hi_plane + plane_stride + off) = x3_pack2(r0, r1);
+}
+
+// 4 floats p[0..3] of which the first `valid` (2 or 4) exist; p is 8-byte aligned
+__device__ __forceinline__ f32x4 tb_ld4(const float* p, int valid) {
+    if (valid >= 4) {
+        const tb_f4u t = *reinterpret_cast<const tb_f4u*>(p);
+        return f32x4{t[0], t[1], t[2], t[3]};
+    }
+    const tb_f2 t = *reinterpret_cast<const tb_f2*>(p);
+    return f32x4{t[0], t[1], 0.f, 0.f};
+}
+__device__ __forceinline__ void tb_st4(float* p, int valid, f32x4 v) {
+    if (valid >= 4) *reinterpret_cast<tb_f4u*>(p) = tb_f4u{v[0], v[1], v[2], v[3]};
+    else *reinterpret_cast<tb_f2*>(p) = tb_f2{v[0], v[1]};
+}
+
+struct tb_fwd_args {
+    const float* x;
+    const unsigned short* packed;
+    const float *bv, *pe, *tokens;
+    const long long* ids;
+    const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;
+    float drop_p, eps, scale;
+    unsigned long long seed;
+    unsigned site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
+};
+
+// one QKV tile of this wave (+ bias) -> global qkv (natural (row, 744) layout) ; values stay in `v` (biased)
+template <bool TRANS>
+__device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int head, int which, int tt, int lane, f32x4 (&v)[4]) {
+    const int fr = lane & 15, g = lane >> 4;
+    const int cbase = which * TB_HE + head * TB_E;
+    if (TRANS) {
+        const int d0 = 16 * tt + 4 * g, valid = TB_E - d0;              // >= 4, or 2 at d0 = 60
+        const f32x4 bias = tb_ld4(a.bqkv + cbase + d0, valid);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = 16 * mt + fr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[mt][i] = i < valid ? v[mt][i] + bias[i] : 0.f;
+            tb_st4(a.qkv + ((long long)b * TB_L + m) * (3 * TB_HE) + cbase + d0, valid, v[mt]);
+        }
+    } else {
+        const int d = 16 * tt + fr;
+        const float bias = d < TB_E ? a.bqkv[cbase + d] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[mt][i] = d < TB_E ? v[mt][i] + bias : 0.f;
+                if (d < TB_E) a.qkv[((long long)b * TB_L + 16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d] = v[mt][i];
+            }
+    }
+}
+// ... -> the head's planes in LDS: q / k as [token][dim], v as [dim][token] (hi plane, lo plane 8 KB behind)
+template <bool TRANS>
+__device__ __forceinline__ void tb_qkv_tile_lds(unsigned char* HQ, int which, int tt, int lane, const f32x4 (&v)[4]) {
+    const int fr = lane & 15, g = lane >> 4;
+    unsigned char* base = HQ + which * (2 * TB_HQ_PLANE);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int off = TRANS ? hq_off(16 * mt + fr, 16 * tt + 4 * g) : hq_off(16 * tt + fr, 16 * mt + 4 * g);
+        tb_store_planes4(base, TB_HQ_PLANE, off, v[mt][0], v[mt][1], v[mt][2], v[mt][3]);
+    }
+}
+
+// V = w & 3: which 3 of the 12 (q t0..3 | k t0..3 | v t0..3) tiles of a head this wave owns: tiles 3 V .. 3 V + 2
+template <int V>
+struct tb_qkv_variant {
+    static constexpr unsigned mask = V == 0 ? 7u : V == 1 ? 7u : V == 2 ? 3u : 0u;      // q and k transposed, v standard
+};
+
+template <int V>
+__device__ __forceinline__ void tb_qkv_pass(const tb_fwd_args& a, const unsigned char* AP, int b, int head, int lane, f32x4 (&acc)[4][3]) {
+    tb_gemm<3, tb_qkv_variant<V>::mask>(AP, a.packed + TB_OFF_QKV + (long long)(head * 12 + 3 * V) * TB_KS * TB_TILE, lane, acc);
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = 3 * V + jj, which = j >> 2, tt = j & 3;
+        f32x4 v[4] = {acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
+        if ((tb_qkv_variant<V>::mask >> jj) & 1u) tb_qkv_tile_out<true>(a, b, head, which, tt, lane, v);
+        else tb_qkv_tile_out<false>(a, b, head, which, tt, lane, v);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][jj] = v[mt];
+    }
+}
+template <int V>
+__device__ __forceinline__ void tb_qkv_to_lds(unsigned char* HQ, int lane, const f32x4 (&acc)[4][3]) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = 3 * V + jj, which = j >> 2, tt = j & 3;
+        const f32x4 v[4] = {acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
+        if ((tb_qkv_variant<V>::mask >> jj) & 1u) tb_qkv_tile_lds<true>(HQ, which, tt, lane, v);
+        else tb_qkv_tile_lds<false>(HQ, which, tt, lane, v);
+    }
+}
+
+// one head, one query tile (16 queries) per wave: S^T = K Q^T (rows = keys), softmax over keys in-lane + 2 shuffles, probability dropout,
+// P -> the wave's own (dead) q rows, ctx^T = V^T P^T.  c[dt][i] = ctx[query 16 qt + fr][dim 16 dt + 4 g + i]
+template <bool TRAIN>
+__device__ __forceinline__ void tb_attention(const tb_fwd_args& a, unsigned char* HQ, int b, int head, int qt, int lane, f32x4 (&c)[4]) {
+    const int fr = lane & 15, g = lane >> 4;
+    unsigned char* Q = HQ;
+    const unsigned char* K = HQ + 2 * TB_HQ_PLANE;
+    const unsigned char* VT = HQ + 4 * TB_HQ_PLANE;
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int qo = hq_off(16 * qt + fr, 32 * ks + 8 * g);
+        const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Q + qo), ql = *reinterpret_cast<const bf16x8*>(Q + TB_HQ_PLANE + qo);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int ko = hq_off(16 * kt + fr, 32 * ks + 8 * g);
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(K + ko), kl = *reinterpret_cast<const bf16x8*>(K + TB_HQ_PLANE + ko);
+            s[kt] = mfma_bf16_16x16x32(kl, qh, s[kt]);
+            s[kt] = mfma_bf16_16x16x32(kh, ql, s[kt]);
+            s[kt] = mfma_bf16_16x16x32(kh, qh, s[kt]);          // S[key 16 kt + 4 g + i][query 16 qt + fr]
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[kt][i] *= a.scale;
+            mx = fmaxf(mx, s[kt][i]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[kt][i] = expf(s[kt][i] - mx);
+            sum += s[kt][i];
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    wave_sync();                                                 // every lane has its q fragments: the rows may be overwritten
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        bool keep[4] = {true, true, true, true};
+        if (TRAIN && a.drop_p > 0.f) {
+            const unsigned long long idx0 = (((unsigned long long)(b * TB_H + head) * TB_L + 16 * qt + fr) * TB_L) + 16 * kt + 4 * g;
+            dropout_keep4(a.seed, a.site_attn, idx0, a.drop_p, keep);
+        }
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = keep[i] ? s[kt][i] * inv * ksc : 0.f;
+        tb_store_planes4(Q, TB_HQ_PLANE, hq_off(16 * qt + fr, 16 * kt + 4 * g), p[0], p[1], p[2], p[3]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) c[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int po = hq_off(16 * qt + fr, 32 * ks + 8 * g);
+        const bf16x8 ph = *reinterpret_cast<const bf16x8*>(Q + po), pl = *reinterpret_cast<const bf16x8*>(Q + TB_HQ_PLANE + po);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int vo = hq_off(16 * dt + fr, 32 * ks + 8 * g);
+            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(VT + vo), vl = *reinterpret_cast<const bf16x8*>(VT + TB_HQ_PLANE + vo);
+            c[dt] = mfma_bf16_16x16x32(vl, ph, c[dt]);
+            c[dt] = mfma_bf16_16x16x32(vh, pl, c[dt]);
+            c[dt] = mfma_bf16_16x16x32(vh, ph, c[dt]);
+        }
+    }
+}
+
+// row pass of the two post-LN sublayer tails: v = resid + dropout(x), y = LN(v) [, y2 = LN(y)].  Wave w owns rows 8 w .. 8 w + 7; a lane owns the 4
+// columns of ONE Philox block of the flat (B, 64, 250) index: c0 = 4 lane - (row odd ? 2 : 0) (row starts are 2 mod 4 for odd rows).
+// x comes from `xs` (an XF-layout LDS image), resid from `resid_lds` (XF layout) or `resid_g` (global rows of 250)
+template <bool TRAIN, bool DOUBLE>
+__device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, int lane, const unsigned char* xs, const unsigned char* resid_lds,
+                                           const float* resid_g, unsigned site, float* r_out, const float* g1, const float* be1, float* y_out, float* mu_out,
+                                           float* rs_out, const float* g2, const float* be2, float* y2_out, float* mu2_out, float* rs2_out,
+                                           unsigned char* y_lds /* XF layout or null */, unsigned char* ap /* planes of y or null */) {
+    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    const float inv = 1.0f / (float)TB_D;
+    tb_f2 rg[8][2];
+    if (resid_g) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = 8 * w + rr, c0 = 4 * lane - ((r & 1) ? 2 : 0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                rg[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(resid_g + ((long long)b * TB_L + r) * TB_D + cp) : tb_f2{0.f, 0.f};
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * w + rr, c0 = 4 * lane - ((r & 1) ? 2 : 0);
+        const long long rbase = ((long long)b * TB_L + r) * TB_D;
+        float v[4];
+        bool ok[2];
+        bool keep[4] = {true, true, true, true};
+        if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, site, (unsigned long long)(rbase + c0), a.drop_p, keep);
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int cp = c0 + 2 * p;
+            ok[p] = cp >= 0 && cp < TB_D;
+            tb_f2 xv = tb_f2{0.f, 0.f}, rv = tb_f2{0.f, 0.f};
+            if (ok[p]) {
+                xv = *reinterpret_cast<const tb_f2*>(xs + xf_off(r, cp));
+                rv = resid_g ? rg[rr][p] : *reinterpret_cast<const tb_f2*>(resid_lds + xf_off(r, cp));
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float d = xv[e];
+                if (TRAIN && a.drop_p > 0.f) d = keep[2 * p + e] ? d * ksc : 0.f;
+                v[2 * p + e] = ok[p] ? d + rv[e] : 0.f;
+                s += v[2 * p + e];
+            }
+            if (ok[p] && r_out) *reinterpret_cast<tb_f2*>(r_out + rbase + cp) = tb_f2{v[2 * p], v[2 * p + 1]};
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dl = ok[e >> 1] ? v[e] - mean : 0.f;
+            q += dl * dl;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv + a.eps);
+        float y[4];
+        float s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int cp = c0 + 2 * p;
+            tb_f2 gg = tb_f2{0.f, 0.f}, bb = tb_f2{0.f, 0.f};
+            if (ok[p]) {
+                gg = *reinterpret_cast<const tb_f2*>(g1 + cp);
+                bb = *reinterpret_cast<const tb_f2*>(be1 + cp);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                y[2 * p + e] = ok[p] ? (v[2 * p + e] - mean) * rstd * gg[e] + bb[e] : 0.f;
+                s2 += y[2 * p + e];
+            }
+            if (ok[p]) {
+                *reinterpret_cast<tb_f2*>(y_out + rbase + cp) = tb_f2{y[2 * p], y[2 * p + 1]};
+                if (y_lds) *reinterpret_cast<tb_f2*>(y_lds + xf_off(r, cp)) = tb_f2{y[2 * p], y[2 * p + 1]};
+            }
+            if (ap && cp >= 0 && cp < 256) tb_store_planes2(ap, TB_AP_PLANE, ap_off(r, cp), y[2 * p], y[2 * p + 1]);      // (zeros past column 249)
+        }
+        if (ap && (r & 1) && lane == 63) tb_store_planes2(ap, TB_AP_PLANE, ap_off(r, 254), 0.f, 0.f);                       // odd rows: 254, 255 belong to no lane
+        if (lane == 0) {
+            mu_out[(long long)b * TB_L + r] = mean;
+            rs_out[(long long)b * TB_L + r] = rstd;
+        }
+        if (DOUBLE) {
+            const float mean2 = wave_sum(s2) * inv;
+            float q2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dl = ok[e >> 1] ? y[e] - mean2 : 0.f;
+                q2 += dl * dl;
+            }
+            const float rstd2 = rsqrtf(wave_sum(q2) * inv + a.eps);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                if (ok[p]) {
+                    const tb_f2 gg = *reinterpret_cast<const tb_f2*>(g2 + cp), bb = *reinterpret_cast<const tb_f2*>(be2 + cp);
+                    *reinterpret_cast<tb_f2*>(y2_out + rbase + cp) =
+                        tb_f2{(y[2 * p] - mean2) * rstd2 * gg[0] + bb[0], (y[2 * p + 1] - mean2) * rstd2 * gg[1] + bb[1]};
+                }
+            }
+            if (lane == 0) {
+                mu2_out[(long long)b * TB_L + r] = mean2;
+                rs2_out[(long long)b * TB_L + r] = rstd2;
+            }
+        }
+    }
+}
+
+// epilogue of the three 64 x 256 Linears whose tiles are all transposed (NT = 2: wave w owns n = 32 w .. 32 w + 31): calls f(m, n0, valid, acc4)
+// for every (row m, 4 consecutive columns n0..) group this lane holds; valid = how many of the 4 columns exist (N = 250: 2 at n0 = 248)
+template <class F>
+__device__ __forceinline__ void tb_for_tiles(int w, int lane, int N, f32x4 (&acc)[4][2], F&& f) {
+    const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n0 = 32 * w + 16 * j + 4 * g;
+        if (n0 >= N) continue;
+        const int valid = N - n0 >= 4 ? 4 : N - n0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) f(16 * mt + fr, n0, valid, acc[mt][j]);
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb_fwd_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    unsigned char* const AP = lds;
+    unsigned char* const XF = lds + TB_AP_BYTES;
+    const int t = threadIdx.x, lane = t & 63, w = wave_uniform(t >> 6), fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    // ---- S0: the EEG sample (63 x 250 fp32) -> A planes, token row 1 + channel; row 0 and k >= 250 are zero
+    {
+        const float* xb = a.x + (long long)b * (TB_NCH * TB_T);
+        tb_f2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int u = t + TB_THREADS * j;
+            v[j] = u < TB_NCH * TB_T / 2 ? *reinterpret_cast<const tb_f2*>(xb + 2 * u) : tb_f2{0.f, 0.f};
+        }
+        if (t < 64) *reinterpret_cast<tb_u4*>(AP + (t >> 5) * TB_AP_PLANE + (t & 31) * 16) = tb_u4{0u, 0u, 0u, 0u};      // row 0 of both planes
+        else if (t < 192) {
+            const int row = (t - 64) & 63, plane = (t - 64) >> 6;
+#pragma unroll
+            for (int k = 250; k < 256; k += 2) *reinterpret_cast<unsigned*>(AP + plane * TB_AP_PLANE + ap_off(row, k)) = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int u = t + TB_THREADS * j;
+            if (u < TB_NCH * TB_T / 2) {
+                const int flat = 2 * u, c = flat / TB_T, k = flat - TB_T * c;
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(c + 1, k), v[j][0], v[j][1]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_V + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        const long long id = a.ids ? a.ids[b] : 0;
+        tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
+            f32x4 o;
+            if (m == 0) o = tb_ld4(a.tokens + id * TB_D + n0, valid);
+            else {
+                const f32x4 bias = tb_ld4(a.bv + n0, valid), pe = tb_ld4(a.pe + (long long)(m - 1) * TB_D + n0, valid);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (v[i] + bias[i]) + pe[i];
+            }
+            if (valid < 4) { o[2] = 0.f; o[3] = 0.f; }
+            *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
+        });
+    }
+    __syncthreads();
+
+    // ---- S2: embedding dropout over the flat (64 x 250) sample (one Philox block = 4 consecutive flat elements); h -> HBM and -> A planes
+    {
+        float* hb = a.h + (long long)b * (TB_L * TB_D);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = t + TB_THREADS * j;
+            if (q < TB_L * TB_D / 4) {
+                const int i0 = 4 * q, row = i0 / TB_D, col = i0 - TB_D * row;
+                const bool wrap = col + 2 >= TB_D;                     // the second pair starts the next row
+                const int row2 = wrap ? row + 1 : row, col2 = wrap ? col + 2 - TB_D : col + 2;
+                const tb_f2 p0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row, col)), p1 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row2, col2));
+                float v[4] = {p0[0], p0[1], p1[0], p1[1]};
+                if (TRAIN && a.drop_p > 0.f) {
+                    bool keep[4];
+                    dropout_keep4(a.seed, a.site_embed, (unsigned long long)b * (TB_L * TB_D) + i0, a.drop_p, keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ksc : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(hb + i0) = f32x4{v[0], v[1], v[2], v[3]};
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, col), v[0], v[1]);
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row2, col2), v[2], v[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S3: q | k | v of all heads (SelfAttention_Family.py:199-207): two passes of 24 tiles (heads 2, 3 first: parked in registers; heads 0, 1
+    //          go to LDS at once), then two rounds of attention, waves 0-3 on one head and 4-7 on the other
+    f32x4 ctxr[2][4];
+    {
+        f32x4 held[4][3], cur[4][3];
+        const int hip = w >> 2;                                      // head within the pair
+        switch (w & 3) {
+            case 0: tb_qkv_pass<0>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<0>(a, AP, b, hip, lane, cur); break;
+            case 1: tb_qkv_pass<1>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<1>(a, AP, b, hip, lane, cur); break;
+            case 2: tb_qkv_pass<2>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<2>(a, AP, b, hip, lane, cur); break;
+            default: tb_qkv_pass<3>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<3>(a, AP, b, hip, lane, cur); break;
+        }
+        unsigned char* const HQ = hip ? XF : AP;
+        __syncthreads();                                             // the h planes are dead: AP and XF become the two heads' q | k | v^T planes
+        switch (w & 3) {
+            case 0: tb_qkv_to_lds<0>(HQ, lane, cur); break;
+            case 1: tb_qkv_to_lds<1>(HQ, lane, cur); break;
+            case 2: tb_qkv_to_lds<2>(HQ, lane, cur); break;
+            default: tb_qkv_to_lds<3>(HQ, lane, cur); break;
+        }
+        __syncthreads();
+        tb_attention<TRAIN>(a, HQ, b, hip, w & 3, lane, ctxr[0]);
+        __syncthreads();
+        switch (w & 3) {
+            case 0: tb_qkv_to_lds<0>(HQ, lane, held); break;
+            case 1: tb_qkv_to_lds<1>(HQ, lane, held); break;
+            case 2: tb_qkv_to_lds<2>(HQ, lane, held); break;
+            default: tb_qkv_to_lds<3>(HQ, lane, held); break;
+        }
+        __syncthreads();
+        tb_attention<TRAIN>(a, HQ, b, 2 + hip, w & 3, lane, ctxr[1]);
+        __syncthreads();
+        // context -> HBM (natural (row, 248) layout) and -> A planes with 64 columns per head (dims 62, 63 are exact zeros)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int head = 2 * rd + hip, m = 16 * (w & 3) + fr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                const f32x4 c = ctxr[rd][dt];
+                if (d0 < TB_E) tb_st4(a.ctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, c);
+                tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, 64 * head + d0), c[0], c[1], c[2], c[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S4: output projection + bias -> XF      (SelfAttention_Family.py:213)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_O + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
+            const f32x4 bias = tb_ld4(a.bo + n0, valid);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = i < valid ? v[i] + bias[i] : 0.f;
+            *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
+        });
+    }
+    __syncthreads();
+    // ---- S5: r1 = h + dropout(attention output), n1 = LayerNorm1(r1); n1 stays in XF (FFN residual) and goes to the A planes
+    tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, a.n1, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, XF, AP);
+    __syncthreads();
+
+    // ---- S6: FFN 1 + bias -> f1 (pre-activation, kept for the backward), g1 = dropout(gelu(f1))      (Transformer_EncDec.py:48)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + n0);
+            const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
+            f32x4 f, gq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = v[i] + bias[i];
+            *reinterpret_cast<f32x4*>(a.f1 + o) = f;
+            bool keep[4] = {true, true, true, true};
+            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ge = gelu_erf(f[i]);
+                gq[i] = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
+            }
+            *reinterpret_cast<f32x4*>(a.g1 + o) = gq;
+            v = gq;
+        });
+        __syncthreads();                                             // every wave is done with the n1 planes
+        tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
+            tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, n0), v[0], v[1], v[2], v[3]);
+        });
+    }
+    __syncthreads();
+
+    // ---- S7: FFN 2 + bias; the result replaces the (dead) g1 planes as an fp32 image      (Transformer_EncDec.py:49)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        __syncthreads();
+        tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
+            const f32x4 bias = tb_ld4(a.b2 + n0, valid);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = i < valid ? v[i] + bias[i] : 0.f;
+            *reinterpret_cast<f32x4*>(AP + xf_off(m, n0)) = o;
+        });
+    }
+    __syncthreads();
+    // ---- S8: r2 = n1 + dropout(FFN output), n2 = LayerNorm2(r2), n3 = final LayerNorm(n2)      (Transformer_EncDec.py:51,77-78)
+    tb_ln_rows<TRAIN, true>(a, b, w, lane, AP, XF, nullptr, a.site_ffn_out, a.r2, a.ln2_g, a.ln2_b, a.n2, a.mu2, a.rs2, a.ln3_g, a.ln3_b, a.n3, a.mu3, a.rs3,
+                            nullptr, nullptr);
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+extern "C" long long eegclip_token_block_packed_bytes(void) { return TB_PACKED_ELEMS * 2; }
+
+extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream) {
+    if (!wv || !wqkv || !wo || !w1 || !w2 || !packed) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(packed) & 15u) return EEGCLIP_EALIGN;
+    tb_pack_args a{{wv, wqkv, wo, w1, w2}, static_cast<unsigned short*>(packed)};
+    const int tiles = (TB_NT_V + TB_NT_QKV + TB_NT_O + TB_NT_1 + TB_NT_2) * TB_KS;
+    EEG_LAUNCH(token_block_pack_kernel, dim3(tiles), dim3(64), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream) {
+    if (!d || d->B < 1 || !d->x || !d->packed || !d->bv || !d->pe || !d->tokens || !d->bqkv || !d->bo || !d->ln1_g || !d->ln1_b || !d->b1 || !d->b2 ||
+        !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctx || !d->r1 || !d->n1 || !d->mu1 || !d->rs1 || !d->f1 || !d->g1 ||
+        !d->r2 || !d->n2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->h) |
+                           reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->g1) | reinterpret_cast<uintptr_t>(d->b1);
+    const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->qkv) | reinterpret_cast<uintptr_t>(d->ctx) | reinterpret_cast<uintptr_t>(d->r1) |
+                          reinterpret_cast<uintptr_t>(d->n1) | reinterpret_cast<uintptr_t>(d->r2) | reinterpret_cast<uintptr_t>(d->n2) |
+                          reinterpret_cast<uintptr_t>(d->n3) | reinterpret_cast<uintptr_t>(d->bv) | reinterpret_cast<uintptr_t>(d->pe) |
+                          reinterpret_cast<uintptr_t>(d->tokens) | reinterpret_cast<uintptr_t>(d->bqkv) | reinterpret_cast<uintptr_t>(d->bo) |
+                          reinterpret_cast<uintptr_t>(d->b2) | reinterpret_cast<uintptr_t>(d->ln1_g) | reinterpret_cast<uintptr_t>(d->ln1_b) |
+                          reinterpret_cast<uintptr_t>(d->ln2_g) | reinterpret_cast<uintptr_t>(d->ln2_b) | reinterpret_cast<uintptr_t>(d->ln3_g) |
+                          reinterpret_cast<uintptr_t>(d->ln3_b);
+    if ((al16 & 15u) || (al8 & 7u)) return EEGCLIP_EALIGN;
+    tb_fwd_args a{d->x, static_cast<const unsigned short*>(d->packed), d->bv, d->pe, d->tokens, d->ids, d->bqkv, d->bo, d->ln1_g, d->ln1_b, d->b1, d->b2,
+                  d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->ctx, d->r1, d->n1, d->mu1, d->rs1, d->f1, d->g1, d->r2, d->n2, d->mu2, d->rs2,
+                  d->n3, d->mu3, d->rs3, d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn, d->site_attn_out, d->site_ffn_act,
+                  d->site_ffn_out};
+    if (d->drop_p > 0.f) EEG_LAUNCH(token_block_fwd_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+    else EEG_LAUNCH(token_block_fwd_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+    return (int)hipGetLastError();
+}

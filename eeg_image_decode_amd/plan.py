@@ -65,6 +65,14 @@ class Plan:
         if seed_at is not None:
             self._seed_slots.append((len(self.ops) - 1, seed_at))
 
+    def call_desc(self, fname, d, seeded=False, side=False):
+        """an op whose only argument is a descriptor struct owned by the plan (`seeded`: its .seed field takes the run's dropout seed)"""
+        self._keep.append(d)
+        if seeded:
+            self._seed_descs.append(d)
+        self.ops.append((getattr(self.L, fname), [ctypes.byref(d), None], fname, side))
+        return d
+
     def desc(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
              alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None, planes=None):
         """a GEMM descriptor owned by the plan but not (yet) an op: member template of a grouped launch"""

@@ -433,6 +433,31 @@ int eegclip_plan_events_destroy(int n, void* const* events);
 int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* const* events,
                      void* join_event, int* dirty, int* failed);
 
+/* ---- the transformer block of the encoder as ONE launch, one workgroup per sample (csrc/token_block.hip): value embedding + positional
+ * embedding + subject token + dropout (models/subject_layers/Embed.py:141-162), fused q | k | v projection, 4-head attention with probability
+ * dropout, output projection (SelfAttention_Family.py:56-75,194-213), dropout + residual + LayerNorm, FFN 250 -> 256 (GELU, dropout) -> 250,
+ * dropout + residual + LayerNorm, final LayerNorm (Transformer_EncDec.py:39-51,61-80).  Replaces ten launches of the forward plan; writes every
+ * tensor the backward reads, in the layouts of the unfused kernels, with the same Philox masks (seed, site, flat element index).  Arithmetic of
+ * the Linears: split-bf16 products, fp32 accumulate (EEGCLIP_PREC_BF16X3).  Specialised for 63 channels x 250 samples, d_model 250, 4 heads x 62,
+ * d_ff 256 (the reference's only configuration, Retrieval/ATMS_retrieval.py:52-66).
+ * eegclip_token_block_pack: the five weight matrices (nn.Linear layout (out, in), row-major; wqkv = q | k | v rows stacked) -> bf16 hi | lo planes
+ * in MFMA-fragment order, eegclip_token_block_packed_bytes() bytes at `packed` (16-byte aligned): once per optimizer step. */
+typedef struct {
+    int B;                                     /* samples = workgroups */
+    const float* x;                            /* (B, 63, 250) */
+    const void* packed;                        /* eegclip_token_block_pack output */
+    const float *bv, *pe, *tokens;             /* value-embedding bias (250); positional table rows 0..62 (row stride 250); token table (rows of 250) */
+    const long long* ids;                      /* (B) row of `tokens` per sample, NULL: row 0 (the shared token) */
+    const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;      /* outputs, rows = B * 64 */
+    float drop_p, eps, scale;                  /* dropout probability of all five sites (0: evaluation), LayerNorm eps, softmax scale */
+    unsigned long long seed;
+    unsigned int site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
+} eegclip_token_block_desc;
+long long eegclip_token_block_packed_bytes(void);
+int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream);
+int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream);
+
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
  * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */

@@ -480,10 +480,11 @@ def test_clip_loss_at_global_batch_2048_matches_torch_fp32_and_its_gradients():
 
 def test_retrieval_accuracy_after_training_matches_the_oracle():
     """north_star: top-1 / top-5 retrieval accuracy on held-out synthetic pairs.  A short version of tools/accuracy_parity.py (whose full run --
-    150 steps, identical accuracies for every k, profiles/r1_accuracy_parity.json -- takes two minutes of host time): same weights, same
-    batches, dropout off; after 40 AdamW steps the held-out 200-way scores of the HIP path and of the CPU oracle must agree."""
+    150 steps, identical accuracies for every k on 1000 held-out classes in the default split-bf16 arithmetic, profiles/r3_accuracy_parity.json --
+    takes two minutes of host time): same weights, same batches, dropout off; after 40 AdamW steps the scores of the HIP path and of the CPU
+    oracle on 1000 held-out classes (0.1 % = one query) must agree within north_star's +-0.1 %."""
     from eeg_image_decode_amd import optim, retrieval
-    n_train, per, n_test, B, steps = 400, 2, 200, 64, 40
+    n_train, per, n_test, B, steps = 400, 2, 1000, 64, 40
     eeg, lab, protos = syn.learnable_pairs(5, n_train + n_test, per, noise=0.5)
     tr = lab < n_train
     xtr, ltr = T(eeg[tr]), T(lab[tr])
@@ -513,5 +514,5 @@ def test_retrieval_accuracy_after_training_matches_the_oracle():
     acc = lambda t: (float((t[:, 0] == want).float().mean()), float((t == want[:, None]).any(1).float().mean()))
     (g1, g5), (o1, o5) = acc(tg), acc(to)
     assert o5 > 3 * 5 / n_test                                    # the model has learnt something: well above the 2.5 % chance level
-    assert abs(g1 - o1) <= 1.0 / n_test + 1e-9 and abs(g5 - o5) <= 1.0 / n_test + 1e-9, ((g1, g5), (o1, o5))
+    assert abs(g1 - o1) <= 0.001 + 1e-9 and abs(g5 - o5) <= 0.001 + 1e-9, ((g1, g5), (o1, o5))       # +-0.1 %
     assert int((tg[:, 0] != to[:, 0]).sum()) <= 2
