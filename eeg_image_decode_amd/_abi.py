@@ -49,6 +49,15 @@ class TokenBlockDesc(C.Structure):
                 + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")])
 
 
+class TokenBlockBwdDesc(C.Structure):
+    _fields_ = ([("B", C.c_int), ("packed", C.c_void_p)]
+                + [(k, C.c_void_p) for k in ("dn3", "n2", "r2", "r1", "f1", "mu1", "rs1", "mu2", "rs2", "mu3", "rs3", "ln1_g", "ln2_g", "ln3_g")]
+                + [(k, C.c_void_p) for k in ("df2", "dg1", "da1", "dr1", "dctx", "partials", "dqkv")]
+                + [(k, C.c_void_p) for k in ("dln3_g", "dln3_b", "dln2_g", "dln2_b", "dln1_g", "dln1_b")]
+                + [("drop_p", C.c_float), ("seed", C.c_ulonglong)]
+                + [(k, C.c_uint) for k in ("site_embed", "site_attn_out", "site_ffn_act", "site_ffn_out")])
+
+
 PLAN_MAX_ARGS = 24
 PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP = -2, -3, 1, 2
 
@@ -140,6 +149,8 @@ PROTOTYPES = {
     "eegclip_token_block_packed_bytes": [],
     "eegclip_token_block_pack": [_P, _P, _P, _P, _P, _P, _P],
     "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],
+    "eegclip_token_block_bwd_workspace_floats": [_I],
+    "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

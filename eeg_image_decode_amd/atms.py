@@ -14,6 +14,7 @@ arithmetic in hand-written HIP kernels reached through the C ABI (include/eegcli
 * There is no CPU / eager-PyTorch fallback: a CPU tensor or a missing library raises.
 """
 import os
+import ctypes
 import math
 
 import numpy as np
@@ -769,36 +770,64 @@ class _Engine:
             # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
             pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
-        # final LN, LN2
-        pl.call("eegclip_layernorm_bwd_full", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
-                _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, lnf_ws)
-        # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2).  LN2 backward emits dr2 (residual path) and df2 = dropout'(dr2);
-        # bias gradients ride on the weight-gradient GEMMs; dropout' and gelu' of the hidden activation are the epilogue of the GEMM
-        # that produces its gradient -- 5 elementwise / reduction passes over (B*64, 250..256) tensors gone
-        pl.call("eegclip_layernorm_bwd_full", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
-                _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, lnf_ws, seed_at=13)
-        wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
-        pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
-                act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PLT["ffn2"])                  # dg1 := df1
-        wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
-        pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
-                accumulate=1, planes=PLT["ffn1"])                                              # dr2 := dn1
-        # attention block: r1 = h + dropout(Wo ctx + bo)
-        pl.call("eegclip_layernorm_bwd_full", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
-                _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, lnf_ws, seed_at=13)
-        wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
-              bias=_LY + "attention.out_projection.bias")
-        pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
-                planes=PLT["out"])
-        pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
-                pe_, 0, SITE_ATTN, seed_at=10)
-        wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
-              bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
-        pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
-                _p(b["dr1"]), D(D_MODEL), D(1), accumulate=2, drop_p=pe_, drop_site=SITE_EMBED, planes=PLT["qkv"])
-        # ^ dr1 := dropout'(dh): the embedding dropout's backward (Embed.py:162) is the epilogue of the GEMM that completes dh -- accumulate FIRST
-        #   (residual-path gradient already in dr1), then the mask of the (B,64,250) element index = m * 250 + n -- instead of a separate in-place
-        #   pass over the 16 MB tensor (35 us in the step)
+        if self._token_block_enabled(pl) and hasattr(self, "tb_packed") and os.environ.get("EEGCLIP_TOKEN_BLOCK_BWD", "1") != "0":
+            # the dX chain of the transformer block, one workgroup per sample (csrc/token_block.hip): part 0 = final LN' .. dctx, the attention
+            # backward, part 1 = dh.  The weight-gradient GEMMs read what the parts leave in HBM (df2, dg1 = df1, da1, dqkv, dr1) on the second stream.
+            if "tb_part" not in b:
+                b["tb_part"] = torch.empty(int(lib().eegclip_token_block_bwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
+            bd = _abi.TokenBlockBwdDesc(
+                B=B, packed=_p(self.tb_packed), dn3=_p(b["dn3"]), n2=_p(b["n2"]), r2=_p(b["r2"]), r1=_p(b["r1"]), f1=_p(b["f1"]), mu1=_p(b["mu1"]),
+                rs1=_p(b["rs1"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]), ln1_g=_p(P[_LY + "norm1.weight"]),
+                ln2_g=_p(P[_LY + "norm2.weight"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), df2=_p(b["df2"]), dg1=_p(b["dg1"]), da1=_p(b["da1"]),
+                dr1=_p(b["dr1"]), dctx=_p(b["dctx"]), partials=_p(b["tb_part"]), dqkv=_p(b["dqkv"]),
+                dln3_g=_p(G["encoder.encoder.norm.weight"]), dln3_b=_p(G["encoder.encoder.norm.bias"]), dln2_g=_p(G[_LY + "norm2.weight"]),
+                dln2_b=_p(G[_LY + "norm2.bias"]), dln1_g=_p(G[_LY + "norm1.weight"]), dln1_b=_p(G[_LY + "norm1.bias"]),
+                drop_p=pe_, seed=0, site_embed=SITE_EMBED, site_attn_out=SITE_ATTN_OUT, site_ffn_act=SITE_FFN_ACT, site_ffn_out=SITE_FFN_OUT)
+            pl._keep.append(bd)
+            if pe_ > 0.0:
+                pl._seed_descs.append(bd)
+            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
+            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
+            wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
+            wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
+            wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
+                  bias=_LY + "attention.out_projection.bias")
+            pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                    pe_, 0, SITE_ATTN, seed_at=10)
+            wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
+                  bias=_LY + "attention.query_projection.bias")
+            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 1)
+        else:
+            # final LN, LN2
+            pl.call("eegclip_layernorm_bwd_full", _p(b["dn3"]), _p(b["n2"]), _p(P["encoder.encoder.norm.weight"]), _p(b["mu3"]), _p(b["rs3"]), _p(b["dn2"]),
+                    _p(G["encoder.encoder.norm.weight"]), _p(G["encoder.encoder.norm.bias"]), R, D_MODEL, 0, None, 0.0, 0, 0, lnf_ws)
+            # FFN: r2 = n1 + dropout(W2 dropout(gelu(W1 n1 + b1)) + b2).  LN2 backward emits dr2 (residual path) and df2 = dropout'(dr2);
+            # bias gradients ride on the weight-gradient GEMMs; dropout' and gelu' of the hidden activation are the epilogue of the GEMM
+            # that produces its gradient -- 5 elementwise / reduction passes over (B*64, 250..256) tensors gone
+            pl.call("eegclip_layernorm_bwd_full", _p(b["dn2"]), _p(b["r2"]), _p(P[_LY + "norm2.weight"]), _p(b["mu2"]), _p(b["rs2"]), _p(b["dr2"]),
+                    _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, lnf_ws, seed_at=13)
+            wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
+            pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
+                    act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PLT["ffn2"])                  # dg1 := df1
+            wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
+            pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
+                    accumulate=1, planes=PLT["ffn1"])                                              # dr2 := dn1
+            # attention block: r1 = h + dropout(Wo ctx + bo)
+            pl.call("eegclip_layernorm_bwd_full", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
+                    _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, lnf_ws, seed_at=13)
+            wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
+                  bias=_LY + "attention.out_projection.bias")
+            pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
+                    planes=PLT["out"])
+            pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                    pe_, 0, SITE_ATTN, seed_at=10)
+            wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
+                  bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
+            pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
+                    _p(b["dr1"]), D(D_MODEL), D(1), accumulate=2, drop_p=pe_, drop_site=SITE_EMBED, planes=PLT["qkv"])
+            # ^ dr1 := dropout'(dh): the embedding dropout's backward (Embed.py:162) is the epilogue of the GEMM that completes dh -- accumulate FIRST
+            #   (residual-path gradient already in dr1), then the mask of the (B,64,250) element index = m * 250 + n -- instead of a separate in-place
+            #   pass over the 16 MB tensor (35 us in the step)
         # embedding: token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
         pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, 0.0, 0, SITE_EMBED)

@@ -14,11 +14,14 @@
 // step by eegclip_token_block_pack into MFMA-fragment order, so a wave's B operand is one coalesced 1 KB load per (16 outputs x 32 k) tile
 // straight into registers (each weight element is used by exactly one wave of a workgroup: LDS staging would be a pure detour).
 //
-// Workgroup = 512 threads = 8 waves (2 per SIMD, 256 VGPRs each).  LDS (128 KB):
+// Workgroup = 512 threads = 8 waves (2 per SIMD, 256 VGPRs each).  LDS (160 KB, all of a CU):
 //   AP  [2 planes][64 rows][256 k] bf16   A operand of the current Linear; 512-byte rows, 16-byte chunk index XOR (row & 15): conflict-free
 //                                         ds_read_b128 fragment fetches
 //   XF  [64][256] fp32                    row-wise work (dropout, residual, LayerNorm); 1 KB rows, 16-byte chunk index XOR (row & 15)
-//   during attention both regions hold the q | k | v^T (| P) planes of one head each ([64][64] bf16 hi | lo, 128-byte rows).
+//   HQ  2 x 48 KB behind AP (over XF, which is dead then): the q | k | v^T (| P) planes of two heads ([64][64] bf16 hi | lo, 128-byte rows).
+// Barriers are s_barrier + lgkmcnt(0) only (raw_barrier): __syncthreads() also drains vmcnt, and on CDNA4 that counts the STORES -- every
+// stage writes something the backward needs, so each barrier would wait for a full HBM write round trip (the first version: 64 % of all wave
+// cycles waiting, 123 us; PMC in profiles/r3_pmc_token_block.json).
 // Dropout masks are Philox(seed, site, flat element index) exactly as in the unfused kernels (csrc/elementwise.hip, norm.hip, attention.hip,
 // gemm_epilogue.h): the backward regenerates them, tests regenerate them in numpy.
 #include "eeg_common.h"
@@ -30,18 +33,25 @@ constexpr int TB_L = 64, TB_D = 250, TB_T = 250, TB_NCH = 63, TB_H = 4, TB_E = 6
 constexpr int TB_AP_PLANE = 64 * 512;                       // bytes of one A plane
 constexpr int TB_AP_BYTES = 2 * TB_AP_PLANE;
 constexpr int TB_XF_BYTES = 64 * 1024;
-constexpr int TB_LDS = TB_AP_BYTES + TB_XF_BYTES;
 constexpr int TB_HQ_PLANE = 64 * 128;                       // one [64][64] bf16 plane of a head
+constexpr int TB_HQ_BYTES = 6 * TB_HQ_PLANE;                // q | k | v^T, hi | lo each
+constexpr int TB_LDS = TB_AP_BYTES + 2 * TB_HQ_BYTES;       // 160 KB: the h planes + two heads' planes (XF is the first 64 KB behind AP)
 // packed weights: per (n-tile of 16, k-step of 32): 64 lanes x 8 bf16 of the hi plane, then of the lo plane (MFMA B / A fragment order)
 constexpr int TB_KS = 8;
 constexpr int TB_TILE = 1024;                               // bf16 elements per (n-tile, k-step)
 constexpr int TB_NT_V = 16, TB_NT_QKV = 48, TB_NT_O = 16, TB_NT_1 = 16, TB_NT_2 = 16;
+constexpr int TB_NMAT = 11;                                 // 5 forward operands, 6 backward (transposed) ones of 16 n-tiles each
 constexpr long long TB_OFF_V = 0;
 constexpr long long TB_OFF_QKV = TB_OFF_V + (long long)TB_NT_V * TB_KS * TB_TILE;
 constexpr long long TB_OFF_O = TB_OFF_QKV + (long long)TB_NT_QKV * TB_KS * TB_TILE;
 constexpr long long TB_OFF_1 = TB_OFF_O + (long long)TB_NT_O * TB_KS * TB_TILE;
 constexpr long long TB_OFF_2 = TB_OFF_1 + (long long)TB_NT_1 * TB_KS * TB_TILE;
-constexpr long long TB_PACKED_ELEMS = TB_OFF_2 + (long long)TB_NT_2 * TB_KS * TB_TILE;
+constexpr long long TB_MAT_ELEMS = 16LL * TB_KS * TB_TILE;  // one 16-tile operand
+constexpr long long TB_OFF_2T = TB_OFF_2 + TB_MAT_ELEMS;    // W2^T   (dg1 = df2 W2)
+constexpr long long TB_OFF_1T = TB_OFF_2T + TB_MAT_ELEMS;   // W1^T   (dn1 += df1 W1)
+constexpr long long TB_OFF_OT = TB_OFF_1T + TB_MAT_ELEMS;   // Wo^T   (dctx = da1 Wo), output columns 64 head + d
+constexpr long long TB_OFF_QT = TB_OFF_OT + TB_MAT_ELEMS;   // Wq^T | Wk^T | Wv^T (dh = dq Wq + dk Wk + dv Wv), k = 64 head + d: three operands
+constexpr long long TB_PACKED_ELEMS = TB_OFF_QT + 3 * TB_MAT_ELEMS;
 
 // a value every lane of the wave agrees on, made provably so for the compiler (scalar branches, SGPR addressing)
 __device__ __forceinline__ int wave_uniform(int v) {
@@ -66,6 +76,11 @@ __device__ __forceinline__ int hq_off(int row, int k) { return row * 128 + ((((k
 //   2  out projection   (n < 250), k = 64 head + d, d < 62               Wo[n][62 head + d]
 //   3  FFN 1            (n < 256, k < 250)            W1[n][k]
 //   4  FFN 2            (n < 250, k < 256)            W2[n][k]
+// backward operands (B[k][n] = W[k][n]: the Linear's weight read transposed):
+//   5  dg1 = df2 W2     (n < 256, k < 250)            W2[k][n]
+//   6  dn1 += df1 W1    (n < 250, k < 256)            W1[k][n]
+//   7  dctx = da1 Wo    n = 64 head + d, d < 62, (k < 250)               Wo[k][62 head + d]
+//   8+which  dh += d{q,k,v} W{q,k,v}   (n < 250), k = 64 head + d        Wqkv[which 248 + 62 head + d][n]
 __device__ __forceinline__ long long tb_src_index(int mat, int n, int k) {
     switch (mat) {
         case 0: return (n < TB_D && k < TB_T) ? (long long)n * TB_T + k : -1;
@@ -78,12 +93,22 @@ __device__ __forceinline__ long long tb_src_index(int mat, int n, int k) {
             return (n < TB_D && head < TB_H && d < TB_E) ? (long long)n * TB_HE + head * TB_E + d : -1;
         }
         case 3: return (n < TB_FF && k < TB_D) ? (long long)n * TB_D + k : -1;
-        default: return (n < TB_D && k < TB_FF) ? (long long)n * TB_FF + k : -1;
+        case 4: return (n < TB_D && k < TB_FF) ? (long long)n * TB_FF + k : -1;
+        case 5: return (n < TB_FF && k < TB_D) ? (long long)k * TB_FF + n : -1;
+        case 6: return (n < TB_D && k < TB_FF) ? (long long)k * TB_D + n : -1;
+        case 7: {
+            const int head = n >> 6, d = n & 63;
+            return (head < TB_H && d < TB_E && k < TB_D) ? (long long)k * TB_HE + head * TB_E + d : -1;
+        }
+        default: {
+            const int head = k >> 6, d = k & 63;
+            return (n < TB_D && head < TB_H && d < TB_E) ? (long long)((mat - 8) * TB_HE + head * TB_E + d) * TB_D + n : -1;
+        }
     }
 }
 
 struct tb_pack_args {
-    const float* w[5];
+    const float* w[TB_NMAT];
     unsigned short* out;
 };
 
@@ -91,8 +116,7 @@ struct tb_pack_args {
 __global__ __launch_bounds__(64) void token_block_pack_kernel(const tb_pack_args a) {
     int tile = blockIdx.x;
     int mat = 0;
-    const int nts[5] = {TB_NT_V, TB_NT_QKV, TB_NT_O, TB_NT_1, TB_NT_2};
-    while (mat < 4 && tile >= nts[mat] * TB_KS) { tile -= nts[mat] * TB_KS; ++mat; }
+    while (mat < TB_NMAT - 1 && tile >= (mat == 1 ? TB_NT_QKV : 16) * TB_KS) { tile -= (mat == 1 ? TB_NT_QKV : 16) * TB_KS; ++mat; }
     const int nt = tile / TB_KS, ks = tile % TB_KS;
     const int lane = threadIdx.x & 63;
     const int n = 16 * nt + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
@@ -120,29 +144,34 @@ __global__ __launch_bounds__(64) void token_block_pack_kernel(const tb_pack_args
 // ---- C[64 x 16 NT] of one wave: A = the AP planes (all 64 rows, K = 256), B = NT packed n-tiles starting at `wp`.
 //      bit j of TM set: tile j is formed TRANSPOSED (MFMA rows = n): lane (fr, g) then holds n = 16 j + 4 g + i of row m = 16 mt + fr;
 //      clear: standard, lane holds rows m = 16 mt + 4 g + i of column n = 16 j + fr.
-template <int NT, unsigned TM>
+template <int NT, unsigned TM, int PF = 2, bool ZERO = true>
 __device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned short* wp, int lane, f32x4 (&acc)[4][NT]) {
     const int fr = lane & 15, g = lane >> 4;
+    if (ZERO) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 bh[2][NT], bl[2][NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const bf16x8* p = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS) * TB_TILE) + lane;
-        bh[0][j] = p[0];
-        bl[0][j] = p[64];
+            for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // the B fragments of k-step ks live in ring slot ks % (PF + 1): PF k-steps of weight loads (L2 round trips) in flight under the MFMAs
+    bf16x8 bh[PF + 1][NT], bl[PF + 1][NT];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bf16x8* q = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + p) * TB_TILE) + lane;
+            bh[p][j] = q[0];
+            bl[p][j] = q[64];
+        }
 #pragma unroll
     for (int ks = 0; ks < TB_KS; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < TB_KS) {
+        const int cur = ks % (PF + 1);
+        if (ks + PF < TB_KS) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const bf16x8* p = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + ks + 1) * TB_TILE) + lane;
-                bh[cur ^ 1][j] = p[0];
-                bl[cur ^ 1][j] = p[64];
+                const bf16x8* q = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + ks + PF) * TB_TILE) + lane;
+                bh[(ks + PF) % (PF + 1)][j] = q[0];
+                bl[(ks + PF) % (PF + 1)][j] = q[64];
             }
         }
         bf16x8 ah[4], al[4];
@@ -152,20 +181,18 @@ __device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned 
             ah[mt] = *reinterpret_cast<const bf16x8*>(AP + off);
             al[mt] = *reinterpret_cast<const bf16x8*>(AP + TB_AP_PLANE + off);
         }
+        // product-major: the three MFMAs of one accumulator are 4 NT instructions apart (back to back they wait for each other's result)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if ((TM >> j) & 1u) {
-                    acc[mt][j] = mfma_bf16_16x16x32(bl[cur][j], ah[mt], acc[mt][j]);
-                    acc[mt][j] = mfma_bf16_16x16x32(bh[cur][j], al[mt], acc[mt][j]);
-                    acc[mt][j] = mfma_bf16_16x16x32(bh[cur][j], ah[mt], acc[mt][j]);
-                } else {
-                    acc[mt][j] = mfma_bf16_16x16x32(al[mt], bh[cur][j], acc[mt][j]);
-                    acc[mt][j] = mfma_bf16_16x16x32(ah[mt], bl[cur][j], acc[mt][j]);
-                    acc[mt][j] = mfma_bf16_16x16x32(ah[mt], bh[cur][j], acc[mt][j]);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bf16x8 bw = pr == 0 ? bl[cur][j] : bh[cur][j];
+                    const bf16x8 aw = pr == 1 ? al[mt] : ah[mt];
+                    if ((TM >> j) & 1u) acc[mt][j] = mfma_bf16_16x16x32(bw, aw, acc[mt][j]);
+                    else acc[mt][j] = mfma_bf16_16x16x32(aw, bw, acc[mt][j]);
                 }
-            }
     }
 }
 
@@ -512,7 +539,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             }
         }
     }
-    __syncthreads();
+    raw_barrier();
 
     // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
     {
@@ -531,7 +558,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
     }
-    __syncthreads();
+    raw_barrier();
 
     // ---- S2: embedding dropout over the flat (64 x 250) sample (one Philox block = 4 consecutive flat elements); h -> HBM and -> A planes
     {
@@ -557,40 +584,27 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             }
         }
     }
-    __syncthreads();
+    raw_barrier();
 
-    // ---- S3: q | k | v of all heads (SelfAttention_Family.py:199-207): two passes of 24 tiles (heads 2, 3 first: parked in registers; heads 0, 1
-    //          go to LDS at once), then two rounds of attention, waves 0-3 on one head and 4-7 on the other
+    // ---- S3: q | k | v (SelfAttention_Family.py:199-207) and attention, two heads at a time: 24 tiles of the pair's q | k | v -> their planes
+    //          behind the (still live) h planes, then waves 0-3 run one head and waves 4-7 the other
     f32x4 ctxr[2][4];
     {
-        f32x4 held[4][3], cur[4][3];
         const int hip = w >> 2;                                      // head within the pair
-        switch (w & 3) {
-            case 0: tb_qkv_pass<0>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<0>(a, AP, b, hip, lane, cur); break;
-            case 1: tb_qkv_pass<1>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<1>(a, AP, b, hip, lane, cur); break;
-            case 2: tb_qkv_pass<2>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<2>(a, AP, b, hip, lane, cur); break;
-            default: tb_qkv_pass<3>(a, AP, b, 2 + hip, lane, held); tb_qkv_pass<3>(a, AP, b, hip, lane, cur); break;
+        unsigned char* const HQ = lds + TB_AP_BYTES + hip * TB_HQ_BYTES;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            f32x4 cur[4][3];
+            switch (w & 3) {
+                case 0: tb_qkv_pass<0>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<0>(HQ, lane, cur); break;
+                case 1: tb_qkv_pass<1>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<1>(HQ, lane, cur); break;
+                case 2: tb_qkv_pass<2>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<2>(HQ, lane, cur); break;
+                default: tb_qkv_pass<3>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<3>(HQ, lane, cur); break;
+            }
+            raw_barrier();
+            tb_attention<TRAIN>(a, HQ, b, 2 * rd + hip, w & 3, lane, ctxr[rd]);
+            raw_barrier();                                           // the pair's planes are dead (and, second round, the h planes too)
         }
-        unsigned char* const HQ = hip ? XF : AP;
-        __syncthreads();                                             // the h planes are dead: AP and XF become the two heads' q | k | v^T planes
-        switch (w & 3) {
-            case 0: tb_qkv_to_lds<0>(HQ, lane, cur); break;
-            case 1: tb_qkv_to_lds<1>(HQ, lane, cur); break;
-            case 2: tb_qkv_to_lds<2>(HQ, lane, cur); break;
-            default: tb_qkv_to_lds<3>(HQ, lane, cur); break;
-        }
-        __syncthreads();
-        tb_attention<TRAIN>(a, HQ, b, hip, w & 3, lane, ctxr[0]);
-        __syncthreads();
-        switch (w & 3) {
-            case 0: tb_qkv_to_lds<0>(HQ, lane, held); break;
-            case 1: tb_qkv_to_lds<1>(HQ, lane, held); break;
-            case 2: tb_qkv_to_lds<2>(HQ, lane, held); break;
-            default: tb_qkv_to_lds<3>(HQ, lane, held); break;
-        }
-        __syncthreads();
-        tb_attention<TRAIN>(a, HQ, b, 2 + hip, w & 3, lane, ctxr[1]);
-        __syncthreads();
         // context -> HBM (natural (row, 248) layout) and -> A planes with 64 columns per head (dims 62, 63 are exact zeros)
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             }
         }
     }
-    __syncthreads();
+    raw_barrier();
 
     // ---- S4: output projection + bias -> XF      (SelfAttention_Family.py:213)
     {
@@ -618,11 +632,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
     }
-    __syncthreads();
+    __syncthreads();                                                 // (the one barrier that also waits for global stores: S5 re-reads h)
     // ---- S5: r1 = h + dropout(attention output), n1 = LayerNorm1(r1); n1 stays in XF (FFN residual) and goes to the A planes
     tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, a.n1, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
                              nullptr, XF, AP);
-    __syncthreads();
+    raw_barrier();
 
     // ---- S6: FFN 1 + bias -> f1 (pre-activation, kept for the backward), g1 = dropout(gelu(f1))      (Transformer_EncDec.py:48)
     {
@@ -645,18 +659,18 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             *reinterpret_cast<f32x4*>(a.g1 + o) = gq;
             v = gq;
         });
-        __syncthreads();                                             // every wave is done with the n1 planes
+        raw_barrier();                                               // every wave is done with the n1 planes
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, n0), v[0], v[1], v[2], v[3]);
         });
     }
-    __syncthreads();
+    raw_barrier();
 
     // ---- S7: FFN 2 + bias; the result replaces the (dead) g1 planes as an fp32 image      (Transformer_EncDec.py:49)
     {
         f32x4 acc[4][2];
         tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-        __syncthreads();
+        raw_barrier();
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             const f32x4 bias = tb_ld4(a.b2 + n0, valid);
             f32x4 o;
@@ -665,10 +679,319 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             *reinterpret_cast<f32x4*>(AP + xf_off(m, n0)) = o;
         });
     }
-    __syncthreads();
+    raw_barrier();
     // ---- S8: r2 = n1 + dropout(FFN output), n2 = LayerNorm2(r2), n3 = final LayerNorm(n2)      (Transformer_EncDec.py:51,77-78)
     tb_ln_rows<TRAIN, true>(a, b, w, lane, AP, XF, nullptr, a.site_ffn_out, a.r2, a.ln2_g, a.ln2_b, a.n2, a.mu2, a.rs2, a.ln3_g, a.ln3_b, a.n3, a.mu3, a.rs3,
                             nullptr, nullptr);
+}
+
+
+// =====================================================================================================================================
+// Backward of the block's dX chain, one workgroup per sample, in two launches around the (unchanged) attention backward:
+//   A  final LayerNorm', LayerNorm2' (+ FFN-output dropout'), dg1 = df2 W2 with dropout' gelu', dn1 = dr2 + df1 W1, LayerNorm1' (+ attention-output
+//      dropout'), dctx = da1 Wo                                                   (Transformer_EncDec.py:45-51,77-78 read backwards)
+//   B  dh = dropout'_embed(dr1 + dq Wq + dk Wk + dv Wv)                            (SelfAttention_Family.py:199-207, Embed.py:162)
+// The weight gradients stay GEMMs over the whole batch on the second stream: they read what these kernels leave in HBM (df2, dg1 = df1, da1,
+// dqkv, dr1).  LayerNorm gamma / beta gradients leave the workgroup as ONE partial row per sample ([6][256]: g3 b3 g2 b2 g1 b1);
+// token_block_param_reduce_kernel sums the rows.
+struct tb_bwd_args {
+    const unsigned short* packed;
+    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln3_g;
+    float *df2, *dg1, *da1, *dr1, *dctx, *partials;
+    const float* dqkv;
+    float drop_p;
+    unsigned long long seed;
+    unsigned site_embed, site_attn_out, site_ffn_act, site_ffn_out;
+};
+
+// LayerNorm backward of one row slice held by a lane (4 columns, ok[p] per pair): dx = rs (g - mean(g) - xh mean(g xh)), g = dy gamma
+__device__ __forceinline__ void tb_ln_bwd_row(const float (&dy)[4], const float (&x)[4], const float (&gam)[4], const bool (&ok)[2], float mu, float rs,
+                                              float (&dx)[4], float (&pg)[4], float (&pb)[4]) {
+    float xh[4], gq[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = ok[e >> 1] ? (x[e] - mu) * rs : 0.f;
+        gq[e] = dy[e] * gam[e];
+        s1 += gq[e];
+        s2 += gq[e] * xh[e];
+        pg[e] += dy[e] * xh[e];
+        pb[e] += dy[e];
+    }
+    const float c1 = wave_sum(s1) * (1.0f / (float)TB_D), c2 = wave_sum(s2) * (1.0f / (float)TB_D);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dx[e] = ok[e >> 1] ? rs * (gq[e] - c1 - xh[e] * c2) : 0.f;
+}
+
+// the per-lane partial sums of NV parameter-gradient vectors (even rows own columns 4 lane.., odd rows 4 lane - 2..) -> one row per vector and
+// sample in `out` ([NV][256]); `slab` = 8 x NV x 256 floats of LDS scratch
+template <int NV>
+__device__ __forceinline__ void tb_reduce_partials(float* slab, int w, int lane, int t, const float (&pe)[NV][4], const float (&po)[NV][4], float* out) {
+    float* mine = slab + w * (NV * 256);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(mine + v * 256 + 4 * lane) = f32x4{pe[v][0], pe[v][1], pe[v][2], pe[v][3]};
+    wave_sync();
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * lane - 2 + e;
+            if (c >= 0) mine[v * 256 + c] += po[v][e];              // (a lane's four odd-row columns belong to no other lane's odd-row set)
+        }
+    raw_barrier();
+    for (int i = t; i < NV * 256; i += TB_THREADS) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) sum += slab[ww * (NV * 256) + i];
+        out[i] = sum;
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const tb_bwd_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    unsigned char* const AP = lds;
+    unsigned char* const XF = lds + TB_AP_BYTES;
+    float* const SC = reinterpret_cast<float*>(lds + TB_AP_BYTES + TB_XF_BYTES);       // 32 KB of scratch for the parameter-gradient rows
+    const int t = threadIdx.x, lane = t & 63, w = wave_uniform(t >> 6);
+    const int b = blockIdx.x;
+    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    float* const part = a.partials + (long long)b * (6 * 256);
+
+    // ---- T1: final LayerNorm' and LayerNorm2' chained per row in registers; df2 = dropout'(dr2) -> HBM + A planes, dr2 -> XF
+    {
+        float pe[4][4], po[4][4];                                    // [g3 b3 g2 b2] x 4 columns, even / odd rows
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pe[v][e] = 0.f; po[v][e] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = 8 * w + rr, c0 = 4 * lane - ((rr & 1) ? 2 : 0);
+            const long long row = (long long)b * TB_L + r, rbase = row * TB_D;
+            float dy[4], x3[4], x2[4], g3[4], g2[4];
+            bool ok[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                ok[p] = cp >= 0 && cp < TB_D;
+                tb_f2 v0 = tb_f2{0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0, v4 = v0;
+                if (ok[p]) {
+                    v0 = *reinterpret_cast<const tb_f2*>(a.dn3 + rbase + cp);
+                    v1 = *reinterpret_cast<const tb_f2*>(a.n2 + rbase + cp);
+                    v2 = *reinterpret_cast<const tb_f2*>(a.r2 + rbase + cp);
+                    v3 = *reinterpret_cast<const tb_f2*>(a.ln3_g + cp);
+                    v4 = *reinterpret_cast<const tb_f2*>(a.ln2_g + cp);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x3[2 * p + e] = v1[e]; x2[2 * p + e] = v2[e]; g3[2 * p + e] = v3[e]; g2[2 * p + e] = v4[e]; }
+            }
+            float dn2[4], dr2[4];
+            if (rr & 1) {
+                tb_ln_bwd_row(dy, x3, g3, ok, a.mu3[row], a.rs3[row], dn2, po[0], po[1]);
+                tb_ln_bwd_row(dn2, x2, g2, ok, a.mu2[row], a.rs2[row], dr2, po[2], po[3]);
+            } else {
+                tb_ln_bwd_row(dy, x3, g3, ok, a.mu3[row], a.rs3[row], dn2, pe[0], pe[1]);
+                tb_ln_bwd_row(dn2, x2, g2, ok, a.mu2[row], a.rs2[row], dr2, pe[2], pe[3]);
+            }
+            bool keep[4] = {true, true, true, true};
+            if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, a.site_ffn_out, (unsigned long long)(rbase + c0), a.drop_p, keep);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr2[2 * p] * ksc : 0.f) : dr2[2 * p];
+                const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr2[2 * p + 1] * ksc : 0.f) : dr2[2 * p + 1];
+                if (ok[p]) {
+                    *reinterpret_cast<tb_f2*>(a.df2 + rbase + cp) = tb_f2{d0, d1};
+                    *reinterpret_cast<tb_f2*>(XF + xf_off(r, cp)) = tb_f2{dr2[2 * p], dr2[2 * p + 1]};
+                }
+                if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
+            }
+            if ((rr & 1) && lane == 63) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, 254), 0.f, 0.f);
+        }
+        tb_reduce_partials<4>(SC, w, lane, t, pe, po, part);
+    }
+    raw_barrier();
+
+    // ---- T2: dg1 = df2 W2, then the FFN activation's dropout' and gelu' (pre-activation f1 from HBM): df1 -> HBM (the dW1 GEMM reads it) + planes
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
+            const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
+            const f32x4 f = *reinterpret_cast<const f32x4*>(a.f1 + o);
+            bool keep[4] = {true, true, true, true};
+            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? v[i] * ksc : 0.f) : v[i];
+                v[i] = d * gelu_erf_grad(f[i]);
+            }
+            *reinterpret_cast<f32x4*>(a.dg1 + o) = v;
+        });
+        raw_barrier();                                               // every wave is done with the df2 planes
+        tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
+            tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, n0), v[0], v[1], v[2], v[3]);
+        });
+    }
+    raw_barrier();
+
+    // ---- T3: dn1 = dr2 + df1 W1 (in place in XF)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_1T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
+            f32x4* p = reinterpret_cast<f32x4*>(XF + xf_off(m, n0));
+            f32x4 o = *p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = i < valid ? o[i] + v[i] : 0.f;
+            *p = o;
+        });
+    }
+    raw_barrier();
+
+    // ---- T4: LayerNorm1': dr1 -> HBM (the residual path into dh), da1 = dropout'(dr1) -> HBM + A planes
+    {
+        float pe[2][4], po[2][4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pe[v][e] = 0.f; po[v][e] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = 8 * w + rr, c0 = 4 * lane - ((rr & 1) ? 2 : 0);
+            const long long row = (long long)b * TB_L + r, rbase = row * TB_D;
+            float dy[4], x1[4], g1[4];
+            bool ok[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                ok[p] = cp >= 0 && cp < TB_D;
+                tb_f2 v0 = tb_f2{0.f, 0.f}, v1 = v0, v2 = v0;
+                if (ok[p]) {
+                    v0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(r, cp));
+                    v1 = *reinterpret_cast<const tb_f2*>(a.r1 + rbase + cp);
+                    v2 = *reinterpret_cast<const tb_f2*>(a.ln1_g + cp);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x1[2 * p + e] = v1[e]; g1[2 * p + e] = v2[e]; }
+            }
+            float dr1[4];
+            if (rr & 1) tb_ln_bwd_row(dy, x1, g1, ok, a.mu1[row], a.rs1[row], dr1, po[0], po[1]);
+            else tb_ln_bwd_row(dy, x1, g1, ok, a.mu1[row], a.rs1[row], dr1, pe[0], pe[1]);
+            bool keep[4] = {true, true, true, true};
+            if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, a.site_attn_out, (unsigned long long)(rbase + c0), a.drop_p, keep);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = c0 + 2 * p;
+                const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr1[2 * p] * ksc : 0.f) : dr1[2 * p];
+                const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr1[2 * p + 1] * ksc : 0.f) : dr1[2 * p + 1];
+                if (ok[p]) {
+                    *reinterpret_cast<tb_f2*>(a.dr1 + rbase + cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
+                    *reinterpret_cast<tb_f2*>(a.da1 + rbase + cp) = tb_f2{d0, d1};
+                }
+                if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
+            }
+            if ((rr & 1) && lane == 63) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, 254), 0.f, 0.f);
+        }
+        raw_barrier();                                               // (the scratch rows of T1 have been read by every thread)
+        tb_reduce_partials<2>(SC, w, lane, t, pe, po, part + 4 * 256);
+    }
+    raw_barrier();
+
+    // ---- T5: dctx = da1 Wo -> HBM, natural (row, 248) layout (the packed operand's columns are 64 head + d)
+    {
+        f32x4 acc[4][2];
+        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_for_tiles(w, lane, 256, acc, [&](int m, int n0, int valid, f32x4& v) {
+            const int head = n0 >> 6, d0 = n0 & 63;
+            if (d0 < TB_E) tb_st4(a.dctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, v);
+        });
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const tb_bwd_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    unsigned char* const AP = lds;
+    unsigned char* const XF = lds + TB_AP_BYTES;
+    const int t = threadIdx.x, lane = t & 63, w = wave_uniform(t >> 6);
+    const int b = blockIdx.x;
+    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    f32x4 acc[4][2];
+    // the k pad of the planes (columns 64 head + 62, 63) stays zero for all three operands
+    if (t < 256) {
+        const int row = t & 63, head = t >> 6;
+        tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, 64 * head + 62), 0.f, 0.f);
+    }
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        // dq | dk | dv rows of the sample (natural (row, 744) layout) -> A planes, 64 columns per head
+        tb_f2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int u = t + TB_THREADS * j;                        // pair index: row = u / 124, pair = u % 124
+            const int row = u / 124, c = 2 * (u - 124 * row);
+            v[j] = u < 64 * 124 ? *reinterpret_cast<const tb_f2*>(a.dqkv + ((long long)b * TB_L + row) * (3 * TB_HE) + which * TB_HE + c) : tb_f2{0.f, 0.f};
+        }
+        if (which > 0) raw_barrier();                                // the previous operand's GEMM has read the planes
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int u = t + TB_THREADS * j;
+            if (u < 64 * 124) {
+                const int row = u / 124, c = 2 * (u - 124 * row), head = c / TB_E, d = c - TB_E * head;
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, 64 * head + d), v[j][0], v[j][1]);
+            }
+        }
+        raw_barrier();
+        if (which == 0) tb_gemm<2, 3u, 2, true>(AP, a.packed + TB_OFF_QT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        else tb_gemm<2, 3u, 2, false>(AP, a.packed + TB_OFF_QT + which * TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+    }
+    // + the residual-path gradient, then the embedding dropout' over the flat sample (one Philox block = 4 consecutive flat elements)
+    tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
+        const f32x4 r = tb_ld4(a.dr1 + ((long long)b * TB_L + m) * TB_D + n0, valid);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = i < valid ? r[i] + v[i] : 0.f;
+        *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
+    });
+    __syncthreads();                                                 // (also: every load of the old dr1 has returned before it is overwritten)
+    float* ob = a.dr1 + (long long)b * (TB_L * TB_D);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = t + TB_THREADS * j;
+        if (q < TB_L * TB_D / 4) {
+            const int i0 = 4 * q, row = i0 / TB_D, col = i0 - TB_D * row;
+            const bool wrap = col + 2 >= TB_D;
+            const int row2 = wrap ? row + 1 : row, col2 = wrap ? col + 2 - TB_D : col + 2;
+            const tb_f2 p0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row, col)), p1 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row2, col2));
+            float v[4] = {p0[0], p0[1], p1[0], p1[1]};
+            if (TRAIN && a.drop_p > 0.f) {
+                bool keep[4];
+                dropout_keep4(a.seed, a.site_embed, (unsigned long long)b * (TB_L * TB_D) + i0, a.drop_p, keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ksc : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(ob + i0) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+// dgamma / dbeta of the three LayerNorms: out[v][c] += sum_b partials[b][v][c]; one workgroup per (vector, 64 columns), 4 waves split the samples
+struct tb_param_args {
+    const float* partials;
+    float* out[6];
+    int B;
+};
+__global__ __launch_bounds__(256) void token_block_param_reduce_kernel(const tb_param_args a) {
+    EEG_LDS_BASE(float, red);
+    const int v = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    for (int b = g; b < a.B; b += 4) s += a.partials[((long long)b * 6 + v) * 256 + c];
+    red[g * 64 + lane] = s;
+    __syncthreads();
+    if (g == 0 && c < TB_D) a.out[v][c] += (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
 }
 
 }  // namespace eeg
@@ -680,8 +1003,8 @@ extern "C" long long eegclip_token_block_packed_bytes(void) { return TB_PACKED_E
 extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream) {
     if (!wv || !wqkv || !wo || !w1 || !w2 || !packed) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(packed) & 15u) return EEGCLIP_EALIGN;
-    tb_pack_args a{{wv, wqkv, wo, w1, w2}, static_cast<unsigned short*>(packed)};
-    const int tiles = (TB_NT_V + TB_NT_QKV + TB_NT_O + TB_NT_1 + TB_NT_2) * TB_KS;
+    tb_pack_args a{{wv, wqkv, wo, w1, w2, w2, w1, wo, wqkv, wqkv, wqkv}, static_cast<unsigned short*>(packed)};
+    const int tiles = (int)(TB_PACKED_ELEMS / TB_TILE);
     EEG_LAUNCH(token_block_pack_kernel, dim3(tiles), dim3(64), 0, stream, a);
     return (int)hipGetLastError();
 }
@@ -691,15 +1014,15 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
         !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctx || !d->r1 || !d->n1 || !d->mu1 || !d->rs1 || !d->f1 || !d->g1 ||
         !d->r2 || !d->n2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
         return EEGCLIP_EINVAL;
-    const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->h) |
-                           reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->g1) | reinterpret_cast<uintptr_t>(d->b1);
-    const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->qkv) | reinterpret_cast<uintptr_t>(d->ctx) | reinterpret_cast<uintptr_t>(d->r1) |
-                          reinterpret_cast<uintptr_t>(d->n1) | reinterpret_cast<uintptr_t>(d->r2) | reinterpret_cast<uintptr_t>(d->n2) |
-                          reinterpret_cast<uintptr_t>(d->n3) | reinterpret_cast<uintptr_t>(d->bv) | reinterpret_cast<uintptr_t>(d->pe) |
-                          reinterpret_cast<uintptr_t>(d->tokens) | reinterpret_cast<uintptr_t>(d->bqkv) | reinterpret_cast<uintptr_t>(d->bo) |
-                          reinterpret_cast<uintptr_t>(d->b2) | reinterpret_cast<uintptr_t>(d->ln1_g) | reinterpret_cast<uintptr_t>(d->ln1_b) |
-                          reinterpret_cast<uintptr_t>(d->ln2_g) | reinterpret_cast<uintptr_t>(d->ln2_b) | reinterpret_cast<uintptr_t>(d->ln3_g) |
-                          reinterpret_cast<uintptr_t>(d->ln3_b);
+    const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->h) | reinterpret_cast<uintptr_t>(d->f1) |
+                           reinterpret_cast<uintptr_t>(d->g1) | reinterpret_cast<uintptr_t>(d->b1);
+    const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->qkv) | reinterpret_cast<uintptr_t>(d->ctx) |
+                          reinterpret_cast<uintptr_t>(d->r1) | reinterpret_cast<uintptr_t>(d->n1) | reinterpret_cast<uintptr_t>(d->r2) |
+                          reinterpret_cast<uintptr_t>(d->n2) | reinterpret_cast<uintptr_t>(d->n3) | reinterpret_cast<uintptr_t>(d->bv) |
+                          reinterpret_cast<uintptr_t>(d->pe) | reinterpret_cast<uintptr_t>(d->tokens) | reinterpret_cast<uintptr_t>(d->bqkv) |
+                          reinterpret_cast<uintptr_t>(d->bo) | reinterpret_cast<uintptr_t>(d->b2) | reinterpret_cast<uintptr_t>(d->ln1_g) |
+                          reinterpret_cast<uintptr_t>(d->ln1_b) | reinterpret_cast<uintptr_t>(d->ln2_g) | reinterpret_cast<uintptr_t>(d->ln2_b) |
+                          reinterpret_cast<uintptr_t>(d->ln3_g) | reinterpret_cast<uintptr_t>(d->ln3_b);
     if ((al16 & 15u) || (al8 & 7u)) return EEGCLIP_EALIGN;
     tb_fwd_args a{d->x, static_cast<const unsigned short*>(d->packed), d->bv, d->pe, d->tokens, d->ids, d->bqkv, d->bo, d->ln1_g, d->ln1_b, d->b1, d->b2,
                   d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->ctx, d->r1, d->n1, d->mu1, d->rs1, d->f1, d->g1, d->r2, d->n2, d->mu2, d->rs2,
@@ -707,5 +1030,38 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
                   d->site_ffn_out};
     if (d->drop_p > 0.f) EEG_LAUNCH(token_block_fwd_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
     else EEG_LAUNCH(token_block_fwd_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" long long eegclip_token_block_bwd_workspace_floats(int B) { return B < 1 ? 0 : (long long)B * 6 * 256; }
+
+extern "C" int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream) {
+    if (!d || d->B < 1 || !d->packed || d->drop_p < 0.f || d->drop_p >= 1.f || part < 0 || part > 2) return EEGCLIP_EINVAL;
+    tb_bwd_args a{static_cast<const unsigned short*>(d->packed), d->dn3, d->n2, d->r2, d->r1, d->f1, d->mu1, d->rs1, d->mu2, d->rs2, d->mu3, d->rs3,
+                  d->ln1_g, d->ln2_g, d->ln3_g, d->df2, d->dg1, d->da1, d->dr1, d->dctx, d->partials, d->dqkv, d->drop_p, d->seed, d->site_embed,
+                  d->site_attn_out, d->site_ffn_act, d->site_ffn_out};
+    if (part == 0) {
+        if (!d->dn3 || !d->n2 || !d->r2 || !d->r1 || !d->f1 || !d->mu1 || !d->rs1 || !d->mu2 || !d->rs2 || !d->mu3 || !d->rs3 || !d->ln1_g || !d->ln2_g ||
+            !d->ln3_g || !d->df2 || !d->dg1 || !d->da1 || !d->dr1 || !d->dctx || !d->partials)
+            return EEGCLIP_EINVAL;
+        const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->dg1);
+        const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->dn3) | reinterpret_cast<uintptr_t>(d->n2) | reinterpret_cast<uintptr_t>(d->r2) |
+                              reinterpret_cast<uintptr_t>(d->r1) | reinterpret_cast<uintptr_t>(d->ln1_g) | reinterpret_cast<uintptr_t>(d->ln2_g) |
+                              reinterpret_cast<uintptr_t>(d->ln3_g) | reinterpret_cast<uintptr_t>(d->df2) | reinterpret_cast<uintptr_t>(d->da1) |
+                              reinterpret_cast<uintptr_t>(d->dr1) | reinterpret_cast<uintptr_t>(d->dctx);
+        if ((al16 & 15u) || (al8 & 7u)) return EEGCLIP_EALIGN;
+        if (d->drop_p > 0.f) EEG_LAUNCH(token_block_bwd_a_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+        else EEG_LAUNCH(token_block_bwd_a_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+    } else if (part == 1) {
+        if (!d->dqkv || !d->dr1) return EEGCLIP_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->dr1)) & 15u) return EEGCLIP_EALIGN;
+        if (reinterpret_cast<uintptr_t>(d->dqkv) & 7u) return EEGCLIP_EALIGN;
+        if (d->drop_p > 0.f) EEG_LAUNCH(token_block_bwd_b_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_AP_BYTES + TB_XF_BYTES, stream, a);
+        else EEG_LAUNCH(token_block_bwd_b_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_AP_BYTES + TB_XF_BYTES, stream, a);
+    } else {
+        if (!d->partials || !d->dln3_g || !d->dln3_b || !d->dln2_g || !d->dln2_b || !d->dln1_g || !d->dln1_b) return EEGCLIP_EINVAL;
+        tb_param_args pa{d->partials, {d->dln3_g, d->dln3_b, d->dln2_g, d->dln2_b, d->dln1_g, d->dln1_b}, d->B};
+        EEG_LAUNCH(token_block_param_reduce_kernel, dim3(4, 6), dim3(256), 256 * sizeof(float), stream, pa);
+    }
     return (int)hipGetLastError();
 }

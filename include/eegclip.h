@@ -458,6 +458,27 @@ long long eegclip_token_block_packed_bytes(void);
 int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream);
 int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream);
 
+/* backward of the block's dX chain, one workgroup per sample (csrc/token_block.hip), `part`:
+ *   0  final LayerNorm', LayerNorm2' + FFN-output dropout', dg1 = df2 W2 with dropout' gelu' (-> dg1 = df1), dn1 = dr2 + df1 W1, LayerNorm1' +
+ *      attention-output dropout', dctx = da1 Wo: writes df2, dg1, da1, dr1 (residual path), dctx and one partial row of the six LayerNorm
+ *      parameter gradients per sample into `partials` (eegclip_token_block_bwd_workspace_floats(B) floats)     (Transformer_EncDec.py:45-51,77-78)
+ *   1  dr1 <- dropout'_embed(dr1 + dq Wq + dk Wk + dv Wv), dqkv in the natural (row, 744) layout           (SelfAttention_Family.py:199-207, Embed.py:162)
+ *   2  dln*_g / dln*_b += column sums of `partials`
+ * between 0 and 1 runs eegclip_attention_bwd; the weight gradients stay batch-wide GEMMs over what these parts leave in HBM. */
+typedef struct {
+    int B;
+    const void* packed;
+    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln3_g;
+    float *df2, *dg1, *da1, *dr1, *dctx, *partials;
+    const float* dqkv;
+    float *dln3_g, *dln3_b, *dln2_g, *dln2_b, *dln1_g, *dln1_b;
+    float drop_p;
+    unsigned long long seed;
+    unsigned int site_embed, site_attn_out, site_ffn_act, site_ffn_out;
+} eegclip_token_block_bwd_desc;
+long long eegclip_token_block_bwd_workspace_floats(int B);
+int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream);
+
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
  * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */

@@ -62,3 +62,48 @@ def test_fused_token_block_equals_the_unfused_plan_on_the_emulator(train, subjec
 @pytest.mark.parametrize("train,subject", [(True, 1), (False, 10), (True, None)])
 def test_fused_token_block_equals_the_unfused_plan_on_the_gpu(B, train, subject, monkeypatch):
     check_fused_forward_equals_the_unfused_plan("cuda", B, train, subject, monkeypatch)
+
+
+def _grads(dev, B, train, subject, fused, monkeypatch):
+    monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK", "1" if fused else "0")
+    m = _model(dev)
+    m.train(train)
+    x = torch.from_numpy(syn.eeg_batch(SEED + 32, B)).to(dev)
+    tgt = torch.from_numpy(syn.unit_features(SEED + 32, B, tag="img")).to(dev)
+    torch.manual_seed(4321)
+    z = m(x, subject)
+    (z * tgt).sum().backward()                                 # a generic upstream gradient (the loss kernels have their own tests)
+    eng = m._engine()
+    names = eng.plans[next(k for k in eng.plans if k[0] == "b")].op_names()
+    assert ("eegclip_token_block_bwd" in names) == fused
+    act = {k: eng.bufs[B][k].detach().cpu().numpy().copy() for k in ("df2", "dg1", "da1", "dctx", "dqkv", "dr1")}
+    return {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}, act
+
+
+def check_fused_backward_equals_the_unfused_plan(dev, B, train, subject, monkeypatch):
+    g0, a0 = _grads(dev, B, train, subject, False, monkeypatch)
+    g1, a1 = _grads(dev, B, train, subject, True, monkeypatch)
+    for k in a0:                                               # what the weight-gradient GEMMs read
+        r = a0[k]
+        np.testing.assert_allclose(a1[k], r, atol=5e-4 * max(1e-6, float(np.abs(r).max())), err_msg=k)
+    assert g0.keys() == g1.keys()
+    for k, r in g0.items():
+        if k.endswith("key_projection.bias"):                  # exactly zero in exact arithmetic (softmax shift invariance): round-off in both
+            assert np.abs(g1[k]).max() < 1e-5
+            continue
+        np.testing.assert_allclose(g1[k], r, atol=1e-3 * float(np.abs(r).max()) + 1e-7, err_msg=k)
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("train,subject", [(True, 1), (False, 10)])
+def test_fused_token_block_backward_equals_the_unfused_plan_on_the_emulator(train, subject, monkeypatch):
+    from emu_patch import product_on_emulator
+    with product_on_emulator():
+        check_fused_backward_equals_the_unfused_plan("cpu", 2, train, subject, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 256])
+@pytest.mark.parametrize("train,subject", [(True, 1), (False, 10), (True, None)])
+def test_fused_token_block_backward_equals_the_unfused_plan_on_the_gpu(B, train, subject, monkeypatch):
+    check_fused_backward_equals_the_unfused_plan("cuda", B, train, subject, monkeypatch)
