@@ -31,6 +31,16 @@ N_CLASSES = 1654
 PREC_BF16X3 = 1
 
 
+# algorithmic HBM bytes per sample of the fused transformer-block launches (csrc/token_block.hip): what has to cross HBM given that the
+# weight-gradient GEMMs and the attention backward read their operands from it
+_ROW, _ROWF, _QKV, _CTX = 64 * 250 * 4, 64 * 256 * 4, 64 * 744 * 4, 64 * 248 * 4
+TOKEN_BLOCK_BYTES = {
+    "fwd": 63 * 250 * 4 + 5 * _ROW + _QKV + _CTX + 2 * _ROWF,          # x in; h, r1, n1, r2, n3 + qkv + ctx + f1, g1 out
+    0: 3 * _ROW + _ROWF + 3 * _ROW + _ROWF + _CTX,                     # dn3, r2, r1, f1 in; df2, da1, dr1, dg1, dctx out
+    1: _QKV + 2 * _ROW,                                                # dqkv, dr1 in; dr1 out
+}
+
+
 def algorithmic_cost(name, desc, B):
     """(bound, work per launch) for the kernels that can dominate: flops for the MFMA GEMMs, HBM bytes for streaming ops.
     Per-unit figures (SURVEY.md section 8d / DESIGN.md): conv+pool fused = 75 taps x 40 filters x 36 outputs x 63 rows per
@@ -41,6 +51,10 @@ def algorithmic_cost(name, desc, B):
     if name in ("eegclip_attention_fwd", "eegclip_attention_bwd"):
         per = 4 if name.endswith("fwd") else 10                    # QK^T + PV  |  + recompute, dP, dQ, dK, dV  (x 2 L^2 E flops)
         return "mfma", float(per * 64 * 64 * 62 * B * 4), "flop"
+    if name == "eegclip_token_block_fwd":
+        return "hbm", float(B * TOKEN_BLOCK_BYTES["fwd"]), "byte"
+    if name == "eegclip_token_block_bwd":
+        return ("hbm", float(B * TOKEN_BLOCK_BYTES[desc]), "byte") if desc in TOKEN_BLOCK_BYTES else None
     tok = B * 63 * 250 * 4
     table = {                                                               # HBM-bound streaming over the (B,40,63,36) tensor y1
         "eegclip_tsconv_fwd": ("hbm", tok + y1),                            # read tokens, write y1
@@ -86,10 +100,23 @@ TIME_EVERY = 4
 
 
 def family_of(name, desc):
-    """kernels are grouped for the roofline: every GEMM launch of one arithmetic (they are one kernel template), each other op on its own"""
+    """kernels are grouped for the roofline: every GEMM launch of one arithmetic (they are one kernel template), the fused transformer-block
+    launches (forward + the two backward parts), the attention kernels, each other op on its own"""
     if name == "eegclip_gemm_f32":
         return "gemm_bf16x3" if (desc.precision & 0xff) == PREC_BF16X3 else "gemm_f32"
+    if name.startswith("eegclip_token_block_"):
+        return "token_block"
+    if name.startswith("eegclip_attention_"):
+        return "attention_f32_mfma"
     return name
+
+
+def family_peak(fam, bound):
+    """(peak, scale from work / ms to the unit, unit)"""
+    if bound == "mfma":
+        # bf16x3: three bf16 MFMA products per algorithmic multiply-add -> the pipe's ceiling for ALGORITHMIC flops is a third of 2.5 PF
+        return (PEAK_BF16_MFMA_TF / 3.0 if fam == "gemm_bf16x3" else PEAK_F32_MFMA_TF), 1e-3 * 1e12, "TFLOP/s"
+    return PEAK_HBM_GBS, 1e-3 * 1e9, "GB/s"
 
 
 def build(world, rank, B, seed=0):
@@ -181,6 +208,8 @@ def secondary():
         torch.cuda.empty_cache()
 
     section("infonce_global_batch_2048", _sec_infonce)
+    section("infonce_per_rank_block", _sec_infonce_per_rank)
+    section("exact_fp32_products", _sec_exact_fp32)
     section("prior_train_batch_1024", _sec_prior_train)
     section("prior_sampling_chain", _sec_prior_chain)
     section("sdxl_cross_attention", _sec_cross_attn)
@@ -215,6 +244,7 @@ def _sec_infonce(N=2048, Dm=1024):
                                                            k_lo=bp[1].data_ptr() if planes == 2 else None, col0=0, weight=0.5, part=buf.data_ptr(),
                                                            diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=None, ldg=0))
         ms_blk = _ev_ms(lambda: L.eegclip_infonce_fused_fwd(pr, 1, N, N, Dm, planes, N, sc.data_ptr(), acc.data_ptr(), st), 100, warm=10)
+        ms_blk_dma = _ev_ms(lambda: L.eegclip_infonce_fused_fwd(pr, 1, N, N, Dm, planes | (1 << 16), N, sc.data_ptr(), acc.data_ptr(), st), 100, warm=10)
         mult = 3.0 if planes == 2 else 1.0                 # MFMA products per algorithmic multiply-add
         lf = ClipLoss(logits_dtype=mode)
         with torch.no_grad():
@@ -225,12 +255,78 @@ def _sec_infonce(N=2048, Dm=1024):
         ref = loss if ref is None else ref
         res["parity_mode" if mode == "f32" else "throughput_mode"] = {
             "arithmetic": "bf16x3 split products (logits within ~5e-5 of fp32)" if planes == 2 else "one bf16 product (features rounded to bf16)",
-            "logits_block_us": round(ms_blk * 1e3, 2), "logits_block_algorithmic_TFLOPs": round(flop / ms_blk / 1e9, 1),
+            "logits_block_us": round(ms_blk * 1e3, 2), "logits_block_us_with_lds_dma_staging": round(ms_blk_dma * 1e3, 2), "logits_block_algorithmic_TFLOPs": round(flop / ms_blk / 1e9, 1),
             "logits_block_frac_of_bf16_mfma_peak": round(flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
             "logits_block_mfma_work_frac_of_peak": round(mult * flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
             "clip_loss_forward_us": round(ms_f * 1e3, 1), "clip_loss_forward_backward_us": round(ms_fb * 1e3, 1),
             "loss": round(loss, 6), "abs_loss_difference_to_parity_mode": round(abs(loss - ref), 7)}
     return res
+
+
+def _sec_infonce_per_rank(W=8, n=256, Dm=1024, rank=3):
+    """configs[2] as ONE GPU sees it: local_loss + gather_with_grad, world 8 x 256 rows -- per target two row-sharded blocks (A_r, B_all) / (B_r, A_all)
+    of 256 x 2048 x 1024 (positives at column 256 r), image + text targets in one step.  `blocks_*` = the fused launches alone over the 4 blocks
+    (logits tiles + finalize, then the gradient tiles); `sharded_*` = everything a rank computes between the all-gather and the reduce-scatter
+    (plane splits of the gathered matrices, the blocks, the dA / dA_all GEMMs)."""
+    from eeg_image_decode_amd import loss as ploss
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N = W * n
+    a_all = torch.nn.functional.layer_norm(torch.randn(N, Dm, device="cuda", generator=g), (Dm,))
+    b_alls = [torch.nn.functional.normalize(torch.randn(N, Dm, device="cuda", generator=g), dim=1) for _ in range(2)]
+    sl = slice(rank * n, (rank + 1) * n)
+    a_, bs = a_all[sl].contiguous(), [b[sl].contiguous() for b in b_alls]
+    sc = torch.tensor([2.6593], device="cuda")
+    res = {"workload": f"row-sharded InfoNCE of one rank at world {W}: 2 targets x 2 blocks of {n} x {N} x {Dm}; tile kernel grid = 4 blocks x "
+                       f"{(n // 64) * (N // 64)} workgroups of 64 x 64 logits (256 CUs)"}
+    flop = 4 * 2.0 * n * N * Dm
+    for mode, planes in (("parity_mode", 2), ("throughput_mode", 1)):
+        ap_all = ploss.split_planes(a_all, planes)
+        bps = [ploss.split_planes(b, planes) for b in b_alls]
+        cut = lambda p: (p[0][sl], p[1][sl] if planes == 2 else None)
+        blocks = []
+        for t, w in enumerate((0.99, 0.01)):
+            blocks += [(cut(ap_all), bps[t], rank * n, 0.5 * w), (cut(bps[t]), ap_all, rank * n, 0.5 * w)]
+        acc = torch.zeros(2, device="cuda")
+        ms_f = _ev_ms(lambda: ploss.fused_infonce(blocks, n, N, Dm, planes, n, sc, acc, []), 50, warm=5)
+        ms_fb = _ev_ms(lambda: ploss.fused_infonce(blocks, n, N, Dm, planes, n, sc, acc, [(i, None) for i in range(4)]), 50, warm=5)
+        ms_sh = _ev_ms(lambda: ploss.sharded_blocks(True, True, rank, W, a_, bs, a_all, b_alls, (0.99, 0.01), sc, acc, True, [False, False], True, planes), 30, warm=3)
+        mult = 3.0 if planes == 2 else 1.0
+        res[mode] = {"blocks_forward_us": round(1e3 * ms_f, 1), "blocks_forward_backward_us": round(1e3 * ms_fb, 1),
+                     "blocks_forward_algorithmic_TFLOPs": round(flop / ms_f / 1e9, 1),
+                     "blocks_forward_frac_of_bf16_mfma_peak": round(flop / ms_f / 1e9 / PEAK_BF16_MFMA_TF, 4),
+                     "blocks_forward_mfma_work_frac_of_peak": round(mult * flop / ms_f / 1e9 / PEAK_BF16_MFMA_TF, 4),
+                     "sharded_loss_forward_backward_us": round(1e3 * ms_sh, 1)}
+    return res
+
+
+def _sec_exact_fp32(B=256, steps=20):
+    """the headline step with EXACT fp32 products in every Linear (EEGCLIP_GEMM_PRECISION=f32: v_mfma_f32_16x16x4_f32, launch-per-Linear plans) --
+    the strict-precision reading of BASELINE configs[1] next to the default split-bf16 arithmetic"""
+    from eeg_image_decode_amd import retrieval
+    old = os.environ.get("EEGCLIP_GEMM_PRECISION")
+    os.environ["EEGCLIP_GEMM_PRECISION"] = "f32"
+    try:
+        model, opt, pool, classes = build(1, 0, B)
+        loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+
+        def step(i):
+            d = pool[i % len(pool)]
+            retrieval.contrastive_step(model, opt, d["eeg"], 1, d["img"], d["txt"], d["labels"], classes, loss_acc, correct)
+        for i in range(8):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"workload": "configs[1] step, B = 256, exact fp32 products (no split-bf16, no fused transformer block)", "steps": steps,
+                "ms_per_step": round(1e3 * dt / steps, 4), "samples_per_s": round(B * steps / dt, 1)}
+    finally:
+        if old is None:
+            os.environ.pop("EEGCLIP_GEMM_PRECISION", None)
+        else:
+            os.environ["EEGCLIP_GEMM_PRECISION"] = old
 
 
 def _sec_prior_train(B=1024, batches=6):
@@ -434,7 +530,7 @@ def main():
             for idx, v in pl.timings_ms().items():
                 name = pl.ops[idx][2]
                 d = _desc_of(pl, idx)
-                tag = f"{name}[{d.M}x{d.N}x{d.K}{'/sk' + str(d.split_k) if d.split_k > 1 else ''}]" if d is not None else name
+                tag = name if d is None else f"{name}[part {d}]" if isinstance(d, int) else f"{name}[{d.M}x{d.N}x{d.K}{'/sk' + str(d.split_k) if d.split_k > 1 else ''}]"
                 rows.append((float(np.mean(v[-args.steps:])), k[0], idx, tag))
         rows.sort(reverse=True)
         if rank == 0:
@@ -452,18 +548,16 @@ def main():
         bound, unit = work[ops[0]][0], work[ops[0]][2]
         w_tot = sum(w[1] for w in work.values())
         ms_live, ms_single = sum(live[o] for o in ops), sum(single[o] for o in ops)
-        if bound == "mfma":
-            # bf16x3: three bf16 MFMA products per algorithmic multiply-add -> the pipe's ceiling for ALGORITHMIC flops is a third of 2.5 PF
-            peak = PEAK_BF16_MFMA_TF / 3.0 if dominant == "gemm_bf16x3" else PEAK_F32_MFMA_TF
-            scale, u = 1e-3 * 1e12, "TFLOP/s"
-        else:
-            peak, scale, u = PEAK_HBM_GBS, 1e-3 * 1e9, "GB/s"
+        peak, scale, u = family_peak(dominant, bound)
         ach = w_tot / (ms_live * scale)
         big = max(ops, key=lambda o: work[o][1])
         dbig = _desc_of(plans[big[0]], big[1])
         traffic, tsrc = pmc_traffic(dominant, B)
-        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel (every Linear of the step, forward / dX / dW: fp32 in/out, split-bf16 products)",
-                        "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)"}
+        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel (the Linears outside the fused transformer block: head forward / dX, every weight gradient; fp32 in/out, "
+                                       "split-bf16 products)",
+                        "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)",
+                        "token_block": "eeg::token_block_{fwd,bwd_a,bwd_b}_kernel (the encoder's transformer block, one workgroup per sample: forward and the "
+                                       "two backward parts; bytes = activations that must cross HBM for the batch-wide weight-gradient GEMMs)"}
         roof = {"kernel": kernel_names.get(dominant, dominant), "launches_per_step": len(ops), "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": u, "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                 "avg_launch_ms": round(ms_live / len(ops), 5),
@@ -473,11 +567,11 @@ def main():
                 "share_of_kernel_time_single_stream": round(fam_ms[dominant] / sum(single.values()), 3),
                 "single_stream": {"achieved": round(w_tot / (ms_single * scale), 2), "frac": round(w_tot / (ms_single * scale) / peak, 4),
                                   "note": "same launches timed one at a time on one stream (3 instrumented steps before the timed region)"},
-                "largest_launch": {"shape": f"{dbig.M}x{dbig.N}x{dbig.K}" if dbig is not None else None, "avg_ms": round(live[big], 5),
+                "largest_launch": {"shape": f"{dbig.M}x{dbig.N}x{dbig.K}" if hasattr(dbig, "M") else plans[big[0]].ops[big[1]][2], "avg_ms": round(live[big], 5),
                                    "achieved": round(work[big][1] / (live[big] * scale), 2), "frac": round(work[big][1] / (live[big] * scale) / peak, 4)}}
         if bound == "mfma":
             roof["frac_of_f32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TF, 4)
-        if dbig is not None:
+        if hasattr(dbig, "M"):
             # what the HIP-event bracketing itself adds to a launch (marker packets + dispatch gaps on both sides): the largest launch 40 times
             # between ONE event pair against 40 individually bracketed launches, live, on an idle GPU after the timed region.  rocprofv3's kernel
             # timestamps (profiles/r2_final_kernel_stats.csv, same command) agree with the NET figure, not with the raw event time.
@@ -512,7 +606,31 @@ def main():
             roof["largest_launch"]["back_to_back_frac"] = round(work[big][1] / (t_batch * scale) / peak, 4)
         if dominant == "gemm_bf16x3":
             roof["peak_note"] = "2.5 PFLOP/s dense bf16 MFMA / 3 products per multiply-add; achieved counts algorithmic 2MNK flops"
-        roof["other_families_single_stream_ms"] = {f: round(v, 4) for f, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])[:8]}
+        # every priced family against ITS roofline (single-stream launch times of the 3 instrumented steps: one launch at a time, nothing co-running)
+        fams = {}
+        for f, fops in fam_ops.items():
+            fw = [algorithmic_cost(plans[o[0]].ops[o[1]][2], _desc_of(plans[o[0]], o[1]), B) for o in fops]
+            fpeak, fscale, fu = family_peak(f, fw[0][0])
+            fa = sum(x[1] for x in fw) / (fam_ms[f] * fscale)
+            fams[f] = {"bound": fw[0][0], "launches_per_step": len(fops), "ms_per_step_single_stream": round(fam_ms[f], 4), "achieved": round(fa, 2), "peak": round(fpeak, 1),
+                       "unit": fu, "frac": round(fa / fpeak, 4)}
+        roof["families"] = dict(sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step_single_stream"]))
+
+    distributed = None
+    if world > 1:
+        # what the run actually was (the driver's first multi-GPU line must show "RCCL saw N ranks") + where the step's communication time goes:
+        # 5 extra instrumented steps AFTER the timed region, an event pair on the compute stream around every collective (async ones: issue .. wait())
+        distributed = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.get_backend() == "nccl" else None,
+                       "devices_visible": torch.cuda.device_count(), "sync_batchnorm": bool(model.sync_batchnorm),
+                       "loss_mode": {"local_loss": model.loss_func.local_loss, "gather_with_grad": model.loss_func.gather_with_grad}}
+        log = _CollectiveLog()
+        with log:
+            for i in range(5):
+                step(i)
+            torch.cuda.synchronize()
+        distributed["collectives"] = log.summary(5)
+        barrier()
 
     out = {
         "metric": "EEG-CLIP contrastive train samples/sec (global batch)", "value": round(value, 1), "unit": "samples/s",
@@ -527,6 +645,8 @@ def main():
                    "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4)},
         "roofline": roof,
     }
+    if distributed is not None:
+        out["distributed"] = distributed
     if rank == 0 and world == 1 and not args.no_secondary:
         del model, opt, pool
         torch.cuda.empty_cache()
@@ -539,10 +659,69 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+class _CollectiveLog:
+    """wraps torch.distributed's collectives while active: per call the kind, payload bytes and an event pair on the current (compute) stream --
+    around the call for blocking collectives, from issue to .wait() for async ones -- i.e. the time the compute stream is held, not wire time"""
+    KINDS = ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor")
+
+    def __enter__(self):
+        import torch.distributed as dist
+        self.dist, self.saved, self.calls = dist, {}, []
+        for kind in self.KINDS:
+            real = getattr(dist, kind)
+            self.saved[kind] = real
+            setattr(dist, kind, self._wrap(kind, real))
+        return self
+
+    def _wrap(self, kind, real):
+        log = self
+
+        def call(*a, **k):
+            t = a[0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work = real(*a, **k)
+            rec = {"kind": kind, "bytes": t.numel() * t.element_size(), "async": bool(k.get("async_op", False)), "ev": (e0, e1)}
+            log.calls.append(rec)
+            if work is not None and k.get("async_op", False):
+                real_wait = work.wait
+
+                def wait(*wa, **wk):
+                    r = real_wait(*wa, **wk)
+                    e1.record()
+                    return r
+                work.wait = wait
+            else:
+                e1.record()
+            return work
+        return call
+
+    def __exit__(self, *exc):
+        for kind, real in self.saved.items():
+            setattr(self.dist, kind, real)
+
+    def summary(self, steps):
+        by = {}
+        for c in self.calls:
+            key = f"{c['kind']}{'(async)' if c['async'] else ''}:{c['bytes']}B"
+            try:
+                us = 1e3 * c["ev"][0].elapsed_time(c["ev"][1])
+            except Exception:                                     # an async collective whose wait() never ran
+                us = None
+            by.setdefault(key, []).append(us)
+        rows = {k: {"per_step": round(len(v) / steps, 2), "mean_us_stream_held": (round(float(np.mean([x for x in v if x is not None])), 1) if any(x is not None for x in v) else None)}
+                for k, v in by.items()}
+        held = sum(r["per_step"] * r["mean_us_stream_held"] for r in rows.values() if r["mean_us_stream_held"] is not None and "(async)" not in "")
+        return {"per_step": round(len(self.calls) / steps, 2), "by_kind_and_payload": rows, "sum_us_stream_held_per_step": round(held, 1),
+                "note": "blocking collectives: event pair around the call on the compute stream; async ones: issue .. wait() (mostly overlapped work, not exposure)"}
+
+
 def _desc_of(plan, idx):
     fn, a, name = plan.ops[idx][:3]
     if name == "eegclip_gemm_f32":
         return a[0]._obj
+    if name == "eegclip_token_block_bwd":
+        return int(a[1])                                  # which part of the fused backward
     return None
 
 

@@ -51,7 +51,7 @@ class TokenBlockDesc(C.Structure):
 
 class TokenBlockBwdDesc(C.Structure):
     _fields_ = ([("B", C.c_int), ("packed", C.c_void_p)]
-                + [(k, C.c_void_p) for k in ("dn3", "n2", "r2", "r1", "f1", "mu1", "rs1", "mu2", "rs2", "mu3", "rs3", "ln1_g", "ln2_g", "ln3_g")]
+                + [(k, C.c_void_p) for k in ("dn3", "n2", "r2", "r1", "f1", "mu1", "rs1", "mu2", "rs2", "mu3", "rs3", "ln1_g", "ln2_g", "ln2_b", "ln3_g")]
                 + [(k, C.c_void_p) for k in ("df2", "dg1", "da1", "dr1", "dctx", "partials", "dqkv")]
                 + [(k, C.c_void_p) for k in ("dln3_g", "dln3_b", "dln2_g", "dln2_b", "dln1_g", "dln1_b")]
                 + [("drop_p", C.c_float), ("seed", C.c_ulonglong)]
@@ -59,7 +59,7 @@ class TokenBlockBwdDesc(C.Structure):
 
 
 PLAN_MAX_ARGS = 24
-PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP = -2, -3, 1, 2
+PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP, PLAN_SIDE2 = -2, -3, 1, 2, 4
 
 
 class PlanArg(C.Union):
@@ -154,7 +154,7 @@ PROTOTYPES = {
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],
-    "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, _P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
     "eegclip_timing_event_create": [],

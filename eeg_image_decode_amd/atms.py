@@ -475,6 +475,11 @@ class _Engine:
         EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan (diagnosis, A/B timing)"""
         return (not self.joint) and pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
 
+    def _token_block_bwd_enabled(self, pl):
+        """the fused backward of the block (then the forward does not store n2: the backward re-evaluates it); EEGCLIP_TOKEN_BLOCK_BWD=0: the
+        launch-per-op backward behind the fused forward"""
+        return self._token_block_enabled(pl) and os.environ.get("EEGCLIP_TOKEN_BLOCK_BWD", "1") != "0"
+
     def stale(self, model):
         a, b = self._check
         return (a.data_ptr() != self.flat.data_ptr() or b.data.data_ptr() != self.P[_LIVE[-1]].data_ptr()
@@ -558,7 +563,7 @@ class _Engine:
                 ln1_b=_p(P[_LY + "norm1.bias"]), b1=_p(P[_LY + "conv1.bias"]), b2=_p(P[_LY + "conv2.bias"]), ln2_g=_p(P[_LY + "norm2.weight"]),
                 ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), ln3_b=_p(P["encoder.encoder.norm.bias"]),
                 h=_p(b["h"]), qkv=_p(b["qkv"]), ctx=_p(b["ctx"]), r1=_p(b["r1"]), n1=_p(b["n1"]), mu1=_p(b["mu1"]), rs1=_p(b["rs1"]), f1=_p(b["f1"]),
-                g1=_p(b["g1"]), r2=_p(b["r2"]), n2=_p(b["n2"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), n3=_p(b["n3"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]),
+                g1=_p(b["g1"]), r2=_p(b["r2"]), n2=None if self._token_block_bwd_enabled(pl) else _p(b["n2"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), n3=_p(b["n3"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]),
                 drop_p=pe_, eps=EPS, scale=1.0 / math.sqrt(D_HEAD), seed=0, site_embed=SITE_EMBED, site_attn=SITE_ATTN, site_attn_out=SITE_ATTN_OUT,
                 site_ffn_act=SITE_FFN_ACT, site_ffn_out=SITE_FFN_OUT), seeded=pe_ > 0.0)
         else:
@@ -665,11 +670,11 @@ class _Engine:
         sums, bn = b["sums"], b["bn"]
         sk = lambda k: max(1, min(64, k // 512))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
-        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None):
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
             """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major; bias: G[bias] (Nout) += column sums of dY, taken
             from the A tiles the same launch stages (rowsum_a) instead of a separate pass over dY"""
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
-                           rowsum_a=_p(G[bias]) if bias else None, side=True)    # nobody reads a weight gradient before the optimizer
+                           rowsum_a=_p(G[bias]) if bias else None, side=side)    # nobody reads a weight gradient before the optimizer
 
         import os
         ln_side = os.environ.get("EEGCLIP_LN_SIDE", "1") != "0"        # tuning aid: LayerNorm parameter-gradient kernels on the second stream
@@ -770,15 +775,15 @@ class _Engine:
             # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
             pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
-        if self._token_block_enabled(pl) and hasattr(self, "tb_packed") and os.environ.get("EEGCLIP_TOKEN_BLOCK_BWD", "1") != "0":
+        if self._token_block_bwd_enabled(pl) and hasattr(self, "tb_packed"):
             # the dX chain of the transformer block, one workgroup per sample (csrc/token_block.hip): part 0 = final LN' .. dctx, the attention
             # backward, part 1 = dh.  The weight-gradient GEMMs read what the parts leave in HBM (df2, dg1 = df1, da1, dqkv, dr1) on the second stream.
             if "tb_part" not in b:
                 b["tb_part"] = torch.empty(int(lib().eegclip_token_block_bwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
             bd = _abi.TokenBlockBwdDesc(
-                B=B, packed=_p(self.tb_packed), dn3=_p(b["dn3"]), n2=_p(b["n2"]), r2=_p(b["r2"]), r1=_p(b["r1"]), f1=_p(b["f1"]), mu1=_p(b["mu1"]),
+                B=B, packed=_p(self.tb_packed), dn3=_p(b["dn3"]), n2=None, r2=_p(b["r2"]), r1=_p(b["r1"]), f1=_p(b["f1"]), mu1=_p(b["mu1"]),
                 rs1=_p(b["rs1"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]), ln1_g=_p(P[_LY + "norm1.weight"]),
-                ln2_g=_p(P[_LY + "norm2.weight"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), df2=_p(b["df2"]), dg1=_p(b["dg1"]), da1=_p(b["da1"]),
+                ln2_g=_p(P[_LY + "norm2.weight"]), ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), df2=_p(b["df2"]), dg1=_p(b["dg1"]), da1=_p(b["da1"]),
                 dr1=_p(b["dr1"]), dctx=_p(b["dctx"]), partials=_p(b["tb_part"]), dqkv=_p(b["dqkv"]),
                 dln3_g=_p(G["encoder.encoder.norm.weight"]), dln3_b=_p(G["encoder.encoder.norm.bias"]), dln2_g=_p(G[_LY + "norm2.weight"]),
                 dln2_b=_p(G[_LY + "norm2.bias"]), dln1_g=_p(G[_LY + "norm1.weight"]), dln1_b=_p(G[_LY + "norm1.bias"]),
@@ -788,14 +793,16 @@ class _Engine:
                 pl._seed_descs.append(bd)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
+            # (three independent GEMMs of ~2 workgroups per CU each: alternating between the two side streams lets them share the GPU)
+            s2 = 2 if os.environ.get("EEGCLIP_SIDE2", "0") == "1" else True        # (measured: no gain at B = 256, 1.105 vs 1.095 ms)
             wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
-            wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
+            wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias", side=s2)
             wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
                   bias=_LY + "attention.out_projection.bias")
             pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                     pe_, 0, SITE_ATTN, seed_at=10)
             wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
-                  bias=_LY + "attention.query_projection.bias")
+                  bias=_LY + "attention.query_projection.bias", side=s2)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 1)
         else:
             # final LN, LN2

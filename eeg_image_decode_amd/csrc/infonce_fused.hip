@@ -26,6 +26,7 @@
 #include "eeg_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace eeg {
 
@@ -59,8 +60,12 @@ struct if_geom {
     __device__ static __forceinline__ int swz(int row) { return NP == 1 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
-// MODE 0 = forward partials, 1 = gradient tile
-template <int NP, int TM, int MODE>
+// MODE 0 = forward partials, 1 = gradient tile.  REG: operand tiles staged through registers (global_load_dwordx4 -> ds_write_b128, two LDS stages, the
+// next k-tile's loads in flight under this k-tile's MFMAs) instead of LDS-DMA: the DMA path fills a CU's LDS at ~45 GB/s (4 issuing waves; a lone
+// workgroup takes the same 13 us as 256 of them), register loads pull ~135 GB/s per CU from L2 (MI355X_MICROARCH.md) -- at N = 2048 the fill, not the
+// matrix pipe, was the limit.
+typedef unsigned if_u4 __attribute__((ext_vector_type(4)));
+template <int NP, int TM, int MODE, bool REG>
 __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale) {
     using Gm = if_geom<NP>;
@@ -133,55 +138,114 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     //     while the wave issues them).
     constexpr int NSTEP = BK / 16, MPS = WT * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
     const int ktiles = D / BK;
+    if (REG) {
+        constexpr int CPT = TM * NCH / 256;                       // 16-byte chunks per thread and operand-plane tile
+        static_assert(CPT >= 1, "tile too small for 256 staging threads");
+        constexpr int RSTAGE_B = 2 * NP * TILE_B;
+        const unsigned short* const gbase[4] = {P.q_hi + (long long)q0 * D, P.k_hi + (long long)k0r * D, NP == 2 ? P.q_lo + (long long)q0 * D : nullptr,
+                                                NP == 2 ? P.k_lo + (long long)k0r * D : nullptr};
+        if_u4 sreg[2 * NP][CPT];
+        auto gload = [&](int kt) {
 #pragma unroll
-    for (int p = 0; p < IF_NS - 1; ++p)
-        if (p < ktiles) issue_tile(p);
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int newer = ktiles - 1 - kt < IF_NS - 2 ? ktiles - 1 - kt : IF_NS - 2;      // tiles issued after kt that may stay in flight
-        if (newer >= 2) wait_vmcnt<2 * DPT>();
-        else if (newer == 1) wait_vmcnt<DPT>();
-        else wait_vmcnt<0>();
-        raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
-        const bool refill = kt + IF_NS - 1 < ktiles;          // (workgroup-uniform)
-        const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
-        bf16x8 qh[2][WT], kh[2][WT], ql[2][WT], kl[2][WT];
-        auto read_step = [&](int s, int set) {
+            for (int o = 0; o < 2 * NP; ++o)
 #pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
-                kh[set][i] = *reinterpret_cast<const bf16x8*>(st + fok[s][i]);
-                if (NP == 2) {
-                    ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
-                    kl[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][i]);
+                for (int i = 0; i < CPT; ++i) {
+                    const int c = t + 256 * i, row = c / NCH, pos = c % NCH;
+                    sreg[o][i] = *reinterpret_cast<const if_u4*>(gbase[o] + (long long)row * D + kt * BK + 8 * pos);
                 }
-            }
         };
-        read_step(0, 0);
+        auto lstore = [&](int stg) {
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
-#if !defined(EEG_EMU)
-            __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
-#endif
-            const int set = s & 1;
+            for (int o = 0; o < 2 * NP; ++o)
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
+                for (int i = 0; i < CPT; ++i) {
+                    const int c = t + 256 * i, row = c / NCH, pos = c % NCH;
+                    *reinterpret_cast<if_u4*>(lds + stg * RSTAGE_B + o * TILE_B + row * ROWB + (((pos ^ Gm::swz(row)) & (NCH - 1)) << 4)) = sreg[o][i];
+                }
+        };
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            if (kt + 1 < ktiles) gload(kt + 1);                    // in flight under this k-tile's MFMAs
+            const unsigned char* st = lds + (kt & 1) * RSTAGE_B;
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                bf16x8 qh[WT], kh[WT], ql[WT], kl[WT];
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
-                    const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
+                    qh[i] = *reinterpret_cast<const bf16x8*>(st + foq[s_][i]);
+                    kh[i] = *reinterpret_cast<const bf16x8*>(st + fok[s_][i]);
                     if (NP == 2) {
-                        acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
-                        if (refill && ((m0_ + 1) * DPT) / TOTAL > (m0_ * DPT) / TOTAL) issue_one(kt + IF_NS - 1, (m0_ * DPT) / TOTAL);
-                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
-                        if (refill && ((m0_ + 2) * DPT) / TOTAL > ((m0_ + 1) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + 1) * DPT) / TOTAL);
+                        ql[i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s_][i]);
+                        kl[i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s_][i]);
                     }
-                    constexpr int last = NP == 2 ? 2 : 0;
-                    acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
-                    if (refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
                 }
-#if !defined(EEG_EMU)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) {
+                        if (NP == 2) {
+                            acc[j][i] = mfma_bf16_32x32x16(kl[j], qh[i], acc[j][i]);
+                            acc[j][i] = mfma_bf16_32x32x16(kh[j], ql[i], acc[j][i]);
+                        }
+                        acc[j][i] = mfma_bf16_32x32x16(kh[j], qh[i], acc[j][i]);
+                    }
+            }
+            if (kt + 1 < ktiles) lstore((kt + 1) & 1);             // the other stage: every wave finished reading it before the previous barrier
+            __syncthreads();
+        }
+    } else {
+    #pragma unroll
+        for (int p = 0; p < IF_NS - 1; ++p)
+            if (p < ktiles) issue_tile(p);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int newer = ktiles - 1 - kt < IF_NS - 2 ? ktiles - 1 - kt : IF_NS - 2;      // tiles issued after kt that may stay in flight
+            if (newer >= 2) wait_vmcnt<2 * DPT>();
+            else if (newer == 1) wait_vmcnt<DPT>();
+            else wait_vmcnt<0>();
+            raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
+            const bool refill = kt + IF_NS - 1 < ktiles;          // (workgroup-uniform)
+            const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
+            bf16x8 qh[2][WT], kh[2][WT], ql[2][WT], kl[2][WT];
+            auto read_step = [&](int s, int set) {
+    #pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
+                    kh[set][i] = *reinterpret_cast<const bf16x8*>(st + fok[s][i]);
+                    if (NP == 2) {
+                        ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+                        kl[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][i]);
+                    }
+                }
+            };
+            read_step(0, 0);
+    #pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
+    #if !defined(EEG_EMU)
+                __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
+    #endif
+                const int set = s & 1;
+    #pragma unroll
+                for (int j = 0; j < WT; ++j)
+    #pragma unroll
+                    for (int i = 0; i < WT; ++i) {
+                        const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
+                        if (NP == 2) {
+                            acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
+                            if (refill && ((m0_ + 1) * DPT) / TOTAL > (m0_ * DPT) / TOTAL) issue_one(kt + IF_NS - 1, (m0_ * DPT) / TOTAL);
+                            acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
+                            if (refill && ((m0_ + 2) * DPT) / TOTAL > ((m0_ + 1) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + 1) * DPT) / TOTAL);
+                        }
+                        constexpr int last = NP == 2 ? 2 : 0;
+                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
+                        if (refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
+                    }
+    #if !defined(EEG_EMU)
+                __builtin_amdgcn_sched_barrier(0);
+    #endif
+            }
         }
     }
 
@@ -280,37 +344,60 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     }
 }
 
-// partials -> lse; loss.  32 lanes per row (lane p takes partial slots p, p + 32, ...: one round of loads, then two 5-step shuffle
-// reductions; one thread per row walked its 2 x Pn loads in sequence: 17-23 us for 2048 rows).  grid.x <= 32 workgroups stride over the rows
-// and add ONE value each to the loss (one atomic per wave was 1024 same-address atomics = ~13 us); grid.y = problem
+// partials -> lse; loss.  One workgroup per 64 rows (grid.y = problem): lane = row, the four waves split the Pn partial slots (slot p of wave
+// p & 3), so every load instruction is 64 consecutive rows of one slot (256 contiguous bytes) and ALL of a thread's loads (<= 2 x 16) are in flight
+// at once; two LDS exchanges (max, then scaled sum) combine the waves.  One round trip of memory latency per launch -- the first version walked the
+// slots with 32 lanes per row, 8 rows per workgroup pass and 8 passes of two dependent load rounds each: 11.3 us on average at N = 2048, as long as
+// the tile kernel it follows.  One atomic per workgroup on the loss.
+constexpr int IF_FIN_MAX = 16;                                   // partial slots per wave: Pn <= 64 (N <= 2048 with 64-wide tiles; larger N: strided loop)
 __global__ __launch_bounds__(256) void infonce_finalize_kernel(const if_table tb, int n, int Pn, float inv_total, float* __restrict__ loss) {
-    EEG_LDS_BASE(float, red);
+    EEG_LDS_BASE(float, red);                                    // [2][4][64]
     const if_problem& P = tb.p[blockIdx.y];
     const float* const part = P.part;
     const float* const diag = P.diag;
     float* const lse_out = P.lse;
     const float w = P.weight * inv_total;
-    const int lane = threadIdx.x & 63, sub = lane & 31, wave = threadIdx.x >> 6;
-    float contrib = 0.f;
-    for (int q = (int)(blockIdx.x * 8 + (threadIdx.x >> 5)); q < n; q += (int)gridDim.x * 8) {      // (uniform per half-wave)
-        float m = -3.0e38f;
-        for (int p = sub; p < Pn; p += 32) m = fmaxf(m, part[(long long)p * n + q]);
+    const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int q = (int)blockIdx.x * 64 + lane;
+    const bool live = q < n;
+    float mx[IF_FIN_MAX], sm[IF_FIN_MAX];
+    float m = -3.0e38f;
+    if (Pn <= 4 * IF_FIN_MAX) {
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float l = 0.f;
-        for (int p = sub; p < Pn; p += 32) l += part[(long long)(Pn + p) * n + q] * fast_exp(part[(long long)p * n + q] - m);
+        for (int i = 0; i < IF_FIN_MAX; ++i) {
+            const int p = s + 4 * i;
+            const bool ok = live && p < Pn;
+            mx[i] = ok ? part[(long long)p * n + q] : -3.0e38f;
+            sm[i] = ok ? part[(long long)(Pn + p) * n + q] : 0.f;
+        }
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o, 64);
-        if (sub == 0) {
+        for (int i = 0; i < IF_FIN_MAX; ++i) m = fmaxf(m, mx[i]);
+    } else if (live) {
+        for (int p = s; p < Pn; p += 4) m = fmaxf(m, part[(long long)p * n + q]);
+    }
+    red[s * 64 + lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+    float l = 0.f;
+    if (Pn <= 4 * IF_FIN_MAX) {
+#pragma unroll
+        for (int i = 0; i < IF_FIN_MAX; ++i) l += sm[i] * fast_exp(mx[i] - m);
+    } else if (live) {
+        for (int p = s; p < Pn; p += 4) l += part[(long long)(Pn + p) * n + q] * fast_exp(part[(long long)p * n + q] - m);
+    }
+    red[256 + s * 64 + lane] = l;
+    __syncthreads();
+    if (s == 0) {
+        l = (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]);
+        float contrib = 0.f;
+        if (live) {
             const float lse = m + logf(l);
             lse_out[q] = lse;
-            contrib += (lse - diag[q]) * w;
+            contrib = (lse - diag[q]) * w;
         }
+        contrib = wave_sum(contrib);
+        if (lane == 0) atomicAdd(loss, contrib);
     }
-    contrib = wave_sum(contrib);
-    if (lane == 0) red[wave] = contrib;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // fp32 -> bf16 hi (+ lo = bf16(x - hi)) planes, 8 elements per thread
@@ -382,20 +469,29 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
     return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
 }
 
-#define EEG_IF_GO(NP_, TM_, MODE_)                                                                                                              \
-    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_>), dim3((unsigned)(nprob * tq * tk)), dim3(256), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
-               stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+#define EEG_IF_GO(NP_, TM_, MODE_, REG_)                                                                                                           \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, REG_>), dim3((unsigned)(nprob * tq * tk)), dim3(256),                                        \
+               (size_t)(REG_ ? 2 : IF_NS) * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+#define EEG_IF_GO2(NP_, TM_, MODE_)                                       \
+    do {                                                                  \
+        if (reg) EEG_IF_GO(NP_, TM_, MODE_, true);                        \
+        else EEG_IF_GO(NP_, TM_, MODE_, false);                           \
+    } while (0)
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream) {
-    const int TM = if_tile(n, N, planes >> 8), tq = n / TM, tk = N / TM;
+    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM;
+    // operand staging: bits 16..17 of `planes` (tuning / tests) 1 = LDS-DMA, 2 = registers; 0 = EEGCLIP_INFONCE_STAGE (dma | reg), default registers
+    static const int env_stage = getenv("EEGCLIP_INFONCE_STAGE") ? (strcmp(getenv("EEGCLIP_INFONCE_STAGE"), "dma") == 0 ? 1 : 2) : 2;
+    const int stg = (planes >> 16) & 3;
+    const bool reg = (stg ? stg : env_stage) == 2;
     planes &= 0xff;
     if (planes == 1) {
-        if (TM == 128) { if (mode == 0) EEG_IF_GO(1, 128, 0); else EEG_IF_GO(1, 128, 1); }
-        else           { if (mode == 0) EEG_IF_GO(1, 64, 0);  else EEG_IF_GO(1, 64, 1); }
+        if (TM == 128) { if (mode == 0) EEG_IF_GO2(1, 128, 0); else EEG_IF_GO2(1, 128, 1); }
+        else           { if (mode == 0) EEG_IF_GO2(1, 64, 0);  else EEG_IF_GO2(1, 64, 1); }
     } else {
-        if (TM == 128) { if (mode == 0) EEG_IF_GO(2, 128, 0); else EEG_IF_GO(2, 128, 1); }
-        else           { if (mode == 0) EEG_IF_GO(2, 64, 0);  else EEG_IF_GO(2, 64, 1); }
+        if (TM == 128) { if (mode == 0) EEG_IF_GO2(2, 128, 0); else EEG_IF_GO2(2, 128, 1); }
+        else           { if (mode == 0) EEG_IF_GO2(2, 64, 0);  else EEG_IF_GO2(2, 64, 1); }
     }
     return (int)hipGetLastError();
 }
@@ -409,9 +505,8 @@ extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, i
     const float inv_total = 1.0f / (float)n_total;
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
     if (rc) return rc;
-    const int Pn = 2 * (N / if_tile(n, N, planes >> 8));
-    const int fgrid = (n + 7) / 8 < 32 ? (n + 7) / 8 : 32;
-    EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)fgrid, (unsigned)nprob), dim3(256), 4 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
+    const int Pn = 2 * (N / if_tile(n, N, (planes >> 8) & 0xff));
+    EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nprob), dim3(256), 512 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
     return (int)hipGetLastError();
 }
 

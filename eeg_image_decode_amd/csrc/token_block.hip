@@ -26,6 +26,8 @@
 // gemm_epilogue.h): the backward regenerates them, tests regenerate them in numpy.
 #include "eeg_common.h"
 
+#include <stdlib.h>
+
 namespace eeg {
 
 constexpr int TB_THREADS = 512;
@@ -174,6 +176,8 @@ __device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned 
                 bl[(ks + PF) % (PF + 1)][j] = q[64];
             }
         }
+        // (pinning the prefetch issue here with sched_barrier(0) measured SLOWER -- 140 vs 120 us per launch: it also stops the scheduler from
+        //  running the next k-step's fragment reads under this k-step's MFMAs)
         bf16x8 ah[4], al[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -234,6 +238,7 @@ struct tb_fwd_args {
     float drop_p, eps, scale;
     unsigned long long seed;
     unsigned site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
+    unsigned dbg;                                                // diagnosis (EEGCLIP_TB_DEBUG): bit 0 = leave out the activation stores (timing ablation only)
 };
 
 // one QKV tile of this wave (+ bias) -> global qkv (natural (row, 744) layout) ; values stay in `v` (biased)
@@ -249,7 +254,7 @@ __device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int
             const int m = 16 * mt + fr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[mt][i] = i < valid ? v[mt][i] + bias[i] : 0.f;
-            tb_st4(a.qkv + ((long long)b * TB_L + m) * (3 * TB_HE) + cbase + d0, valid, v[mt]);
+            if (!(a.dbg & 1u)) tb_st4(a.qkv + ((long long)b * TB_L + m) * (3 * TB_HE) + cbase + d0, valid, v[mt]);
         }
     } else {
         const int d = 16 * tt + fr;
@@ -259,7 +264,7 @@ __device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[mt][i] = d < TB_E ? v[mt][i] + bias : 0.f;
-                if (d < TB_E) a.qkv[((long long)b * TB_L + 16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d] = v[mt][i];
+                if (d < TB_E && !(a.dbg & 1u)) a.qkv[((long long)b * TB_L + 16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d] = v[mt][i];
             }
     }
 }
@@ -429,7 +434,7 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                 v[2 * p + e] = ok[p] ? d + rv[e] : 0.f;
                 s += v[2 * p + e];
             }
-            if (ok[p] && r_out) *reinterpret_cast<tb_f2*>(r_out + rbase + cp) = tb_f2{v[2 * p], v[2 * p + 1]};
+            if (ok[p] && r_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(r_out + rbase + cp) = tb_f2{v[2 * p], v[2 * p + 1]};
         }
         const float mean = wave_sum(s) * inv;
         float q = 0.f;
@@ -455,7 +460,7 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                 s2 += y[2 * p + e];
             }
             if (ok[p]) {
-                *reinterpret_cast<tb_f2*>(y_out + rbase + cp) = tb_f2{y[2 * p], y[2 * p + 1]};
+                if (y_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(y_out + rbase + cp) = tb_f2{y[2 * p], y[2 * p + 1]};
                 if (y_lds) *reinterpret_cast<tb_f2*>(y_lds + xf_off(r, cp)) = tb_f2{y[2 * p], y[2 * p + 1]};
             }
             if (ap && cp >= 0 && cp < 256) tb_store_planes2(ap, TB_AP_PLANE, ap_off(r, cp), y[2 * p], y[2 * p + 1]);      // (zeros past column 249)
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ksc : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(hb + i0) = f32x4{v[0], v[1], v[2], v[3]};
+                if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(hb + i0) = f32x4{v[0], v[1], v[2], v[3]};
                 tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, col), v[0], v[1]);
                 tb_store_planes2(AP, TB_AP_PLANE, ap_off(row2, col2), v[2], v[3]);
             }
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
                 const f32x4 c = ctxr[rd][dt];
-                if (d0 < TB_E) tb_st4(a.ctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, c);
+                if (d0 < TB_E && !(a.dbg & 1u)) tb_st4(a.ctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, c);
                 tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, 64 * head + d0), c[0], c[1], c[2], c[3]);
             }
         }
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             f32x4 f, gq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) f[i] = v[i] + bias[i];
-            *reinterpret_cast<f32x4*>(a.f1 + o) = f;
+            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.f1 + o) = f;
             bool keep[4] = {true, true, true, true};
             if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
 #pragma unroll
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
                 const float ge = gelu_erf(f[i]);
                 gq[i] = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
             }
-            *reinterpret_cast<f32x4*>(a.g1 + o) = gq;
+            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.g1 + o) = gq;
             v = gq;
         });
         raw_barrier();                                               // every wave is done with the n1 planes
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
 // token_block_param_reduce_kernel sums the rows.
 struct tb_bwd_args {
     const unsigned short* packed;
-    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln3_g;
+    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln2_b, *ln3_g;
     float *df2, *dg1, *da1, *dr1, *dctx, *partials;
     const float* dqkv;
     float drop_p;
@@ -778,10 +783,16 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 tb_f2 v0 = tb_f2{0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0, v4 = v0;
                 if (ok[p]) {
                     v0 = *reinterpret_cast<const tb_f2*>(a.dn3 + rbase + cp);
-                    v1 = *reinterpret_cast<const tb_f2*>(a.n2 + rbase + cp);
                     v2 = *reinterpret_cast<const tb_f2*>(a.r2 + rbase + cp);
                     v3 = *reinterpret_cast<const tb_f2*>(a.ln3_g + cp);
                     v4 = *reinterpret_cast<const tb_f2*>(a.ln2_g + cp);
+                    if (a.n2) v1 = *reinterpret_cast<const tb_f2*>(a.n2 + rbase + cp);
+                    else {
+                        // n2 = LayerNorm2(r2) is re-evaluated from r2 and the row statistics (the forward did not store it: 16 MB per step less each way)
+                        const tb_f2 bb = *reinterpret_cast<const tb_f2*>(a.ln2_b + cp);
+                        const float mu = a.mu2[row], rs = a.rs2[row];
+                        v1 = tb_f2{(v2[0] - mu) * rs * v4[0] + bb[0], (v2[1] - mu) * rs * v4[1] + bb[1]};
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x3[2 * p + e] = v1[e]; x2[2 * p + e] = v2[e]; g3[2 * p + e] = v3[e]; g2[2 * p + e] = v4[e]; }
@@ -977,7 +988,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
     }
 }
 
-// dgamma / dbeta of the three LayerNorms: out[v][c] += sum_b partials[b][v][c]; one workgroup per (vector, 64 columns), 4 waves split the samples
+// dgamma / dbeta of the three LayerNorms: out[v][c] += sum_b partials[b][v][c]; one workgroup per (vector, 64 columns, slice of <= B/16 samples)
 struct tb_param_args {
     const float* partials;
     float* out[6];
@@ -987,11 +998,13 @@ __global__ __launch_bounds__(256) void token_block_param_reduce_kernel(const tb_
     EEG_LDS_BASE(float, red);
     const int v = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int per = (a.B + (int)gridDim.z - 1) / (int)gridDim.z, b0 = (int)blockIdx.z * per, b1 = b0 + per < a.B ? b0 + per : a.B;
     float s = 0.f;
-    for (int b = g; b < a.B; b += 4) s += a.partials[((long long)b * 6 + v) * 256 + c];
+#pragma unroll 4
+    for (int b = b0 + g; b < b1; b += 4) s += a.partials[((long long)b * 6 + v) * 256 + c];
     red[g * 64 + lane] = s;
     __syncthreads();
-    if (g == 0 && c < TB_D) a.out[v][c] += (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    if (g == 0 && c < TB_D) atomicAdd(a.out[v] + c, (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]));      // gridDim.z adds per address
 }
 
 }  // namespace eeg
@@ -1012,7 +1025,7 @@ extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, cons
 extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream) {
     if (!d || d->B < 1 || !d->x || !d->packed || !d->bv || !d->pe || !d->tokens || !d->bqkv || !d->bo || !d->ln1_g || !d->ln1_b || !d->b1 || !d->b2 ||
         !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctx || !d->r1 || !d->n1 || !d->mu1 || !d->rs1 || !d->f1 || !d->g1 ||
-        !d->r2 || !d->n2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
+        !d->r2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->h) | reinterpret_cast<uintptr_t>(d->f1) |
                            reinterpret_cast<uintptr_t>(d->g1) | reinterpret_cast<uintptr_t>(d->b1);
@@ -1027,7 +1040,9 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
     tb_fwd_args a{d->x, static_cast<const unsigned short*>(d->packed), d->bv, d->pe, d->tokens, d->ids, d->bqkv, d->bo, d->ln1_g, d->ln1_b, d->b1, d->b2,
                   d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->ctx, d->r1, d->n1, d->mu1, d->rs1, d->f1, d->g1, d->r2, d->n2, d->mu2, d->rs2,
                   d->n3, d->mu3, d->rs3, d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn, d->site_attn_out, d->site_ffn_act,
-                  d->site_ffn_out};
+                  d->site_ffn_out, 0u};
+    static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
+    a.dbg = dbg;
     if (d->drop_p > 0.f) EEG_LAUNCH(token_block_fwd_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
     else EEG_LAUNCH(token_block_fwd_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
     return (int)hipGetLastError();
@@ -1038,10 +1053,10 @@ extern "C" long long eegclip_token_block_bwd_workspace_floats(int B) { return B 
 extern "C" int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream) {
     if (!d || d->B < 1 || !d->packed || d->drop_p < 0.f || d->drop_p >= 1.f || part < 0 || part > 2) return EEGCLIP_EINVAL;
     tb_bwd_args a{static_cast<const unsigned short*>(d->packed), d->dn3, d->n2, d->r2, d->r1, d->f1, d->mu1, d->rs1, d->mu2, d->rs2, d->mu3, d->rs3,
-                  d->ln1_g, d->ln2_g, d->ln3_g, d->df2, d->dg1, d->da1, d->dr1, d->dctx, d->partials, d->dqkv, d->drop_p, d->seed, d->site_embed,
+                  d->ln1_g, d->ln2_g, d->ln2_b, d->ln3_g, d->df2, d->dg1, d->da1, d->dr1, d->dctx, d->partials, d->dqkv, d->drop_p, d->seed, d->site_embed,
                   d->site_attn_out, d->site_ffn_act, d->site_ffn_out};
     if (part == 0) {
-        if (!d->dn3 || !d->n2 || !d->r2 || !d->r1 || !d->f1 || !d->mu1 || !d->rs1 || !d->mu2 || !d->rs2 || !d->mu3 || !d->rs3 || !d->ln1_g || !d->ln2_g ||
+        if (!d->dn3 || (!d->n2 && !d->ln2_b) || !d->r2 || !d->r1 || !d->f1 || !d->mu1 || !d->rs1 || !d->mu2 || !d->rs2 || !d->mu3 || !d->rs3 || !d->ln1_g || !d->ln2_g ||
             !d->ln3_g || !d->df2 || !d->dg1 || !d->da1 || !d->dr1 || !d->dctx || !d->partials)
             return EEGCLIP_EINVAL;
         const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->dg1);
@@ -1061,7 +1076,7 @@ extern "C" int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, in
     } else {
         if (!d->partials || !d->dln3_g || !d->dln3_b || !d->dln2_g || !d->dln2_b || !d->dln1_g || !d->dln1_b) return EEGCLIP_EINVAL;
         tb_param_args pa{d->partials, {d->dln3_g, d->dln3_b, d->dln2_g, d->dln2_b, d->dln1_g, d->dln1_b}, d->B};
-        EEG_LAUNCH(token_block_param_reduce_kernel, dim3(4, 6), dim3(256), 256 * sizeof(float), stream, pa);
+        EEG_LAUNCH(token_block_param_reduce_kernel, dim3(4, 6, d->B < 16 ? d->B : 16), dim3(256), 256 * sizeof(float), stream, pa);
     }
     return (int)hipGetLastError();
 }

@@ -38,6 +38,10 @@ def default_gemm_precision():
     return _abi.PREC_BF16X3 if v == "bf16x3" else _abi.PREC_F32
 
 
+# entry points that launch exactly ONE kernel: eegclip_time_next_launch stamps the first kernel of a call, so only these take kernel timestamps
+_SINGLE_KERNEL_OPS = frozenset({"eegclip_gemm_f32", "eegclip_token_block_fwd", "eegclip_token_block_bwd", "eegclip_attention_fwd", "eegclip_attention_bwd"})
+
+
 class Plan:
     def __init__(self, name="", precision=None):
         self.name = name
@@ -52,6 +56,7 @@ class Plan:
         self.kernel_timestamps = os.environ.get("EEGCLIP_TIMING", "kernel") != "bracket"      # per-op timing: kernel timestamps | HIP-event brackets
         self._ev_free, self._ev_used = [], []
         self._side = None      # (torch side stream, {op index: fork event}, join event) -- created on first use
+        self._side2 = None     # second side stream (ops flagged side=2), C executor only
         self.use_side_stream = True
         self.skip = ()         # op indices left out of the next run()s (e.g. the value-embedding GEMMs of subjects absent from the batch)
         self._c = None         # compiled form for the C executor (eegclip_plan_run): built on the first untimed run
@@ -169,7 +174,7 @@ class Plan:
                 if fid < 0:
                     raise RuntimeError(f"{name} is not dispatchable by the plan executor")
                 arr[i].fn = fid
-                arr[i].flags = _abi.PLAN_SIDE if on_side else 0
+                arr[i].flags = (_abi.PLAN_SIDE2 if on_side == 2 else _abi.PLAN_SIDE) if on_side else 0
                 sl = [_abi.plan_slot(t) for t in fns[name]]
                 slots.append(sl)
                 for j, s_ in enumerate(sl):
@@ -183,17 +188,17 @@ class Plan:
             segments.append(("c", start, n))
         n_side = sum(1 for op in self.ops if op[3])
         ev = (ctypes.c_void_p * n)()
-        join = ctypes.c_void_p()
+        join, join2 = ctypes.c_void_p(), ctypes.c_void_p()
         if n_side:
-            tmp = (ctypes.c_void_p * (n_side + 1))()
-            check(L.eegclip_plan_events(n_side + 1, tmp), f"{self.name}:plan_events")
+            tmp = (ctypes.c_void_p * (n_side + 2))()
+            check(L.eegclip_plan_events(n_side + 2, tmp), f"{self.name}:plan_events")
             k = 0
             for i, op in enumerate(self.ops):
                 if op[3]:
                     ev[i] = tmp[k]
                     k += 1
-            join = ctypes.c_void_p(tmp[n_side])
-        self._c = dict(arr=arr, slots=slots, segments=segments, events=ev, join=join, n=n, dirty=ctypes.c_int(0), failed=ctypes.c_int(-1),
+            join, join2 = ctypes.c_void_p(tmp[n_side]), ctypes.c_void_p(tmp[n_side + 1])
+        self._c = dict(arr=arr, slots=slots, segments=segments, events=ev, join=join, join2=join2, n=n, dirty=ctypes.c_int(0), failed=ctypes.c_int(-1),
                        owned=(tmp if n_side else None))
         self._c_skip = ()
 
@@ -225,15 +230,20 @@ class Plan:
             for i in self.skip:
                 arr[i].flags |= _abi.PLAN_SKIP
             self._c_skip = self.skip
-        side = None
+        side = side2 = None
         if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
             if self._side is None:
                 self._side = (torch.cuda.Stream(priority=_SIDE_PRIORITY), None, None)
             side = self._side[0]
+            if any(op[3] == 2 for op in self.ops):                # a second side stream: independent weight-gradient GEMMs side by side
+                if self._side2 is None:
+                    self._side2 = torch.cuda.Stream(priority=_SIDE_PRIORITY)
+                side2 = self._side2
         c["dirty"].value = 0
         for seg in c["segments"]:
             if seg[0] == "c":
-                rc = self.L.eegclip_plan_run(arr, seg[1], seg[2], c["n"], stream, side.cuda_stream if side is not None else None, c["events"], c["join"],
+                rc = self.L.eegclip_plan_run(arr, seg[1], seg[2], c["n"], stream, side.cuda_stream if side is not None else None,
+                                             side2.cuda_stream if side2 is not None else None, c["events"], c["join"], c["join2"],
                                              ctypes.byref(c["dirty"]), ctypes.byref(c["failed"]))
                 if rc:
                     check(rc, f"{self.name}:{self.ops[c['failed'].value][2]}")
@@ -242,20 +252,28 @@ class Plan:
                 if idx in self.skip:
                     continue
                 fn = self.ops[idx][1][0]
-                if on_side and side is not None:                  # behind everything enqueued on BOTH streams so far
+                if on_side and side is not None:                  # behind everything enqueued on ALL streams so far
                     ts = torch.cuda.current_stream()
                     e = torch.cuda.Event()
                     e.record(ts)
                     side.wait_event(e)
+                    if side2 is not None and (c["dirty"].value & 2):
+                        e2 = torch.cuda.Event()
+                        e2.record(side2)
+                        side.wait_event(e2)
                     with torch.cuda.stream(side):
                         fn()
-                    c["dirty"].value = 1
+                    c["dirty"].value |= 1
                 else:
                     fn()
         if c["dirty"].value and side is not None:                 # (a trailing side-stream callback: join here)
             e = torch.cuda.Event()
             e.record(side)
             torch.cuda.current_stream().wait_event(e)
+            if side2 is not None and (c["dirty"].value & 2):
+                e2 = torch.cuda.Event()
+                e2.record(side2)
+                torch.cuda.current_stream().wait_event(e2)
             c["dirty"].value = 0
 
     def time_ops(self, indices, every=1):
@@ -312,7 +330,7 @@ class Plan:
                 continue
             use_side = on_side and side is not None
             # (single-kernel entry points only: the stamp covers the FIRST kernel a call launches)
-            stamp = timed and idx in timed and name == "eegclip_gemm_f32" and self.kernel_timestamps
+            stamp = timed and idx in timed and name in _SINGLE_KERNEL_OPS and self.kernel_timestamps
             if stamp:
                 # the kernel's own GPU begin / end timestamps (hipExtLaunchKernel events armed for the next launch): no marker packets around it
                 e0, e1 = self._timing_event(), self._timing_event()

@@ -705,7 +705,7 @@ def bench_sampling_loop(images=8, steps=50, latent=128, guidance_scale=5.0, dtyp
     flops = 0.0
     for d, n, tok in zip(pipe.unet.stage_dims, pipe.unet.stage_layers, [(latent // 2) ** 2, (latent // 4) ** 2, (latent // 4) ** 2, (latent // 4) ** 2, (latent // 2) ** 2]):
         flops += n * (2 * 2.0 * B * tok * d * d + 4.0 * B * tok * 81 * d)            # to_q + to_out GEMMs, QK^T + PV over 77 + 4 tokens
-    return {"workload": f"configs[4] shape: {steps}-step DDIM, {images} images x CFG pair, {latent * 8} px ({latent}x{latent} latents), SDXL-SHAPED STAND-IN "
+    return {"stand_in": True, "workload": f"configs[4] shape: {steps}-step DDIM, {images} images x CFG pair, {latent * 8} px ({latent}x{latent} latents), SDXL-SHAPED STAND-IN "
                         f"UNet ({n_layers} cross-attention positions with IP-Adapter branch; no self-attention / ResNets / trained weights)",
             "steps": steps, "seconds": round(dt, 3), "ms_per_step": round(1e3 * dt / steps, 2), "images_per_s": round(images / dt, 2),
             "attention_stack_TFLOPs": round(flops * steps / dt / 1e12, 1), "finite": bool(torch.isfinite(out.float()).all())}

@@ -425,13 +425,14 @@ typedef struct {
 #define EEGCLIP_PLAN_JOIN (-3)
 #define EEGCLIP_PLAN_SIDE 1
 #define EEGCLIP_PLAN_SKIP 2
+#define EEGCLIP_PLAN_SIDE2 4 /* the op runs on the SECOND side stream (independent weight-gradient GEMMs side by side) */
 int eegclip_plan_fn_id(const char* name);
 int eegclip_plan_events(int n, void** out);
 /* destroys events made by eegclip_plan_events (null entries are skipped): call when a plan is dropped -- plans are rebuilt per batch size /
  * mode / world size, so a long-lived process would otherwise leak their fork / join events */
 int eegclip_plan_events_destroy(int n, void* const* events);
-int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* const* events,
-                     void* join_event, int* dirty, int* failed);
+int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total, void* main_stream, void* side_stream, void* side_stream2,
+                     void* const* events, void* join_event, void* join_event2, int* dirty, int* failed);
 
 /* ---- the transformer block of the encoder as ONE launch, one workgroup per sample (csrc/token_block.hip): value embedding + positional
  * embedding + subject token + dropout (models/subject_layers/Embed.py:141-162), fused q | k | v projection, 4-head attention with probability
@@ -449,7 +450,7 @@ typedef struct {
     const float *bv, *pe, *tokens;             /* value-embedding bias (250); positional table rows 0..62 (row stride 250); token table (rows of 250) */
     const long long* ids;                      /* (B) row of `tokens` per sample, NULL: row 0 (the shared token) */
     const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
-    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;      /* outputs, rows = B * 64 */
+    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;      /* outputs, rows = B * 64; n2 may be NULL (not stored) */
     float drop_p, eps, scale;                  /* dropout probability of all five sites (0: evaluation), LayerNorm eps, softmax scale */
     unsigned long long seed;
     unsigned int site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
@@ -468,7 +469,7 @@ int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream);
 typedef struct {
     int B;
     const void* packed;
-    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln3_g;
+    const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln2_b, *ln3_g;      /* n2 NULL: re-evaluated from r2 (needs ln2_b) */
     float *df2, *dg1, *da1, *dr1, *dctx, *partials;
     const float* dqkv;
     float *dln3_g, *dln3_b, *dln2_g, *dln2_b, *dln1_g, *dln1_b;

@@ -515,4 +515,4 @@ def test_retrieval_accuracy_after_training_matches_the_oracle():
     (g1, g5), (o1, o5) = acc(tg), acc(to)
     assert o5 > 3 * 5 / n_test                                    # the model has learnt something: well above the 2.5 % chance level
     assert abs(g1 - o1) <= 0.001 + 1e-9 and abs(g5 - o5) <= 0.001 + 1e-9, ((g1, g5), (o1, o5))       # +-0.1 %
-    assert int((tg[:, 0] != to[:, 0]).sum()) <= 2
+    assert int((tg[:, 0] != to[:, 0]).sum()) <= n_test // 200        # <= 0.5 % of the top-1 INDICES may differ (near-ties); the accuracies above may not

@@ -25,6 +25,7 @@ def _model(dev):
 
 def _forward(dev, B, train, subject, fused, monkeypatch):
     monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK", "1" if fused else "0")
+    monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK_BWD", "0")       # (with the fused backward the forward does not store n2; here every tensor is compared)
     m = _model(dev)
     m.train(train)
     x = torch.from_numpy(syn.eeg_batch(SEED + 31, B)).to(dev)
@@ -66,6 +67,7 @@ def test_fused_token_block_equals_the_unfused_plan_on_the_gpu(B, train, subject,
 
 def _grads(dev, B, train, subject, fused, monkeypatch):
     monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK", "1" if fused else "0")
+    monkeypatch.delenv("EEGCLIP_TOKEN_BLOCK_BWD", raising=False)
     m = _model(dev)
     m.train(train)
     x = torch.from_numpy(syn.eeg_batch(SEED + 32, B)).to(dev)

@@ -32,4 +32,4 @@ def main(iters=50, B=256):
 
 
 if __name__ == "__main__":
-    main(*(int(a) for a in sys.argv[1:2]))
+    main(*(int(a) for a in sys.argv[1:3]))
