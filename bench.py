@@ -711,7 +711,7 @@ class _CollectiveLog:
             by.setdefault(key, []).append(us)
         rows = {k: {"per_step": round(len(v) / steps, 2), "mean_us_stream_held": (round(float(np.mean([x for x in v if x is not None])), 1) if any(x is not None for x in v) else None)}
                 for k, v in by.items()}
-        held = sum(r["per_step"] * r["mean_us_stream_held"] for r in rows.values() if r["mean_us_stream_held"] is not None and "(async)" not in "")
+        held = sum(r["per_step"] * r["mean_us_stream_held"] for k, r in rows.items() if r["mean_us_stream_held"] is not None and "(async)" not in k)
         return {"per_step": round(len(self.calls) / steps, 2), "by_kind_and_payload": rows, "sum_us_stream_held_per_step": round(held, 1),
                 "note": "blocking collectives: event pair around the call on the compute stream; async ones: issue .. wait() (mostly overlapped work, not exposure)"}
 

@@ -97,3 +97,8 @@ def test_bench_runs_on_two_ranks_and_prints_one_json_line():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["global_batch"] == 512 and d["value"] > 0 and d["scaling"] == "weak"
+    # what the run was + where its communication goes (the first multi-GPU line of the driver must explain itself)
+    ds = d["distributed"]
+    assert ds["backend"] == "gloo" and ds["world_size"] == 2 and ds["loss_mode"] == {"local_loss": True, "gather_with_grad": True}
+    c = ds["collectives"]
+    assert c["per_step"] == 9 and c["sum_us_stream_held_per_step"] > 0, c       # 9 collectives per step
