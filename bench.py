@@ -659,10 +659,28 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+class _WorkProxy:
+    """an async collective's Work handle whose wait() also stamps the end event (pybind Work objects take no new attributes)"""
+
+    def __init__(self, work, end_event):
+        self._work, self._end = work, end_event
+
+    def wait(self, *a, **k):
+        r = self._work.wait(*a, **k)
+        self._end.record()
+        return r
+
+    def __getattr__(self, name):
+        return getattr(self._work, name)
+
+
 class _CollectiveLog:
     """wraps torch.distributed's collectives while active: per call the kind, payload bytes and an event pair on the current (compute) stream --
     around the call for blocking collectives, from issue to .wait() for async ones -- i.e. the time the compute stream is held, not wire time"""
     KINDS = ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor")
+
+    def __init__(self, event_factory=None):
+        self.new_event = event_factory or (lambda: torch.cuda.Event(enable_timing=True))
 
     def __enter__(self):
         import torch.distributed as dist
@@ -678,21 +696,14 @@ class _CollectiveLog:
 
         def call(*a, **k):
             t = a[0]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = log.new_event(), log.new_event()
             e0.record()
             work = real(*a, **k)
-            rec = {"kind": kind, "bytes": t.numel() * t.element_size(), "async": bool(k.get("async_op", False)), "ev": (e0, e1)}
-            log.calls.append(rec)
-            if work is not None and k.get("async_op", False):
-                real_wait = work.wait
-
-                def wait(*wa, **wk):
-                    r = real_wait(*wa, **wk)
-                    e1.record()
-                    return r
-                work.wait = wait
-            else:
-                e1.record()
+            is_async = bool(k.get("async_op", False))
+            log.calls.append({"kind": kind, "bytes": t.numel() * t.element_size(), "async": is_async, "ev": (e0, e1)})
+            if work is not None and is_async:
+                return _WorkProxy(work, e1)
+            e1.record()
             return work
         return call
 

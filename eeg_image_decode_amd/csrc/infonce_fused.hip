@@ -61,9 +61,9 @@ struct if_geom {
 };
 
 // MODE 0 = forward partials, 1 = gradient tile.  REG: operand tiles staged through registers (global_load_dwordx4 -> ds_write_b128, two LDS stages, the
-// next k-tile's loads in flight under this k-tile's MFMAs) instead of LDS-DMA: the DMA path fills a CU's LDS at ~45 GB/s (4 issuing waves; a lone
-// workgroup takes the same 13 us as 256 of them), register loads pull ~135 GB/s per CU from L2 (MI355X_MICROARCH.md) -- at N = 2048 the fill, not the
-// matrix pipe, was the limit.
+// next k-tile's loads in flight under this k-tile's MFMAs) instead of LDS-DMA.  Built to test VERDICT r2's reading that the DMA fill (~45 GB/s per
+// CU) is the limit at N = 2048; MEASURED slower than the 4-stage DMA pipeline (20.8 vs 18.3 us per logits block): one barrier per k-tile with the
+// ds_write burst in front of it costs more than the DMA path's fill rate.  Kept selectable (EEGCLIP_INFONCE_STAGE=reg), not the default.
 typedef unsigned if_u4 __attribute__((ext_vector_type(4)));
 template <int NP, int TM, int MODE, bool REG>
 __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
@@ -481,8 +481,9 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream) {
     const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM;
-    // operand staging: bits 16..17 of `planes` (tuning / tests) 1 = LDS-DMA, 2 = registers; 0 = EEGCLIP_INFONCE_STAGE (dma | reg), default registers
-    static const int env_stage = getenv("EEGCLIP_INFONCE_STAGE") ? (strcmp(getenv("EEGCLIP_INFONCE_STAGE"), "dma") == 0 ? 1 : 2) : 2;
+    // operand staging: bits 16..17 of `planes` (tuning / tests) 1 = LDS-DMA, 2 = registers; 0 = EEGCLIP_INFONCE_STAGE (dma | reg), default LDS-DMA:
+    // measured at N = 2048 (bench.py secondary, r3): logits block 18.3 us (DMA) vs 20.8 us (registers) in throughput mode, 37.5 vs 41.1 us in parity mode
+    static const int env_stage = getenv("EEGCLIP_INFONCE_STAGE") ? (strcmp(getenv("EEGCLIP_INFONCE_STAGE"), "reg") == 0 ? 2 : 1) : 1;
     const int stg = (planes >> 16) & 3;
     const bool reg = (stg ? stg : env_stage) == 2;
     planes &= 0xff;

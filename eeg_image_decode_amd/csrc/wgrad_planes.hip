@@ -1,0 +1,245 @@
+// Weight gradients as "long K, small output" GEMMs over bf16 planes:  dW[o][i] (+)= sum_t dY[t][o] X[t][i]   (t = the 16384 token rows of a batch).
+//
+// In the plan GEMM (csrc/gemm_x3.hip) both operands of a weight gradient are k-STRIDED (k = t runs down the rows of dY and X): every workgroup
+// transposes 4 k x 2 m register blocks and splits fp32 -> bf16 hi | lo while it stages -- ~1000 VALU instructions per wave and k-tile; the five
+// weight gradients of the transformer block cost 35 .. 73 us each (60 TF) although they are 2 .. 6 GFLOP (PMC, profiles/r2_pmc_step.json: MFMA
+// pipe 19 % busy).  Here the transposition and the split happen ONCE per operand in a bandwidth-bound pass (split_transpose_kernel: fp32 [t][c] ->
+// bf16 planes [c][t], t contiguous), and the GEMM is a pure planes kernel: 16-byte global loads -> ds_write_b128 -> ds_read_b128 fragments ->
+// v_mfma_f32_32x32x16_bf16, three products per multiply-add like every other split-bf16 contraction of the library.
+//
+//   wgrad_planes_kernel   workgroup = (128 x 64 output tile, K slice); 4 waves as 2 x 2, each 64 x 32 outputs = two 32x32 MFMA tiles; operand tiles
+//                         [128 | 64 rows][64 k] per plane, two LDS stages, the next k-tile's loads in flight under the MFMAs; 128-byte LDS rows with
+//                         the 16-byte chunk index XOR ((row >> 1) & 7) (conflict-free fragment reads, as csrc/infonce_fused.hip).  The bias
+//                         gradient (column sums of dY = row sums of the A planes) rides on the matrix cores: one extra accumulator against an
+//                         all-ones B fragment in the waves of the first output-tile column.  Partial tiles go to per-slice slabs.
+//   wgrad_reduce_kernel   out[m][n] += sum_s slab[s][m][n] (ordered: bit-reproducible), bias[m] += sum_s ...
+#include "eeg_common.h"
+
+namespace eeg {
+
+constexpr int WG_TM = 128, WG_TN = 64, WG_BK = 64;
+constexpr int WG_ROWB = 2 * WG_BK;                               // bytes per LDS row of a plane tile
+constexpr int WG_TILE_A = WG_TM * WG_ROWB, WG_TILE_B = WG_TN * WG_ROWB;
+constexpr int WG_STAGE = 2 * (WG_TILE_A + WG_TILE_B);            // A hi | A lo | B hi | B lo
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+typedef float wg_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ int wg_swz(int row) { return (row >> 1) & 7; }
+
+struct wgrad_args {
+    const unsigned short *a_hi, *a_lo, *b_hi, *b_lo;             // planes [rows][K], k contiguous; rows padded to the tile (zeros)
+    float* slab;                                                 // [slices][Mp][Np] partial tiles, then [slices][Mp] bias partials
+    int Mp, Np, K, slices, want_bias;
+};
+
+__global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int tiles_n = a.Np / WG_TN, tiles = (a.Mp / WG_TM) * tiles_n;
+    const int slice = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - slice * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int ktiles_all = a.K / WG_BK;
+    const int kt0 = (int)((long long)slice * ktiles_all / a.slices), kt1 = (int)((long long)(slice + 1) * ktiles_all / a.slices);
+    const bool bias = a.want_bias && tn == 0 && wn == 0;
+
+    // staging: chunk c = t + 256 i of the stage image [A hi (128 rows) | A lo | B hi (64 rows) | B lo], 8 chunks of 16 bytes per row
+    constexpr int CH_A = WG_TM * 8, CH_B = WG_TN * 8, CH = 2 * (CH_A + CH_B), CPT = CH / 256;      // 3072 chunks, 12 per thread
+    const unsigned short* gsrc[CPT];
+    int loff[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = t + 256 * i;
+        const unsigned short* base;
+        int row0, tile_off;
+        if (c < CH_A) { base = a.a_hi; row0 = tm * WG_TM; tile_off = 0; }
+        else if (c < 2 * CH_A) { c -= CH_A; base = a.a_lo; row0 = tm * WG_TM; tile_off = WG_TILE_A; }
+        else if (c < 2 * CH_A + CH_B) { c -= 2 * CH_A; base = a.b_hi; row0 = tn * WG_TN; tile_off = 2 * WG_TILE_A; }
+        else { c -= 2 * CH_A + CH_B; base = a.b_lo; row0 = tn * WG_TN; tile_off = 2 * WG_TILE_A + WG_TILE_B; }
+        const int row = c >> 3, pos = c & 7;
+        gsrc[i] = base + (long long)(row0 + row) * a.K + 8 * pos;
+        loff[i] = tile_off + row * WG_ROWB + ((pos ^ wg_swz(row)) << 4);
+    }
+    wg_u4 sreg[CPT];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) sreg[i] = *reinterpret_cast<const wg_u4*>(gsrc[i] + (long long)kt * WG_BK);
+    };
+    auto lstore = [&](int stg) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) *reinterpret_cast<wg_u4*>(lds + stg * WG_STAGE + loff[i]) = sreg[i];
+    };
+    // fragment offsets: A rows wm 64 + 32 i + r32, B rows wn 32 + r32; chunk 2 s + h of the row (k-step s of 16)
+    int foa[4][2], fob[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ra = wm * 64 + 32 * i + r32;
+            foa[s][i] = ra * WG_ROWB + (((2 * s + h) ^ wg_swz(ra)) << 4);
+        }
+        const int rb = wn * 32 + r32;
+        fob[s] = 2 * WG_TILE_A + rb * WG_ROWB + (((2 * s + h) ^ wg_swz(rb)) << 4);
+    }
+    f32x16 acc[2], bacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; bacc[i][e] = 0.f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;         // bf16 1.0
+
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) gload(kt + 1);                          // in flight under this k-tile's MFMAs
+        const unsigned char* st = lds + ((kt - kt0) & 1) * WG_STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(st + foa[s][i]);
+                al[i] = *reinterpret_cast<const bf16x8*>(st + WG_TILE_A + foa[s][i]);
+            }
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + fob[s]), bl = *reinterpret_cast<const bf16x8*>(st + WG_TILE_B + fob[s]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16_32x32x16(al[i], bh, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16_32x32x16(ah[i], bl, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16_32x32x16(ah[i], bh, acc[i]);        // D[m = wm 64 + 32 i + row(reg, h)][n = wn 32 + r32]
+            if (bias) {                                           // (wave-uniform) row sums of the A tile: every column of the tile holds them
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bacc[i] = mfma_bf16_32x32x16(al[i], ones, bacc[i]);
+                    bacc[i] = mfma_bf16_32x32x16(ah[i], ones, bacc[i]);
+                }
+            }
+        }
+        if (kt + 1 < kt1) lstore(((kt - kt0) & 1) ^ 1);           // the other stage: every wave finished reading it before the previous barrier
+        __syncthreads();
+    }
+    // partial tile -> this slice's slab (plain stores: the reduce kernel sums the slices in order)
+    float* out = a.slab + (long long)slice * a.Mp * a.Np;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = tm * WG_TM + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[(long long)m * a.Np + tn * WG_TN + wn * 32 + r32] = acc[i][e];
+        }
+    if (bias && r32 == 0) {
+        float* bo = a.slab + (long long)a.slices * a.Mp * a.Np + (long long)slice * a.Mp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bo[tm * WG_TM + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h] = bacc[i][e];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int slices, int Mp, int Np, int M, int N, float* __restrict__ out,
+                                                            long long ldo, float* __restrict__ bias_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)M * N;
+    if (i < total) {
+        const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < slices; ++k) s += slab[((long long)k * Mp + m) * Np + n];
+        out[(long long)m * ldo + n] += s;
+    } else if (bias_out && i < total + M) {
+        const int m = (int)(i - total);
+        const float* bs = slab + (long long)slices * Mp * Np;
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += bs[(long long)k * Mp + m];
+        bias_out[m] += s;
+    }
+}
+
+// fp32 [rows = k][cols = c] (row stride ld) -> bf16 planes [c][k] (row stride ldo elements, k contiguous); rows of the output beyond `cols` (up to
+// gridDim.y * 64) are written as zeros.  One workgroup per 64 k x 64 c tile, transposed through LDS ([64][65] floats).
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ src, long long ld, int rows, int cols, unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ lo, long long ldo) {
+    EEG_LDS_BASE(float, tile);
+    const int t = threadIdx.x;
+    const int k0 = (int)blockIdx.x * 64, c0 = (int)blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (t >> 4) + 16 * i, c = 4 * (t & 15);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + k < rows) {
+            const float* p = src + (long long)(k0 + k) * ld + c0 + c;
+            if (c0 + c + 3 < cols) {
+                const wg_f4u q = *reinterpret_cast<const wg_f4u*>(p);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = c0 + c + e < cols ? p[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[k * 65 + c + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = t + 256 * i, c = item & 63, kg = item >> 6;          // 8 consecutive k of one output row
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[(8 * kg + e) * 65 + c];
+        u32x2_t h0, l0, h1, l1;
+        x3_split4(v[0], v[1], v[2], v[3], h0, l0);
+        x3_split4(v[4], v[5], v[6], v[7], h1, l1);
+        const long long o = (long long)(c0 + c) * ldo + k0 + 8 * kg;
+        *reinterpret_cast<wg_u4*>(hi + o) = wg_u4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<wg_u4*>(lo + o) = wg_u4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+static inline int wg_pad(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int eegclip_split_transpose(const float* src, long long ld, int rows, int cols, int out_rows, void* hi, void* lo, long long ldo, void* stream) {
+    if (!src || !hi || !lo || rows < 1 || cols < 1 || out_rows < cols || (out_rows & 63) || (rows & 63) || ldo < rows || (ldo & 7)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src) & 3u) || ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15u)) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(split_transpose_kernel, dim3((unsigned)(rows / 64), (unsigned)(out_rows / 64)), dim3(256), 64 * 65 * sizeof(float), stream, src, ld, rows, cols,
+               static_cast<unsigned short*>(hi), static_cast<unsigned short*>(lo), ldo);
+    return (int)hipGetLastError();
+}
+
+static int wg_slices(int Mp, int Np, int K) {
+    const int tiles = (Mp / WG_TM) * (Np / WG_TN), kt = K / WG_BK;
+    int s = (512 + tiles - 1) / tiles;                           // ~2 workgroups per CU
+    if (s > kt / 4) s = kt / 4;                                  // at least 4 k-tiles per workgroup
+    return s < 1 ? 1 : s;
+}
+
+extern "C" long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < WG_BK) return 0;
+    const int Mp = wg_pad(M, WG_TM), Np = wg_pad(N, WG_TN);
+    return (long long)wg_slices(Mp, Np, K) * ((long long)Mp * Np + Mp);
+}
+
+// out (M x N, row stride ldo) += A^T B with A = planes [>= pad128(M)][K], B = planes [>= pad64(N)][K] (rows beyond M / N zero); bias_out[m] += sum_k A[m][k]
+extern "C" int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, int M, int N, int K, float* out, long long ldo,
+                                    float* bias_out, float* workspace, void* stream) {
+    if (!a_hi || !a_lo || !b_hi || !b_lo || !out || !workspace || M < 1 || N < 1 || K < WG_BK || (K % WG_BK) || ldo < N) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(b_hi) | reinterpret_cast<uintptr_t>(b_lo)) & 15u)
+        return EEGCLIP_EALIGN;
+    const int Mp = wg_pad(M, WG_TM), Np = wg_pad(N, WG_TN);
+    wgrad_args a{static_cast<const unsigned short*>(a_hi), static_cast<const unsigned short*>(a_lo), static_cast<const unsigned short*>(b_hi),
+                 static_cast<const unsigned short*>(b_lo), workspace, Mp, Np, K, wg_slices(Mp, Np, K), bias_out ? 1 : 0};
+    const int tiles = (Mp / WG_TM) * (Np / WG_TN);
+    EEG_LAUNCH(wgrad_planes_kernel, dim3((unsigned)(tiles * a.slices)), dim3(256), 2 * WG_STAGE, stream, a);
+    const long long total = (long long)M * N + (bias_out ? M : 0);
+    EEG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace, a.slices, Mp, Np, M, N, out, ldo, bias_out);
+    return (int)hipGetLastError();
+}

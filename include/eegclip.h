@@ -480,6 +480,18 @@ typedef struct {
 long long eegclip_token_block_bwd_workspace_floats(int B);
 int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream);
 
+/* ---- weight gradients over bf16 planes (csrc/wgrad_planes.hip): dW[o][i] (+)= sum_t dY[t][o] X[t][i] with t = the batch's token rows -- the
+ * weight-gradient GEMMs of the transformer block (models/subject_layers/Transformer_EncDec.py:48-49, SelfAttention_Family.py:199-213 backward).
+ * eegclip_split_transpose: fp32 src [rows = t][cols] (row stride ld) -> bf16 hi | lo planes [out_rows >= cols][rows] (row stride ldo elements, t
+ * contiguous; rows beyond `cols` zero; rows, out_rows multiples of 64) -- the transposition + split the plan GEMM does per workgroup, once per operand.
+ * eegclip_wgrad_planes: out (M x N, row stride ldo) += A B^T over K with A = planes [pad128(M)][K], B = planes [pad64(N)][K]; bias_out[m] += sum_k
+ * A[m][k] (the bias gradient: column sums of dY) when not NULL; `workspace` = eegclip_wgrad_planes_workspace_floats(M, N, K) floats (per-slice
+ * partial tiles, summed in a fixed order: bit-reproducible).  Split-bf16 products, fp32 accumulate (EEGCLIP_PREC_BF16X3 arithmetic). */
+int eegclip_split_transpose(const float* src, long long ld, int rows, int cols, int out_rows, void* hi, void* lo, long long ldo, void* stream);
+long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K);
+int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, int M, int N, int K, float* out, long long ldo,
+                         float* bias_out, float* workspace, void* stream);
+
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
  * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */
