@@ -795,21 +795,24 @@ class _Engine:
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
             # (three independent GEMMs of ~2 workgroups per CU each: alternating between the two side streams lets them share the GPU)
             s2 = 2 if os.environ.get("EEGCLIP_SIDE2", "0") == "1" else True        # (measured: no gain at B = 256, 1.105 vs 1.095 ms)
-            if os.environ.get("EEGCLIP_WGRAD_PLANES", "1") != "0":
-                # the block's weight gradients over bf16 planes (csrc/wgrad_planes.hip): both operands transposed + split ONCE by a bandwidth-bound
-                # pass, then a pure planes GEMM -- the plan GEMM transposes and splits the k-strided operands in every workgroup (35 .. 73 us each)
+            if os.environ.get("EEGCLIP_WGRAD_PLANES", "0") == "1":
+                # OPT-IN (measured slower end to end, r3): the block's weight gradients over bf16 planes (csrc/wgrad_planes.hip): both operands
+                # transposed + split ONCE by a bandwidth-bound pass, then a pure planes GEMM.  Stand-alone on the MI355X: the planes GEMM takes 19 us
+                # against 30 us of the plan GEMM (250 x 256 x 16384), but the two transposing splits in front of it cost 9.5 us each -- a win only once
+                # the producers write the transposed planes themselves
                 bf = torch.bfloat16
                 pad = lambda v, m: (v + m - 1) // m * m
 
                 def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
                     key = "wg:" + name
                     if key not in b:
-                        b[key] = (torch.empty(2, pad(Nout, 128), K, dtype=bf, device=self.device), torch.empty(2, pad(Nin, 64), K, dtype=bf, device=self.device),
+                        ldp = K + 64                               # plane row stride: one 128-byte line of skew (a power-of-two stride camps on a few channels)
+                        b[key] = (torch.empty(2, pad(Nout, 128), ldp, dtype=bf, device=self.device), torch.empty(2, pad(Nin, 64), ldp, dtype=bf, device=self.device),
                                   torch.empty(int(lib().eegclip_wgrad_planes_workspace_floats(Nout, Nin, K)), dtype=torch.float32, device=self.device))
                     at, bt, ws = b[key]
-                    pl.call("eegclip_split_transpose", dY, ldy, K, Nout, at.shape[1], _p(at[0]), _p(at[1]), K, side=side)
-                    pl.call("eegclip_split_transpose", X, ldx, K, Nin, bt.shape[1], _p(bt[0]), _p(bt[1]), K, side=side)
-                    pl.call("eegclip_wgrad_planes", _p(at[0]), _p(at[1]), _p(bt[0]), _p(bt[1]), Nout, Nin, K, _p(G[name]), Nin,
+                    pl.call("eegclip_split_transpose", dY, ldy, K, Nout, at.shape[1], _p(at[0]), _p(at[1]), at.shape[2], side=side)
+                    pl.call("eegclip_split_transpose", X, ldx, K, Nin, bt.shape[1], _p(bt[0]), _p(bt[1]), bt.shape[2], side=side)
+                    pl.call("eegclip_wgrad_planes", _p(at[0]), _p(at[1]), _p(bt[0]), _p(bt[1]), at.shape[2], Nout, Nin, K, _p(G[name]), Nin,
                             _p(G[bias]) if bias else None, _p(ws), side=side)
             wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
             wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias", side=s2)

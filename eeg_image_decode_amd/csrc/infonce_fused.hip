@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
         };
         gload(0);
         lstore(0);
-        __syncthreads();
+        raw_barrier();
         for (int kt = 0; kt < ktiles; ++kt) {
             if (kt + 1 < ktiles) gload(kt + 1);                    // in flight under this k-tile's MFMAs
             const unsigned char* st = lds + (kt & 1) * RSTAGE_B;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
                     }
             }
             if (kt + 1 < ktiles) lstore((kt + 1) & 1);             // the other stage: every wave finished reading it before the previous barrier
-            __syncthreads();
+            raw_barrier();
         }
     } else {
     #pragma unroll

@@ -30,6 +30,7 @@ struct wgrad_args {
     const unsigned short *a_hi, *a_lo, *b_hi, *b_lo;             // planes [rows][K], k contiguous; rows padded to the tile (zeros)
     float* slab;                                                 // [slices][Mp][Np] partial tiles, then [slices][Mp] bias partials
     int Mp, Np, K, slices, want_bias;
+    long long ld;                                                // elements between plane rows (>= K; NOT a multiple of 2048: see eegclip_wgrad_planes)
 };
 
 __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
@@ -37,7 +38,18 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
     const int tiles_n = a.Np / WG_TN, tiles = (a.Mp / WG_TM) * tiles_n;
-    const int slice = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - slice * tiles;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch; speed only).  All tiles of a K slice read the same 64-k columns of both
+    // operands, so a slice's tiles go to ONE XCD (slices is a multiple of 8: XCD x owns slices x, x + 8, ...) and every operand byte enters exactly
+    // one L2.  (tile-major order put one output tile per XCD: each L2 fetched its tile's rows over ALL of K -- 96 MB instead of 32 per GEMM.)
+    int slice, tile;
+    if ((a.slices & 7) == 0) {
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        slice = xcd + 8 * (j / tiles);
+        tile = j % tiles;
+    } else {
+        slice = (int)blockIdx.x / tiles;
+        tile = (int)blockIdx.x - slice * tiles;
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int ktiles_all = a.K / WG_BK;
     const int kt0 = (int)((long long)slice * ktiles_all / a.slices), kt1 = (int)((long long)(slice + 1) * ktiles_all / a.slices);
@@ -57,17 +69,45 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
         else if (c < 2 * CH_A + CH_B) { c -= 2 * CH_A; base = a.b_hi; row0 = tn * WG_TN; tile_off = 2 * WG_TILE_A; }
         else { c -= 2 * CH_A + CH_B; base = a.b_lo; row0 = tn * WG_TN; tile_off = 2 * WG_TILE_A + WG_TILE_B; }
         const int row = c >> 3, pos = c & 7;
-        gsrc[i] = base + (long long)(row0 + row) * a.K + 8 * pos;
+        gsrc[i] = base + (long long)(row0 + row) * a.ld + 8 * pos;
         loff[i] = tile_off + row * WG_ROWB + ((pos ^ wg_swz(row)) << 4);
     }
-    wg_u4 sreg[CPT];
-    auto gload = [&](int kt) {
+    // three k-tiles of operand loads in flight per thread (a register ring: tile j sits in ring[j % 3] until it is written to LDS stage j & 1):
+    // with ONE k-tile in flight the kernel was latency-bound -- 47 us for 250 x 256 x 16384, a memory round trip per k-tile and workgroup
+    // The loads are inline asm with hand-counted s_waitcnt (cdna_hip_programming.md 5.7 form (ii)): left to hipcc, every wait in this loop came out as
+    // vmcnt(11) .. vmcnt(0) -- the runtime `if (j + 3 < nk)` around a refill makes its counter bookkeeping give up at the merge, so each k-tile waited
+    // for the tiles requested a moment earlier (a full memory round trip per k-tile: 16 us for 250 x 256 x 16384 at any prefetch depth).
+    wg_u4 ring[3][CPT];
+    auto gload = [&](int kt, wg_u4 (&r)[CPT]) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) sreg[i] = *reinterpret_cast<const wg_u4*>(gsrc[i] + (long long)kt * WG_BK);
+        for (int i = 0; i < CPT; ++i) {
+            const unsigned short* p = gsrc[i] + (long long)kt * WG_BK;
+#if defined(EEG_EMU)
+            r[i] = *reinterpret_cast<const wg_u4*>(p);
+#else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(p) : "memory");
+#endif
+        }
     };
-    auto lstore = [&](int stg) {
+    // at most N of this wave's asm loads still in flight; names every register of the tile about to be consumed so that no use is scheduled above it
+    auto wait_tile = [&](int younger_tiles, wg_u4 (&r)[CPT]) {
+#if !defined(EEG_EMU)
+        static_assert(CPT == 12, "the wait statement lists 12 destination registers");
+#define WG_WAIT(N)                                                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                                           \
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),   \
+                   "+v"(r[11])                                                                                                                        \
+                 :                                                                                                                                    \
+                 : "memory")
+        if (younger_tiles >= 2) WG_WAIT(24);
+        else if (younger_tiles == 1) WG_WAIT(12);
+        else WG_WAIT(0);
+#undef WG_WAIT
+#endif
+    };
+    auto lstore = [&](int stg, const wg_u4 (&r)[CPT]) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) *reinterpret_cast<wg_u4*>(lds + stg * WG_STAGE + loff[i]) = sreg[i];
+        for (int i = 0; i < CPT; ++i) *reinterpret_cast<wg_u4*>(lds + stg * WG_STAGE + loff[i]) = r[i];
     };
     // fragment offsets: A rows wm 64 + 32 i + r32, B rows wn 32 + r32; chunk 2 s + h of the row (k-step s of 16)
     int foa[4][2], fob[4];
@@ -90,14 +130,17 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;         // bf16 1.0
 
-    if (kt0 < kt1) {
-        gload(kt0);
-        lstore(0);
+    const int nk = kt1 - kt0;
+    if (nk > 0) gload(kt0, ring[0]);
+    if (nk > 1) gload(kt0 + 1, ring[1]);
+    if (nk > 2) gload(kt0 + 2, ring[2]);
+    if (nk > 0) {
+        wait_tile(nk > 2 ? 2 : nk - 1, ring[0]);
+        lstore(0, ring[0]);
     }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) gload(kt + 1);                          // in flight under this k-tile's MFMAs
-        const unsigned char* st = lds + ((kt - kt0) & 1) * WG_STAGE;
+    raw_barrier();
+    auto compute = [&](int j) {
+        const unsigned char* st = lds + (j & 1) * WG_STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 ah[2], al[2];
@@ -121,9 +164,26 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
                 }
             }
         }
-        if (kt + 1 < kt1) lstore(((kt - kt0) & 1) ^ 1);           // the other stage: every wave finished reading it before the previous barrier
-        __syncthreads();
+    };
+    // step U of a group of three: tile j = j0 + U is in LDS stage j & 1, tile j + 1 in ring[(U + 1) % 3], tile j + 2 in flight in ring[(U + 2) % 3];
+    // ring[U] is free (stored before tile j was computed): refill it with tile j + 3 FIRST, so that load runs under the MFMAs
+#define WG_STEP(U)                                                              \
+    if (j0 + U < nk) {                                                          \
+        const int j = j0 + U;                                                   \
+        if (j + 3 < nk) gload(kt0 + j + 3, ring[U]);                            \
+        compute(j);                                                             \
+        if (j + 1 < nk) {                                                       \
+            wait_tile((j + 3 < nk) + (j + 2 < nk), ring[(U + 1) % 3]);          \
+            lstore((j + 1) & 1, ring[(U + 1) % 3]);                             \
+        }                                                                       \
+        raw_barrier();   /* NOT __syncthreads(): that drains vmcnt(0), i.e. waits for the two k-tiles just requested */ \
     }
+    for (int j0 = 0; j0 < nk; j0 += 3) {
+        WG_STEP(0)
+        WG_STEP(1)
+        WG_STEP(2)
+    }
+#undef WG_STEP
     // partial tile -> this slice's slab (plain stores: the reduce kernel sums the slices in order)
     float* out = a.slab + (long long)slice * a.Mp * a.Np;
 #pragma unroll
@@ -142,20 +202,32 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
     }
 }
 
+// one thread per output element, 16 slices of loads in flight (consecutive threads = consecutive columns of a slab row: coalesced).  (A float4 per
+// thread left 63 workgroups for a 250 x 256 output: 9 us of latency on a quarter of the chip; so did walking the slices 8 at a time.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int slices, int Mp, int Np, int M, int N, float* __restrict__ out,
                                                             long long ldo, float* __restrict__ bias_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)M * N;
+    const long long stride = (long long)Mp * Np;
     if (i < total) {
         const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+        const float* p = slab + (long long)m * Np + n;
         float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < slices; ++k) s += slab[((long long)k * Mp + m) * Np + n];
+        int k = 0;
+        for (; k + 16 <= slices; k += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(long long)(k + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; k < slices; ++k) s += p[(long long)k * stride];
         out[(long long)m * ldo + n] += s;
     } else if (bias_out && i < total + M) {
         const int m = (int)(i - total);
-        const float* bs = slab + (long long)slices * Mp * Np;
+        const float* bs = slab + (long long)slices * stride;
         float s = 0.f;
+#pragma unroll 16
         for (int k = 0; k < slices; ++k) s += bs[(long long)k * Mp + m];
         bias_out[m] += s;
     }
@@ -217,8 +289,10 @@ extern "C" int eegclip_split_transpose(const float* src, long long ld, int rows,
 
 static int wg_slices(int Mp, int Np, int K) {
     const int tiles = (Mp / WG_TM) * (Np / WG_TN), kt = K / WG_BK;
-    int s = (512 + tiles - 1) / tiles;                           // ~2 workgroups per CU
+    int s = (256 + tiles - 1) / tiles;                           // ~one workgroup (96 KB of LDS) per CU
     if (s > kt / 4) s = kt / 4;                                  // at least 4 k-tiles per workgroup
+    if (s >= 8) s = (s + 4) / 8 * 8;                             // a multiple of 8: the XCD-aware order of the kernel
+    if (s > kt) s = kt;
     return s < 1 ? 1 : s;
 }
 
@@ -228,15 +302,18 @@ extern "C" long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K) 
     return (long long)wg_slices(Mp, Np, K) * ((long long)Mp * Np + Mp);
 }
 
-// out (M x N, row stride ldo) += A^T B with A = planes [>= pad128(M)][K], B = planes [>= pad64(N)][K] (rows beyond M / N zero); bias_out[m] += sum_k A[m][k]
-extern "C" int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, int M, int N, int K, float* out, long long ldo,
-                                    float* bias_out, float* workspace, void* stream) {
-    if (!a_hi || !a_lo || !b_hi || !b_lo || !out || !workspace || M < 1 || N < 1 || K < WG_BK || (K % WG_BK) || ldo < N) return EEGCLIP_EINVAL;
+// out (M x N, row stride ldo) += A^T B with A = planes [>= pad128(M)][K], B = planes [>= pad64(N)][K] (rows beyond M / N zero); bias_out[m] += sum_k A[m][k].
+// ld = elements between plane rows.  K * 2 bytes is a power of two for the batch sizes of the path (16384 tokens -> 32 KB): with ld == K every row's
+// k-tile sits at the same offset modulo the L2 / HBM channel interleave and a workgroup's 192 row segments hammer a few channels (measured: 16 us
+// for the 250 x 256 x 16384 kernel); ld = K + 64 (one 128-byte line of skew per row) spreads them.
+extern "C" int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, long long ld, int M, int N, int K, float* out,
+                                    long long ldo, float* bias_out, float* workspace, void* stream) {
+    if (!a_hi || !a_lo || !b_hi || !b_lo || !out || !workspace || M < 1 || N < 1 || K < WG_BK || (K % WG_BK) || ldo < N || ld < K || (ld & 7)) return EEGCLIP_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(b_hi) | reinterpret_cast<uintptr_t>(b_lo)) & 15u)
         return EEGCLIP_EALIGN;
     const int Mp = wg_pad(M, WG_TM), Np = wg_pad(N, WG_TN);
     wgrad_args a{static_cast<const unsigned short*>(a_hi), static_cast<const unsigned short*>(a_lo), static_cast<const unsigned short*>(b_hi),
-                 static_cast<const unsigned short*>(b_lo), workspace, Mp, Np, K, wg_slices(Mp, Np, K), bias_out ? 1 : 0};
+                 static_cast<const unsigned short*>(b_lo), workspace, Mp, Np, K, wg_slices(Mp, Np, K), bias_out ? 1 : 0, ld};
     const int tiles = (Mp / WG_TM) * (Np / WG_TN);
     EEG_LAUNCH(wgrad_planes_kernel, dim3((unsigned)(tiles * a.slices)), dim3(256), 2 * WG_STAGE, stream, a);
     const long long total = (long long)M * N + (bias_out ? M : 0);

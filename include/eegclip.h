@@ -485,12 +485,13 @@ int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, voi
  * eegclip_split_transpose: fp32 src [rows = t][cols] (row stride ld) -> bf16 hi | lo planes [out_rows >= cols][rows] (row stride ldo elements, t
  * contiguous; rows beyond `cols` zero; rows, out_rows multiples of 64) -- the transposition + split the plan GEMM does per workgroup, once per operand.
  * eegclip_wgrad_planes: out (M x N, row stride ldo) += A B^T over K with A = planes [pad128(M)][K], B = planes [pad64(N)][K]; bias_out[m] += sum_k
- * A[m][k] (the bias gradient: column sums of dY) when not NULL; `workspace` = eegclip_wgrad_planes_workspace_floats(M, N, K) floats (per-slice
+ * A[m][k] (the bias gradient: column sums of dY) when not NULL; ld = elements between plane rows (use K + 64, not K: a power-of-two row
+ * stride lands every row on the same memory channels); `workspace` = eegclip_wgrad_planes_workspace_floats(M, N, K) floats (per-slice
  * partial tiles, summed in a fixed order: bit-reproducible).  Split-bf16 products, fp32 accumulate (EEGCLIP_PREC_BF16X3 arithmetic). */
 int eegclip_split_transpose(const float* src, long long ld, int rows, int cols, int out_rows, void* hi, void* lo, long long ldo, void* stream);
 long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K);
-int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, int M, int N, int K, float* out, long long ldo,
-                         float* bias_out, float* workspace, void* stream);
+int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, long long ld, int M, int N, int K, float* out,
+                         long long ldo, float* bias_out, float* workspace, void* stream);
 
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what

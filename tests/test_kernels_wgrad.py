@@ -7,11 +7,11 @@ from backends import be  # noqa: F401
 from test_kernels_gemm_x3 import split
 
 
-def planes_of(be, x, out_rows):
+def planes_of(be, x, out_rows, pad=0):
     rows, cols = x.shape
     X = be.dev(x)
-    hi, lo = be.zeros((out_rows, rows), np.uint16), be.zeros((out_rows, rows), np.uint16)
-    assert be.lib.eegclip_split_transpose(be.ptr(X), x.strides[0] // 4, rows, cols, out_rows, be.ptr(hi), be.ptr(lo), rows, be.stream) == 0
+    hi, lo = be.zeros((out_rows, rows + pad), np.uint16), be.zeros((out_rows, rows + pad), np.uint16)
+    assert be.lib.eegclip_split_transpose(be.ptr(X), x.strides[0] // 4, rows, cols, out_rows, be.ptr(hi), be.ptr(lo), rows + pad, be.stream) == 0
     return X, hi, lo
 
 
@@ -26,7 +26,7 @@ def test_split_transpose(be, rows, cols):
     xs = np.ascontiguousarray(x)
     out_rows = (cols + 63) // 64 * 64
     _, hi, lo = planes_of(be, xs, out_rows)
-    h, l = bf16_to_f64(be.host(hi)), bf16_to_f64(be.host(lo))
+    h, l = bf16_to_f64(be.host(hi))[:, :rows], bf16_to_f64(be.host(lo))[:, :rows]
     xh, xl = split(xs)
     np.testing.assert_array_equal(h[:cols], xh.T)
     np.testing.assert_array_equal(l[:cols], xl.T)
@@ -39,13 +39,13 @@ def test_wgrad_planes_matches_the_split_products(be, M, N, K, bias):
     dy = (rng.standard_normal((K, M)) * rng.uniform(0.1, 2.0, M)).astype(np.float32)
     x = rng.standard_normal((K, N)).astype(np.float32)
     Mp, Np = (M + 127) // 128 * 128, (N + 63) // 64 * 64
-    _, ah, al = planes_of(be, dy, Mp)
-    _, bh, bl = planes_of(be, x, Np)
+    _, ah, al = planes_of(be, dy, Mp, 64)                                              # plane rows K + 64 apart, as the plans allocate them
+    _, bh, bl = planes_of(be, x, Np, 64)
     c0 = rng.standard_normal((M, N + 2)).astype(np.float32)                           # accumulated INTO, row stride N + 2
     b0 = rng.standard_normal(M).astype(np.float32)
     C, Bv = be.dev(c0), be.dev(b0)
     ws = be.zeros(int(be.lib.eegclip_wgrad_planes_workspace_floats(M, N, K)))
-    assert be.lib.eegclip_wgrad_planes(be.ptr(ah), be.ptr(al), be.ptr(bh), be.ptr(bl), M, N, K, be.ptr(C), N + 2, be.ptr(Bv) if bias else None, be.ptr(ws),
+    assert be.lib.eegclip_wgrad_planes(be.ptr(ah), be.ptr(al), be.ptr(bh), be.ptr(bl), K + 64, M, N, K, be.ptr(C), N + 2, be.ptr(Bv) if bias else None, be.ptr(ws),
                                        be.stream) == 0
     dh, dl = split(dy)
     xh, xl = split(x)
