@@ -26,6 +26,7 @@
 // gemm_epilogue.h): the backward regenerates them, tests regenerate them in numpy.
 #include "eeg_common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace eeg {
@@ -239,7 +240,15 @@ struct tb_fwd_args {
     unsigned long long seed;
     unsigned site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
     unsigned dbg;                                                // diagnosis (EEGCLIP_TB_DEBUG): bit 0 = leave out the activation stores (timing ablation only)
+    unsigned long long* tstamp;                                  // diagnosis (bit 1): [B][16] s_memtime stamps of wave 0 at the phase boundaries
 };
+
+// phase stamp of the diagnosis build path: the shader clock as wave 0 passes phase boundary k
+__device__ __forceinline__ void tb_stamp(const tb_fwd_args& a, int b, int t, int k) {
+#if !defined(EEG_EMU)
+    if (a.tstamp && t == 0) a.tstamp[b * 16 + k] = __builtin_amdgcn_s_memtime();
+#endif
+}
 
 // one QKV tile of this wave (+ bias) -> global qkv (natural (row, 744) layout) ; values stay in `v` (biased)
 template <bool TRANS>
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     const int b = blockIdx.x;
     const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
 
+    tb_stamp(a, b, t, 0);
     // ---- S0: the EEG sample (63 x 250 fp32) -> A planes, token row 1 + channel; row 0 and k >= 250 are zero
     {
         const float* xb = a.x + (long long)b * (TB_NCH * TB_T);
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
+    tb_stamp(a, b, t, 1);
     // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
     {
         f32x4 acc[4][2];
@@ -565,6 +576,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
+    tb_stamp(a, b, t, 2);
     // ---- S2: embedding dropout over the flat (64 x 250) sample (one Philox block = 4 consecutive flat elements); h -> HBM and -> A planes
     {
         float* hb = a.h + (long long)b * (TB_L * TB_D);
@@ -591,6 +603,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
+    tb_stamp(a, b, t, 3);
     // ---- S3: q | k | v (SelfAttention_Family.py:199-207) and attention, two heads at a time: 24 tiles of the pair's q | k | v -> their planes
     //          behind the (still live) h planes, then waves 0-3 run one head and waves 4-7 the other
     f32x4 ctxr[2][4];
@@ -625,6 +638,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
+    tb_stamp(a, b, t, 4);
     // ---- S4: output projection + bias -> XF      (SelfAttention_Family.py:213)
     {
         f32x4 acc[4][2];
@@ -638,11 +652,13 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
         });
     }
     __syncthreads();                                                 // (the one barrier that also waits for global stores: S5 re-reads h)
+    tb_stamp(a, b, t, 5);
     // ---- S5: r1 = h + dropout(attention output), n1 = LayerNorm1(r1); n1 stays in XF (FFN residual) and goes to the A planes
     tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, a.n1, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
                              nullptr, XF, AP);
     raw_barrier();
 
+    tb_stamp(a, b, t, 6);
     // ---- S6: FFN 1 + bias -> f1 (pre-activation, kept for the backward), g1 = dropout(gelu(f1))      (Transformer_EncDec.py:48)
     {
         f32x4 acc[4][2];
@@ -671,6 +687,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
+    tb_stamp(a, b, t, 7);
     // ---- S7: FFN 2 + bias; the result replaces the (dead) g1 planes as an fp32 image      (Transformer_EncDec.py:49)
     {
         f32x4 acc[4][2];
@@ -685,9 +702,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
         });
     }
     raw_barrier();
+    tb_stamp(a, b, t, 8);
     // ---- S8: r2 = n1 + dropout(FFN output), n2 = LayerNorm2(r2), n3 = final LayerNorm(n2)      (Transformer_EncDec.py:51,77-78)
     tb_ln_rows<TRAIN, true>(a, b, w, lane, AP, XF, nullptr, a.site_ffn_out, a.r2, a.ln2_g, a.ln2_b, a.n2, a.mu2, a.rs2, a.ln3_g, a.ln3_b, a.n3, a.mu3, a.rs3,
                             nullptr, nullptr);
+    tb_stamp(a, b, t, 9);
 }
 
 
@@ -1040,11 +1059,33 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
     tb_fwd_args a{d->x, static_cast<const unsigned short*>(d->packed), d->bv, d->pe, d->tokens, d->ids, d->bqkv, d->bo, d->ln1_g, d->ln1_b, d->b1, d->b2,
                   d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->ctx, d->r1, d->n1, d->mu1, d->rs1, d->f1, d->g1, d->r2, d->n2, d->mu2, d->rs2,
                   d->n3, d->mu3, d->rs3, d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn, d->site_attn_out, d->site_ffn_act,
-                  d->site_ffn_out, 0u};
+                  d->site_ffn_out, 0u, nullptr};
     static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
     a.dbg = dbg;
+    a.tstamp = nullptr;
+#if !defined(EEG_EMU)
+    static unsigned long long* stamps = nullptr;                 // DIAGNOSIS ONLY (EEGCLIP_TB_DEBUG & 2): the one allocation and sync of the library
+    static int calls = 0;
+    if ((dbg & 2u) && d->B <= 4096) {
+        if (!stamps && hipMalloc(&stamps, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) stamps = nullptr;
+        a.tstamp = stamps;
+    }
+#endif
     if (d->drop_p > 0.f) EEG_LAUNCH(token_block_fwd_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
     else EEG_LAUNCH(token_block_fwd_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
+#if !defined(EEG_EMU)
+    if (a.tstamp && ++calls % 20 == 0) {                         // phase lengths in shader clocks, mean over the workgroups, every 20th launch
+        hipStreamSynchronize((hipStream_t)stream);
+        static unsigned long long host[4096 * 16];
+        hipMemcpy(host, stamps, (size_t)d->B * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ph[9] = {0};
+        for (int b = 0; b < d->B; ++b)
+            for (int k = 0; k < 9; ++k) ph[k] += (double)(host[b * 16 + k + 1] - host[b * 16 + k]);
+        fprintf(stderr, "token_block_fwd phases (s_memtime ticks, mean of %d workgroups): x->planes %.0f | embed GEMM %.0f | dropout+h %.0f | qkv+attention %.0f | out-proj %.0f | "
+                        "LN1 %.0f | FFN1 %.0f | FFN2 %.0f | LN2+LN3 %.0f\n", d->B, ph[0] / d->B, ph[1] / d->B, ph[2] / d->B, ph[3] / d->B, ph[4] / d->B, ph[5] / d->B,
+                ph[6] / d->B, ph[7] / d->B, ph[8] / d->B);
+    }
+#endif
     return (int)hipGetLastError();
 }
 
