@@ -443,7 +443,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     B = args.batch
     model, opt, pool, classes = build(world, rank, B)
-    loss_acc = torch.zeros((), device="cuda")
+    loss_acc = []           # per-step loss scalars (the product loop's form, retrieval.train_model): summed after the timed region
     correct = torch.zeros(1, dtype=torch.int32, device="cuda")
 
     def step(i):
@@ -521,7 +521,7 @@ def main():
         dt = float(tmax)
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
-    final_loss = float(loss_acc) / (i_ramp + args.warmup + args.steps + 3)
+    final_loss = float(retrieval.running_loss(loss_acc)) / max(1, len(loss_acc))
 
     roof = None
     if args.breakdown:

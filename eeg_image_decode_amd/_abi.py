@@ -115,6 +115,7 @@ PROTOTYPES = {
     "eegclip_stage_eeg": [_P, _P, _L, _I, _I, _I, _P, _I, _I, _P],
     "eegclip_gather_rows": [_P, _L, _P, _L, _P, _I, _I, _I, _P],
     "eegclip_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
+    "eegclip_adamw_step_zero_grad": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P, _P],
     "eegclip_clip_scale": [_P, _F, _P, _P],
     "eegclip_attention_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],

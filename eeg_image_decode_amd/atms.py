@@ -376,6 +376,7 @@ class _Engine:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)     # makes autograd call _AtmsFn.backward
+        self._clear_for = self._attached = None          # see attach_grads / grads_cleared
         self.P, self.G, self.params = {}, {}, {}
         for k in order:
             p = sd_params[k]
@@ -505,11 +506,13 @@ class _Engine:
         # everything a plan must clear before use lives in two arenas (forward / backward): ONE memset each instead of five
         nsum = 2 * 2 * C_TS                                        # two BatchNorm sum rows of 2C doubles per direction
         ny2 = (B * C_TS * W_TS + 1) // 2                          # y2 (B,40,36) f32: the K-split spatial conv accumulates into it
-        zf = torch.zeros(nsum + B * P_DIM + ny2, dtype=torch.float64, device=dev)        # fwd: sums[0..1] | hacc (2,B,P_DIM) f32 | y2
-        zb = torch.zeros(nsum + (B * P_DIM + B * F_TS + 1) // 2, dtype=torch.float64, device=dev)   # bwd: sums[2..3] | dgu | dfeat
+        nzf, nzb = nsum + B * P_DIM + ny2, nsum + (B * P_DIM + B * F_TS + 1) // 2
+        # the two arenas are one allocation: a TRAINING forward clears both with one memset (its backward follows), see backward()
+        zfb = torch.zeros(nzf + nzb, dtype=torch.float64, device=dev)
+        zf, zb = zfb[:nzf], zfb[nzf:]            # fwd: sums[0..1] | hacc (2,B,P_DIM) f32 | y2         bwd: sums[2..3] | dgu | dfeat
         sf, sb = zf[:nsum].view(2, 2 * C_TS), zb[:nsum].view(2, 2 * C_TS)
         zbf = zb[nsum:].view(torch.float32)
-        b.update(zf=zf, zb=zb, sums=[sf[0], sf[1], sb[0], sb[1]], hacc=zf[nsum:nsum + B * P_DIM].view(torch.float32).view(2, B, P_DIM),
+        b.update(zf=zf, zb=zb, zfb=zfb, zb_clean=True, sums=[sf[0], sf[1], sb[0], sb[1]], hacc=zf[nsum:nsum + B * P_DIM].view(torch.float32).view(2, B, P_DIM),
                  y2=zf[nsum + B * P_DIM:].view(torch.float32)[:B * C_TS * W_TS].view(B, C_TS, W_TS),
                  dgu=zbf[:B * P_DIM].view(B, P_DIM), dfeat=zbf[B * P_DIM:B * P_DIM + B * F_TS].view(B, F_TS))
         return b
@@ -610,7 +613,8 @@ class _Engine:
                     _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
-        pl.memset(b["zf"])
+        pl.memset(b["zfb"] if train else b["zf"])
+        pl.clears_zb = train
         if "tsf_ws" not in b:
             b["tsf_ws"] = torch.empty(int(lib().eegclip_tsconv_fwd_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
         pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
@@ -687,7 +691,7 @@ class _Engine:
         if "lnf_ws" not in b:
             b["lnf_ws"] = torch.empty(int(lib().eegclip_layernorm_bwd_full_workspace_floats(R, D_MODEL)), dtype=torch.float32, device=self.device)
         lnf_ws = _p(b["lnf_ws"])
-        pl.memset(b["zb"])                        # BatchNorm backward sums + the split-K accumulators dgu / dfeat
+        # (the BatchNorm backward sums and the split-K accumulators dgu / dfeat -- arena zb -- were cleared by the training forward's memset)
         # head LayerNorm
         pl.dout_op = len(pl.ops)
         # s = u + dropout(W4 gelu(u) + b4): the LayerNorm backward writes ds and dv = ds * mask / (1 - p) in one pass
@@ -973,6 +977,8 @@ class _Engine:
         out = torch.empty(B, P_DIM, dtype=torch.float32, device=self.device)
         pl.set_arg(pl.out_op, 8, out.data_ptr())
         pl.run(torch.cuda.current_stream().cuda_stream, seed)
+        if getattr(pl, "clears_zb", False):
+            b["zb_clean"] = True
         self.last_key = key
         self.version[B] = self.version.get(B, 0) + 1
         return out
@@ -986,19 +992,33 @@ class _Engine:
             live = live + [k for s in (range(self.n_subj) if everyone else sorted(subjects)) for k in self.ve_keys[s]]
         mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
         if all(mine(k) for k in live):
+            self._clear_for = None
             return False                                   # accumulating onto existing gradients
         foreign = {k: self.params[k].grad for k in live if self.params[k].grad is not None and not mine(k)}
         if all(self.params[k].grad is None or k in foreign for k in live):
-            self.gflat.zero_()                             # the common case after optimizer.zero_grad(): one memset
+            if self._clear_for != tuple(live):             # (an optimizer step that cleared exactly these gradients behind its reads: nothing to do)
+                self.gflat.zero_()                         # the common case after optimizer.zero_grad(): one memset
         else:
             for k in live:
                 if not mine(k):
                     self.G[k].zero_()
+        self._clear_for = None
         for k, g in foreign.items():                       # e.g. logit_scale.grad written by the loss before this backward ran
             self.G[k].copy_(g)
+        import weakref
+        me = weakref.ref(self)
         for k in live:
             self.params[k].grad = self.G[k]
+            self.params[k]._eegclip_grad_owner = me
+        self._attached = tuple(live)
         return True
+
+    def grads_cleared(self, grad_ptrs):
+        """an optimizer step (optim.AdamW.step(zero_grad=True)) has zeroed the gradients at these addresses behind its reads: if they are exactly
+        the views attached by the last backward, the next attach_grads() need not clear the flat buffer again"""
+        att = getattr(self, "_attached", None)
+        if att and {self.G[k].data_ptr() for k in att} <= set(grad_ptrs):
+            self._clear_for = att
 
     def backward(self, key, x, dout, want_dx):
         B, train, shared, probs, W = key
@@ -1018,5 +1038,8 @@ class _Engine:
             self._joint_layout(pl, b, B, None, x.data_ptr(), True)
         else:
             pl.x_gemm.B = x.data_ptr()          # the value-embedding weight-gradient GEMM reads the EEG batch
+        if not b["zb_clean"]:                   # an eval-mode forward, or a second backward through one forward: clear the arena here
+            b["zb"].zero_()
+        b["zb_clean"] = False
         pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
         return b["dx"].clone() if want_dx else None

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void colsum_blocks_kernel(const float* __restr
 
 // torch.optim.AdamW / Adam single-step math on a flat fp32 segment (decoupled weight decay, bias correction).
 // bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t) are computed on the host in double.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO>       // ZERO: the gradient is cleared behind the read (optimizer.step() + zero_grad() in one pass over g)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                      float wd, float bc1, float bc2s, float grad_scale,
                                                      const float* __restrict__ grad_scale_dev) {
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (grad_scale_dev) grad_scale *= *grad_scale_dev;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
+        if (ZERO) g[i] = 0.f;
         float pi = p[i];
         pi *= (1.f - lr * wd);
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -409,7 +411,18 @@ extern "C" int eegclip_adamw_step(float* p, const float* g, float* m, float* v, 
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    EEG_LAUNCH(adamw_kernel, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+    EEG_LAUNCH(adamw_kernel<false>, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, p, const_cast<float*>(g), m, v, n, lr, beta1, beta2, eps,
+               weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, grad_scale_dev);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_adamw_step_zero_grad(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                            float weight_decay, long long step, float grad_scale, const float* grad_scale_dev, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return EEGCLIP_EINVAL;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    EEG_LAUNCH(adamw_kernel<true>, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                (float)bc1, (float)sqrt(bc2), grad_scale, grad_scale_dev);
     return (int)hipGetLastError();
 }

@@ -250,14 +250,14 @@ __device__ __forceinline__ void tb_stamp(const tb_fwd_args& a, int b, int t, int
 #endif
 }
 
-// one QKV tile of this wave (+ bias) -> global qkv (natural (row, 744) layout) ; values stay in `v` (biased)
+// one QKV tile of this wave (+ bias, handed in: TRANS = the 4 consecutive dims of the lane, else its one dim in all four) -> global qkv (natural
+// (row, 744) layout); values stay in `v` (biased)
 template <bool TRANS>
-__device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int head, int which, int tt, int lane, f32x4 (&v)[4]) {
+__device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int head, int which, int tt, int lane, f32x4 bias, f32x4 (&v)[4]) {
     const int fr = lane & 15, g = lane >> 4;
     const int cbase = which * TB_HE + head * TB_E;
     if (TRANS) {
         const int d0 = 16 * tt + 4 * g, valid = TB_E - d0;              // >= 4, or 2 at d0 = 60
-        const f32x4 bias = tb_ld4(a.bqkv + cbase + d0, valid);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int m = 16 * mt + fr;
@@ -267,12 +267,11 @@ __device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int
         }
     } else {
         const int d = 16 * tt + fr;
-        const float bias = d < TB_E ? a.bqkv[cbase + d] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[mt][i] = d < TB_E ? v[mt][i] + bias : 0.f;
+                v[mt][i] = d < TB_E ? v[mt][i] + bias[0] : 0.f;
                 if (d < TB_E && !(a.dbg & 1u)) a.qkv[((long long)b * TB_L + 16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d] = v[mt][i];
             }
     }
@@ -298,12 +297,27 @@ struct tb_qkv_variant {
 template <int V>
 __device__ __forceinline__ void tb_qkv_pass(const tb_fwd_args& a, const unsigned char* AP, int b, int head, int lane, f32x4 (&acc)[4][3]) {
     tb_gemm<3, tb_qkv_variant<V>::mask>(AP, a.packed + TB_OFF_QKV + (long long)(head * 12 + 3 * V) * TB_KS * TB_TILE, lane, acc);
+    // the three tiles' biases first (loads), then every store of the pass: a bias load behind the previous tile's stores would wait for them
+    const int fr = lane & 15, g = lane >> 4;
+    f32x4 bias[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = 3 * V + jj, which = j >> 2, tt = j & 3, cbase = which * TB_HE + head * TB_E;
+        if ((tb_qkv_variant<V>::mask >> jj) & 1u) {
+            const int d0 = 16 * tt + 4 * g;
+            bias[jj] = tb_ld4(a.bqkv + cbase + d0, TB_E - d0 >= 4 ? 4 : 2);
+        } else {
+            const int d = 16 * tt + fr;
+            const float bv = d < TB_E ? a.bqkv[cbase + d] : 0.f;
+            bias[jj] = f32x4{bv, bv, bv, bv};
+        }
+    }
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
         const int j = 3 * V + jj, which = j >> 2, tt = j & 3;
         f32x4 v[4] = {acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
-        if ((tb_qkv_variant<V>::mask >> jj) & 1u) tb_qkv_tile_out<true>(a, b, head, which, tt, lane, v);
-        else tb_qkv_tile_out<false>(a, b, head, which, tt, lane, v);
+        if ((tb_qkv_variant<V>::mask >> jj) & 1u) tb_qkv_tile_out<true>(a, b, head, which, tt, lane, bias[jj], v);
+        else tb_qkv_tile_out<false>(a, b, head, which, tt, lane, bias[jj], v);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt][jj] = v[mt];
     }
@@ -406,6 +420,23 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                                            unsigned char* y_lds /* XF layout or null */, unsigned char* ap /* planes of y or null */) {
     const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
     const float inv = 1.0f / (float)TB_D;
+    // EVERY global load of the pass is issued here, before the first store: vmcnt retires in order and counts stores, so a load behind a store
+    // waits for that store's HBM round trip -- with the affine parameters fetched inside the row loop each of the 8 rows paid one (~2 us: the two
+    // row passes were 19 + 20 us of a 147 us launch; per-phase s_memtime stamps, EEGCLIP_TB_DEBUG=2)
+    tb_f2 pg1[2][2], pb1[2][2], pg2[2][2], pb2[2][2];            // [row parity][pair]
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int cp = 4 * lane - 2 * par + 2 * p;
+            const bool okc = cp >= 0 && cp < TB_D;
+            pg1[par][p] = okc ? *reinterpret_cast<const tb_f2*>(g1 + cp) : tb_f2{0.f, 0.f};
+            pb1[par][p] = okc ? *reinterpret_cast<const tb_f2*>(be1 + cp) : tb_f2{0.f, 0.f};
+            if (DOUBLE) {
+                pg2[par][p] = okc ? *reinterpret_cast<const tb_f2*>(g2 + cp) : tb_f2{0.f, 0.f};
+                pb2[par][p] = okc ? *reinterpret_cast<const tb_f2*>(be2 + cp) : tb_f2{0.f, 0.f};
+            }
+        }
     tb_f2 rg[8][2];
     if (resid_g) {
 #pragma unroll
@@ -458,11 +489,7 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int cp = c0 + 2 * p;
-            tb_f2 gg = tb_f2{0.f, 0.f}, bb = tb_f2{0.f, 0.f};
-            if (ok[p]) {
-                gg = *reinterpret_cast<const tb_f2*>(g1 + cp);
-                bb = *reinterpret_cast<const tb_f2*>(be1 + cp);
-            }
+            const tb_f2 gg = pg1[rr & 1][p], bb = pb1[rr & 1][p];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 y[2 * p + e] = ok[p] ? (v[2 * p + e] - mean) * rstd * gg[e] + bb[e] : 0.f;
@@ -492,7 +519,7 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
                 if (ok[p]) {
-                    const tb_f2 gg = *reinterpret_cast<const tb_f2*>(g2 + cp), bb = *reinterpret_cast<const tb_f2*>(be2 + cp);
+                    const tb_f2 gg = pg2[rr & 1][p], bb = pb2[rr & 1][p];
                     *reinterpret_cast<tb_f2*>(y2_out + rbase + cp) =
                         tb_f2{(y[2 * p] - mean2) * rstd2 * gg[0] + bb[0], (y[2 * p + 1] - mean2) * rstd2 * gg[1] + bb[1]};
                 }
@@ -663,8 +690,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     {
         f32x4 acc[4][2];
         tb_gemm<2, 3u>(AP, a.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        f32x4 bias1[2];                                              // (loads before the first store: see tb_ln_rows)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias1[j] = *reinterpret_cast<const f32x4*>(a.b1 + 32 * w + 16 * j + 4 * g);
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + n0);
+            const f32x4 bias = bias1[(n0 >> 4) & 1];
             const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
             f32x4 f, gq;
 #pragma unroll
@@ -789,6 +819,30 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
         for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { pe[v][e] = 0.f; po[v][e] = 0.f; }
+        // every global load of the pass before its first store (a load behind a store waits for the store's round trip: vmcnt is in order)
+        tb_f2 pg3[2][2], pg2[2][2], pb2[2][2];                       // LayerNorm parameters, [row parity][pair]
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = 4 * lane - 2 * par + 2 * p;
+                const bool okc = cp >= 0 && cp < TB_D;
+                pg3[par][p] = okc ? *reinterpret_cast<const tb_f2*>(a.ln3_g + cp) : tb_f2{0.f, 0.f};
+                pg2[par][p] = okc ? *reinterpret_cast<const tb_f2*>(a.ln2_g + cp) : tb_f2{0.f, 0.f};
+                pb2[par][p] = (okc && !a.n2) ? *reinterpret_cast<const tb_f2*>(a.ln2_b + cp) : tb_f2{0.f, 0.f};
+            }
+        tb_f2 in_dy[8][2], in_r2[8][2], in_n2[8][2];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = 4 * lane - ((rr & 1) ? 2 : 0) + 2 * p;
+                const long long o = ((long long)b * TB_L + 8 * w + rr) * TB_D + cp;
+                const bool okc = cp >= 0 && cp < TB_D;
+                in_dy[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.dn3 + o) : tb_f2{0.f, 0.f};
+                in_r2[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.r2 + o) : tb_f2{0.f, 0.f};
+                in_n2[rr][p] = (okc && a.n2) ? *reinterpret_cast<const tb_f2*>(a.n2 + o) : tb_f2{0.f, 0.f};
+            }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = 8 * w + rr, c0 = 4 * lane - ((rr & 1) ? 2 : 0);
@@ -799,19 +853,13 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
                 ok[p] = cp >= 0 && cp < TB_D;
-                tb_f2 v0 = tb_f2{0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0, v4 = v0;
-                if (ok[p]) {
-                    v0 = *reinterpret_cast<const tb_f2*>(a.dn3 + rbase + cp);
-                    v2 = *reinterpret_cast<const tb_f2*>(a.r2 + rbase + cp);
-                    v3 = *reinterpret_cast<const tb_f2*>(a.ln3_g + cp);
-                    v4 = *reinterpret_cast<const tb_f2*>(a.ln2_g + cp);
-                    if (a.n2) v1 = *reinterpret_cast<const tb_f2*>(a.n2 + rbase + cp);
-                    else {
-                        // n2 = LayerNorm2(r2) is re-evaluated from r2 and the row statistics (the forward did not store it: 16 MB per step less each way)
-                        const tb_f2 bb = *reinterpret_cast<const tb_f2*>(a.ln2_b + cp);
-                        const float mu = a.mu2[row], rs = a.rs2[row];
-                        v1 = tb_f2{(v2[0] - mu) * rs * v4[0] + bb[0], (v2[1] - mu) * rs * v4[1] + bb[1]};
-                    }
+                const tb_f2 v0 = in_dy[rr][p], v2 = in_r2[rr][p], v3 = pg3[rr & 1][p], v4 = pg2[rr & 1][p];
+                tb_f2 v1 = in_n2[rr][p];
+                if (ok[p] && !a.n2) {
+                    // n2 = LayerNorm2(r2) is re-evaluated from r2 and the row statistics (the forward did not store it: 16 MB per step less each way)
+                    const tb_f2 bb = pb2[rr & 1][p];
+                    const float mu = a.mu2[row], rs = a.rs2[row];
+                    v1 = tb_f2{(v2[0] - mu) * rs * v4[0] + bb[0], (v2[1] - mu) * rs * v4[1] + bb[1]};
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x3[2 * p + e] = v1[e]; x2[2 * p + e] = v2[e]; g3[2 * p + e] = v3[e]; g2[2 * p + e] = v4[e]; }
@@ -847,9 +895,15 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     {
         f32x4 acc[4][2];
         tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        f32x4 fpre[4][2];                                            // the pre-activations of this lane's 8 groups: loaded before the first store
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fpre[mt][j] = *reinterpret_cast<const f32x4*>(a.f1 + ((long long)b * TB_L + 16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4));
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
-            const f32x4 f = *reinterpret_cast<const f32x4*>(a.f1 + o);
+            const f32x4 f = fpre[m >> 4][(n0 >> 4) & 1];
             bool keep[4] = {true, true, true, true};
             if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
 #pragma unroll
@@ -887,6 +941,21 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { pe[v][e] = 0.f; po[v][e] = 0.f; }
+        tb_f2 pg1[2][2], in_r1[8][2];                                // (loads before the first store)
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = 4 * lane - 2 * par + 2 * p;
+                pg1[par][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.ln1_g + cp) : tb_f2{0.f, 0.f};
+            }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cp = 4 * lane - ((rr & 1) ? 2 : 0) + 2 * p;
+                in_r1[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.r1 + ((long long)b * TB_L + 8 * w + rr) * TB_D + cp) : tb_f2{0.f, 0.f};
+            }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = 8 * w + rr, c0 = 4 * lane - ((rr & 1) ? 2 : 0);
@@ -897,12 +966,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
                 ok[p] = cp >= 0 && cp < TB_D;
-                tb_f2 v0 = tb_f2{0.f, 0.f}, v1 = v0, v2 = v0;
-                if (ok[p]) {
-                    v0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(r, cp));
-                    v1 = *reinterpret_cast<const tb_f2*>(a.r1 + rbase + cp);
-                    v2 = *reinterpret_cast<const tb_f2*>(a.ln1_g + cp);
-                }
+                tb_f2 v0 = tb_f2{0.f, 0.f};
+                const tb_f2 v1 = in_r1[rr][p], v2 = pg1[rr & 1][p];
+                if (ok[p]) v0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(r, cp));
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x1[2 * p + e] = v1[e]; g1[2 * p + e] = v2[e]; }
             }

@@ -51,10 +51,17 @@ class AdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._runs_cache.clear()                          # the loaded moments are linked (copied into the flat buffers) at the next step
 
+    supports_step_and_zero_grad = True
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, zero_grad=False):
+        """zero_grad=True: optimizer.step() and the optimizer.zero_grad() that opens the next iteration (ATMS_retrieval.py:209,231) as ONE pass
+        over the gradients -- the update kernel clears each gradient behind its read, then .grad is set to None exactly as
+        zero_grad(set_to_none=True) would; owners of a flat gradient buffer (the ATMS engine) are told their buffer is already clear."""
         loss = closure() if closure is not None else None
         L = lib()
+        fn = L.eegclip_adamw_step_zero_grad if zero_grad else L.eegclip_adamw_step
+        cleared = []
         stream = torch.cuda.current_stream().cuda_stream
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
@@ -82,10 +89,24 @@ class AdamW(torch.optim.Optimizer):
             for (p0, n, step) in runs:
                 m, v = self._moments_for(p0)
                 off = (p0.data_ptr() - p0.untyped_storage().data_ptr()) // 4
-                rc = L.eegclip_adamw_step(p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, n,
-                                          group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0,
-                                          self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None, stream)
+                rc = fn(p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, n,
+                        group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0,
+                        self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None, stream)
                 check(rc, "adamw_step")
+            if zero_grad:
+                cleared += live
+        if zero_grad:
+            owners = {}
+            for p in cleared:
+                own = getattr(p, "_eegclip_grad_owner", None)
+                own = own() if own is not None else None
+                if own is not None:
+                    owners.setdefault(id(own), (own, []))[1].append(p.grad.data_ptr())
+            for own, ptrs in owners.values():
+                own.grads_cleared(ptrs)
+            for group in self.param_groups:                  # zero_grad(set_to_none=True) for every parameter, stepped or not
+                for p in group["params"]:
+                    p.grad = None
         return loss
 
     def _make_runs(self, live):

@@ -148,9 +148,23 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
         main.wait_stream(side)             # join BEFORE the optimizer rewrites logit_scale, which the readout's ranking kernel reads
     else:
         _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
-    optimizer.step()
-    loss_acc += loss.detach()
+    if getattr(optimizer, "supports_step_and_zero_grad", False):
+        optimizer.step(zero_grad=True)     # the update and the zero_grad() that opens the next iteration in one pass over the gradients
+    else:
+        optimizer.step()
+    if isinstance(loss_acc, list):
+        loss_acc.append(loss.detach())     # summed when the epoch ends (running_loss): no launch per step
+    else:
+        loss_acc += loss.detach()
     return eeg_features.detach()
+
+
+def running_loss(loss_acc):
+    """the epoch's summed loss (ATMS_retrieval.py:232 `total_loss += loss.item()`) from what contrastive_step accumulated: a device scalar
+    (legacy: added to in place, one launch per step) or a list of per-step loss scalars (one stack + sum here)"""
+    if isinstance(loss_acc, list):
+        return torch.stack([l.reshape(()) for l in loss_acc]).sum() if loss_acc else torch.zeros(())
+    return loss_acc
 
 
 def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct):
@@ -164,7 +178,7 @@ def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all
     text_features_all = text_features_all.to(device).float()
     img_features_all = (img_features_all[::10]).to(device).float().contiguous()
     features_list = []
-    loss_acc = torch.zeros((), dtype=torch.float32, device=device)
+    loss_acc = []                                          # per-step loss scalars, summed once at the end (running_loss)
     correct = torch.zeros(1, dtype=torch.int32, device=device)
     total, n_batches = 0, 0
     subject_id = extract_id_from_string(sub)
@@ -177,7 +191,7 @@ def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all
                                               img_features_all, loss_acc, correct, alpha=alpha, objective=objective))
         total += eeg_data.size(0)
         n_batches += 1
-    average_loss = float(loss_acc) / n_batches            # the only host syncs of the epoch
+    average_loss = float(running_loss(loss_acc)) / n_batches            # the only host syncs of the epoch
     accuracy = int(correct) / total
     return average_loss, accuracy, torch.cat(features_list, dim=0)
 

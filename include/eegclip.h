@@ -218,6 +218,9 @@ int eegclip_gather_rows(float* dst, long long dst_stride, const float* src, long
  * *grad_scale_dev (device scalar: gradient clipping without a host sync). */
 int eegclip_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, long long step, float grad_scale, const float* grad_scale_dev, void* stream);
+/* the same update, and g := 0 behind the read: optimizer.step() followed by optimizer.zero_grad() (ATMS_retrieval.py:209,231) in one pass */
+int eegclip_adamw_step_zero_grad(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, long long step, float grad_scale, const float* grad_scale_dev, void* stream);
 int eegclip_clip_scale(const double* sumsq, float max_norm, float* scale_out, void* stream); /* min(1, max_norm/(sqrt(sumsq)+1e-6)) */
 
 /* ---- diffusion prior / DDPM pieces (diffusers==0.30.0 semantics restated; Generation/diffusion_prior.py:29,314,370-376)

@@ -264,6 +264,21 @@ def test_adamw_matches_torch(be):
     np.testing.assert_allclose(be.host(P), pt.detach().numpy(), atol=2e-7, rtol=1e-6)
 
 
+def test_adamw_step_zero_grad_is_the_same_update_and_clears_the_gradient(be):
+    rng = np.random.default_rng(16)
+    n = 4099
+    p0, g, m0, v0 = rnd(rng, n), rnd(rng, n), rnd(rng, n) * 0.1, np.abs(rnd(rng, n)) * 0.1
+    res = []
+    for name in ("eegclip_adamw_step", "eegclip_adamw_step_zero_grad"):
+        P, G, M, V = be.dev(p0), be.dev(g), be.dev(m0), be.dev(v0)
+        ok(getattr(be.lib, name)(be.ptr(P), be.ptr(G), be.ptr(M), be.ptr(V), n, 3e-4, 0.9, 0.999, 1e-8, 0.01, 3, 0.5, None, be.stream))
+        res.append([be.host(t) for t in (P, M, V, G)])
+    for a, b in zip(res[0][:3], res[1][:3]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[0][3], g)
+    np.testing.assert_array_equal(res[1][3], np.zeros(n, np.float32))
+
+
 def _attn_ref(qkv, B, H, E, scale, keep, p):
     L = 64
     q, k, v = [t.view(B, L, H, E).permute(0, 2, 1, 3) for t in qkv.view(B * L, 3, H * E).unbind(1)]

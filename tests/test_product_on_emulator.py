@@ -90,6 +90,45 @@ def test_mixed_clip_loss_equals_the_two_reference_calls():
         assert abs(float(outs[1][0]) - float(ref)) < 1e-5
 
 
+def test_step_and_zero_grad_in_one_pass_is_the_plain_loop():
+    """contrastive_step with optim.AdamW (update + zero_grad in one kernel, the engine skips its own clear) against the same steps with an optimizer
+    that only offers step(): the same parameters after 3 steps, and the gradients are None / the flat buffer clear in between"""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B = 3
+    batches = [(T(syn.eeg_batch(SEED + 50 + i, B)), T(syn.unit_features(SEED + 50 + i, B, tag="img")), T(syn.unit_features(SEED + 50 + i, B, tag="txt")))
+               for i in range(3)]
+    labels = torch.arange(B)
+    finals = []
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim, retrieval
+
+        class PlainStep(optim.AdamW):
+            supports_step_and_zero_grad = False
+
+        for cls in (optim.AdamW, PlainStep):
+            m = make_model(state_np).train()
+            opt = cls(m.parameters(), lr=3e-4)
+            acc = [] if cls is optim.AdamW else torch.zeros(())
+            correct = torch.zeros(1, dtype=torch.int32)
+            torch.manual_seed(5)
+            for x, img, txt in batches:
+                retrieval.contrastive_step(m, opt, x, 1, img, txt, labels, img, acc, correct)
+                if cls is optim.AdamW:
+                    assert all(p.grad is None for p in m.parameters())
+                    assert float(m._engine().gflat.abs().max()) == 0.0
+                else:
+                    assert m.logit_scale.grad is not None
+            finals.append(({k: p.detach().clone() for k, p in m.named_parameters()}, float(retrieval.running_loss(acc))))
+    assert abs(finals[0][1] - finals[1][1]) < 1e-5 * abs(finals[1][1])
+    # (gradient sums through atomics are not bit-reproducible run to run, and Adam's first steps move an element by lr * g / |g|: round-off-sized
+    # gradients differ by a fraction of lr = 3e-4 between ANY two runs; a stale or uncleared gradient would move most elements by ~lr)
+    for k in finals[0][0]:
+        if k.endswith("key_projection.bias"):          # its true gradient is zero (softmax shift invariance): pure round-off under Adam
+            continue
+        d = np.abs(finals[0][0][k].numpy() - finals[1][0][k].numpy())
+        assert d.max() <= 3 * 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
+
+
 def test_reconstruction_objective_step_under_emulator_matches_oracle():
     """10 * (0.9 MSE + 0.1 image InfoNCE) through contrastive_step(objective="reconstruction"): loss and parameters after one AdamW step"""
     state_np = syn.make_state(SEED, oatms.state_spec())
