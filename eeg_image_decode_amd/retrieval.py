@@ -95,6 +95,8 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
                      alpha=0.99, objective="retrieval"):
     """One iteration of the reference batch loop (ATMS_retrieval.py:209-250) with every tensor already on the device:
     forward, image + text InfoNCE (0.99/0.01), backward, optimizer step, running loss and train-accuracy -- no host sync.
+    With an optimizer that offers it (optim.AdamW / Adam: supports_step_and_zero_grad) the update also performs the zero_grad() that opens the
+    next iteration, so the gradients are None when this returns; `loss_acc` is a device scalar (added to in place) or a list (appended to).
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
     from . import dist as edist
     optimizer.zero_grad()

@@ -408,11 +408,15 @@ def test_early_gradient_bucket_allreduce_runs_on_rccl(monkeypatch):
         img, txt = T(syn.unit_features(SEED + 50, B, tag="img")).cuda(), T(syn.unit_features(SEED + 50, B, tag="txt")).cuda()
         labels, classes = torch.zeros(B, dtype=torch.long, device="cuda"), T(syn.unit_features(SEED + 51, 7, tag="cls")).cuda()
         grads = []
+
+        class KeepGrads(optim.AdamW):            # (contrastive_step fuses step + zero_grad when the optimizer offers it: the gradients would be gone)
+            supports_step_and_zero_grad = False
+
         for fake_world in (1, 2):
             m = make_model(state_np)
             zero_dropout(m)
             m.train()
-            opt = optim.AdamW(m.parameters(), lr=0.0)                      # lr 0: the step leaves the gradients in place for inspection
+            opt = KeepGrads(m.parameters(), lr=0.0)                        # lr 0: the step leaves the gradients in place for inspection
             if fake_world == 2:
                 monkeypatch.setattr(edist, "world_size", lambda: 2)
                 monkeypatch.setattr(atms, "_dp_world", lambda: 2)
