@@ -77,7 +77,7 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>"}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r2_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r3_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(family, B):

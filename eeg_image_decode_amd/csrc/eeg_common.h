@@ -262,8 +262,9 @@ __device__ __forceinline__ philox4 philox4x32_10(unsigned long long seed, unsign
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        unsigned h0 = __umulhi(M0, c0), l0 = M0 * c0;
-        unsigned h1 = __umulhi(M1, c2), l1 = M1 * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: same bits, half the multiplies
+        const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
         unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += W0; k1 += W1;

@@ -544,8 +544,8 @@ __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, in
     if (i >= n) return;
     float s = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < groups; ++k) s += partials[(long long)k * n + i];      // independent loads: keep 8 in flight per thread
-    dW[i] += s;
+    for (int k = blockIdx.y; k < groups; k += gridDim.y) s += partials[(long long)k * n + i];      // independent loads: keep 8 in flight per thread
+    atomicAdd(dW + i, s);        // gridDim.y (<= 4) adds per address: 394 workgroups of 51 dependent-issue loads each left most of the chip idle
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -796,7 +796,7 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
         else           EEG_LAUNCH(sconv_bwd_w_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
     }
     const long long n = (long long)SC_C * K;
-    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, groups, n, dWs);
+    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256), groups >= 16 ? 4 : 1), dim3(256), 0, stream, workspace, groups, n, dWs);
     return (int)hipGetLastError();
 }
 
