@@ -63,6 +63,7 @@ def algorithmic_cost(name, desc, B):
         "eegclip_sconv_fwd": ("hbm", y1),                                   # read y1 (z1 recomputed, y2 is tiny)
         "eegclip_sconv_bwd_w": ("hbm", y1),
         "eegclip_sconv_bwd_x_stats": ("hbm", y1),
+        "eegclip_sconv_bwd_w_stats": ("hbm", y1),                           # dWs and the BN1-backward sums: ONE read of y1
         "eegclip_sconv_bwd_x_apply": ("hbm", 2 * y1),                       # read y1, write dy1
     }
     if name in table:
@@ -74,6 +75,7 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel<7>",
               "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
               "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_x3_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false, true>",
+              "eegclip_sconv_bwd_w_stats": "eeg::sconv_bwd_ws_x3_kernel<128>",
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>"}
 
 

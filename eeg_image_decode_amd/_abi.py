@@ -134,6 +134,8 @@ PROTOTYPES = {
     "eegclip_sconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_sconv_bwd_w": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_sconv_bwd_x_stats_workspace_floats": [_I],
+    "eegclip_sconv_bwd_w_stats_workspace_floats": [_I, _I],
+    "eegclip_sconv_bwd_w_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_sconv_bwd_x_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],

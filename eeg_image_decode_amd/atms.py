@@ -748,7 +748,6 @@ class _Engine:
         if "scw_ws" not in b:
             b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
-        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
         # split-bf16 products for the K = 40 contraction of both BN1-backward passes (the plan's GEMM precision): Ws^T as bf16 planes
         # [(c,h)][64 o], split by the forward plan of this step
         wt = (None, None)
@@ -756,7 +755,17 @@ class _Engine:
             wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
         if "scx_ws" not in b:
             b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
-        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
+        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_SCONV_FOLD", "0") == "1":
+            # opt-in: dWs and the BatchNorm1-backward sums from ONE pass over y1 (csrc/sconv.hip: sconv_bwd_ws_x3_kernel).  The statistics are on the dX
+            # chain, so the fused launch runs on the main stream.  Measured (B = 256): 70.6 us against 41.6 (second stream) + 44.5 (main) for the two
+            # kernels -- 15 us less kernel time, but the main-stream chain grows by 26 us and the step is 1.100-1.108 vs 1.093-1.096 ms: not the default.
+            if "scws_ws" not in b:
+                b["scws_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_stats_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
+            pl.call("eegclip_sconv_bwd_w_stats", _p(b["y1"]), *bnp, _p(b["dy2"]), *wt, _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), _p(sums[3]),
+                    _p(b["scws_ws"]), B, N_CH)
+        else:
+            pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
+            pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
         local1 = None
         if W > 1:
             local1 = torch.zeros_like(sums[3])

@@ -539,6 +539,211 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_x3_kernel(const float* __rest
         }
 }
 
+// weight gradient AND the BatchNorm1-backward statistics from ONE pass over y1 (the separate statistics pass, sconv_bwd_x_kernel<false>, read the
+// 93 MB tensor a second time).  Same decomposition as the kernel above (workgroup = slab of NS columns n = (c,h) x a group of samples), but y1 is
+// loaded in the layout of the accumulators of  dz^T[w][n] = sum_o dy2^T[w][o] Ws^T[n][o]  -- lane (fr, g), tile (j, tw) holds the 4 positions
+// w = 16 tw + 4 g .. + 3 of column n = 16 NT wv + 16 j + fr -- so the same registers feed the z1 planes of the weight gradient (one 8-byte LDS store
+// per plane, as before) and, after the K = 40 contraction on the matrix cores, da = dz * ELU'(u) and x_hat for  S1[c] = sum da, S2[c] = sum da x_hat.
+// Operands of the second product: dy2^T as planes [48 w][64 o] (staged with 2-byte stores from the same dy2 registers), Ws^T planes [(c,h)][64 o]
+// (eegclip_split_rows(transpose)): the wave's 2 NT fragments per plane live in registers for the whole launch.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void sconv_bwd_ws_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
+                                                                 const unsigned short* __restrict__ wt_hi, const unsigned short* __restrict__ wt_lo,
+                                                                 float* __restrict__ partials, double* __restrict__ stat_parts, int B, int H, int bgroups) {
+    constexpr int NT = NS / 64;
+    constexpr int ZPL = NS * SWX_RS, DPL = SC_OP * SWX_RS;       // bytes per plane
+    EEG_LDS_BASE(float, lds);
+    unsigned char* zp = reinterpret_cast<unsigned char*>(lds);   // z1 planes hi | lo     [NS n][64 w]
+    unsigned char* dp = zp + 2 * ZPL;                            // dy2 planes hi | lo    [48 o][64 w]
+    unsigned char* tp = dp + 2 * DPL;                            // dy2^T planes hi | lo  [48 w][64 o]
+    float* aff = reinterpret_cast<float*>(tp + 2 * DPL);         // [4][40]  sc | sh | mean | rstd
+    float* sl = aff + 4 * SC_C;                                  // [2][40]  per-workgroup channel sums
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int K = SC_C * H;
+    const int n0 = blockIdx.x * NS, bg = blockIdx.y;
+    if (t < SC_C) {
+        const float sc = bn.gamma[t] * bn.rstd[t];
+        aff[t] = sc;
+        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
+        aff[2 * SC_C + t] = bn.mean[t];
+        aff[3 * SC_C + t] = bn.rstd[t];
+    }
+    if (t < 2 * SC_C) sl[t] = 0.f;
+    for (int i = t; i < (2 * ZPL + 4 * DPL) / 16; i += 256) reinterpret_cast<f32x4*>(zp)[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // padding rows / columns: zero for good
+    const int ncols = K - n0 < NS ? K - n0 : NS;
+    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero8{0, 0, 0, 0, 0, 0, 0, 0};
+    // this lane's columns, their Ws^T fragments and BatchNorm constants
+    int nl[NT];
+    bool nok[NT];
+    bf16x8 wh[NT][2], wl[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        nl[j] = 16 * NT * wv + 16 * j + fr;
+        nok[j] = nl[j] < ncols;
+        const long long row = (long long)(n0 + (nok[j] ? nl[j] : 0)) * 64;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            wh[j][s2] = nok[j] ? *reinterpret_cast<const bf16x8*>(wt_hi + row + 32 * s2 + 8 * g) : zero8;
+            wl[j][s2] = nok[j] ? *reinterpret_cast<const bf16x8*>(wt_lo + row + 32 * s2 + 8 * g) : zero8;
+        }
+    }
+    __syncthreads();
+    float csc[NT], csh[NT], cmu[NT], crs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = nok[j] ? (n0 + nl[j]) / H : 0;
+        csc[j] = aff[c]; csh[j] = aff[SC_C + c]; cmu[j] = aff[2 * SC_C + c]; crs[j] = aff[3 * SC_C + c];
+    }
+    f32x4 acc[3][NT];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4v;
+    float s1[NT], s2s[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2s[j] = 0.f; }
+    f32x4 vn[NT][3], vd[2];
+    auto load_sample = [&](int b) {
+        const float* src = y1 + ((long long)b * K + n0) * SC_W;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int w = 16 * tw + 4 * g;                 // 36 % 4 == 0: a quad is all in or all out
+                vn[j][tw] = (nok[j] && w < SC_W) ? *reinterpret_cast<const f32x4*>(src + (long long)nl[j] * SC_W + w) : zero4v;
+            }
+        const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 4 * (t + 256 * j);
+            vd[j] = e < SC_C * SC_W ? *reinterpret_cast<const f32x4*>(dsrc + e) : zero4v;
+        }
+    };
+    if (bg < B) load_sample(bg);
+    for (int b = bg; b < B; b += bgroups) {
+        f32x4 yv[NT][3];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                yv[j][tw] = vn[j][tw];
+                const int w = 16 * tw + 4 * g;
+                if (w >= SC_W) continue;
+                f32x4 z = zero4v;
+                if (nok[j]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] = elu1_fast(yv[j][tw][q] * csc[j] + csh[j]);
+                }
+                u32x2_t hi, lo;
+                x3_split4(z[0], z[1], z[2], z[3], hi, lo);
+                *reinterpret_cast<u32x2_t*>(zp + nl[j] * SWX_RS + 2 * w) = hi;
+                *reinterpret_cast<u32x2_t*>(zp + ZPL + nl[j] * SWX_RS + 2 * w) = lo;
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 4 * (t + 256 * j), o = e / SC_W, w = e % SC_W;
+            if (e >= SC_C * SC_W) continue;
+            u32x2_t hi, lo;
+            x3_split4(vd[j][0], vd[j][1], vd[j][2], vd[j][3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(dp + o * SWX_RS + 2 * w) = hi;
+            *reinterpret_cast<u32x2_t*>(dp + DPL + o * SWX_RS + 2 * w) = lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                          // the transposed planes: 4 rows w, one column o
+                const unsigned hq = (q & 1) ? (hi[q >> 1] >> 16) : (hi[q >> 1] & 0xffffu), lq = (q & 1) ? (lo[q >> 1] >> 16) : (lo[q >> 1] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(tp + (w + q) * SWX_RS + 2 * o) = (unsigned short)hq;
+                *reinterpret_cast<unsigned short*>(tp + DPL + (w + q) * SWX_RS + 2 * o) = (unsigned short)lq;
+            }
+        }
+        __syncthreads();
+        if (b + bgroups < B) load_sample(b + bgroups);
+        // (1) dWs[o][n] += sum_w dy2[o][w] z1[n][w]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ah[3], al[3], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned char* src = dp + (16 * i + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
+                ah[i] = *reinterpret_cast<const bf16x8*>(src);
+                al[i] = *reinterpret_cast<const bf16x8*>(src + DPL);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned char* src = zp + (16 * NT * wv + 16 * j + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
+                bh[j] = *reinterpret_cast<const bf16x8*>(src);
+                bl[j] = *reinterpret_cast<const bf16x8*>(src + ZPL);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {                // D[o = 16i + 4g + r][n = n0 + 16 NT wv + 16j + fr]
+                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        // (2) dz^T[w][n] = sum_o dy2^T[w][o] Ws^T[n][o];  da = dz * ELU'(u);  S1 += da, S2 += da * x_hat
+#pragma unroll
+        for (int tw = 0; tw < 3; ++tw) {
+            bf16x8 th[2], tl[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned char* src = tp + (16 * tw + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
+                th[s2] = *reinterpret_cast<const bf16x8*>(src);
+                tl[s2] = *reinterpret_cast<const bf16x8*>(src + DPL);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 dz = zero4v;                              // D[w = 16 tw + 4g + r][n = column j of this lane]
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dz = mfma_bf16_16x16x32(th[s2], wl[j][s2], dz);
+                    dz = mfma_bf16_16x16x32(tl[s2], wh[j][s2], dz);
+                    dz = mfma_bf16_16x16x32(th[s2], wh[j][s2], dz);
+                }
+                if (nok[j] && 16 * tw + 4 * g < SC_W) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = yv[j][tw][r];
+                        const float u = y * csc[j] + csh[j];
+                        const float da = u > 0.f ? dz[r] : dz[r] * fast_exp(u);
+                        s1[j] += da;
+                        s2s[j] += da * ((y - cmu[j]) * crs[j]);
+                    }
+                }
+            }
+        }
+    }
+    float* out = partials + (long long)bg * SC_C * K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 16 * NT * wv + 16 * j + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * i + 4 * g + r;
+                if (o < SC_C && n < K) out[(long long)o * K + n] = acc[i][j][r];
+            }
+        }
+    // channel sums: the 4 lane groups of a column, then the columns of a channel (LDS adds: <= 2 NT per lane, once per launch)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float a = s1[j], c2 = s2s[j];
+        a += __shfl_xor(a, 16);  c2 += __shfl_xor(c2, 16);
+        a += __shfl_xor(a, 32);  c2 += __shfl_xor(c2, 32);
+        if (g == 0 && nok[j]) {
+            const int c = (n0 + nl[j]) / H;
+            atomicAdd(sl + c, a);
+            atomicAdd(sl + SC_C + c, c2);
+        }
+    }
+    __syncthreads();
+    if (t < 2 * SC_C) stat_parts[((long long)bg * gridDim.x + blockIdx.x) * (2 * SC_C) + t] = (double)sl[t];
+}
+
 __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -801,6 +1006,32 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
 }
 
 static bool scx_planes_ok(const void* hi, const void* lo) { return hi && lo && sc_aligned16(hi) && sc_aligned16(lo); }
+
+extern "C" long long eegclip_sconv_bwd_w_stats_workspace_floats(int B, int H) {
+    if (B < 1 || H < 1 || H > 64) return 0;
+    return 2LL * ((SC_C * H + scw_ns() - 1) / scw_ns()) * scw_groups(B, H) * 2 * SC_C;          // (doubles, in floats)
+}
+
+extern "C" int eegclip_sconv_bwd_w_stats(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
+                                         const void* WsT_hi, const void* WsT_lo, float* dWs, float* workspace, double* sums, float* stats_workspace,
+                                         int B, int H, void* stream) {
+    if (int rc = sc_check(B, H)) return rc;
+    if (!y1 || !mean || !rstd || !gamma || !beta || !dy2 || !WsT_hi || !WsT_lo || !dWs || !workspace || !sums || !stats_workspace) return EEGCLIP_EINVAL;
+    if (!sc_aligned16(y1) || !sc_aligned16(dy2) || !sc_aligned16(WsT_hi) || !sc_aligned16(WsT_lo) || (reinterpret_cast<uintptr_t>(stats_workspace) & 7u))
+        return EEGCLIP_EALIGN;
+    const bn_affine bn{mean, rstd, gamma, beta};
+    const int K = SC_C * H, groups = scw_groups(B, H), ns = scw_ns();
+    const dim3 grid((K + ns - 1) / ns, groups);
+    double* parts = reinterpret_cast<double*>(stats_workspace);
+    const size_t lds = (size_t)2 * ns * SWX_RS + 4 * SC_OP * SWX_RS + 6 * SC_C * sizeof(float);
+    const unsigned short *wh = (const unsigned short*)WsT_hi, *wl = (const unsigned short*)WsT_lo;
+    if (ns == 256) EEG_LAUNCH(sconv_bwd_ws_x3_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, wh, wl, workspace, parts, B, H, groups);
+    else           EEG_LAUNCH(sconv_bwd_ws_x3_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, wh, wl, workspace, parts, B, H, groups);
+    const long long n = (long long)SC_C * K;
+    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256), groups >= 16 ? 4 : 1), dim3(256), 0, stream, workspace, groups, n, dWs);
+    EEG_COLSUM_F64((const double*)parts, (int)(grid.x * grid.y), 2 * SC_C, sums, stream);
+    return (int)hipGetLastError();
+}
 
 extern "C" long long eegclip_sconv_bwd_x_stats_workspace_floats(int B) { return B < 1 ? 0 : 2LL * B * SCX_GY * 2 * SC_C; }     // (doubles, in floats)
 

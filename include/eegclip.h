@@ -294,6 +294,13 @@ int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, c
 /* workspace (optional, 8-byte aligned, eegclip_sconv_bwd_x_stats_workspace_floats(B) floats): the 80 sums leave every workgroup as a partial row and
  * are column-summed by a second kernel instead of 1280-way contended fp64 atomics. */
 long long eegclip_sconv_bwd_x_stats_workspace_floats(int B);
+/* weight gradient AND the BatchNorm1-backward sums (what eegclip_sconv_bwd_x_stats produces) from one pass over y1; split-bf16 products only:
+ * WsT_hi / WsT_lo = bf16 planes [(c,h)][64 o] of Ws^T (eegclip_split_rows, transpose).  workspace: eegclip_sconv_bwd_w_workspace_floats(B, H);
+ * stats_workspace: eegclip_sconv_bwd_w_stats_workspace_floats(B, H) floats, 8-byte aligned; sums (2 x 40 doubles) is ADDED to. */
+long long eegclip_sconv_bwd_w_stats_workspace_floats(int B, int H);
+int eegclip_sconv_bwd_w_stats(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
+                              const void* WsT_hi, const void* WsT_lo, float* dWs, float* workspace, double* sums, float* stats_workspace, int B, int H,
+                              void* stream);
 int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, double* sums, float* workspace, int B, int H, void* stream);
 int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,

@@ -567,6 +567,23 @@ def test_fused_spatial_stage(be, B, H):
         np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
     assert be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(WH), None, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
                                             be.ptr(SUMS), None, B, H, be.stream) < 0
+    # weight gradient + the same BatchNorm-backward sums from ONE pass over y1 (sconv_bwd_ws_x3_kernel), against the two separate kernels and torch
+    SUMS2, DWS2 = be.zeros(80, np.float64), be.dev(np.ones((C, C, H), np.float32))
+    WSP = be.dev(np.full(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)), np.nan, np.float32))
+    SWS = be.dev(np.full(int(be.lib.eegclip_sconv_bwd_w_stats_workspace_floats(B, H)) // 2, np.nan, np.float64))
+    ok(be.lib.eegclip_sconv_bwd_w_stats(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(WH), be.ptr(WL), be.ptr(DWS2),
+                                        be.ptr(WSP), be.ptr(SUMS2), be.ptr(SWS), B, H, be.stream))
+    np.testing.assert_allclose(be.host(DWS2) - 1.0, wt.grad.numpy(), atol=1e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
+    ref_s = be.host(SUMS)                   # (the split-bf16 statistics pass just above)
+    np.testing.assert_allclose(be.host(SUMS2), ref_s, atol=2e-4 * max(1.0, np.abs(ref_s).max()))
+    DY1, DG, DB = be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
+    ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), be.ptr(WH), be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
+                                        be.ptr(SUMS2), None, float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
+    np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
+    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
+    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
+    assert be.lib.eegclip_sconv_bwd_w_stats(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(WH), None, be.ptr(DWS2),
+                                            be.ptr(WSP), be.ptr(SUMS2), be.ptr(SWS), B, H, be.stream) < 0
 
 
 def _bf16_round(a):
