@@ -147,7 +147,16 @@ __global__ __launch_bounds__(64) void token_block_pack_kernel(const tb_pack_args
 // ---- C[64 x 16 NT] of one wave: A = the AP planes (all 64 rows, K = 256), B = NT packed n-tiles starting at `wp`.
 //      bit j of TM set: tile j is formed TRANSPOSED (MFMA rows = n): lane (fr, g) then holds n = 16 j + 4 g + i of row m = 16 mt + fr;
 //      clear: standard, lane holds rows m = 16 mt + 4 g + i of column n = 16 j + fr.
-template <int NT, unsigned TM, int PF = 2, bool ZERO = true>
+#ifndef TB_FWD_RING
+#define TB_FWD_RING false                                   // the forward kernel's GEMMs: compiler-scheduled weight loads (see tb_gemm)
+#endif
+#ifndef TB_QKV_RING
+#define TB_QKV_RING false                                   // ... and its Q | K | V GEMM (NT = 3: 72 ring registers on top of 48 accumulators)
+#endif
+#ifndef TB_BWD_PF
+#define TB_BWD_PF 2                                         // k-steps of weight fragments in flight in the backward kernels' GEMMs
+#endif
+template <int NT, unsigned TM, int PF = 2, bool ZERO = true, bool RING = false>
 __device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned short* wp, int lane, f32x4 (&acc)[4][NT]) {
     const int fr = lane & 15, g = lane >> 4;
     if (ZERO) {
@@ -156,27 +165,68 @@ __device__ __forceinline__ void tb_gemm(const unsigned char* AP, const unsigned 
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // the B fragments of k-step ks live in ring slot ks % (PF + 1): PF k-steps of weight loads (L2 round trips) in flight under the MFMAs
+    // the B fragments of k-step ks live in ring slot ks % (PF + 1): PF k-steps of weight loads (L2 round trips) in flight under the MFMAs.
+    // RING: the loads are inline asm with hand-counted waits: left to the compiler, each load is scheduled 4..20 MFMAs ahead of its use (it sinks
+    // prefetches to shorten live ranges) -- a fraction of the L2 latency -- and every k-step stalls.  Loads retire in order, so "at most
+    // 2 NT x (younger k-steps) operations outstanding" means the fragments of this k-step have landed; the wait names them as read-write so
+    // that no use is scheduled above it (tests/test_asm_rings.py checks the generated code: the compiler must not copy or spill a register whose
+    // load is in flight).  Measured: backward part 0 73 -> 64 us, part 1 37 -> 31 us; the FORWARD kernel, already at the 256-VGPR limit, spills
+    // more with the ring pinned and gets slower (144 -> 151 us train, 107 -> 135 us eval), so it keeps the compiler's schedule.
     bf16x8 bh[PF + 1][NT], bl[PF + 1][NT];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
+    auto issue = [&](int ks) {
+        const int slot = ks % (PF + 1);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const bf16x8* q = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + p) * TB_TILE) + lane;
-            bh[p][j] = q[0];
-            bl[p][j] = q[64];
+            const bf16x8* q = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + ks) * TB_TILE) + lane;
+#if defined(EEG_EMU)
+            bh[slot][j] = q[0];
+            bl[slot][j] = q[64];
+#else
+            if constexpr (RING) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bh[slot][j]) : "v"(q) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(bl[slot][j]) : "v"(q) : "memory");
+            } else {
+                bh[slot][j] = q[0];
+                bl[slot][j] = q[64];
+            }
+#endif
         }
+    };
+    auto landed = [&](int ks) {
+#if !defined(EEG_EMU)
+        if constexpr (!RING) return;
+        static_assert(NT == 2 || NT == 3, "the wait statements list 2 NT fragment registers");
+        const int slot = ks % (PF + 1);
+        const int younger = TB_KS - 1 - ks < PF ? TB_KS - 1 - ks : PF;          // k-steps issued after this one
+#define TB_WAIT(N)                                                                                                                       \
+    do {                                                                                                                                 \
+        if constexpr (NT == 2)                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bh[slot][0]), "+v"(bl[slot][0]), "+v"(bh[slot][1]), "+v"(bl[slot][1])::"memory"); \
+        else                                                                                                                             \
+            asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                       \
+                         : "+v"(bh[slot][0]), "+v"(bl[slot][0]), "+v"(bh[slot][1]), "+v"(bl[slot][1]), "+v"(bh[slot][NT - 1]), "+v"(bl[slot][NT - 1]) \
+                         :                                                                                                               \
+                         : "memory");                                                                                                    \
+    } while (0)
+        const int n = 2 * NT * younger;
+        if (n == 0) TB_WAIT(0);
+        else if (n == 4) TB_WAIT(4);
+        else if (n == 6) TB_WAIT(6);
+        else if (n == 8) TB_WAIT(8);
+        else if (n == 12) TB_WAIT(12);
+        else if (n == 16) TB_WAIT(16);
+        else if (n == 18) TB_WAIT(18);
+        else TB_WAIT(0);
+#undef TB_WAIT
+#endif
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) issue(p);
 #pragma unroll
     for (int ks = 0; ks < TB_KS; ++ks) {
         const int cur = ks % (PF + 1);
-        if (ks + PF < TB_KS) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const bf16x8* q = reinterpret_cast<const bf16x8*>(wp + (long long)(j * TB_KS + ks + PF) * TB_TILE) + lane;
-                bh[(ks + PF) % (PF + 1)][j] = q[0];
-                bl[(ks + PF) % (PF + 1)][j] = q[64];
-            }
-        }
+        if (ks + PF < TB_KS) issue(ks + PF);
+        landed(ks);
         // (pinning the prefetch issue here with sched_barrier(0) measured SLOWER -- 140 vs 120 us per launch: it also stops the scheduler from
         //  running the next k-step's fragment reads under this k-step's MFMAs)
         bf16x8 ah[4], al[4];
@@ -263,7 +313,7 @@ __device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int
             const int m = 16 * mt + fr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[mt][i] = i < valid ? v[mt][i] + bias[i] : 0.f;
-            if (!(a.dbg & 1u)) tb_st4(a.qkv + ((long long)b * TB_L + m) * (3 * TB_HE) + cbase + d0, valid, v[mt]);
+            if (!(a.dbg & 1u)) tb_st4(a.qkv + (long long)b * (TB_L * 3 * TB_HE) + (unsigned)(m * (3 * TB_HE) + cbase + d0), valid, v[mt]);
         }
     } else {
         const int d = 16 * tt + fr;
@@ -272,7 +322,7 @@ __device__ __forceinline__ void tb_qkv_tile_out(const tb_fwd_args& a, int b, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[mt][i] = d < TB_E ? v[mt][i] + bias[0] : 0.f;
-                if (d < TB_E && !(a.dbg & 1u)) a.qkv[((long long)b * TB_L + 16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d] = v[mt][i];
+                if (d < TB_E && !(a.dbg & 1u)) (a.qkv + (long long)b * (TB_L * 3 * TB_HE))[(unsigned)((16 * mt + 4 * g + i) * (3 * TB_HE) + cbase + d)] = v[mt][i];
             }
     }
 }
@@ -296,7 +346,7 @@ struct tb_qkv_variant {
 
 template <int V>
 __device__ __forceinline__ void tb_qkv_pass(const tb_fwd_args& a, const unsigned char* AP, int b, int head, int lane, f32x4 (&acc)[4][3]) {
-    tb_gemm<3, tb_qkv_variant<V>::mask>(AP, a.packed + TB_OFF_QKV + (long long)(head * 12 + 3 * V) * TB_KS * TB_TILE, lane, acc);
+    tb_gemm<3, tb_qkv_variant<V>::mask, 2, true, TB_QKV_RING>(AP, a.packed + TB_OFF_QKV + (long long)(head * 12 + 3 * V) * TB_KS * TB_TILE, lane, acc);
     // the three tiles' biases first (loads), then every store of the pass: a bias load behind the previous tile's stores would wait for them
     const int fr = lane & 15, g = lane >> 4;
     f32x4 bias[3];
@@ -418,6 +468,8 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                                            const float* resid_g, unsigned site, float* r_out, const float* g1, const float* be1, float* y_out, float* mu_out,
                                            float* rs_out, const float* g2, const float* be2, float* y2_out, float* mu2_out, float* rs2_out,
                                            unsigned char* y_lds /* XF layout or null */, unsigned char* ap /* planes of y or null */) {
+    const long long sb = (long long)b * (TB_L * TB_D);            // uniform: this sample's offset in every (B, 64, 250) tensor
+
     const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
     const float inv = 1.0f / (float)TB_D;
     // EVERY global load of the pass is issued here, before the first store: vmcnt retires in order and counts stores, so a load behind a store
@@ -445,18 +497,18 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
-                rg[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(resid_g + ((long long)b * TB_L + r) * TB_D + cp) : tb_f2{0.f, 0.f};
+                rg[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(resid_g + sb + (unsigned)(r * TB_D + cp)) : tb_f2{0.f, 0.f};
             }
         }
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int r = 8 * w + rr, c0 = 4 * lane - ((r & 1) ? 2 : 0);
-        const long long rbase = ((long long)b * TB_L + r) * TB_D;
+        const int rbase = r * TB_D;                                 // within the sample: every global access below is (uniform sample base) + 32-bit offset
         float v[4];
         bool ok[2];
         bool keep[4] = {true, true, true, true};
-        if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, site, (unsigned long long)(rbase + c0), a.drop_p, keep);
+        if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, site, (unsigned long long)(sb + (rbase + c0)), a.drop_p, keep);
         float s = 0.f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -474,7 +526,7 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                 v[2 * p + e] = ok[p] ? d + rv[e] : 0.f;
                 s += v[2 * p + e];
             }
-            if (ok[p] && r_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(r_out + rbase + cp) = tb_f2{v[2 * p], v[2 * p + 1]};
+            if (ok[p] && r_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(r_out + sb + (unsigned)(rbase + cp)) = tb_f2{v[2 * p], v[2 * p + 1]};
         }
         const float mean = wave_sum(s) * inv;
         float q = 0.f;
@@ -496,15 +548,15 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                 s2 += y[2 * p + e];
             }
             if (ok[p]) {
-                if (y_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(y_out + rbase + cp) = tb_f2{y[2 * p], y[2 * p + 1]};
+                if (y_out && !(a.dbg & 1u)) *reinterpret_cast<tb_f2*>(y_out + sb + (unsigned)(rbase + cp)) = tb_f2{y[2 * p], y[2 * p + 1]};
                 if (y_lds) *reinterpret_cast<tb_f2*>(y_lds + xf_off(r, cp)) = tb_f2{y[2 * p], y[2 * p + 1]};
             }
             if (ap && cp >= 0 && cp < 256) tb_store_planes2(ap, TB_AP_PLANE, ap_off(r, cp), y[2 * p], y[2 * p + 1]);      // (zeros past column 249)
         }
         if (ap && (r & 1) && lane == 63) tb_store_planes2(ap, TB_AP_PLANE, ap_off(r, 254), 0.f, 0.f);                       // odd rows: 254, 255 belong to no lane
         if (lane == 0) {
-            mu_out[(long long)b * TB_L + r] = mean;
-            rs_out[(long long)b * TB_L + r] = rstd;
+            (mu_out + (long long)b * TB_L)[(unsigned)r] = mean;
+            (rs_out + (long long)b * TB_L)[(unsigned)r] = rstd;
         }
         if (DOUBLE) {
             const float mean2 = wave_sum(s2) * inv;
@@ -520,13 +572,13 @@ __device__ __forceinline__ void tb_ln_rows(const tb_fwd_args& a, int b, int w, i
                 const int cp = c0 + 2 * p;
                 if (ok[p]) {
                     const tb_f2 gg = pg2[rr & 1][p], bb = pb2[rr & 1][p];
-                    *reinterpret_cast<tb_f2*>(y2_out + rbase + cp) =
+                    *reinterpret_cast<tb_f2*>(y2_out + sb + (unsigned)(rbase + cp)) =
                         tb_f2{(y[2 * p] - mean2) * rstd2 * gg[0] + bb[0], (y[2 * p + 1] - mean2) * rstd2 * gg[1] + bb[1]};
                 }
             }
             if (lane == 0) {
-                mu2_out[(long long)b * TB_L + r] = mean2;
-                rs2_out[(long long)b * TB_L + r] = rstd2;
+                (mu2_out + (long long)b * TB_L)[(unsigned)r] = mean2;
+                (rs2_out + (long long)b * TB_L)[(unsigned)r] = rstd2;
             }
         }
     }
@@ -587,7 +639,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_V + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_V + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         const long long id = a.ids ? a.ids[b] : 0;
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             f32x4 o;
@@ -658,7 +710,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
                 const f32x4 c = ctxr[rd][dt];
-                if (d0 < TB_E && !(a.dbg & 1u)) tb_st4(a.ctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, c);
+                if (d0 < TB_E && !(a.dbg & 1u)) tb_st4(a.ctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, c);
                 tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, 64 * head + d0), c[0], c[1], c[2], c[3]);
             }
         }
@@ -669,7 +721,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     // ---- S4: output projection + bias -> XF      (SelfAttention_Family.py:213)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_O + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_O + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             const f32x4 bias = tb_ld4(a.bo + n0, valid);
             f32x4 o;
@@ -689,25 +741,26 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     // ---- S6: FFN 1 + bias -> f1 (pre-activation, kept for the backward), g1 = dropout(gelu(f1))      (Transformer_EncDec.py:48)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         f32x4 bias1[2];                                              // (loads before the first store: see tb_ln_rows)
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias1[j] = *reinterpret_cast<const f32x4*>(a.b1 + 32 * w + 16 * j + 4 * g);
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             const f32x4 bias = bias1[(n0 >> 4) & 1];
-            const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
+            const long long ob = (long long)b * (TB_L * TB_FF);          // uniform: the stores take it as a scalar base + a 32-bit lane offset
+            const unsigned ol = (unsigned)(m * TB_FF + n0);
             f32x4 f, gq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) f[i] = v[i] + bias[i];
-            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.f1 + o) = f;
+            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.f1 + ob + ol) = f;
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
+            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)ob + ol, a.drop_p, keep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float ge = gelu_erf(f[i]);
                 gq[i] = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
             }
-            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.g1 + o) = gq;
+            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.g1 + ob + ol) = gq;
             v = gq;
         });
         raw_barrier();                                               // every wave is done with the n1 planes
@@ -721,7 +774,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     // ---- S7: FFN 2 + bias; the result replaces the (dead) g1 planes as an fp32 image      (Transformer_EncDec.py:49)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         raw_barrier();
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             const f32x4 bias = tb_ld4(a.b2 + n0, valid);
@@ -894,7 +947,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     // ---- T2: dg1 = df2 W2, then the FFN activation's dropout' and gelu' (pre-activation f1 from HBM): df1 -> HBM (the dW1 GEMM reads it) + planes
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         f32x4 fpre[4][2];                                            // the pre-activations of this lane's 8 groups: loaded before the first store
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -923,7 +976,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     // ---- T3: dn1 = dr2 + df1 W1 (in place in XF)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_1T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_1T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             f32x4* p = reinterpret_cast<f32x4*>(XF + xf_off(m, n0));
             f32x4 o = *p;
@@ -998,7 +1051,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     // ---- T5: dctx = da1 Wo -> HBM, natural (row, 248) layout (the packed operand's columns are 64 head + d)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u>(AP, a.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, 256, acc, [&](int m, int n0, int valid, f32x4& v) {
             const int head = n0 >> 6, d0 = n0 & 63;
             if (d0 < TB_E) tb_st4(a.dctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, v);
@@ -1040,8 +1093,8 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
             }
         }
         raw_barrier();
-        if (which == 0) tb_gemm<2, 3u, 2, true>(AP, a.packed + TB_OFF_QT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-        else tb_gemm<2, 3u, 2, false>(AP, a.packed + TB_OFF_QT + which * TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        if (which == 0) tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_QT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        else tb_gemm<2, 3u, TB_BWD_PF, false, true>(AP, a.packed + TB_OFF_QT + which * TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
     }
     // + the residual-path gradient, then the embedding dropout' over the flat sample (one Philox block = 4 consecutive flat elements)
     tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {

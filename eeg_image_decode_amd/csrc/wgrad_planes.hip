@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const wgrad_args a) {
     if (nk > 1) gload(kt0 + 1, ring[1]);
     if (nk > 2) gload(kt0 + 2, ring[2]);
     if (nk > 0) {
-        wait_tile(nk > 2 ? 2 : nk - 1, ring[0]);
+        // ONE wait form here (everything issued so far): with the three-way choice of wait_tile() the compiler gave the vmcnt(0) branch other
+        // registers for the "+v" operands and COPIED the in-flight ring registers into them ahead of the wait (tests/test_asm_rings.py)
+        wait_tile(0, ring[0]);
         lstore(0, ring[0]);
     }
     raw_barrier();
