@@ -159,7 +159,7 @@ template <bool VEC2>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const attn_args a, float* __restrict__ ctx /* (B*L, H*E) */) {
     EEG_LDS_BASE(float, lds);
     float *Qs = lds, *Ks = lds + AT_T, *Vs = lds + 2 * AT_T, *Ps = lds + 3 * AT_T;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_uniform(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int HE = a.H * a.E;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const attn_args a, c
     EEG_LDS_BASE(float, lds);
     float *Qs = lds, *Ks = lds + AT_T, *Vs = lds + 2 * AT_T, *Ds = lds + 3 * AT_T;
     float *Ps = Vs, *Ss = Ds;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_uniform(threadIdx.x >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int HE = a.H * a.E;

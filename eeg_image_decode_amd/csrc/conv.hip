@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void tsconv_fwd_kernel(const float* __restrict
     float* sl = wl + TS_KP * TS_CP;              // [32][256] box-filtered rows
     float* ps = sl + TSF_R * TS_XS;              // [4][256]  per-wave prefix scratch
     float* sc = ps + 4 * TS_XS;                  // [4][2][48] per-wave channel sums
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
     for (int i = t; i < TS_KP * TS_CP; i += blockDim.x) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void tsconv_bwd_w_kernel(const float* __restri
     float* sl = dl + TS_CP * MS;                 // [R][256]  box-filtered token rows
     float* ps = sl + R * TS_XS;                  // [4][256]
     float* red = dl;                             // 2 x [48][36] cross-wave reduction scratch (after the last item)
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int per = (H + R - 1) / R;             // work items per sample
     f32x4 acc[3][2];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 4) void tsconv_bwd_x_kernel(const float* __res
     float* dl = wl + TS_C * TSX_WL;              // [CH][TSX_CS]  dy slab: dl[c][w][row]
     float* ps = dl + CH * TSX_CS;                // [4][256]  prefix scratch
     float* dsl = dl;                             // [16][256] dS rows (aliases the slab once the accumulation is done)
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int rows = B * H;
     for (int i = t; i < TS_C * TSX_WL; i += 256) wl[i] = (i % TSX_WL) < TS_K1 ? w25[(i / TSX_WL) * TS_K1 + i % TSX_WL] : 0.f;

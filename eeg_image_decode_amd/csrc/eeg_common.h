@@ -253,6 +253,17 @@ __device__ __forceinline__ long long dim_off(const eegclip_dim& d, int i) {
     return (long long)(i / dv) * d.so + (long long)(i % dv) * d.si;
 }
 
+// a value every lane of the wave agrees on, made provably so for the compiler (scalar branches, SGPR addressing): the wave index
+// threadIdx.x >> 6 is uniform, but the compiler only knows that of values it can trace to SGPRs -- without this, everything derived from it (task
+// indices, row bases, 64-bit addresses) is computed per lane on the vector ALU
+__device__ __forceinline__ int wave_uniform(int v) {
+#if defined(EEG_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // ---- Philox4x32-10 counter-based RNG: dropout masks are a pure function of (seed, site, element) so the
 //      backward pass regenerates them instead of storing them ----
 struct philox4 { unsigned x, y, z, w; };

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const eegclip_gemm_
     float* Bs = lds + G_BK * G_BT;      // [G_BK][64]
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * G_BT, n0 = blockIdx.x * G_BT;
     int kt_begin, kt_end;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void gemm_f32_fast_body(const eegclip_gemm_desc& d, i
     }
     const int m0 = (logical / gx) * G_BT, n0 = (logical % gx) * G_BT;
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
     int kt_begin, kt_end;
@@ -384,7 +384,7 @@ constexpr int SK_N = 16;
 template <int MB>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_f32_skinny_kernel(const eegclip_gemm_desc d) {
     EEG_LDS_BASE(float, lds);                                   // [wave][MB][lane] float4 partial accumulators
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * SK_N;
     const int nrow = n0 + fr < d.N ? n0 + fr : d.N - 1;         // clamped rows: their products land in columns / rows nobody stores

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_
     }
     const int m0 = (logical / gx) * BT, n0 = (logical % gx) * BT;
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = wave_uniform(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
     int kt_begin, kt_end;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm
         if (slice >= d.split_k) return;
     }
     const int m0 = (logical / gx) * XP_BM, n0 = (logical % gx) * XP_BN;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
     int kt_begin, kt_end;

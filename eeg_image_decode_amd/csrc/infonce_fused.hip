@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     const int rem = (int)blockIdx.x - prob * tiles;
     const if_problem& P = tb.p[prob];
     const int q0 = (rem / tiles_k) * TM, k0r = (rem % tiles_k) * TM;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
     const int wq = wave >> 1, wk = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
 

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                              int rows, int cols, float eps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const float inv = 1.0f / (float)cols;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (long long)row * cols;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
                                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                                       float* __restrict__ y2, float* __restrict__ mean2_out, float* __restrict__ rstd2_out,
                                                                       int rows, int cols, float eps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     for (int i = 0; i < (PART ? NG : 1); ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pgam[i][e] = 0.f; pbet[i][e] = 0.f; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     auto ld4 = [&](const float* p, int c, float (&v)[4]) {       // 4 consecutive columns starting at c (c % 4 == 0), zero past `cols`
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_kernel(const float* _
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols) {
     EEG_LDS_BASE(float, red);   // [2][4][64]
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, g = wave_uniform(threadIdx.x >> 6);
     const int c = blockIdx.y * 64 + lane;
     float pg = 0.f, pb = 0.f;
     if (c < cols) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_stage1_kernel(const f
                                                                           float* __restrict__ partials, int rows, int cols) {
     EEG_LDS_BASE(float, red);   // [3 waves][2][NG * 256]
     constexpr int W = NG * 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     float pg[NG][4], pb[NG][4];
 #pragma unroll
     for (int i = 0; i < NG; ++i)
@@ -444,7 +444,7 @@ constexpr int LNP_SLICES = 16;
 __global__ __launch_bounds__(256) void layernorm_bwd_param_stage2_kernel(const float* __restrict__ partials, int nparts, int cols,
                                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     EEG_LDS_BASE(float, red);   // [4][64]
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, g = wave_uniform(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane;                    // column of the [dgamma | dbeta] partial row
     float s = 0.f;
     if (c < 2 * cols) {

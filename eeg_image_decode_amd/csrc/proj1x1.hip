@@ -140,7 +140,7 @@ constexpr int PJ_SLICES = 8;
 __global__ __launch_bounds__(256) void proj1x1_bwd_reduce_kernel(const double* __restrict__ partials, int nparts, float* __restrict__ dW,
                                                                   float* __restrict__ dbias, double* __restrict__ sums) {
     EEG_LDS_BASE(double, red);   // [4][64]
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, g = wave_uniform(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane;
     double s = 0.0;
     if (c < PJ_PART) {

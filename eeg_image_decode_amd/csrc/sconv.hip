@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     float* zl = lds;                          // [128][52]      z1[k0 + kk][w]   (cols >= 36 zero)
     float* aff = zl + SCF_KC * SCF_LZ;        // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
     float* red = lds;                         // 2 x [48][52] cross-wave reduction scratch, aliases the activation tile after the last chunk
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int K = SC_C * H;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restri
     unsigned char* zp = reinterpret_cast<unsigned char*>(lds);     // planes hi | lo of z1^T[w][k0 + kk]
     float* aff = lds + 2 * SFX_PLANE / 4;                           // [2][40]
     float* red = lds;                                               // 2 x [48][52] reduction scratch, aliases the planes after the last chunk
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int K = SC_C * H;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restric
     float* zl = lds;                          // [NS][37]  z1[n0 + n][w]
     float* dl = zl + NS * SCW_L;              // [48][37]   dy2[o][w]   (rows >= 40 zero)
     float* aff = dl + SC_OP * SCW_L;          // [2][40]
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int K = SC_C * H;
     const int n0 = blockIdx.x * NS, bg = blockIdx.y;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_x3_kernel(const float* __rest
     unsigned char* zp = reinterpret_cast<unsigned char*>(lds);   // z1 planes hi | lo   [NS n][64 w]
     unsigned char* dp = zp + 2 * ZPL;                            // dy2 planes hi | lo  [48 o][64 w]
     float* aff = reinterpret_cast<float*>(dp + 2 * DPL);         // [2][40]
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int K = SC_C * H;
     const int n0 = blockIdx.x * NS, bg = blockIdx.y;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void sconv_bwd_ws_x3_kernel(const float* __
     unsigned char* tp = dp + 2 * DPL;                            // dy2^T planes hi | lo  [48 w][64 o]
     float* aff = reinterpret_cast<float*>(tp + 2 * DPL);         // [4][40]  sc | sh | mean | rstd
     float* sl = aff + 4 * SC_C;                                  // [2][40]  per-workgroup channel sums
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int K = SC_C * H;
     const int n0 = blockIdx.x * NS, bg = blockIdx.y;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restric
     float* dl = lds;                          // !X3: [40][48] dy2[o][w] (cols >= 36 zero)   X3: two bf16 planes [48 w][144 B] of dy2^T
     float* sl = dl + (X3 ? 2 * SC_OP * SCX_RS / 4 : SC_C * SC_OP);            // [80] per-workgroup channel sums
     unsigned char* dplane = reinterpret_cast<unsigned char*>(lds);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     if (X3) {

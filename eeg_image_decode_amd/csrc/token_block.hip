@@ -56,15 +56,6 @@ constexpr long long TB_OFF_OT = TB_OFF_1T + TB_MAT_ELEMS;   // Wo^T   (dctx = da
 constexpr long long TB_OFF_QT = TB_OFF_OT + TB_MAT_ELEMS;   // Wq^T | Wk^T | Wv^T (dh = dq Wq + dk Wk + dv Wv), k = 64 head + d: three operands
 constexpr long long TB_PACKED_ELEMS = TB_OFF_QT + 3 * TB_MAT_ELEMS;
 
-// a value every lane of the wave agrees on, made provably so for the compiler (scalar branches, SGPR addressing)
-__device__ __forceinline__ int wave_uniform(int v) {
-#if defined(EEG_EMU)
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
-
 typedef float tb_f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte global access from a dword-aligned address
 typedef float tb_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned tb_u4 __attribute__((ext_vector_type(4)));
