@@ -98,7 +98,7 @@ def pmc_traffic(family, B):
     return (round(d["hbm_bytes_per_launch"]), PMC_SUMMARY) if d and "hbm_bytes_per_launch" in d else (None, None)
 
 
-TIME_EVERY = 4
+TIME_EVERY = 8
 
 
 def family_of(name, desc):

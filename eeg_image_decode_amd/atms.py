@@ -14,6 +14,7 @@ arithmetic in hand-written HIP kernels reached through the C ABI (include/eegcli
 * There is no CPU / eager-PyTorch fallback: a CPU tensor or a missing library raises.
 """
 import os
+import weakref
 import ctypes
 import math
 
@@ -22,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from ._lib import EegclipError, lib, require_cuda
+from ._lib import EegclipError, lib, raw_stream, require_cuda
 from .loss import ClipLoss
 from .plan import Plan
 
@@ -377,6 +378,7 @@ class _Engine:
         self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.anchor = torch.zeros(1, device=dev, requires_grad=True)     # makes autograd call _AtmsFn.backward
         self._clear_for = self._attached = None          # see attach_grads / grads_cleared
+        self._live_cache, self._attached_ptrs = {}, {}
         self.P, self.G, self.params = {}, {}, {}
         for k in order:
             p = sd_params[k]
@@ -387,6 +389,7 @@ class _Engine:
             self.P[k] = view
             self.G[k] = self.gflat[offs[k]:offs[k] + n].view(p.shape)
             self.params[k] = p
+            p._eegclip_grad_owner = weakref.ref(self)         # lets optim.AdamW.step(zero_grad=True) tell this engine that its buffer is clear
         n_live = offs[_TOK_TABLE]
         self.segments = [(0, n_live, list(live)),
                          (offs[_TOK_TABLE], sd_params[_TOK_TABLE].numel(), [_TOK_TABLE]),
@@ -985,7 +988,7 @@ class _Engine:
         b["seed"] = seed
         out = torch.empty(B, P_DIM, dtype=torch.float32, device=self.device)
         pl.set_arg(pl.out_op, 8, out.data_ptr())
-        pl.run(torch.cuda.current_stream().cuda_stream, seed)
+        pl.run(raw_stream(), seed)
         if getattr(pl, "clears_zb", False):
             b["zb_clean"] = True
         self.last_key = key
@@ -995,39 +998,57 @@ class _Engine:
     def attach_grads(self, shared, subjects=()):
         """Make p.grad views of the flat gradient buffer for every parameter that receives a gradient; zero the
         buffer if the optimizer cleared the grads (zero_grad(set_to_none=True) is torch's default)."""
-        live = self.live_base + [_TOK_SHARED if shared else _TOK_TABLE]
-        if self.joint:
-            everyone = _dp_world() > 1     # ranks must step the same parameters
-            live = live + [k for s in (range(self.n_subj) if everyone else sorted(subjects)) for k in self.ve_keys[s]]
-        mine = lambda k: self.params[k].grad is not None and self.params[k].grad.data_ptr() == self.G[k].data_ptr()
-        if all(mine(k) for k in live):
+        lk = (shared, tuple(sorted(subjects)) if self.joint else (), _dp_world() > 1 if self.joint else False)
+        cached = self._live_cache.get(lk)
+        if cached is None:
+            live = self.live_base + [_TOK_SHARED if shared else _TOK_TABLE]
+            if self.joint:
+                everyone = lk[2]               # ranks must step the same parameters
+                live = live + [k for s in (range(self.n_subj) if everyone else sorted(subjects)) for k in self.ve_keys[s]]
+            if len(self._live_cache) > 256:
+                self._live_cache.clear()
+            # (parameter, its gradient view) pairs, once per live set: this runs on every backward
+            cached = self._live_cache[lk] = (tuple(live), [(self.params[k], self.G[k]) for k in live])
+        live, pairs = cached
+        # one pass: mine (already the flat-buffer view) | None | foreign (written by somebody else before this backward ran)
+        n_mine, foreign, rest = 0, [], []
+        for p, g in pairs:
+            pg = p.grad
+            if pg is g or (pg is not None and pg.data_ptr() == g.data_ptr()):
+                n_mine += 1
+            else:
+                rest.append((p, g))
+                if pg is not None:
+                    foreign.append((g, pg))
+        if not rest:
             self._clear_for = None
             return False                                   # accumulating onto existing gradients
-        foreign = {k: self.params[k].grad for k in live if self.params[k].grad is not None and not mine(k)}
-        if all(self.params[k].grad is None or k in foreign for k in live):
-            if self._clear_for != tuple(live):             # (an optimizer step that cleared exactly these gradients behind its reads: nothing to do)
+        if n_mine == 0:
+            if self._clear_for != live:                    # (an optimizer step that cleared exactly these gradients behind its reads: nothing to do)
                 self.gflat.zero_()                         # the common case after optimizer.zero_grad(): one memset
         else:
-            for k in live:
-                if not mine(k):
-                    self.G[k].zero_()
+            for p, g in rest:
+                g.zero_()
         self._clear_for = None
-        for k, g in foreign.items():                       # e.g. logit_scale.grad written by the loss before this backward ran
-            self.G[k].copy_(g)
-        import weakref
-        me = weakref.ref(self)
-        for k in live:
-            self.params[k].grad = self.G[k]
-            self.params[k]._eegclip_grad_owner = me
-        self._attached = tuple(live)
+        for g, pg in foreign:                              # e.g. logit_scale.grad written by the loss before this backward ran
+            g.copy_(pg)
+        for p, g in rest:
+            p.grad = g
+        self._attached = live
         return True
 
     def grads_cleared(self, grad_ptrs):
         """an optimizer step (optim.AdamW.step(zero_grad=True)) has zeroed the gradients at these addresses behind its reads: if they are exactly
         the views attached by the last backward, the next attach_grads() need not clear the flat buffer again"""
         att = getattr(self, "_attached", None)
-        if att and {self.G[k].data_ptr() for k in att} <= set(grad_ptrs):
-            self._clear_for = att
+        if att:
+            mine = self._attached_ptrs.get(att)
+            if mine is None:
+                if len(self._attached_ptrs) > 256:
+                    self._attached_ptrs.clear()
+                mine = self._attached_ptrs[att] = frozenset(self.G[k].data_ptr() for k in att)
+            if mine <= (grad_ptrs if isinstance(grad_ptrs, (set, frozenset)) else set(grad_ptrs)):
+                self._clear_for = att
 
     def backward(self, key, x, dout, want_dx):
         B, train, shared, probs, W = key
@@ -1050,5 +1071,5 @@ class _Engine:
         if not b["zb_clean"]:                   # an eval-mode forward, or a second backward through one forward: clear the arena here
             b["zb"].zero_()
         b["zb_clean"] = False
-        pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
+        pl.run(raw_stream(), b.get("seed", 0))
         return b["dx"].clone() if want_dx else None

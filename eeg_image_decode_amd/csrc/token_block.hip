@@ -881,11 +881,12 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = 4 * lane - ((rr & 1) ? 2 : 0) + 2 * p;
-                const long long o = ((long long)b * TB_L + 8 * w + rr) * TB_D + cp;
+                const long long sb = (long long)b * (TB_L * TB_D);           // uniform sample base + a 32-bit lane offset (see tb_ln_rows)
+                const unsigned o = (unsigned)((8 * w + rr) * TB_D + cp);
                 const bool okc = cp >= 0 && cp < TB_D;
-                in_dy[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.dn3 + o) : tb_f2{0.f, 0.f};
-                in_r2[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.r2 + o) : tb_f2{0.f, 0.f};
-                in_n2[rr][p] = (okc && a.n2) ? *reinterpret_cast<const tb_f2*>(a.n2 + o) : tb_f2{0.f, 0.f};
+                in_dy[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.dn3 + sb + o) : tb_f2{0.f, 0.f};
+                in_r2[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.r2 + sb + o) : tb_f2{0.f, 0.f};
+                in_n2[rr][p] = (okc && a.n2) ? *reinterpret_cast<const tb_f2*>(a.n2 + sb + o) : tb_f2{0.f, 0.f};
             }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr2[2 * p] * ksc : 0.f) : dr2[2 * p];
                 const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr2[2 * p + 1] * ksc : 0.f) : dr2[2 * p + 1];
                 if (ok[p]) {
-                    *reinterpret_cast<tb_f2*>(a.df2 + rbase + cp) = tb_f2{d0, d1};
+                    *reinterpret_cast<tb_f2*>(a.df2 + rbase + (unsigned)cp) = tb_f2{d0, d1};
                     *reinterpret_cast<tb_f2*>(XF + xf_off(r, cp)) = tb_f2{dr2[2 * p], dr2[2 * p + 1]};
                 }
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
@@ -944,18 +945,19 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                fpre[mt][j] = *reinterpret_cast<const f32x4*>(a.f1 + ((long long)b * TB_L + 16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4));
+                fpre[mt][j] = *reinterpret_cast<const f32x4*>(a.f1 + (long long)b * (TB_L * TB_FF) + (unsigned)((16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4)));
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
-            const long long o = ((long long)b * TB_L + m) * TB_FF + n0;
+            const long long ob = (long long)b * (TB_L * TB_FF);
+            const unsigned ol = (unsigned)(m * TB_FF + n0);
             const f32x4 f = fpre[m >> 4][(n0 >> 4) & 1];
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)o, a.drop_p, keep);
+            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)ob + ol, a.drop_p, keep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float d = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? v[i] * ksc : 0.f) : v[i];
                 v[i] = d * gelu_erf_grad(f[i]);
             }
-            *reinterpret_cast<f32x4*>(a.dg1 + o) = v;
+            *reinterpret_cast<f32x4*>(a.dg1 + ob + ol) = v;
         });
         raw_barrier();                                               // every wave is done with the df2 planes
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = 4 * lane - ((rr & 1) ? 2 : 0) + 2 * p;
-                in_r1[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.r1 + ((long long)b * TB_L + 8 * w + rr) * TB_D + cp) : tb_f2{0.f, 0.f};
+                in_r1[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.r1 + (long long)b * (TB_L * TB_D) + (unsigned)((8 * w + rr) * TB_D + cp)) : tb_f2{0.f, 0.f};
             }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -1027,8 +1029,8 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr1[2 * p] * ksc : 0.f) : dr1[2 * p];
                 const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr1[2 * p + 1] * ksc : 0.f) : dr1[2 * p + 1];
                 if (ok[p]) {
-                    *reinterpret_cast<tb_f2*>(a.dr1 + rbase + cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
-                    *reinterpret_cast<tb_f2*>(a.da1 + rbase + cp) = tb_f2{d0, d1};
+                    *reinterpret_cast<tb_f2*>(a.dr1 + rbase + (unsigned)cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
+                    *reinterpret_cast<tb_f2*>(a.da1 + rbase + (unsigned)cp) = tb_f2{d0, d1};
                 }
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
             }
@@ -1045,7 +1047,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
         tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, 256, acc, [&](int m, int n0, int valid, f32x4& v) {
             const int head = n0 >> 6, d0 = n0 & 63;
-            if (d0 < TB_E) tb_st4(a.dctx + ((long long)b * TB_L + m) * TB_HE + head * TB_E + d0, TB_E - d0 >= 4 ? 4 : 2, v);
+            if (d0 < TB_E) tb_st4(a.dctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, v);
         });
     }
 }
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
         for (int j = 0; j < 16; ++j) {
             const int u = t + TB_THREADS * j;                        // pair index: row = u / 124, pair = u % 124
             const int row = u / 124, c = 2 * (u - 124 * row);
-            v[j] = u < 64 * 124 ? *reinterpret_cast<const tb_f2*>(a.dqkv + ((long long)b * TB_L + row) * (3 * TB_HE) + which * TB_HE + c) : tb_f2{0.f, 0.f};
+            v[j] = u < 64 * 124 ? *reinterpret_cast<const tb_f2*>(a.dqkv + (long long)b * (TB_L * 3 * TB_HE) + (unsigned)(row * (3 * TB_HE) + which * TB_HE + c)) : tb_f2{0.f, 0.f};
         }
         if (which > 0) raw_barrier();                                // the previous operand's GEMM has read the planes
 #pragma unroll
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
     }
     // + the residual-path gradient, then the embedding dropout' over the flat sample (one Philox block = 4 consecutive flat elements)
     tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
-        const f32x4 r = tb_ld4(a.dr1 + ((long long)b * TB_L + m) * TB_D + n0, valid);
+        const f32x4 r = tb_ld4(a.dr1 + (long long)b * (TB_L * TB_D) + (unsigned)(m * TB_D + n0), valid);
         f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = i < valid ? r[i] + v[i] : 0.f;

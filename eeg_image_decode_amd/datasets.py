@@ -24,7 +24,7 @@ import pickle
 import numpy as np
 import torch
 
-from ._lib import EegclipError, check, lib, require_cuda
+from ._lib import EegclipError, check, lib, raw_stream, require_cuda
 
 model_type = "ViT-H-14"                                   # eegdatasets_leaveone.py:17
 _CHUNK_BYTES = 1 << 29                                    # float64 staging chunk (host -> HBM -> eegclip_stage_eeg)
@@ -37,7 +37,7 @@ def load_config(path="data_config.json"):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return raw_stream()
 
 
 def _listing(directory):

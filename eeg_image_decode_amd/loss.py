@@ -18,13 +18,13 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from ._lib import check, lib, require_cuda
+from ._lib import check, lib, raw_stream, require_cuda
 
 D = _abi.dim
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return raw_stream()
 
 
 def _gemm(M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, alpha=1.0, accumulate=0, split_k=1, precision=0):

@@ -12,13 +12,14 @@ them, so ``state_dict()`` / ``load_state_dict()`` carry step, exp_avg and exp_av
 """
 import torch
 
-from ._lib import EegclipError, check, lib, require_cuda
+from ._lib import EegclipError, check, lib, raw_stream, require_cuda
 
 
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._runs_cache = {}
+        self._fast = {}              # param group index -> the previous step's launches (see step())
         self._moments = {}           # storage base ptr -> (m, v) shaped like the whole flat storage
         self.grad_scale_dev = None   # optional device scalar multiplied into every gradient (clipping)
 
@@ -50,6 +51,7 @@ class AdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._runs_cache.clear()                          # the loaded moments are linked (copied into the flat buffers) at the next step
+        self._fast.clear()
 
     supports_step_and_zero_grad = True
 
@@ -61,10 +63,29 @@ class AdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         L = lib()
         fn = L.eegclip_adamw_step_zero_grad if zero_grad else L.eegclip_adamw_step
+        stream = raw_stream()
+        gs = self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None
         cleared = []
-        stream = torch.cuda.current_stream().cuda_stream
-        for group in self.param_groups:
-            live = [p for p in group["params"] if p.grad is not None]
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            grads = [p.grad for p in params]
+            fast = self._fast.get(gi)
+            b1, b2 = group["betas"]
+            # steady state of a training loop: the very same gradient tensors as at the previous step (views of a flat gradient buffer; the cache
+            # holds them, so an equal id is the same object): every check below already passed and the launches are unchanged -- ~100 us of
+            # per-parameter bookkeeping per step otherwise.  Per-parameter step counts are brought up to date lazily (_flush_steps).
+            if fast is not None and len(grads) == len(fast["grads"]) and all(a is b for a, b in zip(grads, fast["grads"])) and \
+                    all(p0.grad.data_ptr() == gp and p0.data_ptr() == wp for (p0, n, wp, gp, mp, vp) in fast["launch"]):
+                fast["step"] += 1
+                fast["pending"] += 1
+                for (p0, n, wp, gp, mp, vp) in fast["launch"]:
+                    check(fn(wp, gp, mp, vp, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], fast["step"], 1.0, gs, stream), "adamw_step")
+                if zero_grad:
+                    for own, ptrs in fast["owners"]:
+                        own.grads_cleared(ptrs)
+                continue
+            self._flush_steps(gi)
+            live = [p for p in params if p.grad is not None]
             if not live:
                 continue
             for p in live:
@@ -76,7 +97,7 @@ class AdamW(torch.optim.Optimizer):
             steps = {self.state[p]["step"] for p in live}
             ck = (id(group), tuple((id(p), p.data_ptr(), p.grad.data_ptr()) for p in live))
             if len(steps) == 1 and ck in self._runs_cache:
-                st = steps.pop()
+                st = next(iter(steps))
                 runs = [(p0, n, st) for (p0, n) in self._runs_cache[ck]]
             else:
                 self._link_state(live)
@@ -85,29 +106,44 @@ class AdamW(torch.optim.Optimizer):
                     self._runs_cache.clear()
                 if len(steps) == 1:
                     self._runs_cache[ck] = [(p0, n) for (p0, n, _) in runs]
-            b1, b2 = group["betas"]
+            launch = []
             for (p0, n, step) in runs:
                 m, v = self._moments_for(p0)
                 off = (p0.data_ptr() - p0.untyped_storage().data_ptr()) // 4
-                rc = fn(p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, n,
-                        group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0,
-                        self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None, stream)
-                check(rc, "adamw_step")
-            if zero_grad:
-                cleared += live
-        if zero_grad:
+                launch.append((p0, n, p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off))
+                check(fn(*launch[-1][2:], n, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0, gs, stream), "adamw_step")
             owners = {}
-            for p in cleared:
+            for p in live:
                 own = getattr(p, "_eegclip_grad_owner", None)
                 own = own() if own is not None else None
                 if own is not None:
                     owners.setdefault(id(own), (own, []))[1].append(p.grad.data_ptr())
-            for own, ptrs in owners.values():
-                own.grads_cleared(ptrs)
+            owners = [(own, frozenset(ptrs)) for own, ptrs in owners.values()]
+            if zero_grad:
+                for own, ptrs in owners:
+                    own.grads_cleared(ptrs)
+            if len(steps) == 1:
+                self._fast[gi] = dict(grads=grads, live=live, launch=launch, owners=owners, step=next(iter(steps)), pending=0)
+            else:
+                self._fast.pop(gi, None)
+        if zero_grad:
             for group in self.param_groups:                  # zero_grad(set_to_none=True) for every parameter, stepped or not
                 for p in group["params"]:
                     p.grad = None
         return loss
+
+    def _flush_steps(self, gi=None):
+        """bring state[p]["step"] up to date with the steps taken on the fast path"""
+        for g in ([gi] if gi is not None else list(self._fast)):
+            fast = self._fast.get(g)
+            if fast and fast["pending"]:
+                for p in fast["live"]:
+                    self.state[p]["step"] += fast["pending"]
+                fast["pending"] = 0
+
+    def state_dict(self):
+        self._flush_steps()
+        return super().state_dict()
 
     def _make_runs(self, live):
         """maximal runs of parameters that are contiguous (up to 12 bytes of alignment padding) in BOTH the weight and

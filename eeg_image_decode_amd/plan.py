@@ -15,7 +15,7 @@ import ctypes
 import os
 
 from . import _abi
-from ._lib import check, lib
+from ._lib import check, cuda_available, current_stream, lib, use_stream
 
 D = _abi.dim
 
@@ -231,11 +231,11 @@ class Plan:
                 arr[i].flags |= _abi.PLAN_SKIP
             self._c_skip = self.skip
         side = side2 = None
-        if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
+        if self.use_side_stream and cuda_available() and self._uses_side():
             if self._side is None:
                 self._side = (torch.cuda.Stream(priority=_SIDE_PRIORITY), None, None)
             side = self._side[0]
-            if any(op[3] == 2 for op in self.ops):                # a second side stream: independent weight-gradient GEMMs side by side
+            if self._side_kinds[1]:                               # a second side stream: independent weight-gradient GEMMs side by side
                 if self._side2 is None:
                     self._side2 = torch.cuda.Stream(priority=_SIDE_PRIORITY)
                 side2 = self._side2
@@ -253,7 +253,7 @@ class Plan:
                     continue
                 fn = self.ops[idx][1][0]
                 if on_side and side is not None:                  # behind everything enqueued on ALL streams so far
-                    ts = torch.cuda.current_stream()
+                    ts = current_stream()
                     e = torch.cuda.Event()
                     e.record(ts)
                     side.wait_event(e)
@@ -261,7 +261,7 @@ class Plan:
                         e2 = torch.cuda.Event()
                         e2.record(side2)
                         side.wait_event(e2)
-                    with torch.cuda.stream(side):
+                    with use_stream(side):
                         fn()
                     c["dirty"].value |= 1
                 else:
@@ -269,12 +269,19 @@ class Plan:
         if c["dirty"].value and side is not None:                 # (a trailing side-stream callback: join here)
             e = torch.cuda.Event()
             e.record(side)
-            torch.cuda.current_stream().wait_event(e)
+            current_stream().wait_event(e)
             if side2 is not None and (c["dirty"].value & 2):
                 e2 = torch.cuda.Event()
                 e2.record(side2)
-                torch.cuda.current_stream().wait_event(e2)
+                current_stream().wait_event(e2)
             c["dirty"].value = 0
+
+    def _uses_side(self):
+        """does any op run on a side stream (and on the second one)?  Asked per run: cached per op count (plans only grow while they are built)"""
+        k = getattr(self, "_side_kinds", None)
+        if k is None or k[2] != len(self.ops):
+            k = self._side_kinds = (any(op[3] for op in self.ops), any(op[3] == 2 for op in self.ops), len(self.ops))
+        return k[0]
 
     def time_ops(self, indices, every=1):
         """record a HIP event pair around the given ops on every `every`-th run (bench.py roofline / per-kernel breakdown); the other runs go
@@ -317,12 +324,12 @@ class Plan:
             self.ops[i][1][j] = seed
         import torch
         side = None
-        if self.use_side_stream and torch.cuda.is_available() and any(op[3] for op in self.ops):
+        if self.use_side_stream and cuda_available() and self._uses_side():
             if self._side is None or self._side[1] is None:        # (the C executor keeps only the stream: it owns its own events)
                 st_side = self._side[0] if self._side is not None else torch.cuda.Stream(priority=_SIDE_PRIORITY)
                 self._side = (st_side, {i: torch.cuda.Event() for i, op in enumerate(self.ops) if op[3]}, torch.cuda.Event())
             side = self._side
-        ts = torch.cuda.current_stream() if (timed or side) else None
+        ts = current_stream() if (timed or side) else None
         dirty = False                                    # side stream has work the main stream has not waited for
         skip = self.skip
         for idx, (fn, args, name, on_side) in enumerate(self.ops):
@@ -350,7 +357,7 @@ class Plan:
                     ev = side[1][idx]
                     ev.record(ts)
                     side[0].wait_event(ev)
-                    with torch.cuda.stream(side[0]):
+                    with use_stream(side[0]):
                         args[0]()
                     dirty = True
                 else:

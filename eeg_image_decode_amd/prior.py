@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch.utils.data import Dataset
 
 from . import _abi
-from ._lib import EegclipError, check, lib, require_cuda
+from ._lib import EegclipError, check, lib, raw_stream, require_cuda
 from .plan import Plan
 
 D = _abi.dim
@@ -362,7 +362,7 @@ class _PriorEngine:
             g.A = c.data_ptr()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
         b["seed"] = seed
-        pl.run(torch.cuda.current_stream().cuda_stream, seed)
+        pl.run(raw_stream(), seed)
         self.last_key = key
         self.version[key] = self.version.get(key, 0) + 1
         return b["out"]
@@ -394,7 +394,7 @@ class _PriorEngine:
         pl.x_gemm.B = x.data_ptr()
         for g in pl.c_gemms:
             g.B = c.data_ptr()
-        pl.run(torch.cuda.current_stream().cuda_stream, b.get("seed", 0))
+        pl.run(raw_stream(), b.get("seed", 0))
 
 
 class EmbeddingDataset(Dataset):
@@ -455,7 +455,7 @@ class DDPMScheduler:
         out = torch.empty_like(h)
         n = h.shape[0]
         check(lib().eegclip_ddpm_add_noise(h.data_ptr(), nz.data_ptr(), timesteps.to(h.device).long().contiguous().data_ptr(), sa.data_ptr(),
-                                           sb.data_ptr(), out.data_ptr(), n, h.numel() // n, torch.cuda.current_stream().cuda_stream), "ddpm_add_noise")
+                                           sb.data_ptr(), out.data_ptr(), n, h.numel() // n, raw_stream()), "ddpm_add_noise")
         return out
 
     def step_coeffs(self, t):
@@ -490,7 +490,7 @@ class DDPMScheduler:
         eu = model_output_uncond
         check(lib().eegclip_ddpm_step(x.data_ptr(), model_output.contiguous().data_ptr(), eu.contiguous().data_ptr() if eu is not None else None,
                                       float(guidance_scale), sa, sb, c0, ct, sigma, noise.data_ptr() if noise is not None else None, out.data_ptr(),
-                                      out_dup.data_ptr() if out_dup is not None else None, x.numel(), torch.cuda.current_stream().cuda_stream),
+                                      out_dup.data_ptr() if out_dup is not None else None, x.numel(), raw_stream()),
               "ddpm_step")
         return self._Out(out)
 
@@ -553,7 +553,7 @@ class Pipe:
                 noise = torch.randn_like(h_embeds)
                 timesteps = torch.randint(0, T, (N,), device=device)
                 perturbed = self.scheduler.add_noise(h_embeds, noise, timesteps)
-                st = torch.cuda.current_stream().cuda_stream
+                st = raw_stream()
                 optimizer.zero_grad()
                 c32 = c_embeds.float().contiguous() if c_embeds is not None else None
                 pred = eng.forward(perturbed, timesteps.float(), c32, prior.drop_p())
@@ -627,7 +627,7 @@ class Pipe:
         cfg = c_embeds is not None
         rows = 2 * N if cfg else N
         hoist, step, b = eng.sampling(rows, S, N if cfg else 0)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = raw_stream()
         if cfg:
             b["c"].copy_(c_embeds)
         hoist.run(stream)

@@ -12,7 +12,7 @@ import re
 import torch
 
 from . import _abi
-from ._lib import check, lib, require_cuda
+from ._lib import check, cuda_available, current_stream, lib, raw_stream, require_cuda, use_stream
 
 D = _abi.dim
 
@@ -23,7 +23,7 @@ def extract_id_from_string(s):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return raw_stream()
 
 
 def scaled_logits(z, feats, precision=_abi.PREC_F32):
@@ -124,11 +124,11 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
     logit_scale = eeg_model.logit_scale
     # running train accuracy (ATMS_retrieval.py:241-250: logits against all class features, argmax, count): it only needs the
     # forward output, so it runs on a second stream underneath the loss / backward / optimizer kernels instead of after them
-    side = _side_stream(eeg_data.device) if torch.cuda.is_available() else None
-    main = torch.cuda.current_stream() if side is not None else None
+    side = _side_stream(eeg_data.device) if cuda_available() else None
+    main = current_stream() if side is not None else None
     if side is not None:
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        with use_stream(side):
             _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
     if objective == "reconstruction":
         # Generation/ATMS_reconstruction.py:222-228 (alpha = 0.9 there): 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img)); the text

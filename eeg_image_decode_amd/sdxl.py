@@ -27,11 +27,11 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from ._lib import EegclipError, check, lib, require_cuda
+from ._lib import EegclipError, check, lib, raw_stream, require_cuda
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return raw_stream()
 
 
 def _dt(t):

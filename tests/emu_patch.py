@@ -18,7 +18,9 @@ def product_on_emulator():
     mods = [m for n, m in sys.modules.items() if n.startswith("eeg_image_decode_amd.")]
     saved = []
     elib = emu.lib()
-    fake = {"lib": (lambda: elib), "require_cuda": (lambda t, name="tensor": t)}
+    dummy = types.SimpleNamespace(cuda_stream=None, wait_event=lambda *a, **k: None, wait_stream=lambda *a, **k: None)
+    fake = {"lib": (lambda: elib), "require_cuda": (lambda t, name="tensor": t), "raw_stream": (lambda: None), "current_stream": (lambda: dummy)}
+    # (use_stream / cuda_available are never reached on CPU: the side-stream paths are guarded by cuda_available(), False here)
     for m in mods:
         for k, v in fake.items():
             if hasattr(m, k):

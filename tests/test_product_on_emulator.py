@@ -129,6 +129,41 @@ def test_step_and_zero_grad_in_one_pass_is_the_plain_loop():
         assert d.max() <= 3 * 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
 
 
+def test_optimizer_fast_path_is_torch_adamw_and_keeps_step_counts():
+    """the steady-state path of optim.AdamW.step (same gradient tensors as the previous step: cached launches, lazily counted steps) against
+    torch.optim.AdamW over 6 steps with a learning-rate change in between; state_dict() reports the true step count"""
+    rng = np.random.default_rng(3)
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim
+        flat, gflat = torch.zeros(300), torch.zeros(300)
+        shapes, off, ps, gs = [(7, 9), (40,), (11, 3)], 0, [], []
+        for sh in shapes:
+            n = int(np.prod(sh))
+            flat[off:off + n] = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+            ps.append(torch.nn.Parameter(flat[off:off + n].view(sh)))
+            gs.append(gflat[off:off + n].view(sh))
+            off += (n + 3) // 4 * 4
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        opt, topt = optim.AdamW(ps, lr=3e-3, weight_decay=0.02), torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.02)
+        for it in range(6):
+            if it == 4:
+                for o in (opt, topt):
+                    o.param_groups[0]["lr"] = 1e-3
+            for p, g, r in zip(ps, gs, ref):
+                g.copy_(torch.from_numpy(rng.standard_normal(tuple(g.shape)).astype(np.float32)))
+                p.grad = g                                   # the SAME tensor objects every step, as the engine attaches them
+                r.grad = g.clone()
+            opt.step(zero_grad=(it % 2 == 1))
+            topt.step()
+            assert (it < 2) or opt._fast[0]["pending"] >= 1  # from the third step on the cached launches are used
+            if it % 2 == 1:
+                assert all(p.grad is None for p in ps) and float(gflat.abs().max()) == 0.0
+        for p, r in zip(ps, ref):
+            np.testing.assert_allclose(p.detach().numpy(), r.detach().numpy(), atol=2e-6, rtol=1e-5)
+        sd = opt.state_dict()["state"]
+        assert [int(sd[i]["step"]) for i in range(3)] == [6, 6, 6]
+
+
 def test_reconstruction_objective_step_under_emulator_matches_oracle():
     """10 * (0.9 MSE + 0.1 image InfoNCE) through contrastive_step(objective="reconstruction"): loss and parameters after one AdamW step"""
     state_np = syn.make_state(SEED, oatms.state_spec())

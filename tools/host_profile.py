@@ -20,7 +20,7 @@ def run(n, step):
 
 def main():
     model, opt, pool, classes = bench.build(1, 0, 256)
-    loss_acc = torch.zeros((), device="cuda")
+    loss_acc = []
     correct = torch.zeros(1, dtype=torch.int32, device="cuda")
 
     def step(i):
