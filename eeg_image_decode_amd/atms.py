@@ -628,10 +628,12 @@ class _Engine:
         pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
                 _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train),
                 _p(self.buffers[_TS + "2.num_batches_tracked"]))
+        if "scf_ws" not in b:          # the K-slice partial tiles of sconv_fwd: slabs summed by the statistics kernel of the same call (no atomics)
+            b["scf_ws"] = torch.empty(int(lib().eegclip_sconv_fwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
         # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
         # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
         pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
-                *fw, _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1)      # y2 lives in the arena cleared above
+                *fw, _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1, _p(b["scf_ws"]))
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),

@@ -36,8 +36,15 @@ struct bn_affine {            // per-channel BatchNorm as y -> xhat -> u: xhat =
 constexpr int SCF_KC = 128;
 constexpr int SCF_KS = 4;
 constexpr int SCF_LZ = 52;             // activation tile row stride
+template <int dbg>
 __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
-                                                         const float* __restrict__ bs, float* __restrict__ y2, int B, int H, int kper) {
+                                                         const float* __restrict__ bs, float* __restrict__ y2, float* __restrict__ slabs, int B, int H,
+                                                         int kper) {
+    // dbg (template; EEGCLIP_SCF_DEBUG selects an instantiation; timing ablation only -- results are wrong with any bit set): 1 no MFMAs, 2 no ELU,
+    // 4 no y1 loads, 8 no weight loads, 32 no LDS stores of the activation tile.  Measured at B = 256 (tools/bench_sconv_fwd.py, us incl. the 5 us
+    // statistics kernel): full 60, no MFMA 42, no loads 46, no LDS stores 46 -- the phases of a chunk (convert + LDS stores | MFMAs + LDS reads | load
+    // latency) add up instead of overlapping: 146 VGPRs + 64 AGPRs leave 2 workgroups per CU.  (Leaving out the epilogue is NOT a valid ablation:
+    // the compiler then drops the MFMAs of the unused accumulators.)
     EEG_LDS_BASE(float, lds);
     float* zl = lds;                          // [128][52]      z1[k0 + kk][w]   (cols >= 36 zero)
     float* aff = zl + SCF_KC * SCF_LZ;        // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
@@ -69,12 +76,12 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int o = 16 * i + fr, k = k0 + 32 * wv + 16 * h + 4 * g;
-                va[i][h] = (o < SC_C && k < kend) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
+                va[i][h] = (o < SC_C && k < kend && !(dbg & 8)) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
             }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int e = 4 * (t + 256 * j), kk = e / SC_W;                          // 128 rows x 9 float4
-            vy[j] = (e < SCF_KC * SC_W && k0 + kk < kend) ? *reinterpret_cast<const f32x4*>(yb + (long long)k0 * SC_W + e) : zero4v;
+            vy[j] = (e < SCF_KC * SC_W && k0 + kk < kend && !(dbg & 4)) ? *reinterpret_cast<const f32x4*>(yb + (long long)k0 * SC_W + e) : zero4v;
         }
     };
     auto store_chunk = [&](int k0) {
@@ -87,9 +94,9 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
                     const int c = (k0 + kk) / H;
                     const float sc = aff[c], sh = aff[SC_C + c];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) z[q] = elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
+                    for (int q = 0; q < 4; ++q) z[q] = (dbg & 2) ? vy[j][q] * sc + sh : elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
                 }
-                *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
+                if (!(dbg & 32)) *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
             }
         }
     };
@@ -115,7 +122,10 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+                    for (int j = 0; j < 3; ++j) {
+                        if (dbg & 1) acc[i][j][0] += a[i][h][s4] * bv[j];
+                        else acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+                    }
             }
     }
     // cross-wave sum of the four k-partial accumulator sets: a two-level tree through LDS with plain stores (waves 2,3 -> 0,1, then
@@ -147,7 +157,9 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
     __syncthreads();
     if (wv == 0) {
         add(red);
-        float* yo = y2 + (long long)b * SC_C * SC_W;
+        // slabs: this K slice's partial tile as plain stores, summed by sconv_merge_stats2_kernel -- the 1440 device-scope float atomics per
+        // workgroup (they execute at the memory side on this multi-XCD part) were 33 of the kernel's 60 us
+        float* yo = slabs ? slabs + ((long long)blockIdx.y * B + b) * SC_C * SC_W : y2 + (long long)b * SC_C * SC_W;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -155,7 +167,11 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * i + 4 * g + r, w = 16 * j + fr;
-                    if (o < SC_C && w < SC_W) atomicAdd(yo + o * SC_W + w, acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f));
+                    if (o < SC_C && w < SC_W) {
+                        const float v = acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f);
+                        if (slabs) yo[o * SC_W + w] = v;
+                        else atomicAdd(yo + o * SC_W + w, v);
+                    }
                 }
     }
 }
@@ -170,7 +186,7 @@ constexpr int SFX_RS = 272;
 constexpr int SFX_PLANE = SC_OP * SFX_RS;
 __global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const unsigned short* __restrict__ wp_hi,
                                                             const unsigned short* __restrict__ wp_lo, long long ldp, const float* __restrict__ bs,
-                                                            float* __restrict__ y2, int B, int H, int kper) {
+                                                            float* __restrict__ y2, float* __restrict__ slabs, int B, int H, int kper) {
     EEG_LDS_BASE(float, lds);
     unsigned char* zp = reinterpret_cast<unsigned char*>(lds);     // planes hi | lo of z1^T[w][k0 + kk]
     float* aff = lds + 2 * SFX_PLANE / 4;                           // [2][40]
@@ -292,7 +308,9 @@ __global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restri
     __syncthreads();
     if (wv == 0) {
         add(red);
-        float* yo = y2 + (long long)b * SC_C * SC_W;
+        // slabs: this K slice's partial tile as plain stores, summed by sconv_merge_stats2_kernel -- the 1440 device-scope float atomics per
+        // workgroup (they execute at the memory side on this multi-XCD part) were 33 of the kernel's 60 us
+        float* yo = slabs ? slabs + ((long long)blockIdx.y * B + b) * SC_C * SC_W : y2 + (long long)b * SC_C * SC_W;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -300,21 +318,37 @@ __global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * i + 4 * g + r, w = 16 * j + fr;
-                    if (o < SC_C && w < SC_W) atomicAdd(yo + o * SC_W + w, acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f));
+                    if (o < SC_C && w < SC_W) {
+                        const float v = acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f);
+                        if (slabs) yo[o * SC_W + w] = v;
+                        else atomicAdd(yo + o * SC_W + w, v);
+                    }
                 }
     }
 }
 
-// BatchNorm2d #2 batch statistics of y2 (B,40,36): workgroup = (channel, slice of samples); fp64 atomics, 2 per workgroup
-__global__ __launch_bounds__(256) void sconv_stats2_kernel(const float* __restrict__ y2, double* __restrict__ sums2, int B) {
+// y2 = sum of the K-slice slabs of sconv_fwd (slabs != NULL), and the BatchNorm2d #2 batch statistics of y2 (B,40,36) (sums2 != NULL):
+// workgroup = (channel, slice of samples); fp64 atomics, 2 per workgroup
+__global__ __launch_bounds__(256) void sconv_merge_stats2_kernel(const float* __restrict__ slabs, int nslab, float* __restrict__ y2,
+                                                                  double* __restrict__ sums2, int B) {
     EEG_LDS_BASE(double, sh);                 // [2][4] per-wave partial sums
     const int o = blockIdx.x, t = threadIdx.x;
+    const long long slab_stride = (long long)B * SC_C * SC_W;
     double s = 0.0, q = 0.0;
     for (int i = blockIdx.y * 256 + t; i < B * SC_W; i += gridDim.y * 256) {
-        const float v = y2[((long long)(i / SC_W) * SC_C + o) * SC_W + i % SC_W];
+        const long long e = ((long long)(i / SC_W) * SC_C + o) * SC_W + i % SC_W;
+        float v;
+        if (slabs) {
+            v = slabs[e];
+            for (int k = 1; k < nslab; ++k) v += slabs[k * slab_stride + e];       // slice order: a result independent of scheduling
+            y2[e] = v;
+        } else {
+            v = y2[e];
+        }
         s += v;
         q += (double)v * v;
     }
+    if (!sums2) return;
     s = wave_sum(s);
     q = wave_sum(q);
     if ((t & 63) == 0) { sh[t >> 6] = s; sh[4 + (t >> 6)] = q; }
@@ -939,9 +973,11 @@ using namespace eeg;
 static bool sc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static int sc_check(int B, int H) { return (B < 1 || H < 1 || H > 64) ? EEGCLIP_EINVAL : 0; }
 
+extern "C" long long eegclip_sconv_fwd_workspace_floats(int B) { return B < 1 ? 0 : (long long)SCF_KS * B * SC_C * SC_W; }
+
 extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
                                  const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
-                                 int y2_is_zero, void* stream) {
+                                 int y2_is_zero, float* workspace, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
     if ((Ws_hi == nullptr) != (Ws_lo == nullptr)) return EEGCLIP_EINVAL;
@@ -950,7 +986,7 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
     const int K = SC_C * H;
     // the K slices add their partial tiles into y2 with atomics: it must start at zero (callers that clear it together with their other
     // accumulators pass y2_is_zero != 0 and save the extra memset launch)
-    if (!y2_is_zero) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
+    if (!y2_is_zero && !workspace) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
     if (Ws_hi) {
         // a chunk may run up to 127 k past the end of its slice (zeros on the activation side): the planes must be readable there
         if (ld_planes < K + SCF_KC || (ld_planes & 7) != 0) return EEGCLIP_EINVAL;
@@ -958,13 +994,24 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
         const int kper = ((K + SCF_KS - 1) / SCF_KS + 7) & ~7;                 // slices start on 16-byte boundaries of the bf16 planes
         const size_t lds = 2 * SFX_PLANE + 2 * SC_C * sizeof(float);
         EEG_LAUNCH(sconv_fwd_x3_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, (const unsigned short*)Ws_hi, (const unsigned short*)Ws_lo,
-                   ld_planes, bs, y2, B, H, kper);
+                   ld_planes, bs, y2, workspace, B, H, kper);
     } else {
         const int kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;                 // slices start on 16-byte boundaries of both operands
         const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
-        EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, B, H, kper);
+        const int dbg = getenv("EEGCLIP_SCF_DEBUG") ? atoi(getenv("EEGCLIP_SCF_DEBUG")) : 0;          // diagnosis only (see the kernel)
+#define EEG_SCF_GO(D) EEG_LAUNCH(sconv_fwd_kernel<D>, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, workspace, B, H, kper)
+        switch (dbg) {
+            case 1: EEG_SCF_GO(1); break;
+            case 2: EEG_SCF_GO(2); break;
+            case 12: EEG_SCF_GO(12); break;
+            case 32: EEG_SCF_GO(32); break;
+            case 46: EEG_SCF_GO(46); break;
+            default: EEG_SCF_GO(0); break;
+        }
+#undef EEG_SCF_GO
     }
-    if (sums2) EEG_LAUNCH(sconv_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, y2, sums2, B);
+    if (sums2 || workspace)
+        EEG_LAUNCH(sconv_merge_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, (const float*)workspace, SCF_KS, y2, sums2, B);
     return (int)hipGetLastError();
 }
 

@@ -277,13 +277,15 @@ int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx, long long
  *   bwd_w       dWs += sum_{b,w} dy2 (x) z1       (two-stage reduction through `workspace`, size from ..._workspace_floats)
  *   bwd_x_stats sums[c] += sum da, sums[40+c] += sum da*xhat,  da = (Ws^T dy2) * ELU'(BN(y1))     (double[80], zeroed by the caller)
  *   bwd_x_apply dy1 = gamma*rstd*(da - sums/count - xhat*sums'/count); dgamma/dbeta += sums_local (NULL = sums) -- SyncBN: all-reduce
- *               sums between the two calls and pass the global count.  sconv_fwd adds K-slice partial tiles into y2 with atomics:
- * y2_is_zero = 0 lets it clear y2 itself, != 0 says the caller already did. */
+ *               sums between the two calls and pass the global count.  sconv_fwd: with `workspace` (eegclip_sconv_fwd_workspace_floats(B) floats)
+ * the K-slice partial tiles go to slabs as plain stores and the BatchNorm2-statistics kernel of the same call sums them into y2; workspace = NULL:
+ * they are added into y2 with atomics (y2_is_zero = 0 lets the call clear y2 itself, != 0 says the caller already did). */
 /* Ws_hi / Ws_lo (both or neither) + ld_planes: bf16 planes of Ws as eegclip_split_rows{src = Ws, rows = 40, cols = 40 H, ld_src = 40 H,
  * ld_out = ld_planes} writes them, ld_planes >= 40 H + 128 and a multiple of 8, 16-byte aligned: split-bf16 products instead of exact fp32. */
 int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
                       const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
-                      int y2_is_zero, void* stream);
+                      int y2_is_zero, float* workspace, void* stream);
+long long eegclip_sconv_fwd_workspace_floats(int B);
 long long eegclip_sconv_bwd_w_workspace_floats(int B, int H);
 /* precision: EEGCLIP_PREC_F32 (exact fp32 products) | EEGCLIP_PREC_BF16X3 (split-bf16 products; dy2 16-byte aligned) */
 int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,

@@ -534,15 +534,17 @@ def test_fused_spatial_stage(be, B, H):
     FH, FL = be.dev(np.full((C, ldp), 0x7FC0, np.uint16)), be.dev(np.full((C, ldp), 0x7FC0, np.uint16))
     itf = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(WS), hi=be.ptr(FH), lo=be.ptr(FL), rows=C, cols=Kf, ld_src=Kf, ld_out=ldp, transpose=0))
     ok(be.lib.eegclip_split_rows(itf, 1, be.stream))
-    for planes in ((None, None, 0), (be.ptr(FH), be.ptr(FL), ldp)):
-        Y2, S2 = be.zeros((B, C, Wd)), be.zeros(80, np.float64)
+    # (K-slice partial tiles added into y2 with atomics | written to workspace slabs and summed by the statistics kernel of the same call)
+    for planes, slabs in [((None, None, 0), False), ((be.ptr(FH), be.ptr(FL), ldp), False), ((None, None, 0), True), ((be.ptr(FH), be.ptr(FL), ldp), True)]:
+        Y2, S2 = (be.dev(np.full((B, C, Wd), np.nan, np.float32)) if slabs else be.zeros((B, C, Wd))), be.zeros(80, np.float64)
+        WSF = be.dev(np.full(int(be.lib.eegclip_sconv_fwd_workspace_floats(B)), np.nan, np.float32)) if slabs else None
         ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), *planes, be.ptr(BS), be.ptr(Y2), be.ptr(S2),
-                                    B, H, 0, be.stream))
+                                    B, H, 0, be.ptr(WSF) if slabs else None, be.stream))
         np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
         np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3, rtol=2e-5 if planes[0] else 0)   # (sums of ~1e3 terms)
         np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
     assert be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(FH), be.ptr(FL), Kf, be.ptr(BS),
-                                    be.ptr(Y2), be.ptr(S2), B, H, 0, be.stream) < 0           # planes too narrow for the chunk overrun
+                                    be.ptr(Y2), be.ptr(S2), B, H, 0, None, be.stream) < 0     # planes too narrow for the chunk overrun
     for precision in (_abi.PREC_F32, _abi.PREC_BF16X3):
         DWS = be.dev(np.ones((C, C, H), np.float32))
         WSP = be.zeros(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)))
