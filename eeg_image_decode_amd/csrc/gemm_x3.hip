@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const eegclip_gem
 // the standard orientation: their epilogue is atomics only, and a wave's atomic instruction over 4 rows x 16 consecutive words coalesces where
 // 16 rows x 4 strided words does not (measured: the weight-gradient GEMMs 62 -> 174 us with the transposed layout).
 template <int BT, int BK, bool DB, bool A_KC, bool B_KC, bool C_PLAIN, bool K2 = false, bool TRANS = false>
-__global__ __launch_bounds__(X3_THREADS) void gemm_x3_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
+__global__ __launch_bounds__(X3_THREADS, (BT == 64 && !K2) ? 4 : (BT == 64 ? 3 : 1)) void gemm_x3_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
     static_assert(!K2 || (!A_KC && !B_KC), "two-level k maps are implemented for row-contiguous operands");
     using G = x3_geom<BK>;
     constexpr int WT = BT / 32;                  // MFMA tiles per wave and dimension

@@ -37,7 +37,7 @@ constexpr int SCF_KC = 128;
 constexpr int SCF_KS = 4;
 constexpr int SCF_LZ = 52;             // activation tile row stride
 template <int dbg>
-__global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
+__global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
                                                          const float* __restrict__ bs, float* __restrict__ y2, float* __restrict__ slabs, int B, int H,
                                                          int kper) {
     // dbg (template; EEGCLIP_SCF_DEBUG selects an instantiation; timing ablation only -- results are wrong with any bit set): 1 no MFMAs, 2 no ELU,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void sconv_fwd_kernel(const float* __restrict_
 // straight from global memory (16 bytes = 8 k of one output channel per lane, plane and tile).
 constexpr int SFX_RS = 272;
 constexpr int SFX_PLANE = SC_OP * SFX_RS;
-__global__ __launch_bounds__(256) void sconv_fwd_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const unsigned short* __restrict__ wp_hi,
+__global__ __launch_bounds__(256, 3) void sconv_fwd_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const unsigned short* __restrict__ wp_hi,
                                                             const unsigned short* __restrict__ wp_lo, long long ldp, const float* __restrict__ bs,
                                                             float* __restrict__ y2, float* __restrict__ slabs, int B, int H, int kper) {
     EEG_LDS_BASE(float, lds);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void sconv_bwd_w_kernel(const float* __restric
 // 3 x NT x 9 exact-fp32 ones of 32 cycles.
 constexpr int SWX_RS = 144;
 template <int NS>
-__global__ __launch_bounds__(256) void sconv_bwd_w_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
+__global__ __launch_bounds__(256, 3) void sconv_bwd_w_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
                                                               float* __restrict__ partials, int B, int H, int bgroups) {
     constexpr int NT = NS / 64;
     constexpr int NV = (NS * SC_W / 4 + 255) / 256;
@@ -802,7 +802,7 @@ __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, in
 constexpr int SCX_RS = 144;                  // bytes per row of a dy2^T plane
 constexpr int SCX_GY = 5;                    // workgroups per sample: 20 waves x 2 channels x 4 row blocks
 template <bool APPLY, bool X3>
-__global__ __launch_bounds__(256) void sconv_bwd_x_kernel(const float* __restrict__ dy2, const float* __restrict__ Ws,
+__global__ __launch_bounds__(256, 3) void sconv_bwd_x_kernel(const float* __restrict__ dy2, const float* __restrict__ Ws,
                                                            const unsigned short* __restrict__ wt_hi, const unsigned short* __restrict__ wt_lo,
                                                            const float* __restrict__ y1, const bn_affine bn, double* __restrict__ sums,
                                                            const double* __restrict__ sums_param, double count, float* __restrict__ dy1,
