@@ -677,7 +677,8 @@ class _Engine:
         PLT = self.planesT                        # W^T planes of this step's weights (refreshed by the forward plan)
         R = B * L_TOK
         sums, bn = b["sums"], b["bn"]
-        sk = lambda k: max(1, min(64, k // 512))      # split-K for the reduce-over-batch weight-gradient GEMMs
+        wsk = int(os.environ.get("EEGCLIP_WGRAD_SK", "0"))                         # tuning aid: K-slice count of the long-K weight gradients
+        sk = lambda k: (wsk if (wsk > 0 and k >= 4096) else max(1, min(64, k // 512)))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
         def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
             """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major; bias: G[bias] (Nout) += column sums of dY, taken
@@ -685,7 +686,6 @@ class _Engine:
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
                            rowsum_a=_p(G[bias]) if bias else None, side=side)    # nobody reads a weight gradient before the optimizer
 
-        import os
         ln_side = os.environ.get("EEGCLIP_LN_SIDE", "1") != "0"        # tuning aid: LayerNorm parameter-gradient kernels on the second stream
         # the three token-block LayerNorms reduce their gamma / beta gradients through per-workgroup partial rows (one workspace: the three launches
         # are ordered on one stream) instead of 256-way contended atomics
