@@ -317,7 +317,13 @@ class _PriorEngine:
             pl.call("eegclip_layernorm_bwd", _p(b[f"dln{s}"]), _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), _p(b[f"dlin{s}"]),
                     _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), N, ho, 0, None, 0.0, 0, 0)
             wgrad(st["l"] + "0.weight", _p(b[f"dlin{s}"]), ho, _p(b["XIN"]) + 4 * self.col0[s], self.wide, ho, hi, small, bias=st["l"] + "0.bias")
-            pl.gemm(N, hi, ho, _p(b[f"dlin{s}"]), D(ho), D(1), _p(P[st["l"] + "0.weight"]), D(hi), D(1), _p(b[f"dxin{s}"]), D(hi), D(1))
+            # dxin = dlin W (kept pure in Cpre: the weight-gradient GEMMs on the second stream read it) and, in the same epilogue, the gradient
+            # w.r.t. the stage input: dst = dxin (+ the skip branch for encoder stages: decode stage j = n_enc-1-i adds skips[i]) -- two
+            # elementwise launches per stage fewer
+            dst = _p(b[f"dact{s - 1}"]) if s > 0 else _p(b["dactI"])
+            skip = _p(b[f"dact{n_enc + (n_enc - 1 - s)}"]) if st["dec"] is None else None
+            pl.gemm(N, hi, ho, _p(b[f"dlin{s}"]), D(ho), D(1), _p(P[st["l"] + "0.weight"]), D(hi), D(1), dst, D(hi), D(1), Cpre=_p(b[f"dxin{s}"]),
+                    R=skip, Rm=D(hi) if skip else D(0), Rn=D(1) if skip else D(0))
             if cond:
                 pl.c_gemms.append(wgrad(st["c"] + "weight", _p(b[f"dxin{s}"]), hi, 0, Cd, hi, Cd, hi < 256, bias=st["c"] + "bias"))
             wgrad(st["t"] + "linear_2.weight", _p(b[f"dxin{s}"]), hi, _p(b["T1act"]) + 4 * self.col0[s], self.wide, hi, hi, hi < 256,
@@ -326,13 +332,6 @@ class _PriorEngine:
             # first Linears follow once, after the loop)
             pl.gemm(N, hi, hi, _p(b[f"dxin{s}"]), D(hi), D(1), _p(P[st["t"] + "linear_2.weight"]), D(hi), D(1), _p(b["DT1"]) + 4 * self.col0[s],
                     D(self.wide), D(1))
-            # gradient w.r.t. the stage input x: dxin, plus the skip branch for encoder stages (decode stage j = n_enc-1-i adds skips[i])
-            # (the skip gradient is added into the DESTINATION, never into dxin: the weight-gradient GEMMs on the second stream still read dxin)
-            dst = _p(b[f"dact{s - 1}"]) if s > 0 else _p(b["dactI"])
-            pl.call("eegclip_axpby", _p(b[f"dxin{s}"]), dst, N * hi, 1.0, 0.0)
-            if st["dec"] is None:
-                dec_s = n_enc + (n_enc - 1 - s)
-                pl.call("eegclip_axpby", _p(b[f"dact{dec_s}"]), dst, N * hi, 1.0, 1.0)
         pl.call("eegclip_silu_bwd", _p(b["DT1"]), _p(b["T1pre"]), _p(b["DT1"]), N * self.wide, 0, 0.0, 0, 0)
         wgrad(self.stages[0]["t"] + "linear_1.weight", _p(b["DT1"]), self.wide, _p(b["temb"]), Td, self.wide, Td, False,
               bias=self.stages[0]["t"] + "linear_1.bias")                       # the grouped (wide x 512) block of all eight stages
