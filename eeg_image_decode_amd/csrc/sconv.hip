@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
     // 4 no y1 loads, 8 no weight loads, 32 no LDS stores of the activation tile.  Measured at B = 256 (tools/bench_sconv_fwd.py, us incl. the 5 us
     // statistics kernel): full 60, no MFMA 42, no loads 46, no LDS stores 46 -- the phases of a chunk (convert + LDS stores | MFMAs + LDS reads | load
     // latency) add up instead of overlapping: 146 VGPRs + 64 AGPRs leave 2 workgroups per CU.  (Leaving out the epilogue is NOT a valid ablation:
-    // the compiler then drops the MFMAs of the unused accumulators.)
+    // the compiler then drops the MFMAs of the unused accumulators.)  A second activation tile (chunk k+1 converted and stored in the barrier interval
+    // of chunk k's MFMAs, one barrier per chunk) measured SLOWER: 68 vs 58 us (53 KB of LDS per workgroup).
     EEG_LDS_BASE(float, lds);
     float* zl = lds;                          // [128][52]      z1[k0 + kk][w]   (cols >= 36 zero)
     float* aff = zl + SCF_KC * SCF_LZ;        // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
