@@ -129,6 +129,43 @@ def test_step_and_zero_grad_in_one_pass_is_the_plain_loop():
         assert d.max() <= 3 * 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
 
 
+def test_gradient_buffer_attach_accumulates_clears_and_keeps_foreign_gradients():
+    """engine.attach_grads: a second backward without zero_grad accumulates (g1 + g2); after zero_grad the buffer starts from zero; a gradient that
+    somebody else put on a parameter before the backward (a foreign tensor) is added to, not lost; a parameter whose .grad alone was set to None is
+    cleared alone"""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B = 2
+    xs = [T(syn.eeg_batch(SEED + 70 + i, B)) for i in range(2)]
+    img = T(syn.unit_features(SEED + 70, B, tag="img"))
+    key = "encoder.encoder.attn_layers.0.conv1.weight"
+    with product_on_emulator():
+        m = make_model(state_np).eval()                       # eval: no dropout, deterministic BatchNorm -> the two backwards are independent
+        named = dict(m.named_parameters())
+
+        def backward(x):
+            m.loss_func(m(x, 1), img, m.logit_scale).backward()
+
+        def grads():
+            return {k: p.grad.clone() for k, p in named.items() if p.grad is not None}
+
+        backward(xs[0]); g1 = grads()
+        m.zero_grad(set_to_none=True)
+        backward(xs[1]); g2 = grads()
+        backward(xs[0]); g21 = grads()                        # no zero_grad in between: accumulated
+        for k in g1:
+            np.testing.assert_allclose(g21[k].numpy(), (g1[k] + g2[k]).numpy(), atol=1e-6 + 1e-4 * float((g1[k].abs() + g2[k].abs()).max()), err_msg=k)
+        m.zero_grad(set_to_none=True)
+        named[key].grad = torch.full_like(named[key], 0.25)   # a foreign gradient tensor on one parameter
+        backward(xs[0]); gf = grads()
+        np.testing.assert_allclose(gf[key].numpy(), (g1[key] + 0.25).numpy(), atol=1e-6 + 1e-4 * float(g1[key].abs().max()))
+        other = "proj_eeg.0.weight"
+        np.testing.assert_allclose(gf[other].numpy(), g1[other].numpy(), atol=1e-6 + 1e-4 * float(g1[other].abs().max()))
+        named[key].grad = None                                # only this one cleared: the others keep accumulating
+        backward(xs[1]); gm = grads()
+        np.testing.assert_allclose(gm[key].numpy(), g2[key].numpy(), atol=1e-6 + 1e-4 * float(g2[key].abs().max()))
+        np.testing.assert_allclose(gm[other].numpy(), (g1[other] + g2[other]).numpy(), atol=1e-6 + 1e-4 * float((g1[other].abs() + g2[other].abs()).max()))
+
+
 def test_optimizer_fast_path_is_torch_adamw_and_keeps_step_counts():
     """the steady-state path of optim.AdamW.step (same gradient tensors as the previous step: cached launches, lazily counted steps) against
     torch.optim.AdamW over 6 steps with a learning-rate change in between; state_dict() reports the true step count"""
@@ -153,10 +190,14 @@ def test_optimizer_fast_path_is_torch_adamw_and_keeps_step_counts():
                 g.copy_(torch.from_numpy(rng.standard_normal(tuple(g.shape)).astype(np.float32)))
                 p.grad = g                                   # the SAME tensor objects every step, as the engine attaches them
                 r.grad = g.clone()
+            if it == 5:
+                ps[1].grad = gs[1].clone()                   # another tensor object (not in the flat buffer): the cached launches must not be used
             opt.step(zero_grad=(it % 2 == 1))
             topt.step()
-            assert (it < 2) or opt._fast[0]["pending"] >= 1  # from the third step on the cached launches are used
-            if it % 2 == 1:
+            assert (it < 2) or (it == 5) or opt._fast[0]["pending"] >= 1  # from the third step on the cached launches are used
+            if it == 5:
+                assert opt._fast[0]["pending"] == 0 and len(opt._fast[0]["launch"]) >= 2      # re-derived: the run is split at the foreign gradient
+            if it % 2 == 1 and it != 5:
                 assert all(p.grad is None for p in ps) and float(gflat.abs().max()) == 0.0
         for p, r in zip(ps, ref):
             np.testing.assert_allclose(p.detach().numpy(), r.detach().numpy(), atol=2e-6, rtol=1e-5)
