@@ -48,7 +48,7 @@ def algorithmic_cost(name, desc, B):
     y1 = B * 40 * 63 * 36 * 4
     if name == "eegclip_gemm_f32":
         return "mfma", 2.0 * desc.M * desc.N * desc.K, "flop"
-    if name in ("eegclip_attention_fwd", "eegclip_attention_bwd"):
+    if name in ("eegclip_attention_fwd", "eegclip_attention_bwd", "eegclip_attention_bwd_x3"):
         per = 4 if name.endswith("fwd") else 10                    # QK^T + PV  |  + recompute, dP, dQ, dK, dV  (x 2 L^2 E flops)
         return "mfma", float(per * 64 * 64 * 62 * B * 4), "flop"
     if name == "eegclip_token_block_fwd":
@@ -71,7 +71,7 @@ def algorithmic_cost(name, desc, B):
     return None
 
 
-_KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegclip_attention_fwd": "eeg::attention_fwd_kernel<true>",
+_KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegclip_attention_bwd_x3": "eeg::attention_bwd_x3_kernel<true>", "eegclip_attention_fwd": "eeg::attention_fwd_kernel<true>",
               "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel<7>",
               "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
               "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_x3_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false, true>",
@@ -108,6 +108,8 @@ def family_of(name, desc):
         return "gemm_bf16x3" if (desc.precision & 0xff) == PREC_BF16X3 else "gemm_f32"
     if name.startswith("eegclip_token_block_"):
         return "token_block"
+    if name == "eegclip_attention_bwd_x3":
+        return "attention_bf16x3"
     if name.startswith("eegclip_attention_"):
         return "attention_f32_mfma"
     return name
@@ -117,7 +119,7 @@ def family_peak(fam, bound):
     """(peak, scale from work / ms to the unit, unit)"""
     if bound == "mfma":
         # bf16x3: three bf16 MFMA products per algorithmic multiply-add -> the pipe's ceiling for ALGORITHMIC flops is a third of 2.5 PF
-        return (PEAK_BF16_MFMA_TF / 3.0 if fam == "gemm_bf16x3" else PEAK_F32_MFMA_TF), 1e-3 * 1e12, "TFLOP/s"
+        return (PEAK_BF16_MFMA_TF / 3.0 if fam in ("gemm_bf16x3", "attention_bf16x3") else PEAK_F32_MFMA_TF), 1e-3 * 1e12, "TFLOP/s"
     return PEAK_HBM_GBS, 1e-3 * 1e9, "GB/s"
 
 

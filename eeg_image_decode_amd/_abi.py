@@ -119,6 +119,7 @@ PROTOTYPES = {
     "eegclip_clip_scale": [_P, _F, _P, _P],
     "eegclip_attention_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_attention_bwd_x3": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_proj1x1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_proj1x1_bwd_workspace_floats": [_I],
     "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],

@@ -678,6 +678,10 @@ class _Engine:
         R = B * L_TOK
         sums, bn = b["sums"], b["bn"]
         wsk = int(os.environ.get("EEGCLIP_WGRAD_SK", "0"))                         # tuning aid: K-slice count of the long-K weight gradients
+        # attention backward: split-bf16 products (csrc/attention_x3.hip) in plans whose GEMM precision is bf16x3; EEGCLIP_ATTN_BWD_X3=0 keeps the
+        # exact-fp32 MFMA kernel
+        attn_bwd = ("eegclip_attention_bwd_x3" if (pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_ATTN_BWD_X3", "1") != "0")
+                    else "eegclip_attention_bwd")
         sk = lambda k: (wsk if (wsk > 0 and k >= 4096) else max(1, min(64, k // 512)))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
         def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
@@ -836,7 +840,7 @@ class _Engine:
             wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias", side=s2)
             wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
                   bias=_LY + "attention.out_projection.bias")
-            pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+            pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                     pe_, 0, SITE_ATTN, seed_at=10)
             wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
                   bias=_LY + "attention.query_projection.bias", side=s2)
@@ -863,7 +867,7 @@ class _Engine:
                   bias=_LY + "attention.out_projection.bias")
             pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
                     planes=PLT["out"])
-            pl.call("eegclip_attention_bwd", _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+            pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                     pe_, 0, SITE_ATTN, seed_at=10)
             wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
                   bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent

@@ -249,6 +249,10 @@ int eegclip_attention_fwd(const float* qkv, float* ctx, int B, int L, int H, int
                           unsigned long long seed, unsigned int site, void* stream);
 int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream);
+/* the same contract with split-bf16 products (hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate: ~2^-16 relative per term, as
+ * EEGCLIP_PREC_BF16X3): E and ld even, qkv / dctx / dqkv 8-byte aligned.  csrc/attention_x3.hip */
+int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
+                          float drop_p, unsigned long long seed, unsigned int site, void* stream);
 
 /* ---- tsconv front: Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)).  ATMS_retrieval.py:102-103
  * Computed as a 51-sample box filter of every token row (one wave-level prefix sum, shared by the 40 filters) followed by the 25-tap

@@ -304,6 +304,13 @@ def test_attention_fwd_bwd(be, B, H, E, p):
     out.backward(torch.tensor(dctx, dtype=torch.float64))
     np.testing.assert_allclose(be.host(CTX), out.detach().numpy(), atol=2e-5)
     np.testing.assert_allclose(be.host(DQKV), qt.grad.numpy(), atol=5e-5)
+    if E % 2 == 0:          # the split-bf16 backward (csrc/attention_x3.hip: LDS transpose reads): same masks, ~2^-16 relative per product term
+        DQ3 = be.dev(np.full((B * L, ld), np.nan, np.float32))
+        ok(be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQ3), B, L, H, E, ld, scale, p, SEED, 1, be.stream))
+        np.testing.assert_allclose(be.host(DQ3), qt.grad.numpy(), atol=2e-4)
+        assert np.abs(be.host(DQ3) - qt.grad.numpy()).mean() < 1e-5
+    else:
+        assert be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQKV), B, L, H, E, ld, scale, p, SEED, 1, be.stream) < 0
 
 
 @pytest.mark.parametrize("B,H", [(2, 63), (3, 5), (5, 63)])

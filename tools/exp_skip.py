@@ -13,7 +13,7 @@ fams = set(sys.argv[1].split(","))
 sys.argv = ["bench.py"] + sys.argv[2:]
 CALLS = {"convbwd": ("eegclip_sconv_bwd_w", "eegclip_sconv_bwd_x_stats", "eegclip_sconv_bwd_w_stats", "eegclip_sconv_bwd_x_apply", "eegclip_tsconv_bwd_w", "eegclip_tsconv_bwd_x"),
          "convfwd": ("eegclip_sconv_fwd", "eegclip_tsconv_fwd"),
-         "attnbwd": ("eegclip_attention_bwd",), "tb_fwd": ("eegclip_token_block_fwd",), "tb_bwd": ("eegclip_token_block_bwd",)}
+         "attnbwd": ("eegclip_attention_bwd", "eegclip_attention_bwd_x3"), "tb_fwd": ("eegclip_token_block_fwd",), "tb_bwd": ("eegclip_token_block_bwd",)}
 skip_calls = {n for f in fams for n in CALLS.get(f, ())}
 _gemm, _call, _call_desc = _plan.Plan.gemm, _plan.Plan.call, _plan.Plan.call_desc
 

@@ -7,7 +7,7 @@ import sys
 FAMILIES = {
     "gemm_bf16x3": ("eeg::gemm_x3_kernel", "eeg::gemm_x3p_kernel"),
     "token_block": ("eeg::token_block_fwd_kernel", "eeg::token_block_bwd_a_kernel", "eeg::token_block_bwd_b_kernel"),
-    "attention_f32_mfma": ("eeg::attention_bwd_kernel", "eeg::attention_fwd_kernel"),
+    "attention_f32_mfma": ("eeg::attention_bwd_kernel", "eeg::attention_fwd_kernel"), "attention_bf16x3": ("eeg::attention_bwd_x3_kernel",),
     "eegclip_tsconv_fwd": ("eeg::tsconv_fwd_kernel",), "eegclip_tsconv_bwd_w": ("eeg::tsconv_bwd_w_kernel",),
     "eegclip_tsconv_bwd_x": ("eeg::tsconv_bwd_x_kernel",), "eegclip_sconv_fwd": ("eeg::sconv_fwd_kernel", "eeg::sconv_fwd_x3_kernel"),
     "eegclip_sconv_bwd_w": ("eeg::sconv_bwd_w_x3_kernel", "eeg::sconv_bwd_w_kernel"),
