@@ -159,6 +159,9 @@ PROTOTYPES = {
     "eegclip_split_transpose": [_P, _L, _I, _I, _I, _P, _P, _L, _P],
     "eegclip_wgrad_planes_workspace_floats": [_I, _I, _I],
     "eegclip_wgrad_planes": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P],
+    "eegclip_split_rows_natural": [_P, _L, _I, _I, _P, _P, _I, _P],
+    "eegclip_wgrad_tr_workspace_floats": [_I, _I, _I],
+    "eegclip_wgrad_tr": [_P, _P, _L, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

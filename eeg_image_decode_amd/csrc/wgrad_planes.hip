@@ -275,6 +275,195 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient from planes in their NATURAL layout [t][c] (what a producer holds anyway: no transposing pass): operand tiles
+// [32 t][128 | 64 c] go through LDS unchanged (16-byte copies) and both MFMA operands are fetched with ds_read_b64_tr_b16, the LDS transpose read
+// of gfx950 (see csrc/attention_x3.hip for the lane mapping): lane (fr, g) of a 16x16x32 step receives tokens 4g .. 4g+3 and 16 + 4g .. 16 + 4g+3
+// of column c0 + fr -- the same k-slot assignment on both operands.  Row strides 288 B (A) and 160 B (B): the 4 rows x 32 bytes a 16-lane group
+// addresses land 8 banks apart and the groups 32 apart (every bank exactly twice per 512-byte read: the minimum).
+//   wgrad_tr_kernel        workgroup = (128 x 64 output tile, K slice); 4 waves as 2 x 2, each 64 x 32 outputs = 4 x 2 MFMA tiles of 16 x 16;
+//                          k-tile = 32 tokens = one MFMA k-step; the next k-tile's 6 x 16-byte loads per thread are in flight under the MFMAs.
+//   split_rows_natural_kernel   fp32 [t][c] -> bf16 planes [t][ldp] (ldp a multiple of 8, columns >= c zero): the operand of the kernel above.
+// Opt-in (EEGCLIP_WGRAD_TR=1 in the encoder's backward plan): parity-tested on the emulator and the GPU; first timing, untuned and with a plain split
+// launch per operand in front: 1.09 vs 1.01 ms per step -- it needs the producers to write the planes (they hold them in LDS) and a tuning pass.
+constexpr int WT_BK = 32;
+constexpr int WT_RA = 288, WT_RB = 160;                                  // bytes per LDS row of an A / B plane tile
+constexpr int WT_TILE_A = WT_BK * WT_RA, WT_TILE_B = WT_BK * WT_RB;
+constexpr int WT_STAGE = 2 * (WT_TILE_A + WT_TILE_B);                   // A hi | A lo | B hi | B lo
+typedef short wt_s4 __attribute__((ext_vector_type(4)));
+
+struct wgrad_tr_args {
+    const unsigned short *a_hi, *a_lo, *b_hi, *b_lo;             // planes [K][lda] / [K][ldb], channel contiguous
+    float* slab;
+    int M, N, Mp, Np, K, slices, want_bias;
+    long long lda, ldb;
+};
+
+__device__ __forceinline__ wt_s4 wt_tr_read(const unsigned char* p) {
+#if defined(EEG_EMU)
+    const int lane = hipemu::cur->lane, g = lane >> 4, i = lane & 15;
+    wt_s4 r;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long src = hipemu::shfl_idx((unsigned long long)(uintptr_t)p, 16 * g + 4 * j + (i >> 2));
+        r[j] = reinterpret_cast<const short*>((uintptr_t)src)[i & 3];
+    }
+    return r;
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wt_s4*)(p));
+#endif
+}
+// k slots 0-3 <-> tile rows 4g .. 4g+3, slots 4-7 <-> rows 16 + 4g .. of column c0 + (lane & 15)
+__device__ __forceinline__ bf16x8 wt_frag(const unsigned char* plane, int rs, int c0, int lane) {
+    const int l = lane & 15, g = lane >> 4;
+    const unsigned char* p = plane + (4 * g + (l >> 2)) * rs + 2 * (c0 + 4 * (l & 3));
+    const wt_s4 a = wt_tr_read(p), b = wt_tr_read(p + 16 * rs);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const wgrad_tr_args a) {
+    EEG_LDS_BASE(unsigned char, lds);
+    const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+    const int tiles_n = a.Np / WG_TN, tiles = (a.Mp / WG_TM) * tiles_n;
+    int slice, tile;
+    if ((a.slices & 7) == 0) {                                   // all tiles of a K slice on one XCD (see wgrad_planes_kernel)
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        slice = xcd + 8 * (j / tiles);
+        tile = j % tiles;
+    } else {
+        slice = (int)blockIdx.x / tiles;
+        tile = (int)blockIdx.x - slice * tiles;
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int ktiles_all = a.K / WT_BK;
+    const int kt0 = (int)((long long)slice * ktiles_all / a.slices), kt1 = (int)((long long)(slice + 1) * ktiles_all / a.slices);
+    const bool bias = a.want_bias && tn == 0 && wn == 0;
+
+    // staging: chunk c = t + 256 i of [A hi: 32 rows x 16 chunks | A lo | B hi: 32 rows x 8 chunks | B lo]; a chunk past the plane's columns is zero
+    constexpr int CH_A = WT_BK * 16, CH_B = WT_BK * 8, CPT = (2 * CH_A + 2 * CH_B) / 256;      // 6
+    const unsigned short* gsrc[CPT];
+    int loff[CPT];
+    bool gok[CPT];
+    long long gstep[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        int c = t + 256 * i;
+        const unsigned short* base;
+        int row, col, ncols, off;
+        long long ld;
+        if (c < 2 * CH_A) {
+            const bool lo = c >= CH_A;
+            c -= lo ? CH_A : 0;
+            row = c >> 4; col = tm * WG_TM + 8 * (c & 15);
+            base = lo ? a.a_lo : a.a_hi; ld = a.lda; ncols = (int)a.lda;
+            off = (lo ? WT_TILE_A : 0) + row * WT_RA + 16 * (c & 15);
+        } else {
+            c -= 2 * CH_A;
+            const bool lo = c >= CH_B;
+            c -= lo ? CH_B : 0;
+            row = c >> 3; col = tn * WG_TN + 8 * (c & 7);
+            base = lo ? a.b_lo : a.b_hi; ld = a.ldb; ncols = (int)a.ldb;
+            off = 2 * WT_TILE_A + (lo ? WT_TILE_B : 0) + row * WT_RB + 16 * (c & 7);
+        }
+        gok[i] = col + 8 <= ncols;                                // (plane rows are padded to multiples of 8 columns)
+        gsrc[i] = base + (long long)row * ld + (gok[i] ? col : 0);
+        gstep[i] = (long long)WT_BK * ld;
+        loff[i] = off;
+    }
+    wg_u4 regs[CPT];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            regs[i] = gok[i] ? *reinterpret_cast<const wg_u4*>(gsrc[i] + (long long)kt * gstep[i]) : wg_u4{0u, 0u, 0u, 0u};
+    };
+    auto lstore = [&](int stg) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) *reinterpret_cast<wg_u4*>(lds + stg * WT_STAGE + loff[i]) = regs[i];
+    };
+    f32x4 acc[4][2], bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;         // bf16 1.0
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        gload(kt0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+        if (j + 1 < nk) gload(kt0 + j + 1);                      // in flight under this k-tile's MFMAs
+        const unsigned char* st = lds + (j & 1) * WT_STAGE;
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bh[nt] = wt_frag(st + 2 * WT_TILE_A, WT_RB, 32 * wn + 16 * nt, lane);
+            bl[nt] = wt_frag(st + 2 * WT_TILE_A + WT_TILE_B, WT_RB, 32 * wn + 16 * nt, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bf16x8 ah = wt_frag(st, WT_RA, 64 * wm + 16 * mt, lane), al = wt_frag(st + WT_TILE_A, WT_RA, 64 * wm + 16 * mt, lane);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {                     // D[m = 64 wm + 16 mt + 4 g + r][n = 32 wn + 16 nt + fr]
+                acc[mt][nt] = mfma_bf16_16x16x32(al, bh[nt], acc[mt][nt]);
+                acc[mt][nt] = mfma_bf16_16x16x32(ah, bl[nt], acc[mt][nt]);
+                acc[mt][nt] = mfma_bf16_16x16x32(ah, bh[nt], acc[mt][nt]);
+            }
+            if (bias) {                                           // (wave-uniform) column sums of the A tile: every column of the product holds them
+                bacc[mt] = mfma_bf16_16x16x32(al, ones, bacc[mt]);
+                bacc[mt] = mfma_bf16_16x16x32(ah, ones, bacc[mt]);
+            }
+        }
+        if (j + 1 < nk) lstore((j + 1) & 1);                     // the other stage: nobody reads it during this k-tile
+        __syncthreads();
+    }
+    float* out = a.slab + (long long)slice * a.Mp * a.Np;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = tm * WG_TM + 64 * wm + 16 * mt + 4 * g + r;
+                out[(long long)m * a.Np + tn * WG_TN + 32 * wn + 16 * nt + fr] = acc[mt][nt][r];
+            }
+    if (bias && fr == 0) {
+        float* bo = a.slab + (long long)a.slices * a.Mp * a.Np + (long long)slice * a.Mp;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bo[tm * WG_TM + 64 * wm + 16 * mt + 4 * g + r] = bacc[mt][r];
+    }
+}
+
+// fp32 [rows][cols] (row stride ld, 8-byte aligned rows) -> bf16 planes [rows][ldp]; columns cols .. ldp-1 zero.  One thread per 4 columns.
+__global__ __launch_bounds__(256) void split_rows_natural_kernel(const float* __restrict__ src, long long ld, int rows, int cols, unsigned short* __restrict__ hi,
+                                                                  unsigned short* __restrict__ lo, int ldp) {
+    const int q = ldp / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * q) return;
+    const int r = (int)(i / q), c = 4 * (int)(i - (long long)r * q);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* p = src + (long long)r * ld + c;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        if (c + e + 1 < cols) {
+            const f32x2_t w = *reinterpret_cast<const f32x2_t*>(p + e);
+            v[e] = w[0]; v[e + 1] = w[1];
+        } else if (c + e < cols) v[e] = p[e];
+    }
+    u32x2_t h, l;
+    x3_split4(v[0], v[1], v[2], v[3], h, l);
+    *reinterpret_cast<u32x2_t*>(hi + (long long)r * ldp + c) = h;
+    *reinterpret_cast<u32x2_t*>(lo + (long long)r * ldp + c) = l;
+}
+
 }  // namespace eeg
 
 using namespace eeg;
@@ -318,6 +507,49 @@ extern "C" int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const vo
                  static_cast<const unsigned short*>(b_lo), workspace, Mp, Np, K, wg_slices(Mp, Np, K), bias_out ? 1 : 0, ld};
     const int tiles = (Mp / WG_TM) * (Np / WG_TN);
     EEG_LAUNCH(wgrad_planes_kernel, dim3((unsigned)(tiles * a.slices)), dim3(256), 2 * WG_STAGE, stream, a);
+    const long long total = (long long)M * N + (bias_out ? M : 0);
+    EEG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace, a.slices, Mp, Np, M, N, out, ldo, bias_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_split_rows_natural(const float* src, long long ld, int rows, int cols, void* hi, void* lo, int ldp, void* stream) {
+    if (!src || !hi || !lo || rows < 1 || cols < 1 || ld < cols || (ld & 1) || ldp < cols || (ldp & 7)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src) & 7u) || ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15u)) return EEGCLIP_EALIGN;
+    const long long n = (long long)rows * (ldp / 4);
+    EEG_LAUNCH(split_rows_natural_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, ld, rows, cols, static_cast<unsigned short*>(hi),
+               static_cast<unsigned short*>(lo), ldp);
+    return (int)hipGetLastError();
+}
+
+static int wt_slices(int Mp, int Np, int K) {
+    const int tiles = (Mp / WG_TM) * (Np / WG_TN), kt = K / WT_BK;
+    int s = (512 + tiles - 1) / tiles;                           // ~two workgroups (53 KB of LDS each) per CU
+    if (s > kt / 4) s = kt / 4;
+    if (s >= 8) s = (s + 4) / 8 * 8;
+    if (s > kt) s = kt;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" long long eegclip_wgrad_tr_workspace_floats(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < WT_BK) return 0;
+    const int Mp = wg_pad(M, WG_TM), Np = wg_pad(N, WG_TN);
+    return (long long)wt_slices(Mp, Np, K) * ((long long)Mp * Np + Mp);
+}
+
+// out (M x N, row stride ldo) += A^T B with A = planes [K][lda], B = planes [K][ldb] in natural (token-major) layout, lda / ldb multiples of 8 with
+// zeros in the columns past M / N (eegclip_split_rows_natural writes them); bias_out[m] += sum_k A[k][m].  K a multiple of 32.
+extern "C" int eegclip_wgrad_tr(const void* a_hi, const void* a_lo, long long lda, const void* b_hi, const void* b_lo, long long ldb, int M, int N, int K,
+                                float* out, long long ldo, float* bias_out, float* workspace, void* stream) {
+    if (!a_hi || !a_lo || !b_hi || !b_lo || !out || !workspace || M < 1 || N < 1 || K < WT_BK || (K % WT_BK) || ldo < N || lda < M || ldb < N || (lda & 7) ||
+        (ldb & 7))
+        return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(b_hi) | reinterpret_cast<uintptr_t>(b_lo)) & 15u)
+        return EEGCLIP_EALIGN;
+    const int Mp = wg_pad(M, WG_TM), Np = wg_pad(N, WG_TN);
+    wgrad_tr_args a{static_cast<const unsigned short*>(a_hi), static_cast<const unsigned short*>(a_lo), static_cast<const unsigned short*>(b_hi),
+                    static_cast<const unsigned short*>(b_lo), workspace, M, N, Mp, Np, K, wt_slices(Mp, Np, K), bias_out ? 1 : 0, lda, ldb};
+    const int tiles = (Mp / WG_TM) * (Np / WG_TN);
+    EEG_LAUNCH(wgrad_tr_kernel, dim3((unsigned)(tiles * a.slices)), dim3(256), 2 * WT_STAGE, stream, a);
     const long long total = (long long)M * N + (bias_out ? M : 0);
     EEG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace, a.slices, Mp, Np, M, N, out, ldo, bias_out);
     return (int)hipGetLastError();

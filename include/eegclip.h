@@ -508,6 +508,14 @@ int eegclip_split_transpose(const float* src, long long ld, int rows, int cols, 
 long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K);
 int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, long long ld, int M, int N, int K, float* out,
                          long long ldo, float* bias_out, float* workspace, void* stream);
+/* the same weight gradient from planes in NATURAL layout (token-major, what a producer holds): A = planes [K][lda], B = planes [K][ldb], lda / ldb
+ * multiples of 8 with zeros in the columns past M / N (eegclip_split_rows_natural writes exactly that from fp32 [K][cols], row stride ld even, rows
+ * 8-byte aligned); K a multiple of 32; workspace: eegclip_wgrad_tr_workspace_floats(M, N, K) floats.  Both MFMA operands are fetched with the LDS
+ * transpose read of gfx950 -- no transposing pass (csrc/wgrad_planes.hip: wgrad_tr_kernel).  Opt-in in the plans (EEGCLIP_WGRAD_TR=1). */
+int eegclip_split_rows_natural(const float* src, long long ld, int rows, int cols, void* hi, void* lo, int ldp, void* stream);
+long long eegclip_wgrad_tr_workspace_floats(int M, int N, int K);
+int eegclip_wgrad_tr(const void* a_hi, const void* a_lo, long long lda, const void* b_hi, const void* b_lo, long long ldb, int M, int N, int K, float* out,
+                     long long ldo, float* bias_out, float* workspace, void* stream);
 
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what

@@ -57,3 +57,49 @@ def test_wgrad_planes_matches_the_split_products(be, M, N, K, bias):
     assert np.abs(want - exact).max() < 1e-4 * max(1.0, np.abs(exact).max())        # split products vs exact ones: the parity budget
     if bias:
         np.testing.assert_allclose(be.host(Bv) - b0, (dh + dl).sum(0), atol=2e-5 * np.abs(dy).sum(0).max())
+
+
+def natural_planes(be, x, ldp):
+    rows, cols = x.shape
+    X = be.dev(np.ascontiguousarray(x))
+    hi, lo = be.dev(np.full((rows, ldp), 0x7FC0, np.uint16)), be.dev(np.full((rows, ldp), 0x7FC0, np.uint16))
+    assert be.lib.eegclip_split_rows_natural(be.ptr(X), cols, rows, cols, be.ptr(hi), be.ptr(lo), ldp, be.stream) == 0
+    return X, hi, lo
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 62), (96, 250), (32, 744)])
+def test_split_rows_natural(be, rows, cols):
+    rng = np.random.default_rng(rows * 3 + cols)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    ldp = (cols + 7) // 8 * 8
+    _, hi, lo = natural_planes(be, x, ldp)
+    xh, xl = split(x)
+    np.testing.assert_array_equal(bf16_to_f64(be.host(hi))[:, :cols], xh)
+    np.testing.assert_array_equal(bf16_to_f64(be.host(lo))[:, :cols], xl)
+    assert not bf16_to_f64(be.host(hi))[:, cols:].any() and not bf16_to_f64(be.host(lo))[:, cols:].any()
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(250, 256, 256, True), (62, 40, 64, False), (744, 250, 128, True), (300, 130, 512, True)])
+def test_wgrad_tr_from_natural_planes_matches_the_split_products(be, M, N, K, bias):
+    """dW += dY^T X with both operands as token-major planes, fetched through the LDS transpose read (a transpose-detecting check: M != N, random data)"""
+    rng = np.random.default_rng(M + 2 * N + K)
+    dy = (rng.standard_normal((K, M)) * rng.uniform(0.1, 2.0, M)).astype(np.float32)
+    x = rng.standard_normal((K, N)).astype(np.float32)
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    _, ah, al = natural_planes(be, dy, lda)
+    _, bh, bl = natural_planes(be, x, ldb)
+    c0 = rng.standard_normal((M, N + 2)).astype(np.float32)                           # accumulated INTO, row stride N + 2
+    b0 = rng.standard_normal(M).astype(np.float32)
+    C, Bv = be.dev(c0), be.dev(b0)
+    ws = be.dev(np.full(int(be.lib.eegclip_wgrad_tr_workspace_floats(M, N, K)), np.nan, np.float32))
+    assert be.lib.eegclip_wgrad_tr(be.ptr(ah), be.ptr(al), lda, be.ptr(bh), be.ptr(bl), ldb, M, N, K, be.ptr(C), N + 2, be.ptr(Bv) if bias else None,
+                                   be.ptr(ws), be.stream) == 0
+    dh, dl = split(dy)
+    xh, xl = split(x)
+    want = dh.T @ xh + dh.T @ xl + dl.T @ xh
+    got = be.host(C)
+    np.testing.assert_allclose(got[:, :N] - c0[:, :N], want, atol=2e-5 * np.abs(want).max() + 1e-6)
+    np.testing.assert_array_equal(got[:, N:], c0[:, N:])
+    if bias:
+        np.testing.assert_allclose(be.host(Bv) - b0, (dh + dl).sum(0), atol=2e-5 * np.abs(dy).sum(0).max())
+    assert be.lib.eegclip_wgrad_tr(be.ptr(ah), be.ptr(al), lda, be.ptr(bh), be.ptr(bl), ldb, M, N, K + 8, be.ptr(C), N + 2, None, be.ptr(ws), be.stream) < 0

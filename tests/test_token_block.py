@@ -65,9 +65,10 @@ def test_fused_token_block_equals_the_unfused_plan_on_the_gpu(B, train, subject,
     check_fused_forward_equals_the_unfused_plan("cuda", B, train, subject, monkeypatch)
 
 
-def _grads(dev, B, train, subject, fused, monkeypatch):
+def _grads(dev, B, train, subject, fused, monkeypatch, wgrad_tr=False):
     monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK", "1" if fused else "0")
     monkeypatch.delenv("EEGCLIP_TOKEN_BLOCK_BWD", raising=False)
+    monkeypatch.setenv("EEGCLIP_WGRAD_TR", "1" if wgrad_tr else "0")
     m = _model(dev)
     m.train(train)
     x = torch.from_numpy(syn.eeg_batch(SEED + 32, B)).to(dev)
@@ -78,6 +79,7 @@ def _grads(dev, B, train, subject, fused, monkeypatch):
     eng = m._engine()
     names = eng.plans[next(k for k in eng.plans if k[0] == "b")].op_names()
     assert ("eegclip_token_block_bwd" in names) == fused
+    assert ("eegclip_wgrad_tr" in names) == (fused and wgrad_tr)
     act = {k: eng.bufs[B][k].detach().cpu().numpy().copy() for k in ("df2", "dg1", "da1", "dctx", "dqkv", "dr1")}
     return {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}, act
 
@@ -109,3 +111,27 @@ def test_fused_token_block_backward_equals_the_unfused_plan_on_the_emulator(trai
 @pytest.mark.parametrize("train,subject", [(True, 1), (False, 10), (True, None)])
 def test_fused_token_block_backward_equals_the_unfused_plan_on_the_gpu(B, train, subject, monkeypatch):
     check_fused_backward_equals_the_unfused_plan("cuda", B, train, subject, monkeypatch)
+
+
+def check_weight_gradients_from_natural_planes(dev, B, monkeypatch):
+    """EEGCLIP_WGRAD_TR=1: the block's weight gradients through eegclip_split_rows_natural + eegclip_wgrad_tr against the plan GEMMs"""
+    g0, _ = _grads(dev, B, True, 1, True, monkeypatch)
+    g1, _ = _grads(dev, B, True, 1, True, monkeypatch, wgrad_tr=True)
+    assert g0.keys() == g1.keys()
+    for k, r in g0.items():
+        if k.endswith("key_projection.bias"):
+            continue
+        np.testing.assert_allclose(g1[k], r, atol=1e-3 * float(np.abs(r).max()) + 1e-7, err_msg=k)
+
+
+@pytest.mark.emu
+def test_weight_gradients_from_natural_planes_on_the_emulator(monkeypatch):
+    from emu_patch import product_on_emulator
+    with product_on_emulator():
+        check_weight_gradients_from_natural_planes("cpu", 2, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 256])
+def test_weight_gradients_from_natural_planes_on_the_gpu(B, monkeypatch):
+    check_weight_gradients_from_natural_planes("cuda", B, monkeypatch)
