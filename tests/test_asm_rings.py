@@ -26,3 +26,40 @@ def test_no_instruction_touches_an_in_flight_ring_register(tmp_path, src, min_lo
     text = out.read_text()
     assert text.count("global_load_dwordx4") >= min_loads             # the rings are really in this build
     assert check_asm_ring.check(str(out)) == 0
+
+
+GOOD = """
+_Z4kernv:
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v[2:3], off
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dwordx4 v[8:11], v[2:3], off offset:1024
+	;;#ASMEND
+	v_add_f32_e32 v20, v21, v22
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_mfma_f32_16x16x32_bf16 v[12:15], v[4:7], v[16:19], v[12:15]
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	v_mfma_f32_16x16x32_bf16 v[12:15], v[8:11], v[16:19], v[12:15]
+	s_endpgm
+"""
+
+
+def test_the_checker_itself_flags_a_copy_of_an_in_flight_register(tmp_path):
+    """the static check is not vacuous: the well-formed ring passes; a register copy ahead of the guarding wait, a use behind a wait that is too
+    weak, and a load that is never guarded are each reported"""
+    import check_asm_ring
+
+    def run(text):
+        f = tmp_path / "k.s"
+        f.write_text(text)
+        return check_asm_ring.check(str(f))
+
+    assert run(GOOD) == 0
+    assert run(GOOD.replace("\tv_add_f32_e32 v20, v21, v22", "\tv_mov_b32_e32 v30, v5")) == 1          # copies v5 while its load is in flight
+    assert run(GOOD.replace("s_waitcnt vmcnt(1)", "s_waitcnt vmcnt(2)")) == 1                          # vmcnt(2) does not cover the first load
+    assert run(GOOD.replace("\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n", "")) >= 1           # the second load is used unguarded
