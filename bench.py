@@ -34,10 +34,11 @@ PREC_BF16X3 = 1
 # algorithmic HBM bytes per sample of the fused transformer-block launches (csrc/token_block.hip): what has to cross HBM given that the
 # weight-gradient GEMMs and the attention backward read their operands from it
 _ROW, _ROWF, _QKV, _CTX = 64 * 250 * 4, 64 * 256 * 4, 64 * 744 * 4, 64 * 248 * 4
+# (_ROWF = 64 x 256 x 4 B is also one sample of a token-plane tensor: [hi | lo][64][256] bf16)
 TOKEN_BLOCK_BYTES = {
-    "fwd": 63 * 250 * 4 + 5 * _ROW + _QKV + _CTX + 2 * _ROWF,          # x in; h, r1, n1, r2, n3 + qkv + ctx + f1, g1 out
-    0: 3 * _ROW + _ROWF + 3 * _ROW + _ROWF + _CTX,                     # dn3, r2, r1, f1 in; df2, da1, dr1, dg1, dctx out
-    1: _QKV + 2 * _ROW,                                                # dqkv, dr1 in; dr1 out
+    "fwd": 63 * 250 * 4 + 4 * _ROW + _QKV + 6 * _ROWF,                 # x in; h, r1, r2, n3 + qkv + f1 (fp32) + x, h, ctx, n1, g1 (token planes) out
+    0: 3 * _ROW + _ROWF + _ROW + 3 * _ROWF + _CTX,                     # dn3, r2, r1, f1 in; dr1, df2 / dg1 / da1 (token planes), dctx out
+    1: 3 * _ROWF + 2 * _ROW + _ROWF,                                   # dq / dk / dv planes, dr1 in; dr1 + its planes out
 }
 
 
@@ -48,6 +49,10 @@ def algorithmic_cost(name, desc, B):
     y1 = B * 40 * 63 * 36 * 4
     if name == "eegclip_gemm_f32":
         return "mfma", 2.0 * desc.M * desc.N * desc.K, "flop"
+    if name == "eegclip_wgrad_tok":                                # the block's weight gradients from token planes: sum of 2 M N K over the launch's problems
+        return "mfma", float(desc.flops), "flop"
+    if name == "eegclip_wgrad_tok_reduce":                         # its ordered slab reduction: time counted in the family, no additional algorithmic work
+        return "mfma", 0.0, "flop"
     if name in ("eegclip_attention_fwd", "eegclip_attention_bwd", "eegclip_attention_bwd_x3"):
         per = 4 if name.endswith("fwd") else 10                    # QK^T + PV  |  + recompute, dP, dQ, dK, dV  (x 2 L^2 E flops)
         return "mfma", float(per * 64 * 64 * 62 * B * 4), "flop"
@@ -106,6 +111,8 @@ def family_of(name, desc):
     launches (forward + the two backward parts), the attention kernels, each other op on its own"""
     if name == "eegclip_gemm_f32":
         return "gemm_bf16x3" if (desc.precision & 0xff) == PREC_BF16X3 else "gemm_f32"
+    if name.startswith("eegclip_wgrad_tok"):
+        return "gemm_bf16x3"
     if name.startswith("eegclip_token_block_"):
         return "token_block"
     if name == "eegclip_attention_bwd_x3":
@@ -534,7 +541,8 @@ def main():
             for idx, v in pl.timings_ms().items():
                 name = pl.ops[idx][2]
                 d = _desc_of(pl, idx)
-                tag = name if d is None else f"{name}[part {d}]" if isinstance(d, int) else f"{name}[{d.M}x{d.N}x{d.K}{'/sk' + str(d.split_k) if d.split_k > 1 else ''}]"
+                tag = (name if d is None else f"{name}[part {d}]" if isinstance(d, int) else f"{name}[{d.label}/s{d.slices}]" if hasattr(d, "label")
+                       else f"{name}[{d.M}x{d.N}x{d.K}{'/sk' + str(d.split_k) if d.split_k > 1 else ''}]")
                 rows.append((float(np.mean(v[-args.steps:])), k[0], idx, tag))
         rows.sort(reverse=True)
         if rank == 0:
@@ -557,8 +565,8 @@ def main():
         big = max(ops, key=lambda o: work[o][1])
         dbig = _desc_of(plans[big[0]], big[1])
         traffic, tsrc = pmc_traffic(dominant, B)
-        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel (the Linears outside the fused transformer block: head forward / dX, every weight gradient; fp32 in/out, "
-                                       "split-bf16 products)",
+        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel + eeg::wgrad_tok_kernel (the Linears outside the fused transformer block: head forward / dX / weight "
+                                       "gradients on gemm_x3, the block's weight gradients from token planes on wgrad_tok + its slab reduction; split-bf16 products)",
                         "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)",
                         "token_block": "eeg::token_block_{fwd,bwd_a,bwd_b}_kernel (the encoder's transformer block, one workgroup per sample: forward and the "
                                        "two backward parts; bytes = activations that must cross HBM for the batch-wide weight-gradient GEMMs)"}
@@ -571,7 +579,7 @@ def main():
                 "share_of_kernel_time_single_stream": round(fam_ms[dominant] / sum(single.values()), 3),
                 "single_stream": {"achieved": round(w_tot / (ms_single * scale), 2), "frac": round(w_tot / (ms_single * scale) / peak, 4),
                                   "note": "same launches timed one at a time on one stream (3 instrumented steps before the timed region)"},
-                "largest_launch": {"shape": f"{dbig.M}x{dbig.N}x{dbig.K}" if hasattr(dbig, "M") else plans[big[0]].ops[big[1]][2], "avg_ms": round(live[big], 5),
+                "largest_launch": {"shape": f"{dbig.M}x{dbig.N}x{dbig.K}" if hasattr(dbig, "M") else getattr(dbig, "label", plans[big[0]].ops[big[1]][2]), "avg_ms": round(live[big], 5),
                                    "achieved": round(work[big][1] / (live[big] * scale), 2), "frac": round(work[big][1] / (live[big] * scale) / peak, 4)}}
         if bound == "mfma":
             roof["frac_of_f32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TF, 4)
@@ -737,6 +745,11 @@ def _desc_of(plan, idx):
         return a[0]._obj
     if name == "eegclip_token_block_bwd":
         return int(a[1])                                  # which part of the fused backward
+    if name.startswith("eegclip_wgrad_tok"):
+        import types
+        probs, n, B = a[0], int(a[1]), int(a[2])
+        return types.SimpleNamespace(flops=sum(2.0 * probs[i].M * probs[i].N * 64 * B for i in range(n)), label="+".join(f"{probs[i].M}x{probs[i].N}x{64 * B}" for i in range(n)),
+                                     slices=int(a[3]))
     return None
 
 

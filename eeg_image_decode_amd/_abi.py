@@ -44,7 +44,8 @@ class InfonceProblem(C.Structure):
 class TokenBlockDesc(C.Structure):
     _fields_ = ([("B", C.c_int), ("x", C.c_void_p), ("packed", C.c_void_p), ("bv", C.c_void_p), ("pe", C.c_void_p), ("tokens", C.c_void_p), ("ids", C.c_void_p)]
                 + [(k, C.c_void_p) for k in ("bqkv", "bo", "ln1_g", "ln1_b", "b1", "b2", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
-                + [(k, C.c_void_p) for k in ("h", "qkv", "ctx", "r1", "n1", "mu1", "rs1", "f1", "g1", "r2", "n2", "mu2", "rs2", "n3", "mu3", "rs3")]
+                + [(k, C.c_void_p) for k in ("h", "qkv", "r1", "mu1", "rs1", "f1", "r2", "n2", "mu2", "rs2", "n3", "mu3", "rs3")]
+                + [(k, C.c_void_p) for k in ("xp", "hp", "ctxp", "n1p", "g1p")]
                 + [("drop_p", C.c_float), ("eps", C.c_float), ("scale", C.c_float), ("seed", C.c_ulonglong)]
                 + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")])
 
@@ -52,10 +53,15 @@ class TokenBlockDesc(C.Structure):
 class TokenBlockBwdDesc(C.Structure):
     _fields_ = ([("B", C.c_int), ("packed", C.c_void_p)]
                 + [(k, C.c_void_p) for k in ("dn3", "n2", "r2", "r1", "f1", "mu1", "rs1", "mu2", "rs2", "mu3", "rs3", "ln1_g", "ln2_g", "ln2_b", "ln3_g")]
-                + [(k, C.c_void_p) for k in ("df2", "dg1", "da1", "dr1", "dctx", "partials", "dqkv")]
+                + [(k, C.c_void_p) for k in ("dr1", "dctx", "partials", "df2p", "dg1p", "da1p", "dr1p", "dqkvp")]
                 + [(k, C.c_void_p) for k in ("dln3_g", "dln3_b", "dln2_g", "dln2_b", "dln1_g", "dln1_b")]
                 + [("drop_p", C.c_float), ("seed", C.c_ulonglong)]
                 + [(k, C.c_uint) for k in ("site_embed", "site_attn_out", "site_ffn_act", "site_ffn_out")])
+
+
+class WgradTokProblem(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("a_group_stride", C.c_longlong), ("m_groups", C.c_int), ("heads_m", C.c_int), ("heads_n", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("bias_mfma", C.c_int)]
 
 
 PLAN_MAX_ARGS = 24
@@ -72,7 +78,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -119,7 +125,7 @@ PROTOTYPES = {
     "eegclip_clip_scale": [_P, _F, _P, _P],
     "eegclip_attention_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
-    "eegclip_attention_bwd_x3": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_attention_bwd_x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_proj1x1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_proj1x1_bwd_workspace_floats": [_I],
     "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
@@ -156,12 +162,11 @@ PROTOTYPES = {
     "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],
     "eegclip_token_block_bwd_workspace_floats": [_I],
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
-    "eegclip_split_transpose": [_P, _L, _I, _I, _I, _P, _P, _L, _P],
-    "eegclip_wgrad_planes_workspace_floats": [_I, _I, _I],
-    "eegclip_wgrad_planes": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P],
-    "eegclip_split_rows_natural": [_P, _L, _I, _I, _P, _P, _I, _P],
-    "eegclip_wgrad_tr_workspace_floats": [_I, _I, _I],
-    "eegclip_wgrad_tr": [_P, _P, _L, _P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P],
+    "eegclip_wgrad_tok_slices": [_I, _I],
+    "eegclip_wgrad_tok_workspace_floats": [C.POINTER(WgradTokProblem), _I, _I, _I],
+    "eegclip_wgrad_tok": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _I, _P],
+    "eegclip_wgrad_tok_reduce": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _P],
+    "eegclip_tok_planes_from_f32": [_P, _L, _I, _I, _I, _I, _P, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

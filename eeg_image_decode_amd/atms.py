@@ -479,10 +479,31 @@ class _Engine:
         EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan (diagnosis, A/B timing)"""
         return (not self.joint) and pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
 
-    def _token_block_bwd_enabled(self, pl):
-        """the fused backward of the block (then the forward does not store n2: the backward re-evaluates it); EEGCLIP_TOKEN_BLOCK_BWD=0: the
-        launch-per-op backward behind the fused forward"""
-        return self._token_block_enabled(pl) and os.environ.get("EEGCLIP_TOKEN_BLOCK_BWD", "1") != "0"
+    def _token_planes(self, b, B, *names):
+        """token-plane tensors (csrc/wgrad_tok.hip layout: per sample [hi | lo][64 tokens][256 channels] bf16) the fused kernels write for the
+        weight-gradient GEMMs instead of fp32"""
+        for n in names:
+            if n not in b:
+                b[n] = torch.empty((3, B, 2, L_TOK, 256) if n == "dqkvp" else (B, 2, L_TOK, 256), dtype=torch.bfloat16, device=self.device)
+        return [_p(b[n]) for n in names]
+
+    def saved_f32(self, B, name):
+        """fp32 view of a saved activation whichever form the plans of this engine keep it in (tests, feature inspection): the fused transformer
+        block leaves ctx / n1 / g1 / df2 / dg1 / da1 / dqkv as token planes (hi + lo = the value the split-bf16 GEMMs see)"""
+        b = self.bufs[B]
+        key = name + "p"
+        if key not in b:
+            return b[name]
+        t = b[key].to(torch.float32)
+        v = t[..., 0, :, :] + t[..., 1, :, :]                       # (..., B, 64, 256)
+        if name in ("ctx", "dqkv"):                                  # channel 64 head + d -> column 62 head + d
+            v = v.reshape(*v.shape[:-1], N_HEADS, 64)[..., :D_HEAD].reshape(*v.shape[:-1], HE)
+            if name == "dqkv":
+                v = v.permute(1, 2, 0, 3).reshape(B * L_TOK, 3 * HE)
+                return v
+        else:
+            v = v[..., :D_FF if name in ("g1", "dg1") else D_MODEL]
+        return v.reshape(B * L_TOK, -1)
 
     def stale(self, model):
         a, b = self._check
@@ -563,13 +584,17 @@ class _Engine:
             pl.call("eegclip_token_block_pack", _p(P[_E + "value_embedding.weight"]), _p(P[_LY + "attention.query_projection.weight"]),
                     _p(P[_LY + "attention.out_projection.weight"]), _p(P[_LY + "conv1.weight"]), _p(P[_LY + "conv2.weight"]), _p(self.tb_packed))
             tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
+            # the X operands of the block's weight gradients leave as token planes (what the kernel holds in LDS), not fp32: h keeps its fp32 copy
+            # too (the residual of the attention sublayer re-reads it), ctx / n1 / g1 exist only as planes; n2 is re-evaluated by the backward
+            xp, hp, ctxp, n1p, g1p = self._token_planes(b, B, "xp", "hp", "ctxp", "n1p", "g1p")
             pl.tb_desc = pl.call_desc("eegclip_token_block_fwd", _abi.TokenBlockDesc(
                 B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[_E + "value_embedding.bias"]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]),
                 bqkv=_p(P[_LY + "attention.query_projection.bias"]), bo=_p(P[_LY + "attention.out_projection.bias"]), ln1_g=_p(P[_LY + "norm1.weight"]),
                 ln1_b=_p(P[_LY + "norm1.bias"]), b1=_p(P[_LY + "conv1.bias"]), b2=_p(P[_LY + "conv2.bias"]), ln2_g=_p(P[_LY + "norm2.weight"]),
                 ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), ln3_b=_p(P["encoder.encoder.norm.bias"]),
-                h=_p(b["h"]), qkv=_p(b["qkv"]), ctx=_p(b["ctx"]), r1=_p(b["r1"]), n1=_p(b["n1"]), mu1=_p(b["mu1"]), rs1=_p(b["rs1"]), f1=_p(b["f1"]),
-                g1=_p(b["g1"]), r2=_p(b["r2"]), n2=None if self._token_block_bwd_enabled(pl) else _p(b["n2"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), n3=_p(b["n3"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]),
+                h=_p(b["h"]), qkv=_p(b["qkv"]), r1=_p(b["r1"]), mu1=_p(b["mu1"]), rs1=_p(b["rs1"]), f1=_p(b["f1"]),
+                r2=_p(b["r2"]), n2=None, mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), n3=_p(b["n3"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]),
+                xp=xp, hp=hp, ctxp=ctxp, n1p=n1p, g1p=g1p,
                 drop_p=pe_, eps=EPS, scale=1.0 / math.sqrt(D_HEAD), seed=0, site_embed=SITE_EMBED, site_attn=SITE_ATTN, site_attn_out=SITE_ATTN_OUT,
                 site_ffn_act=SITE_FFN_ACT, site_ffn_out=SITE_FFN_OUT), seeded=pe_ > 0.0)
         else:
@@ -797,72 +822,52 @@ class _Engine:
             # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
             pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
         pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
-        if self._token_block_bwd_enabled(pl) and hasattr(self, "tb_packed"):
+        fused = self._token_block_enabled(pl) and hasattr(self, "tb_packed")
+        if fused:
             # the dX chain of the transformer block, one workgroup per sample (csrc/token_block.hip): part 0 = final LN' .. dctx, the attention
             # backward, part 1 = dh.  The weight-gradient GEMMs read what the parts leave in HBM (df2, dg1 = df1, da1, dqkv, dr1) on the second stream.
             if "tb_part" not in b:
                 b["tb_part"] = torch.empty(int(lib().eegclip_token_block_bwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
+            df2p, dg1p, da1p, dr1p, dqkvp = self._token_planes(b, B, "df2p", "dg1p", "da1p", "dr1p", "dqkvp")
+            xp, hp, ctxp, n1p, g1p = self._token_planes(b, B, "xp", "hp", "ctxp", "n1p", "g1p")
             bd = _abi.TokenBlockBwdDesc(
                 B=B, packed=_p(self.tb_packed), dn3=_p(b["dn3"]), n2=None, r2=_p(b["r2"]), r1=_p(b["r1"]), f1=_p(b["f1"]), mu1=_p(b["mu1"]),
                 rs1=_p(b["rs1"]), mu2=_p(b["mu2"]), rs2=_p(b["rs2"]), mu3=_p(b["mu3"]), rs3=_p(b["rs3"]), ln1_g=_p(P[_LY + "norm1.weight"]),
-                ln2_g=_p(P[_LY + "norm2.weight"]), ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), df2=_p(b["df2"]), dg1=_p(b["dg1"]), da1=_p(b["da1"]),
-                dr1=_p(b["dr1"]), dctx=_p(b["dctx"]), partials=_p(b["tb_part"]), dqkv=_p(b["dqkv"]),
+                ln2_g=_p(P[_LY + "norm2.weight"]), ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]),
+                dr1=_p(b["dr1"]), dctx=_p(b["dctx"]), partials=_p(b["tb_part"]), df2p=df2p, dg1p=dg1p, da1p=da1p, dr1p=dr1p, dqkvp=dqkvp,
                 dln3_g=_p(G["encoder.encoder.norm.weight"]), dln3_b=_p(G["encoder.encoder.norm.bias"]), dln2_g=_p(G[_LY + "norm2.weight"]),
                 dln2_b=_p(G[_LY + "norm2.bias"]), dln1_g=_p(G[_LY + "norm1.weight"]), dln1_b=_p(G[_LY + "norm1.bias"]),
                 drop_p=pe_, seed=0, site_embed=SITE_EMBED, site_attn_out=SITE_ATTN_OUT, site_ffn_act=SITE_FFN_ACT, site_ffn_out=SITE_FFN_OUT)
             pl._keep.append(bd)
             if pe_ > 0.0:
                 pl._seed_descs.append(bd)
+            variant = int(os.environ.get("EEGCLIP_WGRAD_VARIANT", "0"))                # tuning aid: 0 = 512-thread workgroups, 1 = 256-thread
+
+            def wgrad_tok(tag, problems, side=True):
+                """the block's weight gradients from the token planes the fused kernels leave (csrc/wgrad_tok.hip): `problems` become ready together
+                and run as ONE launch + one ordered slab reduction.  (name, dY planes, groups, X planes, M, N, heads_m, heads_n, bias, bias_mfma)"""
+                arr = (_abi.WgradTokProblem * len(problems))()
+                for i, (name, a, mg, x, M, N, hm, hn, bias, bm) in enumerate(problems):
+                    arr[i] = _abi.WgradTokProblem(a=a, b=x, a_group_stride=B * 65536 if mg > 1 else 0, m_groups=mg, heads_m=hm, heads_n=hn, M=M, N=N,
+                                                  out=_p(G[name]), ldo=N, bias_out=_p(G[bias]) if bias else None, bias_mfma=bm)
+                groups = sum(q[2] for q in problems)
+                slices = wsk if wsk > 0 else int(lib().eegclip_wgrad_tok_slices(groups, B))
+                key = "wk:" + tag
+                if key not in b:
+                    b[key] = torch.empty(int(lib().eegclip_wgrad_tok_workspace_floats(arr, len(problems), B, slices)), dtype=torch.float32, device=self.device)
+                pl._keep.append(arr)
+                pl.call("eegclip_wgrad_tok", arr, len(problems), B, slices, _p(b[key]), variant, side=side)
+                pl.call("eegclip_wgrad_tok_reduce", arr, len(problems), B, slices, _p(b[key]), side=side)
+
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
-            # (three independent GEMMs of ~2 workgroups per CU each: alternating between the two side streams lets them share the GPU)
-            s2 = 2 if os.environ.get("EEGCLIP_SIDE2", "0") == "1" else True        # (measured: no gain at B = 256, 1.105 vs 1.095 ms)
-            if os.environ.get("EEGCLIP_WGRAD_PLANES", "0") == "1":
-                # OPT-IN (measured slower end to end, r3): the block's weight gradients over bf16 planes (csrc/wgrad_planes.hip): both operands
-                # transposed + split ONCE by a bandwidth-bound pass, then a pure planes GEMM.  Stand-alone on the MI355X: the planes GEMM takes 19 us
-                # against 30 us of the plan GEMM (250 x 256 x 16384), but the two transposing splits in front of it cost 9.5 us each -- a win only once
-                # the producers write the transposed planes themselves
-                bf = torch.bfloat16
-                pad = lambda v, m: (v + m - 1) // m * m
-
-                def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
-                    key = "wg:" + name
-                    if key not in b:
-                        ldp = K + 64                               # plane row stride: one 128-byte line of skew (a power-of-two stride camps on a few channels)
-                        b[key] = (torch.empty(2, pad(Nout, 128), ldp, dtype=bf, device=self.device), torch.empty(2, pad(Nin, 64), ldp, dtype=bf, device=self.device),
-                                  torch.empty(int(lib().eegclip_wgrad_planes_workspace_floats(Nout, Nin, K)), dtype=torch.float32, device=self.device))
-                    at, bt, ws = b[key]
-                    pl.call("eegclip_split_transpose", dY, ldy, K, Nout, at.shape[1], _p(at[0]), _p(at[1]), at.shape[2], side=side)
-                    pl.call("eegclip_split_transpose", X, ldx, K, Nin, bt.shape[1], _p(bt[0]), _p(bt[1]), bt.shape[2], side=side)
-                    pl.call("eegclip_wgrad_planes", _p(at[0]), _p(at[1]), _p(bt[0]), _p(bt[1]), at.shape[2], Nout, Nin, K, _p(G[name]), Nin,
-                            _p(G[bias]) if bias else None, _p(ws), side=side)
-            elif os.environ.get("EEGCLIP_WGRAD_TR", "0") == "1":
-                # OPT-IN (parity-tested on the emulator and the GPU; measured 1.09 vs 1.01 ms per step with the two plain splits in front of every
-                # GEMM and an untuned kernel): the same weight gradients from planes in their NATURAL
-                # token-major layout -- a plain split (no transposition) per operand, then csrc/wgrad_planes.hip: wgrad_tr_kernel fetches both MFMA
-                # operands through the LDS transpose read.  The fused kernels hold these operands as planes in LDS already: once they write them
-                # out themselves the splits disappear
-                bf = torch.bfloat16
-                pad8 = lambda v: (v + 7) // 8 * 8
-
-                def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
-                    key = "wt:" + name
-                    if key not in b:
-                        b[key] = (torch.empty(2, K, pad8(Nout), dtype=bf, device=self.device), torch.empty(2, K, pad8(Nin), dtype=bf, device=self.device),
-                                  torch.empty(int(lib().eegclip_wgrad_tr_workspace_floats(Nout, Nin, K)), dtype=torch.float32, device=self.device))
-                    at, bt, ws = b[key]
-                    pl.call("eegclip_split_rows_natural", dY, ldy, K, Nout, _p(at[0]), _p(at[1]), at.shape[2], side=side)
-                    pl.call("eegclip_split_rows_natural", X, ldx, K, Nin, _p(bt[0]), _p(bt[1]), bt.shape[2], side=side)
-                    pl.call("eegclip_wgrad_tr", _p(at[0]), _p(at[1]), at.shape[2], _p(bt[0]), _p(bt[1]), bt.shape[2], Nout, Nin, K, _p(G[name]), Nin,
-                            _p(G[bias]) if bias else None, _p(ws), side=side)
-            wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
-            wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias", side=s2)
-            wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
-                  bias=_LY + "attention.out_projection.bias")
-            pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
-                    pe_, 0, SITE_ATTN, seed_at=10)
-            wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
-                  bias=_LY + "attention.query_projection.bias", side=s2)
+            wgrad_tok("ffn_out", [
+                (_LY + "conv2.weight", df2p, 1, g1p, D_MODEL, D_FF, 0, 0, _LY + "conv2.bias", 1),          # g1 has 256 real channels: no ones column
+                (_LY + "conv1.weight", dg1p, 1, n1p, D_FF, D_MODEL, 0, 0, _LY + "conv1.bias", 0),
+                (_LY + "attention.out_projection.weight", da1p, 1, ctxp, D_MODEL, HE, 0, 1, _LY + "attention.out_projection.bias", 0)])
+            pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), dqkvp, 1, B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                    pe_, 0, SITE_ATTN, seed_at=11)
+            wgrad_tok("qkv", [(_LY + "attention.query_projection.weight", dqkvp, 3, hp, 3 * HE, D_MODEL, 1, 0, _LY + "attention.query_projection.bias", 0)])
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 1)
         else:
             # final LN, LN2
@@ -886,8 +891,12 @@ class _Engine:
                   bias=_LY + "attention.out_projection.bias")
             pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
                     planes=PLT["out"])
-            pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
-                    pe_, 0, SITE_ATTN, seed_at=10)
+            if attn_bwd == "eegclip_attention_bwd_x3":
+                pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), 0, B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                        pe_, 0, SITE_ATTN, seed_at=11)
+            else:
+                pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
+                        pe_, 0, SITE_ATTN, seed_at=10)
             wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
                   bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
             pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
@@ -901,10 +910,16 @@ class _Engine:
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
-        if not self.joint:
+        pl.x_gemm = None
+        if fused:
+            # value embedding: dY = the token-row gradients part 1 left as planes, X = the EEG sample planes of the forward (row 0 zero: the subject
+            # token has no EEG row; ones column in rows 1..63: bias gradient = sum of the 63 channel rows of every sample)
+            wgrad_tok("embed", [(_E + "value_embedding.weight", dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, _E + "value_embedding.bias", 0)], side=False)
+        elif not self.joint:
             pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), hmap, 0, D(T_LEN), D(1),
                     _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH),
                     rowsum_a=_p(G[_E + "value_embedding.bias"]))      # bias gradient = sum of the 63 channel rows of every sample
+        if not self.joint:
             if want_dx:
                 pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, hmap, D(1),
                         _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1), planes=PLT["embed"])
@@ -1091,7 +1106,7 @@ class _Engine:
         pl._keep_x = (x, dout)
         if self.joint:
             self._joint_layout(pl, b, B, None, x.data_ptr(), True)
-        else:
+        elif pl.x_gemm is not None:
             pl.x_gemm.B = x.data_ptr()          # the value-embedding weight-gradient GEMM reads the EEG batch
         if not b["zb_clean"]:                   # an eval-mode forward, or a second backward through one forward: clear the arena here
             b["zb"].zero_()

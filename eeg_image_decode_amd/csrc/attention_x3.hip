@@ -28,7 +28,8 @@ constexpr int AX_TENSOR = 2 * AX_PLANE;           // hi | lo
 struct ax_args {
     const float* qkv;     // (B*L, ld): q at col h*E+e, k at HE + h*E+e, v at 2HE + h*E+e
     const float* dctx;    // (B*L, H*E)
-    float* dqkv;          // (B*L, ld)
+    float* dqkv;          // (B*L, ld), or null:
+    unsigned char* dqkvp; // dq | dk | dv as token planes (csrc/wgrad_tok.hip: per sample [hi | lo][64][256], channel 64 head + e), groups B * 64 KB apart
     int B, H, E, ld;
     float scale, drop_p;
     unsigned long long seed;
@@ -80,6 +81,15 @@ __device__ __forceinline__ void ax_store4(float* p, int valid, f32x4 v) {
         *reinterpret_cast<ax_f2*>(p) = ax_f2{v[0], v[1]};
         if (valid == 3) p[2] = v[2];
     } else if (valid == 1) p[0] = v[0];
+}
+
+// 4 consecutive dims (e0 ..) of one token row as token planes: 8 bytes into the hi plane, 8 into the lo plane 32 KB behind.  Dims >= E are exact
+// zeros in `v` (the operand planes are zero there), and they must be WRITTEN: the consumers read all 64 channels of a head.
+__device__ __forceinline__ void ax_store4_planes(unsigned char* row_base, int e0, f32x4 v) {
+    u32x2_t hi, lo;
+    x3_split4(v[0], v[1], v[2], v[3], hi, lo);
+    *reinterpret_cast<u32x2_t*>(row_base + 2 * e0) = hi;
+    *reinterpret_cast<u32x2_t*>(row_base + 32768 + 2 * e0) = lo;
 }
 
 template <bool TRAIN>
@@ -208,13 +218,15 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const ax_args 
             }
         }
         float* out = a.dqkv + ((long long)b * AX_L + 16 * w + fr) * a.ld + h * E;
+        unsigned char* outp = a.dqkvp + (long long)b * 65536 + (16 * w + fr) * 512 + 128 * h;
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
             const int e0 = 16 * et + 4 * g;
             f32x4 v = dq[et];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= a.scale;
-            if (e0 < E) ax_store4(out + e0, E - e0, v);
+            if (a.dqkvp) ax_store4_planes(outp, e0, v);
+            else if (e0 < E) ax_store4(out + e0, E - e0, v);
         }
     }
     __syncthreads();                                               // every wave is done with K and V
@@ -249,6 +261,20 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const ax_args 
             dk[et] = ax_mfma3(qh, ql, sh, sl, dk[et]);            // dK^T, same layout
         }
     }
+    if (a.dqkvp) {
+        const long long grp = (long long)a.B * 65536;
+        unsigned char* outp = a.dqkvp + (long long)b * 65536 + (16 * w + fr) * 512 + 128 * h;
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            const int e0 = 16 * et + 4 * g;
+            f32x4 v = dk[et];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= a.scale;
+            ax_store4_planes(outp + grp, e0, v);
+            ax_store4_planes(outp + 2 * grp, e0, dv[et]);
+        }
+        return;
+    }
     float* outk = a.dqkv + ((long long)b * AX_L + 16 * w + fr) * a.ld + HE + h * E;
 #pragma unroll
     for (int et = 0; et < 4; ++et) {
@@ -268,12 +294,15 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const ax_args 
 using namespace eeg;
 
 // same contract as eegclip_attention_bwd (csrc/attention.hip); split-bf16 products.  E and ld even, qkv / dctx / dqkv 8-byte aligned.
-extern "C" int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
+// dqkv_planes = 1: `dqkv` receives dq | dk | dv as token planes instead (3 groups of B * 64 KB, 16-byte aligned; needs H * 64 <= 256)
+extern "C" int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, void* dqkv, int dqkv_planes, int B, int L, int H, int E, int ld, float scale,
                                         float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (dqkv_planes && (H > 4 || (reinterpret_cast<uintptr_t>(dqkv) & 15u))) return dqkv && H <= 4 ? EEGCLIP_EALIGN : EEGCLIP_EINVAL;
     if (!qkv || !dctx || !dqkv || B < 1 || L != AX_L || H < 1 || E < 2 || E > 64 || (E & 1) || (ld & 1) || ld < 3 * H * E || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dctx) | reinterpret_cast<uintptr_t>(dqkv)) & 7u) return EEGCLIP_EALIGN;
-    const ax_args a{qkv, dctx, dqkv, B, H, E, ld, scale, drop_p, seed, site};
+    const ax_args a{qkv, dctx, dqkv_planes ? nullptr : static_cast<float*>(dqkv), dqkv_planes ? static_cast<unsigned char*>(dqkv) : nullptr, B, H, E, ld, scale,
+                    drop_p, seed, site};
     const size_t lds = 4 * AX_TENSOR;
     if (drop_p > 0.f) EEG_LAUNCH(attention_bwd_x3_kernel<true>, dim3(B * H), dim3(256), lds, stream, a);
     else              EEG_LAUNCH(attention_bwd_x3_kernel<false>, dim3(B * H), dim3(256), lds, stream, a);

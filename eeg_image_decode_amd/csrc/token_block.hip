@@ -270,13 +270,37 @@ __device__ __forceinline__ void tb_st4(float* p, int valid, f32x4 v) {
     else *reinterpret_cast<tb_f2*>(p) = tb_f2{v[0], v[1]};
 }
 
+
+// the AP image of this sample (both planes, 64 rows x 256 channels) -> its 64 KB block of a token-plane tensor (csrc/wgrad_tok.hip: [hi | lo][64][256],
+// unswizzled): chunk q = t + 512 j of 16 bytes = (plane q >> 11, row (q >> 5) & 63, chunk q & 31).  ONES_FROM < 64: channel 255 of the hi plane of rows
+// >= ONES_FROM := 1.0 -- column 255 of X^T dY is then the bias gradient.  Called AFTER the k-loop of the GEMM that consumes the planes (its weight
+// loads have been issued: a load behind these stores would wait for them) and before the barrier that lets the next stage overwrite AP.
+template <int ONES_FROM>
+__device__ __forceinline__ void tb_planes_out(const unsigned char* AP, unsigned char* dst, int t) {
+    // row = (t >> 5) + 16 (j & 3), so row & 15 = t >> 5 for every j: ONE per-lane LDS offset and ONE per-lane global offset, everything else is an
+    // immediate / a scalar add (eight hoisted address pairs made the forward kernel spill 200 registers)
+    const unsigned lds_off = (unsigned)((t >> 5) * 512 + (((t & 31) ^ (t >> 5)) << 4)), g_off = (unsigned)t * 16u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        tb_u4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = *reinterpret_cast<const tb_u4*>(AP + half * TB_AP_PLANE + j * 8192 + lds_off);
+            if (ONES_FROM < 64 && half == 0 && (t & 31) == 31 && (ONES_FROM == 0 || j > 0 || (t >> 5) >= ONES_FROM)) v[j][3] = (v[j][3] & 0xffffu) | 0x3F800000u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<tb_u4*>(dst + (half * 4 + j) * 8192 + g_off) = v[j];
+    }
+}
+
 struct tb_fwd_args {
     const float* x;
     const unsigned short* packed;
     const float *bv, *pe, *tokens;
     const long long* ids;
     const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
-    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;
+    float *h, *qkv, *r1, *mu1, *rs1, *f1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;
+    unsigned char *xp, *hp, *ctxp, *n1p, *g1p;                   // token planes (64 KB per sample) of the weight-gradient GEMMs' X operands; xp may be null
     float drop_p, eps, scale;
     unsigned long long seed;
     unsigned site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
@@ -643,6 +667,8 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             if (valid < 4) { o[2] = 0.f; o[3] = 0.f; }
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
+        // the EEG sample as token planes (row 0 zero: the subject token has no EEG row) = the X operand of the value embedding's weight gradient
+        if (a.xp && !(a.dbg & 1u)) tb_planes_out<1>(AP, a.xp + (long long)b * (2 * TB_AP_PLANE), t);
     }
     raw_barrier();
 
@@ -689,11 +715,12 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
                 case 2: tb_qkv_pass<2>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<2>(HQ, lane, cur); break;
                 default: tb_qkv_pass<3>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<3>(HQ, lane, cur); break;
             }
+            if (rd == 1 && !(a.dbg & 1u)) tb_planes_out<0>(AP, a.hp + (long long)b * (2 * TB_AP_PLANE), t);      // (the last reader of the h planes has its weights)
             raw_barrier();
             tb_attention<TRAIN>(a, HQ, b, 2 * rd + hip, w & 3, lane, ctxr[rd]);
             raw_barrier();                                           // the pair's planes are dead (and, second round, the h planes too)
         }
-        // context -> HBM (natural (row, 248) layout) and -> A planes with 64 columns per head (dims 62, 63 are exact zeros)
+        // context -> A planes with 64 columns per head (dims 62, 63 are exact zeros); S4 copies the planes to HBM
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
             const int head = 2 * rd + hip, m = 16 * (w & 3) + fr;
@@ -701,7 +728,6 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
                 const f32x4 c = ctxr[rd][dt];
-                if (d0 < TB_E && !(a.dbg & 1u)) tb_st4(a.ctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, c);
                 tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, 64 * head + d0), c[0], c[1], c[2], c[3]);
             }
         }
@@ -720,11 +746,12 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             for (int i = 0; i < 4; ++i) o[i] = i < valid ? v[i] + bias[i] : 0.f;
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
+        if (!(a.dbg & 1u)) tb_planes_out<0>(AP, a.ctxp + (long long)b * (2 * TB_AP_PLANE), t);      // ctx planes (channel 255 = dim 63 of head 3: the ones column)
     }
     __syncthreads();                                                 // (the one barrier that also waits for global stores: S5 re-reads h)
     tb_stamp(a, b, t, 5);
     // ---- S5: r1 = h + dropout(attention output), n1 = LayerNorm1(r1); n1 stays in XF (FFN residual) and goes to the A planes
-    tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, a.n1, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
+    tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, nullptr, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
                              nullptr, XF, AP);
     raw_barrier();
 
@@ -751,9 +778,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
                 const float ge = gelu_erf(f[i]);
                 gq[i] = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
             }
-            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.g1 + ob + ol) = gq;
             v = gq;
         });
+        if (!(a.dbg & 1u)) tb_planes_out<0>(AP, a.n1p + (long long)b * (2 * TB_AP_PLANE), t);
         raw_barrier();                                               // every wave is done with the n1 planes
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, n0), v[0], v[1], v[2], v[3]);
@@ -766,14 +793,27 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     {
         f32x4 acc[4][2];
         tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-        raw_barrier();
-        tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
-            const f32x4 bias = tb_ld4(a.b2 + n0, valid);
-            f32x4 o;
+        f32x4 bias2[2];                                              // (loads before the stores below)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = i < valid ? v[i] + bias[i] : 0.f;
-            *reinterpret_cast<f32x4*>(AP + xf_off(m, n0)) = o;
-        });
+        for (int j = 0; j < 2; ++j) {
+            const int n0 = 32 * w + 16 * j + 4 * g;
+            bias2[j] = n0 < TB_D ? tb_ld4(a.b2 + n0, TB_D - n0 >= 4 ? 4 : 2) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!(a.dbg & 1u)) tb_planes_out<64>(AP, a.g1p + (long long)b * (2 * TB_AP_PLANE), t);      // g1 planes: 256 real channels, no ones column
+        raw_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                // (tb_for_tiles with the tile index j a compile-time constant: bias2[j] stays in registers)
+            const int n0 = 32 * w + 16 * j + 4 * g;
+            if (n0 >= TB_D) continue;
+            const int valid = TB_D - n0 >= 4 ? 4 : TB_D - n0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = i < valid ? acc[mt][j][i] + bias2[j][i] : 0.f;
+                *reinterpret_cast<f32x4*>(AP + xf_off(16 * mt + fr, n0)) = o;
+            }
+        }
     }
     raw_barrier();
     tb_stamp(a, b, t, 8);
@@ -795,8 +835,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
 struct tb_bwd_args {
     const unsigned short* packed;
     const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln2_b, *ln3_g;
-    float *df2, *dg1, *da1, *dr1, *dctx, *partials;
-    const float* dqkv;
+    float *dr1, *dctx, *partials;
+    unsigned char *df2p, *dg1p, *da1p, *dr1p;                    // token planes: the dY operands of the weight-gradient GEMMs (dr1p may be null)
+    const unsigned char* dqkvp;                                  // dq | dk | dv token planes (eegclip_attention_bwd_x3), B * 64 KB apart
     float drop_p;
     unsigned long long seed;
     unsigned site_embed, site_attn_out, site_ffn_act, site_ffn_out;
@@ -856,7 +897,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
     float* const part = a.partials + (long long)b * (6 * 256);
 
-    // ---- T1: final LayerNorm' and LayerNorm2' chained per row in registers; df2 = dropout'(dr2) -> HBM + A planes, dr2 -> XF
+    // ---- T1: final LayerNorm' and LayerNorm2' chained per row in registers; df2 = dropout'(dr2) -> A planes (T2 copies them to HBM), dr2 -> XF
     {
         float pe[4][4], po[4][4];                                    // [g3 b3 g2 b2] x 4 columns, even / odd rows
 #pragma unroll
@@ -924,10 +965,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const int cp = c0 + 2 * p;
                 const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr2[2 * p] * ksc : 0.f) : dr2[2 * p];
                 const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr2[2 * p + 1] * ksc : 0.f) : dr2[2 * p + 1];
-                if (ok[p]) {
-                    *reinterpret_cast<tb_f2*>(a.df2 + rbase + (unsigned)cp) = tb_f2{d0, d1};
-                    *reinterpret_cast<tb_f2*>(XF + xf_off(r, cp)) = tb_f2{dr2[2 * p], dr2[2 * p + 1]};
-                }
+                if (ok[p]) *reinterpret_cast<tb_f2*>(XF + xf_off(r, cp)) = tb_f2{dr2[2 * p], dr2[2 * p + 1]};
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
             }
             if ((rr & 1) && lane == 63) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, 254), 0.f, 0.f);
@@ -936,7 +974,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     }
     raw_barrier();
 
-    // ---- T2: dg1 = df2 W2, then the FFN activation's dropout' and gelu' (pre-activation f1 from HBM): df1 -> HBM (the dW1 GEMM reads it) + planes
+    // ---- T2: dg1 = df2 W2, then the FFN activation's dropout' and gelu' (pre-activation f1 from HBM): df1 -> A planes (T3 copies them to HBM)
     {
         f32x4 acc[4][2];
         tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
@@ -946,6 +984,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 fpre[mt][j] = *reinterpret_cast<const f32x4*>(a.f1 + (long long)b * (TB_L * TB_FF) + (unsigned)((16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4)));
+        tb_planes_out<64>(AP, a.df2p + (long long)b * (2 * TB_AP_PLANE), t);      // df2 planes (bias gradient: all-ones fragment in the GEMM, g1 has 256 channels)
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             const long long ob = (long long)b * (TB_L * TB_FF);
             const unsigned ol = (unsigned)(m * TB_FF + n0);
@@ -957,7 +996,6 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const float d = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? v[i] * ksc : 0.f) : v[i];
                 v[i] = d * gelu_erf_grad(f[i]);
             }
-            *reinterpret_cast<f32x4*>(a.dg1 + ob + ol) = v;
         });
         raw_barrier();                                               // every wave is done with the df2 planes
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
@@ -977,10 +1015,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             for (int i = 0; i < 4; ++i) o[i] = i < valid ? o[i] + v[i] : 0.f;
             *p = o;
         });
+        tb_planes_out<64>(AP, a.dg1p + (long long)b * (2 * TB_AP_PLANE), t);      // dg1 = df1 planes
     }
     raw_barrier();
 
-    // ---- T4: LayerNorm1': dr1 -> HBM (the residual path into dh), da1 = dropout'(dr1) -> HBM + A planes
+    // ---- T4: LayerNorm1': dr1 -> HBM (the residual path into dh), da1 = dropout'(dr1) -> A planes (T5 copies them to HBM)
     {
         float pe[2][4], po[2][4];
 #pragma unroll
@@ -1030,7 +1069,6 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr1[2 * p + 1] * ksc : 0.f) : dr1[2 * p + 1];
                 if (ok[p]) {
                     *reinterpret_cast<tb_f2*>(a.dr1 + rbase + (unsigned)cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
-                    *reinterpret_cast<tb_f2*>(a.da1 + rbase + (unsigned)cp) = tb_f2{d0, d1};
                 }
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
             }
@@ -1049,6 +1087,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             const int head = n0 >> 6, d0 = n0 & 63;
             if (d0 < TB_E) tb_st4(a.dctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, v);
         });
+        tb_planes_out<64>(AP, a.da1p + (long long)b * (2 * TB_AP_PLANE), t);
     }
 }
 
@@ -1061,34 +1100,31 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
     const int b = blockIdx.x;
     const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
     f32x4 acc[4][2];
-    // the k pad of the planes (columns 64 head + 62, 63) stays zero for all three operands
-    if (t < 256) {
-        const int row = t & 63, head = t >> 6;
-        tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, 64 * head + 62), 0.f, 0.f);
-    }
+    // dq | dk | dv of the sample arrive as token planes = AP images (csrc/attention_x3.hip writes them; columns 64 head + 62, 63 are exact zeros): LDS-DMA
+    // copies, no VGPRs and no fp32 -> hi | lo split here.  Wave w deposits rows 8 w .. 8 w + 7 of both planes (1 KB = 2 rows per instruction; the
+    // lane picks the source chunk so that the AP swizzle comes out).  dq -> AP and dk -> the XF region at once, dv -> AP when the first GEMM is done.
+    auto dma_planes = [&](int which, unsigned char* dst) {
+        const unsigned char* src = a.dqkvp + ((long long)which * gridDim.x + b) * (2 * TB_AP_PLANE);
 #pragma unroll
-    for (int which = 0; which < 3; ++which) {
-        // dq | dk | dv rows of the sample (natural (row, 744) layout) -> A planes, 64 columns per head
-        tb_f2 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int u = t + TB_THREADS * j;                        // pair index: row = u / 124, pair = u % 124
-            const int row = u / 124, c = 2 * (u - 124 * row);
-            v[j] = u < 64 * 124 ? *reinterpret_cast<const tb_f2*>(a.dqkv + (long long)b * (TB_L * 3 * TB_HE) + (unsigned)(row * (3 * TB_HE) + which * TB_HE + c)) : tb_f2{0.f, 0.f};
+        for (int i = 0; i < 8; ++i) {
+            const int plane = i >> 2, row = 8 * w + 2 * (i & 3) + (lane >> 5), c = lane & 31;
+            lds_dma16(dst + plane * TB_AP_PLANE + (8 * w + 2 * (i & 3)) * 512, src + plane * TB_AP_PLANE + row * 512 + ((c ^ (row & 15)) << 4));
         }
-        if (which > 0) raw_barrier();                                // the previous operand's GEMM has read the planes
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int u = t + TB_THREADS * j;
-            if (u < 64 * 124) {
-                const int row = u / 124, c = 2 * (u - 124 * row), head = c / TB_E, d = c - TB_E * head;
-                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, 64 * head + d), v[j][0], v[j][1]);
-            }
-        }
-        raw_barrier();
-        if (which == 0) tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_QT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-        else tb_gemm<2, 3u, TB_BWD_PF, false, true>(AP, a.packed + TB_OFF_QT + which * TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-    }
+    };
+    dma_planes(0, AP);
+    dma_planes(1, XF);
+    wait_vmcnt<8>();
+    raw_barrier();
+    tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_QT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+    raw_barrier();                                                   // every wave has read the dq planes
+    dma_planes(2, AP);
+    wait_vmcnt<8>();
+    raw_barrier();
+    tb_gemm<2, 3u, TB_BWD_PF, false, true>(XF, a.packed + TB_OFF_QT + TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+    wait_vmcnt<0>();
+    raw_barrier();
+    tb_gemm<2, 3u, TB_BWD_PF, false, true>(AP, a.packed + TB_OFF_QT + 2 * TB_MAT_ELEMS + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+    raw_barrier();                                                   // (the dk planes in the XF region are dead: the epilogue writes its fp32 image there)
     // + the residual-path gradient, then the embedding dropout' over the flat sample (one Philox block = 4 consecutive flat elements)
     tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
         const f32x4 r = tb_ld4(a.dr1 + (long long)b * (TB_L * TB_D) + (unsigned)(m * TB_D + n0), valid);
@@ -1115,7 +1151,20 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_b_kernel(const 
                 for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ksc : 0.f;
             }
             *reinterpret_cast<f32x4*>(ob + i0) = f32x4{v[0], v[1], v[2], v[3]};
+            if (a.dr1p) {                                            // dh as token planes: the dY operand of the value embedding's weight gradient
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, col), v[0], v[1]);
+                tb_store_planes2(AP, TB_AP_PLANE, ap_off(row2, col2), v[2], v[3]);
+            }
         }
+    }
+    if (a.dr1p) {
+        if (t < 128) {                                               // channels 250 .. 255 of both planes: zero
+            const int row = t & 63, plane = t >> 6;
+#pragma unroll
+            for (int k = 250; k < 256; k += 2) *reinterpret_cast<unsigned*>(AP + plane * TB_AP_PLANE + ap_off(row, k)) = 0u;
+        }
+        raw_barrier();
+        tb_planes_out<64>(AP, a.dr1p + (long long)b * (2 * TB_AP_PLANE), t);
     }
 }
 
@@ -1155,13 +1204,14 @@ extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, cons
 
 extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream) {
     if (!d || d->B < 1 || !d->x || !d->packed || !d->bv || !d->pe || !d->tokens || !d->bqkv || !d->bo || !d->ln1_g || !d->ln1_b || !d->b1 || !d->b2 ||
-        !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctx || !d->r1 || !d->n1 || !d->mu1 || !d->rs1 || !d->f1 || !d->g1 ||
-        !d->r2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
+        !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctxp || !d->r1 || !d->n1p || !d->mu1 || !d->rs1 || !d->f1 || !d->g1p ||
+        !d->hp || !d->r2 || !d->mu2 || !d->rs2 || !d->n3 || !d->mu3 || !d->rs3 || d->drop_p < 0.f || d->drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->h) | reinterpret_cast<uintptr_t>(d->f1) |
-                           reinterpret_cast<uintptr_t>(d->g1) | reinterpret_cast<uintptr_t>(d->b1);
-    const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->qkv) | reinterpret_cast<uintptr_t>(d->ctx) |
-                          reinterpret_cast<uintptr_t>(d->r1) | reinterpret_cast<uintptr_t>(d->n1) | reinterpret_cast<uintptr_t>(d->r2) |
+                           reinterpret_cast<uintptr_t>(d->b1) | reinterpret_cast<uintptr_t>(d->xp) | reinterpret_cast<uintptr_t>(d->hp) |
+                           reinterpret_cast<uintptr_t>(d->ctxp) | reinterpret_cast<uintptr_t>(d->n1p) | reinterpret_cast<uintptr_t>(d->g1p);
+    const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->qkv) |
+                          reinterpret_cast<uintptr_t>(d->r1) | reinterpret_cast<uintptr_t>(d->r2) |
                           reinterpret_cast<uintptr_t>(d->n2) | reinterpret_cast<uintptr_t>(d->n3) | reinterpret_cast<uintptr_t>(d->bv) |
                           reinterpret_cast<uintptr_t>(d->pe) | reinterpret_cast<uintptr_t>(d->tokens) | reinterpret_cast<uintptr_t>(d->bqkv) |
                           reinterpret_cast<uintptr_t>(d->bo) | reinterpret_cast<uintptr_t>(d->b2) | reinterpret_cast<uintptr_t>(d->ln1_g) |
@@ -1169,9 +1219,10 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
                           reinterpret_cast<uintptr_t>(d->ln3_g) | reinterpret_cast<uintptr_t>(d->ln3_b);
     if ((al16 & 15u) || (al8 & 7u)) return EEGCLIP_EALIGN;
     tb_fwd_args a{d->x, static_cast<const unsigned short*>(d->packed), d->bv, d->pe, d->tokens, d->ids, d->bqkv, d->bo, d->ln1_g, d->ln1_b, d->b1, d->b2,
-                  d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->ctx, d->r1, d->n1, d->mu1, d->rs1, d->f1, d->g1, d->r2, d->n2, d->mu2, d->rs2,
-                  d->n3, d->mu3, d->rs3, d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn, d->site_attn_out, d->site_ffn_act,
-                  d->site_ffn_out, 0u, nullptr};
+                  d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->r1, d->mu1, d->rs1, d->f1, d->r2, d->n2, d->mu2, d->rs2,
+                  d->n3, d->mu3, d->rs3, static_cast<unsigned char*>(d->xp), static_cast<unsigned char*>(d->hp), static_cast<unsigned char*>(d->ctxp),
+                  static_cast<unsigned char*>(d->n1p), static_cast<unsigned char*>(d->g1p), d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn,
+                  d->site_attn_out, d->site_ffn_act, d->site_ffn_out, 0u, nullptr};
     static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
     a.dbg = dbg;
     a.tstamp = nullptr;
@@ -1206,24 +1257,25 @@ extern "C" long long eegclip_token_block_bwd_workspace_floats(int B) { return B 
 extern "C" int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream) {
     if (!d || d->B < 1 || !d->packed || d->drop_p < 0.f || d->drop_p >= 1.f || part < 0 || part > 2) return EEGCLIP_EINVAL;
     tb_bwd_args a{static_cast<const unsigned short*>(d->packed), d->dn3, d->n2, d->r2, d->r1, d->f1, d->mu1, d->rs1, d->mu2, d->rs2, d->mu3, d->rs3,
-                  d->ln1_g, d->ln2_g, d->ln2_b, d->ln3_g, d->df2, d->dg1, d->da1, d->dr1, d->dctx, d->partials, d->dqkv, d->drop_p, d->seed, d->site_embed,
-                  d->site_attn_out, d->site_ffn_act, d->site_ffn_out};
+                  d->ln1_g, d->ln2_g, d->ln2_b, d->ln3_g, d->dr1, d->dctx, d->partials, static_cast<unsigned char*>(d->df2p), static_cast<unsigned char*>(d->dg1p),
+                  static_cast<unsigned char*>(d->da1p), static_cast<unsigned char*>(d->dr1p), static_cast<const unsigned char*>(d->dqkvp), d->drop_p, d->seed,
+                  d->site_embed, d->site_attn_out, d->site_ffn_act, d->site_ffn_out};
     if (part == 0) {
         if (!d->dn3 || (!d->n2 && !d->ln2_b) || !d->r2 || !d->r1 || !d->f1 || !d->mu1 || !d->rs1 || !d->mu2 || !d->rs2 || !d->mu3 || !d->rs3 || !d->ln1_g || !d->ln2_g ||
-            !d->ln3_g || !d->df2 || !d->dg1 || !d->da1 || !d->dr1 || !d->dctx || !d->partials)
+            !d->ln3_g || !d->df2p || !d->dg1p || !d->da1p || !d->dr1 || !d->dctx || !d->partials)
             return EEGCLIP_EINVAL;
-        const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->dg1);
+        const uintptr_t al16 = reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->f1) | reinterpret_cast<uintptr_t>(d->df2p) |
+                               reinterpret_cast<uintptr_t>(d->dg1p) | reinterpret_cast<uintptr_t>(d->da1p);
         const uintptr_t al8 = reinterpret_cast<uintptr_t>(d->dn3) | reinterpret_cast<uintptr_t>(d->n2) | reinterpret_cast<uintptr_t>(d->r2) |
                               reinterpret_cast<uintptr_t>(d->r1) | reinterpret_cast<uintptr_t>(d->ln1_g) | reinterpret_cast<uintptr_t>(d->ln2_g) |
-                              reinterpret_cast<uintptr_t>(d->ln3_g) | reinterpret_cast<uintptr_t>(d->df2) | reinterpret_cast<uintptr_t>(d->da1) |
-                              reinterpret_cast<uintptr_t>(d->dr1) | reinterpret_cast<uintptr_t>(d->dctx);
+                              reinterpret_cast<uintptr_t>(d->ln3_g) | reinterpret_cast<uintptr_t>(d->dr1) | reinterpret_cast<uintptr_t>(d->dctx);
         if ((al16 & 15u) || (al8 & 7u)) return EEGCLIP_EALIGN;
         if (d->drop_p > 0.f) EEG_LAUNCH(token_block_bwd_a_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
         else EEG_LAUNCH(token_block_bwd_a_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_LDS, stream, a);
     } else if (part == 1) {
-        if (!d->dqkv || !d->dr1) return EEGCLIP_EINVAL;
-        if ((reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->dr1)) & 15u) return EEGCLIP_EALIGN;
-        if (reinterpret_cast<uintptr_t>(d->dqkv) & 7u) return EEGCLIP_EALIGN;
+        if (!d->dqkvp || !d->dr1) return EEGCLIP_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d->packed) | reinterpret_cast<uintptr_t>(d->dr1) | reinterpret_cast<uintptr_t>(d->dqkvp) | reinterpret_cast<uintptr_t>(d->dr1p)) & 15u)
+            return EEGCLIP_EALIGN;
         if (d->drop_p > 0.f) EEG_LAUNCH(token_block_bwd_b_kernel<true>, dim3(d->B), dim3(TB_THREADS), TB_AP_BYTES + TB_XF_BYTES, stream, a);
         else EEG_LAUNCH(token_block_bwd_b_kernel<false>, dim3(d->B), dim3(TB_THREADS), TB_AP_BYTES + TB_XF_BYTES, stream, a);
     } else {

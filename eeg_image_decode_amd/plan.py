@@ -39,7 +39,8 @@ def default_gemm_precision():
 
 
 # entry points that launch exactly ONE kernel: eegclip_time_next_launch stamps the first kernel of a call, so only these take kernel timestamps
-_SINGLE_KERNEL_OPS = frozenset({"eegclip_gemm_f32", "eegclip_token_block_fwd", "eegclip_token_block_bwd", "eegclip_attention_fwd", "eegclip_attention_bwd", "eegclip_attention_bwd_x3"})
+_SINGLE_KERNEL_OPS = frozenset({"eegclip_gemm_f32", "eegclip_token_block_fwd", "eegclip_token_block_bwd", "eegclip_attention_fwd", "eegclip_attention_bwd", "eegclip_attention_bwd_x3",
+                                "eegclip_wgrad_tok", "eegclip_wgrad_tok_reduce"})
 
 
 class Plan:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 5
+#define EEGCLIP_ABI_VERSION 6
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -250,8 +250,10 @@ int eegclip_attention_fwd(const float* qkv, float* ctx, int B, int L, int H, int
 int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream);
 /* the same contract with split-bf16 products (hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate: ~2^-16 relative per term, as
- * EEGCLIP_PREC_BF16X3): E and ld even, qkv / dctx / dqkv 8-byte aligned.  csrc/attention_x3.hip */
-int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, float* dqkv, int B, int L, int H, int E, int ld, float scale,
+ * EEGCLIP_PREC_BF16X3): E and ld even, qkv / dctx / dqkv 8-byte aligned.  csrc/attention_x3.hip
+ * dqkv_planes = 1: dq | dk | dv leave as token planes instead (see eegclip_wgrad_tok: 3 groups of B blocks of 64 KB at `dqkv`, channel 64 head + e,
+ * H <= 4, 16-byte aligned) -- what eegclip_token_block_bwd part 1 and the q | k | v weight gradient read. */
+int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, void* dqkv, int dqkv_planes, int B, int L, int H, int E, int ld, float scale,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream);
 
 /* ---- tsconv front: Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)).  ATMS_retrieval.py:102-103
@@ -454,7 +456,8 @@ int eegclip_plan_run(const eegclip_plan_op* ops, int begin, int end, int n_total
  * embedding + subject token + dropout (models/subject_layers/Embed.py:141-162), fused q | k | v projection, 4-head attention with probability
  * dropout, output projection (SelfAttention_Family.py:56-75,194-213), dropout + residual + LayerNorm, FFN 250 -> 256 (GELU, dropout) -> 250,
  * dropout + residual + LayerNorm, final LayerNorm (Transformer_EncDec.py:39-51,61-80).  Replaces ten launches of the forward plan; writes every
- * tensor the backward reads, in the layouts of the unfused kernels, with the same Philox masks (seed, site, flat element index).  Arithmetic of
+ * tensor the backward reads -- fp32 in the layouts of the unfused kernels, or token planes where only a weight-gradient GEMM reads it -- with the same
+ * Philox masks (seed, site, flat element index).  Arithmetic of
  * the Linears: split-bf16 products, fp32 accumulate (EEGCLIP_PREC_BF16X3).  Specialised for 63 channels x 250 samples, d_model 250, 4 heads x 62,
  * d_ff 256 (the reference's only configuration, Retrieval/ATMS_retrieval.py:52-66).
  * eegclip_token_block_pack: the five weight matrices (nn.Linear layout (out, in), row-major; wqkv = q | k | v rows stacked) -> bf16 hi | lo planes
@@ -466,7 +469,9 @@ typedef struct {
     const float *bv, *pe, *tokens;             /* value-embedding bias (250); positional table rows 0..62 (row stride 250); token table (rows of 250) */
     const long long* ids;                      /* (B) row of `tokens` per sample, NULL: row 0 (the shared token) */
     const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
-    float *h, *qkv, *ctx, *r1, *n1, *mu1, *rs1, *f1, *g1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;      /* outputs, rows = B * 64; n2 may be NULL (not stored) */
+    float *h, *qkv, *r1, *mu1, *rs1, *f1, *r2, *n2, *mu2, *rs2, *n3, *mu3, *rs3;      /* outputs, rows = B * 64; n2 may be NULL (not stored) */
+    void *xp, *hp, *ctxp, *n1p, *g1p;          /* outputs as token planes (B blocks of 64 KB, see eegclip_wgrad_tok): the X operands of the weight gradients --
+                                                  EEG sample (token row 1 + channel; NULL: not written), h, ctx (channel 64 head + d), n1, g1; ones column in all but g1 */
     float drop_p, eps, scale;                  /* dropout probability of all five sites (0: evaluation), LayerNorm eps, softmax scale */
     unsigned long long seed;
     unsigned int site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
@@ -477,17 +482,18 @@ int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream);
 
 /* backward of the block's dX chain, one workgroup per sample (csrc/token_block.hip), `part`:
  *   0  final LayerNorm', LayerNorm2' + FFN-output dropout', dg1 = df2 W2 with dropout' gelu' (-> dg1 = df1), dn1 = dr2 + df1 W1, LayerNorm1' +
- *      attention-output dropout', dctx = da1 Wo: writes df2, dg1, da1, dr1 (residual path), dctx and one partial row of the six LayerNorm
+ *      attention-output dropout', dctx = da1 Wo: writes df2, dg1, da1 (token planes), dr1 (residual path), dctx and one partial row of the six LayerNorm
  *      parameter gradients per sample into `partials` (eegclip_token_block_bwd_workspace_floats(B) floats)     (Transformer_EncDec.py:45-51,77-78)
- *   1  dr1 <- dropout'_embed(dr1 + dq Wq + dk Wk + dv Wv), dqkv in the natural (row, 744) layout           (SelfAttention_Family.py:199-207, Embed.py:162)
+ *   1  dr1 <- dropout'_embed(dr1 + dq Wq + dk Wk + dv Wv), d{q,k,v} read as token planes                     (SelfAttention_Family.py:199-207, Embed.py:162)
  *   2  dln*_g / dln*_b += column sums of `partials`
  * between 0 and 1 runs eegclip_attention_bwd; the weight gradients stay batch-wide GEMMs over what these parts leave in HBM. */
 typedef struct {
     int B;
     const void* packed;
     const float *dn3, *n2, *r2, *r1, *f1, *mu1, *rs1, *mu2, *rs2, *mu3, *rs3, *ln1_g, *ln2_g, *ln2_b, *ln3_g;      /* n2 NULL: re-evaluated from r2 (needs ln2_b) */
-    float *df2, *dg1, *da1, *dr1, *dctx, *partials;
-    const float* dqkv;
+    float *dr1, *dctx, *partials;
+    void *df2p, *dg1p, *da1p, *dr1p;           /* token planes (eegclip_wgrad_tok dY operands): part 0 writes df2p, dg1p, da1p; part 1 writes dr1p unless NULL */
+    const void* dqkvp;                         /* part 1 input: dq | dk | dv token planes of eegclip_attention_bwd_x3 (groups B * 64 KB apart) */
     float *dln3_g, *dln3_b, *dln2_g, *dln2_b, *dln1_g, *dln1_b;
     float drop_p;
     unsigned long long seed;
@@ -496,26 +502,36 @@ typedef struct {
 long long eegclip_token_block_bwd_workspace_floats(int B);
 int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream);
 
-/* ---- weight gradients over bf16 planes (csrc/wgrad_planes.hip): dW[o][i] (+)= sum_t dY[t][o] X[t][i] with t = the batch's token rows -- the
- * weight-gradient GEMMs of the transformer block (models/subject_layers/Transformer_EncDec.py:48-49, SelfAttention_Family.py:199-213 backward).
- * eegclip_split_transpose: fp32 src [rows = t][cols] (row stride ld) -> bf16 hi | lo planes [out_rows >= cols][rows] (row stride ldo elements, t
- * contiguous; rows beyond `cols` zero; rows, out_rows multiples of 64) -- the transposition + split the plan GEMM does per workgroup, once per operand.
- * eegclip_wgrad_planes: out (M x N, row stride ldo) += A B^T over K with A = planes [pad128(M)][K], B = planes [pad64(N)][K]; bias_out[m] += sum_k
- * A[m][k] (the bias gradient: column sums of dY) when not NULL; ld = elements between plane rows (use K + 64, not K: a power-of-two row
- * stride lands every row on the same memory channels); `workspace` = eegclip_wgrad_planes_workspace_floats(M, N, K) floats (per-slice
- * partial tiles, summed in a fixed order: bit-reproducible).  Split-bf16 products, fp32 accumulate (EEGCLIP_PREC_BF16X3 arithmetic). */
-int eegclip_split_transpose(const float* src, long long ld, int rows, int cols, int out_rows, void* hi, void* lo, long long ldo, void* stream);
-long long eegclip_wgrad_planes_workspace_floats(int M, int N, int K);
-int eegclip_wgrad_planes(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, long long ld, int M, int N, int K, float* out,
-                         long long ldo, float* bias_out, float* workspace, void* stream);
-/* the same weight gradient from planes in NATURAL layout (token-major, what a producer holds): A = planes [K][lda], B = planes [K][ldb], lda / ldb
- * multiples of 8 with zeros in the columns past M / N (eegclip_split_rows_natural writes exactly that from fp32 [K][cols], row stride ld even, rows
- * 8-byte aligned); K a multiple of 32; workspace: eegclip_wgrad_tr_workspace_floats(M, N, K) floats.  Both MFMA operands are fetched with the LDS
- * transpose read of gfx950 -- no transposing pass (csrc/wgrad_planes.hip: wgrad_tr_kernel).  Opt-in in the plans (EEGCLIP_WGRAD_TR=1). */
-int eegclip_split_rows_natural(const float* src, long long ld, int rows, int cols, void* hi, void* lo, int ldp, void* stream);
-long long eegclip_wgrad_tr_workspace_floats(int M, int N, int K);
-int eegclip_wgrad_tr(const void* a_hi, const void* a_lo, long long lda, const void* b_hi, const void* b_lo, long long ldb, int M, int N, int K, float* out,
-                     long long ldo, float* bias_out, float* workspace, void* stream);
+/* ---- weight gradients of the transformer block from TOKEN-MAJOR bf16 planes (csrc/wgrad_tok.hip): dW[o][i] += sum_t dY[t][o] X[t][i], t = the
+ * 64 B token rows of a batch (models/subject_layers/Transformer_EncDec.py:48-49, SelfAttention_Family.py:199-213, Embed.py:146 w.r.t. the weights).
+ * Operand layout ("token planes"): per sample one 64 KB block [hi | lo][64 tokens][256 channels] bf16 -- what eegclip_token_block_fwd / _bwd and
+ * eegclip_attention_bwd_x3 write instead of fp32 for the tensors only these GEMMs read (eegclip_tok_planes_from_f32 makes the same from fp32).
+ * Channels past the tensor's width are zero, EXCEPT channel 255 of an X operand's hi plane = 1.0: column 255 of the product is then the bias
+ * gradient sum_t dY[t][o] (bias_mfma = 1 when X has 256 real channels: the kernel forms it against an all-ones fragment instead).
+ * heads_m / heads_n: the operand's channel c = 64 head + d (d < 62) is row / column 62 head + d of `out`; m_groups: dY is m_groups channel groups
+ * of 256 (dq | dk | dv), a_group_stride bytes apart, group g = rows 248 g .. of `out` (heads_m) or 256 g ...
+ * One launch takes up to 4 problems (gradients that become ready together); `slices` K slices per output tile (eegclip_wgrad_tok_slices picks
+ * ~one 128 x 128 tile workgroup per CU), partial tiles in `workspace` (eegclip_wgrad_tok_workspace_floats floats) summed in slice order by
+ * eegclip_wgrad_tok_reduce: bit-reproducible.  variant 0: 512-thread workgroups (2 waves per SIMD), 1: 256-thread.  Split-bf16 products, fp32 accumulate. */
+typedef struct {
+    const void* a;                             /* dY token planes (B blocks of 64 KB per channel group) */
+    const void* b;                             /* X token planes */
+    long long a_group_stride;                  /* bytes between channel groups of a (m_groups > 1) */
+    int m_groups, heads_m, heads_n;
+    int M, N;                                  /* rows / columns of out */
+    float* out;                                /* (M, N) row stride ldo: accumulated into */
+    long long ldo;
+    float* bias_out;                           /* (M) accumulated into, or NULL */
+    int bias_mfma;
+} eegclip_wgrad_tok_problem;
+int eegclip_wgrad_tok_slices(int total_m_groups, int B);
+long long eegclip_wgrad_tok_workspace_floats(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices);
+int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, int variant, void* stream);
+/* the second half of the operation (its own entry point = its own kernel: per-launch timing): out += the slices of `workspace`, same arguments */
+int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, void* stream);
+/* fp32 [rows = 64 B][cols] (row stride ld) -> token planes at dst (rows / 64 blocks of 64 KB, 16-byte aligned); heads: column 62 head + d -> channel
+ * 64 head + d; ones: hi[.][255] = 1.0 */
+int eegclip_tok_planes_from_f32(const float* src, long long ld, int rows, int cols, int heads, int ones, void* dst, void* stream);
 
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what

@@ -306,11 +306,22 @@ def test_attention_fwd_bwd(be, B, H, E, p):
     np.testing.assert_allclose(be.host(DQKV), qt.grad.numpy(), atol=5e-5)
     if E % 2 == 0:          # the split-bf16 backward (csrc/attention_x3.hip: LDS transpose reads): same masks, ~2^-16 relative per product term
         DQ3 = be.dev(np.full((B * L, ld), np.nan, np.float32))
-        ok(be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQ3), B, L, H, E, ld, scale, p, SEED, 1, be.stream))
+        ok(be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQ3), 0, B, L, H, E, ld, scale, p, SEED, 1, be.stream))
         np.testing.assert_allclose(be.host(DQ3), qt.grad.numpy(), atol=2e-4)
         assert np.abs(be.host(DQ3) - qt.grad.numpy()).mean() < 1e-5
+        # ... and the same gradients as token planes (what the fused backward + the q | k | v weight gradient read): hi + lo = the fp32 value to 2^-17,
+        # channel 64 head + e, the channels past E exact zeros, channels of absent heads untouched
+        DQP = be.dev(np.full((3, B, 2, L, 256), 0x7FC0, np.uint16))
+        ok(be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQP), 1, B, L, H, E, ld, scale, p, SEED, 1, be.stream))
+        pl = (be.host(DQP).astype(np.uint32) << 16).view(np.float32)
+        val = (pl[:, :, 0] + pl[:, :, 1])[..., :64 * H].reshape(3, B, L, H, 64)
+        np.testing.assert_array_equal(val[..., E:], 0.0)
+        got = val[..., :E].transpose(1, 2, 0, 3, 4).reshape(B * L, ld)
+        ref3 = be.host(DQ3)
+        np.testing.assert_allclose(got, ref3, atol=2e-5 * max(1.0, float(np.abs(ref3).max())))
+        assert np.all(be.host(DQP)[..., 64 * H:] == 0x7FC0)
     else:
-        assert be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQKV), B, L, H, E, ld, scale, p, SEED, 1, be.stream) < 0
+        assert be.lib.eegclip_attention_bwd_x3(be.ptr(QKV), be.ptr(DCTX), be.ptr(DQKV), 0, B, L, H, E, ld, scale, p, SEED, 1, be.stream) < 0
 
 
 @pytest.mark.parametrize("B,H", [(2, 63), (3, 5), (5, 63)])

@@ -1,105 +1,183 @@
-"""csrc/wgrad_planes.hip through the C ABI on both backends: the transposing split (fp32 [t][c] -> bf16 planes [c][t]) and the planes GEMM
-dW += dY^T X with its bias row sums, against float64 products of the split operands (the kernel's arithmetic) and of the exact operands."""
+"""csrc/wgrad_tok.hip through the C ABI on both backends: the token-plane layout (eegclip_tok_planes_from_f32) and the weight-gradient GEMM over it
+(eegclip_wgrad_tok: LDS-DMA staged k-tiles, LDS transpose reads, split-bf16 products, slab reduction in slice order) against numpy on the SAME split
+operands -- every shape / map the backward plan uses: plain, 62-per-head rows and columns, three channel groups, both bias routes, several
+problems per launch."""
+import ctypes
+
 import numpy as np
 import pytest
 
-from backends import be  # noqa: F401
-from test_kernels_gemm_x3 import split
+from backends import BACKENDS, be  # noqa: F401
+from eeg_image_decode_amd import _abi
 
 
-def planes_of(be, x, out_rows, pad=0):
+def bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split(x):
+    hi = bf16_round(x)
+    return hi, bf16_round(x - hi)
+
+
+def planes_to_f32(blob, B):
+    """token planes (uint16 view of B blocks [2][64][256]) -> (hi, lo) fp32 arrays (B * 64, 256)"""
+    p = np.asarray(blob).view(np.uint16).reshape(B, 2, 64, 256).astype(np.uint32) << 16
+    f = p.view(np.float32)
+    return f[:, 0].reshape(B * 64, 256), f[:, 1].reshape(B * 64, 256)
+
+
+def head_channels(cols):
+    """column 62 head + d -> channel 64 head + d"""
+    c = np.arange(cols)
+    return 64 * (c // 62) + c % 62
+
+
+def make_planes(be, x, heads, ones):
     rows, cols = x.shape
+    B = rows // 64
+    dst = be.dev(np.full(B * 32768, 0x7FC0, np.uint16))               # NaN-filled: every element must be written
     X = be.dev(x)
-    hi, lo = be.zeros((out_rows, rows + pad), np.uint16), be.zeros((out_rows, rows + pad), np.uint16)
-    assert be.lib.eegclip_split_transpose(be.ptr(X), x.strides[0] // 4, rows, cols, out_rows, be.ptr(hi), be.ptr(lo), rows + pad, be.stream) == 0
-    return X, hi, lo
+    assert be.lib.eegclip_tok_planes_from_f32(be.ptr(X), cols, rows, cols, int(heads), int(ones), be.ptr(dst), be.stream) == 0
+    be.sync()
+    return dst
 
 
-def bf16_to_f64(u):
-    return (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+@pytest.mark.parametrize("cols,heads,ones", [(250, 0, 1), (256, 0, 0), (248, 1, 1), (250, 0, 0)])
+def test_token_planes_from_fp32(be, cols, heads, ones):
+    rng = np.random.default_rng(5)
+    B = 2
+    x = rng.standard_normal((64 * B, cols)).astype(np.float32)
+    hi, lo = planes_to_f32(be.host(make_planes(be, x, heads, ones)), B)
+    ch = head_channels(cols) if heads else np.arange(cols)
+    eh, el = np.zeros((64 * B, 256), np.float32), np.zeros((64 * B, 256), np.float32)
+    eh[:, ch], el[:, ch] = split(x)
+    if ones:
+        eh[:, 255] = 1.0
+    np.testing.assert_array_equal(hi, eh)
+    np.testing.assert_array_equal(lo, el)
 
 
-@pytest.mark.parametrize("rows,cols", [(64, 62), (128, 250), (192, 130)])
-def test_split_transpose(be, rows, cols):
-    rng = np.random.default_rng(rows + cols)
-    x = rng.standard_normal((rows, cols + 3)).astype(np.float32)[:, :cols]          # a strided view: ld != cols
-    xs = np.ascontiguousarray(x)
-    out_rows = (cols + 63) // 64 * 64
-    _, hi, lo = planes_of(be, xs, out_rows)
-    h, l = bf16_to_f64(be.host(hi))[:, :rows], bf16_to_f64(be.host(lo))[:, :rows]
-    xh, xl = split(xs)
-    np.testing.assert_array_equal(h[:cols], xh.T)
-    np.testing.assert_array_equal(l[:cols], xl.T)
-    assert not h[cols:].any() and not l[cols:].any()
+def reference(dy, x):
+    """dW = dY^T X with the three split products, fp64 accumulation"""
+    ah, al = (v.astype(np.float64) for v in split(dy))
+    bh, bl = (v.astype(np.float64) for v in split(x))
+    return ah.T @ bh + ah.T @ bl + al.T @ bh, (ah + al).sum(0)
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(250, 256, 256, True), (62, 40, 128, False), (300, 250, 512, True)])
-def test_wgrad_planes_matches_the_split_products(be, M, N, K, bias):
-    rng = np.random.default_rng(M + N + K)
-    dy = (rng.standard_normal((K, M)) * rng.uniform(0.1, 2.0, M)).astype(np.float32)
-    x = rng.standard_normal((K, N)).astype(np.float32)
-    Mp, Np = (M + 127) // 128 * 128, (N + 63) // 64 * 64
-    _, ah, al = planes_of(be, dy, Mp, 64)                                              # plane rows K + 64 apart, as the plans allocate them
-    _, bh, bl = planes_of(be, x, Np, 64)
-    c0 = rng.standard_normal((M, N + 2)).astype(np.float32)                           # accumulated INTO, row stride N + 2
-    b0 = rng.standard_normal(M).astype(np.float32)
-    C, Bv = be.dev(c0), be.dev(b0)
-    ws = be.zeros(int(be.lib.eegclip_wgrad_planes_workspace_floats(M, N, K)))
-    assert be.lib.eegclip_wgrad_planes(be.ptr(ah), be.ptr(al), be.ptr(bh), be.ptr(bl), K + 64, M, N, K, be.ptr(C), N + 2, be.ptr(Bv) if bias else None, be.ptr(ws),
-                                       be.stream) == 0
-    dh, dl = split(dy)
-    xh, xl = split(x)
-    want = dh.T @ xh + dh.T @ xl + dl.T @ xh                                          # the three products of the split arithmetic
-    got = be.host(C)
-    np.testing.assert_allclose(got[:, :N] - c0[:, :N], want, atol=2e-5 * np.abs(want).max() + 1e-6)
-    np.testing.assert_array_equal(got[:, N:], c0[:, N:])
-    exact = dy.astype(np.float64).T @ x.astype(np.float64)
-    assert np.abs(want - exact).max() < 1e-4 * max(1.0, np.abs(exact).max())        # split products vs exact ones: the parity budget
-    if bias:
-        np.testing.assert_allclose(be.host(Bv) - b0, (dh + dl).sum(0), atol=2e-5 * np.abs(dy).sum(0).max())
+CASES = {
+    # name: (M, N, m_groups, heads_m, heads_n, bias route)        bias route: 0 none, 1 ones column, 2 all-ones fragment
+    "ffn2": (250, 256, 1, 0, 0, 2),
+    "ffn1": (256, 250, 1, 0, 0, 1),
+    "out_proj": (250, 248, 1, 0, 1, 1),
+    "qkv": (744, 250, 3, 1, 0, 1),
+    "embed": (250, 250, 1, 0, 0, 1),
+    "nobias": (250, 250, 1, 0, 0, 0),
+}
 
 
-def natural_planes(be, x, ldp):
-    rows, cols = x.shape
-    X = be.dev(np.ascontiguousarray(x))
-    hi, lo = be.dev(np.full((rows, ldp), 0x7FC0, np.uint16)), be.dev(np.full((rows, ldp), 0x7FC0, np.uint16))
-    assert be.lib.eegclip_split_rows_natural(be.ptr(X), cols, rows, cols, be.ptr(hi), be.ptr(lo), ldp, be.stream) == 0
-    return X, hi, lo
+def run_problems(be, names, B, slices, variant, seed=0):
+    rng = np.random.default_rng(seed)
+    probs = (_abi.WgradTokProblem * len(names))()
+    keep, outs = [], []
+    for i, nm in enumerate(names):
+        M, N, mg, hm, hn, br = CASES[nm]
+        dy = (rng.standard_normal((64 * B, M)) * rng.uniform(0.5, 2.0)).astype(np.float32)
+        x = rng.standard_normal((64 * B, N)).astype(np.float32)
+        per = M // mg
+        a = [make_planes(be, dy[:, g * per:(g + 1) * per], hm, 0) for g in range(mg)]
+        if mg > 1:                                            # the channel groups of one operand: consecutive regions, a_group_stride apart
+            blob = be.dev(np.concatenate([be.host(v) for v in a]))
+            a = [blob]
+        b = make_planes(be, x, hn, br == 1)
+        out0 = rng.standard_normal((M, N + 3)).astype(np.float32)
+        bias0 = rng.standard_normal(M).astype(np.float32)
+        out, bias = be.dev(out0), be.dev(bias0)
+        keep += [a, b, out, bias]
+        probs[i] = _abi.WgradTokProblem(a=be.ptr(a[0]), b=be.ptr(b), a_group_stride=B * 65536 if mg > 1 else 0, m_groups=mg, heads_m=hm, heads_n=hn, M=M, N=N,
+                                        out=be.ptr(out), ldo=N + 3, bias_out=be.ptr(bias) if br else None, bias_mfma=int(br == 2))
+        ew, eb = reference(dy, x)
+        outs.append((nm, out, bias, out0, bias0, ew, eb, br))
+    nws = int(be.lib.eegclip_wgrad_tok_workspace_floats(probs, len(names), B, slices))
+    assert nws > 0
+    ws = be.dev(np.full(nws, np.nan, np.float32))             # every slab element that is read must have been written
+    assert be.lib.eegclip_wgrad_tok(probs, len(names), B, slices, be.ptr(ws), variant, be.stream) == 0
+    assert be.lib.eegclip_wgrad_tok_reduce(probs, len(names), B, slices, be.ptr(ws), be.stream) == 0
+    be.sync()
+    for nm, out, bias, out0, bias0, ew, eb, br in outs:
+        got = be.host(out).astype(np.float64)
+        N = ew.shape[1]
+        scale = np.abs(ew).max()
+        np.testing.assert_allclose(got[:, :N] - out0[:, :N], ew, atol=2e-6 * scale * np.sqrt(64 * B), err_msg=nm)
+        np.testing.assert_array_equal(got[:, N:], out0[:, N:])                    # the padding columns of `out` are untouched
+        gb = be.host(bias).astype(np.float64) - bias0
+        if br:
+            np.testing.assert_allclose(gb, eb, atol=2e-6 * np.abs(eb).max() * np.sqrt(64 * B) + 1e-5, err_msg=nm + " bias")
+        else:
+            np.testing.assert_array_equal(gb, 0.0)
 
 
-@pytest.mark.parametrize("rows,cols", [(64, 62), (96, 250), (32, 744)])
-def test_split_rows_natural(be, rows, cols):
-    rng = np.random.default_rng(rows * 3 + cols)
-    x = rng.standard_normal((rows, cols)).astype(np.float32)
-    ldp = (cols + 7) // 8 * 8
-    _, hi, lo = natural_planes(be, x, ldp)
-    xh, xl = split(x)
-    np.testing.assert_array_equal(bf16_to_f64(be.host(hi))[:, :cols], xh)
-    np.testing.assert_array_equal(bf16_to_f64(be.host(lo))[:, :cols], xl)
-    assert not bf16_to_f64(be.host(hi))[:, cols:].any() and not bf16_to_f64(be.host(lo))[:, cols:].any()
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", list(CASES))
+def test_wgrad_tok_single_problem(be, name, variant):
+    run_problems(be, [name], 2, 1, variant)
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(250, 256, 256, True), (62, 40, 64, False), (744, 250, 128, True), (300, 130, 512, True)])
-def test_wgrad_tr_from_natural_planes_matches_the_split_products(be, M, N, K, bias):
-    """dW += dY^T X with both operands as token-major planes, fetched through the LDS transpose read (a transpose-detecting check: M != N, random data)"""
-    rng = np.random.default_rng(M + 2 * N + K)
-    dy = (rng.standard_normal((K, M)) * rng.uniform(0.1, 2.0, M)).astype(np.float32)
-    x = rng.standard_normal((K, N)).astype(np.float32)
-    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
-    _, ah, al = natural_planes(be, dy, lda)
-    _, bh, bl = natural_planes(be, x, ldb)
-    c0 = rng.standard_normal((M, N + 2)).astype(np.float32)                           # accumulated INTO, row stride N + 2
-    b0 = rng.standard_normal(M).astype(np.float32)
-    C, Bv = be.dev(c0), be.dev(b0)
-    ws = be.dev(np.full(int(be.lib.eegclip_wgrad_tr_workspace_floats(M, N, K)), np.nan, np.float32))
-    assert be.lib.eegclip_wgrad_tr(be.ptr(ah), be.ptr(al), lda, be.ptr(bh), be.ptr(bl), ldb, M, N, K, be.ptr(C), N + 2, be.ptr(Bv) if bias else None,
-                                   be.ptr(ws), be.stream) == 0
-    dh, dl = split(dy)
-    xh, xl = split(x)
-    want = dh.T @ xh + dh.T @ xl + dl.T @ xh
-    got = be.host(C)
-    np.testing.assert_allclose(got[:, :N] - c0[:, :N], want, atol=2e-5 * np.abs(want).max() + 1e-6)
-    np.testing.assert_array_equal(got[:, N:], c0[:, N:])
-    if bias:
-        np.testing.assert_allclose(be.host(Bv) - b0, (dh + dl).sum(0), atol=2e-5 * np.abs(dy).sum(0).max())
-    assert be.lib.eegclip_wgrad_tr(be.ptr(ah), be.ptr(al), lda, be.ptr(bh), be.ptr(bl), ldb, M, N, K + 8, be.ptr(C), N + 2, None, be.ptr(ws), be.stream) < 0
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wgrad_tok_grouped_launch_and_slices(be, variant):
+    run_problems(be, ["ffn2", "ffn1", "out_proj"], 4, 2, variant, seed=3)       # 8 k-tiles in 2 slices: 4 per workgroup = the ring's full depth
+
+
+def test_wgrad_tok_is_reproducible_and_shape_independent(be):
+    """same operands -> bit-identical gradients from both workgroup shapes and from a second run (ordered slab reduction, no atomics)"""
+    res = []
+    for variant in (0, 1, 0):
+        rng = np.random.default_rng(11)
+        B, slices = 4, 2
+        dy, x = rng.standard_normal((64 * B, 250)).astype(np.float32), rng.standard_normal((64 * B, 250)).astype(np.float32)
+        a, b = make_planes(be, dy, 0, 0), make_planes(be, x, 0, 1)
+        out, bias = be.zeros((250, 250)), be.zeros(250)
+        p = (_abi.WgradTokProblem * 1)(_abi.WgradTokProblem(a=be.ptr(a), b=be.ptr(b), a_group_stride=0, m_groups=1, heads_m=0, heads_n=0, M=250, N=250,
+                                                             out=be.ptr(out), ldo=250, bias_out=be.ptr(bias), bias_mfma=0))
+        ws = be.zeros(int(be.lib.eegclip_wgrad_tok_workspace_floats(p, 1, B, slices)))
+        assert be.lib.eegclip_wgrad_tok(p, 1, B, slices, be.ptr(ws), variant, be.stream) == 0
+        assert be.lib.eegclip_wgrad_tok_reduce(p, 1, B, slices, be.ptr(ws), be.stream) == 0
+        be.sync()
+        res.append((be.host(out).copy(), be.host(bias).copy()))
+    for o, bb in res[1:]:
+        np.testing.assert_array_equal(o, res[0][0])
+        np.testing.assert_array_equal(bb, res[0][1])
+
+
+def test_wgrad_tok_uneven_slices(be):
+    run_problems(be, ["embed", "qkv"], 3, 4, 0, seed=4)                          # 6 k-tiles over 4 slices: 1, 2, 1, 2 per workgroup
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wgrad_tok_full_size(variant):
+    from backends import get
+    b = get("gpu")
+    B = 256
+    s = int(b.lib.eegclip_wgrad_tok_slices(3, B))
+    assert s % 8 == 0                                         # the XCD-aware workgroup order is in use
+    run_problems(b, ["ffn2", "ffn1", "out_proj"], B, s, variant, seed=6)
+    run_problems(b, ["qkv"], B, int(b.lib.eegclip_wgrad_tok_slices(3, B)), variant, seed=7)
+    run_problems(b, ["embed"], B, int(b.lib.eegclip_wgrad_tok_slices(1, B)), variant, seed=8)
+
+
+def test_wgrad_tok_rejects_bad_arguments(be):
+    p = (_abi.WgradTokProblem * 1)()
+    x = be.dev(np.zeros(2 * 32768, np.uint16))
+    o = be.zeros((250, 250))
+    ws = be.zeros(1 << 20)
+    p[0] = _abi.WgradTokProblem(a=be.ptr(x), b=be.ptr(x), a_group_stride=0, m_groups=1, heads_m=0, heads_n=0, M=250, N=256, out=be.ptr(o), ldo=256,
+                                bias_out=be.ptr(o), bias_mfma=0)
+    assert be.lib.eegclip_wgrad_tok(p, 1, 2, 1, be.ptr(ws), 0, be.stream) != 0     # 256 real columns leave no ones column: bias_mfma is required
+    p[0].bias_mfma = 1
+    assert be.lib.eegclip_wgrad_tok(p, 1, 2, 8, be.ptr(ws), 0, be.stream) != 0     # more slices than k-tiles
+    assert be.lib.eegclip_wgrad_tok(p, 5, 2, 1, be.ptr(ws), 0, be.stream) != 0
+    p[0].M = 257
+    assert be.lib.eegclip_wgrad_tok(p, 1, 2, 1, be.ptr(ws), 0, be.stream) != 0
