@@ -13,8 +13,8 @@
 //
 //   wgrad_tok_kernel<WN>   workgroup = (problem, 128 x 128 output tile, K slice), 2 x WN waves, wave tile 64 x (128 / WN) as 16x16x32 MFMAs, three
 //                          products per multiply-add (hi lo + lo hi + hi hi, fp32 accumulate: the arithmetic of every Linear of the step);
-//                          4 LDS stages of 32 KB (A hi | A lo | B hi | B lo), counted vmcnt, the refill of tile kt + 3 issued between the MFMAs
-//                          of tile kt (the pipeline of csrc/infonce_fused.hip).  Several problems per launch (the three gradients that become
+//                          4 LDS stages of 32 KB (A hi | A lo | B hi | B lo), counted vmcnt; the fragment reads of tile kt + 1 and the refill of
+//                          tile kt's stage (tile kt + 4) are issued under the MFMAs of tile kt.  Several problems per launch (the three gradients that become
 //                          ready together are ONE launch); all tiles of a K slice run on one XCD (each operand byte enters one L2).
 //   wgrad_tok_reduce_kernel  out[m][n] += sum_s slab[s][m][n] in slice order (bit-reproducible; the round-3 GEMM added 32 slices with fp32
 //                          atomics: 19.8 MB of write traffic per launch for a 0.25 MB result and a scheduling-dependent sum).
@@ -26,7 +26,6 @@
 
 namespace eeg {
 
-constexpr int WK_NS = 4;                                     // LDS stages
 constexpr int WK_BK = 32;                                    // tokens per k-tile = one MFMA k-step
 constexpr int WK_ROWB = 256;                                 // bytes per LDS row: 128 channels
 constexpr int WK_TILE = WK_BK * WK_ROWB;                     // one operand-plane tile: 8 KB
@@ -64,7 +63,7 @@ __device__ __forceinline__ wk_s4 wk_tr_read(const unsigned char* p) {
 #endif
 }
 
-template <int WN>
+template <int WN, int WK_NS>
 __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int ktiles_all, int slices) {
     constexpr int NWAVE = 2 * WN, NT = 8 / WN;               // n-tiles of 16 per wave
     constexpr int IPW = 32 / NWAVE;                          // DMA instructions (1 KB each) per wave and k-tile
@@ -137,34 +136,41 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;     // bf16 1.0
 
-#pragma unroll
-    for (int p = 0; p < WK_NS - 1; ++p)
-        if (p < nk) {
-#pragma unroll
-            for (int i = 0; i < IPW; ++i) issue_one(p, i);
-        }
-    // one k-tile; REFILL (compile-time: the steady state has no branches between its MFMAs) = tile kt + 3 exists and is requested between the MFMAs
-    auto step = [&](int kt, auto refill_c) {
-        constexpr bool REFILL = decltype(refill_c)::value;
-        if (REFILL) wait_vmcnt<2 * IPW>();                   // tiles kt + 1, kt + 2 may stay in flight
-        else {
-            const int newer = nk - 1 - kt;                   // < 3 here
-            if (newer >= 2) wait_vmcnt<2 * IPW>();
-            else if (newer == 1) wait_vmcnt<IPW>();
-            else wait_vmcnt<0>();
-        }
-        raw_barrier();                                       // tile kt has landed for every wave; the stage about to be refilled is drained
+    // ---- pipeline: all 4 stages are requested up front; iteration kt: [tile kt + 1 landed -> barrier] -> fragment reads of tile kt + 1 into the OTHER
+    //      register set -> MFMAs of tile kt (fragments read one iteration ago), the refill of tile kt's stage with tile kt + 4 issued between them.
+    //      The LDS reads of a k-tile run under the previous tile's MFMAs: with the reads and the MFMAs of ONE tile back to back behind each barrier
+    //      (first version) every wave of the workgroup read at once and nobody computed -- 0.92 us per k-tile for 0.32 us of MFMA time.
+    bf16x8 ah[2][4], al[2][4], bh[2][NT], bl[2][NT];
+    auto read_frags = [&](int kt, auto set_c) {
+        constexpr int S = decltype(set_c)::value;
         const unsigned char* st = lds + (kt % WK_NS) * WK_STAGE;
-        bf16x8 ah[4], al[4], bh[NT], bl[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bh[nt] = frag(st + fob[nt]);
-            bl[nt] = frag(st + WK_TILE + fob[nt]);
+            bh[S][nt] = frag(st + fob[nt]);
+            bl[S][nt] = frag(st + WK_TILE + fob[nt]);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            ah[mt] = frag(st + foa[mt]);
-            al[mt] = frag(st + WK_TILE + foa[mt]);
+            ah[S][mt] = frag(st + foa[mt]);
+            al[S][mt] = frag(st + WK_TILE + foa[mt]);
+        }
+    };
+    auto wait_tiles = [&](int n) {                               // at most n k-tiles of this wave's DMA still in flight
+        if (n >= 4) wait_vmcnt<4 * IPW>();
+        else if (n == 3) wait_vmcnt<3 * IPW>();
+        else if (n == 2) wait_vmcnt<2 * IPW>();
+        else if (n == 1) wait_vmcnt<IPW>();
+        else wait_vmcnt<0>();
+    };
+    auto step = [&](int kt, auto set_c, auto refill_c) {
+        constexpr int S = decltype(set_c)::value;
+        constexpr bool REFILL = decltype(refill_c)::value;       // compile-time: the steady state has no branches between its MFMAs
+        const bool next = REFILL || kt + 1 < nk;
+        if (next) {
+            if (REFILL) wait_vmcnt<(WK_NS - 2) * IPW>();         // tiles kt + 2 .. kt + NS - 1 may stay in flight
+            else wait_tiles(nk - 2 - kt);                        // tiles requested after kt + 1 (< NS - 1 here: nothing was refilled since)
+            raw_barrier();                                       // tile kt + 1 is visible to every wave; every wave's reads of tile kt are complete
+            read_frags(kt + 1, std::integral_constant<int, 1 - S>{});
         }
         // product-major: the three MFMAs of one accumulator are 4 NT instructions apart; MFMA rows = X channels (n), columns = dY channels (m), so a
         // lane holds 4 CONSECUTIVE n of one m: 16-byte slab stores
@@ -174,23 +180,51 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 bw = pr == 0 ? bl[nt] : bh[nt];
-                    const bf16x8 aw = pr == 1 ? al[mt] : ah[mt];
+                    const bf16x8 bw = pr == 0 ? bl[S][nt] : bh[S][nt];
+                    const bf16x8 aw = pr == 1 ? al[S][mt] : ah[S][mt];
                     acc[mt][nt] = mfma_bf16_16x16x32(bw, aw, acc[mt][nt]);      // D[n = .. + 4 g + r][m = .. + fr]
                     const int idx = (pr * 4 + mt) * NT + nt;
-                    if (REFILL && ((idx + 1) * IPW) / MPT > (idx * IPW) / MPT) issue_one(kt + WK_NS - 1, (idx * IPW) / MPT);
+                    if (REFILL && ((idx + 1) * IPW) / MPT > (idx * IPW) / MPT) issue_one(kt + WK_NS, (idx * IPW) / MPT);
                 }
         if (bias) {                                          // column sums of the dY tile: every MFMA row of the product holds them
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                bacc[mt] = mfma_bf16_16x16x32(ones, al[mt], bacc[mt]);
-                bacc[mt] = mfma_bf16_16x16x32(ones, ah[mt], bacc[mt]);
+                bacc[mt] = mfma_bf16_16x16x32(ones, al[S][mt], bacc[mt]);
+                bacc[mt] = mfma_bf16_16x16x32(ones, ah[S][mt], bacc[mt]);
             }
         }
     };
+#pragma unroll
+    for (int p = 0; p < WK_NS; ++p)
+        if (p < nk) {
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) issue_one(p, i);
+        }
+    if (nk > 0) {
+        wait_tiles(nk - 1 < WK_NS - 1 ? nk - 1 : WK_NS - 1);
+        raw_barrier();
+        read_frags(0, std::integral_constant<int, 0>{});
+    }
     int kt = 0;
-    for (; kt + WK_NS - 1 < nk; ++kt) step(kt, std::true_type{});
-    for (; kt < nk; ++kt) step(kt, std::false_type{});
+    for (; kt + 1 + WK_NS < nk; kt += 2) {                       // steady state, two k-tiles per trip (the register sets alternate)
+        step(kt, std::integral_constant<int, 0>{}, std::true_type{});
+        step(kt + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    if (kt + WK_NS < nk) {                                       // one more tile to request
+        step(kt, std::integral_constant<int, 0>{}, std::true_type{});
+        ++kt;
+        for (; kt + 1 < nk; kt += 2) {
+            step(kt, std::integral_constant<int, 1>{}, std::false_type{});
+            step(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
+        }
+        if (kt < nk) step(kt, std::integral_constant<int, 1>{}, std::false_type{});
+    } else {
+        for (; kt + 1 < nk; kt += 2) {
+            step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+            step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        if (kt < nk) step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+    }
 
     // ---- partial tile -> this slice's slab (plain stores; the reduce kernel sums the slices in order)
     const int Mp = 128 * P.m_tiles;
@@ -217,62 +251,109 @@ struct wk_reduce_problem {
     float* bias_out;
     long long ldo;
     int M, N, Mp;                                            // rows / columns of out; slab rows
-    int heads_m, heads_n;                                    // index i of out <-> slab index 256 (i / 248) + 64 ((i % 248) / 62) + (i % 62)
+    int heads_m, heads_n;                                    // slab index 64 head + d (d < 62) of a 256-group <-> index 62 head + d (+ 248 group) of out
     int bias_mfma;
-    int first;                                               // first thread of this problem
+    int first;                                               // first workgroup of this problem
 };
 struct wk_reduce_table {
     wk_reduce_problem p[WK_MAXP];
     int n;
 };
 
-__device__ __forceinline__ int wk_slab_index(int i, int heads) {
-    if (!heads) return i;
-    const int grp = i / 248, r = i - 248 * grp, hd = r / 62;
-    return 256 * grp + 64 * hd + (r - 62 * hd);
+// slab index -> index of `out` (or -1: padding)
+__device__ __forceinline__ int wk_out_index(int i, int heads, int limit) {
+    int o = i;
+    if (heads) {
+        const int grp = i >> 8, r = i & 255, hd = r >> 6, d = r & 63;
+        o = d < 62 ? 248 * grp + 62 * hd + d : -1;
+    }
+    return o < limit ? o : -1;
 }
 
-// one thread per output element, 16 slices of loads in flight (consecutive threads = consecutive columns of a slab row: coalesced)
+// out += sum over the slices, in slice order.  Workgroup = 4 slab rows x 64 column quads x 4 slice groups: thread (row, quad, sg) sums slices sg,
+// sg + 4, ... of its 4 consecutive columns (16-byte loads, all of them in flight), the four groups meet in LDS and are added in a fixed order --
+// the same bits on every run.  (One thread per element walking all slices took 8 .. 18 us per launch: 64 dependent-latency rounds on 250
+// workgroups.)  The bias gradient is column 255 of the slab rows (ones column of X) or the extra per-slice rows behind the tiles (bias_mfma).
 __global__ __launch_bounds__(256) void wgrad_tok_reduce_kernel(const wk_reduce_table tb, int slices) {
-    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    EEG_LDS_BASE(f32x4, red);                                // [4 slice groups][64 threads]
     int prob = 0;
 #pragma unroll
     for (int p = 1; p < WK_MAXP; ++p)
-        if (p < tb.n && i >= tb.p[p].first) prob = p;
+        if (p < tb.n && (int)blockIdx.x >= tb.p[p].first) prob = p;
     const wk_reduce_problem& P = tb.p[prob];
-    const int e = i - P.first, total = P.M * P.N;
+    const int t = threadIdx.x, sg = t >> 6, q = t & 63;
+    const int local = (int)blockIdx.x - P.first;
+    const int tiles_rows = P.Mp / 4;                         // workgroups that cover the slab tiles; then the bias_mfma rows (Mp / 256 workgroups)
     const long long stride = (long long)P.Mp * 256;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool tile_wg = local < tiles_rows;
+    int m = 0, c4 = 0;
     const float* p;
     long long step;
-    float* dst;
-    if (e < total) {
-        const int m = e / P.N, n = e - m * P.N;
-        p = P.slab + (long long)wk_slab_index(m, P.heads_m) * 256 + wk_slab_index(n, P.heads_n);
+    if (tile_wg) {
+        m = 4 * local + (q >> 4);                            // 4 rows x 16 quads per 64 threads ... x 4 column blocks below
+        c4 = q & 15;
+        p = P.slab + (long long)m * 256;
         step = stride;
-        dst = P.out + (long long)m * P.ldo + n;
-    } else if (P.bias_out && e < total + P.M) {
-        const int m = e - total, sm = wk_slab_index(m, P.heads_m);
-        if (P.bias_mfma) {
-            p = P.slab + (long long)slices * stride + sm;
-            step = P.Mp;
-        } else {
-            p = P.slab + (long long)sm * 256 + 255;
-            step = stride;
-        }
-        dst = P.bias_out + m;
-    } else
-        return;
-    float s = 0.f;
-    int k = 0;
-    for (; k + 16 <= slices; k += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(long long)(k + u) * step];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+    } else {
+        m = 256 * (local - tiles_rows) + 4 * q;              // bias_mfma partial rows: 4 consecutive m per thread
+        p = P.slab + (long long)slices * stride + m;
+        step = P.Mp;
     }
-    for (; k < slices; ++k) s += p[(long long)k * step];
-    *dst += s;
+    f32x4 acc4[4];                                           // tile workgroups: 4 column blocks of 64 columns (quad c4 + 16 cb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc4[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tile_wg) {
+#pragma unroll 4
+        for (int k = sg; k < slices; k += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) v[cb] = *reinterpret_cast<const f32x4*>(p + (long long)k * step + 4 * (c4 + 16 * cb));
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc4[cb][e] += v[cb][e];
+        }
+    } else if (P.bias_mfma && P.bias_out) {
+        for (int k = sg; k < slices; k += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long long)k * step);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+        acc4[0] = s;
+    }
+    // the four slice groups in fixed order: ((g0 + g1) + (g2 + g3))
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb > 0 && !tile_wg) break;
+        red[sg * 64 + q] = acc4[cb];
+        __syncthreads();
+        if (sg == 0) {
+            const f32x4 a0 = red[q], a1 = red[64 + q], a2 = red[128 + q], a3 = red[192 + q];
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
+            if (tile_wg) {
+                const int om = wk_out_index(m, P.heads_m, P.M);
+                if (om >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = 4 * (c4 + 16 * cb) + e;
+                        const int on = wk_out_index(n, P.heads_n, P.N);
+                        if (on >= 0) P.out[(long long)om * P.ldo + on] += r[e];
+                        else if (n == 255 && P.bias_out && !P.bias_mfma) P.bias_out[om] += r[e];
+                    }
+                }
+            } else if (P.bias_mfma && P.bias_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int om = wk_out_index(m + e, P.heads_m, P.M);
+                    if (om >= 0) P.bias_out[om] += r[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace eeg
@@ -296,6 +377,7 @@ extern "C" int eegclip_wgrad_tok_slices(int total_m_groups, int B) {
     if (total_m_groups < 1 || B < 1) return 0;
     const int tiles = 4 * total_m_groups, kt = 2 * B;
     int s = 256 / tiles;                                         // one workgroup (128 KB of LDS) per CU
+    if (s > 32) s = 32;                                          // (more slices: the slab traffic of the reduction outgrows what the extra workgroups gain)
     if (s > kt / 4) s = kt / 4;                                  // at least 4 k-tiles per workgroup
     if (s >= 8) s = s / 8 * 8;                                   // a multiple of 8: the XCD-aware order of the kernel
     return s < 1 ? 1 : s;
@@ -326,7 +408,7 @@ static int wk_tables(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int 
                              (q.bias_out && q.bias_mfma) ? 1 : 0, blocks};
         rt.p[i] = wk_reduce_problem{ws, q.out, q.bias_out, q.ldo, q.M, q.N, Mp, q.heads_m ? 1 : 0, q.heads_n ? 1 : 0, q.bias_mfma ? 1 : 0, threads};
         blocks += 4 * q.m_groups * slices;
-        threads += (q.M * q.N + (q.bias_out ? q.M : 0) + 255) / 256 * 256;
+        threads += Mp / 4 + ((q.bias_out && q.bias_mfma) ? q.m_groups : 0);      // (workgroups of the reduction)
         ws += (long long)slices * ((long long)Mp * 256 + Mp);
     }
     return 0;
@@ -339,8 +421,11 @@ extern "C" int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob,
     int blocks, threads;
     const int rc = wk_tables(p, n_prob, B, slices, workspace, tb, rt, blocks, threads);
     if (rc) return rc;
-    if (variant == 1) EEG_LAUNCH(wgrad_tok_kernel<2>, dim3((unsigned)blocks), dim3(256), WK_NS * WK_STAGE, stream, tb, 2 * B, slices);
-    else EEG_LAUNCH(wgrad_tok_kernel<4>, dim3((unsigned)blocks), dim3(512), WK_NS * WK_STAGE, stream, tb, 2 * B, slices);
+    // measured on the MI355X (tools/bench_wgrad_tok.py, B = 256, 16 slices, us): 512-thread / 4 stages 25.0 (q|k|v) 28.7 (FFN + out-projection);
+    // 256-thread 28.9 / 30.7; 5 stages (all 160 KB of LDS) 31.1 / 34.5 -- more bytes in flight do not help: the kernel moves its operands at
+    // 3.3 TB/s (+ 0.8 of slab writes) with the matrix pipe of the CUs it occupies 50 % busy (profiles/r4_pmc_wgrad_tok.json)
+    if (variant == 1) EEG_LAUNCH((wgrad_tok_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 4 * WK_STAGE, stream, tb, 2 * B, slices);
+    else EEG_LAUNCH((wgrad_tok_kernel<4, 4>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, 2 * B, slices);
     return (int)hipGetLastError();
 }
 
@@ -351,7 +436,7 @@ extern "C" int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int 
     int blocks, threads;
     const int rc = wk_tables(p, n_prob, B, slices, workspace, tb, rt, blocks, threads);
     if (rc) return rc;
-    EEG_LAUNCH(wgrad_tok_reduce_kernel, dim3((unsigned)(threads / 256)), dim3(256), 0, stream, rt, slices);
+    EEG_LAUNCH(wgrad_tok_reduce_kernel, dim3((unsigned)threads), dim3(256), 256 * sizeof(f32x4), stream, rt, slices);
     return (int)hipGetLastError();
 }
 

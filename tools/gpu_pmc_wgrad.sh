@@ -1,0 +1,24 @@
+#!/bin/bash
+# PMC counters of csrc/wgrad_tok.hip stand-alone (tools/bench_wgrad_tok.py, one launch shape): separate passes per counter group
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-pmc_wgrad}
+SEL=${2:-qkv,16,0}
+mkdir -p $O
+cd /tmp
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/g$i -o p -- python $R/tools/bench_wgrad_tok.py $O/time.json $SEL > $O/g$i.log 2>&1
+done
+python $R/tools/pmc_summary.py $O/summary.json "$O/g*/**/*counter_collection.csv"
+find $O -name "*.csv" -size +2M -delete
+python - <<PY
+import json
+d=json.load(open("$O/summary.json"))
+for k,v in d.items():
+    if "wgrad" in k: print(k, json.dumps(v, indent=0))
+PY
