@@ -549,7 +549,6 @@ class _Engine:
 
         R = B * L_TOK
         b.update(ds=f(B, P_DIM), dv=f(B, P_DIM), dz2=f(B, C_TS, W_TS), dy2=f(B, C_TS, W_TS),
-                 dy1=f(B, C_TS, N_CH, W_TS),
                  # tsconv_bwd_x writes token rows 0..62 of every sample; row 63 (EEG channel 62, dropped by the reference's [:, :63]
                  # slice) never receives a gradient from the conv path: zeroed once here, nothing else ever writes dn3
                  dn3=torch.zeros(B, L_TOK, D_MODEL, dtype=torch.float32, device=dev),
@@ -811,17 +810,33 @@ class _Engine:
             pl.callback(exchange1, "allreduce_bn1_bwd")
         if not train:
             pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
-        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]) if train else _p(zsum),
-                (_p(local1) if local1 is not None else None) if train else _p(sums[3]), float(W * B * N_CH * W_TS), _p(b["dy1"]), _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
-        if "tsw_ws" not in b:
-            b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
-                C_TS, side=True)
-        if early_reduce:
-            # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
-            # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
-            pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
-        pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
+        count1 = float(W * B * N_CH * W_TS)
+        sums1 = (_p(sums[3]) if train else _p(zsum), (_p(local1) if local1 is not None else None) if train else _p(sums[3]))
+        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CONV_BWD_FUSED", "0") == "1":
+            # OPT-IN: BatchNorm1-backward apply + the temporal conv's weight and input gradients in ONE pass over y1 (csrc/conv.hip: conv_bwd_fused_kernel):
+            # the (B,40,63,36) gradient dy1 -- 93 MB written once and read twice by the three launches this replaces -- never exists in HBM (404 -> 141 MB
+            # of traffic).  Parity-green; measured on the MI355X at B = 256: 109 us against 49 + 37 us on the main stream + 44 us on the second one --
+            # less kernel time, but all of it on the dX chain: the step does not get shorter, so the three launches stay the default
+            if "cbf_ws" not in b:
+                b["cbf_ws"] = torch.empty(int(lib().eegclip_conv_bwd_fused_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+            pl.call("eegclip_conv_bwd_fused", _p(b["dy2"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]),
+                    _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(b["dn3"]), _p(G[_TS + "0.weight"]), _p(b["cbf_ws"]), B, N_CH, 0)
+            if early_reduce:
+                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+        else:
+            if "dy1" not in b:
+                b["dy1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
+            pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(b["dy1"]),
+                    _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
+            if "tsw_ws" not in b:
+                b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+            pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
+                    C_TS, side=True)
+            if early_reduce:
+                # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
+                # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
+                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+            pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
         fused = self._token_block_enabled(pl) and hasattr(self, "tb_packed")
         if fused:
             # the dX chain of the transformer block, one workgroup per sample (csrc/token_block.hip): part 0 = final LN' .. dctx, the attention

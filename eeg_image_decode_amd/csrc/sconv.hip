@@ -10,19 +10,12 @@
 //   sconv_bwd_x<true>  dy1 = BN1 backward(da)                                            reads y1 once, writes dy1 once
 // Contractions: v_mfma_f32_16x16x4_f32 (exact fp32), or -- sconv_bwd_x with pre-split weight planes -- split-bf16 products on
 // v_mfma_f32_16x16x32_bf16.  HBM traffic: 5 passes over the 93 MB tensor per step instead of 14.
-#include "eeg_common.h"
+#include "conv_common.h"
 
 #include <stdlib.h>
 
 namespace eeg {
 
-constexpr int SC_C = 40;      // channels in and out
-constexpr int SC_W = 36;      // positions per row
-constexpr int SC_OP = 48;     // out channels / positions padded to 3 MFMA tiles
-
-struct bn_affine {            // per-channel BatchNorm as y -> xhat -> u: xhat = (y - mean) * rstd ; u = gamma * xhat + beta
-    const float *mean, *rstd, *gamma, *beta;
-};
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = (sample, K slice); K = (c,h) = 40*H is cut into SCF_KS slices (a whole sample per workgroup left ONE workgroup
@@ -800,7 +793,6 @@ __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, in
 // into LDS planes [48 w][64 o] (row stride 144 bytes: the 16 rows of a fragment read land 4 banks apart), its fragments do not depend on the
 // task and live in registers; the weights come PRE-SPLIT from eegclip_split_rows(transpose) as planes [(c,h)][64 o]: one 16-byte load per
 // k-step and plane instead of 10 strided 4-byte gathers + a split in registers.
-constexpr int SCX_RS = 144;                  // bytes per row of a dy2^T plane
 constexpr int SCX_GY = 5;                    // workgroups per sample: 20 waves x 2 channels x 4 row blocks
 template <bool APPLY, bool X3>
 __global__ __launch_bounds__(256, 3) void sconv_bwd_x_kernel(const float* __restrict__ dy2, const float* __restrict__ Ws,
