@@ -735,6 +735,12 @@ class _CollectiveLog:
             by.setdefault(key, []).append(us)
         rows = {k: {"per_step": round(len(v) / steps, 2), "mean_us_stream_held": (round(float(np.mean([x for x in v if x is not None])), 1) if any(x is not None for x in v) else None)}
                 for k, v in by.items()}
+        # payload and algorithmic bandwidth (payload bytes / time the compute stream was held; all_gather / reduce_scatter: the FULL gathered / scattered
+        # tensor) per collective, so that a multi-GPU line can be read against DESIGN.md section 7's per-collective predictions without a profiler
+        for k, r in rows.items():
+            nbytes = int(k.rsplit(":", 1)[1][:-1])
+            r["bytes"] = nbytes
+            r["algbw_GBps"] = round(nbytes / (r["mean_us_stream_held"] * 1e3), 2) if r["mean_us_stream_held"] else None
         held = sum(r["per_step"] * r["mean_us_stream_held"] for k, r in rows.items() if r["mean_us_stream_held"] is not None and "(async)" not in k)
         return {"per_step": round(len(self.calls) / steps, 2), "by_kind_and_payload": rows, "sum_us_stream_held_per_step": round(held, 1),
                 "note": "blocking collectives: event pair around the call on the compute stream; async ones: issue .. wait() (mostly overlapped work, not exposure)"}

@@ -264,15 +264,19 @@ __device__ __forceinline__ int wave_uniform(int v) {
 #endif
 }
 
-// ---- Philox4x32-10 counter-based RNG: dropout masks are a pure function of (seed, site, element) so the
-//      backward pass regenerates them instead of storing them ----
+// ---- Philox4x32 counter-based RNG: dropout masks are a pure function of (seed, site, element) so the
+//      backward pass regenerates them instead of storing them.  7 rounds (round 4; 10 before): Philox4x32-7 is the fewest-round variant Salmon et al.
+//      (SC'11, "Parallel random numbers: as easy as 1, 2, 3") report as passing BigCrush -- ample for a keep / drop decision -- and the generator was
+//      ~20 % of the fused transformer-block forward (5 dropout sites).  The masks cannot match torch's in any case; tests regenerate them in numpy
+//      (tests/philox_np.py, same round count) so that the oracle runs train mode under the kernels' masks. ----
+constexpr int PHILOX_ROUNDS = 7;
 struct philox4 { unsigned x, y, z, w; };
-__device__ __forceinline__ philox4 philox4x32_10(unsigned long long seed, unsigned long long ctr_lo, unsigned ctr_hi) {
+__device__ __forceinline__ philox4 philox4x32(unsigned long long seed, unsigned long long ctr_lo, unsigned ctr_hi) {
     const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0u;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: same bits, half the multiplies
         const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
         const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
@@ -284,7 +288,7 @@ __device__ __forceinline__ philox4 philox4x32_10(unsigned long long seed, unsign
 }
 // keep-decision for element `idx` of dropout site `site`: uniform u in [0,1) from 32 Philox bits, keep iff u >= p.
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
-    philox4 r = philox4x32_10(seed, idx >> 2, site);
+    philox4 r = philox4x32(seed, idx >> 2, site);
     unsigned sel = (unsigned)(idx & 3);
     unsigned bits = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
     return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
@@ -292,7 +296,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned s
 
 // dropout_keep() for the 4 consecutive elements idx4 .. idx4+3 (idx4 % 4 == 0): they share ONE Philox block
 __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned site, unsigned long long idx4, float p, bool (&keep)[4]) {
-    const philox4 r = philox4x32_10(seed, idx4 >> 2, site);
+    const philox4 r = philox4x32(seed, idx4 >> 2, site);
     const float k = 1.0f / 16777216.0f;
     keep[0] = (float)(r.x >> 8) * k >= p;
     keep[1] = (float)(r.y >> 8) * k >= p;
@@ -314,7 +318,7 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
 // quad run ONE block each (lane j takes t = j) and trade words -- 4x fewer Philox evaluations in the attention kernels
 __device__ __forceinline__ void dropout_keep_quad(unsigned long long seed, unsigned site, unsigned long long base, int fr, float p, bool (&keep)[4]) {
     const int q = fr >> 2, j = fr & 3;
-    const philox4 r = philox4x32_10(seed, (base >> 2) + 4 * j + q, site);
+    const philox4 r = philox4x32(seed, (base >> 2) + 4 * j + q, site);
     unsigned bits[4];
 #define EEG_QUAD_PICK(T)                                                                                      \
     {                                                                                                         \
@@ -332,7 +336,7 @@ __device__ __forceinline__ void dropout_keep_quad(unsigned long long seed, unsig
 // column; with N % 4 == 0 the four lanes of a quad sit in the same block of every row.)
 __device__ __forceinline__ void dropout_keep_quad_blocks(unsigned long long seed, unsigned site, unsigned long long my_block, int j, float p,
                                                          bool (&keep)[4]) {
-    const philox4 r = philox4x32_10(seed, my_block, site);
+    const philox4 r = philox4x32(seed, my_block, site);
     unsigned bits[4];
 #define EEG_QUAD_PICK(T)                                                                                      \
     {                                                                                                         \

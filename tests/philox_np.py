@@ -1,4 +1,4 @@
-"""numpy restatement of the kernels' dropout RNG (csrc/eeg_common.h: philox4x32_10 / dropout_keep).
+"""numpy restatement of the kernels' dropout RNG (csrc/eeg_common.h: philox4x32 with PHILOX_ROUNDS = 7 / dropout_keep).
 TEST ONLY: lets the oracle run train-mode forward/backward with exactly the masks the HIP kernels draw."""
 import numpy as np
 
@@ -6,7 +6,10 @@ M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 
 
-def philox4x32_10(seed, ctr_lo, ctr_hi):
+ROUNDS = 7          # csrc/eeg_common.h: PHILOX_ROUNDS
+
+
+def philox4x32(seed, ctr_lo, ctr_hi):
     """seed: python int (64 bit); ctr_lo: uint64 array; ctr_hi: python int (32 bit).  Returns 4 uint32 arrays."""
     ctr_lo = np.asarray(ctr_lo, dtype=np.uint64)
     c0 = (ctr_lo & MASK).astype(np.uint64)
@@ -14,7 +17,7 @@ def philox4x32_10(seed, ctr_lo, ctr_hi):
     c2 = np.full_like(c0, ctr_hi & MASK)
     c3 = np.zeros_like(c0)
     k0, k1 = seed & MASK, (seed >> 32) & MASK
-    for _ in range(10):
+    for _ in range(ROUNDS):
         p0 = np.uint64(M0) * c0
         p1 = np.uint64(M1) * c2
         h0, l0 = p0 >> np.uint64(32), p0 & np.uint64(MASK)
@@ -30,7 +33,7 @@ def philox4x32_10(seed, ctr_lo, ctr_hi):
 def keep_mask(seed, site, n, p):
     """Boolean keep mask for elements 0..n-1 of dropout site `site` (flat, logical index order)."""
     idx = np.arange(n, dtype=np.uint64)
-    r = philox4x32_10(seed, idx >> np.uint64(2), site)
+    r = philox4x32(seed, idx >> np.uint64(2), site)
     sel = (idx & np.uint64(3)).astype(np.int64)
     bits = np.choose(sel, r)
     u = (bits >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)

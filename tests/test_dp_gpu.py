@@ -45,31 +45,62 @@ def _worker(rank, world, port, n, ret):
     opt = optim.AdamW(m.parameters(), lr=3e-4)
     loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
     classes = T(syn.unit_features(SEED + 42, 7, tag="cls")).cuda()
+    calls = []                                                           # every collective of the step: (kind, payload bytes)
+    saved = {}
+    for kind in ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor", "all_gather", "broadcast"):
+        saved[kind] = getattr(dist, kind)
+
+        def wrap(real, kind=kind):
+            def call(*a, **k):
+                t = a[0] if torch.is_tensor(a[0]) else a[0][0]
+                calls.append((kind, t.numel() * t.element_size()))
+                return real(*a, **k)
+            return call
+        setattr(dist, kind, wrap(saved[kind]))
     retrieval.contrastive_step(m, opt, x_all[sl].contiguous(), 1, img_all[sl].contiguous(), txt_all[sl].contiguous(),
                                torch.zeros(n, dtype=torch.long, device="cuda"), classes, loss_acc, correct)
     torch.cuda.synchronize()
+    for kind, real in saved.items():
+        setattr(dist, kind, real)
     eng = m._engine()
     early = any("allreduce_early_bucket" in pl.op_names() for k, pl in eng.plans.items() if k[0] == "b")
     ret[rank] = ({k: p.detach().cpu().numpy() for k, p in m.named_parameters()}, float(loss_acc), early,
-                 {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k})
+                 {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k}, calls)
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_the_single_process_global_batch_step():
-    world, n = 2, 4
+@pytest.mark.parametrize("world,n", [(2, 4), (8, 32)])
+def test_ranks_on_one_gpu_equal_the_single_process_global_batch_step(world, n):
+    """(8, 32): the WHOLE step of a world-8 job -- configs[2]'s rank count -- with every rank's real kernels: SyncBN chain, early gradient bucket, the
+    9 collectives of DESIGN.md section 7 with their payloads, rank-identical parameters, and the single-process global-batch step of the oracle"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29747, n, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29747 + world, n, ret), nprocs=world, join=True)
     state_np = syn.make_state(SEED, oatms.state_spec())
     x_all = T(syn.eeg_batch(SEED + 41, n * world))
     img_all, txt_all = T(syn.unit_features(SEED + 41, n * world, tag="img")), T(syn.unit_features(SEED + 41, n * world, tag="txt"))
     tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
     lo, _ = tr.step(x_all, torch.full((n * world,), 1).long(), img_all, txt_all)
-    (p0, l0, e0, bn0), (p1, l1, e1, _) = ret[0], ret[1]
-    assert e0 and e1                                                     # the asynchronous early-bucket route was taken
-    assert abs(0.5 * (l0 + l1) - float(lo)) < 1e-4
+    p0, l0, e0, bn0, calls0 = ret[0]
+    assert all(ret[r][2] for r in range(world))                          # the asynchronous early-bucket route was taken on every rank
+    assert abs(float(np.mean([ret[r][1] for r in range(world)])) - float(lo)) < 1e-4
+    # the step's collectives (DESIGN.md section 7), identical on every rank: targets gathered in ONE call, Z gathered, its gradient reduce-scattered,
+    # four SyncBN sums of 80 doubles, the flat gradient in two all-reduces (early bucket + rest)
+    D_, nP = 1024, sum(int(np.prod(v.shape)) for v in p0.values())
+    kinds = sorted(c[0] for c in calls0)
+    assert kinds == sorted(["all_gather_into_tensor"] * 2 + ["reduce_scatter_tensor"] + ["all_reduce"] * 6), calls0
+    assert all(ret[r][4] == calls0 for r in range(world))
+    by = {}
+    for kind, nbytes in calls0:
+        by.setdefault(kind, []).append(nbytes)
+    assert sorted(by["all_gather_into_tensor"]) == sorted([world * n * D_ * 4, 2 * world * n * D_ * 4])        # Z | [img | txt] targets, full gathered tensors
+    assert by["reduce_scatter_tensor"] == [n * D_ * 4] or by["reduce_scatter_tensor"] == [world * n * D_ * 4]
+    assert sorted(by["all_reduce"])[:4] == [640] * 4                     # SyncBN: 80 doubles, forward x 2 + backward x 2
+    assert 4 * nP <= sum(sorted(by["all_reduce"])[4:]) <= 4 * nP + 4096  # the flat gradient, once, in two buckets
+    for r in range(1, world):
+        for k in p0:
+            np.testing.assert_array_equal(p0[k], ret[r][0][k], err_msg=f"rank {r}: {k}")          # ranks stay bit-identical
     for k in p0:
-        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)          # ranks stay bit-identical
         if k in oloops.ZERO_GRAD_KEYS or tr.P[k].shape != p0[k].shape:
             continue
         d = np.abs(p0[k] - tr.P[k].numpy())
