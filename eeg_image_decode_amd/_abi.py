@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int),
         ("rowsum_a", C.c_void_p),
         ("precision", C.c_int),
-        ("B_hi", C.c_void_p), ("B_lo", C.c_void_p), ("ldb_planes", C.c_longlong), ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
     ]
 
 
@@ -139,13 +139,11 @@ PROTOTYPES = {
     "eegclip_conv_bwd_fused_workspace_floats": [_I, _I],
     "eegclip_conv_bwd_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_cross_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _P, _P],
+    "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "eegclip_sconv_fwd_workspace_floats": [_I],
     "eegclip_sconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_sconv_bwd_w": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_sconv_bwd_x_stats_workspace_floats": [_I],
-    "eegclip_sconv_bwd_w_stats_workspace_floats": [_I, _I],
-    "eegclip_sconv_bwd_w_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_sconv_bwd_x_stats": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_sconv_bwd_x_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _P],
     "eegclip_lse_rows": [_P, _I, _I, _L, _P, _P, _P],

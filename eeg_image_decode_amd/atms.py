@@ -404,7 +404,6 @@ class _Engine:
         self.early_work = None
         self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])
         self.buffers = dict(model.named_buffers())
-        self._init_weight_planes()
         self.bufs, self.plans, self.version = {}, {}, {}
         self.last_key = None
         self.grad_fresh = True               # gflat holds zeros / stale values that must be cleared before accumulation
@@ -424,55 +423,9 @@ class _Engine:
         f, tr = self.sc_planes, self.sc_planes_t
         src = _p(self.P[_TS + "4.weight"])
         items = [_abi.SplitItem(src=src, hi=tr[0].data_ptr(), lo=tr[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=64, transpose=1)]
-        # measured at B = 256 (single-stream HIP events, profiles/r2_conv_x3_vs_f32.json): the split-bf16 FORWARD kernel is not faster than the exact
-        # fp32 one (61 vs 59 us: both are bound by occupancy and the L1 tag rate of their strided 16-byte accesses, not by the MFMA pipe), so the
-        # forward keeps exact products unless EEGCLIP_SCONV_FWD_X3=1; the backward kernels (apply -4 us, dW -4 us) use the planes
-        if os.environ.get("EEGCLIP_SCONV_FWD_X3", "0") != "1":
-            return (None, None, 0), items
-        items.append(_abi.SplitItem(src=src, hi=f[0].data_ptr(), lo=f[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=ld, transpose=0))
-        return (f[0].data_ptr(), f[1].data_ptr(), ld), items
-
-    def _init_weight_planes(self):
-        """bf16 hi / lo planes of the TRANSPOSED attention / FFN weights (W^T for dX = dY W), refreshed by the eegclip_split_rows launch at the
-        head of every forward plan, for the planes variant of the split-bf16 GEMM (csrc/gemm_x3.hip: B never split in the kernel, 64 x 128 x 64
-        tiles).  OFF by default: EEGCLIP_WEIGHT_PLANES=1 enables it for the plain-epilogue dX GEMMs, =all for every Linear.
-
-        Which launches use planes is a measured choice (bench.py --breakdown at B = 256, us, both-operands-split kernel -> planes kernel):
-        the dX GEMMs with a plain epilogue gain -- fused QKV (K = 744) 45.7 -> 37.0, FFN 24.4 -> 22.3, out-projection 21.5 -> 20.6 -- while launches
-        with a heavy epilogue (GELU / dropout / pre-activation copy / two-level output map: 8 accumulator tiles per wave at 3 waves per SIMD instead
-        of 4 at 4) lose: value embedding 25.4 -> 37.1, GELU' dX 30.7 -> 36.4, and the forward GEMMs are a wash (44.5 -> 47.9, 20.3 -> 20.8,
-        19.1 -> 18.9).  In the STEP, where these launches share the GPU with the weight-gradient stream, neither setting pays: every Linear on planes
-        1.253 vs 1.218 ms, only the three gaining dX launches 1.204 vs 1.196 ms (same box, alternating runs) -- the 155-VGPR / 55 KB-LDS kernel
-        leaves less of a CU to the co-running kernels than it saves."""
-        import collections
-        mode = os.environ.get("EEGCLIP_WEIGHT_PLANES", "0")
-        self.planes, self.planesT = collections.defaultdict(lambda: None), collections.defaultdict(lambda: None)
-        self.plane_items, self.n_plane_items = None, 0
-        if mode == "0":
-            return
-        # (name, flat-buffer key, rows, cols, orientations)
-        base = [("qkv", _LY + "attention.query_projection.weight", 3 * HE, D_MODEL, (1,)), ("out", _LY + "attention.out_projection.weight", D_MODEL, HE, (1,)),
-                ("ffn1", _LY + "conv1.weight", D_FF, D_MODEL, (1,))]
-        if mode == "all":
-            base = [(n, k, r, c, (0, 1)) for n, k, r, c, _ in base] + [("ffn2", _LY + "conv2.weight", D_MODEL, D_FF, (0, 1))]
-            if not self.joint:                                       # (the per-subject value embeddings run as a grouped fp32 launch)
-                base.append(("embed", _E + "value_embedding.weight", D_MODEL, T_LEN, (0, 1)))
-        pad = lambda n: (n + 63) // 64 * 64
-        total = sum((r * pad(c) if 0 in o else 0) + (c * pad(r) if 1 in o else 0) for _, _, r, c, o in base)
-        self.plane_buf = torch.zeros(2 * total, dtype=torch.bfloat16, device=self.device)
-        n_items = sum(len(o) for *_, o in base)
-        items = (_abi.SplitItem * n_items)()
-        off, ptr, j = 0, self.plane_buf.data_ptr(), 0
-        for name, key, rows, cols, orient in base:
-            src = self.P[key].data_ptr()                             # (rows, cols) row-major view of the flat buffer (q|k|v: three adjacent weights)
-            for tr in orient:
-                orow, ld = (cols, pad(rows)) if tr else (rows, pad(cols))
-                hi, lo = ptr + 2 * off, ptr + 2 * (off + orow * ld)
-                items[j] = _abi.SplitItem(src=src, hi=hi, lo=lo, rows=rows, cols=cols, ld_src=cols, ld_out=ld, transpose=tr)
-                (self.planesT if tr else self.planes)[name] = (hi, lo, ld)
-                off += 2 * orow * ld
-                j += 1
-        self.plane_items, self.n_plane_items = items, n_items
+        # (a split-bf16 FORWARD kernel measured no faster than the exact-fp32 one, 61 vs 59 us -- profiles/r2_conv_x3_vs_f32.json -- and was removed
+        #  in round 4: the forward keeps exact products; the backward kernels (apply -4 us, dW -4 us) use the planes)
+        return (None, None, 0), items
 
     def _token_block_enabled(self, pl):
         """the fused transformer-block forward (csrc/token_block.hip): the single-subject model in the default split-bf16 arithmetic;
@@ -562,16 +515,11 @@ class _Engine:
         pl = Plan(f"atms_fwd[B={B}]")
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
-        PL, PLT = self.planes, self.planesT
         # bf16 planes of this step's weights -- every Linear in both orientations + the spatial conv -- in ONE launch
-        fw, conv_items = self._spatial_weight_planes(pl)
-        n_items = self.n_plane_items + len(conv_items)
+        _, conv_items = self._spatial_weight_planes(pl)
+        n_items = len(conv_items)
         if n_items:
-            items = (_abi.SplitItem * n_items)()
-            for i in range(self.n_plane_items):
-                items[i] = self.plane_items[i]
-            for i, it in enumerate(conv_items):
-                items[self.n_plane_items + i] = it
+            items = (_abi.SplitItem * n_items)(*conv_items)
             pl._keep.append(items)
             pl.call("eegclip_split_rows", items, n_items)
         pl.tb_desc = None
@@ -602,7 +550,7 @@ class _Engine:
             if not self.joint:
                 pl.x_gemm = pl.gemm(B * N_CH, D_MODEL, T_LEN, 0, D(T_LEN), D(1), _p(P[_E + "value_embedding.weight"]), D(1), D(T_LEN),
                         _p(b["h"]) + 4 * D_MODEL, hmap, D(1), bias_n=_p(P[_E + "value_embedding.bias"]),
-                        R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1), planes=PL["embed"])
+                        R=_p(pe), Rm=D(D_MODEL, div=N_CH, so=0), Rn=D(1))
             else:
                 # joint-subject model (Embed.py:142-144): one GEMM per subject over that subject's block of the subject-ordered batch.  A batch
                 # that is not already in subject order is gathered into xs first and the token rows are scattered back to batch order after
@@ -620,20 +568,20 @@ class _Engine:
             pl.call("eegclip_embed_finish", _p(b["h"]), _p(tok), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, pe_, 0, SITE_EMBED, seed_at=7)
             # A2: fused QKV projection (weights adjacent in the flat buffer) + attention      (SelfAttention_Family.py:199-213)
             pl.gemm(R, 3 * HE, D_MODEL, _p(b["h"]), D(D_MODEL), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(1), D(D_MODEL),
-                    _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]), planes=PL["qkv"])
+                    _p(b["qkv"]), D(3 * HE), D(1), bias_n=_p(P[_LY + "attention.query_projection.bias"]))
             pl.call("eegclip_attention_fwd", _p(b["qkv"]), _p(b["ctx"]), B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD), pe_, 0,
                     SITE_ATTN, seed_at=9)
             # (dropout + residual of both sublayers live in the LayerNorm kernel that follows, not in the GEMM epilogue: one Philox block per 4
             #  consecutive columns there, one per ELEMENT in an MFMA accumulator layout -- 12 us per GEMM)
             pl.gemm(R, D_MODEL, HE, _p(b["ctx"]), D(HE), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(1), D(HE),
-                    _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]), planes=PL["out"])
+                    _p(b["r1"]), D(D_MODEL), D(1), bias_n=_p(P[_LY + "attention.out_projection.bias"]))
             # A3: post-LN encoder layer + final LN      (Transformer_EncDec.py:45-51,77-78)
             pl.call("eegclip_residual_layernorm_fwd", _p(b["r1"]), _p(b["h"]), _p(b["r1"]), pe_, 0, SITE_ATTN_OUT, _p(P[_LY + "norm1.weight"]),
                     _p(P[_LY + "norm1.bias"]), _p(b["n1"]), _p(b["mu1"]), _p(b["rs1"]), None, None, None, None, None, R, D_MODEL, EPS, seed_at=4)
             pl.gemm(R, D_FF, D_MODEL, _p(b["n1"]), D(D_MODEL), D(1), _p(P[_LY + "conv1.weight"]), D(1), D(D_MODEL), _p(b["g1"]), D(D_FF), D(1),
-                    Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PL["ffn1"])
+                    Cpre=_p(b["f1"]), bias_n=_p(P[_LY + "conv1.bias"]), act=ACT_GELU, drop_p=pe_, drop_site=SITE_FFN_ACT)
             pl.gemm(R, D_MODEL, D_FF, _p(b["g1"]), D(D_FF), D(1), _p(P[_LY + "conv2.weight"]), D(1), D(D_FF), _p(b["r2"]), D(D_MODEL), D(1),
-                    bias_n=_p(P[_LY + "conv2.bias"]), planes=PL["ffn2"])
+                    bias_n=_p(P[_LY + "conv2.bias"]))
             # norm2 and the encoder's final norm back to back in one launch
             pl.call("eegclip_residual_layernorm_fwd", _p(b["r2"]), _p(b["n1"]), _p(b["r2"]), pe_, 0, SITE_FFN_OUT, _p(P[_LY + "norm2.weight"]),
                     _p(P[_LY + "norm2.bias"]), _p(b["n2"]), _p(b["mu2"]), _p(b["rs2"]), _p(P["encoder.encoder.norm.weight"]),
@@ -657,7 +605,7 @@ class _Engine:
         # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
         # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
         pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
-                *fw, _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1, _p(b["scf_ws"]))
+                _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1, _p(b["scf_ws"]))
         if W > 1:
             pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
         pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
@@ -672,16 +620,16 @@ class _Engine:
         skh = _head_split(B)
         if skh > 1:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["hacc"][0]), D(P_DIM), D(1),
-                    accumulate=1, split_k=skh, planes=None)
+                    accumulate=1, split_k=skh)
             pl.call("eegclip_bias_act", _p(b["hacc"][0]), _p(P["proj_eeg.0.bias"]), _p(b["u"]), None, _p(b["gu"]), B, P_DIM, ACT_GELU, 0.0, 0, 0)
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["hacc"][1]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh, planes=None)             # (slice 0 adds the bias)
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), accumulate=1, split_k=skh)             # (slice 0 adds the bias)
             w_lin = b["hacc"][1]
         else:
             pl.gemm(B, P_DIM, F_TS, _p(b["feat"]), D(F_TS), D(1), _p(P["proj_eeg.0.weight"]), D(1), D(F_TS), _p(b["gu"]), D(P_DIM), D(1),
-                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU, planes=None)
+                    Cpre=_p(b["u"]), bias_n=_p(P["proj_eeg.0.bias"]), act=ACT_GELU)
             pl.gemm(B, P_DIM, P_DIM, _p(b["gu"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(1), D(P_DIM), _p(b["s"]), D(P_DIM), D(1),
-                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]), planes=None)
+                    bias_n=_p(P["proj_eeg.1.fn.1.bias"]))
             w_lin = b["s"]
         # s = u + dropout(W gelu(u) + b), out = LayerNorm(s): ResidualAdd + LayerNorm of Proj_eeg in one launch; `out` is a fresh tensor per
         # call (argument 8 is patched by forward()), so callers keep what they are handed and no copy is made
@@ -698,14 +646,11 @@ class _Engine:
         P, G, b = self.P, self.G, self.bufs[B]
         pe_, pc_, pp_ = probs
         pl = Plan(f"atms_bwd[B={B}]")
-        PLT = self.planesT                        # W^T planes of this step's weights (refreshed by the forward plan)
         R = B * L_TOK
         sums, bn = b["sums"], b["bn"]
         wsk = int(os.environ.get("EEGCLIP_WGRAD_SK", "0"))                         # tuning aid: K-slice count of the long-K weight gradients
-        # attention backward: split-bf16 products (csrc/attention_x3.hip) in plans whose GEMM precision is bf16x3; EEGCLIP_ATTN_BWD_X3=0 keeps the
-        # exact-fp32 MFMA kernel
-        attn_bwd = ("eegclip_attention_bwd_x3" if (pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_ATTN_BWD_X3", "1") != "0")
-                    else "eegclip_attention_bwd")
+        # attention backward: split-bf16 products (csrc/attention_x3.hip) in plans whose GEMM precision is bf16x3, the exact-fp32 MFMA kernel otherwise
+        attn_bwd = "eegclip_attention_bwd_x3" if pl.precision == _abi.PREC_BF16X3 else "eegclip_attention_bwd"
         sk = lambda k: (wsk if (wsk > 0 and k >= 4096) else max(1, min(64, k // 512)))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
         def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
@@ -714,7 +659,7 @@ class _Engine:
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
                            rowsum_a=_p(G[bias]) if bias else None, side=side)    # nobody reads a weight gradient before the optimizer
 
-        ln_side = os.environ.get("EEGCLIP_LN_SIDE", "1") != "0"        # tuning aid: LayerNorm parameter-gradient kernels on the second stream
+        ln_side = True                                                 # LayerNorm parameter-gradient kernels on the second stream
         # the three token-block LayerNorms reduce their gamma / beta gradients through per-workgroup partial rows (one workspace: the three launches
         # are ordered on one stream) instead of 256-way contended atomics
         if "lnp_ws" not in b:
@@ -737,11 +682,11 @@ class _Engine:
         wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
         skh = _head_split(B)
         pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
-                accumulate=int(skh > 1), split_k=skh, planes=None)
+                accumulate=int(skh > 1), split_k=skh)
         pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
         wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
         pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
-                accumulate=int(skh > 1), split_k=skh, planes=None)
+                accumulate=int(skh > 1), split_k=skh)
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
         # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.
@@ -788,17 +733,10 @@ class _Engine:
             wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
         if "scx_ws" not in b:
             b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
-        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_SCONV_FOLD", "0") == "1":
-            # opt-in: dWs and the BatchNorm1-backward sums from ONE pass over y1 (csrc/sconv.hip: sconv_bwd_ws_x3_kernel).  The statistics are on the dX
-            # chain, so the fused launch runs on the main stream.  Measured (B = 256): 70.6 us against 41.6 (second stream) + 44.5 (main) for the two
-            # kernels -- 15 us less kernel time, but the main-stream chain grows by 26 us and the step is 1.100-1.108 vs 1.093-1.096 ms: not the default.
-            if "scws_ws" not in b:
-                b["scws_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_stats_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
-            pl.call("eegclip_sconv_bwd_w_stats", _p(b["y1"]), *bnp, _p(b["dy2"]), *wt, _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), _p(sums[3]),
-                    _p(b["scws_ws"]), B, N_CH)
-        else:
-            pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
-            pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
+        # (folding the two into one pass over y1 -- round 3's eegclip_sconv_bwd_w_stats -- saved 15 us of kernel time but moved the weight gradient from
+        #  the second stream onto the dX chain: step 1.100-1.108 vs 1.093-1.096 ms; removed in round 4)
+        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
+        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
         local1 = None
         if W > 1:
             local1 = torch.zeros_like(sums[3])
@@ -856,7 +794,7 @@ class _Engine:
             pl._keep.append(bd)
             if pe_ > 0.0:
                 pl._seed_descs.append(bd)
-            variant = int(os.environ.get("EEGCLIP_WGRAD_VARIANT", "0"))                # tuning aid: 0 = 512-thread workgroups, 1 = 256-thread
+            variant = 0                                                               # 512-thread workgroups (256-thread: 28.9 vs 25.0 us, csrc/wgrad_tok.hip)
 
             def wgrad_tok(tag, problems, side=True):
                 """the block's weight gradients from the token planes the fused kernels leave (csrc/wgrad_tok.hip): `problems` become ready together
@@ -895,17 +833,16 @@ class _Engine:
                     _p(G[_LY + "norm2.weight"]), _p(G[_LY + "norm2.bias"]), R, D_MODEL, 0, _p(b["df2"]), pe_, 0, SITE_FFN_OUT, lnf_ws, seed_at=13)
             wgrad(_LY + "conv2.weight", _p(b["df2"]), D_MODEL, _p(b["g1"]), D_FF, D_MODEL, D_FF, R, bias=_LY + "conv2.bias")
             pl.gemm(R, D_FF, D_MODEL, _p(b["df2"]), D(D_MODEL), D(1), _p(P[_LY + "conv2.weight"]), D(D_FF), D(1), _p(b["dg1"]), D(D_FF), D(1),
-                    act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT, planes=PLT["ffn2"])                  # dg1 := df1
+                    act=ACT_GELU_GRAD, R=_p(b["f1"]), Rm=D(D_FF), Rn=D(1), drop_p=pe_, drop_site=SITE_FFN_ACT)                  # dg1 := df1
             wgrad(_LY + "conv1.weight", _p(b["dg1"]), D_FF, _p(b["n1"]), D_MODEL, D_FF, D_MODEL, R, bias=_LY + "conv1.bias")
             pl.gemm(R, D_MODEL, D_FF, _p(b["dg1"]), D(D_FF), D(1), _p(P[_LY + "conv1.weight"]), D(D_MODEL), D(1), _p(b["dr2"]), D(D_MODEL), D(1),
-                    accumulate=1, planes=PLT["ffn1"])                                              # dr2 := dn1
+                    accumulate=1)                                              # dr2 := dn1
             # attention block: r1 = h + dropout(Wo ctx + bo)
             pl.call("eegclip_layernorm_bwd_full", _p(b["dr2"]), _p(b["r1"]), _p(P[_LY + "norm1.weight"]), _p(b["mu1"]), _p(b["rs1"]), _p(b["dr1"]),
                     _p(G[_LY + "norm1.weight"]), _p(G[_LY + "norm1.bias"]), R, D_MODEL, 0, _p(b["da1"]), pe_, 0, SITE_ATTN_OUT, lnf_ws, seed_at=13)
             wgrad(_LY + "attention.out_projection.weight", _p(b["da1"]), D_MODEL, _p(b["ctx"]), HE, D_MODEL, HE, R,
                   bias=_LY + "attention.out_projection.bias")
-            pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1),
-                    planes=PLT["out"])
+            pl.gemm(R, HE, D_MODEL, _p(b["da1"]), D(D_MODEL), D(1), _p(P[_LY + "attention.out_projection.weight"]), D(HE), D(1), _p(b["dctx"]), D(HE), D(1))
             if attn_bwd == "eegclip_attention_bwd_x3":
                 pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), _p(b["dqkv"]), 0, B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                         pe_, 0, SITE_ATTN, seed_at=11)
@@ -915,7 +852,7 @@ class _Engine:
             wgrad(_LY + "attention.query_projection.weight", _p(b["dqkv"]), 3 * HE, _p(b["h"]), D_MODEL, 3 * HE, D_MODEL, R,
                   bias=_LY + "attention.query_projection.bias")                                    # q|k|v weights and biases are adjacent
             pl.gemm(R, D_MODEL, 3 * HE, _p(b["dqkv"]), D(3 * HE), D(1), _p(P[_LY + "attention.query_projection.weight"]), D(D_MODEL), D(1),
-                    _p(b["dr1"]), D(D_MODEL), D(1), accumulate=2, drop_p=pe_, drop_site=SITE_EMBED, planes=PLT["qkv"])
+                    _p(b["dr1"]), D(D_MODEL), D(1), accumulate=2, drop_p=pe_, drop_site=SITE_EMBED)
             # ^ dr1 := dropout'(dh): the embedding dropout's backward (Embed.py:162) is the epilogue of the GEMM that completes dh -- accumulate FIRST
             #   (residual-path gradient already in dr1), then the mask of the (B,64,250) element index = m * 250 + n -- instead of a separate in-place
             #   pass over the 16 MB tensor (35 us in the step)
@@ -937,7 +874,7 @@ class _Engine:
         if not self.joint:
             if want_dx:
                 pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, hmap, D(1),
-                        _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1), planes=PLT["embed"])
+                        _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
         else:
             # per-subject weight gradients over the subject-ordered batch (mirror of the forward: gather the token-row gradients into
             # subject order first when the batch is not; xs still holds the gathered EEG)

@@ -792,11 +792,8 @@ extern "C" int eegclip_tsconv_fwd(const float* x, long long xs_b, long long xs_h
     return (int)hipGetLastError();
 }
 
-// rows per work item / resident workgroups per CU (tuning aid: EEGCLIP_TSW_R = 6 | 7)
-static int tsw_rows() {
-    static const int r = getenv("EEGCLIP_TSW_R") ? atoi(getenv("EEGCLIP_TSW_R")) : 7;
-    return r == 6 ? 6 : 7;
-}
+// rows per work item: 7 (63 KB of LDS, two workgroups per CU, 63 = 9 x 7 rows split evenly; 6 measured no faster)
+static int tsw_rows() { return 7; }
 static int tsw_grid(int B, int H) {
     const int r = tsw_rows();
     const int items = B * ((H + r - 1) / r), cap = 512;
@@ -816,8 +813,7 @@ extern "C" int eegclip_tsconv_bwd_w(const float* x, long long xs_b, long long xs
     if (int rc = ts_check(B, H, T, C)) return rc;
     if (!x || !dy || !dw25 || !workspace) return EEGCLIP_EINVAL;
     const int grid = tsw_grid(B, H);
-    if (tsw_rows() == 6) tsw_launch<6>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
-    else                 tsw_launch<7>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
+    tsw_launch<7>(grid, stream, x, xs_b, xs_h, dy, workspace, B, H);
     EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_K1 + 255) / 256, grid < 32 ? grid : 32), dim3(256), 0, stream, workspace, grid, dw25);
     return (int)hipGetLastError();
 }

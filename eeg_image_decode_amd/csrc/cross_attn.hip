@@ -457,9 +457,9 @@ extern "C" int eegclip_cross_attn_fwd(const void* q, const void* k, const void* 
     const int ldv = ca_ldv(nt), ldv_ip = ca_ldv(nt_ip);
     const size_t lds = sizeof(unsigned short) * ((size_t)nt * 16 * CA_KLD + CA_D * ldv + (size_t)nt_ip * 16 * CA_KLD + (nt_ip ? CA_D * ldv_ip : 0));
     const dim3 grid((HW + CA_QB - 1) / CA_QB, heads, B);
-    static const bool allow_reg = !(getenv("EEGCLIP_CA_REG") && atoi(getenv("EEGCLIP_CA_REG")) == 0);        // tuning aid
+    const bool allow_reg = true;
     if (allow_reg && nt == 5 && nt_ip <= 1) {            // SDXL: 77 text tokens, 0 / 4 image tokens -- K (and optionally V^T) fragments in registers
-        static const bool vreg = getenv("EEGCLIP_CA_VREG") && atoi(getenv("EEGCLIP_CA_VREG")) != 0;            // tuning aid
+        const bool vreg = false;                              // (V^T fragments in registers as well: measured slower)
         const bool f16 = dtype == EEGCLIP_DT_F16;
 #define EEG_CA_GO(F, I, V) EEG_LAUNCH((cross_attn_reg_kernel<F, 5, I, V>), grid, dim3(256), lds, stream, a)
         if (vreg) {

@@ -482,7 +482,7 @@ static bool same_shared(const eegclip_gemm_desc& a, const eegclip_gemm_desc& b) 
 }
 
 static int launch_gemm_grouped(const eegclip_gemm_desc* ds, int n, void* stream) {
-    static const bool allow = !(getenv("EEGCLIP_GEMM_GROUPED") && atoi(getenv("EEGCLIP_GEMM_GROUPED")) == 0);        // tuning aid
+    const bool allow = true;
     bool akc = false, bkc = false, cpl = false;
     int cls = (allow && n >= 2 && n <= GEMM_MAX_GROUPS) ? fast_class(ds[0], akc, bkc, cpl) : 0;
     gemm_group_table tb;
@@ -506,8 +506,6 @@ static int launch_gemm_grouped(const eegclip_gemm_desc* ds, int n, void* stream)
         return 0;
     }
     tb.n = n;
-    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                           // tuning aid
-    if (trace) fprintf(stderr, "eegclip_gemm_f32_grouped: %d members, class %d <%d,%d,%d>, %d workgroups\n", n, cls, (int)akc, (int)bkc, (int)cpl, tb.first[n]);
     const dim3 grid(tb.first[n]), block(G_THREADS);
     const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
 #define EEG_GROUP_GO(AK, BK_, CP, K2_) EEG_LAUNCH((gemm_f32_grouped_kernel<AK, BK_, CP, K2_>), grid, block, lds, stream, ds[0], tb)
@@ -529,14 +527,12 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ws_query: do not launch; report the split-K workspace the launch would use (0 unless it is routed to the BF16X3 kernels)
 static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_query) {
     if (ws_query) *ws_query = 0;
-    static const bool allow_skinny = !(getenv("EEGCLIP_GEMM_SKINNY") && atoi(getenv("EEGCLIP_GEMM_SKINNY")) == 0);   // tuning aid
+    const bool allow_skinny = true;
     // skinny: few rows against k-contiguous operands, every map a plain stride, 16-byte loads legal, K long enough for the 16-way split
     if (allow_skinny && d.M <= 32 && d.split_k == 1 && d.K >= 64 && (d.K & 3) == 0 && is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) &&
         is_plain(d.Bn) && is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn))) && d.Ak.si == 1 && d.Bk.si == 1 &&
         d.Am.si >= 0 && d.Bn.si >= 0 && (d.Am.si & 3) == 0 && (d.Bn.si & 3) == 0 && aligned16(d.A) && aligned16(d.B)) {
         if (ws_query) return 0;
-        static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "eegclip_gemm_f32: skinny %dx%dx%d\n", d.M, d.N, d.K);
         const dim3 grid((d.N + SK_N - 1) / SK_N), block(SK_WAVES * 64);
         if (d.M <= 16) EEG_LAUNCH((gemm_f32_skinny_kernel<1>), grid, block, SK_WAVES * 1 * 64 * 4 * sizeof(float), stream, d);
         else           EEG_LAUNCH((gemm_f32_skinny_kernel<2>), grid, block, SK_WAVES * 2 * 64 * 4 * sizeof(float), stream, d);
@@ -547,8 +543,7 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_q
     const bool ab_plain = is_plain(d.Am) && is_plain(d.Ak) && is_plain(d.Bk) && is_plain(d.Bn);
     const bool c_plain = is_plain(d.Cm) && is_plain(d.Cn) && (!d.R || (is_plain(d.Rm) && is_plain(d.Rn)));
     const bool plain = ab_plain && c_plain;
-    static const bool allow_fast = !(getenv("EEGCLIP_GEMM_FAST") && atoi(getenv("EEGCLIP_GEMM_FAST")) == 0);   // tuning aid
-    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;                                           // tuning aid
+    const bool allow_fast = true;
     bool akc = false, bkc = false;
     const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
     const dim3 fgrid(d.split_k == 1 ? 8 * chunk : 8 * ((d.split_k + 7) / 8) * ntiles);
@@ -559,7 +554,6 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_q
             return 0;
         }
         if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, akc, bkc, c_plain, false, stream);
-        if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<%d,%d,%d> %dx%dx%d sk%d\n", (int)akc, (int)bkc, (int)c_plain, d.M, d.N, d.K, d.split_k);
         const size_t lds = ((akc ? G_BT * F_LDK : G_BK * G_BT) + (bkc ? G_BT * F_LDK : G_BK * G_BT)) * sizeof(float);
 #define EEG_FAST_GO(AK, BK_)                                                                                                         \
     do {                                                                                                                             \
@@ -581,7 +575,6 @@ static int launch_gemm(const eegclip_gemm_desc& d, void* stream, long long* ws_q
             return 0;
         }
         if ((d.precision & 0xff) == EEGCLIP_PREC_BF16X3) return launch_gemm_x3(d, false, false, true, true, stream);
-        if (trace) fprintf(stderr, "eegclip_gemm_f32: fast<0,0,1,K2> %dx%dx%d sk%d\n", d.M, d.N, d.K, d.split_k);
         const size_t lds = 2 * G_BK * G_BT * sizeof(float);
         EEG_LAUNCH((gemm_f32_fast_kernel<false, false, true, true>), fgrid, block, lds, stream, d, gx, ntiles, chunk);
         return (int)hipGetLastError();

@@ -24,7 +24,7 @@
 //
 // Tile shapes (template): BT x BT output per 256-thread workgroup, 2 x 2 wavefronts, each wave (BT/32)^2 MFMA 16x16x32 tiles;
 // BK = 32 or 64; DB = two LDS images (one barrier per k-tile: the next tile is converted and stored behind the current tile's MFMAs)
-// or one (two barriers).  launch_gemm_x3() picks per problem; EEGCLIP_X3_CFG overrides for tuning.
+// or one (two barriers).  launch_gemm_x3() picks per problem.
 #include "eeg_common.h"
 #include "gemm_epilogue.h"
 
@@ -335,154 +335,7 @@ __global__ __launch_bounds__(X3_THREADS, (BT == 64 && !K2) ? 4 : (BT == 64 ? 3 :
     }
 }
 
-// =================================================================================================================================
-// Pre-split B ("planes") variant.  PMC on the kernel above at the step's shapes (profiles/r2_pmc_gemm_x3.json): ~1000 VALU instructions
-// per wave, half of them the hi/lo split, VALU issue = 46 % of the kernel's SIMD time, MFMA pipe 17 % -- and the split of one operand
-// element is repeated by every tile that stages it: a weight element by all 256 row tiles, an activation element by every column tile.
-// Weights change once per optimizer step, so their split is hoisted out of the GEMMs altogether (eegclip_split_rows: bf16 planes
-// hi / lo, [N][Kpad] with zero padding, plus the transposed planes for the dX = dY W form), and the output tile becomes 64 x 256 -- every
-// Linear of the encoder has N <= 256 except the fused QKV projection (3 tiles) -- so an activation element is split by ONE workgroup
-// (N <= 256) instead of four.  Per k-tile a workgroup then converts 64 x BK activations, copies 256 x BK x 2 plane bytes with 16-byte
-// loads / ds_write_b128 and issues 4 x 48 MFMAs: the matrix pipe is the long pole again.
-//   A: k-contiguous fp32 rows (the layer input, or dY), converted while staged, as above.   B: planes, rows = output columns n.
-//   4 waves side by side, each 64 rows x 64 columns (4 x 4 MFMA tiles); same LDS geometry, same epilogue, same split-K scheme.
-constexpr int XP_BM = 64;
 typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
-
-// XP_BN = 256: 4 waves side by side, 64 x 64 each (16 accumulator tiles per wave: 255 VGPRs, one workgroup per SIMD);
-// XP_BN = 128: 2 x 2 waves, 32 x 64 each (8 tiles: the occupancy of the base kernel, B never split, an A element split by half as many tiles)
-template <int BK, int XP_BN, bool C_PLAIN>
-__global__ __launch_bounds__(X3_THREADS) void gemm_x3p_kernel(const eegclip_gemm_desc d, int gx, int ntiles, int chunk) {
-    using G = x3_geom<BK>;
-    constexpr int WN = XP_BN / 64, WM = 4 / WN, MT = 4 / WM;          // waves along n / m, MFMA row tiles per wave
-    constexpr int IMG_A = XP_BM * G::RS, NQ = BK / 4, RPP = X3_THREADS / NQ, KC_PASS = XP_BM / RPP;
-    constexpr int NCH = BK / 8, BRP = X3_THREADS / NCH, B_PASS = XP_BN / BRP;        // B: thread -> (chunk t % NCH, row t / NCH + BRP i)
-    EEG_LDS_BASE(unsigned char, lds);
-    const int bid = (int)blockIdx.x;
-    int logical, slice = 0;
-    if (d.split_k == 1) {
-        logical = (bid & 7) * chunk + (bid >> 3);
-        if (logical >= ntiles) return;
-    } else {
-        const int slot = bid >> 3;
-        slice = (bid & 7) + 8 * (slot / ntiles);
-        logical = slot % ntiles;
-        if (slice >= d.split_k) return;
-    }
-    const int m0 = (logical / gx) * XP_BM, n0 = (logical % gx) * XP_BN;
-    const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    int kt_begin, kt_end;
-    gemm_k_slice<BK>(d, slice, kt_begin, kt_end);
-    const int a_ld = (int)d.Am.si;
-    const int kc_kq = t % NQ, kc_r0 = t / NQ;
-    int a_fix[KC_PASS];
-#pragma unroll
-    for (int i = 0; i < KC_PASS; ++i) { const int m = m0 + kc_r0 + RPP * i; a_fix[i] = (m < d.M ? m : d.M - 1) * a_ld; }
-    const int b_c = t % NCH, b_r0 = t / NCH;
-    const unsigned short* const Bh = static_cast<const unsigned short*>(d.B_hi);
-    const unsigned short* const Bl = static_cast<const unsigned short*>(d.B_lo);
-    long long b_fix[B_PASS];
-#pragma unroll
-    for (int i = 0; i < B_PASS; ++i) { const int n = n0 + b_r0 + BRP * i; b_fix[i] = (long long)(n < d.N ? n : d.N - 1) * d.ldb_planes + 8 * b_c; }
-
-    f32x2_t ra[KC_PASS * 2];
-    xp_u32x4 rbh[B_PASS], rbl[B_PASS];
-    unsigned a_ok = 0;
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK, ka = k0 + 4 * kc_kq;
-        if (k0 + BK <= d.K) {
-            a_ok = 3u;
-#pragma unroll
-            for (int i = 0; i < KC_PASS; ++i) {
-                const f32x4u_t v = *reinterpret_cast<const f32x4u_t*>(d.A + a_fix[i] + ka);
-                ra[2 * i] = f32x2_t{v[0], v[1]};
-                ra[2 * i + 1] = f32x2_t{v[2], v[3]};
-            }
-        } else {
-            const bool ok0 = ka < d.K, ok1 = ka + 2 < d.K;
-            const int k_0 = ok0 ? ka : 0, k_1 = ok1 ? ka + 2 : 0;
-            a_ok = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
-#pragma unroll
-            for (int i = 0; i < KC_PASS; ++i) {
-                ra[2 * i] = *reinterpret_cast<const f32x2_t*>(d.A + a_fix[i] + k_0);
-                ra[2 * i + 1] = *reinterpret_cast<const f32x2_t*>(d.A + a_fix[i] + k_1);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {                          // the planes are zero padded to a multiple of 64 in k: no tail handling
-            rbh[i] = *reinterpret_cast<const xp_u32x4*>(Bh + b_fix[i] + k0);
-            rbl[i] = *reinterpret_cast<const xp_u32x4*>(Bl + b_fix[i] + k0);
-        }
-    };
-    auto store_tile = [&]() {
-        const f32x2_t zero{0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KC_PASS; ++i) {
-            const f32x2_t p0 = a_ok & 1u ? ra[2 * i] : zero, p1 = a_ok & 2u ? ra[2 * i + 1] : zero;
-            u32x2_t hi, lo;
-            x3_split4(p0[0], p0[1], p1[0], p1[1], hi, lo);
-            const int row = kc_r0 + RPP * i;
-            *reinterpret_cast<u32x2_t*>(lds + G::quad(row, 0, kc_kq)) = hi;
-            *reinterpret_cast<u32x2_t*>(lds + G::quad(row, 1, kc_kq)) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            const int row = b_r0 + BRP * i;
-            *reinterpret_cast<xp_u32x4*>(lds + IMG_A + G::chunk(row, 0, b_c)) = rbh[i];
-            *reinterpret_cast<xp_u32x4*>(lds + IMG_A + G::chunk(row, 1, b_c)) = rbl[i];
-        }
-    };
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = d.rowsum_a != nullptr && n0 == 0;
-    float rowsum = 0.f;
-    if (kt_begin < kt_end) load_tile(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);
-        if (do_rowsum && t < XP_BM) {
-#pragma unroll
-            for (int c = 0; c < G::NCH; ++c) {
-                const bf16x8 h = *reinterpret_cast<const bf16x8*>(lds + G::chunk(t, 0, c));
-                const bf16x8 l = *reinterpret_cast<const bf16x8*>(lds + G::chunk(t, 1, c));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rowsum += bf16_bits_to_f32((unsigned short)h[e]) + bf16_bits_to_f32((unsigned short)l[e]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < BK / 32; ++s) {
-            bf16x8 bh[4], bl[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = 64 * wn + 16 * j + fr;
-                bh[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 0, 4 * s + g));
-                bl[j] = *reinterpret_cast<const bf16x8*>(lds + IMG_A + G::chunk(row, 1, 4 * s + g));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = (XP_BM / WM) * wm + 16 * i + fr;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 0, 4 * s + g));
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + G::chunk(row, 1, 4 * s + g));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = mfma_bf16_16x16x32(bh[j], al, acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(bl[j], ah, acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(bh[j], ah, acc[i][j]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (do_rowsum && t < XP_BM && m0 + t < d.M) atomicAdd(d.rowsum_a + m0 + t, rowsum);
-    gemm_epilogue_t<C_PLAIN, MT, 4>(d, acc, m0 + (XP_BM / WM) * wm, n0 + 64 * wn, lane, slice == 0, d.split_k > 1, d.C);
-}
 
 // rows of an fp32 matrix -> bf16 planes hi / lo, [rows][ld_out] with zeros beyond `cols`; TRANSPOSE: the planes of the transposed matrix.
 // A table of up to 24 matrices per launch (every Linear weight of the encoder, both orientations, in ONE launch per step).
@@ -567,43 +420,11 @@ static int x3_launch_cfg(const eegclip_gemm_desc& d_in, bool akc, bool bkc, bool
 }
 
 // Problem -> tile shape.  cfg: 0 = 64x64x32, 1 = 64x64x32 double-buffered, 2 = 64x64x64, 3 = 64x64x64 double-buffered,
-// 4 = 128x128x32, 5 = 128x128x32 double-buffered.  EEGCLIP_X3_CFG pins one for tuning.
-static bool xp_planes_ok(const eegclip_gemm_desc& d) {
-    return d.B_hi && d.B_lo && d.ldb_planes >= ((d.K + 63) / 64) * 64 && (d.ldb_planes & 7) == 0 &&
-           ((reinterpret_cast<uintptr_t>(d.B_hi) | reinterpret_cast<uintptr_t>(d.B_lo)) & 15u) == 0;
-}
-
+// 4 = 128x128x32, 5 = 128x128x32 double-buffered (bits 8..15 of desc.precision pin one: tests, tools/bench_gemm_x3.py).
 long long gemm_x3_workspace_bytes(const eegclip_gemm_desc& d) { return d.split_k > 1 ? x3_workspace_bytes(d.M, d.N, d.split_k) : 0; }
 
 int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain, bool k2, void* stream) {
-    static const int pinned = getenv("EEGCLIP_X3_CFG") ? atoi(getenv("EEGCLIP_X3_CFG")) : -1;
-    static const bool trace = getenv("EEGCLIP_GEMM_TRACE") != nullptr;
-    static const bool allow_planes = !(getenv("EEGCLIP_X3_PLANES") && atoi(getenv("EEGCLIP_X3_PLANES")) == 0);      // tuning aid
-    // (few rows: the 64 x 64 kernel's larger grid wins -- 1024^3: 20 vs 27 us)
-    if (allow_planes && akc && !k2 && d.split_k == 1 && d.M >= 2048 && xp_planes_ok(d) && ((d.precision >> 8) & 0xff) == 0) {
-        // variant: output tile width x k-tile depth (EEGCLIP_XP_VARIANT = 0: 256 x 32, 1: 128 x 32, 2: 128 x 64; tuning aid).  Measured at the step's
-        // shapes (16384 rows, K ~ 250; us, 64x64x64 kernel -> variant 2): forward 16.4-18.3 -> 16.3-17.1, dX 17.5-17.9 -> 15.6-16.0,
-        // dX of the fused QKV projection (K = 744) 40.9 -> 31.7; variant 0 (255 VGPRs): 21-24.
-        static const int variant = getenv("EEGCLIP_XP_VARIANT") ? atoi(getenv("EEGCLIP_XP_VARIANT")) : 2;
-        const int bn = variant == 0 ? 256 : 128, bk = variant == 2 ? 64 : 32;
-        const int gx = (d.N + bn - 1) / bn, gy = (d.M + XP_BM - 1) / XP_BM;
-        const int ntiles = gx * gy, chunk = (ntiles + 7) / 8;
-        const dim3 grid(8 * chunk), block(X3_THREADS);
-        if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 planes <%d,%d,%d> %dx%dx%d\n", bn, bk, (int)c_plain, d.M, d.N, d.K);
-        const size_t lds = (size_t)(XP_BM + bn) * (bk == 64 ? x3_geom<64>::RS : x3_geom<32>::RS);
-#define EEG_XP_GO(BK_, BN_)                                                                                              \
-    do {                                                                                                                 \
-        if (c_plain) EEG_LAUNCH((gemm_x3p_kernel<BK_, BN_, true>), grid, block, lds, stream, d, gx, ntiles, chunk);      \
-        else         EEG_LAUNCH((gemm_x3p_kernel<BK_, BN_, false>), grid, block, lds, stream, d, gx, ntiles, chunk);     \
-    } while (0)
-        if (variant == 0)      EEG_XP_GO(32, 256);
-        else if (variant == 2) EEG_XP_GO(64, 128);
-        else                   EEG_XP_GO(32, 128);
-#undef EEG_XP_GO
-        return (int)hipGetLastError();
-    }
     int cfg = ((d.precision >> 8) & 0xff) - 1;                  // explicit tile configuration in the descriptor (tuning / tests)
-    if (cfg < 0) cfg = pinned;
     if (cfg < 0) {
         // measured on the shapes of a training step (profiles/r2_gemm_x3_sweep_*.json): 64x64x64 with one LDS image is the best or within 3 % of
         // the best everywhere at K ~ 250 and for the split-K weight gradients; 128x128 tiles only pay once K is long and the grid is large (4096^3:
@@ -611,7 +432,6 @@ int launch_gemm_x3(const eegclip_gemm_desc& d, bool akc, bool bkc, bool c_plain,
         const long long big_tiles = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128);
         cfg = (d.split_k == 1 && big_tiles >= 1024 && d.K >= 1024) ? 5 : 2;
     }
-    if (trace) fprintf(stderr, "eegclip_gemm_f32: x3 cfg %d <%d,%d,%d%s> %dx%dx%d sk%d\n", cfg, (int)akc, (int)bkc, (int)c_plain, k2 ? ",K2" : "", d.M, d.N, d.K, d.split_k);
     switch (cfg) {
         case 0: return x3_launch_cfg<64, 32, false>(d, akc, bkc, c_plain, k2, stream);
         case 2: return x3_launch_cfg<64, 64, false>(d, akc, bkc, c_plain, k2, stream);

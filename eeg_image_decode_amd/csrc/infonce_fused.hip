@@ -60,12 +60,10 @@ struct if_geom {
     __device__ static __forceinline__ int swz(int row) { return NP == 1 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
-// MODE 0 = forward partials, 1 = gradient tile.  REG: operand tiles staged through registers (global_load_dwordx4 -> ds_write_b128, two LDS stages, the
-// next k-tile's loads in flight under this k-tile's MFMAs) instead of LDS-DMA.  Built to test VERDICT r2's reading that the DMA fill (~45 GB/s per
-// CU) is the limit at N = 2048; MEASURED slower than the 4-stage DMA pipeline (20.8 vs 18.3 us per logits block): one barrier per k-tile with the
-// ds_write burst in front of it costs more than the DMA path's fill rate.  Kept selectable (EEGCLIP_INFONCE_STAGE=reg), not the default.
-typedef unsigned if_u4 __attribute__((ext_vector_type(4)));
-template <int NP, int TM, int MODE, bool REG>
+// MODE 0 = forward partials, 1 = gradient tile.  (Round 3 also built a variant that staged the operand tiles through registers -- global_load_dwordx4
+// -> ds_write_b128, two LDS stages -- to test whether the DMA fill is the limit at N = 2048: measured SLOWER than the 4-stage DMA pipeline, 20.8 vs
+// 18.3 us per logits block; removed in round 4.)
+template <int NP, int TM, int MODE>
 __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale) {
     using Gm = if_geom<NP>;
@@ -138,64 +136,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     //     while the wave issues them).
     constexpr int NSTEP = BK / 16, MPS = WT * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
     const int ktiles = D / BK;
-    if (REG) {
-        constexpr int CPT = TM * NCH / 256;                       // 16-byte chunks per thread and operand-plane tile
-        static_assert(CPT >= 1, "tile too small for 256 staging threads");
-        constexpr int RSTAGE_B = 2 * NP * TILE_B;
-        const unsigned short* const gbase[4] = {P.q_hi + (long long)q0 * D, P.k_hi + (long long)k0r * D, NP == 2 ? P.q_lo + (long long)q0 * D : nullptr,
-                                                NP == 2 ? P.k_lo + (long long)k0r * D : nullptr};
-        if_u4 sreg[2 * NP][CPT];
-        auto gload = [&](int kt) {
-#pragma unroll
-            for (int o = 0; o < 2 * NP; ++o)
-#pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const int c = t + 256 * i, row = c / NCH, pos = c % NCH;
-                    sreg[o][i] = *reinterpret_cast<const if_u4*>(gbase[o] + (long long)row * D + kt * BK + 8 * pos);
-                }
-        };
-        auto lstore = [&](int stg) {
-#pragma unroll
-            for (int o = 0; o < 2 * NP; ++o)
-#pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const int c = t + 256 * i, row = c / NCH, pos = c % NCH;
-                    *reinterpret_cast<if_u4*>(lds + stg * RSTAGE_B + o * TILE_B + row * ROWB + (((pos ^ Gm::swz(row)) & (NCH - 1)) << 4)) = sreg[o][i];
-                }
-        };
-        gload(0);
-        lstore(0);
-        raw_barrier();
-        for (int kt = 0; kt < ktiles; ++kt) {
-            if (kt + 1 < ktiles) gload(kt + 1);                    // in flight under this k-tile's MFMAs
-            const unsigned char* st = lds + (kt & 1) * RSTAGE_B;
-#pragma unroll
-            for (int s_ = 0; s_ < NSTEP; ++s_) {
-                bf16x8 qh[WT], kh[WT], ql[WT], kl[WT];
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    qh[i] = *reinterpret_cast<const bf16x8*>(st + foq[s_][i]);
-                    kh[i] = *reinterpret_cast<const bf16x8*>(st + fok[s_][i]);
-                    if (NP == 2) {
-                        ql[i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s_][i]);
-                        kl[i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s_][i]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < WT; ++j)
-#pragma unroll
-                    for (int i = 0; i < WT; ++i) {
-                        if (NP == 2) {
-                            acc[j][i] = mfma_bf16_32x32x16(kl[j], qh[i], acc[j][i]);
-                            acc[j][i] = mfma_bf16_32x32x16(kh[j], ql[i], acc[j][i]);
-                        }
-                        acc[j][i] = mfma_bf16_32x32x16(kh[j], qh[i], acc[j][i]);
-                    }
-            }
-            if (kt + 1 < ktiles) lstore((kt + 1) & 1);             // the other stage: every wave finished reading it before the previous barrier
-            raw_barrier();
-        }
-    } else {
+    {
     #pragma unroll
         for (int p = 0; p < IF_NS - 1; ++p)
             if (p < ktiles) issue_tile(p);
@@ -469,23 +410,13 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
     return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
 }
 
-#define EEG_IF_GO(NP_, TM_, MODE_, REG_)                                                                                                           \
-    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, REG_>), dim3((unsigned)(nprob * tq * tk)), dim3(256),                                        \
-               (size_t)(REG_ ? 2 : IF_NS) * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
-#define EEG_IF_GO2(NP_, TM_, MODE_)                                       \
-    do {                                                                  \
-        if (reg) EEG_IF_GO(NP_, TM_, MODE_, true);                        \
-        else EEG_IF_GO(NP_, TM_, MODE_, false);                           \
-    } while (0)
+#define EEG_IF_GO2(NP_, TM_, MODE_)                                                                                                                 \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_>), dim3((unsigned)(nprob * tq * tk)), dim3(256), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
+               stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream) {
     const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM;
-    // operand staging: bits 16..17 of `planes` (tuning / tests) 1 = LDS-DMA, 2 = registers; 0 = EEGCLIP_INFONCE_STAGE (dma | reg), default LDS-DMA:
-    // measured at N = 2048 (bench.py secondary, r3): logits block 18.3 us (DMA) vs 20.8 us (registers) in throughput mode, 37.5 vs 41.1 us in parity mode
-    static const int env_stage = getenv("EEGCLIP_INFONCE_STAGE") ? (strcmp(getenv("EEGCLIP_INFONCE_STAGE"), "reg") == 0 ? 2 : 1) : 1;
-    const int stg = (planes >> 16) & 3;
-    const bool reg = (stg ? stg : env_stage) == 2;
     planes &= 0xff;
     if (planes == 1) {
         if (TM == 128) { if (mode == 0) EEG_IF_GO2(1, 128, 0); else EEG_IF_GO2(1, 128, 1); }

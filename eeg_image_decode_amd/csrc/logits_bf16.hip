@@ -5,12 +5,9 @@
 // accumulation and the logits stay fp32 (a bf16 logit of magnitude ~80 would carry an error of 0.3 into the softmax).
 //
 // Tiling: 128 x 128 output tile per 256-thread workgroup (N = 2048: 256 tiles = one per CU), BK = 64, 4 waves in a 2 x 2 grid, each
-// wave 64 x 64 = 4 x 4 MFMA tiles (16 accumulators), two LDS stages: global -> registers of k-tile t+1 are issued before the MFMAs of
-// tile t and written to the other stage after them, one barrier per k-tile.
-// LDS image: [row][80 bf16] (64 + 16 pad = 160 B): the operand fetch "lane (fr, g) <- 8 consecutive k of row fr" is one ds_read_b128
-// whose 16-byte slots (10 fr + g) mod 16 are distinct inside each service group of 16 lanes, and staging stores are 8 lanes = one
-// contiguous 128-byte row.  The product is formed TRANSPOSED (MFMA rows = n) so a lane's 4 accumulator registers are 4 consecutive
-// columns of one output row: 16-byte stores of C.
+// wave 64 x 64 = 4 x 4 MFMA tiles (16 accumulators).  The product is formed TRANSPOSED (MFMA rows = n) so a lane's 4 accumulator registers
+// are 4 consecutive columns of one output row: 16-byte stores of C.  (A register-staged two-stage variant was the first version; the LDS-DMA
+// pipeline below replaced it in round 2 and the old kernel was removed in round 4.)
 #include "eeg_common.h"
 
 #include <stdlib.h>
@@ -23,84 +20,7 @@ constexpr int LB_LD = 80;      // LDS row stride in bf16
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void logits_bf16_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                                           float* __restrict__ C, int M, int N, int K, long long ldc,
-                                                           const float* __restrict__ scale, int gx, int ntiles, int chunk) {
-    EEG_LDS_BASE(unsigned short, lds);
-    constexpr int STAGE = 2 * LB_T * LB_LD;                  // A tile + B tile of one stage (bf16 elements)
-    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);      // XCD-aware tile order (see gemm.hip)
-    if (logical >= ntiles) return;
-    const int m0 = (logical / gx) * LB_T, n0 = (logical % gx) * LB_T;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, g = lane >> 4;
-    // staging: chunk c = t + 256 i (i < 4) of an operand tile: row = c >> 3, 8 bf16 at column 8 (c & 7)
-    const unsigned short* ap[4];
-    const unsigned short* bp[4];
-    int soff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = t + 256 * i, row = c >> 3, kc = 8 * (c & 7);
-        ap[i] = A + (long long)(m0 + row) * K + kc;
-        bp[i] = B + (long long)(n0 + row) * K + kc;
-        soff[i] = row * LB_LD + kc;
-    }
-    u32x4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ap[i] + k0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bp[i] + k0);
-    };
-    auto store_tile = [&](unsigned short* st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(st + soff[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(st + LB_T * LB_LD + soff[i]) = rb[i];
-    };
-    f32x4 acc[4][4];           // acc[j][i]: n tile j (MFMA rows), m tile i (MFMA columns)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int ktiles = K / LB_K;
-    load_tile(0);
-    store_tile(lds);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const unsigned short* as = lds + (kt & 1) * STAGE;
-        const unsigned short* bs = as + LB_T * LB_LD;
-        if (kt + 1 < ktiles) load_tile((kt + 1) * LB_K);
-#pragma unroll
-        for (int s = 0; s < LB_K / 32; ++s) {
-            bf16x8 av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + (wr * 64 + 16 * i + fr) * LB_LD + 32 * s + 8 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(bs + (wc * 64 + 16 * j + fr) * LB_LD + 32 * s + 8 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = mfma_bf16_16x16x32(bv[j], av[i], acc[j][i]);      // D[n = 16j + 4g + r][m = 16i + fr]
-        }
-        if (kt + 1 < ktiles) store_tile(lds + ((kt + 1) & 1) * STAGE);      // the other stage: last read one iteration ago, fenced by the barrier below
-        __syncthreads();
-    }
-    const float s = scale ? *scale : 1.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + 16 * i + fr;
-        float* cr = C + (long long)m * ldc + n0 + wc * 64 + 4 * g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc[j][i];
-            *reinterpret_cast<f32x4*>(cr + 16 * j) = f32x4{v[0] * s, v[1] * s, v[2] * s, v[3] * s};
-        }
-    }
-}
-
-// ---- LDS-DMA variant: the operand tiles go global -> LDS without touching VGPRs, NS stages deep -------------------------------------------
+// ---- the operand tiles go global -> LDS by LDS-DMA, without touching VGPRs, NS stages deep -------------------------------------------
 // Stage image: [row][64 bf16] = 128-byte rows, NO padding (an LDS-DMA instruction deposits wave-uniform base + 16 * lane: 8 rows of 128
 // contiguous bytes); bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index with (row & 7), applied on the SOURCE
 // address of the DMA and again on the ds_read address (same involution on both sides): the 16 lanes of every ds_read_b128 service group
@@ -223,15 +143,8 @@ extern "C" int eegclip_logits_bf16(const void* a, const void* b, float* c, int M
     if (M % LB_T || N % LB_T || K % LB_K || (ldc & 3)) return EEGCLIP_EINVAL;          // whole tiles only: ragged sizes take the fp32 GEMM
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) return EEGCLIP_EALIGN;
     const int gx = N / LB_T, ntiles = gx * (M / LB_T), chunk = (ntiles + 7) / 8;
-    static const int variant = getenv("EEGCLIP_LOGITS_VARIANT") ? atoi(getenv("EEGCLIP_LOGITS_VARIANT")) : 1;      // tuning aid: 0 = register staged
-    if (variant == 0) {
-        const size_t lds = (size_t)2 * 2 * LB_T * LB_LD * sizeof(unsigned short);      // 80 KB
-        EEG_LAUNCH(logits_bf16_kernel, dim3(8 * chunk), dim3(256), lds, stream, static_cast<const unsigned short*>(a),
-                   static_cast<const unsigned short*>(b), c, M, N, K, ldc, scale, gx, ntiles, chunk);
-    } else {
-        const size_t lds = (size_t)LD_NS * LD_STAGE * sizeof(unsigned short);          // 128 KB
-        EEG_LAUNCH(logits_bf16_dma_kernel, dim3(8 * chunk), dim3(256), lds, stream, static_cast<const unsigned short*>(a),
-                   static_cast<const unsigned short*>(b), c, M, N, K, ldc, scale, gx, ntiles, chunk);
-    }
+    const size_t lds = (size_t)LD_NS * LD_STAGE * sizeof(unsigned short);              // 128 KB
+    EEG_LAUNCH(logits_bf16_dma_kernel, dim3(8 * chunk), dim3(256), lds, stream, static_cast<const unsigned short*>(a),
+               static_cast<const unsigned short*>(b), c, M, N, K, ldc, scale, gx, ntiles, chunk);
     return (int)hipGetLastError();
 }

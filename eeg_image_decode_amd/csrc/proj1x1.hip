@@ -180,10 +180,9 @@ extern "C" int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const fl
     if (!dfeat || !z2 || !W || !y2 || !mean || !rstd || !gamma || !beta || !dz2 || !dW || !dbias || !sums || B < 1 || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7u)) return EEGCLIP_EALIGN;
-    static const int forced = getenv("EEGCLIP_PJ_SPW") ? atoi(getenv("EEGCLIP_PJ_SPW")) : 0;     // tuning aid
     // samples per workgroup: with a workspace one (the per-sample work is ~11 us of LDS-bound arithmetic: as parallel as possible); with atomics
     // fewer, fatter ones once the grid still fills the chip
-    const int spw = forced > 0 ? forced : (workspace ? 1 : (B >= 512 ? 4 : (B >= 128 ? 2 : 1)));
+    const int spw = workspace ? 1 : (B >= 512 ? 4 : (B >= 128 ? 2 : 1));
     const size_t lds = (PJ_N + PJ_W * PJ_LW + PJ_C * PJ_LW + 2 * PJ_N) * sizeof(float);
     const int nwg = (B + spw - 1) / spw;
     double* parts = reinterpret_cast<double*>(workspace);

@@ -29,13 +29,11 @@ namespace eeg {
 constexpr int SCF_KC = 128;
 constexpr int SCF_KS = 4;
 constexpr int SCF_LZ = 52;             // activation tile row stride
-template <int dbg>
 __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
                                                          const float* __restrict__ bs, float* __restrict__ y2, float* __restrict__ slabs, int B, int H,
                                                          int kper) {
-    // dbg (template; EEGCLIP_SCF_DEBUG selects an instantiation; timing ablation only -- results are wrong with any bit set): 1 no MFMAs, 2 no ELU,
-    // 4 no y1 loads, 8 no weight loads, 32 no LDS stores of the activation tile.  Measured at B = 256 (tools/bench_sconv_fwd.py, us incl. the 5 us
-    // statistics kernel): full 60, no MFMA 42, no loads 46, no LDS stores 46 -- the phases of a chunk (convert + LDS stores | MFMAs + LDS reads | load
+    // Timing ablation of round 3 (pieces switched off through a template parameter, since removed; B = 256, us incl. the 5 us statistics kernel):
+    // full 60, no MFMA 42, no loads 46, no LDS stores 46 -- the phases of a chunk (convert + LDS stores | MFMAs + LDS reads | load
     // latency) add up instead of overlapping: 146 VGPRs + 64 AGPRs leave 2 workgroups per CU.  (Leaving out the epilogue is NOT a valid ablation:
     // the compiler then drops the MFMAs of the unused accumulators.)  A second activation tile (chunk k+1 converted and stored in the barrier interval
     // of chunk k's MFMAs, one barrier per chunk) measured SLOWER: 68 vs 58 us (53 KB of LDS per workgroup).
@@ -70,12 +68,12 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int o = 16 * i + fr, k = k0 + 32 * wv + 16 * h + 4 * g;
-                va[i][h] = (o < SC_C && k < kend && !(dbg & 8)) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
+                va[i][h] = (o < SC_C && k < kend) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
             }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int e = 4 * (t + 256 * j), kk = e / SC_W;                          // 128 rows x 9 float4
-            vy[j] = (e < SCF_KC * SC_W && k0 + kk < kend && !(dbg & 4)) ? *reinterpret_cast<const f32x4*>(yb + (long long)k0 * SC_W + e) : zero4v;
+            vy[j] = (e < SCF_KC * SC_W && k0 + kk < kend) ? *reinterpret_cast<const f32x4*>(yb + (long long)k0 * SC_W + e) : zero4v;
         }
     };
     auto store_chunk = [&](int k0) {
@@ -88,9 +86,9 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
                     const int c = (k0 + kk) / H;
                     const float sc = aff[c], sh = aff[SC_C + c];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) z[q] = (dbg & 2) ? vy[j][q] * sc + sh : elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
+                    for (int q = 0; q < 4; ++q) z[q] = elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
                 }
-                if (!(dbg & 32)) *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
+                *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
             }
         }
     };
@@ -117,8 +115,7 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        if (dbg & 1) acc[i][j][0] += a[i][h][s4] * bv[j];
-                        else acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+                        acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
                     }
             }
     }
@@ -143,157 +140,6 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr];
     };
     __syncthreads();                          // every wave is done with the operand tiles: LDS becomes reduction scratch
-    if (wv >= 2) put(red + (wv - 2) * SC_OP * RLD);
-    __syncthreads();
-    if (wv < 2) add(red + wv * SC_OP * RLD);
-    __syncthreads();
-    if (wv == 1) put(red);
-    __syncthreads();
-    if (wv == 0) {
-        add(red);
-        // slabs: this K slice's partial tile as plain stores, summed by sconv_merge_stats2_kernel -- the 1440 device-scope float atomics per
-        // workgroup (they execute at the memory side on this multi-XCD part) were 33 of the kernel's 60 us
-        float* yo = slabs ? slabs + ((long long)blockIdx.y * B + b) * SC_C * SC_W : y2 + (long long)b * SC_C * SC_W;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * i + 4 * g + r, w = 16 * j + fr;
-                    if (o < SC_C && w < SC_W) {
-                        const float v = acc[i][j][r] + (blockIdx.y == 0 ? bs[o] : 0.f);
-                        if (slabs) yo[o * SC_W + w] = v;
-                        else atomicAdd(yo + o * SC_W + w, v);
-                    }
-                }
-    }
-}
-
-// forward with split-bf16 products (weights pre-split into bf16 planes [40][ldp], k contiguous, by eegclip_split_rows): same decomposition
-// (workgroup = sample x K slice, 128-k chunks, wave v owns k = 32v .. 32v+31 of a chunk = ONE 16x16x32 k-step), but 27 MFMAs of 16 cycles per
-// chunk and wave instead of 72 exact-fp32 ones of 32 cycles.  The activation operand needs 8 consecutive k per lane at a fixed position w while
-// y1 is [k][w]: a thread loads a 4 k x 4 w block (four 16-byte loads), evaluates ELU(BN(.)), splits, and writes 4 k of one w as ONE 8-byte LDS
-// store per plane into z^T [48 w][128 k] (row stride 272 bytes: the 16 rows of a fragment read are 4 banks apart).  Weight fragments come
-// straight from global memory (16 bytes = 8 k of one output channel per lane, plane and tile).
-constexpr int SFX_RS = 272;
-constexpr int SFX_PLANE = SC_OP * SFX_RS;
-__global__ __launch_bounds__(256, 3) void sconv_fwd_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const unsigned short* __restrict__ wp_hi,
-                                                            const unsigned short* __restrict__ wp_lo, long long ldp, const float* __restrict__ bs,
-                                                            float* __restrict__ y2, float* __restrict__ slabs, int B, int H, int kper) {
-    EEG_LDS_BASE(float, lds);
-    unsigned char* zp = reinterpret_cast<unsigned char*>(lds);     // planes hi | lo of z1^T[w][k0 + kk]
-    float* aff = lds + 2 * SFX_PLANE / 4;                           // [2][40]
-    float* red = lds;                                               // 2 x [48][52] reduction scratch, aliases the planes after the last chunk
-    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x;
-    const int K = SC_C * H;
-    const int kbeg = blockIdx.y * kper, kend = kbeg + kper < K ? kbeg + kper : K;
-    if (t < SC_C) {
-        const float sc = bn.gamma[t] * bn.rstd[t];
-        aff[t] = sc;
-        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
-    }
-    for (int i = t; i < 2 * SFX_PLANE / 16; i += 256) reinterpret_cast<f32x4*>(zp)[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // rows w >= 36 stay zero
-    f32x4 acc[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* yb = y1 + (long long)b * K * SC_W;
-    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wh[3], wl[3];
-    f32x4 vy[2][4];
-    auto load_chunk = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int o = 16 * i + fr < SC_C ? 16 * i + fr : SC_C - 1;       // (rows 40..47 of the product are never stored)
-            const long long off = (long long)o * ldp + k0 + 32 * wv + 8 * g;  // k beyond kend: multiplied by the zeros staged on the activation side
-            wh[i] = *reinterpret_cast<const bf16x8*>(wp_hi + off);
-            wl[i] = *reinterpret_cast<const bf16x8*>(wp_lo + off);
-        }
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int u = t + 256 * ps, kq = u / 9, wq = u % 9;              // 32 k-quads x 9 w-quads = 288 blocks of 4 k x 4 w
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 4 * kq + r;
-                vy[ps][r] = (u < 288 && k < kend) ? *reinterpret_cast<const f32x4*>(yb + (long long)k * SC_W + 4 * wq) : zero4v;
-            }
-        }
-    };
-    auto store_chunk = [&](int k0) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int u = t + 256 * ps, kq = u / 9, wq = u % 9;
-            if (u >= 288) continue;
-            f32x4 z[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 4 * kq + r;
-                z[r] = zero4v;
-                if (k < kend) {
-                    const int c = k / H;
-                    const float sc = aff[c], sh = aff[SC_C + c];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) z[r][q] = elu1_fast(vy[ps][r][q] * sc + sh);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32x2_t hi, lo;
-                x3_split4(z[0][q], z[1][q], z[2][q], z[3][q], hi, lo);
-                unsigned char* dst = zp + (4 * wq + q) * SFX_RS + 8 * kq;
-                *reinterpret_cast<u32x2_t*>(dst) = hi;
-                *reinterpret_cast<u32x2_t*>(dst + SFX_PLANE) = lo;
-            }
-        }
-    };
-    if (kbeg < kend) load_chunk(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += SCF_KC) {
-        __syncthreads();
-        store_chunk(k0);
-        bf16x8 ah[3], al[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { ah[i] = wh[i]; al[i] = wl[i]; }
-        __syncthreads();
-        if (k0 + SCF_KC < kend) load_chunk(k0 + SCF_KC);
-        bf16x8 bh[3], bl[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const unsigned char* src = zp + (16 * j + fr) * SFX_RS + 2 * (32 * wv + 8 * g);
-            bh[j] = *reinterpret_cast<const bf16x8*>(src);
-            bl[j] = *reinterpret_cast<const bf16x8*>(src + SFX_PLANE);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {                     // D[o = 16i + 4g + r][w = 16j + fr]
-                acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
-                acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);
-                acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
-            }
-    }
-    // cross-wave sum of the four k-partial accumulator sets (as in sconv_fwd_kernel)
-    constexpr int RLD = 52;
-    auto put = [&](float* reg) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr] = acc[i][j][r];
-    };
-    auto add = [&](const float* reg) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr];
-    };
-    __syncthreads();
     if (wv >= 2) put(red + (wv - 2) * SC_OP * RLD);
     __syncthreads();
     if (wv < 2) add(red + wv * SC_OP * RLD);
@@ -567,211 +413,6 @@ __global__ __launch_bounds__(256, 3) void sconv_bwd_w_x3_kernel(const float* __r
         }
 }
 
-// weight gradient AND the BatchNorm1-backward statistics from ONE pass over y1 (the separate statistics pass, sconv_bwd_x_kernel<false>, read the
-// 93 MB tensor a second time).  Same decomposition as the kernel above (workgroup = slab of NS columns n = (c,h) x a group of samples), but y1 is
-// loaded in the layout of the accumulators of  dz^T[w][n] = sum_o dy2^T[w][o] Ws^T[n][o]  -- lane (fr, g), tile (j, tw) holds the 4 positions
-// w = 16 tw + 4 g .. + 3 of column n = 16 NT wv + 16 j + fr -- so the same registers feed the z1 planes of the weight gradient (one 8-byte LDS store
-// per plane, as before) and, after the K = 40 contraction on the matrix cores, da = dz * ELU'(u) and x_hat for  S1[c] = sum da, S2[c] = sum da x_hat.
-// Operands of the second product: dy2^T as planes [48 w][64 o] (staged with 2-byte stores from the same dy2 registers), Ws^T planes [(c,h)][64 o]
-// (eegclip_split_rows(transpose)): the wave's 2 NT fragments per plane live in registers for the whole launch.
-template <int NS>
-__global__ __launch_bounds__(256, 2) void sconv_bwd_ws_x3_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ dy2,
-                                                                 const unsigned short* __restrict__ wt_hi, const unsigned short* __restrict__ wt_lo,
-                                                                 float* __restrict__ partials, double* __restrict__ stat_parts, int B, int H, int bgroups) {
-    constexpr int NT = NS / 64;
-    constexpr int ZPL = NS * SWX_RS, DPL = SC_OP * SWX_RS;       // bytes per plane
-    EEG_LDS_BASE(float, lds);
-    unsigned char* zp = reinterpret_cast<unsigned char*>(lds);   // z1 planes hi | lo     [NS n][64 w]
-    unsigned char* dp = zp + 2 * ZPL;                            // dy2 planes hi | lo    [48 o][64 w]
-    unsigned char* tp = dp + 2 * DPL;                            // dy2^T planes hi | lo  [48 w][64 o]
-    float* aff = reinterpret_cast<float*>(tp + 2 * DPL);         // [4][40]  sc | sh | mean | rstd
-    float* sl = aff + 4 * SC_C;                                  // [2][40]  per-workgroup channel sums
-    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int K = SC_C * H;
-    const int n0 = blockIdx.x * NS, bg = blockIdx.y;
-    if (t < SC_C) {
-        const float sc = bn.gamma[t] * bn.rstd[t];
-        aff[t] = sc;
-        aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
-        aff[2 * SC_C + t] = bn.mean[t];
-        aff[3 * SC_C + t] = bn.rstd[t];
-    }
-    if (t < 2 * SC_C) sl[t] = 0.f;
-    for (int i = t; i < (2 * ZPL + 4 * DPL) / 16; i += 256) reinterpret_cast<f32x4*>(zp)[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // padding rows / columns: zero for good
-    const int ncols = K - n0 < NS ? K - n0 : NS;
-    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    const bf16x8 zero8{0, 0, 0, 0, 0, 0, 0, 0};
-    // this lane's columns, their Ws^T fragments and BatchNorm constants
-    int nl[NT];
-    bool nok[NT];
-    bf16x8 wh[NT][2], wl[NT][2];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        nl[j] = 16 * NT * wv + 16 * j + fr;
-        nok[j] = nl[j] < ncols;
-        const long long row = (long long)(n0 + (nok[j] ? nl[j] : 0)) * 64;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            wh[j][s2] = nok[j] ? *reinterpret_cast<const bf16x8*>(wt_hi + row + 32 * s2 + 8 * g) : zero8;
-            wl[j][s2] = nok[j] ? *reinterpret_cast<const bf16x8*>(wt_lo + row + 32 * s2 + 8 * g) : zero8;
-        }
-    }
-    __syncthreads();
-    float csc[NT], csh[NT], cmu[NT], crs[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int c = nok[j] ? (n0 + nl[j]) / H : 0;
-        csc[j] = aff[c]; csh[j] = aff[SC_C + c]; cmu[j] = aff[2 * SC_C + c]; crs[j] = aff[3 * SC_C + c];
-    }
-    f32x4 acc[3][NT];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = zero4v;
-    float s1[NT], s2s[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2s[j] = 0.f; }
-    f32x4 vn[NT][3], vd[2];
-    auto load_sample = [&](int b) {
-        const float* src = y1 + ((long long)b * K + n0) * SC_W;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int tw = 0; tw < 3; ++tw) {
-                const int w = 16 * tw + 4 * g;                 // 36 % 4 == 0: a quad is all in or all out
-                vn[j][tw] = (nok[j] && w < SC_W) ? *reinterpret_cast<const f32x4*>(src + (long long)nl[j] * SC_W + w) : zero4v;
-            }
-        const float* dsrc = dy2 + (long long)b * SC_C * SC_W;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = 4 * (t + 256 * j);
-            vd[j] = e < SC_C * SC_W ? *reinterpret_cast<const f32x4*>(dsrc + e) : zero4v;
-        }
-    };
-    if (bg < B) load_sample(bg);
-    for (int b = bg; b < B; b += bgroups) {
-        f32x4 yv[NT][3];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int tw = 0; tw < 3; ++tw) {
-                yv[j][tw] = vn[j][tw];
-                const int w = 16 * tw + 4 * g;
-                if (w >= SC_W) continue;
-                f32x4 z = zero4v;
-                if (nok[j]) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) z[q] = elu1_fast(yv[j][tw][q] * csc[j] + csh[j]);
-                }
-                u32x2_t hi, lo;
-                x3_split4(z[0], z[1], z[2], z[3], hi, lo);
-                *reinterpret_cast<u32x2_t*>(zp + nl[j] * SWX_RS + 2 * w) = hi;
-                *reinterpret_cast<u32x2_t*>(zp + ZPL + nl[j] * SWX_RS + 2 * w) = lo;
-            }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = 4 * (t + 256 * j), o = e / SC_W, w = e % SC_W;
-            if (e >= SC_C * SC_W) continue;
-            u32x2_t hi, lo;
-            x3_split4(vd[j][0], vd[j][1], vd[j][2], vd[j][3], hi, lo);
-            *reinterpret_cast<u32x2_t*>(dp + o * SWX_RS + 2 * w) = hi;
-            *reinterpret_cast<u32x2_t*>(dp + DPL + o * SWX_RS + 2 * w) = lo;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                          // the transposed planes: 4 rows w, one column o
-                const unsigned hq = (q & 1) ? (hi[q >> 1] >> 16) : (hi[q >> 1] & 0xffffu), lq = (q & 1) ? (lo[q >> 1] >> 16) : (lo[q >> 1] & 0xffffu);
-                *reinterpret_cast<unsigned short*>(tp + (w + q) * SWX_RS + 2 * o) = (unsigned short)hq;
-                *reinterpret_cast<unsigned short*>(tp + DPL + (w + q) * SWX_RS + 2 * o) = (unsigned short)lq;
-            }
-        }
-        __syncthreads();
-        if (b + bgroups < B) load_sample(b + bgroups);
-        // (1) dWs[o][n] += sum_w dy2[o][w] z1[n][w]
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 ah[3], al[3], bh[NT], bl[NT];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const unsigned char* src = dp + (16 * i + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
-                ah[i] = *reinterpret_cast<const bf16x8*>(src);
-                al[i] = *reinterpret_cast<const bf16x8*>(src + DPL);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const unsigned char* src = zp + (16 * NT * wv + 16 * j + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
-                bh[j] = *reinterpret_cast<const bf16x8*>(src);
-                bl[j] = *reinterpret_cast<const bf16x8*>(src + ZPL);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {                // D[o = 16i + 4g + r][n = n0 + 16 NT wv + 16j + fr]
-                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
-                }
-        }
-        // (2) dz^T[w][n] = sum_o dy2^T[w][o] Ws^T[n][o];  da = dz * ELU'(u);  S1 += da, S2 += da * x_hat
-#pragma unroll
-        for (int tw = 0; tw < 3; ++tw) {
-            bf16x8 th[2], tl[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const unsigned char* src = tp + (16 * tw + fr) * SWX_RS + 2 * (32 * s2 + 8 * g);
-                th[s2] = *reinterpret_cast<const bf16x8*>(src);
-                tl[s2] = *reinterpret_cast<const bf16x8*>(src + DPL);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                f32x4 dz = zero4v;                              // D[w = 16 tw + 4g + r][n = column j of this lane]
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    dz = mfma_bf16_16x16x32(th[s2], wl[j][s2], dz);
-                    dz = mfma_bf16_16x16x32(tl[s2], wh[j][s2], dz);
-                    dz = mfma_bf16_16x16x32(th[s2], wh[j][s2], dz);
-                }
-                if (nok[j] && 16 * tw + 4 * g < SC_W) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float y = yv[j][tw][r];
-                        const float u = y * csc[j] + csh[j];
-                        const float da = u > 0.f ? dz[r] : dz[r] * fast_exp(u);
-                        s1[j] += da;
-                        s2s[j] += da * ((y - cmu[j]) * crs[j]);
-                    }
-                }
-            }
-        }
-    }
-    float* out = partials + (long long)bg * SC_C * K;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + 16 * NT * wv + 16 * j + fr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * i + 4 * g + r;
-                if (o < SC_C && n < K) out[(long long)o * K + n] = acc[i][j][r];
-            }
-        }
-    // channel sums: the 4 lane groups of a column, then the columns of a channel (LDS adds: <= 2 NT per lane, once per launch)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        float a = s1[j], c2 = s2s[j];
-        a += __shfl_xor(a, 16);  c2 += __shfl_xor(c2, 16);
-        a += __shfl_xor(a, 32);  c2 += __shfl_xor(c2, 32);
-        if (g == 0 && nok[j]) {
-            const int c = (n0 + nl[j]) / H;
-            atomicAdd(sl + c, a);
-            atomicAdd(sl + SC_C + c, c2);
-        }
-    }
-    __syncthreads();
-    if (t < 2 * SC_C) stat_parts[((long long)bg * gridDim.x + blockIdx.x) * (2 * SC_C) + t] = (double)sl[t];
-}
-
 __global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -969,54 +610,30 @@ static int sc_check(int B, int H) { return (B < 1 || H < 1 || H > 64) ? EEGCLIP_
 extern "C" long long eegclip_sconv_fwd_workspace_floats(int B) { return B < 1 ? 0 : (long long)SCF_KS * B * SC_C * SC_W; }
 
 extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                                 const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
-                                 int y2_is_zero, float* workspace, void* stream) {
+                                 const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, float* workspace, void* stream) {
     if (int rc = sc_check(B, H)) return rc;
     if (!y1 || !mean || !rstd || !gamma || !beta || !Ws || !bs || !y2) return EEGCLIP_EINVAL;
-    if ((Ws_hi == nullptr) != (Ws_lo == nullptr)) return EEGCLIP_EINVAL;
     if (!sc_aligned16(y1) || !sc_aligned16(Ws)) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
     const int K = SC_C * H;
     // the K slices add their partial tiles into y2 with atomics: it must start at zero (callers that clear it together with their other
     // accumulators pass y2_is_zero != 0 and save the extra memset launch)
     if (!y2_is_zero && !workspace) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
-    if (Ws_hi) {
-        // a chunk may run up to 127 k past the end of its slice (zeros on the activation side): the planes must be readable there
-        if (ld_planes < K + SCF_KC || (ld_planes & 7) != 0) return EEGCLIP_EINVAL;
-        if (!sc_aligned16(Ws_hi) || !sc_aligned16(Ws_lo)) return EEGCLIP_EALIGN;
-        const int kper = ((K + SCF_KS - 1) / SCF_KS + 7) & ~7;                 // slices start on 16-byte boundaries of the bf16 planes
-        const size_t lds = 2 * SFX_PLANE + 2 * SC_C * sizeof(float);
-        EEG_LAUNCH(sconv_fwd_x3_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, (const unsigned short*)Ws_hi, (const unsigned short*)Ws_lo,
-                   ld_planes, bs, y2, workspace, B, H, kper);
-    } else {
+    {
         const int kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;                 // slices start on 16-byte boundaries of both operands
         const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
-        const int dbg = getenv("EEGCLIP_SCF_DEBUG") ? atoi(getenv("EEGCLIP_SCF_DEBUG")) : 0;          // diagnosis only (see the kernel)
-#define EEG_SCF_GO(D) EEG_LAUNCH(sconv_fwd_kernel<D>, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, workspace, B, H, kper)
-        switch (dbg) {
-            case 1: EEG_SCF_GO(1); break;
-            case 2: EEG_SCF_GO(2); break;
-            case 12: EEG_SCF_GO(12); break;
-            case 32: EEG_SCF_GO(32); break;
-            case 46: EEG_SCF_GO(46); break;
-            default: EEG_SCF_GO(0); break;
-        }
-#undef EEG_SCF_GO
+        EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, workspace, B, H, kper);
     }
     if (sums2 || workspace)
         EEG_LAUNCH(sconv_merge_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, (const float*)workspace, SCF_KS, y2, sums2, B);
     return (int)hipGetLastError();
 }
 
-// slab width / sample groups (tuning aids: EEGCLIP_SCW_NS = 128 | 256, EEGCLIP_SCW_G)
-static int scw_ns() {
-    static const int v = getenv("EEGCLIP_SCW_NS") ? atoi(getenv("EEGCLIP_SCW_NS")) : 128;
-    return v == 256 ? 256 : 128;
-}
+// slab width 128 k (a 256-wide slab measured no faster and its split-bf16 instantiation spilled 225 registers); ~4 workgroups per CU
+constexpr int SCW_NS = 128;
 static int scw_groups(int B, int H) {
-    static const int forced = getenv("EEGCLIP_SCW_G") ? atoi(getenv("EEGCLIP_SCW_G")) : 0;
-    const int slabs = (SC_C * H + scw_ns() - 1) / scw_ns();
-    int gcap = forced > 0 ? forced : 1024 / slabs;             // ~4 workgroups per CU
+    const int slabs = (SC_C * H + SCW_NS - 1) / SCW_NS;
+    int gcap = 1024 / slabs;
     if (gcap < 1) gcap = 1;
     return B < gcap ? B : gcap;
 }
@@ -1029,16 +646,14 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
     if (precision != EEGCLIP_PREC_F32 && precision != EEGCLIP_PREC_BF16X3) return EEGCLIP_EINVAL;
     if (!sc_aligned16(y1) || (precision == EEGCLIP_PREC_BF16X3 && !sc_aligned16(dy2))) return EEGCLIP_EALIGN;
     const bn_affine bn{mean, rstd, gamma, beta};
-    const int K = SC_C * H, groups = scw_groups(B, H), ns = scw_ns();
+    const int K = SC_C * H, groups = scw_groups(B, H), ns = SCW_NS;
     const dim3 grid((K + ns - 1) / ns, groups);
     if (precision == EEGCLIP_PREC_BF16X3) {
         const size_t lds = (size_t)2 * (ns + SC_OP) * SWX_RS + 2 * SC_C * sizeof(float);
-        if (ns == 256) EEG_LAUNCH(sconv_bwd_w_x3_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
-        else           EEG_LAUNCH(sconv_bwd_w_x3_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+        EEG_LAUNCH(sconv_bwd_w_x3_kernel<SCW_NS>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
     } else {
         const size_t lds = (ns * SCW_L + SC_OP * SCW_L + 2 * SC_C) * sizeof(float);
-        if (ns == 256) EEG_LAUNCH(sconv_bwd_w_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
-        else           EEG_LAUNCH(sconv_bwd_w_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
+        EEG_LAUNCH(sconv_bwd_w_kernel<SCW_NS>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
     }
     const long long n = (long long)SC_C * K;
     EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256), groups >= 16 ? 4 : 1), dim3(256), 0, stream, workspace, groups, n, dWs);
@@ -1046,32 +661,6 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
 }
 
 static bool scx_planes_ok(const void* hi, const void* lo) { return hi && lo && sc_aligned16(hi) && sc_aligned16(lo); }
-
-extern "C" long long eegclip_sconv_bwd_w_stats_workspace_floats(int B, int H) {
-    if (B < 1 || H < 1 || H > 64) return 0;
-    return 2LL * ((SC_C * H + scw_ns() - 1) / scw_ns()) * scw_groups(B, H) * 2 * SC_C;          // (doubles, in floats)
-}
-
-extern "C" int eegclip_sconv_bwd_w_stats(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
-                                         const void* WsT_hi, const void* WsT_lo, float* dWs, float* workspace, double* sums, float* stats_workspace,
-                                         int B, int H, void* stream) {
-    if (int rc = sc_check(B, H)) return rc;
-    if (!y1 || !mean || !rstd || !gamma || !beta || !dy2 || !WsT_hi || !WsT_lo || !dWs || !workspace || !sums || !stats_workspace) return EEGCLIP_EINVAL;
-    if (!sc_aligned16(y1) || !sc_aligned16(dy2) || !sc_aligned16(WsT_hi) || !sc_aligned16(WsT_lo) || (reinterpret_cast<uintptr_t>(stats_workspace) & 7u))
-        return EEGCLIP_EALIGN;
-    const bn_affine bn{mean, rstd, gamma, beta};
-    const int K = SC_C * H, groups = scw_groups(B, H), ns = scw_ns();
-    const dim3 grid((K + ns - 1) / ns, groups);
-    double* parts = reinterpret_cast<double*>(stats_workspace);
-    const size_t lds = (size_t)2 * ns * SWX_RS + 4 * SC_OP * SWX_RS + 6 * SC_C * sizeof(float);
-    const unsigned short *wh = (const unsigned short*)WsT_hi, *wl = (const unsigned short*)WsT_lo;
-    if (ns == 256) EEG_LAUNCH(sconv_bwd_ws_x3_kernel<256>, grid, dim3(256), lds, stream, y1, bn, dy2, wh, wl, workspace, parts, B, H, groups);
-    else           EEG_LAUNCH(sconv_bwd_ws_x3_kernel<128>, grid, dim3(256), lds, stream, y1, bn, dy2, wh, wl, workspace, parts, B, H, groups);
-    const long long n = (long long)SC_C * K;
-    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256), groups >= 16 ? 4 : 1), dim3(256), 0, stream, workspace, groups, n, dWs);
-    EEG_COLSUM_F64((const double*)parts, (int)(grid.x * grid.y), 2 * SC_C, sums, stream);
-    return (int)hipGetLastError();
-}
 
 extern "C" long long eegclip_sconv_bwd_x_stats_workspace_floats(int B) { return B < 1 ? 0 : 2LL * B * SCX_GY * 2 * SC_C; }     // (doubles, in floats)
 

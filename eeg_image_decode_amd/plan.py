@@ -22,10 +22,10 @@ D = _abi.dim
 
 # split-K through per-slice slabs + an ordered reduction instead of atomics on C: run-to-run bit-reproducible weight gradients.  Measured equal in
 # time at the step's split (256 x 250 x 16384 / 32 slices: 31.4 us atomics, 32.3 us slabs; tools/wgrad_probe.py), so it is opt-in.
-_SPLITK_WORKSPACE = os.environ.get("EEGCLIP_SPLITK_WORKSPACE", "0") == "1"
+_SPLITK_WORKSPACE = False
 
 
-_SIDE_PRIORITY = int(os.environ.get("EEGCLIP_SIDE_PRIORITY", "0"))     # HIP stream priority of a plan's second stream (tuning aid)
+_SIDE_PRIORITY = 0                                                    # HIP stream priority of a plan's second stream (a higher one measured no gain)
 
 
 def default_gemm_precision():
@@ -80,14 +80,12 @@ class Plan:
         return d
 
     def desc(self, M, N, K, A, Am, Ak, B, Bk, Bn, C, Cm, Cn, *, Cpre=None, bias_n=None, bias_m=None, R=None, Rm=None, Rn=None,
-             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None, planes=None):
+             alpha=1.0, accumulate=0, act=0, drop_p=0.0, drop_site=0, split_k=1, rowsum_a=None, precision=None):
         """a GEMM descriptor owned by the plan but not (yet) an op: member template of a grouped launch"""
         d = _abi.GemmDesc(M=M, N=N, K=K, A=A, Am=Am, Ak=Ak, B=B, Bk=Bk, Bn=Bn, C=C, Cm=Cm, Cn=Cn, Cpre=Cpre, bias_n=bias_n,
                           bias_m=bias_m, R=R, Rm=Rm or D(0), Rn=Rn or D(0), alpha=alpha, accumulate=accumulate, act=act,
                           drop_p=drop_p, seed=0, drop_site=drop_site, split_k=split_k, rowsum_a=rowsum_a,
                           precision=self.precision if precision is None else precision)
-        if planes is not None:                                   # B pre-split into bf16 planes (hi pointer, lo pointer, elements per row)
-            d.B_hi, d.B_lo, d.ldb_planes = planes
         self._keep.append(d)
         return d
 

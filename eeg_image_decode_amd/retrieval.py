@@ -87,7 +87,7 @@ def _side_stream(device):
     """second HIP stream per device for work nobody waits for inside the step (the running train-accuracy readout)"""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("EEGCLIP_ACC_PRIORITY", "0")))
+        _SIDE[key] = torch.cuda.Stream(device=device, priority=0)
     return _SIDE[key]
 
 

@@ -88,11 +88,6 @@ typedef struct {
     float* rowsum_a;      /* [M] or NULL: += sum_k A[m,k] */
     int precision;        /* EEGCLIP_PREC_* (0 = exact fp32 products); bits 8..15: BF16X3 tile configuration, 0 = chosen by the library,
                              1..6 = 64x64x32 | same, two LDS images | 64x64x64 | same, two images | 128x128x32 | same, two images (tuning aid) */
-    const void* B_hi;     /* optional (BF16X3, k-contiguous A): B already split into bf16 planes by eegclip_split_rows -- row n of each plane = B[:, n]
-                             (N rows of ldb_planes elements, k contiguous, zero padded to a multiple of 64).  Weights are split once per optimizer
-                             step instead of once per tile that stages them; B must still be valid (other operand classes fall back to it). */
-    const void* B_lo;
-    long long ldb_planes;
     float* workspace;     /* optional split-K scratch (see above); NULL = atomics */
     long long workspace_bytes;
 } eegclip_gemm_desc;
@@ -298,11 +293,8 @@ int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx, long long
  *               sums between the two calls and pass the global count.  sconv_fwd: with `workspace` (eegclip_sconv_fwd_workspace_floats(B) floats)
  * the K-slice partial tiles go to slabs as plain stores and the BatchNorm2-statistics kernel of the same call sums them into y2; workspace = NULL:
  * they are added into y2 with atomics (y2_is_zero = 0 lets the call clear y2 itself, != 0 says the caller already did). */
-/* Ws_hi / Ws_lo (both or neither) + ld_planes: bf16 planes of Ws as eegclip_split_rows{src = Ws, rows = 40, cols = 40 H, ld_src = 40 H,
- * ld_out = ld_planes} writes them, ld_planes >= 40 H + 128 and a multiple of 8, 16-byte aligned: split-bf16 products instead of exact fp32. */
 int eegclip_sconv_fwd(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* Ws,
-                      const void* Ws_hi, const void* Ws_lo, long long ld_planes, const float* bs, float* y2, double* sums2, int B, int H,
-                      int y2_is_zero, float* workspace, void* stream);
+                      const float* bs, float* y2, double* sums2, int B, int H, int y2_is_zero, float* workspace, void* stream);
 long long eegclip_sconv_fwd_workspace_floats(int B);
 long long eegclip_sconv_bwd_w_workspace_floats(int B, int H);
 /* precision: EEGCLIP_PREC_F32 (exact fp32 products) | EEGCLIP_PREC_BF16X3 (split-bf16 products; dy2 16-byte aligned) */
@@ -314,13 +306,6 @@ int eegclip_sconv_bwd_w(const float* y1, const float* mean, const float* rstd, c
 /* workspace (optional, 8-byte aligned, eegclip_sconv_bwd_x_stats_workspace_floats(B) floats): the 80 sums leave every workgroup as a partial row and
  * are column-summed by a second kernel instead of 1280-way contended fp64 atomics. */
 long long eegclip_sconv_bwd_x_stats_workspace_floats(int B);
-/* weight gradient AND the BatchNorm1-backward sums (what eegclip_sconv_bwd_x_stats produces) from one pass over y1; split-bf16 products only:
- * WsT_hi / WsT_lo = bf16 planes [(c,h)][64 o] of Ws^T (eegclip_split_rows, transpose).  workspace: eegclip_sconv_bwd_w_workspace_floats(B, H);
- * stats_workspace: eegclip_sconv_bwd_w_stats_workspace_floats(B, H) floats, 8-byte aligned; sums (2 x 40 doubles) is ADDED to. */
-long long eegclip_sconv_bwd_w_stats_workspace_floats(int B, int H);
-int eegclip_sconv_bwd_w_stats(const float* y1, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* dy2,
-                              const void* WsT_hi, const void* WsT_lo, float* dWs, float* workspace, double* sums, float* stats_workspace, int B, int H,
-                              void* stream);
 int eegclip_sconv_bwd_x_stats(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, double* sums, float* workspace, int B, int H, void* stream);
 int eegclip_sconv_bwd_x_apply(const float* dy2, const float* Ws, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean,

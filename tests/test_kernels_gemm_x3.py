@@ -186,59 +186,6 @@ def test_split_rows_planes_and_padding(be):
         assert (h[:, src.shape[1]:] == 0).all() and (l[:, src.shape[1]:] == 0).all()
 
 
-@pytest.mark.parametrize("M,N,K,split_k", [(130, 250, 250, 1), (64, 744, 250, 1), (200, 256, 96, 1), (70, 300, 330, 3), (256, 1024, 192, 2), (2, 2, 2, 1)])
-@pytest.mark.parametrize("form", ["fwd", "dx"])
-def test_x3_planes_variant(be, M, N, K, split_k, form):
-    """B pre-split by eegclip_split_rows (weights: once per optimizer step), 64 x 256 output tiles: Y = X W^T with the planes of W (fwd) and
-    dX = dY W with the planes of W^T (dx) -- same three products as the in-kernel split, bit-compatible reference"""
-    rng = np.random.default_rng(M + N + K + (form == "dx"))
-    a = f32(rng, M, K)
-    bias, c0, r0 = f32(rng, N), f32(rng, M, N), f32(rng, M)
-    if form == "fwd":
-        w = f32(rng, N, K)                                    # nn.Linear weight
-        hi, lo, ld, W = planes_of(be, w, False)
-        Bk, Bn, bm = D(1), D(K), w.T
-    else:
-        w = f32(rng, K, N)                                    # dX = dY W, W (K = n_out, N = n_in)
-        hi, lo, ld, W = planes_of(be, w, True)
-        Bk, Bn, bm = D(N), D(1), w
-    A, BI, C, RS = be.dev(a), be.dev(bias), be.dev(c0 if split_k > 1 else np.full((M, N), np.nan, np.float32)), be.dev(r0)
-    d = mk(be, M, N, K, A, D(K), D(1), W, Bk, Bn, C, D(N), D(1), bias_n=be.ptr(BI), split_k=split_k, rowsum_a=be.ptr(RS), precision=_abi.PREC_BF16X3,
-           B_hi=be.ptr(hi), B_lo=be.ptr(lo), ldb_planes=ld)
-    run(be, d)
-    got = be.host(C)
-    want = x3_ref(a, bm) + bias + (c0 if split_k > 1 else 0)
-    np.testing.assert_allclose(got, want, atol=4e-6 * max(1.0, np.abs(got).max()))
-    np.testing.assert_allclose(be.host(RS), r0 + a.astype(np.float64).sum(1), atol=2e-4)
-
-
-def test_x3_planes_variant_full_epilogue_and_embedding_map(be):
-    from scipy.special import erf
-    rng = np.random.default_rng(5)
-    M, N, K = 70, 92, 40
-    a, w, bn, r, c0 = f32(rng, M, K), f32(rng, N, K), f32(rng, N), f32(rng, M, N), f32(rng, M, N)
-    hi, lo, ld, W = planes_of(be, w)
-    A, BN, R, C, CP = be.dev(a), be.dev(bn), be.dev(r), be.dev(c0), be.zeros((M, N))
-    p, seed, site = 0.25, 0x1234567890ABCDEF, 3
-    run(be, mk(be, M, N, K, A, D(K), D(1), W, D(1), D(K), C, D(N), D(1), Cpre=be.ptr(CP), bias_n=be.ptr(BN), R=be.ptr(R), Rm=D(N), Rn=D(1), act=_abi.ACT_GELU,
-               accumulate=1, drop_p=p, seed=seed, drop_site=site, precision=_abi.PREC_BF16X3, B_hi=be.ptr(hi), B_lo=be.ptr(lo), ldb_planes=ld))
-    pre = x3_ref(a, w.T) + bn
-    keep = keep_mask(seed, site, M * N, p).reshape(M, N)
-    np.testing.assert_allclose(be.host(CP), pre, atol=2e-5)
-    np.testing.assert_allclose(be.host(C), 0.5 * pre * (1 + erf(pre / np.sqrt(2))) * keep / (1 - p) + r + c0, atol=4e-5)
-    Bt, Cc, T = 3, 63, 50
-    xe, we, b_, pe = f32(rng, Bt, Cc, T), f32(rng, T, T), f32(rng, T), f32(rng, Cc, T)
-    hi, lo, ld, WE = planes_of(be, we)
-    X, Bv, PE, OUT = be.dev(xe), be.dev(b_), be.dev(pe), be.zeros((Bt, Cc + 1, T))
-    d = mk(be, Bt * Cc, T, T, X, D(T), D(1), WE, D(1), D(T), OUT, D(T, div=Cc, so=(Cc + 1) * T), D(1), bias_n=be.ptr(Bv), R=be.ptr(PE),
-           Rm=D(T, div=Cc, so=0), Rn=D(1), precision=_abi.PREC_BF16X3, B_hi=be.ptr(hi), B_lo=be.ptr(lo), ldb_planes=ld)
-    d.C = be.ptr(OUT) + T * 4
-    run(be, d)
-    out = be.host(OUT)
-    np.testing.assert_allclose(out[:, 1:], x3_ref(xe.reshape(-1, T), we.T).reshape(Bt, Cc, T) + b_ + pe, atol=2e-5)
-    assert (out[:, 0] == 0).all()
-
-
 @pytest.mark.parametrize("cfg", [0, 2, 3, 5])
 @pytest.mark.parametrize("M,N,K,split_k", [(72, 66, 330, 3), (200, 130, 70, 2), (130, 250, 1100, 8), (2, 2, 40, 5)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1)])

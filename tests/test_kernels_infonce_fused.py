@@ -10,9 +10,9 @@ from eeg_image_decode_amd import _abi
 from test_kernels_gemm_x3 import bf16_round, split
 
 
-def planes_arg(planes, tile, stage=0):
-    """planes | tile size << 8 | operand staging << 16 (1 = LDS-DMA, 2 = registers, 0 = the library's default)"""
-    return planes | (tile << 8) | (stage << 16)
+def planes_arg(planes, tile):
+    """planes | tile size << 8 (0 = the library's choice)"""
+    return planes | (tile << 8)
 
 
 def feats(rng, rows, D, kind):
@@ -44,10 +44,9 @@ def lse(x):
     return (m + np.log(np.exp(x - m).sum(1, keepdims=True)))[:, 0]
 
 
-@pytest.mark.parametrize("stage", [1, 2])
 @pytest.mark.parametrize("planes", [1, 2])
 @pytest.mark.parametrize("n,N,D,tile,col0", [(64, 64, 64, 64, 0), (64, 192, 128, 64, 128), (128, 256, 64, 128, 64), (128, 128, 192, 64, 0)])
-def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, stage):
+def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0):
     rng = np.random.default_rng(n + N + D + planes)
     s = 2.6593
     blocks = [(feats(rng, n, D, "ln"), feats(rng, N, D, "unit"), col0, 0.495), (feats(rng, n, D, "unit") * 3, feats(rng, N, D, "ln"), col0, 0.005)]
@@ -65,7 +64,7 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, stag
         refs.append(logits_ref(q, k, planes, s))
     arr = (_abi.InfonceProblem * len(probs))(*probs)
     n_total = 2 * n
-    assert L.eegclip_infonce_fused_fwd(arr, len(probs), n, N, D, planes_arg(planes, tile, stage), n_total, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
+    assert L.eegclip_infonce_fused_fwd(arr, len(probs), n, N, D, planes_arg(planes, tile), n_total, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
     want_loss = 0.0
     for (q, k, c0, w), S, kp in zip(blocks, refs, keep):
         l_ref = lse(S)
@@ -79,7 +78,7 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, stag
         q, k = blocks[0][0], blocks[0][1]
         assert np.abs(refs[0] - s * q.astype(np.float64) @ k.astype(np.float64).T).max() < 1e-4
     # gradient tiles: one normaliser (row-sharded blocks) ...
-    assert L.eegclip_infonce_fused_grad(arr, len(probs), n, N, D, planes_arg(planes, tile, stage), n_total, be.ptr(SC), be.ptr(DS), be.stream) == 0
+    assert L.eegclip_infonce_fused_grad(arr, len(probs), n, N, D, planes_arg(planes, tile), n_total, be.ptr(SC), be.ptr(DS), be.stream) == 0
     want_ds = 0.0
     for (q, k, c0, w), S, kp in zip(blocks, refs, keep):
         Pm = np.exp(S - lse(S)[:, None])

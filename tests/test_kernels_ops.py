@@ -546,23 +546,15 @@ def test_fused_spatial_stage(be, B, H):
     var = y1.astype(np.float64).var((0, 2, 3))
     Y1, G1, B1, WS, BS, DY2 = be.dev(y1), be.dev(g1), be.dev(b1), be.dev(Ws), be.dev(bs), be.dev(dy2)
     MU, RS = be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
-    # forward: exact fp32 products, then split-bf16 products with the weights pre-split by eegclip_split_rows
-    Kf = C * H
-    ldp = (Kf + 128 + 63) // 64 * 64
-    FH, FL = be.dev(np.full((C, ldp), 0x7FC0, np.uint16)), be.dev(np.full((C, ldp), 0x7FC0, np.uint16))
-    itf = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(WS), hi=be.ptr(FH), lo=be.ptr(FL), rows=C, cols=Kf, ld_src=Kf, ld_out=ldp, transpose=0))
-    ok(be.lib.eegclip_split_rows(itf, 1, be.stream))
-    # (K-slice partial tiles added into y2 with atomics | written to workspace slabs and summed by the statistics kernel of the same call)
-    for planes, slabs in [((None, None, 0), False), ((be.ptr(FH), be.ptr(FL), ldp), False), ((None, None, 0), True), ((be.ptr(FH), be.ptr(FL), ldp), True)]:
+    # forward (exact fp32 products): K-slice partial tiles added into y2 with atomics | written to workspace slabs and summed by the statistics kernel
+    for slabs in (False, True):
         Y2, S2 = (be.dev(np.full((B, C, Wd), np.nan, np.float32)) if slabs else be.zeros((B, C, Wd))), be.zeros(80, np.float64)
         WSF = be.dev(np.full(int(be.lib.eegclip_sconv_fwd_workspace_floats(B)), np.nan, np.float32)) if slabs else None
-        ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), *planes, be.ptr(BS), be.ptr(Y2), be.ptr(S2),
+        ok(be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(BS), be.ptr(Y2), be.ptr(S2),
                                     B, H, 0, be.ptr(WSF) if slabs else None, be.stream))
         np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=5e-5)
-        np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3, rtol=2e-5 if planes[0] else 0)   # (sums of ~1e3 terms)
+        np.testing.assert_allclose(be.host(S2)[:40], y2t.detach().sum((0, 2)).numpy(), atol=1e-3)   # (sums of ~1e3 terms)
         np.testing.assert_allclose(be.host(S2)[40:], (y2t.detach() ** 2).sum((0, 2)).numpy(), rtol=1e-4)
-    assert be.lib.eegclip_sconv_fwd(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(WS), be.ptr(FH), be.ptr(FL), Kf, be.ptr(BS),
-                                    be.ptr(Y2), be.ptr(S2), B, H, 0, None, be.stream) < 0     # planes too narrow for the chunk overrun
     for precision in (_abi.PREC_F32, _abi.PREC_BF16X3):
         DWS = be.dev(np.ones((C, C, H), np.float32))
         WSP = be.zeros(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)))
@@ -587,23 +579,6 @@ def test_fused_spatial_stage(be, B, H):
         np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
     assert be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(WH), None, be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
                                             be.ptr(SUMS), None, B, H, be.stream) < 0
-    # weight gradient + the same BatchNorm-backward sums from ONE pass over y1 (sconv_bwd_ws_x3_kernel), against the two separate kernels and torch
-    SUMS2, DWS2 = be.zeros(80, np.float64), be.dev(np.ones((C, C, H), np.float32))
-    WSP = be.dev(np.full(int(be.lib.eegclip_sconv_bwd_w_workspace_floats(B, H)), np.nan, np.float32))
-    SWS = be.dev(np.full(int(be.lib.eegclip_sconv_bwd_w_stats_workspace_floats(B, H)) // 2, np.nan, np.float64))
-    ok(be.lib.eegclip_sconv_bwd_w_stats(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(WH), be.ptr(WL), be.ptr(DWS2),
-                                        be.ptr(WSP), be.ptr(SUMS2), be.ptr(SWS), B, H, be.stream))
-    np.testing.assert_allclose(be.host(DWS2) - 1.0, wt.grad.numpy(), atol=1e-4 * max(1.0, np.abs(wt.grad.numpy()).max()))
-    ref_s = be.host(SUMS)                   # (the split-bf16 statistics pass just above)
-    np.testing.assert_allclose(be.host(SUMS2), ref_s, atol=2e-4 * max(1.0, np.abs(ref_s).max()))
-    DY1, DG, DB = be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
-    ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), be.ptr(WH), be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1),
-                                        be.ptr(SUMS2), None, float(B * H * Wd), be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
-    np.testing.assert_allclose(be.host(DY1), yt.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(yt.grad.numpy()).max())
-    np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
-    np.testing.assert_allclose(be.host(DB), bt.grad.numpy(), atol=2e-4 * max(1.0, np.abs(bt.grad.numpy()).max()))
-    assert be.lib.eegclip_sconv_bwd_w_stats(be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2), be.ptr(WH), None, be.ptr(DWS2),
-                                            be.ptr(WSP), be.ptr(SUMS2), be.ptr(SWS), B, H, be.stream) < 0
 
 
 @pytest.mark.parametrize("B,H,cap", [(3, 63, 0), (2, 5, 0), (5, 63, 3), (9, 17, 4)])

@@ -25,7 +25,6 @@ def run(M, N, K, kind, split=1, reps=20, drop=0.0):
     ms = e0.elapsed_time(e1) / reps
     print(f"{kind} {M}x{N}x{K} sk{split} drop{drop}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF/s")
 if __name__ == "__main__":
-    print("EEGCLIP_GEMM_FAST =", os.environ.get("EEGCLIP_GEMM_FAST", "(default on)"))
     for args in [(16384, 744, 250, "nt"), (16384, 250, 248, "nt"), (16384, 256, 250, "nt"), (16384, 250, 256, "nt"), (16384, 250, 250, "nt", 1, 20, 0.25), (16384, 256, 250, "nt", 1, 20, 0.25),
                  (16384, 250, 744, "nn"), (16384, 250, 256, "nn"), (16384, 256, 250, "nn"), (16384, 248, 250, "nn"),
                  (744, 250, 16384, "tn", 32), (250, 256, 16384, "tn", 32), (256, 250, 16384, "tn", 32), (1024, 1440, 256, "tn"),

@@ -11,7 +11,7 @@ from eeg_image_decode_amd import plan as _plan          # noqa: E402
 
 fams = set(sys.argv[1].split(","))
 sys.argv = ["bench.py"] + sys.argv[2:]
-CALLS = {"convbwd": ("eegclip_sconv_bwd_w", "eegclip_sconv_bwd_x_stats", "eegclip_sconv_bwd_w_stats", "eegclip_sconv_bwd_x_apply", "eegclip_tsconv_bwd_w", "eegclip_tsconv_bwd_x"),
+CALLS = {"convbwd": ("eegclip_sconv_bwd_w", "eegclip_sconv_bwd_x_stats", "eegclip_sconv_bwd_x_apply", "eegclip_tsconv_bwd_w", "eegclip_tsconv_bwd_x"),
          "convfwd": ("eegclip_sconv_fwd", "eegclip_tsconv_fwd"),
          "attnbwd": ("eegclip_attention_bwd", "eegclip_attention_bwd_x3"), "tb_fwd": ("eegclip_token_block_fwd",), "tb_bwd": ("eegclip_token_block_bwd",)}
 skip_calls = {n for f in fams for n in CALLS.get(f, ())}

@@ -11,7 +11,6 @@ FAMILIES = {
     "eegclip_tsconv_fwd": ("eeg::tsconv_fwd_kernel",), "eegclip_tsconv_bwd_w": ("eeg::tsconv_bwd_w_kernel",),
     "eegclip_tsconv_bwd_x": ("eeg::tsconv_bwd_x_kernel",), "eegclip_sconv_fwd": ("eeg::sconv_fwd_kernel", "eeg::sconv_fwd_x3_kernel"),
     "eegclip_sconv_bwd_w": ("eeg::sconv_bwd_w_x3_kernel", "eeg::sconv_bwd_w_kernel"),
-    "eegclip_sconv_bwd_w_stats": ("eeg::sconv_bwd_ws_x3_kernel",),
     "eegclip_sconv_bwd_x_stats": ("eeg::sconv_bwd_x_kernel<false",), "eegclip_sconv_bwd_x_apply": ("eeg::sconv_bwd_x_kernel<true",),
 }
 
