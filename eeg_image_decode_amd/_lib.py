@@ -48,7 +48,8 @@ def current_stream():
     torch.cuda.is_available(), which reads an environment variable each time -- ~40 us per call, and the 11 calls of a training step were 0.45 ms
     of its 0.82 ms of host time (tools/host_profile.py)."""
     import torch
-    return torch.cuda.current_stream(torch._C._cuda_getDevice())
+    get = getattr(torch._C, "_cuda_getDevice", None)          # (private accessor: fall back to the public one if a torch release drops it)
+    return torch.cuda.current_stream(get() if get is not None else torch.cuda.current_device())
 
 
 def raw_stream():

@@ -351,6 +351,7 @@ def _head_split(B):
 
 class _Engine:
     """Flat parameter/gradient storage + per-batch-size activation buffers and launch plans."""
+    check_cleared = False        # debug: verify the flat gradient buffer whenever attach_grads() skips its clear (see there)
 
     def __init__(self, model):
         sd_params = dict(model.named_parameters())
@@ -1018,6 +1019,10 @@ class _Engine:
         if n_mine == 0:
             if self._clear_for != live:                    # (an optimizer step that cleared exactly these gradients behind its reads: nothing to do)
                 self.gflat.zero_()                         # the common case after optimizer.zero_grad(): one memset
+            elif _Engine.check_cleared and bool(self.gflat.any()):
+                # debug (tests set _Engine.check_cleared; a host sync): skipping the clear is only sound if every accumulating backward kernel wrote
+                # exclusively inside the views the optimizer cleared and nothing touched the buffer since
+                raise EegclipError("flat gradient buffer is not clear although the optimizer reported clearing it")
         else:
             for p, g in rest:
                 g.zero_()

@@ -413,13 +413,21 @@ __global__ __launch_bounds__(256, 3) void sconv_bwd_w_x3_kernel(const float* __r
         }
 }
 
-__global__ void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// dW[i] += sum over the sample groups, in a FIXED order: workgroup = 64 elements x 4 group slices (thread (sg, e) sums groups sg, sg + 4, ...; the four
+// slices meet in LDS and are added as (g0 + g1) + (g2 + g3)).  Round 3 split the groups over gridDim.y and combined the slices with float atomics --
+// a scheduling-dependent sum; one thread per element walking all ~51 groups left most of the chip idle.
+__global__ __launch_bounds__(256) void sconv_bwd_w_reduce_kernel(const float* __restrict__ partials, int groups, long long n, float* __restrict__ dW) {
+    EEG_LDS_BASE(float, red);                                // [4][64]
+    const int t = threadIdx.x, sg = t >> 6, e = t & 63;
+    const long long i = (long long)blockIdx.x * 64 + e;
     float s = 0.f;
+    if (i < n) {
 #pragma unroll 8
-    for (int k = blockIdx.y; k < groups; k += gridDim.y) s += partials[(long long)k * n + i];      // independent loads: keep 8 in flight per thread
-    atomicAdd(dW + i, s);        // gridDim.y (<= 4) adds per address: 394 workgroups of 51 dependent-issue loads each left most of the chip idle
+        for (int k = sg; k < groups; k += 4) s += partials[(long long)k * n + i];      // independent loads: 8 in flight per thread
+    }
+    red[sg * 64 + e] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) dW[i] += (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -656,7 +664,7 @@ extern "C" int eegclip_sconv_bwd_w(const float* y1, const float* mean, const flo
         EEG_LAUNCH(sconv_bwd_w_kernel<SCW_NS>, grid, dim3(256), lds, stream, y1, bn, dy2, workspace, B, H, groups);
     }
     const long long n = (long long)SC_C * K;
-    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 255) / 256), groups >= 16 ? 4 : 1), dim3(256), 0, stream, workspace, groups, n, dWs);
+    EEG_LAUNCH(sconv_bwd_w_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 256 * sizeof(float), stream, workspace, groups, n, dWs);
     return (int)hipGetLastError();
 }
 

@@ -65,7 +65,6 @@ class AdamW(torch.optim.Optimizer):
         fn = L.eegclip_adamw_step_zero_grad if zero_grad else L.eegclip_adamw_step
         stream = raw_stream()
         gs = self.grad_scale_dev.data_ptr() if self.grad_scale_dev is not None else None
-        cleared = []
         for gi, group in enumerate(self.param_groups):
             params = group["params"]
             grads = [p.grad for p in params]
@@ -144,6 +143,21 @@ class AdamW(torch.optim.Optimizer):
     def state_dict(self):
         self._flush_steps()
         return super().state_dict()
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle go through here, not through state_dict(): state[p]["step"] is LAZY on the fast path (only the per-group counter
+        advances; the per-parameter counts are brought up to date by _flush_steps), so flush first -- a copy restored from stale counts would apply
+        the wrong bias correction.  torch's Optimizer.__getstate__ keeps defaults / state / param_groups only."""
+        self._flush_steps()
+        return super().__getstate__()
+
+    def __setstate__(self, state):
+        """the copy starts without launch caches and flat moment buffers (raw device addresses of the ORIGINAL's tensors): its moments are the
+        per-parameter tensors of `state`, linked into fresh flat buffers at its first step (as after load_state_dict)"""
+        super().__setstate__(state)
+        self._runs_cache, self._fast, self._moments = {}, {}, {}
+        if not hasattr(self, "grad_scale_dev"):
+            self.grad_scale_dev = None
 
     def _make_runs(self, live):
         """maximal runs of parameters that are contiguous (up to 12 bytes of alignment padding) in BOTH the weight and

@@ -92,11 +92,13 @@ def _side_stream(device):
 
 
 def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
-                     alpha=0.99, objective="retrieval"):
+                     alpha=0.99, objective="retrieval", keep_grads=False):
     """One iteration of the reference batch loop (ATMS_retrieval.py:209-250) with every tensor already on the device:
     forward, image + text InfoNCE (0.99/0.01), backward, optimizer step, running loss and train-accuracy -- no host sync.
     With an optimizer that offers it (optim.AdamW / Adam: supports_step_and_zero_grad) the update also performs the zero_grad() that opens the
-    next iteration, so the gradients are None when this returns; `loss_acc` is a device scalar (added to in place) or a list (appended to).
+    next iteration, so the gradients are None when this returns -- the reference loop leaves them in place until its next zero_grad()
+    (ATMS_retrieval.py:209-231): pass keep_grads=True to get exactly that (gradient-norm logging, clipping diagnostics) at the price of a separate
+    clearing pass; `loss_acc` is a device scalar (added to in place) or a list (appended to).
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
     from . import dist as edist
     optimizer.zero_grad()
@@ -106,13 +108,14 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
         eeg_model.overlap_grad_allreduce = True          # one backward per step HERE: its early gradient bucket may be reduced while it still runs
     try:
         return _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct,
-                                 alpha, objective)
+                                 alpha, objective, keep_grads)
     finally:
         if overlap:
             eeg_model.overlap_grad_allreduce = prev_overlap      # (a caller accumulating gradients over several backwards must not inherit it)
 
 
-def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct, alpha, objective):
+def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct, alpha, objective,
+                      keep_grads=False):
     from . import dist as edist
     batch_size = eeg_data.size(0)
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
@@ -150,7 +153,7 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
         main.wait_stream(side)             # join BEFORE the optimizer rewrites logit_scale, which the readout's ranking kernel reads
     else:
         _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct)
-    if getattr(optimizer, "supports_step_and_zero_grad", False):
+    if getattr(optimizer, "supports_step_and_zero_grad", False) and not keep_grads:
         optimizer.step(zero_grad=True)     # the update and the zero_grad() that opens the next iteration in one pass over the gradients
     else:
         optimizer.step()

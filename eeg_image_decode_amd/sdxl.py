@@ -134,11 +134,14 @@ class HIPIPAdapterAttnProcessor(nn.Module):
         """K, V of the token tensor `src` (make_tokens() -> the (B, S, cross_dim) matrix in the activation dtype).  Outside a sampling run they are
         reused only for THE SAME tensor object at the same version (the entry holds a reference to it, so its address cannot be recycled for
         another tensor while the entry lives -- keying on data_ptr() could hand the K / V of a freed tensor to the next one allocated at its
-        address); inside a run (begin_sampling_run) the first projection of the run is reused for any tensor of that shape."""
+        address); inside a run (begin_sampling_run) the first projection of the run is reused for any OTHER tensor of that shape (pipelines rebuild
+        the constant token tensor every step), but the SAME object must still be at the version it was projected at: a callback that edits
+        prompt_embeds / image_embeds in place between steps gets fresh K / V instead of silently stale ones."""
         hit = self._kv_cache.get(tag)
         wkey = (lin_k.weight.data_ptr(), lin_k.weight._version, lin_v.weight.data_ptr(), lin_v.weight._version)
         if hit is not None and hit[2] == wkey and hit[0].shape == src.shape and hit[0].dtype == src.dtype:
-            if getattr(self, "_run_scope", False) or (hit[0] is src and hit[1] == src._version):
+            same_obj = hit[0] is src
+            if (same_obj and hit[1] == src._version) or (not same_obj and getattr(self, "_run_scope", False)):
                 return hit[3], hit[4]
         tokens = make_tokens()
         k, v = self._lin(lin_k, tokens), self._lin(lin_v, tokens)
