@@ -83,7 +83,7 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>", "eegclip_conv_bwd_fused": "eeg::conv_bwd_fused_kernel"}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r3_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r4_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(family, B):
@@ -100,6 +100,32 @@ def pmc_traffic(family, B):
         return None, None
     d = table.get("families", {}).get(family)
     return (round(d["hbm_bytes_per_launch"]), PMC_SUMMARY) if d and "hbm_bytes_per_launch" in d else (None, None)
+
+
+def pmc_mfma_busy(family, B):
+    """matrix-pipe busy fraction of a family from the same committed PMC summary (None if absent)"""
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    if table.get("batch") != B:
+        return None
+    return table.get("families", {}).get(family, {}).get("mfma_busy_frac")
+
+
+def algorithmic_bytes(name, desc, B):
+    """HBM bytes a launch has to move at least (operands once in, results once out): the traffic the PMC figure is compared with"""
+    if name == "eegclip_gemm_f32":
+        return 4.0 * (desc.M * desc.K + desc.K * desc.N + desc.M * desc.N)
+    if name == "eegclip_wgrad_tok":                                # token planes are 4 bytes per element (hi | lo); partial tiles are not algorithmic
+        return float(desc.bytes)
+    if name == "eegclip_wgrad_tok_reduce":
+        return 0.0
+    if name in ("eegclip_attention_bwd_x3", "eegclip_attention_bwd"):
+        return float(B * 64 * (2 * 744 + 248) * 4)                 # qkv + dctx in, dqkv out
+    c = algorithmic_cost(name, desc, B)
+    return c[1] if c and c[2] == "byte" else None
 
 
 TIME_EVERY = 8
@@ -624,6 +650,24 @@ def main():
             fa = sum(x[1] for x in fw) / (fam_ms[f] * fscale)
             fams[f] = {"bound": fw[0][0], "launches_per_step": len(fops), "ms_per_step_single_stream": round(fam_ms[f], 4), "achieved": round(fa, 2), "peak": round(fpeak, 1),
                        "unit": fu, "frac": round(fa / fpeak, 4)}
+            # algorithmic bytes per launch (family mean) next to the PMC traffic of the committed profile, their ratio, and the matrix-pipe busy fraction:
+            # traffic well above the algorithmic bytes = wasted re-reads; a GEMM family is also priced against the HBM roof (the K ~ 16 k weight
+            # gradients are as much HBM- as MFMA-limited): frac_of_binding_roof = time the binding roof allows / time taken
+            ab = [algorithmic_bytes(plans[o[0]].ops[o[1]][2], _desc_of(plans[o[0]], o[1]), B) for o in fops]
+            if all(x is not None for x in ab):
+                fams[f]["algorithmic_bytes_per_launch"] = round(sum(ab) / len(fops))
+                tr, _ = pmc_traffic(f, B)
+                if tr:
+                    fams[f]["traffic_per_launch"] = tr
+                    fams[f]["traffic_over_algorithmic"] = round(tr / max(1.0, sum(ab) / len(fops)), 2)
+                if fw[0][0] == "mfma":
+                    t_mfma = sum(x[1] for x in fw) / (fpeak * 1e12) * 1e3          # ms at the MFMA roof
+                    t_hbm = sum(ab) / (PEAK_HBM_GBS * 1e9) * 1e3                   # ms at the HBM roof
+                    fams[f]["frac_of_hbm_roof"] = round(t_hbm / fam_ms[f], 4)
+                    fams[f]["frac_of_binding_roof"] = round(max(t_mfma, t_hbm) / fam_ms[f], 4)
+            mb = pmc_mfma_busy(f, B)
+            if mb is not None:
+                fams[f]["mfma_busy_frac"] = mb
         roof["families"] = dict(sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step_single_stream"]))
 
     distributed = None
@@ -753,7 +797,8 @@ def _desc_of(plan, idx):
         import types
         probs, n, B = a[0], int(a[1]), int(a[2])
         return types.SimpleNamespace(flops=sum(2.0 * probs[i].M * probs[i].N * 64 * B for i in range(n)), label="+".join(f"{probs[i].M}x{probs[i].N}x{64 * B}" for i in range(n)),
-                                     slices=int(a[3]))
+                                     slices=int(a[3]),
+                                     bytes=sum((probs[i].m_groups + 1) * B * 65536 + 4.0 * probs[i].M * probs[i].N for i in range(n)))
     return None
 
 

@@ -7,12 +7,16 @@ def summarise(paths):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     mx = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
+    dur, ndur = collections.defaultdict(float), collections.Counter()
     for p in paths:
         for r in csv.DictReader(open(p)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             mx[k][r["Counter_Name"]] = max(mx[k][r["Counter_Name"]], float(r["Counter_Value"]))
             cnt[(k, r["Counter_Name"])] += 1
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):          # kernel duration UNDER THE PROFILER (ns): slower than an unprofiled launch
+                dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                ndur[k] += 1
     out = {}
     for k, v in agg.items():
         d = {c: val / cnt[(k, c)] for c, val in v.items()}
@@ -21,6 +25,12 @@ def summarise(paths):
             # kernels launched on several problem shapes (the GEMMs): the largest launch
             d["hbm_bytes_largest_launch"] = (2.0 * mx[k].get("FETCH_SIZE", 0.0) + mx[k].get("WRITE_SIZE", 0.0)) * 1024.0
         d["launches_sampled"] = max(cnt[(k, c)] for c in v)
+        if ndur[k]:
+            d["profiled_duration_us"] = dur[k] / ndur[k] / 1e3
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["profiled_duration_us"] > 0:
+                # busy cycles of the matrix pipes / (1024 SIMDs x cycles of the launch at the nominal 2.4 GHz): the profiled clock is lower (MI355X_MICROARCH.md,
+                # DVFS), so this UNDER-states the busy fraction a little; ratios between kernels are unaffected
+                d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * 2400.0 * d["profiled_duration_us"])
         out[k] = d
     return out
 

@@ -5,11 +5,11 @@ import json
 import sys
 
 FAMILIES = {
-    "gemm_bf16x3": ("eeg::gemm_x3_kernel", "eeg::gemm_x3p_kernel"),
+    "gemm_bf16x3": ("eeg::gemm_x3_kernel", "eeg::wgrad_tok_kernel", "eeg::wgrad_tok_reduce_kernel"),
     "token_block": ("eeg::token_block_fwd_kernel", "eeg::token_block_bwd_a_kernel", "eeg::token_block_bwd_b_kernel"),
     "attention_f32_mfma": ("eeg::attention_bwd_kernel", "eeg::attention_fwd_kernel"), "attention_bf16x3": ("eeg::attention_bwd_x3_kernel",),
     "eegclip_tsconv_fwd": ("eeg::tsconv_fwd_kernel",), "eegclip_tsconv_bwd_w": ("eeg::tsconv_bwd_w_kernel",),
-    "eegclip_tsconv_bwd_x": ("eeg::tsconv_bwd_x_kernel",), "eegclip_sconv_fwd": ("eeg::sconv_fwd_kernel", "eeg::sconv_fwd_x3_kernel"),
+    "eegclip_tsconv_bwd_x": ("eeg::tsconv_bwd_x_kernel",), "eegclip_sconv_fwd": ("eeg::sconv_fwd_kernel",), "eegclip_conv_bwd_fused": ("eeg::conv_bwd_fused_kernel",),
     "eegclip_sconv_bwd_w": ("eeg::sconv_bwd_w_x3_kernel", "eeg::sconv_bwd_w_kernel"),
     "eegclip_sconv_bwd_x_stats": ("eeg::sconv_bwd_x_kernel<false",), "eegclip_sconv_bwd_x_apply": ("eeg::sconv_bwd_x_kernel<true",),
 }
@@ -19,17 +19,22 @@ def main(path, batch):
     s = json.load(open(path))
     fams = {}
     for fam, prefixes in FAMILIES.items():
-        tot, n, members = 0.0, 0, []
+        tot, n, members, busy, cyc = 0.0, 0, [], 0.0, 0.0
         for k, v in s.items():
             if any(k.startswith(p) for p in prefixes) and "hbm_bytes_per_launch" in v:
                 tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
                 n += v["launches_sampled"]
                 members.append(k)
+                if "mfma_busy_frac" in v:                            # time-weighted over the family's kernels
+                    busy += v["mfma_busy_frac"] * v["profiled_duration_us"] * v["launches_sampled"]
+                    cyc += v["profiled_duration_us"] * v["launches_sampled"]
         if n:
             fams[fam] = {"hbm_bytes_per_launch": tot / n, "launches_sampled": n, "kernels": sorted(members)}
+            if cyc:
+                fams[fam]["mfma_busy_frac"] = round(busy / cyc, 4)
     out = {"batch": batch,
            "source": f"{path}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 8 --warmup 3 "
-                     "--no-secondary --no-cpu-baseline (tools/gpu_r3_evidence.sh); hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 "
+                     "--no-secondary --no-cpu-baseline (tools/final_profiles.sh); hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 "
                      "FETCH_SIZE correction of MI355X_MICROARCH.md), launch-weighted mean over the family's kernels (tools/pmc_summary.py, this script)",
            "families": fams}
     json.dump(out, sys.stdout, indent=1)
