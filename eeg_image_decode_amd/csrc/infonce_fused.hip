@@ -63,34 +63,44 @@ struct if_geom {
 // MODE 0 = forward partials, 1 = gradient tile.  (Round 3 also built a variant that staged the operand tiles through registers -- global_load_dwordx4
 // -> ds_write_b128, two LDS stages -- to test whether the DMA fill is the limit at N = 2048: measured SLOWER than the 4-stage DMA pipeline, 20.8 vs
 // 18.3 us per logits block; removed in round 4.)
-template <int NP, int TM, int MODE>
-__global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
+// NW = 4 | 8 waves per workgroup.  8 (TM = 128 only; round 4): 2 query halves x 4 key quarters, each wave 64 x 32 logits -- two waves per SIMD, so one
+// wave's fragment reads / waits run under the other's MFMAs.  The 4-wave kernel (one wave per SIMD, 128 KB of LDS per workgroup: nothing else on the CU)
+// had the matrix pipe 16 % (one product) / 24 % (three products) busy at N = 2048 with no saturated unit -- 36 % of the wave cycles parked, no LDS bank
+// conflicts, operands L2-resident at a fill rate 3x below what the CU can pull (profiles/r4_pmc_infonce.json, tools/micro/dma_rate.hip).
+template <int NP, int TM, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale) {
     using Gm = if_geom<NP>;
     constexpr int BK = Gm::BK, ROWB = Gm::ROWB, NCH = Gm::NCH, RPI = Gm::RPI;
-    constexpr int WT = TM / 64;                               // 32x32 MFMA tiles per wave and dimension
+    constexpr int NWK = NW / 2;                               // waves along the keys
+    constexpr int WT = TM / 64;                               // 32x32 MFMA tiles per wave along the queries
+    constexpr int WTK = TM / (32 * NWK);                      // ... along the keys
     constexpr int TILE_B = TM * ROWB;                         // bytes of one operand-plane tile
     constexpr int STAGE_B = 2 * NP * TILE_B;                  // q_hi | k_hi | (q_lo | k_lo)
-    constexpr int IPT = TM / RPI / 4;                         // DMA instructions per wave, tile and operand plane
+    constexpr int IPT = TM / RPI / NW;                        // DMA instructions per wave, tile and operand plane
     constexpr int DPT = 2 * NP * IPT;                         // ... per wave and k-tile (what vmcnt counts)
-    static_assert(IPT >= 1, "tile too small for the 4-wave DMA split");
+    static_assert(IPT >= 1 && WTK >= 1, "tile too small for this many waves");
     EEG_LDS_BASE(unsigned char, lds);
 
     const int tiles = tiles_q * tiles_k;
     const int prob = (int)blockIdx.x / tiles;
     const int rem = (int)blockIdx.x - prob * tiles;
+    // (An XCD-aware tile order -- every XCD owning whole 4 x 8 supertiles so that its 32 workgroups share 12 operand tile rows instead of 18 -- was tried
+    //  in round 4 on the reading that fabric traffic bounds the kernel at N = 2048 (FETCH_SIZE 77 MB for 8 MB of operands): no gain, 16.9 vs 15.7 us one
+    //  product, 32.2 vs 29.7 us three products.  A single 128 x 128 tile on an otherwise idle chip takes the same ~0.6 us per 64-k tile as 256 of them:
+    //  the bound is the per-tile chain wait -> barrier -> fragment reads -> MFMAs, not bandwidth.  DESIGN.md section 4.)
     const if_problem& P = tb.p[prob];
     const int q0 = (rem / tiles_k) * TM, k0r = (rem % tiles_k) * TM;
     const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
-    const int wq = wave >> 1, wk = wave & 1;
+    const int wq = wave / NWK, wk = wave % NWK;
     const int r32 = lane & 31, h = lane >> 5;
 
-    // ---- DMA roles: wave w deposits rows [w * TM/4, +TM/4) of every operand-plane tile, instruction i = rows + RPI * i
+    // ---- DMA roles: wave w deposits rows [w * TM/NW, +TM/NW) of every operand-plane tile, instruction i = rows + RPI * i
     const int drow = lane / NCH, dpos = lane % NCH;
     const unsigned short* src[2 * NP][IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
-        const int row = wave * (TM / 4) + RPI * i + drow;
+        const int row = wave * (TM / NW) + RPI * i + drow;
         const int col = 8 * (dpos ^ Gm::swz(row));
         src[0][i] = P.q_hi + (long long)(q0 + row) * D + col;
         src[1][i] = P.k_hi + (long long)(k0r + row) * D + col;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     }
     auto issue_one = [&](int kt, int dnum) {                  // DMA instruction `dnum` (0 .. DPT-1) of k-tile kt
         const int o = dnum / IPT, i = dnum % IPT;
-        unsigned char* st = lds + (kt % IF_NS) * STAGE_B + wave * (TM / 4) * ROWB;
+        unsigned char* st = lds + (kt % IF_NS) * STAGE_B + wave * (TM / NW) * ROWB;
         lds_dma16(st + o * TILE_B + RPI * i * ROWB, src[o][i] + kt * BK);
     };
     auto issue_tile = [&](int kt) {
@@ -109,24 +119,29 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
         for (int dnum = 0; dnum < DPT; ++dnum) issue_one(kt, dnum);
     };
 
-    f32x16 acc[WT][WT];                                       // acc[j][i]: key tile j (MFMA rows), query tile i (MFMA columns)
+    f32x16 acc[WTK][WT];                                      // acc[j][i]: key tile j (MFMA rows), query tile i (MFMA columns)
 #pragma unroll
-    for (int j = 0; j < WT; ++j)
+    for (int j = 0; j < WTK; ++j)
 #pragma unroll
         for (int i = 0; i < WT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
     // fragment addresses (do not depend on the k-tile): byte offset of chunk 2 s + h of this lane's row in a q / k tile
-    int foq[BK / 16][WT], fok[BK / 16][WT];
+    int foq[BK / 16][WT], fok[BK / 16][WTK];
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s)
+    for (int s = 0; s < BK / 16; ++s) {
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            const int rq = wq * (TM / 2) + 32 * i + r32, rk = wk * (TM / 2) + 32 * i + r32;
+            const int rq = wq * (TM / 2) + 32 * i + r32;
             foq[s][i] = rq * ROWB + (((2 * s + h) ^ Gm::swz(rq)) & (NCH - 1)) * 16;
-            fok[s][i] = TILE_B + rk * ROWB + (((2 * s + h) ^ Gm::swz(rk)) & (NCH - 1)) * 16;
         }
+#pragma unroll
+        for (int j = 0; j < WTK; ++j) {
+            const int rk = wk * (TM / NWK) + 32 * j + r32;
+            fok[s][j] = TILE_B + rk * ROWB + (((2 * s + h) ^ Gm::swz(rk)) & (NCH - 1)) * 16;
+        }
+    }
 
     // One k-tile = NSTEP MFMA k-steps.  With ONE wave per SIMD nothing else covers this wave's issue slots, so the order inside the tile
     // is what overlaps the three pipes (first version: barrier -> 8 DMA issues -> 16 fragment reads -> wait -> 16 MFMAs, strictly one after
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     //   * the fragment reads of step s + 1 are issued BEFORE the MFMAs of step s (two register sets),
     //   * the DMA instructions of tile kt + 3 are spread between the MFMAs of the whole tile (the matrix pipe works through its queue
     //     while the wave issues them).
-    constexpr int NSTEP = BK / 16, MPS = WT * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
+    constexpr int NSTEP = BK / 16, MPS = WTK * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
     const int ktiles = D / BK;
     {
     #pragma unroll
@@ -148,16 +163,17 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
             raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
             const bool refill = kt + IF_NS - 1 < ktiles;          // (workgroup-uniform)
             const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
-            bf16x8 qh[2][WT], kh[2][WT], ql[2][WT], kl[2][WT];
+            bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
             auto read_step = [&](int s, int set) {
     #pragma unroll
                 for (int i = 0; i < WT; ++i) {
                     qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
-                    kh[set][i] = *reinterpret_cast<const bf16x8*>(st + fok[s][i]);
-                    if (NP == 2) {
-                        ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
-                        kl[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][i]);
-                    }
+                    if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+                }
+    #pragma unroll
+                for (int j = 0; j < WTK; ++j) {
+                    kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
+                    if (NP == 2) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
                 }
             };
             read_step(0, 0);
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     #endif
                 const int set = s & 1;
     #pragma unroll
-                for (int j = 0; j < WT; ++j)
+                for (int j = 0; j < WTK; ++j)
     #pragma unroll
                     for (int i = 0; i < WT; ++i) {
                         const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     }
 
     // ---- epilogue: lane (r32, h) owns query row q = q0 + wq TM/2 + 32 i + r32 of tile i; register e of key tile j is key
-    //      k = k0r + wk TM/2 + 32 j + (e & 3) + 8 (e >> 2) + 4 h.
+    //      k = k0r + wk TM/NWK + 32 j + (e & 3) + 8 (e >> 2) + 4 h.
     // (every field of the block descriptor is read into a register HERE: `tb.p[prob]` is a dynamically indexed kernel argument, and a use
     //  inside a conditional costs a scalar load + wait per use -- 64 of them per lane in the first version, ~5 us of a 17 us kernel)
     const float s = *scale;
@@ -204,15 +220,15 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
     const int p_col0 = P.col0;
     const float p_weight = P.weight;
     if (MODE == 0) {
-        const int Pn = 2 * tiles_k;                           // partial slots per row: (key tile, wk)
-        const int slot = 2 * (rem % tiles_k) + wk;
+        const int Pn = NWK * tiles_k;                         // partial slots per row: (key tile, wk)
+        const int slot = NWK * (rem % tiles_k) + wk;
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const int pos = p_col0 + q - (k0r + wk * (TM / 2)) - 4 * h;      // key index of the positive in this lane's register numbering, if any
+            const int pos = p_col0 + q - (k0r + wk * (TM / NWK)) - 4 * h;    // key index of the positive in this lane's register numbering, if any
             float mx = -3.0e38f, mn = 3.0e38f;
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
+            for (int j = 0; j < WTK; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     mx = fmaxf(mx, acc[j][i][e]);
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
             float sum = 0.f, dv = 0.f;
             bool have = false;
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
+            for (int j = 0; j < WTK; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float v = s * acc[j][i][e];
@@ -249,11 +265,11 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
         for (int i = 0; i < WT; ++i) {
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
             const float lq = p_lse[q];
-            const int kb = k0r + wk * (TM / 2);
+            const int kb = k0r + wk * (TM / NWK);
             const int pos = p_col0 + q - kb;
             float* grow = p_G + (long long)q * p_ldg + kb;
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
+            for (int j = 0; j < WTK; ++j)
 #pragma unroll
                 for (int eq = 0; eq < 4; ++eq) {              // registers 4 eq .. 4 eq + 3 are 4 CONSECUTIVE keys: one 16-byte store
                     const int kk = 32 * j + 8 * eq + 4 * h;
@@ -281,7 +297,11 @@ __global__ __launch_bounds__(256) void infonce_tile_kernel(const if_table tb, in
         float* red = reinterpret_cast<float*>(lds);
         if (lane == 0) red[wave] = ds;
         __syncthreads();
-        if (t == 0) atomicAdd(dscale, (red[0] + red[1]) + (red[2] + red[3]));
+        if (t == 0) {
+            float tot = (red[0] + red[1]) + (red[2] + red[3]);
+            if (NW == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
+            atomicAdd(dscale, tot);
+        }
     }
 }
 
@@ -410,20 +430,28 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
     return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
 }
 
-#define EEG_IF_GO2(NP_, TM_, MODE_)                                                                                                                 \
-    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_>), dim3((unsigned)(nprob * tq * tk)), dim3(256), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
+#define EEG_IF_GO2(NP_, TM_, MODE_, NW_)                                                                                                                  \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * NW_), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
                stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+
+// waves per workgroup: bits 16..17 of `planes` (tests / benches) 1 = 4 waves, 2 = 8 waves (128-tiles only), 0 = the library's choice: 8 for 128-tiles
+static int if_waves(int TM, int planes) {
+    const int w = (planes >> 16) & 3;
+    return TM == 128 && w != 1 ? 8 : 4;
+}
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream) {
-    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM;
+    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM, NW = if_waves(TM, planes);
     planes &= 0xff;
     if (planes == 1) {
-        if (TM == 128) { if (mode == 0) EEG_IF_GO2(1, 128, 0); else EEG_IF_GO2(1, 128, 1); }
-        else           { if (mode == 0) EEG_IF_GO2(1, 64, 0);  else EEG_IF_GO2(1, 64, 1); }
+        if (TM == 128 && NW == 8) { if (mode == 0) EEG_IF_GO2(1, 128, 0, 8); else EEG_IF_GO2(1, 128, 1, 8); }
+        else if (TM == 128)       { if (mode == 0) EEG_IF_GO2(1, 128, 0, 4); else EEG_IF_GO2(1, 128, 1, 4); }
+        else                      { if (mode == 0) EEG_IF_GO2(1, 64, 0, 4);  else EEG_IF_GO2(1, 64, 1, 4); }
     } else {
-        if (TM == 128) { if (mode == 0) EEG_IF_GO2(2, 128, 0); else EEG_IF_GO2(2, 128, 1); }
-        else           { if (mode == 0) EEG_IF_GO2(2, 64, 0);  else EEG_IF_GO2(2, 64, 1); }
+        if (TM == 128 && NW == 8) { if (mode == 0) EEG_IF_GO2(2, 128, 0, 8); else EEG_IF_GO2(2, 128, 1, 8); }
+        else if (TM == 128)       { if (mode == 0) EEG_IF_GO2(2, 128, 0, 4); else EEG_IF_GO2(2, 128, 1, 4); }
+        else                      { if (mode == 0) EEG_IF_GO2(2, 64, 0, 4);  else EEG_IF_GO2(2, 64, 1, 4); }
     }
     return (int)hipGetLastError();
 }
@@ -437,7 +465,8 @@ extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, i
     const float inv_total = 1.0f / (float)n_total;
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
     if (rc) return rc;
-    const int Pn = 2 * (N / if_tile(n, N, (planes >> 8) & 0xff));
+    const int TMsel = if_tile(n, N, (planes >> 8) & 0xff);
+    const int Pn = (if_waves(TMsel, planes) / 2) * (N / TMsel);
     EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nprob), dim3(256), 512 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
     return (int)hipGetLastError();
 }

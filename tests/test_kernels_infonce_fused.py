@@ -10,9 +10,9 @@ from eeg_image_decode_amd import _abi
 from test_kernels_gemm_x3 import bf16_round, split
 
 
-def planes_arg(planes, tile):
-    """planes | tile size << 8 (0 = the library's choice)"""
-    return planes | (tile << 8)
+def planes_arg(planes, tile, waves=0):
+    """planes | tile size << 8 (0 = the library's choice) | waves per workgroup << 16 (1 = 4 waves, 2 = 8 waves: 128-tiles only, 0 = the library's choice)"""
+    return planes | (tile << 8) | (waves << 16)
 
 
 def feats(rng, rows, D, kind):
@@ -45,8 +45,9 @@ def lse(x):
 
 
 @pytest.mark.parametrize("planes", [1, 2])
-@pytest.mark.parametrize("n,N,D,tile,col0", [(64, 64, 64, 64, 0), (64, 192, 128, 64, 128), (128, 256, 64, 128, 64), (128, 128, 192, 64, 0)])
-def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0):
+@pytest.mark.parametrize("n,N,D,tile,col0,waves", [(64, 64, 64, 64, 0, 0), (64, 192, 128, 64, 128, 0), (128, 256, 64, 128, 64, 1), (128, 256, 64, 128, 64, 2),
+                                                   (128, 384, 128, 128, 256, 2), (128, 128, 192, 64, 0, 0)])
+def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, waves):
     rng = np.random.default_rng(n + N + D + planes)
     s = 2.6593
     blocks = [(feats(rng, n, D, "ln"), feats(rng, N, D, "unit"), col0, 0.495), (feats(rng, n, D, "unit") * 3, feats(rng, N, D, "ln"), col0, 0.005)]
@@ -64,7 +65,7 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0):
         refs.append(logits_ref(q, k, planes, s))
     arr = (_abi.InfonceProblem * len(probs))(*probs)
     n_total = 2 * n
-    assert L.eegclip_infonce_fused_fwd(arr, len(probs), n, N, D, planes_arg(planes, tile), n_total, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
+    assert L.eegclip_infonce_fused_fwd(arr, len(probs), n, N, D, planes_arg(planes, tile, waves), n_total, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
     want_loss = 0.0
     for (q, k, c0, w), S, kp in zip(blocks, refs, keep):
         l_ref = lse(S)
@@ -78,7 +79,7 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0):
         q, k = blocks[0][0], blocks[0][1]
         assert np.abs(refs[0] - s * q.astype(np.float64) @ k.astype(np.float64).T).max() < 1e-4
     # gradient tiles: one normaliser (row-sharded blocks) ...
-    assert L.eegclip_infonce_fused_grad(arr, len(probs), n, N, D, planes_arg(planes, tile), n_total, be.ptr(SC), be.ptr(DS), be.stream) == 0
+    assert L.eegclip_infonce_fused_grad(arr, len(probs), n, N, D, planes_arg(planes, tile, waves), n_total, be.ptr(SC), be.ptr(DS), be.stream) == 0
     want_ds = 0.0
     for (q, k, c0, w), S, kp in zip(blocks, refs, keep):
         Pm = np.exp(S - lse(S)[:, None])
@@ -89,8 +90,8 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0):
     assert abs(float(be.host(DS)[0]) - want_ds) < 2e-5 * max(1.0, abs(want_ds))
 
 
-@pytest.mark.parametrize("planes,tile", [(1, 64), (2, 64), (2, 128)])
-def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes, tile):
+@pytest.mark.parametrize("planes,tile,waves", [(1, 64, 0), (2, 64, 0), (2, 128, 1), (2, 128, 2), (1, 128, 2)])
+def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes, tile, waves):
     """single-process ClipLoss: blocks (A, B) and (B, A); the gradient w.r.t. A needs G = c (P_row + P_col - 2 I): the row normaliser of
     the block and the row normaliser of the swapped block as `lse_k`"""
     rng = np.random.default_rng(5 + planes)
@@ -108,9 +109,9 @@ def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes
     p_ba = _abi.InfonceProblem(q_hi=be.ptr(bh), q_lo=be.ptr(bl), k_hi=be.ptr(ah), k_lo=be.ptr(al), col0=0, weight=0.5, part=be.ptr(bufs[1][0]),
                                diag=be.ptr(bufs[1][1]), lse=be.ptr(bufs[1][2]), lse_k=None, G=None, ldg=0)
     arr = (_abi.InfonceProblem * 2)(p_ab, p_ba)
-    assert L.eegclip_infonce_fused_fwd(arr, 2, n, n, D, planes_arg(planes, tile), n, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
+    assert L.eegclip_infonce_fused_fwd(arr, 2, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(LOSS), be.stream) == 0
     one = (_abi.InfonceProblem * 1)(p_ab)
-    assert L.eegclip_infonce_fused_grad(one, 1, n, n, D, planes_arg(planes, tile), n, be.ptr(SC), be.ptr(DS), be.stream) == 0
+    assert L.eegclip_infonce_fused_grad(one, 1, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(DS), be.stream) == 0
     S = logits_ref(a, b, planes, s)
     lr, lc = lse(S), lse(S.T)
     want = 0.5 / n * ((lr - np.diag(S)).sum() + (lc - np.diag(S)).sum())           # models/loss.py:136-139

@@ -64,11 +64,12 @@ def main():
                     for i in range(nblk):
                         arr[i], buf = problem(qp, bp_, n, N, planes, ws)
                         keep.append(buf)
-                    pl = planes | (tile << 8)
-                    assert L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st) == 0
-                    us = ev_us(lambda: L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st))
-                    row[f"fwd_planes{planes}_tile{tile or 'auto'}_blocks{nblk}"] = {"us": round(us, 2), "TF_algorithmic": round(nblk * flop / us / 1e6, 1),
-                                                                                     "frac": round(nblk * flop / us / 1e6 / PEAK, 4)}
+                    for waves in ((1, 2) if tile == 128 else (0,)):          # 128-tiles: 4 waves (one per SIMD) | 8 waves (two per SIMD, the default)
+                        pl = planes | (tile << 8) | (waves << 16)
+                        assert L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st) == 0
+                        us = ev_us(lambda: L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st))
+                        tag = f"fwd_planes{planes}_tile{tile or 'auto'}{'_waves' + str(4 * waves) if waves else ''}_blocks{nblk}"
+                        row[tag] = {"us": round(us, 2), "TF_algorithmic": round(nblk * flop / us / 1e6, 1), "frac": round(nblk * flop / us / 1e6 / PEAK, 4)}
             G = torch.empty(n, N, device="cuda")
             arr = (_abi.InfonceProblem * 1)()
             arr[0], buf = problem(qp, bp_, n, N, planes, ws, G=G)
