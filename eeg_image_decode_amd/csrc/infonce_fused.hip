@@ -57,29 +57,36 @@ struct if_geom {
     static constexpr int ROWB = 2 * BK;                       // bytes per LDS row
     static constexpr int NCH = BK / 8;                        // 16-byte chunks per row
     static constexpr int RPI = 1024 / ROWB;                   // rows one DMA instruction deposits
-    __device__ static __forceinline__ int swz(int row) { return NP == 1 ? (row >> 1) & 7 : (row >> 2) & 3; }
+    __device__ static __forceinline__ int swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
 // MODE 0 = forward partials, 1 = gradient tile.  (Round 3 also built a variant that staged the operand tiles through registers -- global_load_dwordx4
 // -> ds_write_b128, two LDS stages -- to test whether the DMA fill is the limit at N = 2048: measured SLOWER than the 4-stage DMA pipeline, 20.8 vs
 // 18.3 us per logits block; removed in round 4.)
-// NW = 4 | 8 waves per workgroup.  8 (TM = 128 only; round 4): 2 query halves x 4 key quarters, each wave 64 x 32 logits -- two waves per SIMD, so one
-// wave's fragment reads / waits run under the other's MFMAs.  The 4-wave kernel (one wave per SIMD, 128 KB of LDS per workgroup: nothing else on the CU)
-// had the matrix pipe 16 % (one product) / 24 % (three products) busy at N = 2048 with no saturated unit -- 36 % of the wave cycles parked, no LDS bank
-// conflicts, operands L2-resident at a fill rate 3x below what the CU can pull (profiles/r4_pmc_infonce.json, tools/micro/dma_rate.hip).
-template <int NP, int TM, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
+// NW = 4 | 8 MFMA waves per workgroup.  8 (TM = 128 only; round 4): 2 query halves x 4 key quarters, each wave 64 x 32 logits -- two waves per SIMD, so one
+// wave's fragment reads / waits run under the other's MFMAs.
+// NPRD = 0 | 4 PRODUCER waves (round 4).  What bounds the k-loop is the CU's vector-memory path, not the matrix pipe: a 128 x 128 x 64 bf16 k-tile is 32 KB
+// through the texture addresser / L1 at ~64 B/clk (measured 49-69 B/clk, tools/micro/tile_chain.hip, tools/micro/dma_rate.hip) = ~500-650 cycles, the same
+// ~512 cycles its 16 MFMAs take -- and a wave that issues both is IN ORDER: it stalls ~60 cycles in every LDS-DMA issue (the queue is full) with its MFMAs
+// unissued behind it, so the two costs add (1390 cycles per k-tile: 108 vmcnt wait + 76 barrier + 119 first fragments + 1085 reads/MFMAs/DMA issues; 830 of
+// the 1085 without the refills, 480 with the refills alone).  With NPRD = 4 the LDS-DMA instructions, their counted vmcnt waits and nothing else live in
+// four extra waves (one per SIMD, parked in the memory queue almost all the time); the MFMA waves issue no vector-memory instruction at all and meet the
+// producers at the one barrier per k-tile: 1090 cycles per k-tile in the micro-benchmark, 13.8 -> 10.1 us for the k-loops of one N = 2048 block.
+template <int NP, int TM, int MODE, int NW, int NPRD = 0>
+__global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale) {
     using Gm = if_geom<NP>;
     constexpr int BK = Gm::BK, ROWB = Gm::ROWB, NCH = Gm::NCH, RPI = Gm::RPI;
+    constexpr bool SPEC = NPRD > 0;
+    constexpr int NDW = SPEC ? NPRD : NW;                     // waves that issue LDS-DMA
     constexpr int NWK = NW / 2;                               // waves along the keys
     constexpr int WT = TM / 64;                               // 32x32 MFMA tiles per wave along the queries
     constexpr int WTK = TM / (32 * NWK);                      // ... along the keys
     constexpr int TILE_B = TM * ROWB;                         // bytes of one operand-plane tile
     constexpr int STAGE_B = 2 * NP * TILE_B;                  // q_hi | k_hi | (q_lo | k_lo)
-    constexpr int IPT = TM / RPI / NW;                        // DMA instructions per wave, tile and operand plane
-    constexpr int DPT = 2 * NP * IPT;                         // ... per wave and k-tile (what vmcnt counts)
-    static_assert(IPT >= 1 && WTK >= 1, "tile too small for this many waves");
+    constexpr int IPT = TM / RPI / NDW;                       // DMA instructions per DMA wave, tile and operand plane
+    constexpr int DPT = 2 * NP * IPT;                         // ... per DMA wave and k-tile (what vmcnt counts)
+    static_assert(IPT >= 1 && WTK >= 1 && 2 * DPT < 64, "tile too small for this many waves");
     EEG_LDS_BASE(unsigned char, lds);
 
     const int tiles = tiles_q * tiles_k;
@@ -92,15 +99,17 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
     const if_problem& P = tb.p[prob];
     const int q0 = (rem / tiles_k) * TM, k0r = (rem % tiles_k) * TM;
     const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6);
+    const bool producer = SPEC && wave >= NW;                 // (wave-uniform)
+    const int dw = SPEC ? wave - NW : wave;                   // index among the DMA waves (negative for the MFMA waves of the specialised form: unused there)
     const int wq = wave / NWK, wk = wave % NWK;
     const int r32 = lane & 31, h = lane >> 5;
 
-    // ---- DMA roles: wave w deposits rows [w * TM/NW, +TM/NW) of every operand-plane tile, instruction i = rows + RPI * i
+    // ---- DMA roles: DMA wave w deposits rows [w * TM/NDW, +TM/NDW) of every operand-plane tile, instruction i = rows + RPI * i
     const int drow = lane / NCH, dpos = lane % NCH;
     const unsigned short* src[2 * NP][IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
-        const int row = wave * (TM / NW) + RPI * i + drow;
+        const int row = (dw & (NDW - 1)) * (TM / NDW) + RPI * i + drow;
         const int col = 8 * (dpos ^ Gm::swz(row));
         src[0][i] = P.q_hi + (long long)(q0 + row) * D + col;
         src[1][i] = P.k_hi + (long long)(k0r + row) * D + col;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
     }
     auto issue_one = [&](int kt, int dnum) {                  // DMA instruction `dnum` (0 .. DPT-1) of k-tile kt
         const int o = dnum / IPT, i = dnum % IPT;
-        unsigned char* st = lds + (kt % IF_NS) * STAGE_B + wave * (TM / NW) * ROWB;
+        unsigned char* st = lds + (kt % IF_NS) * STAGE_B + (dw & (NDW - 1)) * (TM / NDW) * ROWB;
         lds_dma16(st + o * TILE_B + RPI * i * ROWB, src[o][i] + kt * BK);
     };
     auto issue_tile = [&](int kt) {
@@ -151,58 +160,77 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
     //     while the wave issues them).
     constexpr int NSTEP = BK / 16, MPS = WTK * WT * (NP == 2 ? 3 : 1), TOTAL = NSTEP * MPS;
     const int ktiles = D / BK;
-    {
-    #pragma unroll
+    auto wait_tile = [&](int kt) {                            // this wave's DMA of tile kt has landed (the newer tiles stay in flight)
+        const int newer = ktiles - 1 - kt < IF_NS - 2 ? ktiles - 1 - kt : IF_NS - 2;
+        if (newer >= 2) wait_vmcnt<2 * DPT>();
+        else if (newer == 1) wait_vmcnt<DPT>();
+        else wait_vmcnt<0>();
+    };
+    auto mfma_tile = [&](int kt, bool refill) {               // the MFMAs of k-tile kt (+ the refill DMA of tile kt + NS - 1 between them when this wave does both)
+        const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
+        bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
+        auto read_step = [&](int s, int set) {
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
+                if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+            }
+#pragma unroll
+            for (int j = 0; j < WTK; ++j) {
+                kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
+                if (NP == 2) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
+            }
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
+#endif
+            const int set = s & 1;
+#pragma unroll
+            for (int j = 0; j < WTK; ++j)
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
+                    if (NP == 2) {
+                        acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
+                        if (!SPEC && refill && ((m0_ + 1) * DPT) / TOTAL > (m0_ * DPT) / TOTAL) issue_one(kt + IF_NS - 1, (m0_ * DPT) / TOTAL);
+                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
+                        if (!SPEC && refill && ((m0_ + 2) * DPT) / TOTAL > ((m0_ + 1) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + 1) * DPT) / TOTAL);
+                    }
+                    constexpr int last = NP == 2 ? 2 : 0;
+                    acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
+                    if (!SPEC && refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
+                }
+#if !defined(EEG_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    if (!SPEC) {
+#pragma unroll
         for (int p = 0; p < IF_NS - 1; ++p)
             if (p < ktiles) issue_tile(p);
         for (int kt = 0; kt < ktiles; ++kt) {
-            const int newer = ktiles - 1 - kt < IF_NS - 2 ? ktiles - 1 - kt : IF_NS - 2;      // tiles issued after kt that may stay in flight
-            if (newer >= 2) wait_vmcnt<2 * DPT>();
-            else if (newer == 1) wait_vmcnt<DPT>();
-            else wait_vmcnt<0>();
+            wait_tile(kt);
             raw_barrier();                                        // tile kt has landed for every wave; the stage about to be refilled is drained
-            const bool refill = kt + IF_NS - 1 < ktiles;          // (workgroup-uniform)
-            const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
-            bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
-            auto read_step = [&](int s, int set) {
-    #pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
-                    if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
-                }
-    #pragma unroll
-                for (int j = 0; j < WTK; ++j) {
-                    kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
-                    if (NP == 2) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
-                }
-            };
-            read_step(0, 0);
-    #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
-    #if !defined(EEG_EMU)
-                __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
-    #endif
-                const int set = s & 1;
-    #pragma unroll
-                for (int j = 0; j < WTK; ++j)
-    #pragma unroll
-                    for (int i = 0; i < WT; ++i) {
-                        const int m0_ = s * MPS + (j * WT + i) * (NP == 2 ? 3 : 1);      // index of this accumulator's first MFMA within the tile
-                        if (NP == 2) {
-                            acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
-                            if (refill && ((m0_ + 1) * DPT) / TOTAL > (m0_ * DPT) / TOTAL) issue_one(kt + IF_NS - 1, (m0_ * DPT) / TOTAL);
-                            acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
-                            if (refill && ((m0_ + 2) * DPT) / TOTAL > ((m0_ + 1) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + 1) * DPT) / TOTAL);
-                        }
-                        constexpr int last = NP == 2 ? 2 : 0;
-                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
-                        if (refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
-                    }
-    #if !defined(EEG_EMU)
-                __builtin_amdgcn_sched_barrier(0);
-    #endif
-            }
+            mfma_tile(kt, kt + IF_NS - 1 < ktiles);               // (workgroup-uniform)
+        }
+    } else if (producer) {
+#pragma unroll
+        for (int p = 0; p < IF_NS - 1; ++p)
+            if (p < ktiles) issue_tile(p);
+        for (int kt = 0; kt < ktiles; ++kt) {
+            wait_tile(kt);
+            raw_barrier();                                        // the one meeting point of the two kinds of waves per k-tile
+            if (kt + IF_NS - 1 < ktiles) issue_tile(kt + IF_NS - 1);
+        }
+    } else {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            raw_barrier();
+            mfma_tile(kt, false);
         }
     }
 
@@ -220,6 +248,7 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
     const int p_col0 = P.col0;
     const float p_weight = P.weight;
     if (MODE == 0) {
+        if (producer) return;
         const int Pn = NWK * tiles_k;                         // partial slots per row: (key tile, wk)
         const int slot = NWK * (rem % tiles_k) + wk;
 #pragma unroll
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
         const float c = p_weight * inv_total;
         float ds = 0.f;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) {
+        for (int i = 0; i < (producer ? 0 : WT); ++i) {       // (the producer waves only take part in the reduction barriers below)
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
             const float lq = p_lse[q];
             const int kb = k0r + wk * (TM / NWK);
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void infonce_tile_kernel(const if_table tb
         ds = wave_sum(ds);
         __syncthreads();
         float* red = reinterpret_cast<float*>(lds);
-        if (lane == 0) red[wave] = ds;
+        if (lane == 0 && !producer) red[wave] = ds;
         __syncthreads();
         if (t == 0) {
             float tot = (red[0] + red[1]) + (red[2] + red[3]);
@@ -430,28 +459,36 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
     return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
 }
 
-#define EEG_IF_GO2(NP_, TM_, MODE_, NW_)                                                                                                                  \
-    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * NW_), (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, \
-               stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+#define EEG_IF_GO2(NP_, TM_, MODE_, NW_, NPRD_)                                                                                                            \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_, NPRD_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * (NW_ + NPRD_)),                            \
+               (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+#define EEG_IF_GO(NP_, TM_, NW_, NPRD_)                                                                                                                    \
+    do {                                                                                                                                                   \
+        if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, NPRD_);                                                                                                \
+        else EEG_IF_GO2(NP_, TM_, 1, NW_, NPRD_);                                                                                                          \
+    } while (0)
 
-// waves per workgroup: bits 16..17 of `planes` (tests / benches) 1 = 4 waves, 2 = 8 waves (128-tiles only), 0 = the library's choice: 8 for 128-tiles
-static int if_waves(int TM, int planes) {
+// wave layout: bits 16..17 of `planes` (tests / benches) 1 = 4 waves, 2 = 8 waves (128-tiles only), 3 = 4 MFMA waves + 4 producer waves,
+// 0 = the library's choice: the producer form, except 8 waves for 128-tiles with one product (kernel durations at N = 2048, 256 workgroups, one product:
+// 12.9 / 12.0 / 12.6 us for 4 / 8 / 4+4 waves; three products: 27.2 / 26.8 / 26.6; 64-tiles, a rank's two 256 x 2048 blocks: 7.8 -> 7.2 and 12.8 -> 10.8 us)
+static int if_wsel(int TM, int planes) {
     const int w = (planes >> 16) & 3;
-    return TM == 128 && w != 1 ? 8 : 4;
+    if (w == 0) return (TM == 128 && (planes & 0xff) == 1) ? 2 : 3;
+    return (w == 2 && TM != 128) ? 1 : w;
 }
+// MFMA waves along the keys (= partial slots per key tile)
+static int if_waves(int TM, int planes) { return if_wsel(TM, planes) == 2 ? 8 : 4; }
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream) {
-    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM, NW = if_waves(TM, planes);
+    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
     planes &= 0xff;
     if (planes == 1) {
-        if (TM == 128 && NW == 8) { if (mode == 0) EEG_IF_GO2(1, 128, 0, 8); else EEG_IF_GO2(1, 128, 1, 8); }
-        else if (TM == 128)       { if (mode == 0) EEG_IF_GO2(1, 128, 0, 4); else EEG_IF_GO2(1, 128, 1, 4); }
-        else                      { if (mode == 0) EEG_IF_GO2(1, 64, 0, 4);  else EEG_IF_GO2(1, 64, 1, 4); }
+        if (TM == 128) { if (wsel == 3) EEG_IF_GO(1, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO(1, 128, 4, 0); }
+        else           { if (wsel == 3) EEG_IF_GO(1, 64, 4, 4); else EEG_IF_GO(1, 64, 4, 0); }
     } else {
-        if (TM == 128 && NW == 8) { if (mode == 0) EEG_IF_GO2(2, 128, 0, 8); else EEG_IF_GO2(2, 128, 1, 8); }
-        else if (TM == 128)       { if (mode == 0) EEG_IF_GO2(2, 128, 0, 4); else EEG_IF_GO2(2, 128, 1, 4); }
-        else                      { if (mode == 0) EEG_IF_GO2(2, 64, 0, 4);  else EEG_IF_GO2(2, 64, 1, 4); }
+        if (TM == 128) { if (wsel == 3) EEG_IF_GO(2, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(2, 128, 8, 0); else EEG_IF_GO(2, 128, 4, 0); }
+        else           { if (wsel == 3) EEG_IF_GO(2, 64, 4, 4); else EEG_IF_GO(2, 64, 4, 0); }
     }
     return (int)hipGetLastError();
 }

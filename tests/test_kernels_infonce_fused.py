@@ -11,7 +11,7 @@ from test_kernels_gemm_x3 import bf16_round, split
 
 
 def planes_arg(planes, tile, waves=0):
-    """planes | tile size << 8 (0 = the library's choice) | waves per workgroup << 16 (1 = 4 waves, 2 = 8 waves: 128-tiles only, 0 = the library's choice)"""
+    """planes | tile size << 8 (0 = the library's choice) | waves per workgroup << 16 (1 = 4 waves, 2 = 8 waves: 128-tiles only, 3 = 4 MFMA waves + 4 producer waves, 0 = the library's choice)"""
     return planes | (tile << 8) | (waves << 16)
 
 
@@ -46,7 +46,7 @@ def lse(x):
 
 @pytest.mark.parametrize("planes", [1, 2])
 @pytest.mark.parametrize("n,N,D,tile,col0,waves", [(64, 64, 64, 64, 0, 0), (64, 192, 128, 64, 128, 0), (128, 256, 64, 128, 64, 1), (128, 256, 64, 128, 64, 2),
-                                                   (128, 384, 128, 128, 256, 2), (128, 128, 192, 64, 0, 0)])
+                                                   (128, 384, 128, 128, 256, 2), (128, 384, 128, 128, 256, 3), (128, 128, 192, 64, 0, 0), (64, 192, 128, 64, 128, 1)])
 def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, waves):
     rng = np.random.default_rng(n + N + D + planes)
     s = 2.6593
@@ -90,7 +90,7 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, wave
     assert abs(float(be.host(DS)[0]) - want_ds) < 2e-5 * max(1.0, abs(want_ds))
 
 
-@pytest.mark.parametrize("planes,tile,waves", [(1, 64, 0), (2, 64, 0), (2, 128, 1), (2, 128, 2), (1, 128, 2)])
+@pytest.mark.parametrize("planes,tile,waves", [(1, 64, 0), (2, 64, 1), (2, 128, 1), (2, 128, 2), (1, 128, 2), (1, 128, 3), (2, 128, 0)])
 def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes, tile, waves):
     """single-process ClipLoss: blocks (A, B) and (B, A); the gradient w.r.t. A needs G = c (P_row + P_col - 2 I): the row normaliser of
     the block and the row normaliser of the swapped block as `lse_k`"""

@@ -64,11 +64,11 @@ def main():
                     for i in range(nblk):
                         arr[i], buf = problem(qp, bp_, n, N, planes, ws)
                         keep.append(buf)
-                    for waves in ((1, 2) if tile == 128 else (0,)):          # 128-tiles: 4 waves (one per SIMD) | 8 waves (two per SIMD, the default)
+                    for waves in ((1, 2, 3) if tile == 128 else (1, 3) if tile == 64 else (0,)):          # 4 waves (one per SIMD) | 8 waves (two per SIMD; 128-tiles) | 4 MFMA + 4 producer waves (the default)
                         pl = planes | (tile << 8) | (waves << 16)
                         assert L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st) == 0
                         us = ev_us(lambda: L.eegclip_infonce_fused_fwd(arr, nblk, n, N, Dm, pl, n, sc.data_ptr(), acc.data_ptr(), st))
-                        tag = f"fwd_planes{planes}_tile{tile or 'auto'}{'_waves' + str(4 * waves) if waves else ''}_blocks{nblk}"
+                        tag = f"fwd_planes{planes}_tile{tile or 'auto'}{'_' + {1: 'waves4', 2: 'waves8', 3: 'waves4+4producers'}[waves] if waves else ''}_blocks{nblk}"
                         row[tag] = {"us": round(us, 2), "TF_algorithmic": round(nblk * flop / us / 1e6, 1), "frac": round(nblk * flop / us / 1e6 / PEAK, 4)}
             G = torch.empty(n, N, device="cuda")
             arr = (_abi.InfonceProblem * 1)()
