@@ -246,6 +246,7 @@ def secondary():
     section("infonce_global_batch_2048", _sec_infonce)
     section("infonce_per_rank_block", _sec_infonce_per_rank)
     section("exact_fp32_products", _sec_exact_fp32)
+    section("bench_joint", _sec_joint)
     section("prior_train_batch_1024", _sec_prior_train)
     section("prior_sampling_chain", _sec_prior_chain)
     section("sdxl_cross_attention", _sec_cross_attn)
@@ -362,6 +363,36 @@ def _sec_exact_fp32(B=256, steps=20):
             os.environ.pop("EEGCLIP_GEMM_PRECISION", None)
         else:
             os.environ["EEGCLIP_GEMM_PRECISION"] = old
+
+
+def _sec_joint(B=256, steps=24):
+    """the joint-subject model (one value embedding per subject, Retrieval/ATMS_retrieval_joint_train.py:172-192) -- the same step on
+    batches that MIX the ten subjects (the general case; the reference's own loop feeds one subject per batch, which is the `uniform` line)"""
+    from eeg_image_decode_amd import optim, retrieval
+    from eeg_image_decode_amd.retrieval_joint import ATMS as JointATMS
+    _, _, pool, classes = build(1, 0, B)
+    torch.manual_seed(0)
+    model = JointATMS(joint_train=True).cuda().train()
+    opt = optim.AdamW(model.parameters(), lr=3e-4)
+    loss_acc, correct = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(3)
+    out = {"workload": "configs[1] step with the joint-subject model (10 value embeddings), B = 256, 1 GPU"}
+    for label, ids in (("mixed", [rng.integers(0, 10, B).tolist() for _ in pool]), ("uniform", [int(i) for i in range(len(pool))])):
+        def step(i):
+            d = pool[i % len(pool)]
+            retrieval.contrastive_step(model, opt, d["eeg"], ids[i % len(pool)], d["img"], d["txt"], d["labels"], classes, loss_acc, correct)
+        for i in range(8):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[label] = {"steps": steps, "ms_per_step": round(1e3 * dt / steps, 4), "samples_per_s": round(B * steps / dt, 1)}
+    eng = model._engine()
+    out["fused_block"] = any(k[0] == "f" and "eegclip_token_block_fwd" in pl.op_names() for k, pl in eng.plans.items())
+    return out
 
 
 def _sec_prior_train(B=1024, batches=6):

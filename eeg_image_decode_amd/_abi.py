@@ -47,7 +47,8 @@ class TokenBlockDesc(C.Structure):
                 + [(k, C.c_void_p) for k in ("h", "qkv", "r1", "mu1", "rs1", "f1", "r2", "n2", "mu2", "rs2", "n3", "mu3", "rs3")]
                 + [(k, C.c_void_p) for k in ("xp", "hp", "ctxp", "n1p", "g1p")]
                 + [("drop_p", C.c_float), ("eps", C.c_float), ("scale", C.c_float), ("seed", C.c_ulonglong)]
-                + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")])
+                + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")]
+                + [("packed_embed", C.c_void_p), ("embed_subject", C.c_void_p), ("bv_stride", C.c_longlong)])
 
 
 class TokenBlockBwdDesc(C.Structure):
@@ -61,7 +62,8 @@ class TokenBlockBwdDesc(C.Structure):
 
 class WgradTokProblem(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("a_group_stride", C.c_longlong), ("m_groups", C.c_int), ("heads_m", C.c_int), ("heads_n", C.c_int),
-                ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("bias_mfma", C.c_int)]
+                ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("bias_mfma", C.c_int),
+                ("sample0", C.c_int), ("samples", C.c_int), ("sample_index", C.c_void_p)]
 
 
 PLAN_MAX_ARGS = 24
@@ -78,7 +80,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -159,6 +161,8 @@ PROTOTYPES = {
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_token_block_packed_bytes": [],
     "eegclip_token_block_pack": [_P, _P, _P, _P, _P, _P, _P],
+    "eegclip_token_block_packed_embed_bytes": [_I],
+    "eegclip_token_block_pack_embed": [_P, _L, _I, _P, _P],
     "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],
     "eegclip_token_block_bwd_workspace_floats": [_I],
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi
-from ._lib import EegclipError, lib, raw_stream, require_cuda
+from ._lib import EegclipError, current_stream, lib, raw_stream, require_cuda
 from .loss import ClipLoss
 from .plan import Plan
 
@@ -429,9 +429,10 @@ class _Engine:
         return (None, None, 0), items
 
     def _token_block_enabled(self, pl):
-        """the fused transformer-block forward (csrc/token_block.hip): the single-subject model in the default split-bf16 arithmetic;
-        EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan (diagnosis, A/B timing)"""
-        return (not self.joint) and pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
+        """the fused transformer-block forward (csrc/token_block.hip) in the default split-bf16 arithmetic -- since round 4 also for the joint-subject
+        model (its value embedding is a per-sample weight base inside the kernel); EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan
+        (diagnosis, A/B timing)"""
+        return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
 
     def _token_planes(self, b, B, *names):
         """token-plane tensors (csrc/wgrad_tok.hip layout: per sample [hi | lo][64 tokens][256 channels] bf16) the fused kernels write for the
@@ -480,7 +481,8 @@ class _Engine:
             bn=f(4, C_TS), ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
         if self.joint:         # subject-ordered copies for batches that arrive in another order (see _build_fwd)
-            b.update(xs=f(B, N_CH, T_LEN), hs=f(B, L_TOK, D_MODEL), perm=torch.zeros(B, dtype=torch.int32, device=dev))
+            jmeta = torch.zeros(2 * B, dtype=torch.int32, device=dev)      # [subject of sample b | the batch's sample numbers ordered by subject]
+            b.update(xs=f(B, N_CH, T_LEN), hs=f(B, L_TOK, D_MODEL), jmeta=jmeta, subj32=jmeta[:B], perm=jmeta[B:])
         # everything a plan must clear before use lives in two arenas (forward / backward): ONE memset each instead of five
         nsum = 2 * 2 * C_TS                                        # two BatchNorm sum rows of 2C doubles per direction
         ny2 = (B * C_TS * W_TS + 1) // 2                          # y2 (B,40,36) f32: the K-split spatial conv accumulates into it
@@ -529,14 +531,27 @@ class _Engine:
             # prologue / epilogue and activation round trips, not by their K ~ 250 contractions
             if not hasattr(self, "tb_packed"):
                 self.tb_packed = torch.empty(int(lib().eegclip_token_block_packed_bytes()) // 2, dtype=torch.bfloat16, device=self.device)
-            pl.call("eegclip_token_block_pack", _p(P[_E + "value_embedding.weight"]), _p(P[_LY + "attention.query_projection.weight"]),
+            ve_w0, ve_b0 = (self.ve_keys[0] if self.joint else (_E + "value_embedding.weight", _E + "value_embedding.bias"))
+            pl.call("eegclip_token_block_pack", _p(P[ve_w0]), _p(P[_LY + "attention.query_projection.weight"]),
                     _p(P[_LY + "attention.out_projection.weight"]), _p(P[_LY + "conv1.weight"]), _p(P[_LY + "conv2.weight"]), _p(self.tb_packed))
+            joint_args = {}
+            if self.joint:
+                # joint-subject model (Embed.py:127-131,142-144): every subject's value embedding packed behind one another (they are equally spaced in
+                # the flat parameter buffer); the kernel takes sample b's matrix and bias from its subject id -- no subject-ordered copy of the batch
+                ve_stride = (P[self.ve_keys[1][0]].data_ptr() - P[ve_w0].data_ptr()) // 4 if self.n_subj > 1 else D_MODEL * T_LEN
+                assert all(P[w].data_ptr() - P[ve_w0].data_ptr() == 4 * ve_stride * i and P[bk].data_ptr() - P[ve_b0].data_ptr() == 4 * ve_stride * i
+                           for i, (w, bk) in enumerate(self.ve_keys)), "value embeddings are not equally spaced in the flat buffer"
+                if not hasattr(self, "tb_packed_embed"):
+                    self.tb_packed_embed = torch.empty(int(lib().eegclip_token_block_packed_embed_bytes(self.n_subj)) // 2, dtype=torch.bfloat16,
+                                                       device=self.device)
+                pl.call("eegclip_token_block_pack_embed", _p(P[ve_w0]), ve_stride, self.n_subj, _p(self.tb_packed_embed))
+                joint_args = dict(packed_embed=_p(self.tb_packed_embed), embed_subject=_p(b["subj32"]), bv_stride=ve_stride)
             tok = P[_TOK_SHARED] if shared else P[_TOK_TABLE]
             # the X operands of the block's weight gradients leave as token planes (what the kernel holds in LDS), not fp32: h keeps its fp32 copy
             # too (the residual of the attention sublayer re-reads it), ctx / n1 / g1 exist only as planes; n2 is re-evaluated by the backward
             xp, hp, ctxp, n1p, g1p = self._token_planes(b, B, "xp", "hp", "ctxp", "n1p", "g1p")
             pl.tb_desc = pl.call_desc("eegclip_token_block_fwd", _abi.TokenBlockDesc(
-                B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[_E + "value_embedding.bias"]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]),
+                B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[ve_b0]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]), **joint_args,
                 bqkv=_p(P[_LY + "attention.query_projection.bias"]), bo=_p(P[_LY + "attention.out_projection.bias"]), ln1_g=_p(P[_LY + "norm1.weight"]),
                 ln1_b=_p(P[_LY + "norm1.bias"]), b1=_p(P[_LY + "conv1.bias"]), b2=_p(P[_LY + "conv2.bias"]), ln2_g=_p(P[_LY + "norm2.weight"]),
                 ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), ln3_b=_p(P["encoder.encoder.norm.bias"]),
@@ -797,21 +812,23 @@ class _Engine:
                 pl._seed_descs.append(bd)
             variant = 0                                                               # 512-thread workgroups (256-thread: 28.9 vs 25.0 us, csrc/wgrad_tok.hip)
 
-            def wgrad_tok(tag, problems, side=True):
+            def wgrad_tok(tag, problems, side=True, slices=None, index=None):
                 """the block's weight gradients from the token planes the fused kernels leave (csrc/wgrad_tok.hip): `problems` become ready together
                 and run as ONE launch + one ordered slab reduction.  (name, dY planes, groups, X planes, M, N, heads_m, heads_n, bias, bias_mfma)"""
                 arr = (_abi.WgradTokProblem * len(problems))()
                 for i, (name, a, mg, x, M, N, hm, hn, bias, bm) in enumerate(problems):
                     arr[i] = _abi.WgradTokProblem(a=a, b=x, a_group_stride=B * 65536 if mg > 1 else 0, m_groups=mg, heads_m=hm, heads_n=hn, M=M, N=N,
-                                                  out=_p(G[name]), ldo=N, bias_out=_p(G[bias]) if bias else None, bias_mfma=bm)
+                                                  out=_p(G[name]), ldo=N, bias_out=_p(G[bias]) if bias else None, bias_mfma=bm, sample_index=index)
                 groups = sum(q[2] for q in problems)
-                slices = wsk if wsk > 0 else int(lib().eegclip_wgrad_tok_slices(groups, B))
+                slices = slices or (wsk if wsk > 0 else int(lib().eegclip_wgrad_tok_slices(groups, B)))
                 key = "wk:" + tag
                 if key not in b:
                     b[key] = torch.empty(int(lib().eegclip_wgrad_tok_workspace_floats(arr, len(problems), B, slices)), dtype=torch.float32, device=self.device)
                 pl._keep.append(arr)
+                ops = (len(pl.ops), len(pl.ops) + 1)
                 pl.call("eegclip_wgrad_tok", arr, len(problems), B, slices, _p(b[key]), variant, side=side)
                 pl.call("eegclip_wgrad_tok_reduce", arr, len(problems), B, slices, _p(b[key]), side=side)
+                return arr, ops
 
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
@@ -867,7 +884,25 @@ class _Engine:
         if fused:
             # value embedding: dY = the token-row gradients part 1 left as planes, X = the EEG sample planes of the forward (row 0 zero: the subject
             # token has no EEG row; ones column in rows 1..63: bias gradient = sum of the 63 channel rows of every sample)
-            wgrad_tok("embed", [(_E + "value_embedding.weight", dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, _E + "value_embedding.bias", 0)], side=False)
+            if not self.joint:
+                wgrad_tok("embed", [(_E + "value_embedding.weight", dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, _E + "value_embedding.bias", 0)], side=False)
+            else:
+                # joint-subject model: one problem per subject PRESENT in the batch, each contracting over that subject's samples only -- a range of
+                # the subject-ordered sample list b["perm"] (the planes stay in batch order: the kernel looks the sample up per k-tile).  The member
+                # problems, their count and sample ranges are patched per call (_joint_layout); absent subjects get no gradient (their .grad stays
+                # None as in the reference, Embed.py:142-144).
+                pl.j_wk_template = [(w, dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, bk, 0) for w, bk in self.ve_keys]
+                # K slices per subject so that (subjects present) x 4 tiles x slices fills the chip: 32 for one subject .. 6 for ten; the workspace takes
+                # the largest product
+                pl.j_wk_slices = [0] + [max(1, min(32, 2 * B // 4, (64 // n) // 8 * 8 if 64 // n >= 8 else 64 // n)) for n in range(1, self.n_subj + 1)]
+                pl.j_wk_arr, pl.j_wk_ops = wgrad_tok("embed_joint", pl.j_wk_template, side=False, slices=8, index=_p(b["perm"]))
+                need = max(int(lib().eegclip_wgrad_tok_workspace_floats(pl.j_wk_arr, n, B, pl.j_wk_slices[n])) for n in range(1, self.n_subj + 1))
+                if b["wk:embed_joint"].numel() < need:
+                    b["wk:embed_joint"] = torch.empty(need, dtype=torch.float32, device=self.device)
+                    for op in pl.j_wk_ops:
+                        pl.set_arg(op, 4, _p(b["wk:embed_joint"]))
+                pl.j_wk_all = (_abi.WgradTokProblem * self.n_subj)(*pl.j_wk_arr)          # (the per-subject originals; j_wk_arr holds this batch's members)
+                pl._keep.append(pl.j_wk_all)
         elif not self.joint:
             pl.x_gemm = pl.gemm(D_MODEL, T_LEN, B * N_CH, _p(b["dr1"]) + 4 * D_MODEL, D(1), hmap, 0, D(T_LEN), D(1),
                     _p(G[_E + "value_embedding.weight"]), D(T_LEN), D(1), accumulate=1, split_k=sk(B * N_CH),
@@ -876,6 +911,8 @@ class _Engine:
             if want_dx:
                 pl.gemm(B * N_CH, T_LEN, D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, hmap, D(1),
                         _p(P[_E + "value_embedding.weight"]), D(T_LEN), D(1), _p(b["dx"]), D(T_LEN), D(1))
+        elif fused and not want_dx:
+            pass                                   # (the weight gradients above are all the joint-subject value embedding needs)
         else:
             # per-subject weight gradients over the subject-ordered batch (mirror of the forward: gather the token-row gradients into
             # subject order first when the batch is not; xs still holds the gathered EEG)
@@ -883,9 +920,10 @@ class _Engine:
             pl.j_gather = len(pl.ops)
             pl.call("eegclip_gather_rows", _p(b["hs"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["dr1"]) + 4 * D_MODEL, L_TOK * D_MODEL, _p(b["perm"]), B,
                     N_CH * D_MODEL, 0)
-            pl.j_gemm = [pl.desc(D_MODEL, T_LEN, N_CH, 0, D(1), hmap, 0, D(T_LEN), D(1), _p(G[w]), D(T_LEN), D(1), accumulate=1, split_k=1,
-                                 rowsum_a=_p(G[bk])) for w, bk in self.ve_keys]
-            pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)
+            if not fused:
+                pl.j_gemm = [pl.desc(D_MODEL, T_LEN, N_CH, 0, D(1), hmap, 0, D(T_LEN), D(1), _p(G[w]), D(T_LEN), D(1), accumulate=1, split_k=1,
+                                     rowsum_a=_p(G[bk])) for w, bk in self.ve_keys]
+                pl.j_arr, pl.j_group = pl.gemm_grouped(self.n_subj)
             if want_dx:
                 b["dxs"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
                 pl.j_dx = [pl.desc(N_CH, T_LEN, D_MODEL, 0, hmap, D(1), _p(P[w]), D(T_LEN), D(1), 0, D(T_LEN), D(1)) for w, _ in self.ve_keys]
@@ -912,10 +950,31 @@ class _Engine:
     def _joint_layout(self, pl, b, B, host_ids, x_ptr, backward):
         """Point the per-subject GEMMs of a joint-model plan at this batch: subject blocks of the subject-ordered batch (the batch itself if its
         ids are already non-decreasing, else the gathered copy xs / hs)."""
+        fused = getattr(pl, "tb_desc", None) is not None or hasattr(pl, "j_wk_arr") or getattr(pl, "j_fused", False)
         if not backward:
             a = np.asarray(host_ids, dtype=np.int64)
             in_order = bool((a[1:] >= a[:-1]).all())
-            if not in_order:
+            if fused:
+                # the fused block takes each sample's value embedding from its subject id; the backward's per-subject weight gradients walk the
+                # subject-ordered sample list (identity when the batch is already ordered).  Both go up in ONE asynchronous copy from a pinned
+                # staging buffer (a ring: the copy of step i may still be in flight when step i + 1 fills the next slot) -- a blocking copy_ from
+                # pageable memory would make the host wait for everything queued on the stream, every step
+                perm = np.argsort(a, kind="stable")
+                on_gpu = b["jmeta"].is_cuda
+                ring = b.setdefault("jmeta_ring", [[torch.empty(2 * B, dtype=torch.int32).pin_memory() if on_gpu else torch.empty(2 * B, dtype=torch.int32),
+                                                    None] for _ in range(8)])
+                slot = ring[b.get("jmeta_i", 0) % len(ring)]
+                b["jmeta_i"] = b.get("jmeta_i", 0) + 1
+                if slot[1] is not None:
+                    slot[1].synchronize()                   # (the copy that last read this slot, 8 steps ago: long complete unless the host runs far ahead)
+                stage = slot[0].numpy()
+                stage[:B], stage[B:] = a, perm
+                b["jmeta"].copy_(slot[0], non_blocking=True)
+                if on_gpu:
+                    slot[1] = slot[1] or torch.cuda.Event()
+                    slot[1].record(current_stream())
+                a = a[perm]
+            elif not in_order:
                 perm = np.argsort(a, kind="stable")
                 b["perm"].copy_(torch.from_numpy(perm.astype(np.int32)))
                 a = a[perm]
@@ -925,8 +984,22 @@ class _Engine:
             b["in_order"] = in_order
         segs, in_order = b["segs"], b["in_order"]
         XR, HR = 4 * N_CH * T_LEN, 4 * L_TOK * D_MODEL
+        if fused and not backward:
+            pl.tb_desc.x = x_ptr
+            return
         skip = set()
         has_dx = hasattr(pl, "j_dx")
+        has_gemm = hasattr(pl, "j_gemm")
+        if hasattr(pl, "j_wk_arr"):
+            for i, (s_, st, n) in enumerate(segs):
+                q = pl.j_wk_all[s_]
+                q.sample0, q.samples = st, n
+                pl.j_wk_arr[i] = q                           # struct copy: the members of this batch, in subject order
+            for op in pl.j_wk_ops:
+                pl.set_arg(op, 1, len(segs))
+                pl.set_arg(op, 3, pl.j_wk_slices[len(segs)])
+            if not has_dx:
+                return
         if in_order:
             skip.add(pl.j_gather)
             if not backward or has_dx:
@@ -940,15 +1013,17 @@ class _Engine:
         else:
             xb, gb = (x_ptr, _p(b["dr1"])) if in_order else (_p(b["xs"]), _p(b["hs"]))
             for s, st, n in segs:
-                d = pl.j_gemm[s]
-                d.K, d.A, d.B = n * N_CH, gb + st * HR + 4 * D_MODEL, xb + st * XR
-                d.split_k = max(1, min(16, n * N_CH // 256))
+                if has_gemm:
+                    d = pl.j_gemm[s]
+                    d.K, d.A, d.B = n * N_CH, gb + st * HR + 4 * D_MODEL, xb + st * XR
+                    d.split_k = max(1, min(16, n * N_CH // 256))
                 if has_dx:
                     d = pl.j_dx[s]
                     d.M, d.A, d.C = n * N_CH, gb + st * HR + 4 * D_MODEL, (_p(b["dx"]) if in_order else _p(b["dxs"])) + st * XR
-        for i, (s, _, _) in enumerate(segs):
-            pl.j_arr[i] = pl.j_gemm[s]                   # struct copy: the members of this batch, in subject order
-        pl.set_arg(pl.j_group, 1, len(segs))
+        if has_gemm:
+            for i, (s, _, _) in enumerate(segs):
+                pl.j_arr[i] = pl.j_gemm[s]                   # struct copy: the members of this batch, in subject order
+            pl.set_arg(pl.j_group, 1, len(segs))
         if has_dx:
             for i, (s, _, _) in enumerate(segs):
                 pl.j_dx_arr[i] = pl.j_dx[s]

@@ -306,6 +306,9 @@ struct tb_fwd_args {
     unsigned site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
     unsigned dbg;                                                // diagnosis (EEGCLIP_TB_DEBUG): bit 0 = leave out the activation stores (timing ablation only)
     unsigned long long* tstamp;                                  // diagnosis (bit 1): [B][16] s_memtime stamps of wave 0 at the phase boundaries
+    const unsigned short* packed_embed;                          // joint-subject model: one packed value embedding per subject (null: the one in `packed`)
+    const int* embed_subject;                                    // ... (B) the sample's subject: matrix and bias row
+    long long bv_stride;                                         // ... floats between the subjects' biases
 };
 
 // phase stamp of the diagnosis build path: the shader clock as wave 0 passes phase boundary k
@@ -654,13 +657,17 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_V + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        // (joint-subject model, Embed.py:142-144: the sample's subject picks the Linear -- a workgroup-uniform base, nothing else changes)
+        const int vs = a.embed_subject ? a.embed_subject[b] : 0;
+        const unsigned short* const wv = a.embed_subject ? a.packed_embed + (long long)vs * TB_MAT_ELEMS : a.packed + TB_OFF_V;
+        const float* const bvp = a.bv + (long long)vs * a.bv_stride;
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, wv + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         const long long id = a.ids ? a.ids[b] : 0;
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             f32x4 o;
             if (m == 0) o = tb_ld4(a.tokens + id * TB_D + n0, valid);
             else {
-                const f32x4 bias = tb_ld4(a.bv + n0, valid), pe = tb_ld4(a.pe + (long long)(m - 1) * TB_D + n0, valid);
+                const f32x4 bias = tb_ld4(bvp + n0, valid), pe = tb_ld4(a.pe + (long long)(m - 1) * TB_D + n0, valid);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (v[i] + bias[i]) + pe[i];
             }
@@ -1202,6 +1209,44 @@ extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, cons
     return (int)hipGetLastError();
 }
 
+// the value embeddings of a joint-subject model: matrix s (nn.Linear (250, 250) at w0 + s * w_stride floats) -> out + s * one packed operand
+namespace eeg {
+__global__ __launch_bounds__(64) void token_block_pack_embed_kernel(const float* __restrict__ w0, long long w_stride, unsigned short* __restrict__ out) {
+    const int tile = blockIdx.x, s = blockIdx.y;
+    const int nt = tile / TB_KS, ks = tile % TB_KS;
+    const int lane = threadIdx.x & 63;
+    const int n = 16 * nt + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    const float* src = w0 + (long long)s * w_stride;
+    unsigned hb[8], lb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const long long si = tb_src_index(0, n, k0 + e);
+        const float v = si >= 0 ? src[si] : 0.f;
+        const unsigned short h = f32_to_bf16_bits(v);
+        hb[e] = h;
+        lb[e] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+    }
+    unsigned short* dst = out + (long long)s * TB_MAT_ELEMS + (long long)tile * TB_TILE + lane * 8;
+    tb_u4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        oh[e] = hb[2 * e] | (hb[2 * e + 1] << 16);
+        ol[e] = lb[2 * e] | (lb[2 * e + 1] << 16);
+    }
+    *reinterpret_cast<tb_u4*>(dst) = oh;
+    *reinterpret_cast<tb_u4*>(dst + 512) = ol;
+}
+}  // namespace eeg
+
+extern "C" long long eegclip_token_block_packed_embed_bytes(int n_subjects) { return n_subjects < 1 ? 0 : (long long)n_subjects * TB_MAT_ELEMS * 2; }
+
+extern "C" int eegclip_token_block_pack_embed(const float* w0, long long w_stride, int n_subjects, void* out, void* stream) {
+    if (!w0 || !out || n_subjects < 1 || n_subjects > 65535 || w_stride < (long long)TB_D * TB_T) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(out) & 15u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(token_block_pack_embed_kernel, dim3(16 * TB_KS, (unsigned)n_subjects), dim3(64), 0, stream, w0, w_stride, static_cast<unsigned short*>(out));
+    return (int)hipGetLastError();
+}
+
 extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream) {
     if (!d || d->B < 1 || !d->x || !d->packed || !d->bv || !d->pe || !d->tokens || !d->bqkv || !d->bo || !d->ln1_g || !d->ln1_b || !d->b1 || !d->b2 ||
         !d->ln2_g || !d->ln2_b || !d->ln3_g || !d->ln3_b || !d->h || !d->qkv || !d->ctxp || !d->r1 || !d->n1p || !d->mu1 || !d->rs1 || !d->f1 || !d->g1p ||
@@ -1222,7 +1267,9 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
                   d->ln2_g, d->ln2_b, d->ln3_g, d->ln3_b, d->h, d->qkv, d->r1, d->mu1, d->rs1, d->f1, d->r2, d->n2, d->mu2, d->rs2,
                   d->n3, d->mu3, d->rs3, static_cast<unsigned char*>(d->xp), static_cast<unsigned char*>(d->hp), static_cast<unsigned char*>(d->ctxp),
                   static_cast<unsigned char*>(d->n1p), static_cast<unsigned char*>(d->g1p), d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn,
-                  d->site_attn_out, d->site_ffn_act, d->site_ffn_out, 0u, nullptr};
+                  d->site_attn_out, d->site_ffn_act, d->site_ffn_out, 0u, nullptr, static_cast<const unsigned short*>(d->packed_embed), d->embed_subject,
+                  d->embed_subject ? d->bv_stride : 0};
+    if (d->embed_subject && (!d->packed_embed || (reinterpret_cast<uintptr_t>(d->packed_embed) & 15u) || d->bv_stride < 0 || (d->bv_stride & 1))) return EEGCLIP_EINVAL;
     static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
     a.dbg = dbg;
     a.tstamp = nullptr;

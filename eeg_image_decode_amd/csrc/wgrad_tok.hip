@@ -31,7 +31,7 @@ constexpr int WK_ROWB = 256;                                 // bytes per LDS ro
 constexpr int WK_TILE = WK_BK * WK_ROWB;                     // one operand-plane tile: 8 KB
 constexpr int WK_STAGE = 4 * WK_TILE;                        // A hi | A lo | B hi | B lo
 constexpr int WK_SAMPLE = 65536, WK_PLANE = 32768, WK_TOKB = 512;      // bytes: sample block, plane, token row of the global layout
-constexpr int WK_MAXP = 4;
+constexpr int WK_MAXP = 12;                                // (the joint-subject value embedding: one problem per subject of the batch)
 
 struct wk_problem {
     const unsigned char* a;                                  // dY planes
@@ -41,9 +41,11 @@ struct wk_problem {
     int m_tiles;                                             // 128-channel tiles of A: 2 per group
     int bias_mfma;                                           // bias gradient through an all-ones fragment (X has no spare column)
     int first_block;                                         // first workgroup of this problem in the launch
+    int sample0, ktiles;                                     // the contraction runs over samples sample0 .. of the (indexed) batch: 2 k-tiles per sample
 };
 struct wk_table {
     wk_problem p[WK_MAXP];
+    const int* index;                                        // IDX: position -> sample of the batch (one subject's samples are a range of positions)
     int n;
 };
 
@@ -63,8 +65,8 @@ __device__ __forceinline__ wk_s4 wk_tr_read(const unsigned char* p) {
 #endif
 }
 
-template <int WN, int WK_NS>
-__global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int ktiles_all, int slices) {
+template <int WN, int WK_NS, bool IDX>
+__global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int slices) {
     constexpr int NWAVE = 2 * WN, NT = 8 / WN;               // n-tiles of 16 per wave
     constexpr int IPW = 32 / NWAVE;                          // DMA instructions (1 KB each) per wave and k-tile
     constexpr int MPT = 4 * NT * 3;                          // MFMAs per wave and k-tile
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
         tile = local - slice * tiles;
     }
     const int tm = tile >> 1, tn = tile & 1;
+    const int ktiles_all = P.ktiles;
     const int kt0 = (int)((long long)slice * ktiles_all / slices), kt1 = (int)((long long)(slice + 1) * ktiles_all / slices);
+    const int sample0 = P.sample0;
+    const int* const index = tb.index;
     const int nk = kt1 - kt0;
     const unsigned char* const abase = P.a + (long long)(tm >> 1) * P.a_group_stride + (tm & 1) * 256;
     const unsigned char* const bbase = P.b + tn * 256;
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
     auto issue_one = [&](int kt, int i) {                    // kt relative to kt0
         const int q = wave * IPW + i, o = q >> 3;
         const int k = kt0 + kt;
-        const long long koff = (long long)(k >> 1) * WK_SAMPLE + (k & 1) * (WK_BK * WK_TOKB) + (o & 1) * WK_PLANE;
+        const int smp = IDX ? index[sample0 + (k >> 1)] : sample0 + (k >> 1);      // (wave-uniform: a scalar load)
+        const long long koff = (long long)smp * WK_SAMPLE + (k & 1) * (WK_BK * WK_TOKB) + (o & 1) * WK_PLANE;
         const unsigned char* src = (o < 2 ? abase : bbase) + koff + doff[i];
         lds_dma16(lds + (kt % WK_NS) * WK_STAGE + q * 1024, src);
     };
@@ -369,6 +375,9 @@ static int wk_check(const eegclip_wgrad_tok_problem* p, int n_prob, int B) {
         if (q.bias_out && !q.bias_mfma && q.N > (q.heads_n ? 248 : 255)) return EEGCLIP_EINVAL;      // column 255 must be the ones column, not data
         if (q.m_groups > 1 && q.a_group_stride < (long long)B * WK_SAMPLE) return EEGCLIP_EINVAL;
         if ((reinterpret_cast<uintptr_t>(q.a) | reinterpret_cast<uintptr_t>(q.b) | (uintptr_t)q.a_group_stride) & 15u) return EEGCLIP_EALIGN;
+        // a sample range (the joint-subject value embedding: one problem per subject) must lie inside the batch; ONE index list per launch
+        if (q.sample0 < 0 || q.samples < 0 || q.sample0 + q.samples > B || (q.samples == 0 && q.sample0 != 0)) return EEGCLIP_EINVAL;
+        if (q.sample_index != p[0].sample_index || (reinterpret_cast<uintptr_t>(q.sample_index) & 3u)) return EEGCLIP_EINVAL;
     }
     return 0;
 }
@@ -399,13 +408,14 @@ static int wk_tables(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int 
     memset(&tb, 0, sizeof(tb));
     memset(&rt, 0, sizeof(rt));
     tb.n = rt.n = n_prob;
+    tb.index = p[0].sample_index;
     blocks = threads = 0;
     float* ws = workspace;
     for (int i = 0; i < n_prob; ++i) {
         const eegclip_wgrad_tok_problem& q = p[i];
         const int Mp = 256 * q.m_groups;
         tb.p[i] = wk_problem{static_cast<const unsigned char*>(q.a), static_cast<const unsigned char*>(q.b), ws, q.a_group_stride, 2 * q.m_groups,
-                             (q.bias_out && q.bias_mfma) ? 1 : 0, blocks};
+                             (q.bias_out && q.bias_mfma) ? 1 : 0, blocks, q.sample0, 2 * (q.samples ? q.samples : B)};
         rt.p[i] = wk_reduce_problem{ws, q.out, q.bias_out, q.ldo, q.M, q.N, Mp, q.heads_m ? 1 : 0, q.heads_n ? 1 : 0, q.bias_mfma ? 1 : 0, threads};
         blocks += 4 * q.m_groups * slices;
         threads += Mp / 4 + ((q.bias_out && q.bias_mfma) ? q.m_groups : 0);      // (workgroups of the reduction)
@@ -424,8 +434,9 @@ extern "C" int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob,
     // measured on the MI355X (tools/bench_wgrad_tok.py, B = 256, 16 slices, us): 512-thread / 4 stages 25.0 (q|k|v) 28.7 (FFN + out-projection);
     // 256-thread 28.9 / 30.7; 5 stages (all 160 KB of LDS) 31.1 / 34.5 -- more bytes in flight do not help: the kernel moves its operands at
     // 3.3 TB/s (+ 0.8 of slab writes) with the matrix pipe of the CUs it occupies 50 % busy (profiles/r4_pmc_wgrad_tok.json)
-    if (variant == 1) EEG_LAUNCH((wgrad_tok_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 4 * WK_STAGE, stream, tb, 2 * B, slices);
-    else EEG_LAUNCH((wgrad_tok_kernel<4, 4>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, 2 * B, slices);
+    if (tb.index) EEG_LAUNCH((wgrad_tok_kernel<4, 4, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
+    else if (variant == 1) EEG_LAUNCH((wgrad_tok_kernel<2, 4, false>), dim3((unsigned)blocks), dim3(256), 4 * WK_STAGE, stream, tb, slices);
+    else EEG_LAUNCH((wgrad_tok_kernel<4, 4, false>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
     return (int)hipGetLastError();
 }
 

@@ -19,7 +19,8 @@ class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._runs_cache = {}
-        self._fast = {}              # param group index -> the previous step's launches (see step())
+        self._fast = {}              # param group index -> {gradient-tensor identities -> that set's launches} (see step())
+        self._fast_last = {}         # param group index -> the set the last step used (its lazy step counts are pending)
         self._moments = {}           # storage base ptr -> (m, v) shaped like the whole flat storage
         self.grad_scale_dev = None   # optional device scalar multiplied into every gradient (clipping)
 
@@ -52,6 +53,7 @@ class AdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._runs_cache.clear()                          # the loaded moments are linked (copied into the flat buffers) at the next step
         self._fast.clear()
+        self._fast_last.clear()
 
     supports_step_and_zero_grad = True
 
@@ -68,22 +70,39 @@ class AdamW(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             params = group["params"]
             grads = [p.grad for p in params]
-            fast = self._fast.get(gi)
             b1, b2 = group["betas"]
-            # steady state of a training loop: the very same gradient tensors as at the previous step (views of a flat gradient buffer; the cache
+            # steady state of a training loop: the very same gradient tensors as at an earlier step (views of a flat gradient buffer; the cache
             # holds them, so an equal id is the same object): every check below already passed and the launches are unchanged -- ~100 us of
-            # per-parameter bookkeeping per step otherwise.  Per-parameter step counts are brought up to date lazily (_flush_steps).
-            if fast is not None and len(grads) == len(fast["grads"]) and all(a is b for a, b in zip(grads, fast["grads"])) and \
-                    all(p0.grad.data_ptr() == gp and p0.data_ptr() == wp for (p0, n, wp, gp, mp, vp) in fast["launch"]):
-                fast["step"] += 1
+            # per-parameter bookkeeping per step otherwise.  Per-parameter step counts are brought up to date lazily (_flush_steps).  Several
+            # such sets are remembered (the joint-subject model: the value embeddings that are live change with the subjects of the batch, and
+            # the reference's joint loop alternates subjects batch by batch); switching between them settles the lazy counts first.
+            table = self._fast.setdefault(gi, {})
+            fast = table.get(tuple(map(id, grads)))
+            if fast is not None and all(a is b for a, b in zip(grads, fast["grads"])) and \
+                    all(p0.grad.data_ptr() == gp and p0.data_ptr() == wp for (p0, n, wp, gp, mp, vp, members) in fast["launch"]):
+                if self._fast_last.get(gi) is not fast:
+                    self._flush_steps(gi)
+                    # the runs were formed from parameters with EQUAL step counts; another set may since have stepped only some of them
+                    steps_now = [self.state[p0]["step"] for (p0, *_rest) in fast["launch"]]
+                    if all(self.state[q]["step"] == st for (_p0, _n, _w, _g, _m, _v, members), st in zip(fast["launch"], steps_now) for q in members):
+                        fast["run_steps"] = steps_now
+                        self._fast_last[gi] = fast
+                    else:
+                        table.pop(tuple(map(id, grads)), None)
+                        fast = None
+            else:
+                fast = None
+            if fast is not None:
+                fast["run_steps"] = [st + 1 for st in fast["run_steps"]]
                 fast["pending"] += 1
-                for (p0, n, wp, gp, mp, vp) in fast["launch"]:
-                    check(fn(wp, gp, mp, vp, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], fast["step"], 1.0, gs, stream), "adamw_step")
+                for (p0, n, wp, gp, mp, vp, members), st in zip(fast["launch"], fast["run_steps"]):
+                    check(fn(wp, gp, mp, vp, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], st, 1.0, gs, stream), "adamw_step")
                 if zero_grad:
                     for own, ptrs in fast["owners"]:
                         own.grads_cleared(ptrs)
                 continue
             self._flush_steps(gi)
+            self._fast_last[gi] = None
             live = [p for p in params if p.grad is not None]
             if not live:
                 continue
@@ -93,24 +112,22 @@ class AdamW(torch.optim.Optimizer):
                     raise EegclipError("eeg_image_decode_amd.optim works on float32 parameters")
                 st = self.state[p]
                 st["step"] = st.get("step", 0) + 1
-            steps = {self.state[p]["step"] for p in live}
             ck = (id(group), tuple((id(p), p.data_ptr(), p.grad.data_ptr()) for p in live))
-            if len(steps) == 1 and ck in self._runs_cache:
-                st = next(iter(steps))
-                runs = [(p0, n, st) for (p0, n) in self._runs_cache[ck]]
+            cached = self._runs_cache.get(ck)
+            if cached is not None and all(self.state[q]["step"] == self.state[p0]["step"] for (p0, n, members) in cached for q in members):
+                runs = [(p0, n, self.state[p0]["step"], members) for (p0, n, members) in cached]
             else:
                 self._link_state(live)
                 runs = self._make_runs(live)
                 if len(self._runs_cache) >= 64:           # (joint-subject training: the live set changes with the subjects of the batch)
                     self._runs_cache.clear()
-                if len(steps) == 1:
-                    self._runs_cache[ck] = [(p0, n) for (p0, n, _) in runs]
+                self._runs_cache[ck] = [(p0, n, members) for (p0, n, _, members) in runs]
             launch = []
-            for (p0, n, step) in runs:
+            for (p0, n, step, members) in runs:
                 m, v = self._moments_for(p0)
                 off = (p0.data_ptr() - p0.untyped_storage().data_ptr()) // 4
-                launch.append((p0, n, p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off))
-                check(fn(*launch[-1][2:], n, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0, gs, stream), "adamw_step")
+                launch.append((p0, n, p0.data_ptr(), p0.grad.data_ptr(), m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, members))
+                check(fn(*launch[-1][2:6], n, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, 1.0, gs, stream), "adamw_step")
             owners = {}
             for p in live:
                 own = getattr(p, "_eegclip_grad_owner", None)
@@ -121,10 +138,11 @@ class AdamW(torch.optim.Optimizer):
             if zero_grad:
                 for own, ptrs in owners:
                     own.grads_cleared(ptrs)
-            if len(steps) == 1:
-                self._fast[gi] = dict(grads=grads, live=live, launch=launch, owners=owners, step=next(iter(steps)), pending=0)
-            else:
-                self._fast.pop(gi, None)
+            if len(table) >= 64:
+                table.clear()
+            fast = dict(grads=grads, live=live, launch=launch, owners=owners, run_steps=[r[2] for r in runs], pending=0)
+            table[tuple(map(id, grads))] = fast
+            self._fast_last[gi] = fast
         if zero_grad:
             for group in self.param_groups:                  # zero_grad(set_to_none=True) for every parameter, stepped or not
                 for p in group["params"]:
@@ -133,8 +151,8 @@ class AdamW(torch.optim.Optimizer):
 
     def _flush_steps(self, gi=None):
         """bring state[p]["step"] up to date with the steps taken on the fast path"""
-        for g in ([gi] if gi is not None else list(self._fast)):
-            fast = self._fast.get(g)
+        for g in ([gi] if gi is not None else list(self._fast_last)):
+            fast = self._fast_last.get(g)
             if fast and fast["pending"]:
                 for p in fast["live"]:
                     self.state[p]["step"] += fast["pending"]
@@ -155,29 +173,30 @@ class AdamW(torch.optim.Optimizer):
         """the copy starts without launch caches and flat moment buffers (raw device addresses of the ORIGINAL's tensors): its moments are the
         per-parameter tensors of `state`, linked into fresh flat buffers at its first step (as after load_state_dict)"""
         super().__setstate__(state)
-        self._runs_cache, self._fast, self._moments = {}, {}, {}
+        self._runs_cache, self._fast, self._fast_last, self._moments = {}, {}, {}, {}
         if not hasattr(self, "grad_scale_dev"):
             self.grad_scale_dev = None
 
     def _make_runs(self, live):
         """maximal runs of parameters that are contiguous (up to 12 bytes of alignment padding) in BOTH the weight and
-        the gradient storage and share a step count -> [(first param, numel incl. padding, step)]"""
+        the gradient storage and share a step count -> [(first param, numel incl. padding, step, member parameters)]"""
         items = sorted(live, key=lambda p: p.data_ptr())
         runs = []
         cur = None
         for p in items:
             step = self.state[p]["step"]
             if cur is not None:
-                p0, end_w, end_g, st0 = cur
+                p0, end_w, end_g, st0, members = cur
                 gap_w, gap_g = p.data_ptr() - end_w, p.grad.data_ptr() - end_g
                 same = p.untyped_storage().data_ptr() == p0.untyped_storage().data_ptr()
                 if same and st0 == step and 0 <= gap_w <= 12 and gap_w == gap_g:
-                    cur = (p0, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), st0)
+                    members.append(p)
+                    cur = (p0, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), st0, members)
                     continue
-                runs.append((p0, (end_w - p0.data_ptr()) // 4, st0))
-            cur = (p, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), step)
-        p0, end_w, _, st0 = cur
-        runs.append((p0, (end_w - p0.data_ptr()) // 4, st0))
+                runs.append((p0, (end_w - p0.data_ptr()) // 4, st0, members))
+            cur = (p, p.data_ptr() + 4 * p.numel(), p.grad.data_ptr() + 4 * p.numel(), step, [p])
+        p0, end_w, _, st0, members = cur
+        runs.append((p0, (end_w - p0.data_ptr()) // 4, st0, members))
         return runs
 
 

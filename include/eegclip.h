@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 6
+#define EEGCLIP_ABI_VERSION 7
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -472,9 +472,19 @@ typedef struct {
     float drop_p, eps, scale;                  /* dropout probability of all five sites (0: evaluation), LayerNorm eps, softmax scale */
     unsigned long long seed;
     unsigned int site_embed, site_attn, site_attn_out, site_ffn_act, site_ffn_out;
+    /* joint-subject model (Retrieval/ATMS_retrieval_joint_train.py:172-192, models/subject_layers/Embed.py:127-131,142-144: one value embedding per
+       subject, chosen per sample): embed_subject non-NULL = (B) subject of each sample, its matrix is number embed_subject[b] of `packed_embed`
+       (eegclip_token_block_pack_embed) and its bias bv + embed_subject[b] * bv_stride (even, 8-byte aligned rows).  NULL: the matrix in `packed`, bias bv. */
+    const void* packed_embed;
+    const int* embed_subject;
+    long long bv_stride;
 } eegclip_token_block_desc;
 long long eegclip_token_block_packed_bytes(void);
 int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream);
+/* n_subjects value-embedding matrices ((250, 250) row-major, w_stride floats apart) -> n_subjects packed operands at `out`
+ * (eegclip_token_block_packed_embed_bytes(n_subjects) bytes, 16-byte aligned) */
+long long eegclip_token_block_packed_embed_bytes(int n_subjects);
+int eegclip_token_block_pack_embed(const float* w0, long long w_stride, int n_subjects, void* out, void* stream);
 int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* stream);
 
 /* backward of the block's dX chain, one workgroup per sample (csrc/token_block.hip), `part`:
@@ -507,7 +517,7 @@ int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, voi
  * gradient sum_t dY[t][o] (bias_mfma = 1 when X has 256 real channels: the kernel forms it against an all-ones fragment instead).
  * heads_m / heads_n: the operand's channel c = 64 head + d (d < 62) is row / column 62 head + d of `out`; m_groups: dY is m_groups channel groups
  * of 256 (dq | dk | dv), a_group_stride bytes apart, group g = rows 248 g .. of `out` (heads_m) or 256 g ...
- * One launch takes up to 4 problems (gradients that become ready together); `slices` K slices per output tile (eegclip_wgrad_tok_slices picks
+ * One launch takes up to 12 problems (gradients that become ready together; the subjects of a joint-subject batch); `slices` K slices per output tile (eegclip_wgrad_tok_slices picks
  * ~one 128 x 128 tile workgroup per CU), partial tiles in `workspace` (eegclip_wgrad_tok_workspace_floats floats) summed in slice order by
  * eegclip_wgrad_tok_reduce: bit-reproducible.  variant 0: 512-thread workgroups (2 waves per SIMD), 1: 256-thread.  Split-bf16 products, fp32 accumulate. */
 typedef struct {
@@ -520,6 +530,9 @@ typedef struct {
     long long ldo;
     float* bias_out;                           /* (M) accumulated into, or NULL */
     int bias_mfma;
+    int sample0, samples;                      /* contract over samples sample0 .. sample0 + samples - 1 only (samples = 0: the whole batch) ... */
+    const int* sample_index;                   /* ... of this list of B sample numbers (device memory; NULL: identity; one list per launch).  The joint-subject
+                                                  value embedding (Embed.py:142-144): list = the batch ordered by subject, one problem per subject present */
 } eegclip_wgrad_tok_problem;
 int eegclip_wgrad_tok_slices(int total_m_groups, int B);
 long long eegclip_wgrad_tok_workspace_floats(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices);

@@ -155,6 +155,49 @@ def test_wgrad_tok_uneven_slices(be):
     run_problems(be, ["embed", "qkv"], 3, 4, 0, seed=4)                          # 6 k-tiles over 4 slices: 1, 2, 1, 2 per workgroup
 
 
+def joint_case(be, ids, slices, seed):
+    """the joint-subject value embedding (Embed.py:142-144): one problem per subject present, each contracting over that subject's samples only --
+    a range of the subject-ordered sample list; the planes stay in batch order"""
+    rng = np.random.default_rng(seed)
+    ids = np.asarray(ids)
+    B = len(ids)
+    dy, x = rng.standard_normal((64 * B, 250)).astype(np.float32), rng.standard_normal((64 * B, 250)).astype(np.float32)
+    a, b = make_planes(be, dy, 0, 0), make_planes(be, x, 0, 1)
+    perm = np.argsort(ids, kind="stable").astype(np.int32)
+    PERM = be.dev(perm)
+    subjects = sorted(set(ids.tolist()))
+    probs = (_abi.WgradTokProblem * len(subjects))()
+    outs = []
+    start = 0
+    for i, sj in enumerate(subjects):
+        n = int((ids == sj).sum())
+        out, bias = be.zeros((250, 250)), be.zeros(250)
+        probs[i] = _abi.WgradTokProblem(a=be.ptr(a), b=be.ptr(b), a_group_stride=0, m_groups=1, heads_m=0, heads_n=0, M=250, N=250, out=be.ptr(out), ldo=250,
+                                        bias_out=be.ptr(bias), bias_mfma=0, sample0=start, samples=n, sample_index=be.ptr(PERM))
+        rows = np.concatenate([np.arange(64 * sb, 64 * sb + 64) for sb in np.flatnonzero(ids == sj)])
+        outs.append((sj, out, bias, reference(dy[rows], x[rows])))
+        start += n
+    ws = be.dev(np.full(int(be.lib.eegclip_wgrad_tok_workspace_floats(probs, len(subjects), B, slices)), np.nan, np.float32))
+    assert be.lib.eegclip_wgrad_tok(probs, len(subjects), B, slices, be.ptr(ws), 0, be.stream) == 0
+    assert be.lib.eegclip_wgrad_tok_reduce(probs, len(subjects), B, slices, be.ptr(ws), be.stream) == 0
+    be.sync()
+    for sj, out, bias, (ew, eb) in outs:
+        np.testing.assert_allclose(be.host(out).astype(np.float64), ew, atol=2e-6 * np.abs(ew).max() * np.sqrt(64 * B), err_msg=f"subject {sj}")
+        np.testing.assert_allclose(be.host(bias).astype(np.float64), eb, atol=2e-6 * np.abs(eb).max() * np.sqrt(64 * B) + 1e-5, err_msg=f"subject {sj} bias")
+
+
+@pytest.mark.parametrize("ids,slices", [([3, 0, 3, 7, 0, 3], 2), ([5, 5, 5], 1), ([9, 1, 1, 1, 1, 4], 4)], ids=["mixed", "uniform", "empty-slices"])
+def test_wgrad_tok_per_subject_sample_ranges(be, ids, slices):
+    joint_case(be, ids, slices, seed=len(ids))
+
+
+@pytest.mark.gpu
+def test_wgrad_tok_per_subject_full_size():
+    from backends import get
+    rng = np.random.default_rng(2)
+    joint_case(get("gpu"), rng.integers(0, 10, 256), 8, seed=9)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1])
 def test_wgrad_tok_full_size(variant):
@@ -178,6 +221,10 @@ def test_wgrad_tok_rejects_bad_arguments(be):
     assert be.lib.eegclip_wgrad_tok(p, 1, 2, 1, be.ptr(ws), 0, be.stream) != 0     # 256 real columns leave no ones column: bias_mfma is required
     p[0].bias_mfma = 1
     assert be.lib.eegclip_wgrad_tok(p, 1, 2, 8, be.ptr(ws), 0, be.stream) != 0     # more slices than k-tiles
-    assert be.lib.eegclip_wgrad_tok(p, 5, 2, 1, be.ptr(ws), 0, be.stream) != 0
+    many = (_abi.WgradTokProblem * 13)(*[p[0]] * 13)
+    assert be.lib.eegclip_wgrad_tok(many, 13, 2, 1, be.ptr(ws), 0, be.stream) != 0  # at most 12 problems per launch
+    p[0].sample0, p[0].samples = 1, 2
+    assert be.lib.eegclip_wgrad_tok(p, 1, 2, 1, be.ptr(ws), 0, be.stream) != 0     # sample range outside the batch
+    p[0].sample0, p[0].samples = 0, 0
     p[0].M = 257
     assert be.lib.eegclip_wgrad_tok(p, 1, 2, 1, be.ptr(ws), 0, be.stream) != 0

@@ -199,13 +199,13 @@ def test_optimizer_fast_path_is_torch_adamw_and_keeps_step_counts():
                 ps[1].grad = gs[1].clone()                   # another tensor object (not in the flat buffer): the cached launches must not be used
             opt.step(zero_grad=(it % 2 == 1))
             topt.step()
-            assert (it < 2) or (it == 5) or opt._fast[0]["pending"] >= 1  # from the third step on the cached launches are used
+            assert (it < 2) or (it == 5) or opt._fast_last[0]["pending"] >= 1  # from the third step on the cached launches are used
             if it == 5:
-                assert opt._fast[0]["pending"] == 0 and len(opt._fast[0]["launch"]) >= 2      # re-derived: the run is split at the foreign gradient
+                assert opt._fast_last[0]["pending"] == 0 and len(opt._fast_last[0]["launch"]) >= 2      # re-derived: the run is split at the foreign gradient
             if it == 4:
                 # copy.deepcopy / pickle go through __getstate__, not state_dict(): the lazily counted steps must be flushed there too
                 import copy
-                assert opt._fast[0]["pending"] >= 1
+                assert opt._fast_last[0]["pending"] >= 1
                 dup = copy.deepcopy(opt)
                 assert [int(st["step"]) for st in dup.state.values()] == [5, 5, 5] and dup._fast == {} and dup._moments == {}
             if it % 2 == 1 and it != 5:
@@ -214,6 +214,46 @@ def test_optimizer_fast_path_is_torch_adamw_and_keeps_step_counts():
             np.testing.assert_allclose(p.detach().numpy(), r.detach().numpy(), atol=2e-6, rtol=1e-5)
         sd = opt.state_dict()["state"]
         assert [int(sd[i]["step"]) for i in range(3)] == [6, 6, 6]
+
+
+def test_optimizer_alternating_live_sets_keep_their_cached_launches():
+    """the joint-subject model's pattern (the reference's joint loop alternates subjects batch by batch, ATMS_retrieval_joint_train.py:219-222): the
+    parameters with a gradient change from step to step between a few sets.  Every set keeps its cached launches; switching settles the lazily
+    counted steps, and a run whose members' step counts have drifted apart is re-derived.  Against torch.optim.AdamW, step counts included."""
+    rng = np.random.default_rng(8)
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim
+        flat, gflat = torch.zeros(400), torch.zeros(400)
+        shapes, off, ps, gs = [(6, 5), (12,), (8, 4), (8,), (8, 4), (8,)], 0, [], []      # shared weight, shared bias, subject A (w, b), subject B (w, b)
+        for sh in shapes:
+            n = int(np.prod(sh))
+            flat[off:off + n] = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+            ps.append(torch.nn.Parameter(flat[off:off + n].view(sh)))
+            gs.append(gflat[off:off + n].view(sh))
+            off += (n + 3) // 4 * 4
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        opt, topt = optim.AdamW(ps, lr=2e-3, weight_decay=0.01), torch.optim.AdamW(ref, lr=2e-3, weight_decay=0.01)
+        sets = {"A": [0, 1, 2, 3], "B": [0, 1, 4, 5], "AB": [0, 1, 2, 3, 4, 5]}
+        order = ["A", "B", "A", "A", "B", "AB", "B", "B", "A", "AB", "AB", "A"]
+        fast_hits = 0
+        for it, name in enumerate(order):
+            for i, (p, g, r) in enumerate(zip(ps, gs, ref)):
+                if i in sets[name]:
+                    g.copy_(torch.from_numpy(rng.standard_normal(tuple(g.shape)).astype(np.float32)))
+                    p.grad, r.grad = g, g.clone()
+                else:
+                    p.grad, r.grad = None, None
+            before = opt._fast_last.get(0)
+            known = tuple(map(id, [p.grad for p in ps])) in opt._fast.get(0, {})
+            opt.step(zero_grad=True)
+            topt.step()
+            fast_hits += int(known and opt._fast_last[0]["pending"] >= 1)
+            assert all(p.grad is None for p in ps)
+        assert fast_hits >= 6                                  # every set after its first appearance, unless its runs had to be re-derived
+        for p, r in zip(ps, ref):
+            np.testing.assert_allclose(p.detach().numpy(), r.detach().numpy(), atol=2e-6, rtol=1e-5)
+        sd, tsd = opt.state_dict()["state"], topt.state_dict()["state"]
+        assert [int(sd[i]["step"]) for i in range(6)] == [int(tsd[i]["step"]) for i in range(6)] == [12, 12, 8, 8, 7, 7]
 
 
 def test_reconstruction_objective_step_under_emulator_matches_oracle():
@@ -265,6 +305,25 @@ def test_joint_subject_model_under_emulator_matches_oracle(ids):
         loss.backward()
         grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
         dx = x.grad.clone()
+        # the joint-subject plans run the fused transformer block (per-sample value-embedding base) and take the per-subject weight gradients from the
+        # token planes through the subject-ordered sample list; only the input gradient (not part of training) still uses the grouped GEMM
+        eng = m._engine()
+        fnames = eng.plans[next(k for k in eng.plans if k[0] == "f" and k[2])].op_names()
+        assert "eegclip_token_block_fwd" in fnames and "eegclip_token_block_pack_embed" in fnames and "eegclip_gemm_f32_grouped" not in fnames
+        bnames = eng.plans[next(k for k in eng.plans if k[0] == "b")].op_names()
+        assert bnames.count("eegclip_wgrad_tok") == 3 and bnames.count("eegclip_gemm_f32_grouped") == 1
+        # a training step proper (no input gradient): no grouped GEMM, no subject-ordered copies at all
+        for p_ in m.parameters():
+            p_.grad = None
+        z2 = m(T(x0), idt)
+        (0.99 * m.loss_func(z2, img, m.logit_scale) + 0.01 * m.loss_func(z2, txt, m.logit_scale)).backward()
+        bn2 = eng.plans[next(k for k in eng.plans if k[0] == "b" and not k[5])].op_names()
+        assert "eegclip_gemm_f32_grouped" not in bn2 and "eegclip_gather_rows" not in bn2 and bn2.count("eegclip_wgrad_tok") == 3
+        for k, p_ in m.named_parameters():
+            if grads[k] is None:
+                assert p_.grad is None, k
+            else:
+                np.testing.assert_allclose(p_.grad.numpy(), grads[k].numpy(), atol=1e-6 + 1e-4 * float(grads[k].abs().max()), err_msg=k)
         with pytest.raises(Exception, match="value embeddings for subjects"):
             m(T(x0), torch.tensor([0, 1, 2, 10][:B]))
     tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
