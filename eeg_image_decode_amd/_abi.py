@@ -60,10 +60,22 @@ class TokenBlockBwdDesc(C.Structure):
                 + [(k, C.c_uint) for k in ("site_embed", "site_attn_out", "site_ffn_act", "site_ffn_out")])
 
 
+class GemmPlanesDesc(C.Structure):
+    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("lda", C.c_longlong), ("ldb", C.c_longlong),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("C", C.c_void_p), ("ldc", C.c_longlong), ("Cpre", C.c_void_p), ("ldcpre", C.c_longlong),
+                ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_longlong), ("p_hi", C.c_void_p), ("p_lo", C.c_void_p), ("ldp", C.c_longlong),
+                ("act", C.c_int), ("accumulate", C.c_int), ("planes_of", C.c_int)]
+
+
 class WgradTokProblem(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("a_group_stride", C.c_longlong), ("m_groups", C.c_int), ("heads_m", C.c_int), ("heads_n", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("bias_mfma", C.c_int),
                 ("sample0", C.c_int), ("samples", C.c_int), ("sample_index", C.c_void_p)]
+
+
+class WgradPlanesProblem(C.Structure):
+    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("lda", C.c_longlong), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("ldb", C.c_longlong),
+                ("rows", C.c_int), ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("slices", C.c_int)]
 
 
 PLAN_MAX_ARGS = 24
@@ -166,10 +178,16 @@ PROTOTYPES = {
     "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],
     "eegclip_token_block_bwd_workspace_floats": [_I],
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
+    "eegclip_gemm_planes": [C.POINTER(GemmPlanesDesc), _P],
+    "eegclip_split_transpose": [C.POINTER(SplitItem), _I, _P],
+    "eegclip_prior_stage_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
+    "eegclip_prior_stage_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U, _P],
+    "eegclip_silu_bwd_planes": [_P, _P, _P, _P, _L, _P],
     "eegclip_wgrad_tok_slices": [_I, _I],
     "eegclip_wgrad_tok_workspace_floats": [C.POINTER(WgradTokProblem), _I, _I, _I],
     "eegclip_wgrad_tok": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _I, _P],
     "eegclip_wgrad_tok_reduce": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _P],
+    "eegclip_wgrad_planes": [C.POINTER(WgradPlanesProblem), _I, _P],
     "eegclip_tok_planes_from_f32": [_P, _L, _I, _I, _I, _I, _P, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],

@@ -11,7 +11,9 @@ __global__ __launch_bounds__(256) void layernorm_silu_fwd_kernel(const float* __
                                                                   const float* __restrict__ beta, float* __restrict__ y_ln,
                                                                   float* __restrict__ y_act, float* __restrict__ mean_out,
                                                                   float* __restrict__ rstd_out, int rows, int cols, float eps,
-                                                                  float drop_p, unsigned long long seed, unsigned site) {
+                                                                  float drop_p, unsigned long long seed, unsigned site,
+                                                                  const float* __restrict__ skip, unsigned short* __restrict__ act_hi,
+                                                                  unsigned short* __restrict__ act_lo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)cols;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -43,7 +45,13 @@ __global__ __launch_bounds__(256) void layernorm_silu_fwd_kernel(const float* __
                 y_ln[idx] = y;
                 float a = silu(y);
                 if (drop_p > 0.f) a = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? a * ks : 0.f;
+                if (skip) a += skip[idx];                    // decoder stages: x += hidden_activations[-1 - j]   (diffusion_prior.py:199)
                 y_act[idx] = a;
+                if (act_hi) {                                // the activation again as bf16 planes: operand of the next plane GEMM
+                    const unsigned short hb = f32_to_bf16_bits(a);
+                    act_hi[idx] = hb;
+                    act_lo[idx] = f32_to_bf16_bits(a - bf16_bits_to_f32(hb));
+                }
             }
         }
         if (lane == 0) {
@@ -119,6 +127,98 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__
         if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
         const float v = d * silu_grad(pre[i]);
         dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// dx = dy * silu'(pre) as bf16 hi | lo planes only (the gradient of the time embeddings' hidden layer: its one reader is a weight-gradient plane GEMM)
+__global__ __launch_bounds__(256) void silu_bwd_planes_kernel(const float* __restrict__ dy, const float* __restrict__ pre, unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ lo, long long n4) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + 4 * q), p = *reinterpret_cast<const f32x4*>(pre + 4 * q);
+        u32x2_t h, l;
+        x3_split4(d[0] * silu_grad(p[0]), d[1] * silu_grad(p[1]), d[2] * silu_grad(p[2]), d[3] * silu_grad(p[3]), h, l);
+        *reinterpret_cast<u32x2_t*>(hi + 4 * q) = h;
+        *reinterpret_cast<u32x2_t*>(lo + 4 * q) = l;
+    }
+}
+
+// Backward of a stage tail in ONE pass (diffusion_prior.py:173-175,186-199 differentiated): act = dropout(SiLU(LayerNorm(x))) -> d LN-output =
+// dropout'(dact) * silu'(y_ln); dx = rstd (g - mean(g) - xhat mean(g xhat)), g = d * gamma; dgamma += sum_rows d * xhat, dbeta += sum_rows d.
+// Replaces silu_bwd + layernorm_bwd (two kernels, three passes) per stage; dx leaves as bf16 hi | lo planes (operand of the dX and weight-gradient
+// plane GEMMs) and / or fp32.  A wave owns a row (<= 1024 columns: 16 per lane); a lane's columns are the same for every row, so the parameter
+// gradients accumulate in registers over the workgroup's rows and meet in LDS: one atomic per column and workgroup.
+__global__ __launch_bounds__(256) void prior_stage_bwd_kernel(const float* __restrict__ dact, const float* __restrict__ y_ln, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ dx, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols, float drop_p,
+                                                               unsigned long long seed, unsigned site) {
+    EEG_LDS_BASE(float, red);                                // [2][4 waves][64 LNS_MAXC]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float gm[LNS_MAXC], pg[LNS_MAXC], pb[LNS_MAXC];
+#pragma unroll
+    for (int i = 0; i < LNS_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        gm[i] = c < cols ? gamma[c] : 0.f;
+        pg[i] = 0.f;
+        pb[i] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const long long base = (long long)row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        float g[LNS_MAXC], xh[LNS_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            g[i] = 0.f;
+            xh[i] = 0.f;
+            if (c < cols) {
+                float d = dact[base + c];
+                if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)(base + c), drop_p) ? d * ks : 0.f;
+                d *= silu_grad(y_ln[base + c]);
+                xh[i] = (x[base + c] - mu) * rs;
+                pg[i] += d * xh[i];
+                pb[i] += d;
+                g[i] = d * gm[i];
+                s1 += g[i];
+                s2 += g[i] * xh[i];
+            }
+        }
+        const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+#pragma unroll
+        for (int i = 0; i < LNS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) {
+                const float v = rs * (g[i] - m1 - xh[i] * m2);
+                if (dx) dx[base + c] = v;
+                if (dx_hi) {
+                    const unsigned short hb = f32_to_bf16_bits(v);
+                    dx_hi[base + c] = hb;
+                    dx_lo[base + c] = f32_to_bf16_bits(v - bf16_bits_to_f32(hb));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LNS_MAXC; ++i) {
+        red[(wave * LNS_MAXC + i) * 64 + lane] = pg[i];
+        red[((4 + wave) * LNS_MAXC + i) * 64 + lane] = pb[i];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * LNS_MAXC; q += 256) {   // q = i * 64 + lane  <->  column lane + 64 i
+        const int i = q >> 6, l = q & 63, c = l + 64 * i;
+        if (c < cols) {
+            float sg = 0.f, sb = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                sg += red[(w * LNS_MAXC + i) * 64 + l];
+                sb += red[((4 + w) * LNS_MAXC + i) * 64 + l];
+            }
+            atomicAdd(dgamma + c, sg);
+            atomicAdd(dbeta + c, sb);
+        }
     }
 }
 
@@ -199,7 +299,45 @@ extern "C" int eegclip_layernorm_silu_fwd(const float* x, const float* gamma, co
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
     EEG_LAUNCH(layernorm_silu_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y_ln, y_act, mean, rstd, rows, cols, eps, drop_p,
-               seed, site);
+               seed, site, (const float*)nullptr, (unsigned short*)nullptr, (unsigned short*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_prior_stage_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y_ln, float* y_act, float* mean,
+                                       float* rstd, void* act_hi, void* act_lo, int rows, int cols, float eps, float drop_p, unsigned long long seed,
+                                       unsigned site, void* stream) {
+    if (!x || !gamma || !beta || !y_ln || !y_act || !mean || !rstd || rows < 0 || cols < 1 || cols > 64 * LNS_MAXC || drop_p < 0.f || drop_p >= 1.f ||
+        (!act_hi) != (!act_lo))
+        return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    EEG_LAUNCH(layernorm_silu_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y_ln, y_act, mean, rstd, rows, cols, eps, drop_p,
+               seed, site, skip, static_cast<unsigned short*>(act_hi), static_cast<unsigned short*>(act_lo));
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_prior_stage_bwd(const float* dact, const float* y_ln, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                       float* dx, void* dx_hi, void* dx_lo, float* dgamma, float* dbeta, int rows, int cols, float drop_p,
+                                       unsigned long long seed, unsigned site, void* stream) {
+    if (!dact || !y_ln || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || (!dx && !dx_hi) || (!dx_hi) != (!dx_lo) || rows < 0 || cols < 1 ||
+        cols > 64 * LNS_MAXC || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    int grid = (rows + 7) / 8;                               // 2 rows per wave: the parameter-gradient partials of a workgroup cover 8 rows
+    if (grid > 1024) grid = 1024;
+    EEG_LAUNCH(prior_stage_bwd_kernel, dim3(grid), dim3(256), 2 * 4 * 64 * LNS_MAXC * sizeof(float), stream, dact, y_ln, x, gamma, mean, rstd, dx,
+               static_cast<unsigned short*>(dx_hi), static_cast<unsigned short*>(dx_lo), dgamma, dbeta, rows, cols, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_silu_bwd_planes(const float* dy, const float* pre, void* dx_hi, void* dx_lo, long long n, void* stream) {
+    if (!dy || !pre || !dx_hi || !dx_lo || n < 0 || (n & 3)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(pre)) & 15u) return EEGCLIP_EALIGN;
+    if ((reinterpret_cast<uintptr_t>(dx_hi) | reinterpret_cast<uintptr_t>(dx_lo)) & 7u) return EEGCLIP_EALIGN;
+    if (n == 0) return 0;
+    EEG_LAUNCH(silu_bwd_planes_kernel, dim3(pgrid(n / 4, 4096)), dim3(256), 0, stream, dy, pre, static_cast<unsigned short*>(dx_hi),
+               static_cast<unsigned short*>(dx_lo), n / 4);
     return (int)hipGetLastError();
 }
 

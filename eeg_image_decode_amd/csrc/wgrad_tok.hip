@@ -42,6 +42,14 @@ struct wk_problem {
     int bias_mfma;                                           // bias gradient through an all-ones fragment (X has no spare column)
     int first_block;                                         // first workgroup of this problem in the launch
     int sample0, ktiles;                                     // the contraction runs over samples sample0 .. of the (indexed) batch: 2 k-tiles per sample
+    // PLAIN 2-D planes (eegclip_wgrad_planes: [rows][ld] bf16, hi and lo planes apart) -- the template flag L2D selects these fields:
+    long long a_lo, b_lo;                                    // bytes from the hi to the lo plane
+    int a_tok, b_tok;                                        // bytes per k-row of A / B
+    int n_tiles, slices;                                     // 128-column tiles of the output; K slices of THIS problem
+    float* out;                                              // (M, N) row stride ldo, accumulated into directly (atomically when slices > 1)
+    float* bias_out;
+    long long ldo;
+    int M, N;
 };
 struct wk_table {
     wk_problem p[WK_MAXP];
@@ -65,8 +73,8 @@ __device__ __forceinline__ wk_s4 wk_tr_read(const unsigned char* p) {
 #endif
 }
 
-template <int WN, int WK_NS, bool IDX>
-__global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int slices) {
+template <int WN, int WK_NS, bool IDX, bool L2D = false>
+__global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int slices_all) {
     constexpr int NWAVE = 2 * WN, NT = 8 / WN;               // n-tiles of 16 per wave
     constexpr int IPW = 32 / NWAVE;                          // DMA instructions (1 KB each) per wave and k-tile
     constexpr int MPT = 4 * NT * 3;                          // MFMAs per wave and k-tile
@@ -79,7 +87,9 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
     for (int p = 1; p < WK_MAXP; ++p)
         if (p < tb.n && (int)blockIdx.x >= tb.p[p].first_block) prob = p;
     const wk_problem& P = tb.p[prob];
-    const int tiles = 2 * P.m_tiles;
+    const int n_tiles = L2D ? P.n_tiles : 2;
+    const int tiles = n_tiles * P.m_tiles;
+    const int slices = L2D ? P.slices : slices_all;
     const int local = (int)blockIdx.x - P.first_block;
     int slice, tile;
     if ((slices & 7) == 0) {                                 // workgroup b runs on XCD b % 8 (observed dispatch; speed only): a slice's tiles share one L2
@@ -90,13 +100,13 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
         slice = local / tiles;
         tile = local - slice * tiles;
     }
-    const int tm = tile >> 1, tn = tile & 1;
+    const int tm = tile / n_tiles, tn = tile - tm * n_tiles;
     const int ktiles_all = P.ktiles;
     const int kt0 = (int)((long long)slice * ktiles_all / slices), kt1 = (int)((long long)(slice + 1) * ktiles_all / slices);
     const int sample0 = P.sample0;
     const int* const index = tb.index;
     const int nk = kt1 - kt0;
-    const unsigned char* const abase = P.a + (long long)(tm >> 1) * P.a_group_stride + (tm & 1) * 256;
+    const unsigned char* const abase = L2D ? P.a + tm * 256 : P.a + (long long)(tm >> 1) * P.a_group_stride + (tm & 1) * 256;
     const unsigned char* const bbase = P.b + tn * 256;
     const bool bias = P.bias_mfma && tn == 0 && wn == 0;     // (wave-uniform)
 
@@ -105,13 +115,15 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int q = wave * IPW + i, row = 4 * (q & 7) + (lane >> 4), pos = lane & 15;
-        doff[i] = row * WK_TOKB + ((pos ^ ((row & 7) << 1)) << 4);
+        doff[i] = row * (L2D ? ((q >> 3) < 2 ? P.a_tok : P.b_tok) : WK_TOKB) + ((pos ^ ((row & 7) << 1)) << 4);
     }
     auto issue_one = [&](int kt, int i) {                    // kt relative to kt0
         const int q = wave * IPW + i, o = q >> 3;
         const int k = kt0 + kt;
         const int smp = IDX ? index[sample0 + (k >> 1)] : sample0 + (k >> 1);      // (wave-uniform: a scalar load)
-        const long long koff = (long long)smp * WK_SAMPLE + (k & 1) * (WK_BK * WK_TOKB) + (o & 1) * WK_PLANE;
+        long long koff;
+        if (L2D) koff = (long long)k * WK_BK * (o < 2 ? P.a_tok : P.b_tok) + ((o & 1) ? (o < 2 ? P.a_lo : P.b_lo) : 0);
+        else koff = (long long)smp * WK_SAMPLE + (k & 1) * (WK_BK * WK_TOKB) + (o & 1) * WK_PLANE;
         const unsigned char* src = (o < 2 ? abase : bbase) + koff + doff[i];
         lds_dma16(lds + (kt % WK_NS) * WK_STAGE + q * 1024, src);
     };
@@ -232,6 +244,41 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
         if (kt < nk) step(kt, std::integral_constant<int, 0>{}, std::false_type{});
     }
 
+    if (L2D) {
+        // ---- plain planes: straight into the gradient (fp32 atomics only when this problem is K-sliced: small outputs, few addresses)
+        const bool atomic = slices > 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = 128 * tm + 64 * wm + 16 * mt + fr;
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 128 * tn + 16 * NT * wn + 16 * nt + 4 * g;
+                if (n >= P.N) continue;
+                float* o = P.out + (long long)m * P.ldo + n;
+                if (atomic) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(o + e, acc[mt][nt][e]);
+                } else {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += acc[mt][nt][e];
+                    *reinterpret_cast<f32x4*>(o) = v;
+                }
+            }
+        }
+        if (bias && g == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = 128 * tm + 64 * wm + 16 * mt + fr;
+                if (m < P.M) {
+                    if (atomic) atomicAdd(P.bias_out + m, bacc[mt][0]);
+                    else P.bias_out[m] += bacc[mt][0];
+                }
+            }
+        }
+        return;
+    }
     // ---- partial tile -> this slice's slab (plain stores; the reduce kernel sums the slices in order)
     const int Mp = 128 * P.m_tiles;
     float* out = P.slab + (long long)slice * Mp * 256;
@@ -448,6 +495,49 @@ extern "C" int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int 
     const int rc = wk_tables(p, n_prob, B, slices, workspace, tb, rt, blocks, threads);
     if (rc) return rc;
     EEG_LAUNCH(wgrad_tok_reduce_kernel, dim3((unsigned)threads), dim3(256), 256 * sizeof(f32x4), stream, rt, slices);
+    return (int)hipGetLastError();
+}
+
+// ---- the same kernel over PLAIN 2-D planes: dW[m][n] += sum_r dY[r][m] X[r][n], dY (rows, M) and X (rows, N) each a hi and a lo bf16 plane with the
+// channel index contiguous (rows lda / ldb elements apart) -- the weight gradients of the diffusion prior's Linears (Generation/diffusion_prior.py:
+// 167-203 differentiated w.r.t. the weights; rows = the batch).  The general split-bf16 GEMM took 37 us for each of them whatever its size (both
+// operands k-strided: transposed in registers while staged), 27 launches per step on the plan's second stream = the critical path of the backward.
+extern "C" int eegclip_wgrad_planes(const eegclip_wgrad_planes_problem* p, int n_prob, void* stream) {
+    if (!p || n_prob < 1 || n_prob > WK_MAXP) return EEGCLIP_EINVAL;
+    wk_table tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.n = n_prob;
+    int blocks = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const eegclip_wgrad_planes_problem& q = p[i];
+        if (!q.a_hi || !q.a_lo || !q.b_hi || !q.b_lo || !q.out || q.rows < WK_BK || q.rows % WK_BK || q.M < 1 || q.N < 1 || q.lda < q.M || q.ldb < q.N ||
+            q.ldo < q.N || (q.ldo & 3) || (q.N & 3) || (q.lda & 7) || (q.ldb & 7) || q.slices < 1 || q.slices > q.rows / WK_BK)
+            return EEGCLIP_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(q.a_hi) | reinterpret_cast<uintptr_t>(q.a_lo) | reinterpret_cast<uintptr_t>(q.b_hi) | reinterpret_cast<uintptr_t>(q.b_lo) |
+             reinterpret_cast<uintptr_t>(q.out)) & 15u)
+            return EEGCLIP_EALIGN;
+        wk_problem& w = tb.p[i];
+        w.a = static_cast<const unsigned char*>(q.a_hi);
+        w.b = static_cast<const unsigned char*>(q.b_hi);
+        w.a_lo = static_cast<const unsigned char*>(q.a_lo) - w.a;
+        w.b_lo = static_cast<const unsigned char*>(q.b_lo) - w.b;
+        w.a_tok = (int)(2 * q.lda);
+        w.b_tok = (int)(2 * q.ldb);
+        w.m_tiles = (q.M + 127) / 128;
+        w.n_tiles = (q.N + 127) / 128;
+        w.slices = q.slices;
+        w.bias_mfma = q.bias_out ? 1 : 0;
+        w.first_block = blocks;
+        w.sample0 = 0;
+        w.ktiles = q.rows / WK_BK;
+        w.out = q.out;
+        w.bias_out = q.bias_out;
+        w.ldo = q.ldo;
+        w.M = q.M;
+        w.N = q.N;
+        blocks += w.m_tiles * w.n_tiles * q.slices;
+    }
+    EEG_LAUNCH((wgrad_tok_kernel<4, 4, false, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, 1);
     return (int)hipGetLastError();
 }
 

@@ -509,6 +509,44 @@ typedef struct {
 long long eegclip_token_block_bwd_workspace_floats(int B);
 int eegclip_token_block_bwd(const eegclip_token_block_bwd_desc* d, int part, void* stream);
 
+/* ---- C = A B^T from bf16 hi | lo planes (csrc/gemm_planes.hip): the Linear layers of the diffusion prior (Generation/diffusion_prior.py:167-203) in
+ * EEGCLIP_PREC_BF16X3 arithmetic WITHOUT the per-launch fp32 -> plane conversion of eegclip_gemm_f32: A (M, K) and B (N, K) are each two k-contiguous
+ * bf16 planes (value = hi + lo; eegclip_split_bf16, eegclip_split_rows, or the plane output of the producing launch), rows lda / ldb ELEMENTS apart
+ * (multiples of 8, 16-byte aligned bases).  M, N multiples of 64, K of 32.  Epilogue, in this order: v = acc + bias[n]; Cpre[m][n] = v (if given);
+ * v = act(v) (EEGCLIP_ACT_NONE | EEGCLIP_ACT_SILU); v += R[m][n]; v += C[m][n] (accumulate); C[m][n] = v (if given); planes_of = 1: v again as hi | lo
+ * planes at p_hi / p_lo (row stride ldp elements), 2: the value stored to Cpre instead.  All fp32 row strides in elements, multiples of 4. */
+typedef struct {
+    const void *a_hi, *a_lo, *b_hi, *b_lo;
+    long long lda, ldb;
+    int M, N, K;
+    float* C;
+    long long ldc;
+    float* Cpre;
+    long long ldcpre;
+    const float* bias;
+    const float* R;
+    long long ldr;
+    void *p_hi, *p_lo;
+    long long ldp;
+    int act, accumulate, planes_of;
+} eegclip_gemm_planes_desc;
+int eegclip_gemm_planes(const eegclip_gemm_planes_desc* d, void* stream);
+
+/* matrices (rows, cols; multiples of 64) -> the bf16 hi | lo planes of their transposes ([cols][ld_out]; the `transpose` field is ignored): the weights a
+ * dX plane GEMM contracts over the output index, up to 24 per launch (tiled through LDS -- eegclip_split_rows' transposing path is for small matrices) */
+int eegclip_split_transpose(const eegclip_split_item* items, int n, void* stream);
+/* stage tail of the diffusion prior with plane outputs (csrc/prior.hip; Generation/diffusion_prior.py:173-175,186-199):
+ *   forward   y_ln = LayerNorm(x), y_act = dropout(SiLU(y_ln)) (+ skip), mean / rstd saved; act_hi / act_lo: y_act again as bf16 planes (or NULL)
+ *   backward  d = dropout'(dact) * silu'(y_ln); dx = LayerNorm'(d) as fp32 (dx, or NULL) and / or bf16 planes (dx_hi / dx_lo, or NULL);
+ *             dgamma += sum_rows d * xhat, dbeta += sum_rows d  -- one pass instead of eegclip_silu_bwd + eegclip_layernorm_bwd
+ *   eegclip_silu_bwd_planes: dy * silu'(pre) as planes only (n a multiple of 4, 16-byte aligned inputs) */
+int eegclip_prior_stage_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y_ln, float* y_act, float* mean, float* rstd,
+                            void* act_hi, void* act_lo, int rows, int cols, float eps, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_prior_stage_bwd(const float* dact, const float* y_ln, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                            void* dx_hi, void* dx_lo, float* dgamma, float* dbeta, int rows, int cols, float drop_p, unsigned long long seed,
+                            unsigned int site, void* stream);
+int eegclip_silu_bwd_planes(const float* dy, const float* pre, void* dx_hi, void* dx_lo, long long n, void* stream);
+
 /* ---- weight gradients of the transformer block from TOKEN-MAJOR bf16 planes (csrc/wgrad_tok.hip): dW[o][i] += sum_t dY[t][o] X[t][i], t = the
  * 64 B token rows of a batch (models/subject_layers/Transformer_EncDec.py:48-49, SelfAttention_Family.py:199-213, Embed.py:146 w.r.t. the weights).
  * Operand layout ("token planes"): per sample one 64 KB block [hi | lo][64 tokens][256 channels] bf16 -- what eegclip_token_block_fwd / _bwd and
@@ -539,6 +577,24 @@ long long eegclip_wgrad_tok_workspace_floats(const eegclip_wgrad_tok_problem* p,
 int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, int variant, void* stream);
 /* the second half of the operation (its own entry point = its own kernel: per-launch timing): out += the slices of `workspace`, same arguments */
 int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, void* stream);
+/* the same kernel over PLAIN 2-D planes: out[m][n] += sum_r dY[r][m] X[r][n] with dY (rows, M) and X (rows, N) each a hi and a lo bf16 plane, channel
+ * index contiguous, rows lda / ldb ELEMENTS apart (multiples of 8; 16-byte aligned).  rows: multiple of 32.  The kernel reads whole 128-channel tiles:
+ * the planes must be readable up to the next multiple of 128 channels past M / N in every row (a column block of a wider buffer, or 256 bytes of
+ * padding behind the last row) -- what it reads there does not reach `out`.  bias_out[m] += sum_r dY[r][m].  slices: K slices of this problem (1: plain
+ * read-modify-write of out; > 1: fp32 atomics -- small outputs that would not fill the chip otherwise).  Up to 12 problems per launch.
+ * The weight gradients of the diffusion prior's Linear layers (Generation/diffusion_prior.py:167-203, rows = the batch). */
+typedef struct {
+    const void *a_hi, *a_lo;                   /* dY planes */
+    long long lda;
+    const void *b_hi, *b_lo;                   /* X planes */
+    long long ldb;
+    int rows, M, N;
+    float* out;                                /* (M, N), row stride ldo (multiple of 4), N a multiple of 4 */
+    long long ldo;
+    float* bias_out;                           /* (M) or NULL */
+    int slices;
+} eegclip_wgrad_planes_problem;
+int eegclip_wgrad_planes(const eegclip_wgrad_planes_problem* p, int n_prob, void* stream);
 /* fp32 [rows = 64 B][cols] (row stride ld) -> token planes at dst (rows / 64 blocks of 64 KB, 16-byte aligned); heads: column 62 head + d -> channel
  * 64 head + d; ones: hi[.][255] = 1.0 */
 int eegclip_tok_planes_from_f32(const float* src, long long ld, int rows, int cols, int heads, int ones, void* dst, void* stream);
