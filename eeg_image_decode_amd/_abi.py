@@ -181,7 +181,9 @@ PROTOTYPES = {
     "eegclip_gemm_planes": [C.POINTER(GemmPlanesDesc), _P],
     "eegclip_split_transpose": [C.POINTER(SplitItem), _I, _P],
     "eegclip_prior_stage_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
-    "eegclip_prior_stage_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U, _P],
+    "eegclip_prior_stage_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U, _P, _P],
+    "eegclip_prior_stage_bwd_workspace_floats": [_I, _I],
+    "eegclip_prior_stage_bwd_params": [_P, _I, _I, _P, _P, _P],
     "eegclip_silu_bwd_planes": [_P, _P, _P, _P, _L, _P],
     "eegclip_wgrad_tok_slices": [_I, _I],
     "eegclip_wgrad_tok_workspace_floats": [C.POINTER(WgradTokProblem), _I, _I, _I],

@@ -438,6 +438,6 @@ extern "C" int eegclip_adamw_step_zero_grad(float* p, float* g, float* m, float*
 extern "C" int eegclip_sumsq(const float* x, long long n, double* out, void* stream) {
     if (!x || !out || n < 0) return EEGCLIP_EINVAL;
     if (n == 0) return 0;
-    EEG_LAUNCH(sumsq_kernel, dim3(ew_grid(n, 1024, 512)), dim3(256), 4 * sizeof(double), stream, x, n, out);
+    EEG_LAUNCH(sumsq_kernel, dim3(ew_grid(n, 1024, 256)), dim3(256), 4 * sizeof(double), stream, x, n, out);
     return (int)hipGetLastError();
 }

@@ -61,6 +61,186 @@ __global__ __launch_bounds__(256) void layernorm_silu_fwd_kernel(const float* __
     }
 }
 
+// The same stage tail with a lane owning 4 CONSECUTIVE columns (cols % 4 == 0): 16-byte loads / stores, 8-byte plane stores and ONE Philox block per
+// lane and column group (dropout_keep4: the mask of element idx is word idx & 3 of block idx >> 2 -- identical to the per-element kernel above).
+// A wave owns a row; NG column groups of 256 cover <= 1024 columns.
+template <int NG>
+__global__ __launch_bounds__(256) void prior_stage_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ skip, float* __restrict__ y_ln, float* __restrict__ y_act,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out, unsigned short* __restrict__ act_hi,
+                                                                  unsigned short* __restrict__ act_lo, int rows, int cols, float eps, float drop_p,
+                                                                  unsigned long long seed, unsigned site) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const long long base = (long long)row * cols;
+        f32x4 v[NG], sk[NG];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            const bool ok = c < cols;
+            v[i] = ok ? *reinterpret_cast<const f32x4*>(x + base + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sk[i] = ok && skip ? *reinterpret_cast<const f32x4*>(skip + base + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            if (256 * i + 4 * lane < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q += (v[i][e] - mean) * (v[i][e] - mean);
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            if (c < cols) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+                bool keep[4] = {true, true, true, true};
+                if (drop_p > 0.f) dropout_keep4(seed, site, (unsigned long long)(base + c), drop_p, keep);
+                f32x4 y, a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                    float t = silu(y[e]);
+                    if (drop_p > 0.f) t = keep[e] ? t * ks : 0.f;
+                    a[e] = t + sk[i][e];
+                }
+                *reinterpret_cast<f32x4*>(y_ln + base + c) = y;
+                *reinterpret_cast<f32x4*>(y_act + base + c) = a;
+                if (act_hi) {
+                    u32x2_t h, l;
+                    x3_split4(a[0], a[1], a[2], a[3], h, l);
+                    *reinterpret_cast<u32x2_t*>(act_hi + base + c) = h;
+                    *reinterpret_cast<u32x2_t*>(act_lo + base + c) = l;
+                }
+            }
+        }
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// Backward of a stage tail, lane = 4 consecutive columns (see prior_stage_bwd_kernel below for the arithmetic): 8 waves, a row per wave; the parameter
+// gradients of the workgroup's 8 rows meet in LDS -- one atomic per column and workgroup.
+template <int NG>
+__global__ __launch_bounds__(512) void prior_stage_bwd_v4_kernel(const float* __restrict__ dact, const float* __restrict__ y_ln, const float* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  float* __restrict__ dx, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols, float drop_p,
+                                                                  unsigned long long seed, unsigned site, float* __restrict__ partials) {
+    EEG_LDS_BASE(f32x4, red);                                // [2][8 waves][NG][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / (float)cols;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    f32x4 pg[NG], pb[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) pg[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int row = blockIdx.x * 8 + wave; row < rows; row += gridDim.x * 8) {
+        const long long base = (long long)row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[NG], xh[NG];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            g[i] = xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < cols) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dact + base + c), y4 = *reinterpret_cast<const f32x4*>(y_ln + base + c);
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + base + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
+                bool keep[4] = {true, true, true, true};
+                if (drop_p > 0.f) dropout_keep4(seed, site, (unsigned long long)(base + c), drop_p, keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = d4[e];
+                    if (drop_p > 0.f) d = keep[e] ? d * ks : 0.f;
+                    d *= silu_grad(y4[e]);
+                    xh[i][e] = (x4[e] - mu) * rs;
+                    pg[i][e] += d * xh[i][e];
+                    pb[i][e] += d;
+                    g[i][e] = d * gm[e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int c = 256 * i + 4 * lane;
+            if (c < cols) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rs * (g[i][e] - m1 - xh[i][e] * m2);
+                if (dx) *reinterpret_cast<f32x4*>(dx + base + c) = v;
+                if (dx_hi) {
+                    u32x2_t h, l;
+                    x3_split4(v[0], v[1], v[2], v[3], h, l);
+                    *reinterpret_cast<u32x2_t*>(dx_hi + base + c) = h;
+                    *reinterpret_cast<u32x2_t*>(dx_lo + base + c) = l;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        red[(wave * NG + i) * 64 + lane] = pg[i];
+        red[((8 + wave) * NG + i) * 64 + lane] = pb[i];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < NG * 64; q += 512) {         // q = i * 64 + lane  <->  columns 256 i + 4 lane .. + 3
+        const int i = q >> 6, l = q & 63, c = 256 * i + 4 * l;
+        if (c < cols) {
+            f32x4 sg = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sg;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const f32x4 a = red[(w * NG + i) * 64 + l], b = red[((8 + w) * NG + i) * 64 + l];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sg[e] += a[e]; sb[e] += b[e]; }
+            }
+            if (partials) {                                    // one partial row per workgroup: [gridDim.x][dgamma | dbeta], summed by prior_param_sum_kernel
+                float* pr = partials + (long long)blockIdx.x * 2 * cols;
+                *reinterpret_cast<f32x4*>(pr + c) = sg;
+                *reinterpret_cast<f32x4*>(pr + cols + c) = sb;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(dgamma + c + e, sg[e]);
+                    atomicAdd(dbeta + c + e, sb[e]);
+                }
+            }
+        }
+    }
+}
+
+// out[c] += sum over the partial rows, c over [dgamma | dbeta] (2 cols values): a thread per column, 4 independent accumulators.  (Every workgroup of the
+// stage-backward kernel adding its partials with atomics put 128 .. 256 workgroups x 2 cols atomics onto 64 cache lines: same-line atomics retire one after
+// the other -- 12 of that kernel's 18 us; with 32 workgroups the kernel was latency-bound instead, 16 us.)
+__global__ __launch_bounds__(256) void prior_param_sum_kernel(const float* __restrict__ partials, int parts, int cols, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    // blockIdx.y = one of gridDim.y groups of partial rows (a thread walking all 128 rows of a batch of 1024 alone took 11 us: 32 dependent-latency
+    // rounds on 8 workgroups); the groups meet with one atomic per column -- gridDim.y-way contention only
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * cols) return;
+    const int p0 = (int)((long long)blockIdx.y * parts / gridDim.y), p1 = (int)((long long)(blockIdx.y + 1) * parts / gridDim.y);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+        a0 += partials[(long long)p * 2 * cols + c];
+        a1 += partials[(long long)(p + 1) * 2 * cols + c];
+        a2 += partials[(long long)(p + 2) * 2 * cols + c];
+        a3 += partials[(long long)(p + 3) * 2 * cols + c];
+    }
+    for (; p < p1; ++p) a0 += partials[(long long)p * 2 * cols + c];
+    const float s = (a0 + a1) + (a2 + a3);
+    if (p1 > p0) atomicAdd(c < cols ? dgamma + c : dbeta + (c - cols), s);
+}
+
 // Inference form of a prior stage's tail for the sampling chain (Generation/diffusion_prior.py:186-199 inside :358-377).  Every row of a
 // sampling batch shares the timestep and the condition never changes along the chain, so the time / condition embeddings of all stages are
 // computed once per chain; what is left per stage and DDPM step is
@@ -312,22 +492,46 @@ extern "C" int eegclip_prior_stage_fwd(const float* x, const float* gamma, const
     if (rows == 0) return 0;
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
-    EEG_LAUNCH(layernorm_silu_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y_ln, y_act, mean, rstd, rows, cols, eps, drop_p,
-               seed, site, skip, static_cast<unsigned short*>(act_hi), static_cast<unsigned short*>(act_lo));
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(skip) |
+                         reinterpret_cast<uintptr_t>(y_ln) | reinterpret_cast<uintptr_t>(y_act);
+    const bool v4 = cols % 4 == 0 && !(al & 15u) && !((reinterpret_cast<uintptr_t>(act_hi) | reinterpret_cast<uintptr_t>(act_lo)) & 7u);
+    unsigned short *ph = static_cast<unsigned short*>(act_hi), *plo = static_cast<unsigned short*>(act_lo);
+    if (v4 && cols <= 256) EEG_LAUNCH(prior_stage_fwd_v4_kernel<1>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, skip, y_ln, y_act, mean, rstd, ph, plo, rows, cols, eps, drop_p, seed, site);
+    else if (v4) EEG_LAUNCH(prior_stage_fwd_v4_kernel<4>, dim3(grid), dim3(256), 0, stream, x, gamma, beta, skip, y_ln, y_act, mean, rstd, ph, plo, rows, cols, eps, drop_p, seed, site);
+    else EEG_LAUNCH(layernorm_silu_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, gamma, beta, y_ln, y_act, mean, rstd, rows, cols, eps, drop_p, seed, site, skip, ph, plo);
     return (int)hipGetLastError();
 }
 
+static int psb_grid(int rows) { const int g = (rows + 7) / 8; return g < 1 ? 1 : (g > 1024 ? 1024 : g); }
+extern "C" long long eegclip_prior_stage_bwd_workspace_floats(int rows, int cols) { return rows < 1 || cols < 1 ? 0 : (long long)psb_grid(rows) * 2 * cols; }
+
+// workspace: NULL -> the parameter gradients are added with atomics by this launch; else eegclip_prior_stage_bwd_workspace_floats(rows, cols) floats that
+// receive one partial row per workgroup, to be summed into dgamma / dbeta by eegclip_prior_stage_bwd_params (its own launch: it can run off the dX chain)
 extern "C" int eegclip_prior_stage_bwd(const float* dact, const float* y_ln, const float* x, const float* gamma, const float* mean, const float* rstd,
                                        float* dx, void* dx_hi, void* dx_lo, float* dgamma, float* dbeta, int rows, int cols, float drop_p,
-                                       unsigned long long seed, unsigned site, void* stream) {
-    if (!dact || !y_ln || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || (!dx && !dx_hi) || (!dx_hi) != (!dx_lo) || rows < 0 || cols < 1 ||
+                                       unsigned long long seed, unsigned site, float* workspace, void* stream) {
+    if (!dact || !y_ln || !x || !gamma || !mean || !rstd || (!workspace && (!dgamma || !dbeta)) || (!dx && !dx_hi) || (!dx_hi) != (!dx_lo) || rows < 0 || cols < 1 ||
         cols > 64 * LNS_MAXC || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
-    int grid = (rows + 7) / 8;                               // 2 rows per wave: the parameter-gradient partials of a workgroup cover 8 rows
+    unsigned short *ph = static_cast<unsigned short*>(dx_hi), *plo = static_cast<unsigned short*>(dx_lo);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(dact) | reinterpret_cast<uintptr_t>(y_ln) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
+                         reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace);
+    const bool v4 = cols % 4 == 0 && !(al & 15u) && !((reinterpret_cast<uintptr_t>(dx_hi) | reinterpret_cast<uintptr_t>(dx_lo)) & 7u);
+    if (workspace && !v4) return EEGCLIP_EALIGN;             // (the partial-row form is the vectorised kernel's)
+    // with a workspace: a row per wave, 8 rows per workgroup, nothing contended; without: 32 rows per workgroup, so that few workgroups end in atomics
+    int grid = workspace ? psb_grid(rows) : (rows + 31) / 32;
     if (grid > 1024) grid = 1024;
-    EEG_LAUNCH(prior_stage_bwd_kernel, dim3(grid), dim3(256), 2 * 4 * 64 * LNS_MAXC * sizeof(float), stream, dact, y_ln, x, gamma, mean, rstd, dx,
-               static_cast<unsigned short*>(dx_hi), static_cast<unsigned short*>(dx_lo), dgamma, dbeta, rows, cols, drop_p, seed, site);
+    if (v4 && cols <= 256) EEG_LAUNCH(prior_stage_bwd_v4_kernel<1>, dim3(grid), dim3(512), 2 * 8 * 1 * 64 * sizeof(f32x4), stream, dact, y_ln, x, gamma, mean, rstd, dx, ph, plo, dgamma, dbeta, rows, cols, drop_p, seed, site, workspace);
+    else if (v4) EEG_LAUNCH(prior_stage_bwd_v4_kernel<4>, dim3(grid), dim3(512), 2 * 8 * 4 * 64 * sizeof(f32x4), stream, dact, y_ln, x, gamma, mean, rstd, dx, ph, plo, dgamma, dbeta, rows, cols, drop_p, seed, site, workspace);
+    else EEG_LAUNCH(prior_stage_bwd_kernel, dim3((rows + 7) / 8 > 1024 ? 1024 : (rows + 7) / 8), dim3(256), 2 * 4 * 64 * LNS_MAXC * sizeof(float), stream, dact, y_ln, x, gamma, mean, rstd, dx, ph, plo, dgamma, dbeta, rows, cols, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_prior_stage_bwd_params(const float* workspace, int rows, int cols, float* dgamma, float* dbeta, void* stream) {
+    if (!workspace || !dgamma || !dbeta || rows < 1 || cols < 1) return EEGCLIP_EINVAL;
+    const int parts = psb_grid(rows);
+    EEG_LAUNCH(prior_param_sum_kernel, dim3((2 * cols + 255) / 256, parts >= 16 ? 16 : 1), dim3(256), 0, stream, workspace, parts, cols, dgamma, dbeta);
     return (int)hipGetLastError();
 }
 
@@ -380,6 +584,6 @@ extern "C" int eegclip_ddpm_step(const float* x, const float* eps_c, const float
 
 extern "C" int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream) {
     if (!pred || !target || n < 1 || (!loss && !dpred)) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n, 1024)), dim3(256), 4 * sizeof(float), stream, pred, target, n, loss, dpred);
+    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n / 8 + 1, 256)), dim3(256), 4 * sizeof(float), stream, pred, target, n, loss, dpred);
     return (int)hipGetLastError();
 }

@@ -73,13 +73,19 @@ __device__ __forceinline__ wk_s4 wk_tr_read(const unsigned char* p) {
 #endif
 }
 
-template <int WN, int WK_NS, bool IDX, bool L2D = false>
-__global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, int slices_all) {
-    constexpr int NWAVE = 2 * WN, NT = 8 / WN;               // n-tiles of 16 per wave
-    constexpr int IPW = 32 / NWAVE;                          // DMA instructions (1 KB each) per wave and k-tile
+// SPEC (round 4): four extra PRODUCER waves issue every LDS-DMA instruction and hold the counted vmcnt waits; the MFMA waves issue no vector-memory
+// instruction in the k-loop.  A wave that does both is in order: it stalls in each LDS-DMA issue while the CU's vector-memory path (~64 B/clk) works
+// through its queue, with its MFMAs unissued behind it -- the two costs add (tools/micro/tile_chain.hip; the InfoNCE tile kernel).
+template <int WN, int WK_NS, bool IDX, bool L2D = false, bool SPEC = false>
+__global__ __launch_bounds__(128 * WN + (SPEC ? 256 : 0)) void wgrad_tok_kernel(const wk_table tb, int slices_all) {
+    constexpr int NWAVE = 2 * WN, NT = 8 / WN;               // MFMA waves; n-tiles of 16 per wave
+    constexpr int NDW = SPEC ? 4 : NWAVE;                    // waves that issue LDS-DMA
+    constexpr int IPW = 32 / NDW;                            // DMA instructions (1 KB each) per DMA wave and k-tile
     constexpr int MPT = 4 * NT * 3;                          // MFMAs per wave and k-tile
     EEG_LDS_BASE(unsigned char, lds);
     const int t = threadIdx.x, lane = t & 63, wave = wave_uniform(t >> 6), wm = wave / WN, wn = wave % WN;
+    const bool producer = SPEC && wave >= NWAVE;             // (wave-uniform)
+    const int dw = SPEC ? (wave - NWAVE) & 3 : wave;         // index among the DMA waves
     const int fr = lane & 15, g = lane >> 4;
 
     int prob = 0;
@@ -114,11 +120,11 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
     int doff[IPW];                                           // lane's source offset within the k-tile's 16 KB token block of its plane
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int q = wave * IPW + i, row = 4 * (q & 7) + (lane >> 4), pos = lane & 15;
+        const int q = dw * IPW + i, row = 4 * (q & 7) + (lane >> 4), pos = lane & 15;
         doff[i] = row * (L2D ? ((q >> 3) < 2 ? P.a_tok : P.b_tok) : WK_TOKB) + ((pos ^ ((row & 7) << 1)) << 4);
     }
     auto issue_one = [&](int kt, int i) {                    // kt relative to kt0
-        const int q = wave * IPW + i, o = q >> 3;
+        const int q = dw * IPW + i, o = q >> 3;
         const int k = kt0 + kt;
         const int smp = IDX ? index[sample0 + (k >> 1)] : sample0 + (k >> 1);      // (wave-uniform: a scalar load)
         long long koff;
@@ -180,16 +186,9 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
         else if (n == 1) wait_vmcnt<IPW>();
         else wait_vmcnt<0>();
     };
-    auto step = [&](int kt, auto set_c, auto refill_c) {
+    auto mfmas = [&](int kt, auto set_c, auto refill_c) {
         constexpr int S = decltype(set_c)::value;
-        constexpr bool REFILL = decltype(refill_c)::value;       // compile-time: the steady state has no branches between its MFMAs
-        const bool next = REFILL || kt + 1 < nk;
-        if (next) {
-            if (REFILL) wait_vmcnt<(WK_NS - 2) * IPW>();         // tiles kt + 2 .. kt + NS - 1 may stay in flight
-            else wait_tiles(nk - 2 - kt);                        // tiles requested after kt + 1 (< NS - 1 here: nothing was refilled since)
-            raw_barrier();                                       // tile kt + 1 is visible to every wave; every wave's reads of tile kt are complete
-            read_frags(kt + 1, std::integral_constant<int, 1 - S>{});
-        }
+        constexpr bool REFILL = decltype(refill_c)::value;
         // product-major: the three MFMAs of one accumulator are 4 NT instructions apart; MFMA rows = X channels (n), columns = dY channels (m), so a
         // lane holds 4 CONSECUTIVE n of one m: 16-byte slab stores
 #pragma unroll
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
                     const bf16x8 aw = pr == 1 ? al[S][mt] : ah[S][mt];
                     acc[mt][nt] = mfma_bf16_16x16x32(bw, aw, acc[mt][nt]);      // D[n = .. + 4 g + r][m = .. + fr]
                     const int idx = (pr * 4 + mt) * NT + nt;
-                    if (REFILL && ((idx + 1) * IPW) / MPT > (idx * IPW) / MPT) issue_one(kt + WK_NS, (idx * IPW) / MPT);
+                    if (!SPEC && REFILL && ((idx + 1) * IPW) / MPT > (idx * IPW) / MPT) issue_one(kt + WK_NS, (idx * IPW) / MPT);
                 }
         if (bias) {                                          // column sums of the dY tile: every MFMA row of the product holds them
 #pragma unroll
@@ -212,6 +211,45 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
             }
         }
     };
+    auto step = [&](int kt, auto set_c, auto refill_c) {
+        constexpr int S = decltype(set_c)::value;
+        constexpr bool REFILL = decltype(refill_c)::value;       // compile-time: the steady state has no branches between its MFMAs
+        const bool next = REFILL || kt + 1 < nk;
+        if (next) {
+            if (REFILL) wait_vmcnt<(WK_NS - 2) * IPW>();         // tiles kt + 2 .. kt + NS - 1 may stay in flight
+            else wait_tiles(nk - 2 - kt);                        // tiles requested after kt + 1 (< NS - 1 here: nothing was refilled since)
+            raw_barrier();                                       // tile kt + 1 is visible to every wave; every wave's reads of tile kt are complete
+            read_frags(kt + 1, std::integral_constant<int, 1 - S>{});
+        }
+        mfmas(kt, set_c, refill_c);
+    };
+    if (SPEC) {
+        // ---- producer / consumer form: ONE fragment register set (two MFMA waves per SIMD cover each other's LDS reads; 12 waves leave 168 registers)
+        //      per k-tile: [producers: tile kt has landed] barrier [producers: refill the stage of tile kt - 1] fragment reads of tile kt, its MFMAs
+        if (producer) {
+#pragma unroll
+            for (int p = 0; p < WK_NS; ++p)
+                if (p < nk) {
+#pragma unroll
+                    for (int i = 0; i < IPW; ++i) issue_one(p, i);
+                }
+            for (int kt = 0; kt < nk; ++kt) {
+                const int fly = nk - 1 - kt < WK_NS - 2 ? nk - 1 - kt : WK_NS - 2;      // tiles kt + 1 .. kt + NS - 2 may stay in flight (kt - 1 + NS comes below)
+                wait_tiles(kt == 0 ? (nk - 1 < WK_NS - 1 ? nk - 1 : WK_NS - 1) : fly);
+                raw_barrier();
+                if (kt >= 1 && kt - 1 + WK_NS < nk) {
+#pragma unroll
+                    for (int i = 0; i < IPW; ++i) issue_one(kt - 1 + WK_NS, i);
+                }
+            }
+            return;
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            raw_barrier();
+            read_frags(kt, std::integral_constant<int, 0>{});
+            mfmas(kt, std::integral_constant<int, 0>{}, std::false_type{});
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < WK_NS; ++p)
         if (p < nk) {
@@ -242,6 +280,7 @@ __global__ __launch_bounds__(128 * WN) void wgrad_tok_kernel(const wk_table tb, 
             step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
         if (kt < nk) step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+    }
     }
 
     if (L2D) {
@@ -482,6 +521,7 @@ extern "C" int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob,
     // 256-thread 28.9 / 30.7; 5 stages (all 160 KB of LDS) 31.1 / 34.5 -- more bytes in flight do not help: the kernel moves its operands at
     // 3.3 TB/s (+ 0.8 of slab writes) with the matrix pipe of the CUs it occupies 50 % busy (profiles/r4_pmc_wgrad_tok.json)
     if (tb.index) EEG_LAUNCH((wgrad_tok_kernel<4, 4, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
+    else if (variant == 2) EEG_LAUNCH((wgrad_tok_kernel<4, 4, false, false, true>), dim3((unsigned)blocks), dim3(768), 4 * WK_STAGE, stream, tb, slices);
     else if (variant == 1) EEG_LAUNCH((wgrad_tok_kernel<2, 4, false>), dim3((unsigned)blocks), dim3(256), 4 * WK_STAGE, stream, tb, slices);
     else EEG_LAUNCH((wgrad_tok_kernel<4, 4, false>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
     return (int)hipGetLastError();
@@ -537,7 +577,7 @@ extern "C" int eegclip_wgrad_planes(const eegclip_wgrad_planes_problem* p, int n
         w.N = q.N;
         blocks += w.m_tiles * w.n_tiles * q.slices;
     }
-    EEG_LAUNCH((wgrad_tok_kernel<4, 4, false, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, 1);
+    EEG_LAUNCH((wgrad_tok_kernel<4, 4, false, true, true>), dim3((unsigned)blocks), dim3(768), 4 * WK_STAGE, stream, tb, 1);
     return (int)hipGetLastError();
 }
 

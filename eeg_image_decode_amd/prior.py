@@ -20,7 +20,7 @@ from torch.utils.data import Dataset
 
 from . import _abi
 from ._lib import EegclipError, check, lib, raw_stream, require_cuda
-from .plan import Plan
+from .plan import Plan, default_gemm_precision
 
 D = _abi.dim
 ACT_SILU = _abi.ACT_SILU
@@ -341,6 +341,160 @@ class _PriorEngine:
         pl.x_gemm = wgrad("input_layer.0.weight", _p(b["dlinI"]), h0, 0, E, h0, E, False, bias="input_layer.0.bias")
         return pl
 
+    # ---- training plans over bf16 hi | lo PLANES (round 4) ---------------------------------------------------------------------------------
+    # Every Linear of the step takes its operands as planes and leaves its result as planes for the next one (csrc/gemm_planes.hip: C = A B^T;
+    # csrc/wgrad_tok.hip: the weight gradients, contraction over the batch through LDS transpose reads), so nothing is converted inside a GEMM.
+    # The general split-bf16 GEMM split both fp32 operands in every workgroup of every launch: ~20 us per launch on these shapes whatever their
+    # size, 37 us for each of the 27 weight gradients (both operands k-strided) -- 64 launches, 1.33 of the step's 1.5 ms.
+    def _planes_ok(self, N, cond_rows):
+        m = self.model
+        dims = [m.embed_dim, m.time_embed_dim] + list(m.hidden_dim) + ([m.cond_dim] if m.cond_dim else [])
+        return (cond_rows is None and N % 64 == 0 and all(d % 64 == 0 for d in dims) and default_gemm_precision() == _abi.PREC_BF16X3
+                and os.environ.get("EEGCLIP_PRIOR_PLANES", "1") != "0")
+
+    def _alloc_planes(self, N, b):
+        if "xp" in b:
+            return
+        dev, m, W = self.device, self.model, self.wide
+        bf = lambda rows, cols: torch.zeros(2, rows * cols + 256, dtype=torch.bfloat16, device=dev)      # [hi | lo]; 512 bytes of slack: the weight-gradient
+        #                                                                                                    kernel reads whole 128-channel tiles
+        b.update(xp=bf(N, m.embed_dim), cp=bf(N, m.cond_dim), tembp=bf(N, m.time_embed_dim), T1actP=bf(N, W), XINP=bf(N, W), actLP=bf(N, m.hidden_dim[0]),
+                 doutP=bf(N, m.embed_dim), DXINP=bf(N, W), DT1P=bf(N, W), dlinIP=bf(N, m.hidden_dim[0]))
+        for s, st in enumerate(self.stages):
+            b[f"dlinP{s}"] = bf(N, st["hout"])
+        if not hasattr(self, "wp"):
+            self.wp = torch.zeros(2, self.flat.numel(), dtype=torch.bfloat16, device=dev)       # planes of the whole flat parameter buffer, same offsets
+            self.wt = {}                                                                        # transposed planes of the weights the dX GEMMs contract over
+            for st in self.stages:
+                for k in (st["l"] + "0.weight", st["t"] + "linear_2.weight"):
+                    r, c = self.P[k].shape
+                    self.wt[k] = torch.zeros(2, c * r, dtype=torch.bfloat16, device=dev)
+            r, c = self.P["output_layer.weight"].shape
+            self.wt["output_layer.weight"] = torch.zeros(2, c * r, dtype=torch.bfloat16, device=dev)
+
+    def _wplanes(self, k):
+        off = (self.P[k].data_ptr() - self.flat.data_ptr()) // 2            # bytes into a bf16 plane = half the fp32 byte offset
+        return self.wp[0].data_ptr() + off, self.wp[1].data_ptr() + off
+
+    @staticmethod
+    def _pl(t, col=0):
+        return t[0].data_ptr() + 2 * col, t[1].data_ptr() + 2 * col
+
+    def _gp(self, pl, A, lda, Bw, ldb, M, Nn, K, side=False, **kw):
+        a_hi, a_lo = A
+        b_hi, b_lo = Bw
+        d = _abi.GemmPlanesDesc(a_hi=a_hi, a_lo=a_lo, b_hi=b_hi, b_lo=b_lo, lda=lda, ldb=ldb, M=M, N=Nn, K=K, **kw)
+        return pl.call_desc("eegclip_gemm_planes", d, side=side)
+
+    def _build_fwd_planes(self, N, cond, p):
+        P, b, m = self.P, self.bufs[N], self.model
+        self._alloc_planes(N, b)
+        pl = Plan(f"prior_fwd_planes[N={N}]")
+        pl.planes = True
+        E, Td, Cd, h0, W = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0], self.wide
+        pl.call("eegclip_timestep_embedding", _p(b["tt"]), N, Td, _p(b["temb"]))
+        # this step's weights as planes: the flat parameter buffer in one pass (a Linear's planes sit at its offset), the transposes the dX GEMMs need
+        pl.call("eegclip_split_bf16", _p(self.flat), self.wp[0].data_ptr(), self.wp[1].data_ptr(), self.flat.numel())
+        items = []
+        for k, t in self.wt.items():
+            r, c = P[k].shape
+            items.append(_abi.SplitItem(src=_p(P[k]), hi=t[0].data_ptr(), lo=t[1].data_ptr(), rows=r, cols=c, ld_src=c, ld_out=r, transpose=1))
+        arr = (_abi.SplitItem * len(items))(*items)
+        pl._keep.append(arr)
+        pl.call("eegclip_split_transpose", arr, len(items))
+        # the inputs: x, c (patched per call) and the timestep sinusoid
+        ins = [_abi.SplitItem(src=0, hi=b["xp"][0].data_ptr(), lo=b["xp"][1].data_ptr(), rows=N, cols=E, ld_src=E, ld_out=E, transpose=0),
+               _abi.SplitItem(src=_p(b["temb"]), hi=b["tembp"][0].data_ptr(), lo=b["tembp"][1].data_ptr(), rows=N, cols=Td, ld_src=Td, ld_out=Td, transpose=0)]
+        if cond:
+            ins.append(_abi.SplitItem(src=0, hi=b["cp"][0].data_ptr(), lo=b["cp"][1].data_ptr(), rows=N, cols=Cd, ld_src=Cd, ld_out=Cd, transpose=0))
+        pl.in_items = (_abi.SplitItem * len(ins))(*ins)
+        pl._keep.append(pl.in_items)
+        pl.call("eegclip_split_rows", pl.in_items, len(ins))
+        self._gp(pl, self._pl(b["xp"]), E, self._wplanes("input_layer.0.weight"), E, N, h0, E, C=_p(b["linI"]), ldc=h0, bias=_p(P["input_layer.0.bias"]))
+        pl.call("eegclip_prior_stage_fwd", _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(P["input_layer.1.bias"]), None, _p(b["lnI"]), _p(b["actI"]),
+                _p(b["muI"]), _p(b["rsI"]), None, None, N, h0, 1e-5, 0.0, 0, 0)
+        s0 = self.stages[0]
+        # all eight time-embedding hidden layers: SiLU(t_emb W1^T + b1) as planes (pre-activation kept in fp32 for the backward)
+        self._gp(pl, self._pl(b["tembp"]), Td, self._wplanes(s0["t"] + "linear_1.weight"), Td, N, W, Td, Cpre=_p(b["T1pre"]), ldcpre=W,
+                 bias=_p(P[s0["t"] + "linear_1.bias"]), act=ACT_SILU, p_hi=b["T1actP"][0].data_ptr(), p_lo=b["T1actP"][1].data_ptr(), ldp=W, planes_of=1)
+        if cond:
+            self._gp(pl, self._pl(b["cp"]), Cd, self._wplanes(s0["c"] + "weight"), Cd, N, W, Cd, C=_p(b["XIN"]), ldc=W, bias=_p(P[s0["c"] + "bias"]))
+        cur, skips = "actI", []
+        n_enc, n_st = m.num_layers - 1, len(self.stages)
+        for s, st in enumerate(self.stages):
+            hi, ho, c0 = st["hin"], st["hout"], self.col0[s]
+            if st["dec"] is None:
+                skips.append(cur)
+            xh, xl = self._pl(b["XINP"], c0)
+            # stage input x + t_emb (+ c_emb): fp32 accumulator column block of XIN, and its planes for the stage Linear and its weight gradient
+            self._gp(pl, self._pl(b["T1actP"], c0), W, self._wplanes(st["t"] + "linear_2.weight"), hi, N, hi, hi, C=_p(b["XIN"]) + 4 * c0, ldc=W,
+                     bias=_p(P[st["t"] + "linear_2.bias"]), R=_p(b[cur]), ldr=hi, accumulate=1 if cond else 0, p_hi=xh, p_lo=xl, ldp=W, planes_of=1)
+            self._gp(pl, (xh, xl), W, self._wplanes(st["l"] + "0.weight"), hi, N, ho, hi, C=_p(b[f"lin{s}"]), ldc=ho, bias=_p(P[st["l"] + "0.bias"]))
+            last = s == n_st - 1
+            skip = _p(b[skips[n_enc - 1 - st["dec"]]]) if st["dec"] is not None else None          # x += hidden_activations[-1-j]
+            pl.call("eegclip_prior_stage_fwd", _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(P[st["l"] + "1.bias"]), skip, _p(b[f"ln{s}"]), _p(b[f"act{s}"]),
+                    _p(b[f"mu{s}"]), _p(b[f"rs{s}"]), b["actLP"][0].data_ptr() if last else None, b["actLP"][1].data_ptr() if last else None, N, ho, 1e-5, p, 0, s,
+                    seed_at=14)
+            cur = f"act{s}"
+        self._gp(pl, self._pl(b["actLP"]), h0, self._wplanes("output_layer.weight"), h0, N, E, h0, C=_p(b["out"]), ldc=E, bias=_p(P["output_layer.bias"]))
+        return pl
+
+    def _build_bwd_planes(self, N, cond, p):
+        P, G, b, m = self.P, self.G, self.bufs[N], self.model
+        pl = Plan(f"prior_bwd_planes[N={N}]")
+        pl.planes = True
+        E, Td, Cd, h0, W = m.embed_dim, m.time_embed_dim, m.cond_dim, m.hidden_dim[0], self.wide
+
+        def wgrad(problems):
+            """weight (+ bias) gradients on the plan's second stream: (weight key, bias key, dY planes, ld, M, X planes, ld, N); small outputs are
+            K-sliced (fp32 atomics onto few addresses), large ones are one read-modify-write pass"""
+            arr = (_abi.WgradPlanesProblem * len(problems))()
+            for i, (wk, bk, dy, lda, M, x, ldb, Nn) in enumerate(problems):
+                tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+                slices = 1 if tiles >= 48 else max(1, min(8, N // 32 // 4, 64 // tiles))
+                arr[i] = _abi.WgradPlanesProblem(a_hi=dy[0], a_lo=dy[1], lda=lda, b_hi=x[0], b_lo=x[1], ldb=ldb, rows=N, M=M, N=Nn, out=_p(G[wk]), ldo=Nn,
+                                                 bias_out=_p(G[bk]), slices=slices)
+            pl._keep.append(arr)
+            pl.call("eegclip_wgrad_planes", arr, len(problems), side=True)
+
+        n_st, n_enc = len(self.stages), m.num_layers - 1
+        pl.call("eegclip_split_bf16", _p(b["dout"]), b["doutP"][0].data_ptr(), b["doutP"][1].data_ptr(), N * E)
+        wt = lambda k: (self.wt[k][0].data_ptr(), self.wt[k][1].data_ptr())
+        wgrad([("output_layer.weight", "output_layer.bias", self._pl(b["doutP"]), E, E, self._pl(b["actLP"]), h0, h0)])
+        self._gp(pl, self._pl(b["doutP"]), E, wt("output_layer.weight"), E, N, h0, E, C=_p(b[f"dact{n_st - 1}"]), ldc=h0)
+        for s in range(n_st - 1, -1, -1):
+            st = self.stages[s]
+            hi, ho, c0 = st["hin"], st["hout"], self.col0[s]
+            dl = self._pl(b[f"dlinP{s}"])
+            ws = b.setdefault(f"psb_ws{s}", torch.empty(int(lib().eegclip_prior_stage_bwd_workspace_floats(N, ho)), dtype=torch.float32, device=self.device))
+            pl.call("eegclip_prior_stage_bwd", _p(b[f"dact{s}"]), _p(b[f"ln{s}"]), _p(b[f"lin{s}"]), _p(P[st["l"] + "1.weight"]), _p(b[f"mu{s}"]), _p(b[f"rs{s}"]),
+                    None, dl[0], dl[1], None, None, N, ho, p, 0, s, _p(ws), seed_at=14)
+            pl.call("eegclip_prior_stage_bwd_params", _p(ws), N, ho, _p(G[st["l"] + "1.weight"]), _p(G[st["l"] + "1.bias"]), side=True)
+            # dxin = dlin W: as planes (operand of the time-embedding dX GEMM and of three weight gradients); in the same epilogue the gradient w.r.t.
+            # the previous activation = dxin (+ the skip branch for encoder stages: decode stage j = n_enc-1-i adds skips[i])
+            dst = _p(b[f"dact{s - 1}"]) if s > 0 else _p(b["dactI"])
+            skip = _p(b[f"dact{n_enc + (n_enc - 1 - s)}"]) if st["dec"] is None else None
+            dx = self._pl(b["DXINP"], c0)
+            self._gp(pl, dl, ho, wt(st["l"] + "0.weight"), ho, N, hi, ho, C=dst, ldc=hi, R=skip, ldr=hi, p_hi=dx[0], p_lo=dx[1], ldp=W, planes_of=2)
+            wgrad([(st["l"] + "0.weight", st["l"] + "0.bias", dl, ho, ho, self._pl(b["XINP"], c0), W, hi),
+                   (st["t"] + "linear_2.weight", st["t"] + "linear_2.bias", dx, W, hi, self._pl(b["T1actP"], c0), W, hi)])
+            # gradient of the time embedding's hidden layer, into this stage's columns of DT1
+            self._gp(pl, dx, W, wt(st["t"] + "linear_2.weight"), hi, N, hi, hi, C=_p(b["DT1"]) + 4 * c0, ldc=W)
+        s0 = self.stages[0]
+        if cond:                                   # all eight condition Linears: ONE weight gradient (wide x cond_dim) from the wide dxin planes
+            wgrad([(s0["c"] + "weight", s0["c"] + "bias", self._pl(b["DXINP"]), W, W, self._pl(b["cp"]), Cd, Cd)])
+        pl.call("eegclip_silu_bwd_planes", _p(b["DT1"]), _p(b["T1pre"]), b["DT1P"][0].data_ptr(), b["DT1P"][1].data_ptr(), N * W)
+        di = self._pl(b["dlinIP"])
+        ws = b.setdefault("psb_wsI", torch.empty(int(lib().eegclip_prior_stage_bwd_workspace_floats(N, h0)), dtype=torch.float32, device=self.device))
+        pl.call("eegclip_prior_stage_bwd", _p(b["dactI"]), _p(b["lnI"]), _p(b["linI"]), _p(P["input_layer.1.weight"]), _p(b["muI"]), _p(b["rsI"]), None, di[0], di[1],
+                None, None, N, h0, 0.0, 0, 0, _p(ws))
+        pl.call("eegclip_prior_stage_bwd_params", _p(ws), N, h0, _p(G["input_layer.1.weight"]), _p(G["input_layer.1.bias"]), side=True)
+        # the last two weight gradients (the eight first time-embedding Linears as one wide x 512 block, the input Linear) are ONE launch: nothing is
+        # left to run under them, and together their 92 + 64 output tiles are one wave of workgroups
+        wgrad([(s0["t"] + "linear_1.weight", s0["t"] + "linear_1.bias", self._pl(b["DT1P"]), W, W, self._pl(b["tembp"]), Td, Td),
+               ("input_layer.0.weight", "input_layer.0.bias", di, h0, h0, self._pl(b["xp"]), E, E)])
+        return pl
+
     def forward(self, x, t, c, p, cond_rows=None):
         """cond_rows (inference only): the condition embeddings `c` (cond_rows, cond_dim) apply to the FIRST cond_rows rows of x, the rest run
         unconditioned -- a classifier-free-guidance pair in one pass of 2N rows (the condition term is a separate accumulate-GEMM,
@@ -353,12 +507,17 @@ class _PriorEngine:
         key = (N, cond, p) if cond_rows is None else (N, cond, p, cond_rows)
         pk = ("f",) + key
         if pk not in self.plans:
-            self.plans[pk] = self._build_fwd(N, cond, p, cond_rows)
+            self.plans[pk] = self._build_fwd_planes(N, cond, p) if self._planes_ok(N, cond_rows) else self._build_fwd(N, cond, p, cond_rows)
         pl = self.plans[pk]
         b["tt"].copy_(t)
-        pl.x_gemm.A = x.data_ptr()
-        for g in pl.c_gemms:
-            g.A = c.data_ptr()
+        if getattr(pl, "planes", False):
+            pl.in_items[0].src = x.data_ptr()
+            if cond:
+                pl.in_items[2].src = c.data_ptr()
+        else:
+            pl.x_gemm.A = x.data_ptr()
+            for g in pl.c_gemms:
+                g.A = c.data_ptr()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
         b["seed"] = seed
         pl.run(raw_stream(), seed)
@@ -385,14 +544,16 @@ class _PriorEngine:
         b = self.bufs[N]
         pk = ("b",) + key
         if pk not in self.plans:
-            self.plans[pk] = self._build_bwd(N, cond, p)
+            fwd = self.plans.get(("f",) + key)
+            self.plans[pk] = self._build_bwd_planes(N, cond, p) if getattr(fwd, "planes", False) else self._build_bwd(N, cond, p)
         pl = self.plans[pk]
         self.attach_grads(cond)
         if dout.data_ptr() != b["dout"].data_ptr():
             b["dout"].copy_(dout)
-        pl.x_gemm.B = x.data_ptr()
-        for g in pl.c_gemms:
-            g.B = c.data_ptr()
+        if not getattr(pl, "planes", False):
+            pl.x_gemm.B = x.data_ptr()
+            for g in pl.c_gemms:
+                g.B = c.data_ptr()
         pl.run(raw_stream(), b.get("seed", 0))
 
 

@@ -544,7 +544,12 @@ int eegclip_prior_stage_fwd(const float* x, const float* gamma, const float* bet
                             void* act_hi, void* act_lo, int rows, int cols, float eps, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 int eegclip_prior_stage_bwd(const float* dact, const float* y_ln, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                             void* dx_hi, void* dx_lo, float* dgamma, float* dbeta, int rows, int cols, float drop_p, unsigned long long seed,
-                            unsigned int site, void* stream);
+                            unsigned int site, float* workspace, void* stream);
+/* workspace == NULL: dgamma / dbeta are added by that launch (atomics).  Else (cols % 4 == 0, 16-byte aligned) it takes
+ * eegclip_prior_stage_bwd_workspace_floats(rows, cols) floats of per-workgroup partial rows and eegclip_prior_stage_bwd_params adds their column sums to
+ * dgamma / dbeta -- a launch of its own, so it can run off the dX chain */
+long long eegclip_prior_stage_bwd_workspace_floats(int rows, int cols);
+int eegclip_prior_stage_bwd_params(const float* workspace, int rows, int cols, float* dgamma, float* dbeta, void* stream);
 int eegclip_silu_bwd_planes(const float* dy, const float* pre, void* dx_hi, void* dx_lo, long long n, void* stream);
 
 /* ---- weight gradients of the transformer block from TOKEN-MAJOR bf16 planes (csrc/wgrad_tok.hip): dW[o][i] += sum_t dY[t][o] X[t][i], t = the

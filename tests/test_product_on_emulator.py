@@ -474,6 +474,43 @@ def test_prior_sampling_chain_under_emulator_matches_oracle(guided):
     np.testing.assert_allclose(h.numpy(), ho.numpy(), atol=2e-4)
 
 
+@pytest.mark.parametrize("cond", [True, False], ids=["conditioned", "unconditioned"])
+def test_prior_training_step_on_plane_gemms_equals_the_fp32_operand_plans(cond, monkeypatch):
+    """configs[3]'s training plans over bf16 planes (csrc/gemm_planes.hip, eegclip_wgrad_planes, fused stage tails; batch a multiple of 64) against the
+    launch-per-Linear plans on fp32 operands (EEGCLIP_PRIOR_PLANES=0): same epsilon prediction, same gradient for every parameter, dropout masks
+    included.  A narrow model so that the lane emulator finishes in seconds; the arithmetic (three split products, fp32 accumulate) is the same in both."""
+    rng = np.random.default_rng(12)
+    N, E, Cd = 64, 128, 64
+    x, c = T(rng.standard_normal((N, E)).astype(np.float32)), T(rng.standard_normal((N, Cd)).astype(np.float32) * 4)
+    tt = torch.from_numpy(rng.integers(0, 1000, N))
+    w = T(rng.standard_normal((N, E)).astype(np.float32))
+    res = {}
+    with product_on_emulator():
+        from eeg_image_decode_amd.prior import DiffusionPriorUNet
+        for mode in ("1", "0"):
+            monkeypatch.setenv("EEGCLIP_PRIOR_PLANES", mode)
+            torch.manual_seed(5)
+            m = DiffusionPriorUNet(embed_dim=E, cond_dim=Cd, hidden_dim=[128, 64, 64], time_embed_dim=64, dropout=0.2).train()
+            torch.manual_seed(6)                                   # the forward draws its dropout seed from torch's generator
+            out = m(x, tt, c if cond else None)
+            (out * w).sum().backward()
+            eng = m._engine()
+            names = eng.plans[next(k for k in eng.plans if k[0] == "f")].op_names()
+            assert ("eegclip_gemm_planes" in names) == (mode == "1") and ("eegclip_gemm_f32" in names) == (mode == "0")
+            bn = eng.plans[next(k for k in eng.plans if k[0] == "b")].op_names()
+            assert ("eegclip_wgrad_planes" in bn) == (mode == "1")
+            res[mode] = (out.detach().clone(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()})
+    o1, g1 = res["1"]
+    o0, g0 = res["0"]
+    np.testing.assert_allclose(o1.numpy(), o0.numpy(), atol=2e-5 * max(1.0, float(o0.abs().max())))
+    for k in g0:
+        if g0[k] is None:
+            assert g1[k] is None, k
+            continue
+        assert g1[k] is not None, k
+        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), atol=1e-6 + 2e-4 * float(g0[k].abs().max()), err_msg=k)
+
+
 @pytest.fixture(scope="module")
 def small_things_tree(tmp_path_factory):
     """the synthetic THINGS-EEG tree with the reference's class counts (they are hard-coded in its loader) but one channel pair and few samples"""

@@ -52,7 +52,7 @@ for name, probs in LAUNCHES.items():
             continue
         ws = torch.empty(int(L.eegclip_wgrad_tok_workspace_floats(arr, len(probs), B, slices)), device="cuda")
         row = {}
-        for v in ((int(ONLY[2]),) if ONLY else (0, 1)):
+        for v in ((int(ONLY[2]),) if ONLY else (0, 1, 2)):          # 512 threads | 256 threads | 8 MFMA + 4 producer waves
             t = ev(lambda: L.eegclip_wgrad_tok(arr, len(probs), B, slices, ws.data_ptr(), v, st))
             row[f"kernel_v{v}_us"] = round(t, 2)
         row["reduce_us"] = round(ev(lambda: L.eegclip_wgrad_tok_reduce(arr, len(probs), B, slices, ws.data_ptr(), st)), 2)
