@@ -359,6 +359,19 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
     const int orow_n = E.transpose ? E.cols : E.rows, ocol_n = E.transpose ? E.rows : E.cols;
     const long long per_row = E.ld_out;                              // output elements per row incl. padding
     const long long total = (long long)orow_n * per_row;
+    const int span = (ei + 1 < tb.n ? tb.e[ei + 1].first_block : (int)gridDim.x) - E.first_block;
+    if (!E.transpose && E.ld_src == E.cols && E.ld_out == E.cols && (total & 3) == 0 &&
+        !((reinterpret_cast<uintptr_t>(E.src) & 15u) | ((reinterpret_cast<uintptr_t>(E.hi) | reinterpret_cast<uintptr_t>(E.lo)) & 7u))) {
+        // a dense matrix split in place-order (the diffusion prior's 1024-wide inputs): 4 elements per lane, 16-byte loads, 8-byte plane stores
+        for (long long q4 = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; 4 * q4 < total; q4 += 256LL * span) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(E.src + 4 * q4);
+            u32x2_t h, l;
+            x3_split4(v[0], v[1], v[2], v[3], h, l);
+            *reinterpret_cast<u32x2_t*>(E.hi + 4 * q4) = h;
+            *reinterpret_cast<u32x2_t*>(E.lo + 4 * q4) = l;
+        }
+        return;
+    }
     for (long long q = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; q < total;
          q += 256LL * ((ei + 1 < tb.n ? tb.e[ei + 1].first_block : (int)gridDim.x) - E.first_block)) {
         const int r = (int)(q / per_row), c = (int)(q % per_row);
