@@ -522,6 +522,7 @@ extern "C" int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob,
     // 3.3 TB/s (+ 0.8 of slab writes) with the matrix pipe of the CUs it occupies 50 % busy (profiles/r4_pmc_wgrad_tok.json)
     if (tb.index) EEG_LAUNCH((wgrad_tok_kernel<4, 4, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
     else if (variant == 2) EEG_LAUNCH((wgrad_tok_kernel<4, 4, false, false, true>), dim3((unsigned)blocks), dim3(768), 4 * WK_STAGE, stream, tb, slices);
+    else if (variant == 3) EEG_LAUNCH((wgrad_tok_kernel<2, 4, false, false, true>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
     else if (variant == 1) EEG_LAUNCH((wgrad_tok_kernel<2, 4, false>), dim3((unsigned)blocks), dim3(256), 4 * WK_STAGE, stream, tb, slices);
     else EEG_LAUNCH((wgrad_tok_kernel<4, 4, false>), dim3((unsigned)blocks), dim3(512), 4 * WK_STAGE, stream, tb, slices);
     return (int)hipGetLastError();

@@ -119,13 +119,13 @@ def run_problems(be, names, B, slices, variant, seed=0):
             np.testing.assert_array_equal(gb, 0.0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", list(CASES))
 def test_wgrad_tok_single_problem(be, name, variant):
     run_problems(be, [name], 2, 1, variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_wgrad_tok_grouped_launch_and_slices(be, variant):
     run_problems(be, ["ffn2", "ffn1", "out_proj"], 4, 2, variant, seed=3)       # 8 k-tiles in 2 slices: 4 per workgroup = the ring's full depth
 
@@ -133,7 +133,7 @@ def test_wgrad_tok_grouped_launch_and_slices(be, variant):
 def test_wgrad_tok_is_reproducible_and_shape_independent(be):
     """same operands -> bit-identical gradients from both workgroup shapes and from a second run (ordered slab reduction, no atomics)"""
     res = []
-    for variant in (0, 1, 2, 0):
+    for variant in (0, 1, 2, 3, 0):
         rng = np.random.default_rng(11)
         B, slices = 4, 2
         dy, x = rng.standard_normal((64 * B, 250)).astype(np.float32), rng.standard_normal((64 * B, 250)).astype(np.float32)
@@ -199,7 +199,7 @@ def test_wgrad_tok_per_subject_full_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_wgrad_tok_full_size(variant):
     from backends import get
     b = get("gpu")

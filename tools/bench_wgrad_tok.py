@@ -47,12 +47,12 @@ for name, probs in LAUNCHES.items():
                                       out=out.data_ptr(), ldo=N, bias_out=bias.data_ptr(), bias_mfma=bm)
     groups = sum(p[2] for p in probs)
     flops = sum(2.0 * p[0] * p[1] * 64 * B for p in probs)
-    for slices in sorted({8, 16, 24, 32, 64, int(L.eegclip_wgrad_tok_slices(groups, B))}):
+    for slices in sorted({8, 16, 20, 21, 24, 32, 40, 42, 64, int(L.eegclip_wgrad_tok_slices(groups, B))}):
         if 4 * groups * slices > 1024 or (ONLY and slices != int(ONLY[1])):
             continue
         ws = torch.empty(int(L.eegclip_wgrad_tok_workspace_floats(arr, len(probs), B, slices)), device="cuda")
         row = {}
-        for v in ((int(ONLY[2]),) if ONLY else (0, 1, 2)):          # 512 threads | 256 threads | 8 MFMA + 4 producer waves
+        for v in ((int(ONLY[2]),) if ONLY else (0, 2, 3)):          # 512 threads | 256 threads | 8 MFMA + 4 producer waves
             t = ev(lambda: L.eegclip_wgrad_tok(arr, len(probs), B, slices, ws.data_ptr(), v, st))
             row[f"kernel_v{v}_us"] = round(t, 2)
         row["reduce_us"] = round(ev(lambda: L.eegclip_wgrad_tok_reduce(arr, len(probs), B, slices, ws.data_ptr(), st)), 2)
