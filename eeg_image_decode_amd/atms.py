@@ -273,9 +273,10 @@ class ATMS(nn.Module):
                     host_ids = [hint] * x.shape[0] if hint is not None else subject_ids.tolist()
             if len(host_ids) != x.shape[0]:
                 raise EegclipError(f"subject_ids has {len(host_ids)} entries for a batch of {x.shape[0]}")
-            bad = [i for i in host_ids if not 0 <= i < self.table_subjects]
-            if bad:
-                raise EegclipError(f"joint_train model has value embeddings for subjects 0..{self.table_subjects - 1}; got id {bad[0]}")
+            host_ids = np.asarray(host_ids, dtype=np.int64)
+            if host_ids.size and (host_ids.min() < 0 or host_ids.max() >= self.table_subjects):
+                bad = host_ids[(host_ids < 0) | (host_ids >= self.table_subjects)]
+                raise EegclipError(f"joint_train model has value embeddings for subjects 0..{self.table_subjects - 1}; got id {int(bad[0])}")
             ids, shared = subject_ids.to(device=x.device, dtype=torch.long), False
         elif subject_ids is None:
             ids, shared = None, True
@@ -289,7 +290,7 @@ class ATMS(nn.Module):
             if hint is not None:
                 shared = hint >= 10
             elif host is not None:
-                shared = any(i >= 10 for i in host)
+                shared = bool((np.asarray(host) >= 10).any())
             else:
                 shared = bool((ids >= 10).any())                            # the reference syncs here too
             if shared:
@@ -978,9 +979,10 @@ class _Engine:
                 perm = np.argsort(a, kind="stable")
                 b["perm"].copy_(torch.from_numpy(perm.astype(np.int32)))
                 a = a[perm]
-            starts = np.flatnonzero(np.r_[True, a[1:] != a[:-1]])
-            ends = np.r_[starts[1:], B]
-            b["segs"] = [(int(a[i]), int(i), int(j - i)) for i, j in zip(starts, ends)]
+            # (subject s occupies positions [starts[s], starts[s] + counts[s]) of the subject-ordered batch)
+            counts = np.bincount(a, minlength=max(self.n_subj, 1))
+            starts = np.cumsum(counts) - counts
+            b["segs"] = [(s_, st, c) for s_, (st, c) in enumerate(zip(starts.tolist(), counts.tolist())) if c]
             b["in_order"] = in_order
         segs, in_order = b["segs"], b["in_order"]
         XR, HR = 4 * N_CH * T_LEN, 4 * L_TOK * D_MODEL
