@@ -536,6 +536,9 @@ def main():
         if i_ramp % 16 == 0:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
+    # what the product's own loops do before their first step (retrieval.train_model, Pipe.train): one full collection + gc.freeze(), so that no
+    # generation-2 collection -- 75 ms on this host, at an unpredictable step (tools/host_stalls.py) -- lands in an epoch.  Before the warm-up, not in the clock.
+    retrieval.settle_gc()
     for i in range(args.warmup):
         step(i)
     eng = model._engine()
@@ -731,7 +734,9 @@ def main():
                    "optimizer": "AdamW lr 3e-4 (fused)", "final_mean_loss": round(final_loss, 4),
                    "gemm_arithmetic": "bf16x3 split products, fp32 accumulate (embeddings within 3e-5 of exact fp32 products)"
                    if os.environ.get("EEGCLIP_GEMM_PRECISION", "bf16x3") != "f32" else "exact fp32 products (v_mfma_f32_16x16x4_f32)",
-                   "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4)},
+                   "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
+                   "python_gc": "gc.collect() + gc.freeze() once before the warm-up, as the product's training loops do (retrieval.settle_gc): a "
+                                "generation-2 collection costs 75 ms on this host"},
         "roofline": roof,
     }
     if distributed is not None:

@@ -679,8 +679,10 @@ class Pipe:
     def train(self, dataloader, num_epochs=10, learning_rate=1e-4):
         from . import dist as edist
         from . import optim
+        from .retrieval import settle_gc
         prior = self.diffusion_prior
         prior.train()
+        settle_gc()                                   # no generation-2 collection (75 ms on this host) in the middle of an epoch
         device = self.device
         optimizer = optim.Adam(prior.parameters(), lr=learning_rate)
         total_steps = len(dataloader) * num_epochs

@@ -79,6 +79,22 @@ def _uniform_ids(batch_size, subject_id, device):
 
 
 _UNIFORM_IDS = {}
+_GC_SETTLED = False
+
+
+def settle_gc(force=False):
+    """One full collection, then gc.freeze(): everything alive now -- the module graphs of torch and the libraries it pulled in, millions of tracked
+    objects -- moves to the permanent generation and is never walked again.  Python's generation-2 collection otherwise walks all of it at an
+    unpredictable step of an epoch: 75 ms on the MI355X host (tools/host_stalls.py), as long as 80 training steps, with the GPU queue running dry
+    behind it.  Called once per process by the training loops (train_model, Pipe.train) before their first step; semantics are unchanged (objects
+    created afterwards are collected as usual)."""
+    global _GC_SETTLED
+    if _GC_SETTLED and not force:
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_SETTLED = True
 
 
 _SIDE = {}
@@ -102,6 +118,8 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
     clearing pass; `loss_acc` is a device scalar (added to in place) or a list (appended to).
     Under torch.distributed (world > 1) the loss gathers embeddings across ranks and the flat gradient is averaged."""
     from . import dist as edist
+    if not _GC_SETTLED:
+        settle_gc()
     optimizer.zero_grad()
     overlap = edist.world_size() > 1 and hasattr(eeg_model, "_engine") and os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0"
     prev_overlap = getattr(eeg_model, "overlap_grad_allreduce", False)
@@ -181,6 +199,7 @@ def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_s
 
 def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config, objective="retrieval", alpha=0.99):
     eeg_model.train()
+    settle_gc()
     text_features_all = text_features_all.to(device).float()
     img_features_all = (img_features_all[::10]).to(device).float().contiguous()
     features_list = []
