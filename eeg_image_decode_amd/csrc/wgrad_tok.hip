@@ -18,6 +18,10 @@
 //                          ready together are ONE launch); all tiles of a K slice run on one XCD (each operand byte enters one L2).
 //   wgrad_tok_reduce_kernel  out[m][n] += sum_s slab[s][m][n] in slice order (bit-reproducible; the round-3 GEMM added 32 slices with fp32
 //                          atomics: 19.8 MB of write traffic per launch for a 0.25 MB result and a scheduling-dependent sum).
+// Template switches of the kernel: IDX = the contraction of a problem runs over a sample range of an index list (the joint-subject value embedding: one
+// problem per subject); L2D = plain row-major planes [rows][ld] and direct accumulation into the gradient (the diffusion prior, eegclip_wgrad_planes);
+// SPEC = four extra producer waves issue all LDS-DMA (variants 2 / 3 of eegclip_wgrad_tok: measured within 5 % of the default -- the kernel is bound by
+// operand delivery, 3.4 TB/s on the 192 CUs its 12 tiles x 16 XCD-aligned slices occupy, not by its wave layout).
 #include "eeg_common.h"
 
 #include <string.h>

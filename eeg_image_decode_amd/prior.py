@@ -3,8 +3,10 @@
 scheduler pieces the reference takes from diffusers==0.30.0 (restated: diffusers is not a dependency here).
 
 * DiffusionPriorUNet keeps the reference's state_dict keys (input_layer.0/1, encode_time_embedding.i.linear_1/2, ...,
-  output_layer); parameters / gradients are views of flat buffers; forward and backward are replayed launch plans of the
-  fp32-MFMA GEMM (SiLU / residual / accumulate epilogues) + LayerNorm->SiLU->dropout kernels (csrc/prior.hip).
+  output_layer); parameters / gradients are views of flat buffers; forward and backward are replayed launch plans.  Training at batches that
+  are multiples of 64 (round 4): every Linear is a plane GEMM (csrc/gemm_planes.hip: operands and results as bf16 hi | lo planes, split-bf16
+  products), weight gradients through eegclip_wgrad_planes, fused stage tails (csrc/prior.hip); other shapes / exact-fp32 arithmetic: the
+  general GEMM (SiLU / residual / accumulate epilogues) + LayerNorm->SiLU->dropout kernels.
 * Pipe.train reproduces the reference step order: 10 % whole-batch condition drop, epsilon-MSE, clip_grad_norm_(1.0),
   LR scheduler stepped BEFORE the optimizer, Adam.  Loss is accumulated on the device (one host sync per epoch); the
   gradient-norm clip factor stays on the device (no sync per step).
