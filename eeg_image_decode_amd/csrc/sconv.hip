@@ -18,51 +18,89 @@ namespace eeg {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// forward: workgroup = (sample, K slice); K = (c,h) = 40*H is cut into SCF_KS slices (a whole sample per workgroup left ONE workgroup
-// of 4 waves per CU: 126 us for a 93 MB read); each slice is streamed in chunks of 128 k, wave v owning k = 32v .. 32v+31 of a chunk.
-//   B operand (activations): y1 chunk -> registers -> ELU(BN(.)) -> LDS [128][52] (16-byte stores; rows 4 apart land 16 banks apart)
+// forward: workgroup = (sample, K slice); K = (c,h) = 40*H is cut into SCF_KS slices, each streamed in chunks of 128 k, MFMA wave v owning
+// k = 32v .. 32v+31 of a chunk.
+//   B operand (activations): the y1 chunk [128 k][36 w] fp32 is 18 KB that lie contiguously in y1: copied as they are global -> LDS by LDS-DMA from a
+//       PRODUCER wave (18 instructions of 1 KB, two stages); the MFMA waves read RAW y1 values as their fragment and evaluate z1 = ELU(BN(y1)) on it in
+//       registers (every element is the B operand of exactly one lane), software-pipelined by one k-step and written branch-free.
+//       Round 3's kernel staged the chunk through registers (load -> ELU -> ds_write, two barriers per chunk); its phases added up (42 / 46 / 46 us with
+//       one of load | convert + LDS store | MFMA switched off, 60 with all).  Round 4 measured on this form: the DMA stream alone runs at 5.5 TB/s (17 us);
+//       fragment reads + ELU add 15 us, the fp32 MFMAs another 13 -- the MFMA waves are the bound; 62 -> 57 us in the step (4 -> 2 K slices: 10 chunks per
+//       workgroup amortise the pipeline fill), not the 30 us the ablation of round 3 suggested.
 //   A operand (weights):     straight from global/L2 into registers in MFMA order -- lane (fr, g) fetches Ws[o = 16i + fr][k .. k+3] as
-//       one 16-byte load and feeds four k-steps (the k-slot <-> lane-group assignment is free as long as both operands agree).  A staged
-//       [48][129] weight tile cost 3.2 LDS conflict cycles per LDS instruction (SQ_LDS_BANK_CONFLICT) and half the LDS traffic.
-// The 4 waves keep private 3x3 accumulator tiles (o x w), combined through LDS at the end and added atomically into y2 (zeroed by
-// the launcher).
-constexpr int SCF_KC = 128;
-constexpr int SCF_KS = 4;
-constexpr int SCF_LZ = 52;             // activation tile row stride
-__global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
-                                                         const float* __restrict__ bs, float* __restrict__ y2, float* __restrict__ slabs, int B, int H,
-                                                         int kper) {
-    // Timing ablation of round 3 (pieces switched off through a template parameter, since removed; B = 256, us incl. the 5 us statistics kernel):
-    // full 60, no MFMA 42, no loads 46, no LDS stores 46 -- the phases of a chunk (convert + LDS stores | MFMAs + LDS reads | load
-    // latency) add up instead of overlapping: 146 VGPRs + 64 AGPRs leave 2 workgroups per CU.  (Leaving out the epilogue is NOT a valid ablation:
-    // the compiler then drops the MFMAs of the unused accumulators.)  A second activation tile (chunk k+1 converted and stored in the barrier interval
-    // of chunk k's MFMAs, one barrier per chunk) measured SLOWER: 68 vs 58 us (53 KB of LDS per workgroup).
-    EEG_LDS_BASE(float, lds);
-    float* zl = lds;                          // [128][52]      z1[k0 + kk][w]   (cols >= 36 zero)
-    float* aff = zl + SCF_KC * SCF_LZ;        // [2][40]  BatchNorm folded to u = y * aff[c] + aff[40 + c] (LDS: no dependent global loads in staging)
-    float* red = lds;                         // 2 x [48][52] cross-wave reduction scratch, aliases the activation tile after the last chunk
+//       one 16-byte load and feeds four k-steps (the k-slot <-> lane-group assignment is free as long as both operands agree).
+// The 4 MFMA waves keep private 3x3 accumulator tiles (o x w), combined through LDS at the end; the K slices leave slabs that
+// sconv_merge_stats2_kernel sums (1440 device-scope float atomics per workgroup were 33 of 60 us).
+constexpr int SCF_KS = 2;
+constexpr int SCF_KC = 128;            // k rows per chunk
+constexpr int SCD_NS = 2;
+constexpr int SCD_STAGE = SCF_KC * SC_W * 4;             // bytes of a chunk: 18432
+constexpr int SCD_DMA = SCD_STAGE / 1024;                // LDS-DMA instructions per chunk: 18
+constexpr int SCD_LDS = SCD_NS * SCD_STAGE + 256 + 2 * SC_C * 4;
+template <int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW, 3) void sconv_fwd_kernel(const float* __restrict__ y1, const bn_affine bn, const float* __restrict__ Ws,
+                                                                const float* __restrict__ bs, float* __restrict__ y2, float* __restrict__ slabs, int B,
+                                                                int H, int kper) {
+    EEG_LDS_BASE(unsigned char, ldsb);
+    float* aff = reinterpret_cast<float*>(ldsb + SCD_NS * SCD_STAGE + 256);      // [2][40] (256 bytes of slack behind the ring: the w >= 36 lanes of the
+    float* red = reinterpret_cast<float*>(ldsb);                                 //  last row read past it)
     const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int K = SC_C * H;
     const int kbeg = blockIdx.y * kper, kend = kbeg + kper < K ? kbeg + kper : K;
+    const int nch = kend > kbeg ? (kend - kbeg + SCF_KC - 1) / SCF_KC : 0;
     if (t < SC_C) {
         const float sc = bn.gamma[t] * bn.rstd[t];
         aff[t] = sc;
         aff[SC_C + t] = bn.beta[t] - bn.mean[t] * sc;
     }
-    for (int i = t; i < SCF_KC * SCF_LZ; i += 256) zl[i] = 0.f;
+    __syncthreads();
+    const float* yb = y1 + (long long)b * K * SC_W;
+    if (wv >= 4) {                                          // ---------------- producers: wave p issues instructions p, p + NPW, ...
+        constexpr int IPP = SCD_DMA / NPW;
+        static_assert(SCD_DMA % NPW == 0, "18 DMA instructions per chunk");
+        const int pw = wv - 4;
+        const unsigned char* src0 = reinterpret_cast<const unsigned char*>(yb + (long long)kbeg * SC_W);
+        auto issue = [&](int c) {
+            const int rows = kend - kbeg - SCF_KC * c;
+            unsigned char* st = ldsb + (c % SCD_NS) * SCD_STAGE;
+            const unsigned char* sc_ = src0 + (long long)c * SCD_STAGE + 16 * lane;
+            if (rows >= SCF_KC) {                           // (wave-uniform) a full chunk: no clamping
+#pragma unroll
+                for (int i = 0; i < IPP; ++i) lds_dma16(st + 1024 * (pw + NPW * i), sc_ + 1024 * (pw + NPW * i));
+            } else {
+                const int valid = rows * SC_W * 4;
+#pragma unroll
+                for (int i = 0; i < IPP; ++i) {
+                    int off = 1024 * (pw + NPW * i) + 16 * lane;
+                    off = off < valid ? off : valid - 16;   // past the slice: re-read its last 16 bytes (those rows are masked by the MFMA waves) -- never past y1
+                    lds_dma16(st + 1024 * (pw + NPW * i), src0 + (long long)c * SCD_STAGE + off);
+                }
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < SCD_NS; ++p)
+            if (p < nch) issue(p);
+        for (int c = 0; c < nch; ++c) {
+            const int fly = c == 0 ? (nch - 1 < SCD_NS - 1 ? nch - 1 : SCD_NS - 1) : (nch - 1 - c < SCD_NS - 2 ? nch - 1 - c : SCD_NS - 2);
+            if (fly >= 3) wait_vmcnt<3 * IPP>();
+            else if (fly == 2) wait_vmcnt<2 * IPP>();
+            else if (fly == 1) wait_vmcnt<IPP>();
+            else wait_vmcnt<0>();
+            raw_barrier();                                  // chunk c has landed; the MFMA waves are done with chunk c - 1
+            if (c >= 1 && c - 1 + SCD_NS < nch) issue(c - 1 + SCD_NS);
+        }
+        return;
+    }
     f32x4 acc[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* yb = y1 + (long long)b * K * SC_W;
-    // software pipeline: the global loads of chunk k0+128 (6 weight + 5 activation float4 per thread; kbeg, K and 36 are multiples of 4,
-    // so a float4 never straddles a row of either operand) are issued before the MFMAs of chunk k0 and land under them
-    f32x4 va[3][2], vy[5];
+    f32x4 va[3][2];
     const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    auto load_chunk = [&](int k0) {
+    auto load_weights = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -70,59 +108,73 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
                 const int o = 16 * i + fr, k = k0 + 32 * wv + 16 * h + 4 * g;
                 va[i][h] = (o < SC_C && k < kend) ? *reinterpret_cast<const f32x4*>(Ws + (long long)o * K + k) : zero4v;
             }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int e = 4 * (t + 256 * j), kk = e / SC_W;                          // 128 rows x 9 float4
-            vy[j] = (e < SCF_KC * SC_W && k0 + kk < kend) ? *reinterpret_cast<const f32x4*>(yb + (long long)k0 * SC_W + e) : zero4v;
-        }
     };
-    auto store_chunk = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int e = 4 * (t + 256 * j), kk = e / SC_W, w = e % SC_W;
-            if (e < SCF_KC * SC_W) {
-                f32x4 z = zero4v;
-                if (k0 + kk < kend) {
-                    const int c = (k0 + kk) / H;
-                    const float sc = aff[c], sh = aff[SC_C + c];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) z[q] = elu1_fast(vy[j][q] * sc + sh);    // z1 = ELU(BN(y1)) evaluated on the way into LDS
-                }
-                *reinterpret_cast<f32x4*>(zl + kk * SCF_LZ + w) = z;
-            }
-        }
-    };
-    if (kbeg < kend) load_chunk(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += SCF_KC) {
-        __syncthreads();
-        store_chunk(k0);
+    if (nch > 0) load_weights(kbeg);
+    const float inv_h = 1.0f / (float)H;
+    for (int c = 0; c < nch; ++c) {
+        const int k0 = kbeg + SCF_KC * c;
+        raw_barrier();
         f32x4 a[3][2];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) a[i][h] = va[i][h];
-        __syncthreads();
-        if (k0 + SCF_KC < kend) load_chunk(k0 + SCF_KC);
+        if (c + 1 < nch) load_weights(k0 + SCF_KC);
+        const float* st = reinterpret_cast<const float*>(ldsb + (c % SCD_NS) * SCD_STAGE);
+        // k-step hs = (h, s4) of this wave's 32 k: software-pipelined by one step -- the LDS reads of step hs + 1 are issued before the MFMAs of step hs and
+        // its ELU is evaluated behind them (the matrix pipe works through the 9 MFMAs meanwhile).  Written branch-free: a conditional around the channel
+        // lookup / the ELU became an execz branch per k-step and serialised read -> wait -> ELU -> MFMA (66 us against the 56 of sconv_fwd_kernel).
+        float raw[2][3], scv[2], shv[2];
+        bool okv[2];
+        auto ld = [&](int hs, int slot) {
+            const int kk = 32 * wv + 16 * (hs >> 2) + 4 * g + (hs & 3), k = k0 + kk;
+            okv[slot] = k < kend;
+            const int kc = okv[slot] ? k : kend - 1;
+            const int ch = (int)(((float)kc + 0.5f) * inv_h);      // k / H, exact for k < 2^20
+            scv[slot] = aff[ch];
+            shv[slot] = aff[SC_C + ch];
+            const float* zp = st + kk * SC_W + fr;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 3; ++j) raw[slot][j] = zp[16 * j];
+        };
+        auto fin = [&](int slot, float (&bv)[3]) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const float* zp = zl + (32 * wv + 16 * h + 4 * g + s4) * SCF_LZ + fr;
-                float bv[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) bv[j] = zp[16 * j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        acc[i][j] = mfma_f32_16x16x4(a[i][h][s4], bv[j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
-                    }
+            for (int j = 0; j < 3; ++j) {
+                const float u = raw[slot][j] * scv[slot] + shv[slot];
+                const float e = fast_exp(u < 0.f ? u : 0.f) - 1.0f;
+                const float z = u > 0.f ? u : e;                 // z1 = ELU(BN(y1)) on the fragment (columns w >= 36 hold neighbours' values: their
+                bv[j] = okv[slot] ? z : 0.f;                     //  output columns are dropped below)
             }
+        };
+        float bv[2][3];
+        ld(0, 0);
+        fin(0, bv[0]);
+#pragma unroll
+        for (int hs = 0; hs < 8; ++hs) {
+            const int cur = hs & 1, nxt = cur ^ 1;
+            if (hs + 1 < 8) ld(hs + 1, nxt);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[i][j] = mfma_f32_16x16x4(a[i][hs >> 2][hs & 3], bv[cur][j], acc[i][j]);      // D[o = 16i+4g+r][w = 16j+fr]
+                }
+            if (hs + 1 < 8) fin(nxt, bv[nxt]);
+#if !defined(EEG_EMU)
+            // issue order of the step: the LDS reads of step hs + 1 first, then its ~45 vector instructions dealt out BETWEEN the 9 MFMAs of step hs
+            // (a wave issues in order and each fp32 MFMA holds the matrix pipe for 32 cycles: vector work placed behind the MFMAs waits for all nine)
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+#endif
+        }
     }
-    // cross-wave sum of the four k-partial accumulator sets: a two-level tree through LDS with plain stores (waves 2,3 -> 0,1, then
-    // 1 -> 0).  The first version used 36 ds_add_f32 per lane into one tile: LDS float atomics retire at ~170 cycles per wave
-    // instruction, and with 4 K-slice workgroups per sample that epilogue alone was ~40 % of the kernel.
-    constexpr int RLD = 52;                   // 4 accumulator row groups land 16 banks apart: 2-way at most, free for stores
+    // cross-wave sum of the four k-partial accumulator sets: a two-level tree through LDS with plain stores (waves 2,3 -> 0,1, then 1 -> 0); the ring is
+    // dead, LDS becomes reduction scratch.  (36 ds_add_f32 per lane into one tile: LDS float atomics retire at ~170 cycles per wave instruction.)
+    constexpr int RLD = 52;
     auto put = [&](float* reg) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -139,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += reg[(16 * i + 4 * g + r) * RLD + 16 * j + fr];
     };
-    __syncthreads();                          // every wave is done with the operand tiles: LDS becomes reduction scratch
+    __syncthreads();
     if (wv >= 2) put(red + (wv - 2) * SC_OP * RLD);
     __syncthreads();
     if (wv < 2) add(red + wv * SC_OP * RLD);
@@ -148,8 +200,6 @@ __global__ __launch_bounds__(256, 3) void sconv_fwd_kernel(const float* __restri
     __syncthreads();
     if (wv == 0) {
         add(red);
-        // slabs: this K slice's partial tile as plain stores, summed by sconv_merge_stats2_kernel -- the 1440 device-scope float atomics per
-        // workgroup (they execute at the memory side on this multi-XCD part) were 33 of the kernel's 60 us
         float* yo = slabs ? slabs + ((long long)blockIdx.y * B + b) * SC_C * SC_W : y2 + (long long)b * SC_C * SC_W;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -629,8 +679,7 @@ extern "C" int eegclip_sconv_fwd(const float* y1, const float* mean, const float
     if (!y2_is_zero && !workspace) (void)hipMemsetAsync(y2, 0, (size_t)B * SC_C * SC_W * sizeof(float), (hipStream_t)stream);
     {
         const int kper = ((K + SCF_KS - 1) / SCF_KS + 3) & ~3;                 // slices start on 16-byte boundaries of both operands
-        const size_t lds = (SCF_KC * SCF_LZ + 2 * SC_C) * sizeof(float);
-        EEG_LAUNCH(sconv_fwd_kernel, dim3(B, SCF_KS), dim3(256), lds, stream, y1, bn, Ws, bs, y2, workspace, B, H, kper);
+        EEG_LAUNCH((sconv_fwd_kernel<1>), dim3(B, SCF_KS), dim3(320), SCD_LDS, stream, y1, bn, Ws, bs, y2, workspace, B, H, kper);
     }
     if (sums2 || workspace)
         EEG_LAUNCH(sconv_merge_stats2_kernel, dim3(SC_C, 8), dim3(256), 8 * sizeof(double), stream, (const float*)workspace, SCF_KS, y2, sums2, B);
