@@ -962,8 +962,10 @@ class _Engine:
                 # pageable memory would make the host wait for everything queued on the stream, every step
                 perm = np.argsort(a, kind="stable")
                 on_gpu = b["jmeta"].is_cuda
-                ring = b.setdefault("jmeta_ring", [[torch.empty(2 * B, dtype=torch.int32).pin_memory() if on_gpu else torch.empty(2 * B, dtype=torch.int32),
-                                                    None] for _ in range(8)])
+                if "jmeta_ring" not in b:                   # (not setdefault: its default is evaluated -- eight pinned allocations -- on every call)
+                    b["jmeta_ring"] = [[torch.empty(2 * B, dtype=torch.int32).pin_memory() if on_gpu else torch.empty(2 * B, dtype=torch.int32), None]
+                                       for _ in range(8)]
+                ring = b["jmeta_ring"]
                 slot = ring[b.get("jmeta_i", 0) % len(ring)]
                 b["jmeta_i"] = b.get("jmeta_i", 0) + 1
                 if slot[1] is not None:
