@@ -153,3 +153,15 @@ def test_wgrad_planes_against_split_products(be, rows, M, N, slices, bias, strid
 def test_wgrad_planes_prior_shapes(M, N, slices):
     from backends import get
     tn_case(get("gpu"), 1024, M, N, slices, 1, 0, seed=M + N)
+
+
+def test_wgrad_planes_rejects_bad_arguments(be):
+    z = be.dev(np.zeros((64, 128), np.uint16))
+    o = be.zeros((64, 64))
+    ok = dict(a_hi=be.ptr(z), a_lo=be.ptr(z), lda=128, b_hi=be.ptr(z), b_lo=be.ptr(z), ldb=128, rows=64, M=64, N=64, out=be.ptr(o), ldo=64, bias_out=None, slices=1)
+    mk = lambda **kw: (_abi.WgradPlanesProblem * 1)(_abi.WgradPlanesProblem(**{**ok, **kw}))
+    assert be.lib.eegclip_wgrad_planes(mk(), 1, be.stream) == 0
+    for bad in (dict(rows=48), dict(slices=3), dict(slices=0), dict(lda=60), dict(ldo=62), dict(N=62), dict(out=None), dict(a_lo=None)):
+        assert be.lib.eegclip_wgrad_planes(mk(**bad), 1, be.stream) != 0, bad
+    many = (_abi.WgradPlanesProblem * 13)(*[_abi.WgradPlanesProblem(**ok)] * 13)
+    assert be.lib.eegclip_wgrad_planes(many, 13, be.stream) != 0

@@ -111,3 +111,25 @@ def test_split_transpose_items(be):
         assert (np.asarray(be.host(hi))[:, r:] == 0x7FC0).all()
     items[0].rows = 96
     assert be.lib.eegclip_split_transpose(items, 1, be.stream) != 0
+
+
+def test_stage_kernels_and_embed_pack_reject_bad_arguments(be):
+    x = be.zeros((8, 64))
+    v = be.zeros(64)
+    r = be.zeros(8)
+    hi = be.dev(np.zeros((8, 64), np.uint16))
+    L = be.lib
+    # planes: both or neither
+    assert L.eegclip_prior_stage_fwd(be.ptr(x), be.ptr(v), be.ptr(v), None, be.ptr(x), be.ptr(x), be.ptr(r), be.ptr(r), be.ptr(hi), None, 8, 64, 1e-5, 0.0, 0, 0, be.stream) != 0
+    assert L.eegclip_prior_stage_fwd(be.ptr(x), be.ptr(v), be.ptr(v), None, be.ptr(x), be.ptr(x), be.ptr(r), be.ptr(r), None, None, 8, 64, 1e-5, 1.0, 0, 0, be.stream) != 0      # p = 1
+    # backward: an output is required; parameter gradients need a destination (arrays or workspace)
+    assert L.eegclip_prior_stage_bwd(be.ptr(x), be.ptr(x), be.ptr(x), be.ptr(v), be.ptr(r), be.ptr(r), None, None, None, be.ptr(v), be.ptr(v), 8, 64, 0.0, 0, 0, None, be.stream) != 0
+    assert L.eegclip_prior_stage_bwd(be.ptr(x), be.ptr(x), be.ptr(x), be.ptr(v), be.ptr(r), be.ptr(r), be.ptr(x), None, None, None, None, 8, 64, 0.0, 0, 0, None, be.stream) != 0
+    assert int(L.eegclip_prior_stage_bwd_workspace_floats(0, 64)) == 0 and int(L.eegclip_prior_stage_bwd_workspace_floats(16, 64)) == 2 * 2 * 64
+    # the per-subject value-embedding pack: stride at least one matrix
+    w = be.zeros(250 * 250)
+    out = be.dev(np.zeros(int(L.eegclip_token_block_packed_embed_bytes(1)) // 2, np.uint16))
+    assert L.eegclip_token_block_pack_embed(be.ptr(w), 250 * 250, 1, be.ptr(out), be.stream) == 0
+    assert L.eegclip_token_block_pack_embed(be.ptr(w), 100, 1, be.ptr(out), be.stream) != 0
+    assert L.eegclip_token_block_pack_embed(be.ptr(w), 250 * 250, 0, be.ptr(out), be.stream) != 0
+    assert int(L.eegclip_token_block_packed_embed_bytes(0)) == 0
