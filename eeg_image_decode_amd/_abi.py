@@ -73,6 +73,14 @@ class WgradTokProblem(C.Structure):
                 ("sample0", C.c_int), ("samples", C.c_int), ("sample_index", C.c_void_p)]
 
 
+class CstackFwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("x", C.c_void_p), ("xs_b", C.c_longlong), ("xs_h", C.c_longlong), ("w25", C.c_void_p), ("bias1", C.c_void_p),
+                ("stat1", C.c_void_p), ("nstat1", C.c_int), ("count1", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
+                ("gamma1", C.c_void_p), ("beta1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("run_mean1", C.c_void_p),
+                ("run_var1", C.c_void_p), ("nbt1", C.c_void_p), ("packed", C.c_void_p), ("bias2", C.c_void_p), ("y2", C.c_void_p), ("stat2", C.c_void_p),
+                ("y1", C.c_void_p)]
+
+
 class WgradPlanesProblem(C.Structure):
     _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("lda", C.c_longlong), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("ldb", C.c_longlong),
                 ("rows", C.c_int), ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("slices", C.c_int)]
@@ -119,6 +127,7 @@ PROTOTYPES = {
     "eegclip_mse_loss_grad": [_P, _P, _L, _P, _P, _P],
     "eegclip_bn_stats": [_P, _I, _I, _I, _P, _P],
     "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P, _P],
+    "eegclip_bn_finalize_rows": [_P, _I, _D, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     "eegclip_bn_elu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_bn_elu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_bn_elu_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
@@ -191,6 +200,10 @@ PROTOTYPES = {
     "eegclip_wgrad_tok_reduce": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _P],
     "eegclip_wgrad_planes": [C.POINTER(WgradPlanesProblem), _I, _P],
     "eegclip_tok_planes_from_f32": [_P, _L, _I, _I, _I, _I, _P, _P],
+    "eegclip_cstack_packed_bytes": [_I],
+    "eegclip_cstack_pack": [_P, _P, _I, _P],
+    "eegclip_cstack_stats1": [_P, _L, _L, _P, _P, _P, _I, _I, _P],
+    "eegclip_cstack_fwd": [C.POINTER(CstackFwdDesc), _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

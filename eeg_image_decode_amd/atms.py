@@ -607,27 +607,11 @@ class _Engine:
         sums, bn = b["sums"], b["bn"]
         pl.memset(b["zfb"] if train else b["zf"])
         pl.clears_zb = train
-        if "tsf_ws" not in b:
-            b["tsf_ws"] = torch.empty(int(lib().eegclip_tsconv_fwd_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
-        pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
-                C_TS, _p(sums[0]) if train else None, _p(b["tsf_ws"]))
         W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
-        if W > 1:
-            pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
-        pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
-                _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train),
-                _p(self.buffers[_TS + "2.num_batches_tracked"]))
-        if "scf_ws" not in b:          # the K-slice partial tiles of sconv_fwd: slabs summed by the statistics kernel of the same call (no atomics)
-            b["scf_ws"] = torch.empty(int(lib().eegclip_sconv_fwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
-        # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
-        # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
-        pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
-                _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1, _p(b["scf_ws"]))
-        if W > 1:
-            pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
-        pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
-                _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train),
-                _p(self.buffers[_TS + "5.num_batches_tracked"]))
+        if self._cstack_enabled(pl):
+            self._build_fwd_cstack(pl, b, B, train, W)
+        else:
+            self._build_fwd_conv_y1(pl, b, B, train, W)
         # BN2 -> ELU -> dropout -> 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e], one workgroup per sample      (:107-114,145)
         pl.call("eegclip_proj1x1_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
                 _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
@@ -654,6 +638,81 @@ class _Engine:
         pl.call("eegclip_residual_layernorm_fwd", _p(w_lin), _p(b["u"]), _p(b["s"]), pp_, 0, SITE_PROJ, _p(P["proj_eeg.2.weight"]),
                 _p(P["proj_eeg.2.bias"]), 0, _p(b["mu4"]), _p(b["rs4"]), None, None, None, None, None, B, P_DIM, EPS, seed_at=4)
         return pl
+
+    def _cstack_enabled(self, pl):
+        """the conv stack recomputed from the token rows (csrc/cstack*.hip: y1 never written) in split-bf16 plans; EEGCLIP_CSTACK=0 pins the round-4
+        kernels around y1 in HBM (diagnosis, A/B timing); exact-fp32 plans always use those"""
+        return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CSTACK", "1") != "0"
+
+    def _build_fwd_cstack(self, pl, b, B, train, W):
+        """A4+A5 on csrc/cstack.hip (round 5): BatchNorm1 sums WITHOUT writing y1, then per sample y1 tile -> BN1 -> ELU -> spatial conv chained on the
+        bf16 matrix cores; the BatchNorm finalizes ride in the consumers' prologues / one rows kernel.      (ATMS_retrieval.py:91,102-106)"""
+        P, sums, bn = self.P, b["sums"], b["bn"]
+        dev = self.device
+        if not hasattr(self, "cs_packed"):
+            self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=dev)
+        pl.call("eegclip_cstack_pack", _p(P[_TS + "4.weight"]), _p(self.cs_packed), N_CH)
+        if "cs_rows" not in b:
+            b["cs_rows"] = torch.empty(2, B, 2 * C_TS, dtype=torch.float64, device=dev)          # BatchNorm1 | BatchNorm2 partial rows, one per sample
+        rows1, rows2 = b["cs_rows"][0], b["cs_rows"][1]
+        keep_y1 = not self._cstack_bwd_enabled(pl)                 # the round-4 backward kernels still read y1
+        count1 = float(W * B * N_CH * W_TS)
+        stat1, nstat1 = None, 0
+        if train:
+            pl.call("eegclip_cstack_stats1", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(rows1), B, N_CH)
+            stat1, nstat1 = _p(rows1), B
+            if W > 1:
+                pl.call("eegclip_bn_finalize_rows", _p(rows1), B, count1, EPS, 0.1, C_TS, None, None, None, None, None, _p(sums[0]))
+                pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
+                stat1, nstat1 = _p(sums[0]), 1
+        else:
+            pl.call("eegclip_bn_finalize", _p(sums[0]), count1, EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
+                    _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), 0,
+                    _p(self.buffers[_TS + "2.num_batches_tracked"]))
+        pl.call_desc("eegclip_cstack_fwd", _abi.CstackFwdDesc(
+            B=B, H=N_CH, x=_p(b["n3"]), xs_b=L_TOK * D_MODEL, xs_h=D_MODEL, w25=_p(P[_TS + "0.weight"]), bias1=_p(P[_TS + "0.bias"]), stat1=stat1,
+            nstat1=nstat1, count1=count1, eps=EPS, momentum=0.1, gamma1=_p(P[_TS + "2.weight"]), beta1=_p(P[_TS + "2.bias"]), mean1=_p(bn[0]),
+            rstd1=_p(bn[1]), run_mean1=_p(self.buffers[_TS + "2.running_mean"]) if train else None,
+            run_var1=_p(self.buffers[_TS + "2.running_var"]) if train else None,
+            nbt1=_p(self.buffers[_TS + "2.num_batches_tracked"]) if train else None, packed=_p(self.cs_packed), bias2=_p(P[_TS + "4.bias"]),
+            y2=_p(b["y2"]), stat2=_p(rows2) if train else None, y1=_p(b["y1"]) if keep_y1 else None))
+        count2 = float(W * B * W_TS)
+        run2 = (_p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]))
+        nbt2 = _p(self.buffers[_TS + "5.num_batches_tracked"])
+        if train and W == 1:
+            pl.call("eegclip_bn_finalize_rows", _p(rows2), B, count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, nbt2, None)
+        else:
+            if train:
+                pl.call("eegclip_bn_finalize_rows", _p(rows2), B, count2, EPS, 0.1, C_TS, None, None, None, None, None, _p(sums[1]))
+                pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
+            pl.call("eegclip_bn_finalize", _p(sums[1]), count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, int(train), nbt2)
+
+    def _cstack_bwd_enabled(self, pl):
+        return False
+
+    def _build_fwd_conv_y1(self, pl, b, B, train, W):
+        """A4+A5 around y1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""
+        P, sums, bn = self.P, b["sums"], b["bn"]
+        if "tsf_ws" not in b:
+            b["tsf_ws"] = torch.empty(int(lib().eegclip_tsconv_fwd_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
+        pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
+                C_TS, _p(sums[0]) if train else None, _p(b["tsf_ws"]))
+        if W > 1:
+            pl.callback(lambda: self._allreduce(sums[0]), "allreduce_bn1")
+        pl.call("eegclip_bn_finalize", _p(sums[0]), float(W * B * N_CH * W_TS), EPS, 0.1, C_TS, _p(bn[0]), _p(bn[1]),
+                _p(self.buffers[_TS + "2.running_mean"]), _p(self.buffers[_TS + "2.running_var"]), int(train),
+                _p(self.buffers[_TS + "2.num_batches_tracked"]))
+        if "scf_ws" not in b:          # the K-slice partial tiles of sconv_fwd: slabs summed by the statistics kernel of the same call (no atomics)
+            b["scf_ws"] = torch.empty(int(lib().eegclip_sconv_fwd_workspace_floats(B)), dtype=torch.float32, device=self.device)
+        # BN1 -> ELU -> spatial (63x1) conv in ONE kernel: z1 = ELU(BN(y1)) is re-evaluated while y1 is staged, never stored; the
+        # BatchNorm2 batch sums of y2 are accumulated by the same kernel      (:104-107)
+        pl.call("eegclip_sconv_fwd", _p(b["y1"]), _p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]), _p(P[_TS + "4.weight"]),
+                _p(P[_TS + "4.bias"]), _p(b["y2"]), _p(sums[1]) if train else None, B, N_CH, 1, _p(b["scf_ws"]))
+        if W > 1:
+            pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
+        pl.call("eegclip_bn_finalize", _p(sums[1]), float(W * B * W_TS), EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]),
+                _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), int(train),
+                _p(self.buffers[_TS + "5.num_batches_tracked"]))
 
     # ---- backward plan -----------------------------------------------------------------------------------------
     def _build_bwd(self, B, shared, probs, want_dx, early_reduce=False, train=True):

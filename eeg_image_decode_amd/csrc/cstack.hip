@@ -1,0 +1,336 @@
+// Conv stack of Enc_eeg, forward, recomputed from the token rows (see cstack_common.h; Retrieval/ATMS_retrieval.py:102-106):
+//   cstack_stats1_kernel   BatchNorm1 batch sums of y1 = pool(conv(x)) WITHOUT writing y1: one partial row [sum | sumsq] per sample
+//   cstack_fwd_kernel      per sample: y1 tile (tap contraction) -> BatchNorm1 -> ELU -> spatial (H x 1) conv, chained on the matrix cores:
+//                          the accumulator tiles of the tap contraction, D[c][w] of one token row h, ARE the k = (c, h) operand fragments of the
+//                          spatial contraction y2[o][w] += sum_c Ws[o][c][h] z1[c][h][w] once passed through BN1 / ELU and split in registers
+//   cstack_pack_kernel     Ws (40,40,H) fp32 -> bf16 hi | lo planes in MFMA-fragment order for that chain, once per optimizer step
+// Replaces tsconv_fwd (y1 write, 93 MB) + colsum + bn_finalize + sconv_fwd (y1 read) + sconv_merge_stats2 of rounds 1-4.
+#include "cstack_common.h"
+
+#include <stdlib.h>
+
+namespace eeg {
+
+// ---- packed spatial weights ---------------------------------------------------------------------------------------------------------------------
+// Token rows are taken in pairs (h0, h1) = (2 q, 2 q + 1); pair q has three k-steps of 32:
+//   step 3q     k slot j of lane group kg <-> c = 16 (j >> 2) + 4 kg + (j & 3) (filters 0 .. 31) of row h0      = accumulator tiles ct 0 | 1 of h0
+//   step 3q + 1 the same of row h1
+//   step 3q + 2 slots 0 .. 3 <-> c = 32 + 4 kg + j of h0, slots 4 .. 7 <-> c = 32 + 4 kg + (j - 4) of h1 (c >= 40: zero)   = tile ct 2 of both rows
+// i.e. 2.5 accumulator tiles of real filters per row in 1.5 MFMA k-steps.  Fragment (step, ot, plane): 64 lanes x 16 bytes, lane (n, kg) <- o = 16 ot + n.
+constexpr int CSP_FRAG = 1024;                       // bytes
+__host__ __device__ inline long long csp_offset(int step, int ot, int plane) { return (((long long)step * 3 + ot) * 2 + plane) * CSP_FRAG; }
+inline int cs_pairs(int H) { return (H + 1) / 2; }
+
+__global__ __launch_bounds__(256) void cstack_pack_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nsteps = 3 * ((H + 1) / 2);
+    if (id >= nsteps * 3 * 64) return;
+    const int lane = id & 63, ot = (id >> 6) % 3, step = id / 192;
+    const int n = lane & 15, kg = lane >> 4, o = 16 * ot + n;
+    const int q = step / 3, kind = step % 3;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int c, h;
+        if (kind < 2) { c = 16 * (j >> 2) + 4 * kg + (j & 3); h = 2 * q + kind; }
+        else          { c = 32 + 4 * kg + (j & 3);            h = 2 * q + (j >> 2); }
+        v[j] = (o < CS_C && c < CS_C && h < H) ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+    bf16x8 hi, lo;
+    cs_split8(v, hi, lo);
+    *reinterpret_cast<bf16x8*>(packed + csp_offset(step, ot, 0) + 16 * lane) = hi;
+    *reinterpret_cast<bf16x8*>(packed + csp_offset(step, ot, 1) + 16 * lane) = lo;
+}
+
+// ---- BatchNorm1 batch sums ------------------------------------------------------------------------------------------------------------------------
+constexpr int CS_LDS_S = CS_MAXH * CS_RS * 4;        // packed rows
+constexpr int CS_LDS_PS = CS_NW * 256 * 4;           // prefix-sum scratch
+__global__ __launch_bounds__(CS_NT) void cstack_stats1_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
+                                                              const float* __restrict__ bias, double* __restrict__ rows, int B, int H, int vec2) {
+    EEG_LDS_BASE(unsigned char, ldsb);
+    unsigned* S32 = reinterpret_cast<unsigned*>(ldsb);
+    float* ps = reinterpret_cast<float*>(ldsb + CS_LDS_S);
+    float* sc = ps;                                   // [NW][2][48] per-wave filter sums (after the staging)
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.x;
+    cs_stage_sample(S32, ps, x, xs_b, xs_h, b, H, vec2 != 0);
+    bf16x8 wh[3], wl[3];
+    cs_tap_frags(w25, wh, wl);
+    float bc[3][4], ss[3][4], sq[3][4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * kg + r;
+            bc[ct][r] = c < CS_C ? bias[c] : 0.f;
+            ss[ct][r] = 0.f;
+            sq[ct][r] = 0.f;
+        }
+    __syncthreads();
+    for (int h = wv; h < H; h += CS_NW) {
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) {
+            bf16x8 xh, xl;
+            cs_sfrag(S32, h, wt, xh, xl);
+            const bool wok = 16 * wt + n < CS_W;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const f32x4 acc = cs_mma3(wh[ct], wl[ct], xh, xl, f32x4{0.f, 0.f, 0.f, 0.f});      // D[c = 16 ct + 4 kg + r][w = 16 wt + n]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = wok ? acc[r] + bc[ct][r] : 0.f;
+                    ss[ct][r] += v;
+                    sq[ct][r] += v * v;
+                }
+            }
+        }
+    }
+    __syncthreads();                                  // the scratch rows are dead: they become the per-wave sums
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = ss[ct][r], q = sq[ct][r];
+#pragma unroll
+            for (int msk = 8; msk >= 1; msk >>= 1) { a += __shfl_xor(a, msk, 64); q += __shfl_xor(q, msk, 64); }
+            if (n == 0) { sc[(wv * 2 + 0) * 48 + 16 * ct + 4 * kg + r] = a; sc[(wv * 2 + 1) * 48 + 16 * ct + 4 * kg + r] = q; }
+        }
+    __syncthreads();
+    if (t < 2 * CS_C) {
+        const int which = t / CS_C, c = t % CS_C;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CS_NW; ++k) s += (double)sc[(k * 2 + which) * 48 + c];
+        rows[(long long)b * 2 * CS_C + t] = s;
+    }
+}
+
+// ---- the fused forward ------------------------------------------------------------------------------------------------------------------------------
+struct cs_fwd_args {
+    const float* x;
+    long long xs_b, xs_h;
+    const float *w25, *bias1;
+    const double* stat1;          // train: partial rows of BatchNorm1 sums (NULL: eval -- mean1 / rstd1 are inputs)
+    int nstat1;
+    double count1;
+    float eps, momentum;
+    const float *gamma1, *beta1;
+    float *mean1, *rstd1;
+    float *run_mean1, *run_var1;
+    long long* nbt1;
+    const unsigned char* packed;
+    const float* bias2;
+    float* y2;                    // [B][40][36]
+    double* stat2;                // [B][80] BatchNorm2 partial rows of y2 (NULL: none)
+    float* y1;                    // optional [B][40][H][36] (kernels that still read it)
+    int B, H, vec2;
+};
+
+constexpr int CSF_RLD = 52;                                        // row stride of the cross-wave reduction tiles [48][52]
+constexpr int CSF_LDS_RED = CS_NW * 48 * CSF_RLD * 4;              // 79,872 B: aliases the packed rows + scratch once the contractions are done
+constexpr int CSF_LDS_MAIN = (CS_LDS_S + CS_LDS_PS) > CSF_LDS_RED ? (CS_LDS_S + CS_LDS_PS) : CSF_LDS_RED;
+constexpr int CSF_LDS = CSF_LDS_MAIN + 2 * 48 * 4 + CS_C * CS_W * 4;        // + BatchNorm1 scale | shift + the y2 tile
+
+__global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) {
+    EEG_LDS_BASE(unsigned char, ldsb);
+    unsigned* S32 = reinterpret_cast<unsigned*>(ldsb);
+    float* ps = reinterpret_cast<float*>(ldsb + CS_LDS_S);
+    float* red = reinterpret_cast<float*>(ldsb);
+    float* aff = reinterpret_cast<float*>(ldsb + CSF_LDS_MAIN);    // [48] scale | [48] shift (filters >= 40: 0 -> z1 = ELU(0) = 0)
+    float* yt = aff + 96;                                          // [40][36] y2 of this sample
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.x, H = a.H;
+    double* bnscr = reinterpret_cast<double*>(yt);                 // [6][80] partial sums of the BatchNorm1 rows (the y2 tile is written much later)
+    {
+        float vx[CS_RPW][4];
+        cs_stage_load(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
+        if (a.stat1) cs_bn_rows_partial(a.stat1, a.nstat1, bnscr);  // (under the row loads)
+        cs_stage_finish(S32, ps, vx, H);
+    }
+    __syncthreads();
+    if (t < 48) {
+        float sc = 0.f, sh = 0.f;
+        if (t < CS_C) {
+            float mean, rstd;
+            if (a.stat1) {
+                double var;
+                cs_bn_rows_finish(bnscr, a.count1, a.eps, t, mean, rstd, var);
+                if (b == 0) {                                      // what bn_finalize did: statistics for the backward, running statistics, step counter
+                    a.mean1[t] = mean;
+                    a.rstd1[t] = rstd;
+                    if (a.run_mean1) {
+                        const double unb = a.count1 > 1.0 ? var * (a.count1 / (a.count1 - 1.0)) : var;
+                        a.run_mean1[t] = (1.f - a.momentum) * a.run_mean1[t] + a.momentum * mean;
+                        a.run_var1[t] = (1.f - a.momentum) * a.run_var1[t] + a.momentum * (float)unb;
+                    }
+                    if (t == 0 && a.nbt1) *a.nbt1 += 1;
+                }
+            } else {
+                mean = a.mean1[t];
+                rstd = a.rstd1[t];
+            }
+            sc = a.gamma1[t] * rstd;
+            sh = a.beta1[t] + (a.bias1[t] - mean) * sc;           // u = gamma * (acc + bias - mean) * rstd + beta
+        }
+        aff[t] = sc;
+        aff[48 + t] = sh;
+    }
+    bf16x8 wh[3], wl[3];
+    cs_tap_frags(a.w25, wh, wl);
+    __syncthreads();
+    float sc[3][4], sh[3][4], bc[3][4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * kg + r;
+            sc[ct][r] = aff[c];
+            sh[ct][r] = aff[48 + c];
+            bc[ct][r] = (a.y1 && c < CS_C) ? a.bias1[c] : 0.f;
+        }
+    f32x4 acc2[3][3];                                              // y2 partial D[o = 16 ot + 4 kg + r][w = 16 wt + n] over this wave's rows
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) acc2[ot][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    const int npairs = (H + 1) / 2;
+    for (int q = wv; q < npairs; q += CS_NW) {
+        u32x2_t th[2][3], tl[2][3];                                // tile ct = 2 of both rows: the halves of the pair's third k-step
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int h = 2 * q + e;
+            if (h >= H) {                                          // (odd H: the last pair has one row; wave-uniform)
+#pragma unroll
+                for (int wt = 0; wt < 3; ++wt) { th[e][wt] = u32x2_t{0u, 0u}; tl[e][wt] = u32x2_t{0u, 0u}; }
+                continue;
+            }
+            bf16x8 a2h[3], a2l[3];                                 // Ws fragments of step 3 q + e: straight from L2 (every workgroup reads the same 576 KB)
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) {
+                a2h[ot] = *reinterpret_cast<const bf16x8*>(a.packed + csp_offset(3 * q + e, ot, 0) + 16 * lane);
+                a2l[ot] = *reinterpret_cast<const bf16x8*>(a.packed + csp_offset(3 * q + e, ot, 1) + 16 * lane);
+            }
+#pragma unroll
+            for (int wt = 0; wt < 3; ++wt) {
+                bf16x8 xh, xl;
+                cs_sfrag(S32, h, wt, xh, xl);
+                float z[3][4];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const f32x4 acc = cs_mma3(wh[ct], wl[ct], xh, xl, zero4);       // D[c = 16 ct + 4 kg + r][w = 16 wt + n]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc[r] * sc[ct][r] + sh[ct][r];
+                        const float ex = fast_exp(u < 0.f ? u : 0.f) - 1.0f;
+                        z[ct][r] = u > 0.f ? u : ex;
+                    }
+                    if (a.y1) {
+                        const int w = 16 * wt + n;
+                        if (w < CS_W) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 16 * ct + 4 * kg + r;
+                                if (c < CS_C) a.y1[(((long long)b * CS_C + c) * H + h) * CS_W + w] = acc[r] + bc[ct][r];
+                            }
+                        }
+                    }
+                }
+                bf16x8 zh, zl;
+                {
+                    const float v8[8] = {z[0][0], z[0][1], z[0][2], z[0][3], z[1][0], z[1][1], z[1][2], z[1][3]};
+                    cs_split8(v8, zh, zl);
+                }
+                x3_split4(z[2][0], z[2][1], z[2][2], z[2][3], th[e][wt], tl[e][wt]);
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot) acc2[ot][wt] = cs_mma3(a2h[ot], a2l[ot], zh, zl, acc2[ot][wt]);
+            }
+        }
+        {
+            bf16x8 a2h[3], a2l[3];
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) {
+                a2h[ot] = *reinterpret_cast<const bf16x8*>(a.packed + csp_offset(3 * q + 2, ot, 0) + 16 * lane);
+                a2l[ot] = *reinterpret_cast<const bf16x8*>(a.packed + csp_offset(3 * q + 2, ot, 1) + 16 * lane);
+            }
+#pragma unroll
+            for (int wt = 0; wt < 3; ++wt) {
+                const bf16x8 zh = cs_frag(th[0][wt][0], th[0][wt][1], th[1][wt][0], th[1][wt][1]);
+                const bf16x8 zl = cs_frag(tl[0][wt][0], tl[0][wt][1], tl[1][wt][0], tl[1][wt][1]);
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot) acc2[ot][wt] = cs_mma3(a2h[ot], a2l[ot], zh, zl, acc2[ot][wt]);
+            }
+        }
+    }
+    // cross-wave sum of the row-partial y2 tiles (fixed order), bias, the sample's BatchNorm2 partial row
+    __syncthreads();
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wv * 48 + 16 * ot + 4 * kg + r) * CSF_RLD + 16 * wt + n] = acc2[ot][wt][r];
+    __syncthreads();
+    for (int i = t; i < CS_C * CS_W; i += CS_NT) {
+        const int o = i / CS_W, w = i % CS_W;
+        float v = a.bias2[o];
+#pragma unroll
+        for (int k = 0; k < CS_NW; ++k) v += red[(k * 48 + o) * CSF_RLD + w];
+        a.y2[(long long)b * CS_C * CS_W + i] = v;
+        yt[i] = v;
+    }
+    if (a.stat2) {
+        __syncthreads();
+        if (t < 2 * CS_C) {
+            const int which = t / CS_C, o = t % CS_C;
+            double s = 0.0;
+            for (int w = 0; w < CS_W; ++w) {
+                const double v = (double)yt[o * CS_W + w];
+                s += which ? v * v : v;
+            }
+            a.stat2[(long long)b * 2 * CS_C + t] = s;
+        }
+    }
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+static int cs_vec2(const float* x, long long xs_b, long long xs_h) {
+    return ((reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (xs_b & 1) == 0 && (xs_h & 1) == 0) ? 1 : 0;
+}
+
+extern "C" long long eegclip_cstack_packed_bytes(int H) { return (H < 1 || H > CS_MAXH) ? 0 : csp_offset(3 * cs_pairs(H), 0, 0); }
+
+extern "C" int eegclip_cstack_pack(const float* Ws, void* packed, int H, void* stream) {
+    if (!Ws || !packed || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(packed) & 15u) return EEGCLIP_EALIGN;
+    const int nthr = 3 * cs_pairs(H) * 3 * 64;
+    EEG_LAUNCH(cstack_pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, Ws, static_cast<unsigned char*>(packed), H);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_cstack_stats1(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, double* rows, int B, int H,
+                                     void* stream) {
+    if (!x || !w25 || !bias || !rows || B < 1 || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(cstack_stats1_kernel, dim3(B), dim3(CS_NT), CS_LDS_S + CS_LDS_PS, stream, x, xs_b, xs_h, w25, bias, rows, B, H, cs_vec2(x, xs_b, xs_h));
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_cstack_fwd(const eegclip_cstack_fwd_desc* d, void* stream) {
+    if (!d || d->B < 1 || d->H < 1 || d->H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (!d->x || !d->w25 || !d->bias1 || !d->gamma1 || !d->beta1 || !d->mean1 || !d->rstd1 || !d->packed || !d->bias2 || !d->y2) return EEGCLIP_EINVAL;
+    if (d->stat1 && (d->nstat1 < 1 || d->count1 < 1.0)) return EEGCLIP_EINVAL;
+    if ((d->run_mean1 == nullptr) != (d->run_var1 == nullptr)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d->packed) & 15u) || (reinterpret_cast<uintptr_t>(d->stat1) & 7u) || (reinterpret_cast<uintptr_t>(d->stat2) & 7u))
+        return EEGCLIP_EALIGN;
+    const cs_fwd_args a{d->x, d->xs_b, d->xs_h, d->w25, d->bias1, d->stat1, d->nstat1, d->count1, d->eps, d->momentum, d->gamma1, d->beta1, d->mean1,
+                        d->rstd1, d->run_mean1, d->run_var1, d->nbt1, static_cast<const unsigned char*>(d->packed), d->bias2, d->y2, d->stat2, d->y1,
+                        d->B, d->H, cs_vec2(d->x, d->xs_b, d->xs_h)};
+    EEG_LAUNCH(cstack_fwd_kernel, dim3(d->B), dim3(CS_NT), CSF_LDS, stream, a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,230 @@
+// The conv stack of Enc_eeg recomputed from the token rows (round 5):
+//     Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)) -> BatchNorm2d(40) -> ELU -> Conv2d(40,40,(63,1))      (Retrieval/ATMS_retrieval.py:102-106)
+// Rounds 1-4 kept y1 = conv + pool output (B,40,63,36) fp32 in HBM (93 MB at B = 256) and made seven passes over it (and over its gradient) per
+// step; each pass sat at 0.2-0.44 of the HBM roof on the 1/16-rate fp32 matrix pipe.  y1 is a 25-tap stride-5 convolution of the box-filtered
+// token row -- 4.5 MFLOP per sample -- and the token rows of a sample are 63 KB: every kernel of this family re-derives the y1 tile it needs on the
+// bf16 matrix cores (split-bf16 products, csrc/gemm_x3.hip arithmetic) from rows staged ONCE per workgroup in LDS, and chains the next contraction
+// straight from the accumulator registers.  y1, z1 = ELU(BN(y1)), dz1 and dy1 never exist in HBM.
+//
+// Staging: S[h][j] = 1/51 sum_{p<51} x[h][j+p] (j < 200), one wave-level prefix sum per row; stored as ONE 32-bit word per sample,
+// (bf16 hi << 16) | bf16 lo  -- the im2col fragment of the tap contraction, X[(h,w)][t] = S[h][5w + t], starts at an arbitrary word (5w), so both
+// planes come out of the same eight 4-byte reads (a bf16 plane would need 2-byte-aligned 16-byte reads) and two v_perm_b32 per pair re-pack them.
+//
+// MFMA fragment conventions (v_mfma_f32_16x16x32_bf16, eeg_common.h): lane = 16 * kg + n; an operand fragment holds, for row / column n, the eight
+// k slots 8 kg .. 8 kg + 7; the accumulator holds D[4 kg + r][n] in register r.  The k-slot <-> contraction-index assignment is free as long as
+// both operands agree, which is what lets an ACCUMULATOR tile pair (rows 4 kg + r of tiles 0 and 1) be the next product's operand with no data
+// movement: slot j <-> row 16 (j >> 2) + 4 kg + (j & 3).
+#pragma once
+#include "conv_common.h"
+
+namespace eeg {
+
+constexpr int CS_C = 40;       // temporal filters = channels of the spatial conv (in and out)
+constexpr int CS_W = 36;       // pooled positions per row
+constexpr int CS_K1 = 25;      // taps
+constexpr int CS_T = 250;      // samples per token row
+constexpr int CS_POOL = 51;
+constexpr int CS_NS = 200;     // box-filtered samples the 36 x 25 windows touch
+constexpr int CS_RS = 272;     // words per packed row: fragment reads of the padded tiles (w < 48, t < 32) reach word 5 * 47 + 31 = 266
+constexpr int CS_MAXH = 64;
+constexpr int CS_NW = 8;       // waves per workgroup of the sample-major kernels
+constexpr int CS_NT = 64 * CS_NW;
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// (w1 & 0xffff0000) | (w0 >> 16)  and  (w1 << 16) | (w0 & 0xffff): the hi / lo bf16 halves of two packed words as one fragment dword (v_perm_b32)
+__device__ __forceinline__ unsigned cs_pair_hi(unsigned w1, unsigned w0) {
+#if defined(EEG_EMU)
+    return (w1 & 0xffff0000u) | (w0 >> 16);
+#else
+    return __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+#endif
+}
+__device__ __forceinline__ unsigned cs_pair_lo(unsigned w1, unsigned w0) {
+#if defined(EEG_EMU)
+    return (w1 << 16) | (w0 & 0xffffu);
+#else
+    return __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+#endif
+}
+// fp32 -> (bf16 hi << 16) | bf16 lo,  lo = bf16(v - hi)
+__device__ __forceinline__ unsigned cs_pack_word(float v) {
+    const float hi = __uint_as_float(x3_pack2(v, v) & 0xffff0000u);
+    return x3_pack2(v - hi, v);
+}
+__device__ __forceinline__ float cs_word_value(unsigned w) { return __uint_as_float(w & 0xffff0000u) + __uint_as_float(w << 16); }
+
+__device__ __forceinline__ bf16x8 cs_frag(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(bf16x8, u32x4_t{a, b, c, d}); }
+
+// eight consecutive packed words -> the hi and lo operand fragments (slot i <-> word i)
+__device__ __forceinline__ void cs_words_to_frags(const unsigned (&w)[8], bf16x8& hi, bf16x8& lo) {
+    hi = cs_frag(cs_pair_hi(w[1], w[0]), cs_pair_hi(w[3], w[2]), cs_pair_hi(w[5], w[4]), cs_pair_hi(w[7], w[6]));
+    lo = cs_frag(cs_pair_lo(w[1], w[0]), cs_pair_lo(w[3], w[2]), cs_pair_lo(w[5], w[4]), cs_pair_lo(w[7], w[6]));
+}
+// im2col fragment of row h at position tile wt: lane (n, kg) <- S[h][5 (16 wt + n) + 8 kg + i], i < 8
+__device__ __forceinline__ void cs_sfrag(const unsigned* __restrict__ S32, int h, int wt, bf16x8& hi, bf16x8& lo) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + 8 * kg;
+    unsigned w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = p[i];
+    cs_words_to_frags(w, hi, lo);
+}
+
+// eight fp32 values -> hi / lo fragments (slot i <-> v[i])
+__device__ __forceinline__ void cs_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    u32x2_t h0, l0, h1, l1;
+    x3_split4(v[0], v[1], v[2], v[3], h0, l0);
+    x3_split4(v[4], v[5], v[6], v[7], h1, l1);
+    hi = cs_frag(h0[0], h0[1], h1[0], h1[1]);
+    lo = cs_frag(l0[0], l0[1], l1[0], l1[1]);
+}
+
+// a += x_hi * y_lo + x_lo * y_hi + x_hi * y_hi   (the split-bf16 product, small terms first)
+__device__ __forceinline__ f32x4 cs_mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 acc) {
+    acc = mfma_bf16_16x16x32(ah, bl, acc);
+    acc = mfma_bf16_16x16x32(al, bh, acc);
+    return mfma_bf16_16x16x32(ah, bh, acc);
+}
+
+// the taps as the filter-side operand: lane (n, kg), tile ct <- w25[16 ct + n][8 kg + i] (zero past 40 filters / 25 taps)
+__device__ __forceinline__ void cs_tap_frags(const float* __restrict__ w25, bf16x8 (&wh)[3], bf16x8 (&wl)[3]) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const int c = 16 * ct + n;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 8 * kg + i;
+            v[i] = (c < CS_C && t < CS_K1) ? w25[c * CS_K1 + t] : 0.f;
+        }
+        cs_split8(v, wh[ct], wl[ct]);
+    }
+}
+
+// inclusive prefix sum over the wave in DPP data movement: Hillis-Steele inside the four 16-lane rows (row_shr 1, 2, 4, 8), then the row totals
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- 6 VALU instructions; the __shfl_up form is 6 dependent ds_bpermute round trips
+__device__ __forceinline__ float cs_wave_scan(float v) {
+#if defined(EEG_EMU)
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) {
+        const float o = hipemu::shfl_idx(v, (lane - s) & 63);
+        if ((lane & 15) >= s) v += o;
+    }
+    {
+        const float o = hipemu::shfl_idx(v, ((lane & ~15) - 1) & 63);
+        if ((lane >> 4) & 1) v += o;
+    }
+    {
+        const float o = hipemu::shfl_idx(v, 31);
+        if (lane >= 32) v += o;
+    }
+    return v;
+#else
+    v += dpp_mov<0x111, 0xf>(0.f, v);      // row_shr:1 (lanes without a source add the `old` operand: 0)
+    v += dpp_mov<0x112, 0xf>(0.f, v);      // row_shr:2
+    v += dpp_mov<0x114, 0xf>(0.f, v);      // row_shr:4
+    v += dpp_mov<0x118, 0xf>(0.f, v);      // row_shr:8
+    v += dpp_mov<0x142, 0xa>(0.f, v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xc>(0.f, v);      // row_bcast:31 -> rows 2, 3
+    return v;
+#endif
+}
+
+// lane l <- x[4l .. 4l+3] of one token row (zero past the 250 samples)
+__device__ __forceinline__ void cs_load_row(float (&v)[4], const float* __restrict__ xr, bool ok, bool vec2) {
+    const int lane = threadIdx.x & 63;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if (vec2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 4 * lane + 2 * h;
+            const f32x2 t = (ok && c < CS_T) ? *reinterpret_cast<const f32x2*>(xr + c) : f32x2{0.f, 0.f};
+            v[2 * h] = t[0];
+            v[2 * h + 1] = t[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (ok && 4 * lane + e < CS_T) ? xr[4 * lane + e] : 0.f;
+    }
+}
+
+// one wave: token row (lane l holds samples 4l .. 4l+3) -> its packed box-filtered row [256 words] (zeros from j = 200); pscr = the wave's 256-float
+// scratch row for the exclusive prefix sums P[i] = sum_{k<i} x[k]:  S[j] = (P[j + 51] - P[j]) / 51
+__device__ __forceinline__ void cs_box_row(unsigned* __restrict__ srow, float* __restrict__ pscr, const float (&v)[4]) {
+    const int lane = threadIdx.x & 63;
+    const float p0 = v[0], p1 = p0 + v[1], p2 = p1 + v[2], p3 = p2 + v[3];
+    const float base = cs_wave_scan(p3) - p3;
+    const f32x4 P{base, base + p0, base + p1, base + p2};
+    *reinterpret_cast<f32x4*>(pscr + 4 * lane) = P;
+    wave_sync();
+    u32x4_t S;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = 4 * lane + e;
+        S[e] = j < CS_NS ? cs_pack_word((pscr[j + CS_POOL] - P[e]) * (1.0f / CS_POOL)) : 0u;
+    }
+    wave_sync();
+    *reinterpret_cast<u32x4_t*>(srow + 4 * lane) = S;
+}
+
+// the H token rows of sample b -> S32[h][CS_RS] (workgroup of CS_NW waves; the caller puts a barrier behind it).  Two halves so that other prologue
+// loads can be issued while the rows are in flight.
+constexpr int CS_RPW = CS_MAXH / CS_NW;
+__device__ __forceinline__ void cs_stage_load(float (&vx)[CS_RPW][4], const float* __restrict__ x, long long xs_b, long long xs_h, int b, int H, bool vec2) {
+    const int wv = wave_uniform(threadIdx.x >> 6);
+#pragma unroll
+    for (int j = 0; j < CS_RPW; ++j) {
+        const int h = wv + CS_NW * j;
+        cs_load_row(vx[j], x + (long long)b * xs_b + (long long)(h < H ? h : 0) * xs_h, h < H, vec2);
+    }
+}
+__device__ __forceinline__ void cs_stage_finish(unsigned* __restrict__ S32, float* __restrict__ ps, const float (&vx)[CS_RPW][4], int H) {
+    const int t = threadIdx.x, wv = wave_uniform(t >> 6);
+    for (int i = t; i < H * 16; i += CS_NT) S32[(i >> 4) * CS_RS + 256 + (i & 15)] = 0u;     // words 256 .. 271: read by the padded tiles only, must be finite
+#pragma unroll
+    for (int j = 0; j < CS_RPW; ++j) {
+        const int h = wv + CS_NW * j;
+        if (h < H) cs_box_row(S32 + h * CS_RS, ps + wv * 256, vx[j]);
+    }
+}
+__device__ __forceinline__ void cs_stage_sample(unsigned* __restrict__ S32, float* __restrict__ ps, const float* __restrict__ x, long long xs_b,
+                                                long long xs_h, int b, int H, bool vec2) {
+    float vx[CS_RPW][4];
+    cs_stage_load(vx, x, xs_b, xs_h, b, H, vec2);
+    cs_stage_finish(S32, ps, vx, H);
+}
+
+// BatchNorm batch statistics from `nrows` partial rows [sum(40) | sumsq(40)] (fp64), summed in a FIXED order by every workgroup that needs them: no
+// atomics, nothing to clear, the same value everywhere.  nrows = 1: the sums themselves (after a data-parallel all-reduce).  All CS_NT threads take
+// part: thread (slice, col) sums rows slice, slice + 6, ...; the six slices are then added in slice order.  scratch: [6][80] doubles of LDS.
+constexpr int CS_BN_SLICES = 6;
+__device__ __forceinline__ void cs_bn_rows_partial(const double* __restrict__ rows, int nrows, double* __restrict__ scratch) {
+    const int t = threadIdx.x;
+    if (t < CS_BN_SLICES * 2 * CS_C) {
+        const int sl = t / (2 * CS_C), col = t % (2 * CS_C);
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = sl; r < nrows; r += CS_BN_SLICES) s += rows[(long long)r * 2 * CS_C + col];
+        scratch[t] = s;
+    }
+}
+// (behind a barrier) channel c's batch mean, 1 / sqrt(var + eps) and biased variance
+__device__ __forceinline__ void cs_bn_rows_finish(const double* __restrict__ scratch, double count, float eps, int c, float& mean, float& rstd, double& var_out) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < CS_BN_SLICES; ++sl) {
+        s += scratch[sl * 2 * CS_C + c];
+        q += scratch[sl * 2 * CS_C + CS_C + c];
+    }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    var_out = var;
+}
+
+}  // namespace eeg

@@ -512,6 +512,45 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     }
 }
 
+// BatchNorm finalize from per-workgroup partial rows [sum(C) | sumsq(C)] (fp64) in ONE launch: the rows are summed in a fixed order (thread (slice, col)
+// sums rows slice, slice + S, ...; the S slices are added in slice order) -- no atomics, nothing to clear -- then mean / rstd / running statistics as
+// bn_finalize_kernel.  sums_out (optional): the 2C column sums (the operand of a data-parallel all-reduce); mean == NULL: only those.
+__global__ __launch_bounds__(512) void bn_finalize_rows_kernel(const double* __restrict__ rows, int nrows, double count, float eps, float momentum, int C,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
+                                                               double* __restrict__ sums_out) {
+    EEG_LDS_BASE(double, scr);                 // [slices][2C]
+    const int t = threadIdx.x, nsl = 512 / (2 * C);
+    if (t < nsl * 2 * C) {
+        const int sl = t / (2 * C), col = t % (2 * C);
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = sl; r < nrows; r += nsl) s += rows[(long long)r * 2 * C + col];
+        scr[t] = s;
+    }
+    __syncthreads();
+    if (t < 2 * C) {
+        double s = 0.0;
+        for (int sl = 0; sl < nsl; ++sl) s += scr[sl * 2 * C + t];
+        scr[t] = s;                            // (slice 0's slot: read only by this thread above)
+        if (sums_out) sums_out[t] = s;
+    }
+    __syncthreads();
+    if (mean && t < C) {
+        if (t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        const double m = scr[t] / count;
+        double var = scr[C + t] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[t] = (float)m;
+        rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[t] = (1.f - momentum) * running_mean[t] + momentum * (float)m;
+            running_var[t] = (1.f - momentum) * running_var[t] + momentum * (float)unb;
+        }
+    }
+}
+
 // y = dropout( ELU( gamma * (x - mean) * rstd + beta ) )   over the (outer, C, inner) view, flat grid-stride
 __global__ __launch_bounds__(256) void bn_elu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -729,6 +768,16 @@ extern "C" int eegclip_bn_finalize(const double* sums, double count, float eps, 
     if (!train && (!running_mean || !running_var)) return EEGCLIP_EINVAL;
     EEG_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, sums, count, eps, momentum, C, mean, rstd,
                running_mean, running_var, train, num_batches_tracked);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_bn_finalize_rows(const double* rows, int nrows, double count, float eps, float momentum, int C, float* mean, float* rstd,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked, double* sums_out, void* stream) {
+    if (!rows || nrows < 1 || C < 1 || 2 * C > 512 || count < 1.0) return EEGCLIP_EINVAL;
+    if ((mean == nullptr) != (rstd == nullptr) || (!mean && !sums_out) || (running_mean == nullptr) != (running_var == nullptr)) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(sums_out)) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(bn_finalize_rows_kernel, dim3(1), dim3(512), (512 / (2 * C)) * 2 * C * sizeof(double), stream, rows, nrows, count, eps, momentum, C, mean,
+               rstd, running_mean, running_var, num_batches_tracked, sums_out);
     return (int)hipGetLastError();
 }
 

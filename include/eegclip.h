@@ -159,6 +159,10 @@ int eegclip_silu_bwd(const float* dy, const float* pre, float* dx, long long n, 
 int eegclip_bn_stats(const float* x, int outer, int C, int inner, double* sums, void* stream);
 int eegclip_bn_finalize(const double* sums, double count, float eps, float momentum, int C, float* mean, float* rstd,
                         float* running_mean, float* running_var, int train, long long* num_batches_tracked, void* stream);
+/* finalize (train) from `nrows` per-workgroup partial rows [sum(C) | sumsq(C)] (fp64, 8-byte aligned), summed in a fixed order: one launch, no atomics,
+ * nothing to clear.  sums_out (optional): the 2C column sums (what a data-parallel job all-reduces); mean = rstd = NULL: only those.  2C <= 512. */
+int eegclip_bn_finalize_rows(const double* rows, int nrows, double count, float eps, float momentum, int C, float* mean, float* rstd,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, double* sums_out, void* stream);
 int eegclip_bn_elu_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
                        int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 int eegclip_bn_elu_bwd(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -603,6 +607,43 @@ int eegclip_wgrad_planes(const eegclip_wgrad_planes_problem* p, int n_prob, void
 /* fp32 [rows = 64 B][cols] (row stride ld) -> token planes at dst (rows / 64 blocks of 64 KB, 16-byte aligned); heads: column 62 head + d -> channel
  * 64 head + d; ones: hi[.][255] = 1.0 */
 int eegclip_tok_planes_from_f32(const float* src, long long ld, int rows, int cols, int heads, int ones, void* dst, void* stream);
+
+/* ---- the conv stack of Enc_eeg recomputed from the token rows (csrc/cstack*.hip, round 5).  Retrieval/ATMS_retrieval.py:102-106:
+ *   Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)) -> BatchNorm2d(40) -> ELU -> Conv2d(40,40,(H,1))
+ * y1 = conv + pool output (B,40,H,36), its activation z1 and their gradients never exist in HBM: every kernel re-derives the y1 tile it needs on the
+ * bf16 matrix cores (split-bf16 products, EEGCLIP_PREC_BF16X3 arithmetic) from the H token rows of a sample staged once per workgroup in LDS, and
+ * chains the next contraction from the accumulator registers.  x: token rows of 250 floats at x + b*xs_b + h*xs_h (h < H <= 64); w25 (40,25) taps.
+ *   eegclip_cstack_pack    Ws (40,40,H) fp32 -> bf16 hi | lo planes in MFMA-fragment order (eegclip_cstack_packed_bytes(H) bytes, 16-byte aligned);
+ *                          once per optimizer step
+ *   eegclip_cstack_stats1  BatchNorm1 batch sums of y1: rows[b] = [sum_c(40) | sumsq_c(40)] (fp64) of sample b -- no atomics, nothing to clear
+ *   eegclip_cstack_fwd     y2[b,o,w] = bias2[o] + sum_{c,h} Ws[o,c,h] ELU(BN1(y1))[b,c,h,w]; BatchNorm1 statistics from `nstat1` partial rows (summed
+ *                          in row order by every workgroup; nstat1 = 1: the all-reduced sums of a data-parallel job) with element count `count1`;
+ *                          workgroup 0 stores mean1 / rstd1 (for the backward) and updates the running statistics + step counter (what
+ *                          eegclip_bn_finalize did).  stat1 = NULL: eval mode, mean1 / rstd1 are INPUTS.  stat2 (optional): BatchNorm2 partial rows
+ *                          [sum_o | sumsq_o] of y2 per sample.  y1 (optional): the conv + pool output for kernels that still read it. */
+typedef struct {
+    int B, H;
+    const float* x;
+    long long xs_b, xs_h;
+    const float *w25, *bias1;
+    const double* stat1;
+    int nstat1;
+    double count1;
+    float eps, momentum;
+    const float *gamma1, *beta1;
+    float *mean1, *rstd1;
+    float *run_mean1, *run_var1;
+    long long* nbt1;
+    const void* packed;
+    const float* bias2;
+    float* y2;
+    double* stat2;
+    float* y1;
+} eegclip_cstack_fwd_desc;
+long long eegclip_cstack_packed_bytes(int H);
+int eegclip_cstack_pack(const float* Ws, void* packed, int H, void* stream);
+int eegclip_cstack_stats1(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, double* rows, int B, int H, void* stream);
+int eegclip_cstack_fwd(const eegclip_cstack_fwd_desc* d, void* stream);
 
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
