@@ -81,6 +81,13 @@ class CstackFwdDesc(C.Structure):
                 ("y1", C.c_void_p)]
 
 
+class CstackBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("x", C.c_void_p), ("xs_b", C.c_longlong), ("xs_h", C.c_longlong), ("w25", C.c_void_p), ("bias1", C.c_void_p),
+                ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("gamma1", C.c_void_p), ("beta1", C.c_void_p), ("packed_t", C.c_void_p), ("dy2", C.c_void_p),
+                ("rows_out", C.c_void_p), ("stat", C.c_void_p), ("nstat", C.c_int), ("count", C.c_double), ("stat_local", C.c_void_p),
+                ("nstat_local", C.c_int), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dx", C.c_void_p), ("dw_partials", C.c_void_p), ("dw25", C.c_void_p)]
+
+
 class WgradPlanesProblem(C.Structure):
     _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("lda", C.c_longlong), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("ldb", C.c_longlong),
                 ("rows", C.c_int), ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("slices", C.c_int)]
@@ -204,6 +211,13 @@ PROTOTYPES = {
     "eegclip_cstack_pack": [_P, _P, _I, _P],
     "eegclip_cstack_stats1": [_P, _L, _L, _P, _P, _P, _I, _I, _P],
     "eegclip_cstack_fwd": [C.POINTER(CstackFwdDesc), _P],
+    "eegclip_cstack_packed_t_bytes": [_I],
+    "eegclip_cstack_pack_t": [_P, _P, _I, _P],
+    "eegclip_cstack_bwd_stats": [C.POINTER(CstackBwdDesc), _P],
+    "eegclip_cstack_bwd_workspace_floats": [_I],
+    "eegclip_cstack_bwd_apply": [C.POINTER(CstackBwdDesc), _P],
+    "eegclip_cstack_bwd_w2_workspace_floats": [_I, _I],
+    "eegclip_cstack_bwd_w2": [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_plan_fn_id": [C.c_char_p],
     "eegclip_plan_events": [_I, C.POINTER(C.c_void_p)],
     "eegclip_plan_events_destroy": [_I, C.POINTER(C.c_void_p)],

@@ -415,7 +415,7 @@ class _Engine:
         """bf16 hi / lo planes of the spatial conv weights for the split-bf16 conv kernels (csrc/sconv.hip), refreshed by ONE eegclip_split_rows
         launch in the forward plan (shared with the Linear weights): Ws^T as [(c,h)][64] (both BN1-backward passes) and, opt-in, Ws as [40][ld]
         (k contiguous: forward).  Returns the forward kernel's (hi, lo, ld) arguments -- (None, None, 0) = exact fp32 products -- and the split items."""
-        if pl.precision != _abi.PREC_BF16X3:
+        if pl.precision != _abi.PREC_BF16X3 or self._cstack_bwd_enabled(pl):
             return (None, None, 0), []
         Kc = C_TS * N_CH
         ld = (Kc + 128 + 63) // 64 * 64             # a forward chunk may read up to 127 k past the end of its K slice
@@ -477,7 +477,7 @@ class _Engine:
         b = dict(
             h=f(B, L_TOK, D_MODEL), qkv=f(R, 3 * HE), ctx=f(R, HE), r1=f(R, D_MODEL), n1=f(R, D_MODEL), mu1=f(R), rs1=f(R),
             f1=f(R, D_FF), g1=f(R, D_FF), r2=f(R, D_MODEL), n2=f(R, D_MODEL), mu2=f(R), rs2=f(R), n3=f(B, L_TOK, D_MODEL), mu3=f(R), rs3=f(R),
-            y1=f(B, C_TS, N_CH, W_TS), z2=f(B, C_TS, W_TS),
+            z2=f(B, C_TS, W_TS),
             feat=f(B, F_TS), u=f(B, P_DIM), gu=f(B, P_DIM), s=f(B, P_DIM), out=f(B, P_DIM), mu4=f(B), rs4=f(B),
             bn=f(4, C_TS), ids=torch.zeros(B, dtype=torch.long, device=dev),
         )
@@ -642,7 +642,9 @@ class _Engine:
     def _cstack_enabled(self, pl):
         """the conv stack recomputed from the token rows (csrc/cstack*.hip: y1 never written) in split-bf16 plans; EEGCLIP_CSTACK=0 pins the round-4
         kernels around y1 in HBM (diagnosis, A/B timing); exact-fp32 plans always use those"""
-        return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CSTACK", "1") != "0"
+        from .plan import default_gemm_precision
+        precision = pl.precision if pl is not None else default_gemm_precision()
+        return precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CSTACK", "1") != "0"
 
     def _build_fwd_cstack(self, pl, b, B, train, W):
         """A4+A5 on csrc/cstack.hip (round 5): BatchNorm1 sums WITHOUT writing y1, then per sample y1 tile -> BN1 -> ELU -> spatial conv chained on the
@@ -652,10 +654,16 @@ class _Engine:
         if not hasattr(self, "cs_packed"):
             self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=dev)
         pl.call("eegclip_cstack_pack", _p(P[_TS + "4.weight"]), _p(self.cs_packed), N_CH)
+        if self._cstack_bwd_enabled(pl):
+            if not hasattr(self, "cs_packed_t"):
+                self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=dev)
+            pl.call("eegclip_cstack_pack_t", _p(P[_TS + "4.weight"]), _p(self.cs_packed_t), N_CH)
         if "cs_rows" not in b:
             b["cs_rows"] = torch.empty(2, B, 2 * C_TS, dtype=torch.float64, device=dev)          # BatchNorm1 | BatchNorm2 partial rows, one per sample
         rows1, rows2 = b["cs_rows"][0], b["cs_rows"][1]
         keep_y1 = not self._cstack_bwd_enabled(pl)                 # the round-4 backward kernels still read y1
+        if keep_y1 and "y1" not in b:
+            b["y1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=dev)
         count1 = float(W * B * N_CH * W_TS)
         stat1, nstat1 = None, 0
         if train:
@@ -688,11 +696,15 @@ class _Engine:
             pl.call("eegclip_bn_finalize", _p(sums[1]), count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, int(train), nbt2)
 
     def _cstack_bwd_enabled(self, pl):
-        return False
+        """the conv-stack backward recomputed from the token rows too (csrc/cstack_bwd.hip); EEGCLIP_CSTACK_BWD=0 keeps the round-4 backward around y1
+        (the forward then still writes y1 for it)"""
+        return self._cstack_enabled(pl) and os.environ.get("EEGCLIP_CSTACK_BWD", "1") != "0"
 
     def _build_fwd_conv_y1(self, pl, b, B, train, W):
         """A4+A5 around y1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""
         P, sums, bn = self.P, b["sums"], b["bn"]
+        if "y1" not in b:              # the conv + pool output (B,40,63,36): exists in HBM only for the kernels around it
+            b["y1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
         if "tsf_ws" not in b:
             b["tsf_ws"] = torch.empty(int(lib().eegclip_tsconv_fwd_workspace_floats(B, N_CH)) // 2, dtype=torch.float64, device=self.device)
         pl.call("eegclip_tsconv_fwd", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(b["y1"]), B, N_CH, T_LEN,
@@ -796,61 +808,10 @@ class _Engine:
         pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
                 _p(sums[2]) if train else _p(zsum), (_p(local2) if local2 is not None else None) if train else _p(sums[2]), float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
                 W_TS, pc_, 0, SITE_CONV, seed_at=16)
-        # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
-        # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
-        # (d(conv bias) in front of a train-mode BatchNorm is identically zero: tsconv.0.bias / tsconv.4.bias keep the cleared zero.)
-        if "scw_ws" not in b:
-            b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-        bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
-        # split-bf16 products for the K = 40 contraction of both BN1-backward passes (the plan's GEMM precision): Ws^T as bf16 planes
-        # [(c,h)][64 o], split by the forward plan of this step
-        wt = (None, None)
-        if pl.precision == _abi.PREC_BF16X3:
-            wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
-        if "scx_ws" not in b:
-            b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
-        # (folding the two into one pass over y1 -- round 3's eegclip_sconv_bwd_w_stats -- saved 15 us of kernel time but moved the weight gradient from
-        #  the second stream onto the dX chain: step 1.100-1.108 vs 1.093-1.096 ms; removed in round 4)
-        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
-        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
-        local1 = None
-        if W > 1:
-            local1 = torch.zeros_like(sums[3])
-            pl._keep.append(local1)
-
-            def exchange1():
-                local1.copy_(sums[3])
-                self._allreduce(sums[3])
-            pl.callback(exchange1, "allreduce_bn1_bwd")
-        if not train:
-            pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
-        count1 = float(W * B * N_CH * W_TS)
-        sums1 = (_p(sums[3]) if train else _p(zsum), (_p(local1) if local1 is not None else None) if train else _p(sums[3]))
-        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CONV_BWD_FUSED", "0") == "1":
-            # OPT-IN: BatchNorm1-backward apply + the temporal conv's weight and input gradients in ONE pass over y1 (csrc/conv.hip: conv_bwd_fused_kernel):
-            # the (B,40,63,36) gradient dy1 -- 93 MB written once and read twice by the three launches this replaces -- never exists in HBM (404 -> 141 MB
-            # of traffic).  Parity-green; measured on the MI355X at B = 256: 109 us against 49 + 37 us on the main stream + 44 us on the second one --
-            # less kernel time, but all of it on the dX chain: the step does not get shorter, so the three launches stay the default
-            if "cbf_ws" not in b:
-                b["cbf_ws"] = torch.empty(int(lib().eegclip_conv_bwd_fused_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-            pl.call("eegclip_conv_bwd_fused", _p(b["dy2"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]),
-                    _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(b["dn3"]), _p(G[_TS + "0.weight"]), _p(b["cbf_ws"]), B, N_CH, 0)
-            if early_reduce:
-                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+        if self._cstack_bwd_enabled(pl):
+            self._build_bwd_cstack(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce)
         else:
-            if "dy1" not in b:
-                b["dy1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
-            pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(b["dy1"]),
-                    _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
-            if "tsw_ws" not in b:
-                b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-            pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
-                    C_TS, side=True)
-            if early_reduce:
-                # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
-                # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
-                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
-            pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
+            self._build_bwd_conv_y1(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce)
         fused = self._token_block_enabled(pl) and hasattr(self, "tb_packed")
         if fused:
             # the dX chain of the transformer block, one workgroup per sample (csrc/token_block.hip): part 0 = final LN' .. dctx, the attention
@@ -991,6 +952,99 @@ class _Engine:
                 pl.j_scatter = len(pl.ops)
                 pl.call("eegclip_gather_rows", _p(b["dx"]), XR, _p(b["dxs"]), XR, _p(b["perm"]), B, XR, 1)
         return pl
+
+    def _build_bwd_cstack(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce):
+        """spatial conv + BN1 + ELU + temporal conv backward recomputed from the token rows (csrc/cstack_bwd.hip, round 5): y1 / z1 / dz1 / dy1 never
+        exist in HBM.  dWs on the second stream; BatchNorm1-backward sums as one partial row per sample, summed in a fixed order by the apply pass."""
+        P, G, sums, bn = self.P, self.G, b["sums"], b["bn"]
+        dev = self.device
+        if "csw_ws" not in b:
+            b["csw_ws"] = torch.empty(int(lib().eegclip_cstack_bwd_w2_workspace_floats(B, N_CH)), dtype=torch.float32, device=dev)
+            b["csb_ws"] = torch.empty(int(lib().eegclip_cstack_bwd_workspace_floats(B)), dtype=torch.float32, device=dev)
+            b["cs_rows3"] = torch.empty(B, 2 * C_TS, dtype=torch.float64, device=dev)
+        xs = (_p(b["n3"]), L_TOK * D_MODEL, D_MODEL)
+        bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
+        pl.call("eegclip_cstack_bwd_w2", *xs, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["csw_ws"]),
+                B, N_CH, side=True)
+        rows3 = b["cs_rows3"]
+        count1 = float(W * B * N_CH * W_TS)
+        common = dict(B=B, H=N_CH, x=xs[0], xs_b=xs[1], xs_h=xs[2], w25=_p(P[_TS + "0.weight"]), bias1=_p(P[_TS + "0.bias"]), mean1=bnp[0], rstd1=bnp[1],
+                      gamma1=bnp[2], beta1=bnp[3], packed_t=_p(self.cs_packed_t), dy2=_p(b["dy2"]), rows_out=_p(rows3), count=count1,
+                      dgamma=_p(G[_TS + "2.weight"]), dbeta=_p(G[_TS + "2.bias"]), dx=_p(b["dn3"]), dw_partials=_p(b["csb_ws"]), dw25=_p(G[_TS + "0.weight"]))
+        pl.call_desc("eegclip_cstack_bwd_stats", _abi.CstackBwdDesc(stat=None, nstat=0, stat_local=None, nstat_local=0, **common))
+        stat, nstat, local, nlocal = _p(rows3), B, None, 0
+        if W > 1 or not train:
+            pl.call("eegclip_bn_finalize_rows", _p(rows3), B, count1, EPS, 0.1, C_TS, None, None, None, None, None, _p(sums[3]))
+            local, nlocal = _p(rows3), B
+            if W > 1:
+                pl.callback(lambda: self._allreduce(sums[3]), "allreduce_bn1_bwd")
+            stat, nstat = (_p(sums[3]), 1) if train else (_p(zsum), 1)
+            if not train:
+                pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
+        pl.call_desc("eegclip_cstack_bwd_apply", _abi.CstackBwdDesc(stat=stat, nstat=nstat, stat_local=local, nstat_local=nlocal, **common))
+        if early_reduce:
+            # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
+            # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
+            pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+
+    def _build_bwd_conv_y1(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce):
+        """spatial conv + BN1 + ELU + temporal conv backward around y1 / dy1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""
+        P, G, sums, bn = self.P, self.G, b["sums"], b["bn"]
+        # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
+        # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
+        # (d(conv bias) in front of a train-mode BatchNorm is identically zero: tsconv.0.bias / tsconv.4.bias keep the cleared zero.)
+        if "scw_ws" not in b:
+            b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+        bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
+        # split-bf16 products for the K = 40 contraction of both BN1-backward passes (the plan's GEMM precision): Ws^T as bf16 planes
+        # [(c,h)][64 o], split by the forward plan of this step
+        wt = (None, None)
+        if pl.precision == _abi.PREC_BF16X3:
+            wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
+        if "scx_ws" not in b:
+            b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
+        # (folding the two into one pass over y1 -- round 3's eegclip_sconv_bwd_w_stats -- saved 15 us of kernel time but moved the weight gradient from
+        #  the second stream onto the dX chain: step 1.100-1.108 vs 1.093-1.096 ms; removed in round 4)
+        pl.call("eegclip_sconv_bwd_w", _p(b["y1"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["scw_ws"]), B, N_CH, pl.precision & 0xff, side=True)
+        pl.call("eegclip_sconv_bwd_x_stats", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, _p(sums[3]), _p(b["scx_ws"]), B, N_CH)
+        local1 = None
+        if W > 1:
+            local1 = torch.zeros_like(sums[3])
+            pl._keep.append(local1)
+
+            def exchange1():
+                local1.copy_(sums[3])
+                self._allreduce(sums[3])
+            pl.callback(exchange1, "allreduce_bn1_bwd")
+        if not train:
+            pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
+        count1 = float(W * B * N_CH * W_TS)
+        sums1 = (_p(sums[3]) if train else _p(zsum), (_p(local1) if local1 is not None else None) if train else _p(sums[3]))
+        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CONV_BWD_FUSED", "0") == "1":
+            # OPT-IN: BatchNorm1-backward apply + the temporal conv's weight and input gradients in ONE pass over y1 (csrc/conv.hip: conv_bwd_fused_kernel):
+            # the (B,40,63,36) gradient dy1 -- 93 MB written once and read twice by the three launches this replaces -- never exists in HBM (404 -> 141 MB
+            # of traffic).  Parity-green; measured on the MI355X at B = 256: 109 us against 49 + 37 us on the main stream + 44 us on the second one --
+            # less kernel time, but all of it on the dX chain: the step does not get shorter (DESIGN.md section 9), so the three launches stay the default
+            if "cbf_ws" not in b:
+                b["cbf_ws"] = torch.empty(int(lib().eegclip_conv_bwd_fused_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+            pl.call("eegclip_conv_bwd_fused", _p(b["dy2"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]),
+                    _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(b["dn3"]), _p(G[_TS + "0.weight"]), _p(b["cbf_ws"]), B, N_CH, 0)
+            if early_reduce:
+                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+        else:
+            if "dy1" not in b:
+                b["dy1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
+            pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(b["dy1"]),
+                    _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
+            if "tsw_ws" not in b:
+                b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+            pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
+                    C_TS, side=True)
+            if early_reduce:
+                # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
+                # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
+                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+            pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
 
     def _world(self):
         import torch.distributed as dist

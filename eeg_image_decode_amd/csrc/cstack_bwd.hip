@@ -1,0 +1,614 @@
+// Conv stack of Enc_eeg, backward, recomputed from the token rows (see cstack_common.h; Retrieval/ATMS_retrieval.py:102-106).  Given dy2 (B,40,36), the
+// gradient entering the spatial conv's output:
+//   cstack_bwd_kernel<false>   BatchNorm1-backward sums: per sample and token row h the y1 tile (tap contraction) and dz1 = Ws^T dy2 (K = 40 out channels)
+//                              on the matrix cores, da = dz1 * ELU'(BN1(y1)) in registers -> one partial row [sum da | sum da * xhat] per sample
+//   cstack_bwd_kernel<true>    the same tiles again, dy1 = BatchNorm1-backward(da) in registers, then
+//                                * E[w][t] = sum_c dy1[c][w] taps[c][t]  (the accumulator tiles ARE the operand), overlap-added through a wave-private LDS
+//                                  tile into dS[j = 5w + t], transposed box filter -> the token-row gradient dx[b][h][:]
+//                                * dW1[c][t] += sum_w dy1[c][w] S[h][5w + t]: dy1 transposed through a wave-private packed LDS tile
+//   cstack_bwd_w2_kernel       dWs[o][c][h] = sum_{b,w} dy2[b][o][w] z1[b][c][h][w]: workgroup = (4 token rows, sample group), a wave owns ONE row h of
+//                              every sample of its group: y1^T tile -> z1^T in registers = the k = w operand; per-group slabs + an ordered reduction
+//   cstack_pack_t_kernel       Ws (40,40,H) -> Ws^T fragments (rows = filters c, k = out channels o), once per optimizer step
+// Replaces sconv_bwd_w (+ reduce), sconv_bwd_x<stats> (+ colsum), sconv_bwd_x<apply> (dy1 write, 93 MB), tsconv_bwd_w (+ reduce), tsconv_bwd_x.
+#include "cstack_common.h"
+
+#include <stdlib.h>
+
+namespace eeg {
+
+// ---- Ws^T fragments ----------------------------------------------------------------------------------------------------------------------------------
+// per token row h and filter tile ct:  main hi | main lo (1024 B each: lane (n, kg) slot j <-> o = 16 (j >> 2) + 4 kg + (j & 3), filter c = 16 ct + n)
+//                                      tail hi | tail lo (512 B each: slot j < 4 <-> o = 32 + 4 kg + j, zero from o = 40)
+constexpr int CST_TILE = 3072, CST_ROW = 3 * CST_TILE;
+__global__ __launch_bounds__(256) void cstack_pack_t_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= H * 3 * 64) return;
+    const int lane = id & 63, ct = (id >> 6) % 3, h = id / 192;
+    const int n = lane & 15, kg = lane >> 4, c = 16 * ct + n;
+    float v[8], tl[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int o = 16 * (j >> 2) + 4 * kg + (j & 3);
+        v[j] = c < CS_C ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = 32 + 4 * kg + j;
+        tl[j] = (c < CS_C && o < CS_C) ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+    bf16x8 hi, lo;
+    cs_split8(v, hi, lo);
+    u32x2_t th, tlo;
+    x3_split4(tl[0], tl[1], tl[2], tl[3], th, tlo);
+    unsigned char* base = packed + (long long)h * CST_ROW + ct * CST_TILE;
+    *reinterpret_cast<bf16x8*>(base + 16 * lane) = hi;
+    *reinterpret_cast<bf16x8*>(base + 1024 + 16 * lane) = lo;
+    *reinterpret_cast<u32x2_t*>(base + 2048 + 8 * lane) = th;
+    *reinterpret_cast<u32x2_t*>(base + 2560 + 8 * lane) = tlo;
+}
+
+__device__ __forceinline__ bf16x8 cs_half_frag(u32x2_t v) { return cs_frag(v[0], v[1], 0u, 0u); }
+
+// ---- BatchNorm1-backward sums / apply + temporal-conv backward ------------------------------------------------------------------------------------------
+struct cs_bwd_args {
+    const float* x;
+    long long xs_b, xs_h;
+    const float *w25, *bias1;
+    const float *mean1, *rstd1, *gamma1, *beta1;
+    const unsigned char* packed_t;
+    const float* dy2;
+    double* rows_out;               // stats pass: [B][80]
+    const double* stat;             // apply pass: partial rows [sum da | sum da * xhat] (nstat of them) and the element count
+    int nstat;
+    double count;
+    const double* stat_local;       // this rank's own sums for dgamma / dbeta (NULL: stat)
+    int nstat_local;
+    float *dgamma, *dbeta;
+    float* dx;
+    float* dw_partials;             // [B][40 * 25]
+    int B, H, vec2;
+};
+
+constexpr int CSB_ES = 27;                                  // E tile [36 w][27]: taps 0 .. 24
+constexpr int CSB_E_BYTES = CS_W * CSB_ES * 4;              // 3888
+constexpr int CSB_DT_BYTES = CS_C * CS_W * 4;               // 5760: dy1 as packed words [40 c][36 w]
+constexpr int CSB_WAVE = CSB_E_BYTES + CSB_DT_BYTES;        // 9648
+constexpr int CSB_DYF = 3 * 3072;                           // dy2 fragment images (3 position tiles)
+constexpr int CSB_TAPF = 2 * 3072;                          // taps as the k = filter operand (2 tap tiles)
+constexpr int CSB_NCOEF = 7;                                // U1 U0 A1 A0 K M1 M2
+
+template <bool APPLY>
+__global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) {
+    EEG_LDS_BASE(unsigned char, ldsb);
+    const int H = a.H;
+    unsigned* S32 = reinterpret_cast<unsigned*>(ldsb);
+    unsigned char* p = ldsb + H * CS_RS * 4;
+    float* coef = reinterpret_cast<float*>(p);               // [7][48]
+    p += CSB_NCOEF * 48 * 4;
+    unsigned char* dyf = p;                                  // dy2 fragments: per position tile  main hi | main lo | tail hi | tail lo
+    p += CSB_DYF;
+    unsigned char* tapf = p;                                 // (APPLY) taps fragments: per tap tile the same four images
+    p += APPLY ? CSB_TAPF : 0;
+    unsigned char* wreg = p;                                 // per-wave regions
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.x;
+    constexpr int WREG = APPLY ? CSB_WAVE : 1024;
+    unsigned char* mine = wreg + wv * WREG;
+    float* Et = reinterpret_cast<float*>(mine);              // [36][27]
+    unsigned* DT = reinterpret_cast<unsigned*>(mine + (APPLY ? CSB_E_BYTES : 0));
+    float* qscr = reinterpret_cast<float*>(mine);            // 256 floats of prefix-sum scratch (staging; the transposed box filter once E is consumed)
+    double* bnscr = reinterpret_cast<double*>(wreg);         // [6][80] (before the staging uses the region)
+
+    float vx[CS_RPW][4];
+    cs_stage_load(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
+    if (APPLY) {
+        cs_bn_rows_partial(a.stat, a.nstat, bnscr);
+        if (b == 0 && a.stat_local) cs_bn_rows_partial(a.stat_local, a.nstat_local, bnscr + CS_BN_SLICES * 2 * CS_C);
+    }
+    // dy2 of this sample as the k = out-channel operand: lane (n, kg) of position tile wt <- dy2[o][w = 16 wt + n]
+    if (t < 192) {
+        const int wt = t >> 6, w = 16 * wt + n;
+        const float* src = a.dy2 + (long long)b * CS_C * CS_W + w;
+        float v[8], tl[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w < CS_W ? src[(16 * (j >> 2) + 4 * kg + (j & 3)) * CS_W] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[j] = (w < CS_W && 32 + 4 * kg + j < CS_C) ? src[(32 + 4 * kg + j) * CS_W] : 0.f;
+        bf16x8 hi, lo;
+        cs_split8(v, hi, lo);
+        u32x2_t th, tlo;
+        x3_split4(tl[0], tl[1], tl[2], tl[3], th, tlo);
+        unsigned char* base = dyf + wt * 3072;
+        *reinterpret_cast<bf16x8*>(base + 16 * lane) = hi;
+        *reinterpret_cast<bf16x8*>(base + 1024 + 16 * lane) = lo;
+        *reinterpret_cast<u32x2_t*>(base + 2048 + 8 * lane) = th;
+        *reinterpret_cast<u32x2_t*>(base + 2560 + 8 * lane) = tlo;
+    } else if (APPLY && t < 320) {
+        // taps as the k = filter operand of E = dy1^T taps: lane (n, kg) of tap tile tt <- w25[c][t = 16 tt + n]
+        const int tt = (t - 192) >> 6, tp = 16 * tt + n;
+        float v[8], tl[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tp < CS_K1 ? a.w25[(16 * (j >> 2) + 4 * kg + (j & 3)) * CS_K1 + tp] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[j] = (tp < CS_K1 && 32 + 4 * kg + j < CS_C) ? a.w25[(32 + 4 * kg + j) * CS_K1 + tp] : 0.f;
+        bf16x8 hi, lo;
+        cs_split8(v, hi, lo);
+        u32x2_t th, tlo;
+        x3_split4(tl[0], tl[1], tl[2], tl[3], th, tlo);
+        unsigned char* base = tapf + tt * 3072;
+        *reinterpret_cast<bf16x8*>(base + 16 * lane) = hi;
+        *reinterpret_cast<bf16x8*>(base + 1024 + 16 * lane) = lo;
+        *reinterpret_cast<u32x2_t*>(base + 2048 + 8 * lane) = th;
+        *reinterpret_cast<u32x2_t*>(base + 2560 + 8 * lane) = tlo;
+    }
+    __syncthreads();                                          // bnscr complete
+    if (t < 48) {
+        float U1 = 0.f, U0 = 0.f, A1 = 0.f, A0 = 0.f, K = 0.f, M1 = 0.f, M2 = 0.f;
+        if (t < CS_C) {
+            const float mean = a.mean1[t], rstd = a.rstd1[t], gam = a.gamma1[t], bet = a.beta1[t];
+            A1 = rstd;
+            A0 = (a.bias1[t] - mean) * rstd;                 // xhat = acc * A1 + A0   (acc = y1 - bias)
+            U1 = gam * rstd;
+            U0 = gam * A0 + bet;                             // u = gamma * xhat + beta
+            if (APPLY) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < CS_BN_SLICES; ++sl) { s1 += bnscr[sl * 2 * CS_C + t]; s2 += bnscr[sl * 2 * CS_C + CS_C + t]; }
+                K = gam * rstd;
+                M1 = (float)(s1 / a.count);
+                M2 = (float)(s2 / a.count);
+                if (b == 0) {                                // BatchNorm1 parameter gradients from this rank's own sums (fixed summation order)
+                    if (a.stat_local) {
+                        s1 = 0.0;
+                        s2 = 0.0;
+                        const double* loc = bnscr + CS_BN_SLICES * 2 * CS_C;
+#pragma unroll
+                        for (int sl = 0; sl < CS_BN_SLICES; ++sl) { s1 += loc[sl * 2 * CS_C + t]; s2 += loc[sl * 2 * CS_C + CS_C + t]; }
+                    }
+                    atomicAdd(a.dbeta + t, (float)s1);
+                    atomicAdd(a.dgamma + t, (float)s2);
+                }
+            }
+        }
+        coef[0 * 48 + t] = U1; coef[1 * 48 + t] = U0; coef[2 * 48 + t] = A1; coef[3 * 48 + t] = A0;
+        coef[4 * 48 + t] = K;  coef[5 * 48 + t] = M1; coef[6 * 48 + t] = M2;
+    }
+    __syncthreads();                                          // bnscr consumed: the per-wave regions may be used
+    cs_stage_finish(S32, reinterpret_cast<float*>(wreg), vx, H);     // (scratch row of wave v = the first KB of ... a private KB per wave)
+    bf16x8 wh[3], wl[3];
+    cs_tap_frags(a.w25, wh, wl);
+    __syncthreads();
+
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    float s1[3][4], s2[3][4];
+    f32x4 acc5[3][2];                                         // (APPLY) taps gradient D[c = 16 ct + 4 kg + r][t = 16 tt + n]
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+        acc5[ct][0] = zero4;
+        acc5[ct][1] = zero4;
+    }
+    // gather map of the overlap-add: lane l < 50 owns j = 4 l + e; dS[j] = sum_a E[w = j / 5 - a][t = j % 5 + 5 a]
+    int gq[4], gr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int j = 4 * lane + e; gq[e] = j / 5; gr[e] = j % 5; }
+
+    const unsigned char* const dyf0 = dyf;
+    const unsigned char* const tapf0 = tapf;
+    const float* const coef0 = coef;
+    for (int h = wv; h < H; h += CS_NW) {
+        const int oz = cs_opaque_zero();                      // (see cstack_common.h: keeps the loop-invariant LDS operands out of registers)
+        const unsigned char* dyf = dyf0 + oz;
+        const unsigned char* tapf = tapf0 + oz;
+        const float* coef = coef0 + oz;
+        // Ws^T fragments of this row: straight from L2 (every workgroup reads the same rows)
+        bf16x8 th_[3], tl_[3];
+        u32x2_t uh_[3], ul_[3];
+        {
+            const unsigned char* base = a.packed_t + (long long)h * CST_ROW;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                th_[ct] = *reinterpret_cast<const bf16x8*>(base + ct * CST_TILE + 16 * lane);
+                tl_[ct] = *reinterpret_cast<const bf16x8*>(base + ct * CST_TILE + 1024 + 16 * lane);
+                uh_[ct] = *reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2048 + 8 * lane);
+                ul_[ct] = *reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2560 + 8 * lane);
+            }
+        }
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) {
+            bf16x8 xh, xl;
+            cs_sfrag(S32, h, wt, xh, xl);
+            const bf16x8 dh = *reinterpret_cast<const bf16x8*>(dyf + wt * 3072 + 16 * lane);
+            const bf16x8 dl = *reinterpret_cast<const bf16x8*>(dyf + wt * 3072 + 1024 + 16 * lane);
+            const bf16x8 eh = cs_half_frag(*reinterpret_cast<const u32x2_t*>(dyf + wt * 3072 + 2048 + 8 * lane));
+            const bf16x8 el = cs_half_frag(*reinterpret_cast<const u32x2_t*>(dyf + wt * 3072 + 2560 + 8 * lane));
+            const bool wok = 16 * wt + n < CS_W;
+            float dy1[3][4];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const f32x4 acc1 = cs_mma3(wh[ct], wl[ct], xh, xl, zero4);                               // y1 - bias:  D[c = 16 ct + 4 kg + r][w = 16 wt + n]
+                f32x4 acc3 = cs_mma3(th_[ct], tl_[ct], dh, dl, zero4);                                   // dz1 = Ws^T dy2, out channels 0 .. 31
+                acc3 = cs_mma3(cs_half_frag(uh_[ct]), cs_half_frag(ul_[ct]), eh, el, acc3);              //                 out channels 32 .. 39
+                if (APPLY) {
+                    const f32x4 U1 = *reinterpret_cast<const f32x4*>(coef + 0 * 48 + 16 * ct + 4 * kg), U0 = *reinterpret_cast<const f32x4*>(coef + 1 * 48 + 16 * ct + 4 * kg);
+                    const f32x4 A1 = *reinterpret_cast<const f32x4*>(coef + 2 * 48 + 16 * ct + 4 * kg), A0 = *reinterpret_cast<const f32x4*>(coef + 3 * 48 + 16 * ct + 4 * kg);
+                    const f32x4 K = *reinterpret_cast<const f32x4*>(coef + 4 * 48 + 16 * ct + 4 * kg), M1 = *reinterpret_cast<const f32x4*>(coef + 5 * 48 + 16 * ct + 4 * kg);
+                    const f32x4 M2 = *reinterpret_cast<const f32x4*>(coef + 6 * 48 + 16 * ct + 4 * kg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc1[r] * U1[r] + U0[r], xh_ = acc1[r] * A1[r] + A0[r];
+                        const float ex = fast_exp(u < 0.f ? u : 0.f);
+                        const float da = u > 0.f ? acc3[r] : acc3[r] * ex;
+                        dy1[ct][r] = wok ? K[r] * (da - M1[r] - xh_ * M2[r]) : 0.f;
+                    }
+                } else {
+                    const f32x4 U1 = *reinterpret_cast<const f32x4*>(coef + 0 * 48 + 16 * ct + 4 * kg), U0 = *reinterpret_cast<const f32x4*>(coef + 1 * 48 + 16 * ct + 4 * kg);
+                    const f32x4 A1 = *reinterpret_cast<const f32x4*>(coef + 2 * 48 + 16 * ct + 4 * kg), A0 = *reinterpret_cast<const f32x4*>(coef + 3 * 48 + 16 * ct + 4 * kg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = acc1[r] * U1[r] + U0[r], xh_ = acc1[r] * A1[r] + A0[r];
+                        const float ex = fast_exp(u < 0.f ? u : 0.f);
+                        const float da = u > 0.f ? acc3[r] : acc3[r] * ex;                               // (exact zeros at w >= 36 and c >= 40: zero operands)
+                        s1[ct][r] += da;
+                        s2[ct][r] += da * xh_;
+                    }
+                }
+            }
+            if (APPLY) {
+                // E[w][t] = sum_c dy1[c][w] taps[c][t]: the dy1 tiles are the A operand (row = position w = 16 wt + n, k slot j <-> c = 16 (j >> 2) + 4 kg + (j & 3))
+                bf16x8 ah, al;
+                {
+                    const float v8[8] = {dy1[0][0], dy1[0][1], dy1[0][2], dy1[0][3], dy1[1][0], dy1[1][1], dy1[1][2], dy1[1][3]};
+                    cs_split8(v8, ah, al);
+                }
+                u32x2_t a2h, a2l;
+                x3_split4(dy1[2][0], dy1[2][1], dy1[2][2], dy1[2][3], a2h, a2l);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 16 * lane);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 1024 + 16 * lane);
+                    const bf16x8 ch = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2048 + 8 * lane));
+                    const bf16x8 cl = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2560 + 8 * lane));
+                    f32x4 accE = cs_mma3(ah, al, bh, bl, zero4);
+                    accE = cs_mma3(cs_half_frag(a2h), cs_half_frag(a2l), ch, cl, accE);                  // D[w = 16 wt + 4 kg + r][t = 16 tt + n]
+                    const int tp = 16 * tt + n;
+                    if (tp < CS_K1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int w = 16 * wt + 4 * kg + r;
+                            if (w < CS_W) Et[w * CSB_ES + tp] = accE[r];
+                        }
+                    }
+                }
+                // dy1 as packed words DT[c][w] for the taps gradient (contraction over w needs the transposed tile)
+                if (wok) {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * ct + 4 * kg + r;
+                            if (c < CS_C) DT[c * CS_W + 16 * wt + n] = cs_pack_word(dy1[ct][r]);
+                        }
+                }
+            }
+        }
+        if (APPLY) {
+            wave_sync();
+            // overlap-add: dS[j] = sum_{a < 5} E[j / 5 - a][j % 5 + 5 a]
+            float ds[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int w = gq[e] - k;
+                    const float v = Et[(w >= 0 && w < CS_W ? w : 0) * CSB_ES + gr[e] + 5 * k];
+                    s += (w >= 0 && w < CS_W) ? v : 0.f;
+                }
+                ds[e] = 4 * lane + e < CS_NS ? s : 0.f;
+            }
+            wave_sync();                                      // E is consumed: its first KB becomes the prefix-sum scratch
+            // transposed box filter: Q[i] = sum_{k < i} dS[k];  dx[i] = (Q[i + 1] - Q[max(i - 50, 0)]) / 51
+            {
+                const float p0 = ds[0], p1 = p0 + ds[1], p2 = p1 + ds[2], p3 = p2 + ds[3];
+                const float basev = cs_wave_scan(p3) - p3;
+                const float q4[5] = {basev, basev + p0, basev + p1, basev + p2, basev + p3};
+                *reinterpret_cast<f32x4*>(qscr + 4 * lane) = f32x4{q4[0], q4[1], q4[2], q4[3]};
+                wave_sync();
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * lane + e;
+                    const float lo = i >= CS_POOL - 1 ? qscr[i - (CS_POOL - 1)] : 0.f;
+                    o[e] = (q4[e + 1] - lo) * (1.0f / CS_POOL);
+                }
+                float* xr = a.dx + (long long)b * a.xs_b + (long long)h * a.xs_h;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                if (a.vec2) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        if (4 * lane + 2 * hf < CS_T) *reinterpret_cast<f32x2*>(xr + 4 * lane + 2 * hf) = f32x2{o[2 * hf], o[2 * hf + 1]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * lane + e < CS_T) xr[4 * lane + e] = o[e];
+                }
+            }
+            // taps gradient: dW1[c][t] += sum_w dy1[c][w] S[h][5 w + t];  A = DT rows (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); tail w = 32 + 4 kg + j, kg = 0)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                bf16x8 bh, bl, ch, cl;
+                {
+                    const unsigned* sp = S32 + h * CS_RS + 16 * tt + n;
+                    unsigned w8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w8[j] = sp[5 * (16 * (j >> 2) + 4 * kg + (j & 3))];
+                    cs_words_to_frags(w8, bh, bl);
+                    unsigned w4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w4[j] = sp[5 * (32 + 4 * kg + j)];
+                    ch = cs_frag(cs_pair_hi(w4[1], w4[0]), cs_pair_hi(w4[3], w4[2]), 0u, 0u);
+                    cl = cs_frag(cs_pair_lo(w4[1], w4[0]), cs_pair_lo(w4[3], w4[2]), 0u, 0u);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const int c = 16 * ct + n < CS_C ? 16 * ct + n : CS_C - 1;          // (filters >= 40: discarded output rows)
+                    const u32x4_t m0 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 4 * kg);
+                    const u32x4_t m1 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 16 + 4 * kg);
+                    u32x4_t m2 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 32);
+                    if (kg != 0) m2 = u32x4_t{0u, 0u, 0u, 0u};                            // positions >= 36
+                    const unsigned w8[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+                    bf16x8 ah, al;
+                    cs_words_to_frags(w8, ah, al);
+                    const bf16x8 a2h = cs_frag(cs_pair_hi(m2[1], m2[0]), cs_pair_hi(m2[3], m2[2]), 0u, 0u);
+                    const bf16x8 a2l = cs_frag(cs_pair_lo(m2[1], m2[0]), cs_pair_lo(m2[3], m2[2]), 0u, 0u);
+                    acc5[ct][tt] = cs_mma3(ah, al, bh, bl, acc5[ct][tt]);
+                    acc5[ct][tt] = cs_mma3(a2h, a2l, ch, cl, acc5[ct][tt]);
+                }
+            }
+            wave_sync();                                      // the next row rewrites E / DT
+        }
+    }
+
+    __syncthreads();                                          // every wave is done: LDS becomes reduction scratch
+    if (!APPLY) {
+        float* sc = reinterpret_cast<float*>(ldsb);           // [NW][2][48]
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[ct][r], v = s2[ct][r];
+#pragma unroll
+                for (int msk = 8; msk >= 1; msk >>= 1) { u += __shfl_xor(u, msk, 64); v += __shfl_xor(v, msk, 64); }
+                if (n == 0) { sc[(wv * 2 + 0) * 48 + 16 * ct + 4 * kg + r] = u; sc[(wv * 2 + 1) * 48 + 16 * ct + 4 * kg + r] = v; }
+            }
+        __syncthreads();
+        if (t < 2 * CS_C) {
+            const int which = t / CS_C, c = t % CS_C;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < CS_NW; ++k) s += (double)sc[(k * 2 + which) * 48 + c];
+            a.rows_out[(long long)b * 2 * CS_C + t] = s;
+        }
+    } else {
+        float* red = reinterpret_cast<float*>(ldsb);          // [NW][48][33]
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wv * 48 + 16 * ct + 4 * kg + r) * 33 + 16 * tt + n] = acc5[ct][tt][r];
+        __syncthreads();
+        for (int i = t; i < CS_C * CS_K1; i += CS_NT) {
+            const int c = i / CS_K1, tp = i % CS_K1;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < CS_NW; ++k) s += red[(k * 48 + c) * 33 + tp];
+            a.dw_partials[(long long)b * CS_C * CS_K1 + i] = s;
+        }
+    }
+}
+
+// dw25[i] += sum_b partials[b][i] in sample order: workgroup = 64 elements x 4 sample slices, the slices added in a fixed order
+__global__ __launch_bounds__(256) void cstack_rows_reduce_kernel(const float* __restrict__ partials, int nrows, int n, float* __restrict__ out) {
+    EEG_LDS_BASE(float, red);                                 // [4][64]
+    const int t = threadIdx.x, sg = t >> 6, e = t & 63;
+    const int i = blockIdx.x * 64 + e;
+    float s = 0.f;
+    if (i < n) {
+#pragma unroll 8
+        for (int k = sg; k < nrows; k += 4) s += partials[(long long)k * n + i];
+    }
+    red[sg * 64 + e] = s;
+    __syncthreads();
+    if (sg == 0 && i < n) out[i] += (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+}
+
+// ---- spatial-conv weight gradient -----------------------------------------------------------------------------------------------------------------------
+// workgroup (row block of 4 token rows, sample group g): wave v owns row h = 4 blockIdx.x + v and walks the samples g, g + G, ...
+//   y1^T tile D[w][c] = sum_t S[h][5 w + t] taps[c][t] (the operands of the forward's tap contraction swapped) -> z1^T = ELU(BN1(.)) in registers
+//   = the k = w operand (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); positions 32 .. 35 as a second, mostly empty k-step) of
+//   dWs[o][c] += sum_w dy2[b][o][w] z1[c][w]; the dy2 fragments (rows o, the same k slots) come from global memory, 16 bytes per quarter.
+// Slabs [G][H][48 o][48 c] (o, c padded: whole accumulator tiles, coalesced), summed over G in a fixed order by cstack_w2_reduce_kernel.
+constexpr int CSW_NW = 4;
+__global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
+                                                                    const float* __restrict__ bias1, const float* __restrict__ mean1,
+                                                                    const float* __restrict__ rstd1, const float* __restrict__ gamma1,
+                                                                    const float* __restrict__ beta1, const float* __restrict__ dy2, float* __restrict__ slabs,
+                                                                    int B, int H, int G, int vec2) {
+    EEG_LDS_BASE(unsigned char, ldsb);
+    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    unsigned* srow = reinterpret_cast<unsigned*>(ldsb) + wv * (CS_RS + 256);      // the wave's packed row + its prefix-sum scratch
+    float* pscr = reinterpret_cast<float*>(srow + CS_RS);
+    const int h = 4 * blockIdx.x + wv, g = blockIdx.y;
+    if (h >= H) return;                                       // (no workgroup barrier below: waves are independent)
+    for (int i = lane; i < 16; i += 64) srow[256 + i] = 0u;
+    bf16x8 wh[3], wl[3];
+    cs_tap_frags(w25, wh, wl);
+    float sc[3], sh[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const int c = 16 * ct + n;
+        sc[ct] = 0.f;
+        sh[ct] = 0.f;
+        if (c < CS_C) {
+            sc[ct] = gamma1[c] * rstd1[c];
+            sh[ct] = beta1[c] + (bias1[c] - mean1[c]) * sc[ct];
+        }
+    }
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[3][3];                                          // D[o = 16 ot + 4 kg + r][c = 16 ct + n]
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[ot][ct] = zero4;
+    float vx[4];
+    f32x4 vd[3][3];
+    auto load_sample = [&](int b) {
+        cs_load_row(vx, x + (long long)b * xs_b + (long long)h * xs_h, true, vec2 != 0);
+        const float* src = dy2 + (long long)b * CS_C * CS_W;
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+            const int o = 16 * ot + n;
+            const bool ok = o < CS_C;
+            const float* r = src + (ok ? o : 0) * CS_W;
+            vd[ot][0] = ok ? *reinterpret_cast<const f32x4*>(r + 4 * kg) : zero4;
+            vd[ot][1] = ok ? *reinterpret_cast<const f32x4*>(r + 16 + 4 * kg) : zero4;
+            vd[ot][2] = (ok && kg == 0) ? *reinterpret_cast<const f32x4*>(r + 32) : zero4;
+        }
+    };
+    if (g < B) load_sample(g);
+    for (int b = g; b < B; b += G) {
+        cs_box_row(srow, pscr, vx);
+        bf16x8 dh[3], dl[3];
+        u32x2_t eh[3], el[3];
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+            const float v8[8] = {vd[ot][0][0], vd[ot][0][1], vd[ot][0][2], vd[ot][0][3], vd[ot][1][0], vd[ot][1][1], vd[ot][1][2], vd[ot][1][3]};
+            cs_split8(v8, dh[ot], dl[ot]);
+            x3_split4(vd[ot][2][0], vd[ot][2][1], vd[ot][2][2], vd[ot][2][3], eh[ot], el[ot]);
+        }
+        if (b + G < B) load_sample(b + G);                    // the next sample's loads land under this sample's MFMAs
+        wave_sync();
+        float z[3][3][4];                                     // z1^T[w = 16 wt + 4 kg + r][c = 16 ct + n]
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt) {
+            bf16x8 xh, xl;
+            cs_sfrag(srow, 0, wt, xh, xl);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const f32x4 a1 = cs_mma3(xh, xl, wh[ct], wl[ct], zero4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = a1[r] * sc[ct] + sh[ct];
+                    const float ex = fast_exp(u < 0.f ? u : 0.f) - 1.0f;
+                    z[wt][ct][r] = u > 0.f ? u : ex;
+                }
+            }
+        }
+        wave_sync();                                          // the row is consumed: the next sample may overwrite it
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            bf16x8 zh, zl;
+            {
+                const float v8[8] = {z[0][ct][0], z[0][ct][1], z[0][ct][2], z[0][ct][3], z[1][ct][0], z[1][ct][1], z[1][ct][2], z[1][ct][3]};
+                cs_split8(v8, zh, zl);
+            }
+            u32x2_t th, tl;
+            x3_split4(z[2][ct][0], z[2][ct][1], z[2][ct][2], z[2][ct][3], th, tl);     // (positions >= 36: finite, and the dy2 operand is zero there)
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) {
+                acc[ot][ct] = cs_mma3(dh[ot], dl[ot], zh, zl, acc[ot][ct]);
+                acc[ot][ct] = cs_mma3(cs_half_frag(eh[ot]), cs_half_frag(el[ot]), cs_half_frag(th), cs_half_frag(tl), acc[ot][ct]);
+            }
+        }
+    }
+    float* out = slabs + ((long long)g * H + h) * 48 * 48;
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * ot + 4 * kg + r) * 48 + 16 * ct + n] = acc[ot][ct][r];
+}
+
+// dWs[o][c][h] += sum_g slabs[g][h][o][c], groups in order; one thread per (h, o, c): reads coalesced along c, the transposing store is 0.4 MB
+__global__ __launch_bounds__(256) void cstack_w2_reduce_kernel(const float* __restrict__ slabs, int G, int H, float* __restrict__ dWs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * CS_C * CS_C) return;
+    const int c = i % CS_C, o = (i / CS_C) % CS_C, h = i / (CS_C * CS_C);
+    float s = 0.f;
+#pragma unroll 4
+    for (int g = 0; g < G; ++g) s += slabs[(((long long)g * H + h) * 48 + o) * 48 + c];
+    dWs[((long long)o * CS_C + c) * H + h] += s;
+}
+
+}  // namespace eeg
+
+using namespace eeg;
+
+static int csb_vec2(const float* x, long long xs_b, long long xs_h) {
+    return ((reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (xs_b & 1) == 0 && (xs_h & 1) == 0) ? 1 : 0;
+}
+static int csw_groups(int B) { return B < 16 ? B : 16; }
+
+extern "C" long long eegclip_cstack_packed_t_bytes(int H) { return (H < 1 || H > CS_MAXH) ? 0 : (long long)H * CST_ROW; }
+
+extern "C" int eegclip_cstack_pack_t(const float* Ws, void* packed_t, int H, void* stream) {
+    if (!Ws || !packed_t || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(packed_t) & 15u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(cstack_pack_t_kernel, dim3((H * 192 + 255) / 256), dim3(256), 0, stream, Ws, static_cast<unsigned char*>(packed_t), H);
+    return (int)hipGetLastError();
+}
+
+static int csb_check(const eegclip_cstack_bwd_desc* d) {
+    if (!d || d->B < 1 || d->H < 1 || d->H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (!d->x || !d->w25 || !d->bias1 || !d->mean1 || !d->rstd1 || !d->gamma1 || !d->beta1 || !d->packed_t || !d->dy2) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d->packed_t) & 15u)) return EEGCLIP_EALIGN;
+    return 0;
+}
+static cs_bwd_args csb_args(const eegclip_cstack_bwd_desc* d) {
+    return cs_bwd_args{d->x, d->xs_b, d->xs_h, d->w25, d->bias1, d->mean1, d->rstd1, d->gamma1, d->beta1, static_cast<const unsigned char*>(d->packed_t), d->dy2,
+                       d->rows_out, d->stat, d->nstat, d->count, d->stat_local, d->nstat_local, d->dgamma, d->dbeta, d->dx, d->dw_partials, d->B, d->H,
+                       (csb_vec2(d->x, d->xs_b, d->xs_h) && (!d->dx || csb_vec2(d->dx, d->xs_b, d->xs_h))) ? 1 : 0};
+}
+
+extern "C" int eegclip_cstack_bwd_stats(const eegclip_cstack_bwd_desc* d, void* stream) {
+    if (int rc = csb_check(d)) return rc;
+    if (!d->rows_out) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d->rows_out) & 7u) return EEGCLIP_EALIGN;
+    const size_t lds = (size_t)d->H * CS_RS * 4 + CSB_NCOEF * 48 * 4 + CSB_DYF + CS_NW * 1024;
+    EEG_LAUNCH(cstack_bwd_kernel<false>, dim3(d->B), dim3(CS_NT), lds, stream, csb_args(d));
+    return (int)hipGetLastError();
+}
+
+extern "C" long long eegclip_cstack_bwd_workspace_floats(int B) { return B < 1 ? 0 : (long long)B * CS_C * CS_K1; }
+
+extern "C" int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* stream) {
+    if (int rc = csb_check(d)) return rc;
+    if (!d->stat || d->nstat < 1 || d->count < 1.0 || !d->dgamma || !d->dbeta || !d->dx || !d->dw_partials || !d->dw25) return EEGCLIP_EINVAL;
+    if (d->stat_local && d->nstat_local < 1) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d->stat) | reinterpret_cast<uintptr_t>(d->stat_local)) & 7u) return EEGCLIP_EALIGN;
+    const size_t lds = (size_t)d->H * CS_RS * 4 + CSB_NCOEF * 48 * 4 + CSB_DYF + CSB_TAPF + CS_NW * CSB_WAVE;
+    EEG_LAUNCH(cstack_bwd_kernel<true>, dim3(d->B), dim3(CS_NT), lds, stream, csb_args(d));
+    const int n = CS_C * CS_K1;
+    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((n + 63) / 64), dim3(256), 256 * sizeof(float), stream, (const float*)d->dw_partials, d->B, n, d->dw25);
+    return (int)hipGetLastError();
+}
+
+extern "C" long long eegclip_cstack_bwd_w2_workspace_floats(int B, int H) { return (B < 1 || H < 1 || H > CS_MAXH) ? 0 : (long long)csw_groups(B) * H * 48 * 48; }
+
+extern "C" int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias1, const float* mean1, const float* rstd1,
+                                     const float* gamma1, const float* beta1, const float* dy2, float* dWs, float* workspace, int B, int H, void* stream) {
+    if (!x || !w25 || !bias1 || !mean1 || !rstd1 || !gamma1 || !beta1 || !dy2 || !dWs || !workspace || B < 1 || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(dy2) & 15u) return EEGCLIP_EALIGN;
+    const int G = csw_groups(B);
+    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4;
+    EEG_LAUNCH(cstack_bwd_w2_kernel, dim3((H + 3) / 4, G), dim3(64 * CSW_NW), lds, stream, x, xs_b, xs_h, w25, bias1, mean1, rstd1, gamma1, beta1, dy2, workspace, B,
+               H, G, csb_vec2(x, xs_b, xs_h));
+    EEG_LAUNCH(cstack_w2_reduce_kernel, dim3((H * CS_C * CS_C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, G, H, dWs);
+    return (int)hipGetLastError();
+}

@@ -103,6 +103,16 @@ __device__ __forceinline__ void cs_tap_frags(const float* __restrict__ w25, bf16
     }
 }
 
+// an integer zero the compiler cannot see through: added to the address of loop-invariant LDS operands it keeps their loads INSIDE the loop (hoisted, the
+// per-sample fragments and coefficient rows of the backward kernels occupied ~90 VGPRs for the whole row loop and spilled)
+__device__ __forceinline__ int cs_opaque_zero() {
+    int z = 0;
+#if !defined(EEG_EMU)
+    asm volatile("" : "+s"(z));
+#endif
+    return z;
+}
+
 // inclusive prefix sum over the wave in DPP data movement: Hillis-Steele inside the four 16-lane rows (row_shr 1, 2, 4, 8), then the row totals
 // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- 6 VALU instructions; the __shfl_up form is 6 dependent ds_bpermute round trips
 __device__ __forceinline__ float cs_wave_scan(float v) {

@@ -645,6 +645,45 @@ int eegclip_cstack_pack(const float* Ws, void* packed, int H, void* stream);
 int eegclip_cstack_stats1(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias, double* rows, int B, int H, void* stream);
 int eegclip_cstack_fwd(const eegclip_cstack_fwd_desc* d, void* stream);
 
+/* backward of the same stack, given dy2 (B,40,36) = the gradient entering the spatial conv's output (16-byte aligned):
+ *   eegclip_cstack_pack_t     Ws -> Ws^T fragments for dz1 = Ws^T dy2 (eegclip_cstack_packed_t_bytes(H) bytes, 16-byte aligned); once per optimizer step
+ *   eegclip_cstack_bwd_stats  rows_out[b] = [sum da (40) | sum da * xhat (40)] (fp64) of sample b, da = dz1 * ELU'(BN1(y1))
+ *   eegclip_cstack_bwd_apply  dy1 = BatchNorm1-backward(da) with the sums of `nstat` partial rows `stat` (fixed summation order; nstat = 1: all-reduced
+ *                             sums; a zero row: eval-mode BatchNorm, no batch terms) and element count `count`; token-row gradients dx[b][h][0..249]
+ *                             (rows h < H overwritten, same strides as x), taps gradient dw25 += (per-sample partials in `dw_partials`,
+ *                             eegclip_cstack_bwd_workspace_floats(B) floats, summed in sample order), dgamma / dbeta += this rank's own sums
+ *                             (stat_local / nstat_local; NULL: stat)
+ *   eegclip_cstack_bwd_w2     dWs[o][c][h] += sum_{b,w} dy2[b][o][w] ELU(BN1(y1))[b][c][h][w]   (workspace: eegclip_cstack_bwd_w2_workspace_floats(B, H) floats;
+ *                             per-group slabs summed in a fixed order: bit-reproducible)
+ * mean1 / rstd1: the batch statistics eegclip_cstack_fwd stored. */
+typedef struct {
+    int B, H;
+    const float* x;
+    long long xs_b, xs_h;
+    const float *w25, *bias1;
+    const float *mean1, *rstd1, *gamma1, *beta1;
+    const void* packed_t;
+    const float* dy2;
+    double* rows_out;
+    const double* stat;
+    int nstat;
+    double count;
+    const double* stat_local;
+    int nstat_local;
+    float *dgamma, *dbeta;
+    float* dx;
+    float* dw_partials;
+    float* dw25;
+} eegclip_cstack_bwd_desc;
+long long eegclip_cstack_packed_t_bytes(int H);
+int eegclip_cstack_pack_t(const float* Ws, void* packed_t, int H, void* stream);
+int eegclip_cstack_bwd_stats(const eegclip_cstack_bwd_desc* d, void* stream);
+long long eegclip_cstack_bwd_workspace_floats(int B);
+int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* stream);
+long long eegclip_cstack_bwd_w2_workspace_floats(int B, int H);
+int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias1, const float* mean1, const float* rstd1,
+                          const float* gamma1, const float* beta1, const float* dy2, float* dWs, float* workspace, int B, int H, void* stream);
+
 /* ---- per-kernel timing by the kernel's own GPU timestamps (bench.py roofline): eegclip_time_next_launch(start, stop) arms a pair of
  * library-owned events for the FIRST kernel the calling thread's next entry point launches (hipExtLaunchKernel start / stop events: what
  * rocprofv3 reports, without the marker packets of an event bracket).  Read with eegclip_timing_elapsed_ms after synchronising. */

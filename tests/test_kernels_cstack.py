@@ -102,3 +102,63 @@ def test_cstack_forward(be, B, H):
     assert be.lib.eegclip_cstack_stats1(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS1), be.ptr(ROWS), B, 65, be.stream) < 0
     assert be.lib.eegclip_cstack_pack(None, be.ptr(PK), H, be.stream) < 0
     assert int(be.lib.eegclip_cstack_packed_bytes(0)) == 0
+
+
+@pytest.mark.parametrize("B,H", [(2, 63), (3, 5), (2, 64), (18, 7)])
+def test_cstack_backward(be, B, H):
+    """BatchNorm1-backward sums, the apply pass (token-row gradients, taps gradient, dgamma / dbeta) and the spatial-conv weight gradient, all recomputed
+    from the token rows, against autograd of the fp64 reference"""
+    p = _problem(B, H, 1000 + 11 * B + H)
+    t, y1t, y2t = _reference(p, B, H)
+    y2t.backward(t["dy2"])
+    y1 = y1t.detach().numpy()
+    mean_ref, var_ref = y1.mean((0, 2, 3)), y1.var((0, 2, 3))
+    X, W25, BIAS1, G1, B1, DY2, WS = (be.dev(p[k]) for k in ("x", "w25", "bias1", "g1", "b1", "dy2", "Ws"))
+    MU, RS = be.dev(mean_ref.astype(np.float32)), be.dev((1 / np.sqrt(var_ref + 1e-5)).astype(np.float32))
+    nt = int(be.lib.eegclip_cstack_packed_t_bytes(H))
+    assert nt == H * 9216
+    PT = be.dev(np.full(nt // 2, 0x7FC0, np.uint16))
+    ok(be.lib.eegclip_cstack_pack_t(be.ptr(WS), be.ptr(PT), H, be.stream))
+    ROWS = be.dev(np.full((B, 80), np.nan, np.float64))
+    DG, DB = be.dev(np.full(C, 0.25, np.float32)), be.dev(np.full(C, -0.25, np.float32))
+    DX = be.dev(np.full((B, 64, 250), 7.0, np.float32))
+    DWP = be.dev(np.full(int(be.lib.eegclip_cstack_bwd_workspace_floats(B)), np.nan, np.float32))
+    DW25 = be.dev(np.ones((C, 25), np.float32))
+    d = _abi.CstackBwdDesc(B=B, H=H, x=be.ptr(X), xs_b=64 * 250, xs_h=250, w25=be.ptr(W25), bias1=be.ptr(BIAS1), mean1=be.ptr(MU), rstd1=be.ptr(RS),
+                           gamma1=be.ptr(G1), beta1=be.ptr(B1), packed_t=be.ptr(PT), dy2=be.ptr(DY2), rows_out=be.ptr(ROWS), stat=be.ptr(ROWS), nstat=B,
+                           count=float(B * H * WD), stat_local=None, nstat_local=0, dgamma=be.ptr(DG), dbeta=be.ptr(DB), dx=be.ptr(DX),
+                           dw_partials=be.ptr(DWP), dw25=be.ptr(DW25))
+    ok(be.lib.eegclip_cstack_bwd_stats(ctypes.byref(d), be.stream))
+    rows = be.host(ROWS)
+    gb, gg = t["b1"].grad.numpy(), t["g1"].grad.numpy()
+    np.testing.assert_allclose(rows[:, :40].sum(0), gb, atol=2e-4 * max(1.0, np.abs(gb).max()))
+    np.testing.assert_allclose(rows[:, 40:].sum(0), gg, atol=2e-4 * max(1.0, np.abs(gg).max()))
+    ok(be.lib.eegclip_cstack_bwd_apply(ctypes.byref(d), be.stream))
+    dx, gx = be.host(DX), t["x"].grad.numpy()
+    np.testing.assert_array_equal(dx[:, H:], 7.0)                    # token rows past H are not touched
+    np.testing.assert_allclose(dx[:, :H], gx[:, :H], atol=3e-5 * max(1.0, float(np.abs(gx).max())))
+    gw = t["w25"].grad.numpy()
+    np.testing.assert_allclose(be.host(DW25) - 1.0, gw, atol=2e-4 * max(1.0, np.abs(gw).max()))
+    np.testing.assert_allclose(be.host(DB) + 0.25, gb, atol=2e-4 * max(1.0, np.abs(gb).max()))
+    np.testing.assert_allclose(be.host(DG) - 0.25, gg, atol=2e-4 * max(1.0, np.abs(gg).max()))
+    # data-parallel form: all-reduced sums as ONE row, dgamma / dbeta from the rank's own rows; eval-mode BatchNorm: a zero row drops the batch terms
+    ONE = be.dev(rows.sum(0, keepdims=True))
+    DG2, DB2, DX2 = be.zeros(C), be.zeros(C), be.dev(np.full((B, 64, 250), 7.0, np.float32))
+    d.stat, d.nstat, d.stat_local, d.nstat_local, d.dgamma, d.dbeta, d.dx = be.ptr(ONE), 1, be.ptr(ROWS), B, be.ptr(DG2), be.ptr(DB2), be.ptr(DX2)
+    ok(be.lib.eegclip_cstack_bwd_apply(ctypes.byref(d), be.stream))
+    np.testing.assert_allclose(be.host(DX2), dx, atol=1e-6)
+    np.testing.assert_allclose(be.host(DB2), gb, atol=2e-4 * max(1.0, np.abs(gb).max()))
+    np.testing.assert_allclose(be.host(DG2), gg, atol=2e-4 * max(1.0, np.abs(gg).max()))
+    # spatial-conv weight gradient
+    DWS = be.dev(np.ones((C, C, H), np.float32))
+    WSP = be.dev(np.full(int(be.lib.eegclip_cstack_bwd_w2_workspace_floats(B, H)), np.nan, np.float32))
+    ok(be.lib.eegclip_cstack_bwd_w2(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2),
+                                    be.ptr(DWS), be.ptr(WSP), B, H, be.stream))
+    gws = t["Ws"].grad.numpy()
+    np.testing.assert_allclose(be.host(DWS) - 1.0, gws, atol=1e-4 * max(1.0, np.abs(gws).max()))
+    # argument checks
+    d.packed_t = None
+    assert be.lib.eegclip_cstack_bwd_stats(ctypes.byref(d), be.stream) < 0
+    assert be.lib.eegclip_cstack_bwd_apply(ctypes.byref(d), be.stream) < 0
+    assert be.lib.eegclip_cstack_bwd_w2(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(DY2),
+                                        be.ptr(DWS), None, B, H, be.stream) < 0
