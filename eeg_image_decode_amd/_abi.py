@@ -77,8 +77,7 @@ class CstackFwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("x", C.c_void_p), ("xs_b", C.c_longlong), ("xs_h", C.c_longlong), ("w25", C.c_void_p), ("bias1", C.c_void_p),
                 ("stat1", C.c_void_p), ("nstat1", C.c_int), ("count1", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
                 ("gamma1", C.c_void_p), ("beta1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("run_mean1", C.c_void_p),
-                ("run_var1", C.c_void_p), ("nbt1", C.c_void_p), ("packed", C.c_void_p), ("bias2", C.c_void_p), ("y2", C.c_void_p), ("stat2", C.c_void_p),
-                ("y1", C.c_void_p)]
+                ("run_var1", C.c_void_p), ("nbt1", C.c_void_p), ("packed", C.c_void_p), ("bias2", C.c_void_p), ("y2", C.c_void_p), ("stat2", C.c_void_p)]
 
 
 class CstackBwdDesc(C.Structure):

@@ -661,9 +661,6 @@ class _Engine:
         if "cs_rows" not in b:
             b["cs_rows"] = torch.empty(2, B, 2 * C_TS, dtype=torch.float64, device=dev)          # BatchNorm1 | BatchNorm2 partial rows, one per sample
         rows1, rows2 = b["cs_rows"][0], b["cs_rows"][1]
-        keep_y1 = not self._cstack_bwd_enabled(pl)                 # the round-4 backward kernels still read y1
-        if keep_y1 and "y1" not in b:
-            b["y1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=dev)
         count1 = float(W * B * N_CH * W_TS)
         stat1, nstat1 = None, 0
         if train:
@@ -683,7 +680,7 @@ class _Engine:
             rstd1=_p(bn[1]), run_mean1=_p(self.buffers[_TS + "2.running_mean"]) if train else None,
             run_var1=_p(self.buffers[_TS + "2.running_var"]) if train else None,
             nbt1=_p(self.buffers[_TS + "2.num_batches_tracked"]) if train else None, packed=_p(self.cs_packed), bias2=_p(P[_TS + "4.bias"]),
-            y2=_p(b["y2"]), stat2=_p(rows2) if train else None, y1=_p(b["y1"]) if keep_y1 else None))
+            y2=_p(b["y2"]), stat2=_p(rows2) if train else None))
         count2 = float(W * B * W_TS)
         run2 = (_p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]))
         nbt2 = _p(self.buffers[_TS + "5.num_batches_tracked"])
@@ -696,9 +693,8 @@ class _Engine:
             pl.call("eegclip_bn_finalize", _p(sums[1]), count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, int(train), nbt2)
 
     def _cstack_bwd_enabled(self, pl):
-        """the conv-stack backward recomputed from the token rows too (csrc/cstack_bwd.hip); EEGCLIP_CSTACK_BWD=0 keeps the round-4 backward around y1
-        (the forward then still writes y1 for it)"""
-        return self._cstack_enabled(pl) and os.environ.get("EEGCLIP_CSTACK_BWD", "1") != "0"
+        """the conv-stack backward is recomputed from the token rows whenever the forward is (csrc/cstack_bwd.hip): y1 does not exist for anything else"""
+        return self._cstack_enabled(pl)
 
     def _build_fwd_conv_y1(self, pl, b, B, train, W):
         """A4+A5 around y1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""

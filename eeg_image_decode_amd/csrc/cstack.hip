@@ -54,35 +54,32 @@ __global__ __launch_bounds__(CS_NT) void cstack_stats1_kernel(const float* __res
     const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int b = blockIdx.x;
-    cs_stage_sample(S32, ps, x, xs_b, xs_h, b, H, vec2 != 0);
+    float vx[CS_RPW][4];
+    cs_stage_load<false>(vx, x, xs_b, xs_h, b, H, vec2 != 0);
     bf16x8 wh[3], wl[3];
-    cs_tap_frags(w25, wh, wl);
-    float bc[3][4], ss[3][4], sq[3][4];
+    cs_tap_frags_affine(w25, [&](int c, float& sc, float& sh) { sc = 1.f; sh = bias[c]; }, wh, wl);      // the conv bias rides in the ones slot
+    cs_stage_finish<false>(S32, ps + wv * 256, vx, H);          // (a wave works on the rows it staged: no workgroup barrier)
+    f32x2_t ss[3][2], sq[3][2];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + 4 * kg + r;
-            bc[ct][r] = c < CS_C ? bias[c] : 0.f;
-            ss[ct][r] = 0.f;
-            sq[ct][r] = 0.f;
-        }
-    __syncthreads();
+        for (int k = 0; k < 2; ++k) { ss[ct][k] = f32x2_t{0.f, 0.f}; sq[ct][k] = f32x2_t{0.f, 0.f}; }
     for (int h = wv; h < H; h += CS_NW) {
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             bf16x8 xh, xl;
-            cs_sfrag(S32, h, wt, xh, xl);
-            const bool wok = 16 * wt + n < CS_W;
+            cs_sfrag_ones(S32, h, wt, xh, xl);
+            const float wm = 16 * wt + n < CS_W ? 1.f : 0.f;                                               // (only the last tile has columns w >= 36)
+            f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            cs_mma3_a3(wh, wl, xh, xl, acc);                                                             // y1: D[c = 16 ct + 4 kg + r][w = 16 wt + n]
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
-                const f32x4 acc = cs_mma3(wh[ct], wl[ct], xh, xl, f32x4{0.f, 0.f, 0.f, 0.f});      // D[c = 16 ct + 4 kg + r][w = 16 wt + n]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = wok ? acc[r] + bc[ct][r] : 0.f;
-                    ss[ct][r] += v;
-                    sq[ct][r] += v * v;
-                }
+                f32x2_t v0 = cs_lo2(acc[ct]), v1 = cs_hi2(acc[ct]);
+                if (wt == 2) { v0 = v0 * f32x2_t{wm, wm}; v1 = v1 * f32x2_t{wm, wm}; }
+                ss[ct][0] += v0;
+                ss[ct][1] += v1;
+                sq[ct][0] = cs_fma2(v0, v0, sq[ct][0]);
+                sq[ct][1] = cs_fma2(v1, v1, sq[ct][1]);
             }
         }
     }
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(CS_NT) void cstack_stats1_kernel(const float* __res
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = ss[ct][r], q = sq[ct][r];
+            float a = ss[ct][r >> 1][r & 1], q = sq[ct][r >> 1][r & 1];
 #pragma unroll
             for (int msk = 8; msk >= 1; msk >>= 1) { a += __shfl_xor(a, msk, 64); q += __shfl_xor(q, msk, 64); }
             if (n == 0) { sc[(wv * 2 + 0) * 48 + 16 * ct + 4 * kg + r] = a; sc[(wv * 2 + 1) * 48 + 16 * ct + 4 * kg + r] = q; }
@@ -123,7 +120,6 @@ struct cs_fwd_args {
     const float* bias2;
     float* y2;                    // [B][40][36]
     double* stat2;                // [B][80] BatchNorm2 partial rows of y2 (NULL: none)
-    float* y1;                    // optional [B][40][H][36] (kernels that still read it)
     int B, H, vec2;
 };
 
@@ -143,12 +139,9 @@ __global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) 
     const int n = lane & 15, kg = lane >> 4;
     const int b = blockIdx.x, H = a.H;
     double* bnscr = reinterpret_cast<double*>(yt);                 // [6][80] partial sums of the BatchNorm1 rows (the y2 tile is written much later)
-    {
-        float vx[CS_RPW][4];
-        cs_stage_load(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
-        if (a.stat1) cs_bn_rows_partial(a.stat1, a.nstat1, bnscr);  // (under the row loads)
-        cs_stage_finish(S32, ps, vx, H);
-    }
+    float vx[CS_RPW][4];
+    cs_stage_load<true>(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
+    if (a.stat1) cs_bn_rows_partial(a.stat1, a.nstat1, bnscr);      // (under the row loads)
     __syncthreads();
     if (t < 48) {
         float sc = 0.f, sh = 0.f;
@@ -177,19 +170,11 @@ __global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) 
         aff[t] = sc;
         aff[48 + t] = sh;
     }
-    bf16x8 wh[3], wl[3];
-    cs_tap_frags(a.w25, wh, wl);
     __syncthreads();
-    float sc[3][4], sh[3][4], bc[3][4];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + 4 * kg + r;
-            sc[ct][r] = aff[c];
-            sh[ct][r] = aff[48 + c];
-            bc[ct][r] = (a.y1 && c < CS_C) ? a.bias1[c] : 0.f;
-        }
+    // taps scaled by gamma * rstd with the constant beta + (bias - mean) * gamma * rstd in the ones slot: the tap contraction yields u = BN1(y1) itself
+    bf16x8 wh[3], wl[3];
+    cs_tap_frags_affine(a.w25, [&](int c, float& sc, float& sh) { sc = aff[c]; sh = aff[48 + c]; }, wh, wl);
+    cs_stage_finish<true>(S32, ps + wv * 256, vx, H);               // (a wave works on the row pairs it staged: no workgroup barrier)
     f32x4 acc2[3][3];                                              // y2 partial D[o = 16 ot + 4 kg + r][w = 16 wt + n] over this wave's rows
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot)
@@ -216,27 +201,14 @@ __global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) 
 #pragma unroll
             for (int wt = 0; wt < 3; ++wt) {
                 bf16x8 xh, xl;
-                cs_sfrag(S32, h, wt, xh, xl);
+                cs_sfrag_ones(S32, h, wt, xh, xl);
                 float z[3][4];
+                f32x4 u[3] = {zero4, zero4, zero4};
+                cs_mma3_a3(wh, wl, xh, xl, u);                                        // u = BN1(y1):  D[c = 16 ct + 4 kg + r][w = 16 wt + n]
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
-                    const f32x4 acc = cs_mma3(wh[ct], wl[ct], xh, xl, zero4);       // D[c = 16 ct + 4 kg + r][w = 16 wt + n]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float u = acc[r] * sc[ct][r] + sh[ct][r];
-                        const float ex = fast_exp(u < 0.f ? u : 0.f) - 1.0f;
-                        z[ct][r] = u > 0.f ? u : ex;
-                    }
-                    if (a.y1) {
-                        const int w = 16 * wt + n;
-                        if (w < CS_W) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int c = 16 * ct + 4 * kg + r;
-                                if (c < CS_C) a.y1[(((long long)b * CS_C + c) * H + h) * CS_W + w] = acc[r] + bc[ct][r];
-                            }
-                        }
-                    }
+                    const f32x2_t z0 = cs_elu2(cs_lo2(u[ct])), z1 = cs_elu2(cs_hi2(u[ct]));
+                    z[ct][0] = z0[0]; z[ct][1] = z0[1]; z[ct][2] = z1[0]; z[ct][3] = z1[1];
                 }
                 bf16x8 zh, zl;
                 {
@@ -244,8 +216,11 @@ __global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) 
                     cs_split8(v8, zh, zl);
                 }
                 x3_split4(z[2][0], z[2][1], z[2][2], z[2][3], th[e][wt], tl[e][wt]);
-#pragma unroll
-                for (int ot = 0; ot < 3; ++ot) acc2[ot][wt] = cs_mma3(a2h[ot], a2l[ot], zh, zl, acc2[ot][wt]);
+                {
+                    f32x4 t3[3] = {acc2[0][wt], acc2[1][wt], acc2[2][wt]};
+                    cs_mma3_a3(a2h, a2l, zh, zl, t3);
+                    acc2[0][wt] = t3[0]; acc2[1][wt] = t3[1]; acc2[2][wt] = t3[2];
+                }
             }
         }
         {
@@ -259,8 +234,9 @@ __global__ __launch_bounds__(CS_NT) void cstack_fwd_kernel(const cs_fwd_args a) 
             for (int wt = 0; wt < 3; ++wt) {
                 const bf16x8 zh = cs_frag(th[0][wt][0], th[0][wt][1], th[1][wt][0], th[1][wt][1]);
                 const bf16x8 zl = cs_frag(tl[0][wt][0], tl[0][wt][1], tl[1][wt][0], tl[1][wt][1]);
-#pragma unroll
-                for (int ot = 0; ot < 3; ++ot) acc2[ot][wt] = cs_mma3(a2h[ot], a2l[ot], zh, zl, acc2[ot][wt]);
+                f32x4 t3[3] = {acc2[0][wt], acc2[1][wt], acc2[2][wt]};
+                cs_mma3_a3(a2h, a2l, zh, zl, t3);
+                acc2[0][wt] = t3[0]; acc2[1][wt] = t3[1]; acc2[2][wt] = t3[2];
             }
         }
     }
@@ -329,7 +305,7 @@ extern "C" int eegclip_cstack_fwd(const eegclip_cstack_fwd_desc* d, void* stream
     if ((reinterpret_cast<uintptr_t>(d->packed) & 15u) || (reinterpret_cast<uintptr_t>(d->stat1) & 7u) || (reinterpret_cast<uintptr_t>(d->stat2) & 7u))
         return EEGCLIP_EALIGN;
     const cs_fwd_args a{d->x, d->xs_b, d->xs_h, d->w25, d->bias1, d->stat1, d->nstat1, d->count1, d->eps, d->momentum, d->gamma1, d->beta1, d->mean1,
-                        d->rstd1, d->run_mean1, d->run_var1, d->nbt1, static_cast<const unsigned char*>(d->packed), d->bias2, d->y2, d->stat2, d->y1,
+                        d->rstd1, d->run_mean1, d->run_var1, d->nbt1, static_cast<const unsigned char*>(d->packed), d->bias2, d->y2, d->stat2,
                         d->B, d->H, cs_vec2(d->x, d->xs_b, d->xs_h)};
     EEG_LAUNCH(cstack_fwd_kernel, dim3(d->B), dim3(CS_NT), CSF_LDS, stream, a);
     return (int)hipGetLastError();

@@ -75,7 +75,7 @@ constexpr int CSB_DT_BYTES = CS_C * CS_W * 4;               // 5760: dy1 as pack
 constexpr int CSB_WAVE = CSB_E_BYTES + CSB_DT_BYTES;        // 9648
 constexpr int CSB_DYF = 3 * 3072;                           // dy2 fragment images (3 position tiles)
 constexpr int CSB_TAPF = 2 * 3072;                          // taps as the k = filter operand (2 tap tiles)
-constexpr int CSB_NCOEF = 7;                                // U1 U0 A1 A0 K M1 M2
+constexpr int CSB_NCOEF = 5;                                // gamma beta K -S1/n -S2/n
 
 template <bool APPLY>
 __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
     double* bnscr = reinterpret_cast<double*>(wreg);         // [6][80] (before the staging uses the region)
 
     float vx[CS_RPW][4];
-    cs_stage_load(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
+    cs_stage_load<false>(vx, a.x, a.xs_b, a.xs_h, b, H, a.vec2 != 0);
     if (APPLY) {
         cs_bn_rows_partial(a.stat, a.nstat, bnscr);
         if (b == 0 && a.stat_local) cs_bn_rows_partial(a.stat_local, a.nstat_local, bnscr + CS_BN_SLICES * 2 * CS_C);
@@ -144,20 +144,19 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
     }
     __syncthreads();                                          // bnscr complete
     if (t < 48) {
-        float U1 = 0.f, U0 = 0.f, A1 = 0.f, A0 = 0.f, K = 0.f, M1 = 0.f, M2 = 0.f;
+        // u = G * xhat + Bt;  dy1 = K * (da + NM1 + xhat * NM2)
+        float G = 0.f, Bt = 0.f, K = 0.f, NM1 = 0.f, NM2 = 0.f;
         if (t < CS_C) {
-            const float mean = a.mean1[t], rstd = a.rstd1[t], gam = a.gamma1[t], bet = a.beta1[t];
-            A1 = rstd;
-            A0 = (a.bias1[t] - mean) * rstd;                 // xhat = acc * A1 + A0   (acc = y1 - bias)
-            U1 = gam * rstd;
-            U0 = gam * A0 + bet;                             // u = gamma * xhat + beta
+            const float rstd = a.rstd1[t];
+            G = a.gamma1[t];
+            Bt = a.beta1[t];
             if (APPLY) {
                 double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int sl = 0; sl < CS_BN_SLICES; ++sl) { s1 += bnscr[sl * 2 * CS_C + t]; s2 += bnscr[sl * 2 * CS_C + CS_C + t]; }
-                K = gam * rstd;
-                M1 = (float)(s1 / a.count);
-                M2 = (float)(s2 / a.count);
+                K = G * rstd;
+                NM1 = -(float)(s1 / a.count);
+                NM2 = -(float)(s2 / a.count);
                 if (b == 0) {                                // BatchNorm1 parameter gradients from this rank's own sums (fixed summation order)
                     if (a.stat_local) {
                         s1 = 0.0;
@@ -171,22 +170,21 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                 }
             }
         }
-        coef[0 * 48 + t] = U1; coef[1 * 48 + t] = U0; coef[2 * 48 + t] = A1; coef[3 * 48 + t] = A0;
-        coef[4 * 48 + t] = K;  coef[5 * 48 + t] = M1; coef[6 * 48 + t] = M2;
+        coef[0 * 48 + t] = G; coef[1 * 48 + t] = Bt; coef[2 * 48 + t] = K; coef[3 * 48 + t] = NM1; coef[4 * 48 + t] = NM2;
     }
-    __syncthreads();                                          // bnscr consumed: the per-wave regions may be used
-    cs_stage_finish(S32, reinterpret_cast<float*>(wreg), vx, H);     // (scratch row of wave v = the first KB of ... a private KB per wave)
+    // taps scaled by rstd with (bias - mean) * rstd in the ones slot: the tap contraction yields xhat = (y1 - mean) * rstd itself
     bf16x8 wh[3], wl[3];
-    cs_tap_frags(a.w25, wh, wl);
-    __syncthreads();
+    cs_tap_frags_affine(a.w25, [&](int c, float& sc, float& sh) { sc = a.rstd1[c]; sh = (a.bias1[c] - a.mean1[c]) * sc; }, wh, wl);
+    __syncthreads();                                          // bnscr consumed (the per-wave regions may be used), coefficients + fragment images visible
+    cs_stage_finish<false>(S32, qscr, vx, H);                 // (a wave works on the rows it staged: no workgroup barrier)
 
     const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
-    float s1[3][4], s2[3][4];
+    f32x2_t s1[3][2], s2[3][2];
     f32x4 acc5[3][2];                                         // (APPLY) taps gradient D[c = 16 ct + 4 kg + r][t = 16 tt + n]
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+        for (int k = 0; k < 2; ++k) { s1[ct][k] = f32x2_t{0.f, 0.f}; s2[ct][k] = f32x2_t{0.f, 0.f}; }
         acc5[ct][0] = zero4;
         acc5[ct][1] = zero4;
     }
@@ -204,93 +202,106 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
         const unsigned char* tapf = tapf0 + oz;
         const float* coef = coef0 + oz;
         // Ws^T fragments of this row: straight from L2 (every workgroup reads the same rows)
-        bf16x8 th_[3], tl_[3];
-        u32x2_t uh_[3], ul_[3];
+        bf16x8 th_[3], tl_[3], uh_[3], ul_[3];
         {
             const unsigned char* base = a.packed_t + (long long)h * CST_ROW;
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 th_[ct] = *reinterpret_cast<const bf16x8*>(base + ct * CST_TILE + 16 * lane);
                 tl_[ct] = *reinterpret_cast<const bf16x8*>(base + ct * CST_TILE + 1024 + 16 * lane);
-                uh_[ct] = *reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2048 + 8 * lane);
-                ul_[ct] = *reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2560 + 8 * lane);
+                uh_[ct] = cs_half_frag(*reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2048 + 8 * lane));
+                ul_[ct] = cs_half_frag(*reinterpret_cast<const u32x2_t*>(base + ct * CST_TILE + 2560 + 8 * lane));
             }
         }
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
             bf16x8 xh, xl;
-            cs_sfrag(S32, h, wt, xh, xl);
+            cs_sfrag_ones(S32, h, wt, xh, xl);
             const bf16x8 dh = *reinterpret_cast<const bf16x8*>(dyf + wt * 3072 + 16 * lane);
             const bf16x8 dl = *reinterpret_cast<const bf16x8*>(dyf + wt * 3072 + 1024 + 16 * lane);
             const bf16x8 eh = cs_half_frag(*reinterpret_cast<const u32x2_t*>(dyf + wt * 3072 + 2048 + 8 * lane));
             const bf16x8 el = cs_half_frag(*reinterpret_cast<const u32x2_t*>(dyf + wt * 3072 + 2560 + 8 * lane));
-            const bool wok = 16 * wt + n < CS_W;
-            float dy1[3][4];
+            f32x4 xhat[3] = {zero4, zero4, zero4}, dz[3] = {zero4, zero4, zero4};
+            cs_mma3_a3(wh, wl, xh, xl, xhat);                 // xhat = (y1 - mean) * rstd:  D[c = 16 ct + 4 kg + r][w = 16 wt + n]
+            cs_mma3_a3(th_, tl_, dh, dl, dz);                 // dz1 = Ws^T dy2, out channels 0 .. 31
+            cs_mma3_a3(uh_, ul_, eh, el, dz);                 //                 out channels 32 .. 39   (exact zeros at w >= 36 and c >= 40: zero operands)
+            f32x2_t dy1[3][2];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
-                const f32x4 acc1 = cs_mma3(wh[ct], wl[ct], xh, xl, zero4);                               // y1 - bias:  D[c = 16 ct + 4 kg + r][w = 16 wt + n]
-                f32x4 acc3 = cs_mma3(th_[ct], tl_[ct], dh, dl, zero4);                                   // dz1 = Ws^T dy2, out channels 0 .. 31
-                acc3 = cs_mma3(cs_half_frag(uh_[ct]), cs_half_frag(ul_[ct]), eh, el, acc3);              //                 out channels 32 .. 39
-                if (APPLY) {
-                    const f32x4 U1 = *reinterpret_cast<const f32x4*>(coef + 0 * 48 + 16 * ct + 4 * kg), U0 = *reinterpret_cast<const f32x4*>(coef + 1 * 48 + 16 * ct + 4 * kg);
-                    const f32x4 A1 = *reinterpret_cast<const f32x4*>(coef + 2 * 48 + 16 * ct + 4 * kg), A0 = *reinterpret_cast<const f32x4*>(coef + 3 * 48 + 16 * ct + 4 * kg);
-                    const f32x4 K = *reinterpret_cast<const f32x4*>(coef + 4 * 48 + 16 * ct + 4 * kg), M1 = *reinterpret_cast<const f32x4*>(coef + 5 * 48 + 16 * ct + 4 * kg);
-                    const f32x4 M2 = *reinterpret_cast<const f32x4*>(coef + 6 * 48 + 16 * ct + 4 * kg);
+                const f32x4 G = *reinterpret_cast<const f32x4*>(coef + 0 * 48 + 16 * ct + 4 * kg), Bt = *reinterpret_cast<const f32x4*>(coef + 1 * 48 + 16 * ct + 4 * kg);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float u = acc1[r] * U1[r] + U0[r], xh_ = acc1[r] * A1[r] + A0[r];
-                        const float ex = fast_exp(u < 0.f ? u : 0.f);
-                        const float da = u > 0.f ? acc3[r] : acc3[r] * ex;
-                        dy1[ct][r] = wok ? K[r] * (da - M1[r] - xh_ * M2[r]) : 0.f;
-                    }
-                } else {
-                    const f32x4 U1 = *reinterpret_cast<const f32x4*>(coef + 0 * 48 + 16 * ct + 4 * kg), U0 = *reinterpret_cast<const f32x4*>(coef + 1 * 48 + 16 * ct + 4 * kg);
-                    const f32x4 A1 = *reinterpret_cast<const f32x4*>(coef + 2 * 48 + 16 * ct + 4 * kg), A0 = *reinterpret_cast<const f32x4*>(coef + 3 * 48 + 16 * ct + 4 * kg);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float u = acc1[r] * U1[r] + U0[r], xh_ = acc1[r] * A1[r] + A0[r];
-                        const float ex = fast_exp(u < 0.f ? u : 0.f);
-                        const float da = u > 0.f ? acc3[r] : acc3[r] * ex;                               // (exact zeros at w >= 36 and c >= 40: zero operands)
-                        s1[ct][r] += da;
-                        s2[ct][r] += da * xh_;
+                for (int k = 0; k < 2; ++k) {
+                    const f32x2_t xk = k ? cs_hi2(xhat[ct]) : cs_lo2(xhat[ct]), zk = k ? cs_hi2(dz[ct]) : cs_lo2(dz[ct]);
+                    const f32x2_t u = cs_fma2(xk, k ? cs_hi2(G) : cs_lo2(G), k ? cs_hi2(Bt) : cs_lo2(Bt));
+                    const f32x2_t da = zk * cs_elu_grad2(u);                           // da = dz1 * ELU'(u)
+                    if (APPLY) {
+                        const f32x4 K = *reinterpret_cast<const f32x4*>(coef + 2 * 48 + 16 * ct + 4 * kg), NM1 = *reinterpret_cast<const f32x4*>(coef + 3 * 48 + 16 * ct + 4 * kg);
+                        const f32x4 NM2 = *reinterpret_cast<const f32x4*>(coef + 4 * 48 + 16 * ct + 4 * kg);
+                        const f32x2_t tq = cs_fma2(xk, k ? cs_hi2(NM2) : cs_lo2(NM2), da) + (k ? cs_hi2(NM1) : cs_lo2(NM1));
+                        dy1[ct][k] = tq * (k ? cs_hi2(K) : cs_lo2(K));                 // dy1 = gamma * rstd * (da - S1 / n - xhat * S2 / n)
+                    } else {
+                        s1[ct][k] += da;
+                        s2[ct][k] = cs_fma2(da, xk, s2[ct][k]);
                     }
                 }
             }
             if (APPLY) {
-                // E[w][t] = sum_c dy1[c][w] taps[c][t]: the dy1 tiles are the A operand (row = position w = 16 wt + n, k slot j <-> c = 16 (j >> 2) + 4 kg + (j & 3))
-                bf16x8 ah, al;
-                {
-                    const float v8[8] = {dy1[0][0], dy1[0][1], dy1[0][2], dy1[0][3], dy1[1][0], dy1[1][1], dy1[1][2], dy1[1][3]};
-                    cs_split8(v8, ah, al);
+                if (wt == 2) {                                // positions >= 36 of the last tile: no gradient (their xhat is not a real position's)
+                    const float wm = 32 + n < CS_W ? 1.f : 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) { dy1[ct][0] = dy1[ct][0] * f32x2_t{wm, wm}; dy1[ct][1] = dy1[ct][1] * f32x2_t{wm, wm}; }
                 }
-                u32x2_t a2h, a2l;
-                x3_split4(dy1[2][0], dy1[2][1], dy1[2][2], dy1[2][3], a2h, a2l);
+                // split once: the halves are the A operand of E = dy1^T taps (row = position w = 16 wt + n, k slot j <-> c = 16 (j >> 2) + 4 kg + (j & 3)) AND, re-paired
+                // into (hi << 16) | lo words, the transposed tile DT[c][w] the taps gradient contracts over w from
+                u32x2_t sh_[3], sl_[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) x3_split4(dy1[ct][0][0], dy1[ct][0][1], dy1[ct][1][0], dy1[ct][1][1], sh_[ct], sl_[ct]);
+                const bf16x8 ah = cs_frag(sh_[0][0], sh_[0][1], sh_[1][0], sh_[1][1]), al = cs_frag(sl_[0][0], sl_[0][1], sl_[1][0], sl_[1][1]);
+                const bf16x8 a2h = cs_half_frag(sh_[2]), a2l = cs_half_frag(sl_[2]);
+                bf16x8 bh[2], bl[2], ch[2], cl[2];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 16 * lane);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 1024 + 16 * lane);
-                    const bf16x8 ch = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2048 + 8 * lane));
-                    const bf16x8 cl = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2560 + 8 * lane));
-                    f32x4 accE = cs_mma3(ah, al, bh, bl, zero4);
-                    accE = cs_mma3(cs_half_frag(a2h), cs_half_frag(a2l), ch, cl, accE);                  // D[w = 16 wt + 4 kg + r][t = 16 tt + n]
+                    bh[tt] = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 16 * lane);
+                    bl[tt] = *reinterpret_cast<const bf16x8*>(tapf + tt * 3072 + 1024 + 16 * lane);
+                    ch[tt] = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2048 + 8 * lane));
+                    cl[tt] = cs_half_frag(*reinterpret_cast<const u32x2_t*>(tapf + tt * 3072 + 2560 + 8 * lane));
+                }
+                f32x4 accE[2] = {zero4, zero4};               // D[w = 16 wt + 4 kg + r][t = 16 tt + n], product-major over the two tap tiles
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(ah, bl[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(a2h, cl[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(al, bh[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(a2l, ch[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(ah, bh[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) accE[tt] = mfma_bf16_16x16x32(a2h, ch[tt], accE[tt]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
                     const int tp = 16 * tt + n;
                     if (tp < CS_K1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int w = 16 * wt + 4 * kg + r;
-                            if (w < CS_W) Et[w * CSB_ES + tp] = accE[r];
+                            if (w < CS_W) Et[w * CSB_ES + tp] = accE[tt][r];
                         }
                     }
                 }
-                // dy1 as packed words DT[c][w] for the taps gradient (contraction over w needs the transposed tile)
-                if (wok) {
+                if (wt < 2 || 32 + n < CS_W) {
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int c = 16 * ct + 4 * kg + r;
-                            if (c < CS_C) DT[c * CS_W + 16 * wt + n] = cs_pack_word(dy1[ct][r]);
+                    for (int ct = 0; ct < 3; ++ct) {
+                        const int c0 = 16 * ct + 4 * kg;
+                        if (c0 < CS_C) {                      // (40 = 10 groups of 4 filters: a group is all in or all out)
+                            unsigned* d = DT + c0 * CS_W + 16 * wt + n;
+                            d[0 * CS_W] = cs_pair_lo(sh_[ct][0], sl_[ct][0]);       // (hi(r) << 16) | lo(r) of r = 0 .. 3
+                            d[1 * CS_W] = cs_pair_hi(sh_[ct][0], sl_[ct][0]);
+                            d[2 * CS_W] = cs_pair_lo(sh_[ct][1], sl_[ct][1]);
+                            d[3 * CS_W] = cs_pair_hi(sh_[ct][1], sl_[ct][1]);
                         }
+                    }
                 }
             }
         }
@@ -325,11 +336,10 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                     o[e] = (q4[e + 1] - lo) * (1.0f / CS_POOL);
                 }
                 float* xr = a.dx + (long long)b * a.xs_b + (long long)h * a.xs_h;
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
                 if (a.vec2) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
-                        if (4 * lane + 2 * hf < CS_T) *reinterpret_cast<f32x2*>(xr + 4 * lane + 2 * hf) = f32x2{o[2 * hf], o[2 * hf + 1]};
+                        if (4 * lane + 2 * hf < CS_T) *reinterpret_cast<f32x2_t*>(xr + 4 * lane + 2 * hf) = f32x2_t{o[2 * hf], o[2 * hf + 1]};
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -337,21 +347,23 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                 }
             }
             // taps gradient: dW1[c][t] += sum_w dy1[c][w] S[h][5 w + t];  A = DT rows (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); tail w = 32 + 4 kg + j, kg = 0)
+            bf16x8 bh[2], bl[2], ch[2], cl[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                bf16x8 bh, bl, ch, cl;
-                {
-                    const unsigned* sp = S32 + h * CS_RS + 16 * tt + n;
-                    unsigned w8[8];
+                const unsigned* sp = S32 + h * CS_RS + 16 * tt + n;
+                unsigned w8[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) w8[j] = sp[5 * (16 * (j >> 2) + 4 * kg + (j & 3))];
-                    cs_words_to_frags(w8, bh, bl);
-                    unsigned w4[4];
+                for (int j = 0; j < 8; ++j) w8[j] = sp[5 * (16 * (j >> 2) + 4 * kg + (j & 3))];
+                cs_words_to_frags(w8, bh[tt], bl[tt]);
+                unsigned w4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w4[j] = sp[5 * (32 + 4 * kg + j)];
-                    ch = cs_frag(cs_pair_hi(w4[1], w4[0]), cs_pair_hi(w4[3], w4[2]), 0u, 0u);
-                    cl = cs_frag(cs_pair_lo(w4[1], w4[0]), cs_pair_lo(w4[3], w4[2]), 0u, 0u);
-                }
+                for (int j = 0; j < 4; ++j) w4[j] = sp[5 * (32 + 4 * kg + j)];
+                ch[tt] = cs_frag(cs_pair_hi(w4[1], w4[0]), cs_pair_hi(w4[3], w4[2]), 0u, 0u);
+                cl[tt] = cs_frag(cs_pair_lo(w4[1], w4[0]), cs_pair_lo(w4[3], w4[2]), 0u, 0u);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                bf16x8 ah[3], al[3], a2h[3], a2l[3];
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
                     const int c = 16 * ct + n < CS_C ? 16 * ct + n : CS_C - 1;          // (filters >= 40: discarded output rows)
@@ -360,13 +372,14 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                     u32x4_t m2 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 32);
                     if (kg != 0) m2 = u32x4_t{0u, 0u, 0u, 0u};                            // positions >= 36
                     const unsigned w8[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-                    bf16x8 ah, al;
-                    cs_words_to_frags(w8, ah, al);
-                    const bf16x8 a2h = cs_frag(cs_pair_hi(m2[1], m2[0]), cs_pair_hi(m2[3], m2[2]), 0u, 0u);
-                    const bf16x8 a2l = cs_frag(cs_pair_lo(m2[1], m2[0]), cs_pair_lo(m2[3], m2[2]), 0u, 0u);
-                    acc5[ct][tt] = cs_mma3(ah, al, bh, bl, acc5[ct][tt]);
-                    acc5[ct][tt] = cs_mma3(a2h, a2l, ch, cl, acc5[ct][tt]);
+                    cs_words_to_frags(w8, ah[ct], al[ct]);
+                    a2h[ct] = cs_frag(cs_pair_hi(m2[1], m2[0]), cs_pair_hi(m2[3], m2[2]), 0u, 0u);
+                    a2l[ct] = cs_frag(cs_pair_lo(m2[1], m2[0]), cs_pair_lo(m2[3], m2[2]), 0u, 0u);
                 }
+                f32x4 t3[3] = {acc5[0][tt], acc5[1][tt], acc5[2][tt]};
+                cs_mma3_a3(ah, al, bh[tt], bl[tt], t3);
+                cs_mma3_a3(a2h, a2l, ch[tt], cl[tt], t3);
+                acc5[0][tt] = t3[0]; acc5[1][tt] = t3[1]; acc5[2][tt] = t3[2];
             }
             wave_sync();                                      // the next row rewrites E / DT
         }
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float u = s1[ct][r], v = s2[ct][r];
+                float u = s1[ct][r >> 1][r & 1], v = s2[ct][r >> 1][r & 1];
 #pragma unroll
                 for (int msk = 8; msk >= 1; msk >>= 1) { u += __shfl_xor(u, msk, 64); v += __shfl_xor(v, msk, 64); }
                 if (n == 0) { sc[(wv * 2 + 0) * 48 + 16 * ct + 4 * kg + r] = u; sc[(wv * 2 + 1) * 48 + 16 * ct + 4 * kg + r] = v; }
@@ -428,11 +441,13 @@ __global__ __launch_bounds__(256) void cstack_rows_reduce_kernel(const float* __
 
 // ---- spatial-conv weight gradient -----------------------------------------------------------------------------------------------------------------------
 // workgroup (row block of 4 token rows, sample group g): wave v owns row h = 4 blockIdx.x + v and walks the samples g, g + G, ...
-//   y1^T tile D[w][c] = sum_t S[h][5 w + t] taps[c][t] (the operands of the forward's tap contraction swapped) -> z1^T = ELU(BN1(.)) in registers
-//   = the k = w operand (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); positions 32 .. 35 as a second, mostly empty k-step) of
-//   dWs[o][c] += sum_w dy2[b][o][w] z1[c][w]; the dy2 fragments (rows o, the same k slots) come from global memory, 16 bytes per quarter.
-// Slabs [G][H][48 o][48 c] (o, c padded: whole accumulator tiles, coalesced), summed over G in a fixed order by cstack_w2_reduce_kernel.
+//   u^T tile D[w][c] = BN1(y1)^T: the operands of the forward's tap contraction swapped (taps scaled by gamma * rstd, the BatchNorm constant in the ones
+//   slot) -> z1^T = ELU(.) in registers = the k = w operand (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); positions 32 .. 35 as a second, mostly empty
+//   k-step) of dWs[o][c] += sum_w dy2[b][o][w] z1[c][w]; the dy2 fragments (rows o, the same k slots) come from global memory, 16 bytes per quarter.
+// The four rows of a workgroup meet in LDS and leave as slab[g][o][c][h .. h + 3] (the layout of dWs): the slabs are then summed over g by a plain,
+// fully coalesced ordered reduction (the first version wrote [g][h][o][c] and transposed in the reduction: 48 us of 4-byte scattered read-modify-writes).
 constexpr int CSW_NW = 4;
+constexpr int CSW_TLD = 41;                                    // LDS tile [40 o][41]
 __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
                                                                     const float* __restrict__ bias1, const float* __restrict__ mean1,
                                                                     const float* __restrict__ rstd1, const float* __restrict__ gamma1,
@@ -443,107 +458,91 @@ __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float*
     const int n = lane & 15, kg = lane >> 4;
     unsigned* srow = reinterpret_cast<unsigned*>(ldsb) + wv * (CS_RS + 256);      // the wave's packed row + its prefix-sum scratch
     float* pscr = reinterpret_cast<float*>(srow + CS_RS);
+    float* tile = reinterpret_cast<float*>(ldsb) + CSW_NW * (CS_RS + 256);       // [4 rows][40 o][41]: the workgroup's result before it leaves
     const int h = 4 * blockIdx.x + wv, g = blockIdx.y;
-    if (h >= H) return;                                       // (no workgroup barrier below: waves are independent)
-    for (int i = lane; i < 16; i += 64) srow[256 + i] = 0u;
-    bf16x8 wh[3], wl[3];
-    cs_tap_frags(w25, wh, wl);
-    float sc[3], sh[3];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
-        const int c = 16 * ct + n;
-        sc[ct] = 0.f;
-        sh[ct] = 0.f;
-        if (c < CS_C) {
-            sc[ct] = gamma1[c] * rstd1[c];
-            sh[ct] = beta1[c] + (bias1[c] - mean1[c]) * sc[ct];
-        }
-    }
+    const bool active = h < H;                                 // (a last row block may be short; idle waves still meet the barrier)
     const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[3][3];                                          // D[o = 16 ot + 4 kg + r][c = 16 ct + n]
 #pragma unroll
     for (int ot = 0; ot < 3; ++ot)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) acc[ot][ct] = zero4;
-    float vx[4];
-    f32x4 vd[3][3];
-    auto load_sample = [&](int b) {
-        cs_load_row(vx, x + (long long)b * xs_b + (long long)h * xs_h, true, vec2 != 0);
-        const float* src = dy2 + (long long)b * CS_C * CS_W;
-#pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
-            const int o = 16 * ot + n;
-            const bool ok = o < CS_C;
-            const float* r = src + (ok ? o : 0) * CS_W;
-            vd[ot][0] = ok ? *reinterpret_cast<const f32x4*>(r + 4 * kg) : zero4;
-            vd[ot][1] = ok ? *reinterpret_cast<const f32x4*>(r + 16 + 4 * kg) : zero4;
-            vd[ot][2] = (ok && kg == 0) ? *reinterpret_cast<const f32x4*>(r + 32) : zero4;
-        }
-    };
-    if (g < B) load_sample(g);
-    for (int b = g; b < B; b += G) {
-        cs_box_row(srow, pscr, vx);
-        bf16x8 dh[3], dl[3];
-        u32x2_t eh[3], el[3];
-#pragma unroll
-        for (int ot = 0; ot < 3; ++ot) {
-            const float v8[8] = {vd[ot][0][0], vd[ot][0][1], vd[ot][0][2], vd[ot][0][3], vd[ot][1][0], vd[ot][1][1], vd[ot][1][2], vd[ot][1][3]};
-            cs_split8(v8, dh[ot], dl[ot]);
-            x3_split4(vd[ot][2][0], vd[ot][2][1], vd[ot][2][2], vd[ot][2][3], eh[ot], el[ot]);
-        }
-        if (b + G < B) load_sample(b + G);                    // the next sample's loads land under this sample's MFMAs
-        wave_sync();
-        float z[3][3][4];                                     // z1^T[w = 16 wt + 4 kg + r][c = 16 ct + n]
-#pragma unroll
-        for (int wt = 0; wt < 3; ++wt) {
-            bf16x8 xh, xl;
-            cs_sfrag(srow, 0, wt, xh, xl);
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                const f32x4 a1 = cs_mma3(xh, xl, wh[ct], wl[ct], zero4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = a1[r] * sc[ct] + sh[ct];
-                    const float ex = fast_exp(u < 0.f ? u : 0.f) - 1.0f;
-                    z[wt][ct][r] = u > 0.f ? u : ex;
-                }
-            }
-        }
-        wave_sync();                                          // the row is consumed: the next sample may overwrite it
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-            bf16x8 zh, zl;
-            {
-                const float v8[8] = {z[0][ct][0], z[0][ct][1], z[0][ct][2], z[0][ct][3], z[1][ct][0], z[1][ct][1], z[1][ct][2], z[1][ct][3]};
-                cs_split8(v8, zh, zl);
-            }
-            u32x2_t th, tl;
-            x3_split4(z[2][ct][0], z[2][ct][1], z[2][ct][2], z[2][ct][3], th, tl);     // (positions >= 36: finite, and the dy2 operand is zero there)
+    if (active) {
+        bf16x8 wh[3], wl[3];
+        cs_tap_frags_affine(w25, [&](int c, float& sc, float& sh) { sc = gamma1[c] * rstd1[c]; sh = beta1[c] + (bias1[c] - mean1[c]) * sc; }, wh, wl);
+        float vx[4];
+        f32x4 vd[3][3];
+        auto load_sample = [&](int b) {
+            cs_load_row(vx, x + (long long)b * xs_b + (long long)h * xs_h, true, vec2 != 0);
+            const float* src = dy2 + (long long)b * CS_C * CS_W;
 #pragma unroll
             for (int ot = 0; ot < 3; ++ot) {
-                acc[ot][ct] = cs_mma3(dh[ot], dl[ot], zh, zl, acc[ot][ct]);
-                acc[ot][ct] = cs_mma3(cs_half_frag(eh[ot]), cs_half_frag(el[ot]), cs_half_frag(th), cs_half_frag(tl), acc[ot][ct]);
+                const int o = 16 * ot + n;
+                const bool ok = o < CS_C;
+                const float* r = src + (ok ? o : 0) * CS_W;
+                vd[ot][0] = ok ? *reinterpret_cast<const f32x4*>(r + 4 * kg) : zero4;
+                vd[ot][1] = ok ? *reinterpret_cast<const f32x4*>(r + 16 + 4 * kg) : zero4;
+                vd[ot][2] = (ok && kg == 0) ? *reinterpret_cast<const f32x4*>(r + 32) : zero4;
+            }
+        };
+        if (g < B) load_sample(g);
+        for (int b = g; b < B; b += G) {
+            cs_box_row(srow, pscr, vx);
+            bf16x8 dh[3], dl[3], eh[3], el[3];
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) {
+                const float v8[8] = {vd[ot][0][0], vd[ot][0][1], vd[ot][0][2], vd[ot][0][3], vd[ot][1][0], vd[ot][1][1], vd[ot][1][2], vd[ot][1][3]};
+                cs_split8(v8, dh[ot], dl[ot]);
+                u32x2_t a_, b_;
+                x3_split4(vd[ot][2][0], vd[ot][2][1], vd[ot][2][2], vd[ot][2][3], a_, b_);
+                eh[ot] = cs_half_frag(a_);
+                el[ot] = cs_half_frag(b_);
+            }
+            if (b + G < B) load_sample(b + G);                // the next sample's loads land under this sample's MFMAs
+            wave_sync();
+            f32x2_t z[3][3][2];                               // z1^T[w = 16 wt + 4 kg + r][c = 16 ct + n]
+#pragma unroll
+            for (int wt = 0; wt < 3; ++wt) {
+                bf16x8 xh, xl;
+                cs_sfrag_ones(srow, 0, wt, xh, xl);
+                f32x4 u[3] = {zero4, zero4, zero4};
+                cs_mma3_b3(xh, xl, wh, wl, u);                // u^T = BN1(y1)^T
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) { z[wt][ct][0] = cs_elu2(cs_lo2(u[ct])); z[wt][ct][1] = cs_elu2(cs_hi2(u[ct])); }
+            }
+            wave_sync();                                      // the row is consumed: the next sample may overwrite it
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                bf16x8 zh, zl;
+                {
+                    const float v8[8] = {z[0][ct][0][0], z[0][ct][0][1], z[0][ct][1][0], z[0][ct][1][1], z[1][ct][0][0], z[1][ct][0][1], z[1][ct][1][0], z[1][ct][1][1]};
+                    cs_split8(v8, zh, zl);
+                }
+                u32x2_t th, tl;
+                x3_split4(z[2][ct][0][0], z[2][ct][0][1], z[2][ct][1][0], z[2][ct][1][1], th, tl);     // (positions >= 36: finite, and the dy2 operand is zero there)
+                f32x4 t3[3] = {acc[0][ct], acc[1][ct], acc[2][ct]};
+                cs_mma3_a3(dh, dl, zh, zl, t3);
+                cs_mma3_a3(eh, el, cs_half_frag(th), cs_half_frag(tl), t3);
+                acc[0][ct] = t3[0]; acc[1][ct] = t3[1]; acc[2][ct] = t3[2];
             }
         }
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * ot + 4 * kg + r, c = 16 * ct + n;
+                    if (o < CS_C && c < CS_C) tile[(wv * CS_C + o) * CSW_TLD + c] = acc[ot][ct][r];
+                }
     }
-    float* out = slabs + ((long long)g * H + h) * 48 * 48;
-#pragma unroll
-    for (int ot = 0; ot < 3; ++ot)
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * ot + 4 * kg + r) * 48 + 16 * ct + n] = acc[ot][ct][r];
-}
-
-// dWs[o][c][h] += sum_g slabs[g][h][o][c], groups in order; one thread per (h, o, c): reads coalesced along c, the transposing store is 0.4 MB
-__global__ __launch_bounds__(256) void cstack_w2_reduce_kernel(const float* __restrict__ slabs, int G, int H, float* __restrict__ dWs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * CS_C * CS_C) return;
-    const int c = i % CS_C, o = (i / CS_C) % CS_C, h = i / (CS_C * CS_C);
-    float s = 0.f;
-#pragma unroll 4
-    for (int g = 0; g < G; ++g) s += slabs[(((long long)g * H + h) * 48 + o) * 48 + c];
-    dWs[((long long)o * CS_C + c) * H + h] += s;
+    __syncthreads();
+    const int h0 = 4 * blockIdx.x, nh = H - h0 < 4 ? H - h0 : 4;
+    float* out = slabs + (long long)g * CS_C * CS_C * H;
+    for (int i = t; i < CS_C * CS_C; i += 64 * CSW_NW) {       // (o, c) -> 4 consecutive h of slab[g][o][c][.]
+        const int o = i / CS_C, c = i % CS_C;
+        for (int k = 0; k < nh; ++k) out[(long long)i * H + h0 + k] = tile[(k * CS_C + o) * CSW_TLD + c];
+    }
 }
 
 }  // namespace eeg
@@ -599,16 +598,17 @@ extern "C" int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* 
     return (int)hipGetLastError();
 }
 
-extern "C" long long eegclip_cstack_bwd_w2_workspace_floats(int B, int H) { return (B < 1 || H < 1 || H > CS_MAXH) ? 0 : (long long)csw_groups(B) * H * 48 * 48; }
+extern "C" long long eegclip_cstack_bwd_w2_workspace_floats(int B, int H) { return (B < 1 || H < 1 || H > CS_MAXH) ? 0 : (long long)csw_groups(B) * H * CS_C * CS_C; }
 
 extern "C" int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias1, const float* mean1, const float* rstd1,
                                      const float* gamma1, const float* beta1, const float* dy2, float* dWs, float* workspace, int B, int H, void* stream) {
     if (!x || !w25 || !bias1 || !mean1 || !rstd1 || !gamma1 || !beta1 || !dy2 || !dWs || !workspace || B < 1 || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(dy2) & 15u) return EEGCLIP_EALIGN;
     const int G = csw_groups(B);
-    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4;
+    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4 + (size_t)CSW_NW * CS_C * CSW_TLD * 4;
     EEG_LAUNCH(cstack_bwd_w2_kernel, dim3((H + 3) / 4, G), dim3(64 * CSW_NW), lds, stream, x, xs_b, xs_h, w25, bias1, mean1, rstd1, gamma1, beta1, dy2, workspace, B,
                H, G, csb_vec2(x, xs_b, xs_h));
-    EEG_LAUNCH(cstack_w2_reduce_kernel, dim3((H * CS_C * CS_C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, G, H, dWs);
+    const int nw = CS_C * CS_C * H;
+    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((nw + 63) / 64), dim3(256), 256 * sizeof(float), stream, (const float*)workspace, G, nw, dWs);
     return (int)hipGetLastError();
 }

@@ -86,22 +86,110 @@ __device__ __forceinline__ f32x4 cs_mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8
     acc = mfma_bf16_16x16x32(al, bh, acc);
     return mfma_bf16_16x16x32(ah, bh, acc);
 }
+// the same for three tiles that share one operand, PRODUCT-major: the three MFMAs that follow one another write different accumulators, so none of
+// them waits for its predecessor's result (a dependent MFMA issued back to back stalls the wave for the pipe latency: SQ_WAIT_INST_ANY was 28 % of the
+// wave cycles of the first version of these kernels, whose order was tile-major)
+__device__ __forceinline__ void cs_mma3_a3(const bf16x8 (&ah)[3], const bf16x8 (&al)[3], bf16x8 bh, bf16x8 bl, f32x4 (&acc)[3]) {      // three A tiles, one B
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah[i], bl, acc[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(al[i], bh, acc[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah[i], bh, acc[i]);
+}
+__device__ __forceinline__ void cs_mma3_b3(bf16x8 ah, bf16x8 al, const bf16x8 (&bh)[3], const bf16x8 (&bl)[3], f32x4 (&acc)[3]) {      // one A, three B tiles
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah, bl[i], acc[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(al, bh[i], acc[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah, bh[i], acc[i]);
+}
+// max(x, 0) / min(x, 0) as ONE instruction (fmaxf / fminf compile to a canonicalising v_max x, x, x first)
+__device__ __forceinline__ float cs_max0(float x) {
+#if defined(EEG_EMU)
+    return x > 0.f ? x : 0.f;
+#else
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+#endif
+}
+__device__ __forceinline__ float cs_min0(float x) {
+#if defined(EEG_EMU)
+    return x < 0.f ? x : 0.f;
+#else
+    float r;
+    asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+#endif
+}
 
-// the taps as the filter-side operand: lane (n, kg), tile ct <- w25[16 ct + n][8 kg + i] (zero past 40 filters / 25 taps)
-__device__ __forceinline__ void cs_tap_frags(const float* __restrict__ w25, bf16x8 (&wh)[3], bf16x8 (&wl)[3]) {
+// the taps as the filter-side operand: lane (n, kg), tile ct <- scale[c] * w25[c = 16 ct + n][t = 8 kg + i] (zero past 40 filters / 25 taps), and in the
+// otherwise unused k slot t = 25 the per-filter constant shift[c]: against an activation operand whose slot 25 is 1.0 (cs_sfrag_ones) the contraction
+// yields  scale[c] * (conv)[c][w] + shift[c]  -- a BatchNorm affine (or the conv bias) costs no vector instruction in the epilogue.
+constexpr int CS_ONE_SLOT = 25;
+template <class F>
+__device__ __forceinline__ void cs_tap_frags_affine(const float* __restrict__ w25, F&& scale_shift, bf16x8 (&wh)[3], bf16x8 (&wl)[3]) {
     const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const int c = 16 * ct + n;
+        float sc = 0.f, sh = 0.f;
+        if (c < CS_C) scale_shift(c, sc, sh);
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = 8 * kg + i;
-            v[i] = (c < CS_C && t < CS_K1) ? w25[c * CS_K1 + t] : 0.f;
+            v[i] = (c < CS_C && t < CS_K1) ? sc * w25[c * CS_K1 + t] : (t == CS_ONE_SLOT ? sh : 0.f);
         }
         cs_split8(v, wh[ct], wl[ct]);
     }
 }
+__device__ __forceinline__ void cs_tap_frags(const float* __restrict__ w25, bf16x8 (&wh)[3], bf16x8 (&wl)[3]) {
+    cs_tap_frags_affine(w25, [](int, float& sc, float& sh) { sc = 1.f; sh = 0.f; }, wh, wl);
+}
+// cs_sfrag with k slot 25 (lane group 3, word 1) replaced by 1.0: the partner of cs_tap_frags_affine's shift slot
+__device__ __forceinline__ void cs_sfrag_ones(const unsigned* __restrict__ S32, int h, int wt, bf16x8& hi, bf16x8& lo) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + 8 * kg;
+    unsigned w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = p[i];
+    const unsigned keep = kg == 3 ? 0x0000ffffu : 0xffffffffu, one = kg == 3 ? 0x3f800000u : 0u;     // bf16(1.0) = 0x3f80 in the upper half of dword 0
+    hi = cs_frag((cs_pair_hi(w[1], w[0]) & keep) | one, cs_pair_hi(w[3], w[2]), cs_pair_hi(w[5], w[4]), cs_pair_hi(w[7], w[6]));
+    lo = cs_frag(cs_pair_lo(w[1], w[0]) & keep, cs_pair_lo(w[3], w[2]), cs_pair_lo(w[5], w[4]), cs_pair_lo(w[7], w[6]));
+}
+
+// ---- packed fp32 helpers: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two elements per issue slot (the elementwise epilogues of this family are
+// bound by vector-instruction issue, ~4 cycles per wave instruction) ----
+__device__ __forceinline__ f32x2_t cs_fma2(f32x2_t a, f32x2_t b, f32x2_t c) {
+#if defined(EEG_EMU)
+    return f32x2_t{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ float cs_exp2(float x) {
+#if defined(EEG_EMU)
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+constexpr float CS_LOG2E = 1.4426950408889634f;
+// ELU'(u) = exp(min(u, 0)) for two elements: 1 for u >= 0
+__device__ __forceinline__ f32x2_t cs_elu_grad2(f32x2_t u) {
+    const f32x2_t m = u * f32x2_t{CS_LOG2E, CS_LOG2E};
+    return f32x2_t{cs_exp2(cs_min0(m[0])), cs_exp2(cs_min0(m[1]))};
+}
+// ELU(u) = max(u, 0) + (exp(min(u, 0)) - 1) for two elements (exact u for u > 0; absolute error <= 2e-7 otherwise, cf. elu1_fast)
+__device__ __forceinline__ f32x2_t cs_elu2(f32x2_t u) {
+    const f32x2_t e = cs_elu_grad2(u);
+    return (e + f32x2_t{-1.f, -1.f}) + f32x2_t{cs_max0(u[0]), cs_max0(u[1])};
+}
+__device__ __forceinline__ f32x2_t cs_lo2(f32x4 v) { return f32x2_t{v[0], v[1]}; }
+__device__ __forceinline__ f32x2_t cs_hi2(f32x4 v) { return f32x2_t{v[2], v[3]}; }
 
 // an integer zero the compiler cannot see through: added to the address of loop-invariant LDS operands it keeps their loads INSIDE the loop (hoisted, the
 // per-sample fragments and coefficient rows of the backward kernels occupied ~90 VGPRs for the whole row loop and spilled)
@@ -161,7 +249,7 @@ __device__ __forceinline__ void cs_load_row(float (&v)[4], const float* __restri
     }
 }
 
-// one wave: token row (lane l holds samples 4l .. 4l+3) -> its packed box-filtered row [256 words] (zeros from j = 200); pscr = the wave's 256-float
+// one wave: token row (lane l holds samples 4l .. 4l+3) -> its packed box-filtered row [272 words] (zeros from j = 200); pscr = the wave's 256-float
 // scratch row for the exclusive prefix sums P[i] = sum_{k<i} x[k]:  S[j] = (P[j + 51] - P[j]) / 51
 __device__ __forceinline__ void cs_box_row(unsigned* __restrict__ srow, float* __restrict__ pscr, const float (&v)[4]) {
     const int lane = threadIdx.x & 63;
@@ -178,33 +266,33 @@ __device__ __forceinline__ void cs_box_row(unsigned* __restrict__ srow, float* _
     }
     wave_sync();
     *reinterpret_cast<u32x4_t*>(srow + 4 * lane) = S;
+    if (lane < 16) srow[256 + lane] = 0u;                      // words 256 .. 271: read by the padded tiles only, must be finite
 }
 
-// the H token rows of sample b -> S32[h][CS_RS] (workgroup of CS_NW waves; the caller puts a barrier behind it).  Two halves so that other prologue
-// loads can be issued while the rows are in flight.
+// The H token rows of sample b -> S32[h][CS_RS].  Every wave stages exactly the rows it later works on (rows wv, wv + 8, ... -- or, PAIRS, the row
+// pairs (2q, 2q + 1), q = wv, wv + 8, ...), so no workgroup barrier separates the staging from the contractions: a wave_sync does.  Two halves so that
+// other prologue loads can be issued while the rows are in flight.
 constexpr int CS_RPW = CS_MAXH / CS_NW;
+template <bool PAIRS>
+__device__ __forceinline__ int cs_stage_row(int wv, int j) { return PAIRS ? 2 * (wv + CS_NW * (j >> 1)) + (j & 1) : wv + CS_NW * j; }
+template <bool PAIRS>
 __device__ __forceinline__ void cs_stage_load(float (&vx)[CS_RPW][4], const float* __restrict__ x, long long xs_b, long long xs_h, int b, int H, bool vec2) {
     const int wv = wave_uniform(threadIdx.x >> 6);
 #pragma unroll
     for (int j = 0; j < CS_RPW; ++j) {
-        const int h = wv + CS_NW * j;
+        const int h = cs_stage_row<PAIRS>(wv, j);
         cs_load_row(vx[j], x + (long long)b * xs_b + (long long)(h < H ? h : 0) * xs_h, h < H, vec2);
     }
 }
-__device__ __forceinline__ void cs_stage_finish(unsigned* __restrict__ S32, float* __restrict__ ps, const float (&vx)[CS_RPW][4], int H) {
-    const int t = threadIdx.x, wv = wave_uniform(t >> 6);
-    for (int i = t; i < H * 16; i += CS_NT) S32[(i >> 4) * CS_RS + 256 + (i & 15)] = 0u;     // words 256 .. 271: read by the padded tiles only, must be finite
+template <bool PAIRS>
+__device__ __forceinline__ void cs_stage_finish(unsigned* __restrict__ S32, float* __restrict__ pscr, const float (&vx)[CS_RPW][4], int H) {
+    const int wv = wave_uniform(threadIdx.x >> 6);
 #pragma unroll
     for (int j = 0; j < CS_RPW; ++j) {
-        const int h = wv + CS_NW * j;
-        if (h < H) cs_box_row(S32 + h * CS_RS, ps + wv * 256, vx[j]);
+        const int h = cs_stage_row<PAIRS>(wv, j);
+        if (h < H) cs_box_row(S32 + h * CS_RS, pscr, vx[j]);
     }
-}
-__device__ __forceinline__ void cs_stage_sample(unsigned* __restrict__ S32, float* __restrict__ ps, const float* __restrict__ x, long long xs_b,
-                                                long long xs_h, int b, int H, bool vec2) {
-    float vx[CS_RPW][4];
-    cs_stage_load(vx, x, xs_b, xs_h, b, H, vec2);
-    cs_stage_finish(S32, ps, vx, H);
+    wave_sync();
 }
 
 // BatchNorm batch statistics from `nrows` partial rows [sum(40) | sumsq(40)] (fp64), summed in a FIXED order by every workgroup that needs them: no

@@ -620,7 +620,7 @@ int eegclip_tok_planes_from_f32(const float* src, long long ld, int rows, int co
  *                          in row order by every workgroup; nstat1 = 1: the all-reduced sums of a data-parallel job) with element count `count1`;
  *                          workgroup 0 stores mean1 / rstd1 (for the backward) and updates the running statistics + step counter (what
  *                          eegclip_bn_finalize did).  stat1 = NULL: eval mode, mean1 / rstd1 are INPUTS.  stat2 (optional): BatchNorm2 partial rows
- *                          [sum_o | sumsq_o] of y2 per sample.  y1 (optional): the conv + pool output for kernels that still read it. */
+ *                          [sum_o | sumsq_o] of y2 per sample. */
 typedef struct {
     int B, H;
     const float* x;
@@ -638,7 +638,6 @@ typedef struct {
     const float* bias2;
     float* y2;
     double* stat2;
-    float* y1;
 } eegclip_cstack_fwd_desc;
 long long eegclip_cstack_packed_bytes(int H);
 int eegclip_cstack_pack(const float* Ws, void* packed, int H, void* stream);

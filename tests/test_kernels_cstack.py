@@ -54,20 +54,19 @@ def test_cstack_forward(be, B, H):
     ok(be.lib.eegclip_cstack_stats1(be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(BIAS1), be.ptr(ROWS), B, H, be.stream))
     rows = be.host(ROWS)
     y1 = y1t.detach().numpy()
-    np.testing.assert_allclose(rows[:, :40], y1.sum((2, 3)), atol=2e-3)
+    np.testing.assert_allclose(rows[:, :40], y1.sum((2, 3)), rtol=1e-5, atol=2e-3)       # (sums of 2268 values)
     np.testing.assert_allclose(rows[:, 40:], (y1 ** 2).sum((2, 3)), rtol=2e-4, atol=1e-5)
     count = float(B * H * WD)
     mean_ref, var_ref = y1.mean((0, 2, 3)), y1.var((0, 2, 3))
-    for with_y1 in (False, True):
+    for _ in range(2):                                      # (twice: nothing may depend on what a previous call left behind)
         MU, RS = be.dev(np.full(C, np.nan, np.float32)), be.dev(np.full(C, np.nan, np.float32))
         RM, RV = be.dev(np.full(C, 0.5, np.float32)), be.dev(np.full(C, 2.0, np.float32))
         NBT = be.dev(np.array([7], np.int64))
         Y2, ST2 = be.dev(np.full((B, C, WD), np.nan, np.float32)), be.dev(np.full((B, 80), np.nan, np.float64))
-        Y1 = be.dev(np.full((B, C, H, WD), np.nan, np.float32)) if with_y1 else None
         d = _abi.CstackFwdDesc(B=B, H=H, x=be.ptr(X), xs_b=64 * 250, xs_h=250, w25=be.ptr(W25), bias1=be.ptr(BIAS1), stat1=be.ptr(ROWS), nstat1=B,
                                count1=count, eps=1e-5, momentum=0.1, gamma1=be.ptr(G1), beta1=be.ptr(B1), mean1=be.ptr(MU), rstd1=be.ptr(RS),
                                run_mean1=be.ptr(RM), run_var1=be.ptr(RV), nbt1=be.ptr(NBT), packed=be.ptr(PK), bias2=be.ptr(BIAS2), y2=be.ptr(Y2),
-                               stat2=be.ptr(ST2), y1=be.ptr(Y1) if with_y1 else None)
+                               stat2=be.ptr(ST2))
         ok(be.lib.eegclip_cstack_fwd(ctypes.byref(d), be.stream))
         y2 = y2t.detach().numpy()
         np.testing.assert_allclose(be.host(Y2), y2, atol=1e-4)
@@ -80,14 +79,12 @@ def test_cstack_forward(be, B, H):
         st2 = be.host(ST2)
         np.testing.assert_allclose(st2[:, :40], be.host(Y2).astype(np.float64).sum(2), atol=1e-5)
         np.testing.assert_allclose(st2[:, 40:], (be.host(Y2).astype(np.float64) ** 2).sum(2), rtol=1e-6)
-        if with_y1:
-            np.testing.assert_allclose(be.host(Y1), y1, atol=2e-5)
     # eval mode: mean1 / rstd1 are inputs, no statistics are touched; all-reduced sums as one row
     MU, RS = be.dev(mean_ref.astype(np.float32)), be.dev((1 / np.sqrt(var_ref + 1e-5)).astype(np.float32))
     Y2 = be.dev(np.full((B, C, WD), np.nan, np.float32))
     d = _abi.CstackFwdDesc(B=B, H=H, x=be.ptr(X), xs_b=64 * 250, xs_h=250, w25=be.ptr(W25), bias1=be.ptr(BIAS1), stat1=None, nstat1=0, count1=0.0, eps=1e-5,
                            momentum=0.1, gamma1=be.ptr(G1), beta1=be.ptr(B1), mean1=be.ptr(MU), rstd1=be.ptr(RS), run_mean1=None, run_var1=None, nbt1=None,
-                           packed=be.ptr(PK), bias2=be.ptr(BIAS2), y2=be.ptr(Y2), stat2=None, y1=None)
+                           packed=be.ptr(PK), bias2=be.ptr(BIAS2), y2=be.ptr(Y2), stat2=None)
     ok(be.lib.eegclip_cstack_fwd(ctypes.byref(d), be.stream))
     np.testing.assert_allclose(be.host(Y2), y2t.detach().numpy(), atol=1e-4)
     ONE = be.dev(rows.sum(0, keepdims=True))

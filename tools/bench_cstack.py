@@ -48,13 +48,13 @@ def fwd_desc(with_y1, train=True):
                               stat1=rows[0].data_ptr() if train else None, nstat1=B if train else 0, count1=float(B * H * W), eps=1e-5, momentum=0.1,
                               gamma1=g1.data_ptr(), beta1=b1.data_ptr(), mean1=mu.data_ptr(), rstd1=rs.data_ptr(), run_mean1=rm.data_ptr() if train else None,
                               run_var1=rv.data_ptr() if train else None, nbt1=nbt.data_ptr() if train else None, packed=packed.data_ptr(), bias2=bias2.data_ptr(),
-                              y2=y2.data_ptr(), stat2=rows[1].data_ptr() if train else None, y1=y1.data_ptr() if with_y1 else None)
+                              y2=y2.data_ptr(), stat2=rows[1].data_ptr() if train else None)
 
 
 res = {"B": B}
 res["pack_us"] = ev(lambda: chk(L.eegclip_cstack_pack(Ws.data_ptr(), packed.data_ptr(), H, st)))
 res["stats1_us"] = ev(lambda: chk(L.eegclip_cstack_stats1(x.data_ptr(), 64 * 250, 250, w25.data_ptr(), bias1.data_ptr(), rows[0].data_ptr(), B, H, st)))
-for name, d in (("fwd_us", fwd_desc(False)), ("fwd_with_y1_us", fwd_desc(True)), ("fwd_eval_us", fwd_desc(False, False))):
+for name, d in (("fwd_us", fwd_desc(False)), ("fwd_eval_us", fwd_desc(False, False))):
     res[name] = ev(lambda: chk(L.eegclip_cstack_fwd(ctypes.byref(d), st)))
 # backward
 packed_t = torch.empty(int(L.eegclip_cstack_packed_t_bytes(H)) // 2, dtype=torch.bfloat16, device=dev)
