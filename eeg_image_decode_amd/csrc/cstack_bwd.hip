@@ -424,19 +424,45 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
     }
 }
 
-// dw25[i] += sum_b partials[b][i] in sample order: workgroup = 64 elements x 4 sample slices, the slices added in a fixed order
+// out[i] += sum_r partials[r][i], rows in a fixed order: workgroup = 16 elements x 16 row slices (thread (sl, e) sums rows sl, sl + 16, ...: 16 independent
+// loads in flight for 256 rows), the slices added pairwise in a fixed tree
 __global__ __launch_bounds__(256) void cstack_rows_reduce_kernel(const float* __restrict__ partials, int nrows, int n, float* __restrict__ out) {
-    EEG_LDS_BASE(float, red);                                 // [4][64]
-    const int t = threadIdx.x, sg = t >> 6, e = t & 63;
-    const int i = blockIdx.x * 64 + e;
+    EEG_LDS_BASE(float, red);                                 // [16][16]
+    const int t = threadIdx.x, sl = t >> 4, e = t & 15;
+    const int i = blockIdx.x * 16 + e;
     float s = 0.f;
     if (i < n) {
-#pragma unroll 8
-        for (int k = sg; k < nrows; k += 4) s += partials[(long long)k * n + i];
+#pragma unroll 16
+        for (int k = sl; k < nrows; k += 16) s += partials[(long long)k * n + i];
     }
-    red[sg * 64 + e] = s;
+    red[sl * 16 + e] = s;
     __syncthreads();
-    if (sg == 0 && i < n) out[i] += (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+#pragma unroll
+    for (int half = 8; half >= 1; half >>= 1) {
+        if (sl < half) red[sl * 16 + e] += red[(sl + half) * 16 + e];
+        __syncthreads();
+    }
+    if (sl == 0 && i < n) out[i] += red[e];
+}
+
+// dWs[o][c][h] += sum_g slabs[g][h][o][c] (groups in order) with the (h, c) transpose in LDS: workgroup = (o, block of 8 filters c); thread (hh, cc) sums
+// the G slabs of rows hh and hh + 32 (32-byte runs of a slab, 6.4 MB in all), then 63 consecutive h per (o, c) leave as one run
+__global__ __launch_bounds__(256) void cstack_w2_reduce_kernel(const float* __restrict__ slabs, int G, int H, float* __restrict__ dWs) {
+    EEG_LDS_BASE(float, tile);                                // [8 c][65]
+    const int t = threadIdx.x, o = blockIdx.x, cb = blockIdx.y;
+    const int hh = t >> 3, cc = t & 7, c = 8 * cb + cc;
+    for (int h = hh; h < H; h += 32) {
+        const float* src = slabs + ((long long)h * CS_C + o) * CS_C + c;
+        float s = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < G; ++g) s += src[(long long)g * H * CS_C * CS_C];
+        tile[cc * 65 + h] = s;
+    }
+    __syncthreads();
+    for (int i = t; i < 8 * H; i += 256) {
+        const int c2 = i / H, h = i % H;
+        dWs[((long long)o * CS_C + 8 * cb + c2) * H + h] += tile[c2 * 65 + h];
+    }
 }
 
 // ---- spatial-conv weight gradient -----------------------------------------------------------------------------------------------------------------------
@@ -444,10 +470,9 @@ __global__ __launch_bounds__(256) void cstack_rows_reduce_kernel(const float* __
 //   u^T tile D[w][c] = BN1(y1)^T: the operands of the forward's tap contraction swapped (taps scaled by gamma * rstd, the BatchNorm constant in the ones
 //   slot) -> z1^T = ELU(.) in registers = the k = w operand (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); positions 32 .. 35 as a second, mostly empty
 //   k-step) of dWs[o][c] += sum_w dy2[b][o][w] z1[c][w]; the dy2 fragments (rows o, the same k slots) come from global memory, 16 bytes per quarter.
-// The four rows of a workgroup meet in LDS and leave as slab[g][o][c][h .. h + 3] (the layout of dWs): the slabs are then summed over g by a plain,
-// fully coalesced ordered reduction (the first version wrote [g][h][o][c] and transposed in the reduction: 48 us of 4-byte scattered read-modify-writes).
+// Slabs [G][H][40 o][40 c] (coalesced 64-byte runs), summed over G in a fixed order by cstack_w2_reduce_kernel, which transposes (h, c) through LDS
+// (a first version transposed with 4-byte scattered read-modify-writes: 48 us in the step).
 constexpr int CSW_NW = 4;
-constexpr int CSW_TLD = 41;                                    // LDS tile [40 o][41]
 __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
                                                                     const float* __restrict__ bias1, const float* __restrict__ mean1,
                                                                     const float* __restrict__ rstd1, const float* __restrict__ gamma1,
@@ -458,9 +483,8 @@ __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float*
     const int n = lane & 15, kg = lane >> 4;
     unsigned* srow = reinterpret_cast<unsigned*>(ldsb) + wv * (CS_RS + 256);      // the wave's packed row + its prefix-sum scratch
     float* pscr = reinterpret_cast<float*>(srow + CS_RS);
-    float* tile = reinterpret_cast<float*>(ldsb) + CSW_NW * (CS_RS + 256);       // [4 rows][40 o][41]: the workgroup's result before it leaves
     const int h = 4 * blockIdx.x + wv, g = blockIdx.y;
-    const bool active = h < H;                                 // (a last row block may be short; idle waves still meet the barrier)
+    const bool active = h < H;                                 // (a last row block may be short)
     const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[3][3];                                          // D[o = 16 ot + 4 kg + r][c = 16 ct + n]
 #pragma unroll
@@ -526,6 +550,7 @@ __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float*
                 acc[0][ct] = t3[0]; acc[1][ct] = t3[1]; acc[2][ct] = t3[2];
             }
         }
+        float* out = slabs + ((long long)g * H + h) * CS_C * CS_C;     // slab[g][h][o][c]: 64-byte runs along c
 #pragma unroll
         for (int ot = 0; ot < 3; ++ot)
 #pragma unroll
@@ -533,15 +558,8 @@ __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float*
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * ot + 4 * kg + r, c = 16 * ct + n;
-                    if (o < CS_C && c < CS_C) tile[(wv * CS_C + o) * CSW_TLD + c] = acc[ot][ct][r];
+                    if (o < CS_C && c < CS_C) out[o * CS_C + c] = acc[ot][ct][r];
                 }
-    }
-    __syncthreads();
-    const int h0 = 4 * blockIdx.x, nh = H - h0 < 4 ? H - h0 : 4;
-    float* out = slabs + (long long)g * CS_C * CS_C * H;
-    for (int i = t; i < CS_C * CS_C; i += 64 * CSW_NW) {       // (o, c) -> 4 consecutive h of slab[g][o][c][.]
-        const int o = i / CS_C, c = i % CS_C;
-        for (int k = 0; k < nh; ++k) out[(long long)i * H + h0 + k] = tile[(k * CS_C + o) * CSW_TLD + c];
     }
 }
 
@@ -552,7 +570,7 @@ using namespace eeg;
 static int csb_vec2(const float* x, long long xs_b, long long xs_h) {
     return ((reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (xs_b & 1) == 0 && (xs_h & 1) == 0) ? 1 : 0;
 }
-static int csw_groups(int B) { return B < 16 ? B : 16; }
+static int csw_groups(int B) { return B < 32 ? B : 32; }      // 16 row blocks x 32 groups x 4 waves = 2 waves per SIMD
 
 extern "C" long long eegclip_cstack_packed_t_bytes(int H) { return (H < 1 || H > CS_MAXH) ? 0 : (long long)H * CST_ROW; }
 
@@ -594,7 +612,7 @@ extern "C" int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* 
     const size_t lds = (size_t)d->H * CS_RS * 4 + CSB_NCOEF * 48 * 4 + CSB_DYF + CSB_TAPF + CS_NW * CSB_WAVE;
     EEG_LAUNCH(cstack_bwd_kernel<true>, dim3(d->B), dim3(CS_NT), lds, stream, csb_args(d));
     const int n = CS_C * CS_K1;
-    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((n + 63) / 64), dim3(256), 256 * sizeof(float), stream, (const float*)d->dw_partials, d->B, n, d->dw25);
+    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((n + 15) / 16), dim3(256), 256 * sizeof(float), stream, (const float*)d->dw_partials, d->B, n, d->dw25);
     return (int)hipGetLastError();
 }
 
@@ -605,10 +623,9 @@ extern "C" int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long x
     if (!x || !w25 || !bias1 || !mean1 || !rstd1 || !gamma1 || !beta1 || !dy2 || !dWs || !workspace || B < 1 || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(dy2) & 15u) return EEGCLIP_EALIGN;
     const int G = csw_groups(B);
-    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4 + (size_t)CSW_NW * CS_C * CSW_TLD * 4;
+    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4;
     EEG_LAUNCH(cstack_bwd_w2_kernel, dim3((H + 3) / 4, G), dim3(64 * CSW_NW), lds, stream, x, xs_b, xs_h, w25, bias1, mean1, rstd1, gamma1, beta1, dy2, workspace, B,
                H, G, csb_vec2(x, xs_b, xs_h));
-    const int nw = CS_C * CS_C * H;
-    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((nw + 63) / 64), dim3(256), 256 * sizeof(float), stream, (const float*)workspace, G, nw, dWs);
+    EEG_LAUNCH(cstack_w2_reduce_kernel, dim3(CS_C, CS_C / 8), dim3(256), 8 * 65 * sizeof(float), stream, (const float*)workspace, G, H, dWs);
     return (int)hipGetLastError();
 }

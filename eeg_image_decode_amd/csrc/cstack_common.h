@@ -105,26 +105,6 @@ __device__ __forceinline__ void cs_mma3_b3(bf16x8 ah, bf16x8 al, const bf16x8 (&
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah, bh[i], acc[i]);
 }
-// max(x, 0) / min(x, 0) as ONE instruction (fmaxf / fminf compile to a canonicalising v_max x, x, x first)
-__device__ __forceinline__ float cs_max0(float x) {
-#if defined(EEG_EMU)
-    return x > 0.f ? x : 0.f;
-#else
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-#endif
-}
-__device__ __forceinline__ float cs_min0(float x) {
-#if defined(EEG_EMU)
-    return x < 0.f ? x : 0.f;
-#else
-    float r;
-    asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-#endif
-}
-
 // the taps as the filter-side operand: lane (n, kg), tile ct <- scale[c] * w25[c = 16 ct + n][t = 8 kg + i] (zero past 40 filters / 25 taps), and in the
 // otherwise unused k slot t = 25 the per-filter constant shift[c]: against an activation operand whose slot 25 is 1.0 (cs_sfrag_ones) the contraction
 // yields  scale[c] * (conv)[c][w] + shift[c]  -- a BatchNorm affine (or the conv bias) costs no vector instruction in the epilogue.
@@ -178,15 +158,26 @@ __device__ __forceinline__ float cs_exp2(float x) {
 #endif
 }
 constexpr float CS_LOG2E = 1.4426950408889634f;
-// ELU'(u) = exp(min(u, 0)) for two elements: 1 for u >= 0
-__device__ __forceinline__ f32x2_t cs_elu_grad2(f32x2_t u) {
+constexpr float CS_LN2 = 0.6931471805599453f;
+// ELU'(u) = exp(min(u, 0)) for two elements (1 for u >= 0); mneg <- min(u * log2(e), 0).  The min is taken of the PRODUCT, a value the compiler knows to be
+// canonical: fminf / fmaxf of a raw MFMA result cost an extra canonicalising v_max each -- and no inline asm here: an asm statement that reads an MFMA
+// result gets none of the wait states the hazard recogniser inserts for compiler-visible instructions (wrong values on the hardware, right ones on the
+// emulator).
+__device__ __forceinline__ f32x2_t cs_elu_grad2(f32x2_t u, f32x2_t& mneg) {
     const f32x2_t m = u * f32x2_t{CS_LOG2E, CS_LOG2E};
-    return f32x2_t{cs_exp2(cs_min0(m[0])), cs_exp2(cs_min0(m[1]))};
+    mneg = f32x2_t{fminf(m[0], 0.f), fminf(m[1], 0.f)};
+    return f32x2_t{cs_exp2(mneg[0]), cs_exp2(mneg[1])};
 }
-// ELU(u) = max(u, 0) + (exp(min(u, 0)) - 1) for two elements (exact u for u > 0; absolute error <= 2e-7 otherwise, cf. elu1_fast)
+__device__ __forceinline__ f32x2_t cs_elu_grad2(f32x2_t u) {
+    f32x2_t mneg;
+    return cs_elu_grad2(u, mneg);
+}
+// ELU(u) = max(u, 0) + (exp(min(u, 0)) - 1) for two elements, with max(u, 0) = u - ln(2) * min(u * log2(e), 0) as ONE packed fma (exact u for u > 0; the
+// product round trip leaves <= 1.2e-7 |u| for u < 0, cf. elu1_fast's 2e-7)
 __device__ __forceinline__ f32x2_t cs_elu2(f32x2_t u) {
-    const f32x2_t e = cs_elu_grad2(u);
-    return (e + f32x2_t{-1.f, -1.f}) + f32x2_t{cs_max0(u[0]), cs_max0(u[1])};
+    f32x2_t mneg;
+    const f32x2_t e = cs_elu_grad2(u, mneg);
+    return cs_fma2(mneg, f32x2_t{-CS_LN2, -CS_LN2}, u) + (e + f32x2_t{-1.f, -1.f});
 }
 __device__ __forceinline__ f32x2_t cs_lo2(f32x4 v) { return f32x2_t{v[0], v[1]}; }
 __device__ __forceinline__ f32x2_t cs_hi2(f32x4 v) { return f32x2_t{v[2], v[3]}; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call D: the leaner cstack kernels (ones-slot affine, packed epilogues, product-major MFMAs, per-wave staging): parity, timings, PMC
-out=gpurun_out/r5d
+out=gpurun_out/r5e
 mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -30,5 +30,5 @@ for r in rows[:24]:
     n=r['Name'].split('(')[0].replace('void ','')[:56]
     print(f"{n:56s} {int(r['Calls'])/steps:5.2f} avg {float(r['AverageNs'])/1e3:7.1f} per-step {float(r['TotalDurationNs'])/steps/1e3:7.1f}")
 PY
-bash tools/gpu_pmc_cmd.sh r5d/pmc cstack bench_cstack.py > $out/pmc_tail.log 2>&1
-find $out/pmc -name "*.csv" -delete
+true
+
