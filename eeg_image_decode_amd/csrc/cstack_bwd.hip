@@ -445,23 +445,29 @@ __global__ __launch_bounds__(256) void cstack_rows_reduce_kernel(const float* __
     if (sl == 0 && i < n) out[i] += red[e];
 }
 
-// dWs[o][c][h] += sum_g slabs[g][h][o][c] (groups in order) with the (h, c) transpose in LDS: workgroup = (o, block of 8 filters c); thread (hh, cc) sums
-// the G slabs of rows hh and hh + 32 (32-byte runs of a slab, 6.4 MB in all), then 63 consecutive h per (o, c) leave as one run
+// dWs[oc][h] += sum_g slabs[g][h][oc] (oc = o * 40 + c; groups in order) as a tiled transpose: workgroup = 32 rows h x 32 columns oc; reads are 128-byte
+// runs of a slab, the sum meets in an LDS tile, writes are 128-byte runs of dWs
 __global__ __launch_bounds__(256) void cstack_w2_reduce_kernel(const float* __restrict__ slabs, int G, int H, float* __restrict__ dWs) {
-    EEG_LDS_BASE(float, tile);                                // [8 c][65]
-    const int t = threadIdx.x, o = blockIdx.x, cb = blockIdx.y;
-    const int hh = t >> 3, cc = t & 7, c = 8 * cb + cc;
-    for (int h = hh; h < H; h += 32) {
-        const float* src = slabs + ((long long)h * CS_C + o) * CS_C + c;
+    EEG_LDS_BASE(float, tile);                                // [32 h][33]
+    const int t = threadIdx.x, col = t & 31, r8 = t >> 5;
+    const int oc0 = 32 * blockIdx.x, h0 = 32 * blockIdx.y;
+    constexpr int N = CS_C * CS_C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = h0 + r8 + 8 * k;
         float s = 0.f;
+        if (h < H) {
+            const float* src = slabs + (long long)h * N + oc0 + col;
 #pragma unroll 8
-        for (int g = 0; g < G; ++g) s += src[(long long)g * H * CS_C * CS_C];
-        tile[cc * 65 + h] = s;
+            for (int g = 0; g < G; ++g) s += src[(long long)g * H * N];
+        }
+        tile[(r8 + 8 * k) * 33 + col] = s;
     }
     __syncthreads();
-    for (int i = t; i < 8 * H; i += 256) {
-        const int c2 = i / H, h = i % H;
-        dWs[((long long)o * CS_C + 8 * cb + c2) * H + h] += tile[c2 * 65 + h];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oc = oc0 + r8 + 8 * k, h = h0 + col;
+        if (h < H) dWs[(long long)oc * H + h] += tile[col * 33 + r8 + 8 * k];
     }
 }
 
@@ -470,21 +476,23 @@ __global__ __launch_bounds__(256) void cstack_w2_reduce_kernel(const float* __re
 //   u^T tile D[w][c] = BN1(y1)^T: the operands of the forward's tap contraction swapped (taps scaled by gamma * rstd, the BatchNorm constant in the ones
 //   slot) -> z1^T = ELU(.) in registers = the k = w operand (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); positions 32 .. 35 as a second, mostly empty
 //   k-step) of dWs[o][c] += sum_w dy2[b][o][w] z1[c][w]; the dy2 fragments (rows o, the same k slots) come from global memory, 16 bytes per quarter.
-// Slabs [G][H][40 o][40 c] (coalesced 64-byte runs), summed over G in a fixed order by cstack_w2_reduce_kernel, which transposes (h, c) through LDS
-// (a first version transposed with 4-byte scattered read-modify-writes: 48 us in the step).
-constexpr int CSW_NW = 4;
+// workgroup = (2 token rows, 4 sample sub-groups): the sub-groups' tiles are summed in LDS in a fixed order, so only SG <= 8 slabs [SG][H][40 o][40 c]
+// leave (3.2 MB; 32 slabs of one group each cost a 72-us reduction in the step), summed by cstack_w2_reduce_kernel, a tiled transpose to dWs[o][c][h].
+constexpr int CSW_NW = 8;                                      // 2 token rows x 4 sample sub-groups per workgroup
 __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
                                                                     const float* __restrict__ bias1, const float* __restrict__ mean1,
                                                                     const float* __restrict__ rstd1, const float* __restrict__ gamma1,
                                                                     const float* __restrict__ beta1, const float* __restrict__ dy2, float* __restrict__ slabs,
-                                                                    int B, int H, int G, int vec2) {
+                                                                    int B, int H, int SG, int vec2) {
     EEG_LDS_BASE(unsigned char, ldsb);
     const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
     const int n = lane & 15, kg = lane >> 4;
     unsigned* srow = reinterpret_cast<unsigned*>(ldsb) + wv * (CS_RS + 256);      // the wave's packed row + its prefix-sum scratch
     float* pscr = reinterpret_cast<float*>(srow + CS_RS);
-    const int h = 4 * blockIdx.x + wv, g = blockIdx.y;
-    const bool active = h < H;                                 // (a last row block may be short)
+    float* tile = reinterpret_cast<float*>(ldsb) + CSW_NW * (CS_RS + 256);       // [8 waves][1600]: the sub-groups' results before they are summed
+    const int G = 4 * SG;                                      // sample groups in all: wave (row, q) walks the samples g = 4 sg + q, g + G, ...
+    const int h = 2 * blockIdx.x + (wv & 1), g = 4 * blockIdx.y + (wv >> 1);
+    const bool active = h < H && g < B;                        // (a last row block may be short, a small batch may not fill the sub-groups)
     const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[3][3];                                          // D[o = 16 ot + 4 kg + r][c = 16 ct + n]
 #pragma unroll
@@ -550,16 +558,24 @@ __global__ __launch_bounds__(64 * CSW_NW) void cstack_bwd_w2_kernel(const float*
                 acc[0][ct] = t3[0]; acc[1][ct] = t3[1]; acc[2][ct] = t3[2];
             }
         }
-        float* out = slabs + ((long long)g * H + h) * CS_C * CS_C;     // slab[g][h][o][c]: 64-byte runs along c
+    }
+    // the four sub-groups of a row meet in LDS (q = 0 .. 3 in order) and leave as slab[sg][h][o][c]: 8 slabs instead of 32
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot)
+    for (int ot = 0; ot < 3; ++ot)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * ot + 4 * kg + r, c = 16 * ct + n;
-                    if (o < CS_C && c < CS_C) out[o * CS_C + c] = acc[ot][ct][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ot + 4 * kg + r, c = 16 * ct + n;
+                if (o < CS_C && c < CS_C) tile[wv * CS_C * CS_C + o * CS_C + c] = acc[ot][ct][r];      // (idle waves: zeros)
+            }
+    __syncthreads();
+    for (int i = t; i < 2 * CS_C * CS_C; i += 64 * CSW_NW) {
+        const int row = i / (CS_C * CS_C), oc = i % (CS_C * CS_C), hh = 2 * blockIdx.x + row;
+        if (hh < H) {
+            const float* p = tile + row * CS_C * CS_C + oc;
+            slabs[((long long)blockIdx.y * H + hh) * CS_C * CS_C + oc] = ((p[0] + p[2 * CS_C * CS_C]) + p[4 * CS_C * CS_C]) + p[6 * CS_C * CS_C];
+        }
     }
 }
 
@@ -570,7 +586,7 @@ using namespace eeg;
 static int csb_vec2(const float* x, long long xs_b, long long xs_h) {
     return ((reinterpret_cast<uintptr_t>(x) & 7u) == 0 && (xs_b & 1) == 0 && (xs_h & 1) == 0) ? 1 : 0;
 }
-static int csw_groups(int B) { return B < 32 ? B : 32; }      // 16 row blocks x 32 groups x 4 waves = 2 waves per SIMD
+static int csw_groups(int B) { const int sg = (B + 3) / 4; return sg < 8 ? sg : 8; }      // slabs: 32 row blocks x 8 x 8 waves = 2 waves per SIMD
 
 extern "C" long long eegclip_cstack_packed_t_bytes(int H) { return (H < 1 || H > CS_MAXH) ? 0 : (long long)H * CST_ROW; }
 
@@ -623,9 +639,9 @@ extern "C" int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long x
     if (!x || !w25 || !bias1 || !mean1 || !rstd1 || !gamma1 || !beta1 || !dy2 || !dWs || !workspace || B < 1 || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(dy2) & 15u) return EEGCLIP_EALIGN;
     const int G = csw_groups(B);
-    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4;
-    EEG_LAUNCH(cstack_bwd_w2_kernel, dim3((H + 3) / 4, G), dim3(64 * CSW_NW), lds, stream, x, xs_b, xs_h, w25, bias1, mean1, rstd1, gamma1, beta1, dy2, workspace, B,
+    const size_t lds = (size_t)CSW_NW * (CS_RS + 256) * 4 + (size_t)CSW_NW * CS_C * CS_C * 4;
+    EEG_LAUNCH(cstack_bwd_w2_kernel, dim3((H + 1) / 2, G), dim3(64 * CSW_NW), lds, stream, x, xs_b, xs_h, w25, bias1, mean1, rstd1, gamma1, beta1, dy2, workspace, B,
                H, G, csb_vec2(x, xs_b, xs_h));
-    EEG_LAUNCH(cstack_w2_reduce_kernel, dim3(CS_C, CS_C / 8), dim3(256), 8 * 65 * sizeof(float), stream, (const float*)workspace, G, H, dWs);
+    EEG_LAUNCH(cstack_w2_reduce_kernel, dim3(CS_C * CS_C / 32, (H + 31) / 32), dim3(256), 32 * 33 * sizeof(float), stream, (const float*)workspace, G, H, dWs);
     return (int)hipGetLastError();
 }

@@ -277,10 +277,17 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt, arit
             assert int(sd[k]) == 6
 
 
-def test_reconstruction_train_model_matches_reference_fixture(state_np, golden):
+@pytest.mark.parametrize("arith,fwd_tol,traj_tol", [("bf16x3", 1e-4, 3e-3), ("f32", 1e-5, 3e-4)])
+def test_reconstruction_train_model_matches_reference_fixture(state_np, golden, arith, fwd_tol, traj_tol, monkeypatch):
     """reconstruction.train_model == the reference's Generation/ATMS_reconstruction.py:train_model (10 * (0.9 MSE + 0.1 image
-    InfoNCE)) on the same 3-batch loader, 2 epochs of AdamW"""
+    InfoNCE)) on the same 3-batch loader, 2 epochs of AdamW -- in the default split-bf16 arithmetic and with exact fp32 products.
+    Two bounds on the first epoch's features: the FIRST batch is a pure forward of the initial weights (parity budget of north_star 1e-3; held to
+    1e-4 / 1e-5); the later batches follow AdamW steps, whose first updates are lr * sign(g) for every element whatever |g| -- an element whose
+    gradient is round-off sized moves by +-3e-4 in a direction set by the last bit, which amplifies the forward's arithmetic noise ~35x (measured
+    with EXACT fp32 products: 3.4e-6 on the first batch, 1.2e-4 on the second).  Since round 5 the conv stack computes in split-bf16 like the
+    rest of the encoder (csrc/cstack*.hip; its fp32-MFMA predecessor was exact): first batch 5e-5, trajectory 9e-4."""
     from eeg_image_decode_amd import optim, reconstruction
+    monkeypatch.setenv("EEGCLIP_GEMM_PRECISION", arith)
     g = golden("recon_loop.npz")
     n_classes, B = 20, 16
     img_all = T(syn.unit_features(SEED + 4, n_classes * 10, tag="imgall"))
@@ -296,7 +303,9 @@ def test_reconstruction_train_model_matches_reference_fixture(state_np, golden):
         losses.append(l)
         accs.append(a)
         if ep == 0:
-            np.testing.assert_allclose(feats.cpu().numpy()[:, :64], g["feats_ep0"], atol=1e-3)
+            f = feats.cpu().numpy()[:, :64]
+            np.testing.assert_allclose(f[:B], g["feats_ep0"][:B], atol=fwd_tol)
+            np.testing.assert_allclose(f, g["feats_ep0"], atol=traj_tol)
     np.testing.assert_allclose(losses, g["losses"], atol=2e-3)
     np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
     for k, p in m.named_parameters():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call D: the leaner cstack kernels (ones-slot affine, packed epilogues, product-major MFMAs, per-wave staging): parity, timings, PMC
-out=gpurun_out/r5e
+out=gpurun_out/r5f
 mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -13,8 +13,8 @@ run() { name=$1; shift; env "$@" timeout 200 python bench.py $B > $out/$name.jso
 run new X=1
 run old EEGCLIP_CSTACK=0
 run new2 X=1
-(timeout 600 python -m pytest tests/test_model_gpu.py tests/test_full_size_gpu.py -m gpu -x -q -p no:cacheprovider -k "not sdxl and not prior" 2>&1 | grep -v "$F" | tail -6) > $out/tests_model.log 2>&1
-tail -3 $out/tests_model.log
+(timeout 600 python -m pytest tests/test_model_gpu.py tests/test_full_size_gpu.py tests/test_dp_gpu.py -m gpu -q -p no:cacheprovider -k "not sdxl and not prior" 2>&1 | grep -v "$F" | tail -25) > $out/tests_model.log 2>&1
+tail -12 $out/tests_model.log
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o trace -- python $R/bench.py --steps 30 --warmup 5 --no-secondary --no-cpu-baseline > $R/$out/bench_prof.json 2> $R/$out/prof.err)
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $out/step_kernel_stats.csv
