@@ -61,6 +61,14 @@ def algorithmic_cost(name, desc, B):
     if name == "eegclip_token_block_bwd":
         return ("hbm", float(B * TOKEN_BLOCK_BYTES[desc]), "byte") if desc in TOKEN_BLOCK_BYTES else None
     tok = B * 63 * 250 * 4
+    # the conv stack recomputed from the token rows (csrc/cstack*.hip, round 5): contractions on the bf16 matrix cores, HBM traffic = the token rows.
+    # algorithmic flops per sample: tap contraction 2 x 40 x 25 x 63 x 36, spatial contraction (and its transposes) 2 x 40 x 40 x 63 x 36
+    tap, spat = 2.0 * 40 * 25 * 63 * 36, 2.0 * 40 * 40 * 63 * 36
+    cstack = {"eegclip_cstack_stats1": tap, "eegclip_cstack_fwd": tap + spat, "eegclip_cstack_bwd_stats": tap + spat,
+              "eegclip_cstack_bwd_apply": 3 * tap + spat,        # y1 + dz1 + E = dy1^T taps + the taps gradient
+              "eegclip_cstack_bwd_w2": tap + spat, "eegclip_cstack_pack": 0.0, "eegclip_cstack_pack_t": 0.0, "eegclip_bn_finalize_rows": 0.0}
+    if name in cstack:
+        return "mfma", B * cstack[name], "flop"
     table = {                                                               # HBM-bound streaming over the (B,40,63,36) tensor y1
         "eegclip_tsconv_fwd": ("hbm", tok + y1),                            # read tokens, write y1
         "eegclip_tsconv_bwd_w": ("hbm", tok + y1),                          # read tokens + dy1
@@ -124,8 +132,26 @@ def algorithmic_bytes(name, desc, B):
         return 0.0
     if name in ("eegclip_attention_bwd_x3", "eegclip_attention_bwd"):
         return float(B * 64 * (2 * 744 + 248) * 4)                 # qkv + dctx in, dqkv out
+    if name.startswith("eegclip_cstack_") or name == "eegclip_bn_finalize_rows":
+        tok = B * 63 * 250 * 4.0                                    # the token rows in (apply: + their gradients out); packs / finalize: nothing per sample
+        return {"eegclip_cstack_bwd_apply": 2 * tok, "eegclip_cstack_pack": 0.0, "eegclip_cstack_pack_t": 0.0, "eegclip_bn_finalize_rows": 0.0}.get(name, tok)
     c = algorithmic_cost(name, desc, B)
     return c[1] if c and c[2] == "byte" else None
+
+
+# algorithmic flops per sample of the fused transformer-block launches (2 M N K of every Linear + 4 L^2 E per head of the attention forward; the
+# backward parts hold the dX GEMMs only -- the weight gradients are the wgrad_tok launches): the MFMA-roof sibling of the family's HBM fraction
+TOKEN_BLOCK_FLOPS = {"fwd": 2.0 * 63 * 250 * 250 + 2.0 * 64 * 250 * 744 + 4 * 4.0 * 64 * 64 * 62 + 2.0 * 64 * 248 * 250 + 2 * 2.0 * 64 * 250 * 256,
+                     0: 2 * 2.0 * 64 * 250 * 256 + 2.0 * 64 * 248 * 250, 1: 2.0 * 64 * 744 * 250}
+
+
+def algorithmic_flops(name, desc, B):
+    if name == "eegclip_token_block_fwd":
+        return B * TOKEN_BLOCK_FLOPS["fwd"]
+    if name == "eegclip_token_block_bwd":
+        return B * TOKEN_BLOCK_FLOPS.get(desc, 0.0)
+    c = algorithmic_cost(name, desc, B)
+    return c[1] if c and c[2] == "flop" else None
 
 
 TIME_EVERY = 8
@@ -140,6 +166,8 @@ def family_of(name, desc):
         return "gemm_bf16x3"
     if name.startswith("eegclip_token_block_"):
         return "token_block"
+    if name.startswith("eegclip_cstack_") or name == "eegclip_bn_finalize_rows":
+        return "conv_stack"
     if name == "eegclip_attention_bwd_x3":
         return "attention_bf16x3"
     if name.startswith("eegclip_attention_"):
@@ -151,7 +179,7 @@ def family_peak(fam, bound):
     """(peak, scale from work / ms to the unit, unit)"""
     if bound == "mfma":
         # bf16x3: three bf16 MFMA products per algorithmic multiply-add -> the pipe's ceiling for ALGORITHMIC flops is a third of 2.5 PF
-        return (PEAK_BF16_MFMA_TF / 3.0 if fam in ("gemm_bf16x3", "attention_bf16x3") else PEAK_F32_MFMA_TF), 1e-3 * 1e12, "TFLOP/s"
+        return (PEAK_BF16_MFMA_TF / 3.0 if fam in ("gemm_bf16x3", "attention_bf16x3", "conv_stack") else PEAK_F32_MFMA_TF), 1e-3 * 1e12, "TFLOP/s"
     return PEAK_HBM_GBS, 1e-3 * 1e9, "GB/s"
 
 
@@ -505,6 +533,8 @@ def main():
     ap.add_argument("--roofline-kernel", default="auto", help="kernel family for the roofline object: gemm_bf16x3, gemm_f32 or an op name such as "
                     "eegclip_sconv_fwd (auto = the family with the largest total time)")
     args = ap.parse_args()
+    if args.breakdown:
+        os.environ["EEGCLIP_STEP_PLAN"] = "0"       # every op is timed through the encoder's own plans (the step plan replays the same launches)
 
     from eeg_image_decode_amd import dist as edist
     from eeg_image_decode_amd import retrieval
@@ -547,6 +577,10 @@ def main():
     # grouped into families (all GEMM launches of one arithmetic are one kernel template) and the family with the largest total time is
     # the one the roofline object describes.  ALL its launches are then timed live inside the timed region (HIP events on the stream each
     # launch goes to -- the backward overlaps two streams there, which stretches per-launch durations: both figures are reported).
+    # (the single-submission step plan -- step_plan.py -- replays the very same launches; the instrumented steps go launch by launch through the
+    #  encoder's own plans, whose ops carry the timing hooks)
+    os.environ["EEGCLIP_STEP_PLAN_OFF_FOR_BENCH"] = os.environ.get("EEGCLIP_STEP_PLAN", "1")
+    os.environ["EEGCLIP_STEP_PLAN"] = "0"
     for k, pl in plans.items():
         pl.use_side_stream = False
         pl.time_ops(range(len(pl.ops)))
@@ -558,6 +592,9 @@ def main():
             single[(k, idx)] = float(np.mean(v))
         pl.time_ops([])
         pl.use_side_stream = True
+    os.environ["EEGCLIP_STEP_PLAN"] = os.environ.pop("EEGCLIP_STEP_PLAN_OFF_FOR_BENCH")
+    step(0)                                       # (back on the step plan, if the configuration has one)
+    sp = next((st["plan"] for st in getattr(eng, "_step_plans", {}).values() if st["plan"]), None)
     fam_ops, fam_ms = {}, {}
     for (k, idx), ms in single.items():
         name = plans[k].ops[idx][2]
@@ -578,8 +615,13 @@ def main():
             by_plan.setdefault(k, []).append(idx)
         # every launch of the family is timed on every TIME_EVERY-th step of the timed region (two HIP events per launch: ~40 per step for the GEMM
         # family, ~0.1 ms of a 1.2 ms step if recorded on every step -- instrumentation the product does not carry; 3+ sampled steps x 20 launches)
-        for k, idxs in by_plan.items():
-            plans[k].time_ops(idxs, every=TIME_EVERY if args.steps >= 2 * TIME_EVERY else 1)
+        every = TIME_EVERY if args.steps >= 2 * TIME_EVERY else 1
+        if sp is not None:                        # the step plan holds the encoder plans' ops at fixed offsets
+            base = {"f": sp.fwd_base, "b": sp.bwd_base}
+            sp.pl.time_ops([base[k[0]] + i for k, idxs in by_plan.items() for i in idxs], every=every)
+        else:
+            for k, idxs in by_plan.items():
+                plans[k].time_ops(idxs, every=every)
 
     barrier()
     t0 = time.perf_counter()
@@ -615,9 +657,15 @@ def main():
     elif dominant in fam_ops:
         ops = fam_ops[dominant]
         live = {}
-        for k in {k for k, _ in ops}:
-            for idx, v in plans[k].timings_ms().items():
-                live[(k, idx)] = float(np.mean(v[-args.steps:]))
+        if sp is not None:
+            base = {"f": sp.fwd_base, "b": sp.bwd_base}
+            tm = sp.pl.timings_ms()
+            for (k, idx) in ops:
+                live[(k, idx)] = float(np.mean(tm[base[k[0]] + idx][-args.steps:]))
+        else:
+            for k in {k for k, _ in ops}:
+                for idx, v in plans[k].timings_ms().items():
+                    live[(k, idx)] = float(np.mean(v[-args.steps:]))
         work = {o: algorithmic_cost(plans[o[0]].ops[o[1]][2], _desc_of(plans[o[0]], o[1]), B) for o in ops}
         bound, unit = work[ops[0]][0], work[ops[0]][2]
         w_tot = sum(w[1] for w in work.values())
@@ -627,7 +675,9 @@ def main():
         big = max(ops, key=lambda o: work[o][1])
         dbig = _desc_of(plans[big[0]], big[1])
         traffic, tsrc = pmc_traffic(dominant, B)
-        kernel_names = {"gemm_bf16x3": "eeg::gemm_x3_kernel + eeg::wgrad_tok_kernel (the Linears outside the fused transformer block: head forward / dX / weight "
+        kernel_names = {"conv_stack": "eeg::cstack_{stats1,fwd,bwd<false>,bwd<true>,bwd_w2}_kernel (+ weight packs, row reductions): Conv(1x25) + AvgPool + BatchNorm + ELU + "
+                                      "Conv(63x1) forward and backward recomputed from the token rows on the bf16 matrix cores (split-bf16 products); y1 / dy1 never in HBM",
+                        "gemm_bf16x3": "eeg::gemm_x3_kernel + eeg::wgrad_tok_kernel (the Linears outside the fused transformer block: head forward / dX / weight "
                                        "gradients on gemm_x3, the block's weight gradients from token planes on wgrad_tok + its slab reduction; split-bf16 products)",
                         "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)",
                         "token_block": "eeg::token_block_{fwd,bwd_a,bwd_b}_kernel (the encoder's transformer block, one workgroup per sample: forward and the "
@@ -703,6 +753,10 @@ def main():
                     t_hbm = sum(ab) / (PEAK_HBM_GBS * 1e9) * 1e3                   # ms at the HBM roof
                     fams[f]["frac_of_hbm_roof"] = round(t_hbm / fam_ms[f], 4)
                     fams[f]["frac_of_binding_roof"] = round(max(t_mfma, t_hbm) / fam_ms[f], 4)
+            if fw[0][0] == "hbm":
+                fl = [algorithmic_flops(plans[o[0]].ops[o[1]][2], _desc_of(plans[o[0]], o[1]), B) for o in fops]
+                if all(x is not None for x in fl) and sum(fl) > 0:                 # the same launches against the (split-bf16) matrix-pipe roof
+                    fams[f]["frac_of_mfma_roof"] = round(sum(fl) / (fam_ms[f] * 1e-3) / (PEAK_BF16_MFMA_TF / 3.0 * 1e12), 4)
             mb = pmc_mfma_busy(f, B)
             if mb is not None:
                 fams[f]["mfma_busy_frac"] = mb
@@ -735,6 +789,9 @@ def main():
                    "gemm_arithmetic": "bf16x3 split products, fp32 accumulate (embeddings within 3e-5 of exact fp32 products)"
                    if os.environ.get("EEGCLIP_GEMM_PRECISION", "bf16x3") != "f32" else "exact fp32 products (v_mfma_f32_16x16x4_f32)",
                    "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
+                   "submission": ("one eegclip_plan_run call per step (step_plan.py: forward, accuracy readout, fused InfoNCE, backward, AdamW)" if sp is not None
+                                  else "launch by launch from the Python loop (two encoder plans + loss / optimizer calls)"),
+                   "launches_per_step": (len([o for o in sp.pl.ops if o[0] is not None]) if sp is not None else None),
                    "python_gc": "gc.collect() + gc.freeze() once before the warm-up, as the product's training loops do (retrieval.settle_gc): a "
                                 "generation-2 collection costs 75 ms on this host"},
         "roofline": roof,

@@ -11,7 +11,7 @@ import re
 
 import torch
 
-from . import _abi
+from . import _abi, step_plan as _step_plan_module  # noqa: F401  (loaded with this module: the test emulator patches every loaded module)
 from ._lib import check, cuda_available, current_stream, lib, raw_stream, require_cuda, use_stream
 
 D = _abi.dim
@@ -133,9 +133,54 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
             eeg_model.overlap_grad_allreduce = prev_overlap      # (a caller accumulating gradients over several backwards must not inherit it)
 
 
+_STEP_PLANS_MAX = 8
+
+
+def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, alpha, objective, keep_grads):
+    """(state, StepPlan or None): the single-submission plan of this steady-state step (step_plan.py) once the ordinary path has run it
+    StepPlan.WARM_STEPS times -- those steps create the encoder plans, the activation buffers and the optimizer's launch cache the plan is built
+    from.  state is the per-configuration counter the caller advances after an ordinary step."""
+    from . import dist as edist
+    from .step_plan import StepPlan
+    if not StepPlan.eligible(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, objective, keep_grads,
+                             edist.world_size()):
+        return None, None
+    eng = eeg_model._engine()
+    table = eng.__dict__.setdefault("_step_plans", {})
+    key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subject_id)
+    st = table.get(key)
+    if st is None:
+        if len(table) >= _STEP_PLANS_MAX:
+            table.clear()
+        st = table[key] = {"warm": 0, "plan": None, "opt": optimizer}
+    sp = st["plan"]
+    if sp is not None and sp is not False:
+        if sp.still_valid(eeg_model, optimizer) and (subject_id >= 10 or eng.bufs[eeg_data.shape[0]].get("ids_uniform") == subject_id):
+            return st, sp
+        st["plan"], st["warm"] = None, 0             # something changed under the plan: warm up again on the ordinary path
+        return st, None
+    if sp is None and st["warm"] >= StepPlan.WARM_STEPS and optimizer._fast_last.get(0) is not None and all(p.grad is None for p in optimizer.param_groups[0]["params"]):
+        try:
+            st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0])
+            return st, st["plan"]
+        except (KeyError, AssertionError, AttributeError):
+            st["plan"] = False                        # this configuration does not have the pieces (e.g. launch-per-Linear plans): ordinary path for good
+    return st, None
+
+
 def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, loss_acc, correct, alpha, objective,
                       keep_grads=False):
     from . import dist as edist
+    st, sp = _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, alpha, objective, keep_grads)
+    if sp is not None:
+        feats, loss = sp.run(eeg_data, img_features, text_features, labels, class_feats, correct)
+        if isinstance(loss_acc, list):
+            loss_acc.append(loss)
+        else:
+            loss_acc += loss
+        return feats
+    if st is not None:
+        st["warm"] += 1
     batch_size = eeg_data.size(0)
     subject_ids = _uniform_ids(batch_size, subject_id, eeg_data.device)
     loss_func = eeg_model.loss_func

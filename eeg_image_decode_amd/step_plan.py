@@ -1,0 +1,234 @@
+"""One submission per training step (round 5).
+
+The reference's batch loop (Retrieval/ATMS_retrieval.py:209-250) is paced by the Python interpreter: forward, two losses, backward, optimizer, the
+running accuracy -- every torch op issued from the loop.  This build already replayed the encoder's forward and backward as two C-side launch plans
+(plan.py), but the loss, the accuracy readout and the optimizer were still enqueued from Python between them, through two autograd Functions:
+~0.3 ms of interpreter time per 0.85 ms step.  In steady state nothing about the step changes except a handful of pointers (the batch, its targets and
+labels, the fresh output tensor), the dropout seed and the optimizer's step count, so the WHOLE step is one plan:
+
+    [encoder forward] -> accuracy GEMM / top-1 / count (second stream) -> feature split -> fused InfoNCE forward + gradient matrices -> dA GEMMs
+    -> [encoder backward] -> join -> fused AdamW + gradient clear
+
+replayed by ONE foreign call (eegclip_plan_run).  The launches, their order, their arguments and the random-number consumption are exactly those of
+the launch-by-launch path -- tests/test_product_on_emulator.py trains both ways and compares parameters bit for bit -- so this is a host-side
+optimisation only; anything outside the steady state (first steps of a run, another batch size, a user-supplied loss or optimizer, gradient
+accumulation, data parallelism, the joint-subject model) takes the ordinary path.  EEGCLIP_STEP_PLAN=0 disables it.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _abi
+from ._lib import cuda_available, lib, raw_stream
+from .plan import Plan
+
+D = _abi.dim
+
+
+def enabled():
+    return os.environ.get("EEGCLIP_STEP_PLAN", "1") != "0"
+
+
+def _runtime_ok():
+    return cuda_available()
+
+
+def _on_device(t):
+    return t.is_cuda
+
+
+class StepPlan:
+    """the steady-state contrastive step of one (model, optimizer, batch size, loss mix) as a single launch plan"""
+
+    WARM_STEPS = 3          # ordinary steps before the plan is built: they create the encoder plans, the activation buffers and the optimizer's launch cache
+
+    def __init__(self, model, optimizer, B, alpha, n_classes):
+        from . import loss as eloss
+        from .atms import P_DIM
+        eng = model._engine()
+        self.model, self.optimizer, self.eng, self.B, self.alpha, self.n_classes = model, optimizer, eng, B, float(alpha), n_classes
+        key = eng.last_key
+        self.key = key
+        Bk, train, shared, probs, W = key
+        assert Bk == B and train and W == 1
+        self.fwd = eng.plans[("f",) + key]
+        self.bwd = eng.plans[("b", B, train, shared, probs, False, W, False)]
+        if self.fwd.tb_desc is None or self.bwd.x_gemm is not None or optimizer._fast_last.get(0) is None:
+            raise KeyError("the fused transformer-block plans and the optimizer's launch cache are required")
+        self.probs = probs
+        dev = eng.device
+        self.dev = dev
+        L = lib()
+        Dm = P_DIM
+        self.planes = 2 if model.loss_func.logits_dtype == "f32" else 1
+        pl = Plan(f"contrastive_step[B={B}]", precision=self.fwd.precision)
+        pl._keep += [self.fwd, self.bwd]
+
+        def splice(src):
+            base = len(pl.ops)
+            for fn, args, name, side in src.ops:
+                pl.ops.append((fn, list(args), name, side))
+            pl._seed_slots += [(base + i, j) for i, j in src._seed_slots]
+            pl._seed_descs += src._seed_descs
+            return base
+
+        # ---- encoder forward
+        f0 = splice(self.fwd)
+        self.fwd_base = f0
+        self.out_op = f0 + self.fwd.out_op
+        # ---- running train accuracy: raw z @ class_feats^T, top-1, count (second stream, under everything that follows)
+        self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
+        self.pred = torch.empty(B, 1, dtype=torch.long, device=dev)
+        self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
+                                      Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
+                                      drop_site=0, split_k=1, precision=self.fwd.precision)
+        pl._keep.append(self.acc_desc)
+        sc_ptr = model.logit_scale.detach().reshape(1).data_ptr()
+        pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
+        pl.call("eegclip_topk_rows", self.logits.data_ptr(), B, n_classes, n_classes, 1, sc_ptr, self.pred.data_ptr(), side=True)
+        self.count_op = len(pl.ops)
+        pl.call("eegclip_count_equal", self.pred.data_ptr(), 1, 0, B, 0, side=True)
+        # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch)
+        self.plane_buf = torch.empty(3, 2, B, Dm, dtype=torch.bfloat16, device=dev)
+        self.items = (_abi.SplitItem * 3)()
+        for i in range(3):
+            self.items[i] = _abi.SplitItem(src=0, hi=self.plane_buf[i, 0].data_ptr(), lo=self.plane_buf[i, 1].data_ptr(), rows=B, cols=Dm, ld_src=Dm, ld_out=Dm,
+                                           transpose=0)
+        pl._keep.append(self.items)
+        pl.call("eegclip_split_rows", self.items, 3)
+        ws = int(L.eegclip_infonce_fused_workspace_floats(B, B))
+        self.if_buf = torch.empty(4 * (ws + 2 * B), dtype=torch.float32, device=dev)
+        self.G = torch.empty(2, B, B, dtype=torch.float32, device=dev)
+        base = self.if_buf.data_ptr()
+
+        def planes_of(i):
+            return (self.plane_buf[i, 0].data_ptr(), self.plane_buf[i, 1].data_ptr() if self.planes == 2 else None)
+
+        ap = planes_of(0)
+        arr = (_abi.InfonceProblem * 4)()
+        weights = (self.alpha, 1.0 - self.alpha)
+        for t_, w in enumerate(weights):
+            bp = planes_of(1 + t_)
+            for j, (q, k) in enumerate(((ap, bp), (bp, ap))):
+                o = base + 4 * (2 * t_ + j) * (ws + 2 * B)
+                arr[2 * t_ + j] = _abi.InfonceProblem(q_hi=q[0], q_lo=q[1], k_hi=k[0], k_lo=k[1], col0=0, weight=0.5 * w, part=o, diag=o + 4 * ws,
+                                                      lse=o + 4 * (ws + B), lse_k=None, G=None, ldg=0)
+        garr = (_abi.InfonceProblem * 2)()
+        for t_ in range(2):
+            garr[t_] = arr[2 * t_]
+            garr[t_].G, garr[t_].ldg = self.G[t_].data_ptr(), B
+            garr[t_].lse_k = arr[2 * t_ + 1].lse
+        pl._keep += [arr, garr]
+        self.if_fwd_op = len(pl.ops)
+        pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
+        pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
+        self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
+        self.da_descs = []
+        for t_ in range(2):
+            d = _abi.GemmDesc(M=B, N=Dm, K=B, A=self.G[t_].data_ptr(), Am=D(B), Ak=D(1), B=0, Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(), Cm=D(Dm), Cn=D(1),
+                              Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=int(t_ > 0), act=0, drop_p=0.0, seed=0,
+                              drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
+            pl._keep.append(d)
+            self.da_descs.append(d)
+            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
+        # ---- encoder backward
+        b0 = splice(self.bwd)
+        self.bwd_base = b0
+        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
+        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
+        pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
+        # ---- fused AdamW + the zero_grad() that opens the next iteration
+        fast = optimizer._fast_last.get(0)
+        self.fast = fast
+        self.group = optimizer.param_groups[0]
+        self.adam_ops = []
+        gs = optimizer.grad_scale_dev.data_ptr() if optimizer.grad_scale_dev is not None else None
+        b1, b2 = self.group["betas"]
+        for (p0, n, wp, gp, mp, vp, members) in fast["launch"]:
+            self.adam_ops.append(len(pl.ops))
+            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"], 0, 1.0, gs)
+        self.hyper = (self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"])
+        self.pl = pl
+        self._class_ptr = None
+
+    # ------------------------------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def eligible(model, optimizer, eeg_data, subject_id, img, txt, labels, class_feats, objective, keep_grads, world):
+        """can this call go through a step plan at all (cheap checks, every step)"""
+        from .atms import ATMS
+        from .loss import ClipLoss, fused_enabled
+        from .optim import AdamW
+        if not (enabled() and world == 1 and objective == "retrieval" and not keep_grads and _runtime_ok()):
+            return False
+        if not (isinstance(model, ATMS) and not model.joint_train and model.training and isinstance(subject_id, int)):
+            return False
+        lf = model.loss_func
+        if type(lf) is not ClipLoss or lf.world_size != 1:
+            return False
+        if not isinstance(optimizer, AdamW) or len(optimizer.param_groups) != 1 or optimizer.grad_scale_dev is not None:
+            return False
+        B = eeg_data.shape[0]
+        for t_, shape in ((eeg_data, None), (img, (B, 1024)), (txt, (B, 1024)), (class_feats, None)):
+            if not (_on_device(t_) and t_.dtype == torch.float32 and t_.is_contiguous() and not t_.requires_grad):
+                return False
+            if shape is not None and tuple(t_.shape) != shape:
+                return False
+        if labels.dtype != torch.long or not _on_device(labels) or labels.numel() != B or class_feats.dim() != 2 or class_feats.shape[1] != 1024:
+            return False
+        return bool(fused_enabled(B, B, 1024))
+
+    def still_valid(self, model, optimizer):
+        """the captured state is still the live one: same engine / plans / optimizer launch cache, nobody attached gradients or changed hyper-parameters"""
+        eng = self.eng
+        if model._eng is not eng or eng.stale(model) or eng.plans.get(("f",) + self.key) is not self.fwd:
+            return False
+        if model.drop_probs(True) != self.probs or optimizer._fast_last.get(0) is not self.fast:
+            return False
+        g = self.group
+        if optimizer.param_groups[0] is not g or (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]) != self.hyper:
+            b1, b2 = g["betas"]
+            if optimizer.param_groups[0] is not g:
+                return False
+            self.hyper = (g["lr"], b1, b2, g["eps"], g["weight_decay"])       # (a learning-rate schedule: patch the optimizer launches)
+            for op in self.adam_ops:
+                for j, v in zip((5, 6, 7, 8, 9), self.hyper):
+                    self.pl.set_arg(op, j, v)
+        return all(p.grad is None for p in g["params"])
+
+    def run(self, eeg_data, img, txt, labels, class_feats, correct):
+        """enqueue one step; returns (features (B,1024), loss scalar) -- both device tensors, no host sync"""
+        from .loss import _zero_pair
+        eng, pl, B = self.eng, self.pl, self.B
+        b = eng.bufs[B]
+        self.fwd.tb_desc.x = eeg_data.data_ptr()
+        out = torch.empty(B, 1024, dtype=torch.float32, device=self.dev)
+        op = out.data_ptr()
+        pl.set_arg(self.out_op, 8, op)
+        self.acc_desc.A = op
+        cp = class_feats.data_ptr()
+        if cp != self._class_ptr:
+            self.acc_desc.B = cp
+            self._class_ptr = cp
+        pl.set_arg(self.count_op, 2, labels.data_ptr())
+        pl.set_arg(self.count_op, 4, correct.data_ptr())
+        self.items[0].src, self.items[1].src, self.items[2].src = op, img.data_ptr(), txt.data_ptr()
+        self.da_descs[0].B, self.da_descs[1].B = img.data_ptr(), txt.data_ptr()
+        acc = _zero_pair(self.dev)
+        pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
+        fast = self.fast
+        fast["run_steps"] = [st + 1 for st in fast["run_steps"]]
+        fast["pending"] += 1
+        for opi, st in zip(self.adam_ops, fast["run_steps"]):
+            pl.set_arg(opi, 10, st)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if max(self.probs) > 0 else 0
+        b["seed"] = seed
+        pl._keep_step = (eeg_data, img, txt, labels, class_feats, out)      # (alive until the next step has been enqueued)
+        pl.run(raw_stream(), seed)
+        # what the launch-by-launch path leaves behind
+        b["zb_clean"] = False
+        eng.last_key = self.key
+        eng.version[B] = eng.version.get(B, 0) + 1
+        for own, ptrs in fast["owners"]:
+            own.grads_cleared(ptrs)
+        return out, acc[0].reshape(())

@@ -529,3 +529,40 @@ def test_retrieval_accuracy_after_training_matches_the_oracle():
     assert o5 > 3 * 5 / n_test                                    # the model has learnt something: well above the 2.5 % chance level
     assert abs(g1 - o1) <= 0.001 + 1e-9 and abs(g5 - o5) <= 0.001 + 1e-9, ((g1, g5), (o1, o5))       # +-0.1 %
     assert int((tg[:, 0] != to[:, 0]).sum()) <= n_test // 200        # <= 0.5 % of the top-1 INDICES may differ (near-ties); the accuracies above may not
+
+
+def test_single_submission_step_plan_trains_like_the_launch_by_launch_loop(state_np, monkeypatch):
+    """step_plan.StepPlan on the hardware: 10 contrastive steps at B = 256 (3 of them the ordinary warm-up) against the same 10 steps with
+    EEGCLIP_STEP_PLAN=0, dropout on (same seeds: the plan consumes the RNG exactly like the ordinary path).  Per-step losses and the accuracy count agree;
+    the parameters agree as two runs of the ordinary path do (float atomics are unordered; AdamW's first updates are lr * sign(g)).  The plan is ONE
+    foreign call per step."""
+    from eeg_image_decode_amd import optim, retrieval, step_plan
+    B, NC, steps = 256, 200, 10
+    cls = T(syn.unit_features(SEED + 4, NC, tag="c")).cuda()
+    rng = np.random.default_rng(1)
+    data = [(T(syn.eeg_batch(SEED + 100 + i, B)).cuda(), T(syn.unit_features(SEED + 200 + i, B, tag="i")).cuda(), T(syn.unit_features(SEED + 300 + i, B, tag="t")).cuda(),
+             T(rng.integers(0, NC, size=B).astype(np.int64)).cuda()) for i in range(steps)]
+    runs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EEGCLIP_STEP_PLAN", mode)
+        torch.manual_seed(11)
+        m = make_model(state_np).train()
+        opt = optim.AdamW(m.parameters(), lr=3e-4)
+        acc, correct = [], torch.zeros(1, dtype=torch.int32, device="cuda")
+        feats = [retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct) for x, img, txt, lab in data]
+        plans = [st["plan"] for st in getattr(m._engine(), "_step_plans", {}).values()]
+        assert (len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)) == (mode == "1")
+        assert all(p.grad is None for p in m.parameters())
+        runs.append(([float(l) for l in acc], int(correct), feats[3].cpu().numpy(), {k: p.detach().cpu().numpy() for k, p in m.named_parameters()},
+                     {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k}, opt.state_dict()["state"][0]["step"]))
+    (la, ca, fa, pa, ba, sa), (lb, cb, fb, pb, bb, sb) = runs
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+    assert abs(ca - cb) <= 2 and sa == sb == steps
+    np.testing.assert_allclose(fa, fb, atol=2e-3)                       # the first step through the plan (after 3 ordinary ones)
+    for k in ba:
+        np.testing.assert_allclose(ba[k], bb[k], rtol=1e-3, atol=1e-5)
+    for k in pa:
+        if k.endswith("key_projection.bias"):
+            continue
+        d = np.abs(pa[k] - pb[k])
+        assert d.max() <= steps * 3e-4 * 1.01 and (d > 3e-4).mean() <= 0.02, (k, float(d.max()), float((d > 3e-4).mean()))

@@ -830,3 +830,59 @@ def test_sdxl_schedulers_reproduce_their_defining_identities():
             oe.i = i
             np.testing.assert_allclose(cx * x + ce * eps + cn * nz, oe.step(eps, x, nz), rtol=1e-10, atol=1e-10)
         assert e.coefficients(n - 1)[2] == 0.0                    # the last step lands on sigma = 0: no noise is added
+
+
+def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch):
+    """step_plan.StepPlan (the whole steady-state step -- forward, accuracy readout, fused InfoNCE, backward, AdamW -- replayed by ONE eegclip_plan_run call)
+    against retrieval's launch-by-launch step FROM THE SAME STATE: after two ordinary steps (they create the plans and the optimizer's launch cache) the
+    model / optimizer / RNG state is snapshotted, the third step runs through the plan, then again the ordinary way from the snapshot.  Same features, loss
+    and accuracy count (computed before the update); the parameters agree as two runs of the ordinary path do.  (With a single-threaded emulator, where float
+    atomics are ordered, four such steps are bit-identical: HIPEMU_THREADS=1, 12 minutes.)  The fused InfoNCE kernels take whole 64-tiles: B = 64."""
+    import copy
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B, NC = 64, 40
+    cls = T(syn.unit_features(SEED + 4, NC, tag="c"))
+    rng = np.random.default_rng(1)
+    data = [(T(syn.eeg_batch(SEED + 100 + i, B)), T(syn.unit_features(SEED + 200 + i, B, tag="i")), T(syn.unit_features(SEED + 300 + i, B, tag="t")),
+             T(rng.integers(0, NC, size=B).astype(np.int64))) for i in range(3)]
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim, retrieval, step_plan
+        monkeypatch.setattr(step_plan, "_runtime_ok", lambda: True)
+        monkeypatch.setattr(step_plan, "_on_device", lambda t: True)
+        monkeypatch.setattr(step_plan.StepPlan, "WARM_STEPS", 2)
+        torch.manual_seed(5)
+        m = make_model(state_np).train()
+        opt = optim.AdamW(m.parameters(), lr=3e-4)
+        acc, correct = [], torch.zeros(1, dtype=torch.int32)
+        for x, img, txt, lab in data[:2]:
+            retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct)
+        assert not any(st["plan"] for st in m._engine()._step_plans.values())           # warm-up: the ordinary path
+        snap = (copy.deepcopy(m.state_dict()), copy.deepcopy(opt.state_dict()), torch.get_rng_state(), correct.clone())
+        x, img, txt, lab = data[2]
+        f_plan = retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct)
+        plans = [st["plan"] for st in m._engine()._step_plans.values()]
+        assert len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)             # the third step went through the plan ...
+        names = plans[0].pl.op_names()
+        assert names.count("eegclip_adamw_step_zero_grad") >= 1 and "eegclip_infonce_fused_fwd" in names and names[-1].startswith("eegclip_adamw")
+        assert all(p.grad is None for p in m.parameters()) and float(m._engine().gflat.abs().max()) == 0.0
+        res_plan = ({k: p.detach().clone() for k, p in m.named_parameters()}, float(acc[-1]), int(correct), f_plan.clone(),
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+        # ... and once more the ordinary way, from the same state
+        monkeypatch.setenv("EEGCLIP_STEP_PLAN", "0")
+        m2 = make_model(state_np).train()
+        m2.load_state_dict(snap[0])
+        opt2 = optim.AdamW(m2.parameters(), lr=3e-4)
+        opt2.load_state_dict(snap[1])
+        torch.set_rng_state(snap[2])
+        acc2, correct2 = [], snap[3].clone()
+        f_ord = retrieval.contrastive_step(m2, opt2, x, 1, img, txt, lab, cls, acc2, correct2)
+        assert not getattr(m2._engine(), "_step_plans", {})
+    np.testing.assert_allclose(res_plan[3].numpy(), f_ord.numpy(), atol=2e-5)            # (the head's split-K atomics: unordered under the multi-threaded emulator)
+    assert abs(res_plan[1] - float(acc2[-1])) < 1e-5 * abs(res_plan[1]) and res_plan[2] == int(correct2)
+    for k, v in res_plan[4].items():
+        np.testing.assert_allclose(v.numpy(), m2.state_dict()[k].numpy(), rtol=1e-5, atol=1e-6)
+    for k, p in m2.named_parameters():
+        if k.endswith("key_projection.bias"):
+            continue
+        d = np.abs(res_plan[0][k].numpy() - p.detach().numpy())
+        assert d.max() <= 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
