@@ -223,6 +223,7 @@ PROTOTYPES = {
     "eegclip_plan_run": [C.POINTER(PlanOp), _I, _I, _I, _P, _P, _P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "eegclip_topk_rows": [_P, _I, _I, _L, _I, _P, _P, _P],
     "eegclip_count_equal": [_P, _I, _P, _I, _P, _P],
+    "eegclip_top1_count": [_P, _I, _I, _L, _P, _P, _P, _P],
     "eegclip_timing_event_create": [],
     "eegclip_timing_event_destroy": [_P],
     "eegclip_time_next_launch": [_P, _P],

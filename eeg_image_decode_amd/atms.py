@@ -190,6 +190,7 @@ class Proj_eeg(nn.Sequential):
 
 
 # flat-buffer order: the always-live group first (QKV adjacent), then the two conditionally-live token tensors, then dead
+WGRAD_TOK_MAX_PROBLEMS = 12          # csrc/wgrad_tok.hip: WK_MAXP
 _E, _LY, _TS = "encoder.enc_embedding.", "encoder.encoder.attn_layers.0.", "enc_eeg.0.tsconv."
 _LIVE = [
     # gradients that are complete EARLY in the backward first (loss -> head -> conv stack: 10.5 of the 12.8 MB), the transformer's after them: under
@@ -352,13 +353,22 @@ def _head_split(B):
 
 class _Engine:
     """Flat parameter/gradient storage + per-batch-size activation buffers and launch plans."""
-    check_cleared = False        # debug: verify the flat gradient buffer whenever attach_grads() skips its clear (see there)
+    check_cleared = False
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise EegclipError("the ATMS model of this engine has been garbage-collected")
+        return m
+        # debug: verify the flat gradient buffer whenever attach_grads() skips its clear (see there)
 
     def __init__(self, model):
         sd_params = dict(model.named_parameters())
         dev = model.logit_scale.device
         self.device = dev
-        self.model = model
+        self._model_ref = weakref.ref(model)          # (weak: model._eng -> engine is the only strong edge, so a dropped model frees its engine --
+        #                                                 flat buffers, activation buffers, plans -- even after retrieval.settle_gc()'s gc.freeze())
         # joint-subject model: the single value embedding is replaced by one Linear per subject, each live only in steps whose batch holds
         # that subject (the reference never touches the others: their .grad stays None and AdamW skips them)
         self.joint = bool(model.joint_train)
@@ -433,6 +443,9 @@ class _Engine:
         """the fused transformer-block forward (csrc/token_block.hip) in the default split-bf16 arithmetic -- since round 4 also for the joint-subject
         model (its value embedding is a per-sample weight base inside the kernel); EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan
         (diagnosis, A/B timing)"""
+        if self.joint and self.n_subj > WGRAD_TOK_MAX_PROBLEMS:
+            return False        # the per-subject value-embedding gradients are ONE eegclip_wgrad_tok launch (<= 12 problems): larger subject tables take the
+            #                     grouped-GEMM plans, which split into per-member launches (the reference takes any num_subjects, Embed.py:127-131)
         return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_TOKEN_BLOCK", "1") != "0"
 
     def _token_planes(self, b, B, *names):

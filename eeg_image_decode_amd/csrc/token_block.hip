@@ -1271,6 +1271,9 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
                   d->embed_subject ? d->bv_stride : 0};
     if (d->embed_subject && (!d->packed_embed || (reinterpret_cast<uintptr_t>(d->packed_embed) & 15u) || d->bv_stride < 0 || (d->bv_stride & 1))) return EEGCLIP_EINVAL;
     static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
+    //  bit 0 leaves out every activation / plane store -- a timing ablation.  The weight-gradient operands exist ONLY as those planes, so a stray
+    // environment variable would make training read uninitialised memory: refuse the combination instead of producing silent garbage.
+    if ((dbg & 1u) && (d->xp || d->hp || d->ctxp || d->n1p || d->g1p)) return EEGCLIP_EINVAL;
     a.dbg = dbg;
     a.tstamp = nullptr;
 #if !defined(EEG_EMU)

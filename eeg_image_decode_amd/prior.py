@@ -351,8 +351,10 @@ class _PriorEngine:
     def _planes_ok(self, N, cond_rows):
         m = self.model
         dims = [m.embed_dim, m.time_embed_dim] + list(m.hidden_dim) + ([m.cond_dim] if m.cond_dim else [])
+        # (eegclip_split_transpose takes at most 24 items -- GPT_MAX of csrc/gemm_planes.hip -- and the planes plan passes 2 per stage + 1: deeper stacks keep the
+        #  general GEMM plans)
         return (cond_rows is None and N % 64 == 0 and all(d % 64 == 0 for d in dims) and default_gemm_precision() == _abi.PREC_BF16X3
-                and os.environ.get("EEGCLIP_PRIOR_PLANES", "1") != "0")
+                and 2 * len(self.stages) + 1 <= 24 and os.environ.get("EEGCLIP_PRIOR_PLANES", "1") != "0")
 
     def _alloc_planes(self, N, b):
         if "xp" in b:

@@ -238,8 +238,10 @@ def running_loss(loss_acc):
 
 def _accumulate_accuracy(eeg_features, class_feats, logit_scale, labels, batch_size, correct):
     from .plan import default_gemm_precision
-    pred = topk_retrieval(eeg_features, class_feats, logit_scale, 1, default_gemm_precision())
-    check(lib().eegclip_count_equal(pred.data_ptr(), 1, labels.data_ptr(), batch_size, correct.data_ptr(), _stream()), "count_equal")
+    logits = scaled_logits(eeg_features.detach().float(), class_feats.detach().float(), default_gemm_precision())
+    sc = logit_scale.detach().reshape(1) if torch.is_tensor(logit_scale) else torch.full((1,), float(logit_scale), dtype=torch.float32, device=logits.device)
+    check(lib().eegclip_top1_count(logits.data_ptr(), batch_size, logits.shape[1], logits.stride(0), sc.data_ptr(), labels.data_ptr(), correct.data_ptr(),
+                                   _stream()), "top1_count")
 
 
 def train_model(sub, eeg_model, dataloader, optimizer, device, text_features_all, img_features_all, config, objective="retrieval", alpha=0.99):

@@ -79,16 +79,14 @@ class StepPlan:
         self.out_op = f0 + self.fwd.out_op
         # ---- running train accuracy: raw z @ class_feats^T, top-1, count (second stream, under everything that follows)
         self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
-        self.pred = torch.empty(B, 1, dtype=torch.long, device=dev)
         self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
                                       Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
                                       drop_site=0, split_k=1, precision=self.fwd.precision)
         pl._keep.append(self.acc_desc)
         sc_ptr = model.logit_scale.detach().reshape(1).data_ptr()
         pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
-        pl.call("eegclip_topk_rows", self.logits.data_ptr(), B, n_classes, n_classes, 1, sc_ptr, self.pred.data_ptr(), side=True)
         self.count_op = len(pl.ops)
-        pl.call("eegclip_count_equal", self.pred.data_ptr(), 1, 0, B, 0, side=True)
+        pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch)
         self.plane_buf = torch.empty(3, 2, B, Dm, dtype=torch.bfloat16, device=dev)
         self.items = (_abi.SplitItem * 3)()
@@ -210,8 +208,8 @@ class StepPlan:
         if cp != self._class_ptr:
             self.acc_desc.B = cp
             self._class_ptr = cp
-        pl.set_arg(self.count_op, 2, labels.data_ptr())
-        pl.set_arg(self.count_op, 4, correct.data_ptr())
+        pl.set_arg(self.count_op, 5, labels.data_ptr())
+        pl.set_arg(self.count_op, 6, correct.data_ptr())
         self.items[0].src, self.items[1].src, self.items[2].src = op, img.data_ptr(), txt.data_ptr()
         self.da_descs[0].B, self.da_descs[1].B = img.data_ptr(), txt.data_ptr()
         acc = _zero_pair(self.dev)

@@ -411,6 +411,9 @@ int eegclip_cross_attn_fwd(const void* q, const void* k, const void* v, const vo
 int eegclip_topk_rows(const float* X, int rows, int cols, long long ld, int k, const float* scale /* device scalar or NULL: rank by scale*x */,
                       long long* out_idx, void* stream);
 int eegclip_count_equal(const long long* pred, int stride, const long long* labels, int n, int* count, void* stream);
+/* *count += #{rows whose arg-max column of scale * X (ties -> lowest index) equals labels[row]}: top-1 + comparison of the running train accuracy
+ * (ATMS_retrieval.py:241-250) in one launch */
+int eegclip_top1_count(const float* X, int rows, int cols, long long ld, const float* scale, const long long* labels, int* count, void* stream);
 
 /* ---- launch-plan executor: the forward / backward of the encoder are fixed sequences of the entry points above (~50 per direction).  Issuing
  * them one foreign call at a time from Python costs ~5 us each -- more than the GPU needs for most of them -- so a sequence is described ONCE as an

@@ -696,3 +696,20 @@ def test_proj1x1_fused_stage(be, B, p):
     np.testing.assert_allclose(be.host(DY2), yt.grad.numpy(), atol=1e-6 + 3e-4 * np.abs(yt.grad.numpy()).max())
     np.testing.assert_allclose(be.host(DG), gt.grad.numpy(), atol=3e-4 * max(1.0, np.abs(gt.grad.numpy()).max()))
     np.testing.assert_allclose(be.host(DB), btt.grad.numpy(), atol=3e-4 * max(1.0, np.abs(btt.grad.numpy()).max()))
+
+
+@pytest.mark.parametrize("rows,cols,neg", [(256, 1654, False), (5, 7, True), (64, 200, False)])
+def test_top1_count(be, rows, cols, neg):
+    """eegclip_top1_count == arg-max per row (ties -> lowest index, ranking by scale * x) compared with the labels, counted"""
+    rng = np.random.default_rng(rows + cols)
+    x = rnd(rng, rows, cols)
+    x[0, :] = 1.0                                          # a row of ties: index 0 (or the lowest index under a negative scale, too)
+    x[1 % rows, [2 % cols, 5 % cols]] = 9.0
+    labels = rng.integers(0, cols, size=rows).astype(np.int64)
+    sc = np.array([-2.0 if neg else 2.5], np.float32)
+    ref = np.argmax(sc[0] * x, axis=1)
+    labels[::3] = ref[::3]
+    X, LAB, SC, CNT = be.dev(x), be.dev(labels), be.dev(sc), be.dev(np.array([7], np.int32))
+    ok(be.lib.eegclip_top1_count(be.ptr(X), rows, cols, cols, be.ptr(SC), be.ptr(LAB), be.ptr(CNT), be.stream))
+    assert int(be.host(CNT)[0]) == 7 + int((ref == labels).sum())
+    assert be.lib.eegclip_top1_count(be.ptr(X), rows, cols, cols - 1, be.ptr(SC), be.ptr(LAB), be.ptr(CNT), be.stream) < 0

@@ -257,7 +257,11 @@ def test_train_model_matches_reference_fixture(state_np, golden, which_opt, arit
         losses.append(l)
         accs.append(a)
         if ep == 0:
-            np.testing.assert_allclose(feats.cpu().numpy()[:, :64], g["feats_ep0"], atol=1e-3)
+            # first batch = a pure forward of the initial weights (held to 1e-4 / 1e-5 of north_star's 1e-3); the later batches follow AdamW steps that
+            # amplify arithmetic noise ~35x (see test_reconstruction_train_model_matches_reference_fixture)
+            f = feats.cpu().numpy()[:, :64]
+            np.testing.assert_allclose(f[:B], g["feats_ep0"][:B], atol=1e-4 if arith == "bf16x3" else 1e-5)
+            np.testing.assert_allclose(f, g["feats_ep0"], atol=3e-3 if arith == "bf16x3" else 3e-4)
     np.testing.assert_allclose(losses, g["losses"], atol=5e-4)
     np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
     for k, p in m.named_parameters():

@@ -886,3 +886,49 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch):
             continue
         d = np.abs(res_plan[0][k].numpy() - p.detach().numpy())
         assert d.max() <= 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
+
+
+def test_joint_subject_model_with_more_subjects_than_one_weight_gradient_launch_holds():
+    """eegclip_wgrad_tok takes <= 12 problems per launch; a joint-subject model with a larger subject table (atms.ATMS(table_subjects=14):
+    the reference takes any num_subjects, Embed.py:127-131) must still train -- it takes the grouped-GEMM plans instead of the fused block.  Checked against
+    a 10-subject model carrying the same value embeddings for the subjects of the batch: same embeddings, same gradients."""
+    ids14, ids10 = [13, 0, 13, 5], [3, 0, 3, 5]
+    B = 4
+    x0 = T(syn.eeg_batch(SEED + 43, B))
+    img, txt = T(syn.unit_features(SEED + 43, B, tag="img")), T(syn.unit_features(SEED + 43, B, tag="txt"))
+    with product_on_emulator():
+        from eeg_image_decode_amd import atms
+        torch.manual_seed(3)
+        big = atms.ATMS(joint_train=True, table_subjects=14)
+        small = atms.ATMS(joint_train=True, table_subjects=10)
+        sd_b, sd_s = big.state_dict(), small.state_dict()
+        for k in sd_s:
+            if ".value_embedding." in k:
+                s_ = int(k.split(".value_embedding.")[1].split(".")[0])
+                sd_s[k] = sd_b[k.replace(f".value_embedding.{s_}.", f".value_embedding.{13 if s_ == 3 else s_}.")].clone()
+            elif sd_s[k].shape == sd_b[k].shape:
+                sd_s[k] = sd_b[k].clone()
+            else:                                              # the subject-token table: rows of the subjects present
+                sd_s[k] = sd_b[k][:sd_s[k].shape[0]].clone()
+                sd_s[k][3] = sd_b[k][13]
+        small.load_state_dict(sd_s)
+        res = []
+        for m, ids in ((big, ids14), (small, ids10)):
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            m.train()
+            z = m(x0, torch.tensor(ids))
+            (0.99 * m.loss_func(z, img, m.logit_scale) + 0.01 * m.loss_func(z, txt, m.logit_scale)).backward()
+            names = m._engine().plans[next(k for k in m._engine().plans if k[0] == "f")].op_names()
+            res.append((z.detach().clone(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}, names))
+    assert "eegclip_token_block_fwd" not in res[0][2] and "eegclip_gemm_f32_grouped" in res[0][2]          # 14 subjects: launch-per-Linear plans
+    assert "eegclip_token_block_fwd" in res[1][2]
+    np.testing.assert_allclose(res[0][0].numpy(), res[1][0].numpy(), atol=1e-4)
+    gb, gs = res[0][1], res[1][1]
+    for s_big, s_small in ((13, 3), (0, 0), (5, 5)):
+        for leaf in ("weight", "bias"):
+            a, b = gb[f"encoder.enc_embedding.value_embedding.{s_big}.{leaf}"], gs[f"encoder.enc_embedding.value_embedding.{s_small}.{leaf}"]
+            np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-7 + 3e-3 * float(b.abs().max()))
+    assert gb["encoder.enc_embedding.value_embedding.7.weight"] is None and gb["encoder.enc_embedding.value_embedding.12.weight"] is None
+    np.testing.assert_allclose(gb["proj_eeg.0.weight"].numpy(), gs["proj_eeg.0.weight"].numpy(), atol=3e-3 * float(gs["proj_eeg.0.weight"].abs().max()))
