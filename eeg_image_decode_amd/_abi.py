@@ -156,6 +156,7 @@ PROTOTYPES = {
     "eegclip_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_attention_bwd_x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_proj1x1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
+    "eegclip_proj1x1_fwd_rows": [_P, _P, _I, _D, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_proj1x1_bwd_workspace_floats": [_I],
     "eegclip_proj1x1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
     "eegclip_cast_bf16": [_P, _P, _L, _P],
@@ -212,6 +213,7 @@ PROTOTYPES = {
     "eegclip_cstack_fwd": [C.POINTER(CstackFwdDesc), _P],
     "eegclip_cstack_packed_t_bytes": [_I],
     "eegclip_cstack_pack_t": [_P, _P, _I, _P],
+    "eegclip_cstack_pack_all": [_P, _P, _P, _I, _P],
     "eegclip_cstack_bwd_stats": [C.POINTER(CstackBwdDesc), _P],
     "eegclip_cstack_bwd_workspace_floats": [_I],
     "eegclip_cstack_bwd_apply": [C.POINTER(CstackBwdDesc), _P],

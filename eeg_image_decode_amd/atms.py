@@ -540,6 +540,16 @@ class _Engine:
             pl._keep.append(items)
             pl.call("eegclip_split_rows", items, n_items)
         pl.tb_desc = None
+        cstack = self._cstack_enabled(pl)
+        if cstack:
+            # nothing before the conv stack needs them: the arena clear and the conv stack's weight fragments go to the second stream, under the
+            # transformer block; the main stream joins in front of the conv stack
+            pl.memset(b["zfb"] if train else b["zf"], side=True)
+            pl.clears_zb = train
+            if not hasattr(self, "cs_packed"):
+                self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
+                self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
+            pl.call("eegclip_cstack_pack_all", _p(P[_TS + "4.weight"]), _p(self.cs_packed), _p(self.cs_packed_t), N_CH, side=True)       # (both sets: an eval-mode forward may be followed by a backward too)
         if self._token_block_enabled(pl):
             # A1-A3 in ONE launch, one workgroup per sample (csrc/token_block.hip): the ten launches below it replace were bound by per-launch
             # prologue / epilogue and activation round trips, not by their K ~ 250 contractions
@@ -618,17 +628,26 @@ class _Engine:
                     _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
-        pl.memset(b["zfb"] if train else b["zf"])
-        pl.clears_zb = train
         W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
-        if self._cstack_enabled(pl):
-            self._build_fwd_cstack(pl, b, B, train, W)
+        bn2_rows = None
+        if cstack:
+            pl.join()
+            bn2_rows = self._build_fwd_cstack(pl, b, B, train, W)
         else:
+            pl.memset(b["zfb"] if train else b["zf"])
+            pl.clears_zb = train
             self._build_fwd_conv_y1(pl, b, B, train, W)
         # BN2 -> ELU -> dropout -> 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e], one workgroup per sample      (:107-114,145)
-        pl.call("eegclip_proj1x1_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
-                _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
-                seed_at=11)
+        if bn2_rows is not None:
+            # (the BatchNorm2 finalize rides in this kernel's prologue: the batch statistics as the per-sample partial rows eegclip_cstack_fwd left)
+            pl.call("eegclip_proj1x1_fwd_rows", _p(b["y2"]), _p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]),
+                    _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), _p(self.buffers[_TS + "5.num_batches_tracked"]),
+                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]),
+                    _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV, seed_at=19)
+        else:
+            pl.call("eegclip_proj1x1_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                    _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
+                    seed_at=11)
         # A6: projection head      (:157-167).  M = B is small (256): a 4 x 16 tile grid cannot fill 256 CUs and each workgroup walks K = 1440
         # serially, so the products are split over K (atomics into a zeroed buffer) and bias/GELU/dropout/residual run as a tiny epilogue.
         skh = _head_split(B)
@@ -664,13 +683,6 @@ class _Engine:
         bf16 matrix cores; the BatchNorm finalizes ride in the consumers' prologues / one rows kernel.      (ATMS_retrieval.py:91,102-106)"""
         P, sums, bn = self.P, b["sums"], b["bn"]
         dev = self.device
-        if not hasattr(self, "cs_packed"):
-            self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=dev)
-        pl.call("eegclip_cstack_pack", _p(P[_TS + "4.weight"]), _p(self.cs_packed), N_CH)
-        if self._cstack_bwd_enabled(pl):
-            if not hasattr(self, "cs_packed_t"):
-                self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=dev)
-            pl.call("eegclip_cstack_pack_t", _p(P[_TS + "4.weight"]), _p(self.cs_packed_t), N_CH)
         if "cs_rows" not in b:
             b["cs_rows"] = torch.empty(2, B, 2 * C_TS, dtype=torch.float64, device=dev)          # BatchNorm1 | BatchNorm2 partial rows, one per sample
         rows1, rows2 = b["cs_rows"][0], b["cs_rows"][1]
@@ -698,12 +710,13 @@ class _Engine:
         run2 = (_p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]))
         nbt2 = _p(self.buffers[_TS + "5.num_batches_tracked"])
         if train and W == 1:
-            pl.call("eegclip_bn_finalize_rows", _p(rows2), B, count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, nbt2, None)
+            return rows2                            # finalized in the prologue of eegclip_proj1x1_fwd_rows
         else:
             if train:
                 pl.call("eegclip_bn_finalize_rows", _p(rows2), B, count2, EPS, 0.1, C_TS, None, None, None, None, None, _p(sums[1]))
                 pl.callback(lambda: self._allreduce(sums[1]), "allreduce_bn2")
             pl.call("eegclip_bn_finalize", _p(sums[1]), count2, EPS, 0.1, C_TS, _p(bn[2]), _p(bn[3]), *run2, int(train), nbt2)
+        return None
 
     def _cstack_bwd_enabled(self, pl):
         """the conv-stack backward is recomputed from the token rows whenever the forward is (csrc/cstack_bwd.hip): y1 does not exist for anything else"""

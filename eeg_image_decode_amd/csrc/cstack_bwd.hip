@@ -20,9 +20,20 @@ namespace eeg {
 // per token row h and filter tile ct:  main hi | main lo (1024 B each: lane (n, kg) slot j <-> o = 16 (j >> 2) + 4 kg + (j & 3), filter c = 16 ct + n)
 //                                      tail hi | tail lo (512 B each: slot j < 4 <-> o = 32 + 4 kg + j, zero from o = 40)
 constexpr int CST_TILE = 3072, CST_ROW = 3 * CST_TILE;
+__device__ __forceinline__ void cstack_pack_t_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id);
 __global__ __launch_bounds__(256) void cstack_pack_t_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= H * 3 * 64) return;
+    cstack_pack_t_item(Ws, packed, H, id);
+}
+// both fragment sets of a step in ONE launch (the forward's, cstack_common.h: cs_pack_item, then the backward's)
+__global__ __launch_bounds__(256) void cstack_pack_all_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, unsigned char* __restrict__ packed_t, int H) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = 3 * ((H + 1) / 2) * 3 * 64;
+    if (id < n1) cs_pack_item(Ws, packed, H, id);
+    else if (packed_t && id - n1 < H * 3 * 64) cstack_pack_t_item(Ws, packed_t, H, id - n1);
+}
+__device__ __forceinline__ void cstack_pack_t_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id) {
     const int lane = id & 63, ct = (id >> 6) % 3, h = id / 192;
     const int n = lane & 15, kg = lane >> 4, c = 16 * ct + n;
     float v[8], tl[4];
@@ -589,6 +600,14 @@ static int csb_vec2(const float* x, long long xs_b, long long xs_h) {
 static int csw_groups(int B) { const int sg = (B + 3) / 4; return sg < 8 ? sg : 8; }      // slabs: 32 row blocks x 8 x 8 waves = 2 waves per SIMD
 
 extern "C" long long eegclip_cstack_packed_t_bytes(int H) { return (H < 1 || H > CS_MAXH) ? 0 : (long long)H * CST_ROW; }
+
+extern "C" int eegclip_cstack_pack_all(const float* Ws, void* packed, void* packed_t, int H, void* stream) {
+    if (!Ws || !packed || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(packed_t)) & 15u) return EEGCLIP_EALIGN;
+    const int nthr = 3 * ((H + 1) / 2) * 3 * 64 + (packed_t ? H * 3 * 64 : 0);
+    EEG_LAUNCH(cstack_pack_all_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, Ws, static_cast<unsigned char*>(packed), static_cast<unsigned char*>(packed_t), H);
+    return (int)hipGetLastError();
+}
 
 extern "C" int eegclip_cstack_pack_t(const float* Ws, void* packed_t, int H, void* stream) {
     if (!Ws || !packed_t || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;

@@ -316,4 +316,30 @@ __device__ __forceinline__ void cs_bn_rows_finish(const double* __restrict__ scr
     var_out = var;
 }
 
+// ---- packed spatial weights of the forward chain ---------------------------------------------------------------------------------------------------
+// Token rows are taken in pairs (h0, h1) = (2 q, 2 q + 1); pair q has three k-steps of 32:
+//   step 3q     k slot j of lane group kg <-> c = 16 (j >> 2) + 4 kg + (j & 3) (filters 0 .. 31) of row h0      = accumulator tiles ct 0 | 1 of h0
+//   step 3q + 1 the same of row h1
+//   step 3q + 2 slots 0 .. 3 <-> c = 32 + 4 kg + j of h0, slots 4 .. 7 <-> c = 32 + 4 kg + (j - 4) of h1 (c >= 40: zero)   = tile ct 2 of both rows
+// i.e. 2.5 accumulator tiles of real filters per row in 1.5 MFMA k-steps.  Fragment (step, ot, plane): 64 lanes x 16 bytes, lane (n, kg) <- o = 16 ot + n.
+constexpr int CSP_FRAG = 1024;                       // bytes
+__host__ __device__ inline long long csp_offset(int step, int ot, int plane) { return (((long long)step * 3 + ot) * 2 + plane) * CSP_FRAG; }
+__device__ __forceinline__ void cs_pack_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id) {
+    const int lane = id & 63, ot = (id >> 6) % 3, step = id / 192;
+    const int n = lane & 15, kg = lane >> 4, o = 16 * ot + n;
+    const int q = step / 3, kind = step % 3;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int c, h;
+        if (kind < 2) { c = 16 * (j >> 2) + 4 * kg + (j & 3); h = 2 * q + kind; }
+        else          { c = 32 + 4 * kg + (j & 3);            h = 2 * q + (j >> 2); }
+        v[j] = (o < CS_C && c < CS_C && h < H) ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+    bf16x8 hi, lo;
+    cs_split8(v, hi, lo);
+    *reinterpret_cast<bf16x8*>(packed + csp_offset(step, ot, 0) + 16 * lane) = hi;
+    *reinterpret_cast<bf16x8*>(packed + csp_offset(step, ot, 1) + 16 * lane) = lo;
+}
+
 }  // namespace eeg

@@ -16,20 +16,61 @@ constexpr int PJ_N = PJ_C * PJ_W;
 constexpr int PJ_LW = 41;      // padded row stride of the [e][c] / [w][e] images
 constexpr int PJ_PART = PJ_C * PJ_C + PJ_C + 2 * PJ_C;      // partial row of the backward: dW | dbias | BatchNorm-backward sums
 
+// rows != NULL (training, round 5): the BatchNorm2 batch statistics come as `nrows` partial rows [sum(40) | sumsq(40)] (fp64; what eegclip_cstack_fwd leaves
+// per sample) -- every workgroup sums them in a fixed order (3 slices x 80 columns, slices added in order: the same value everywhere, no atomics), workgroup
+// 0 stores mean / rstd for the backward and updates the running statistics + step counter: eegclip_bn_finalize's work without its launch.
 __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ z2,
-                                                           float* __restrict__ feat, int B, float drop_p, unsigned long long seed, unsigned site) {
+                                                           float* __restrict__ feat, int B, float drop_p, unsigned long long seed, unsigned site,
+                                                           const double* __restrict__ rows, int nrows, double count, float eps, float momentum,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, long long* __restrict__ nbt) {
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2 of this sample
     float* ws = zs + PJ_N;                // [40][41]  W[e][c]
+    float* aff = ws + PJ_C * PJ_LW;       // [40] scale | [40] shift of BatchNorm2
+    double* scr = reinterpret_cast<double*>(aff + 2 * PJ_C);      // [3][80] (rows != NULL)
     const int t = threadIdx.x, b = blockIdx.x;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     for (int i = t; i < PJ_C * PJ_C; i += 256) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = Wt[i];
+    if (rows) {
+        if (t < 3 * 2 * PJ_C) {
+            const int sl = t / (2 * PJ_C), col = t % (2 * PJ_C);
+            double s = 0.0;
+#pragma unroll 8
+            for (int r = sl; r < nrows; r += 3) s += rows[(long long)r * 2 * PJ_C + col];
+            scr[t] = s;
+        }
+        __syncthreads();
+        if (t < PJ_C) {
+            const double s = (scr[t] + scr[2 * PJ_C + t]) + scr[4 * PJ_C + t], q = (scr[PJ_C + t] + scr[3 * PJ_C + t]) + scr[5 * PJ_C + t];
+            const double m = s / count;
+            double var = q / count - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+            if (b == 0) {
+                mean_out[t] = mf;
+                rstd_out[t] = rs;
+                if (run_mean) {
+                    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                    run_mean[t] = (1.f - momentum) * run_mean[t] + momentum * mf;
+                    run_var[t] = (1.f - momentum) * run_var[t] + momentum * (float)unb;
+                }
+                if (t == 0 && nbt) *nbt += 1;
+            }
+            aff[t] = gamma[t] * rs;
+            aff[PJ_C + t] = beta[t] - mf * gamma[t] * rs;
+        }
+    } else if (t < PJ_C) {
+        aff[t] = gamma[t] * rstd[t];
+        aff[PJ_C + t] = beta[t] - mean[t] * gamma[t] * rstd[t];
+    }
+    __syncthreads();
     for (int i = t; i < PJ_N; i += 256) {
         const int c = i / PJ_W;
         const long long idx = (long long)b * PJ_N + i;
-        float v = elu1(gamma[c] * (y2[idx] - mean[c]) * rstd[c] + beta[c]);
+        float v = elu1(y2[idx] * aff[c] + aff[PJ_C + c]);
         if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? v * ks : 0.f;
         z2[idx] = v;
         zs[i] = v;
@@ -163,12 +204,27 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_reduce_kernel(const double* _
 
 using namespace eeg;
 
+static size_t pj_fwd_lds() { return (PJ_N + PJ_C * PJ_LW + 2 * PJ_C) * sizeof(float) + 6 * PJ_C * sizeof(double); }
+
 extern "C" int eegclip_proj1x1_fwd(const float* y2, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                                    const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site,
                                    void* stream) {
     if (!y2 || !mean || !rstd || !gamma || !beta || !W || !bias || !z2 || !feat || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
-    const size_t lds = (PJ_N + PJ_C * PJ_LW) * sizeof(float);
-    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), lds, stream, y2, mean, rstd, gamma, beta, W, bias, z2, feat, B, drop_p, seed, site);
+    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, mean, rstd, gamma, beta, W, bias, z2, feat, B, drop_p, seed, site,
+               (const double*)nullptr, 0, 1.0, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (long long*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_proj1x1_fwd_rows(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
+                                        const float* W, const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed,
+                                        unsigned int site, void* stream) {
+    if (!y2 || !rows || nrows < 1 || count < 1.0 || !mean || !rstd || !gamma || !beta || !W || !bias || !z2 || !feat || B < 1 || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, (const float*)nullptr, (const float*)nullptr, gamma, beta, W, bias, z2, feat, B,
+               drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
     return (int)hipGetLastError();
 }
 

@@ -119,9 +119,10 @@ class Plan:
         either stream have produced)"""
         self.ops.append((None, [fn], name, side))
 
-    def memset(self, tensor):
-        """zero a torch tensor as part of the plan (stream-ordered)"""
-        self.ops.append((None, [tensor], "memset", False))
+    def memset(self, tensor, side=False):
+        """zero a torch tensor as part of the plan (stream-ordered).  side=True: on the second stream, behind everything enqueued on the main stream so
+        far -- the main stream sees the cleared buffer after the next join()"""
+        self.ops.append((None, [tensor], "memset", bool(side)))
 
     def join(self):
         """the main stream waits for everything launched on the side stream so far"""
@@ -156,6 +157,7 @@ class Plan:
             if fn is None and name == "memset":
                 t = args[0]
                 arr[i].fn = _abi.PLAN_MEMSET
+                arr[i].flags = _abi.PLAN_SIDE if on_side else 0
                 arr[i].a[0].p, arr[i].a[1].i = t.data_ptr(), t.numel() * t.element_size()
                 slots.append(None)
             elif fn is None and name == "join":
@@ -345,7 +347,14 @@ class Plan:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side[0] if use_side else ts)
             if fn is None:
-                if name == "memset":
+                if name == "memset" and use_side:
+                    ev = side[1][idx]
+                    ev.record(ts)
+                    side[0].wait_event(ev)
+                    with use_stream(side[0]):
+                        args[0].zero_()
+                    dirty = True
+                elif name == "memset":
                     args[0].zero_()
                 elif name == "join":
                     if dirty:

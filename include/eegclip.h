@@ -385,6 +385,12 @@ int eegclip_infonce_fused_grad(const eegclip_infonce_problem* blocks, int n_bloc
  *        da = dz2 * mask/(1-p) * ELU'(BN(y2)) -- followed (after the SyncBN all-reduce of sums, if any) by eegclip_bn_elu_bwd_apply(dz2, y2, ...). */
 int eegclip_proj1x1_fwd(const float* y2, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                         const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+/* the same with the BatchNorm2 finalize folded in (training): the batch statistics come as `nrows` partial rows [sum(40) | sumsq(40)] (fp64, what
+ * eegclip_cstack_fwd leaves per sample) summed in a fixed order by every workgroup; workgroup 0 stores mean / rstd and updates the running statistics and
+ * the step counter (eegclip_bn_finalize's work without its launch) */
+int eegclip_proj1x1_fwd_rows(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta, const float* W,
+                             const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 /* workspace (optional, 8-byte aligned, eegclip_proj1x1_bwd_workspace_floats(B) floats, contents irrelevant): dW / dbias / sums are accumulated through
  * per-workgroup partial rows + a column reduction instead of 1720 contended atomics per workgroup */
 long long eegclip_proj1x1_bwd_workspace_floats(int B);
@@ -679,6 +685,8 @@ typedef struct {
 } eegclip_cstack_bwd_desc;
 long long eegclip_cstack_packed_t_bytes(int H);
 int eegclip_cstack_pack_t(const float* Ws, void* packed_t, int H, void* stream);
+/* both fragment sets of a step in one launch (packed_t may be NULL: forward only) */
+int eegclip_cstack_pack_all(const float* Ws, void* packed, void* packed_t, int H, void* stream);
 int eegclip_cstack_bwd_stats(const eegclip_cstack_bwd_desc* d, void* stream);
 long long eegclip_cstack_bwd_workspace_floats(int B);
 int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* stream);

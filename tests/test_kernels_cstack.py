@@ -116,6 +116,11 @@ def test_cstack_backward(be, B, H):
     assert nt == H * 9216
     PT = be.dev(np.full(nt // 2, 0x7FC0, np.uint16))
     ok(be.lib.eegclip_cstack_pack_t(be.ptr(WS), be.ptr(PT), H, be.stream))
+    # both fragment sets in one launch == the two separate packs
+    PK1 = _pack(be, p, H)
+    PK2, PT2 = be.dev(np.full(int(be.lib.eegclip_cstack_packed_bytes(H)) // 2, 0x7FC0, np.uint16)), be.dev(np.full(nt // 2, 0x7FC0, np.uint16))
+    ok(be.lib.eegclip_cstack_pack_all(be.ptr(WS), be.ptr(PK2), be.ptr(PT2), H, be.stream))
+    assert np.array_equal(be.host(PK2), be.host(PK1)) and np.array_equal(be.host(PT2), be.host(PT))
     ROWS = be.dev(np.full((B, 80), np.nan, np.float64))
     DG, DB = be.dev(np.full(C, 0.25, np.float32)), be.dev(np.full(C, -0.25, np.float32))
     DX = be.dev(np.full((B, 64, 250), 7.0, np.float32))

@@ -678,6 +678,25 @@ def test_proj1x1_fused_stage(be, B, p):
                                   SEED, 2, be.stream))
     np.testing.assert_allclose(be.host(Z2), z.detach().numpy(), atol=2e-5)
     np.testing.assert_allclose(be.host(FEAT), ft.detach().numpy(), atol=5e-5)
+    # the same with the BatchNorm finalize folded into the prologue: statistics from per-sample partial rows [sum | sumsq], mean / rstd / running statistics
+    # written by workgroup 0 (eegclip_proj1x1_fwd_rows)
+    rows = np.concatenate([y2.astype(np.float64).sum(2), (y2.astype(np.float64) ** 2).sum(2)], axis=1)
+    ROWS = be.dev(rows)
+    MU2, RS2 = be.dev(np.full(C, np.nan, np.float32)), be.dev(np.full(C, np.nan, np.float32))
+    RM, RV, NBT = be.dev(np.full(C, 0.5, np.float32)), be.dev(np.full(C, 2.0, np.float32)), be.dev(np.array([3], np.int64))
+    Z2r, FEATr = be.zeros((B, C, Wd)), be.zeros((B, Wd * C))
+    count = float(B * Wd)
+    ok(be.lib.eegclip_proj1x1_fwd_rows(be.ptr(Y2), be.ptr(ROWS), B, count, 1e-5, 0.1, be.ptr(MU2), be.ptr(RS2), be.ptr(RM), be.ptr(RV), be.ptr(NBT), be.ptr(G),
+                                       be.ptr(BT), be.ptr(WC), be.ptr(BC), be.ptr(Z2r), be.ptr(FEATr), B, p, SEED, 2, be.stream))
+    np.testing.assert_allclose(be.host(Z2r), z.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(be.host(FEATr), ft.detach().numpy(), atol=5e-5)
+    np.testing.assert_allclose(be.host(MU2), mean, atol=1e-6)
+    np.testing.assert_allclose(be.host(RS2), 1 / np.sqrt(var + 1e-5), rtol=1e-5)
+    np.testing.assert_allclose(be.host(RM), 0.45 + 0.1 * mean, atol=1e-6)
+    np.testing.assert_allclose(be.host(RV), 1.8 + 0.1 * var * (count / (count - 1) if count > 1 else 1.0), rtol=1e-5)
+    assert int(be.host(NBT)[0]) == 4
+    assert be.lib.eegclip_proj1x1_fwd_rows(be.ptr(Y2), None, B, count, 1e-5, 0.1, be.ptr(MU2), be.ptr(RS2), None, None, None, be.ptr(G), be.ptr(BT), be.ptr(WC),
+                                           be.ptr(BC), be.ptr(Z2r), be.ptr(FEATr), B, p, SEED, 2, be.stream) < 0
     sums_seen = []
     for use_ws in (False, True):        # atomics on dW / dbias / sums, then per-workgroup partial rows + column reduction
         DZ2, DW, DBC, SUMS = be.zeros((B, C, Wd)), be.dev(np.ones((C, C), np.float32)), be.zeros(C), be.zeros(2 * C, np.float64)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # round 5, call G: the single-submission step plan on the hardware: parity, host enqueue time, kernel trace
-out=gpurun_out/r5g
+out=gpurun_out/r5h
 mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 F='RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids'
-(timeout 300 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider -k "single_submission or reconstruction_train" 2>&1 | grep -v "$F" | tail -30) > $out/tests_step.log 2>&1
+(timeout 300 python -m pytest tests/test_model_gpu.py -m gpu -q -p no:cacheprovider -k "single_submission or reconstruction_train or train_model_matches" 2>&1 | grep -v "$F" | tail -30) > $out/tests_step.log 2>&1
 tail -5 $out/tests_step.log
 B="--steps 60 --warmup 8 --no-secondary --no-cpu-baseline"
 run() { name=$1; shift; env "$@" timeout 200 python bench.py $B > $out/$name.json 2> $out/$name.err; python -c "import json; d=json.load(open('$out/$name.json')); c=d['config']; print('$name', d['ms_per_step'], c.get('host_enqueue_ms_per_step'), c.get('launches_per_step'), d['roofline']['kernel'][:40], d['roofline']['frac'])" || tail -5 $out/$name.err; }
@@ -28,5 +28,5 @@ for r in rows:
     n=r['Name'].split('(')[0].replace('void ','')[:56]
     if int(r['Calls'])/steps > 0.3: print(f"{n:56s} {int(r['Calls'])/steps:5.2f} avg {float(r['AverageNs'])/1e3:7.1f} per-step {float(r['TotalDurationNs'])/steps/1e3:7.1f}")
 PY
-(timeout 900 python -m pytest tests/test_model_gpu.py tests/test_full_size_gpu.py tests/test_dp_gpu.py tests/test_dataset_gpu.py -m gpu -q -p no:cacheprovider -k "not sdxl and not prior" 2>&1 | grep -v "$F" | tail -12) > $out/tests_model.log 2>&1
+(timeout 900 python -m pytest tests/test_kernels_cstack.py tests/test_kernels_ops.py tests/test_model_gpu.py tests/test_full_size_gpu.py tests/test_dp_gpu.py tests/test_dataset_gpu.py tests/test_token_block.py -m gpu -q -p no:cacheprovider -k "not sdxl and not prior" 2>&1 | grep -v "$F" | tail -12) > $out/tests_model.log 2>&1
 tail -4 $out/tests_model.log
