@@ -91,7 +91,7 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>", "eegclip_conv_bwd_fused": "eeg::conv_bwd_fused_kernel"}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r4_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r5_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(family, B):
@@ -272,6 +272,8 @@ def secondary():
         torch.cuda.empty_cache()
 
     section("infonce_global_batch_2048", _sec_infonce)
+    section("infonce_global_batch_4096", lambda: _sec_infonce(4096, light=True))       # where does the tile shape reach north_star's 0.40 of the bf16 roof?
+    section("infonce_global_batch_8192", lambda: _sec_infonce(8192, light=True))
     section("infonce_per_rank_block", _sec_infonce_per_rank)
     section("exact_fp32_products", _sec_exact_fp32)
     section("bench_joint", _sec_joint)
@@ -283,7 +285,7 @@ def secondary():
     return out
 
 
-def _sec_infonce(N=2048, Dm=1024):
+def _sec_infonce(N=2048, Dm=1024, light=False):
     """north_star's kernel target: the InfoNCE logits at global batch 2048 on the bf16 matrix cores.  `logits_block` = ONE fused launch over one
     N x N block (tile kernel + the small finalize kernel): 2 N^2 D algorithmic flops, the logits never leave the chip.  `clip_loss_*` = the whole
     ClipLoss call (feature split, both blocks of the symmetric loss = 4 N^2 D flops, and for forward_backward the gradient matrix + dA GEMM)."""
@@ -297,7 +299,7 @@ def _sec_infonce(N=2048, Dm=1024):
     b = torch.nn.functional.normalize(torch.randn(N, Dm, device="cuda", generator=g), dim=1)          # CLIP targets are unit norm
     sc = torch.tensor(2.6593, device="cuda")
     flop = 2.0 * N * N * Dm
-    res = {"workload": f"CLIP-symmetric InfoNCE, N = {N} (8 x 256 gathered), D = {Dm}; fractions are of the dense bf16 MFMA peak (2.5 PFLOP/s)"}
+    res = {"workload": f"CLIP-symmetric InfoNCE, N = {N} ({N // 256} x 256 gathered), D = {Dm}; fractions are of the dense bf16 MFMA peak (2.5 PFLOP/s)"}
     st = torch.cuda.current_stream().cuda_stream
     ws = int(L.eegclip_infonce_fused_workspace_floats(N, N))
     ref = None
@@ -310,20 +312,24 @@ def _sec_infonce(N=2048, Dm=1024):
                                                            diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=None, ldg=0))
         ms_blk = _ev_ms(lambda: L.eegclip_infonce_fused_fwd(pr, 1, N, N, Dm, planes, N, sc.data_ptr(), acc.data_ptr(), st), 100, warm=10)
         mult = 3.0 if planes == 2 else 1.0                 # MFMA products per algorithmic multiply-add
-        lf = ClipLoss(logits_dtype=mode)
-        with torch.no_grad():
-            ms_f = _ev_ms(lambda: lf(a, b, sc), 30)
-            loss = float(lf(a, b, sc))
-        ar = a.clone().requires_grad_()
-        ms_fb = _ev_ms(lambda: lf(ar, b, sc), 20)            # ClipLoss computes the gradients in its forward (one pass)
-        ref = loss if ref is None else ref
-        res["parity_mode" if mode == "f32" else "throughput_mode"] = {
+        row = {
             "arithmetic": "bf16x3 split products (logits within ~5e-5 of fp32)" if planes == 2 else "one bf16 product (features rounded to bf16)",
+            # which mode meets north_star's 1e-3 logit tolerance: the split products do (5e-5); one bf16 product does not (~3e-2 at |logit| ~ 16)
+            "meets_north_star_logit_tolerance_1e-3": planes == 2,
             "logits_block_us": round(ms_blk * 1e3, 2), "logits_block_algorithmic_TFLOPs": round(flop / ms_blk / 1e9, 1),
             "logits_block_frac_of_bf16_mfma_peak": round(flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
-            "logits_block_mfma_work_frac_of_peak": round(mult * flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4),
-            "clip_loss_forward_us": round(ms_f * 1e3, 1), "clip_loss_forward_backward_us": round(ms_fb * 1e3, 1),
-            "loss": round(loss, 6), "abs_loss_difference_to_parity_mode": round(abs(loss - ref), 7)}
+            "logits_block_mfma_work_frac_of_peak": round(mult * flop / ms_blk / 1e9 / PEAK_BF16_MFMA_TF, 4)}
+        if not light:
+            lf = ClipLoss(logits_dtype=mode)
+            with torch.no_grad():
+                ms_f = _ev_ms(lambda: lf(a, b, sc), 30)
+                loss = float(lf(a, b, sc))
+            ar = a.clone().requires_grad_()
+            ms_fb = _ev_ms(lambda: lf(ar, b, sc), 20)            # ClipLoss computes the gradients in its forward (one pass)
+            ref = loss if ref is None else ref
+            row.update({"clip_loss_forward_us": round(ms_f * 1e3, 1), "clip_loss_forward_backward_us": round(ms_fb * 1e3, 1),
+                        "loss": round(loss, 6), "abs_loss_difference_to_parity_mode": round(abs(loss - ref), 7)})
+        res["parity_mode" if mode == "f32" else "throughput_mode"] = row
     return res
 
 

@@ -189,6 +189,7 @@ PROTOTYPES = {
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_token_block_packed_bytes": [],
     "eegclip_token_block_pack": [_P, _P, _P, _P, _P, _P, _P],
+    "eegclip_weight_prep": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "eegclip_token_block_packed_embed_bytes": [_I],
     "eegclip_token_block_pack_embed": [_P, _L, _I, _P, _P],
     "eegclip_token_block_fwd": [C.POINTER(TokenBlockDesc), _P],

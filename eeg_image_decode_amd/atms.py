@@ -549,15 +549,21 @@ class _Engine:
             if not hasattr(self, "cs_packed"):
                 self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
                 self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
-            pl.call("eegclip_cstack_pack_all", _p(P[_TS + "4.weight"]), _p(self.cs_packed), _p(self.cs_packed_t), N_CH, side=True)       # (both sets: an eval-mode forward may be followed by a backward too)
+            cs_prep = (_p(P[_TS + "4.weight"]), _p(self.cs_packed), _p(self.cs_packed_t), N_CH)       # (both sets: an eval-mode forward may be followed by a backward too)
+            if not self._token_block_enabled(pl):
+                pl.call("eegclip_cstack_pack_all", *cs_prep)
         if self._token_block_enabled(pl):
             # A1-A3 in ONE launch, one workgroup per sample (csrc/token_block.hip): the ten launches below it replace were bound by per-launch
             # prologue / epilogue and activation round trips, not by their K ~ 250 contractions
             if not hasattr(self, "tb_packed"):
                 self.tb_packed = torch.empty(int(lib().eegclip_token_block_packed_bytes()) // 2, dtype=torch.bfloat16, device=self.device)
             ve_w0, ve_b0 = (self.ve_keys[0] if self.joint else (_E + "value_embedding.weight", _E + "value_embedding.bias"))
-            pl.call("eegclip_token_block_pack", _p(P[ve_w0]), _p(P[_LY + "attention.query_projection.weight"]),
-                    _p(P[_LY + "attention.out_projection.weight"]), _p(P[_LY + "conv1.weight"]), _p(P[_LY + "conv2.weight"]), _p(self.tb_packed))
+            tb_prep = (_p(P[ve_w0]), _p(P[_LY + "attention.query_projection.weight"]), _p(P[_LY + "attention.out_projection.weight"]),
+                       _p(P[_LY + "conv1.weight"]), _p(P[_LY + "conv2.weight"]), _p(self.tb_packed))
+            if cstack:      # the step's whole weight preparation in one launch (the fused block's packed matrices + the conv stack's fragments)
+                pl.call("eegclip_weight_prep", *tb_prep, *cs_prep)
+            else:
+                pl.call("eegclip_token_block_pack", *tb_prep)
             joint_args = {}
             if self.joint:
                 # joint-subject model (Embed.py:127-131,142-144): every subject's value embedding packed behind one another (they are equally spaced in

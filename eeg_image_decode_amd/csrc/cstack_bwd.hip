@@ -16,46 +16,15 @@
 
 namespace eeg {
 
-// ---- Ws^T fragments ----------------------------------------------------------------------------------------------------------------------------------
-// per token row h and filter tile ct:  main hi | main lo (1024 B each: lane (n, kg) slot j <-> o = 16 (j >> 2) + 4 kg + (j & 3), filter c = 16 ct + n)
-//                                      tail hi | tail lo (512 B each: slot j < 4 <-> o = 32 + 4 kg + j, zero from o = 40)
-constexpr int CST_TILE = 3072, CST_ROW = 3 * CST_TILE;
-__device__ __forceinline__ void cstack_pack_t_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id);
+// ---- Ws^T fragments: see cstack_common.h (cs_pack_t_item) -----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cstack_pack_t_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= H * 3 * 64) return;
-    cstack_pack_t_item(Ws, packed, H, id);
+    cs_pack_t_item(Ws, packed, H, id);
 }
-// both fragment sets of a step in ONE launch (the forward's, cstack_common.h: cs_pack_item, then the backward's)
+// both fragment sets of a step in ONE launch
 __global__ __launch_bounds__(256) void cstack_pack_all_kernel(const float* __restrict__ Ws, unsigned char* __restrict__ packed, unsigned char* __restrict__ packed_t, int H) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n1 = 3 * ((H + 1) / 2) * 3 * 64;
-    if (id < n1) cs_pack_item(Ws, packed, H, id);
-    else if (packed_t && id - n1 < H * 3 * 64) cstack_pack_t_item(Ws, packed_t, H, id - n1);
-}
-__device__ __forceinline__ void cstack_pack_t_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id) {
-    const int lane = id & 63, ct = (id >> 6) % 3, h = id / 192;
-    const int n = lane & 15, kg = lane >> 4, c = 16 * ct + n;
-    float v[8], tl[4];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int o = 16 * (j >> 2) + 4 * kg + (j & 3);
-        v[j] = c < CS_C ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int o = 32 + 4 * kg + j;
-        tl[j] = (c < CS_C && o < CS_C) ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
-    }
-    bf16x8 hi, lo;
-    cs_split8(v, hi, lo);
-    u32x2_t th, tlo;
-    x3_split4(tl[0], tl[1], tl[2], tl[3], th, tlo);
-    unsigned char* base = packed + (long long)h * CST_ROW + ct * CST_TILE;
-    *reinterpret_cast<bf16x8*>(base + 16 * lane) = hi;
-    *reinterpret_cast<bf16x8*>(base + 1024 + 16 * lane) = lo;
-    *reinterpret_cast<u32x2_t*>(base + 2048 + 8 * lane) = th;
-    *reinterpret_cast<u32x2_t*>(base + 2560 + 8 * lane) = tlo;
+    cs_pack_both(Ws, packed, packed_t, H, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __device__ __forceinline__ bf16x8 cs_half_frag(u32x2_t v) { return cs_frag(v[0], v[1], 0u, 0u); }
@@ -604,7 +573,7 @@ extern "C" long long eegclip_cstack_packed_t_bytes(int H) { return (H < 1 || H >
 extern "C" int eegclip_cstack_pack_all(const float* Ws, void* packed, void* packed_t, int H, void* stream) {
     if (!Ws || !packed || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
     if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(packed_t)) & 15u) return EEGCLIP_EALIGN;
-    const int nthr = 3 * ((H + 1) / 2) * 3 * 64 + (packed_t ? H * 3 * 64 : 0);
+    const int nthr = cs_pack_items(H, packed_t != nullptr);
     EEG_LAUNCH(cstack_pack_all_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, Ws, static_cast<unsigned char*>(packed), static_cast<unsigned char*>(packed_t), H);
     return (int)hipGetLastError();
 }

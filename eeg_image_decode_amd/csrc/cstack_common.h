@@ -342,4 +342,40 @@ __device__ __forceinline__ void cs_pack_item(const float* __restrict__ Ws, unsig
     *reinterpret_cast<bf16x8*>(packed + csp_offset(step, ot, 1) + 16 * lane) = lo;
 }
 
+// ---- Ws^T fragments of the backward (dz1 = Ws^T dy2: rows = filters c, k = out channels o) -------------------------------------------------------------
+// per token row h and filter tile ct:  main hi | main lo (1024 B each: lane (n, kg) slot j <-> o = 16 (j >> 2) + 4 kg + (j & 3), filter c = 16 ct + n)
+//                                      tail hi | tail lo (512 B each: slot j < 4 <-> o = 32 + 4 kg + j, zero from o = 40)
+constexpr int CST_TILE = 3072, CST_ROW = 3 * CST_TILE;
+__device__ __forceinline__ void cs_pack_t_item(const float* __restrict__ Ws, unsigned char* __restrict__ packed, int H, int id) {
+    const int lane = id & 63, ct = (id >> 6) % 3, h = id / 192;
+    const int n = lane & 15, kg = lane >> 4, c = 16 * ct + n;
+    float v[8], tl[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int o = 16 * (j >> 2) + 4 * kg + (j & 3);
+        v[j] = c < CS_C ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = 32 + 4 * kg + j;
+        tl[j] = (c < CS_C && o < CS_C) ? Ws[((long long)o * CS_C + c) * H + h] : 0.f;
+    }
+    bf16x8 hi, lo;
+    cs_split8(v, hi, lo);
+    u32x2_t th, tlo;
+    x3_split4(tl[0], tl[1], tl[2], tl[3], th, tlo);
+    unsigned char* base = packed + (long long)h * CST_ROW + ct * CST_TILE;
+    *reinterpret_cast<bf16x8*>(base + 16 * lane) = hi;
+    *reinterpret_cast<bf16x8*>(base + 1024 + 16 * lane) = lo;
+    *reinterpret_cast<u32x2_t*>(base + 2048 + 8 * lane) = th;
+    *reinterpret_cast<u32x2_t*>(base + 2560 + 8 * lane) = tlo;
+}
+// work item `id` of both packs: the forward's fragments first, then the backward's (packed_t may be null)
+__host__ __device__ inline int cs_pack_items(int H, bool with_t) { return 3 * ((H + 1) / 2) * 3 * 64 + (with_t ? H * 3 * 64 : 0); }
+__device__ __forceinline__ void cs_pack_both(const float* __restrict__ Ws, unsigned char* __restrict__ packed, unsigned char* __restrict__ packed_t, int H, int id) {
+    const int n1 = 3 * ((H + 1) / 2) * 3 * 64;
+    if (id < n1) cs_pack_item(Ws, packed, H, id);
+    else if (packed_t && id - n1 < H * 3 * 64) cs_pack_t_item(Ws, packed_t, H, id - n1);
+}
+
 }  // namespace eeg

@@ -24,7 +24,7 @@
 // cycles waiting, 123 us; PMC in profiles/r3_pmc_token_block.json).
 // Dropout masks are Philox(seed, site, flat element index) exactly as in the unfused kernels (csrc/elementwise.hip, norm.hip, attention.hip,
 // gemm_epilogue.h): the backward regenerates them, tests regenerate them in numpy.
-#include "eeg_common.h"
+#include "cstack_common.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -104,10 +104,19 @@ __device__ __forceinline__ long long tb_src_index(int mat, int n, int k) {
 struct tb_pack_args {
     const float* w[TB_NMAT];
     unsigned short* out;
+    // (eegclip_weight_prep) the conv stack's weight fragments ride in the same launch: workgroups tb_tiles .. run csrc/cstack_common.h: cs_pack_both
+    int tb_tiles;
+    const float* Ws;
+    unsigned char *cs_packed, *cs_packed_t;
+    int H;
 };
 
 // one 64-thread workgroup per (matrix, n-tile, k-step): lane l owns the 8 k of fragment lane l
 __global__ __launch_bounds__(64) void token_block_pack_kernel(const tb_pack_args a) {
+    if ((int)blockIdx.x >= a.tb_tiles) {
+        cs_pack_both(a.Ws, a.cs_packed, a.cs_packed_t, a.H, ((int)blockIdx.x - a.tb_tiles) * 64 + (int)(threadIdx.x & 63));
+        return;
+    }
     int tile = blockIdx.x;
     int mat = 0;
     while (mat < TB_NMAT - 1 && tile >= (mat == 1 ? TB_NT_QKV : 16) * TB_KS) { tile -= (mat == 1 ? TB_NT_QKV : 16) * TB_KS; ++mat; }
@@ -1203,9 +1212,23 @@ extern "C" long long eegclip_token_block_packed_bytes(void) { return TB_PACKED_E
 extern "C" int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream) {
     if (!wv || !wqkv || !wo || !w1 || !w2 || !packed) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(packed) & 15u) return EEGCLIP_EALIGN;
-    tb_pack_args a{{wv, wqkv, wo, w1, w2, w2, w1, wo, wqkv, wqkv, wqkv}, static_cast<unsigned short*>(packed)};
     const int tiles = (int)(TB_PACKED_ELEMS / TB_TILE);
+    tb_pack_args a{{wv, wqkv, wo, w1, w2, w2, w1, wo, wqkv, wqkv, wqkv}, static_cast<unsigned short*>(packed), tiles, nullptr, nullptr, nullptr, 0};
     EEG_LAUNCH(token_block_pack_kernel, dim3(tiles), dim3(64), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// the per-step weight preparation of the encoder as ONE launch: eegclip_token_block_pack + eegclip_cstack_pack_all (Ws (40,40,H) -> cs_packed, and
+// cs_packed_t unless NULL)
+extern "C" int eegclip_weight_prep(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, const float* Ws,
+                                   void* cs_packed, void* cs_packed_t, int H, void* stream) {
+    if (!wv || !wqkv || !wo || !w1 || !w2 || !packed || !Ws || !cs_packed || H < 1 || H > CS_MAXH) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(cs_packed) | reinterpret_cast<uintptr_t>(cs_packed_t)) & 15u) return EEGCLIP_EALIGN;
+    const int tiles = (int)(TB_PACKED_ELEMS / TB_TILE);
+    tb_pack_args a{{wv, wqkv, wo, w1, w2, w2, w1, wo, wqkv, wqkv, wqkv}, static_cast<unsigned short*>(packed), tiles, Ws, static_cast<unsigned char*>(cs_packed),
+                   static_cast<unsigned char*>(cs_packed_t), H};
+    const int extra = (cs_pack_items(H, cs_packed_t != nullptr) + 63) / 64;
+    EEG_LAUNCH(token_block_pack_kernel, dim3(tiles + extra), dim3(64), 0, stream, a);
     return (int)hipGetLastError();
 }
 

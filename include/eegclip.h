@@ -494,6 +494,9 @@ typedef struct {
 } eegclip_token_block_desc;
 long long eegclip_token_block_packed_bytes(void);
 int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream);
+/* the encoder's whole per-step weight preparation as ONE launch: eegclip_token_block_pack + eegclip_cstack_pack_all (below) */
+int eegclip_weight_prep(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, const float* Ws, void* cs_packed,
+                        void* cs_packed_t, int H, void* stream);
 /* n_subjects value-embedding matrices ((250, 250) row-major, w_stride floats apart) -> n_subjects packed operands at `out`
  * (eegclip_token_block_packed_embed_bytes(n_subjects) bytes, 16-byte aligned) */
 long long eegclip_token_block_packed_embed_bytes(int n_subjects);

@@ -7,6 +7,7 @@ import sys
 FAMILIES = {
     "gemm_bf16x3": ("eeg::gemm_x3_kernel", "eeg::wgrad_tok_kernel", "eeg::wgrad_tok_reduce_kernel"),
     "token_block": ("eeg::token_block_fwd_kernel", "eeg::token_block_bwd_a_kernel", "eeg::token_block_bwd_b_kernel"),
+    "conv_stack": ("eeg::cstack_", "eeg::bn_finalize_rows_kernel"),
     "attention_f32_mfma": ("eeg::attention_bwd_kernel", "eeg::attention_fwd_kernel"), "attention_bf16x3": ("eeg::attention_bwd_x3_kernel",),
     "eegclip_tsconv_fwd": ("eeg::tsconv_fwd_kernel",), "eegclip_tsconv_bwd_w": ("eeg::tsconv_bwd_w_kernel",),
     "eegclip_tsconv_bwd_x": ("eeg::tsconv_bwd_x_kernel",), "eegclip_sconv_fwd": ("eeg::sconv_fwd_kernel",), "eegclip_conv_bwd_fused": ("eeg::conv_bwd_fused_kernel",),
