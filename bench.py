@@ -623,8 +623,7 @@ def main():
         # family, ~0.1 ms of a 1.2 ms step if recorded on every step -- instrumentation the product does not carry; 3+ sampled steps x 20 launches)
         every = TIME_EVERY if args.steps >= 2 * TIME_EVERY else 1
         if sp is not None:                        # the step plan holds the encoder plans' ops at fixed offsets
-            base = {"f": sp.fwd_base, "b": sp.bwd_base}
-            sp.pl.time_ops([base[k[0]] + i for k, idxs in by_plan.items() for i in idxs], every=every)
+            sp.pl.time_ops([sp.index_of(k[0], i) for k, idxs in by_plan.items() for i in idxs], every=every)
         else:
             for k, idxs in by_plan.items():
                 plans[k].time_ops(idxs, every=every)
@@ -664,10 +663,9 @@ def main():
         ops = fam_ops[dominant]
         live = {}
         if sp is not None:
-            base = {"f": sp.fwd_base, "b": sp.bwd_base}
             tm = sp.pl.timings_ms()
             for (k, idx) in ops:
-                live[(k, idx)] = float(np.mean(tm[base[k[0]] + idx][-args.steps:]))
+                live[(k, idx)] = float(np.mean(tm[sp.index_of(k[0], idx)][-args.steps:]))
         else:
             for k in {k for k, _ in ops}:
                 for idx, v in plans[k].timings_ms().items():

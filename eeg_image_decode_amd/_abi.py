@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
 
 class SplitItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_src", C.c_longlong),
-                ("ld_out", C.c_longlong), ("transpose", C.c_int)]
+                ("ld_out", C.c_longlong), ("transpose", C.c_int), ("copy", C.c_void_p), ("ld_copy", C.c_longlong)]
 
 
 class InfonceProblem(C.Structure):
@@ -106,7 +106,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 

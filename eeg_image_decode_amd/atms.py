@@ -199,14 +199,17 @@ _LIVE = [
     _TS + "0.weight", _TS + "0.bias", _TS + "2.weight", _TS + "2.bias", _TS + "4.weight", _TS + "4.bias", _TS + "5.weight", _TS + "5.bias",
     "enc_eeg.0.projection.0.weight", "enc_eeg.0.projection.0.bias",
     "proj_eeg.0.weight", "proj_eeg.0.bias", "proj_eeg.1.fn.1.weight", "proj_eeg.1.fn.1.bias", "proj_eeg.2.weight", "proj_eeg.2.bias",
-    _E + "value_embedding.weight", _E + "value_embedding.bias",
     _LY + "attention.query_projection.weight", _LY + "attention.key_projection.weight", _LY + "attention.value_projection.weight",
     _LY + "attention.query_projection.bias", _LY + "attention.key_projection.bias", _LY + "attention.value_projection.bias",
     _LY + "attention.out_projection.weight", _LY + "attention.out_projection.bias",
     _LY + "conv1.weight", _LY + "conv1.bias", _LY + "conv2.weight", _LY + "conv2.bias",
     _LY + "norm1.weight", _LY + "norm1.bias", _LY + "norm2.weight", _LY + "norm2.bias",
     "encoder.encoder.norm.weight", "encoder.encoder.norm.bias",
+    # LAST: the gradient that completes last (its dY is the final output of the backward chain).  step_plan.StepPlan runs AdamW over everything before it
+    # on the second stream while this weight gradient is still being formed, and a second AdamW launch over the tail [value embedding | token rows]
+    _E + "value_embedding.weight", _E + "value_embedding.bias",
 ]
+_CHECK_KEY = "encoder.encoder.norm.bias"          # (a live parameter of every model variant: Engine.stale)
 _TOK_TABLE = _E + "subject_embedding.subject_embedding.weight"
 _TOK_SHARED = _E + "subject_embedding.shared_embedding"
 
@@ -414,7 +417,7 @@ class _Engine:
         assert offs["logit_scale"] == 0 and a1 == offs[self.live_base[self.live_base.index("proj_eeg.2.bias") + 1]]
         self.early_bucket = (a0, a1)
         self.early_work = None
-        self._check = (self.params["logit_scale"], self.params[_LIVE[-1]])
+        self._check = (self.params["logit_scale"], self.params[_CHECK_KEY])
         self.buffers = dict(model.named_buffers())
         self.bufs, self.plans, self.version = {}, {}, {}
         self.last_key = None
@@ -476,7 +479,7 @@ class _Engine:
 
     def stale(self, model):
         a, b = self._check
-        return (a.data_ptr() != self.flat.data_ptr() or b.data.data_ptr() != self.P[_LIVE[-1]].data_ptr()
+        return (a.data_ptr() != self.flat.data_ptr() or b.data.data_ptr() != self.P[_CHECK_KEY].data_ptr()
                 or model.logit_scale.device != self.device)
 
     # ---- buffers -----------------------------------------------------------------------------------------------
@@ -925,7 +928,10 @@ class _Engine:
             #   pass over the 16 MB tensor (35 us in the step)
         # embedding: token row + value embedding
         tokg = G[_TOK_SHARED] if shared else G[_TOK_TABLE]
-        pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, 0.0, 0, SITE_EMBED)
+        # (drop_p = 0: the dropout' is already in dr1 -- this launch only sums the token rows' gradients, reads dr1 and can run beside the embedding's
+        #  weight gradient)
+        pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, 0.0, 0, SITE_EMBED, side=True)
+        pl.tail_op = len(pl.ops)          # everything from here on forms the value embedding's gradient only (step_plan: AdamW of the rest forks here)
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)

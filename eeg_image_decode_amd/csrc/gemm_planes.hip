@@ -212,7 +212,7 @@ extern "C" int eegclip_split_transpose(const eegclip_split_item* items, int n, v
     for (int i = 0; i < n; ++i) {
         const eegclip_split_item& it = items[i];
         if (!it.src || !it.hi || !it.lo || it.rows < 64 || it.cols < 64 || (it.rows & 63) || (it.cols & 63) || it.ld_src < it.cols || it.ld_out < it.rows ||
-            (it.ld_src & 3) || (it.ld_out & 3))
+            (it.ld_src & 3) || (it.ld_out & 3) || it.copy)
             return EEGCLIP_EINVAL;
         if ((reinterpret_cast<uintptr_t>(it.src) & 15u) || ((reinterpret_cast<uintptr_t>(it.hi) | reinterpret_cast<uintptr_t>(it.lo)) & 7u)) return EEGCLIP_EALIGN;
         tb.e[i] = gpt_entry{it.src, static_cast<unsigned short*>(it.hi), static_cast<unsigned short*>(it.lo), it.ld_src, it.ld_out, it.rows, it.cols, blocks,

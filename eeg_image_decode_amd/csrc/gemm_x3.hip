@@ -346,6 +346,8 @@ struct xp_split_entry {
     int rows, cols;                  // of the SOURCE matrix
     long long ld_src, ld_out;
     int transpose, first_block;      // workgroups [first_block, next first_block) belong to this entry
+    float* copy;                     // optional fp32 copy of the source, rows ld_copy apart (several sources stacked into one GEMM operand)
+    long long ld_copy;
 };
 constexpr int XP_SPLIT_MAX = 24;
 struct xp_split_table {
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
     const long long per_row = E.ld_out;                              // output elements per row incl. padding
     const long long total = (long long)orow_n * per_row;
     const int span = (ei + 1 < tb.n ? tb.e[ei + 1].first_block : (int)gridDim.x) - E.first_block;
-    if (!E.transpose && E.ld_src == E.cols && E.ld_out == E.cols && (total & 3) == 0 &&
+    if (!E.transpose && E.ld_src == E.cols && E.ld_out == E.cols && (total & 3) == 0 && (!E.copy || (E.ld_copy == E.cols && !(reinterpret_cast<uintptr_t>(E.copy) & 15u))) &&
         !((reinterpret_cast<uintptr_t>(E.src) & 15u) | ((reinterpret_cast<uintptr_t>(E.hi) | reinterpret_cast<uintptr_t>(E.lo)) & 7u))) {
         // a dense matrix split in place-order (the diffusion prior's 1024-wide inputs): 4 elements per lane, 16-byte loads, 8-byte plane stores
         for (long long q4 = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; 4 * q4 < total; q4 += 256LL * span) {
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
             x3_split4(v[0], v[1], v[2], v[3], h, l);
             *reinterpret_cast<u32x2_t*>(E.hi + 4 * q4) = h;
             *reinterpret_cast<u32x2_t*>(E.lo + 4 * q4) = l;
+            if (E.copy) *reinterpret_cast<f32x4*>(E.copy + 4 * q4) = v;          // (this path: ld_copy == cols, 16-byte aligned -- checked by the host)
         }
         return;
     }
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
         const unsigned short h = f32_to_bf16_bits(v);
         E.hi[q] = h;
         E.lo[q] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+        if (E.copy && c < ocol_n) E.copy[(long long)r * E.ld_copy + c] = v;      // (never with transpose: refused by the host)
     }
 }
 
@@ -469,8 +473,9 @@ extern "C" int eegclip_split_rows(const eegclip_split_item* items, int n, void* 
         const eegclip_split_item& it = items[i];
         const int orow = it.transpose ? it.cols : it.rows, ocol = it.transpose ? it.rows : it.cols;
         if (!it.src || !it.hi || !it.lo || it.rows < 1 || it.cols < 1 || it.ld_src < it.cols || it.ld_out < ocol) return EEGCLIP_EINVAL;
+        if (it.copy && (it.transpose || it.ld_copy < it.cols)) return EEGCLIP_EINVAL;
         tb.e[i] = xp_split_entry{it.src, static_cast<unsigned short*>(it.hi), static_cast<unsigned short*>(it.lo), it.rows, it.cols, it.ld_src, it.ld_out,
-                                 it.transpose, blocks};
+                                 it.transpose, blocks, it.copy, it.copy ? it.ld_copy : 0};
         long long b = ((long long)orow * it.ld_out + 1023) / 1024;          // ~4 elements per thread
         if (b > 256) b = 256;
         blocks += (int)b;

@@ -320,6 +320,21 @@ struct tb_fwd_args {
     long long bv_stride;                                         // ... floats between the subjects' biases
 };
 
+// The forward kernel takes ~50 pointers (backward part A: 25).  hipcc loads every kernel argument in the entry block and keeps it in scalar registers until its last use, so the
+// phases ran with 104 SGPRs + 99 spilled to vector lanes: every use of a spilled value (the Philox round keys of each dropout site, the per-row store
+// bases) was a v_readlane + hazard nops inside the row loops.  Each phase therefore reads ITS arguments again from the kernel-argument segment through a
+// pointer the optimiser cannot see through: scalar loads at the phase's start, dead at its end.
+template <class ARGS>
+__device__ __forceinline__ ARGS tb_args_again(const ARGS& a) {
+#if defined(EEG_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+    return a;                                                    // (the emulator, and the host pass of hipcc over this device function)
+#else
+    auto p = (const __attribute__((address_space(4))) ARGS*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;                                                   // by value: one scalar load per field the phase uses, none for the others
+#endif
+}
+
 // phase stamp of the diagnosis build path: the shader clock as wave 0 passes phase boundary k
 __device__ __forceinline__ void tb_stamp(const tb_fwd_args& a, int b, int t, int k) {
 #if !defined(EEG_EMU)
@@ -627,18 +642,19 @@ __device__ __forceinline__ void tb_for_tiles(int w, int lane, int N, f32x4 (&acc
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb_fwd_args a) {
+__global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb_fwd_args a0) {
     EEG_LDS_BASE(unsigned char, lds);
     unsigned char* const AP = lds;
     unsigned char* const XF = lds + TB_AP_BYTES;
     const int t = threadIdx.x, lane = t & 63, w = wave_uniform(t >> 6), fr = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
-    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+    const float ksc = (TRAIN && a0.drop_p > 0.f) ? 1.f / (1.f - a0.drop_p) : 1.f;
 
-    tb_stamp(a, b, t, 0);
+    tb_stamp(a0, b, t, 0);
+    const tb_fwd_args p0 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S0: the EEG sample (63 x 250 fp32) -> A planes, token row 1 + channel; row 0 and k >= 250 are zero
     {
-        const float* xb = a.x + (long long)b * (TB_NCH * TB_T);
+        const float* xb = p0.x + (long long)b * (TB_NCH * TB_T);
         tb_f2 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -662,21 +678,22 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
-    tb_stamp(a, b, t, 1);
+    tb_stamp(a0, b, t, 1);
+    const tb_fwd_args p1 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S1: value embedding + bias + positional embedding (row = channel), subject token in row 0      (Embed.py:146-160)
     {
         f32x4 acc[4][2];
         // (joint-subject model, Embed.py:142-144: the sample's subject picks the Linear -- a workgroup-uniform base, nothing else changes)
-        const int vs = a.embed_subject ? a.embed_subject[b] : 0;
-        const unsigned short* const wv = a.embed_subject ? a.packed_embed + (long long)vs * TB_MAT_ELEMS : a.packed + TB_OFF_V;
-        const float* const bvp = a.bv + (long long)vs * a.bv_stride;
+        const int vs = p1.embed_subject ? p1.embed_subject[b] : 0;
+        const unsigned short* const wv = p1.embed_subject ? p1.packed_embed + (long long)vs * TB_MAT_ELEMS : p1.packed + TB_OFF_V;
+        const float* const bvp = p1.bv + (long long)vs * p1.bv_stride;
         tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, wv + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
-        const long long id = a.ids ? a.ids[b] : 0;
+        const long long id = p1.ids ? p1.ids[b] : 0;
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             f32x4 o;
-            if (m == 0) o = tb_ld4(a.tokens + id * TB_D + n0, valid);
+            if (m == 0) o = tb_ld4(p1.tokens + id * TB_D + n0, valid);
             else {
-                const f32x4 bias = tb_ld4(bvp + n0, valid), pe = tb_ld4(a.pe + (long long)(m - 1) * TB_D + n0, valid);
+                const f32x4 bias = tb_ld4(bvp + n0, valid), pe = tb_ld4(p1.pe + (long long)(m - 1) * TB_D + n0, valid);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (v[i] + bias[i]) + pe[i];
             }
@@ -684,14 +701,15 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
         // the EEG sample as token planes (row 0 zero: the subject token has no EEG row) = the X operand of the value embedding's weight gradient
-        if (a.xp && !(a.dbg & 1u)) tb_planes_out<1>(AP, a.xp + (long long)b * (2 * TB_AP_PLANE), t);
+        if (p1.xp && !(p1.dbg & 1u)) tb_planes_out<1>(AP, p1.xp + (long long)b * (2 * TB_AP_PLANE), t);
     }
     raw_barrier();
 
-    tb_stamp(a, b, t, 2);
+    tb_stamp(a0, b, t, 2);
+    const tb_fwd_args p2 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S2: embedding dropout over the flat (64 x 250) sample (one Philox block = 4 consecutive flat elements); h -> HBM and -> A planes
     {
-        float* hb = a.h + (long long)b * (TB_L * TB_D);
+        float* hb = p2.h + (long long)b * (TB_L * TB_D);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int q = t + TB_THREADS * j;
@@ -701,13 +719,13 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
                 const int row2 = wrap ? row + 1 : row, col2 = wrap ? col + 2 - TB_D : col + 2;
                 const tb_f2 p0 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row, col)), p1 = *reinterpret_cast<const tb_f2*>(XF + xf_off(row2, col2));
                 float v[4] = {p0[0], p0[1], p1[0], p1[1]};
-                if (TRAIN && a.drop_p > 0.f) {
+                if (TRAIN && p2.drop_p > 0.f) {
                     bool keep[4];
-                    dropout_keep4(a.seed, a.site_embed, (unsigned long long)b * (TB_L * TB_D) + i0, a.drop_p, keep);
+                    dropout_keep4(p2.seed, p2.site_embed, (unsigned long long)b * (TB_L * TB_D) + i0, p2.drop_p, keep);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ksc : 0.f;
                 }
-                if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(hb + i0) = f32x4{v[0], v[1], v[2], v[3]};
+                if (!(p2.dbg & 1u)) *reinterpret_cast<f32x4*>(hb + i0) = f32x4{v[0], v[1], v[2], v[3]};
                 tb_store_planes2(AP, TB_AP_PLANE, ap_off(row, col), v[0], v[1]);
                 tb_store_planes2(AP, TB_AP_PLANE, ap_off(row2, col2), v[2], v[3]);
             }
@@ -715,7 +733,8 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
-    tb_stamp(a, b, t, 3);
+    tb_stamp(a0, b, t, 3);
+    const tb_fwd_args p3 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S3: q | k | v (SelfAttention_Family.py:199-207) and attention, two heads at a time: 24 tiles of the pair's q | k | v -> their planes
     //          behind the (still live) h planes, then waves 0-3 run one head and waves 4-7 the other
     f32x4 ctxr[2][4];
@@ -726,14 +745,14 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
         for (int rd = 0; rd < 2; ++rd) {
             f32x4 cur[4][3];
             switch (w & 3) {
-                case 0: tb_qkv_pass<0>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<0>(HQ, lane, cur); break;
-                case 1: tb_qkv_pass<1>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<1>(HQ, lane, cur); break;
-                case 2: tb_qkv_pass<2>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<2>(HQ, lane, cur); break;
-                default: tb_qkv_pass<3>(a, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<3>(HQ, lane, cur); break;
+                case 0: tb_qkv_pass<0>(p3, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<0>(HQ, lane, cur); break;
+                case 1: tb_qkv_pass<1>(p3, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<1>(HQ, lane, cur); break;
+                case 2: tb_qkv_pass<2>(p3, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<2>(HQ, lane, cur); break;
+                default: tb_qkv_pass<3>(p3, AP, b, 2 * rd + hip, lane, cur); tb_qkv_to_lds<3>(HQ, lane, cur); break;
             }
-            if (rd == 1 && !(a.dbg & 1u)) tb_planes_out<0>(AP, a.hp + (long long)b * (2 * TB_AP_PLANE), t);      // (the last reader of the h planes has its weights)
+            if (rd == 1 && !(p3.dbg & 1u)) tb_planes_out<0>(AP, p3.hp + (long long)b * (2 * TB_AP_PLANE), t);      // (the last reader of the h planes has its weights)
             raw_barrier();
-            tb_attention<TRAIN>(a, HQ, b, 2 * rd + hip, w & 3, lane, ctxr[rd]);
+            tb_attention<TRAIN>(p3, HQ, b, 2 * rd + hip, w & 3, lane, ctxr[rd]);
             raw_barrier();                                           // the pair's planes are dead (and, second round, the h planes too)
         }
         // context -> A planes with 64 columns per head (dims 62, 63 are exact zeros); S4 copies the planes to HBM
@@ -750,35 +769,38 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
-    tb_stamp(a, b, t, 4);
+    tb_stamp(a0, b, t, 4);
+    const tb_fwd_args p4 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S4: output projection + bias -> XF      (SelfAttention_Family.py:213)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_O + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, p4.packed + TB_OFF_O + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
-            const f32x4 bias = tb_ld4(a.bo + n0, valid);
+            const f32x4 bias = tb_ld4(p4.bo + n0, valid);
             f32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = i < valid ? v[i] + bias[i] : 0.f;
             *reinterpret_cast<f32x4*>(XF + xf_off(m, n0)) = o;
         });
-        if (!(a.dbg & 1u)) tb_planes_out<0>(AP, a.ctxp + (long long)b * (2 * TB_AP_PLANE), t);      // ctx planes (channel 255 = dim 63 of head 3: the ones column)
+        if (!(p4.dbg & 1u)) tb_planes_out<0>(AP, p4.ctxp + (long long)b * (2 * TB_AP_PLANE), t);      // ctx planes (channel 255 = dim 63 of head 3: the ones column)
     }
     __syncthreads();                                                 // (the one barrier that also waits for global stores: S5 re-reads h)
-    tb_stamp(a, b, t, 5);
+    tb_stamp(a0, b, t, 5);
+    const tb_fwd_args p5 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S5: r1 = h + dropout(attention output), n1 = LayerNorm1(r1); n1 stays in XF (FFN residual) and goes to the A planes
-    tb_ln_rows<TRAIN, false>(a, b, w, lane, XF, nullptr, a.h, a.site_attn_out, a.r1, a.ln1_g, a.ln1_b, nullptr, a.mu1, a.rs1, nullptr, nullptr, nullptr, nullptr,
+    tb_ln_rows<TRAIN, false>(p5, b, w, lane, XF, nullptr, p5.h, p5.site_attn_out, p5.r1, p5.ln1_g, p5.ln1_b, nullptr, p5.mu1, p5.rs1, nullptr, nullptr, nullptr, nullptr,
                              nullptr, XF, AP);
     raw_barrier();
 
-    tb_stamp(a, b, t, 6);
+    tb_stamp(a0, b, t, 6);
+    const tb_fwd_args p6 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S6: FFN 1 + bias -> f1 (pre-activation, kept for the backward), g1 = dropout(gelu(f1))      (Transformer_EncDec.py:48)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, p6.packed + TB_OFF_1 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         f32x4 bias1[2];                                              // (loads before the first store: see tb_ln_rows)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias1[j] = *reinterpret_cast<const f32x4*>(a.b1 + 32 * w + 16 * j + 4 * g);
+        for (int j = 0; j < 2; ++j) bias1[j] = *reinterpret_cast<const f32x4*>(p6.b1 + 32 * w + 16 * j + 4 * g);
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             const f32x4 bias = bias1[(n0 >> 4) & 1];
             const long long ob = (long long)b * (TB_L * TB_FF);          // uniform: the stores take it as a scalar base + a 32-bit lane offset
@@ -786,17 +808,17 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             f32x4 f, gq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) f[i] = v[i] + bias[i];
-            if (!(a.dbg & 1u)) *reinterpret_cast<f32x4*>(a.f1 + ob + ol) = f;
+            if (!(p6.dbg & 1u)) *reinterpret_cast<f32x4*>(p6.f1 + ob + ol) = f;
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)ob + ol, a.drop_p, keep);
+            if (TRAIN && p6.drop_p > 0.f) dropout_keep4(p6.seed, p6.site_ffn_act, (unsigned long long)ob + ol, p6.drop_p, keep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float ge = gelu_erf(f[i]);
-                gq[i] = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
+                gq[i] = (TRAIN && p6.drop_p > 0.f) ? (keep[i] ? ge * ksc : 0.f) : ge;
             }
             v = gq;
         });
-        if (!(a.dbg & 1u)) tb_planes_out<0>(AP, a.n1p + (long long)b * (2 * TB_AP_PLANE), t);
+        if (!(p6.dbg & 1u)) tb_planes_out<0>(AP, p6.n1p + (long long)b * (2 * TB_AP_PLANE), t);
         raw_barrier();                                               // every wave is done with the n1 planes
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             tb_store_planes4(AP, TB_AP_PLANE, ap_off(m, n0), v[0], v[1], v[2], v[3]);
@@ -804,18 +826,19 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     }
     raw_barrier();
 
-    tb_stamp(a, b, t, 7);
+    tb_stamp(a0, b, t, 7);
+    const tb_fwd_args p7 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S7: FFN 2 + bias; the result replaces the (dead) g1 planes as an fp32 image      (Transformer_EncDec.py:49)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, a.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, 2, true, TB_FWD_RING>(AP, p7.packed + TB_OFF_2 + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         f32x4 bias2[2];                                              // (loads before the stores below)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n0 = 32 * w + 16 * j + 4 * g;
-            bias2[j] = n0 < TB_D ? tb_ld4(a.b2 + n0, TB_D - n0 >= 4 ? 4 : 2) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias2[j] = n0 < TB_D ? tb_ld4(p7.b2 + n0, TB_D - n0 >= 4 ? 4 : 2) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!(a.dbg & 1u)) tb_planes_out<64>(AP, a.g1p + (long long)b * (2 * TB_AP_PLANE), t);      // g1 planes: 256 real channels, no ones column
+        if (!(p7.dbg & 1u)) tb_planes_out<64>(AP, p7.g1p + (long long)b * (2 * TB_AP_PLANE), t);      // g1 planes: 256 real channels, no ones column
         raw_barrier();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                                // (tb_for_tiles with the tile index j a compile-time constant: bias2[j] stays in registers)
@@ -832,11 +855,12 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
         }
     }
     raw_barrier();
-    tb_stamp(a, b, t, 8);
+    tb_stamp(a0, b, t, 8);
+    const tb_fwd_args p8 = tb_args_again(a0);                 // this phase's arguments, re-read from the kernel-argument segment (see tb_args_again)
     // ---- S8: r2 = n1 + dropout(FFN output), n2 = LayerNorm2(r2), n3 = final LayerNorm(n2)      (Transformer_EncDec.py:51,77-78)
-    tb_ln_rows<TRAIN, true>(a, b, w, lane, AP, XF, nullptr, a.site_ffn_out, a.r2, a.ln2_g, a.ln2_b, a.n2, a.mu2, a.rs2, a.ln3_g, a.ln3_b, a.n3, a.mu3, a.rs3,
+    tb_ln_rows<TRAIN, true>(p8, b, w, lane, AP, XF, nullptr, p8.site_ffn_out, p8.r2, p8.ln2_g, p8.ln2_b, p8.n2, p8.mu2, p8.rs2, p8.ln3_g, p8.ln3_b, p8.n3, p8.mu3, p8.rs3,
                             nullptr, nullptr);
-    tb_stamp(a, b, t, 9);
+    tb_stamp(a0, b, t, 9);
 }
 
 
@@ -903,16 +927,17 @@ __device__ __forceinline__ void tb_reduce_partials(float* slab, int w, int lane,
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const tb_bwd_args a) {
+__global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const tb_bwd_args a0) {
     EEG_LDS_BASE(unsigned char, lds);
     unsigned char* const AP = lds;
     unsigned char* const XF = lds + TB_AP_BYTES;
     float* const SC = reinterpret_cast<float*>(lds + TB_AP_BYTES + TB_XF_BYTES);       // 32 KB of scratch for the parameter-gradient rows
     const int t = threadIdx.x, lane = t & 63, w = wave_uniform(t >> 6);
     const int b = blockIdx.x;
-    const float ksc = (TRAIN && a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
-    float* const part = a.partials + (long long)b * (6 * 256);
+    const float ksc = (TRAIN && a0.drop_p > 0.f) ? 1.f / (1.f - a0.drop_p) : 1.f;
+    float* const part = a0.partials + (long long)b * (6 * 256);
 
+    const tb_bwd_args q1 = tb_args_again(a0);                 // (see tb_args_again)
     // ---- T1: final LayerNorm' and LayerNorm2' chained per row in registers; df2 = dropout'(dr2) -> A planes (T2 copies them to HBM), dr2 -> XF
     {
         float pe[4][4], po[4][4];                                    // [g3 b3 g2 b2] x 4 columns, even / odd rows
@@ -928,9 +953,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             for (int p = 0; p < 2; ++p) {
                 const int cp = 4 * lane - 2 * par + 2 * p;
                 const bool okc = cp >= 0 && cp < TB_D;
-                pg3[par][p] = okc ? *reinterpret_cast<const tb_f2*>(a.ln3_g + cp) : tb_f2{0.f, 0.f};
-                pg2[par][p] = okc ? *reinterpret_cast<const tb_f2*>(a.ln2_g + cp) : tb_f2{0.f, 0.f};
-                pb2[par][p] = (okc && !a.n2) ? *reinterpret_cast<const tb_f2*>(a.ln2_b + cp) : tb_f2{0.f, 0.f};
+                pg3[par][p] = okc ? *reinterpret_cast<const tb_f2*>(q1.ln3_g + cp) : tb_f2{0.f, 0.f};
+                pg2[par][p] = okc ? *reinterpret_cast<const tb_f2*>(q1.ln2_g + cp) : tb_f2{0.f, 0.f};
+                pb2[par][p] = (okc && !q1.n2) ? *reinterpret_cast<const tb_f2*>(q1.ln2_b + cp) : tb_f2{0.f, 0.f};
             }
         tb_f2 in_dy[8][2], in_r2[8][2], in_n2[8][2];
 #pragma unroll
@@ -941,9 +966,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 const long long sb = (long long)b * (TB_L * TB_D);           // uniform sample base + a 32-bit lane offset (see tb_ln_rows)
                 const unsigned o = (unsigned)((8 * w + rr) * TB_D + cp);
                 const bool okc = cp >= 0 && cp < TB_D;
-                in_dy[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.dn3 + sb + o) : tb_f2{0.f, 0.f};
-                in_r2[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(a.r2 + sb + o) : tb_f2{0.f, 0.f};
-                in_n2[rr][p] = (okc && a.n2) ? *reinterpret_cast<const tb_f2*>(a.n2 + sb + o) : tb_f2{0.f, 0.f};
+                in_dy[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(q1.dn3 + sb + o) : tb_f2{0.f, 0.f};
+                in_r2[rr][p] = okc ? *reinterpret_cast<const tb_f2*>(q1.r2 + sb + o) : tb_f2{0.f, 0.f};
+                in_n2[rr][p] = (okc && q1.n2) ? *reinterpret_cast<const tb_f2*>(q1.n2 + sb + o) : tb_f2{0.f, 0.f};
             }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -957,10 +982,10 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 ok[p] = cp >= 0 && cp < TB_D;
                 const tb_f2 v0 = in_dy[rr][p], v2 = in_r2[rr][p], v3 = pg3[rr & 1][p], v4 = pg2[rr & 1][p];
                 tb_f2 v1 = in_n2[rr][p];
-                if (ok[p] && !a.n2) {
+                if (ok[p] && !q1.n2) {
                     // n2 = LayerNorm2(r2) is re-evaluated from r2 and the row statistics (the forward did not store it: 16 MB per step less each way)
                     const tb_f2 bb = pb2[rr & 1][p];
-                    const float mu = a.mu2[row], rs = a.rs2[row];
+                    const float mu = q1.mu2[row], rs = q1.rs2[row];
                     v1 = tb_f2{(v2[0] - mu) * rs * v4[0] + bb[0], (v2[1] - mu) * rs * v4[1] + bb[1]};
                 }
 #pragma unroll
@@ -968,19 +993,19 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             }
             float dn2[4], dr2[4];
             if (rr & 1) {
-                tb_ln_bwd_row(dy, x3, g3, ok, a.mu3[row], a.rs3[row], dn2, po[0], po[1]);
-                tb_ln_bwd_row(dn2, x2, g2, ok, a.mu2[row], a.rs2[row], dr2, po[2], po[3]);
+                tb_ln_bwd_row(dy, x3, g3, ok, q1.mu3[row], q1.rs3[row], dn2, po[0], po[1]);
+                tb_ln_bwd_row(dn2, x2, g2, ok, q1.mu2[row], q1.rs2[row], dr2, po[2], po[3]);
             } else {
-                tb_ln_bwd_row(dy, x3, g3, ok, a.mu3[row], a.rs3[row], dn2, pe[0], pe[1]);
-                tb_ln_bwd_row(dn2, x2, g2, ok, a.mu2[row], a.rs2[row], dr2, pe[2], pe[3]);
+                tb_ln_bwd_row(dy, x3, g3, ok, q1.mu3[row], q1.rs3[row], dn2, pe[0], pe[1]);
+                tb_ln_bwd_row(dn2, x2, g2, ok, q1.mu2[row], q1.rs2[row], dr2, pe[2], pe[3]);
             }
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, a.site_ffn_out, (unsigned long long)(rbase + c0), a.drop_p, keep);
+            if (TRAIN && q1.drop_p > 0.f && c0 < TB_D) dropout_keep4(q1.seed, q1.site_ffn_out, (unsigned long long)(rbase + c0), q1.drop_p, keep);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
-                const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr2[2 * p] * ksc : 0.f) : dr2[2 * p];
-                const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr2[2 * p + 1] * ksc : 0.f) : dr2[2 * p + 1];
+                const float d0 = (TRAIN && q1.drop_p > 0.f) ? (keep[2 * p] ? dr2[2 * p] * ksc : 0.f) : dr2[2 * p];
+                const float d1 = (TRAIN && q1.drop_p > 0.f) ? (keep[2 * p + 1] ? dr2[2 * p + 1] * ksc : 0.f) : dr2[2 * p + 1];
                 if (ok[p]) *reinterpret_cast<tb_f2*>(XF + xf_off(r, cp)) = tb_f2{dr2[2 * p], dr2[2 * p + 1]};
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
             }
@@ -990,26 +1015,27 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     }
     raw_barrier();
 
+    const tb_bwd_args q2 = tb_args_again(a0);                 // (see tb_args_again)
     // ---- T2: dg1 = df2 W2, then the FFN activation's dropout' and gelu' (pre-activation f1 from HBM): df1 -> A planes (T3 copies them to HBM)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, q2.packed + TB_OFF_2T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         f32x4 fpre[4][2];                                            // the pre-activations of this lane's 8 groups: loaded before the first store
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                fpre[mt][j] = *reinterpret_cast<const f32x4*>(a.f1 + (long long)b * (TB_L * TB_FF) + (unsigned)((16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4)));
-        tb_planes_out<64>(AP, a.df2p + (long long)b * (2 * TB_AP_PLANE), t);      // df2 planes (bias gradient: all-ones fragment in the GEMM, g1 has 256 channels)
+                fpre[mt][j] = *reinterpret_cast<const f32x4*>(q2.f1 + (long long)b * (TB_L * TB_FF) + (unsigned)((16 * mt + (lane & 15)) * TB_FF + 32 * w + 16 * j + 4 * (lane >> 4)));
+        tb_planes_out<64>(AP, q2.df2p + (long long)b * (2 * TB_AP_PLANE), t);      // df2 planes (bias gradient: all-ones fragment in the GEMM, g1 has 256 channels)
         tb_for_tiles(w, lane, TB_FF, acc, [&](int m, int n0, int valid, f32x4& v) {
             const long long ob = (long long)b * (TB_L * TB_FF);
             const unsigned ol = (unsigned)(m * TB_FF + n0);
             const f32x4 f = fpre[m >> 4][(n0 >> 4) & 1];
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f) dropout_keep4(a.seed, a.site_ffn_act, (unsigned long long)ob + ol, a.drop_p, keep);
+            if (TRAIN && q2.drop_p > 0.f) dropout_keep4(q2.seed, q2.site_ffn_act, (unsigned long long)ob + ol, q2.drop_p, keep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float d = (TRAIN && a.drop_p > 0.f) ? (keep[i] ? v[i] * ksc : 0.f) : v[i];
+                const float d = (TRAIN && q2.drop_p > 0.f) ? (keep[i] ? v[i] * ksc : 0.f) : v[i];
                 v[i] = d * gelu_erf_grad(f[i]);
             }
         });
@@ -1020,10 +1046,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     }
     raw_barrier();
 
+    const tb_bwd_args q3 = tb_args_again(a0);                 // (see tb_args_again)
     // ---- T3: dn1 = dr2 + df1 W1 (in place in XF)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_1T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, q3.packed + TB_OFF_1T + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, TB_D, acc, [&](int m, int n0, int valid, f32x4& v) {
             f32x4* p = reinterpret_cast<f32x4*>(XF + xf_off(m, n0));
             f32x4 o = *p;
@@ -1031,10 +1058,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
             for (int i = 0; i < 4; ++i) o[i] = i < valid ? o[i] + v[i] : 0.f;
             *p = o;
         });
-        tb_planes_out<64>(AP, a.dg1p + (long long)b * (2 * TB_AP_PLANE), t);      // dg1 = df1 planes
+        tb_planes_out<64>(AP, q3.dg1p + (long long)b * (2 * TB_AP_PLANE), t);      // dg1 = df1 planes
     }
     raw_barrier();
 
+    const tb_bwd_args q4 = tb_args_again(a0);                 // (see tb_args_again)
     // ---- T4: LayerNorm1': dr1 -> HBM (the residual path into dh), da1 = dropout'(dr1) -> A planes (T5 copies them to HBM)
     {
         float pe[2][4], po[2][4];
@@ -1048,14 +1076,14 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = 4 * lane - 2 * par + 2 * p;
-                pg1[par][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.ln1_g + cp) : tb_f2{0.f, 0.f};
+                pg1[par][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(q4.ln1_g + cp) : tb_f2{0.f, 0.f};
             }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = 4 * lane - ((rr & 1) ? 2 : 0) + 2 * p;
-                in_r1[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(a.r1 + (long long)b * (TB_L * TB_D) + (unsigned)((8 * w + rr) * TB_D + cp)) : tb_f2{0.f, 0.f};
+                in_r1[rr][p] = (cp >= 0 && cp < TB_D) ? *reinterpret_cast<const tb_f2*>(q4.r1 + (long long)b * (TB_L * TB_D) + (unsigned)((8 * w + rr) * TB_D + cp)) : tb_f2{0.f, 0.f};
             }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -1074,17 +1102,17 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
                 for (int e = 0; e < 2; ++e) { dy[2 * p + e] = v0[e]; x1[2 * p + e] = v1[e]; g1[2 * p + e] = v2[e]; }
             }
             float dr1[4];
-            if (rr & 1) tb_ln_bwd_row(dy, x1, g1, ok, a.mu1[row], a.rs1[row], dr1, po[0], po[1]);
-            else tb_ln_bwd_row(dy, x1, g1, ok, a.mu1[row], a.rs1[row], dr1, pe[0], pe[1]);
+            if (rr & 1) tb_ln_bwd_row(dy, x1, g1, ok, q4.mu1[row], q4.rs1[row], dr1, po[0], po[1]);
+            else tb_ln_bwd_row(dy, x1, g1, ok, q4.mu1[row], q4.rs1[row], dr1, pe[0], pe[1]);
             bool keep[4] = {true, true, true, true};
-            if (TRAIN && a.drop_p > 0.f && c0 < TB_D) dropout_keep4(a.seed, a.site_attn_out, (unsigned long long)(rbase + c0), a.drop_p, keep);
+            if (TRAIN && q4.drop_p > 0.f && c0 < TB_D) dropout_keep4(q4.seed, q4.site_attn_out, (unsigned long long)(rbase + c0), q4.drop_p, keep);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int cp = c0 + 2 * p;
-                const float d0 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p] ? dr1[2 * p] * ksc : 0.f) : dr1[2 * p];
-                const float d1 = (TRAIN && a.drop_p > 0.f) ? (keep[2 * p + 1] ? dr1[2 * p + 1] * ksc : 0.f) : dr1[2 * p + 1];
+                const float d0 = (TRAIN && q4.drop_p > 0.f) ? (keep[2 * p] ? dr1[2 * p] * ksc : 0.f) : dr1[2 * p];
+                const float d1 = (TRAIN && q4.drop_p > 0.f) ? (keep[2 * p + 1] ? dr1[2 * p + 1] * ksc : 0.f) : dr1[2 * p + 1];
                 if (ok[p]) {
-                    *reinterpret_cast<tb_f2*>(a.dr1 + rbase + (unsigned)cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
+                    *reinterpret_cast<tb_f2*>(q4.dr1 + rbase + (unsigned)cp) = tb_f2{dr1[2 * p], dr1[2 * p + 1]};
                 }
                 if (cp >= 0 && cp < 256) tb_store_planes2(AP, TB_AP_PLANE, ap_off(r, cp), ok[p] ? d0 : 0.f, ok[p] ? d1 : 0.f);
             }
@@ -1095,15 +1123,16 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_bwd_a_kernel(const 
     }
     raw_barrier();
 
+    const tb_bwd_args q5 = tb_args_again(a0);                 // (see tb_args_again)
     // ---- T5: dctx = da1 Wo -> HBM, natural (row, 248) layout (the packed operand's columns are 64 head + d)
     {
         f32x4 acc[4][2];
-        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, a.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
+        tb_gemm<2, 3u, TB_BWD_PF, true, true>(AP, q5.packed + TB_OFF_OT + (long long)(2 * w) * TB_KS * TB_TILE, lane, acc);
         tb_for_tiles(w, lane, 256, acc, [&](int m, int n0, int valid, f32x4& v) {
             const int head = n0 >> 6, d0 = n0 & 63;
-            if (d0 < TB_E) tb_st4(a.dctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, v);
+            if (d0 < TB_E) tb_st4(q5.dctx + (long long)b * (TB_L * TB_HE) + (unsigned)(m * TB_HE + head * TB_E + d0), TB_E - d0 >= 4 ? 4 : 2, v);
         });
-        tb_planes_out<64>(AP, a.da1p + (long long)b * (2 * TB_AP_PLANE), t);
+        tb_planes_out<64>(AP, q5.da1p + (long long)b * (2 * TB_AP_PLANE), t);
     }
 }
 

@@ -49,19 +49,24 @@ def split_planes(x, planes):
     return hi, lo
 
 
-def split_planes_many(xs, planes):
+def split_planes_many(xs, planes, stack=None):
     """split_planes of several same-shaped feature matrices in ONE launch (eegclip_split_rows over a table: the query features and both
-    targets of the batch loop -- three 5-us launches of a 1 MB split each, between the encoder's forward and the loss, became one)"""
+    targets of the batch loop -- three 5-us launches of a 1 MB split each, between the encoder's forward and the loss, became one).
+    stack = a ((len(xs) - 1) n, D) fp32 tensor: the same launch also leaves xs[1:] stacked in it (the targets as ONE contraction operand of the
+    query gradient, _grad_rows_stacked)"""
     # (only where launches, not bytes, are the cost: the table kernel converts element by element, the single-tensor one in 16-byte vectors --
     #  at N = 2048 three vectorised launches are faster: 82.6 vs 92.4 us for the whole loss forward)
     if (len(xs) == 1 or any(x.shape != xs[0].shape or not x.is_contiguous() for x in xs) or xs[0].shape[1] % 64 != 0 or len(xs) > 24
             or xs[0].numel() > (1 << 19)):
+        if stack is not None:
+            torch.cat(list(xs[1:]), out=stack)
         return [split_planes(x, planes) for x in xs]
     n, Dm = xs[0].shape
     buf = torch.empty(len(xs), 2, n, Dm, dtype=torch.bfloat16, device=xs[0].device)
     items = (_abi.SplitItem * len(xs))()
     for i, x in enumerate(xs):
-        items[i] = _abi.SplitItem(src=x.data_ptr(), hi=buf[i, 0].data_ptr(), lo=buf[i, 1].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0)
+        items[i] = _abi.SplitItem(src=x.data_ptr(), hi=buf[i, 0].data_ptr(), lo=buf[i, 1].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0,
+                                  copy=stack[(i - 1) * n].data_ptr() if stack is not None and i > 0 else None, ld_copy=Dm)
     check(lib().eegclip_split_rows(items, len(xs), _stream()), "split_rows")
     return [(buf[i, 0], buf[i, 1] if planes == 2 else None) for i in range(len(xs))]
 
@@ -69,10 +74,11 @@ def split_planes_many(xs, planes):
 MAX_BLOCKS_PER_LAUNCH = 8          # IF_MAX_PROB of csrc/infonce_fused.hip (eegclip_infonce_fused_{fwd,grad} reject more)
 
 
-def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
+def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=None):
     """blocks = [(q planes, k planes, col0, weight)]: adds sum_blocks weight / n_total * sum_rows (lse_row - positive) to acc[0].
     want_grad = [(block index, index of the block whose lse is the second (per-key) normaliser, or None)]: for each, the gradient matrix
-    G = s * dL/dS of that block ((n, N) fp32, written once) is returned and d loss / d s is added to acc[1]."""
+    G = s * dL/dS of that block ((n, N) fp32, written once) is returned and d loss / d s is added to acc[1].  G_out = where to write them (one (n, N)
+    view per entry of want_grad, unit column stride, row stride a multiple of 4: e.g. side by side in one (n, T N) matrix)."""
     L = lib()
     dev = sc.device
     nb = len(blocks)
@@ -94,10 +100,10 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad):
     garr = (_abi.InfonceProblem * len(want_grad))()
     Gs = []
     for j, (bi, ki) in enumerate(want_grad):
-        G = torch.empty(n, N, dtype=torch.float32, device=dev)
+        G = G_out[j] if G_out is not None else torch.empty(n, N, dtype=torch.float32, device=dev)
         Gs.append(G)
         garr[j] = arr[bi]
-        garr[j].G, garr[j].ldg = G.data_ptr(), N
+        garr[j].G, garr[j].ldg = G.data_ptr(), G.stride(0)
         garr[j].lse_k = arr[ki].lse if ki is not None else None
     for c0 in range(0, len(want_grad), MAX_BLOCKS_PER_LAUNCH):
         chunk = (_abi.InfonceProblem * min(MAX_BLOCKS_PER_LAUNCH, len(want_grad) - c0))(*garr[c0:c0 + MAX_BLOCKS_PER_LAUNCH])
@@ -299,14 +305,23 @@ class _ClipLossFn(torch.autograd.Function):
         Dm = a_.shape[1]
         if W == 1 and fused_enabled(n, n, Dm) and all(b.shape == a_.shape for b in bs):
             # blocks (A, B_t) and (B_t, A) of every target in ONE launch; one gradient matrix per target with both normalisers
-            ap, *bps = split_planes_many([a_] + bs, planes)
+            # query gradient of T >= 2 targets as ONE contraction over the stacked targets: dA = [G_1 | .. | G_T] [B_1; ..; B_T] -- the gradient matrices
+            # side by side in one (n, T n) buffer, the targets stacked by the launch that splits them (T GEMM launches of K = n -> one of K = T n)
+            T_ = len(bs)
+            stacked = need_a and T_ >= 2
+            stack = torch.empty(T_ * n, Dm, dtype=torch.float32, device=dev) if stacked else None
+            ap, *bps = split_planes_many([a_] + bs, planes, stack)
             blocks, want = [], []
             for t, w in enumerate(weights):
                 blocks += [(ap, bps[t], 0, 0.5 * w), (bps[t], ap, 0, 0.5 * w)]
                 want.append((2 * t, 2 * t + 1))
-            Gs = fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want if need else [])
+            Gcat = torch.empty(n, T_ * n, dtype=torch.float32, device=dev) if stacked and need else None
+            Gs = fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want if need else [],
+                               [Gcat[:, t * n:(t + 1) * n] for t in range(T_)] if Gcat is not None else None)
+            if stacked and need:
+                da = _grad_rows(Gcat, stack, None, PX3)
             for t, b_ in enumerate(bs):
-                if need_a:
+                if need_a and not stacked:
                     da = _grad_rows(Gs[t], b_, da, PX3)
                 if need_b[t]:
                     dbs[t] = _grad_cols(Gs[t], a_, None, PX3)

@@ -65,12 +65,16 @@ class StepPlan:
         pl = Plan(f"contrastive_step[B={B}]", precision=self.fwd.precision)
         pl._keep += [self.fwd, self.bwd]
 
-        def splice(src):
-            base = len(pl.ops)
-            for fn, args, name, side in src.ops:
+        def splice(src, lo=0, hi=None, at=None):
+            """ops [lo, hi) of `src` appended; op i of src lands at (at if given else the current end) + i - lo ... i.e. `at` = plan index of src op 0 + shift"""
+            hi = len(src.ops) if hi is None else hi
+            base = len(pl.ops) - lo if at is None else at
+            assert base + lo == len(pl.ops)
+            for fn, args, name, side in src.ops[lo:hi]:
                 pl.ops.append((fn, list(args), name, side))
-            pl._seed_slots += [(base + i, j) for i, j in src._seed_slots]
-            pl._seed_descs += src._seed_descs
+            pl._seed_slots += [(base + i, j) for i, j in src._seed_slots if lo <= i < hi]
+            if lo == 0:
+                pl._seed_descs += src._seed_descs
             return base
 
         # ---- encoder forward
@@ -89,15 +93,16 @@ class StepPlan:
         pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch)
         self.plane_buf = torch.empty(3, 2, B, Dm, dtype=torch.bfloat16, device=dev)
+        self.stack = torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # [img; txt]: the ONE right-hand operand of the query gradient (loss.py)
         self.items = (_abi.SplitItem * 3)()
         for i in range(3):
             self.items[i] = _abi.SplitItem(src=0, hi=self.plane_buf[i, 0].data_ptr(), lo=self.plane_buf[i, 1].data_ptr(), rows=B, cols=Dm, ld_src=Dm, ld_out=Dm,
-                                           transpose=0)
+                                           transpose=0, copy=self.stack[(i - 1) * B].data_ptr() if i else None, ld_copy=Dm)
         pl._keep.append(self.items)
         pl.call("eegclip_split_rows", self.items, 3)
         ws = int(L.eegclip_infonce_fused_workspace_floats(B, B))
         self.if_buf = torch.empty(4 * (ws + 2 * B), dtype=torch.float32, device=dev)
-        self.G = torch.empty(2, B, B, dtype=torch.float32, device=dev)
+        self.G = torch.empty(B, 2 * B, dtype=torch.float32, device=dev)            # [G_img | G_txt] side by side
         base = self.if_buf.data_ptr()
 
         def planes_of(i):
@@ -115,40 +120,74 @@ class StepPlan:
         garr = (_abi.InfonceProblem * 2)()
         for t_ in range(2):
             garr[t_] = arr[2 * t_]
-            garr[t_].G, garr[t_].ldg = self.G[t_].data_ptr(), B
+            garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), 2 * B
             garr[t_].lse_k = arr[2 * t_ + 1].lse
         pl._keep += [arr, garr]
         self.if_fwd_op = len(pl.ops)
         pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
         pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
         self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
-        self.da_descs = []
-        for t_ in range(2):
-            d = _abi.GemmDesc(M=B, N=Dm, K=B, A=self.G[t_].data_ptr(), Am=D(B), Ak=D(1), B=0, Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(), Cm=D(Dm), Cn=D(1),
-                              Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=int(t_ > 0), act=0, drop_p=0.0, seed=0,
-                              drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
-            pl._keep.append(d)
-            self.da_descs.append(d)
-            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
-        # ---- encoder backward
-        b0 = splice(self.bwd)
-        self.bwd_base = b0
-        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
-        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
-        pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
-        # ---- fused AdamW + the zero_grad() that opens the next iteration
+        # dA = [G_img | G_txt] [img; txt]: one launch, K = 2 B
+        d = _abi.GemmDesc(M=B, N=Dm, K=2 * B, A=self.G.data_ptr(), Am=D(2 * B), Ak=D(1), B=self.stack.data_ptr(), Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(),
+                          Cm=D(Dm), Cn=D(1), Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0,
+                          seed=0, drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
+        pl._keep.append(d)
+        pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
+        # ---- encoder backward + fused AdamW (and the zero_grad() that opens the next iteration).  The value embedding's weight gradient is the LAST thing the
+        # backward forms (its dY is the end of the chain: 58 us of weight-gradient launch + slab reduction for 63 k parameters); it sits at the end of the flat
+        # parameter buffer (atms._LIVE), so AdamW over everything before it forks onto the second stream where that tail begins, and the main stream ends
+        # with a second, small AdamW launch over [value embedding | token rows].  Same element-wise update either way.
         fast = optimizer._fast_last.get(0)
         self.fast = fast
         self.group = optimizer.param_groups[0]
-        self.adam_ops = []
+        self.adam_ops = []                # (plan op, index into fast["launch"]): the step count of that run is patched per call
         gs = optimizer.grad_scale_dev.data_ptr() if optimizer.grad_scale_dev is not None else None
         b1, b2 = self.group["betas"]
-        for (p0, n, wp, gp, mp, vp, members) in fast["launch"]:
-            self.adam_ops.append(len(pl.ops))
-            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"], 0, 1.0, gs)
+
+        def adam(li, lo, hi, side):
+            p0, n, wp, gp, mp, vp, members = fast["launch"][li]
+            if hi > lo:
+                self.adam_ops.append((len(pl.ops), li))
+                pl.call("eegclip_adamw_step_zero_grad", wp + 4 * lo, gp + 4 * lo, mp + 4 * lo, vp + 4 * lo, hi - lo, self.group["lr"], b1, b2, self.group["eps"],
+                        self.group["weight_decay"], 0, 1.0, gs, side=side)
+
+        tail = getattr(self.bwd, "tail_op", None)
+        ve = eng.P.get("encoder.enc_embedding.value_embedding.weight")
+        cut = {}                          # run index -> element offset of the value embedding inside that run
+        if tail is not None and ve is not None and os.environ.get("EEGCLIP_ADAM_SPLIT", "0") == "1":
+            for li, (p0, n, wp, gp, mp, vp, members) in enumerate(fast["launch"]):
+                off = (ve.data_ptr() - wp) // 4
+                if 0 < off < n and (off & 3) == 0:
+                    cut[li] = off
+        b0 = len(pl.ops)
+        self.bwd_base = b0
+        self.bwd_cut, self.bwd_shift = (tail, 0) if cut else (len(self.bwd.ops), 0)
+        if cut:
+            splice(self.bwd, 0, tail)
+            n0 = len(pl.ops)
+            for li, (p0, n, *_r) in enumerate(fast["launch"]):
+                adam(li, 0, cut.get(li, n), True)                    # second stream: behind every weight gradient launched so far (they are all on that stream
+            self.bwd_shift = len(pl.ops) - n0                        #   or on the main stream before this point)
+            splice(self.bwd, tail, len(self.bwd.ops), at=b0 + self.bwd_shift)
+        else:
+            splice(self.bwd, 0, len(self.bwd.ops))
+        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
+        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
+        pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
+        for li, (p0, n, *_r) in enumerate(fast["launch"]):
+            if not cut:
+                adam(li, 0, n, False)
+            elif li in cut:
+                adam(li, cut[li], n, False)
         self.hyper = (self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"])
         self.pl = pl
         self._class_ptr = None
+
+    def index_of(self, kind, i):
+        """plan op index of op `i` of the spliced forward ("f") / backward ("b") plan (bench.py maps its per-launch timings through this)"""
+        if kind == "f":
+            return self.fwd_base + i
+        return self.bwd_base + i + (self.bwd_shift if i >= self.bwd_cut else 0)
 
     # ------------------------------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -189,7 +228,7 @@ class StepPlan:
             if optimizer.param_groups[0] is not g:
                 return False
             self.hyper = (g["lr"], b1, b2, g["eps"], g["weight_decay"])       # (a learning-rate schedule: patch the optimizer launches)
-            for op in self.adam_ops:
+            for op, _li in self.adam_ops:
                 for j, v in zip((5, 6, 7, 8, 9), self.hyper):
                     self.pl.set_arg(op, j, v)
         return all(p.grad is None for p in g["params"])
@@ -211,14 +250,13 @@ class StepPlan:
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
         self.items[0].src, self.items[1].src, self.items[2].src = op, img.data_ptr(), txt.data_ptr()
-        self.da_descs[0].B, self.da_descs[1].B = img.data_ptr(), txt.data_ptr()
         acc = _zero_pair(self.dev)
         pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
         fast = self.fast
         fast["run_steps"] = [st + 1 for st in fast["run_steps"]]
         fast["pending"] += 1
-        for opi, st in zip(self.adam_ops, fast["run_steps"]):
-            pl.set_arg(opi, 10, st)
+        for opi, li in self.adam_ops:
+            pl.set_arg(opi, 10, fast["run_steps"][li])
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if max(self.probs) > 0 else 0
         b["seed"] = seed
         pl._keep_step = (eeg_data, img, txt, labels, class_feats, out)      # (alive until the next step has been enqueued)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 7
+#define EEGCLIP_ABI_VERSION 8
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -102,6 +102,9 @@ typedef struct {
     int rows, cols;       /* of the source */
     long long ld_src, ld_out;
     int transpose;
+    float* copy;          /* NULL, or (transpose == 0 only) where to leave an fp32 copy of the source as well, rows ld_copy >= cols elements apart: several
+                             matrices stacked into ONE contraction operand (the image and text targets of the loss gradient, models/loss.py:122-140) */
+    long long ld_copy;
 } eegclip_split_item;
 int eegclip_split_rows(const eegclip_split_item* items, int n, void* stream);
 int eegclip_gemm_f32(const eegclip_gemm_desc* d, void* stream);

@@ -186,6 +186,35 @@ def test_split_rows_planes_and_padding(be):
         assert (h[:, src.shape[1]:] == 0).all() and (l[:, src.shape[1]:] == 0).all()
 
 
+def test_split_rows_also_stacks_fp32_copies(be):
+    """eegclip_split_item.copy: the launch that splits several matrices into planes also leaves their fp32 rows in ONE stacked matrix (the image and text
+    targets as one operand of the loss's query gradient); both kernel paths (dense 16-byte, element-wise with a padded ld), refused with transpose"""
+    rng = np.random.default_rng(3)
+    for rows, cols, ld_copy in ((32, 64, 64), (5, 50, 72)):
+        ws = [f32(rng, rows, cols) for _ in range(3)]
+        ld = (cols + 63) // 64 * 64 if cols % 64 else cols
+        W = [be.dev(w) for w in ws]
+        hi = [be.dev(np.zeros((rows, ld), np.uint16)) for _ in ws]
+        lo = [be.dev(np.zeros((rows, ld), np.uint16)) for _ in ws]
+        stack = be.dev(np.full((2 * rows, ld_copy), 7.0, np.float32))
+        its = (_abi.SplitItem * 3)()
+        for i in range(3):
+            its[i] = _abi.SplitItem(src=be.ptr(W[i]), hi=be.ptr(hi[i]), lo=be.ptr(lo[i]), rows=rows, cols=cols, ld_src=cols, ld_out=ld, transpose=0,
+                                    copy=be.ptr(stack) + 4 * (i - 1) * rows * ld_copy if i else None, ld_copy=ld_copy)
+        assert be.lib.eegclip_split_rows(its, 3, be.stream) == 0
+        got = be.host(stack)
+        np.testing.assert_array_equal(got[:rows, :cols], ws[1])
+        np.testing.assert_array_equal(got[rows:, :cols], ws[2])
+        assert (got[:, cols:] == 7.0).all()                                      # the padding of the copy is not touched
+        for i in range(3):
+            h = (be.host(hi[i]).astype(np.uint32) << 16).view(np.float32)
+            np.testing.assert_array_equal(h[:, :cols], bf16_round(ws[i]))
+    its[1].transpose = 1
+    assert be.lib.eegclip_split_rows(its, 3, be.stream) != 0
+    its[1].transpose, its[1].ld_copy = 0, 8
+    assert be.lib.eegclip_split_rows(its, 3, be.stream) != 0
+
+
 @pytest.mark.parametrize("cfg", [0, 2, 3, 5])
 @pytest.mark.parametrize("M,N,K,split_k", [(72, 66, 330, 3), (200, 130, 70, 2), (130, 250, 1100, 8), (2, 2, 40, 5)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1)])
