@@ -119,6 +119,7 @@ PROTOTYPES = {
     "eegclip_gemm_f32_grouped": [_P, _I, _P],
     "eegclip_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "eegclip_residual_layernorm_fwd": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "eegclip_residual_layernorm_fwd_planes": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P],
     "eegclip_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P],
     "eegclip_layernorm_bwd_full_workspace_floats": [_I, _I],
     "eegclip_layernorm_bwd_full": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _F, _U64, _U, _P, _P],
@@ -218,6 +219,7 @@ PROTOTYPES = {
     "eegclip_cstack_bwd_stats": [C.POINTER(CstackBwdDesc), _P],
     "eegclip_cstack_bwd_workspace_floats": [_I],
     "eegclip_cstack_bwd_apply": [C.POINTER(CstackBwdDesc), _P],
+    "eegclip_cstack_bwd_taps_reduce": [_P, _I, _P, _P],
     "eegclip_cstack_bwd_w2_workspace_floats": [_I, _I],
     "eegclip_cstack_bwd_w2": [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "eegclip_plan_fn_id": [C.c_char_p],

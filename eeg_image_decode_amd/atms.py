@@ -772,7 +772,9 @@ class _Engine:
         attn_bwd = "eegclip_attention_bwd_x3" if pl.precision == _abi.PREC_BF16X3 else "eegclip_attention_bwd"
         sk = lambda k: (wsk if (wsk > 0 and k >= 4096) else max(1, min(64, k // 512)))      # split-K for the reduce-over-batch weight-gradient GEMMs
 
-        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=True):
+        head_side = os.environ.get("EEGCLIP_HEAD_WGRAD_SIDE", "1") != "0"      # (A/B aid)
+
+        def wgrad(name, dY, ldy, X, ldx, Nout, Nin, K, bias=None, side=head_side):
             """G[name] (Nout, Nin) += dY^T X   with dY (K, ldy), X (K, ldx) row-major; bias: G[bias] (Nout) += column sums of dY, taken
             from the A tiles the same launch stages (rowsum_a) instead of a separate pass over dY"""
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
@@ -882,15 +884,29 @@ class _Engine:
                 pl.call("eegclip_wgrad_tok_reduce", arr, len(problems), B, slices, _p(b[key]), side=side)
                 return arr, ops
 
-            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
-            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
-            wgrad_tok("ffn_out", [
+            # EEGCLIP_WGRAD_MERGE (single-embedding model): 0 = three weight-gradient launches, each as soon as its dY planes exist (second stream);
+            # 1 = the q | k | v gradient waits for the embedding's and shares its launch; 2 = all five in ONE launch after the last dY.  The fused backward
+            # kernels own their CUs (160 KB of LDS, 2 waves per SIMD of 200+ VGPRs), so an "overlapping" weight-gradient launch in fact queues for CUs behind
+            # them: fewer, fuller launches read the same 192 MB of planes with more workgroups in flight
+            merge = 0 if self.joint else int(os.environ.get("EEGCLIP_WGRAD_MERGE", "2"))
+            late = []
+            ffn_out = [
                 (_LY + "conv2.weight", df2p, 1, g1p, D_MODEL, D_FF, 0, 0, _LY + "conv2.bias", 1),          # g1 has 256 real channels: no ones column
                 (_LY + "conv1.weight", dg1p, 1, n1p, D_FF, D_MODEL, 0, 0, _LY + "conv1.bias", 0),
-                (_LY + "attention.out_projection.weight", da1p, 1, ctxp, D_MODEL, HE, 0, 1, _LY + "attention.out_projection.bias", 0)])
+                (_LY + "attention.out_projection.weight", da1p, 1, ctxp, D_MODEL, HE, 0, 1, _LY + "attention.out_projection.bias", 0)]
+            qkv_w = [(_LY + "attention.query_projection.weight", dqkvp, 3, hp, 3 * HE, D_MODEL, 1, 0, _LY + "attention.query_projection.bias", 0)]
+            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
+            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
+            if merge >= 2:
+                late += ffn_out
+            else:
+                wgrad_tok("ffn_out", ffn_out)
             pl.call(attn_bwd, _p(b["qkv"]), _p(b["dctx"]), dqkvp, 1, B, L_TOK, N_HEADS, D_HEAD, 3 * HE, 1.0 / math.sqrt(D_HEAD),
                     pe_, 0, SITE_ATTN, seed_at=11)
-            wgrad_tok("qkv", [(_LY + "attention.query_projection.weight", dqkvp, 3, hp, 3 * HE, D_MODEL, 1, 0, _LY + "attention.query_projection.bias", 0)])
+            if merge >= 1:
+                late += qkv_w
+            else:
+                wgrad_tok("qkv", qkv_w)
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 1)
         else:
             # final LN, LN2
@@ -940,7 +956,7 @@ class _Engine:
             # value embedding: dY = the token-row gradients part 1 left as planes, X = the EEG sample planes of the forward (row 0 zero: the subject
             # token has no EEG row; ones column in rows 1..63: bias gradient = sum of the 63 channel rows of every sample)
             if not self.joint:
-                wgrad_tok("embed", [(_E + "value_embedding.weight", dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, _E + "value_embedding.bias", 0)], side=False)
+                wgrad_tok("embed" + ("+%d" % len(late) if late else ""), late + [(_E + "value_embedding.weight", dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, _E + "value_embedding.bias", 0)], side=False)
             else:
                 # joint-subject model: one problem per subject PRESENT in the batch, each contracting over that subject's samples only -- a range of
                 # the subject-ordered sample list b["perm"] (the planes stay in batch order: the kernel looks the sample up per k-tile).  The member
@@ -999,7 +1015,7 @@ class _Engine:
         xs = (_p(b["n3"]), L_TOK * D_MODEL, D_MODEL)
         bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
         pl.call("eegclip_cstack_bwd_w2", *xs, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), *bnp, _p(b["dy2"]), _p(G[_TS + "4.weight"]), _p(b["csw_ws"]),
-                B, N_CH, side=True)
+                B, N_CH, side=os.environ.get("EEGCLIP_W2_SIDE", "1") != "0")
         rows3 = b["cs_rows3"]
         count1 = float(W * B * N_CH * W_TS)
         common = dict(B=B, H=N_CH, x=xs[0], xs_b=xs[1], xs_h=xs[2], w25=_p(P[_TS + "0.weight"]), bias1=_p(P[_TS + "0.bias"]), mean1=bnp[0], rstd1=bnp[1],
@@ -1015,7 +1031,9 @@ class _Engine:
             stat, nstat = (_p(sums[3]), 1) if train else (_p(zsum), 1)
             if not train:
                 pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
-        pl.call_desc("eegclip_cstack_bwd_apply", _abi.CstackBwdDesc(stat=stat, nstat=nstat, stat_local=local, nstat_local=nlocal, **common))
+        # (the tap gradient leaves the apply pass as one partial row per sample; their sum is read by the optimizer only: second stream)
+        pl.call_desc("eegclip_cstack_bwd_apply", _abi.CstackBwdDesc(stat=stat, nstat=nstat, stat_local=local, nstat_local=nlocal, **dict(common, dw25=None)))
+        pl.call("eegclip_cstack_bwd_taps_reduce", _p(b["csb_ws"]), B, _p(G[_TS + "0.weight"]), side=True)
         if early_reduce:
             # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
             # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest

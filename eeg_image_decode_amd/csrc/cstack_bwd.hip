@@ -610,13 +610,22 @@ extern "C" long long eegclip_cstack_bwd_workspace_floats(int B) { return B < 1 ?
 
 extern "C" int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* stream) {
     if (int rc = csb_check(d)) return rc;
-    if (!d->stat || d->nstat < 1 || d->count < 1.0 || !d->dgamma || !d->dbeta || !d->dx || !d->dw_partials || !d->dw25) return EEGCLIP_EINVAL;
+    if (!d->stat || d->nstat < 1 || d->count < 1.0 || !d->dgamma || !d->dbeta || !d->dx || !d->dw_partials) return EEGCLIP_EINVAL;
     if (d->stat_local && d->nstat_local < 1) return EEGCLIP_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d->stat) | reinterpret_cast<uintptr_t>(d->stat_local)) & 7u) return EEGCLIP_EALIGN;
     const size_t lds = (size_t)d->H * CS_RS * 4 + CSB_NCOEF * 48 * 4 + CSB_DYF + CSB_TAPF + CS_NW * CSB_WAVE;
     EEG_LAUNCH(cstack_bwd_kernel<true>, dim3(d->B), dim3(CS_NT), lds, stream, csb_args(d));
+    if (!d->dw25) return (int)hipGetLastError();                 // the caller sums the tap-gradient rows itself (eegclip_cstack_bwd_taps_reduce, any stream)
     const int n = CS_C * CS_K1;
     EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((n + 15) / 16), dim3(256), 256 * sizeof(float), stream, (const float*)d->dw_partials, d->B, n, d->dw25);
+    return (int)hipGetLastError();
+}
+
+// dw25 (+)= the B partial rows eegclip_cstack_bwd_apply left in `dw_partials` (a launch of its own so that it can leave the dX chain: only the optimizer reads it)
+extern "C" int eegclip_cstack_bwd_taps_reduce(const float* dw_partials, int B, float* dw25, void* stream) {
+    if (!dw_partials || !dw25 || B < 1) return EEGCLIP_EINVAL;
+    const int n = CS_C * CS_K1;
+    EEG_LAUNCH(cstack_rows_reduce_kernel, dim3((n + 15) / 16), dim3(256), 256 * sizeof(float), stream, dw_partials, B, n, dw25);
     return (int)hipGetLastError();
 }
 

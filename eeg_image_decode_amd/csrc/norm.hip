@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
                                                                       float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                                       float* __restrict__ y2, float* __restrict__ mean2_out, float* __restrict__ rstd2_out,
-                                                                      int rows, int cols, float eps) {
+                                                                      int rows, int cols, float eps, unsigned short* __restrict__ y_hi,
+                                                                      unsigned short* __restrict__ y_lo) {
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
                 s2 += v[i][e];
             }
             st4(y + rbase, c, v[i]);
+            if (y_hi && c < cols) {                               // y again as bf16 hi | lo planes (cols % 4 == 0: checked by the host): the next contraction's operand
+                u32x2_t hi, lo;
+                x3_split4(v[i][0], v[i][1], v[i][2], v[i][3], hi, lo);
+                *reinterpret_cast<u32x2_t*>(y_hi + rbase + c) = hi;
+                *reinterpret_cast<u32x2_t*>(y_lo + rbase + c) = lo;
+            }
         }
         if (lane == 0) {
             if (mean_out) mean_out[row] = mean;
@@ -652,10 +659,10 @@ extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const f
     return (int)hipGetLastError();
 }
 
-extern "C" int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
+static int residual_layernorm_fwd_go(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
                                               unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                               const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
-                                              float eps, void* stream) {
+                                              float eps, unsigned short* y_hi, unsigned short* y_lo, void* stream) {
     const bool dbl = gamma2 != nullptr;
     if (!x || !gamma || !beta || !y || rows < 0 || cols < 1 || cols > 64 * LN_MAXC || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if ((x_out || drop_p > 0.f) && !resid) return EEGCLIP_EINVAL;
@@ -668,7 +675,7 @@ extern "C" int eegclip_residual_layernorm_fwd(const float* x, const float* resid
                          reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2) | reinterpret_cast<uintptr_t>(y2)) & 7u);
 #define EEG_RLN_GO(NG, V2, DB)                                                                                                              \
     EEG_LAUNCH((residual_layernorm_fwd_kernel<NG, V2, DB>), dim3(grid), dim3(256), 0, stream, x, resid, x_out, drop_p, seed, site, gamma, beta, y, \
-               mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps)
+               mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps, y_hi, y_lo)
     if (cols <= 256) {
         if (vec2) { if (dbl) EEG_RLN_GO(1, true, true); else EEG_RLN_GO(1, true, false); }
         else      { if (dbl) EEG_RLN_GO(1, false, true); else EEG_RLN_GO(1, false, false); }
@@ -678,6 +685,23 @@ extern "C" int eegclip_residual_layernorm_fwd(const float* x, const float* resid
     }
 #undef EEG_RLN_GO
     return (int)hipGetLastError();
+}
+
+extern "C" int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
+                                              unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                              const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
+                                              float eps, void* stream) {
+    return residual_layernorm_fwd_go(x, resid, x_out, drop_p, seed, site, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps, nullptr,
+                                     nullptr, stream);
+}
+
+extern "C" int eegclip_residual_layernorm_fwd_planes(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
+                                                     unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                                     const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
+                                                     float eps, void* y_hi, void* y_lo, void* stream) {
+    if (!y_hi || !y_lo || (cols & 3) || ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7u)) return EEGCLIP_EINVAL;
+    return residual_layernorm_fwd_go(x, resid, x_out, drop_p, seed, site, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps,
+                                     static_cast<unsigned short*>(y_hi), static_cast<unsigned short*>(y_lo), stream);
 }
 
 extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -77,6 +77,9 @@ class StepPlan:
                 pl._seed_descs += src._seed_descs
             return base
 
+        # ---- the targets' operand planes + fp32 stack: inputs only, second stream, under the encoder's forward (items filled below)
+        self.split_op = len(pl.ops)
+        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", True))
         # ---- encoder forward
         f0 = splice(self.fwd)
         self.fwd_base = f0
@@ -91,15 +94,21 @@ class StepPlan:
         pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
         self.count_op = len(pl.ops)
         pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
-        # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch)
+        # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch).  Operand planes: the targets are inputs of the
+        # step -- split (and stacked for the query gradient) by a second-stream launch at the very start; the query features leave the head's LayerNorm as
+        # planes (eegclip_residual_layernorm_fwd_planes: the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
         self.plane_buf = torch.empty(3, 2, B, Dm, dtype=torch.bfloat16, device=dev)
         self.stack = torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # [img; txt]: the ONE right-hand operand of the query gradient (loss.py)
-        self.items = (_abi.SplitItem * 3)()
-        for i in range(3):
-            self.items[i] = _abi.SplitItem(src=0, hi=self.plane_buf[i, 0].data_ptr(), lo=self.plane_buf[i, 1].data_ptr(), rows=B, cols=Dm, ld_src=Dm, ld_out=Dm,
-                                           transpose=0, copy=self.stack[(i - 1) * B].data_ptr() if i else None, ld_copy=Dm)
+        self.items = (_abi.SplitItem * 2)()
+        for i in range(2):
+            self.items[i] = _abi.SplitItem(src=0, hi=self.plane_buf[1 + i, 0].data_ptr(), lo=self.plane_buf[1 + i, 1].data_ptr(), rows=B, cols=Dm, ld_src=Dm,
+                                           ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr(), ld_copy=Dm)
         pl._keep.append(self.items)
-        pl.call("eegclip_split_rows", self.items, 3)
+        pl.ops[self.split_op][1][0] = self.items
+        fn, args, name, side = pl.ops[self.out_op]
+        assert name == "eegclip_residual_layernorm_fwd"
+        pl.ops[self.out_op] = (L.eegclip_residual_layernorm_fwd_planes, args[:-1] + [self.plane_buf[0, 0].data_ptr(), self.plane_buf[0, 1].data_ptr(), None],
+                               "eegclip_residual_layernorm_fwd_planes", side)
         ws = int(L.eegclip_infonce_fused_workspace_floats(B, B))
         self.if_buf = torch.empty(4 * (ws + 2 * B), dtype=torch.float32, device=dev)
         self.G = torch.empty(B, 2 * B, dtype=torch.float32, device=dev)            # [G_img | G_txt] side by side
@@ -249,7 +258,7 @@ class StepPlan:
             self._class_ptr = cp
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
-        self.items[0].src, self.items[1].src, self.items[2].src = op, img.data_ptr(), txt.data_ptr()
+        self.items[0].src, self.items[1].src = img.data_ptr(), txt.data_ptr()
         acc = _zero_pair(self.dev)
         pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
         fast = self.fast

@@ -131,6 +131,12 @@ int eegclip_layernorm_fwd(const float* x, const float* gamma, const float* beta,
 int eegclip_residual_layernorm_fwd(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed, unsigned int site,
                                    const float* gamma, const float* beta, float* y, float* mean, float* rstd, const float* gamma2,
                                    const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols, float eps, void* stream);
+/* the same pass, y additionally as bf16 hi | lo planes (value = hi + lo, [rows][cols], cols % 4 == 0, 8-byte aligned): the operand form of the fused InfoNCE
+ * kernels / plane GEMMs without a separate eegclip_split_rows launch (the projection head's output, Retrieval/ATMS_retrieval.py:157-167 -> models/loss.py:122) */
+int eegclip_residual_layernorm_fwd_planes(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed, unsigned int site,
+                                          const float* gamma, const float* beta, float* y, float* mean, float* rstd, const float* gamma2,
+                                          const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols, float eps, void* y_hi, void* y_lo,
+                                          void* stream);
 int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop, float drop_p,
                           unsigned long long seed, unsigned int site, void* stream);
@@ -696,6 +702,9 @@ int eegclip_cstack_pack_all(const float* Ws, void* packed, void* packed_t, int H
 int eegclip_cstack_bwd_stats(const eegclip_cstack_bwd_desc* d, void* stream);
 long long eegclip_cstack_bwd_workspace_floats(int B);
 int eegclip_cstack_bwd_apply(const eegclip_cstack_bwd_desc* d, void* stream);
+/* dw25 == NULL in the descriptor: eegclip_cstack_bwd_apply leaves the tap gradient as its B partial rows and this call sums them (dw25 += ...; only the
+ * optimizer reads the result, so the launch can run beside the rest of the backward) */
+int eegclip_cstack_bwd_taps_reduce(const float* dw_partials, int B, float* dw25, void* stream);
 long long eegclip_cstack_bwd_w2_workspace_floats(int B, int H);
 int eegclip_cstack_bwd_w2(const float* x, long long xs_b, long long xs_h, const float* w25, const float* bias1, const float* mean1, const float* rstd1,
                           const float* gamma1, const float* beta1, const float* dy2, float* dWs, float* workspace, int B, int H, void* stream);

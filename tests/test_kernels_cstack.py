@@ -147,7 +147,13 @@ def test_cstack_backward(be, B, H):
     ONE = be.dev(rows.sum(0, keepdims=True))
     DG2, DB2, DX2 = be.zeros(C), be.zeros(C), be.dev(np.full((B, 64, 250), 7.0, np.float32))
     d.stat, d.nstat, d.stat_local, d.nstat_local, d.dgamma, d.dbeta, d.dx = be.ptr(ONE), 1, be.ptr(ROWS), B, be.ptr(DG2), be.ptr(DB2), be.ptr(DX2)
+    d.dw25 = None                                                    # ... and the tap gradient left as rows for a launch of its own (second stream in the plans)
     ok(be.lib.eegclip_cstack_bwd_apply(ctypes.byref(d), be.stream))
+    DW25b = be.dev(np.ones((C, 25), np.float32))
+    ok(be.lib.eegclip_cstack_bwd_taps_reduce(be.ptr(DWP), B, be.ptr(DW25b), be.stream))
+    np.testing.assert_array_equal(be.host(DW25b), be.host(DW25))
+    assert be.lib.eegclip_cstack_bwd_taps_reduce(None, B, be.ptr(DW25b), be.stream) < 0 and be.lib.eegclip_cstack_bwd_taps_reduce(be.ptr(DWP), 0, be.ptr(DW25b), be.stream) < 0
+    d.dw25 = be.ptr(DW25)
     np.testing.assert_allclose(be.host(DX2), dx, atol=1e-6)
     np.testing.assert_allclose(be.host(DB2), gb, atol=2e-4 * max(1.0, np.abs(gb).max()))
     np.testing.assert_allclose(be.host(DG2), gg, atol=2e-4 * max(1.0, np.abs(gg).max()))

@@ -103,6 +103,21 @@ def test_residual_layernorm_fwd(be, rows, cols, p, double):
     np.testing.assert_allclose(be.host(Y3), y3.numpy(), atol=3e-5)
     assert be.lib.eegclip_residual_layernorm_fwd(be.ptr(Rz), None, None, 0.25, 0, 0, be.ptr(G1), be.ptr(B1), be.ptr(Y3), None, None, None, None, None,
                                                  None, None, rows, cols, 1e-5, be.stream) < 0
+    # the same pass leaving y as bf16 hi | lo planes as well (the InfoNCE kernels' operand form): same y, planes = the split eegclip_split_rows makes of it
+    YH, YL = be.dev(np.zeros((rows, cols), np.uint16)), be.dev(np.zeros((rows, cols), np.uint16))
+    Y4 = be.zeros((rows, cols))
+    rc = be.lib.eegclip_residual_layernorm_fwd_planes(be.ptr(Rz), None, None, 0.0, 0, 0, be.ptr(G1), be.ptr(B1), be.ptr(Y4), None, None, None, None, None, None,
+                                                      None, rows, cols, 1e-5, be.ptr(YH), be.ptr(YL), be.stream)
+    if cols % 4:
+        assert rc < 0
+    else:
+        ok(rc)
+        y4 = be.host(Y4)
+        np.testing.assert_array_equal(y4, be.host(Y3))
+        hi = (be.host(YH).astype(np.uint32) << 16).view(np.float32)
+        lo = (be.host(YL).astype(np.uint32) << 16).view(np.float32)
+        np.testing.assert_array_equal(hi, _bf16_round(y4))
+        np.testing.assert_array_equal(lo, _bf16_round((y4 - _bf16_round(y4)).astype(np.float32)))
 
 
 @pytest.mark.parametrize("outer,C,inner,p", [(6, 40, 63 * 36, 0.0), (9, 40, 36, 0.5), (2, 3, 5, 0.0)])
