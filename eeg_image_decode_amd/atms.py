@@ -884,11 +884,12 @@ class _Engine:
                 pl.call("eegclip_wgrad_tok_reduce", arr, len(problems), B, slices, _p(b[key]), side=side)
                 return arr, ops
 
-            # EEGCLIP_WGRAD_MERGE (single-embedding model): 0 = three weight-gradient launches, each as soon as its dY planes exist (second stream);
-            # 1 = the q | k | v gradient waits for the embedding's and shares its launch; 2 = all five in ONE launch after the last dY.  The fused backward
+            # EEGCLIP_WGRAD_MERGE: 0 = three weight-gradient launches, each as soon as its dY planes exist (second stream);
+            # 1 = the q | k | v gradient waits for the embedding's and shares its launch; 2 = all five in ONE launch after the last dY (joint-subject model: the
+            # four shared ones in one launch, the per-subject value embeddings in theirs).  The fused backward
             # kernels own their CUs (160 KB of LDS, 2 waves per SIMD of 200+ VGPRs), so an "overlapping" weight-gradient launch in fact queues for CUs behind
             # them: fewer, fuller launches read the same 192 MB of planes with more workgroups in flight
-            merge = 0 if self.joint else int(os.environ.get("EEGCLIP_WGRAD_MERGE", "2"))
+            merge = int(os.environ.get("EEGCLIP_WGRAD_MERGE", "2"))
             late = []
             ffn_out = [
                 (_LY + "conv2.weight", df2p, 1, g1p, D_MODEL, D_FF, 0, 0, _LY + "conv2.bias", 1),          # g1 has 256 real channels: no ones column
@@ -962,6 +963,8 @@ class _Engine:
                 # the subject-ordered sample list b["perm"] (the planes stay in batch order: the kernel looks the sample up per k-tile).  The member
                 # problems, their count and sample ranges are patched per call (_joint_layout); absent subjects get no gradient (their .grad stays
                 # None as in the reference, Embed.py:142-144).
+                if late:
+                    wgrad_tok("block", late, side=False)
                 pl.j_wk_template = [(w, dr1p, 1, xp, D_MODEL, T_LEN, 0, 0, bk, 0) for w, bk in self.ve_keys]
                 # K slices per subject so that (subjects present) x 4 tiles x slices fills the chip: 32 for one subject .. 6 for ten; the workspace takes
                 # the largest product
