@@ -752,8 +752,10 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
             }
             if (rd == 1 && !(p3.dbg & 1u)) tb_planes_out<0>(AP, p3.hp + (long long)b * (2 * TB_AP_PLANE), t);      // (the last reader of the h planes has its weights)
             raw_barrier();
+            tb_stamp(a0, b, t, 10 + 2 * rd);                         // (diagnosis: q | k | v of the head pair done)
             tb_attention<TRAIN>(p3, HQ, b, 2 * rd + hip, w & 3, lane, ctxr[rd]);
             raw_barrier();                                           // the pair's planes are dead (and, second round, the h planes too)
+            tb_stamp(a0, b, t, 11 + 2 * rd);                         // (diagnosis: attention of the head pair done)
         }
         // context -> A planes with 64 columns per head (dims 62, 63 are exact zeros); S4 copies the planes to HBM
 #pragma unroll
@@ -1349,6 +1351,13 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
         fprintf(stderr, "token_block_fwd phases (s_memtime ticks, mean of %d workgroups): x->planes %.0f | embed GEMM %.0f | dropout+h %.0f | qkv+attention %.0f | out-proj %.0f | "
                         "LN1 %.0f | FFN1 %.0f | FFN2 %.0f | LN2+LN3 %.0f\n", d->B, ph[0] / d->B, ph[1] / d->B, ph[2] / d->B, ph[3] / d->B, ph[4] / d->B, ph[5] / d->B,
                 ph[6] / d->B, ph[7] / d->B, ph[8] / d->B);
+        double q[4] = {0};                                         // inside qkv+attention: [qkv pair 0, attention pair 0, qkv pair 1, attention pair 1]
+        for (int b = 0; b < d->B; ++b) {
+            const unsigned long long* h = host + b * 16;
+            q[0] += (double)(h[10] - h[3]); q[1] += (double)(h[11] - h[10]); q[2] += (double)(h[12] - h[11]); q[3] += (double)(h[13] - h[12]);
+        }
+        fprintf(stderr, "  qkv+attention: qkv(heads 0,1) %.0f | attention %.0f | qkv(heads 2,3) + h planes out %.0f | attention %.0f\n", q[0] / d->B, q[1] / d->B, q[2] / d->B,
+                q[3] / d->B);
     }
 #endif
     return (int)hipGetLastError();
