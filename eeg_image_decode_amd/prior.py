@@ -459,7 +459,17 @@ class _PriorEngine:
                 arr[i] = _abi.WgradPlanesProblem(a_hi=dy[0], a_lo=dy[1], lda=lda, b_hi=x[0], b_lo=x[1], ldb=ldb, rows=N, M=M, N=Nn, out=_p(G[wk]), ldo=Nn,
                                                  bias_out=_p(G[bk]), slices=slices)
             pl._keep.append(arr)
-            pl.call("eegclip_wgrad_planes", arr, len(problems), side=True)
+            pl.call("eegclip_wgrad_planes", arr, len(problems), side=not merge)
+
+        # EEGCLIP_PRIOR_WGRAD_MERGE (default 1): the 22 weight gradients wait for the end of the dX chain and run as two launches of <= 12 problems instead
+        # of eleven launches "beside" the chain -- a weight-gradient workgroup (128 KB of LDS) and a plane-GEMM workgroup (64 KB x 2) exclude each other on
+        # a CU, so the second stream did not overlap, it queued (main 0.70 ms + second stream 0.33 ms = the 1.03 ms span of the trace).  Every operand
+        # (per-stage dY / X planes) is still intact at the end of the backward.
+        merge = os.environ.get("EEGCLIP_PRIOR_WGRAD_MERGE", "1") != "0"
+        pending = []
+        if merge:
+            wgrad_now = wgrad
+            wgrad = lambda problems: pending.extend(problems)       # noqa: E731
 
         n_st, n_enc = len(self.stages), m.num_layers - 1
         pl.call("eegclip_split_bf16", _p(b["dout"]), b["doutP"][0].data_ptr(), b["doutP"][1].data_ptr(), N * E)
@@ -497,6 +507,8 @@ class _PriorEngine:
         # left to run under them, and together their 92 + 64 output tiles are one wave of workgroups
         wgrad([(s0["t"] + "linear_1.weight", s0["t"] + "linear_1.bias", self._pl(b["DT1P"]), W, W, self._pl(b["tembp"]), Td, Td),
                ("input_layer.0.weight", "input_layer.0.bias", di, h0, h0, self._pl(b["xp"]), E, E)])
+        for i in range(0, len(pending), 12):                         # (eegclip_wgrad_planes: <= 12 problems per launch)
+            wgrad_now(pending[i:i + 12])
         return pl
 
     def forward(self, x, t, c, p, cond_rows=None):
