@@ -294,10 +294,8 @@ __device__ __forceinline__ void cs_bn_rows_partial(const double* __restrict__ ro
     const int t = threadIdx.x;
     if (t < CS_BN_SLICES * 2 * CS_C) {
         const int sl = t / (2 * CS_C), col = t % (2 * CS_C);
-        double s = 0.0;
-#pragma unroll 8
-        for (int r = sl; r < nrows; r += CS_BN_SLICES) s += rows[(long long)r * 2 * CS_C + col];
-        scratch[t] = s;
+        // (22 rows in flight: the 43 rows of a slice at B = 256 are two L2 round trips at the head of every sample-major kernel, not six)
+        scratch[t] = ordered_column_sum<CS_BN_SLICES, 22>(rows, nrows, sl, 2 * CS_C, col);
     }
 }
 // (behind a barrier) channel c's batch mean, 1 / sqrt(var + eps) and biased variance

@@ -129,6 +129,31 @@ __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
 #endif
+// sum of rows first, first + STEP, ... (< nrows) of column `col` of a row-major fp64 matrix, IN THAT ORDER, with BATCH loads in flight: written as
+// load-all-then-add because hipcc serialised `s += rows[...]` loops into load / s_waitcnt vmcnt(0) / add per row whenever it chose to reuse the
+// address registers (csrc/proj1x1.hip: 85 dependent L2 round trips at the head of a 58 k-MAC kernel)
+template <int STEP, int BATCH>
+__device__ __forceinline__ double ordered_column_sum(const double* __restrict__ rows, int nrows, int first, long long ld, int col) {
+    double s = 0.0;
+    int r = first;
+    for (; r + (BATCH - 1) * STEP < nrows; r += BATCH * STEP) {
+        double v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) v[j] = rows[(long long)(r + j * STEP) * ld + col];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) s += v[j];
+    }
+    {
+        double v[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) v[j] = r + j * STEP < nrows ? rows[(long long)(r + j * STEP) * ld + col] : 0.0;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (r + j * STEP < nrows) s += v[j];
+    }
+    return s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #if defined(EEG_EMU)
 #pragma unroll

@@ -37,10 +37,7 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
     if (rows) {
         if (t < 3 * 2 * PJ_C) {
             const int sl = t / (2 * PJ_C), col = t % (2 * PJ_C);
-            double s = 0.0;
-#pragma unroll 8
-            for (int r = sl; r < nrows; r += 3) s += rows[(long long)r * 2 * PJ_C + col];
-            scr[t] = s;
+            scr[t] = ordered_column_sum<3, 29>(rows, nrows, sl, 2 * PJ_C, col);      // (29 loads in flight: 3 L2 round trips for the 86 rows of a slice)
         }
         __syncthreads();
         if (t < PJ_C) {
