@@ -205,8 +205,7 @@ _LIVE = [
     _LY + "conv1.weight", _LY + "conv1.bias", _LY + "conv2.weight", _LY + "conv2.bias",
     _LY + "norm1.weight", _LY + "norm1.bias", _LY + "norm2.weight", _LY + "norm2.bias",
     "encoder.encoder.norm.weight", "encoder.encoder.norm.bias",
-    # LAST: the gradient that completes last (its dY is the final output of the backward chain).  step_plan.StepPlan runs AdamW over everything before it
-    # on the second stream while this weight gradient is still being formed, and a second AdamW launch over the tail [value embedding | token rows]
+    # LAST: the gradient that completes last (its dY is the final output of the backward chain)
     _E + "value_embedding.weight", _E + "value_embedding.bias",
 ]
 _CHECK_KEY = "encoder.encoder.norm.bias"          # (a live parameter of every model variant: Engine.stale)
@@ -547,7 +546,7 @@ class _Engine:
         if cstack:
             # nothing before the conv stack needs them: the arena clear and the conv stack's weight fragments go to the second stream, under the
             # transformer block; the main stream joins in front of the conv stack
-            pl.memset(b["zfb"] if train else b["zf"], side=True)
+            pl.memset(b["zfb"] if train else b["zf"], side=os.environ.get("EEGCLIP_START_SIDE", "1") != "0")
             pl.clears_zb = train
             if not hasattr(self, "cs_packed"):
                 self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
@@ -767,6 +766,10 @@ class _Engine:
         pl = Plan(f"atms_bwd[B={B}]")
         R = B * L_TOK
         sums, bn = b["sums"], b["bn"]
+        # the small parameter-gradient reductions (conv taps, the block's LayerNorm rows) wait for the end of the backward and go to the second stream behind
+        # ONE fork with the token-row gradient: a fork costs the main stream 4 - 13 us of idle queue (tools/step_timeline.py), as much as each of them runs
+        defer_small = os.environ.get("EEGCLIP_DEFER_SMALL", "1") != "0"
+        pl.deferred = []
         wsk = int(os.environ.get("EEGCLIP_WGRAD_SK", "0"))                         # tuning aid: K-slice count of the long-K weight gradients
         # attention backward: split-bf16 products (csrc/attention_x3.hip) in plans whose GEMM precision is bf16x3, the exact-fp32 MFMA kernel otherwise
         attn_bwd = "eegclip_attention_bwd_x3" if pl.precision == _abi.PREC_BF16X3 else "eegclip_attention_bwd"
@@ -780,7 +783,7 @@ class _Engine:
             return pl.gemm(Nout, Nin, K, dY, D(1), D(ldy), X, D(ldx), D(1), _p(G[name]), D(Nin), D(1), accumulate=1, split_k=sk(K),
                            rowsum_a=_p(G[bias]) if bias else None, side=side)    # nobody reads a weight gradient before the optimizer
 
-        ln_side = True                                                 # LayerNorm parameter-gradient kernels on the second stream
+        ln_side = os.environ.get("EEGCLIP_LN_SIDE", "1") != "0"           # LayerNorm parameter-gradient kernels on the second stream (A/B aid)
         # the three token-block LayerNorms reduce their gamma / beta gradients through per-workgroup partial rows (one workspace: the three launches
         # are ordered on one stream) instead of 256-way contended atomics
         if "lnp_ws" not in b:
@@ -842,7 +845,7 @@ class _Engine:
                 _p(sums[2]) if train else _p(zsum), (_p(local2) if local2 is not None else None) if train else _p(sums[2]), float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
                 W_TS, pc_, 0, SITE_CONV, seed_at=16)
         if self._cstack_bwd_enabled(pl):
-            self._build_bwd_cstack(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce)
+            self._build_bwd_cstack(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce, defer_small)
         else:
             self._build_bwd_conv_y1(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce)
         fused = self._token_block_enabled(pl) and hasattr(self, "tb_packed")
@@ -897,7 +900,10 @@ class _Engine:
                 (_LY + "attention.out_projection.weight", da1p, 1, ctxp, D_MODEL, HE, 0, 1, _LY + "attention.out_projection.bias", 0)]
             qkv_w = [(_LY + "attention.query_projection.weight", dqkvp, 3, hp, 3 * HE, D_MODEL, 1, 0, _LY + "attention.query_projection.bias", 0)]
             pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 0)
-            pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
+            if defer_small:
+                pl.deferred.append(lambda: pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=True))
+            else:
+                pl.call("eegclip_token_block_bwd", ctypes.byref(bd), 2, side=ln_side)
             if merge >= 2:
                 late += ffn_out
             else:
@@ -948,7 +954,8 @@ class _Engine:
         # (drop_p = 0: the dropout' is already in dr1 -- this launch only sums the token rows' gradients, reads dr1 and can run beside the embedding's
         #  weight gradient)
         pl.call("eegclip_embed_finish_bwd", _p(b["dr1"]), _p(tokg), None if shared else _p(b["ids"]), B, L_TOK, D_MODEL, 0.0, 0, SITE_EMBED, side=True)
-        pl.tail_op = len(pl.ops)          # everything from here on forms the value embedding's gradient only (step_plan: AdamW of the rest forks here)
+        for f in pl.deferred:             # (second-stream ops right behind one another share one fork: csrc/plan_exec.hip)
+            f()
         hmap = D(D_MODEL, div=N_CH, so=L_TOK * D_MODEL)
         if want_dx:
             b["dx"] = torch.empty(B, N_CH, T_LEN, dtype=torch.float32, device=self.device)
@@ -1006,7 +1013,7 @@ class _Engine:
                 pl.call("eegclip_gather_rows", _p(b["dx"]), XR, _p(b["dxs"]), XR, _p(b["perm"]), B, XR, 1)
         return pl
 
-    def _build_bwd_cstack(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce):
+    def _build_bwd_cstack(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce, defer_small=False):
         """spatial conv + BN1 + ELU + temporal conv backward recomputed from the token rows (csrc/cstack_bwd.hip, round 5): y1 / z1 / dz1 / dy1 never
         exist in HBM.  dWs on the second stream; BatchNorm1-backward sums as one partial row per sample, summed in a fixed order by the apply pass."""
         P, G, sums, bn = self.P, self.G, b["sums"], b["bn"]
@@ -1036,7 +1043,11 @@ class _Engine:
                 pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
         # (the tap gradient leaves the apply pass as one partial row per sample; their sum is read by the optimizer only: second stream)
         pl.call_desc("eegclip_cstack_bwd_apply", _abi.CstackBwdDesc(stat=stat, nstat=nstat, stat_local=local, nstat_local=nlocal, **dict(common, dw25=None)))
-        pl.call("eegclip_cstack_bwd_taps_reduce", _p(b["csb_ws"]), B, _p(G[_TS + "0.weight"]), side=True)
+        taps = lambda: pl.call("eegclip_cstack_bwd_taps_reduce", _p(b["csb_ws"]), B, _p(G[_TS + "0.weight"]), side=True)      # noqa: E731
+        if early_reduce or not defer_small:
+            taps()
+        else:
+            pl.deferred.append(taps)          # with the other small reductions, behind ONE fork at the end of the backward (see _build_bwd)
         if early_reduce:
             # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
             # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest

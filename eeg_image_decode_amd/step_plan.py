@@ -79,21 +79,25 @@ class StepPlan:
 
         # ---- the targets' operand planes + fp32 stack: inputs only, second stream, under the encoder's forward (items filled below)
         self.split_op = len(pl.ops)
-        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", True))
+        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", os.environ.get("EEGCLIP_START_SIDE", "1") != "0"))
         # ---- encoder forward
         f0 = splice(self.fwd)
         self.fwd_base = f0
         self.out_op = f0 + self.fwd.out_op
-        # ---- running train accuracy: raw z @ class_feats^T, top-1, count (second stream, under everything that follows)
+        # ---- running train accuracy: raw z @ class_feats^T, top-1, count: second stream.  The ops are emitted INSIDE the backward, right behind its first
+        # second-stream launch (the head LayerNorm's parameter gradients), so that they share that fork instead of paying one of their own
         self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
         self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
                                       Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
                                       drop_site=0, split_k=1, precision=self.fwd.precision)
         pl._keep.append(self.acc_desc)
         sc_ptr = model.logit_scale.detach().reshape(1).data_ptr()
-        pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
-        self.count_op = len(pl.ops)
-        pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
+
+        def accuracy_ops():
+            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
+            self.count_op = len(pl.ops)
+            pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
+
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch).  Operand planes: the targets are inputs of the
         # step -- split (and stacked for the query gradient) by a second-stream launch at the very start; the query features leave the head's LayerNorm as
         # planes (eegclip_residual_layernorm_fwd_planes: the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
@@ -142,52 +146,28 @@ class StepPlan:
                           seed=0, drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
         pl._keep.append(d)
         pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
-        # ---- encoder backward + fused AdamW (and the zero_grad() that opens the next iteration).  The value embedding's weight gradient is the LAST thing the
-        # backward forms (its dY is the end of the chain: 58 us of weight-gradient launch + slab reduction for 63 k parameters); it sits at the end of the flat
-        # parameter buffer (atms._LIVE), so AdamW over everything before it forks onto the second stream where that tail begins, and the main stream ends
-        # with a second, small AdamW launch over [value embedding | token rows].  Same element-wise update either way.
+        # ---- encoder backward, the accuracy readout behind its first second-stream launch
+        cut = self.bwd.dout_par_op + 1
+        b0 = len(pl.ops)
+        self.bwd_base, self.bwd_cut = b0, cut
+        splice(self.bwd, 0, cut)
+        n0 = len(pl.ops)
+        accuracy_ops()
+        self.bwd_shift = len(pl.ops) - n0
+        splice(self.bwd, cut, len(self.bwd.ops), at=b0 + self.bwd_shift)
+        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
+        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
+        pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
+        # ---- fused AdamW + the zero_grad() that opens the next iteration
         fast = optimizer._fast_last.get(0)
         self.fast = fast
         self.group = optimizer.param_groups[0]
         self.adam_ops = []                # (plan op, index into fast["launch"]): the step count of that run is patched per call
         gs = optimizer.grad_scale_dev.data_ptr() if optimizer.grad_scale_dev is not None else None
         b1, b2 = self.group["betas"]
-
-        def adam(li, lo, hi, side):
-            p0, n, wp, gp, mp, vp, members = fast["launch"][li]
-            if hi > lo:
-                self.adam_ops.append((len(pl.ops), li))
-                pl.call("eegclip_adamw_step_zero_grad", wp + 4 * lo, gp + 4 * lo, mp + 4 * lo, vp + 4 * lo, hi - lo, self.group["lr"], b1, b2, self.group["eps"],
-                        self.group["weight_decay"], 0, 1.0, gs, side=side)
-
-        tail = getattr(self.bwd, "tail_op", None)
-        ve = eng.P.get("encoder.enc_embedding.value_embedding.weight")
-        cut = {}                          # run index -> element offset of the value embedding inside that run
-        if tail is not None and ve is not None and os.environ.get("EEGCLIP_ADAM_SPLIT", "0") == "1":
-            for li, (p0, n, wp, gp, mp, vp, members) in enumerate(fast["launch"]):
-                off = (ve.data_ptr() - wp) // 4
-                if 0 < off < n and (off & 3) == 0:
-                    cut[li] = off
-        b0 = len(pl.ops)
-        self.bwd_base = b0
-        self.bwd_cut, self.bwd_shift = (tail, 0) if cut else (len(self.bwd.ops), 0)
-        if cut:
-            splice(self.bwd, 0, tail)
-            n0 = len(pl.ops)
-            for li, (p0, n, *_r) in enumerate(fast["launch"]):
-                adam(li, 0, cut.get(li, n), True)                    # second stream: behind every weight gradient launched so far (they are all on that stream
-            self.bwd_shift = len(pl.ops) - n0                        #   or on the main stream before this point)
-            splice(self.bwd, tail, len(self.bwd.ops), at=b0 + self.bwd_shift)
-        else:
-            splice(self.bwd, 0, len(self.bwd.ops))
-        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
-        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
-        pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
-        for li, (p0, n, *_r) in enumerate(fast["launch"]):
-            if not cut:
-                adam(li, 0, n, False)
-            elif li in cut:
-                adam(li, cut[li], n, False)
+        for li, (p0, n, wp, gp, mp, vp, members) in enumerate(fast["launch"]):
+            self.adam_ops.append((len(pl.ops), li))
+            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"], 0, 1.0, gs)
         self.hyper = (self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"])
         self.pl = pl
         self._class_ptr = None
