@@ -24,6 +24,7 @@ cp $O/pmc_hbm_traffic.json $R/profiles/r5_pmc_hbm_traffic.json
 find $O -name "*.csv" -delete
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python $R/bench.py --steps 30 --warmup 8 --no-secondary --no-cpu-baseline > $O/stats.log 2>&1 < /dev/null
 cp $O/stats/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+python $R/tools/step_timeline.py $(find $O/stats -name "*kernel_trace.csv" | head -1) 3 > $O/step_timeline.txt 2>/dev/null      # one steady-state step, dispatch by dispatch
 find $O/stats -name "*.csv" -size +1M -delete
 cd $R
 timeout 400 python bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err < /dev/null
