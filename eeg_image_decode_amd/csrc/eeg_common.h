@@ -311,22 +311,25 @@ __device__ __forceinline__ philox4 philox4x32(unsigned long long seed, unsigned 
     }
     return philox4{c0, c1, c2, c3};
 }
-// keep-decision for element `idx` of dropout site `site`: uniform u in [0,1) from 32 Philox bits, keep iff u >= p.
+// keep-decision for element `idx` of dropout site `site`: uniform u = (bits >> 8) / 2^24 in [0,1) from 32 Philox bits, keep iff u >= p.  Evaluated on the
+// integers: u >= p  <=>  (bits >> 8) >= ceil(p 2^24)  <=>  bits >= ceil(p 2^24) << 8 (p 2^24 is exact in fp32 and < 2^24 for p < 1) -- one compare per
+// element instead of shift + convert + multiply + compare; the same decisions bit for bit (tests/philox_np.py keeps the float form).
+__device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)ceilf(p * 16777216.0f) << 8; }
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned site, unsigned long long idx, float p) {
     philox4 r = philox4x32(seed, idx >> 2, site);
     unsigned sel = (unsigned)(idx & 3);
     unsigned bits = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
-    return (float)(bits >> 8) * (1.0f / 16777216.0f) >= p;
+    return bits >= dropout_threshold(p);
 }
 
 // dropout_keep() for the 4 consecutive elements idx4 .. idx4+3 (idx4 % 4 == 0): they share ONE Philox block
 __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned site, unsigned long long idx4, float p, bool (&keep)[4]) {
     const philox4 r = philox4x32(seed, idx4 >> 2, site);
-    const float k = 1.0f / 16777216.0f;
-    keep[0] = (float)(r.x >> 8) * k >= p;
-    keep[1] = (float)(r.y >> 8) * k >= p;
-    keep[2] = (float)(r.z >> 8) * k >= p;
-    keep[3] = (float)(r.w >> 8) * k >= p;
+    const unsigned thr = dropout_threshold(p);
+    keep[0] = r.x >= thr;
+    keep[1] = r.y >= thr;
+    keep[2] = r.z >= thr;
+    keep[3] = r.w >= thr;
 }
 
 // value held by lane T of the caller's quad (lanes 4q..4q+3): one DPP move, no LDS crossbar
@@ -353,7 +356,7 @@ __device__ __forceinline__ void dropout_keep_quad(unsigned long long seed, unsig
     EEG_QUAD_PICK(0) EEG_QUAD_PICK(1) EEG_QUAD_PICK(2) EEG_QUAD_PICK(3)
 #undef EEG_QUAD_PICK
 #pragma unroll
-    for (int t = 0; t < 4; ++t) keep[t] = (float)(bits[t] >> 8) * (1.0f / 16777216.0f) >= p;
+    for (int t = 0; t < 4; ++t) keep[t] = bits[t] >= dropout_threshold(p);
 }
 
 // the same trade for four elements that share the quad's lane-in-quad word: lane j hands in the Philox block of ITS element t = j
@@ -371,7 +374,7 @@ __device__ __forceinline__ void dropout_keep_quad_blocks(unsigned long long seed
     EEG_QUAD_PICK(0) EEG_QUAD_PICK(1) EEG_QUAD_PICK(2) EEG_QUAD_PICK(3)
 #undef EEG_QUAD_PICK
 #pragma unroll
-    for (int t = 0; t < 4; ++t) keep[t] = (float)(bits[t] >> 8) * (1.0f / 16777216.0f) >= p;
+    for (int t = 0; t < 4; ++t) keep[t] = bits[t] >= dropout_threshold(p);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
