@@ -38,7 +38,8 @@ class SplitItem(C.Structure):
 
 class InfonceProblem(C.Structure):
     _fields_ = [("q_hi", C.c_void_p), ("q_lo", C.c_void_p), ("k_hi", C.c_void_p), ("k_lo", C.c_void_p), ("col0", C.c_int), ("weight", C.c_float),
-                ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong)]
+                ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong),
+                ("part_k", C.c_void_p), ("diag_k", C.c_void_p)]
 
 
 class TokenBlockDesc(C.Structure):
@@ -106,7 +107,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -188,6 +189,7 @@ PROTOTYPES = {
     "eegclip_infonce_fused_workspace_floats": [_I, _I],
     "eegclip_infonce_fused_fwd": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "eegclip_infonce_fused_grad": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "eegclip_infonce_fused_grad_finalize": [C.POINTER(InfonceProblem), _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "eegclip_token_block_packed_bytes": [],
     "eegclip_token_block_pack": [_P, _P, _P, _P, _P, _P, _P],
     "eegclip_weight_prep": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],

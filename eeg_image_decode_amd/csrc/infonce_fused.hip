@@ -46,6 +46,8 @@ struct if_problem {                      // device copy of eegclip_infonce_probl
     long long ldg;
     int col0;
     float weight;
+    const float* part_k;                 // gradient pass with the finalize folded in: partials / positives of the SWAPPED block (its rows = this block's keys)
+    const float* diag_k;
 };
 struct if_table {
     if_problem p[IF_MAX_PROB];
@@ -74,7 +76,7 @@ struct if_geom {
 // producers at the one barrier per k-tile: 1090 cycles per k-tile in the micro-benchmark, 13.8 -> 10.1 us for the k-loops of one N = 2048 block.
 template <int NP, int TM, int MODE, int NW, int NPRD = 0>
 __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
-                                                            float inv_total, float* __restrict__ dscale) {
+                                                            float inv_total, float* __restrict__ dscale, float* __restrict__ loss) {
     using Gm = if_geom<NP>;
     constexpr int BK = Gm::BK, ROWB = Gm::ROWB, NCH = Gm::NCH, RPI = Gm::RPI;
     constexpr bool SPEC = NPRD > 0;
@@ -286,14 +288,46 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
             }
         }
     } else {
-        const bool two_norm = p_lse_k != nullptr;
+        // `fin` (eegclip_infonce_fused_grad_finalize): no finalize launch ran -- every workgroup forms the log-sum-exp of ITS TM rows and TM keys from the
+        // forward's per-tile partials (rows: this block's, keys: the swapped block's) in the dead operand stages, and the first workgroup of every row /
+        // key block adds their loss terms.  No cross-workgroup ordering is involved: the partials are the previous launch's output.
+        const float* const p_part_k = P.part_k;
+        const float* const p_diag_k = P.diag_k;
+        const bool fin = p_part_k != nullptr;
+        float* const fin_q = reinterpret_cast<float*>(lds) + 64;
+        float* const fin_k = fin_q + TM;
+        if (fin) {
+            __syncthreads();                                         // every wave is done with the operand stages
+            float contrib = 0.f;
+            if (t < 2 * TM) {
+                const bool keys = t >= TM;
+                const int idx = keys ? k0r + (t - TM) : q0 + t;
+                const float* const part = keys ? p_part_k : p_part;
+                const long long ld = keys ? N : n;
+                const int Pn = NWK * (keys ? tiles_q : tiles_k);
+                float m = -3.0e38f;
+                for (int sl = 0; sl < Pn; ++sl) m = fmaxf(m, part[(long long)sl * ld + idx]);
+                float l = 0.f;
+                for (int sl = 0; sl < Pn; ++sl) l += part[(long long)(Pn + sl) * ld + idx] * fast_exp(part[(long long)sl * ld + idx] - m);
+                const float lse = m + logf(l);
+                (keys ? fin_k : fin_q)[keys ? t - TM : t] = lse;
+                const bool mine = keys ? rem / tiles_k == 0 : rem % tiles_k == 0;
+                if (mine) contrib = (lse - (keys ? p_diag_k : p_diag)[idx]) * (p_weight * inv_total);
+            }
+            if (t < 2 * TM) {                                        // (whole waves: 2 TM is a multiple of 64)
+                contrib = wave_sum(contrib);
+                if (lane == 0 && contrib != 0.f) atomicAdd(loss, contrib);
+            }
+            __syncthreads();
+        }
+        const bool two_norm = p_lse_k != nullptr || fin;
         const float two = two_norm ? 2.f : 1.f;
         const float c = p_weight * inv_total;
         float ds = 0.f;
 #pragma unroll
         for (int i = 0; i < (producer ? 0 : WT); ++i) {       // (the producer waves only take part in the reduction barriers below)
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const float lq = p_lse[q];
+            const float lq = fin ? fin_q[q - q0] : p_lse[q];
             const int kb = k0r + wk * (TM / NWK);
             const int pos = p_col0 + q - kb;
             float* grow = p_G + (long long)q * p_ldg + kb;
@@ -303,7 +337,8 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                 for (int eq = 0; eq < 4; ++eq) {              // registers 4 eq .. 4 eq + 3 are 4 CONSECUTIVE keys: one 16-byte store
                     const int kk = 32 * j + 8 * eq + 4 * h;
                     f32x4 lk = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (two_norm) lk = *reinterpret_cast<const f32x4*>(p_lse_k + kb + kk);
+                    if (fin) lk = *reinterpret_cast<const f32x4*>(fin_k + (kb - k0r) + kk);
+                    else if (two_norm) lk = *reinterpret_cast<const f32x4*>(p_lse_k + kb + kk);
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -423,17 +458,20 @@ static inline int if_tile(int n, int N, int force = 0) {
     return (n % 128 == 0 && N % 128 == 0 && (long long)(n / 128) * (N / 128) >= 256) ? 128 : 64;
 }
 
-static int if_table_from(const eegclip_infonce_problem* probs, int nprob, int planes, bool grad, if_table& tb) {
+static int if_table_from(const eegclip_infonce_problem* probs, int nprob, int planes, bool grad, if_table& tb, bool want_fin = false) {
     if (!probs || nprob < 1 || nprob > IF_MAX_PROB) return EEGCLIP_EINVAL;
     for (int i = 0; i < nprob; ++i) {
         const eegclip_infonce_problem& p = probs[i];
-        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || !p.lse || (!grad && (!p.part || !p.diag)) || (grad && (!p.G || (p.ldg & 3))))
+        const bool fin = grad && p.part_k != nullptr;
+        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || (!p.lse && !fin) || (!grad && (!p.part || !p.diag)) || (grad && (!p.G || (p.ldg & 3))))
             return EEGCLIP_EINVAL;
+        if (fin != want_fin || (fin && (!p.part || !p.diag || !p.diag_k))) return EEGCLIP_EINVAL;
         uintptr_t al = reinterpret_cast<uintptr_t>(p.q_hi) | reinterpret_cast<uintptr_t>(p.k_hi) | reinterpret_cast<uintptr_t>(p.q_lo) |
                        reinterpret_cast<uintptr_t>(p.k_lo) | reinterpret_cast<uintptr_t>(p.G) | reinterpret_cast<uintptr_t>(p.lse_k);
         if (al & 15u) return EEGCLIP_EALIGN;
         tb.p[i] = if_problem{static_cast<const unsigned short*>(p.q_hi), static_cast<const unsigned short*>(p.q_lo), static_cast<const unsigned short*>(p.k_hi),
-                             static_cast<const unsigned short*>(p.k_lo), p.part, p.diag, p.lse, p.lse_k, p.G, p.ldg, p.col0, p.weight};
+                             static_cast<const unsigned short*>(p.k_lo), p.part, p.diag, p.lse, p.lse_k, p.G, p.ldg, p.col0, p.weight, fin ? p.part_k : nullptr,
+                             fin ? p.diag_k : nullptr};
     }
     return 0;
 }
@@ -461,7 +499,7 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
 
 #define EEG_IF_GO2(NP_, TM_, MODE_, NW_, NPRD_)                                                                                                            \
     EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_, NPRD_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * (NW_ + NPRD_)),                            \
-               (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale)
+               (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale, loss)
 #define EEG_IF_GO(NP_, TM_, NW_, NPRD_)                                                                                                                    \
     do {                                                                                                                                                   \
         if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, NPRD_);                                                                                                \
@@ -480,7 +518,7 @@ static int if_wsel(int TM, int planes) {
 static int if_waves(int TM, int planes) { return if_wsel(TM, planes) == 2 ? 8 : 4; }
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
-                           void* stream) {
+                           void* stream, float* loss = nullptr) {
     const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
     planes &= 0xff;
     if (planes == 1) {
@@ -495,13 +533,13 @@ static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, i
 
 extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, int nprob, int n, int N, int D, int planes, int n_total,
                                          const float* scale, float* loss, void* stream) {
-    if (!eegclip_infonce_fused_supported(n, N, D) || ((planes & 0xff) != 1 && (planes & 0xff) != 2) || !scale || !loss || n_total < 1) return EEGCLIP_EINVAL;
+    if (!eegclip_infonce_fused_supported(n, N, D) || ((planes & 0xff) != 1 && (planes & 0xff) != 2) || !scale || n_total < 1) return EEGCLIP_EINVAL;
     if_table tb;
     int rc = if_table_from(probs, nprob, planes & 0xff, false, tb);
     if (rc) return rc;
     const float inv_total = 1.0f / (float)n_total;
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
-    if (rc) return rc;
+    if (rc || !loss) return rc;                                  // loss == NULL: partials only -- eegclip_infonce_fused_grad_finalize finishes them
     const int TMsel = if_tile(n, N, (planes >> 8) & 0xff);
     const int Pn = (if_waves(TMsel, planes) / 2) * (N / TMsel);
     EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nprob), dim3(256), 512 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
@@ -515,4 +553,17 @@ extern "C" int eegclip_infonce_fused_grad(const eegclip_infonce_problem* probs, 
     const int rc = if_table_from(probs, nprob, planes & 0xff, true, tb);
     if (rc) return rc;
     return if_launch_tiles(tb, nprob, n, N, D, planes, 1, scale, 1.0f / (float)n_total, dscale, stream);
+}
+
+// the gradient pass with the forward's finalize folded in (training: every block of the loss is also differentiated): `blocks` as for eegclip_infonce_fused_grad
+// plus part / diag (this block's forward partials) and part_k / diag_k (the swapped block's); lse / lse_k are not read.  Adds the loss terms of BOTH
+// blocks of every entry to *loss.  Preceded by eegclip_infonce_fused_fwd(..., loss = NULL) over all the blocks.
+extern "C" int eegclip_infonce_fused_grad_finalize(const eegclip_infonce_problem* probs, int nprob, int n, int N, int D, int planes, int n_total,
+                                                   const float* scale, float* loss, float* dscale, void* stream) {
+    if (!eegclip_infonce_fused_supported(n, N, D) || ((planes & 0xff) != 1 && (planes & 0xff) != 2) || !scale || !loss || !dscale || n_total < 1 || n != N)
+        return EEGCLIP_EINVAL;
+    if_table tb;
+    const int rc = if_table_from(probs, nprob, planes & 0xff, true, tb, true);
+    if (rc) return rc;
+    return if_launch_tiles(tb, nprob, n, N, D, planes, 1, scale, 1.0f / (float)n_total, dscale, stream, loss);
 }

@@ -92,9 +92,15 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=N
                                      k_lo=kl.data_ptr() if kl is not None else None, col0=int(col0), weight=float(w), part=o, diag=o + 4 * ws,
                                      lse=o + 4 * (ws + n), lse_k=None, G=None, ldg=0)
     st = _stream()
+    # training (every block is differentiated: want_grad pairs each block with its swapped block): the forward leaves only the per-tile partials and the
+    # gradient pass forms the log-sum-exps itself -- no finalize launch between the two tile launches (eegclip_infonce_fused_grad_finalize)
+    covered = sorted(i for pair in want_grad for i in pair if i is not None)
+    inline = (n == N and bool(want_grad) and covered == list(range(nb)) and all(ki is not None for _, ki in want_grad)
+              and all(blocks[bi][3] == blocks[ki][3] for bi, ki in want_grad) and os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0")
     for c0 in range(0, nb, MAX_BLOCKS_PER_LAUNCH):                  # (any number of targets: the launch table holds 8 blocks)
         chunk = (_abi.InfonceProblem * min(MAX_BLOCKS_PER_LAUNCH, nb - c0))(*arr[c0:c0 + MAX_BLOCKS_PER_LAUNCH])
-        check(L.eegclip_infonce_fused_fwd(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr(), st), "infonce_fused_fwd")
+        check(L.eegclip_infonce_fused_fwd(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), None if inline else acc.data_ptr(), st),
+              "infonce_fused_fwd")
     if not want_grad:
         return []
     garr = (_abi.InfonceProblem * len(want_grad))()
@@ -105,9 +111,15 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=N
         garr[j] = arr[bi]
         garr[j].G, garr[j].ldg = G.data_ptr(), G.stride(0)
         garr[j].lse_k = arr[ki].lse if ki is not None else None
+        if inline:
+            garr[j].part_k, garr[j].diag_k = arr[ki].part, arr[ki].diag
     for c0 in range(0, len(want_grad), MAX_BLOCKS_PER_LAUNCH):
         chunk = (_abi.InfonceProblem * min(MAX_BLOCKS_PER_LAUNCH, len(want_grad) - c0))(*garr[c0:c0 + MAX_BLOCKS_PER_LAUNCH])
-        check(L.eegclip_infonce_fused_grad(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
+        if inline:
+            check(L.eegclip_infonce_fused_grad_finalize(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr(), acc.data_ptr() + 4, st),
+                  "infonce_fused_grad_finalize")
+        else:
+            check(L.eegclip_infonce_fused_grad(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
     Gs[0]._eegclip_keep = buf                      # the lse vectors must outlive the launch (stream-ordered allocator: already safe; explicit)
     return Gs
 

@@ -135,10 +135,19 @@ class StepPlan:
             garr[t_] = arr[2 * t_]
             garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), 2 * B
             garr[t_].lse_k = arr[2 * t_ + 1].lse
+            garr[t_].part_k, garr[t_].diag_k = arr[2 * t_ + 1].part, arr[2 * t_ + 1].diag
         pl._keep += [arr, garr]
-        self.if_fwd_op = len(pl.ops)
-        pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
-        pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
+        # (loss.fused_infonce's training form: the forward leaves the per-tile partials, the gradient pass finalises them itself and adds the loss)
+        if os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
+            pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, None)
+            self.if_fwd_op = len(pl.ops)                                # (the op whose `loss` argument is patched per step)
+            pl.call("eegclip_infonce_fused_grad_finalize", garr, 2, B, B, Dm, self.planes, B, sc_ptr, 0, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
+        else:
+            for t_ in range(2):
+                garr[t_].part_k = garr[t_].diag_k = None
+            self.if_fwd_op = len(pl.ops)
+            pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
+            pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())
         self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
         # dA = [G_img | G_txt] [img; txt]: one launch, K = 2 B
         d = _abi.GemmDesc(M=B, N=Dm, K=2 * B, A=self.G.data_ptr(), Am=D(2 * B), Ak=D(1), B=self.stack.data_ptr(), Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 8
+#define EEGCLIP_ABI_VERSION 9
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -358,7 +358,8 @@ int eegclip_sampler_step(const void* x, const void* eps_u, const void* eps_c, co
  * row i at column col0 + i (loss.py:129-130).  The symmetric loss of the reference is two blocks, (A, B) and (B, A) -- it computes both logit
  * matrices, loss.py:122-123; the row-sharded data-parallel form (loss.py:113-115) is the same two blocks against the gathered features.
  *   split_bf16   x -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL); n % 8 == 0, 16-byte aligned pointers
- *   fused_fwd    per block: row log-sum-exp -> lse[n]; *loss += sum_blocks weight / n_total * sum_rows (lse - S[i, col0 + i])
+ *   fused_fwd    per block: row log-sum-exp -> lse[n]; *loss += sum_blocks weight / n_total * sum_rows (lse - S[i, col0 + i])   (loss = NULL: the per-tile
+ *                partials only, see eegclip_infonce_fused_grad_finalize)
  *                (`part` = workspace of eegclip_infonce_fused_workspace_floats(n, N) floats, `diag` = n floats; both written here)
  *   fused_grad   per block: G[i, j] = s * weight / n_total * (exp(S_ij - lse[i]) + (lse_k ? exp(S_ij - lse_k[j]) : 0) - (lse_k ? 2 : 1) [j == col0 + i])
  *                in fp32 (n x N, leading dimension ldg, ldg % 4 == 0) and *dscale += d loss / d s: then dQ = G K and dK = G^T Q are plain GEMMs.
@@ -379,6 +380,8 @@ typedef struct {
     const float* lse_k;   /* [N] or NULL (grad in) */
     float* G;             /* (n, ldg) fp32 (grad out) */
     long long ldg;
+    const float* part_k;  /* eegclip_infonce_fused_grad_finalize only: `part` / `diag` of the SWAPPED block (its rows are this block's keys) */
+    const float* diag_k;
 } eegclip_infonce_problem;
 int eegclip_split_bf16(const float* x, void* hi, void* lo, long long n, void* stream);
 int eegclip_infonce_fused_supported(int n, int N, int D);
@@ -387,6 +390,12 @@ int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* blocks, int n_block
                               const float* scale, float* loss, void* stream);
 int eegclip_infonce_fused_grad(const eegclip_infonce_problem* blocks, int n_blocks, int n, int N, int D, int planes, int n_total,
                                const float* scale, float* dscale, void* stream);
+/* training: the finalize folded into the gradient pass (no log-sum-exp launch between the two tile launches).  eegclip_infonce_fused_fwd with loss = NULL
+ * leaves only the per-tile partials; this call forms, per workgroup, the log-sum-exp of its rows (from `part`) and of its keys (from `part_k`), writes G as
+ * eegclip_infonce_fused_grad with both normalisers does, and adds the loss terms of BOTH blocks of every entry (the block and its swapped block, same
+ * weight) to *loss.  Square blocks only (n == N: the single-process symmetric loss, models/loss.py:122-140). */
+int eegclip_infonce_fused_grad_finalize(const eegclip_infonce_problem* blocks, int n_blocks, int n, int N, int D, int planes, int n_total,
+                                        const float* scale, float* loss, float* dscale, void* stream);
 
 /* ---- tail of tsconv + Enc_eeg projection, one workgroup per sample (ATMS_retrieval.py:107-109,113-114,145):
  *   fwd: z2 = dropout(ELU(BatchNorm2(y2)))  (B,40,36);  feat[b, w*40+e] = bias[e] + sum_c W[e,c] z2[b,c,w]   (B,1440)

@@ -119,6 +119,23 @@ def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes
     Gp = 0.5 / n * (np.exp(S - lr[:, None]) + np.exp(S - lc[None, :]) - 2 * np.eye(n))
     np.testing.assert_allclose(be.host(G), s * Gp, atol=2e-6)
     assert abs(float(be.host(DS)[0]) - (Gp * S / s).sum()) < 2e-5
+    # training form: the forward leaves only the partials (loss = NULL) and the gradient pass finalises them itself -- same G, d scale and loss, no
+    # finalize launch; lse / lse_k are not read (poisoned here)
+    LOSS2, DS2, G2 = be.zeros(1), be.zeros(1), be.dev(np.full((n, n), np.nan, np.float32))
+    POISON = be.dev(np.full(n, np.nan, np.float32))
+    assert L.eegclip_infonce_fused_fwd(arr, 2, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), None, be.stream) == 0
+    p_fin = _abi.InfonceProblem(q_hi=be.ptr(ah), q_lo=be.ptr(al), k_hi=be.ptr(bh), k_lo=be.ptr(bl), col0=0, weight=0.5, part=be.ptr(bufs[0][0]),
+                                diag=be.ptr(bufs[0][1]), lse=be.ptr(POISON), lse_k=be.ptr(POISON), G=be.ptr(G2), ldg=n, part_k=be.ptr(bufs[1][0]),
+                                diag_k=be.ptr(bufs[1][1]))
+    fin = (_abi.InfonceProblem * 1)(p_fin)
+    assert L.eegclip_infonce_fused_grad_finalize(fin, 1, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(LOSS2), be.ptr(DS2), be.stream) == 0
+    np.testing.assert_allclose(be.host(G2), be.host(G), rtol=2e-5, atol=1e-9)
+    assert abs(float(be.host(LOSS2)[0]) - want) < 2e-5 * max(1.0, abs(want))
+    assert abs(float(be.host(DS2)[0]) - float(be.host(DS)[0])) < 2e-5
+    # argument checks: the plain gradient entry refuses the folded form and vice versa, rectangular blocks are refused
+    assert L.eegclip_infonce_fused_grad(fin, 1, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(DS2), be.stream) < 0
+    assert L.eegclip_infonce_fused_grad_finalize(one, 1, n, n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(LOSS2), be.ptr(DS2), be.stream) < 0
+    assert L.eegclip_infonce_fused_grad_finalize(fin, 1, n, 2 * n, D, planes_arg(planes, tile, waves), n, be.ptr(SC), be.ptr(LOSS2), be.ptr(DS2), be.stream) < 0
 
 
 def test_fused_rejects_unsupported_shapes(be):
