@@ -47,7 +47,7 @@ def algorithmic_cost(name, desc, B):
     Per-unit figures (SURVEY.md section 8d / DESIGN.md): conv+pool fused = 75 taps x 40 filters x 36 outputs x 63 rows per
     sample; BN/ELU passes move the (B,40,63,36) fp32 tensor (362,880 B per sample per pass)."""
     y1 = B * 40 * 63 * 36 * 4
-    if name == "eegclip_gemm_f32":
+    if name in ("eegclip_gemm_f32", "eegclip_head_gemm"):
         return "mfma", 2.0 * desc.M * desc.N * desc.K, "flop"
     if name == "eegclip_wgrad_tok":                                # the block's weight gradients from token planes: sum of 2 M N K over the launch's problems
         return "mfma", float(desc.flops), "flop"
@@ -124,7 +124,7 @@ def pmc_mfma_busy(family, B):
 
 def algorithmic_bytes(name, desc, B):
     """HBM bytes a launch has to move at least (operands once in, results once out): the traffic the PMC figure is compared with"""
-    if name == "eegclip_gemm_f32":
+    if name in ("eegclip_gemm_f32", "eegclip_head_gemm"):             # (plane operands are 4 bytes per element too: hi | lo)
         return 4.0 * (desc.M * desc.K + desc.K * desc.N + desc.M * desc.N)
     if name == "eegclip_wgrad_tok":                                # token planes are 4 bytes per element (hi | lo); partial tiles are not algorithmic
         return float(desc.bytes)
@@ -162,7 +162,7 @@ def family_of(name, desc):
     launches (forward + the two backward parts), the attention kernels, each other op on its own"""
     if name == "eegclip_gemm_f32":
         return "gemm_bf16x3" if (desc.precision & 0xff) == PREC_BF16X3 else "gemm_f32"
-    if name.startswith("eegclip_wgrad_tok"):
+    if name.startswith("eegclip_wgrad_tok") or name == "eegclip_head_gemm":
         return "gemm_bf16x3"
     if name.startswith("eegclip_token_block_"):
         return "token_block"
@@ -600,7 +600,7 @@ def main():
         pl.use_side_stream = True
     os.environ["EEGCLIP_STEP_PLAN"] = os.environ.pop("EEGCLIP_STEP_PLAN_OFF_FOR_BENCH")
     step(0)                                       # (back on the step plan, if the configuration has one)
-    sp = next((st["plan"] for st in getattr(eng, "_step_plans", {}).values() if st["plan"]), None)
+    sp = next(iter(retrieval.step_plans_of(model)), None)
     fam_ops, fam_ms = {}, {}
     for (k, idx), ms in single.items():
         name = plans[k].ops[idx][2]
@@ -611,11 +611,6 @@ def main():
         fam_ops.setdefault(fam, []).append((k, idx))
         fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
     dominant = max(fam_ms, key=fam_ms.get) if args.roofline_kernel == "auto" else args.roofline_kernel
-    # the same ruler from round to round: three families are within a few per cent of one another since round 5 (token_block 0.197, conv_stack 0.199,
-    # gemm_bf16x3 0.165 ms single-stream) and the largest one changes from run to run; a tie within 5 % resolves to the family the previous rounds
-    # reported (`roofline.families` prices every family either way)
-    if args.roofline_kernel == "auto" and "token_block" in fam_ms and fam_ms["token_block"] >= 0.95 * fam_ms[dominant]:
-        dominant = "token_block"
     if args.breakdown:
         for k, pl in plans.items():
             pl.use_side_stream = False
@@ -656,6 +651,7 @@ def main():
                 name = pl.ops[idx][2]
                 d = _desc_of(pl, idx)
                 tag = (name if d is None else f"{name}[part {d}]" if isinstance(d, int) else f"{name}[{d.label}/s{d.slices}]" if hasattr(d, "label")
+                       else f"{name}[{d.M}x{d.N}x{d.K}/s{d.slices}]" if hasattr(d, "slices")
                        else f"{name}[{d.M}x{d.N}x{d.K}{'/sk' + str(d.split_k) if d.split_k > 1 else ''}]")
                 rows.append((float(np.mean(v[-args.steps:])), k[0], idx, tag))
         rows.sort(reverse=True)
@@ -686,8 +682,9 @@ def main():
         traffic, tsrc = pmc_traffic(dominant, B)
         kernel_names = {"conv_stack": "eeg::cstack_{stats1,fwd,bwd<false>,bwd<true>,bwd_w2}_kernel (+ weight packs, row reductions): Conv(1x25) + AvgPool + BatchNorm + ELU + "
                                       "Conv(63x1) forward and backward recomputed from the token rows on the bf16 matrix cores (split-bf16 products); y1 / dy1 never in HBM",
-                        "gemm_bf16x3": "eeg::gemm_x3_kernel + eeg::wgrad_tok_kernel (the Linears outside the fused transformer block: head forward / dX / weight "
-                                       "gradients on gemm_x3, the block's weight gradients from token planes on wgrad_tok + its slab reduction; split-bf16 products)",
+                        "gemm_bf16x3": "eeg::head_gemm_kernel + eeg::gemm_x3_kernel + eeg::wgrad_tok_kernel (the Linears outside the fused transformer block: head forward / "
+                                       "dX / query gradient K-parallel from planes on head_gemm, the head's weight gradients on gemm_x3, the block's weight gradients "
+                                       "from token planes on wgrad_tok + its slab reduction; split-bf16 products)",
                         "gemm_f32": "eeg::gemm_f32_fast_kernel (every Linear of the step, exact fp32 products)",
                         "token_block": "eeg::token_block_{fwd,bwd_a,bwd_b}_kernel (the encoder's transformer block, one workgroup per sample: forward and the "
                                        "two backward parts; bytes = activations that must cross HBM for the batch-wide weight-gradient GEMMs)"}
@@ -704,7 +701,7 @@ def main():
                                    "achieved": round(work[big][1] / (live[big] * scale), 2), "frac": round(work[big][1] / (live[big] * scale) / peak, 4)}}
         if bound == "mfma":
             roof["frac_of_f32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TF, 4)
-        if hasattr(dbig, "M"):
+        if hasattr(dbig, "M") and hasattr(dbig, "split_k"):
             # what the HIP-event bracketing itself adds to a launch (marker packets + dispatch gaps on both sides): the largest launch 40 times
             # between ONE event pair against 40 individually bracketed launches, live, on an idle GPU after the timed region.  rocprofv3's kernel
             # timestamps (profiles/r2_final_kernel_stats.csv, same command) agree with the NET figure, not with the raw event time.
@@ -770,6 +767,13 @@ def main():
             if mb is not None:
                 fams[f]["mfma_busy_frac"] = mb
         roof["families"] = dict(sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step_single_stream"]))
+        # the headline family is simply the one with the most single-stream kernel time; the three largest with BOTH roofs side by side, so that a change
+        # of ruler from round to round is visible at the top level (no tie rule)
+        for k_ in ("frac_of_mfma_roof", "frac_of_hbm_roof", "frac_of_binding_roof"):
+            if k_ in fams[dominant]:
+                roof[k_] = fams[dominant][k_]
+        roof["largest_families"] = [{"family": f, **{k_: v[k_] for k_ in ("ms_per_step_single_stream", "bound", "frac", "frac_of_mfma_roof", "frac_of_hbm_roof") if k_ in v}}
+                                    for f, v in list(roof["families"].items())[:3]]
 
     distributed = None
     if world > 1:
@@ -895,7 +899,7 @@ class _CollectiveLog:
 
 def _desc_of(plan, idx):
     fn, a, name = plan.ops[idx][:3]
-    if name == "eegclip_gemm_f32":
+    if name in ("eegclip_gemm_f32", "eegclip_head_gemm"):
         return a[0]._obj
     if name == "eegclip_token_block_bwd":
         return int(a[1])                                  # which part of the fused backward

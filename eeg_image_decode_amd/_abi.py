@@ -39,7 +39,7 @@ class SplitItem(C.Structure):
 class InfonceProblem(C.Structure):
     _fields_ = [("q_hi", C.c_void_p), ("q_lo", C.c_void_p), ("k_hi", C.c_void_p), ("k_lo", C.c_void_p), ("col0", C.c_int), ("weight", C.c_float),
                 ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("lse_k", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_longlong),
-                ("part_k", C.c_void_p), ("diag_k", C.c_void_p)]
+                ("part_k", C.c_void_p), ("diag_k", C.c_void_p), ("G_hi", C.c_void_p), ("G_lo", C.c_void_p)]
 
 
 class TokenBlockDesc(C.Structure):
@@ -66,6 +66,14 @@ class GemmPlanesDesc(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("C", C.c_void_p), ("ldc", C.c_longlong), ("Cpre", C.c_void_p), ("ldcpre", C.c_longlong),
                 ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_longlong), ("p_hi", C.c_void_p), ("p_lo", C.c_void_p), ("ldp", C.c_longlong),
                 ("act", C.c_int), ("accumulate", C.c_int), ("planes_of", C.c_int)]
+
+
+class HeadGemmDesc(C.Structure):
+    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p), ("lda", C.c_longlong), ("ldb", C.c_longlong),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("slices", C.c_int), ("slab_stride", C.c_longlong), ("bias", C.c_void_p),
+                ("Cpre", C.c_void_p), ("ldcpre", C.c_longlong), ("act", C.c_int), ("aux", C.c_void_p), ("ldaux", C.c_longlong), ("R", C.c_void_p),
+                ("ldr", C.c_longlong), ("C", C.c_void_p), ("ldc", C.c_longlong), ("p_hi", C.c_void_p), ("p_lo", C.c_void_p), ("ldp", C.c_longlong),
+                ("b_kmajor", C.c_int)]
 
 
 class WgradTokProblem(C.Structure):
@@ -107,7 +115,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -200,6 +208,14 @@ PROTOTYPES = {
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
     "eegclip_gemm_planes": [C.POINTER(GemmPlanesDesc), _P],
     "eegclip_split_transpose": [C.POINTER(SplitItem), _I, _P],
+    "eegclip_head_gemm_slices": [_I, _I, _I],
+    "eegclip_head_gemm": [C.POINTER(HeadGemmDesc), _P],
+    "eegclip_head_act": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P],
+    "eegclip_head_act_bwd": [_P, _I, _L, _P, _P, _P, _P, _P, _L, _P],
+    "eegclip_residual_layernorm_fwd_slabs": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _L, _P, _P],
+    "eegclip_layernorm_bwd_slabs": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U, _P],
+    "eegclip_proj1x1_bwd_slabs": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
+    "eegclip_proj1x1_fwd_rows_planes": [_P, _P, _I, _D, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P, _P, _P],
     "eegclip_prior_stage_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_prior_stage_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U, _P, _P],
     "eegclip_prior_stage_bwd_workspace_floats": [_I, _I],

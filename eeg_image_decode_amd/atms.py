@@ -441,6 +441,42 @@ class _Engine:
         #  in round 4: the forward keeps exact products; the backward kernels (apply -4 us, dW -4 us) use the planes)
         return (None, None, 0), items
 
+    def _head_planes_enabled(self, pl):
+        """the projection head (and, in the step plan / ClipLoss, the query gradient) on the K-parallel plane GEMM csrc/head_gemm.hip (round 6) in split-bf16
+        plans; EEGCLIP_HEAD_GEMM=0 pins round 5's split-K gemm_x3 launches (diagnosis, A/B timing); exact-fp32 plans always use those"""
+        return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_HEAD_GEMM", "1") != "0"
+
+    def _head_weight_planes(self, pl):
+        """bf16 hi | lo planes of this step's projection-head weights: the span [W1 | b1 | W2] as it lies in the flat parameter buffer by ONE vectorised
+        split.  The forward GEMMs read them as B (N, K) operands (k contiguous); the input-gradient GEMMs, which contract over the OUTPUT index, read the
+        SAME planes as k-major operands (csrc/head_gemm.hip b_kmajor: fragments through the LDS transpose read) -- no transposed copy.  Second stream, at the
+        very start of the forward plan: nothing reads them before the conv stack has run, and the launch (no LDS, 24 registers) runs beside the fused
+        transformer-block forward."""
+        P = self.P
+        w1, w2 = P["proj_eeg.0.weight"], P["proj_eeg.1.fn.1.weight"]
+        span = (w2.data_ptr() - w1.data_ptr()) // 4 + w2.numel()
+        assert w2.data_ptr() > w1.data_ptr() and span % 8 == 0 and span < 4 * w1.numel(), "projection-head weights are not adjacent in the flat buffer"
+        if not hasattr(self, "hw_planes"):
+            self.hw_planes = torch.empty(2, span, dtype=torch.bfloat16, device=self.device)
+        side = os.environ.get("EEGCLIP_START_SIDE", "1") != "0"
+        items = (_abi.SplitItem * 1)(_abi.SplitItem(src=_p(w1), hi=_p(self.hw_planes[0]), lo=_p(self.hw_planes[1]), rows=1, cols=span, ld_src=span, ld_out=span,
+                                                    transpose=0))
+        pl._keep.append(items)
+        pl.call("eegclip_split_rows", items, 1, side=side)
+        o2 = (w2.data_ptr() - w1.data_ptr()) // 4
+        # (hi, lo) of W1 (1024, 1440) and W2 (1024, 1024)
+        self.hw = dict(w1=(_p(self.hw_planes[0]), _p(self.hw_planes[1])), w2=(_p(self.hw_planes[0]) + 2 * o2, _p(self.hw_planes[1]) + 2 * o2))
+
+    def _head_gemm(self, pl, b, tag, a_planes, K, w, N, B, kmajor=False):
+        """one K-parallel head GEMM: (B, K) planes x the weight planes `w` -- (N, K), k contiguous, or with kmajor (K, N), n contiguous -> partial slabs
+        b[tag] (slices, B, N); returns (slab pointer, slice count, slab stride) for the launch that consumes them"""
+        S = int(lib().eegclip_head_gemm_slices(B, N, K))
+        if tag not in b or b[tag].shape != (S, B, N):
+            b[tag] = torch.empty(S, B, N, dtype=torch.float32, device=self.device)
+        pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=a_planes[0], a_lo=a_planes[1], b_hi=w[0], b_lo=w[1], lda=K, ldb=N if kmajor else K, M=B, N=N, K=K,
+                                                           slices=S, slab_stride=B * N, C=_p(b[tag]), ldc=N, b_kmajor=int(kmajor)))
+        return _p(b[tag]), S, B * N
+
     def _token_block_enabled(self, pl):
         """the fused transformer-block forward (csrc/token_block.hip) in the default split-bf16 arithmetic -- since round 4 also for the joint-subject
         model (its value embedding is a per-sample weight base inside the kernel); EEGCLIP_TOKEN_BLOCK=0 pins the launch-per-Linear plan
@@ -543,11 +579,16 @@ class _Engine:
             pl.call("eegclip_split_rows", items, n_items)
         pl.tb_desc = None
         cstack = self._cstack_enabled(pl)
+        head_planes = self._head_planes_enabled(pl)
+        if head_planes and not cstack:
+            self._head_weight_planes(pl)
         if cstack:
             # nothing before the conv stack needs them: the arena clear and the conv stack's weight fragments go to the second stream, under the
             # transformer block; the main stream joins in front of the conv stack
             pl.memset(b["zfb"] if train else b["zf"], side=os.environ.get("EEGCLIP_START_SIDE", "1") != "0")
             pl.clears_zb = train
+            if head_planes:
+                self._head_weight_planes(pl)                # (second stream too: consecutive second-stream ops share one fork)
             if not hasattr(self, "cs_packed"):
                 self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
                 self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
@@ -646,17 +687,46 @@ class _Engine:
             pl.clears_zb = train
             self._build_fwd_conv_y1(pl, b, B, train, W)
         # BN2 -> ELU -> dropout -> 1x1 conv + 'b e h w -> b (h w) e' + flatten: feat[b, w*40+e], one workgroup per sample      (:107-114,145)
-        if bn2_rows is not None:
+        run2 = (_p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), _p(self.buffers[_TS + "5.num_batches_tracked"]))
+        if head_planes:
+            # (round 6) ... and feat again as bf16 hi | lo planes: the A operand of the head's first Linear.  With per-sample BatchNorm2 partial rows the
+            # finalize rides in this kernel's prologue; otherwise mean / rstd are inputs
+            if "featp" not in b:
+                b["featp"] = torch.empty(2, B, F_TS, dtype=torch.bfloat16, device=self.device)
+                b["gup"] = torch.empty(2, B, P_DIM, dtype=torch.bfloat16, device=self.device)
+            rows_args = (_p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]), *run2) if bn2_rows is not None else \
+                (None, 0, 1.0, EPS, 0.1, _p(bn[2]), _p(bn[3]), None, None, None)
+            pl.call("eegclip_proj1x1_fwd_rows_planes", _p(b["y2"]), *rows_args, _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                    _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
+                    _p(b["featp"][0]), _p(b["featp"][1]), seed_at=19)
+        elif bn2_rows is not None:
             # (the BatchNorm2 finalize rides in this kernel's prologue: the batch statistics as the per-sample partial rows eegclip_cstack_fwd left)
-            pl.call("eegclip_proj1x1_fwd_rows", _p(b["y2"]), _p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]),
-                    _p(self.buffers[_TS + "5.running_mean"]), _p(self.buffers[_TS + "5.running_var"]), _p(self.buffers[_TS + "5.num_batches_tracked"]),
+            pl.call("eegclip_proj1x1_fwd_rows", _p(b["y2"]), _p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]), *run2,
                     _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]),
                     _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV, seed_at=19)
         else:
             pl.call("eegclip_proj1x1_fwd", _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
                     _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
                     seed_at=11)
-        # A6: projection head      (:157-167).  M = B is small (256): a 4 x 16 tile grid cannot fill 256 CUs and each workgroup walks K = 1440
+        pl.head_planes = head_planes
+        if head_planes:
+            # A6: projection head      (:157-167) on the K-parallel plane GEMM (csrc/head_gemm.hip, round 6): M = B is small, so K is split over workgroups --
+            # each slice leaves its partial tile as a slab and the launch that consumes the result anyway adds the slabs while it loads them:
+            # bias + GELU (+ the planes of gelu(u) for the second Linear) after the first, dropout + residual + LayerNorm after the second
+            if not cstack:
+                pl.join()                                   # (the weight planes came from the second stream)
+            fp, gp = (_p(b["featp"][0]), _p(b["featp"][1])), (_p(b["gup"][0]), _p(b["gup"][1]))
+            sl1 = self._head_gemm(pl, b, "hslab1", fp, F_TS, self.hw["w1"], P_DIM, B)
+            pl.call("eegclip_head_act", *sl1, _p(P["proj_eeg.0.bias"]), _p(b["u"]), _p(b["gu"]), *gp, B, P_DIM)
+            sl2 = self._head_gemm(pl, b, "hslab2", gp, P_DIM, self.hw["w2"], P_DIM, B)
+            # s = u + dropout(W gelu(u) + b), out = LayerNorm(s): ResidualAdd + LayerNorm of Proj_eeg in one launch; `out` is a fresh tensor per call
+            # (argument 8 is patched by forward()); arguments 19 / 20: out again as planes (the step plan's loss operand)
+            pl.out_op = len(pl.ops)
+            pl.call("eegclip_residual_layernorm_fwd_slabs", sl2[0], _p(b["u"]), _p(b["s"]), pp_, 0, SITE_PROJ, _p(P["proj_eeg.2.weight"]),
+                    _p(P["proj_eeg.2.bias"]), 0, _p(b["mu4"]), _p(b["rs4"]), None, None, None, None, None, B, P_DIM, EPS, None, None, sl2[1], sl2[2],
+                    _p(P["proj_eeg.1.fn.1.bias"]), seed_at=4)
+            return pl
+        # A6 on fp32 operands (exact-fp32 plans, EEGCLIP_HEAD_GEMM=0): a 4 x 16 tile grid cannot fill 256 CUs and each workgroup walks K = 1440
         # serially, so the products are split over K (atomics into a zeroed buffer) and bias/GELU/dropout/residual run as a tiny epilogue.
         skh = _head_split(B)
         if skh > 1:
@@ -796,21 +866,30 @@ class _Engine:
         # (the BatchNorm backward sums and the split-K accumulators dgu / dfeat -- arena zb -- were cleared by the training forward's memset)
         # head LayerNorm
         pl.dout_op = len(pl.ops)
-        # s = u + dropout(W4 gelu(u) + b4): the LayerNorm backward writes ds and dv = ds * mask / (1 - p) in one pass
-        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
-                None, None, B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
-        # (the gamma / beta gradients of every LayerNorm are a second, independent kernel: it runs on the side stream, off the dX chain)
-        pl.dout_par_op = len(pl.ops)
-        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
-                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
-        wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
-        skh = _head_split(B)
-        pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
-                accumulate=int(skh > 1), split_k=skh)
-        pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
-        wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
-        pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
-                accumulate=int(skh > 1), split_k=skh)
+        head_planes = self._head_planes_enabled(pl) and hasattr(self, "hw")
+        pl.head_planes = head_planes
+        dfeat_slabs = None
+        if head_planes:
+            # (round 6) the head's backward on the K-parallel plane GEMM.  The upstream gradient may itself be the partial slabs of the loss's query-gradient
+            # GEMM (arguments 1 / 2, patched by the step plan); the LayerNorm backward leaves ds, dv = ds * mask / (1 - p) (fp32: the weight gradients'
+            # operands), dv again as planes (the next GEMM's A operand) and the summed upstream gradient for its parameter half
+            if "dvp" not in b:
+                b["dvp"] = torch.empty(2, B, P_DIM, dtype=torch.bfloat16, device=self.device)
+                b["dup"] = torch.empty(2, B, P_DIM, dtype=torch.bfloat16, device=self.device)
+                b["dout_sum"] = torch.empty(B, P_DIM, dtype=torch.float32, device=self.device)
+            vp, up = (_p(b["dvp"][0]), _p(b["dvp"][1])), (_p(b["dup"][0]), _p(b["dup"][1]))
+            pl.call("eegclip_layernorm_bwd_slabs", 0, 1, 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]), B, P_DIM,
+                    _p(b["dv"]), *vp, None, pp_, 0, SITE_PROJ, seed_at=15)
+            pl.dout_par_op = len(pl.ops)
+            pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
+                    _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
+            wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
+            sl = self._head_gemm(pl, b, "dgu_slabs", vp, P_DIM, self.hw["w2"], P_DIM, B, kmajor=True)
+            pl.call("eegclip_head_act_bwd", *sl, _p(b["u"]), _p(b["ds"]), _p(b["ds"]), *up, B * P_DIM)          # ds := du = ds + dgu * gelu'(u)
+            wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
+            dfeat_slabs = self._head_gemm(pl, b, "dfeat_slabs", up, P_DIM, self.hw["w1"], F_TS, B, kmajor=True)
+        else:
+            self._build_bwd_head_f32(pl, b, B, pp_, ln_side, wgrad)
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
         # mean-all-reduce of the flat gradient (every rank's gradient is W x its share) reproduces the single-process value.
@@ -827,9 +906,14 @@ class _Engine:
                 return lambda: G[bias_key].add_((P[gamma_key] * rstd * s[:C_TS].to(torch.float32)))
         if "pj_ws" not in b:
             b["pj_ws"] = torch.empty(int(lib().eegclip_proj1x1_bwd_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
-        pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
-                _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
-                _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=15)
+        if dfeat_slabs is not None:
+            pl.call("eegclip_proj1x1_bwd_slabs", *dfeat_slabs, _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
+                    _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=17)
+        else:
+            pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
+                    _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=15)
         local2 = None
         if W > 1:
             local2 = torch.zeros_like(sums[2])
@@ -1012,6 +1096,25 @@ class _Engine:
                 pl.j_scatter = len(pl.ops)
                 pl.call("eegclip_gather_rows", _p(b["dx"]), XR, _p(b["dxs"]), XR, _p(b["perm"]), B, XR, 1)
         return pl
+
+    def _build_bwd_head_f32(self, pl, b, B, pp_, ln_side, wgrad):
+        """the projection head's backward on fp32-operand GEMMs (exact-fp32 plans, EEGCLIP_HEAD_GEMM=0): split-K with atomics into the cleared arena"""
+        P, G = self.P, self.G
+        # s = u + dropout(W4 gelu(u) + b4): the LayerNorm backward writes ds and dv = ds * mask / (1 - p) in one pass
+        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]),
+                None, None, B, P_DIM, 0, _p(b["dv"]), pp_, 0, SITE_PROJ, seed_at=13)
+        # (the gamma / beta gradients of every LayerNorm are a second, independent kernel: it runs on the side stream, off the dX chain)
+        pl.dout_par_op = len(pl.ops)
+        pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
+                _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
+        wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
+        skh = _head_split(B)
+        pl.gemm(B, P_DIM, P_DIM, _p(b["dv"]), D(P_DIM), D(1), _p(P["proj_eeg.1.fn.1.weight"]), D(P_DIM), D(1), _p(b["dgu"]), D(P_DIM), D(1),
+                accumulate=int(skh > 1), split_k=skh)
+        pl.call("eegclip_gelu_bwd", _p(b["dgu"]), _p(b["u"]), _p(b["ds"]), B * P_DIM, 1, 0.0, 0, 0)          # ds := du
+        wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
+        pl.gemm(B, F_TS, P_DIM, _p(b["ds"]), D(P_DIM), D(1), _p(P["proj_eeg.0.weight"]), D(F_TS), D(1), _p(b["dfeat"]), D(F_TS), D(1),
+                accumulate=int(skh > 1), split_k=skh)
 
     def _build_bwd_cstack(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce, defer_small=False):
         """spatial conv + BN1 + ELU + temporal conv backward recomputed from the token rows (csrc/cstack_bwd.hip, round 5): y1 / z1 / dz1 / dy1 never

@@ -124,6 +124,66 @@ __global__ __launch_bounds__(256) void dropout_scale_kernel(float* __restrict__ 
 }
 
 // dx (+)= dy * mask/(1-p) * gelu'(pre)      (backward of y = dropout(gelu(pre)); p = 0 -> plain GELU backward)
+// ---- the projection head's elementwise stages behind its K-parallel GEMMs (csrc/head_gemm.hip): they ADD the GEMM's partial slabs (slice order), so the
+// split costs no launch of its own.  One lane = 4 consecutive columns (16-byte accesses; N % 4 == 0).
+//   head_act      u = sum_s slab[s] + bias;  pre = u;  out = gelu(u);  (out_hi | out_lo) = out again as bf16 planes     (ATMS_retrieval.py:160-162)
+//   head_act_bwd  dx = base + (sum_s slab[s]) * gelu'(pre)  (base may be dx: the residual branch's gradient), + planes   (its backward)
+__device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ slabs, int nslabs, long long stride, long long i) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + i);
+    for (int s = 1; s < nslabs; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(slabs + (long long)s * stride + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__ slabs, int nslabs, long long stride, const float* __restrict__ bias,
+                                                        float* __restrict__ pre, float* __restrict__ out, unsigned short* __restrict__ out_hi,
+                                                        unsigned short* __restrict__ out_lo, long long n4, int N) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const long long i = 4 * q;
+        f32x4 v = slab_sum4(slabs, nslabs, stride, i);
+        if (bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + (int)(i % N));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (pre) *reinterpret_cast<f32x4*>(pre + i) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        if (out) *reinterpret_cast<f32x4*>(out + i) = v;
+        if (out_hi) {
+            u32x2_t hi, lo;
+            x3_split4(v[0], v[1], v[2], v[3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(out_hi + i) = hi;
+            *reinterpret_cast<u32x2_t*>(out_lo + i) = lo;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void head_act_bwd_kernel(const float* __restrict__ slabs, int nslabs, long long stride, const float* __restrict__ pre,
+                                                            const float* __restrict__ base, float* __restrict__ dx, unsigned short* __restrict__ dx_hi,
+                                                            unsigned short* __restrict__ dx_lo, long long n4) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const long long i = 4 * q;
+        f32x4 v = slab_sum4(slabs, nslabs, stride, i);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(pre + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(u[e]);
+        if (base) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(base + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
+        }
+        if (dx) *reinterpret_cast<f32x4*>(dx + i) = v;
+        if (dx_hi) {
+            u32x2_t hi, lo;
+            x3_split4(v[0], v[1], v[2], v[3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(dx_hi + i) = hi;
+            *reinterpret_cast<u32x2_t*>(dx_lo + i) = lo;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
                                                         float* __restrict__ dx, long long n, int accumulate, float drop_p,
                                                         unsigned long long seed, unsigned site) {
@@ -370,6 +430,27 @@ extern "C" int eegclip_dropout_scale(float* x, long long n, float drop_p, unsign
     return (int)hipGetLastError();
 }
 
+extern "C" int eegclip_head_act(const float* slabs, int nslabs, long long slab_stride, const float* bias, float* pre, float* out, void* out_hi, void* out_lo,
+                                int M, int N, void* stream) {
+    if (!slabs || nslabs < 1 || nslabs > 16 || M < 1 || N < 4 || (N & 3) || (nslabs > 1 && (slab_stride < (long long)M * N || (slab_stride & 3)))) return EEGCLIP_EINVAL;
+    if ((!pre && !out && !out_hi) || ((out_hi != nullptr) != (out_lo != nullptr))) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(out)) & 15u) return EEGCLIP_EALIGN;
+    if ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 7u) return EEGCLIP_EALIGN;
+    const long long n4 = (long long)M * N / 4;
+    EEG_LAUNCH(head_act_kernel, dim3(ew_grid(n4)), dim3(256), 0, stream, slabs, nslabs, slab_stride, bias, pre, out, static_cast<unsigned short*>(out_hi),
+               static_cast<unsigned short*>(out_lo), n4, N);
+    return (int)hipGetLastError();
+}
+extern "C" int eegclip_head_act_bwd(const float* slabs, int nslabs, long long slab_stride, const float* pre, const float* base, float* dx, void* dx_hi, void* dx_lo,
+                                    long long n, void* stream) {
+    if (!slabs || !pre || nslabs < 1 || nslabs > 16 || n < 4 || (n & 3) || (nslabs > 1 && (slab_stride < n || (slab_stride & 3)))) return EEGCLIP_EINVAL;
+    if ((!dx && !dx_hi) || ((dx_hi != nullptr) != (dx_lo != nullptr))) return EEGCLIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(dx)) & 15u) return EEGCLIP_EALIGN;
+    if ((reinterpret_cast<uintptr_t>(dx_hi) | reinterpret_cast<uintptr_t>(dx_lo)) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(head_act_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, slabs, nslabs, slab_stride, pre, base, dx, static_cast<unsigned short*>(dx_hi),
+               static_cast<unsigned short*>(dx_lo), n / 4);
+    return (int)hipGetLastError();
+}
 extern "C" int eegclip_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, int accumulate, float drop_p,
                                 unsigned long long seed, unsigned site, void* stream) {
     if (!dy || !pre || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;

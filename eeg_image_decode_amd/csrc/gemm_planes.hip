@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const gpt_table tb
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = rr + 16 * i;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(E.src + (long long)(r0 + r) * E.ld_src + c0 + 4 * q);
+        const f32x4 v = c0 + 4 * q < E.cols ? *reinterpret_cast<const f32x4*>(E.src + (long long)(r0 + r) * E.ld_src + c0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[(4 * q + e) * 65 + r] = v[e];
     }
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const gpt_table tb
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = rr + 16 * i;
+        if (c0 + c >= E.cols) continue;                      // (cols need only be a multiple of 4: the head's 1440-column weight)
         const float* tr = tile + c * 65 + 4 * q;
         u32x2_t h, l;
         x3_split4(tr[0], tr[1], tr[2], tr[3], h, l);
@@ -211,13 +212,13 @@ extern "C" int eegclip_split_transpose(const eegclip_split_item* items, int n, v
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         const eegclip_split_item& it = items[i];
-        if (!it.src || !it.hi || !it.lo || it.rows < 64 || it.cols < 64 || (it.rows & 63) || (it.cols & 63) || it.ld_src < it.cols || it.ld_out < it.rows ||
+        if (!it.src || !it.hi || !it.lo || it.rows < 64 || it.cols < 4 || (it.rows & 63) || (it.cols & 3) || it.ld_src < it.cols || it.ld_out < it.rows ||
             (it.ld_src & 3) || (it.ld_out & 3) || it.copy)
             return EEGCLIP_EINVAL;
         if ((reinterpret_cast<uintptr_t>(it.src) & 15u) || ((reinterpret_cast<uintptr_t>(it.hi) | reinterpret_cast<uintptr_t>(it.lo)) & 7u)) return EEGCLIP_EALIGN;
         tb.e[i] = gpt_entry{it.src, static_cast<unsigned short*>(it.hi), static_cast<unsigned short*>(it.lo), it.ld_src, it.ld_out, it.rows, it.cols, blocks,
-                            it.cols / 64};
-        blocks += (it.rows / 64) * (it.cols / 64);
+                            (it.cols + 63) / 64};
+        blocks += (it.rows / 64) * ((it.cols + 63) / 64);
     }
     EEG_LAUNCH(split_transpose_kernel, dim3((unsigned)blocks), dim3(256), 64 * 65 * sizeof(float), stream, tb);
     return (int)hipGetLastError();

@@ -375,6 +375,23 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const xp_split_table tb
         }
         return;
     }
+    if (E.transpose == 2) {
+        // out[c][r .. r + 3] = src[r .. r + 3][c]: a transposing split WITHOUT LDS and without padding writes (rows % 4 == 0; the output may be a column block of
+        // a wider matrix).  Consecutive lanes take consecutive source columns: four coalesced row reads, one 8-byte store per plane and lane.  LDS-free and
+        // ~20 VGPRs on purpose: at the start of a training step it runs on the second stream BESIDE the fused transformer-block forward, whose workgroups hold
+        // every CU's LDS and all but ~30 VGPRs per SIMD lane -- the tiled eegclip_split_transpose waited for it to end (109 us in the step's trace)
+        const long long items = (long long)(E.rows / 4) * E.cols;
+        for (long long q = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; q < items; q += 256LL * span) {
+            const int c = (int)(q % E.cols), r = 4 * (int)(q / E.cols);
+            const float* sp = E.src + (long long)r * E.ld_src + c;
+            const float v0 = sp[0], v1 = sp[E.ld_src], v2 = sp[2 * E.ld_src], v3 = sp[3 * E.ld_src];
+            u32x2_t h, l;
+            x3_split4(v0, v1, v2, v3, h, l);
+            *reinterpret_cast<u32x2_t*>(E.hi + (long long)c * E.ld_out + r) = h;
+            *reinterpret_cast<u32x2_t*>(E.lo + (long long)c * E.ld_out + r) = l;
+        }
+        return;
+    }
     for (long long q = (long long)((int)blockIdx.x - E.first_block) * 256 + threadIdx.x; q < total;
          q += 256LL * ((ei + 1 < tb.n ? tb.e[ei + 1].first_block : (int)gridDim.x) - E.first_block)) {
         const int r = (int)(q / per_row), c = (int)(q % per_row);
@@ -474,6 +491,8 @@ extern "C" int eegclip_split_rows(const eegclip_split_item* items, int n, void* 
         const int orow = it.transpose ? it.cols : it.rows, ocol = it.transpose ? it.rows : it.cols;
         if (!it.src || !it.hi || !it.lo || it.rows < 1 || it.cols < 1 || it.ld_src < it.cols || it.ld_out < ocol) return EEGCLIP_EINVAL;
         if (it.copy && (it.transpose || it.ld_copy < it.cols)) return EEGCLIP_EINVAL;
+        if (it.transpose == 2 && ((it.rows & 3) || (it.ld_out & 3) || ((reinterpret_cast<uintptr_t>(it.hi) | reinterpret_cast<uintptr_t>(it.lo)) & 7u))) return EEGCLIP_EINVAL;
+        if (it.transpose < 0 || it.transpose > 2) return EEGCLIP_EINVAL;
         tb.e[i] = xp_split_entry{it.src, static_cast<unsigned short*>(it.hi), static_cast<unsigned short*>(it.lo), it.rows, it.cols, it.ld_src, it.ld_out,
                                  it.transpose, blocks, it.copy, it.copy ? it.ld_copy : 0};
         long long b = ((long long)orow * it.ld_out + 1023) / 1024;          // ~4 elements per thread

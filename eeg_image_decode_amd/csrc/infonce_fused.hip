@@ -48,6 +48,8 @@ struct if_problem {                      // device copy of eegclip_infonce_probl
     float weight;
     const float* part_k;                 // gradient pass with the finalize folded in: partials / positives of the SWAPPED block (its rows = this block's keys)
     const float* diag_k;
+    unsigned short* G_hi;                // G again as bf16 hi | lo planes (or null)
+    unsigned short* G_lo;
 };
 struct if_table {
     if_problem p[IF_MAX_PROB];
@@ -246,6 +248,8 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
     const float* const p_lse = P.lse;
     const float* const p_lse_k = P.lse_k;
     float* const p_G = P.G;
+    unsigned short* const p_Ghi = P.G_hi;
+    unsigned short* const p_Glo = P.G_lo;
     const long long p_ldg = P.ldg;
     const int p_col0 = P.col0;
     const float p_weight = P.weight;
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
             const float lq = fin ? fin_q[q - q0] : p_lse[q];
             const int kb = k0r + wk * (TM / NWK);
             const int pos = p_col0 + q - kb;
-            float* grow = p_G + (long long)q * p_ldg + kb;
+            const long long goff = (long long)q * p_ldg + kb;
+            float* grow = p_G + goff;
 #pragma unroll
             for (int j = 0; j < WTK; ++j)
 #pragma unroll
@@ -351,7 +356,13 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                         ds += g * raw;
                         o[e] = g * s;
                     }
-                    *reinterpret_cast<f32x4*>(grow + kk) = o;
+                    if (p_G) *reinterpret_cast<f32x4*>(grow + kk) = o;
+                    if (p_Ghi) {                              // the query-gradient GEMM's A operand, already split
+                        u32x2_t hi, lo;
+                        x3_split4(o[0], o[1], o[2], o[3], hi, lo);
+                        *reinterpret_cast<u32x2_t*>(p_Ghi + goff + kk) = hi;
+                        *reinterpret_cast<u32x2_t*>(p_Glo + goff + kk) = lo;
+                    }
                 }
         }
         // one atomic per WORKGROUP (same-address atomics retire at ~12 ns each: one per wave was 1024 of them = ~13 us at N = 2048);
@@ -463,15 +474,16 @@ static int if_table_from(const eegclip_infonce_problem* probs, int nprob, int pl
     for (int i = 0; i < nprob; ++i) {
         const eegclip_infonce_problem& p = probs[i];
         const bool fin = grad && p.part_k != nullptr;
-        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || (!p.lse && !fin) || (!grad && (!p.part || !p.diag)) || (grad && (!p.G || (p.ldg & 3))))
+        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || (!p.lse && !fin) || (!grad && (!p.part || !p.diag)) || (grad && ((!p.G && !p.G_hi) || (p.ldg & 3))))
             return EEGCLIP_EINVAL;
+        if ((p.G_hi != nullptr) != (p.G_lo != nullptr) || ((reinterpret_cast<uintptr_t>(p.G_hi) | reinterpret_cast<uintptr_t>(p.G_lo)) & 7u)) return EEGCLIP_EINVAL;
         if (fin != want_fin || (fin && (!p.part || !p.diag || !p.diag_k))) return EEGCLIP_EINVAL;
         uintptr_t al = reinterpret_cast<uintptr_t>(p.q_hi) | reinterpret_cast<uintptr_t>(p.k_hi) | reinterpret_cast<uintptr_t>(p.q_lo) |
                        reinterpret_cast<uintptr_t>(p.k_lo) | reinterpret_cast<uintptr_t>(p.G) | reinterpret_cast<uintptr_t>(p.lse_k);
         if (al & 15u) return EEGCLIP_EALIGN;
         tb.p[i] = if_problem{static_cast<const unsigned short*>(p.q_hi), static_cast<const unsigned short*>(p.q_lo), static_cast<const unsigned short*>(p.k_hi),
                              static_cast<const unsigned short*>(p.k_lo), p.part, p.diag, p.lse, p.lse_k, p.G, p.ldg, p.col0, p.weight, fin ? p.part_k : nullptr,
-                             fin ? p.diag_k : nullptr};
+                             fin ? p.diag_k : nullptr, grad ? static_cast<unsigned short*>(p.G_hi) : nullptr, grad ? static_cast<unsigned short*>(p.G_lo) : nullptr};
     }
     return 0;
 }

@@ -58,6 +58,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // sit in 16 different blocks: +12 us on a 32 us GEMM), here a lane owns 4 consecutive columns and one block serves all four.
 // Same mask (Philox(seed, site, row * cols + c)) and the same arithmetic order, so results are bit-identical to the epilogue form.
 typedef float ln_f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte global access from a dword-aligned address
+// the row operand of a LayerNorm launch as the partial slabs of a K-parallel GEMM (csrc/head_gemm.hip): value = sum_{s < n} p[s * stride + i] (+ bias[col]),
+// added in slice order while the row is loaded -- the GEMM's split costs no launch of its own.  n <= 1: the plain operand.
+struct ln_slabs {
+    int n;
+    long long stride;
+    const float* bias;
+};
 template <int NG, bool VEC2, bool DOUBLE>
 __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                                       float* __restrict__ x_out, float drop_p, unsigned long long seed, unsigned site,
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
                                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
                                                                       float* __restrict__ y2, float* __restrict__ mean2_out, float* __restrict__ rstd2_out,
                                                                       int rows, int cols, float eps, unsigned short* __restrict__ y_hi,
-                                                                      unsigned short* __restrict__ y_lo) {
+                                                                      unsigned short* __restrict__ y_lo, const ln_slabs xs) {
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     const float inv = 1.0f / (float)cols;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -112,6 +119,18 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
         for (int i = 0; i < NG; ++i) {
             const int c = 256 * i + 4 * lane;
             ld4(x + rbase, c, v[i]);
+            for (int sl = 1; sl < xs.n; ++sl) {
+                float pv[4];
+                ld4(x + (long long)sl * xs.stride + rbase, c, pv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += pv[e];
+            }
+            if (xs.bias) {
+                float pv[4];
+                ld4(xs.bias, c, pv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += pv[e];
+            }
             if (resid) {
                 float rv[4];
                 ld4(resid + rbase, c, rv);
@@ -211,7 +230,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, float* __restrict__ dx, int rows, int cols,
                                                                 int accumulate_dx, float* __restrict__ dx_drop, float drop_p,
-                                                                unsigned long long seed, unsigned site, float* __restrict__ partials) {
+                                                                unsigned long long seed, unsigned site, float* __restrict__ partials,
+                                                                const ln_slabs dys, unsigned short* __restrict__ dd_hi, unsigned short* __restrict__ dd_lo,
+                                                                float* __restrict__ dy_sum) {
     float pgam[PART ? NG : 1][4], pbet[PART ? NG : 1][4];
 #pragma unroll
     for (int i = 0; i < (PART ? NG : 1); ++i)
@@ -251,6 +272,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
             float xv[4], dv[4], gv[4];
             ld4(xr, c, xv);
             ld4(dr, c, dv);
+            for (int sl = 1; sl < dys.n; ++sl) {
+                float pv[4];
+                ld4(dr + (long long)sl * dys.stride, c, pv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] += pv[e];
+            }
+            if (dy_sum) {                                         // the summed upstream gradient, for the parameter-gradient launch (cols % 4 == 0 with VEC2)
+                if (VEC2 && c + 3 < cols) *reinterpret_cast<ln_f32x4u*>(dy_sum + (long long)row * cols + c) = ln_f32x4u{dv[0], dv[1], dv[2], dv[3]};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < cols) dy_sum[(long long)row * cols + c + e] = dv[e];
+                }
+            }
             ld4(gamma, c, gv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -285,10 +320,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
             }
             if (VEC2 && c + 3 < cols) {
                 *reinterpret_cast<ln_f32x4u*>(dxr + c) = ln_f32x4u{v[0], v[1], v[2], v[3]};
-                if (dx_drop)
-                    *reinterpret_cast<ln_f32x4u*>(dx_drop + rbase + c) =
-                        ln_f32x4u{keep[0] ? v[0] * keep_scale : 0.f, keep[1] ? v[1] * keep_scale : 0.f, keep[2] ? v[2] * keep_scale : 0.f,
-                                  keep[3] ? v[3] * keep_scale : 0.f};
+                if (dx_drop) {
+                    const ln_f32x4u dd = ln_f32x4u{keep[0] ? v[0] * keep_scale : 0.f, keep[1] ? v[1] * keep_scale : 0.f, keep[2] ? v[2] * keep_scale : 0.f,
+                                                   keep[3] ? v[3] * keep_scale : 0.f};
+                    *reinterpret_cast<ln_f32x4u*>(dx_drop + rbase + c) = dd;
+                    if (dd_hi) {                                  // ... again as bf16 hi | lo planes (cols % 4 == 0: checked by the host): the next GEMM's operand
+                        u32x2_t hi, lo;
+                        x3_split4(dd[0], dd[1], dd[2], dd[3], hi, lo);
+                        *reinterpret_cast<u32x2_t*>(dd_hi + rbase + c) = hi;
+                        *reinterpret_cast<u32x2_t*>(dd_lo + rbase + c) = lo;
+                    }
+                }
             } else if (VEC2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -662,7 +704,7 @@ extern "C" int eegclip_layernorm_fwd(const float* x, const float* gamma, const f
 static int residual_layernorm_fwd_go(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
                                               unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                               const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
-                                              float eps, unsigned short* y_hi, unsigned short* y_lo, void* stream) {
+                                              float eps, unsigned short* y_hi, unsigned short* y_lo, void* stream, ln_slabs xs = ln_slabs{1, 0, nullptr}) {
     const bool dbl = gamma2 != nullptr;
     if (!x || !gamma || !beta || !y || rows < 0 || cols < 1 || cols > 64 * LN_MAXC || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if ((x_out || drop_p > 0.f) && !resid) return EEGCLIP_EINVAL;
@@ -672,10 +714,11 @@ static int residual_layernorm_fwd_go(const float* x, const float* resid, float* 
     const bool vec2 = (cols % 2 == 0) &&
                       !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(x_out) |
                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
-                         reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2) | reinterpret_cast<uintptr_t>(y2)) & 7u);
+                         reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2) | reinterpret_cast<uintptr_t>(y2) |
+                         reinterpret_cast<uintptr_t>(xs.bias) | (uintptr_t)((xs.stride & 1) << 2)) & 7u);
 #define EEG_RLN_GO(NG, V2, DB)                                                                                                              \
     EEG_LAUNCH((residual_layernorm_fwd_kernel<NG, V2, DB>), dim3(grid), dim3(256), 0, stream, x, resid, x_out, drop_p, seed, site, gamma, beta, y, \
-               mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps, y_hi, y_lo)
+               mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps, y_hi, y_lo, xs)
     if (cols <= 256) {
         if (vec2) { if (dbl) EEG_RLN_GO(1, true, true); else EEG_RLN_GO(1, true, false); }
         else      { if (dbl) EEG_RLN_GO(1, false, true); else EEG_RLN_GO(1, false, false); }
@@ -704,6 +747,42 @@ extern "C" int eegclip_residual_layernorm_fwd_planes(const float* x, const float
                                      static_cast<unsigned short*>(y_hi), static_cast<unsigned short*>(y_lo), stream);
 }
 
+// eegclip_residual_layernorm_fwd_planes whose row operand x is the partial slabs of a K-parallel GEMM: x = sum_{s < nslabs} x[s * slab_stride + .] + x_bias[col]
+extern "C" int eegclip_residual_layernorm_fwd_slabs(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed,
+                                                    unsigned int site, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                                    const float* gamma2, const float* beta2, float* y2, float* mean2, float* rstd2, int rows, int cols,
+                                                    float eps, void* y_hi, void* y_lo, int nslabs, long long slab_stride, const float* x_bias, void* stream) {
+    if ((y_hi != nullptr) != (y_lo != nullptr) || (y_hi && ((cols & 3) || ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7u)))) return EEGCLIP_EINVAL;
+    if (nslabs < 1 || nslabs > 16 || (nslabs > 1 && slab_stride < (long long)rows * cols)) return EEGCLIP_EINVAL;
+    return residual_layernorm_fwd_go(x, resid, x_out, drop_p, seed, site, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, rows, cols, eps,
+                                     static_cast<unsigned short*>(y_hi), static_cast<unsigned short*>(y_lo), stream, ln_slabs{nslabs, slab_stride, x_bias});
+}
+
+// the input-gradient half of eegclip_layernorm_bwd whose upstream gradient dy is the partial slabs of a K-parallel GEMM (dy = sum_{s < nslabs} dy[s * slab_stride + .])
+// and whose second output dx_drop = dropout'(dx) leaves again as bf16 hi | lo planes (dd_hi / dd_lo, or NULL): the A operand of the next plane GEMM; dy_sum
+// (or NULL): the summed dy, for the parameter-gradient half (eegclip_layernorm_bwd with dx == NULL), which runs as a launch of its own off the dX chain
+extern "C" int eegclip_layernorm_bwd_slabs(const float* dy, int nslabs, long long slab_stride, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                           float* dx, int rows, int cols, float* dx_drop, void* dd_hi, void* dd_lo, float* dy_sum, float drop_p,
+                                           unsigned long long seed, unsigned int site, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || rows < 0 || cols < 1 || cols > 64 * LN_MAXC || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (nslabs < 1 || nslabs > 16 || (nslabs > 1 && slab_stride < (long long)rows * cols)) return EEGCLIP_EINVAL;
+    if ((dd_hi != nullptr) != (dd_lo != nullptr) || (dd_hi && (!dx_drop || (cols & 3) || ((reinterpret_cast<uintptr_t>(dd_hi) | reinterpret_cast<uintptr_t>(dd_lo)) & 7u))))
+        return EEGCLIP_EINVAL;
+    if (rows == 0) return 0;
+    const dim3 grid(grid_for(rows, 4, 8192));
+    const bool vec2 = (cols % 2 == 0) && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop) | (uintptr_t)((slab_stride & 1) << 2)) & 7u);
+    if (dd_hi && !vec2) return EEGCLIP_EALIGN;
+    const ln_slabs dys{nslabs, slab_stride, nullptr};
+#define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
+    EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, 0, dx_drop, drop_p, seed, site, \
+               (float*)nullptr, dys, static_cast<unsigned short*>(dd_hi), static_cast<unsigned short*>(dd_lo), dy_sum)
+    if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
+    else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
+#undef EEG_LN_BWD_GO
+    return (int)hipGetLastError();
+}
+
 extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                      float* dx, float* dgamma, float* dbeta, int rows, int cols, int accumulate_dx, float* dx_drop,
                                      float drop_p, unsigned long long seed, unsigned int site, void* stream) {
@@ -720,7 +799,7 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
                                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop)) & 7u);
 #define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
     EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, \
-               drop_p, seed, site, (float*)nullptr)
+               drop_p, seed, site, (float*)nullptr, ln_slabs{1, 0, nullptr}, (unsigned short*)nullptr, (unsigned short*)nullptr, (float*)nullptr)
     if (want_dx) {
         if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
         else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
@@ -752,7 +831,7 @@ extern "C" int eegclip_layernorm_bwd_full(const float* dy, const float* x, const
                                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop)) & 7u);
 #define EEG_LNF_GO(NG, V2)                                                                                                                         \
     EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2, true>), grid, dim3(256), 3 * 2 * NG * 256 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, rows, \
-               cols, accumulate_dx, dx_drop, drop_p, seed, site, workspace)
+               cols, accumulate_dx, dx_drop, drop_p, seed, site, workspace, ln_slabs{1, 0, nullptr}, (unsigned short*)nullptr, (unsigned short*)nullptr, (float*)nullptr)
     if (cols <= 256) { if (vec2) EEG_LNF_GO(1, true); else EEG_LNF_GO(1, false); }
     else             { if (vec2) EEG_LNF_GO(4, true); else EEG_LNF_GO(4, false); }
 #undef EEG_LNF_GO

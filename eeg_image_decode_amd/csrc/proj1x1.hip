@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
                                                            float* __restrict__ feat, int B, float drop_p, unsigned long long seed, unsigned site,
                                                            const double* __restrict__ rows, int nrows, double count, float eps, float momentum,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ run_mean,
-                                                           float* __restrict__ run_var, long long* __restrict__ nbt) {
+                                                           float* __restrict__ run_var, long long* __restrict__ nbt,
+                                                           unsigned short* __restrict__ feat_hi, unsigned short* __restrict__ feat_lo) {
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2 of this sample
     float* ws = zs + PJ_N;                // [40][41]  W[e][c]
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
 #pragma unroll 8
         for (int c = 0; c < PJ_C; ++c) acc += ws[e * PJ_LW + c] * zs[c * PJ_W + w];
         feat[(long long)b * PJ_N + o] = acc;
+        if (feat_hi) {                    // ... again as bf16 hi | lo planes: the A operand of the projection head's first Linear (csrc/head_gemm.hip)
+            const unsigned short hi = f32_to_bf16_bits(acc);
+            feat_hi[(long long)b * PJ_N + o] = hi;
+            feat_lo[(long long)b * PJ_N + o] = f32_to_bf16_bits(acc - bf16_bits_to_f32(hi));
+        }
     }
 }
 
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
                                                            const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dz2,
                                                            float* __restrict__ dW, float* __restrict__ dbias, double* __restrict__ sums, double* __restrict__ partials, int B, int spw,
-                                                           float drop_p, unsigned long long seed, unsigned site) {
+                                                           float drop_p, unsigned long long seed, unsigned site, int nslabs, long long slab_stride) {
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2[c][w]
     float* ds = zs + PJ_N;                // [36][41]  dfeat[w][e]
@@ -110,7 +116,9 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
         __syncthreads();                                // previous sample consumed (first pass: orders the weight staging)
         for (int i = t; i < PJ_N; i += 256) {
             zs[i] = z2[(long long)b * PJ_N + i];
-            ds[(i / PJ_C) * PJ_LW + i % PJ_C] = dfeat[(long long)b * PJ_N + i];
+            float g = dfeat[(long long)b * PJ_N + i];
+            for (int sl = 1; sl < nslabs; ++sl) g += dfeat[(long long)sl * slab_stride + (long long)b * PJ_N + i];      // (partial slabs of the K-parallel GEMM, slice order)
+            ds[(i / PJ_C) * PJ_LW + i % PJ_C] = g;
         }
         __syncthreads();
         for (int i = t; i < PJ_N; i += 256) {           // input gradient of the 1x1 conv + BatchNorm-backward statistics
@@ -208,7 +216,8 @@ extern "C" int eegclip_proj1x1_fwd(const float* y2, const float* mean, const flo
                                    void* stream) {
     if (!y2 || !mean || !rstd || !gamma || !beta || !W || !bias || !z2 || !feat || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, mean, rstd, gamma, beta, W, bias, z2, feat, B, drop_p, seed, site,
-               (const double*)nullptr, 0, 1.0, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (long long*)nullptr);
+               (const double*)nullptr, 0, 1.0, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (long long*)nullptr,
+               (unsigned short*)nullptr, (unsigned short*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -221,15 +230,47 @@ extern "C" int eegclip_proj1x1_fwd_rows(const float* y2, const double* rows, int
     if ((running_mean == nullptr) != (running_var == nullptr)) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
     EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, (const float*)nullptr, (const float*)nullptr, gamma, beta, W, bias, z2, feat, B,
-               drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+               drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked, (unsigned short*)nullptr,
+               (unsigned short*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// eegclip_proj1x1_fwd_rows that also leaves `feat` as bf16 hi | lo planes (feat_hi / feat_lo, (B, 1440) each)
+extern "C" int eegclip_proj1x1_fwd_rows_planes(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
+                                               float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
+                                               const float* W, const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed,
+                                               unsigned int site, void* feat_hi, void* feat_lo, void* stream) {
+    if (!y2 || !gamma || !beta || !W || !bias || !z2 || !feat || !feat_hi || !feat_lo || !mean || !rstd || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (rows && (nrows < 1 || count < 1.0)) return EEGCLIP_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
+    // rows == NULL: mean / rstd are INPUTS (eval mode, or statistics finalised by an earlier launch: data parallelism)
+    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, rows ? (const float*)nullptr : mean, rows ? (const float*)nullptr : rstd, gamma, beta,
+               W, bias, z2, feat, B, drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked,
+               static_cast<unsigned short*>(feat_hi), static_cast<unsigned short*>(feat_lo));
     return (int)hipGetLastError();
 }
 
 extern "C" long long eegclip_proj1x1_bwd_workspace_floats(int B) { return B < 1 ? 0 : 2LL * B * PJ_PART; }      // (doubles, counted in floats)
 
+static int proj1x1_bwd_go(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
+                          float drop_p, unsigned long long seed, unsigned int site, void* stream);
 extern "C" int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const float* W, const float* y2, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
                                    float drop_p, unsigned long long seed, unsigned int site, void* stream) {
+    return proj1x1_bwd_go(dfeat, 1, 0, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, workspace, B, drop_p, seed, site, stream);
+}
+// eegclip_proj1x1_bwd whose upstream gradient is the partial slabs of a K-parallel GEMM: dfeat = sum_{s < nslabs} dfeat[s * slab_stride + .]
+extern "C" int eegclip_proj1x1_bwd_slabs(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                                         const float* rstd, const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums,
+                                         float* workspace, int B, float drop_p, unsigned long long seed, unsigned int site, void* stream) {
+    if (nslabs < 1 || nslabs > 16 || (nslabs > 1 && slab_stride < (long long)B * PJ_N)) return EEGCLIP_EINVAL;
+    return proj1x1_bwd_go(dfeat, nslabs, slab_stride, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, workspace, B, drop_p, seed, site, stream);
+}
+static int proj1x1_bwd_go(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
+                          float drop_p, unsigned long long seed, unsigned int site, void* stream) {
     if (!dfeat || !z2 || !W || !y2 || !mean || !rstd || !gamma || !beta || !dz2 || !dW || !dbias || !sums || B < 1 || drop_p < 0.f || drop_p >= 1.f)
         return EEGCLIP_EINVAL;
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7u)) return EEGCLIP_EALIGN;
@@ -240,7 +281,7 @@ extern "C" int eegclip_proj1x1_bwd(const float* dfeat, const float* z2, const fl
     const int nwg = (B + spw - 1) / spw;
     double* parts = reinterpret_cast<double*>(workspace);
     EEG_LAUNCH(proj1x1_bwd_kernel, dim3(nwg), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, parts, B, spw,
-               drop_p, seed, site);
+               drop_p, seed, site, nslabs, slab_stride);
     if (parts) {
         const int slices = nwg < PJ_SLICES ? nwg : PJ_SLICES;
         EEG_LAUNCH(proj1x1_bwd_reduce_kernel, dim3((PJ_PART + 63) / 64, slices), dim3(256), 256 * sizeof(double), stream, parts, nwg, dW, dbias, sums);

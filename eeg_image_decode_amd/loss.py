@@ -74,11 +74,57 @@ def split_planes_many(xs, planes, stack=None):
 MAX_BLOCKS_PER_LAUNCH = 8          # IF_MAX_PROB of csrc/infonce_fused.hip (eegclip_infonce_fused_{fwd,grad} reject more)
 
 
-def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=None):
+def head_gemm_enabled(n, K, Dm):
+    """the query gradient dA = [G_1 | .. | G_T] [B_1; ..; B_T] on the K-parallel plane GEMM (csrc/head_gemm.hip, round 6): gradient matrices as planes
+    straight from the InfoNCE gradient pass, the stacked target planes read k-major (no transposed copy); EEGCLIP_HEAD_GEMM=0 pins the fp32-operand GEMM"""
+    return os.environ.get("EEGCLIP_HEAD_GEMM", "1") != "0" and n % 4 == 0 and K % 32 == 0 and Dm % 8 == 0
+
+
+def stacked_target_planes(a_, bs, planes):
+    """ONE split launch for the query features and the T targets: (ap, [bp_t], tp) -- tp = the targets' planes STACKED, (2, T n, D): hi | lo of [B_1; ..; B_T],
+    the k-major B operand of the query-gradient GEMM as it is (bp_t are its row blocks)"""
+    n, Dm = a_.shape
+    T_ = len(bs)
+    dev = a_.device
+    aq = torch.empty(2, n, Dm, dtype=torch.bfloat16, device=dev)
+    tp = torch.empty(2, T_ * n, Dm, dtype=torch.bfloat16, device=dev)
+    items = (_abi.SplitItem * (T_ + 1))()
+    items[0] = _abi.SplitItem(src=a_.data_ptr(), hi=aq[0].data_ptr(), lo=aq[1].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0)
+    for t, b_ in enumerate(bs):
+        items[1 + t] = _abi.SplitItem(src=b_.data_ptr(), hi=tp[0, t * n:].data_ptr(), lo=tp[1, t * n:].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0)
+    check(lib().eegclip_split_rows(items, T_ + 1, _stream()), "split_rows")
+    pick = (lambda hi, lo: (hi, lo if planes == 2 else None))
+    return pick(aq[0], aq[1]), [pick(tp[0, t * n:(t + 1) * n], tp[1, t * n:(t + 1) * n]) for t in range(T_)], tp
+
+
+def query_grad_slabs(Gp, tp, n, K, Dm, slabs=None):
+    """the K-parallel GEMM itself: (slabs (S, n, D) fp32, S).  Gp = [G_1 | .. | G_T] as planes (2, n, K), tp = the stacked target planes (2, K, D) read k-major.
+    dA = slabs[0] + slabs[1] + .. in slice order -- added by whoever consumes it (the encoder's backward plan takes the slabs as they are; add_slabs for a
+    plain tensor)"""
+    L = lib()
+    S = int(L.eegclip_head_gemm_slices(n, Dm, K))
+    if slabs is None:
+        slabs = torch.empty(S, n, Dm, dtype=torch.float32, device=Gp.device)
+    d = _abi.HeadGemmDesc(a_hi=Gp[0].data_ptr(), a_lo=Gp[1].data_ptr(), b_hi=tp[0].data_ptr(), b_lo=tp[1].data_ptr(), lda=K, ldb=Dm, M=n, N=Dm, K=K,
+                          slices=S, slab_stride=n * Dm, C=slabs.data_ptr(), ldc=Dm, b_kmajor=1)
+    check(L.eegclip_head_gemm(ctypes.byref(d), _stream()), "head_gemm")
+    return slabs, S
+
+
+def add_slabs(slabs):
+    """slabs[0] + slabs[1] + .. in that order (what the slab-consuming kernels compute, bit for bit)"""
+    out = slabs[0]
+    for i in range(1, slabs.shape[0]):
+        out = out + slabs[i]
+    return out
+
+
+def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=None, G_planes=None):
     """blocks = [(q planes, k planes, col0, weight)]: adds sum_blocks weight / n_total * sum_rows (lse_row - positive) to acc[0].
     want_grad = [(block index, index of the block whose lse is the second (per-key) normaliser, or None)]: for each, the gradient matrix
     G = s * dL/dS of that block ((n, N) fp32, written once) is returned and d loss / d s is added to acc[1].  G_out = where to write them (one (n, N)
-    view per entry of want_grad, unit column stride, row stride a multiple of 4: e.g. side by side in one (n, T N) matrix)."""
+    view per entry of want_grad, unit column stride, row stride a multiple of 4: e.g. side by side in one (n, T N) matrix).  G_planes = [(hi, lo)] bf16
+    views of the same shape / strides: G leaves as the planes of the query-gradient GEMM instead (nothing is returned then)."""
     L = lib()
     dev = sc.device
     nb = len(blocks)
@@ -106,10 +152,14 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=N
     garr = (_abi.InfonceProblem * len(want_grad))()
     Gs = []
     for j, (bi, ki) in enumerate(want_grad):
-        G = G_out[j] if G_out is not None else torch.empty(n, N, dtype=torch.float32, device=dev)
-        Gs.append(G)
         garr[j] = arr[bi]
-        garr[j].G, garr[j].ldg = G.data_ptr(), G.stride(0)
+        if G_planes is not None:
+            hi, lo = G_planes[j]
+            garr[j].G, garr[j].ldg, garr[j].G_hi, garr[j].G_lo = None, hi.stride(0), hi.data_ptr(), lo.data_ptr()
+        else:
+            G = G_out[j] if G_out is not None else torch.empty(n, N, dtype=torch.float32, device=dev)
+            Gs.append(G)
+            garr[j].G, garr[j].ldg = G.data_ptr(), G.stride(0)
         garr[j].lse_k = arr[ki].lse if ki is not None else None
         if inline:
             garr[j].part_k, garr[j].diag_k = arr[ki].part, arr[ki].diag
@@ -120,7 +170,8 @@ def fused_infonce(blocks, n, N, Dm, planes, n_total, sc, acc, want_grad, G_out=N
                   "infonce_fused_grad_finalize")
         else:
             check(L.eegclip_infonce_fused_grad(chunk, len(chunk), n, N, Dm, planes, n_total, sc.data_ptr(), acc.data_ptr() + 4, st), "infonce_fused_grad")
-    Gs[0]._eegclip_keep = buf                      # the lse vectors must outlive the launch (stream-ordered allocator: already safe; explicit)
+    if Gs:
+        Gs[0]._eegclip_keep = buf                  # the lse vectors must outlive the launch (stream-ordered allocator: already safe; explicit)
     return Gs
 
 
@@ -321,15 +372,28 @@ class _ClipLossFn(torch.autograd.Function):
             # side by side in one (n, T n) buffer, the targets stacked by the launch that splits them (T GEMM launches of K = n -> one of K = T n)
             T_ = len(bs)
             stacked = need_a and T_ >= 2
-            stack = torch.empty(T_ * n, Dm, dtype=torch.float32, device=dev) if stacked else None
-            ap, *bps = split_planes_many([a_] + bs, planes, stack)
+            # (round 6) ... on the K-parallel plane GEMM when nothing else needs the fp32 gradient matrices: G leaves the gradient pass as planes, the
+            # targets are split transposed, dA = the GEMM's slabs added in slice order (the step plan hands the slabs to the encoder's backward as they are)
+            on_planes = need_a and need and not any(need_b) and head_gemm_enabled(n, T_ * n, Dm)
+            stack = torch.empty(T_ * n, Dm, dtype=torch.float32, device=dev) if stacked and not on_planes else None
+            if on_planes:
+                ap, bps, tp = stacked_target_planes(a_, bs, planes)
+            else:
+                ap, *bps = split_planes_many([a_] + bs, planes, stack)
             blocks, want = [], []
             for t, w in enumerate(weights):
                 blocks += [(ap, bps[t], 0, 0.5 * w), (bps[t], ap, 0, 0.5 * w)]
                 want.append((2 * t, 2 * t + 1))
+            if on_planes:
+                Gp = torch.empty(2, n, T_ * n, dtype=torch.bfloat16, device=dev)
+                fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want, None, [(Gp[0, :, t * n:(t + 1) * n], Gp[1, :, t * n:(t + 1) * n]) for t in range(T_)])
+                da = add_slabs(query_grad_slabs(Gp, tp, n, T_ * n, Dm)[0])
+                stacked, Gs = False, None
+                need_a = False                                    # (da is complete)
             Gcat = torch.empty(n, T_ * n, dtype=torch.float32, device=dev) if stacked and need else None
-            Gs = fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want if need else [],
-                               [Gcat[:, t * n:(t + 1) * n] for t in range(T_)] if Gcat is not None else None)
+            if not on_planes:
+                Gs = fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want if need else [],
+                                   [Gcat[:, t * n:(t + 1) * n] for t in range(T_)] if Gcat is not None else None)
             if stacked and need:
                 da = _grad_rows(Gcat, stack, None, PX3)
             for t, b_ in enumerate(bs):

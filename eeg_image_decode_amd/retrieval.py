@@ -8,6 +8,8 @@ import ctypes
 import os
 import random
 import re
+import warnings
+import weakref
 
 import torch
 
@@ -134,6 +136,15 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
 
 
 _STEP_PLANS_MAX = 8
+# model -> {configuration: state}.  Keyed weakly by the model and holding neither the model nor the optimizer strongly (StepPlan keeps weak references
+# too): a dropped model frees its plans, buffers and engine -- nothing here closes a reference cycle through the engine, which retrieval.settle_gc()'s
+# gc.freeze() would make immortal for the first model of a process
+_STEP_PLAN_TABLES = weakref.WeakKeyDictionary()
+
+
+def step_plans_of(model):
+    """the StepPlan objects built for `model` so far (tests, bench.py)"""
+    return [st["plan"] for st in _STEP_PLAN_TABLES.get(model, {}).values() if st["plan"]]
 
 
 def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, alpha, objective, keep_grads):
@@ -141,18 +152,22 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
     StepPlan.WARM_STEPS times -- those steps create the encoder plans, the activation buffers and the optimizer's launch cache the plan is built
     from.  state is the per-configuration counter the caller advances after an ordinary step."""
     from . import dist as edist
-    from .step_plan import StepPlan
+    from .step_plan import NotApplicable, StepPlan
     if not StepPlan.eligible(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, objective, keep_grads,
                              edist.world_size()):
         return None, None
     eng = eeg_model._engine()
-    table = eng.__dict__.setdefault("_step_plans", {})
+    table = _STEP_PLAN_TABLES.get(eeg_model)
+    if table is None:
+        table = _STEP_PLAN_TABLES[eeg_model] = {}
     key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subject_id)
     st = table.get(key)
+    if st is not None and st["opt"]() is not optimizer:               # (an id reused by another optimizer)
+        st = None
     if st is None:
         if len(table) >= _STEP_PLANS_MAX:
             table.clear()
-        st = table[key] = {"warm": 0, "plan": None, "opt": optimizer}
+        st = table[key] = {"warm": 0, "plan": None, "opt": weakref.ref(optimizer)}
     sp = st["plan"]
     if sp is not None and sp is not False:
         if sp.still_valid(eeg_model, optimizer) and (subject_id >= 10 or eng.bufs[eeg_data.shape[0]].get("ids_uniform") == subject_id):
@@ -163,8 +178,9 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
         try:
             st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0])
             return st, st["plan"]
-        except (KeyError, AssertionError, AttributeError):
+        except NotApplicable as e:                    # (anything else is a bug in the plan builder and propagates)
             st["plan"] = False                        # this configuration does not have the pieces (e.g. launch-per-Linear plans): ordinary path for good
+            warnings.warn(f"single-submission step plan not applicable, keeping the launch-by-launch path: {e}", RuntimeWarning, stacklevel=3)
     return st, None
 
 

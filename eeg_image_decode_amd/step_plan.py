@@ -10,12 +10,15 @@ labels, the fresh output tensor), the dropout seed and the optimizer's step coun
     -> [encoder backward] -> join -> fused AdamW + gradient clear
 
 replayed by ONE foreign call (eegclip_plan_run).  The launches, their order, their arguments and the random-number consumption are exactly those of
-the launch-by-launch path -- tests/test_product_on_emulator.py trains both ways and compares parameters bit for bit -- so this is a host-side
-optimisation only; anything outside the steady state (first steps of a run, another batch size, a user-supplied loss or optimizer, gradient
-accumulation, data parallelism, the joint-subject model) takes the ordinary path.  EEGCLIP_STEP_PLAN=0 disables it.
+the launch-by-launch path -- tools/check_step_plan_bitwise.py (single-threaded emulator: ordered float atomics) compares every tensor bit for bit,
+tests/test_product_on_emulator.py one step from a common snapshot at round-off tolerance, tests/test_full_size_gpu.py the plan's losses, embeddings and
+post-AdamW parameters against the ORACLE at B = 256 -- so this is a host-side optimisation only; anything outside the steady state (first steps of a
+run, another batch size, a user-supplied loss or optimizer, gradient accumulation, data parallelism, the joint-subject model) takes the ordinary
+path.  EEGCLIP_STEP_PLAN=0 disables it.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -38,24 +41,39 @@ def _on_device(t):
     return t.is_cuda
 
 
+class NotApplicable(Exception):
+    """this configuration does not have the pieces a step plan is built from (launch-per-Linear encoder plans, no optimizer launch cache ...): the caller
+    keeps the ordinary path.  Anything else raised while a plan is built is a bug and propagates."""
+
+
 class StepPlan:
     """the steady-state contrastive step of one (model, optimizer, batch size, loss mix) as a single launch plan"""
 
     WARM_STEPS = 3          # ordinary steps before the plan is built: they create the encoder plans, the activation buffers and the optimizer's launch cache
 
+    @property
+    def eng(self):
+        return self._eng_ref()
+
     def __init__(self, model, optimizer, B, alpha, n_classes):
         from . import loss as eloss
         from .atms import P_DIM
         eng = model._engine()
-        self.model, self.optimizer, self.eng, self.B, self.alpha, self.n_classes = model, optimizer, eng, B, float(alpha), n_classes
+        # (weak: the plan hangs off the engine, which hangs off the model -- a strong reference back would be a cycle that retrieval.settle_gc()'s
+        #  gc.freeze() makes immortal for the first model of a process)
+        self._model_ref, self._opt_ref = weakref.ref(model), weakref.ref(optimizer)
+        self._eng_ref = weakref.ref(eng)
+        self.B, self.alpha, self.n_classes = B, float(alpha), n_classes
         key = eng.last_key
         self.key = key
         Bk, train, shared, probs, W = key
-        assert Bk == B and train and W == 1
-        self.fwd = eng.plans[("f",) + key]
-        self.bwd = eng.plans[("b", B, train, shared, probs, False, W, False)]
-        if self.fwd.tb_desc is None or self.bwd.x_gemm is not None or optimizer._fast_last.get(0) is None:
-            raise KeyError("the fused transformer-block plans and the optimizer's launch cache are required")
+        if not (Bk == B and train and W == 1):
+            raise NotApplicable("the last forward was not a single-process training forward at this batch size")
+        self.bwd_key = ("b", B, train, shared, probs, False, W, False)
+        self.fwd = eng.plans.get(("f",) + key)
+        self.bwd = eng.plans.get(self.bwd_key)
+        if self.fwd is None or self.bwd is None or self.fwd.tb_desc is None or self.bwd.x_gemm is not None or optimizer._fast_last.get(0) is None:
+            raise NotApplicable("the fused transformer-block plans and the optimizer's launch cache are required")
         self.probs = probs
         dev = eng.device
         self.dev = dev
@@ -79,7 +97,11 @@ class StepPlan:
 
         # ---- the targets' operand planes + fp32 stack: inputs only, second stream, under the encoder's forward (items filled below)
         self.split_op = len(pl.ops)
-        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", os.environ.get("EEGCLIP_START_SIDE", "1") != "0"))
+        start_side = os.environ.get("EEGCLIP_START_SIDE", "1") != "0"
+        # (round 6) the query gradient on the K-parallel plane GEMM: it reads the targets' planes STACKED, k-major -- the same two split items, written
+        # behind one another
+        self.on_planes = bool(getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and eloss.head_gemm_enabled(B, 2 * B, Dm))
+        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", start_side))
         # ---- encoder forward
         f0 = splice(self.fwd)
         self.fwd_base = f0
@@ -99,27 +121,37 @@ class StepPlan:
             pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
 
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch).  Operand planes: the targets are inputs of the
-        # step -- split (and stacked for the query gradient) by a second-stream launch at the very start; the query features leave the head's LayerNorm as
-        # planes (eegclip_residual_layernorm_fwd_planes: the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
-        self.plane_buf = torch.empty(3, 2, B, Dm, dtype=torch.bfloat16, device=dev)
-        self.stack = torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # [img; txt]: the ONE right-hand operand of the query gradient (loss.py)
+        # step -- split (and, for the query gradient, split TRANSPOSED: round 6) by second-stream launches at the very start; the query features leave the
+        # head's LayerNorm as planes (the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
+        self.q_planes = torch.empty(2, B, Dm, dtype=torch.bfloat16, device=dev)                 # the query features, written by the head's LayerNorm
+        self.t_planes = torch.empty(2, 2 * B, Dm, dtype=torch.bfloat16, device=dev)             # hi | lo of [img; txt]
+        self.stack = None if self.on_planes else torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # round 5's fp32 right-hand operand of the query gradient (loss.py)
         self.items = (_abi.SplitItem * 2)()
         for i in range(2):
-            self.items[i] = _abi.SplitItem(src=0, hi=self.plane_buf[1 + i, 0].data_ptr(), lo=self.plane_buf[1 + i, 1].data_ptr(), rows=B, cols=Dm, ld_src=Dm,
-                                           ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr(), ld_copy=Dm)
+            self.items[i] = _abi.SplitItem(src=0, hi=self.t_planes[0, i * B:].data_ptr(), lo=self.t_planes[1, i * B:].data_ptr(), rows=B, cols=Dm, ld_src=Dm,
+                                           ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr() if self.stack is not None else None, ld_copy=Dm)
         pl._keep.append(self.items)
         pl.ops[self.split_op][1][0] = self.items
         fn, args, name, side = pl.ops[self.out_op]
-        assert name == "eegclip_residual_layernorm_fwd"
-        pl.ops[self.out_op] = (L.eegclip_residual_layernorm_fwd_planes, args[:-1] + [self.plane_buf[0, 0].data_ptr(), self.plane_buf[0, 1].data_ptr(), None],
-                               "eegclip_residual_layernorm_fwd_planes", side)
+        if name == "eegclip_residual_layernorm_fwd_slabs":              # (round 6: the head's LayerNorm adds the second Linear's slabs; planes are arguments 19 / 20)
+            args[19], args[20] = self.q_planes[0].data_ptr(), self.q_planes[1].data_ptr()
+        else:
+            if name != "eegclip_residual_layernorm_fwd":
+                raise NotApplicable(f"unexpected output op {name}")
+            pl.ops[self.out_op] = (L.eegclip_residual_layernorm_fwd_planes, args[:-1] + [self.q_planes[0].data_ptr(), self.q_planes[1].data_ptr(), None],
+                                   "eegclip_residual_layernorm_fwd_planes", side)
         ws = int(L.eegclip_infonce_fused_workspace_floats(B, B))
         self.if_buf = torch.empty(4 * (ws + 2 * B), dtype=torch.float32, device=dev)
-        self.G = torch.empty(B, 2 * B, dtype=torch.float32, device=dev)            # [G_img | G_txt] side by side
+        if self.on_planes:
+            self.G = None
+            self.Gp = torch.empty(2, B, 2 * B, dtype=torch.bfloat16, device=dev)            # [G_img | G_txt] side by side, as hi | lo planes
+        else:
+            self.G = torch.empty(B, 2 * B, dtype=torch.float32, device=dev)
         base = self.if_buf.data_ptr()
 
         def planes_of(i):
-            return (self.plane_buf[i, 0].data_ptr(), self.plane_buf[i, 1].data_ptr() if self.planes == 2 else None)
+            hi, lo = (self.q_planes[0], self.q_planes[1]) if i == 0 else (self.t_planes[0, (i - 1) * B:], self.t_planes[1, (i - 1) * B:])
+            return (hi.data_ptr(), lo.data_ptr() if self.planes == 2 else None)
 
         ap = planes_of(0)
         arr = (_abi.InfonceProblem * 4)()
@@ -133,10 +165,18 @@ class StepPlan:
         garr = (_abi.InfonceProblem * 2)()
         for t_ in range(2):
             garr[t_] = arr[2 * t_]
-            garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), 2 * B
+            if self.on_planes:
+                garr[t_].G, garr[t_].ldg = None, 2 * B
+                garr[t_].G_hi, garr[t_].G_lo = self.Gp[0, :, t_ * B:].data_ptr(), self.Gp[1, :, t_ * B:].data_ptr()
+            else:
+                garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), 2 * B
             garr[t_].lse_k = arr[2 * t_ + 1].lse
             garr[t_].part_k, garr[t_].diag_k = arr[2 * t_ + 1].part, arr[2 * t_ + 1].diag
         pl._keep += [arr, garr]
+        # the loss reads planes (and, round 5's form, the fp32 stack) that the SECOND stream wrote at the start of the step: ordered by the forward plan's join
+        # in front of the conv stack when it has one -- an explicit join otherwise (free when nothing is pending)
+        if "join" not in [op[2] for op in pl.ops[self.fwd_base:]]:
+            pl.join()
         # (loss.fused_infonce's training form: the forward leaves the per-tile partials, the gradient pass finalises them itself and adds the loss)
         if os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
             pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, None)
@@ -148,13 +188,23 @@ class StepPlan:
             self.if_fwd_op = len(pl.ops)
             pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
             pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())
-        self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
         # dA = [G_img | G_txt] [img; txt]: one launch, K = 2 B
-        d = _abi.GemmDesc(M=B, N=Dm, K=2 * B, A=self.G.data_ptr(), Am=D(2 * B), Ak=D(1), B=self.stack.data_ptr(), Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(),
-                          Cm=D(Dm), Cn=D(1), Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0,
-                          seed=0, drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
-        pl._keep.append(d)
-        pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
+        if self.on_planes:
+            # ... K-parallel from planes (csrc/head_gemm.hip); the encoder's backward adds the slabs while its first kernel loads them
+            S = int(L.eegclip_head_gemm_slices(B, Dm, 2 * B))
+            self.da = torch.empty(S, B, Dm, dtype=torch.float32, device=dev)
+            self.da_slices = S
+            pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=self.Gp[0].data_ptr(), a_lo=self.Gp[1].data_ptr(), b_hi=self.t_planes[0].data_ptr(),
+                                                               b_lo=self.t_planes[1].data_ptr(), lda=2 * B, ldb=Dm, M=B, N=Dm, K=2 * B, slices=S,
+                                                               slab_stride=B * Dm, C=self.da.data_ptr(), ldc=Dm, b_kmajor=1))
+        else:
+            self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
+            self.da_slices = 1
+            d = _abi.GemmDesc(M=B, N=Dm, K=2 * B, A=self.G.data_ptr(), Am=D(2 * B), Ak=D(1), B=self.stack.data_ptr(), Bk=D(Dm), Bn=D(1), C=self.da.data_ptr(),
+                              Cm=D(Dm), Cn=D(1), Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0,
+                              seed=0, drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
+            pl._keep.append(d)
+            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
         # ---- encoder backward, the accuracy readout behind its first second-stream launch
         cut = self.bwd.dout_par_op + 1
         b0 = len(pl.ops)
@@ -165,7 +215,15 @@ class StepPlan:
         self.bwd_shift = len(pl.ops) - n0
         splice(self.bwd, cut, len(self.bwd.ops), at=b0 + self.bwd_shift)
         pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
-        pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
+        if self.on_planes:
+            # the backward's first kernel adds the S slabs while it loads them and leaves the sum for the parameter half of the head's LayerNorm
+            bb = eng.bufs[B]
+            pl.set_arg(b0 + self.bwd.dout_op, 1, self.da_slices)
+            pl.set_arg(b0 + self.bwd.dout_op, 2, B * Dm)
+            pl.set_arg(b0 + self.bwd.dout_op, 13, bb["dout_sum"].data_ptr())
+            pl.set_arg(b0 + self.bwd.dout_par_op, 0, bb["dout_sum"].data_ptr())
+        else:
+            pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
         pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
         # ---- fused AdamW + the zero_grad() that opens the next iteration
         fast = optimizer._fast_last.get(0)
@@ -216,7 +274,9 @@ class StepPlan:
     def still_valid(self, model, optimizer):
         """the captured state is still the live one: same engine / plans / optimizer launch cache, nobody attached gradients or changed hyper-parameters"""
         eng = self.eng
-        if model._eng is not eng or eng.stale(model) or eng.plans.get(("f",) + self.key) is not self.fwd:
+        if eng is None or model._eng is not eng or eng.stale(model) or eng.plans.get(("f",) + self.key) is not self.fwd or eng.plans.get(self.bwd_key) is not self.bwd:
+            return False
+        if self._model_ref() is not model or self._opt_ref() is not optimizer:
             return False
         if model.drop_probs(True) != self.probs or optimizer._fast_last.get(0) is not self.fast:
             return False
@@ -248,6 +308,11 @@ class StepPlan:
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
         self.items[0].src, self.items[1].src = img.data_ptr(), txt.data_ptr()
+        # the plan ACCUMULATES into the flat gradient buffer without attach_grads(): it must be clear.  It is when the optimizer's fused step cleared
+        # exactly the views the last backward attached and nothing touched them since (every plan step leaves it so); after anything else -- a
+        # keep_grads=True step, a manual backward followed by zero_grad(set_to_none=True): .grad is None but the buffer still holds values -- clear it here
+        if eng._clear_for is None or eng._clear_for != eng._attached:
+            eng.gflat.zero_()
         acc = _zero_pair(self.dev)
         pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
         fast = self.fast

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 9
+#define EEGCLIP_ABI_VERSION 10
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -93,8 +93,10 @@ typedef struct {
 } eegclip_gemm_desc;
 
 /* fp32 matrices -> bf16 planes hi = bf16(x), lo = bf16(x - hi), [rows][ld_out] with zeros beyond the source columns; transpose != 0: the planes
- * of the transposed matrix ([cols][ld_out]).  Up to 24 matrices per launch: every Linear weight of the encoder, both orientations (W for
- * Y = X W^T, W^T for dX = dY W), once per step. */
+ * of the transposed matrix ([cols][ld_out]).  transpose = 2: the transposed planes WITHOUT the zero fill beyond the source rows (rows % 4 == 0, ld_out % 4 == 0,
+ * 8-byte aligned planes: the output may be a column block of a wider matrix) by a kernel path that needs no LDS and ~20 registers, so that it can run beside
+ * a kernel that owns the CUs' LDS (the projection head's weights and the loss targets at the start of a step).  Up to 24 matrices per launch: every Linear
+ * weight of the encoder, both orientations (W for Y = X W^T, W^T for dX = dY W), once per step. */
 typedef struct {
     const float* src;
     void* hi;
@@ -382,6 +384,8 @@ typedef struct {
     long long ldg;
     const float* part_k;  /* eegclip_infonce_fused_grad_finalize only: `part` / `diag` of the SWAPPED block (its rows are this block's keys) */
     const float* diag_k;
+    void *G_hi, *G_lo;    /* grad out, optional: G again as bf16 hi | lo planes (leading dimension ldg; 8-byte aligned) -- the A operand of the query-gradient
+                             plane GEMM dQ = G K (eegclip_head_gemm); G itself may then be NULL */
 } eegclip_infonce_problem;
 int eegclip_split_bf16(const float* x, void* hi, void* lo, long long n, void* stream);
 int eegclip_infonce_fused_supported(int n, int N, int D);
@@ -566,9 +570,71 @@ typedef struct {
 } eegclip_gemm_planes_desc;
 int eegclip_gemm_planes(const eegclip_gemm_planes_desc* d, void* stream);
 
-/* matrices (rows, cols; multiples of 64) -> the bf16 hi | lo planes of their transposes ([cols][ld_out]; the `transpose` field is ignored): the weights a
- * dX plane GEMM contracts over the output index, up to 24 per launch (tiled through LDS -- eegclip_split_rows' transposing path is for small matrices) */
+/* matrices (rows a multiple of 64, cols a multiple of 4) -> the bf16 hi | lo planes of their transposes ([cols][ld_out]; the `transpose` field is ignored):
+ * the weights a dX plane GEMM contracts over the output index, up to 24 per launch (tiled through LDS -- eegclip_split_rows' transposing path is for small
+ * matrices) */
 int eegclip_split_transpose(const eegclip_split_item* items, int n, void* stream);
+
+/* ---- the projection head's GEMMs at M = the batch (csrc/head_gemm.hip; Retrieval/ATMS_retrieval.py:157-167 forward, its input gradients, and the query
+ * gradient of the loss, models/loss.py:122-140): C[m][n] = sum_k A[m][k] B[n][k] from k-contiguous bf16 hi | lo planes like eegclip_gemm_planes, but
+ * K-PARALLEL across workgroups without atomics or in-launch hand-offs: with slices > 1 workgroup (64 x 64 tile, slice s) stores its partial tile into
+ * C + s * slab_stride (row stride ldc) and the launch that CONSUMES the result adds the slabs in slice order (eegclip_head_act, eegclip_head_act_bwd,
+ * eegclip_residual_layernorm_fwd_slabs, eegclip_layernorm_bwd_slabs, eegclip_proj1x1_bwd_slabs) -- no epilogue field may be set then.  slices = 1: the
+ * launch runs the epilogue itself, in this order: v += bias[n]; Cpre[m][n] = v; act: EEGCLIP_ACT_GELU v = gelu(v) | EEGCLIP_ACT_GELU_GRAD
+ * v *= gelu'(aux[m][n]); v += R[m][n] (R may be C); C[m][n] = v; p_hi / p_lo: v again as planes.  Any M >= 1, N a multiple of 4, K a multiple of 32 with at
+ * least one 32-k tile per slice (<= 16 slices); lda / ldb multiples of 8, fp32 strides multiples of 4, 16-byte aligned bases.
+ * eegclip_head_gemm_slices = the slice count that fills the chip for a shape. */
+typedef struct {
+    const void *a_hi, *a_lo, *b_hi, *b_lo;
+    long long lda, ldb;
+    int M, N, K, slices;
+    long long slab_stride;
+    const float* bias;
+    float* Cpre;
+    long long ldcpre;
+    int act;
+    const float* aux;
+    long long ldaux;
+    const float* R;
+    long long ldr;
+    float* C;
+    long long ldc;
+    void *p_hi, *p_lo;
+    long long ldp;
+    int b_kmajor;          /* 0: B (N, K) planes, k contiguous, rows ldb >= K apart.  1: B given as B[k][n] planes (K rows of N, n contiguous, rows ldb >= N apart,
+                              N % 8 == 0): the operand of an input-gradient GEMM dX = dY W is the forward's weight planes as they are, no transposed copy */
+} eegclip_head_gemm_desc;
+int eegclip_head_gemm_slices(int M, int N, int K);
+int eegclip_head_gemm(const eegclip_head_gemm_desc* d, void* stream);
+/* the launches that CONSUME a K-parallel eegclip_head_gemm result add its partial slabs while they load it (value = sum_{s < nslabs} p[s * slab_stride + i],
+ * slice order; nslabs = 1: a plain operand), so the K split costs no launch of its own:
+ *   eegclip_head_act            u = slabs + bias; pre = u; out = gelu(u); out_hi | out_lo = out again as bf16 planes (M x N contiguous, N % 4 == 0; any output
+ *                               may be NULL)                                                     Proj_eeg's Linear -> GELU, ATMS_retrieval.py:160-162
+ *   eegclip_head_act_bwd        dx = base + slabs * gelu'(pre) (base may be NULL or dx itself), dx_hi | dx_lo = dx as planes; n % 4 == 0
+ *   eegclip_residual_layernorm_fwd_slabs    eegclip_residual_layernorm_fwd_planes (planes optional) with x = slabs + x_bias[col]
+ *   eegclip_layernorm_bwd_slabs             input-gradient half of eegclip_layernorm_bwd with dy = slabs; dx_drop also as planes dd_hi | dd_lo (optional);
+ *                                           dy_sum (optional): the summed dy for the parameter-gradient half, a launch of its own
+ *   eegclip_proj1x1_bwd_slabs               eegclip_proj1x1_bwd with dfeat = slabs
+ *   eegclip_proj1x1_fwd_rows_planes         eegclip_proj1x1_fwd_rows that also leaves feat as bf16 planes (the head's first A operand); rows == NULL: mean / rstd
+ *                                           are inputs (eval mode, or statistics finalised by an earlier launch) */
+int eegclip_head_act(const float* slabs, int nslabs, long long slab_stride, const float* bias, float* pre, float* out, void* out_hi, void* out_lo, int M, int N,
+                     void* stream);
+int eegclip_head_act_bwd(const float* slabs, int nslabs, long long slab_stride, const float* pre, const float* base, float* dx, void* dx_hi, void* dx_lo,
+                         long long n, void* stream);
+int eegclip_residual_layernorm_fwd_slabs(const float* x, const float* resid, float* x_out, float drop_p, unsigned long long seed, unsigned int site,
+                                         const float* gamma, const float* beta, float* y, float* mean, float* rstd, const float* gamma2, const float* beta2,
+                                         float* y2, float* mean2, float* rstd2, int rows, int cols, float eps, void* y_hi, void* y_lo, int nslabs,
+                                         long long slab_stride, const float* x_bias, void* stream);
+int eegclip_layernorm_bwd_slabs(const float* dy, int nslabs, long long slab_stride, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, int rows, int cols, float* dx_drop, void* dd_hi, void* dd_lo, float* dy_sum, float drop_p, unsigned long long seed,
+                                unsigned int site, void* stream);
+int eegclip_proj1x1_bwd_slabs(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace,
+                              int B, float drop_p, unsigned long long seed, unsigned int site, void* stream);
+int eegclip_proj1x1_fwd_rows_planes(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
+                                    const float* W, const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed,
+                                    unsigned int site, void* feat_hi, void* feat_lo, void* stream);
 /* stage tail of the diffusion prior with plane outputs (csrc/prior.hip; Generation/diffusion_prior.py:173-175,186-199):
  *   forward   y_ln = LayerNorm(x), y_act = dropout(SiLU(y_ln)) (+ skip), mean / rstd saved; act_hi / act_lo: y_act again as bf16 planes (or NULL)
  *   backward  d = dropout'(dact) * silu'(y_ln); dx = LayerNorm'(d) as fp32 (dx, or NULL) and / or bf16 planes (dx_hi / dx_lo, or NULL);

@@ -58,6 +58,64 @@ def test_train_step_at_batch_256_matches_the_oracle():
         np.testing.assert_allclose(sd[k].cpu().numpy(), tr2.P[k].numpy(), atol=2e-5, err_msg=k)
 
 
+def test_step_plan_at_batch_256_matches_the_oracle_step_by_step():
+    """the path bench.py times.  Five retrieval.contrastive_step calls at B = 256 (dropout off): steps 1 - 3 are the ordinary warm-up, steps 4 - 5 run
+    as ONE eegclip_plan_run each (step_plan.StepPlan).  EVERY step is held against oracle.OracleTrainer.step at the single-step tolerances of
+    test_train_step_at_batch_256_matches_the_oracle: before each step the oracle takes over the model's current state (parameters, BatchNorm buffers, AdamW
+    moments and step count), so that what is compared is that step's own arithmetic -- loss, embeddings, running accuracy, post-AdamW parameters, BatchNorm
+    running statistics -- not five steps of AdamW-amplified round-off."""
+    from eeg_image_decode_amd import optim, retrieval, step_plan
+    from oracle import loss as oloss
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B, NC, steps = 256, 200, 5
+    cls = T(syn.unit_features(SEED + 4, NC, tag="c"))
+    rng = np.random.default_rng(1)
+    data = [(T(syn.eeg_batch(SEED + 100 + i, B)), T(syn.unit_features(SEED + 200 + i, B, tag="i")), T(syn.unit_features(SEED + 300 + i, B, tag="t")),
+             T(rng.integers(0, NC, size=B).astype(np.int64))) for i in range(steps)]
+    m = make_model(state_np)
+    zero_dropout(m)
+    m.train()
+    opt = optim.AdamW(m.parameters(), lr=3e-4)
+    tr = oloops.OracleTrainer(oloops.torch_state(state_np), p_scale=0.0)
+    names = [k for k, _ in m.named_parameters()]
+    acc, correct = [], torch.zeros(1, dtype=torch.int32, device="cuda")
+    cg = cls.cuda()
+    for i, (x, img, txt, lab) in enumerate(data):
+        # the oracle starts this step from the model's state
+        sd = m.state_dict()
+        for k in tr.P:
+            tr.P[k] = sd[k].detach().cpu().clone()
+        st = opt.state_dict()["state"]
+        tr.t = i
+        for idx, k in enumerate(names):
+            if idx in st:
+                assert int(st[idx]["step"]) == i
+                tr.m[k], tr.v[k] = st[idx]["exp_avg"].cpu().numpy().copy(), st[idx]["exp_avg_sq"].cpu().numpy().copy()
+        before = int(correct)
+        z = retrieval.contrastive_step(m, opt, x.cuda(), 1, img.cuda(), txt.cuda(), lab.cuda(), cg, acc, correct)
+        on_plan = bool(retrieval.step_plans_of(m))
+        assert on_plan == (i >= step_plan.StepPlan.WARM_STEPS), (i, on_plan)          # (an invalidated plan would have been dropped from the table)
+        scale_before = tr.P["logit_scale"].clone()
+        lo, zo = tr.step(x, torch.full((B,), 1).long(), img, txt)
+        np.testing.assert_allclose(z.cpu().numpy(), zo.numpy(), atol=1e-4, err_msg=f"embeddings, step {i}")
+        assert abs(float(acc[-1]) - float(lo)) < 1e-4, (i, float(acc[-1]), float(lo))
+        want = int((oloss.train_accuracy_predictions(zo, cls, scale_before) == lab).sum())
+        assert abs(int(correct) - before - want) <= 1, (i, int(correct) - before, want)         # (one near-tie may rank the other way)
+        for k, p in m.named_parameters():
+            if p.grad is None and k not in tr.m:
+                continue
+            if k in oloops.ZERO_GRAD_KEYS:
+                continue
+            d = np.abs(p.detach().cpu().numpy() - tr.P[k].numpy())        # an element whose gradient is round-off-sized may move by up to ~lr either way
+            assert d.mean() < 6e-6 and d.max() <= 6.1e-4, (i, k, float(d.mean()), float(d.max()))
+        sd = m.state_dict()
+        for k in ("enc_eeg.0.tsconv.2.running_mean", "enc_eeg.0.tsconv.2.running_var", "enc_eeg.0.tsconv.5.running_mean", "enc_eeg.0.tsconv.5.running_var"):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), tr.P[k].numpy(), atol=2e-5, err_msg=f"{k}, step {i}")
+        assert int(sd["enc_eeg.0.tsconv.2.num_batches_tracked"]) == i + 1
+    assert all(p.grad is None for p in m.parameters()) and float(m._engine().gflat.abs().max()) == 0.0
+    assert opt.state_dict()["state"][0]["step"] == steps
+
+
 def test_train_step_at_batch_256_with_real_dropout_matches_the_oracle_under_the_same_philox_masks():
     state_np = syn.make_state(SEED, oatms.state_spec())
     B = 256
@@ -319,16 +377,17 @@ def test_kernel_timestamp_timing_of_one_launch():
     e0, e1 = L.eegclip_timing_event_create(), L.eegclip_timing_event_create()
     assert e0 and e1
     assert L.eegclip_time_next_launch(e0, None) < 0                 # both or neither
-    assert L.eegclip_time_next_launch(e0, e1) == 0
-    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0
+    torch.cuda.synchronize()
     b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    assert L.eegclip_time_next_launch(e0, e1) == 0
     b0.record()
-    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0            # not armed: an ordinary launch
+    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0            # the stamped launch ITSELF inside an event bracket
     b1.record()
+    assert L.eegclip_gemm_f32(ctypes.byref(d), st) == 0            # not armed: an ordinary launch (must leave e0 / e1 alone)
     torch.cuda.synchronize()
     ms = float(L.eegclip_timing_elapsed_ms(e0, e1))
     assert 0.003 < ms < 0.2, ms                                     # ~17 us for this shape
-    # (the bracket is around the NEXT launch of the same shape, not the stamped one: two launches differ by a few microseconds run to run)
-    assert ms <= 1.5 * b0.elapsed_time(b1) + 0.005
+    # the kernel's own begin .. end lies INSIDE the bracket around the same launch (the bracket adds marker packets and dispatch gaps, never removes time)
+    assert ms <= b0.elapsed_time(b1) + 0.0005, (ms, b0.elapsed_time(b1))
     np.testing.assert_allclose(c[:4].cpu().numpy(), (a[:4].double() @ w.double().T).cpu().numpy(), atol=2e-3)
     assert L.eegclip_timing_event_destroy(e0) == 0 and L.eegclip_timing_event_destroy(e1) == 0

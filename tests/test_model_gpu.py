@@ -554,7 +554,7 @@ def test_single_submission_step_plan_trains_like_the_launch_by_launch_loop(state
         opt = optim.AdamW(m.parameters(), lr=3e-4)
         acc, correct = [], torch.zeros(1, dtype=torch.int32, device="cuda")
         feats = [retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct) for x, img, txt, lab in data]
-        plans = [st["plan"] for st in getattr(m._engine(), "_step_plans", {}).values()]
+        plans = retrieval.step_plans_of(m)
         assert (len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)) == (mode == "1")
         assert all(p.grad is None for p in m.parameters())
         runs.append(([float(l) for l in acc], int(correct), feats[3].cpu().numpy(), {k: p.detach().cpu().numpy() for k, p in m.named_parameters()},

@@ -856,11 +856,11 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch):
         acc, correct = [], torch.zeros(1, dtype=torch.int32)
         for x, img, txt, lab in data[:2]:
             retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct)
-        assert not any(st["plan"] for st in m._engine()._step_plans.values())           # warm-up: the ordinary path
+        assert not retrieval.step_plans_of(m)           # warm-up: the ordinary path
         snap = (copy.deepcopy(m.state_dict()), copy.deepcopy(opt.state_dict()), torch.get_rng_state(), correct.clone())
         x, img, txt, lab = data[2]
         f_plan = retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct)
-        plans = [st["plan"] for st in m._engine()._step_plans.values()]
+        plans = retrieval.step_plans_of(m)
         assert len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)             # the third step went through the plan ...
         names = plans[0].pl.op_names()
         assert names.count("eegclip_adamw_step_zero_grad") >= 1 and "eegclip_infonce_fused_fwd" in names and names[-1].startswith("eegclip_adamw")
@@ -876,7 +876,7 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch):
         torch.set_rng_state(snap[2])
         acc2, correct2 = [], snap[3].clone()
         f_ord = retrieval.contrastive_step(m2, opt2, x, 1, img, txt, lab, cls, acc2, correct2)
-        assert not getattr(m2._engine(), "_step_plans", {})
+        assert not retrieval.step_plans_of(m2)
     np.testing.assert_allclose(res_plan[3].numpy(), f_ord.numpy(), atol=2e-5)            # (the head's split-K atomics: unordered under the multi-threaded emulator)
     assert abs(res_plan[1] - float(acc2[-1])) < 1e-5 * abs(res_plan[1]) and res_plan[2] == int(correct2)
     for k, v in res_plan[4].items():
@@ -886,6 +886,47 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch):
             continue
         d = np.abs(res_plan[0][k].numpy() - p.detach().numpy())
         assert d.max() <= 3e-4 * 1.01 and (d > 2e-5).mean() <= 2e-3, (k, float(d.max()), float((d > 2e-5).mean()))
+
+
+def test_step_plan_after_a_keep_grads_step_does_not_accumulate_onto_stale_gradients(monkeypatch):
+    """contrastive_step(keep_grads=True) -- documented for gradient-norm logging -- leaves the gradients in the flat buffer; the next call's
+    zero_grad(set_to_none=True) drops the .grad views but not the values.  A plan step accumulates into that buffer without attach_grads(): it must clear it
+    first.  Sequence: 2 warm steps, 1 plan step, 1 keep_grads step (ordinary path), 1 plan step -- against the same five steps with EEGCLIP_STEP_PLAN=0."""
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    B, NC = 64, 40
+    cls = T(syn.unit_features(SEED + 4, NC, tag="c"))
+    rng = np.random.default_rng(2)
+    data = [(T(syn.eeg_batch(SEED + 400 + i, B)), T(syn.unit_features(SEED + 500 + i, B, tag="i")), T(syn.unit_features(SEED + 600 + i, B, tag="t")),
+             T(rng.integers(0, NC, size=B).astype(np.int64))) for i in range(5)]
+    keep = (False, False, False, True, False)
+    runs = []
+    with product_on_emulator():
+        from eeg_image_decode_amd import optim, retrieval, step_plan
+        monkeypatch.setattr(step_plan, "_runtime_ok", lambda: True)
+        monkeypatch.setattr(step_plan, "_on_device", lambda t: True)
+        monkeypatch.setattr(step_plan.StepPlan, "WARM_STEPS", 2)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("EEGCLIP_STEP_PLAN", mode)
+            torch.manual_seed(5)
+            m = make_model(state_np).train()
+            opt = optim.AdamW(m.parameters(), lr=3e-4)
+            acc, correct = [], torch.zeros(1, dtype=torch.int32)
+            seen = []
+            for (x, img, txt, lab), kg in zip(data, keep):
+                retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct, keep_grads=kg)
+                if kg:
+                    assert float(m._engine().gflat.abs().max()) > 0.0 and m.proj_eeg[0].weight.grad is not None      # the gradients were kept
+                seen.append(bool(retrieval.step_plans_of(m)))
+            if mode == "1":
+                assert seen == [False, False, True, True, True]
+                assert float(m._engine().gflat.abs().max()) == 0.0              # the last plan step ended with the fused clear
+            runs.append(([float(a) for a in acc], {k: p.detach().clone() for k, p in m.named_parameters()}))
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-5)
+    for k, p in runs[1][1].items():
+        if k.endswith("key_projection.bias"):
+            continue
+        d = np.abs(runs[0][1][k].numpy() - p.numpy())
+        assert d.max() <= 5 * 3e-4 * 1.01 and (d > 5e-5).mean() <= 5e-3, (k, float(d.max()), float((d > 5e-5).mean()))      # stale gradients would move everything by ~lr
 
 
 def test_joint_subject_model_with_more_subjects_than_one_weight_gradient_launch_holds():

@@ -30,7 +30,7 @@ with product_on_emulator():
     snap = (copy.deepcopy(m.state_dict()), copy.deepcopy(opt.state_dict()), torch.get_rng_state(), correct.clone())
     for x, img, txt, lab in data[2:]:
         retrieval.contrastive_step(m, opt, x, 1, img, txt, lab, cls, acc, correct)
-    assert any(st["plan"] for st in m._engine()._step_plans.values()), "the plan did not engage"
+    assert retrieval.step_plans_of(m), "the plan did not engage"
     res = ({k: v.clone() for k, v in m.state_dict().items()}, [float(a) for a in acc[2:]], int(correct))
     os.environ["EEGCLIP_STEP_PLAN"] = "0"
     m2 = ATMS().train()
