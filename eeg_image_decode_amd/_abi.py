@@ -101,7 +101,7 @@ class WgradPlanesProblem(C.Structure):
                 ("rows", C.c_int), ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("slices", C.c_int)]
 
 
-PLAN_MAX_ARGS = 24
+PLAN_MAX_ARGS = 28
 PLAN_MEMSET, PLAN_JOIN, PLAN_SIDE, PLAN_SKIP, PLAN_SIDE2 = -2, -3, 1, 2, 4
 
 
@@ -215,7 +215,10 @@ PROTOTYPES = {
     "eegclip_residual_layernorm_fwd_slabs": [_P, _P, _P, _F, _U64, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _L, _P, _P],
     "eegclip_layernorm_bwd_slabs": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _U64, _U, _P],
     "eegclip_proj1x1_bwd_slabs": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
-    "eegclip_proj1x1_fwd_rows_planes": [_P, _P, _I, _D, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P, _P, _P],
+    "eegclip_proj1x1_fwd_rows_planes": [_P, _P, _I, _D, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P, _P, C.POINTER(SplitItem), _I, _P],
+    "eegclip_proj1x1_bwd_rows": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U64, _U, _P],
+    "eegclip_proj1x1_bwd_reduce": [_P, _I, _P, _P, _P, _P],
+    "eegclip_bn_elu_bwd_apply_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _D, _P, _P, _P, _I, _I, _I, _F, _U64, _U, _P],
     "eegclip_prior_stage_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U, _P],
     "eegclip_prior_stage_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U, _P, _P],
     "eegclip_prior_stage_bwd_workspace_floats": [_I, _I],

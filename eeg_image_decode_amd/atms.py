@@ -446,26 +446,28 @@ class _Engine:
         plans; EEGCLIP_HEAD_GEMM=0 pins round 5's split-K gemm_x3 launches (diagnosis, A/B timing); exact-fp32 plans always use those"""
         return pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_HEAD_GEMM", "1") != "0"
 
-    def _head_weight_planes(self, pl):
-        """bf16 hi | lo planes of this step's projection-head weights: the span [W1 | b1 | W2] as it lies in the flat parameter buffer by ONE vectorised
-        split.  The forward GEMMs read them as B (N, K) operands (k contiguous); the input-gradient GEMMs, which contract over the OUTPUT index, read the
-        SAME planes as k-major operands (csrc/head_gemm.hip b_kmajor: fragments through the LDS transpose read) -- no transposed copy.  Second stream, at the
-        very start of the forward plan: nothing reads them before the conv stack has run, and the launch (no LDS, 24 registers) runs beside the fused
-        transformer-block forward."""
+    def _head_weight_planes(self):
+        """bf16 hi | lo planes of this step's projection-head weights: the span [W1 | b1 | W2] as it lies in the flat parameter buffer, ONE dense split.  The
+        forward GEMMs read them as B (N, K) operands (k contiguous); the input-gradient GEMMs, which contract over the OUTPUT index, read the SAME planes as
+        k-major operands (csrc/head_gemm.hip b_kmajor: fragments through the LDS transpose read) -- no transposed copy.  Returns the split item: it RIDES in
+        the 1x1-conv launch in front of the head (csrc/split_rider.h: extra workgroups of a launch that leaves the memory system idle), so that the split
+        costs no launch, no second stream and no join."""
         P = self.P
         w1, w2 = P["proj_eeg.0.weight"], P["proj_eeg.1.fn.1.weight"]
         span = (w2.data_ptr() - w1.data_ptr()) // 4 + w2.numel()
         assert w2.data_ptr() > w1.data_ptr() and span % 8 == 0 and span < 4 * w1.numel(), "projection-head weights are not adjacent in the flat buffer"
         if not hasattr(self, "hw_planes"):
             self.hw_planes = torch.empty(2, span, dtype=torch.bfloat16, device=self.device)
-        side = os.environ.get("EEGCLIP_START_SIDE", "1") != "0"
-        items = (_abi.SplitItem * 1)(_abi.SplitItem(src=_p(w1), hi=_p(self.hw_planes[0]), lo=_p(self.hw_planes[1]), rows=1, cols=span, ld_src=span, ld_out=span,
-                                                    transpose=0))
-        pl._keep.append(items)
-        pl.call("eegclip_split_rows", items, 1, side=side)
         o2 = (w2.data_ptr() - w1.data_ptr()) // 4
         # (hi, lo) of W1 (1024, 1440) and W2 (1024, 1024)
         self.hw = dict(w1=(_p(self.hw_planes[0]), _p(self.hw_planes[1])), w2=(_p(self.hw_planes[0]) + 2 * o2, _p(self.hw_planes[1]) + 2 * o2))
+        return _abi.SplitItem(src=_p(w1), hi=_p(self.hw_planes[0]), lo=_p(self.hw_planes[1]), rows=1, cols=span, ld_src=span, ld_out=span, transpose=0)
+
+    def _lean(self, pl, train, W):
+        """the default single-process training plans (conv stack recomputed from the token rows + the head on plane GEMMs) touch NO accumulator that must be
+        cleared beforehand: BatchNorm statistics travel as per-sample partial rows, K splits as slabs -- no arena memset, hence no second-stream work and no
+        join at the start of the step"""
+        return bool(train and W == 1 and self._cstack_enabled(pl) and self._head_planes_enabled(pl))
 
     def _head_gemm(self, pl, b, tag, a_planes, K, w, N, B, kmajor=False):
         """one K-parallel head GEMM: (B, K) planes x the weight planes `w` -- (N, K), k contiguous, or with kmajor (K, N), n contiguous -> partial slabs
@@ -580,15 +582,15 @@ class _Engine:
         pl.tb_desc = None
         cstack = self._cstack_enabled(pl)
         head_planes = self._head_planes_enabled(pl)
-        if head_planes and not cstack:
-            self._head_weight_planes(pl)
+        W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
+        lean = self._lean(pl, train, W)
+        pl.lean = lean
         if cstack:
-            # nothing before the conv stack needs them: the arena clear and the conv stack's weight fragments go to the second stream, under the
-            # transformer block; the main stream joins in front of the conv stack
-            pl.memset(b["zfb"] if train else b["zf"], side=os.environ.get("EEGCLIP_START_SIDE", "1") != "0")
-            pl.clears_zb = train
-            if head_planes:
-                self._head_weight_planes(pl)                # (second stream too: consecutive second-stream ops share one fork)
+            # nothing before the conv stack needs it: the arena clear goes to the second stream, under the transformer block; the main stream joins in front of
+            # the conv stack.  (The lean plans have nothing to clear.)
+            if not lean:
+                pl.memset(b["zfb"] if train else b["zf"], side=os.environ.get("EEGCLIP_START_SIDE", "1") != "0")
+                pl.clears_zb = train
             if not hasattr(self, "cs_packed"):
                 self.cs_packed = torch.empty(int(lib().eegclip_cstack_packed_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
                 self.cs_packed_t = torch.empty(int(lib().eegclip_cstack_packed_t_bytes(N_CH)) // 2, dtype=torch.bfloat16, device=self.device)
@@ -677,10 +679,10 @@ class _Engine:
                     _p(P["encoder.encoder.norm.bias"]), _p(b["n3"]), _p(b["mu3"]), _p(b["rs3"]), R, D_MODEL, EPS, seed_at=4)
         # A4+A5: tokens 0..62 -> box filter + 25-tap stride-5 conv (= conv + avg-pool) -> BN -> ELU      (ATMS_retrieval.py:91,102-105)
         sums, bn = b["sums"], b["bn"]
-        W = self._world() if train else 1          # data-parallel SyncBN: batch statistics over the GLOBAL batch
         bn2_rows = None
         if cstack:
-            pl.join()
+            if not lean:
+                pl.join()
             bn2_rows = self._build_fwd_cstack(pl, b, B, train, W)
         else:
             pl.memset(b["zfb"] if train else b["zf"])
@@ -692,13 +694,20 @@ class _Engine:
             # (round 6) ... and feat again as bf16 hi | lo planes: the A operand of the head's first Linear.  With per-sample BatchNorm2 partial rows the
             # finalize rides in this kernel's prologue; otherwise mean / rstd are inputs
             if "featp" not in b:
-                b["featp"] = torch.empty(2, B, F_TS, dtype=torch.bfloat16, device=self.device)
+                # (+ 128 elements of slack: eegclip_wgrad_planes reads whole 128-channel tiles -- up to channel 1535 of the LAST row of the lo plane)
+                b["featp_buf"] = torch.zeros(2 * B * F_TS + 128, dtype=torch.bfloat16, device=self.device)
+                b["featp"] = b["featp_buf"][:2 * B * F_TS].view(2, B, F_TS)
                 b["gup"] = torch.empty(2, B, P_DIM, dtype=torch.bfloat16, device=self.device)
             rows_args = (_p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]), *run2) if bn2_rows is not None else \
                 (None, 0, 1.0, EPS, 0.1, _p(bn[2]), _p(bn[3]), None, None, None)
+            # riders (arguments 23 / 24): the head weights' plane split by extra workgroups of this launch; the step plan adds the loss targets
+            pl.rider_items = (_abi.SplitItem * 4)()
+            pl.rider_items[0] = self._head_weight_planes()
+            pl._keep.append(pl.rider_items)
+            pl.rider_op = len(pl.ops)
             pl.call("eegclip_proj1x1_fwd_rows_planes", _p(b["y2"]), *rows_args, _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
                     _p(P["enc_eeg.0.projection.0.weight"]), _p(P["enc_eeg.0.projection.0.bias"]), _p(b["z2"]), _p(b["feat"]), B, pc_, 0, SITE_CONV,
-                    _p(b["featp"][0]), _p(b["featp"][1]), seed_at=19)
+                    _p(b["featp"][0]), _p(b["featp"][1]), pl.rider_items, 1, seed_at=19)
         elif bn2_rows is not None:
             # (the BatchNorm2 finalize rides in this kernel's prologue: the batch statistics as the per-sample partial rows eegclip_cstack_fwd left)
             pl.call("eegclip_proj1x1_fwd_rows", _p(b["y2"]), _p(bn2_rows), B, float(B * W_TS), EPS, 0.1, _p(bn[2]), _p(bn[3]), *run2,
@@ -713,8 +722,6 @@ class _Engine:
             # A6: projection head      (:157-167) on the K-parallel plane GEMM (csrc/head_gemm.hip, round 6): M = B is small, so K is split over workgroups --
             # each slice leaves its partial tile as a slab and the launch that consumes the result anyway adds the slabs while it loads them:
             # bias + GELU (+ the planes of gelu(u) for the second Linear) after the first, dropout + residual + LayerNorm after the second
-            if not cstack:
-                pl.join()                                   # (the weight planes came from the second stream)
             fp, gp = (_p(b["featp"][0]), _p(b["featp"][1])), (_p(b["gup"][0]), _p(b["gup"][1]))
             sl1 = self._head_gemm(pl, b, "hslab1", fp, F_TS, self.hw["w1"], P_DIM, B)
             pl.call("eegclip_head_act", *sl1, _p(P["proj_eeg.0.bias"]), _p(b["u"]), _p(b["gu"]), *gp, B, P_DIM)
@@ -880,15 +887,44 @@ class _Engine:
             vp, up = (_p(b["dvp"][0]), _p(b["dvp"][1])), (_p(b["dup"][0]), _p(b["dup"][1]))
             pl.call("eegclip_layernorm_bwd_slabs", 0, 1, 0, _p(b["s"]), _p(P["proj_eeg.2.weight"]), _p(b["mu4"]), _p(b["rs4"]), _p(b["ds"]), B, P_DIM,
                     _p(b["dv"]), *vp, None, pp_, 0, SITE_PROJ, seed_at=15)
-            pl.dout_par_op = len(pl.ops)
-            pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
-                    _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
-            wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias")
+            # the head's second-stream launches (LayerNorm parameter half, the two weight gradients: operands dv | gu and du | feat stay untouched until the
+            # optimizer) are emitted TOGETHER in front of the conv stack's backward, next to its own second-stream launch: ONE fork instead of three -- every
+            # fork idles the main queue for ~7 us (tools/step_timeline.py).  EEGCLIP_HEAD_FORKS=3: each as soon as its operands exist (A/B aid)
+            one_fork = os.environ.get("EEGCLIP_HEAD_FORKS", "1") == "1"
+            head_side_ops = []
+
+            def later(fn):
+                if one_fork:
+                    head_side_ops.append(fn)
+                else:
+                    fn()
+
+            def ln_params():
+                pl.dout_par_op = len(pl.ops)
+                pl.call("eegclip_layernorm_bwd", 0, _p(b["s"]), None, _p(b["mu4"]), _p(b["rs4"]), None,
+                        _p(G["proj_eeg.2.weight"]), _p(G["proj_eeg.2.bias"]), B, P_DIM, 0, None, 0.0, 0, 0, side=ln_side)
+            later(ln_params)
+            # both weight gradients of the head from the planes that exist anyway (dv | gelu(u), du | feat: every operand row-major, contraction over the batch
+            # rows) in ONE eegclip_wgrad_planes launch -- the fp32-operand GEMMs (k-strided operands) took 30 + 37 us alone and far longer beside the backward
+            wplanes = B % 32 == 0 and os.environ.get("EEGCLIP_HEAD_WGRAD_PLANES", "1") != "0"
+            if not wplanes:
+                later(lambda: wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias"))
             sl = self._head_gemm(pl, b, "dgu_slabs", vp, P_DIM, self.hw["w2"], P_DIM, B, kmajor=True)
             pl.call("eegclip_head_act_bwd", *sl, _p(b["u"]), _p(b["ds"]), _p(b["ds"]), *up, B * P_DIM)          # ds := du = ds + dgu * gelu'(u)
-            wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias")
+            if wplanes:
+                gp_, fp_ = (_p(b["gup"][0]), _p(b["gup"][1])), (_p(b["featp"][0]), _p(b["featp"][1]))
+                probs = (_abi.WgradPlanesProblem * 2)(
+                    _abi.WgradPlanesProblem(a_hi=vp[0], a_lo=vp[1], lda=P_DIM, b_hi=gp_[0], b_lo=gp_[1], ldb=P_DIM, rows=B, M=P_DIM, N=P_DIM,
+                                            out=_p(G["proj_eeg.1.fn.1.weight"]), ldo=P_DIM, bias_out=_p(G["proj_eeg.1.fn.1.bias"]), slices=1),
+                    _abi.WgradPlanesProblem(a_hi=up[0], a_lo=up[1], lda=P_DIM, b_hi=fp_[0], b_lo=fp_[1], ldb=F_TS, rows=B, M=P_DIM, N=F_TS,
+                                            out=_p(G["proj_eeg.0.weight"]), ldo=F_TS, bias_out=_p(G["proj_eeg.0.bias"]), slices=1))
+                pl._keep.append(probs)
+                later(lambda: pl.call("eegclip_wgrad_planes", probs, 2, side=head_side))
+            else:
+                later(lambda: wgrad("proj_eeg.0.weight", _p(b["ds"]), P_DIM, _p(b["feat"]), F_TS, P_DIM, F_TS, B, bias="proj_eeg.0.bias"))
             dfeat_slabs = self._head_gemm(pl, b, "dfeat_slabs", up, P_DIM, self.hw["w1"], F_TS, B, kmajor=True)
         else:
+            head_side_ops = []
             self._build_bwd_head_f32(pl, b, B, pp_, ln_side, wgrad)
         # 1x1 conv backward + BatchNorm2 / ELU / dropout backward statistics in one launch (dW, dbias, dz2, sums[2]); then -- after the SyncBN
         # all-reduce of the sums under torch.distributed -- the apply pass.  dgamma / dbeta take this rank's LOCAL sums, so the later
@@ -906,28 +942,47 @@ class _Engine:
                 return lambda: G[bias_key].add_((P[gamma_key] * rstd * s[:C_TS].to(torch.float32)))
         if "pj_ws" not in b:
             b["pj_ws"] = torch.empty(int(lib().eegclip_proj1x1_bwd_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
-        if dfeat_slabs is not None:
-            pl.call("eegclip_proj1x1_bwd_slabs", *dfeat_slabs, _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
-                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
-                    _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=17)
+        lean = dfeat_slabs is not None and self._lean(pl, train, W)
+        pl.lean = lean
+        if lean:
+            # (round 6) the 1x1-conv backward leaves one partial row per sample; the BatchNorm2-backward apply pass adds the rows' 80 sums itself (fixed order,
+            # every workgroup the same value): no cleared accumulator, and the reduction of the rows into dW / dbias -- read by the optimizer only -- leaves
+            # the dX chain for the second stream
+            if "pj_bn_rows" not in b:
+                b["pj_bn_rows"] = torch.empty(B, 2 * C_TS, dtype=torch.float64, device=self.device)
+            pl.call("eegclip_proj1x1_bwd_rows", *dfeat_slabs, _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(b["pj_ws"]), _p(b["pj_bn_rows"]), B, pc_, 0, SITE_CONV, seed_at=15)
+            pl.call("eegclip_bn_elu_bwd_apply_rows", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                    _p(b["pj_bn_rows"]), B, 2 * C_TS, 0, float(B * W_TS),
+                    _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS, W_TS, pc_, 0, SITE_CONV, seed_at=18)
+            for f in head_side_ops:
+                f()
+            pl.call("eegclip_proj1x1_bwd_reduce", _p(b["pj_ws"]), B, _p(G["enc_eeg.0.projection.0.weight"]), _p(G["enc_eeg.0.projection.0.bias"]), None, side=True)
         else:
-            pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
-                    _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
-                    _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=15)
-        local2 = None
-        if W > 1:
-            local2 = torch.zeros_like(sums[2])
-            pl._keep.append(local2)
+            if dfeat_slabs is not None:
+                pl.call("eegclip_proj1x1_bwd_slabs", *dfeat_slabs, _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                        _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
+                        _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=17)
+            else:
+                pl.call("eegclip_proj1x1_bwd", _p(b["dfeat"]), _p(b["z2"]), _p(P["enc_eeg.0.projection.0.weight"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]),
+                        _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]), _p(b["dz2"]), _p(G["enc_eeg.0.projection.0.weight"]),
+                        _p(G["enc_eeg.0.projection.0.bias"]), _p(sums[2]), _p(b["pj_ws"]), B, pc_, 0, SITE_CONV, seed_at=15)
+            local2 = None
+            if W > 1:
+                local2 = torch.zeros_like(sums[2])
+                pl._keep.append(local2)
 
-            def exchange2():
-                local2.copy_(sums[2])
-                self._allreduce(sums[2])
-            pl.callback(exchange2, "allreduce_bn2_bwd")
-        if not train:
-            pl.callback(conv_bias_grad(_TS + "4.bias", _TS + "5.weight", bn[3], sums[2]), "conv2_bias_grad_eval")
-        pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
-                _p(sums[2]) if train else _p(zsum), (_p(local2) if local2 is not None else None) if train else _p(sums[2]), float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
-                W_TS, pc_, 0, SITE_CONV, seed_at=16)
+                def exchange2():
+                    local2.copy_(sums[2])
+                    self._allreduce(sums[2])
+                pl.callback(exchange2, "allreduce_bn2_bwd")
+            if not train:
+                pl.callback(conv_bias_grad(_TS + "4.bias", _TS + "5.weight", bn[3], sums[2]), "conv2_bias_grad_eval")
+            pl.call("eegclip_bn_elu_bwd_apply", _p(b["dz2"]), _p(b["y2"]), _p(bn[2]), _p(bn[3]), _p(P[_TS + "5.weight"]), _p(P[_TS + "5.bias"]),
+                    _p(sums[2]) if train else _p(zsum), (_p(local2) if local2 is not None else None) if train else _p(sums[2]), float(W * B * W_TS), _p(b["dy2"]), _p(G[_TS + "5.weight"]), _p(G[_TS + "5.bias"]), B, C_TS,
+                    W_TS, pc_, 0, SITE_CONV, seed_at=16)
+            for f in head_side_ops:
+                f()
         if self._cstack_bwd_enabled(pl):
             self._build_bwd_cstack(pl, b, B, train, W, zsum, conv_bias_grad if not train else None, early_reduce, defer_small)
         else:
@@ -1426,8 +1481,9 @@ class _Engine:
             self._joint_layout(pl, b, B, None, x.data_ptr(), True)
         elif pl.x_gemm is not None:
             pl.x_gemm.B = x.data_ptr()          # the value-embedding weight-gradient GEMM reads the EEG batch
-        if not b["zb_clean"]:                   # an eval-mode forward, or a second backward through one forward: clear the arena here
-            b["zb"].zero_()
-        b["zb_clean"] = False
+        if not getattr(pl, "lean", False):
+            if not b["zb_clean"]:               # an eval-mode forward, or a second backward through one forward: clear the arena here
+                b["zb"].zero_()
+            b["zb_clean"] = False
         pl.run(raw_stream(), b.get("seed", 0))
         return b["dx"].clone() if want_dx else None

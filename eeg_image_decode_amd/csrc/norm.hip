@@ -216,6 +216,131 @@ __global__ __launch_bounds__(256) void residual_layernorm_fwd_kernel(const float
     }
 }
 
+// ---- rows of exactly 1024 columns, FEW of them (the projection head's LayerNorm at M = the batch, ATMS_retrieval.py:166): ONE 256-thread workgroup per row,
+// lane t owns columns 4 t .. 4 t + 3 (one 16-byte access per operand, one Philox block), row sums through one LDS exchange.  The wave-per-row kernels above put
+// 256 rows on 64 workgroups and walk each row in four dependent 256-column groups: 15 us for 1 MB at B = 256 (round 6 trace); this form is 256 workgroups.
+__device__ __forceinline__ void ln_block_sum2(float& a, float& b, float* red) {       // sums of a and b over the 256 threads (4 waves); red: 8 floats of LDS
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();                                             // (red may still be read from the previous exchange)
+    if (lane == 0) { red[w] = a; red[4 + w] = b; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+__global__ __launch_bounds__(256) void head_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ x_out, float drop_p,
+                                                           unsigned long long seed, unsigned site, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, float eps,
+                                                           unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo, const ln_slabs xs) {
+    EEG_LDS_BASE(float, red);
+    constexpr int COLS = 1024;
+    const int row = blockIdx.x, c = 4 * threadIdx.x;
+    const long long i0 = (long long)row * COLS + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i0);
+    for (int sl = 1; sl < xs.n; ++sl) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(x + (long long)sl * xs.stride + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+    }
+    if (xs.bias) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xs.bias + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+    }
+    if (resid) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + i0);
+        if (drop_p > 0.f) {
+            bool keep[4];
+            dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
+            const float ks = 1.0f / (1.0f - drop_p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * ks : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        if (x_out) *reinterpret_cast<f32x4*>(x_out + i0) = v;
+    }
+    float s = (v[0] + v[1]) + (v[2] + v[3]), dummy = 0.f;
+    ln_block_sum2(s, dummy, red);
+    const float mean = s * (1.0f / COLS);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q += (v[e] - mean) * (v[e] - mean);
+    ln_block_sum2(q, dummy, red);
+    const float rstd = rsqrtf(q * (1.0f / COLS) + eps);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c), bv = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * gv[e] + bv[e];
+    *reinterpret_cast<f32x4*>(y + i0) = v;
+    if (y_hi) {
+        u32x2_t hi, lo;
+        x3_split4(v[0], v[1], v[2], v[3], hi, lo);
+        *reinterpret_cast<u32x2_t*>(y_hi + i0) = hi;
+        *reinterpret_cast<u32x2_t*>(y_lo + i0) = lo;
+    }
+    if (threadIdx.x == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+__global__ __launch_bounds__(256) void head_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                                                           int accumulate_dx, float* __restrict__ dx_drop, float drop_p, unsigned long long seed, unsigned site,
+                                                           const ln_slabs dys, unsigned short* __restrict__ dd_hi, unsigned short* __restrict__ dd_lo,
+                                                           float* __restrict__ dy_sum) {
+    EEG_LDS_BASE(float, red);
+    constexpr int COLS = 1024;
+    const int row = blockIdx.x, c = 4 * threadIdx.x;
+    const long long i0 = (long long)row * COLS + c;
+    f32x4 dv = *reinterpret_cast<const f32x4*>(dy + i0);
+    for (int sl = 1; sl < dys.n; ++sl) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(dy + (long long)sl * dys.stride + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[e] += p[e];
+    }
+    if (dy_sum) *reinterpret_cast<f32x4*>(dy_sum + i0) = dv;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i0), gv = *reinterpret_cast<const f32x4*>(gamma + c);
+    const float mu = mean[row], rs = rstd[row];
+    float xh[4], g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = (xv[e] - mu) * rs;
+        g[e] = dv[e] * gv[e];
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+    }
+    ln_block_sum2(s1, s2, red);
+    const float c1 = s1 * (1.0f / COLS), c2 = s2 * (1.0f / COLS);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rs * (g[e] - c1 - xh[e] * c2);
+    if (accumulate_dx) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(dx + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    *reinterpret_cast<f32x4*>(dx + i0) = v;
+    if (dx_drop) {
+        f32x4 dd = v;
+        if (drop_p > 0.f) {
+            bool keep[4];
+            dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
+            const float ks = 1.0f / (1.0f - drop_p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dd[e] = keep[e] ? v[e] * ks : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dx_drop + i0) = dd;
+        if (dd_hi) {
+            u32x2_t hi, lo;
+            x3_split4(dd[0], dd[1], dd[2], dd[3], hi, lo);
+            *reinterpret_cast<u32x2_t*>(dd_hi + i0) = hi;
+            *reinterpret_cast<u32x2_t*>(dd_lo + i0) = lo;
+        }
+    }
+}
+constexpr int HEAD_LN_MAX_ROWS = 4096;          // beyond that the wave-per-row kernels fill the chip on their own
+
 // backward, part 1:  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   [+ dx_drop = dropout'(dx)]
 // One wave per row, one row per wave.  Lane l owns the 4 CONSECUTIVE columns 256 i + 4 l .. + 3 of every 256-column group: 8-byte
 // accesses, and the dropout mask of a lane's 4 elements comes from one Philox block (two when row * cols is not a multiple of 4 --
@@ -680,6 +805,48 @@ __global__ __launch_bounds__(256) void bn_elu_bwd_apply_kernel(const float* __re
     }
 }
 
+// bn_elu_bwd_apply_kernel whose batch sums come as `nrows` fp64 partial rows (`ld` doubles apart, the 2 C sums at column `col0`: what eegclip_proj1x1_bwd_rows
+// leaves per sample).  A workgroup = (channel c, block of 32 samples): it needs only TWO columns of the table -- sum_da[c] and sum_da_xhat[c], one pair of
+// loads per thread and one exchange, the same fixed order in every workgroup of a channel: no atomics, no cleared accumulator, no reduction launch on the dX
+// chain.  (First version: flat elementwise grid, every workgroup summed all 2 C columns -- 1440 workgroups x 164 KB of table reads = 20 us; 128 fat workgroups
+// serialised their element loop instead: 19 us.)  Workgroup (c, 0) adds dgamma[c] / dbeta[c].
+__global__ __launch_bounds__(256) void bn_elu_bwd_apply_rows_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const double* __restrict__ rows, int nrows, long long ld,
+                                                                     int col0, double count, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta, int outer, int C, int inner, float drop_p,
+                                                                     unsigned long long seed, unsigned site) {
+    EEG_LDS_BASE(double, scr);                               // [4][2] wave sums
+    const int t = threadIdx.x, c = blockIdx.x, lane = t & 63, w = t >> 6;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = t; r < nrows; r += 256) {
+        s0 += rows[(long long)r * ld + col0 + c];
+        s1 += rows[(long long)r * ld + col0 + C + c];
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) { scr[2 * w] = s0; scr[2 * w + 1] = s1; }
+    __syncthreads();
+    const double sum_da = (scr[0] + scr[2]) + (scr[4] + scr[6]), sum_dax = (scr[1] + scr[3]) + (scr[5] + scr[7]);
+    if (blockIdx.y == 0 && t == 0) {
+        dgamma[c] += (float)sum_dax;
+        dbeta[c] += (float)sum_da;
+    }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float rs = rstd[c], g = gamma[c], mu = mean[c], be = beta[c];
+    const float m1 = (float)(sum_da / count), m2 = (float)(sum_dax / count);
+    const int b0 = blockIdx.y * 32, nb = outer - b0 < 32 ? outer - b0 : 32;
+    for (int q = t; q < nb * inner; q += 256) {
+        const long long i = ((long long)(b0 + q / inner) * C + c) * inner + q % inner;
+        const float xh = (x[i] - mu) * rs;
+        const float u = g * xh + be;
+        float d = dz[i];
+        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
+        const float da = u > 0.f ? d : d * expf(u);
+        dx[i] = g * rs * (da - m1 - xh * m2);
+    }
+}
+
 static inline int grid_for(long long n, int block, int cap) {
     long long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -710,6 +877,13 @@ static int residual_layernorm_fwd_go(const float* x, const float* resid, float* 
     if ((x_out || drop_p > 0.f) && !resid) return EEGCLIP_EINVAL;
     if (dbl && (!beta2 || !y2)) return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
+    if (cols == 1024 && rows <= HEAD_LN_MAX_ROWS && !dbl && (xs.n <= 1 || !(xs.stride & 3)) &&
+        !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(gamma) |
+           reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(xs.bias)) & 15u)) {
+        EEG_LAUNCH(head_ln_fwd_kernel, dim3(rows), dim3(256), 8 * sizeof(float), stream, x, resid, x_out, drop_p, seed, site, gamma, beta, y, mean, rstd, eps, y_hi,
+                   y_lo, xs);
+        return (int)hipGetLastError();
+    }
     const int grid = grid_for(rows, 4, 8192);
     const bool vec2 = (cols % 2 == 0) &&
                       !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(x_out) |
@@ -758,6 +932,13 @@ extern "C" int eegclip_residual_layernorm_fwd_slabs(const float* x, const float*
                                      static_cast<unsigned short*>(y_hi), static_cast<unsigned short*>(y_lo), stream, ln_slabs{nslabs, slab_stride, x_bias});
 }
 
+static bool head_ln_bwd_applies(const float* dy, const float* x, const float* gamma, const float* dx, const float* dx_drop, const float* dy_sum, int rows, int cols,
+                                int nslabs, long long slab_stride) {
+    return cols == 1024 && rows <= HEAD_LN_MAX_ROWS && (nslabs <= 1 || !(slab_stride & 3)) &&
+           !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx) |
+              reinterpret_cast<uintptr_t>(dx_drop) | reinterpret_cast<uintptr_t>(dy_sum)) & 15u);
+}
+
 // the input-gradient half of eegclip_layernorm_bwd whose upstream gradient dy is the partial slabs of a K-parallel GEMM (dy = sum_{s < nslabs} dy[s * slab_stride + .])
 // and whose second output dx_drop = dropout'(dx) leaves again as bf16 hi | lo planes (dd_hi / dd_lo, or NULL): the A operand of the next plane GEMM; dy_sum
 // (or NULL): the summed dy, for the parameter-gradient half (eegclip_layernorm_bwd with dx == NULL), which runs as a launch of its own off the dX chain
@@ -769,6 +950,11 @@ extern "C" int eegclip_layernorm_bwd_slabs(const float* dy, int nslabs, long lon
     if ((dd_hi != nullptr) != (dd_lo != nullptr) || (dd_hi && (!dx_drop || (cols & 3) || ((reinterpret_cast<uintptr_t>(dd_hi) | reinterpret_cast<uintptr_t>(dd_lo)) & 7u))))
         return EEGCLIP_EINVAL;
     if (rows == 0) return 0;
+    if (head_ln_bwd_applies(dy, x, gamma, dx, dx_drop, dy_sum, rows, cols, nslabs, slab_stride)) {
+        EEG_LAUNCH(head_ln_bwd_kernel, dim3(rows), dim3(256), 8 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, 0, dx_drop, drop_p, seed, site,
+                   ln_slabs{nslabs, slab_stride, nullptr}, static_cast<unsigned short*>(dd_hi), static_cast<unsigned short*>(dd_lo), dy_sum);
+        return (int)hipGetLastError();
+    }
     const dim3 grid(grid_for(rows, 4, 8192));
     const bool vec2 = (cols % 2 == 0) && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
                                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx_drop) | (uintptr_t)((slab_stride & 1) << 2)) & 7u);
@@ -800,7 +986,10 @@ extern "C" int eegclip_layernorm_bwd(const float* dy, const float* x, const floa
 #define EEG_LN_BWD_GO(NG, V2)                                                                                                          \
     EEG_LAUNCH((layernorm_bwd_dx_kernel<NG, V2>), grid, dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, rows, cols, accumulate_dx, dx_drop, \
                drop_p, seed, site, (float*)nullptr, ln_slabs{1, 0, nullptr}, (unsigned short*)nullptr, (unsigned short*)nullptr, (float*)nullptr)
-    if (want_dx) {
+    if (want_dx && head_ln_bwd_applies(dy, x, gamma, dx, dx_drop, nullptr, rows, cols, 1, 0)) {
+        EEG_LAUNCH(head_ln_bwd_kernel, dim3(rows), dim3(256), 8 * sizeof(float), stream, dy, x, gamma, mean, rstd, dx, accumulate_dx, dx_drop, drop_p, seed, site,
+                   ln_slabs{1, 0, nullptr}, (unsigned short*)nullptr, (unsigned short*)nullptr, (float*)nullptr);
+    } else if (want_dx) {
         if (cols <= 256) { if (vec2) EEG_LN_BWD_GO(1, true); else EEG_LN_BWD_GO(1, false); }
         else             { if (vec2) EEG_LN_BWD_GO(4, true); else EEG_LN_BWD_GO(4, false); }
     }
@@ -906,6 +1095,18 @@ extern "C" int eegclip_bn_elu_bwd_stats(const float* dz, const float* x, const f
                inner, drop_p, seed, site, sums);
     return (int)hipGetLastError();
 }
+extern "C" int eegclip_bn_elu_bwd_apply_rows(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                             const double* rows, int nrows, long long ld, int col0, double count, float* dx, float* dgamma, float* dbeta,
+                                             int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!dz || !x || !mean || !rstd || !gamma || !beta || !rows || nrows < 1 || ld < col0 + 2 * C || col0 < 0 || !dx || !dgamma || !dbeta || outer < 1 || C < 1 ||
+        inner < 1 || count < 1.0 || drop_p < 0.f || drop_p >= 1.f)
+        return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
+    EEG_LAUNCH(bn_elu_bwd_apply_rows_kernel, dim3(C, (outer + 31) / 32), dim3(256), 8 * sizeof(double), stream, dz, x, mean, rstd, gamma, beta, rows, nrows,
+               ld, col0, count, dx, dgamma, dbeta, outer, C, inner, drop_p, seed, site);
+    return (int)hipGetLastError();
+}
+
 extern "C" int eegclip_bn_elu_bwd_apply(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
                                         const float* beta, const double* sums, const double* sums_local, double count, float* dx, float* dgamma,
                                         float* dbeta, int outer, int C, int inner, float drop_p, unsigned long long seed, unsigned site,

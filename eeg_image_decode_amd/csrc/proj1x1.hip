@@ -5,6 +5,7 @@
 // 9216 x 40 x 40 GEMM through two-level index maps, split-K weight gradient) it cost 29 + 7 us forward and 22 + 23 + 8 us backward,
 // almost all of it launch latency and index arithmetic.  Here a sample's 40 x 36 tile, its gradient and the 40 x 40 weights sit in LDS.
 #include "eeg_common.h"
+#include "split_rider.h"
 
 #include <stdlib.h>
 
@@ -26,7 +27,11 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
                                                            const double* __restrict__ rows, int nrows, double count, float eps, float momentum,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ run_mean,
                                                            float* __restrict__ run_var, long long* __restrict__ nbt,
-                                                           unsigned short* __restrict__ feat_hi, unsigned short* __restrict__ feat_lo) {
+                                                           unsigned short* __restrict__ feat_hi, unsigned short* __restrict__ feat_lo, const rider_table riders) {
+    if ((int)blockIdx.x >= B) {           // extra workgroups: plane splits riding in this launch (csrc/split_rider.h); nothing here depends on them
+        split_rider(riders, (int)blockIdx.x - B, (int)gridDim.x - B);
+        return;
+    }
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2 of this sample
     float* ws = zs + PJ_N;                // [40][41]  W[e][c]
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
                                                            const float* __restrict__ y2, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dz2,
                                                            float* __restrict__ dW, float* __restrict__ dbias, double* __restrict__ sums, double* __restrict__ partials, int B, int spw,
-                                                           float drop_p, unsigned long long seed, unsigned site, int nslabs, long long slab_stride) {
+                                                           float drop_p, unsigned long long seed, unsigned site, int nslabs, long long slab_stride,
+                                                           double* __restrict__ bn_rows) {
     EEG_LDS_BASE(float, lds);
     float* zs = lds;                      // [40][36]  z2[c][w]
     float* ds = zs + PJ_N;                // [36][41]  dfeat[w][e]
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
         }
         if (t < PJ_C) row[PJ_C * PJ_C + t] = (double)dbp;
         if (t < 2 * PJ_C) row[PJ_C * PJ_C + PJ_C + t] = csum;
+        if (bn_rows && t < 2 * PJ_C) bn_rows[(long long)blockIdx.x * 2 * PJ_C + t] = csum;      // ... again as a compact [workgroup][80] table for the apply pass's prologue
         return;
     }
 #pragma unroll
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_reduce_kernel(const double* _
         const double v = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
         if (c < PJ_C * PJ_C)             atomicAdd(dW + c, (float)v);
         else if (c < PJ_C * PJ_C + PJ_C) atomicAdd(dbias + c - PJ_C * PJ_C, (float)v);
-        else                             atomicAdd(sums + c - PJ_C * PJ_C - PJ_C, v);
+        else if (sums)                   atomicAdd(sums + c - PJ_C * PJ_C - PJ_C, v);
     }
 }
 
@@ -217,7 +224,7 @@ extern "C" int eegclip_proj1x1_fwd(const float* y2, const float* mean, const flo
     if (!y2 || !mean || !rstd || !gamma || !beta || !W || !bias || !z2 || !feat || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, mean, rstd, gamma, beta, W, bias, z2, feat, B, drop_p, seed, site,
                (const double*)nullptr, 0, 1.0, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (long long*)nullptr,
-               (unsigned short*)nullptr, (unsigned short*)nullptr);
+               (unsigned short*)nullptr, (unsigned short*)nullptr, rider_table{});
     return (int)hipGetLastError();
 }
 
@@ -231,23 +238,30 @@ extern "C" int eegclip_proj1x1_fwd_rows(const float* y2, const double* rows, int
     if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
     EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, (const float*)nullptr, (const float*)nullptr, gamma, beta, W, bias, z2, feat, B,
                drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked, (unsigned short*)nullptr,
-               (unsigned short*)nullptr);
+               (unsigned short*)nullptr, rider_table{});
     return (int)hipGetLastError();
 }
 
-// eegclip_proj1x1_fwd_rows that also leaves `feat` as bf16 hi | lo planes (feat_hi / feat_lo, (B, 1440) each)
+// eegclip_proj1x1_fwd_rows that also leaves `feat` as bf16 hi | lo planes (feat_hi / feat_lo, (B, 1440) each); riders: dense plane splits performed by extra
+// workgroups of this launch (csrc/split_rider.h)
 extern "C" int eegclip_proj1x1_fwd_rows_planes(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
                                                float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
                                                const float* W, const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed,
-                                               unsigned int site, void* feat_hi, void* feat_lo, void* stream) {
+                                               unsigned int site, void* feat_hi, void* feat_lo, const eegclip_split_item* riders, int n_riders, void* stream) {
+    rider_table rt;
+    if (const int rc = rider_table_from(riders, n_riders, rt)) return rc;
+    long long r4 = 0;
+    for (int i = 0; i < rt.n; ++i) r4 += rt.it[i].n4;
+    int rblocks = (int)((r4 + 2047) / 2048);                 // ~8 float4 per rider thread
+    if (rblocks > 512) rblocks = 512;
     if (!y2 || !gamma || !beta || !W || !bias || !z2 || !feat || !feat_hi || !feat_lo || !mean || !rstd || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
     if (rows && (nrows < 1 || count < 1.0)) return EEGCLIP_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return EEGCLIP_EINVAL;
     if (reinterpret_cast<uintptr_t>(rows) & 7u) return EEGCLIP_EALIGN;
     // rows == NULL: mean / rstd are INPUTS (eval mode, or statistics finalised by an earlier launch: data parallelism)
-    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B), dim3(256), pj_fwd_lds(), stream, y2, rows ? (const float*)nullptr : mean, rows ? (const float*)nullptr : rstd, gamma, beta,
+    EEG_LAUNCH(proj1x1_fwd_kernel, dim3(B + rblocks), dim3(256), pj_fwd_lds(), stream, y2, rows ? (const float*)nullptr : mean, rows ? (const float*)nullptr : rstd, gamma, beta,
                W, bias, z2, feat, B, drop_p, seed, site, rows, nrows, count, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked,
-               static_cast<unsigned short*>(feat_hi), static_cast<unsigned short*>(feat_lo));
+               static_cast<unsigned short*>(feat_hi), static_cast<unsigned short*>(feat_lo), rt);
     return (int)hipGetLastError();
 }
 
@@ -268,6 +282,29 @@ extern "C" int eegclip_proj1x1_bwd_slabs(const float* dfeat, int nslabs, long lo
     if (nslabs < 1 || nslabs > 16 || (nslabs > 1 && slab_stride < (long long)B * PJ_N)) return EEGCLIP_EINVAL;
     return proj1x1_bwd_go(dfeat, nslabs, slab_stride, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, workspace, B, drop_p, seed, site, stream);
 }
+// the two halves of eegclip_proj1x1_bwd_slabs as launches of their own: _rows leaves one partial row [dW 1600 | dbias 40 | BatchNorm-backward sums 80] (fp64) per
+// sample in `workspace` and dz2; eegclip_bn_elu_bwd_apply_rows takes the BatchNorm sums straight from those rows (fixed-order sum in its prologue), so that
+// eegclip_proj1x1_bwd_reduce -- dW, dbias (and `sums` unless NULL) -- is read by the optimizer only and can leave the dX chain
+extern "C" int eegclip_proj1x1_bwd_rows(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta, float* dz2, float* workspace, double* bn_rows, int B,
+                                        float drop_p, unsigned long long seed, unsigned int site, void* stream) {
+    if (reinterpret_cast<uintptr_t>(bn_rows) & 7u) return EEGCLIP_EALIGN;
+    if (!dfeat || !z2 || !W || !y2 || !mean || !rstd || !gamma || !beta || !dz2 || !workspace || B < 1 || drop_p < 0.f || drop_p >= 1.f) return EEGCLIP_EINVAL;
+    if (nslabs < 1 || nslabs > 16 || (nslabs > 1 && slab_stride < (long long)B * PJ_N)) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 7u) return EEGCLIP_EALIGN;
+    const size_t lds = (PJ_N + PJ_W * PJ_LW + PJ_C * PJ_LW + 2 * PJ_N) * sizeof(float);
+    EEG_LAUNCH(proj1x1_bwd_kernel, dim3(B), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, (float*)nullptr, (float*)nullptr,
+               (double*)nullptr, reinterpret_cast<double*>(workspace), B, 1, drop_p, seed, site, nslabs, slab_stride, bn_rows);
+    return (int)hipGetLastError();
+}
+extern "C" int eegclip_proj1x1_bwd_reduce(const float* workspace, int B, float* dW, float* dbias, double* sums, void* stream) {
+    if (!workspace || !dW || !dbias || B < 1) return EEGCLIP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 7u) return EEGCLIP_EALIGN;
+    const int slices = B < PJ_SLICES ? B : PJ_SLICES;
+    EEG_LAUNCH(proj1x1_bwd_reduce_kernel, dim3((PJ_PART + 63) / 64, slices), dim3(256), 256 * sizeof(double), stream, reinterpret_cast<const double*>(workspace), B,
+               dW, dbias, sums);
+    return (int)hipGetLastError();
+}
 static int proj1x1_bwd_go(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, float* dz2, float* dW, float* dbias, double* sums, float* workspace, int B,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream) {
@@ -281,7 +318,7 @@ static int proj1x1_bwd_go(const float* dfeat, int nslabs, long long slab_stride,
     const int nwg = (B + spw - 1) / spw;
     double* parts = reinterpret_cast<double*>(workspace);
     EEG_LAUNCH(proj1x1_bwd_kernel, dim3(nwg), dim3(256), lds, stream, dfeat, z2, W, y2, mean, rstd, gamma, beta, dz2, dW, dbias, sums, parts, B, spw,
-               drop_p, seed, site, nslabs, slab_stride);
+               drop_p, seed, site, nslabs, slab_stride, (double*)nullptr);
     if (parts) {
         const int slices = nwg < PJ_SLICES ? nwg : PJ_SLICES;
         EEG_LAUNCH(proj1x1_bwd_reduce_kernel, dim3((PJ_PART + 63) / 64, slices), dim3(256), 256 * sizeof(double), stream, parts, nwg, dW, dbias, sums);

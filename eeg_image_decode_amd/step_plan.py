@@ -95,43 +95,67 @@ class StepPlan:
                 pl._seed_descs += src._seed_descs
             return base
 
-        # ---- the targets' operand planes + fp32 stack: inputs only, second stream, under the encoder's forward (items filled below)
-        self.split_op = len(pl.ops)
-        start_side = os.environ.get("EEGCLIP_START_SIDE", "1") != "0"
-        # (round 6) the query gradient on the K-parallel plane GEMM: it reads the targets' planes STACKED, k-major -- the same two split items, written
-        # behind one another
+        # ---- the targets' operand planes: inputs only.  With the head on plane GEMMs (round 6) their split RIDES in the forward's 1x1-conv launch next to the
+        # head weights' (csrc/split_rider.h: no launch, no second stream, no join); otherwise a second-stream launch under the encoder's forward (items below)
         self.on_planes = bool(getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and eloss.head_gemm_enabled(B, 2 * B, Dm))
-        pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", start_side))
+        self.split_op = None
+        if not self.on_planes:
+            self.split_op = len(pl.ops)
+            pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", os.environ.get("EEGCLIP_START_SIDE", "1") != "0"))
         # ---- encoder forward
         f0 = splice(self.fwd)
         self.fwd_base = f0
         self.out_op = f0 + self.fwd.out_op
         # ---- running train accuracy: raw z @ class_feats^T, top-1, count: second stream.  The ops are emitted INSIDE the backward, right behind its first
         # second-stream launch (the head LayerNorm's parameter gradients), so that they share that fork instead of paying one of their own
-        self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
-        self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
-                                      Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
-                                      drop_site=0, split_k=1, precision=self.fwd.precision)
-        pl._keep.append(self.acc_desc)
         sc_ptr = model.logit_scale.detach().reshape(1).data_ptr()
+        ncp = (n_classes + 3) // 4 * 4
+        self.acc_on_planes = bool(getattr(self.fwd, "head_planes", False)) and os.environ.get("EEGCLIP_HEAD_GEMM", "1") != "0"
+        if self.acc_on_planes:
+            # (round 6) from planes on csrc/head_gemm.hip: the query features leave the head's LayerNorm as planes anyway, the class table is split ONCE per
+            # table (run()); the fp32-operand GEMM took 30 us alone and 90 us beside the conv stack's backward
+            self.logits = torch.empty(B, ncp, dtype=torch.float32, device=dev)
+            self.class_planes = torch.zeros(2, ncp, Dm, dtype=torch.bfloat16, device=dev)       # (rows >= n_classes: zero padding up to a multiple of 4 columns)
+            self.acc_desc = None
+        else:
+            self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
+            self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
+                                          Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
+                                          drop_site=0, split_k=1, precision=self.fwd.precision)
+            pl._keep.append(self.acc_desc)
 
         def accuracy_ops():
-            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
+            if self.acc_on_planes:
+                pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=self.q_planes[0].data_ptr(), a_lo=self.q_planes[1].data_ptr(), b_hi=self.class_planes[0].data_ptr(),
+                                                                   b_lo=self.class_planes[1].data_ptr(), lda=Dm, ldb=Dm, M=B, N=ncp, K=Dm, slices=1, slab_stride=0,
+                                                                   C=self.logits.data_ptr(), ldc=ncp), side=True)
+            else:
+                pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
             self.count_op = len(pl.ops)
-            pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, n_classes, sc_ptr, 0, 0, side=True)
+            pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, self.logits.shape[1], sc_ptr, 0, 0, side=True)
 
+        self.q_planes = torch.empty(2, B, Dm, dtype=torch.bfloat16, device=dev)                 # the query features, written by the head's LayerNorm
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch).  Operand planes: the targets are inputs of the
         # step -- split (and, for the query gradient, split TRANSPOSED: round 6) by second-stream launches at the very start; the query features leave the
         # head's LayerNorm as planes (the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
-        self.q_planes = torch.empty(2, B, Dm, dtype=torch.bfloat16, device=dev)                 # the query features, written by the head's LayerNorm
         self.t_planes = torch.empty(2, 2 * B, Dm, dtype=torch.bfloat16, device=dev)             # hi | lo of [img; txt]
         self.stack = None if self.on_planes else torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # round 5's fp32 right-hand operand of the query gradient (loss.py)
-        self.items = (_abi.SplitItem * 2)()
+        if self.on_planes:
+            self.items = (_abi.SplitItem * 4)()                    # this plan's own rider table: the forward plan's weights item + the two targets
+            self.items[0] = self.fwd.rider_items[0]
+            self.item0 = 1
+            pl._keep.append(self.items)
+            pl.set_arg(self.fwd_base + self.fwd.rider_op, 23, self.items)
+            pl.set_arg(self.fwd_base + self.fwd.rider_op, 24, 3)
+        else:
+            self.items = (_abi.SplitItem * 2)()
+            self.item0 = 0
+            pl._keep.append(self.items)
+            pl.ops[self.split_op][1][0] = self.items
         for i in range(2):
-            self.items[i] = _abi.SplitItem(src=0, hi=self.t_planes[0, i * B:].data_ptr(), lo=self.t_planes[1, i * B:].data_ptr(), rows=B, cols=Dm, ld_src=Dm,
-                                           ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr() if self.stack is not None else None, ld_copy=Dm)
-        pl._keep.append(self.items)
-        pl.ops[self.split_op][1][0] = self.items
+            self.items[self.item0 + i] = _abi.SplitItem(src=0, hi=self.t_planes[0, i * B:].data_ptr(), lo=self.t_planes[1, i * B:].data_ptr(), rows=B, cols=Dm,
+                                                        ld_src=Dm, ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr() if self.stack is not None else None,
+                                                        ld_copy=Dm)
         fn, args, name, side = pl.ops[self.out_op]
         if name == "eegclip_residual_layernorm_fwd_slabs":              # (round 6: the head's LayerNorm adds the second Linear's slabs; planes are arguments 19 / 20)
             args[19], args[20] = self.q_planes[0].data_ptr(), self.q_planes[1].data_ptr()
@@ -174,9 +198,15 @@ class StepPlan:
             garr[t_].part_k, garr[t_].diag_k = arr[2 * t_ + 1].part, arr[2 * t_ + 1].diag
         pl._keep += [arr, garr]
         # the loss reads planes (and, round 5's form, the fp32 stack) that the SECOND stream wrote at the start of the step: ordered by the forward plan's join
-        # in front of the conv stack when it has one -- an explicit join otherwise (free when nothing is pending)
-        if "join" not in [op[2] for op in pl.ops[self.fwd_base:]]:
+        # in front of the conv stack when it has one -- an explicit join otherwise.  With riders nothing ran on the second stream yet.
+        if self.split_op is not None and "join" not in [op[2] for op in pl.ops[self.fwd_base:]]:
             pl.join()
+        # (round 6) the accuracy readout forks HERE, right behind the forward: its ~30 us of second-stream work overlap the loss and the head's backward -- small
+        # launches that leave most of the chip idle -- instead of queueing behind the conv stack's backward, whose workgroups own the CUs' LDS (the plane
+        # GEMM took 83 us there).  EEGCLIP_ACC_EARLY=0: inside the backward's first fork (round 5's place; A/B aid)
+        self.acc_early = os.environ.get("EEGCLIP_ACC_EARLY", "1") != "0" and self.acc_on_planes
+        if self.acc_early:
+            accuracy_ops()
         # (loss.fused_infonce's training form: the forward leaves the per-tile partials, the gradient pass finalises them itself and adds the loss)
         if os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
             pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, None)
@@ -211,7 +241,8 @@ class StepPlan:
         self.bwd_base, self.bwd_cut = b0, cut
         splice(self.bwd, 0, cut)
         n0 = len(pl.ops)
-        accuracy_ops()
+        if not self.acc_early:
+            accuracy_ops()
         self.bwd_shift = len(pl.ops) - n0
         splice(self.bwd, cut, len(self.bwd.ops), at=b0 + self.bwd_shift)
         pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
@@ -300,14 +331,24 @@ class StepPlan:
         out = torch.empty(B, 1024, dtype=torch.float32, device=self.dev)
         op = out.data_ptr()
         pl.set_arg(self.out_op, 8, op)
-        self.acc_desc.A = op
-        cp = class_feats.data_ptr()
-        if cp != self._class_ptr:
-            self.acc_desc.B = cp
-            self._class_ptr = cp
+        cp = (class_feats.data_ptr(), class_feats._version)
+        if self.acc_on_planes:
+            if cp != self._class_ptr:                  # a new (or modified) class table: its planes, once
+                nc = class_feats.shape[0]
+                it = (_abi.SplitItem * 1)(_abi.SplitItem(src=class_feats.data_ptr(), hi=self.class_planes[0].data_ptr(), lo=self.class_planes[1].data_ptr(), rows=nc,
+                                                          cols=1024, ld_src=1024, ld_out=1024, transpose=0))
+                rc = lib().eegclip_split_rows(it, 1, raw_stream())
+                if rc:
+                    raise RuntimeError(f"eegclip_split_rows returned {rc}")
+                self._class_ptr = cp
+        else:
+            self.acc_desc.A = op
+            if cp != self._class_ptr:
+                self.acc_desc.B = cp[0]
+                self._class_ptr = cp
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
-        self.items[0].src, self.items[1].src = img.data_ptr(), txt.data_ptr()
+        self.items[self.item0].src, self.items[self.item0 + 1].src = img.data_ptr(), txt.data_ptr()
         # the plan ACCUMULATES into the flat gradient buffer without attach_grads(): it must be clear.  It is when the optimizer's fused step cleared
         # exactly the views the last backward attached and nothing touched them since (every plan step leaves it so); after anything else -- a
         # keep_grads=True step, a manual backward followed by zero_grad(set_to_none=True): .grad is None but the buffer still holds values -- clear it here

@@ -465,7 +465,7 @@ typedef union {
     int i32;
     unsigned int u32;
 } eegclip_plan_arg;
-#define EEGCLIP_PLAN_MAX_ARGS 24
+#define EEGCLIP_PLAN_MAX_ARGS 28
 typedef struct {
     int fn;
     int flags;
@@ -634,7 +634,22 @@ int eegclip_proj1x1_bwd_slabs(const float* dfeat, int nslabs, long long slab_str
 int eegclip_proj1x1_fwd_rows_planes(const float* y2, const double* rows, int nrows, double count, float eps, float momentum, float* mean, float* rstd,
                                     float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
                                     const float* W, const float* bias, float* z2, float* feat, int B, float drop_p, unsigned long long seed,
-                                    unsigned int site, void* feat_hi, void* feat_lo, void* stream);
+                                    unsigned int site, void* feat_hi, void* feat_lo, const eegclip_split_item* riders, int n_riders, void* stream);
+/* riders (<= 4, or NULL / 0): dense eegclip_split_item entries (transpose = 0, no copy, ld_src = ld_out = cols, rows * cols % 4 == 0) split into planes by EXTRA
+ * workgroups of that launch (csrc/split_rider.h): this step's projection-head weights and the loss targets, which the plane GEMMs after it read -- the launch is
+ * one small workgroup per sample and leaves the memory system idle, the splits cost no launch, no second stream and no join.
+ * The backward's two halves as launches of their own: eegclip_proj1x1_bwd_rows leaves dz2, one fp64 partial row per sample ([dW 1600 | dbias 40 | BatchNorm2-
+ * backward sums 80]) in `workspace` (eegclip_proj1x1_bwd_workspace_floats(B) floats) and the 80 BatchNorm sums again as a compact (B, 80) fp64 table bn_rows;
+ * eegclip_bn_elu_bwd_apply_rows = eegclip_bn_elu_bwd_apply with the batch sums taken from such a table (`nrows` rows of 2 C doubles, `ld` doubles apart, first
+ * column col0; added in a fixed order by every workgroup: no cleared accumulator, no reduction on the dX chain); eegclip_proj1x1_bwd_reduce adds the partial
+ * rows' dW / dbias column sums to the gradients (and the BatchNorm sums to `sums` unless NULL) -- read by the optimizer only. */
+int eegclip_proj1x1_bwd_rows(const float* dfeat, int nslabs, long long slab_stride, const float* z2, const float* W, const float* y2, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, float* dz2, float* workspace, double* bn_rows, int B, float drop_p,
+                             unsigned long long seed, unsigned int site, void* stream);
+int eegclip_proj1x1_bwd_reduce(const float* workspace, int B, float* dW, float* dbias, double* sums, void* stream);
+int eegclip_bn_elu_bwd_apply_rows(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const double* rows, int nrows, long long ld, int col0, double count, float* dx, float* dgamma, float* dbeta, int outer, int C,
+                                  int inner, float drop_p, unsigned long long seed, unsigned int site, void* stream);
 /* stage tail of the diffusion prior with plane outputs (csrc/prior.hip; Generation/diffusion_prior.py:173-175,186-199):
  *   forward   y_ln = LayerNorm(x), y_act = dropout(SiLU(y_ln)) (+ skip), mean / rstd saved; act_hi / act_lo: y_act again as bf16 planes (or NULL)
  *   backward  d = dropout'(dact) * silu'(y_ln); dx = LayerNorm'(d) as fp32 (dx, or NULL) and / or bf16 planes (dx_hi / dx_lo, or NULL);
