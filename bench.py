@@ -281,8 +281,19 @@ def secondary():
     section("prior_sampling_chain", _sec_prior_chain)
     section("sdxl_cross_attention", _sec_cross_attn)
     section("sdxl_sampling_loop", _sec_sdxl_loop)
+    section("vae_decode_1024px", _sec_vae_decode)
     section("end_to_end_dataset_loader_train_model", _sec_end_to_end)
     return out
+
+
+def _sec_vae_decode():
+    """the VAE decode that ends a sampling loop (Generation/custom_pipeline.py:421) at 1024 x 1024 on csrc/vae.hip: SDXL's VAE layout (83.65 M parameters), random
+    weights -- diffusers / the checkpoint are absent offline (stand_in)"""
+    from eeg_image_decode_amd import vae
+    r = vae.bench_decode(images=1, latent=128)
+    r["frac_of_bf16_mfma_peak"] = round(r["algorithmic_TFLOPs"] / PEAK_BF16_MFMA_TF, 4)
+    r["workload"] = "AutoencoderKL decode of one 128 x 128 x 4 latent -> 1024 x 1024 x 3, bf16 activations, fp32 accumulation"
+    return r
 
 
 def _sec_infonce(N=2048, Dm=1024, light=False):

@@ -76,6 +76,13 @@ class HeadGemmDesc(C.Structure):
                 ("b_kmajor", C.c_int)]
 
 
+class Conv16Desc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("N", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int), ("in_pad", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int), ("out_pad", C.c_int),
+                ("KS", C.c_int), ("stride", C.c_int), ("pad_top", C.c_int), ("pad_left", C.c_int), ("upsample", C.c_int), ("dtype", C.c_int)]
+
+
 class WgradTokProblem(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("a_group_stride", C.c_longlong), ("m_groups", C.c_int), ("heads_m", C.c_int), ("heads_n", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("out", C.c_void_p), ("ldo", C.c_longlong), ("bias_out", C.c_void_p), ("bias_mfma", C.c_int),
@@ -208,6 +215,10 @@ PROTOTYPES = {
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
     "eegclip_gemm_planes": [C.POINTER(GemmPlanesDesc), _P],
     "eegclip_split_transpose": [C.POINTER(SplitItem), _I, _P],
+    "eegclip_conv16": [C.POINTER(Conv16Desc), _P],
+    "eegclip_groupnorm16": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P],
+    "eegclip_softmax_rows16": [_P, _I, _I, _L, _F, _I, _P],
+    "eegclip_vae_sample16": [_P, _P, _P, _L, _I, _I, _P],
     "eegclip_head_gemm_slices": [_I, _I, _I],
     "eegclip_head_gemm": [C.POINTER(HeadGemmDesc), _P],
     "eegclip_head_act": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -488,15 +488,22 @@ class _Output:
 class StandInSDXLPipeline:
     """What `generate_ip_adapter_embeds` needs from a diffusers StableDiffusionXLPipeline, around the stand-in UNet: scheduler, empty-prompt
     embeddings (there is no text encoder offline: prompt '' maps to fixed embeddings, like the reference's constant empty prompt), micro-conditioning
-    ids.  There is no VAE: output_type must be "latent" unless a `vae_decode` callable is supplied."""
+    ids.  vae: a vae.SDXLShapedVAE (round 6: SDXL's VAE layout on csrc/vae.hip) -- `low_level_image` is then encoded by it
+    (custom_pipeline_low_level.py:8-31) and output_type "pt" / "np" decodes the final latents (custom_pipeline.py:421 + image_processor.postprocess:
+    image / 2 + 0.5 clamped to [0, 1]); without one, output_type must be "latent" unless `vae_decode` / `vae_encode` callables are supplied."""
 
-    def __init__(self, unet=None, scheduler=None, device="cuda", dtype=torch.float16, default_sample_size=64, vae_decode=None, vae_encode=None):
+    def __init__(self, unet=None, scheduler=None, device="cuda", dtype=torch.float16, default_sample_size=64, vae_decode=None, vae_encode=None, vae=None):
         self.unet = (unet if unet is not None else SDXLShapedUNet(dtype=dtype)).to(device)
         self.scheduler = scheduler if scheduler is not None else EulerAncestralDiscreteScheduler()
         self.device, self.dtype = device, dtype
         self.default_sample_size = default_sample_size           # sdxl-turbo: 512 px = 64 latent; SDXL-base: 128
         self.vae_scale_factor = 8
         self.vae_scaling_factor = 0.13025                        # SDXL VAE config.scaling_factor
+        self.vae = vae.to(device) if vae is not None else None
+        if self.vae is not None:
+            self.vae_scaling_factor = self.vae.scaling_factor
+            vae_decode = vae_decode or (lambda lat: self.vae.decode(lat))
+            vae_encode = vae_encode or (lambda img, gen: self.vae.encode(img, generator=gen))
         self.vae_decode, self.vae_encode = vae_decode, vae_encode
         g = torch.Generator().manual_seed(1234)
         self.empty_prompt_embeds = (torch.randn(1, 77, 2048, generator=g) * 0.5).to(device=device, dtype=dtype)
@@ -649,6 +656,13 @@ def generate_ip_adapter_embeds(self, prompt=None, prompt_2=None, height=None, wi
         if self.vae_decode is None:
             raise EegclipError("decoding to an image needs the SDXL VAE (absent offline): use output_type='latent' or supply vae_decode")
         image = self.vae_decode(latents / self.vae_scaling_factor)
+        if output_type in ("pt", "np", "pil"):                 # VaeImageProcessor.postprocess: denormalise to [0, 1]; "np" / "pil": (N, H, W, 3) on the host
+            image = (image.float() / 2 + 0.5).clamp(0, 1)
+            if output_type in ("np", "pil"):
+                image = image.permute(0, 2, 3, 1).cpu().numpy()
+                if output_type == "pil":
+                    from PIL import Image
+                    image = [Image.fromarray((im * 255).round().astype("uint8")) for im in image]
     return _Output(image) if return_dict else (image,)
 
 

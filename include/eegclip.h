@@ -575,6 +575,35 @@ int eegclip_gemm_planes(const eegclip_gemm_planes_desc* d, void* stream);
  * matrices) */
 int eegclip_split_transpose(const eegclip_split_item* items, int n, void* stream);
 
+/* ---- the SDXL VAE's layers (csrc/vae.hip; Generation/custom_pipeline_low_level.py:8-31 `vae.encode`, Generation/custom_pipeline.py:421 `vae.decode`; the module is
+ * diffusers 0.30.0's AutoencoderKL, not vendored by the reference) on 16-bit PADDED NHWC activations: a tensor is [image][H + 2 pad][W + 2 pad][C] with a zero
+ * border that no launch writes (pad = 1; 0 for tensors that only 1 x 1 layers / the attention read).
+ *   eegclip_conv16       out[n][y][x][co] = bias[co] + residual[n][y][x][co] + sum_{ky,kx,ci} in[n][y * stride + ky - pad_top][x * stride + kx - pad_left][ci]
+ *                        W[co][ky][kx][ci]   (W stored [Cout][KS * KS][Cin], 16-bit; KS 1 | 3, stride 1 | 2; pad_top / pad_left <= in_pad, the bottom / right
+ *                        taps must stay inside the padded frame: stride 2 with pad (0, 1, 0, 1) is the encoder's downsampler).  upsample = 1: `in` is (Hi, Wi)
+ *                        and the convolution runs over its nearest-2x upsampling (Ho = 2 Hi; KS 3, stride 1, pad 1) -- Upsample2D + conv without the
+ *                        upsampled tensor.  Cin % 64 == 0 and Cout % 128 == 0: implicit GEMM on v_mfma_f32_32x32x16 (the tile loop of eegclip_gemm16, row
+ *                        addresses recomputed per tap); otherwise a direct kernel for the 3 / 4 / 8-channel layers (weights <= 150 KB).
+ *   eegclip_groupnorm16  y = GroupNorm(x) (* SiLU if silu): statistics over the interior pixels, fp64 sums in `sums` (N * groups * 2 doubles, cleared by the
+ *                        call); C / groups a multiple of 4
+ *   eegclip_softmax_rows16   rows of a 16-bit matrix <- softmax(scale * row), in place (the mid-block attention's score matrix)
+ *   eegclip_vae_sample16     z = mean + exp(0.5 clamp(logvar, -30, 20)) * noise from moments (pixels, 2 L) = [mean | logvar] (noise NULL: the mode) */
+typedef struct {
+    const void* in;
+    const void* W;
+    void* out;
+    const void* bias;
+    const void* residual;        /* in the output's layout, or NULL */
+    int N, Hi, Wi, Cin, in_pad;
+    int Ho, Wo, Cout, out_pad;
+    int KS, stride, pad_top, pad_left, upsample, dtype;
+} eegclip_conv16_desc;
+int eegclip_conv16(const eegclip_conv16_desc* d, void* stream);
+int eegclip_groupnorm16(const void* x, int N, int H, int W, int C, int pad, int groups, const void* gamma, const void* beta, float eps, int silu, void* y,
+                        int out_pad, double* sums, int dtype, void* stream);
+int eegclip_softmax_rows16(void* s, int rows, int cols, long long ld, float scale, int dtype, void* stream);
+int eegclip_vae_sample16(const void* moments, const void* noise, void* z, long long pixels, int latent_channels, int dtype, void* stream);
+
 /* ---- the projection head's GEMMs at M = the batch (csrc/head_gemm.hip; Retrieval/ATMS_retrieval.py:157-167 forward, its input gradients, and the query
  * gradient of the loss, models/loss.py:122-140): C[m][n] = sum_k A[m][k] B[n][k] from k-contiguous bf16 hi | lo planes like eegclip_gemm_planes, but
  * K-PARALLEL across workgroups without atomics or in-launch hand-offs: with slices > 1 workgroup (64 x 64 tile, slice s) stores its partial tile into
