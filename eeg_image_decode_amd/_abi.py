@@ -148,6 +148,7 @@ PROTOTYPES = {
     "eegclip_ddpm_step": [_P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _L, _P],
     "eegclip_prior_stage_infer": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _P],
     "eegclip_mse_loss_grad": [_P, _P, _L, _P, _P, _P],
+    "eegclip_mse_loss_grad_scaled": [_P, _P, _L, _F, _P, _P, _P],
     "eegclip_bn_stats": [_P, _I, _I, _I, _P, _P],
     "eegclip_bn_finalize": [_P, _D, _F, _F, _I, _P, _P, _P, _P, _I, _P, _P],
     "eegclip_bn_finalize_rows": [_P, _I, _D, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],

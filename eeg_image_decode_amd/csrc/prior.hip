@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void mse_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
-                                                             float* __restrict__ loss, float* __restrict__ dpred) {
-    const float inv = 1.0f / (float)n;
+                                                             float* __restrict__ loss, float* __restrict__ dpred, float weight) {
+    const float inv = weight / (float)n;
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float d = pred[i] - target[i];
@@ -584,6 +584,13 @@ extern "C" int eegclip_ddpm_step(const float* x, const float* eps_c, const float
 
 extern "C" int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream) {
     if (!pred || !target || n < 1 || (!loss && !dpred)) return EEGCLIP_EINVAL;
-    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n / 8 + 1, 256)), dim3(256), 4 * sizeof(float), stream, pred, target, n, loss, dpred);
+    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n / 8 + 1, 256)), dim3(256), 4 * sizeof(float), stream, pred, target, n, loss, dpred, 1.0f);
+    return (int)hipGetLastError();
+}
+// *loss += weight * mean((pred - target)^2), dpred = weight * 2 (pred - target) / n: the MSE term of the reconstruction objective inside the step plan
+// (Generation/ATMS_reconstruction.py:227: 10 * alpha * MSE), its gradient written as one more slab of the encoder backward's upstream gradient
+extern "C" int eegclip_mse_loss_grad_scaled(const float* pred, const float* target, long long n, float weight, float* loss, float* dpred, void* stream) {
+    if (!pred || !target || n < 1 || (!loss && !dpred)) return EEGCLIP_EINVAL;
+    EEG_LAUNCH(mse_loss_grad_kernel, dim3(pgrid(n / 8 + 1, 256)), dim3(256), 4 * sizeof(float), stream, pred, target, n, loss, dpred, weight);
     return (int)hipGetLastError();
 }

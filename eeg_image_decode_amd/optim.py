@@ -157,6 +157,22 @@ class AdamW(torch.optim.Optimizer):
                     p.grad = None
         return loss
 
+    def activate_launch_set(self, gi, fast):
+        """make `fast` (one of this optimizer's cached launch sets) the set whose lazy step counts are pending -- what step() does when the live set changes
+        (the joint-subject model alternates subjects batch by batch) -- for a caller that replays the set's launches itself (step_plan.StepPlan).  False:
+        the set is gone, or its runs no longer share step counts (the caller takes the ordinary path, which rebuilds it)."""
+        if self._fast_last.get(gi) is fast:
+            return True
+        if not any(f is fast for f in self._fast.get(gi, {}).values()):
+            return False
+        self._flush_steps(gi)
+        steps_now = [self.state[p0]["step"] for (p0, *_rest) in fast["launch"]]
+        if not all(self.state[q]["step"] == st for (_p0, _n, _w, _g, _m, _v, members), st in zip(fast["launch"], steps_now) for q in members):
+            return False
+        fast["run_steps"] = steps_now
+        self._fast_last[gi] = fast
+        return True
+
     def _flush_steps(self, gi=None):
         """bring state[p]["step"] up to date with the steps taken on the fast path"""
         for g in ([gi] if gi is not None else list(self._fast_last)):

@@ -135,7 +135,7 @@ def contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, t
             eeg_model.overlap_grad_allreduce = prev_overlap      # (a caller accumulating gradients over several backwards must not inherit it)
 
 
-_STEP_PLANS_MAX = 8
+_STEP_PLANS_MAX = 16
 # model -> {configuration: state}.  Keyed weakly by the model and holding neither the model nor the optimizer strongly (StepPlan keeps weak references
 # too): a dropped model frees its plans, buffers and engine -- nothing here closes a reference cycle through the engine, which retrieval.settle_gc()'s
 # gc.freeze() would make immortal for the first model of a process
@@ -160,7 +160,12 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
     table = _STEP_PLAN_TABLES.get(eeg_model)
     if table is None:
         table = _STEP_PLAN_TABLES[eeg_model] = {}
-    key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subject_id)
+    if isinstance(subject_id, int):
+        subj_key = subject_id
+    else:       # joint-subject model with per-sample ids: the optimizer's launch set depends on WHICH subjects are present (their value embeddings are live)
+        import numpy as np
+        subj_key = tuple(np.unique(np.asarray(subject_id.cpu() if isinstance(subject_id, torch.Tensor) else subject_id, dtype=np.int64)).tolist())
+    key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subj_key, objective)
     st = table.get(key)
     if st is not None and st["opt"]() is not optimizer:               # (an id reused by another optimizer)
         st = None
@@ -170,13 +175,13 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
         st = table[key] = {"warm": 0, "plan": None, "opt": weakref.ref(optimizer)}
     sp = st["plan"]
     if sp is not None and sp is not False:
-        if sp.still_valid(eeg_model, optimizer) and (subject_id >= 10 or eng.bufs[eeg_data.shape[0]].get("ids_uniform") == subject_id):
+        if sp.still_valid(eeg_model, optimizer) and (eeg_model.joint_train or subject_id >= 10 or eng.bufs[eeg_data.shape[0]].get("ids_uniform") == subject_id):
             return st, sp
         st["plan"], st["warm"] = None, 0             # something changed under the plan: warm up again on the ordinary path
         return st, None
     if sp is None and st["warm"] >= StepPlan.WARM_STEPS and optimizer._fast_last.get(0) is not None and all(p.grad is None for p in optimizer.param_groups[0]["params"]):
         try:
-            st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0])
+            st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0], objective)
             return st, st["plan"]
         except NotApplicable as e:                    # (anything else is a bug in the plan builder and propagates)
             st["plan"] = False                        # this configuration does not have the pieces (e.g. launch-per-Linear plans): ordinary path for good
@@ -189,7 +194,7 @@ def _contrastive_step(eeg_model, optimizer, eeg_data, subject_id, img_features, 
     from . import dist as edist
     st, sp = _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_features, labels, class_feats, alpha, objective, keep_grads)
     if sp is not None:
-        feats, loss = sp.run(eeg_data, img_features, text_features, labels, class_feats, correct)
+        feats, loss = sp.run(eeg_data, img_features, text_features, labels, class_feats, correct, subject_id)
         if isinstance(loss_acc, list):
             loss_acc.append(loss)
         else:

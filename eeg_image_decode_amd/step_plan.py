@@ -55,10 +55,19 @@ class StepPlan:
     def eng(self):
         return self._eng_ref()
 
-    def __init__(self, model, optimizer, B, alpha, n_classes):
+    def __init__(self, model, optimizer, B, alpha, n_classes, objective="retrieval"):
         from . import loss as eloss
         from .atms import P_DIM
         eng = model._engine()
+        # the loss mix: retrieval = alpha * ClipLoss(z, img) + (1 - alpha) * ClipLoss(z, txt)  (ATMS_retrieval.py:224-234); reconstruction =
+        # 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img))  (Generation/ATMS_reconstruction.py:222-228): one InfoNCE target + an MSE term whose
+        # gradient joins the query gradient as one more slab of the backward's upstream gradient
+        self.objective = objective
+        self.weights = (float(alpha), 1.0 - float(alpha)) if objective == "retrieval" else (10.0 * (1.0 - float(alpha)),)
+        self.mse_w = 0.0 if objective == "retrieval" else 10.0 * float(alpha)
+        T_ = len(self.weights)
+        self.T = T_
+        self.joint = bool(eng.joint)
         # (weak: the plan hangs off the engine, which hangs off the model -- a strong reference back would be a cycle that retrieval.settle_gc()'s
         #  gc.freeze() makes immortal for the first model of a process)
         self._model_ref, self._opt_ref = weakref.ref(model), weakref.ref(optimizer)
@@ -74,6 +83,8 @@ class StepPlan:
         self.bwd = eng.plans.get(self.bwd_key)
         if self.fwd is None or self.bwd is None or self.fwd.tb_desc is None or self.bwd.x_gemm is not None or optimizer._fast_last.get(0) is None:
             raise NotApplicable("the fused transformer-block plans and the optimizer's launch cache are required")
+        if self.joint and not hasattr(self.bwd, "j_wk_ops"):
+            raise NotApplicable("joint-subject model: the per-subject weight gradients must be the fused block's (eegclip_wgrad_tok) launches")
         self.probs = probs
         dev = eng.device
         self.dev = dev
@@ -97,11 +108,13 @@ class StepPlan:
 
         # ---- the targets' operand planes: inputs only.  With the head on plane GEMMs (round 6) their split RIDES in the forward's 1x1-conv launch next to the
         # head weights' (csrc/split_rider.h: no launch, no second stream, no join); otherwise a second-stream launch under the encoder's forward (items below)
-        self.on_planes = bool(getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and eloss.head_gemm_enabled(B, 2 * B, Dm))
+        self.on_planes = bool(getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and eloss.head_gemm_enabled(B, T_ * B, Dm))
+        if self.mse_w and not self.on_planes:
+            raise NotApplicable("the reconstruction objective's plan needs the head on plane GEMMs (the MSE gradient is a slab of the upstream gradient)")
         self.split_op = None
         if not self.on_planes:
             self.split_op = len(pl.ops)
-            pl.ops.append((L.eegclip_split_rows, [None, 2, None], "eegclip_split_rows", os.environ.get("EEGCLIP_START_SIDE", "1") != "0"))
+            pl.ops.append((L.eegclip_split_rows, [None, T_, None], "eegclip_split_rows", os.environ.get("EEGCLIP_START_SIDE", "1") != "0"))
         # ---- encoder forward
         f0 = splice(self.fwd)
         self.fwd_base = f0
@@ -138,21 +151,21 @@ class StepPlan:
         # ---- image + text InfoNCE on the fused kernels (loss.py: _ClipLossFn.forward, the W == 1 fused branch).  Operand planes: the targets are inputs of the
         # step -- split (and, for the query gradient, split TRANSPOSED: round 6) by second-stream launches at the very start; the query features leave the
         # head's LayerNorm as planes (the same rounding as eegclip_split_rows), so no split launch sits between the forward and the loss
-        self.t_planes = torch.empty(2, 2 * B, Dm, dtype=torch.bfloat16, device=dev)             # hi | lo of [img; txt]
-        self.stack = None if self.on_planes else torch.empty(2 * B, Dm, dtype=torch.float32, device=dev)      # round 5's fp32 right-hand operand of the query gradient (loss.py)
+        self.t_planes = torch.empty(2, T_ * B, Dm, dtype=torch.bfloat16, device=dev)            # hi | lo of [img; txt]
+        self.stack = None if self.on_planes else torch.empty(T_ * B, Dm, dtype=torch.float32, device=dev)     # round 5's fp32 right-hand operand of the query gradient (loss.py)
         if self.on_planes:
-            self.items = (_abi.SplitItem * 4)()                    # this plan's own rider table: the forward plan's weights item + the two targets
+            self.items = (_abi.SplitItem * 4)()                    # this plan's own rider table: the forward plan's weights item + the targets
             self.items[0] = self.fwd.rider_items[0]
             self.item0 = 1
             pl._keep.append(self.items)
             pl.set_arg(self.fwd_base + self.fwd.rider_op, 23, self.items)
-            pl.set_arg(self.fwd_base + self.fwd.rider_op, 24, 3)
+            pl.set_arg(self.fwd_base + self.fwd.rider_op, 24, 1 + T_)
         else:
             self.items = (_abi.SplitItem * 2)()
             self.item0 = 0
             pl._keep.append(self.items)
             pl.ops[self.split_op][1][0] = self.items
-        for i in range(2):
+        for i in range(T_):
             self.items[self.item0 + i] = _abi.SplitItem(src=0, hi=self.t_planes[0, i * B:].data_ptr(), lo=self.t_planes[1, i * B:].data_ptr(), rows=B, cols=Dm,
                                                         ld_src=Dm, ld_out=Dm, transpose=0, copy=self.stack[i * B].data_ptr() if self.stack is not None else None,
                                                         ld_copy=Dm)
@@ -165,12 +178,12 @@ class StepPlan:
             pl.ops[self.out_op] = (L.eegclip_residual_layernorm_fwd_planes, args[:-1] + [self.q_planes[0].data_ptr(), self.q_planes[1].data_ptr(), None],
                                    "eegclip_residual_layernorm_fwd_planes", side)
         ws = int(L.eegclip_infonce_fused_workspace_floats(B, B))
-        self.if_buf = torch.empty(4 * (ws + 2 * B), dtype=torch.float32, device=dev)
+        self.if_buf = torch.empty(2 * T_ * (ws + 2 * B), dtype=torch.float32, device=dev)
         if self.on_planes:
             self.G = None
-            self.Gp = torch.empty(2, B, 2 * B, dtype=torch.bfloat16, device=dev)            # [G_img | G_txt] side by side, as hi | lo planes
+            self.Gp = torch.empty(2, B, T_ * B, dtype=torch.bfloat16, device=dev)           # [G_img | G_txt] side by side, as hi | lo planes
         else:
-            self.G = torch.empty(B, 2 * B, dtype=torch.float32, device=dev)
+            self.G = torch.empty(B, T_ * B, dtype=torch.float32, device=dev)
         base = self.if_buf.data_ptr()
 
         def planes_of(i):
@@ -178,22 +191,21 @@ class StepPlan:
             return (hi.data_ptr(), lo.data_ptr() if self.planes == 2 else None)
 
         ap = planes_of(0)
-        arr = (_abi.InfonceProblem * 4)()
-        weights = (self.alpha, 1.0 - self.alpha)
-        for t_, w in enumerate(weights):
+        arr = (_abi.InfonceProblem * (2 * T_))()
+        for t_, w in enumerate(self.weights):
             bp = planes_of(1 + t_)
             for j, (q, k) in enumerate(((ap, bp), (bp, ap))):
                 o = base + 4 * (2 * t_ + j) * (ws + 2 * B)
                 arr[2 * t_ + j] = _abi.InfonceProblem(q_hi=q[0], q_lo=q[1], k_hi=k[0], k_lo=k[1], col0=0, weight=0.5 * w, part=o, diag=o + 4 * ws,
                                                       lse=o + 4 * (ws + B), lse_k=None, G=None, ldg=0)
-        garr = (_abi.InfonceProblem * 2)()
-        for t_ in range(2):
+        garr = (_abi.InfonceProblem * T_)()
+        for t_ in range(T_):
             garr[t_] = arr[2 * t_]
             if self.on_planes:
-                garr[t_].G, garr[t_].ldg = None, 2 * B
+                garr[t_].G, garr[t_].ldg = None, T_ * B
                 garr[t_].G_hi, garr[t_].G_lo = self.Gp[0, :, t_ * B:].data_ptr(), self.Gp[1, :, t_ * B:].data_ptr()
             else:
-                garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), 2 * B
+                garr[t_].G, garr[t_].ldg = self.G[:, t_ * B:].data_ptr(), T_ * B
             garr[t_].lse_k = arr[2 * t_ + 1].lse
             garr[t_].part_k, garr[t_].diag_k = arr[2 * t_ + 1].part, arr[2 * t_ + 1].diag
         pl._keep += [arr, garr]
@@ -209,24 +221,29 @@ class StepPlan:
             accuracy_ops()
         # (loss.fused_infonce's training form: the forward leaves the per-tile partials, the gradient pass finalises them itself and adds the loss)
         if os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
-            pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, None)
+            pl.call("eegclip_infonce_fused_fwd", arr, 2 * T_, B, B, Dm, self.planes, B, sc_ptr, None)
             self.if_fwd_op = len(pl.ops)                                # (the op whose `loss` argument is patched per step)
-            pl.call("eegclip_infonce_fused_grad_finalize", garr, 2, B, B, Dm, self.planes, B, sc_ptr, 0, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
+            pl.call("eegclip_infonce_fused_grad_finalize", garr, T_, B, B, Dm, self.planes, B, sc_ptr, 0, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
         else:
-            for t_ in range(2):
+            for t_ in range(T_):
                 garr[t_].part_k = garr[t_].diag_k = None
             self.if_fwd_op = len(pl.ops)
-            pl.call("eegclip_infonce_fused_fwd", arr, 4, B, B, Dm, self.planes, B, sc_ptr, 0)
-            pl.call("eegclip_infonce_fused_grad", garr, 2, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())
-        # dA = [G_img | G_txt] [img; txt]: one launch, K = 2 B
+            pl.call("eegclip_infonce_fused_fwd", arr, 2 * T_, B, B, Dm, self.planes, B, sc_ptr, 0)
+            pl.call("eegclip_infonce_fused_grad", garr, T_, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())
+        # dA = [G_img | G_txt] [img; txt]: one launch, K = T B
+        self.mse_op = None
         if self.on_planes:
             # ... K-parallel from planes (csrc/head_gemm.hip); the encoder's backward adds the slabs while its first kernel loads them
-            S = int(L.eegclip_head_gemm_slices(B, Dm, 2 * B))
-            self.da = torch.empty(S, B, Dm, dtype=torch.float32, device=dev)
-            self.da_slices = S
+            S = int(L.eegclip_head_gemm_slices(B, Dm, T_ * B))
+            self.da = torch.empty(S + (1 if self.mse_w else 0), B, Dm, dtype=torch.float32, device=dev)
+            self.da_slices = S + (1 if self.mse_w else 0)
             pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=self.Gp[0].data_ptr(), a_lo=self.Gp[1].data_ptr(), b_hi=self.t_planes[0].data_ptr(),
-                                                               b_lo=self.t_planes[1].data_ptr(), lda=2 * B, ldb=Dm, M=B, N=Dm, K=2 * B, slices=S,
+                                                               b_lo=self.t_planes[1].data_ptr(), lda=T_ * B, ldb=Dm, M=B, N=Dm, K=T_ * B, slices=S,
                                                                slab_stride=B * Dm, C=self.da.data_ptr(), ldc=Dm, b_kmajor=1))
+            if self.mse_w:
+                # the MSE term: weight * mean((z - img)^2) added to the step's loss, its gradient = the LAST slab of the backward's upstream gradient
+                self.mse_op = len(pl.ops)
+                pl.call("eegclip_mse_loss_grad_scaled", 0, 0, B * Dm, self.mse_w, 0, self.da[S].data_ptr())
         else:
             self.da = torch.empty(B, Dm, dtype=torch.float32, device=dev)
             self.da_slices = 1
@@ -283,9 +300,9 @@ class StepPlan:
         from .atms import ATMS
         from .loss import ClipLoss, fused_enabled
         from .optim import AdamW
-        if not (enabled() and world == 1 and objective == "retrieval" and not keep_grads and _runtime_ok()):
+        if not (enabled() and world == 1 and objective in ("retrieval", "reconstruction") and not keep_grads and _runtime_ok()):
             return False
-        if not (isinstance(model, ATMS) and not model.joint_train and model.training and isinstance(subject_id, int)):
+        if not (isinstance(model, ATMS) and model.training and (isinstance(subject_id, int) or model.joint_train)):
             return False
         lf = model.loss_func
         if type(lf) is not ClipLoss or lf.world_size != 1:
@@ -293,7 +310,7 @@ class StepPlan:
         if not isinstance(optimizer, AdamW) or len(optimizer.param_groups) != 1 or optimizer.grad_scale_dev is not None:
             return False
         B = eeg_data.shape[0]
-        for t_, shape in ((eeg_data, None), (img, (B, 1024)), (txt, (B, 1024)), (class_feats, None)):
+        for t_, shape in ((eeg_data, None), (img, (B, 1024)), (class_feats, None)) + (((txt, (B, 1024)),) if objective == "retrieval" else ()):
             if not (_on_device(t_) and t_.dtype == torch.float32 and t_.is_contiguous() and not t_.requires_grad):
                 return False
             if shape is not None and tuple(t_.shape) != shape:
@@ -309,7 +326,7 @@ class StepPlan:
             return False
         if self._model_ref() is not model or self._opt_ref() is not optimizer:
             return False
-        if model.drop_probs(True) != self.probs or optimizer._fast_last.get(0) is not self.fast:
+        if model.drop_probs(True) != self.probs or not optimizer.activate_launch_set(0, self.fast):
             return False
         g = self.group
         if optimizer.param_groups[0] is not g or (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]) != self.hyper:
@@ -322,11 +339,30 @@ class StepPlan:
                     self.pl.set_arg(op, j, v)
         return all(p.grad is None for p in g["params"])
 
-    def run(self, eeg_data, img, txt, labels, class_feats, correct):
+    def run(self, eeg_data, img, txt, labels, class_feats, correct, subject_id=None):
         """enqueue one step; returns (features (B,1024), loss scalar) -- both device tensors, no host sync"""
         from .loss import _zero_pair
         eng, pl, B = self.eng, self.pl, self.B
         b = eng.bufs[B]
+        if self.joint:
+            # joint-subject model: the per-step subject layout (Embed.py:142-144) -- subject ids + the subject-ordered sample list go up in one asynchronous
+            # copy, the per-subject weight-gradient problems of the backward are re-pointed (atms._Engine._joint_layout, exactly as the ordinary path);
+            # the two arguments it patches on the backward plan's launches are mirrored onto this plan's copies
+            import numpy as np
+            from .retrieval import _uniform_ids
+            ids = _uniform_ids(B, subject_id, eeg_data.device)
+            host = getattr(ids, "_eegclip_host_ids", None)
+            if host is None:
+                host = np.full(B, int(subject_id), dtype=np.int64)
+            uid = getattr(ids, "_eegclip_uniform_id", None)
+            if uid is None or b.get("ids_uniform") != uid:
+                b["ids"].copy_(ids)
+                b["ids_uniform"] = uid
+            eng._joint_layout(self.fwd, b, B, host, eeg_data.data_ptr(), False)
+            eng._joint_layout(self.bwd, b, B, None, eeg_data.data_ptr(), True)
+            for op in self.bwd.j_wk_ops:
+                pl.set_arg(self.index_of("b", op), 1, self.bwd.ops[op][1][1])
+                pl.set_arg(self.index_of("b", op), 3, self.bwd.ops[op][1][3])
         self.fwd.tb_desc.x = eeg_data.data_ptr()
         out = torch.empty(B, 1024, dtype=torch.float32, device=self.dev)
         op = out.data_ptr()
@@ -348,7 +384,9 @@ class StepPlan:
                 self._class_ptr = cp
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
-        self.items[self.item0].src, self.items[self.item0 + 1].src = img.data_ptr(), txt.data_ptr()
+        self.items[self.item0].src = img.data_ptr()
+        if self.T > 1:
+            self.items[self.item0 + 1].src = txt.data_ptr()
         # the plan ACCUMULATES into the flat gradient buffer without attach_grads(): it must be clear.  It is when the optimizer's fused step cleared
         # exactly the views the last backward attached and nothing touched them since (every plan step leaves it so); after anything else -- a
         # keep_grads=True step, a manual backward followed by zero_grad(set_to_none=True): .grad is None but the buffer still holds values -- clear it here
@@ -356,6 +394,10 @@ class StepPlan:
             eng.gflat.zero_()
         acc = _zero_pair(self.dev)
         pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
+        if self.mse_op is not None:
+            pl.set_arg(self.mse_op, 0, op)
+            pl.set_arg(self.mse_op, 1, img.data_ptr())
+            pl.set_arg(self.mse_op, 4, acc.data_ptr())
         fast = self.fast
         fast["run_steps"] = [st + 1 for st in fast["run_steps"]]
         fast["pending"] += 1

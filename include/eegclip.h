@@ -251,6 +251,8 @@ int eegclip_ddpm_step(const float* x, const float* eps_c, const float* eps_u, fl
 int eegclip_prior_stage_infer(const float* x, const float* gamma, const float* beta, const float* skip, float* act_out, const float* te,
                               const float* ce, int ce_rows, float* xin_out, int rows, int cols, float eps, void* stream);
 int eegclip_mse_loss_grad(const float* pred, const float* target, long long n, float* loss, float* dpred, void* stream);
+/* the same with both outputs scaled by `weight` (a term of a mixed objective: Generation/ATMS_reconstruction.py:227) */
+int eegclip_mse_loss_grad_scaled(const float* pred, const float* target, long long n, float weight, float* loss, float* dpred, void* stream);
 
 /* ---- 64-token multi-head self-attention.  SelfAttention_Family.py:56-75
  * qkv: (B*L, ld) rows with q | k | v column blocks of H*E each; ctx/dctx: (B*L, H*E); dqkv like qkv.  L must be 64, E <= 64.
