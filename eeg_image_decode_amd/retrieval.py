@@ -165,7 +165,7 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
     else:       # joint-subject model with per-sample ids: the optimizer's launch set depends on WHICH subjects are present (their value embeddings are live)
         import numpy as np
         subj_key = tuple(np.unique(np.asarray(subject_id.cpu() if isinstance(subject_id, torch.Tensor) else subject_id, dtype=np.int64)).tolist())
-    key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subj_key, objective)
+    key = (id(optimizer), eeg_data.shape[0], float(alpha), class_feats.shape[0], subj_key, objective, edist.world_size())
     st = table.get(key)
     if st is not None and st["opt"]() is not optimizer:               # (an id reused by another optimizer)
         st = None
@@ -181,7 +181,7 @@ def _step_plan(eeg_model, optimizer, eeg_data, subject_id, img_features, text_fe
         return st, None
     if sp is None and st["warm"] >= StepPlan.WARM_STEPS and optimizer._fast_last.get(0) is not None and all(p.grad is None for p in optimizer.param_groups[0]["params"]):
         try:
-            st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0], objective)
+            st["plan"] = StepPlan(eeg_model, optimizer, eeg_data.shape[0], alpha, class_feats.shape[0], objective, edist.world_size())
             return st, st["plan"]
         except NotApplicable as e:                    # (anything else is a bug in the plan builder and propagates)
             st["plan"] = False                        # this configuration does not have the pieces (e.g. launch-per-Linear plans): ordinary path for good

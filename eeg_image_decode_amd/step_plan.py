@@ -55,10 +55,11 @@ class StepPlan:
     def eng(self):
         return self._eng_ref()
 
-    def __init__(self, model, optimizer, B, alpha, n_classes, objective="retrieval"):
+    def __init__(self, model, optimizer, B, alpha, n_classes, objective="retrieval", world=1):
         from . import loss as eloss
         from .atms import P_DIM
         eng = model._engine()
+        self.world = int(world)
         # the loss mix: retrieval = alpha * ClipLoss(z, img) + (1 - alpha) * ClipLoss(z, txt)  (ATMS_retrieval.py:224-234); reconstruction =
         # 10 * (alpha * MSE(z, img) + (1 - alpha) * ClipLoss(z, img))  (Generation/ATMS_reconstruction.py:222-228): one InfoNCE target + an MSE term whose
         # gradient joins the query gradient as one more slab of the backward's upstream gradient
@@ -76,13 +77,16 @@ class StepPlan:
         key = eng.last_key
         self.key = key
         Bk, train, shared, probs, W = key
-        if not (Bk == B and train and W == 1):
-            raise NotApplicable("the last forward was not a single-process training forward at this batch size")
-        self.bwd_key = ("b", B, train, shared, probs, False, W, False)
+        if not (Bk == B and train and W == (self.world if model.sync_batchnorm else 1)):
+            raise NotApplicable("the last forward was not a training forward of this job at this batch size")
+        early = self.world > 1 and os.environ.get("EEGCLIP_DP_OVERLAP", "1") != "0"
+        self.bwd_key = ("b", B, train, shared, probs, False, W, early)
         self.fwd = eng.plans.get(("f",) + key)
         self.bwd = eng.plans.get(self.bwd_key)
         if self.fwd is None or self.bwd is None or self.fwd.tb_desc is None or self.bwd.x_gemm is not None or optimizer._fast_last.get(0) is None:
             raise NotApplicable("the fused transformer-block plans and the optimizer's launch cache are required")
+        if self.world > 1 and (self.joint or objective != "retrieval"):
+            raise NotApplicable("data-parallel plans cover the retrieval objective of the single-subject model")
         if self.joint and not hasattr(self.bwd, "j_wk_ops"):
             raise NotApplicable("joint-subject model: the per-subject weight gradients must be the fused block's (eegclip_wgrad_tok) launches")
         self.probs = probs
@@ -108,7 +112,15 @@ class StepPlan:
 
         # ---- the targets' operand planes: inputs only.  With the head on plane GEMMs (round 6) their split RIDES in the forward's 1x1-conv launch next to the
         # head weights' (csrc/split_rider.h: no launch, no second stream, no join); otherwise a second-stream launch under the encoder's forward (items below)
-        self.on_planes = bool(getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and eloss.head_gemm_enabled(B, T_ * B, Dm))
+        self.on_planes = bool(self.world == 1 and getattr(self.fwd, "head_planes", False) and getattr(self.bwd, "head_planes", False) and
+                              eloss.head_gemm_enabled(B, T_ * B, Dm))
+        if self.world > 1:
+            # ---- data parallel (round 6): the same single plan, cut into segments by HOST CALLBACKS at the collectives -- the targets' all-gather (started
+            # before the forward), the SyncBN exchanges inside the spliced encoder plans, the loss (all-gather of the embeddings, the rank's row-sharded
+            # InfoNCE blocks, reduce-scatter of the gathered-copy gradients: loss._ClipLossFn's own code, called without autograd), the early gradient
+            # bucket's asynchronous all-reduce and the final one.  Every segment between two callbacks is one eegclip_plan_run call.
+            self._build_data_parallel(model, optimizer, eng, pl, splice, B, n_classes, Dm, L, dev)
+            return
         if self.mse_w and not self.on_planes:
             raise NotApplicable("the reconstruction objective's plan needs the head on plane GEMMs (the MSE gradient is a slab of the upstream gradient)")
         self.split_op = None
@@ -274,18 +286,82 @@ class StepPlan:
             pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
         pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
         # ---- fused AdamW + the zero_grad() that opens the next iteration
+        self._append_adamw(pl, optimizer)
+        self.pl = pl
+        self._class_ptr = None
+
+    def _build_data_parallel(self, model, optimizer, eng, pl, splice, B, n_classes, Dm, L, dev):
+        self.split_op = self.mse_op = None
+        self.if_fwd_op = None
+        self._cur = {}
+        pl.callback(lambda: model.loss_func.gather_targets(self._cur["img"], self._cur["txt"]), "allgather_targets")
+        f0 = splice(self.fwd)
+        self.fwd_base = f0
+        self.out_op = f0 + self.fwd.out_op
+        sc_ptr = model.logit_scale.detach().reshape(1).data_ptr()
+        ncp = (n_classes + 3) // 4 * 4
+        self.q_planes = torch.empty(2, B, Dm, dtype=torch.bfloat16, device=dev)
+        fn, args, name, side = pl.ops[self.out_op]
+        self.acc_on_planes = name == "eegclip_residual_layernorm_fwd_slabs" and os.environ.get("EEGCLIP_HEAD_GEMM", "1") != "0"
+        if self.acc_on_planes:
+            args[19], args[20] = self.q_planes[0].data_ptr(), self.q_planes[1].data_ptr()
+            self.logits = torch.empty(B, ncp, dtype=torch.float32, device=dev)
+            self.class_planes = torch.zeros(2, ncp, Dm, dtype=torch.bfloat16, device=dev)
+            self.acc_desc = None
+            pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=self.q_planes[0].data_ptr(), a_lo=self.q_planes[1].data_ptr(), b_hi=self.class_planes[0].data_ptr(),
+                                                               b_lo=self.class_planes[1].data_ptr(), lda=Dm, ldb=Dm, M=B, N=ncp, K=Dm, slices=1, slab_stride=0,
+                                                               C=self.logits.data_ptr(), ldc=ncp), side=True)
+        else:
+            self.logits = torch.empty(B, n_classes, dtype=torch.float32, device=dev)
+            self.acc_desc = _abi.GemmDesc(M=B, N=n_classes, K=Dm, A=0, Am=D(Dm), Ak=D(1), B=0, Bk=D(1), Bn=D(Dm), C=self.logits.data_ptr(), Cm=D(n_classes), Cn=D(1),
+                                          Cpre=None, bias_n=None, bias_m=None, R=None, Rm=D(0), Rn=D(0), alpha=1.0, accumulate=0, act=0, drop_p=0.0, seed=0,
+                                          drop_site=0, split_k=1, precision=self.fwd.precision)
+            pl._keep.append(self.acc_desc)
+            pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(self.acc_desc), None], "eegclip_gemm_f32", True))
+        self.count_op = len(pl.ops)
+        pl.call("eegclip_top1_count", self.logits.data_ptr(), B, n_classes, self.logits.shape[1], sc_ptr, 0, 0, side=True)
+        self.acc_early = True
+        # ---- the loss between the collectives
+        b0_holder = {}
+
+        def loss_cb():
+            import types
+            from .loss import _ClipLossFn
+            cur = self._cur
+            ctx = types.SimpleNamespace()
+            a = cur["out"].requires_grad_(True)                  # (a fresh leaf: only its requires_grad flag is read)
+            cur["loss"] = _ClipLossFn.forward(ctx, a, model.logit_scale, model.loss_func, self.weights, cur["img"], cur["txt"])
+            da, ds, _ = ctx.grads
+            cur["da"] = da                                        # (alive until the backward has been enqueued)
+            eng.G["logit_scale"].copy_(ds.reshape(eng.G["logit_scale"].shape))
+            pl.set_arg(b0_holder["b0"] + self.bwd.dout_op, 0, da.data_ptr())
+            pl.set_arg(b0_holder["b0"] + self.bwd.dout_par_op, 0, da.data_ptr())
+        pl.callback(loss_cb, "clip_loss_data_parallel")
+        # ---- encoder backward (its callbacks: SyncBN sums, the early bucket's asynchronous all-reduce)
+        b0 = len(pl.ops)
+        b0_holder["b0"] = b0
+        self.bwd_base, self.bwd_cut, self.bwd_shift = b0, len(self.bwd.ops), 0
+        splice(self.bwd)
+        from . import dist as edist
+        pl.callback(lambda: edist.average_flat_grads(eng.gflat, eng), "allreduce_flat_gradient")
+        pl.join()
+        self._append_adamw(pl, optimizer)
+        self.pl = pl
+        self._class_ptr = None
+        self.items, self.item0 = None, 0
+
+    def _append_adamw(self, pl, optimizer):
+        """fused AdamW + the zero_grad() that opens the next iteration: the optimizer's cached launches, the step count of every run patched per call"""
         fast = optimizer._fast_last.get(0)
         self.fast = fast
         self.group = optimizer.param_groups[0]
-        self.adam_ops = []                # (plan op, index into fast["launch"]): the step count of that run is patched per call
+        self.adam_ops = []                # (plan op, index into fast["launch"])
         gs = optimizer.grad_scale_dev.data_ptr() if optimizer.grad_scale_dev is not None else None
         b1, b2 = self.group["betas"]
         for li, (p0, n, wp, gp, mp, vp, members) in enumerate(fast["launch"]):
             self.adam_ops.append((len(pl.ops), li))
             pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"], 0, 1.0, gs)
         self.hyper = (self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"])
-        self.pl = pl
-        self._class_ptr = None
 
     def index_of(self, kind, i):
         """plan op index of op `i` of the spliced forward ("f") / backward ("b") plan (bench.py maps its per-launch timings through this)"""
@@ -300,12 +376,14 @@ class StepPlan:
         from .atms import ATMS
         from .loss import ClipLoss, fused_enabled
         from .optim import AdamW
-        if not (enabled() and world == 1 and objective in ("retrieval", "reconstruction") and not keep_grads and _runtime_ok()):
+        if not (enabled() and objective in ("retrieval", "reconstruction") and not keep_grads and _runtime_ok()):
+            return False
+        if world > 1 and (objective != "retrieval" or model.joint_train or os.environ.get("EEGCLIP_STEP_PLAN_DP", "1") == "0"):
             return False
         if not (isinstance(model, ATMS) and model.training and (isinstance(subject_id, int) or model.joint_train)):
             return False
         lf = model.loss_func
-        if type(lf) is not ClipLoss or lf.world_size != 1:
+        if type(lf) is not ClipLoss or lf.world_size != world:
             return False
         if not isinstance(optimizer, AdamW) or len(optimizer.param_groups) != 1 or optimizer.grad_scale_dev is not None:
             return False
@@ -317,7 +395,7 @@ class StepPlan:
                 return False
         if labels.dtype != torch.long or not _on_device(labels) or labels.numel() != B or class_feats.dim() != 2 or class_feats.shape[1] != 1024:
             return False
-        return bool(fused_enabled(B, B, 1024))
+        return world > 1 or bool(fused_enabled(B, B, 1024))
 
     def still_valid(self, model, optimizer):
         """the captured state is still the live one: same engine / plans / optimizer launch cache, nobody attached gradients or changed hyper-parameters"""
@@ -384,16 +462,20 @@ class StepPlan:
                 self._class_ptr = cp
         pl.set_arg(self.count_op, 5, labels.data_ptr())
         pl.set_arg(self.count_op, 6, correct.data_ptr())
-        self.items[self.item0].src = img.data_ptr()
-        if self.T > 1:
-            self.items[self.item0 + 1].src = txt.data_ptr()
+        if self.world > 1:
+            self._cur = {"img": img, "txt": txt, "out": out}
+        else:
+            self.items[self.item0].src = img.data_ptr()
+            if self.T > 1:
+                self.items[self.item0 + 1].src = txt.data_ptr()
         # the plan ACCUMULATES into the flat gradient buffer without attach_grads(): it must be clear.  It is when the optimizer's fused step cleared
         # exactly the views the last backward attached and nothing touched them since (every plan step leaves it so); after anything else -- a
         # keep_grads=True step, a manual backward followed by zero_grad(set_to_none=True): .grad is None but the buffer still holds values -- clear it here
         if eng._clear_for is None or eng._clear_for != eng._attached:
             eng.gflat.zero_()
-        acc = _zero_pair(self.dev)
-        pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
+        acc = _zero_pair(self.dev) if self.world == 1 else None
+        if self.if_fwd_op is not None:
+            pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
         if self.mse_op is not None:
             pl.set_arg(self.mse_op, 0, op)
             pl.set_arg(self.mse_op, 1, img.data_ptr())
@@ -413,4 +495,8 @@ class StepPlan:
         eng.version[B] = eng.version.get(B, 0) + 1
         for own, ptrs in fast["owners"]:
             own.grads_cleared(ptrs)
+        if self.world > 1:
+            loss = self._cur.pop("loss")
+            self._cur = {"da": self._cur.get("da")}
+            return out, loss.reshape(())
         return out, acc[0].reshape(())

@@ -435,6 +435,81 @@ def _loss_worker(rank, world, port, mode, ret):
     dist.destroy_process_group()
 
 
+def _dp_plan_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["HIPEMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    state_np = syn.make_state(SEED, oatms.state_spec())
+    n, steps = 4, 4
+    data = [(T(syn.eeg_batch(SEED + 50 + i, n * world)), T(syn.unit_features(SEED + 50 + i, n * world, tag="img")), T(syn.unit_features(SEED + 50 + i, n * world, tag="txt")))
+            for i in range(steps)]
+    sl = slice(rank * n, (rank + 1) * n)
+    classes = T(syn.unit_features(SEED + 42, 7, tag="cls"))
+    out = {}
+    with product_on_emulator():
+        from eeg_image_decode_amd import dist as edist
+        from eeg_image_decode_amd import optim, retrieval, step_plan
+        step_plan._runtime_ok = lambda: True
+        step_plan._on_device = lambda t: True
+        step_plan.StepPlan.WARM_STEPS = 2
+        for mode in ("1", "0"):
+            os.environ["EEGCLIP_STEP_PLAN"] = mode
+            m = make_model(state_np).train()
+            edist.configure_loss_for_world(m.loss_func, rank, world)
+            opt = optim.AdamW(m.parameters(), lr=3e-4)
+            acc, correct = [], torch.zeros(1, dtype=torch.int32)
+            seen, ncalls = [], []
+            real_ar = dist.all_reduce
+            cnt = {"n": 0}
+
+            def counted(*a, **k):
+                cnt["n"] += 1
+                return real_ar(*a, **k)
+            dist.all_reduce = counted
+            try:
+                for x, img, txt in data:
+                    cnt["n"] = 0
+                    retrieval.contrastive_step(m, opt, x[sl].contiguous(), 1, img[sl].contiguous(), txt[sl].contiguous(), torch.zeros(n, dtype=torch.long), classes, acc,
+                                               correct)
+                    seen.append(bool(retrieval.step_plans_of(m)))
+                    ncalls.append(cnt["n"])
+            finally:
+                dist.all_reduce = real_ar
+            assert seen == ([False, False, True, True] if mode == "1" else [False] * 4), seen
+            assert len(set(ncalls)) == 1, ncalls                              # the plan issues the ordinary path's all-reduces (4 SyncBN + the 2 gradient buckets)
+            if mode == "1":
+                plan = retrieval.step_plans_of(m)[0]
+                names = plan.pl.op_names()
+                for cb in ("allgather_targets", "allreduce_bn1", "allreduce_bn2", "clip_loss_data_parallel", "allreduce_bn2_bwd", "allreduce_early_bucket",
+                           "allreduce_flat_gradient"):
+                    assert cb in names, (cb, names)
+                assert all(p.grad is None for p in m.parameters()) and float(m._engine().gflat.abs().max()) == 0.0
+            out[mode] = ([float(a) for a in acc], {k: p.detach().clone().numpy() for k, p in m.named_parameters()}, int(correct))
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_plan_is_the_launch_by_launch_data_parallel_step():
+    """VERDICT r5 #4a: the single plan under data parallelism -- cut into segments by host callbacks at the collectives (targets' all-gather, SyncBN exchanges,
+    the loss between all-gather and reduce-scatter, the early gradient bucket, the final all-reduce).  Two gloo ranks, four steps (two ordinary, two through the
+    plan) against the same four steps with EEGCLIP_STEP_PLAN=0: per-step losses, the final parameters of both ranks, and rank-identical parameters."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_plan_worker, args=(2, 29641, ret), nprocs=2, join=True)
+    for r in range(2):
+        (la, pa, ca), (lb, pb, cb) = ret[r]["1"], ret[r]["0"]
+        np.testing.assert_allclose(la, lb, rtol=2e-5)
+        assert ca == cb
+        for k in pa:
+            if k.endswith("key_projection.bias"):
+                continue
+            d = np.abs(pa[k] - pb[k])
+            assert d.max() <= 4 * 3e-4 * 1.01 and (d > 5e-5).mean() <= 5e-3, (r, k, float(d.max()))
+    for k in ret[0]["1"][1]:
+        np.testing.assert_array_equal(ret[0]["1"][1][k], ret[1]["1"][1][k])      # the replicas stay identical
+
+
 @pytest.mark.parametrize("mode", [(False, False), (False, True), (True, True)])
 def test_clip_loss_gather_modes_match_reference_gloo_fixture(mode, golden):
     """B2: the three gather modes of models/loss.py:20-75, product ClipLoss under gloo vs the fixture recorded from the reference."""
