@@ -324,14 +324,18 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
             }
             __syncthreads();
         }
-        const bool two_norm = p_lse_k != nullptr || fin;
+        // key_only (round 6): no row normaliser given -- G[i][j] = c s (exp(S_ij - lse_k[j]) - [j == col0 + i]): the gradient matrix of the SWAPPED block,
+        // produced already transposed (rows = the gathered queries, columns = this rank's targets), i.e. k-contiguous for the GEMM that contracts over the
+        // rank's targets (the gathered-copy gradient of the row-sharded loss, models/loss.py:52-58,129-130)
+        const bool key_only = !fin && p_lse == nullptr;
+        const bool two_norm = (p_lse_k != nullptr && !key_only) || fin;
         const float two = two_norm ? 2.f : 1.f;
         const float c = p_weight * inv_total;
         float ds = 0.f;
 #pragma unroll
         for (int i = 0; i < (producer ? 0 : WT); ++i) {       // (the producer waves only take part in the reduction barriers below)
             const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const float lq = fin ? fin_q[q - q0] : p_lse[q];
+            const float lq = fin ? fin_q[q - q0] : (key_only ? 0.f : p_lse[q]);
             const int kb = k0r + wk * (TM / NWK);
             const int pos = p_col0 + q - kb;
             const long long goff = (long long)q * p_ldg + kb;
@@ -343,13 +347,13 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                     const int kk = 32 * j + 8 * eq + 4 * h;
                     f32x4 lk = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (fin) lk = *reinterpret_cast<const f32x4*>(fin_k + (kb - k0r) + kk);
-                    else if (two_norm) lk = *reinterpret_cast<const f32x4*>(p_lse_k + kb + kk);
+                    else if (two_norm || key_only) lk = *reinterpret_cast<const f32x4*>(p_lse_k + kb + kk);
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float raw = acc[j][i][4 * eq + e];
                         const float v = s * raw;
-                        float g = fast_exp(v - lq);
+                        float g = key_only ? fast_exp(v - lk[e]) : fast_exp(v - lq);
                         if (two_norm) g += fast_exp(v - lk[e]);
                         g -= (kk + e == pos) ? two : 0.f;
                         g *= c;
@@ -474,7 +478,7 @@ static int if_table_from(const eegclip_infonce_problem* probs, int nprob, int pl
     for (int i = 0; i < nprob; ++i) {
         const eegclip_infonce_problem& p = probs[i];
         const bool fin = grad && p.part_k != nullptr;
-        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || (!p.lse && !fin) || (!grad && (!p.part || !p.diag)) || (grad && ((!p.G && !p.G_hi) || (p.ldg & 3))))
+        if (!p.q_hi || !p.k_hi || (planes == 2 && (!p.q_lo || !p.k_lo)) || (!p.lse && !fin && !(grad && p.lse_k)) || (!grad && (!p.part || !p.diag)) || (grad && ((!p.G && !p.G_hi) || (p.ldg & 3))))
             return EEGCLIP_EINVAL;
         if ((p.G_hi != nullptr) != (p.G_lo != nullptr) || ((reinterpret_cast<uintptr_t>(p.G_hi) | reinterpret_cast<uintptr_t>(p.G_lo)) & 7u)) return EEGCLIP_EINVAL;
         if (fin != want_fin || (fin && (!p.part || !p.diag || !p.diag_k))) return EEGCLIP_EINVAL;

@@ -368,6 +368,8 @@ int eegclip_sampler_step(const void* x, const void* eps_u, const void* eps_c, co
  *   fused_grad   per block: G[i, j] = s * weight / n_total * (exp(S_ij - lse[i]) + (lse_k ? exp(S_ij - lse_k[j]) : 0) - (lse_k ? 2 : 1) [j == col0 + i])
  *                in fp32 (n x N, leading dimension ldg, ldg % 4 == 0) and *dscale += d loss / d s: then dQ = G K and dK = G^T Q are plain GEMMs.
  *                lse_k = the lse of the SWAPPED block (the column normaliser of the square single-process case: one G for both CE terms).
+ *                lse == NULL with lse_k given: the key-normalised term alone, G[i, j] = s * weight / n_total * (exp(S_ij - lse_k[j]) - [j == col0 + i]) -- the
+ *                swapped block's gradient matrix produced TRANSPOSED (rows = gathered queries, columns = the rank's targets; col0 may be negative).
  * planes = 1: one bf16 product (features rounded to bf16: logit error ~2^-9 |q||k|, the throughput mode); planes = 2: q k = q_hi k_hi + q_hi k_lo +
  * q_lo k_hi, fp32 accumulate (logits within ~5e-5 of exact fp32 products: the parity mode).  All blocks of one call share n, N, D; at most 8.
  * Supported shapes: n, N, D multiples of 64 (eegclip_infonce_fused_supported); anything else takes the GEMM + lse_rows/lse_cols route. */

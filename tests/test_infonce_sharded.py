@@ -63,6 +63,31 @@ def _simulate_job(ploss, dev, world, n, mode, planes=2):
     return out
 
 
+def _simulate_training_job(ploss, dev, world, n, planes=2):
+    """the TRAINING configuration (local_loss + gather_with_grad, frozen targets): sharded_blocks takes the all-planes route (round 6); the gradient of a
+    rank's queries = its own part + its rows of the reduce-scattered gathered-copy gradients"""
+    a_np, b_np = _features(world, n)
+    a_all, b_all = torch.from_numpy(a_np).to(dev), torch.from_numpy(b_np).to(dev)
+    sc = torch.full((1,), S0, dtype=torch.float32, device=dev)
+    per_rank, ga_sum = [], None
+    calls = []
+    real = ploss._sharded_blocks_on_planes
+    ploss._sharded_blocks_on_planes = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for r in range(world):
+            acc = torch.zeros(2, dtype=torch.float32, device=dev)
+            sl = slice(r * n, (r + 1) * n)
+            da, ga, dbs, gbs = ploss.sharded_blocks(True, True, r, world, a_all[sl].contiguous(), [b_all[sl].contiguous()], a_all, [b_all], (1.0,), sc, acc, True,
+                                                    [False], True, planes)
+            assert dbs == [None] and gbs == [None]
+            per_rank.append((acc.clone(), da))
+            ga_sum = ga.clone() if ga_sum is None else ga_sum + ga
+    finally:
+        ploss._sharded_blocks_on_planes = real
+    assert len(calls) == world, "the all-planes route was not taken"
+    return [(float(acc[0]), (da + ga_sum[r * n:(r + 1) * n]).cpu().numpy(), None, float(acc[1])) for r, (acc, da) in enumerate(per_rank)]
+
+
 def _check_against_the_reference_fixture(out, world, n, mode):
     g = np.load(os.path.join(GOLDEN, "dist_loss_fused.npz"))
     tag = f"w{world}_n{n}_ll{int(mode[0])}_gwg{int(mode[1])}"
@@ -72,7 +97,8 @@ def _check_against_the_reference_fixture(out, world, n, mode):
         assert abs(loss - g[tag + "_loss"][r]) < 1e-4, (r, loss, g[tag + "_loss"][r])
         ra, rb = g[tag + "_da"][r], g[tag + "_db"][r]
         np.testing.assert_allclose(da[:, :cols], ra, atol=5e-4 * np.abs(ra).max(), err_msg=f"{tag} rank {r} da")
-        np.testing.assert_allclose(db[:, :cols], rb, atol=5e-4 * np.abs(rb).max(), err_msg=f"{tag} rank {r} db")
+        if db is not None:
+            np.testing.assert_allclose(db[:, :cols], rb, atol=5e-4 * np.abs(rb).max(), err_msg=f"{tag} rank {r} db")
         assert abs(ds - g[tag + "_ds"][r]) < 2e-4 * abs(g[tag + "_ds"][r]), (r, ds, g[tag + "_ds"][r])
 
 
@@ -87,7 +113,36 @@ def test_simulated_two_rank_job_on_the_emulator_matches_the_reference_gloo_fixtu
     _check_against_the_reference_fixture(out, 2, 64, mode)
 
 
+@pytest.mark.emu
+def test_training_configuration_on_planes_on_the_emulator_matches_the_reference_gloo_fixture():
+    from emu_patch import product_on_emulator
+    with product_on_emulator():
+        from eeg_image_decode_amd import loss as ploss
+        out = _simulate_training_job(ploss, "cpu", 2, 64)
+    _check_against_the_reference_fixture(out, 2, 64, (True, True))
+
+
 # ------------------------------------------------------------------------------------------------ MI355X
+@pytest.mark.gpu
+@pytest.mark.parametrize("planes", [2, 1])
+@pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (8, 256)])
+def test_training_configuration_on_planes_on_the_gpu_matches_the_reference_gloo_fixture(world, n, planes):
+    """frozen targets, local_loss + gather_with_grad: gradient matrices as planes, the swapped blocks' produced transposed, both gradient GEMMs K-parallel from
+    planes (round 6) -- every rank of the job against the reference's own ClipLoss under gloo"""
+    from eeg_image_decode_amd import loss as ploss
+    out = _simulate_training_job(ploss, "cuda", world, n, planes)
+    if planes == 2:
+        _check_against_the_reference_fixture(out, world, n, (True, True))
+    else:       # one bf16 product per multiply-add: the throughput arithmetic, within its documented distance of the reference
+        g = np.load(os.path.join(GOLDEN, "dist_loss_fused.npz"))
+        tag = f"w{world}_n{n}_ll1_gwg1"
+        for r in range(world):
+            assert abs(out[r][0] - g[tag + "_loss"][r]) < 5e-3
+            ra = g[tag + "_da"][r]
+            np.testing.assert_allclose(out[r][1][:, :ra.shape[1]], ra, atol=3e-2 * np.abs(ra).max())
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (8, 256)])
