@@ -216,6 +216,10 @@ PROTOTYPES = {
     "eegclip_token_block_bwd": [C.POINTER(TokenBlockBwdDesc), _I, _P],
     "eegclip_gemm_planes": [C.POINTER(GemmPlanesDesc), _P],
     "eegclip_split_transpose": [C.POINTER(SplitItem), _I, _P],
+    "eegclip_infonce_small_supported": [_I, _I],
+    "eegclip_infonce_small_workspace_floats": [_I, _I],
+    "eegclip_infonce_small_fwd": [_P, _I, _L, _I, _I, _P, _P, _P],
+    "eegclip_infonce_small_grad": [_I, _I, _P, _P, _F, _F, _F, _F, _P, _P, _L, _P, _P, _P],
     "eegclip_conv16": [C.POINTER(Conv16Desc), _P],
     "eegclip_groupnorm16": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P, _I, _P],
     "eegclip_softmax_rows16": [_P, _I, _I, _L, _F, _I, _P],

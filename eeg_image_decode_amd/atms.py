@@ -1201,7 +1201,12 @@ class _Engine:
                 pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
         # (the tap gradient leaves the apply pass as one partial row per sample; their sum is read by the optimizer only: second stream)
         pl.call_desc("eegclip_cstack_bwd_apply", _abi.CstackBwdDesc(stat=stat, nstat=nstat, stat_local=local, nstat_local=nlocal, **dict(common, dw25=None)))
-        taps = lambda: pl.call("eegclip_cstack_bwd_taps_reduce", _p(b["csb_ws"]), B, _p(G[_TS + "0.weight"]), side=True)      # noqa: E731
+        pl.early_cut = len(pl.ops)          # every gradient of the early bucket (loss scale, conv stack, head) has been ISSUED once the ops before this index
+        #                                     and the taps reduction below have: the step plan starts their optimizer update here (step_plan.py)
+
+        def taps():
+            pl.taps_op = len(pl.ops)
+            pl.call("eegclip_cstack_bwd_taps_reduce", _p(b["csb_ws"]), B, _p(G[_TS + "0.weight"]), side=True)
         if early_reduce or not defer_small:
             taps()
         else:

@@ -81,8 +81,8 @@ def head_gemm_enabled(n, K, Dm):
 
 
 def stacked_target_planes(a_, bs, planes):
-    """ONE split launch for the query features and the T targets: (ap, [bp_t], tp) -- tp = the targets' planes STACKED, (2, T n, D): hi | lo of [B_1; ..; B_T],
-    the k-major B operand of the query-gradient GEMM as it is (bp_t are its row blocks)"""
+    """ONE split launch for the query features and the T targets: (ap, [bp_t], tp, aq) -- tp = the targets' planes STACKED, (2, T n, D): hi | lo of [B_1; ..; B_T],
+    the k-major B operand of the query-gradient GEMM as it is (bp_t are its row blocks); aq = the query planes as one (2, n, D) tensor"""
     n, Dm = a_.shape
     T_ = len(bs)
     dev = a_.device
@@ -94,7 +94,7 @@ def stacked_target_planes(a_, bs, planes):
         items[1 + t] = _abi.SplitItem(src=b_.data_ptr(), hi=tp[0, t * n:].data_ptr(), lo=tp[1, t * n:].data_ptr(), rows=n, cols=Dm, ld_src=Dm, ld_out=Dm, transpose=0)
     check(lib().eegclip_split_rows(items, T_ + 1, _stream()), "split_rows")
     pick = (lambda hi, lo: (hi, lo if planes == 2 else None))
-    return pick(aq[0], aq[1]), [pick(tp[0, t * n:(t + 1) * n], tp[1, t * n:(t + 1) * n]) for t in range(T_)], tp
+    return pick(aq[0], aq[1]), [pick(tp[0, t * n:(t + 1) * n], tp[1, t * n:(t + 1) * n]) for t in range(T_)], tp, aq
 
 
 def query_grad_slabs(Gp, tp, n, K, Dm, slabs=None):
@@ -109,6 +109,29 @@ def query_grad_slabs(Gp, tp, n, K, Dm, slabs=None):
                           slices=S, slab_stride=n * Dm, C=slabs.data_ptr(), ldc=Dm, b_kmajor=1)
     check(L.eegclip_head_gemm(ctypes.byref(d), _stream()), "head_gemm")
     return slabs, S
+
+
+def infonce_small_enabled(n, T_, planes):
+    """one process at the training batch size: logits as ONE K-parallel plane GEMM + two row-block kernels (csrc/infonce_small.hip, round 6) instead of the
+    tile kernels' 64 workgroups that each walk D alone; EEGCLIP_INFONCE_SMALL=0 pins the tile kernels"""
+    return planes == 2 and os.environ.get("EEGCLIP_INFONCE_SMALL", "1") != "0" and bool(lib().eegclip_infonce_small_supported(int(n), int(T_)))
+
+
+def infonce_small(aq, tp, n, T_, Dm, weights, sc, acc, Gp):
+    """loss / d scale added to acc[0] / acc[1]; G = [G_1 | .. | G_T] as planes into Gp (2, n, T n).  aq: query planes (2, n, D), tp: stacked target planes (2, T n, D)"""
+    L, st = lib(), _stream()
+    NC = T_ * n
+    S = min(8, int(L.eegclip_head_gemm_slices(n, NC, Dm)))            # (eegclip_infonce_small_fwd adds at most 8 slabs)
+    slabs = torch.empty(S, n, NC, dtype=torch.float32, device=aq.device)
+    d = _abi.HeadGemmDesc(a_hi=aq[0].data_ptr(), a_lo=aq[1].data_ptr(), b_hi=tp[0].data_ptr(), b_lo=tp[1].data_ptr(), lda=Dm, ldb=Dm, M=n, N=NC, K=Dm, slices=S,
+                          slab_stride=n * NC, C=slabs.data_ptr(), ldc=NC)
+    check(L.eegclip_head_gemm(ctypes.byref(d), st), "head_gemm")
+    ws = torch.empty(int(L.eegclip_infonce_small_workspace_floats(n, T_)), dtype=torch.float32, device=aq.device)
+    check(L.eegclip_infonce_small_fwd(slabs.data_ptr(), S, n * NC, n, T_, sc.data_ptr(), ws.data_ptr(), st), "infonce_small_fwd")
+    w4 = [float(w) for w in weights] + [0.0] * (4 - T_)
+    check(L.eegclip_infonce_small_grad(n, T_, sc.data_ptr(), ws.data_ptr(), *w4, Gp[0].data_ptr(), Gp[1].data_ptr(), NC, acc.data_ptr(), acc.data_ptr() + 4, st),
+          "infonce_small_grad")
+    Gp._eegclip_keep = (slabs, ws)
 
 
 def add_slabs(slabs):
@@ -436,8 +459,9 @@ class _ClipLossFn(torch.autograd.Function):
             # targets are split transposed, dA = the GEMM's slabs added in slice order (the step plan hands the slabs to the encoder's backward as they are)
             on_planes = need_a and need and not any(need_b) and head_gemm_enabled(n, T_ * n, Dm)
             stack = torch.empty(T_ * n, Dm, dtype=torch.float32, device=dev) if stacked and not on_planes else None
+            small = on_planes and infonce_small_enabled(n, T_, planes)
             if on_planes:
-                ap, bps, tp = stacked_target_planes(a_, bs, planes)
+                ap, bps, tp, aq = stacked_target_planes(a_, bs, planes)
             else:
                 ap, *bps = split_planes_many([a_] + bs, planes, stack)
             blocks, want = [], []
@@ -446,7 +470,10 @@ class _ClipLossFn(torch.autograd.Function):
                 want.append((2 * t, 2 * t + 1))
             if on_planes:
                 Gp = torch.empty(2, n, T_ * n, dtype=torch.bfloat16, device=dev)
-                fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want, None, [(Gp[0, :, t * n:(t + 1) * n], Gp[1, :, t * n:(t + 1) * n]) for t in range(T_)])
+                if small:
+                    infonce_small(aq, tp, n, T_, Dm, weights, sc, acc, Gp)
+                else:
+                    fused_infonce(blocks, n, n, Dm, planes, n, sc, acc, want, None, [(Gp[0, :, t * n:(t + 1) * n], Gp[1, :, t * n:(t + 1) * n]) for t in range(T_)])
                 da = add_slabs(query_grad_slabs(Gp, tp, n, T_ * n, Dm)[0])
                 stacked, Gs = False, None
                 need_a = False                                    # (da is complete)

@@ -231,15 +231,31 @@ class StepPlan:
         self.acc_early = os.environ.get("EEGCLIP_ACC_EARLY", "1") != "0" and self.acc_on_planes
         if self.acc_early:
             accuracy_ops()
+        self.small = self.on_planes and eloss.infonce_small_enabled(B, T_, self.planes)
+        if self.small:
+            # (round 6) one process at the training batch size: the raw logits of all targets as ONE K-parallel plane GEMM, then two row-block kernels
+            # (csrc/infonce_small.hip) -- the tile kernels below are 64 workgroups that each walk D alone (12 + 17 us of the critical path at B = 256)
+            NC = T_ * B
+            S_ = min(8, int(L.eegclip_head_gemm_slices(B, NC, Dm)))
+            self.s_slabs = torch.empty(S_, B, NC, dtype=torch.float32, device=dev)
+            self.s_ws = torch.empty(int(L.eegclip_infonce_small_workspace_floats(B, T_)), dtype=torch.float32, device=dev)
+            pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=self.q_planes[0].data_ptr(), a_lo=self.q_planes[1].data_ptr(), b_hi=self.t_planes[0].data_ptr(),
+                                                               b_lo=self.t_planes[1].data_ptr(), lda=Dm, ldb=Dm, M=B, N=NC, K=Dm, slices=S_, slab_stride=B * NC,
+                                                               C=self.s_slabs.data_ptr(), ldc=NC))
+            pl.call("eegclip_infonce_small_fwd", self.s_slabs.data_ptr(), S_, B * NC, B, T_, sc_ptr, self.s_ws.data_ptr())
+            w4 = list(self.weights) + [0.0] * (4 - T_)
+            self.if_fwd_op, self.loss_arg = len(pl.ops), 11                 # (the op whose `loss` argument is patched per step)
+            pl.call("eegclip_infonce_small_grad", B, T_, sc_ptr, self.s_ws.data_ptr(), *w4, self.Gp[0].data_ptr(), self.Gp[1].data_ptr(), NC, 0,
+                    eng.G["logit_scale"].data_ptr())                        # d loss / d scale straight into its gradient
         # (loss.fused_infonce's training form: the forward leaves the per-tile partials, the gradient pass finalises them itself and adds the loss)
-        if os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
+        elif os.environ.get("EEGCLIP_INFONCE_INLINE_FINALIZE", "1") != "0":
             pl.call("eegclip_infonce_fused_fwd", arr, 2 * T_, B, B, Dm, self.planes, B, sc_ptr, None)
-            self.if_fwd_op = len(pl.ops)                                # (the op whose `loss` argument is patched per step)
+            self.if_fwd_op, self.loss_arg = len(pl.ops), 8                  # (the op whose `loss` argument is patched per step)
             pl.call("eegclip_infonce_fused_grad_finalize", garr, T_, B, B, Dm, self.planes, B, sc_ptr, 0, eng.G["logit_scale"].data_ptr())      # d loss / d scale straight into its gradient
         else:
             for t_ in range(T_):
                 garr[t_].part_k = garr[t_].diag_k = None
-            self.if_fwd_op = len(pl.ops)
+            self.if_fwd_op, self.loss_arg = len(pl.ops), 8
             pl.call("eegclip_infonce_fused_fwd", arr, 2 * T_, B, B, Dm, self.planes, B, sc_ptr, 0)
             pl.call("eegclip_infonce_fused_grad", garr, T_, B, B, Dm, self.planes, B, sc_ptr, eng.G["logit_scale"].data_ptr())
         # dA = [G_img | G_txt] [img; txt]: one launch, K = T B
@@ -264,29 +280,49 @@ class StepPlan:
                               seed=0, drop_site=0, split_k=1, precision=_abi.PREC_BF16X3)
             pl._keep.append(d)
             pl.ops.append((L.eegclip_gemm_f32, [ctypes.byref(d), None], "eegclip_gemm_f32", False))
-        # ---- encoder backward, the accuracy readout behind its first second-stream launch
-        cut = self.bwd.dout_par_op + 1
+        # ---- encoder backward, op by op (self.bwd_index: backward-plan op -> this plan's op).  Inserted on the way: the accuracy readout behind the backward's
+        # first second-stream launch (unless it forked behind the forward), and -- round 6 -- the optimizer update of the EARLY gradient bucket (loss scale,
+        # conv stack, projection head: 82 % of the parameters) on the second stream as soon as the conv stack's backward has issued its last gradient, under
+        # the transformer block's backward; the update at the end of the step then covers only the block's parameters (17 -> ~5 us on the exposed tail)
+        self._plan_adamw(optimizer, eng)
+        early_cut = getattr(self.bwd, "early_cut", None) if (self.adam_early and os.environ.get("EEGCLIP_ADAMW_EARLY", "1") != "0") else None
+        taps_op = getattr(self.bwd, "taps_op", None)
+        if early_cut is None or (taps_op is not None and taps_op < early_cut):
+            early_cut = None
         b0 = len(pl.ops)
-        self.bwd_base, self.bwd_cut = b0, cut
-        splice(self.bwd, 0, cut)
-        n0 = len(pl.ops)
-        if not self.acc_early:
-            accuracy_ops()
-        self.bwd_shift = len(pl.ops) - n0
-        splice(self.bwd, cut, len(self.bwd.ops), at=b0 + self.bwd_shift)
-        pl.set_arg(b0 + self.bwd.dout_op, 0, self.da.data_ptr())
+        self.bwd_base = b0
+        self.bwd_index = [None] * len(self.bwd.ops)
+        pl._seed_descs += self.bwd._seed_descs
+
+        def emit_bwd(i):
+            fn, args, name, side = self.bwd.ops[i]
+            self.bwd_index[i] = len(pl.ops)
+            pl.ops.append((fn, list(args), name, side))
+            pl._seed_slots += [(self.bwd_index[i], j) for i0, j in self.bwd._seed_slots if i0 == i]
+
+        for i in range(len(self.bwd.ops)):
+            if early_cut is not None and i == taps_op:
+                continue                                     # (moved in front of the early update)
+            emit_bwd(i)
+            if i == self.bwd.dout_par_op and not self.acc_early:
+                accuracy_ops()
+            if early_cut is not None and i == early_cut - 1:
+                if taps_op is not None:
+                    emit_bwd(taps_op)
+                self._emit_adamw(pl, self.adam_early, side=True)
+        pl.set_arg(self.bwd_index[self.bwd.dout_op], 0, self.da.data_ptr())
         if self.on_planes:
             # the backward's first kernel adds the S slabs while it loads them and leaves the sum for the parameter half of the head's LayerNorm
             bb = eng.bufs[B]
-            pl.set_arg(b0 + self.bwd.dout_op, 1, self.da_slices)
-            pl.set_arg(b0 + self.bwd.dout_op, 2, B * Dm)
-            pl.set_arg(b0 + self.bwd.dout_op, 13, bb["dout_sum"].data_ptr())
-            pl.set_arg(b0 + self.bwd.dout_par_op, 0, bb["dout_sum"].data_ptr())
+            pl.set_arg(self.bwd_index[self.bwd.dout_op], 1, self.da_slices)
+            pl.set_arg(self.bwd_index[self.bwd.dout_op], 2, B * Dm)
+            pl.set_arg(self.bwd_index[self.bwd.dout_op], 13, bb["dout_sum"].data_ptr())
+            pl.set_arg(self.bwd_index[self.bwd.dout_par_op], 0, bb["dout_sum"].data_ptr())
         else:
-            pl.set_arg(b0 + self.bwd.dout_par_op, 0, self.da.data_ptr())
+            pl.set_arg(self.bwd_index[self.bwd.dout_par_op], 0, self.da.data_ptr())
         pl.join()               # the optimizer reads every gradient (second-stream weight gradients) and rewrites logit_scale (read by the accuracy readout)
-        # ---- fused AdamW + the zero_grad() that opens the next iteration
-        self._append_adamw(pl, optimizer)
+        # ---- fused AdamW + the zero_grad() that opens the next iteration (what the early update has not taken)
+        self._emit_adamw(pl, self.adam_late if early_cut is not None else self.adam_early + self.adam_late)
         self.pl = pl
         self._class_ptr = None
 
@@ -340,34 +376,54 @@ class StepPlan:
         # ---- encoder backward (its callbacks: SyncBN sums, the early bucket's asynchronous all-reduce)
         b0 = len(pl.ops)
         b0_holder["b0"] = b0
-        self.bwd_base, self.bwd_cut, self.bwd_shift = b0, len(self.bwd.ops), 0
+        self.bwd_base = b0
+        self.bwd_index = [b0 + i for i in range(len(self.bwd.ops))]
         splice(self.bwd)
         from . import dist as edist
         pl.callback(lambda: edist.average_flat_grads(eng.gflat, eng), "allreduce_flat_gradient")
         pl.join()
-        self._append_adamw(pl, optimizer)
+        self._plan_adamw(optimizer, eng)
+        self._emit_adamw(pl, self.adam_early + self.adam_late)
         self.pl = pl
         self._class_ptr = None
         self.items, self.item0 = None, 0
 
-    def _append_adamw(self, pl, optimizer):
-        """fused AdamW + the zero_grad() that opens the next iteration: the optimizer's cached launches, the step count of every run patched per call"""
+    def _plan_adamw(self, optimizer, eng):
+        """the optimizer's cached launches of this step (optim.AdamW: one per contiguous run of live parameters), each cut at the end of the engine's EARLY
+        gradient bucket: self.adam_early / self.adam_late = [(launch index, weights, grads, m, v, count)]"""
         fast = optimizer._fast_last.get(0)
         self.fast = fast
         self.group = optimizer.param_groups[0]
-        self.adam_ops = []                # (plan op, index into fast["launch"])
-        gs = optimizer.grad_scale_dev.data_ptr() if optimizer.grad_scale_dev is not None else None
-        b1, b2 = self.group["betas"]
+        self.adam_ops = []                # (plan op, index into fast["launch"]): the step count of that run is patched per call
+        self.adam_early, self.adam_late = [], []
+        base, (a0, a1) = eng.flat.data_ptr(), eng.early_bucket
         for li, (p0, n, wp, gp, mp, vp, members) in enumerate(fast["launch"]):
+            off = (wp - base) // 4
+            if not (0 <= off < eng.flat.numel()) or gp - eng.gflat.data_ptr() != wp - base:
+                self.adam_late.append((li, wp, gp, mp, vp, n))                       # (not a run of this engine's flat buffers)
+                continue
+            n_early = max(0, min(off + n, a1) - max(off, a0)) if off <= a0 else 0    # (a run that starts inside the bucket is not cut)
+            if off == a0 and n_early > 0:
+                self.adam_early.append((li, wp, gp, mp, vp, n_early))
+                if n > n_early:
+                    self.adam_late.append((li, wp + 4 * n_early, gp + 4 * n_early, mp + 4 * n_early, vp + 4 * n_early, n - n_early))
+            else:
+                self.adam_late.append((li, wp, gp, mp, vp, n))
+        g = self.group
+        self.hyper = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
+
+    def _emit_adamw(self, pl, launches, side=False):
+        gs = None
+        lr, b1, b2, eps, wd = self.hyper
+        for li, wp, gp, mp, vp, n in launches:
             self.adam_ops.append((len(pl.ops), li))
-            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"], 0, 1.0, gs)
-        self.hyper = (self.group["lr"], b1, b2, self.group["eps"], self.group["weight_decay"])
+            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, lr, b1, b2, eps, wd, 0, 1.0, gs, side=side)
 
     def index_of(self, kind, i):
         """plan op index of op `i` of the spliced forward ("f") / backward ("b") plan (bench.py maps its per-launch timings through this)"""
         if kind == "f":
             return self.fwd_base + i
-        return self.bwd_base + i + (self.bwd_shift if i >= self.bwd_cut else 0)
+        return self.bwd_index[i]
 
     # ------------------------------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -475,7 +531,7 @@ class StepPlan:
             eng.gflat.zero_()
         acc = _zero_pair(self.dev) if self.world == 1 else None
         if self.if_fwd_op is not None:
-            pl.set_arg(self.if_fwd_op, 8, acc.data_ptr())
+            pl.set_arg(self.if_fwd_op, self.loss_arg, acc.data_ptr())
         if self.mse_op is not None:
             pl.set_arg(self.mse_op, 0, op)
             pl.set_arg(self.mse_op, 1, img.data_ptr())

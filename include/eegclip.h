@@ -579,6 +579,19 @@ int eegclip_gemm_planes(const eegclip_gemm_planes_desc* d, void* stream);
  * matrices) */
 int eegclip_split_transpose(const eegclip_split_item* items, int n, void* stream);
 
+/* ---- InfoNCE of one process at the training batch size (csrc/infonce_small.hip; models/loss.py:122-140 with world_size = 1): the raw logits of all T targets
+ * are ONE K-parallel eegclip_head_gemm launch (A = the query planes, B = the targets' planes stacked, M = n, N = T n: partial slabs), then
+ *   eegclip_infonce_small_fwd   adds the slabs, keeps the raw logits, row log-sum-exps, positives and per-row-block column partials in `workspace`
+ *                               (eegclip_infonce_small_workspace_floats(n, T) floats)
+ *   eegclip_infonce_small_grad  finishes the column log-sum-exps, adds sum_t w_t * ClipLoss_t to *loss and d loss / d scale to *dscale, and writes
+ *                               G = [G_1 | .. | G_T] (n, ldg), G_t = s dL/dS_t, as bf16 hi | lo planes -- the A operand of dQ = G [B_1; ..; B_T]
+ * n a multiple of 64 and <= 1024, T <= 4 (eegclip_infonce_small_supported). */
+int eegclip_infonce_small_supported(int n, int T);
+long long eegclip_infonce_small_workspace_floats(int n, int T);
+int eegclip_infonce_small_fwd(const float* slabs, int nslabs, long long slab_stride, int n, int T, const float* scale, float* workspace, void* stream);
+int eegclip_infonce_small_grad(int n, int T, const float* scale, const float* workspace, float w0, float w1, float w2, float w3, void* g_hi, void* g_lo,
+                               long long ldg, float* loss, float* dscale, void* stream);
+
 /* ---- the SDXL VAE's layers (csrc/vae.hip; Generation/custom_pipeline_low_level.py:8-31 `vae.encode`, Generation/custom_pipeline.py:421 `vae.decode`; the module is
  * diffusers 0.30.0's AutoencoderKL, not vendored by the reference) on 16-bit PADDED NHWC activations: a tensor is [image][H + 2 pad][W + 2 pad][C] with a zero
  * border that no launch writes (pad = 1; 0 for tensors that only 1 x 1 layers / the attention read).

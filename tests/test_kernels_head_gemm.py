@@ -311,3 +311,51 @@ def test_split_rows_lds_free_transposing_path_writes_column_blocks_without_paddi
     np.testing.assert_array_equal(l_, l2)
     bad = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(B0), hi=be.ptr(hi), lo=be.ptr(lo), rows=n - 1, cols=Dm, ld_src=Dm, ld_out=2 * n, transpose=2))
     assert be.lib.eegclip_split_rows(bad, 1, be.stream) != 0               # rows % 4 != 0
+
+
+@pytest.mark.parametrize("n,T,nslabs", [(64, 2, 3), (128, 1, 1)])
+def test_infonce_small_against_fp64(be, n, T, nslabs):
+    """csrc/infonce_small.hip: from partial slabs of the raw logits -> loss, d loss / d scale and the gradient matrices as planes, against an fp64 evaluation of
+    models/loss.py:122-140 (symmetric cross-entropy of S = s A B^T, RAW scale) for T targets with weights w_t"""
+    rng = np.random.default_rng(n + T)
+    NC = T * n
+    raw = (rng.standard_normal((n, NC)) * 4).astype(np.float32)
+    parts = rng.standard_normal((nslabs, n, NC)).astype(np.float32)
+    parts[nslabs - 1] = raw - parts[:nslabs - 1].sum(0)
+    tot = parts[0].copy()
+    for i in range(1, nslabs):
+        tot = tot + parts[i]
+    stride = n * NC + 16
+    buf = np.full(nslabs * stride, np.nan, np.float32)
+    for i in range(nslabs):
+        buf[i * stride:i * stride + n * NC] = parts[i].ravel()
+    s = np.float32(2.6593)
+    w = [0.99, 0.01][:T] if T == 2 else [0.7]
+    SL, SC = be.dev(buf), be.dev(np.array([s], np.float32))
+    nws = int(be.lib.eegclip_infonce_small_workspace_floats(n, T))
+    WS = be.dev(np.full(nws, np.nan, np.float32))
+    GH, GL = be.dev(np.full((n, NC + 8), 0x7FC0, np.uint16)), be.dev(np.full((n, NC + 8), 0x7FC0, np.uint16))
+    ACC = be.dev(np.array([0.5, -0.25], np.float32))
+    assert be.lib.eegclip_infonce_small_fwd(be.ptr(SL), nslabs, stride, n, T, be.ptr(SC), be.ptr(WS), be.stream) == 0
+    w4 = w + [0.0] * (4 - T)
+    assert be.lib.eegclip_infonce_small_grad(n, T, be.ptr(SC), be.ptr(WS), *w4, be.ptr(GH), be.ptr(GL), NC + 8, be.ptr(ACC), be.ptr(ACC) + 4, be.stream) == 0
+    be.sync()
+    want_loss, want_ds = 0.0, 0.0
+    G = np.zeros((n, NC))
+    for t in range(T):
+        R = tot[:, t * n:(t + 1) * n].astype(np.float64)
+        S = float(s) * R
+        lr = np.log(np.exp(S - S.max(1, keepdims=True)).sum(1)) + S.max(1)
+        lc = np.log(np.exp(S - S.max(0, keepdims=True)).sum(0)) + S.max(0)
+        d = np.diag(S)
+        want_loss += w[t] * 0.5 / n * ((lr - d).sum() + (lc - d).sum())
+        g = w[t] * 0.5 / n * (np.exp(S - lr[:, None]) + np.exp(S - lc[None, :]) - 2 * np.eye(n))
+        want_ds += (g * R).sum()
+        G[:, t * n:(t + 1) * n] = g * float(s)
+    acc = be.host(ACC)
+    assert abs(acc[0] - 0.5 - want_loss) < 2e-5 * max(1.0, abs(want_loss)), (acc[0] - 0.5, want_loss)
+    assert abs(acc[1] + 0.25 - want_ds) < 1e-4 * max(1.0, abs(want_ds)), (acc[1] + 0.25, want_ds)
+    hi, lo = from_planes(be.host(GH)[:, :NC], be.host(GL)[:, :NC])
+    np.testing.assert_allclose(hi.astype(np.float64) + lo, G, atol=3e-5 * np.abs(G).max() + 1e-9)
+    assert (be.host(GH)[:, NC:] == 0x7FC0).all()
+    assert be.lib.eegclip_infonce_small_supported(96, 2) == 0 and be.lib.eegclip_infonce_small_supported(64, 5) == 0 and be.lib.eegclip_infonce_small_supported(256, 2) == 1

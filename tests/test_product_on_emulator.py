@@ -956,7 +956,7 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch, v
         plans = retrieval.step_plans_of(m)
         assert len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)             # the third step went through the plan ...
         names = plans[0].pl.op_names()
-        assert names.count("eegclip_adamw_step_zero_grad") >= 1 and "eegclip_infonce_fused_fwd" in names and names[-1].startswith("eegclip_adamw")
+        assert names.count("eegclip_adamw_step_zero_grad") >= 1 and ("eegclip_infonce_small_grad" in names or "eegclip_infonce_fused_fwd" in names) and names[-1].startswith("eegclip_adamw")
         assert ("eegclip_mse_loss_grad_scaled" in names) == (objective == "reconstruction")
         assert all(p.grad is None for p in m.parameters()) and float(m._engine().gflat.abs().max()) == 0.0
         res_plan = ({k: p.detach().clone() for k, p in m.named_parameters()}, float(acc[-1]), int(correct), f_plan.clone(),
