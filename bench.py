@@ -77,7 +77,6 @@ def algorithmic_cost(name, desc, B):
         "eegclip_sconv_bwd_w": ("hbm", y1),
         "eegclip_sconv_bwd_x_stats": ("hbm", y1),
         "eegclip_sconv_bwd_x_apply": ("hbm", 2 * y1),                       # read y1, write dy1
-        "eegclip_conv_bwd_fused": ("hbm", y1 + 2 * tok),                    # read y1 + tokens, write token gradients (dy1 stays on chip)
     }
     if name in table:
         return table[name][0], float(table[name][1]), "byte"
@@ -88,10 +87,10 @@ _KERNEL_OF = {"eegclip_attention_bwd": "eeg::attention_bwd_kernel<true>", "eegcl
               "eegclip_tsconv_fwd": "eeg::tsconv_fwd_kernel", "eegclip_tsconv_bwd_w": "eeg::tsconv_bwd_w_kernel<7>",
               "eegclip_tsconv_bwd_x": "eeg::tsconv_bwd_x_kernel", "eegclip_sconv_fwd": "eeg::sconv_fwd_kernel",
               "eegclip_sconv_bwd_w": "eeg::sconv_bwd_w_x3_kernel<128>", "eegclip_sconv_bwd_x_stats": "eeg::sconv_bwd_x_kernel<false, true>",
-              "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>", "eegclip_conv_bwd_fused": "eeg::conv_bwd_fused_kernel"}
+              "eegclip_sconv_bwd_x_apply": "eeg::sconv_bwd_x_kernel<true, true>"}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r5_pmc_hbm_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r6_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(family, B):

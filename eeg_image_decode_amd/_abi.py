@@ -184,8 +184,6 @@ PROTOTYPES = {
     "eegclip_tsconv_bwd_w": [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P],
     "eegclip_tsconv_bwd_w_workspace_floats": [_I, _I],
     "eegclip_tsconv_bwd_x": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _P],
-    "eegclip_conv_bwd_fused_workspace_floats": [_I, _I],
-    "eegclip_conv_bwd_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _P],
     "eegclip_cross_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "eegclip_sconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "eegclip_sconv_fwd_workspace_floats": [_I],

@@ -423,24 +423,6 @@ class _Engine:
         self.grad_fresh = True               # gflat holds zeros / stale values that must be cleared before accumulation
         lib()
 
-    def _spatial_weight_planes(self, pl):
-        """bf16 hi / lo planes of the spatial conv weights for the split-bf16 conv kernels (csrc/sconv.hip), refreshed by ONE eegclip_split_rows
-        launch in the forward plan (shared with the Linear weights): Ws^T as [(c,h)][64] (both BN1-backward passes) and, opt-in, Ws as [40][ld]
-        (k contiguous: forward).  Returns the forward kernel's (hi, lo, ld) arguments -- (None, None, 0) = exact fp32 products -- and the split items."""
-        if pl.precision != _abi.PREC_BF16X3 or self._cstack_bwd_enabled(pl):
-            return (None, None, 0), []
-        Kc = C_TS * N_CH
-        ld = (Kc + 128 + 63) // 64 * 64             # a forward chunk may read up to 127 k past the end of its K slice
-        if not hasattr(self, "sc_planes"):
-            self.sc_planes = torch.zeros(2, C_TS, ld, dtype=torch.bfloat16, device=self.device)
-            self.sc_planes_t = torch.zeros(2, Kc, 64, dtype=torch.bfloat16, device=self.device)
-        f, tr = self.sc_planes, self.sc_planes_t
-        src = _p(self.P[_TS + "4.weight"])
-        items = [_abi.SplitItem(src=src, hi=tr[0].data_ptr(), lo=tr[1].data_ptr(), rows=C_TS, cols=Kc, ld_src=Kc, ld_out=64, transpose=1)]
-        # (a split-bf16 FORWARD kernel measured no faster than the exact-fp32 one, 61 vs 59 us -- profiles/r2_conv_x3_vs_f32.json -- and was removed
-        #  in round 4: the forward keeps exact products; the backward kernels (apply -4 us, dW -4 us) use the planes)
-        return (None, None, 0), items
-
     def _head_planes_enabled(self, pl):
         """the projection head (and, in the step plan / ClipLoss, the query gradient) on the K-parallel plane GEMM csrc/head_gemm.hip (round 6) in split-bf16
         plans; EEGCLIP_HEAD_GEMM=0 pins round 5's split-K gemm_x3 launches (diagnosis, A/B timing); exact-fp32 plans always use those"""
@@ -572,13 +554,6 @@ class _Engine:
         pl = Plan(f"atms_fwd[B={B}]")
         R = B * L_TOK
         pe = self.buffers[_E + "position_embedding.pe"]
-        # bf16 planes of this step's weights -- every Linear in both orientations + the spatial conv -- in ONE launch
-        _, conv_items = self._spatial_weight_planes(pl)
-        n_items = len(conv_items)
-        if n_items:
-            items = (_abi.SplitItem * n_items)(*conv_items)
-            pl._keep.append(items)
-            pl.call("eegclip_split_rows", items, n_items)
         pl.tb_desc = None
         cstack = self._cstack_enabled(pl)
         head_planes = self._head_planes_enabled(pl)
@@ -757,11 +732,11 @@ class _Engine:
         return pl
 
     def _cstack_enabled(self, pl):
-        """the conv stack recomputed from the token rows (csrc/cstack*.hip: y1 never written) in split-bf16 plans; EEGCLIP_CSTACK=0 pins the round-4
-        kernels around y1 in HBM (diagnosis, A/B timing); exact-fp32 plans always use those"""
+        """the conv stack recomputed from the token rows (csrc/cstack*.hip: y1 never written) in split-bf16 plans; exact-fp32 plans
+        (EEGCLIP_GEMM_PRECISION=f32) keep the round-4 kernels around y1 in HBM"""
         from .plan import default_gemm_precision
         precision = pl.precision if pl is not None else default_gemm_precision()
-        return precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CSTACK", "1") != "0"
+        return precision == _abi.PREC_BF16X3
 
     def _build_fwd_cstack(self, pl, b, B, train, W):
         """A4+A5 on csrc/cstack.hip (round 5): BatchNorm1 sums WITHOUT writing y1, then per sample y1 tile -> BN1 -> ELU -> spatial conv chained on the
@@ -808,7 +783,7 @@ class _Engine:
         return self._cstack_enabled(pl)
 
     def _build_fwd_conv_y1(self, pl, b, B, train, W):
-        """A4+A5 around y1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""
+        """A4+A5 around y1 in HBM (rounds 1-4 kernels; exact-fp32 plans only)"""
         P, sums, bn = self.P, b["sums"], b["bn"]
         if "y1" not in b:              # the conv + pool output (B,40,63,36): exists in HBM only for the kernels around it
             b["y1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
@@ -1217,7 +1192,7 @@ class _Engine:
             pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
 
     def _build_bwd_conv_y1(self, pl, b, B, train, W, zsum, conv_bias_grad, early_reduce):
-        """spatial conv + BN1 + ELU + temporal conv backward around y1 / dy1 in HBM (rounds 1-4; exact-fp32 plans and EEGCLIP_CSTACK=0)"""
+        """spatial conv + BN1 + ELU + temporal conv backward around y1 / dy1 in HBM (rounds 1-4 kernels; exact-fp32 plans only)"""
         P, G, sums, bn = self.P, self.G, b["sums"], b["bn"]
         # spatial conv + BN1 + ELU backward, fused around y1 (csrc/sconv.hip): dWs from re-evaluated z1; dz1 = Ws^T dy2 recomputed on the
         # matrix cores in both BatchNorm-backward passes instead of being written and re-read.
@@ -1225,11 +1200,7 @@ class _Engine:
         if "scw_ws" not in b:
             b["scw_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
         bnp = (_p(bn[0]), _p(bn[1]), _p(P[_TS + "2.weight"]), _p(P[_TS + "2.bias"]))
-        # split-bf16 products for the K = 40 contraction of both BN1-backward passes (the plan's GEMM precision): Ws^T as bf16 planes
-        # [(c,h)][64 o], split by the forward plan of this step
-        wt = (None, None)
-        if pl.precision == _abi.PREC_BF16X3:
-            wt = (self.sc_planes_t[0].data_ptr(), self.sc_planes_t[1].data_ptr())
+        wt = (None, None)                       # exact fp32 products (these plans only exist under EEGCLIP_GEMM_PRECISION=f32 since round 6)
         if "scx_ws" not in b:
             b["scx_ws"] = torch.empty(int(lib().eegclip_sconv_bwd_x_stats_workspace_floats(B)) // 2, dtype=torch.float64, device=self.device)
         # (folding the two into one pass over y1 -- round 3's eegclip_sconv_bwd_w_stats -- saved 15 us of kernel time but moved the weight gradient from
@@ -1249,31 +1220,19 @@ class _Engine:
             pl.callback(conv_bias_grad(_TS + "0.bias", _TS + "2.weight", bn[1], sums[3]), "conv1_bias_grad_eval")
         count1 = float(W * B * N_CH * W_TS)
         sums1 = (_p(sums[3]) if train else _p(zsum), (_p(local1) if local1 is not None else None) if train else _p(sums[3]))
-        if pl.precision == _abi.PREC_BF16X3 and os.environ.get("EEGCLIP_CONV_BWD_FUSED", "0") == "1":
-            # OPT-IN: BatchNorm1-backward apply + the temporal conv's weight and input gradients in ONE pass over y1 (csrc/conv.hip: conv_bwd_fused_kernel):
-            # the (B,40,63,36) gradient dy1 -- 93 MB written once and read twice by the three launches this replaces -- never exists in HBM (404 -> 141 MB
-            # of traffic).  Parity-green; measured on the MI355X at B = 256: 109 us against 49 + 37 us on the main stream + 44 us on the second one --
-            # less kernel time, but all of it on the dX chain: the step does not get shorter, so the three launches stay the default
-            if "cbf_ws" not in b:
-                b["cbf_ws"] = torch.empty(int(lib().eegclip_conv_bwd_fused_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-            pl.call("eegclip_conv_bwd_fused", _p(b["dy2"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]),
-                    _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(b["dn3"]), _p(G[_TS + "0.weight"]), _p(b["cbf_ws"]), B, N_CH, 0)
-            if early_reduce:
-                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
-        else:
-            if "dy1" not in b:
-                b["dy1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
-            pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(b["dy1"]),
-                    _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
-            if "tsw_ws" not in b:
-                b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
-            pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
-                    C_TS, side=True)
-            if early_reduce:
-                # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
-                # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
-                pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
-            pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
+        if "dy1" not in b:
+            b["dy1"] = torch.empty(B, C_TS, N_CH, W_TS, dtype=torch.float32, device=self.device)
+        pl.call("eegclip_sconv_bwd_x_apply", _p(b["dy2"]), _p(P[_TS + "4.weight"]), *wt, _p(b["y1"]), *bnp, *sums1, count1, _p(b["dy1"]),
+                _p(G[_TS + "2.weight"]), _p(G[_TS + "2.bias"]), B, N_CH)
+        if "tsw_ws" not in b:
+            b["tsw_ws"] = torch.empty(int(lib().eegclip_tsconv_bwd_w_workspace_floats(B, N_CH)), dtype=torch.float32, device=self.device)
+        pl.call("eegclip_tsconv_bwd_w", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(b["dy1"]), _p(G[_TS + "0.weight"]), _p(b["tsw_ws"]), B, N_CH, T_LEN,
+                C_TS, side=True)
+        if early_reduce:
+            # every gradient of the conv stack and the head is final here: start their all-reduce now (asynchronously, ordered behind both
+            # streams); dist.average_flat_grads() waits for it after the backward and reduces the rest
+            pl.callback(self._start_early_reduce, "allreduce_early_bucket", side=True)
+        pl.call("eegclip_tsconv_bwd_x", _p(b["dy1"]), _p(P[_TS + "0.weight"]), _p(b["dn3"]), L_TOK * D_MODEL, D_MODEL, B, N_CH, T_LEN, C_TS)
 
     def _world(self):
         import torch.distributed as dist

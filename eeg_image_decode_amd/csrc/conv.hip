@@ -449,319 +449,6 @@ __global__ __launch_bounds__(256, 4) void tsconv_bwd_x_kernel(const float* __res
 }
 
 
-// ===============================================================================================================
-// BatchNorm1-backward apply + the whole temporal-conv backward in ONE pass over y1 (round 4): the 93 MB gradient dy1 never exists in HBM.
-//   round 3:  sconv_bwd_x<APPLY> (read y1, WRITE dy1)  ->  tsconv_bwd_w (READ dy1 + token rows)  +  tsconv_bwd_x (READ dy1, write token gradients)
-//   here:     work item = (sample b, block of 16 EEG rows h): for slabs of 16 channels, each wave forms dy1[c][16 h][36 w] of its channels on the
-//             matrix cores exactly as sconv_bwd_x<APPLY, X3> does (dz^T = dy2^T Ws on split-bf16 products, ELU' / BatchNorm backward in the
-//             epilogue) and drops it into the LDS slab dl[c][w][row]; behind a barrier ALL waves consume the slab twice:
-//               * dS[row][j] += sum_{w,c} dy1[c][w][row] taps[c][j - 5w]      the banded GEMM of tsconv_bwd_x (accumulators live across the slabs)
-//               * dW[c][t]   += sum_{row,w} dy1[c][w][row] S[row][5w + t]     the GEMM of tsconv_bwd_w over the item's box-filtered token rows
-//             then dS -> transpose of the box filter -> token-row gradients.  HBM: y1 (93 MB) + token rows in, token gradients out.
-// LDS 80 KB: taps 5 KB | BatchNorm coefficients | dy2^T planes 13.5 KB | slab 39 KB (later the dS rows / the reduction scratch) | S rows 16 KB |
-// scan scratch 4 KB: two workgroups per CU.
-constexpr int CB_CH = 16;                        // channels per slab: one MFMA M tile of the taps gradient
-constexpr int CB_NSLAB = (TS_C + CB_CH - 1) / CB_CH;
-constexpr int CB_WS = 17, CB_CS = 624;          // slab cell (c, w) = 16 rows + 1 pad; floats per channel (16 mod 32: conflict-free banded-GEMM reads)
-struct cb_args {
-    const float* dy2;
-    const unsigned short *wt_hi, *wt_lo;         // Ws^T planes [(c, h)][64 o]
-    const float* y1;
-    bn_affine bn;
-    const double *sums, *sums_param;
-    double count;
-    float *dgamma, *dbeta;
-    const float* x;                              // token rows (the tsconv input)
-    long long xs_b, xs_h;
-    const float* w25;
-    float* dx;                                   // token-row gradients, same strides as x
-    float* partials;                             // [workgroup][40][25] taps-gradient partials
-    int B, H, vec2;
-};
-
-__global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(const cb_args a) {
-    // Every wave PRODUCES its channels of a dy1 slab (apply tasks: y1 / weight loads, split-bf16 MFMAs, ELU' + BatchNorm-backward epilogue), then every
-    // wave CONSUMES the slab (the two f32-MFMA GEMMs); two workgroups per CU run out of phase.  Measured at B = 256 (tools/bench_conv_bwd.py): 109 us against
-    // 49 + 44 + 37 us for the three kernels it replaces, HBM traffic 141 MB against 404 (profiles/r4_pmc_conv_bwd_fused.json).  A producer / consumer
-    // split (512 threads: 4 waves produce slab k + 1 into a second buffer while 4 consume slab k) measured SLOWER, 139 us: half the waves issuing loads
-    // halves the bytes in flight, and the kernel is bound by exactly that (44 % of all wave cycles parked on loads / barriers, matrix pipe 31 % busy).
-    EEG_LDS_BASE(float, lds);
-    float* wl = lds;                                                             // [40][32] taps (cols >= 25 zero)
-    float* coef = wl + TS_C * TSX_WL;                                             // [40][8] mean, rstd, gamma, beta, S1 / n, S2 / n per channel
-    unsigned char* dplane = reinterpret_cast<unsigned char*>(coef + 8 * SC_C);    // two bf16 planes [48 w][144 B] of dy2^T
-    float* dl0 = reinterpret_cast<float*>(dplane + 2 * SC_OP * SCX_RS);            // [16][624] slab
-    float* sl = dl0 + CB_CH * CB_CS;                                              // [16][256] box-filtered token rows
-    float* ps = sl + TSX_R * TS_XS;                                               // [4][256] scan scratch
-    float* dsl = dl0;                                                             // [16][256] dS rows (after the last slab)
-    float* red = dl0;                                                             // reduction scratch (after the last item)
-    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int H = a.H, MT = (H + 15) / 16, nitems = a.B * MT;
-    const f32x4 zero4v{0.f, 0.f, 0.f, 0.f};
-    const bf16x8 zero8{0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = t; i < TS_C * TSX_WL; i += 256) wl[i] = (i % TSX_WL) < TS_K1 ? a.w25[(i / TSX_WL) * TS_K1 + i % TSX_WL] : 0.f;
-    for (int i = t; i < SC_OP * 64; i += 256) {                                   // o >= 40 and w >= 36 of the planes: zeros, for every item
-        const int w = i >> 6, o = i & 63;
-        if (o >= SC_C || w >= SC_W) {
-            *reinterpret_cast<unsigned short*>(dplane + w * SCX_RS + 2 * o) = 0;
-            *reinterpret_cast<unsigned short*>(dplane + SC_OP * SCX_RS + w * SCX_RS + 2 * o) = 0;
-        }
-    }
-    if (t < SC_C) {                                                               // (once per workgroup: the apply tasks read one 32-byte row instead of four
-        float* cf = coef + 8 * t;                                                 //  scalar loads + two fp64 divisions each)
-        cf[0] = a.bn.mean[t]; cf[1] = a.bn.rstd[t]; cf[2] = a.bn.gamma[t]; cf[3] = a.bn.beta[t];
-        cf[4] = (float)(a.sums[t] / a.count); cf[5] = (float)(a.sums[SC_C + t] / a.count);
-    }
-    if (blockIdx.x == 0 && t < SC_C) {                                            // BatchNorm1 parameter gradients from this rank's own sums
-        atomicAdd(a.dgamma + t, (float)a.sums_param[SC_C + t]);
-        atomicAdd(a.dbeta + t, (float)a.sums_param[t]);
-    }
-    f32x4 accw[CB_NSLAB][2];                                                      // taps gradient D[c = 16 s + 4 g + r][t = 16 ut + fr]
-#pragma unroll
-    for (int s = 0; s < CB_NSLAB; ++s)
-#pragma unroll
-        for (int ut = 0; ut < 2; ++ut) accw[s][ut] = zero4v;
-
-    // apply task of channel c for the item (b, h0): two tasks of loads in flight per wave (a task is ~600 cycles, an HBM round trip 2000+)
-    bf16x8 nbh[2][2], nbl[2][2];
-    f32x4 nyv[2][3];
-    auto load_task = [&](int b, int h0, int c, auto slot_c) {
-        constexpr int SL = decltype(slot_c)::value;
-        const int h = h0 + fr;
-        const bool hok = h < H;
-        const long long row = ((long long)c * H + (hok ? h : H - 1)) * 64;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            nbh[SL][s2] = *reinterpret_cast<const bf16x8*>(a.wt_hi + row + 32 * s2 + 8 * g);
-            nbl[SL][s2] = *reinterpret_cast<const bf16x8*>(a.wt_lo + row + 32 * s2 + 8 * g);
-            if (!hok) { nbh[SL][s2] = zero8; nbl[SL][s2] = zero8; }
-        }
-        const float* yr = a.y1 + (((long long)b * SC_C + c) * H + h) * SC_W;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int w = 16 * j + 4 * g;
-            nyv[SL][j] = (hok && w < SC_W) ? *reinterpret_cast<const f32x4*>(yr + w) : zero4v;
-        }
-    };
-    if ((int)blockIdx.x < nitems) {                                               // the first item's first two tasks: in flight under its staging
-        const int b = (int)blockIdx.x / MT, h0 = 16 * ((int)blockIdx.x - b * MT);
-        load_task(b, h0, wv, std::integral_constant<int, 0>{});
-        load_task(b, h0, wv + 4, std::integral_constant<int, 1>{});
-    }
-
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int b = item / MT, mt = item - b * MT, h0 = 16 * mt;
-        const int nitem = item + (int)gridDim.x, nb = nitem / MT, nh0 = 16 * (nitem - nb * MT);       // (this workgroup's next item)
-        __syncthreads();                                                          // the previous item is fully consumed (planes, S rows, dS rows)
-        for (int i = t; i < SC_C * SC_W; i += 256) {                              // dy2 of the sample -> transposed hi | lo planes
-            const int o = i / SC_W, w = i % SC_W;
-            const float v = a.dy2[(long long)b * SC_C * SC_W + i];
-            const unsigned short hb = f32_to_bf16_bits(v);
-            *reinterpret_cast<unsigned short*>(dplane + w * SCX_RS + 2 * o) = hb;
-            *reinterpret_cast<unsigned short*>(dplane + SC_OP * SCX_RS + w * SCX_RS + 2 * o) = f32_to_bf16_bits(v - bf16_bits_to_f32(hb));
-        }
-        {
-            float vx[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int h = h0 + 4 * wv + j;
-                load_row4(vx[j], a.x, a.xs_b, a.xs_h, h < H ? b * H + h : a.B * H, a.B * H, H, a.vec2 != 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) box_filter_row(sl + (4 * wv + j) * TS_XS, ps + wv * TS_XS, vx[j]);
-        }
-        __syncthreads();
-        const bool hok = h0 + fr < H;
-        f32x4 accx[4];                                                            // dS tile rows
-#pragma unroll
-        for (int q = 0; q < 4; ++q) accx[q] = zero4v;
-
-        // (the slab index is a compile-time constant: with a runtime index the compiler turned the per-slab accumulator choice into a dynamically
-        //  indexed private array -- 112 bytes of scratch per lane, a scratch load + store around every taps-gradient MFMA: 490 us)
-        auto produce = [&](auto s_c) {
-            constexpr int s = decltype(s_c)::value;
-            constexpr int c0 = CB_CH * s, nch = TS_C - c0 < CB_CH ? TS_C - c0 : CB_CH;
-            float* dl = dl0;
-#pragma unroll
-            for (int ti = 0; ti < nch / 4; ++ti) {
-                const int cl = wv + 4 * ti, c = c0 + cl;
-                const int SL = ti & 1;                                            // task index within the item = 4 s + ti (compile-time after unrolling)
-                f32x4 acc[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[j] = zero4v;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {                                 // D[w = 16 j + 4 g + r][h = h0 + fr]
-                        // dy2^T fragments (rows w = 16 j + fr, k = o = 32 s2 + 8 g ..) re-read from the planes per task: held in registers (48) next to the
-                        // two prefetch slots and the consumers' accumulators they made the kernel spill
-                        const bf16x8 ahf = *reinterpret_cast<const bf16x8*>(dplane + (16 * j + fr) * SCX_RS + 2 * (32 * s2 + 8 * g));
-                        const bf16x8 alf = *reinterpret_cast<const bf16x8*>(dplane + SC_OP * SCX_RS + (16 * j + fr) * SCX_RS + 2 * (32 * s2 + 8 * g));
-                        acc[j] = mfma_bf16_16x16x32(ahf, SL ? nbl[1][s2] : nbl[0][s2], acc[j]);
-                        acc[j] = mfma_bf16_16x16x32(alf, SL ? nbh[1][s2] : nbh[0][s2], acc[j]);
-                        acc[j] = mfma_bf16_16x16x32(ahf, SL ? nbh[1][s2] : nbh[0][s2], acc[j]);
-                    }
-                const f32x4 cf0 = *reinterpret_cast<const f32x4*>(coef + 8 * c);
-                const f32x2 cf1 = *reinterpret_cast<const f32x2*>(coef + 8 * c + 4);
-                const float mean = cf0[0], rstd = cf0[1], gam = cf0[2], bet = cf0[3], m1 = cf1[0], m2 = cf1[1];
-                float* cell = dl + cl * CB_CS + (fr ^ (cl >> 1));                   // (row index XOR (channel >> 1): see the taps-gradient reads below)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int w = 16 * j + 4 * g;
-                    if (w < SC_W) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float xh = ((SL ? nyv[1][j][r] : nyv[0][j][r]) - mean) * rstd;
-                            const float u = gam * xh + bet;
-                            const float da = u > 0.f ? acc[j][r] : acc[j][r] * fast_exp(u);
-                            cell[(w + r) * CB_WS] = hok ? gam * rstd * (da - m1 - xh * m2) : 0.f;      // dy1[c][h][w + r]; rows past H are zero rows
-                        }
-                    }
-                }
-                // the task after next into the slot this task has emptied: channel c + 8 of this item, or -- at its last two tasks -- the first two
-                // of the workgroup's next item (in flight under the last slab's GEMMs and the staging of that item)
-                if (c + 8 < TS_C) {
-                    if (SL) load_task(b, h0, c + 8, std::integral_constant<int, 1>{});
-                    else load_task(b, h0, c + 8, std::integral_constant<int, 0>{});
-                } else if (nitem < nitems) {
-                    if (SL) load_task(nb, nh0, c + 8 - TS_C, std::integral_constant<int, 1>{});
-                    else load_task(nb, nh0, c + 8 - TS_C, std::integral_constant<int, 0>{});
-                }
-            }
-        };
-        auto consume = [&](auto s_c) {
-            constexpr int s = decltype(s_c)::value;
-            constexpr int c0 = CB_CH * s, nch = TS_C - c0 < CB_CH ? TS_C - c0 : CB_CH;
-            const float* dl = dl0;
-            // ---- token-row gradient: banded GEMM over this slab (csrc/conv.hip: tsconv_bwd_x_kernel)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int jt = wv + 4 * q;                                        // j tile: j = 16 jt .. 16 jt + 15
-                if (jt >= TSX_NJ) continue;
-                int w_lo = (16 * jt - (TS_K1 - 1) + 4) / 5;
-                if (16 * jt - (TS_K1 - 1) <= 0) w_lo = 0;
-                int w_hi = (16 * jt + 15) / 5;
-                if (w_hi > TS_W - 1) w_hi = TS_W - 1;
-                const int j = 16 * jt + fr;
-                for (int w = w_lo; w <= w_hi; ++w) {
-                    const int u = j - 5 * w;
-                    const bool inb = u >= 0 && u < TS_K1;
-#pragma unroll
-                    for (int cc = 0; cc < nch / 4; ++cc) {
-                        const int cl = 4 * cc + g;
-                        const float av = dl[cl * CB_CS + w * CB_WS + (fr ^ (cl >> 1))];            // A[row = fr][k = (w, c)]
-                        const float bq = inb ? wl[(c0 + cl) * TSX_WL + u] : 0.f;                   // B[k][j] = taps[c][j - 5 w]
-                        accx[q] = mfma_f32_16x16x4(av, bq, accx[q]);                               // D[row = 4 g + r][j]
-                    }
-                }
-            }
-            // ---- taps gradient: K = the item's 16 x 36 positions; MFMA step ks = (w, rq), its 4 k slots = rows rq, rq + 8, rq + 4, rq + 12 of position w.
-            //      The lanes of an A read are 16 CHANNELS (stride 624 floats = 16 banks): with the rows stored at row ^ (channel >> 1) the 8 even and the 8
-            //      odd channels of a half-wave spread over 8 banks each, and its two k slots (rows 8 apart) over the two 8-bank halves: conflict-free
-            //      (plain rows: 8 lanes per bank, 50 % of all LDS cycles of the first version were bank conflicts -- SQ_LDS_BANK_CONFLICT)
-            for (int ks = wv; ks < TSX_R * TS_W / 4; ks += 4) {
-                const int w = ks >> 2, row = (ks & 3) + 4 * (g >> 1) + 8 * (g & 1);
-                const float av = fr < nch ? dl[fr * CB_CS + w * CB_WS + (row ^ (fr >> 1))] : 0.f;  // A[c = fr][(w, row)]  (a short last slab: zero channels)
-                const float* xp = sl + row * TS_XS + 5 * w + fr;
-#pragma unroll
-                for (int ut = 0; ut < 2; ++ut) accw[s][ut] = mfma_f32_16x16x4(av, xp[16 * ut], accw[s][ut]);      // B[(w, row)][t] = S[row][5 w + t]
-            }
-        };
-        static_assert(CB_NSLAB == 3, "three slabs written out");
-        produce(std::integral_constant<int, 0>{});
-        __syncthreads();
-        consume(std::integral_constant<int, 0>{});
-        __syncthreads();                                                          // the slab has been consumed
-        produce(std::integral_constant<int, 1>{});
-        __syncthreads();
-        consume(std::integral_constant<int, 1>{});
-        __syncthreads();
-        produce(std::integral_constant<int, 2>{});
-        __syncthreads();
-        consume(std::integral_constant<int, 2>{});
-        __syncthreads();                                                          // every wave is done with the last slab: it becomes the dS rows
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int jt = wv + 4 * q;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (jt < TSX_NJ) dsl[(4 * g + r) * TS_XS + 16 * jt + fr] = accx[q][r];
-        }
-        __syncthreads();
-        // transpose of the box filter, 4 rows per wave: Q[i] = sum_{k<i} dS[k] ; dx[i] = (Q[i+1] - Q[max(i-50, 0)]) / 51
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int rl = 4 * wv + rr, hh = h0 + rl;
-            const f32x4 d = 4 * lane < 16 * TSX_NJ ? *reinterpret_cast<const f32x4*>(dsl + rl * TS_XS + 4 * lane) : zero4v;
-            const float p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
-            const float basev = wave_inclusive_scan(p3) - p3;
-            float* pq = ps + wv * TS_XS;
-            const float q4[5] = {basev, basev + p0, basev + p1, basev + p2, basev + p3};
-            *reinterpret_cast<f32x4*>(pq + 4 * lane) = f32x4{q4[0], q4[1], q4[2], q4[3]};
-            wave_sync();
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * lane + e;
-                const float lo = i >= TS_POOL - 1 ? pq[i - (TS_POOL - 1)] : 0.f;
-                o[e] = (q4[e + 1] - lo) * (1.0f / TS_POOL);
-            }
-            wave_sync();
-            if (hh < H) {
-                float* xr = a.dx + b * a.xs_b + hh * a.xs_h;
-                if (a.vec2) {
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf)
-                        if (4 * lane + 2 * hf < TS_T) *reinterpret_cast<f32x2*>(xr + 4 * lane + 2 * hf) = f32x2{o[2 * hf], o[2 * hf + 1]};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * lane + e < TS_T) xr[4 * lane + e] = o[e];
-                }
-            }
-        }
-    }
-    // cross-wave sum of the four waves' position-partial taps gradients (as tsconv_bwd_w_kernel), then this workgroup's partial row
-    constexpr int RLD = 36;
-    auto put = [&](float* reg) {
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-            for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) reg[(16 * ct + 4 * g + r) * RLD + 16 * ut + fr] = accw[ct][ut][r];
-    };
-    auto add = [&](const float* reg) {
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-            for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accw[ct][ut][r] += reg[(16 * ct + 4 * g + r) * RLD + 16 * ut + fr];
-    };
-    static_assert(2 * TS_CP * RLD <= CB_CH * CB_CS, "reduction scratch must fit in the slab");
-    __syncthreads();
-    if (wv >= 2) put(red + (wv - 2) * TS_CP * RLD);
-    __syncthreads();
-    if (wv < 2) add(red + wv * TS_CP * RLD);
-    __syncthreads();
-    if (wv == 1) put(red);
-    __syncthreads();
-    if (wv == 0) {
-        add(red);
-        float* out = a.partials + (long long)blockIdx.x * (TS_C * TS_K1);
-#pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-            for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * ct + 4 * g + r, u = 16 * ut + fr;
-                    if (c < TS_C && u < TS_K1) out[c * TS_K1 + u] = accw[ct][ut][r];
-                }
-    }
-}
-
 }  // namespace eeg
 
 using namespace eeg;
@@ -830,27 +517,3 @@ extern "C" int eegclip_tsconv_bwd_x(const float* dy, const float* w25, float* dx
     return (int)hipGetLastError();
 }
 
-static int cbf_grid(int B, int H, int limit) {
-    const int items = B * ((H + 15) / 16), cap = limit > 0 ? limit : 512;      // default: two 80 KB workgroups per CU
-    return items < cap ? items : cap;
-}
-extern "C" long long eegclip_conv_bwd_fused_workspace_floats(int B, int H) { return (B < 1 || H < 1) ? 0 : (long long)cbf_grid(B, H, 1 << 30) * TS_C * TS_K1; }
-
-extern "C" int eegclip_conv_bwd_fused(const float* dy2, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean, const float* rstd,
-                                      const float* gamma, const float* beta, const double* sums, const double* sums_local, double count, float* dgamma,
-                                      float* dbeta, const float* x, long long xs_b, long long xs_h, const float* w25, float* dx, float* dw25,
-                                      float* workspace, int B, int H, int max_workgroups, void* stream) {
-    if (B < 1 || H < 1 || H > 64 || max_workgroups < 0) return EEGCLIP_EINVAL;
-    if (!dy2 || !WsT_hi || !WsT_lo || !y1 || !mean || !rstd || !gamma || !beta || !sums || !dgamma || !dbeta || !x || !w25 || !dx || !dw25 || !workspace ||
-        count < 1.0)
-        return EEGCLIP_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(WsT_hi) | reinterpret_cast<uintptr_t>(WsT_lo)) & 15u) return EEGCLIP_EALIGN;
-    const cb_args a{dy2, static_cast<const unsigned short*>(WsT_hi), static_cast<const unsigned short*>(WsT_lo), y1, bn_affine{mean, rstd, gamma, beta},
-                    sums, sums_local ? sums_local : sums, count, dgamma, dbeta, x, xs_b, xs_h, w25, dx, workspace, B, H,
-                    (ts_vec2(x, xs_b, xs_h) && ts_vec2(dx, xs_b, xs_h)) ? 1 : 0};
-    const int grid = cbf_grid(B, H, max_workgroups);
-    const size_t lds = (TS_C * TSX_WL + CB_CH * CB_CS + TSX_R * TS_XS + 4 * TS_XS + 8 * SC_C) * sizeof(float) + 2 * SC_OP * SCX_RS;
-    EEG_LAUNCH(conv_bwd_fused_kernel, dim3(grid), dim3(256), lds, stream, a);
-    EEG_LAUNCH(tsconv_bwd_w_reduce_kernel, dim3((TS_C * TS_K1 + 255) / 256, grid < 32 ? grid : 32), dim3(256), 0, stream, workspace, grid, dw25);
-    return (int)hipGetLastError();
-}

@@ -21,9 +21,10 @@ namespace eeg {
 #if !defined(EEG_EMU)
 struct launch_events {
     hipEvent_t start, stop;
+    int launches;                         // kernels launched by this thread since the field was last cleared (csrc/plan_exec.hip: fork events)
 };
 inline launch_events& tls_launch_events() {
-    static thread_local launch_events e{nullptr, nullptr};
+    static thread_local launch_events e{nullptr, nullptr, 0};
     return e;
 }
 #endif
@@ -46,10 +47,12 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // eegclip_time_next_launch(start, stop) arms a pair of events for the NEXT kernel this thread launches: the launch then goes through
 // hipExtLaunchKernelGGL, which stamps the events with the kernel's own begin / end timestamps (what rocprofv3 reports) -- no marker packets
 // around the kernel, so neither the dispatch bubbles of an event bracket (~5 us per launch) nor their serialisation end up in the measurement.
+// A stop event alone (csrc/plan_exec.hip) is BOUND to the kernel's own completion: the fork point of a launch plan without a marker packet on the main queue.
 #define EEG_LAUNCH(kern, grid, block, smem, stream, ...)                                                                                  \
     do {                                                                                                                                 \
         eeg::launch_events& ev_ = eeg::tls_launch_events();                                                                              \
-        if (ev_.start) {                                                                                                                 \
+        ++ev_.launches;                                                                                                                  \
+        if (ev_.start || ev_.stop) {                                                                                                     \
             hipExtLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), ev_.start, ev_.stop, 0, __VA_ARGS__);            \
             ev_.start = ev_.stop = nullptr;                                                                                              \
         } else {                                                                                                                         \

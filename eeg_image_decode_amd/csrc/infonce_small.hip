@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void infonce_small_grad_kernel(const is_args a
 using namespace eeg;
 
 static int is_check(int n, int T, int nslabs, long long stride) {
-    if (n < 64 || n % 64 || n > 1024 || T < 1 || T > IS_MAXT || nslabs < 1 || nslabs > IS_MAXS || (nslabs > 1 && (stride < (long long)n * T * n || (stride & 3)))) return EEGCLIP_EINVAL;
+    if (n < 8 || n % 8 || n > 1024 || T < 1 || T > IS_MAXT || nslabs < 1 || nslabs > IS_MAXS || (nslabs > 1 && (stride < (long long)n * T * n || (stride & 3)))) return EEGCLIP_EINVAL;
     return 0;
 }
 

@@ -430,7 +430,7 @@ class StepPlan:
     def eligible(model, optimizer, eeg_data, subject_id, img, txt, labels, class_feats, objective, keep_grads, world):
         """can this call go through a step plan at all (cheap checks, every step)"""
         from .atms import ATMS
-        from .loss import ClipLoss, fused_enabled
+        from .loss import ClipLoss, fused_enabled, head_gemm_enabled, infonce_small_enabled
         from .optim import AdamW
         if not (enabled() and objective in ("retrieval", "reconstruction") and not keep_grads and _runtime_ok()):
             return False
@@ -451,7 +451,10 @@ class StepPlan:
                 return False
         if labels.dtype != torch.long or not _on_device(labels) or labels.numel() != B or class_feats.dim() != 2 or class_feats.shape[1] != 1024:
             return False
-        return world > 1 or bool(fused_enabled(B, B, 1024))
+        if world > 1 or fused_enabled(B, B, 1024):
+            return True
+        T_ = 2 if objective == "retrieval" else 1              # batches that are not whole 64-tiles: the small InfoNCE form only
+        return bool(head_gemm_enabled(B, T_ * B, 1024) and infonce_small_enabled(B, T_, 2) and lf.logits_dtype == "f32")
 
     def still_valid(self, model, optimizer):
         """the captured state is still the live one: same engine / plans / optimizer launch cache, nobody attached gradients or changed hyper-parameters"""

@@ -268,18 +268,6 @@ int eegclip_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int 
 int eegclip_attention_bwd_x3(const float* qkv, const float* dctx, void* dqkv, int dqkv_planes, int B, int L, int H, int E, int ld, float scale,
                           float drop_p, unsigned long long seed, unsigned int site, void* stream);
 
-/* ---- BatchNorm1-backward apply + temporal conv / pool backward in ONE pass over y1 (csrc/conv.hip: conv_bwd_fused_kernel): what
- * eegclip_sconv_bwd_x_apply -> eegclip_tsconv_bwd_w + eegclip_tsconv_bwd_x compute, without writing the (B,40,H,36) gradient dy1 to HBM and reading it
- * twice (Retrieval/ATMS_retrieval.py:102-105 backward).  Arguments as in those three calls: WsT planes from eegclip_split_rows(transpose) are REQUIRED
- * (split-bf16 products for the K = 40 contraction), x / dx = token rows and their gradient (same strides), dw25 (40 x 25) accumulated into,
- * dgamma / dbeta (40) accumulated into; workspace: eegclip_conv_bwd_fused_workspace_floats(B, H) floats; max_workgroups: 0 = two per CU (the
- * workgroups are persistent over the (sample, 16-row block) work items). */
-long long eegclip_conv_bwd_fused_workspace_floats(int B, int H);
-int eegclip_conv_bwd_fused(const float* dy2, const void* WsT_hi, const void* WsT_lo, const float* y1, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, const double* sums, const double* sums_local, double count, float* dgamma, float* dbeta,
-                           const float* x, long long xs_b, long long xs_h, const float* w25, float* dx, float* dw25, float* workspace, int B, int H,
-                           int max_workgroups, void* stream);
-
 /* ---- tsconv front: Conv2d(1,40,(1,25)) -> AvgPool2d((1,51),(1,5)).  ATMS_retrieval.py:102-103
  * Computed as a 51-sample box filter of every token row (one wave-level prefix sum, shared by the 40 filters) followed by the 25-tap
  * convolution at stride 5 -- the two commute, and K = 25 on the matrix cores instead of 75 for the folded filter; the (B,40,H,226)
@@ -585,7 +573,7 @@ int eegclip_split_transpose(const eegclip_split_item* items, int n, void* stream
  *                               (eegclip_infonce_small_workspace_floats(n, T) floats)
  *   eegclip_infonce_small_grad  finishes the column log-sum-exps, adds sum_t w_t * ClipLoss_t to *loss and d loss / d scale to *dscale, and writes
  *                               G = [G_1 | .. | G_T] (n, ldg), G_t = s dL/dS_t, as bf16 hi | lo planes -- the A operand of dQ = G [B_1; ..; B_T]
- * n a multiple of 64 and <= 1024, T <= 4 (eegclip_infonce_small_supported). */
+ * n a multiple of 8 and <= 1024, T <= 4 (eegclip_infonce_small_supported). */
 int eegclip_infonce_small_supported(int n, int T);
 long long eegclip_infonce_small_workspace_floats(int n, int T);
 int eegclip_infonce_small_fwd(const float* slabs, int nslabs, long long slab_stride, int n, int T, const float* scale, float* workspace, void* stream);

@@ -313,7 +313,7 @@ def test_split_rows_lds_free_transposing_path_writes_column_blocks_without_paddi
     assert be.lib.eegclip_split_rows(bad, 1, be.stream) != 0               # rows % 4 != 0
 
 
-@pytest.mark.parametrize("n,T,nslabs", [(64, 2, 3), (128, 1, 1)])
+@pytest.mark.parametrize("n,T,nslabs", [(64, 2, 3), (128, 1, 1), (24, 3, 2), (8, 1, 8)])
 def test_infonce_small_against_fp64(be, n, T, nslabs):
     """csrc/infonce_small.hip: from partial slabs of the raw logits -> loss, d loss / d scale and the gradient matrices as planes, against an fp64 evaluation of
     models/loss.py:122-140 (symmetric cross-entropy of S = s A B^T, RAW scale) for T targets with weights w_t"""
@@ -330,7 +330,7 @@ def test_infonce_small_against_fp64(be, n, T, nslabs):
     for i in range(nslabs):
         buf[i * stride:i * stride + n * NC] = parts[i].ravel()
     s = np.float32(2.6593)
-    w = [0.99, 0.01][:T] if T == 2 else [0.7]
+    w = [0.99, 0.01, 0.4, 0.7][:T] if T > 1 else [0.7]
     SL, SC = be.dev(buf), be.dev(np.array([s], np.float32))
     nws = int(be.lib.eegclip_infonce_small_workspace_floats(n, T))
     WS = be.dev(np.full(nws, np.nan, np.float32))
@@ -358,4 +358,4 @@ def test_infonce_small_against_fp64(be, n, T, nslabs):
     hi, lo = from_planes(be.host(GH)[:, :NC], be.host(GL)[:, :NC])
     np.testing.assert_allclose(hi.astype(np.float64) + lo, G, atol=3e-5 * np.abs(G).max() + 1e-9)
     assert (be.host(GH)[:, NC:] == 0x7FC0).all()
-    assert be.lib.eegclip_infonce_small_supported(96, 2) == 0 and be.lib.eegclip_infonce_small_supported(64, 5) == 0 and be.lib.eegclip_infonce_small_supported(256, 2) == 1
+    assert be.lib.eegclip_infonce_small_supported(100, 2) == 0 and be.lib.eegclip_infonce_small_supported(96, 2) == 1 and be.lib.eegclip_infonce_small_supported(64, 5) == 0 and be.lib.eegclip_infonce_small_supported(256, 2) == 1

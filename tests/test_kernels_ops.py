@@ -600,55 +600,6 @@ def test_fused_spatial_stage(be, B, H):
                                             be.ptr(SUMS), None, B, H, be.stream) < 0
 
 
-@pytest.mark.parametrize("B,H,cap", [(3, 63, 0), (2, 5, 0), (5, 63, 3), (9, 17, 4)])
-def test_conv_backward_fused_equals_the_three_kernels_it_replaces(be, B, H, cap):
-    """csrc/conv.hip: conv_bwd_fused_kernel -- BatchNorm1-backward apply + temporal-conv backward in one pass over y1 (dy1 never leaves the CU) against
-    eegclip_sconv_bwd_x_apply -> eegclip_tsconv_bwd_w + eegclip_tsconv_bwd_x (each pinned against torch above), incl. a short last row block and
-    persistent workgroups that take several work items (cap)"""
-    rng = np.random.default_rng(B * 1000 + H)
-    C, Wd = 40, 36
-    y1 = rnd(rng, B, C, H, Wd) * 1.3 + 0.2
-    g1, b1 = 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C)
-    Ws = (rnd(rng, C, C, H) / np.sqrt(C * H)).astype(np.float32)
-    dy2 = rnd(rng, B, C, Wd)
-    w25 = rnd(rng, 40, 25, scale=0.2)
-    xfull = rnd(rng, B, 64, 250)
-    mean = y1.astype(np.float64).mean((0, 2, 3))
-    var = y1.astype(np.float64).var((0, 2, 3))
-    Y1, G1, B1, WS, DY2, W25, X = be.dev(y1), be.dev(g1), be.dev(b1), be.dev(Ws), be.dev(dy2), be.dev(w25), be.dev(xfull)
-    MU, RS = be.dev(mean.astype(np.float32)), be.dev((1 / np.sqrt(var + 1e-5)).astype(np.float32))
-    K = C * H
-    WH, WL = be.dev(np.full((K, 64), 0x7FC0, np.uint16)), be.dev(np.full((K, 64), 0x7FC0, np.uint16))
-    it = (_abi.SplitItem * 1)(_abi.SplitItem(src=be.ptr(WS), hi=be.ptr(WH), lo=be.ptr(WL), rows=C, cols=K, ld_src=K, ld_out=64, transpose=1))
-    ok(be.lib.eegclip_split_rows(it, 1, be.stream))
-    SUMS = be.zeros(80, np.float64)
-    ok(be.lib.eegclip_sconv_bwd_x_stats(be.ptr(DY2), be.ptr(WS), be.ptr(WH), be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
-                                        None, B, H, be.stream))
-    count = float(B * H * Wd)
-    # the three kernels
-    DY1, DG, DB = be.zeros((B, C, H, Wd)), be.zeros(C), be.zeros(C)
-    ok(be.lib.eegclip_sconv_bwd_x_apply(be.ptr(DY2), be.ptr(WS), be.ptr(WH), be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS),
-                                        None, count, be.ptr(DY1), be.ptr(DG), be.ptr(DB), B, H, be.stream))
-    DW, DX = be.dev(np.ones((40, 25), np.float32)), be.dev(np.full((B, 64, 250), 7.0, np.float32))
-    WSW = be.zeros(int(be.lib.eegclip_tsconv_bwd_w_workspace_floats(B, H)))
-    ok(be.lib.eegclip_tsconv_bwd_w(be.ptr(X), 64 * 250, 250, be.ptr(DY1), be.ptr(DW), be.ptr(WSW), B, H, 250, 40, be.stream))
-    ok(be.lib.eegclip_tsconv_bwd_x(be.ptr(DY1), be.ptr(W25), be.ptr(DX), 64 * 250, 250, B, H, 250, 40, be.stream))
-    # the fused kernel
-    DG2, DB2 = be.zeros(C), be.zeros(C)
-    DW2, DX2 = be.dev(np.ones((40, 25), np.float32)), be.dev(np.full((B, 64, 250), 7.0, np.float32))
-    WSF = be.dev(np.full(int(be.lib.eegclip_conv_bwd_fused_workspace_floats(B, H)), np.nan, np.float32))
-    ok(be.lib.eegclip_conv_bwd_fused(be.ptr(DY2), be.ptr(WH), be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), None, count,
-                                     be.ptr(DG2), be.ptr(DB2), be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(DX2), be.ptr(DW2), be.ptr(WSF), B, H, cap, be.stream))
-    dx, dx2 = be.host(DX), be.host(DX2)
-    np.testing.assert_array_equal(dx2[:, H:], 7.0)                      # token rows past H are not touched
-    np.testing.assert_allclose(dx2[:, :H], dx[:, :H], atol=2e-5 * max(1.0, float(np.abs(dx[:, :H]).max())))
-    np.testing.assert_allclose(be.host(DW2), be.host(DW), atol=2e-5 * max(1.0, float(np.abs(be.host(DW)).max())))
-    np.testing.assert_allclose(be.host(DG2), be.host(DG), rtol=1e-6, atol=1e-7)
-    np.testing.assert_allclose(be.host(DB2), be.host(DB), rtol=1e-6, atol=1e-7)
-    assert be.lib.eegclip_conv_bwd_fused(be.ptr(DY2), None, be.ptr(WL), be.ptr(Y1), be.ptr(MU), be.ptr(RS), be.ptr(G1), be.ptr(B1), be.ptr(SUMS), None, count,
-                                         be.ptr(DG2), be.ptr(DB2), be.ptr(X), 64 * 250, 250, be.ptr(W25), be.ptr(DX2), be.ptr(DW2), be.ptr(WSF), B, H, 0, be.stream) < 0
-
-
 def _bf16_round(a):
     u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000

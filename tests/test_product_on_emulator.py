@@ -913,14 +913,14 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch, v
     against retrieval's launch-by-launch step FROM THE SAME STATE: after two ordinary steps (they create the plans and the optimizer's launch cache) the
     model / optimizer / RNG state is snapshotted, the third step runs through the plan, then again the ordinary way from the snapshot.  Same features, loss
     and accuracy count (computed before the update); the parameters agree as two runs of the ordinary path do.  (With a single-threaded emulator, where float
-    atomics are ordered, four such steps are bit-identical: HIPEMU_THREADS=1, 12 minutes.)  The fused InfoNCE kernels take whole 64-tiles: B = 64.
+    atomics are ordered, four such steps are bit-identical: tools/check_step_plan_bitwise.py.)  B = 32: the plan takes batches that are not whole 64-tiles through the small InfoNCE form.
     Variants: the reconstruction objective (Generation/ATMS_reconstruction.py:222-228: one InfoNCE target + an MSE term), the joint-subject
     model (Retrieval/ATMS_retrieval_joint_train.py:172-192) on one-subject batches and on a batch that mixes four subjects."""
     import copy
     joint = variant.startswith("joint")
     objective = "reconstruction" if variant == "reconstruction" else "retrieval"
     alpha = 0.9 if objective == "reconstruction" else 0.99
-    B, NC = 64, 40
+    B, NC = 32, 40
     cls = T(syn.unit_features(SEED + 4, NC, tag="c"))
     rng = np.random.default_rng(1)
     data = [(T(syn.eeg_batch(SEED + 100 + i, B)), T(syn.unit_features(SEED + 200 + i, B, tag="i")), T(syn.unit_features(SEED + 300 + i, B, tag="t")),
@@ -987,7 +987,7 @@ def test_step_plan_after_a_keep_grads_step_does_not_accumulate_onto_stale_gradie
     zero_grad(set_to_none=True) drops the .grad views but not the values.  A plan step accumulates into that buffer without attach_grads(): it must clear it
     first.  Sequence: 2 warm steps, 1 plan step, 1 keep_grads step (ordinary path), 1 plan step -- against the same five steps with EEGCLIP_STEP_PLAN=0."""
     state_np = syn.make_state(SEED, oatms.state_spec())
-    B, NC = 64, 40
+    B, NC = 32, 40
     cls = T(syn.unit_features(SEED + 4, NC, tag="c"))
     rng = np.random.default_rng(2)
     data = [(T(syn.eeg_batch(SEED + 400 + i, B)), T(syn.unit_features(SEED + 500 + i, B, tag="i")), T(syn.unit_features(SEED + 600 + i, B, tag="t")),

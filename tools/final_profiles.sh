@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 evidence run on the GPU box:  bash tools/final_profiles.sh [tag]
+# round-6 evidence run on the GPU box:  bash tools/final_profiles.sh [tag]
 #   1. PMC passes of the bench command (separate --pmc runs, kernel-trace only) -> per-kernel summary -> per-family HBM-traffic / MFMA-busy table
 #      (written into profiles/ of this copy so that the bench runs below pick it up, and into gpurun_out/ to travel back)
 #   2. rocprofv3 --kernel-trace --stats of the bench command
@@ -7,7 +7,7 @@
 #   4. PMC of the InfoNCE tile kernel at N = 2048, both arithmetic modes
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r5_final}
+TAG=${1:-r6_final}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
@@ -20,7 +20,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 python $R/tools/pmc_summary.py $O/pmc_step.json "$O/g*/**/*counter_collection.csv"
 python $R/tools/pmc_traffic_table.py $O/pmc_step.json 256 > $O/pmc_hbm_traffic.json
-cp $O/pmc_hbm_traffic.json $R/profiles/r5_pmc_hbm_traffic.json
+cp $O/pmc_hbm_traffic.json $R/profiles/r6_pmc_hbm_traffic.json
 find $O -name "*.csv" -delete
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python $R/bench.py --steps 30 --warmup 8 --no-secondary --no-cpu-baseline > $O/stats.log 2>&1 < /dev/null
 cp $O/stats/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

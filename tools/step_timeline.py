@@ -1,5 +1,5 @@
 """timeline of ONE steady-state training step from a rocprofv3 --kernel-trace CSV: start offset / duration / queue of every dispatch between two
-consecutive token_block_fwd launches (tools/round5/gpu_timeline.sh).   python tools/step_timeline.py <kernel_trace.csv> [step index from the end]"""
+consecutive token_block_fwd launches (tools/final_profiles.sh).   python tools/step_timeline.py <kernel_trace.csv> [step index from the end]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
