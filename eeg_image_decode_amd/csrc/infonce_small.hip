@@ -17,7 +17,8 @@
 
 namespace eeg {
 
-constexpr int IS_R = 4;                   // query rows per row workgroup (forward) / per workgroup (gradient)
+constexpr int IS_R = 4;                   // query rows per workgroup of the gradient kernel
+constexpr int IS_RF = 2;                  // query rows per row workgroup of the forward kernel (one pass of slab loads, one (row, target) pair per wave at T = 2)
 constexpr int IS_C = 8;                   // key columns per column workgroup
 constexpr int IS_MAXT = 4;
 constexpr int IS_MAXS = 8;                // partial slabs (all their loads of an element are in flight together: no runtime-length dependent-load loop)
@@ -54,15 +55,15 @@ __device__ __forceinline__ f32x4 is_slab_sum(const float* __restrict__ slabs, in
     return x;
 }
 
-// forward: workgroups [0, n / IS_R) own IS_R query rows each (raw logits out, row log-sum-exps, positives); workgroups behind them own IS_C key columns each
+// forward: workgroups [0, n / IS_RF) own IS_RF query rows each (raw logits out, row log-sum-exps, positives); workgroups behind them own IS_C key columns each
 // over ALL rows (column log-sum-exps) -- both kinds add the slabs themselves, nothing is exchanged inside the launch
 __global__ __launch_bounds__(256) void infonce_small_fwd_kernel(const is_args a) {
     EEG_LDS_BASE(float, v);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, NC = a.T * a.n, nrb = a.n / IS_R;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, NC = a.T * a.n, nrb = a.n / IS_RF;
     const float s = *a.scale;
     if ((int)blockIdx.x < nrb) {
-        const int r0 = blockIdx.x * IS_R;                    // v: [IS_R][T n] scaled logits of this row block
-        for (int q = t; q < IS_R * NC / 4; q += 256) {
+        const int r0 = blockIdx.x * IS_RF;                    // v: [IS_RF][T n] scaled logits of this row block
+        for (int q = t; q < IS_RF * NC / 4; q += 256) {
             const long long off = (long long)r0 * NC + 4 * q;
             const f32x4 x = is_slab_sum(a.slabs, a.nslabs, a.stride, off);
             *reinterpret_cast<f32x4*>(a.S + off) = x;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void infonce_small_fwd_kernel(const is_args a)
             for (int e = 0; e < 4; ++e) v[4 * q + e] = s * x[e];
         }
         __syncthreads();
-        for (int pr = wave; pr < IS_R * a.T; pr += 4) {      // one wave per (row, target)
+        for (int pr = wave; pr < IS_RF * a.T; pr += 4) {      // one wave per (row, target)
             const int i = pr / a.T, tg = pr - i * a.T;
             const float* row = v + i * NC + tg * a.n;
             float m = -3.0e38f;
@@ -196,7 +197,7 @@ extern "C" int eegclip_infonce_small_fwd(const float* slabs, int nslabs, long lo
     if ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(workspace)) & 15u) return EEGCLIP_EALIGN;
     is_args a{};
     is_fill(a, slabs, nslabs, slab_stride, n, T, scale, workspace);
-    EEG_LAUNCH(infonce_small_fwd_kernel, dim3(n / IS_R + T * n / IS_C), dim3(256), (size_t)IS_R * T * n * sizeof(float) + 256, stream, a);
+    EEG_LAUNCH(infonce_small_fwd_kernel, dim3(n / IS_RF + T * n / IS_C), dim3(256), (size_t)IS_RF * T * n * sizeof(float) + 256, stream, a);
     return (int)hipGetLastError();
 }
 

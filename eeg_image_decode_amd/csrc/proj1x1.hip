@@ -39,7 +39,14 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
     double* scr = reinterpret_cast<double*>(aff + 2 * PJ_C);      // [3][80] (rows != NULL)
     const int t = threadIdx.x, b = blockIdx.x;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int i = t; i < PJ_C * PJ_C; i += 256) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = Wt[i];
+    // every global load of the sample is issued HERE, before the statistics prologue: as `for (i = t; ..) lds[..] = global[..]` loops (runtime trip count, not
+    // unrolled) each iteration waited for its own L2 round trip -- 6 + 7 serialised latencies per workgroup of a kernel that is nothing but latency
+    constexpr int NY = (PJ_N + 255) / 256, NWL = (PJ_C * PJ_C + 255) / 256;
+    float yv[NY], wv[NWL];
+#pragma unroll
+    for (int j = 0; j < NY; ++j) yv[j] = t + 256 * j < PJ_N ? y2[(long long)b * PJ_N + t + 256 * j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) wv[j] = t + 256 * j < PJ_C * PJ_C ? Wt[t + 256 * j] : 0.f;
     if (rows) {
         if (t < 3 * 2 * PJ_C) {
             const int sl = t / (2 * PJ_C), col = t % (2 * PJ_C);
@@ -69,14 +76,23 @@ __global__ __launch_bounds__(256) void proj1x1_fwd_kernel(const float* __restric
         aff[t] = gamma[t] * rstd[t];
         aff[PJ_C + t] = beta[t] - mean[t] * gamma[t] * rstd[t];
     }
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int i = t + 256 * j;
+        if (i < PJ_C * PJ_C) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = wv[j];
+    }
     __syncthreads();
-    for (int i = t; i < PJ_N; i += 256) {
-        const int c = i / PJ_W;
-        const long long idx = (long long)b * PJ_N + i;
-        float v = elu1(y2[idx] * aff[c] + aff[PJ_C + c]);
-        if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? v * ks : 0.f;
-        z2[idx] = v;
-        zs[i] = v;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+        const int i = t + 256 * j;
+        if (i < PJ_N) {
+            const int c = i / PJ_W;
+            const long long idx = (long long)b * PJ_N + i;
+            float v = elu1(yv[j] * aff[c] + aff[PJ_C + c]);
+            if (drop_p > 0.f) v = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? v * ks : 0.f;
+            z2[idx] = v;
+            zs[i] = v;
+        }
     }
     __syncthreads();
     for (int o = t; o < PJ_N; o += 256) {
@@ -110,7 +126,17 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
     float* das = ws + PJ_C * PJ_LW;       // [2][40][36]  da and da * xhat of this sample (reduced per channel by 80 threads: no LDS atomics)
     const int t = threadIdx.x;
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int i = t; i < PJ_C * PJ_C; i += 256) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = Wt[i];
+    {
+        constexpr int NWL = (PJ_C * PJ_C + 255) / 256;
+        float wv[NWL];
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) wv[j] = t + 256 * j < PJ_C * PJ_C ? Wt[t + 256 * j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const int i = t + 256 * j;
+            if (i < PJ_C * PJ_C) ws[(i / PJ_C) * PJ_LW + i % PJ_C] = wv[j];
+        }
+    }
     double csum = 0.0;                                  // threads < 80: running channel sum (t < 40: da, else da * xhat)
     constexpr int NWO = (PJ_C * PJ_C + 255) / 256;      // weight-gradient entries per thread
     float dwp[NWO];
@@ -118,24 +144,62 @@ __global__ __launch_bounds__(256) void proj1x1_bwd_kernel(const float* __restric
     for (int j = 0; j < NWO; ++j) dwp[j] = 0.f;
     float dbp = 0.f;                                    // threads < 40: bias gradient of channel t
     const int b0 = blockIdx.x * spw;
+    constexpr int NY = (PJ_N + 255) / 256, SLB = 4;
     for (int b = b0; b < b0 + spw && b < B; ++b) {
+        // all global loads of the sample in flight together (z2, y2, the partial slabs of dfeat in groups of SLB): as runtime-length loops each element waited
+        // for its own L2 round trip, and each slab for the previous one
+        float zv[NY], yv[NY], gv[NY], mv[NY], rv[NY], gav[NY], bev[NY];
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const bool ok = t + 256 * j < PJ_N;
+            const int i = ok ? t + 256 * j : 0;
+            const long long idx = (long long)b * PJ_N + i;
+            zv[j] = z2[idx];
+            yv[j] = y2[idx];
+            gv[j] = 0.f;
+            mv[j] = mean[i / PJ_W];
+            rv[j] = rstd[i / PJ_W];
+            gav[j] = gamma[i / PJ_W];
+            bev[j] = beta[i / PJ_W];
+        }
+        for (int s0 = 0; s0 < nslabs; s0 += SLB) {      // (partial slabs of the K-parallel GEMM, added in slice order)
+            float pv[SLB][NY];
+#pragma unroll
+            for (int k = 0; k < SLB; ++k)
+#pragma unroll
+                for (int j = 0; j < NY; ++j) {
+                    const bool ok = t + 256 * j < PJ_N && s0 + k < nslabs;
+                    pv[k][j] = dfeat[(ok ? (long long)(s0 + k) * slab_stride : 0) + (long long)b * PJ_N + (ok ? t + 256 * j : 0)];
+                }
+#pragma unroll
+            for (int k = 0; k < SLB; ++k)
+                if (s0 + k < nslabs) {
+#pragma unroll
+                    for (int j = 0; j < NY; ++j) gv[j] = (s0 + k == 0) ? pv[k][j] : gv[j] + pv[k][j];
+                }
+        }
         __syncthreads();                                // previous sample consumed (first pass: orders the weight staging)
-        for (int i = t; i < PJ_N; i += 256) {
-            zs[i] = z2[(long long)b * PJ_N + i];
-            float g = dfeat[(long long)b * PJ_N + i];
-            for (int sl = 1; sl < nslabs; ++sl) g += dfeat[(long long)sl * slab_stride + (long long)b * PJ_N + i];      // (partial slabs of the K-parallel GEMM, slice order)
-            ds[(i / PJ_C) * PJ_LW + i % PJ_C] = g;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int i = t + 256 * j;
+            if (i < PJ_N) {
+                zs[i] = zv[j];
+                ds[(i / PJ_C) * PJ_LW + i % PJ_C] = gv[j];
+            }
         }
         __syncthreads();
-        for (int i = t; i < PJ_N; i += 256) {           // input gradient of the 1x1 conv + BatchNorm-backward statistics
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {                  // input gradient of the 1x1 conv + BatchNorm-backward statistics
+            const int i = t + 256 * j;
+            if (i >= PJ_N) break;
             const int c = i / PJ_W, w = i % PJ_W;
             float acc = 0.f;
 #pragma unroll 8
             for (int e = 0; e < PJ_C; ++e) acc += ws[e * PJ_LW + c] * ds[w * PJ_LW + e];
             const long long idx = (long long)b * PJ_N + i;
             dz2[idx] = acc;
-            const float xh = (y2[idx] - mean[c]) * rstd[c];
-            const float u = gamma[c] * xh + beta[c];
+            const float xh = (yv[j] - mv[j]) * rv[j];
+            const float u = gav[j] * xh + bev[j];
             float d = acc;
             if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)idx, drop_p) ? d * ks : 0.f;
             const float da = u > 0.f ? d : d * expf(u);

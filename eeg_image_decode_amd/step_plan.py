@@ -434,6 +434,9 @@ class StepPlan:
         from .optim import AdamW
         if not (enabled() and objective in ("retrieval", "reconstruction") and not keep_grads and _runtime_ok()):
             return False
+        from .plan import default_gemm_precision
+        if default_gemm_precision() != _abi.PREC_BF16X3:          # exact-fp32 plans are launch-per-Linear: nothing to build a plan from (and nothing to warn about)
+            return False
         if world > 1 and (objective != "retrieval" or model.joint_train or os.environ.get("EEGCLIP_STEP_PLAN_DP", "1") == "0"):
             return False
         if not (isinstance(model, ATMS) and model.training and (isinstance(subject_id, int) or model.joint_train)):
