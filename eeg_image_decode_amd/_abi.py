@@ -122,7 +122,7 @@ class PlanOp(C.Structure):
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_GELU_GRAD = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 DT_BF16, DT_F16 = 0, 1
 _P, _I, _F, _L, _U64, _U, _D = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_ulonglong, C.c_uint, C.c_double
 
@@ -242,6 +242,7 @@ PROTOTYPES = {
     "eegclip_wgrad_tok_workspace_floats": [C.POINTER(WgradTokProblem), _I, _I, _I],
     "eegclip_wgrad_tok": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _I, _P],
     "eegclip_wgrad_tok_reduce": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _P],
+    "eegclip_wgrad_tok_reduce_adamw": [C.POINTER(WgradTokProblem), _I, _I, _I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P],
     "eegclip_wgrad_planes": [C.POINTER(WgradPlanesProblem), _I, _P],
     "eegclip_tok_planes_from_f32": [_P, _L, _I, _I, _I, _I, _P, _P],
     "eegclip_cstack_packed_bytes": [_I],

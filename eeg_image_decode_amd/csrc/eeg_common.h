@@ -61,6 +61,20 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
     } while (0)
 #endif
 
+// torch.optim.AdamW single-step math of ONE element (decoupled weight decay, bias correction; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t) from the host
+// in double): shared by csrc/elementwise.hip (adamw_kernel) and csrc/wgrad_tok.hip (the slab reduction that steps the optimizer) -- one expression tree.
+__device__ __forceinline__ void adamw_element(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float gi, float lr, float b1, float b2,
+                                              float eps, float wd, float step, float bc2s) {
+    float pi = *p;
+    pi *= (1.f - lr * wd);
+    const float mi = b1 * *m + (1.f - b1) * gi;
+    const float vi = b2 * *v + (1.f - b2) * gi * gi;
+    *m = mi;
+    *v = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    *p = pi - step * (mi / denom);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

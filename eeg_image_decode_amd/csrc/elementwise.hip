@@ -284,14 +284,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
         if (ZERO) g[i] = 0.f;
-        float pi = p[i];
-        pi *= (1.f - lr * wd);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2s + eps;
-        p[i] = pi - step * (mi / denom);
+        adamw_element(p + i, m + i, v + i, gi, lr, b1, b2, eps, wd, step, bc2s);
     }
 }
 

@@ -24,6 +24,7 @@
 // operand delivery, 3.4 TB/s on the 192 CUs its 12 tiles x 16 XCD-aligned slices occupy, not by its wave layout).
 #include "eeg_common.h"
 
+#include <math.h>
 #include <string.h>
 
 #include <type_traits>
@@ -370,8 +371,44 @@ __device__ __forceinline__ int wk_out_index(int i, int heads, int limit) {
 // sg + 4, ... of its 4 consecutive columns (16-byte loads, all of them in flight), the four groups meet in LDS and are added in a fixed order --
 // the same bits on every run.  (One thread per element walking all slices took 8 .. 18 us per launch: 64 dependent-latency rounds on 250
 // workgroups.)  The bias gradient is column 255 of the slab rows (ones column of X) or the extra per-slice rows behind the tiles (bias_mfma).
-__global__ __launch_bounds__(256) void wgrad_tok_reduce_kernel(const wk_reduce_table tb, int slices) {
+// ADAM (eegclip_wgrad_tok_reduce_adamw): the sums do not land in the gradient, they STEP THE OPTIMIZER -- element x of the gradient run [G, G + n) is
+// x = old gradient + slices (what the plain form stores), then AdamW on the parameter / moments at the same offset and G[x] = 0 (the zero_grad() that opens
+// the next iteration).  The elements of the run that no problem covers (LayerNorm rows, embeddings: their gradients came from other kernels) are stepped
+// by the workgroups behind the reduction's, range by range.  One launch instead of reduction -> optimizer at the end of the training step.
+constexpr int WK_GAPS = 2 * WK_MAXP + 2;
+struct wk_adam {
+    float *G, *P, *M, *V;
+    float lr, b1, b2, eps, wd, step, bc2s;                   // step = lr / (1 - beta1^t)
+    int first_gap_wg, gap_wgs, n_gaps;
+    long long gap0[WK_GAPS], gapn[WK_GAPS];                  // uncovered ranges of the run (offset, count)
+};
+template <bool ADAM>
+__device__ __forceinline__ void wk_land(const wk_adam& A, float* g, float r) {
+    if constexpr (ADAM) {
+        const long long off = g - A.G;
+        const float gi = *g + r;
+        *g = 0.f;
+        adamw_element(A.P + off, A.M + off, A.V + off, gi, A.lr, A.b1, A.b2, A.eps, A.wd, A.step, A.bc2s);
+    } else {
+        *g += r;
+    }
+}
+template <bool ADAM>
+__global__ __launch_bounds__(256) void wgrad_tok_reduce_kernel(const wk_reduce_table tb, int slices, const wk_adam A) {
     EEG_LDS_BASE(f32x4, red);                                // [4 slice groups][64 threads]
+    if constexpr (ADAM) {
+        if ((int)blockIdx.x >= A.first_gap_wg) {             // plain AdamW over the uncovered ranges
+            const int w = (int)blockIdx.x - A.first_gap_wg;
+            for (int r = 0; r < A.n_gaps; ++r)
+                for (long long i = (long long)w * 256 + threadIdx.x; i < A.gapn[r]; i += 256LL * A.gap_wgs) {
+                    const long long x = A.gap0[r] + i;
+                    const float gi = A.G[x];
+                    A.G[x] = 0.f;
+                    adamw_element(A.P + x, A.M + x, A.V + x, gi, A.lr, A.b1, A.b2, A.eps, A.wd, A.step, A.bc2s);
+                }
+            return;
+        }
+    }
     int prob = 0;
 #pragma unroll
     for (int p = 1; p < WK_MAXP; ++p)
@@ -436,15 +473,15 @@ __global__ __launch_bounds__(256) void wgrad_tok_reduce_kernel(const wk_reduce_t
                     for (int e = 0; e < 4; ++e) {
                         const int n = 4 * (c4 + 16 * cb) + e;
                         const int on = wk_out_index(n, P.heads_n, P.N);
-                        if (on >= 0) P.out[(long long)om * P.ldo + on] += r[e];
-                        else if (n == 255 && P.bias_out && !P.bias_mfma) P.bias_out[om] += r[e];
+                        if (on >= 0) wk_land<ADAM>(A, P.out + (long long)om * P.ldo + on, r[e]);
+                        else if (n == 255 && P.bias_out && !P.bias_mfma) wk_land<ADAM>(A, P.bias_out + om, r[e]);
                     }
                 }
             } else if (P.bias_mfma && P.bias_out) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int om = wk_out_index(m + e, P.heads_m, P.M);
-                    if (om >= 0) P.bias_out[om] += r[e];
+                    if (om >= 0) wk_land<ADAM>(A, P.bias_out + om, r[e]);
                 }
             }
         }
@@ -539,7 +576,62 @@ extern "C" int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int 
     int blocks, threads;
     const int rc = wk_tables(p, n_prob, B, slices, workspace, tb, rt, blocks, threads);
     if (rc) return rc;
-    EEG_LAUNCH(wgrad_tok_reduce_kernel, dim3((unsigned)threads), dim3(256), 256 * sizeof(f32x4), stream, rt, slices);
+    wk_adam none;
+    memset(&none, 0, sizeof(none));
+    EEG_LAUNCH(wgrad_tok_reduce_kernel<false>, dim3((unsigned)threads), dim3(256), 256 * sizeof(f32x4), stream, rt, slices, none);
+    return (int)hipGetLastError();
+}
+
+// ... or, at the end of a training step: the sums step the optimizer instead (see wk_adam).  [G, G + n) is one run of the flat gradient buffer with its
+// parameters P and moments M, V at the same offsets; every problem's out (dense: ldo == N) and bias_out must lie inside it, disjoint.
+extern "C" int eegclip_wgrad_tok_reduce_adamw(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, float* P, float* G, float* M,
+                                              float* V, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                                              void* stream) {
+    if (!P || !G || !M || !V || n < 1 || step < 1) return EEGCLIP_EINVAL;
+    wk_table tb;
+    wk_reduce_table rt;
+    int blocks, threads;
+    const int rc = wk_tables(p, n_prob, B, slices, workspace, tb, rt, blocks, threads);
+    if (rc) return rc;
+    // covered ranges of the run, sorted; what lies between them are the gaps
+    long long c0[2 * WK_MAXP], cn[2 * WK_MAXP];
+    int nc = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        if (p[i].ldo != p[i].N) return EEGCLIP_EINVAL;
+        c0[nc] = p[i].out - G;
+        cn[nc++] = (long long)p[i].M * p[i].N;
+        if (p[i].bias_out) {
+            c0[nc] = p[i].bias_out - G;
+            cn[nc++] = p[i].M;
+        }
+    }
+    for (int i = 1; i < nc; ++i)
+        for (int j = i; j > 0 && c0[j] < c0[j - 1]; --j) {
+            const long long a = c0[j], b = cn[j];
+            c0[j] = c0[j - 1]; cn[j] = cn[j - 1];
+            c0[j - 1] = a; cn[j - 1] = b;
+        }
+    wk_adam A;
+    memset(&A, 0, sizeof(A));
+    long long at = 0, gap_total = 0;
+    for (int i = 0; i <= nc; ++i) {
+        const long long upto = i < nc ? c0[i] : n;
+        if (upto < at || (i < nc && c0[i] + cn[i] > n)) return EEGCLIP_EINVAL;       // outside the run, or overlapping ranges
+        if (upto > at) {
+            A.gap0[A.n_gaps] = at;
+            A.gapn[A.n_gaps++] = upto - at;
+            gap_total += upto - at;
+        }
+        if (i < nc) at = c0[i] + cn[i];
+    }
+    A.G = G; A.P = P; A.M = M; A.V = V;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    A.lr = lr; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.wd = weight_decay;
+    A.step = lr / (float)bc1;
+    A.bc2s = (float)sqrt(bc2);
+    A.first_gap_wg = threads;
+    A.gap_wgs = gap_total ? (int)((gap_total + 1023) / 1024 < 64 ? (gap_total + 1023) / 1024 : 64) : 0;
+    EEG_LAUNCH(wgrad_tok_reduce_kernel<true>, dim3((unsigned)(threads + A.gap_wgs)), dim3(256), 256 * sizeof(f32x4), stream, rt, slices, A);
     return (int)hipGetLastError();
 }
 

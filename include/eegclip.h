@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EEGCLIP_ABI_VERSION 10
+#define EEGCLIP_ABI_VERSION 11
 #define EEGCLIP_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
 #define EEGCLIP_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
 
@@ -731,6 +731,13 @@ long long eegclip_wgrad_tok_workspace_floats(const eegclip_wgrad_tok_problem* p,
 int eegclip_wgrad_tok(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, int variant, void* stream);
 /* the second half of the operation (its own entry point = its own kernel: per-launch timing): out += the slices of `workspace`, same arguments */
 int eegclip_wgrad_tok_reduce(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, void* stream);
+/* ... or, at the end of a training step (Retrieval/ATMS_retrieval.py:230-231: loss.backward(); optimizer.step()), the sums STEP THE OPTIMIZER instead of
+ * landing in the gradient: [G, G + n) is one run of the flat gradient buffer, P / M / V the parameters and AdamW moments at the same offsets; every
+ * problem's out (dense: ldo == N) and bias_out must lie inside the run, disjoint.  Element x: g = G[x] + slices (what the plain form would store),
+ * AdamW(step) on P / M / V [x] exactly as eegclip_adamw_step_zero_grad, G[x] = 0.  Elements of the run that no problem covers are stepped from G as it
+ * is.  One launch for reduction + optimizer.step() + zero_grad(). */
+int eegclip_wgrad_tok_reduce_adamw(const eegclip_wgrad_tok_problem* p, int n_prob, int B, int slices, float* workspace, float* P, float* G, float* M, float* V,
+                                   long long n, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream);
 /* the same kernel over PLAIN 2-D planes: out[m][n] += sum_r dY[r][m] X[r][n] with dY (rows, M) and X (rows, N) each a hi and a lo bf16 plane, channel
  * index contiguous, rows lda / ldb ELEMENTS apart (multiples of 8; 16-byte aligned).  rows: multiple of 32.  The kernel reads whole 128-channel tiles:
  * the planes must be readable up to the next multiple of 128 channels past M / N in every row (a column block of a wider buffer, or 256 bytes of

@@ -130,6 +130,66 @@ def test_wgrad_tok_grouped_launch_and_slices(be, variant):
     run_problems(be, ["ffn2", "ffn1", "out_proj"], 4, 2, variant, seed=3)       # 8 k-tiles in 2 slices: 4 per workgroup = the ring's full depth
 
 
+@pytest.mark.parametrize("slices,step", [(1, 1), (3, 7)])
+def test_wgrad_tok_reduce_that_steps_the_optimizer(be, slices, step):
+    """eegclip_wgrad_tok_reduce_adamw == eegclip_wgrad_tok_reduce followed by eegclip_adamw_step_zero_grad over the whole run, BIT FOR BIT: the problems' weight
+    and bias gradients lie scattered inside one flat gradient run with uncovered stretches between them (parameters whose gradients came from elsewhere),
+    the run's old gradient content is part of the sum, and the gradient run ends up zero."""
+    rng = np.random.default_rng(5 + slices)
+    names = ["ffn2", "qkv", "out_proj", "nobias"]
+    B = 2
+    sizes = [(CASES[nm][0], CASES[nm][1], CASES[nm][5]) for nm in names]
+    # layout of the run: gap | W0 | b0 | gap | W1 | gap | b1 | W2 | b2 | W3 | gap
+    lay, at = [], 37
+    for i, (M, N, br) in enumerate(sizes):
+        w_off = at
+        at += M * N + (11 if i % 2 else 0)
+        b_off = at if br else None
+        at += (M if br else 0) + (5 if i == 1 else 0)
+        lay.append((w_off, b_off))
+    n = at + 23
+    g0 = rng.standard_normal(n).astype(np.float32) * 0.01
+    p0, m0, v0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32) * 0.1, rng.random(n).astype(np.float32) * 0.01
+    hyper = (3e-4, 0.9, 0.999, 1e-8, 0.01)
+
+    def run(fused):
+        G, P, M_, V = be.dev(g0.copy()), be.dev(p0.copy()), be.dev(m0.copy()), be.dev(v0.copy())
+        r2 = np.random.default_rng(11)
+        probs = (_abi.WgradTokProblem * len(names))()
+        keep = []
+        for i, nm in enumerate(names):
+            M, N, mg, hm, hn, br = CASES[nm]
+            dy = (r2.standard_normal((64 * B, M)) * 0.5).astype(np.float32)
+            x = r2.standard_normal((64 * B, N)).astype(np.float32)
+            per = M // mg
+            a = [make_planes(be, dy[:, g * per:(g + 1) * per], hm, 0) for g in range(mg)]
+            if mg > 1:
+                a = [be.dev(np.concatenate([be.host(v) for v in a]))]
+            b = make_planes(be, x, hn, br == 1)
+            keep += [a, b]
+            w_off, b_off = lay[i]
+            probs[i] = _abi.WgradTokProblem(a=be.ptr(a[0]), b=be.ptr(b), a_group_stride=B * 65536 if mg > 1 else 0, m_groups=mg, heads_m=hm, heads_n=hn, M=M, N=N,
+                                            out=be.ptr(G) + 4 * w_off, ldo=N, bias_out=(be.ptr(G) + 4 * b_off) if br else None, bias_mfma=int(br == 2))
+        ws = be.dev(np.full(int(be.lib.eegclip_wgrad_tok_workspace_floats(probs, len(names), B, slices)), np.nan, np.float32))
+        assert be.lib.eegclip_wgrad_tok(probs, len(names), B, slices, be.ptr(ws), 0, be.stream) == 0
+        if fused:
+            assert be.lib.eegclip_wgrad_tok_reduce_adamw(probs, len(names), B, slices, be.ptr(ws), be.ptr(P), be.ptr(G), be.ptr(M_), be.ptr(V), n, *hyper, step, be.stream) == 0
+        else:
+            assert be.lib.eegclip_wgrad_tok_reduce(probs, len(names), B, slices, be.ptr(ws), be.stream) == 0
+            assert be.lib.eegclip_adamw_step_zero_grad(be.ptr(P), be.ptr(G), be.ptr(M_), be.ptr(V), n, *hyper, step, 1.0, None, be.stream) == 0
+        be.sync()
+        if fused:                                             # a problem outside the run / a strided output: refused, nothing enqueued
+            assert be.lib.eegclip_wgrad_tok_reduce_adamw(probs, len(names), B, slices, be.ptr(ws), be.ptr(P), be.ptr(G), be.ptr(M_), be.ptr(V), lay[2][0], *hyper, step, be.stream) < 0
+            assert be.lib.eegclip_wgrad_tok_reduce_adamw(probs, len(names), B, slices, be.ptr(ws), be.ptr(P), be.ptr(G), be.ptr(M_), be.ptr(V), n, *hyper, 0, be.stream) < 0
+        return [be.host(t) for t in (G, P, M_, V)]
+
+    a, b = run(True), run(False)
+    assert not a[0].any() and not b[0].any()                  # zero_grad
+    assert np.abs(b[1] - p0).max() > 1e-5                     # (something was stepped)
+    for x, y, nm in zip(a[1:], b[1:], "PMV"):
+        np.testing.assert_array_equal(x, y, err_msg=nm)
+
+
 def test_wgrad_tok_is_reproducible_and_shape_independent(be):
     """same operands -> bit-identical gradients from both workgroup shapes and from a second run (ordered slab reduction, no atomics)"""
     res = []

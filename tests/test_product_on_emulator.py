@@ -943,6 +943,8 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch, v
         monkeypatch.setattr(step_plan, "_runtime_ok", lambda: True)
         monkeypatch.setattr(step_plan, "_on_device", lambda t: True)
         monkeypatch.setattr(step_plan.StepPlan, "WARM_STEPS", 2)
+        if variant == "reconstruction":
+            monkeypatch.setenv("EEGCLIP_WGRAD_ADAMW", "1")
         torch.manual_seed(5)
         m = new_model()
         opt = optim.AdamW(m.parameters(), lr=3e-4)
@@ -956,7 +958,9 @@ def test_single_submission_step_plan_is_the_launch_by_launch_step(monkeypatch, v
         plans = retrieval.step_plans_of(m)
         assert len(plans) == 1 and isinstance(plans[0], step_plan.StepPlan)             # the third step went through the plan ...
         names = plans[0].pl.op_names()
-        assert names.count("eegclip_adamw_step_zero_grad") >= 1 and ("eegclip_infonce_small_grad" in names or "eegclip_infonce_fused_fwd" in names) and names[-1].startswith("eegclip_adamw")
+        assert names.count("eegclip_adamw_step_zero_grad") >= 1 and ("eegclip_infonce_small_grad" in names or "eegclip_infonce_fused_fwd" in names)
+        # the step ends in the optimizer; opt-in (here: the reconstruction variant) the slab reduction of the block's weight gradients steps it itself
+        assert names[-1] == ("eegclip_wgrad_tok_reduce_adamw" if variant == "reconstruction" else "eegclip_adamw_step_zero_grad"), names[-3:]
         assert ("eegclip_mse_loss_grad_scaled" in names) == (objective == "reconstruction")
         assert all(p.grad is None for p in m.parameters()) and float(m._engine().gflat.abs().max()) == 0.0
         res_plan = ({k: p.detach().clone() for k, p in m.named_parameters()}, float(acc[-1]), int(correct), f_plan.clone(),
