@@ -49,7 +49,8 @@ class TokenBlockDesc(C.Structure):
                 + [(k, C.c_void_p) for k in ("xp", "hp", "ctxp", "n1p", "g1p")]
                 + [("drop_p", C.c_float), ("eps", C.c_float), ("scale", C.c_float), ("seed", C.c_ulonglong)]
                 + [(k, C.c_uint) for k in ("site_embed", "site_attn", "site_attn_out", "site_ffn_act", "site_ffn_out")]
-                + [("packed_embed", C.c_void_p), ("embed_subject", C.c_void_p), ("bv_stride", C.c_longlong)])
+                + [("packed_embed", C.c_void_p), ("embed_subject", C.c_void_p), ("bv_stride", C.c_longlong)]
+                + [("cs_w25", C.c_void_p), ("cs_bias", C.c_void_p), ("cs_rows", C.c_void_p), ("cs_H", C.c_int)])
 
 
 class TokenBlockBwdDesc(C.Structure):

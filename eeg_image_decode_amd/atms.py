@@ -600,8 +600,16 @@ class _Engine:
             # the X operands of the block's weight gradients leave as token planes (what the kernel holds in LDS), not fp32: h keeps its fp32 copy
             # too (the residual of the attention sublayer re-reads it), ctx / n1 / g1 exist only as planes; n2 is re-evaluated by the backward
             xp, hp, ctxp, n1p, g1p = self._token_planes(b, B, "xp", "hp", "ctxp", "n1p", "g1p")
+            # (round 6) training plans: the conv stack's BatchNorm1 batch sums of a sample are the TAIL of the block kernel's workgroup (the n3 rows it has just
+            # written are in L2; csrc/cstack_common.h: cs_stats1_sample) instead of the eegclip_cstack_stats1 launch.  EEGCLIP_STATS1_TAIL=0: the launch (A/B aid)
+            stats_args = {}
+            pl.stats1_in_block = bool(cstack and train and os.environ.get("EEGCLIP_STATS1_TAIL", "1") != "0")
+            if pl.stats1_in_block:
+                if "cs_rows" not in b:
+                    b["cs_rows"] = torch.empty(2, B, 2 * C_TS, dtype=torch.float64, device=self.device)
+                stats_args = dict(cs_w25=_p(P[_TS + "0.weight"]), cs_bias=_p(P[_TS + "0.bias"]), cs_rows=_p(b["cs_rows"][0]), cs_H=N_CH)
             pl.tb_desc = pl.call_desc("eegclip_token_block_fwd", _abi.TokenBlockDesc(
-                B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[ve_b0]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]), **joint_args,
+                B=B, x=0, packed=_p(self.tb_packed), bv=_p(P[ve_b0]), pe=_p(pe), tokens=_p(tok), ids=None if shared else _p(b["ids"]), **joint_args, **stats_args,
                 bqkv=_p(P[_LY + "attention.query_projection.bias"]), bo=_p(P[_LY + "attention.out_projection.bias"]), ln1_g=_p(P[_LY + "norm1.weight"]),
                 ln1_b=_p(P[_LY + "norm1.bias"]), b1=_p(P[_LY + "conv1.bias"]), b2=_p(P[_LY + "conv2.bias"]), ln2_g=_p(P[_LY + "norm2.weight"]),
                 ln2_b=_p(P[_LY + "norm2.bias"]), ln3_g=_p(P["encoder.encoder.norm.weight"]), ln3_b=_p(P["encoder.encoder.norm.bias"]),
@@ -749,7 +757,8 @@ class _Engine:
         count1 = float(W * B * N_CH * W_TS)
         stat1, nstat1 = None, 0
         if train:
-            pl.call("eegclip_cstack_stats1", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(rows1), B, N_CH)
+            if not getattr(pl, "stats1_in_block", False):        # (else: row b of rows1 was written by sample b's workgroup of the transformer-block kernel)
+                pl.call("eegclip_cstack_stats1", _p(b["n3"]), L_TOK * D_MODEL, D_MODEL, _p(P[_TS + "0.weight"]), _p(P[_TS + "0.bias"]), _p(rows1), B, N_CH)
             stat1, nstat1 = _p(rows1), B
             if W > 1:
                 pl.call("eegclip_bn_finalize_rows", _p(rows1), B, count1, EPS, 0.1, C_TS, None, None, None, None, None, _p(sums[0]))

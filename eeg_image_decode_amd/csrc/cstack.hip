@@ -21,64 +21,10 @@ __global__ __launch_bounds__(256) void cstack_pack_kernel(const float* __restric
 }
 
 // ---- BatchNorm1 batch sums ------------------------------------------------------------------------------------------------------------------------
-constexpr int CS_LDS_S = CS_MAXH * CS_RS * 4;        // packed rows
-constexpr int CS_LDS_PS = CS_NW * 256 * 4;           // prefix-sum scratch
 __global__ __launch_bounds__(CS_NT) void cstack_stats1_kernel(const float* __restrict__ x, long long xs_b, long long xs_h, const float* __restrict__ w25,
                                                               const float* __restrict__ bias, double* __restrict__ rows, int B, int H, int vec2) {
     EEG_LDS_BASE(unsigned char, ldsb);
-    unsigned* S32 = reinterpret_cast<unsigned*>(ldsb);
-    float* ps = reinterpret_cast<float*>(ldsb + CS_LDS_S);
-    float* sc = ps;                                   // [NW][2][48] per-wave filter sums (after the staging)
-    const int t = threadIdx.x, lane = t & 63, wv = wave_uniform(t >> 6);
-    const int n = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.x;
-    float vx[CS_RPW][4];
-    cs_stage_load<false>(vx, x, xs_b, xs_h, b, H, vec2 != 0);
-    bf16x8 wh[3], wl[3];
-    cs_tap_frags_affine(w25, [&](int c, float& sc, float& sh) { sc = 1.f; sh = bias[c]; }, wh, wl);      // the conv bias rides in the ones slot
-    cs_stage_finish<false>(S32, ps + wv * 256, vx, H);          // (a wave works on the rows it staged: no workgroup barrier)
-    f32x2_t ss[3][2], sq[3][2];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { ss[ct][k] = f32x2_t{0.f, 0.f}; sq[ct][k] = f32x2_t{0.f, 0.f}; }
-    for (int h = wv; h < H; h += CS_NW) {
-#pragma unroll
-        for (int wt = 0; wt < 3; ++wt) {
-            bf16x8 xh, xl;
-            cs_sfrag_ones(S32, h, wt, xh, xl);
-            const float wm = 16 * wt + n < CS_W ? 1.f : 0.f;                                               // (only the last tile has columns w >= 36)
-            f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            cs_mma3_a3(wh, wl, xh, xl, acc);                                                             // y1: D[c = 16 ct + 4 kg + r][w = 16 wt + n]
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                f32x2_t v0 = cs_lo2(acc[ct]), v1 = cs_hi2(acc[ct]);
-                if (wt == 2) { v0 = v0 * f32x2_t{wm, wm}; v1 = v1 * f32x2_t{wm, wm}; }
-                ss[ct][0] += v0;
-                ss[ct][1] += v1;
-                sq[ct][0] = cs_fma2(v0, v0, sq[ct][0]);
-                sq[ct][1] = cs_fma2(v1, v1, sq[ct][1]);
-            }
-        }
-    }
-    __syncthreads();                                  // the scratch rows are dead: they become the per-wave sums
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = ss[ct][r >> 1][r & 1], q = sq[ct][r >> 1][r & 1];
-#pragma unroll
-            for (int msk = 8; msk >= 1; msk >>= 1) { a += __shfl_xor(a, msk, 64); q += __shfl_xor(q, msk, 64); }
-            if (n == 0) { sc[(wv * 2 + 0) * 48 + 16 * ct + 4 * kg + r] = a; sc[(wv * 2 + 1) * 48 + 16 * ct + 4 * kg + r] = q; }
-        }
-    __syncthreads();
-    if (t < 2 * CS_C) {
-        const int which = t / CS_C, c = t % CS_C;
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < CS_NW; ++k) s += (double)sc[(k * 2 + which) * 48 + c];
-        rows[(long long)b * 2 * CS_C + t] = s;
-    }
+    cs_stats1_sample(ldsb, x, xs_b, xs_h, w25, bias, rows, blockIdx.x, H, vec2);
 }
 
 // ---- the fused forward ------------------------------------------------------------------------------------------------------------------------------

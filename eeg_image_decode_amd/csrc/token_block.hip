@@ -318,6 +318,9 @@ struct tb_fwd_args {
     const unsigned short* packed_embed;                          // joint-subject model: one packed value embedding per subject (null: the one in `packed`)
     const int* embed_subject;                                    // ... (B) the sample's subject: matrix and bias row
     long long bv_stride;                                         // ... floats between the subjects' biases
+    const float *cs_w25, *cs_bias;                               // the conv stack's BatchNorm1 batch sums of this sample as the kernel's tail (cs_rows non-null):
+    double* cs_rows;                                             // ... cs_stats1_sample (cstack_common.h) over the n3 rows just written
+    int cs_H;
 };
 
 // The forward kernel takes ~50 pointers (backward part A: 25).  hipcc loads every kernel argument in the entry block and keeps it in scalar registers until its last use, so the
@@ -863,6 +866,14 @@ __global__ __launch_bounds__(TB_THREADS, 2) void token_block_fwd_kernel(const tb
     tb_ln_rows<TRAIN, true>(p8, b, w, lane, AP, XF, nullptr, p8.site_ffn_out, p8.r2, p8.ln2_g, p8.ln2_b, p8.n2, p8.mu2, p8.rs2, p8.ln3_g, p8.ln3_b, p8.n3, p8.mu3, p8.rs3,
                             nullptr, nullptr);
     tb_stamp(a0, b, t, 9);
+    // ---- S9 (training plans): the conv stack's BatchNorm1 batch sums of this sample.  The statistics need y1 of EVERY sample before cstack_fwd can normalise
+    // one, so they were a launch of their own (cstack_stats1: 18 - 20 us, 16 MB of token rows read back from HBM); here the workgroup goes on with its own
+    // sample while the rows are in L2 and the chip is its anyway.  The LDS images of the block are dead: the packed rows overlay them.
+    if (a0.cs_rows) {
+        __syncthreads();                                         // (vmcnt(0) + barrier: every wave's n3 rows are in L2, every LDS read of the row pass is done)
+        const tb_fwd_args p9 = tb_args_again(a0);
+        cs_stats1_sample(lds, p9.n3, (long long)(TB_L * TB_D), (long long)TB_D, p9.cs_w25, p9.cs_bias, p9.cs_rows, b, p9.cs_H, 1);
+    }
 }
 
 
@@ -1322,7 +1333,9 @@ extern "C" int eegclip_token_block_fwd(const eegclip_token_block_desc* d, void* 
                   d->n3, d->mu3, d->rs3, static_cast<unsigned char*>(d->xp), static_cast<unsigned char*>(d->hp), static_cast<unsigned char*>(d->ctxp),
                   static_cast<unsigned char*>(d->n1p), static_cast<unsigned char*>(d->g1p), d->drop_p, d->eps, d->scale, d->seed, d->site_embed, d->site_attn,
                   d->site_attn_out, d->site_ffn_act, d->site_ffn_out, 0u, nullptr, static_cast<const unsigned short*>(d->packed_embed), d->embed_subject,
-                  d->embed_subject ? d->bv_stride : 0};
+                  d->embed_subject ? d->bv_stride : 0, d->cs_w25, d->cs_bias, d->cs_rows, d->cs_H};
+    if (d->cs_rows && (!d->cs_w25 || !d->cs_bias || d->cs_H < 1 || d->cs_H > CS_MAXH || (reinterpret_cast<uintptr_t>(d->cs_rows) & 7u))) return EEGCLIP_EINVAL;
+    static_assert(CS_LDS_S + CS_LDS_PS <= TB_LDS && CS_NT == TB_THREADS, "the conv stack's statistics pass runs in the block kernel's workgroup");
     if (d->embed_subject && (!d->packed_embed || (reinterpret_cast<uintptr_t>(d->packed_embed) & 15u) || d->bv_stride < 0 || (d->bv_stride & 1))) return EEGCLIP_EINVAL;
     static const unsigned dbg = getenv("EEGCLIP_TB_DEBUG") ? (unsigned)atoi(getenv("EEGCLIP_TB_DEBUG")) : 0u;
     //  bit 0 leaves out every activation / plane store -- a timing ablation.  The weight-gradient operands exist ONLY as those planes, so a stray

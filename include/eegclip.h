@@ -505,6 +505,12 @@ typedef struct {
     const void* packed_embed;
     const int* embed_subject;
     long long bv_stride;
+    /* (round 6) cs_rows non-NULL: the workgroup goes on with the BatchNorm1 batch sums of the conv stack for its sample -- eegclip_cstack_stats1's work
+       (Retrieval/ATMS_retrieval.py:102-104: y1 = pool(conv(n3 rows 0 .. cs_H - 1)), per-channel [sum | sumsq] as row b of cs_rows (B, 80) fp64) from the n3
+       rows it has just written (still in L2): that launch and its 16 MB read go.  cs_w25 (40, 25) / cs_bias (40): the temporal conv; cs_H <= 64. */
+    const float *cs_w25, *cs_bias;
+    double* cs_rows;
+    int cs_H;
 } eegclip_token_block_desc;
 long long eegclip_token_block_packed_bytes(void);
 int eegclip_token_block_pack(const float* wv, const float* wqkv, const float* wo, const float* w1, const float* w2, void* packed, void* stream);

@@ -145,3 +145,41 @@ def test_both_workgroup_shapes_of_the_weight_gradient_kernel_on_the_emulator(mon
 @pytest.mark.parametrize("B", [3, 256])
 def test_both_workgroup_shapes_of_the_weight_gradient_kernel_on_the_gpu(B, monkeypatch):
     check_both_workgroup_shapes_of_the_weight_gradient_kernel("cuda", B, monkeypatch)
+
+
+def check_stats_tail_equals_the_statistics_launch(dev, B, monkeypatch):
+    """(round 6) the conv stack's BatchNorm1 batch sums as the TAIL of the block kernel (eegclip_token_block_desc.cs_rows) against the eegclip_cstack_stats1
+    launch it replaces (EEGCLIP_STATS1_TAIL=0): the same device function over the same n3 rows -- the partial rows, and with them the embeddings and the
+    BatchNorm running statistics, are identical bit for bit."""
+    res = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("EEGCLIP_STATS1_TAIL", tail)
+        monkeypatch.setenv("EEGCLIP_TOKEN_BLOCK", "1")
+        m = _model(dev).train()
+        x = torch.from_numpy(syn.eeg_batch(SEED + 33, B)).to(dev)
+        torch.manual_seed(77)
+        with torch.no_grad():
+            z = m(x, 1)
+        eng = m._engine()
+        names = eng.plans[next(k for k in eng.plans if k[0] == "f")].op_names()
+        assert ("eegclip_cstack_stats1" in names) == (tail == "0") and "eegclip_cstack_fwd" in names
+        res.append((eng.bufs[B]["cs_rows"][0].cpu().numpy().copy(), z.cpu().numpy(), {k: v.cpu().numpy().copy() for k, v in m.state_dict().items() if "running" in k}))
+    (r1, z1, bn1), (r0, z0, bn0) = res
+    assert np.isfinite(r1).all() and np.abs(r1).max() > 0
+    np.testing.assert_array_equal(r1, r0)
+    np.testing.assert_array_equal(z1, z0)
+    for k in bn1:
+        np.testing.assert_array_equal(bn1[k], bn0[k], err_msg=k)
+
+
+@pytest.mark.emu
+def test_conv_stack_statistics_as_the_block_kernels_tail_on_the_emulator(monkeypatch):
+    from emu_patch import product_on_emulator
+    with product_on_emulator():
+        check_stats_tail_equals_the_statistics_launch(torch.device("cpu"), 3, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 256])
+def test_conv_stack_statistics_as_the_block_kernels_tail_on_the_gpu(B, monkeypatch):
+    check_stats_tail_equals_the_statistics_launch(torch.device("cuda"), B, monkeypatch)

@@ -4,11 +4,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 R=$GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r6j}
 mkdir -p $O
-timeout 900 python -m pytest tests/test_kernels_wgrad.py tests/test_model_gpu.py tests/test_full_size_gpu.py -x -q -m gpu -k "optimizer or step_plan or train_model or train_step" 2>&1 | grep -v "amdgpu.ids\|RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -4 > $O/tests.txt
+timeout 900 python -m pytest tests/test_token_block.py tests/test_model_gpu.py tests/test_full_size_gpu.py tests/test_dp_gpu.py -x -q -m gpu 2>&1 | grep -v "amdgpu.ids\|RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -4 > $O/tests.txt
 cat $O/tests.txt
 for i in 1 2; do
 python bench.py --steps 200 --warmup 30 --no-secondary --no-cpu-baseline > $O/bench_$i.json 2>> $O/bench.err
-EEGCLIP_WGRAD_ADAMW=0 python bench.py --steps 200 --warmup 30 --no-secondary --no-cpu-baseline > $O/bench_off_$i.json 2>> $O/bench.err
+EEGCLIP_STATS1_TAIL=0 python bench.py --steps 200 --warmup 30 --no-secondary --no-cpu-baseline > $O/bench_off_$i.json 2>> $O/bench.err
 done
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/$O/prof -o trace -- python $R/bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $R/$O/bench_prof.json 2> $R/$O/prof.err)
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
