@@ -355,7 +355,7 @@ def _head_split(B):
 
 class _Engine:
     """Flat parameter/gradient storage + per-batch-size activation buffers and launch plans."""
-    check_cleared = False
+    check_cleared = False        # debug: verify the flat gradient buffer whenever attach_grads() skips its clear (see there)
 
     @property
     def model(self):
@@ -363,7 +363,6 @@ class _Engine:
         if m is None:
             raise EegclipError("the ATMS model of this engine has been garbage-collected")
         return m
-        # debug: verify the flat gradient buffer whenever attach_grads() skips its clear (see there)
 
     def __init__(self, model):
         sd_params = dict(model.named_parameters())

@@ -1,20 +1,24 @@
-"""One submission per training step (round 5).
+"""One submission per training step (round 5; widened in round 6).
 
 The reference's batch loop (Retrieval/ATMS_retrieval.py:209-250) is paced by the Python interpreter: forward, two losses, backward, optimizer, the
-running accuracy -- every torch op issued from the loop.  This build already replayed the encoder's forward and backward as two C-side launch plans
-(plan.py), but the loss, the accuracy readout and the optimizer were still enqueued from Python between them, through two autograd Functions:
-~0.3 ms of interpreter time per 0.85 ms step.  In steady state nothing about the step changes except a handful of pointers (the batch, its targets and
-labels, the fresh output tensor), the dropout seed and the optimizer's step count, so the WHOLE step is one plan:
+running accuracy -- every torch op issued from the loop.  In steady state nothing about the step changes except a handful of pointers (the batch, its
+targets and labels, the fresh output tensor), the dropout seed and the optimizer's step count, so the WHOLE step is one plan:
 
-    [encoder forward] -> accuracy GEMM / top-1 / count (second stream) -> feature split -> fused InfoNCE forward + gradient matrices -> dA GEMMs
-    -> [encoder backward] -> join -> fused AdamW + gradient clear
+    [encoder forward; riders of its 1x1-conv launch split this step's head weights and loss targets into planes]
+    -> logits of all targets (one K-parallel plane GEMM) -> InfoNCE rows / columns -> gradient matrices as planes -> query-gradient GEMM (slabs)
+       [fork: accuracy GEMM from planes + top-1 count]
+    -> [encoder backward; the optimizer update of the early gradient bucket on the second stream behind the conv stack's last gradient]
+    -> join -> fused AdamW + gradient clear over the rest
 
-replayed by ONE foreign call (eegclip_plan_run).  The launches, their order, their arguments and the random-number consumption are exactly those of
-the launch-by-launch path -- tools/check_step_plan_bitwise.py (single-threaded emulator: ordered float atomics) compares every tensor bit for bit,
-tests/test_product_on_emulator.py one step from a common snapshot at round-off tolerance, tests/test_full_size_gpu.py the plan's losses, embeddings and
-post-AdamW parameters against the ORACLE at B = 256 -- so this is a host-side optimisation only; anything outside the steady state (first steps of a
-run, another batch size, a user-supplied loss or optimizer, gradient accumulation, data parallelism, the joint-subject model) takes the ordinary
-path.  EEGCLIP_STEP_PLAN=0 disables it.
+replayed by ONE foreign call (eegclip_plan_run).  The launches, their order, their arguments and the random-number consumption are those of the
+launch-by-launch path -- tools/check_step_plan_bitwise.py (single-threaded emulator: ordered float atomics) compares every tensor bit for bit,
+tests/test_product_on_emulator.py one step from a common snapshot at round-off tolerance for the four objectives, tests/test_full_size_gpu.py the plan's
+losses, embeddings and post-AdamW parameters against the ORACLE at B = 256, tests/test_dp_gpu.py the data-parallel form against the launch-by-launch
+data-parallel loop -- so this is a host-side optimisation only.  Objectives: retrieval, reconstruction (Generation/ATMS_reconstruction.py:222-228),
+the joint-subject model (Retrieval/ATMS_retrieval_joint_train.py:172-192; the per-step subject layout is patched into the plan), and -- world > 1 -- data
+parallelism (the op array is cut into segments around host callbacks: target all-gather, the data-parallel loss, the flat-gradient all-reduce).
+Anything outside the steady state (first steps of a run, another batch size, a user-supplied loss or optimizer, keep_grads) takes the ordinary path;
+EEGCLIP_STEP_PLAN=0 disables the plan, NotApplicable says why one cannot be built.
 """
 import ctypes
 import os
