@@ -61,6 +61,28 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
     } while (0)
 #endif
 
+// sum of the partial slabs of a K-parallel GEMM (csrc/head_gemm.hip) at float offset i, 4 consecutive floats, in SLICE ORDER: p[0] + p[1] + ... -- the loads
+// of up to 8 slabs issued before the first add (as a runtime-length `v += slab[s][i]` loop every slab waits for the previous one's L2 round trip: the
+// compiler does not pipeline loads across iterations of a loop it cannot unroll).  Slabs past nslabs re-read slab 0 (a cache hit) and are not added.
+__device__ __forceinline__ f32x4 slab_sum4_inflight(const float* __restrict__ slabs, int nslabs, long long stride, long long i) {
+    f32x4 v;
+    for (int s0 = 0; s0 < nslabs; s0 += 8) {
+        f32x4 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = *reinterpret_cast<const f32x4*>(slabs + (long long)(s0 + k < nslabs ? s0 + k : 0) * stride + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < nslabs) {
+                if (s0 + k == 0) v = p[k];
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p[k][e];
+                }
+            }
+    }
+    return v;
+}
+
 // torch.optim.AdamW single-step math of ONE element (decoupled weight decay, bias correction; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t) from the host
 // in double): shared by csrc/elementwise.hip (adamw_kernel) and csrc/wgrad_tok.hip (the slab reduction that steps the optimizer) -- one expression tree.
 __device__ __forceinline__ void adamw_element(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float gi, float lr, float b1, float b2,

@@ -129,13 +129,7 @@ __global__ __launch_bounds__(256) void dropout_scale_kernel(float* __restrict__ 
 //   head_act      u = sum_s slab[s] + bias;  pre = u;  out = gelu(u);  (out_hi | out_lo) = out again as bf16 planes     (ATMS_retrieval.py:160-162)
 //   head_act_bwd  dx = base + (sum_s slab[s]) * gelu'(pre)  (base may be dx: the residual branch's gradient), + planes   (its backward)
 __device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ slabs, int nslabs, long long stride, long long i) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + i);
-    for (int s = 1; s < nslabs; ++s) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(slabs + (long long)s * stride + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += w[e];
-    }
-    return v;
+    return slab_sum4_inflight(slabs, nslabs < 1 ? 1 : nslabs, stride, i);
 }
 __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__ slabs, int nslabs, long long stride, const float* __restrict__ bias,
                                                         float* __restrict__ pre, float* __restrict__ out, unsigned short* __restrict__ out_hi,

@@ -133,11 +133,28 @@ __global__ __launch_bounds__(256) void infonce_small_grad_kernel(const is_args a
     const float s = *a.scale;
     float ds = 0.f, ls = 0.f;
     const float inv2n = 0.5f / (float)a.n;
-    for (int q = t; q < IS_R * NC / 4; q += 256) {
+    // two column quads per thread and pass, their loads in flight together (n = 256, T = 2: the whole row block in one pass)
+    constexpr int NQ = 2;
+    for (int qb = t; qb < IS_R * NC / 4; qb += 256 * NQ) {
+      f32x4 raws[NQ], lcvs[NQ];
+      float lrs[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int q = qb + 256 * u;
+        const bool ok = q < IS_R * NC / 4;
+        const int i = ok ? (4 * q) / NC : 0, j0 = ok ? 4 * q - i * NC : 0, tg = j0 / a.n;
+        lrs[u] = a.lse_r[tg * a.n + r0 + i];
+        raws[u] = *reinterpret_cast<const f32x4*>(a.S + (long long)(r0 + i) * NC + j0);
+        lcvs[u] = *reinterpret_cast<const f32x4*>(a.lse_c + j0);
+      }
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int q = qb + 256 * u;
+        if (q >= IS_R * NC / 4) continue;
         const int i = (4 * q) / NC, j0 = 4 * q - i * NC, tg = j0 / a.n;          // (n % 4 == 0: the 4 columns share a target)
-        const float c = a.w[tg] * inv2n, lr = a.lse_r[tg * a.n + r0 + i];
-        const f32x4 raw = *reinterpret_cast<const f32x4*>(a.S + (long long)(r0 + i) * NC + j0);
-        const f32x4 lcv = *reinterpret_cast<const f32x4*>(a.lse_c + j0);
+        const float c = a.w[tg] * inv2n, lr = lrs[u];
+        const f32x4 raw = raws[u];
+        const f32x4 lcv = lcvs[u];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -152,6 +169,7 @@ __global__ __launch_bounds__(256) void infonce_small_grad_kernel(const is_args a
         x3_split4(o[0], o[1], o[2], o[3], hi, lo);
         *reinterpret_cast<u32x2_t*>(a.g_hi + (long long)(r0 + i) * a.ldg + j0) = hi;
         *reinterpret_cast<u32x2_t*>(a.g_lo + (long long)(r0 + i) * a.ldg + j0) = lo;
+      }
     }
     // loss terms of this block's rows and of the columns that are its rows' positives
     if (t < IS_R * a.T) {

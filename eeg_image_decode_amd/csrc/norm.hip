@@ -237,19 +237,17 @@ __global__ __launch_bounds__(256) void head_ln_fwd_kernel(const float* __restric
     constexpr int COLS = 1024;
     const int row = blockIdx.x, c = 4 * threadIdx.x;
     const long long i0 = (long long)row * COLS + c;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + i0);
-    for (int sl = 1; sl < xs.n; ++sl) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(x + (long long)sl * xs.stride + i0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += p[e];
-    }
+    // every load of the row is issued here (the affine parameters were fetched behind the two block reductions: one more L2 round trip each)
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c), bv = *reinterpret_cast<const f32x4*>(beta + c);
+    const f32x4 rv = resid ? *reinterpret_cast<const f32x4*>(resid + i0) : zero4;
+    const f32x4 pb = xs.bias ? *reinterpret_cast<const f32x4*>(xs.bias + c) : zero4;
+    f32x4 v = slab_sum4_inflight(x, xs.n < 1 ? 1 : xs.n, xs.stride, i0);
     if (xs.bias) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(xs.bias + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += p[e];
+        for (int e = 0; e < 4; ++e) v[e] += pb[e];
     }
     if (resid) {
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(resid + i0);
         if (drop_p > 0.f) {
             bool keep[4];
             dropout_keep4(seed, site, (unsigned long long)i0, drop_p, keep);
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(256) void head_ln_fwd_kernel(const float* __restric
     for (int e = 0; e < 4; ++e) q += (v[e] - mean) * (v[e] - mean);
     ln_block_sum2(q, dummy, red);
     const float rstd = rsqrtf(q * (1.0f / COLS) + eps);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c), bv = *reinterpret_cast<const f32x4*>(beta + c);
+    
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * gv[e] + bv[e];
     *reinterpret_cast<f32x4*>(y + i0) = v;
@@ -293,15 +291,12 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const float* __restric
     constexpr int COLS = 1024;
     const int row = blockIdx.x, c = 4 * threadIdx.x;
     const long long i0 = (long long)row * COLS + c;
-    f32x4 dv = *reinterpret_cast<const f32x4*>(dy + i0);
-    for (int sl = 1; sl < dys.n; ++sl) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(dy + (long long)sl * dys.stride + i0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dv[e] += p[e];
-    }
-    if (dy_sum) *reinterpret_cast<f32x4*>(dy_sum + i0) = dv;
+    // every load of the row before its first store (vmcnt retires in order and counts stores: a load behind a store waits for the store's round trip)
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i0), gv = *reinterpret_cast<const f32x4*>(gamma + c);
     const float mu = mean[row], rs = rstd[row];
+    const f32x4 dx_old = accumulate_dx ? *reinterpret_cast<const f32x4*>(dx + i0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dv = slab_sum4_inflight(dy, dys.n < 1 ? 1 : dys.n, dys.stride, i0);
+    if (dy_sum) *reinterpret_cast<f32x4*>(dy_sum + i0) = dv;
     float xh[4], g[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -316,9 +311,8 @@ __global__ __launch_bounds__(256) void head_ln_bwd_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = rs * (g[e] - c1 - xh[e] * c2);
     if (accumulate_dx) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(dx + i0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += o[e];
+        for (int e = 0; e < 4; ++e) v[e] += dx_old[e];
     }
     *reinterpret_cast<f32x4*>(dx + i0) = v;
     if (dx_drop) {
@@ -818,6 +812,23 @@ __global__ __launch_bounds__(256) void bn_elu_bwd_apply_rows_kernel(const float*
                                                                      unsigned long long seed, unsigned site) {
     EEG_LDS_BASE(double, scr);                               // [4][2] wave sums
     const int t = threadIdx.x, c = blockIdx.x, lane = t & 63, w = t >> 6;
+    const int b0 = blockIdx.y * 32, nb = outer - b0 < 32 ? outer - b0 : 32;
+    // the elements of this workgroup in batches of NB per thread, all loads of a batch in flight (a plain runtime-length loop waits for one L2 round trip per
+    // element); the FIRST batch -- all of it at inner = 36 -- is issued before the table is summed: it does not depend on the sums
+    constexpr int NB = 6;
+    float xv[NB], dv[NB];
+    long long idx[NB];
+    auto load = [&](int q0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int q = q0 + 256 * j;
+            const bool ok = q < nb * inner;
+            idx[j] = ok ? ((long long)(b0 + q / inner) * C + c) * inner + q % inner : -1;
+            xv[j] = ok ? x[idx[j]] : 0.f;
+            dv[j] = ok ? dz[idx[j]] : 0.f;
+        }
+    };
+    load(t);
     double s0 = 0.0, s1 = 0.0;
     for (int r = t; r < nrows; r += 256) {
         s0 += rows[(long long)r * ld + col0 + c];
@@ -835,15 +846,19 @@ __global__ __launch_bounds__(256) void bn_elu_bwd_apply_rows_kernel(const float*
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const float rs = rstd[c], g = gamma[c], mu = mean[c], be = beta[c];
     const float m1 = (float)(sum_da / count), m2 = (float)(sum_dax / count);
-    const int b0 = blockIdx.y * 32, nb = outer - b0 < 32 ? outer - b0 : 32;
-    for (int q = t; q < nb * inner; q += 256) {
-        const long long i = ((long long)(b0 + q / inner) * C + c) * inner + q % inner;
-        const float xh = (x[i] - mu) * rs;
-        const float u = g * xh + be;
-        float d = dz[i];
-        if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
-        const float da = u > 0.f ? d : d * expf(u);
-        dx[i] = g * rs * (da - m1 - xh * m2);
+    for (int q0 = t; q0 < nb * inner; q0 += 256 * NB) {
+        if (q0 != t) load(q0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (idx[j] < 0) continue;
+            const long long i = idx[j];
+            const float xh = (xv[j] - mu) * rs;
+            const float u = g * xh + be;
+            float d = dv[j];
+            if (drop_p > 0.f) d = dropout_keep(seed, site, (unsigned long long)i, drop_p) ? d * ks : 0.f;
+            const float da = u > 0.f ? d : d * expf(u);
+            dx[i] = g * rs * (da - m1 - xh * m2);
+        }
     }
 }
 
