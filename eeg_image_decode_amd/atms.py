@@ -705,8 +705,17 @@ class _Engine:
             # each slice leaves its partial tile as a slab and the launch that consumes the result anyway adds the slabs while it loads them:
             # bias + GELU (+ the planes of gelu(u) for the second Linear) after the first, dropout + residual + LayerNorm after the second
             fp, gp = (_p(b["featp"][0]), _p(b["featp"][1])), (_p(b["gup"][0]), _p(b["gup"][1]))
-            sl1 = self._head_gemm(pl, b, "hslab1", fp, F_TS, self.hw["w1"], P_DIM, B)
-            pl.call("eegclip_head_act", *sl1, _p(P["proj_eeg.0.bias"]), _p(b["u"]), _p(b["gu"]), *gp, B, P_DIM)
+            # (OPT-IN EEGCLIP_HEAD_FUSED_EPI=1: the first Linear unsplit with bias + GELU + planes in its own epilogue -- one launch instead of GEMM slabs +
+            #  head_act; measured SLOWER in the step, 0.658 - 0.661 against 0.647 - 0.655 ms alternated in one call (34 launches against 36): the unsplit GEMM walks
+            #  K alone for 13 us where the K-parallel GEMM + the elementwise launch take 6.5 + 6)
+            fused_epi = os.environ.get("EEGCLIP_HEAD_FUSED_EPI", "0") == "1"
+            if fused_epi:
+                pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=fp[0], a_lo=fp[1], b_hi=self.hw["w1"][0], b_lo=self.hw["w1"][1], lda=F_TS, ldb=F_TS, M=B,
+                                                                   N=P_DIM, K=F_TS, slices=1, slab_stride=0, bias=_p(P["proj_eeg.0.bias"]), Cpre=_p(b["u"]),
+                                                                   ldcpre=P_DIM, act=ACT_GELU, C=_p(b["gu"]), ldc=P_DIM, p_hi=gp[0], p_lo=gp[1], ldp=P_DIM))
+            else:
+                sl1 = self._head_gemm(pl, b, "hslab1", fp, F_TS, self.hw["w1"], P_DIM, B)
+                pl.call("eegclip_head_act", *sl1, _p(P["proj_eeg.0.bias"]), _p(b["u"]), _p(b["gu"]), *gp, B, P_DIM)
             sl2 = self._head_gemm(pl, b, "hslab2", gp, P_DIM, self.hw["w2"], P_DIM, B)
             # s = u + dropout(W gelu(u) + b), out = LayerNorm(s): ResidualAdd + LayerNorm of Proj_eeg in one launch; `out` is a fresh tensor per call
             # (argument 8 is patched by forward()); arguments 19 / 20: out again as planes (the step plan's loss operand)
@@ -892,8 +901,13 @@ class _Engine:
             wplanes = B % 32 == 0 and os.environ.get("EEGCLIP_HEAD_WGRAD_PLANES", "1") != "0"
             if not wplanes:
                 later(lambda: wgrad("proj_eeg.1.fn.1.weight", _p(b["dv"]), P_DIM, _p(b["gu"]), P_DIM, P_DIM, P_DIM, B, bias="proj_eeg.1.fn.1.bias"))
-            sl = self._head_gemm(pl, b, "dgu_slabs", vp, P_DIM, self.hw["w2"], P_DIM, B, kmajor=True)
-            pl.call("eegclip_head_act_bwd", *sl, _p(b["u"]), _p(b["ds"]), _p(b["ds"]), *up, B * P_DIM)          # ds := du = ds + dgu * gelu'(u)
+            if os.environ.get("EEGCLIP_HEAD_FUSED_EPI", "0") == "1":     # (opt-in, see the forward: GELU' + the residual in the unsplit GEMM's epilogue)
+                pl.call_desc("eegclip_head_gemm", _abi.HeadGemmDesc(a_hi=vp[0], a_lo=vp[1], b_hi=self.hw["w2"][0], b_lo=self.hw["w2"][1], lda=P_DIM, ldb=P_DIM, M=B,
+                                                                   N=P_DIM, K=P_DIM, slices=1, slab_stride=0, act=ACT_GELU_GRAD, aux=_p(b["u"]), ldaux=P_DIM,
+                                                                   R=_p(b["ds"]), ldr=P_DIM, C=_p(b["ds"]), ldc=P_DIM, p_hi=up[0], p_lo=up[1], ldp=P_DIM, b_kmajor=1))
+            else:
+                sl = self._head_gemm(pl, b, "dgu_slabs", vp, P_DIM, self.hw["w2"], P_DIM, B, kmajor=True)
+                pl.call("eegclip_head_act_bwd", *sl, _p(b["u"]), _p(b["ds"]), _p(b["ds"]), *up, B * P_DIM)          # ds := du = ds + dgu * gelu'(u)
             if wplanes:
                 gp_, fp_ = (_p(b["gup"][0]), _p(b["gup"][1])), (_p(b["featp"][0]), _p(b["featp"][1]))
                 probs = (_abi.WgradPlanesProblem * 2)(
