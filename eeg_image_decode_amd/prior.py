@@ -573,6 +573,86 @@ class _PriorEngine:
         pl.run(raw_stream(), b.get("seed", 0))
 
 
+class _TrainStepPlan:
+    """Pipe.train's steady-state iteration (Generation/diffusion_prior.py:302-333: add_noise, forward, MSE, backward, clip_grad_norm_, optimizer.step) as ONE
+    launch plan replayed by one foreign call -- what step_plan.StepPlan is for the contrastive loop.  Built from the engine's own forward / backward plans of a
+    (batch size, condition present, dropout) key and the optimizer's cached launches once the ordinary path has run that key; per step the host draws the
+    noise and the timesteps into fixed buffers (the same generator calls in the same order), patches four pointers, the learning rate and the step counts.
+    Launch for launch the ordinary step, except that the optimizer launches clear the gradients behind their read (the zero_grad() that opens the next
+    iteration) instead of a 39 MB fill.  Single process only (data parallel: the gradient all-reduce sits between backward and clipping)."""
+
+    def __init__(self, pipe, eng, optimizer, key, fast, sumsq, clip):
+        N, cond, p = key
+        self.key, self.fast, self.eng = key, fast, eng
+        fwd, bwd = eng.plans[("f",) + key], eng.plans[("b",) + key]
+        if not (getattr(fwd, "planes", False) and getattr(bwd, "planes", False)):
+            raise ValueError("plane-GEMM plans required")
+        b = eng.bufs[N]
+        E, dev = eng.model.embed_dim, eng.device
+        T = pipe.scheduler.config.num_train_timesteps
+        self.T = T
+        self.noise = torch.empty(N, E, dtype=torch.float32, device=dev)
+        self.ts = torch.empty(N, dtype=torch.int64, device=dev)
+        self.x = torch.empty(N, E, dtype=torch.float32, device=dev)
+        sa, sb = pipe.scheduler._tables(dev)
+        pl = Plan(f"prior_train_step[N={N}]")
+        pl._keep += [fwd, bwd, sa, sb, self.noise, self.ts, self.x, sumsq, clip]
+
+        def splice(src):
+            base = len(pl.ops)
+            for fn, args, name, side in src.ops:
+                pl.ops.append((fn, list(args), name, side))
+            pl._seed_slots += [(base + i, j) for i, j in src._seed_slots]
+            pl._seed_descs += src._seed_descs
+        self.noise_op = len(pl.ops)
+        pl.call("eegclip_ddpm_add_noise", 0, _p(self.noise), _p(self.ts), _p(sa), _p(sb), _p(self.x), N, E)
+        self.fwd = fwd
+        splice(fwd)
+        self.mse_op = len(pl.ops)
+        pl.call("eegclip_mse_loss_grad", _p(b["out"]), _p(self.noise), N * E, 0, _p(b["dout"]))
+        splice(bwd)
+        pl.join()
+        pl.memset(sumsq)
+        pl.call("eegclip_sumsq", _p(eng.gflat), eng.gflat.numel(), _p(sumsq))
+        pl.call("eegclip_clip_scale", _p(sumsq), 1.0, _p(clip))
+        g = optimizer.param_groups[0]
+        b1, b2 = g["betas"]
+        self.adam_ops = []
+        for (p0, n, wp, gp, mp, vp, members) in fast["launch"]:
+            self.adam_ops.append(len(pl.ops))
+            pl.call("eegclip_adamw_step_zero_grad", wp, gp, mp, vp, n, g["lr"], b1, b2, g["eps"], g["weight_decay"], 0, 1.0, _p(clip))
+        self.pl = pl
+        self.group = g
+
+    def usable(self, optimizer):
+        eng, key = self.eng, self.key
+        return eng.plans.get(("f",) + key) is self.fwd and optimizer.param_groups[0] is self.group and optimizer.activate_launch_set(0, self.fast)
+
+    def run(self, h, c, loss_sum, tt):
+        """h (N, E) fp32 contiguous on the device, c the condition or None (as the key says); draws noise / timesteps like the ordinary step"""
+        pl, fast, g = self.pl, self.fast, self.group
+        N, cond, p = self.key
+        self.noise.normal_()                                   # torch.randn_like(h): the same generator call
+        self.ts.random_(0, self.T)                             # torch.randint(0, T, (N,), device=...)
+        tt.copy_(self.ts)                                      # the time embedding's fp32 timesteps
+        pl.set_arg(self.noise_op, 0, h.data_ptr())
+        pl.set_arg(self.mse_op, 3, loss_sum.data_ptr())
+        self.fwd.in_items[0].src = self.x.data_ptr()
+        if cond:
+            self.fwd.in_items[2].src = c.data_ptr()
+        fast["run_steps"] = [st + 1 for st in fast["run_steps"]]
+        fast["pending"] += 1
+        for op, st in zip(self.adam_ops, fast["run_steps"]):
+            pl.set_arg(op, 5, g["lr"])
+            pl.set_arg(op, 10, st)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        self.eng.bufs[N]["seed"] = seed
+        pl._keep_step = (h, c, loss_sum)
+        pl.run(raw_stream(), seed)
+        self.eng.last_key = self.key
+        self.eng.version[self.key] = self.eng.version.get(self.key, 0) + 1
+
+
 class EmbeddingDataset(Dataset):
     def __init__(self, c_embeddings, h_embeddings):
         self.c_embeddings = c_embeddings
@@ -710,6 +790,8 @@ class Pipe:
         optimizer.grad_scale_dev = clip
         step = 0
         drop_gen = None
+        plans, warm = {}, {}
+        plan_on = edist.world_size() == 1 and os.environ.get("EEGCLIP_PRIOR_STEP_PLAN", "1") != "0"
         if edist.world_size() > 1:
             # data parallel: the whole-batch condition drop must be ONE decision for all ranks -- a rank that dropped the condition has no
             # gradient for the condition layers, Adam would skip them there and step them elsewhere, and the replicas would drift apart for
@@ -728,12 +810,30 @@ class Pipe:
                 if (torch.rand(1, generator=drop_gen) if drop_gen is not None else torch.rand(1)) < self.cond_drop_prob:      # (:304)
                     c_embeds = None
                 self.cond_dropped.append(c_embeds is None)
+                step += 1
+                lr = cosine_with_warmup_lr(step, learning_rate, 500, total_steps)      # lr_scheduler.step() BEFORE optimizer.step() (:331-332)
+                self.lr_history.append(lr)
+                for gq in optimizer.param_groups:
+                    gq["lr"] = lr
+                c32 = c_embeds.float().contiguous() if c_embeds is not None else None
+                # the steady state as one submission (_TrainStepPlan): a (batch size, condition, dropout) key that the ordinary path below has stepped
+                # twice -- its plans and the optimizer's launch set exist -- goes through its plan; EEGCLIP_PRIOR_STEP_PLAN=0: never
+                tkey = (N, c32 is not None, prior.drop_p())
+                tp = plans.get(tkey)
+                if tp is not None and tp is not False and h_embeds.is_contiguous() and tp.usable(optimizer):
+                    if any(q.grad is not None for q in optimizer.param_groups[0]["params"]):
+                        optimizer.zero_grad()                           # (an ordinary step of another key came between: its gradients are spent, the
+                        eng.gflat.zero_()                               #  plan accumulates into a clear buffer)
+                    tp.run(h_embeds, c32, loss_sum, eng.bufs[N]["tt"])
+                    continue
+                if tp is not None and tp is not False:
+                    plans.pop(tkey)                                     # something changed under the plan (the optimizer's runs were re-formed): warm up again
+                    warm[tkey] = 0
                 noise = torch.randn_like(h_embeds)
                 timesteps = torch.randint(0, T, (N,), device=device)
                 perturbed = self.scheduler.add_noise(h_embeds, noise, timesteps)
                 st = raw_stream()
                 optimizer.zero_grad()
-                c32 = c_embeds.float().contiguous() if c_embeds is not None else None
                 pred = eng.forward(perturbed, timesteps.float(), c32, prior.drop_p())
                 b = eng.bufs[N]
                 check(L.eegclip_mse_loss_grad(pred.data_ptr(), noise.data_ptr(), pred.numel(), loss_sum.data_ptr(), b["dout"].data_ptr(), st), "mse")
@@ -743,12 +843,15 @@ class Pipe:
                 sumsq.zero_()                                             # clip_grad_norm_(params, 1.0) without a host sync
                 check(L.eegclip_sumsq(eng.gflat.data_ptr(), eng.gflat.numel(), sumsq.data_ptr(), st), "sumsq")
                 check(L.eegclip_clip_scale(sumsq.data_ptr(), 1.0, clip.data_ptr(), st), "clip_scale")
-                step += 1
-                lr = cosine_with_warmup_lr(step, learning_rate, 500, total_steps)      # lr_scheduler.step() BEFORE optimizer.step() (:331-332)
-                self.lr_history.append(lr)
-                for gq in optimizer.param_groups:
-                    gq["lr"] = lr
                 optimizer.step()
+                warm[tkey] = warm.get(tkey, 0) + 1
+                if plan_on and warm[tkey] >= 2 and tkey not in plans and optimizer._fast_last.get(0) is not None:
+                    try:
+                        plans[tkey] = _TrainStepPlan(self, eng, optimizer, tkey, optimizer._fast_last[0], sumsq, clip)
+                        optimizer.zero_grad()                           # the plan accumulates into a CLEAR flat gradient buffer and leaves it clear
+                        eng.gflat.zero_()
+                    except (ValueError, KeyError):
+                        plans[tkey] = False                             # (general-GEMM plans: launch by launch for good)
             loss_epoch = float(loss_sum) / len(dataloader)
             print(f'epoch: {epoch}, loss: {loss_epoch}')
         return self

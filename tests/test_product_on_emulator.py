@@ -586,6 +586,57 @@ def test_prior_training_step_on_plane_gemms_equals_the_fp32_operand_plans(cond, 
         np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), atol=1e-6 + 2e-4 * float(g0[k].abs().max()), err_msg=k)
 
 
+def test_prior_training_step_plan_is_the_launch_by_launch_training_loop(monkeypatch):
+    """prior._TrainStepPlan (Pipe.train's steady-state iteration -- add_noise, forward, MSE, backward, clip_grad_norm_, Adam -- as ONE launch plan) against the
+    same training run launch by launch (EEGCLIP_PRIOR_STEP_PLAN=0): 9 updates with whole-batch condition drops in between (both keys get a plan, the optimizer's
+    launch sets are re-formed when the condition layers start to lag), the same generator calls in the same order, so the noise, the timesteps, the dropout
+    seeds and the drop decisions are the same: per-update learning rates and drop decisions identical, the epoch losses and every parameter equal to
+    round-off (the plan's optimizer launches clear the gradients behind their read; the arithmetic is launch for launch the loop's)."""
+    rng = np.random.default_rng(21)
+    N, E, Cd = 64, 128, 64
+    data = [{"c_embedding": T(rng.standard_normal((N, Cd)).astype(np.float32)), "h_embedding": T(rng.standard_normal((N, E)).astype(np.float32))} for _ in range(9)]
+    runs = {}
+    with product_on_emulator():
+        from eeg_image_decode_amd import prior as eprior
+        built = []
+        real_init = eprior._TrainStepPlan.__init__
+
+        def counting_init(self, *a, **k):
+            real_init(self, *a, **k)
+            built.append(self.key)
+        monkeypatch.setattr(eprior._TrainStepPlan, "__init__", counting_init)
+        ran = []
+        real_run = eprior._TrainStepPlan.run
+
+        def counting_run(self, *a, **k):
+            ran.append(self.key)
+            return real_run(self, *a, **k)
+        monkeypatch.setattr(eprior._TrainStepPlan, "run", counting_run)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("EEGCLIP_PRIOR_STEP_PLAN", mode)
+            torch.manual_seed(5)
+            m = eprior.DiffusionPriorUNet(embed_dim=E, cond_dim=Cd, hidden_dim=[128, 64, 64], time_embed_dim=64, dropout=0.1)
+            pipe = eprior.Pipe(m, device="cpu")
+            pipe.cond_drop_prob = 0.3
+            torch.manual_seed(11)
+            losses = []
+            import builtins
+            monkeypatch.setattr(builtins, "print", lambda *a, **k: losses.append(a[0]))
+            pipe.train(data, num_epochs=1, learning_rate=1e-3)
+            runs[mode] = (list(pipe.lr_history), list(pipe.cond_dropped), losses[-1], {k: p.detach().clone() for k, p in m.named_parameters()})
+            if mode == "1":
+                assert any(pipe.cond_dropped) and not all(pipe.cond_dropped)          # the sequence holds both keys
+                assert len(built) >= 2 and len({k[1] for k in built}) == 2, built     # ... and both went through a plan
+                n_built, n_ran = len(built), len(ran)
+                assert n_ran >= 3, (ran, pipe.cond_dropped)                            # ... that then carried the updates
+        assert len(built) == n_built and len(ran) == n_ran                                                 # EEGCLIP_PRIOR_STEP_PLAN=0 builds none
+    (lr1, d1, l1, p1), (lr0, d0, l0, p0) = runs["1"], runs["0"]
+    assert lr1 == lr0 and d1 == d0
+    assert abs(float(l1.split("loss:")[1]) - float(l0.split("loss:")[1])) < 1e-5
+    for k in p0:
+        np.testing.assert_allclose(p1[k].numpy(), p0[k].numpy(), atol=2e-6 + 2e-5 * float(p0[k].abs().max()), err_msg=k)
+
+
 @pytest.fixture(scope="module")
 def small_things_tree(tmp_path_factory):
     """the synthetic THINGS-EEG tree with the reference's class counts (they are hard-coded in its loader) but one channel pair and few samples"""
