@@ -36,7 +36,8 @@ constexpr int WK_ROWB = 256;                                 // bytes per LDS ro
 constexpr int WK_TILE = WK_BK * WK_ROWB;                     // one operand-plane tile: 8 KB
 constexpr int WK_STAGE = 4 * WK_TILE;                        // A hi | A lo | B hi | B lo
 constexpr int WK_SAMPLE = 65536, WK_PLANE = 32768, WK_TOKB = 512;      // bytes: sample block, plane, token row of the global layout
-constexpr int WK_MAXP = 12;                                // (the joint-subject value embedding: one problem per subject of the batch)
+constexpr int WK_MAXP = 24;                                // problems per launch of the plain-planes form (the diffusion prior's 22 weight gradients are ONE launch)
+constexpr int WK_MAXP_TOK = 12;                            // ... of the token-plane form (the joint-subject value embedding: one problem per subject of the batch)
 
 struct wk_problem {
     const unsigned char* a;                                  // dY planes
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void wgrad_tok_reduce_kernel(const wk_reduce_t
 using namespace eeg;
 
 static int wk_check(const eegclip_wgrad_tok_problem* p, int n_prob, int B) {
-    if (!p || n_prob < 1 || n_prob > WK_MAXP || B < 1) return EEGCLIP_EINVAL;
+    if (!p || n_prob < 1 || n_prob > WK_MAXP_TOK || B < 1) return EEGCLIP_EINVAL;
     for (int i = 0; i < n_prob; ++i) {
         const eegclip_wgrad_tok_problem& q = p[i];
         if (!q.a || !q.b || !q.out || q.m_groups < 1 || q.m_groups > 3 || q.M < 1 || q.N < 1 || q.ldo < q.N) return EEGCLIP_EINVAL;

@@ -507,8 +507,11 @@ class _PriorEngine:
         # left to run under them, and together their 92 + 64 output tiles are one wave of workgroups
         wgrad([(s0["t"] + "linear_1.weight", s0["t"] + "linear_1.bias", self._pl(b["DT1P"]), W, W, self._pl(b["tembp"]), Td, Td),
                ("input_layer.0.weight", "input_layer.0.bias", di, h0, h0, self._pl(b["xp"]), E, E)])
-        for i in range(0, len(pending), 12):                         # (eegclip_wgrad_planes: <= 12 problems per launch)
-            wgrad_now(pending[i:i + 12])
+        # (eegclip_wgrad_planes: <= 24 problems per launch -- ONE launch since round 6: two launches of 360 + 444 workgroups were 2 + 2 rounds on 256 CUs,
+        #  804 workgroups are 3.1; EEGCLIP_PRIOR_WGRAD_CHUNK=12: the two launches, A/B aid)
+        chunk = int(os.environ.get("EEGCLIP_PRIOR_WGRAD_CHUNK", "24"))
+        for i in range(0, len(pending), chunk):
+            wgrad_now(pending[i:i + chunk])
         return pl
 
     def forward(self, x, t, c, p, cond_rows=None):

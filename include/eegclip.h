@@ -748,7 +748,7 @@ int eegclip_wgrad_tok_reduce_adamw(const eegclip_wgrad_tok_problem* p, int n_pro
  * index contiguous, rows lda / ldb ELEMENTS apart (multiples of 8; 16-byte aligned).  rows: multiple of 32.  The kernel reads whole 128-channel tiles:
  * the planes must be readable up to the next multiple of 128 channels past M / N in every row (a column block of a wider buffer, or 256 bytes of
  * padding behind the last row) -- what it reads there does not reach `out`.  bias_out[m] += sum_r dY[r][m].  slices: K slices of this problem (1: plain
- * read-modify-write of out; > 1: fp32 atomics -- small outputs that would not fill the chip otherwise).  Up to 12 problems per launch.
+ * read-modify-write of out; > 1: fp32 atomics -- small outputs that would not fill the chip otherwise).  Up to 24 problems per launch.
  * The weight gradients of the diffusion prior's Linear layers (Generation/diffusion_prior.py:167-203, rows = the batch). */
 typedef struct {
     const void *a_hi, *a_lo;                   /* dY planes */

@@ -163,5 +163,5 @@ def test_wgrad_planes_rejects_bad_arguments(be):
     assert be.lib.eegclip_wgrad_planes(mk(), 1, be.stream) == 0
     for bad in (dict(rows=48), dict(slices=3), dict(slices=0), dict(lda=60), dict(ldo=62), dict(N=62), dict(out=None), dict(a_lo=None)):
         assert be.lib.eegclip_wgrad_planes(mk(**bad), 1, be.stream) != 0, bad
-    many = (_abi.WgradPlanesProblem * 13)(*[_abi.WgradPlanesProblem(**ok)] * 13)
-    assert be.lib.eegclip_wgrad_planes(many, 13, be.stream) != 0
+    many = (_abi.WgradPlanesProblem * 25)(*[_abi.WgradPlanesProblem(**ok)] * 25)
+    assert be.lib.eegclip_wgrad_planes(many, 25, be.stream) != 0
