@@ -49,8 +49,12 @@ struct cs_bwd_args {
     int B, H, vec2;
 };
 
-constexpr int CSB_ES = 27;                                  // E tile [36 w][27]: taps 0 .. 24
-constexpr int CSB_E_BYTES = CS_W * CSB_ES * 4;              // 3888
+// E[w][t] = sum_c dy1[c][w] taps[c][t] is kept as FIVE PLANES indexed by the output sample: plane a = t / 5 holds E[w][t] at word 5 w + t (= 5 (w + a) + t % 5),
+// so the overlap-add dS[j] = sum_a E[j / 5 - a][j % 5 + 5 a] is sum_a plane_a[j]: one 16-byte read per plane and lane (j = 4 lane + e), no index arithmetic.
+// Words of a plane no E element lands on (j < 5 a and j >= 180 + 5 a) stay zero.  (Round 5 kept E as [36][27] and gathered 20 words per lane through
+// computed, range-checked addresses: ~120 LDS cycles of a possible 40 per row, 2.5-way conflicts on average, and ~100 vector instructions.)
+constexpr int CSB_EP = 200;                                 // words per plane = CS_NS
+constexpr int CSB_E_BYTES = 5 * CSB_EP * 4;                 // 4000
 constexpr int CSB_DT_BYTES = CS_C * CS_W * 4;               // 5760: dy1 as packed words [40 c][36 w]
 constexpr int CSB_WAVE = CSB_E_BYTES + CSB_DT_BYTES;        // 9648
 constexpr int CSB_DYF = 3 * 3072;                           // dy2 fragment images (3 position tiles)
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
     const int b = blockIdx.x;
     constexpr int WREG = APPLY ? CSB_WAVE : 1024;
     unsigned char* mine = wreg + wv * WREG;
-    float* Et = reinterpret_cast<float*>(mine);              // [36][27]
+    float* Et = reinterpret_cast<float*>(mine);              // [5][200] (CSB_EP)
     unsigned* DT = reinterpret_cast<unsigned*>(mine + (APPLY ? CSB_E_BYTES : 0));
     float* qscr = reinterpret_cast<float*>(mine);            // 256 floats of prefix-sum scratch (staging; the transposed box filter once E is consumed)
     double* bnscr = reinterpret_cast<double*>(wreg);         // [6][80] (before the staging uses the region)
@@ -168,11 +172,13 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
         acc5[ct][0] = zero4;
         acc5[ct][1] = zero4;
     }
-    // gather map of the overlap-add: lane l < 50 owns j = 4 l + e; dS[j] = sum_a E[w = j / 5 - a][t = j % 5 + 5 a]
-    int gq[4], gr[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const int j = 4 * lane + e; gq[e] = j / 5; gr[e] = j % 5; }
-
+    // the 20 words of every E plane that no element lands on (plane a: j < 5 a, j >= 180 + 5 a); the prefix-sum scratch shares the first 256 words with
+    // the planes, so the row loop re-zeroes the 25 of them it overwrites (cs_e_border)
+    auto cs_e_border = [&](int i) { const int pa = i / 20, idx = i % 20; return pa * CSB_EP + (idx < 5 * pa ? idx : 180 + idx); };
+    if (APPLY) {
+        Et[cs_e_border(lane)] = 0.f;
+        if (lane < 36) Et[cs_e_border(64 + lane)] = 0.f;
+    }
     const unsigned char* const dyf0 = dyf;
     const unsigned char* const tapf0 = tapf;
     const float* const coef0 = coef;
@@ -263,10 +269,11 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                 for (int tt = 0; tt < 2; ++tt) {
                     const int tp = 16 * tt + n;
                     if (tp < CS_K1) {
+                        float* ep = Et + (tp / 5) * CSB_EP + tp + 5 * (16 * wt + 4 * kg);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int w = 16 * wt + 4 * kg + r;
-                            if (w < CS_W) Et[w * CSB_ES + tp] = accE[tt][r];
+                            if (w < CS_W) ep[5 * r] = accE[tt][r];
                         }
                     }
                 }
@@ -287,18 +294,15 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
         }
         if (APPLY) {
             wave_sync();
-            // overlap-add: dS[j] = sum_{a < 5} E[j / 5 - a][j % 5 + 5 a]
+            // overlap-add: dS[j] = sum_{a < 5} E[j / 5 - a][j % 5 + 5 a] = sum_a plane_a[j], lane l < 50 owns j = 4 l .. 4 l + 3
             float ds[4];
+            {
+                const float* ep = Et + 4 * (lane < CS_NS / 4 ? lane : 0);
+                f32x4 s = *reinterpret_cast<const f32x4*>(ep);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s = 0.f;
+                for (int k = 1; k < 5; ++k) s += *reinterpret_cast<const f32x4*>(ep + k * CSB_EP);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int w = gq[e] - k;
-                    const float v = Et[(w >= 0 && w < CS_W ? w : 0) * CSB_ES + gr[e] + 5 * k];
-                    s += (w >= 0 && w < CS_W) ? v : 0.f;
-                }
-                ds[e] = 4 * lane + e < CS_NS ? s : 0.f;
+                for (int e = 0; e < 4; ++e) ds[e] = lane < CS_NS / 4 ? s[e] : 0.f;
             }
             wave_sync();                                      // E is consumed: its first KB becomes the prefix-sum scratch
             // transposed box filter: Q[i] = sum_{k < i} dS[k];  dx[i] = (Q[i + 1] - Q[max(i - 50, 0)]) / 51
@@ -326,18 +330,20 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                         if (4 * lane + e < CS_T) xr[4 * lane + e] = o[e];
                 }
             }
-            // taps gradient: dW1[c][t] += sum_w dy1[c][w] S[h][5 w + t];  A = DT rows (k slot j <-> w = 16 (j >> 2) + 4 kg + (j & 3); tail w = 32 + 4 kg + j, kg = 0)
+            // taps gradient: dW1[c][t] += sum_w dy1[c][w] S[h][5 w + t];  A = DT rows, k slot j <-> w = 16 (kg & 1) + 8 (kg >> 1) + j (the lane groups a 4-byte
+            // LDS read serves together, kg = 0 | 1 and 2 | 3, sit 80 words apart: their 16-word runs share no bank); tail w = 32 + j in lane group 0 (the other
+            // groups' A slots are zero: they read the same words, a broadcast)
             bf16x8 bh[2], bl[2], ch[2], cl[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const unsigned* sp = S32 + h * CS_RS + 16 * tt + n;
                 unsigned w8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w8[j] = sp[5 * (16 * (j >> 2) + 4 * kg + (j & 3))];
+                for (int j = 0; j < 8; ++j) w8[j] = sp[5 * (cs_tap_base(kg) + j)];
                 cs_words_to_frags(w8, bh[tt], bl[tt]);
                 unsigned w4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w4[j] = sp[5 * (32 + 4 * kg + j)];
+                for (int j = 0; j < 4; ++j) w4[j] = sp[5 * (32 + j)];
                 ch[tt] = cs_frag(cs_pair_hi(w4[1], w4[0]), cs_pair_hi(w4[3], w4[2]), 0u, 0u);
                 cl[tt] = cs_frag(cs_pair_lo(w4[1], w4[0]), cs_pair_lo(w4[3], w4[2]), 0u, 0u);
             }
@@ -347,8 +353,8 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) {
                     const int c = 16 * ct + n < CS_C ? 16 * ct + n : CS_C - 1;          // (filters >= 40: discarded output rows)
-                    const u32x4_t m0 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 4 * kg);
-                    const u32x4_t m1 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 16 + 4 * kg);
+                    const u32x4_t m0 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + cs_tap_base(kg));
+                    const u32x4_t m1 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + cs_tap_base(kg) + 4);
                     u32x4_t m2 = *reinterpret_cast<const u32x4_t*>(DT + c * CS_W + 32);
                     if (kg != 0) m2 = u32x4_t{0u, 0u, 0u, 0u};                            // positions >= 36
                     const unsigned w8[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(CS_NT) void cstack_bwd_kernel(const cs_bwd_args a) 
                 acc5[0][tt] = t3[0]; acc5[1][tt] = t3[1]; acc5[2][tt] = t3[2];
             }
             wave_sync();                                      // the next row rewrites E / DT
+            if (lane < 25) Et[cs_e_border(lane)] = 0.f;        // the scratch lay over plane 0's words 180 .. 199 and plane 1's words 0 .. 4
         }
     }
 

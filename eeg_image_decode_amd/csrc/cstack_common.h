@@ -25,7 +25,7 @@ constexpr int CS_K1 = 25;      // taps
 constexpr int CS_T = 250;      // samples per token row
 constexpr int CS_POOL = 51;
 constexpr int CS_NS = 200;     // box-filtered samples the 36 x 25 windows touch
-constexpr int CS_RS = 272;     // words per packed row: fragment reads of the padded tiles (w < 48, t < 32) reach word 5 * 47 + 31 = 266
+constexpr int CS_RS = 268;     // words per packed row (a multiple of 4): fragment reads of the padded tiles (w < 48, t < 32) reach word 5 * 47 + 31 = 266
 constexpr int CS_MAXH = 64;
 constexpr int CS_NW = 8;       // waves per workgroup of the sample-major kernels
 constexpr int CS_NT = 64 * CS_NW;
@@ -61,10 +61,15 @@ __device__ __forceinline__ void cs_words_to_frags(const unsigned (&w)[8], bf16x8
     hi = cs_frag(cs_pair_hi(w[1], w[0]), cs_pair_hi(w[3], w[2]), cs_pair_hi(w[5], w[4]), cs_pair_hi(w[7], w[6]));
     lo = cs_frag(cs_pair_lo(w[1], w[0]), cs_pair_lo(w[3], w[2]), cs_pair_lo(w[5], w[4]), cs_pair_lo(w[7], w[6]));
 }
-// im2col fragment of row h at position tile wt: lane (n, kg) <- S[h][5 (16 wt + n) + 8 kg + i], i < 8
+// The taps a lane group holds in its eight k slots: t = cs_tap_base(kg) + i with bases 0, 16, 8, 24 -- NOT 8 kg.  The im2col reads below are 4-byte
+// LDS reads at word 5 n + base + i; ds_read_b32 / ds_read2_b32 serve lanes 0-31 (kg = 0 | 1) and 32-63 (kg = 2 | 3) as one group each on 32 banks, and
+// {5 n} and {5 n + d}, n < 16, share no bank only for d = 16 (mod 32): with bases 8 kg every read was a 2-way conflict (0.8 M conflict cycles per
+// launch in each kernel of the family, round-5 PMC); the k-slot <-> tap assignment is free as long as the tap operand agrees, so the fix costs nothing.
+__device__ __forceinline__ int cs_tap_base(int kg) { return 16 * (kg & 1) + 8 * (kg >> 1); }
+// im2col fragment of row h at position tile wt: lane (n, kg) <- S[h][5 (16 wt + n) + cs_tap_base(kg) + i], i < 8
 __device__ __forceinline__ void cs_sfrag(const unsigned* __restrict__ S32, int h, int wt, bf16x8& hi, bf16x8& lo) {
     const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
-    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + 8 * kg;
+    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + cs_tap_base(kg);
     unsigned w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = p[i];
@@ -105,7 +110,7 @@ __device__ __forceinline__ void cs_mma3_b3(bf16x8 ah, bf16x8 al, const bf16x8 (&
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16_16x16x32(ah, bh[i], acc[i]);
 }
-// the taps as the filter-side operand: lane (n, kg), tile ct <- scale[c] * w25[c = 16 ct + n][t = 8 kg + i] (zero past 40 filters / 25 taps), and in the
+// the taps as the filter-side operand: lane (n, kg), tile ct <- scale[c] * w25[c = 16 ct + n][t = cs_tap_base(kg) + i] (zero past 40 filters / 25 taps), and in the
 // otherwise unused k slot t = 25 the per-filter constant shift[c]: against an activation operand whose slot 25 is 1.0 (cs_sfrag_ones) the contraction
 // yields  scale[c] * (conv)[c][w] + shift[c]  -- a BatchNorm affine (or the conv bias) costs no vector instruction in the epilogue.
 constexpr int CS_ONE_SLOT = 25;
@@ -120,7 +125,7 @@ __device__ __forceinline__ void cs_tap_frags_affine(const float* __restrict__ w2
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int t = 8 * kg + i;
+            const int t = cs_tap_base(kg) + i;
             v[i] = (c < CS_C && t < CS_K1) ? sc * w25[c * CS_K1 + t] : (t == CS_ONE_SLOT ? sh : 0.f);
         }
         cs_split8(v, wh[ct], wl[ct]);
@@ -129,10 +134,10 @@ __device__ __forceinline__ void cs_tap_frags_affine(const float* __restrict__ w2
 __device__ __forceinline__ void cs_tap_frags(const float* __restrict__ w25, bf16x8 (&wh)[3], bf16x8 (&wl)[3]) {
     cs_tap_frags_affine(w25, [](int, float& sc, float& sh) { sc = 1.f; sh = 0.f; }, wh, wl);
 }
-// cs_sfrag with k slot 25 (lane group 3, word 1) replaced by 1.0: the partner of cs_tap_frags_affine's shift slot
+// cs_sfrag with k slot 25 (lane group 3 -- tap base 24 --, word 1) replaced by 1.0: the partner of cs_tap_frags_affine's shift slot
 __device__ __forceinline__ void cs_sfrag_ones(const unsigned* __restrict__ S32, int h, int wt, bf16x8& hi, bf16x8& lo) {
     const int lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
-    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + 8 * kg;
+    const unsigned* p = S32 + h * CS_RS + 5 * (16 * wt + n) + cs_tap_base(kg);
     unsigned w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = p[i];
@@ -240,7 +245,7 @@ __device__ __forceinline__ void cs_load_row(float (&v)[4], const float* __restri
     }
 }
 
-// one wave: token row (lane l holds samples 4l .. 4l+3) -> its packed box-filtered row [272 words] (zeros from j = 200); pscr = the wave's 256-float
+// one wave: token row (lane l holds samples 4l .. 4l+3) -> its packed box-filtered row [CS_RS words] (zeros from j = 200); pscr = the wave's 256-float
 // scratch row for the exclusive prefix sums P[i] = sum_{k<i} x[k]:  S[j] = (P[j + 51] - P[j]) / 51
 __device__ __forceinline__ void cs_box_row(unsigned* __restrict__ srow, float* __restrict__ pscr, const float (&v)[4]) {
     const int lane = threadIdx.x & 63;
@@ -257,7 +262,7 @@ __device__ __forceinline__ void cs_box_row(unsigned* __restrict__ srow, float* _
     }
     wave_sync();
     *reinterpret_cast<u32x4_t*>(srow + 4 * lane) = S;
-    if (lane < 16) srow[256 + lane] = 0u;                      // words 256 .. 271: read by the padded tiles only, must be finite
+    if (lane < CS_RS - 256) srow[256 + lane] = 0u;             // words 256 .. 267: read by the padded tiles only, must be finite
 }
 
 // The H token rows of sample b -> S32[h][CS_RS].  Every wave stages exactly the rows it later works on (rows wv, wv + 8, ... -- or, PAIRS, the row

@@ -55,9 +55,11 @@ struct if_table {
     if_problem p[IF_MAX_PROB];
 };
 
-template <int NP>
+// k elements per LDS stage: 64 with one product, 32 with three (two planes per operand) -- and 32 for the 256 x 256 tile, whose stage then is 32 KB like the others
+constexpr int if_bk(int NP, int TM) { return (NP == 1 && TM <= 128) ? 64 : 32; }
+template <int BK_>
 struct if_geom {
-    static constexpr int BK = NP == 1 ? 64 : 32;              // bf16 elements per row of a stage tile
+    static constexpr int BK = BK_;                            // bf16 elements per row of a stage tile
     static constexpr int ROWB = 2 * BK;                       // bytes per LDS row
     static constexpr int NCH = BK / 8;                        // 16-byte chunks per row
     static constexpr int RPI = 1024 / ROWB;                   // rows one DMA instruction deposits
@@ -79,7 +81,7 @@ struct if_geom {
 template <int NP, int TM, int MODE, int NW, int NPRD = 0>
 __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale, float* __restrict__ loss) {
-    using Gm = if_geom<NP>;
+    using Gm = if_geom<if_bk(NP, TM)>;
     constexpr int BK = Gm::BK, ROWB = Gm::ROWB, NCH = Gm::NCH, RPI = Gm::RPI;
     constexpr bool SPEC = NPRD > 0;
     constexpr int NDW = SPEC ? NPRD : NW;                     // waves that issue LDS-DMA
@@ -465,10 +467,16 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     }
 }
 
-// `force`: bits 8..15 of the `planes` argument (tuning / tests): 0 = chosen here, 64 or 128
-static inline int if_tile(int n, int N, int force = 0) {
+// `force`: bits 8..15 of the `planes` argument (tuning / tests): 0 = chosen here, 64, 128 or 255 (= 256 x 256 tiles: one product only)
+constexpr long long IF_T256_MIN_TILES = 512;                     // 256-tiles once every CU gets two of them (N = 8192 square: 1024)
+static inline int if_tile(int n, int N, int force, int nplanes) {
+    const bool can256 = nplanes == 1 && n % 256 == 0 && N % 256 == 0;
+    if (force == 255 && can256) return 256;
     if (force == 128 && n % 128 == 0 && N % 128 == 0) return 128;
     if (force == 64) return 64;
+    // 256 x 256 tiles (8 waves of 128 x 64 logits: 0.75 fragment reads per MFMA instead of 1 -- 1.5, a k-loop with twice the matrix work per barrier) where
+    // the block is large enough to give every CU several of them
+    if (force == 0 && can256 && (long long)(n / 256) * (N / 256) >= IF_T256_MIN_TILES) return 256;
     // 128 x 128 tiles once they fill the chip on their own; 64 x 64 otherwise (a rank's 256 x 2048 block: 128 workgroups per block)
     return (n % 128 == 0 && N % 128 == 0 && (long long)(n / 128) * (N / 128) >= 256) ? 128 : 64;
 }
@@ -515,7 +523,7 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
 
 #define EEG_IF_GO2(NP_, TM_, MODE_, NW_, NPRD_)                                                                                                            \
     EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_, NPRD_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * (NW_ + NPRD_)),                            \
-               (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<NP_>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale, loss)
+               (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<if_bk(NP_, TM_)>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale, loss)
 #define EEG_IF_GO(NP_, TM_, NW_, NPRD_)                                                                                                                    \
     do {                                                                                                                                                   \
         if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, NPRD_);                                                                                                \
@@ -527,6 +535,7 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
 // 12.9 / 12.0 / 12.6 us for 4 / 8 / 4+4 waves; three products: 27.2 / 26.8 / 26.6; 64-tiles, a rank's two 256 x 2048 blocks: 7.8 -> 7.2 and 12.8 -> 10.8 us)
 static int if_wsel(int TM, int planes) {
     const int w = (planes >> 16) & 3;
+    if (TM == 256) return 2;                                     // the 256-tile exists with 8 waves only (128 accumulator registers per wave)
     if (w == 0) return (TM == 128 && (planes & 0xff) == 1) ? 2 : 3;
     return (w == 2 && TM != 128) ? 1 : w;
 }
@@ -535,10 +544,11 @@ static int if_waves(int TM, int planes) { return if_wsel(TM, planes) == 2 ? 8 : 
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream, float* loss = nullptr) {
-    const int TM = if_tile(n, N, (planes >> 8) & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
+    const int TM = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
     planes &= 0xff;
     if (planes == 1) {
-        if (TM == 128) { if (wsel == 3) EEG_IF_GO(1, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO(1, 128, 4, 0); }
+        if (TM == 256) EEG_IF_GO(1, 256, 8, 0);
+        else if (TM == 128) { if (wsel == 3) EEG_IF_GO(1, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO(1, 128, 4, 0); }
         else           { if (wsel == 3) EEG_IF_GO(1, 64, 4, 4); else EEG_IF_GO(1, 64, 4, 0); }
     } else {
         if (TM == 128) { if (wsel == 3) EEG_IF_GO(2, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(2, 128, 8, 0); else EEG_IF_GO(2, 128, 4, 0); }
@@ -556,7 +566,7 @@ extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, i
     const float inv_total = 1.0f / (float)n_total;
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
     if (rc || !loss) return rc;                                  // loss == NULL: partials only -- eegclip_infonce_fused_grad_finalize finishes them
-    const int TMsel = if_tile(n, N, (planes >> 8) & 0xff);
+    const int TMsel = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff);
     const int Pn = (if_waves(TMsel, planes) / 2) * (N / TMsel);
     EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nprob), dim3(256), 512 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
     return (int)hipGetLastError();

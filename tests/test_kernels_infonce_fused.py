@@ -11,7 +11,7 @@ from test_kernels_gemm_x3 import bf16_round, split
 
 
 def planes_arg(planes, tile, waves=0):
-    """planes | tile size << 8 (0 = the library's choice) | waves per workgroup << 16 (1 = 4 waves, 2 = 8 waves: 128-tiles only, 3 = 4 MFMA waves + 4 producer waves, 0 = the library's choice)"""
+    """planes | tile size << 8 (0 = the library's choice, 255 = 256 x 256) | waves per workgroup << 16 (1 = 4 waves, 2 = 8 waves: 128-tiles only, 3 = 4 MFMA waves + 4 producer waves, 0 = the library's choice)"""
     return planes | (tile << 8) | (waves << 16)
 
 
@@ -46,7 +46,8 @@ def lse(x):
 
 @pytest.mark.parametrize("planes", [1, 2])
 @pytest.mark.parametrize("n,N,D,tile,col0,waves", [(64, 64, 64, 64, 0, 0), (64, 192, 128, 64, 128, 0), (128, 256, 64, 128, 64, 1), (128, 256, 64, 128, 64, 2),
-                                                   (128, 384, 128, 128, 256, 2), (128, 384, 128, 128, 256, 3), (128, 128, 192, 64, 0, 0), (64, 192, 128, 64, 128, 1)])
+                                                   (128, 384, 128, 128, 256, 2), (128, 384, 128, 128, 256, 3), (128, 128, 192, 64, 0, 0), (64, 192, 128, 64, 128, 1),
+                                                   (256, 512, 128, 255, 256, 0), (256, 256, 64, 255, 0, 0)])   # tile code 255 = 256 x 256 (one product only; with two planes the library falls back to its own choice)
 def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, waves):
     rng = np.random.default_rng(n + N + D + planes)
     s = 2.6593
