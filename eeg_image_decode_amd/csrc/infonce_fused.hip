@@ -78,7 +78,12 @@ struct if_geom {
 // the 1085 without the refills, 480 with the refills alone).  With NPRD = 4 the LDS-DMA instructions, their counted vmcnt waits and nothing else live in
 // four extra waves (one per SIMD, parked in the memory queue almost all the time); the MFMA waves issue no vector-memory instruction at all and meet the
 // producers at the one barrier per k-tile: 1090 cycles per k-tile in the micro-benchmark, 13.8 -> 10.1 us for the k-loops of one N = 2048 block.
-template <int NP, int TM, int MODE, int NW, int NPRD = 0>
+// PF (round 6; 256-tiles): the barrier of k-tile kt + 1 is met INSIDE k-tile kt, in front of its last MFMA step, and the first fragments of tile kt + 1 are
+// requested right behind it -- so every wave leaves the barrier with a step's MFMAs ready to issue and the fragment-read latency of the next tile under them.
+// (Without it both waves of a SIMD come out of the barrier with nothing to feed the matrix pipe until their first six ds_read_b128 return.)  The refill DMA of
+// tile kt + NS - 1 is issued behind that barrier too (its stage held tile kt - 1, whose reads every wave has consumed by then), so two tiles instead of
+// three are in flight.
+template <int NP, int TM, int MODE, int NW, int NPRD = 0, bool PF = false>
 __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if_table tb, int n, int N, int D, int tiles_q, int tiles_k, const float* __restrict__ scale,
                                                             float inv_total, float* __restrict__ dscale, float* __restrict__ loss) {
     using Gm = if_geom<if_bk(NP, TM)>;
@@ -175,24 +180,28 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
     auto mfma_tile = [&](int kt, bool refill) {               // the MFMAs of k-tile kt (+ the refill DMA of tile kt + NS - 1 between them when this wave does both)
         const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
         bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
+        // Issue order: the operands of a step's FIRST MFMA are read LAST, and the next step's reads go out BEHIND that first MFMA.  The compiler's LDS counting
+        // is conservative around this loop (it emitted s_waitcnt lgkmcnt(0) in front of a step's MFMAs with the NEXT step's reads already issued, i.e. no
+        // overlap at all); this way its one full wait sits in front of the first MFMA and covers only reads issued a whole step earlier.
         auto read_step = [&](int s, int set) {
 #pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
-                if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+            for (int j = WTK - 1; j >= 0; --j) {
+                if (NP == 2 && j > 0) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
+                if (NP == 2 || j > 0) kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
             }
 #pragma unroll
-            for (int j = 0; j < WTK; ++j) {
-                kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
-                if (NP == 2) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
+            for (int i = WT - 1; i >= 0; --i) {
+                if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
             }
+            if (NP == 2) kl[set][0] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][0]);
+            else kh[set][0] = *reinterpret_cast<const bf16x8*>(st + fok[s][0]);
         };
         read_step(0, 0);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) read_step(s + 1, (s + 1) & 1);
 #if !defined(EEG_EMU)
-            __builtin_amdgcn_sched_barrier(0);                // the reads of step s + 1 stay ahead of the MFMAs of step s
+            __builtin_amdgcn_sched_barrier(0);
 #endif
             const int set = s & 1;
 #pragma unroll
@@ -209,13 +218,94 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                     constexpr int last = NP == 2 ? 2 : 0;
                     acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);      // D[key 32j + row(reg, h)][query 32i + r32]
                     if (!SPEC && refill && ((m0_ + last + 1) * DPT) / TOTAL > ((m0_ + last) * DPT) / TOTAL) issue_one(kt + IF_NS - 1, ((m0_ + last) * DPT) / TOTAL);
+                    if (j == 0 && i == 0 && s + 1 < NSTEP) {
+#if !defined(EEG_EMU)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                        read_step(s + 1, (s + 1) & 1);
+#if !defined(EEG_EMU)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                    }
                 }
 #if !defined(EEG_EMU)
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
     };
-    if (!SPEC) {
+    if (PF) {
+        static_assert(!PF || (!SPEC && NSTEP % 2 == 0), "the prefetching loop is the un-specialised form; fragment sets alternate by step parity");
+        bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
+        // (issue order: what a step's FIRST MFMA takes -- key fragment 0, query fragment 0 -- is read LAST, so the one wait in front of that MFMA covers the
+        //  whole set and no later MFMA of the step waits again behind the next set's reads)
+        auto read_step = [&](int kt, int s, int set) {
+            const unsigned char* st = lds + (kt % IF_NS) * STAGE_B;
+#pragma unroll
+            for (int j = WTK - 1; j >= 0; --j) {
+                if (NP == 2 && j > 0) kl[set][j] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][j]);
+                if (NP == 2 || j > 0) kh[set][j] = *reinterpret_cast<const bf16x8*>(st + fok[s][j]);
+            }
+#pragma unroll
+            for (int i = WT - 1; i >= 0; --i) {
+                if (NP == 2) ql[set][i] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + foq[s][i]);
+                qh[set][i] = *reinterpret_cast<const bf16x8*>(st + foq[s][i]);
+            }
+            if (NP == 2) kl[set][0] = *reinterpret_cast<const bf16x8*>(st + 2 * TILE_B + fok[s][0]);
+            else kh[set][0] = *reinterpret_cast<const bf16x8*>(st + fok[s][0]);
+        };
+#pragma unroll
+        for (int p = 0; p < IF_NS - 1; ++p)
+            if (p < ktiles) issue_tile(p);
+        wait_tile(0);
+        raw_barrier();
+        read_step(0, 0, 0);
+        constexpr int MPSP = MPS;                                 // MFMAs of one step
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const bool more = kt + 1 < ktiles, refill = kt + IF_NS - 1 < ktiles;      // (workgroup-uniform)
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int set = s & 1;
+                if (s + 1 == NSTEP && more) {
+                    // this wave's part of tile kt + 1 has landed (tile kt + 2, issued a tile ago, may stay in flight)
+                    if (kt + 2 < ktiles) wait_vmcnt<DPT>();
+                    else wait_vmcnt<0>();
+                    raw_barrier();                                // tile kt + 1 visible to every wave; every wave is past its reads of tile kt - 1
+                }
+                int m = 0;
+#pragma unroll
+                for (int j = 0; j < WTK; ++j)
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) {
+                        if (NP == 2) {
+                            acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
+                            if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                            ++m;
+                            acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
+                            if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                            ++m;
+                        }
+                        acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);
+                        if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                        ++m;
+                        if (j == 0 && i == 0) {
+                            // the next step's fragment reads go out BEHIND this step's first MFMA: the s_waitcnt lgkmcnt(0) the compiler puts in front of that MFMA
+                            // (it does not count LDS reads across the loop edge) then covers only reads issued a whole step ago
+#if !defined(EEG_EMU)
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                            if (s + 1 < NSTEP) read_step(kt, s + 1, set ^ 1);
+                            else read_step(more ? kt + 1 : kt, 0, set ^ 1);      // (unconditional: a branch here makes the compiler's LDS counts conservative; the last tile re-reads itself)
+#if !defined(EEG_EMU)
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                        }
+                    }
+#if !defined(EEG_EMU)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+    } else if (!SPEC) {
 #pragma unroll
         for (int p = 0; p < IF_NS - 1; ++p)
             if (p < ktiles) issue_tile(p);
@@ -521,13 +611,18 @@ extern "C" long long eegclip_infonce_fused_workspace_floats(int n, int N) {
     return 2LL * (2 * (N / 64)) * n;                              // [2 planes][2 slots per key tile][n], sized for the smaller tile
 }
 
-#define EEG_IF_GO2(NP_, TM_, MODE_, NW_, NPRD_)                                                                                                            \
-    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_, NPRD_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * (NW_ + NPRD_)),                            \
+#define EEG_IF_GO2(NP_, TM_, MODE_, NW_, NPRD_, PF_)                                                                                                       \
+    EEG_LAUNCH((infonce_tile_kernel<NP_, TM_, MODE_, NW_, NPRD_, PF_>), dim3((unsigned)(nprob * tq * tk)), dim3(64 * (NW_ + NPRD_)),                       \
                (size_t)IF_NS * 2 * NP_ * TM_ * if_geom<if_bk(NP_, TM_)>::ROWB, stream, tb, n, N, D, tq, tk, scale, inv_total, dscale, loss)
 #define EEG_IF_GO(NP_, TM_, NW_, NPRD_)                                                                                                                    \
     do {                                                                                                                                                   \
-        if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, NPRD_);                                                                                                \
-        else EEG_IF_GO2(NP_, TM_, 1, NW_, NPRD_);                                                                                                          \
+        if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, NPRD_, false);                                                                                         \
+        else EEG_IF_GO2(NP_, TM_, 1, NW_, NPRD_, false);                                                                                                   \
+    } while (0)
+#define EEG_IF_GO_PF(NP_, TM_, NW_)                                                                                                                        \
+    do {                                                                                                                                                   \
+        if (mode == 0) EEG_IF_GO2(NP_, TM_, 0, NW_, 0, true);                                                                                              \
+        else EEG_IF_GO2(NP_, TM_, 1, NW_, 0, true);                                                                                                        \
     } while (0)
 
 // wave layout: bits 16..17 of `planes` (tests / benches) 1 = 4 waves, 2 = 8 waves (128-tiles only), 3 = 4 MFMA waves + 4 producer waves,
@@ -545,9 +640,10 @@ static int if_waves(int TM, int planes) { return if_wsel(TM, planes) == 2 ? 8 : 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream, float* loss = nullptr) {
     const int TM = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
+    const bool no_pf = ((planes >> 18) & 1) != 0;                // bit 18 (benches): the 256-tile without the cross-barrier fragment prefetch
     planes &= 0xff;
     if (planes == 1) {
-        if (TM == 256) EEG_IF_GO(1, 256, 8, 0);
+        if (TM == 256) { if (no_pf) EEG_IF_GO(1, 256, 8, 0); else EEG_IF_GO_PF(1, 256, 8); }
         else if (TM == 128) { if (wsel == 3) EEG_IF_GO(1, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO(1, 128, 4, 0); }
         else           { if (wsel == 3) EEG_IF_GO(1, 64, 4, 4); else EEG_IF_GO(1, 64, 4, 0); }
     } else {

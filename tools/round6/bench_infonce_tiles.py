@@ -41,8 +41,8 @@ for N in (2048, 4096, 8192):
     arr[0] = _abi.InfonceProblem(q_hi=ap_[0].data_ptr(), q_lo=None, k_hi=bp_[0].data_ptr(), k_lo=None, col0=0, weight=0.5, part=buf.data_ptr(),
                                  diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=G.data_ptr(), ldg=N)
     row, ref = {}, None
-    for tag, tile, waves in (("tile128_waves8", 128, 2), ("tile128_waves4+4", 128, 3), ("tile256_waves8", 255, 0), ("auto", 0, 0)):
-        pl = 1 | (tile << 8) | (waves << 16)
+    for tag, tile, waves in (("tile128_waves8", 128, 2), ("tile128_waves4+4", 128, 3), ("tile256_waves8", 255, 0), ("tile256_waves8_no_prefetch", 255, 4), ("auto", 0, 0)):
+        pl = 1 | (tile << 8) | (waves << 16)            # (waves = 4: bit 18, the 256-tile without the cross-barrier fragment prefetch)
         acc.zero_()
         assert L.eegclip_infonce_fused_fwd(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr(), st) == 0
         torch.cuda.synchronize()
