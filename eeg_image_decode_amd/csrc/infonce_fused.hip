@@ -31,6 +31,14 @@
 namespace eeg {
 
 constexpr int IF_NS = 4;                 // LDS stages
+constexpr float IF_LOG2E = 1.4426950408889634f, IF_LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float if_exp2(float x) {
+#if defined(EEG_EMU)
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);      // v_exp_f32
+#endif
+}
 constexpr int IF_MAX_PROB = 8;
 
 struct if_problem {                      // device copy of eegclip_infonce_problem (pointers only what the kernels use)
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
     constexpr int NWK = NW / 2;                               // waves along the keys
     constexpr int WT = TM / 64;                               // 32x32 MFMA tiles per wave along the queries
     constexpr int WTK = TM / (32 * NWK);                      // ... along the keys
+    constexpr int SPT = TM == 256 ? 1 : NWK;                  // partial slots per (row, key tile): the 256-tile combines its key quarters in LDS first
     constexpr int TILE_B = TM * ROWB;                         // bytes of one operand-plane tile
     constexpr int STAGE_B = 2 * NP * TILE_B;                  // q_hi | k_hi | (q_lo | k_lo)
     constexpr int IPT = TM / RPI / NDW;                       // DMA instructions per DMA wave, tile and operand plane
@@ -347,40 +356,74 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
     const float p_weight = P.weight;
     if (MODE == 0) {
         if (producer) return;
-        const int Pn = NWK * tiles_k;                         // partial slots per row: (key tile, wk)
-        const int slot = NWK * (rem % tiles_k) + wk;
+        const int Pn = SPT * tiles_k;                         // partial slots per row: (key tile, wk) -- or one per key tile
+        const int slot = SPT * (rem % tiles_k) + (SPT == 1 ? 0 : wk);
+        float* const comb = reinterpret_cast<float*>(lds);    // (SPT == 1) [NWK][TM][2]: the key quarters' (max, sum) of every row, in base-2 units
+        if (SPT == 1) __syncthreads();                        // every wave is done with the operand stages
+        // Four vector instructions + one v_exp_f32 per logit (round 6; the first version spent eleven: max AND min of the raw accumulators -- each with a
+        // canonicalising extra --, s * acc twice, the subtraction, __expf's own multiply, and the positive's compare / select on every element of every tile;
+        // at 128 logits per thread of the 256-tile that epilogue was ~12 % of the tile's time): the accumulators are scaled IN PLACE to base-2 logits
+        // w = acc * (s log2 e), monotone in the logit whatever the sign of s, so one max serves; exp2(w - max) is a subtract + the hardware exp2; the positive is
+        // looked for only by the waves whose key range meets the diagonal.  Partials leave in natural units (max * ln 2).
+        const float sl2 = s * IF_LOG2E;
+        const int kb = k0r + wk * (TM / NWK);
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            const int q = q0 + wq * (TM / 2) + 32 * i + r32;
-            const int pos = p_col0 + q - (k0r + wk * (TM / NWK)) - 4 * h;    // key index of the positive in this lane's register numbering, if any
-            float mx = -3.0e38f, mn = 3.0e38f;
+            const int qw = q0 + wq * (TM / 2) + 32 * i, q = qw + r32;
+            float mx = -3.0e38f;
 #pragma unroll
             for (int j = 0; j < WTK; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
+                    acc[j][i][e] *= sl2;
                     mx = fmaxf(mx, acc[j][i][e]);
-                    mn = fminf(mn, acc[j][i][e]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // the other half-wave holds the other 16 keys of every 32-key tile
-            mn = fminf(mn, __shfl_xor(mn, 32, 64));
-            const float m = fmaxf(s * mx, s * mn);            // (s is a trained raw multiplier: it may be negative in principle)
-            float sum = 0.f, dv = 0.f;
-            bool have = false;
+            float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < WTK; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float v = s * acc[j][i][e];
-                    sum += fast_exp(v - m);
-                    const bool hit = 32 * j + (e & 3) + 8 * (e >> 2) == pos;
-                    dv = hit ? v : dv;
-                    have = have || hit;
-                }
+                for (int e = 0; e < 16; ++e) sum += if_exp2(acc[j][i][e] - mx);
             sum += __shfl_xor(sum, 32, 64);
-            if (have) p_diag[q] = dv;                         // exactly one lane of the launch per row
+            if (p_col0 + qw + 31 >= kb && p_col0 + qw < kb + 32 * WTK) {      // (wave-uniform) the positives of these 32 rows fall among this wave's keys
+                const int pos = p_col0 + q - kb - 4 * h;      // key index of the positive in this lane's register numbering, if any
+                float dv = 0.f;
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < WTK; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const bool hit = 32 * j + (e & 3) + 8 * (e >> 2) == pos;
+                        dv = hit ? acc[j][i][e] : dv;
+                        have = have || hit;
+                    }
+                if (have) p_diag[q] = dv * IF_LN2;            // exactly one lane of the launch per row
+            }
             if (h == 0) {
-                p_part[(long long)slot * n + q] = m;
-                p_part[(long long)(Pn + slot) * n + q] = sum;
+                if (SPT == 1) {
+                    *reinterpret_cast<f32x2_t*>(comb + ((wk * TM) + (q - q0)) * 2) = f32x2_t{mx, sum};
+                } else {
+                    p_part[(long long)slot * n + q] = mx * IF_LN2;
+                    p_part[(long long)(Pn + slot) * n + q] = sum;
+                }
+            }
+        }
+        if (SPT == 1) {
+            // one partial per row and key TILE: the four key quarters meet here (at N = 8192 the finalize launch read 128 slots per row through its slow
+            // path, 16 us of a 150 us logits block; 32 slots take its all-loads-in-flight path, and the partial planes shrink 4 x)
+            __syncthreads();
+            if (t < TM) {
+                f32x2_t v[NWK];
+#pragma unroll
+                for (int k = 0; k < NWK; ++k) v[k] = *reinterpret_cast<const f32x2_t*>(comb + (k * TM + t) * 2);
+                float m = v[0][0];
+#pragma unroll
+                for (int k = 1; k < NWK; ++k) m = fmaxf(m, v[k][0]);
+                float l = 0.f;
+#pragma unroll
+                for (int k = 0; k < NWK; ++k) l += v[k][1] * if_exp2(v[k][0] - m);
+                p_part[(long long)slot * n + q0 + t] = m * IF_LN2;
+                p_part[(long long)(Pn + slot) * n + q0 + t] = l;
             }
         }
     } else {
@@ -400,7 +443,7 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                 const int idx = keys ? k0r + (t - TM) : q0 + t;
                 const float* const part = keys ? p_part_k : p_part;
                 const long long ld = keys ? N : n;
-                const int Pn = NWK * (keys ? tiles_q : tiles_k);
+                const int Pn = SPT * (keys ? tiles_q : tiles_k);
                 float m = -3.0e38f;
                 for (int sl = 0; sl < Pn; ++sl) m = fmaxf(m, part[(long long)sl * ld + idx]);
                 float l = 0.f;
@@ -558,15 +601,15 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 // `force`: bits 8..15 of the `planes` argument (tuning / tests): 0 = chosen here, 64, 128 or 255 (= 256 x 256 tiles: one product only)
-constexpr long long IF_T256_MIN_TILES = 512;                     // 256-tiles once every CU gets two of them (N = 8192 square: 1024)
-static inline int if_tile(int n, int N, int force, int nplanes) {
+constexpr long long IF_T256_MIN_TILES = 256;                     // 256-tiles once every CU gets one (N = 4096 square; measured 40.0 us against 48.9 with 128-tiles)
+static inline int if_tile(int n, int N, int force, int nplanes, bool auto256 = true) {
     const bool can256 = nplanes == 1 && n % 256 == 0 && N % 256 == 0;
     if (force == 255 && can256) return 256;
     if (force == 128 && n % 128 == 0 && N % 128 == 0) return 128;
     if (force == 64) return 64;
     // 256 x 256 tiles (8 waves of 128 x 64 logits: 0.75 fragment reads per MFMA instead of 1 -- 1.5, a k-loop with twice the matrix work per barrier) where
     // the block is large enough to give every CU several of them
-    if (force == 0 && can256 && (long long)(n / 256) * (N / 256) >= IF_T256_MIN_TILES) return 256;
+    if (force == 0 && auto256 && can256 && (long long)(n / 256) * (N / 256) >= IF_T256_MIN_TILES) return 256;
     // 128 x 128 tiles once they fill the chip on their own; 64 x 64 otherwise (a rank's 256 x 2048 block: 128 workgroups per block)
     return (n % 128 == 0 && N % 128 == 0 && (long long)(n / 128) * (N / 128) >= 256) ? 128 : 64;
 }
@@ -634,12 +677,15 @@ static int if_wsel(int TM, int planes) {
     if (w == 0) return (TM == 128 && (planes & 0xff) == 1) ? 2 : 3;
     return (w == 2 && TM != 128) ? 1 : w;
 }
-// MFMA waves along the keys (= partial slots per key tile)
+// MFMA waves of a workgroup; partial slots per key tile = the waves along the keys, 1 for the 256-tile (combined in the workgroup)
 static int if_waves(int TM, int planes) { return if_wsel(TM, planes) == 2 ? 8 : 4; }
+static int if_slots(int TM, int planes) { return TM == 256 ? 1 : if_waves(TM, planes) / 2; }
 
 static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, int planes, int mode, const float* scale, float inv_total, float* dscale,
                            void* stream, float* loss = nullptr) {
-    const int TM = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
+    // the gradient pass keeps 128-tiles unless it finalises the forward's partials itself (their slot layout is the forward tile's): its 256-tile
+    // instantiation spills (128 accumulators + the G store's operands) and measured 254 against 231 us at N = 8192
+    const int TM = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff, mode == 0 || loss != nullptr), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
     const bool no_pf = ((planes >> 18) & 1) != 0;                // bit 18 (benches): the 256-tile without the cross-barrier fragment prefetch
     planes &= 0xff;
     if (planes == 1) {
@@ -663,7 +709,7 @@ extern "C" int eegclip_infonce_fused_fwd(const eegclip_infonce_problem* probs, i
     rc = if_launch_tiles(tb, nprob, n, N, D, planes, 0, scale, inv_total, nullptr, stream);
     if (rc || !loss) return rc;                                  // loss == NULL: partials only -- eegclip_infonce_fused_grad_finalize finishes them
     const int TMsel = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff);
-    const int Pn = (if_waves(TMsel, planes) / 2) * (N / TMsel);
+    const int Pn = if_slots(TMsel, planes) * (N / TMsel);
     EEG_LAUNCH(infonce_finalize_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nprob), dim3(256), 512 * sizeof(float), stream, tb, n, Pn, inv_total, loss);
     return (int)hipGetLastError();
 }
