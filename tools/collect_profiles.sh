@@ -11,6 +11,7 @@ cp $O/step_timeline.txt profiles/${R}_step_timeline.txt
 cp $O/pmc_step.json profiles/${R}_final_pmc_step.json
 cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
 cp $O/pmc_infonce.json profiles/${R}_pmc_infonce.json
+[ -f $O/infonce_tiles.json ] && cp $O/infonce_tiles.json profiles/${R}_infonce_tiles.json
 [ -f gpurun_out/${R}_head_gemm_bench.json ] && cp gpurun_out/${R}_head_gemm_bench.json profiles/${R}_head_gemm_bench.json
 (tail -3 $O/tests_gpu.log; tail -2 $O/smoke.log) > profiles/${R}_final_tests_gpu.txt
 python tools/numbers_table.py profiles/${R}_final_bench.json > profiles/${R}_numbers.md

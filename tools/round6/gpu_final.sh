@@ -11,6 +11,8 @@ tail -3 $out/tests_gpu.log
 tail -2 $out/smoke.log
 bash tools/final_profiles.sh r6_final > $out/final_profiles.log 2>&1
 tail -5 $out/final_profiles.log | cut -c1-300
+timeout 300 python tools/round6/bench_infonce_tiles.py $out/infonce_tiles.json > $out/infonce_tiles.txt 2>&1
+tail -3 $out/infonce_tiles.txt | cut -c1-600
 timeout 300 python tools/round6/bench_head_gemm.py > $out/head_gemm_bench.txt 2>&1
 tail -12 $out/head_gemm_bench.txt
 ls $out | head -40
