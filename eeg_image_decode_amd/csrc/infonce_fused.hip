@@ -86,7 +86,7 @@ struct if_geom {
 // the 1085 without the refills, 480 with the refills alone).  With NPRD = 4 the LDS-DMA instructions, their counted vmcnt waits and nothing else live in
 // four extra waves (one per SIMD, parked in the memory queue almost all the time); the MFMA waves issue no vector-memory instruction at all and meet the
 // producers at the one barrier per k-tile: 1090 cycles per k-tile in the micro-benchmark, 13.8 -> 10.1 us for the k-loops of one N = 2048 block.
-// PF (round 6; 256-tiles): the barrier of k-tile kt + 1 is met INSIDE k-tile kt, in front of its last MFMA step, and the first fragments of tile kt + 1 are
+// PF (round 6; the 8-wave forms: 256-tiles and 128-tiles): the barrier of k-tile kt + 1 is met INSIDE k-tile kt, in front of its last MFMA step, and the first fragments of tile kt + 1 are
 // requested right behind it -- so every wave leaves the barrier with a step's MFMAs ready to issue and the fragment-read latency of the next tile under them.
 // (Without it both waves of a SIMD come out of the barrier with nothing to feed the matrix pipe until their first six ds_read_b128 return.)  The refill DMA of
 // tile kt + NS - 1 is issued behind that barrier too (its stage held tile kt - 1, whose reads every wave has consumed by then), so two tiles instead of
@@ -243,6 +243,8 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
         }
     };
     if (PF) {
+        // (measured with producer waves too -- they promise tile kt + 1 at the barrier inside tile kt and refill behind it: neutral on the 4 + 4 form,
+        //  16.6 against 16.4 us at N = 2048, 383.5 against 385.2 with three products at N = 8192; not kept)
         static_assert(!PF || (!SPEC && NSTEP % 2 == 0), "the prefetching loop is the un-specialised form; fragment sets alternate by step parity");
         bf16x8 qh[2][WT], kh[2][WTK], ql[2][WT], kl[2][WTK];
         // (issue order: what a step's FIRST MFMA takes -- key fragment 0, query fragment 0 -- is read LAST, so the one wait in front of that MFMA covers the
@@ -269,6 +271,12 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
         raw_barrier();
         read_step(0, 0, 0);
         constexpr int MPSP = MPS;                                 // MFMAs of one step
+        // the refill's DPT DMA instructions spread over the last step's MPSP MFMAs: behind MFMA m go pieces [m DPT / MPSP, (m + 1) DPT / MPSP)
+        auto refill_after = [&](int kt, int m) {
+#pragma unroll
+            for (int d = 0; d < DPT; ++d)
+                if (d >= (m * DPT) / MPSP && d < ((m + 1) * DPT) / MPSP) issue_one(kt + IF_NS - 1, d);
+        };
         for (int kt = 0; kt < ktiles; ++kt) {
             const bool more = kt + 1 < ktiles, refill = kt + IF_NS - 1 < ktiles;      // (workgroup-uniform)
 #pragma unroll
@@ -287,14 +295,14 @@ __global__ __launch_bounds__(64 * (NW + NPRD)) void infonce_tile_kernel(const if
                     for (int i = 0; i < WT; ++i) {
                         if (NP == 2) {
                             acc[j][i] = mfma_bf16_32x32x16(kl[set][j], qh[set][i], acc[j][i]);
-                            if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                            if (s == NSTEP - 1 && refill) refill_after(kt, m);
                             ++m;
                             acc[j][i] = mfma_bf16_32x32x16(kh[set][j], ql[set][i], acc[j][i]);
-                            if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                            if (s == NSTEP - 1 && refill) refill_after(kt, m);
                             ++m;
                         }
                         acc[j][i] = mfma_bf16_32x32x16(kh[set][j], qh[set][i], acc[j][i]);
-                        if (s == NSTEP - 1 && refill && ((m + 1) * DPT) / MPSP > (m * DPT) / MPSP) issue_one(kt + IF_NS - 1, (m * DPT) / MPSP);
+                        if (s == NSTEP - 1 && refill) refill_after(kt, m);
                         ++m;
                         if (j == 0 && i == 0) {
                             // the next step's fragment reads go out BEHIND this step's first MFMA: the s_waitcnt lgkmcnt(0) the compiler puts in front of that MFMA
@@ -686,14 +694,22 @@ static int if_launch_tiles(const if_table& tb, int nprob, int n, int N, int D, i
     // the gradient pass keeps 128-tiles unless it finalises the forward's partials itself (their slot layout is the forward tile's): its 256-tile
     // instantiation spills (128 accumulators + the G store's operands) and measured 254 against 231 us at N = 8192
     const int TM = if_tile(n, N, (planes >> 8) & 0xff, planes & 0xff, mode == 0 || loss != nullptr), tq = n / TM, tk = N / TM, wsel = if_wsel(TM, planes);
-    const bool no_pf = ((planes >> 18) & 1) != 0;                // bit 18 (benches): the 256-tile without the cross-barrier fragment prefetch
+    const bool no_pf = ((planes >> 18) & 1) != 0;                // bit 18 (benches): the 8-wave forms without the cross-barrier fragment prefetch
     planes &= 0xff;
     if (planes == 1) {
         if (TM == 256) { if (no_pf) EEG_IF_GO(1, 256, 8, 0); else EEG_IF_GO_PF(1, 256, 8); }
-        else if (TM == 128) { if (wsel == 3) EEG_IF_GO(1, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO(1, 128, 4, 0); }
+        else if (TM == 128) {
+            if (wsel == 3) EEG_IF_GO(1, 128, 4, 4);
+            else if (wsel == 2) { if (no_pf) EEG_IF_GO(1, 128, 8, 0); else EEG_IF_GO_PF(1, 128, 8); }
+            else EEG_IF_GO(1, 128, 4, 0);
+        }
         else           { if (wsel == 3) EEG_IF_GO(1, 64, 4, 4); else EEG_IF_GO(1, 64, 4, 0); }
     } else {
-        if (TM == 128) { if (wsel == 3) EEG_IF_GO(2, 128, 4, 4); else if (wsel == 2) EEG_IF_GO(2, 128, 8, 0); else EEG_IF_GO(2, 128, 4, 0); }
+        if (TM == 128) {
+            if (wsel == 3) EEG_IF_GO(2, 128, 4, 4);
+            else if (wsel == 2) { if (no_pf) EEG_IF_GO(2, 128, 8, 0); else EEG_IF_GO_PF(2, 128, 8); }
+            else EEG_IF_GO(2, 128, 4, 0);
+        }
         else           { if (wsel == 3) EEG_IF_GO(2, 64, 4, 4); else EEG_IF_GO(2, 64, 4, 0); }
     }
     return (int)hipGetLastError();

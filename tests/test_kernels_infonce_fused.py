@@ -91,12 +91,12 @@ def test_fused_forward_and_gradient_blocks(be, planes, n, N, D, tile, col0, wave
     assert abs(float(be.host(DS)[0]) - want_ds) < 2e-5 * max(1.0, abs(want_ds))
 
 
-@pytest.mark.parametrize("planes,tile,waves", [(1, 64, 0), (2, 64, 1), (2, 128, 1), (2, 128, 2), (1, 128, 2), (1, 128, 3), (2, 128, 0)])
+@pytest.mark.parametrize("planes,tile,waves", [(1, 64, 0), (2, 64, 1), (2, 128, 1), (2, 128, 2), (1, 128, 2), (1, 128, 3), (2, 128, 0), (1, 255, 0)])
 def test_fused_symmetric_square_case_one_gradient_tile_for_both_terms(be, planes, tile, waves):
     """single-process ClipLoss: blocks (A, B) and (B, A); the gradient w.r.t. A needs G = c (P_row + P_col - 2 I): the row normaliser of
     the block and the row normaliser of the swapped block as `lse_k`"""
     rng = np.random.default_rng(5 + planes)
-    n, D, s = 128, 64, 2.6593
+    n, D, s = (256 if tile == 255 else 128), 64, 2.6593          # (tile code 255: one 256 x 256 tile, one partial slot per row and key tile)
     a, b = feats(rng, n, D, "ln"), feats(rng, n, D, "unit")
     L = be.lib
     SC, LOSS, DS = be.dev(np.array([s], np.float32)), be.zeros(1), be.zeros(1)

@@ -1,5 +1,5 @@
-"""round 6: the InfoNCE tile kernel's forward (tile launch + finalize launch = `logits_block`) and gradient pass by tile size at N = 2048 / 4096 / 8192, D = 1024,
-one product (throughput mode); 256 x 256 tiles (tile code 255) against 128 x 128 (8 waves | 4 + 4 producer waves).   python tools/round6/bench_infonce_tiles.py"""
+"""round 6: the InfoNCE tile kernel's forward (tile launch + finalize launch = `logits_block`) and gradient pass by tile form at N = 2048 / 4096 / 8192, D = 1024,
+one product (throughput mode) and three (parity mode, `parity_` rows); 256 x 256 tiles (tile code 255) against 128 x 128 (8 waves | 4 + 4 producer waves).   python tools/round6/bench_infonce_tiles.py"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -34,27 +34,37 @@ for N in (2048, 4096, 8192):
     b = torch.nn.functional.normalize(torch.randn(N, Dm, device="cuda", generator=g), dim=1)
     flop = 2.0 * N * N * Dm
     ws = int(L.eegclip_infonce_fused_workspace_floats(N, N))
-    ap_, bp_ = split_planes(a, 1), split_planes(b, 1)
-    buf = torch.empty(ws + 2 * N, device="cuda")
-    G = torch.empty(N, N, device="cuda")
-    arr = (_abi.InfonceProblem * 1)()
-    arr[0] = _abi.InfonceProblem(q_hi=ap_[0].data_ptr(), q_lo=None, k_hi=bp_[0].data_ptr(), k_lo=None, col0=0, weight=0.5, part=buf.data_ptr(),
-                                 diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=G.data_ptr(), ldg=N)
-    row, ref = {}, None
-    for tag, tile, waves in (("tile128_waves8", 128, 2), ("tile128_waves4+4", 128, 3), ("tile256_waves8", 255, 0), ("tile256_waves8_no_prefetch", 255, 4), ("auto", 0, 0)):
-        pl = 1 | (tile << 8) | (waves << 16)            # (waves = 4: bit 18, the 256-tile without the cross-barrier fragment prefetch)
-        acc.zero_()
-        assert L.eegclip_infonce_fused_fwd(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr(), st) == 0
-        torch.cuda.synchronize()
-        loss = float(acc[0])
-        lse = buf[ws + N:ws + 2 * N].clone()
-        if ref is None:
-            ref = (loss, lse)
-        dl, dlse = abs(loss - ref[0]), float((lse - ref[1]).abs().max())
-        us = ev_us(lambda: L.eegclip_infonce_fused_fwd(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr(), st))
-        usg = ev_us(lambda: L.eegclip_infonce_fused_grad(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr() + 4, st), reps=30)
-        row[tag] = {"logits_block_us": round(us, 2), "TF": round(flop / us / 1e6, 1), "frac_of_bf16_peak": round(flop / us / 1e6 / PEAK, 4), "grad_us": round(usg, 2),
-                    "loss_diff_to_128": dl, "lse_maxdiff_to_128": dlse}
+    row = {}
+    for planes in (1, 2):
+        ap_, bp_ = split_planes(a, planes), split_planes(b, planes)
+        buf = torch.empty(ws + 2 * N, device="cuda")
+        G = torch.empty(N, N, device="cuda")
+        arr = (_abi.InfonceProblem * 1)()
+        arr[0] = _abi.InfonceProblem(q_hi=ap_[0].data_ptr(), q_lo=ap_[1].data_ptr() if planes == 2 else None, k_hi=bp_[0].data_ptr(),
+                                     k_lo=bp_[1].data_ptr() if planes == 2 else None, col0=0, weight=0.5, part=buf.data_ptr(),
+                                     diag=buf.data_ptr() + 4 * ws, lse=buf.data_ptr() + 4 * (ws + N), lse_k=None, G=G.data_ptr(), ldg=N)
+        ref = None
+        # waves: 2 = 8 waves, 3 = 4 MFMA + 4 producer waves, + 4 (bit 18) = the 8-wave form without the cross-barrier fragment prefetch; tile code 255 = 256 x 256 (one product only)
+        forms = [("tile128_waves8", 128, 2), ("tile128_waves8_no_prefetch", 128, 6), ("tile128_waves4+4", 128, 3)]
+        if planes == 1:
+            forms += [("tile256_waves8", 255, 0), ("tile256_waves8_no_prefetch", 255, 4)]
+        forms += [("auto", 0, 0)]
+        for tag, tile, waves in forms:
+            pl = planes | (tile << 8) | (waves << 16)
+            acc.zero_()
+            assert L.eegclip_infonce_fused_fwd(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr(), st) == 0
+            torch.cuda.synchronize()
+            loss = float(acc[0])
+            lse = buf[ws + N:ws + 2 * N].clone()
+            if ref is None:
+                ref = (loss, lse)
+            dl, dlse = abs(loss - ref[0]), float((lse - ref[1]).abs().max())
+            us = ev_us(lambda: L.eegclip_infonce_fused_fwd(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr(), st))
+            usg = ev_us(lambda: L.eegclip_infonce_fused_grad(arr, 1, N, N, Dm, pl, N, sc.data_ptr(), acc.data_ptr() + 4, st), reps=30)
+            mult = 3 if planes == 2 else 1
+            row[("parity_" if planes == 2 else "") + tag] = {"logits_block_us": round(us, 2), "TF": round(flop / us / 1e6, 1), "frac_of_bf16_peak": round(flop / us / 1e6 / PEAK, 4),
+                                                             "mfma_work_frac_of_peak": round(mult * flop / us / 1e6 / PEAK, 4), "grad_us": round(usg, 2),
+                                                             "loss_diff_to_first": dl, "lse_maxdiff_to_first": dlse}
     out[f"N{N}"] = row
     print(N, json.dumps(row), flush=True)
 if len(sys.argv) > 1:
