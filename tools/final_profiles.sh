@@ -27,8 +27,11 @@ cp $O/stats/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/stats -
 python $R/tools/step_timeline.py $(find $O/stats -name "*kernel_trace.csv" | head -1) 3 > $O/step_timeline.txt 2>/dev/null      # one steady-state step, dispatch by dispatch
 find $O/stats -name "*.csv" -size +1M -delete
 cd $R
+if [ -z "$SKIP_BENCH" ]; then      # (tools/round6/gpu_final.sh takes the bench line FIRST, on the fresh box: after six minutes of tests and profiling passes the same
+                                    #  command reads 5-7 % slower -- 0.695-0.70 against 0.653 ms per step on boxes that A/B calls measured at 0.65-0.66)
 timeout 400 python bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err < /dev/null
 cut -c1-400 $O/bench.json
+fi
 cd /tmp
 j=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
