@@ -495,6 +495,36 @@ def test_clip_loss_at_global_batch_2048_matches_torch_fp32_and_its_gradients():
     assert abs(outs[0][2] - outs[1][2]) < 2e-3 * abs(outs[1][2]) + 1e-6
 
 
+def test_clip_loss_at_global_batch_4096_on_256_tiles_matches_torch():
+    """N = 4096 (16 x 256 gathered), one bf16 product: the size from which the tile kernel runs 256 x 256 tiles (csrc/infonce_fused.hip: one partial slot per
+    row and key tile, combined in the workgroup) -- forward-only (tile launch + finalize launch) and forward + backward (the gradient pass finalises the 256-tile
+    partials itself) against a plain torch evaluation of models/loss.py:122-140 on the bf16-rounded features"""
+    from eeg_image_decode_amd.loss import ClipLoss
+    N, Dm = 4096, 1024
+    a0 = T(syn.unit_features(SEED + 62, N, Dm, tag="a")).cuda() * 3.0
+    b0 = T(syn.unit_features(SEED + 62, N, Dm, tag="b")).cuda()
+    ar, br = a0.bfloat16().float(), b0.bfloat16().float()
+    lab = torch.arange(N, device="cuda")
+    a_ref = ar.clone().requires_grad_()
+    sc_ref = torch.tensor(2.6593, device="cuda", requires_grad=True)
+    logits = sc_ref * a_ref @ br.T
+    want = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.T, lab))
+    want.backward()
+    lf = ClipLoss(logits_dtype="bf16")
+    with torch.no_grad():
+        got_fwd = float(lf(a0, b0, torch.tensor(2.6593, device="cuda")))
+    want_v = float(want.detach())
+    assert abs(got_fwd - want_v) < 1e-4 * abs(want_v)
+    a = a0.clone().requires_grad_()
+    sc = torch.tensor(2.6593, device="cuda", requires_grad=True)
+    loss = lf(a, b0, sc)
+    loss.backward()
+    assert abs(float(loss.detach()) - want_v) < 1e-4 * abs(want_v)
+    # (one-product mode: the gradient matrix and the targets enter the dA GEMM rounded to bf16 -- 2^-9 relative per element; measured 3e-3 of the largest entry)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), a_ref.grad.cpu().numpy(), atol=6e-3 * float(a_ref.grad.abs().max()))
+    assert abs(float(sc.grad) - float(sc_ref.grad)) < 2e-3 * abs(float(sc_ref.grad)) + 1e-6
+
+
 def test_retrieval_accuracy_after_training_matches_the_oracle():
     """north_star: top-1 / top-5 retrieval accuracy on held-out synthetic pairs.  A short version of tools/accuracy_parity.py (whose full run --
     150 steps, identical accuracies for every k on 1000 held-out classes in the default split-bf16 arithmetic, profiles/r3_accuracy_parity.json --
