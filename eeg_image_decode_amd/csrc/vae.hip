@@ -25,6 +25,7 @@ constexpr int CV_STAGE_B = 2 * CV_TILE_B;
 
 typedef _Float16 cv_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short cv_u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short cv_u16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x16 cv_mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {
 #if defined(EEG_EMU)
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
     auto swz = [](int row) { return (row >> 1) & 7; };
     // DMA roles (csrc/gemm16.hip): wave w deposits rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per instruction
     const int drow = lane >> 3, dpos = lane & 7;
-    int pn[4], py[4], px[4], acol[4];
+    int pn[4], py[4], px[4], acol[4], pbase[4];
     const unsigned short* wsrc[4];
     const int hw = a.Ho * a.Wo;
 #pragma unroll
@@ -114,20 +115,35 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
         px[i] = rem - py[i] * a.Wo;
         acol[i] = col;
         wsrc[i] = a.W + (long long)(n0 + row) * a.KS * a.KS * a.Cin + col;
+        // pixel index of tap (0, 0) in the padded input frame (plain form) / of the frame row 0 of this image (`up`: the source row depends on the tap's parity)
+        pbase[i] = a.up ? pn[i] * a.Hp : (pn[i] * a.Hp + py[i] * a.stride + a.oy) * a.Wp + px[i] * a.stride + a.ox;
     }
     const int cpt = a.Cin / CV_K;                             // k-tiles per tap
-    auto issue_one = [&](int kt, int dnum) {
+    // (tap, channel offset) of the NEXT k-tile to be issued, stepped once per tile: k-tile kt is tap kt / cpt, channels (kt % cpt) CV_K .. -- the first version
+    // took those two integer divisions (and the tap's / KS) inside every one of the 8 DMA instructions of a tile: ~65 instructions of address arithmetic per
+    // instruction, ~520 per k-tile against the 16 MFMAs they sit between (240 TFLOP/s for the decode); the weights' offset is simply kt CV_K
+    int t_ky = 0, t_kx = 0, t_c0 = 0;
+    auto advance = [&]() {
+        t_c0 += CV_K;
+        if (t_c0 == a.Cin) {
+            t_c0 = 0;
+            if (++t_kx == a.KS) { t_kx = 0; ++t_ky; }
+        }
+    };
+    auto issue_one = [&](int kt, int dnum) {                  // DMA instruction `dnum` of k-tile kt == the tile (t_ky, t_kx, t_c0) describes
         const int o = dnum >> 2, i = dnum & 3;
         unsigned char* st = lds + (kt % CV_NS) * CV_STAGE_B + 32 * wave * CV_ROWB;
-        const int tap = kt / cpt, c0 = (kt - tap * cpt) * CV_K;
         if (o == 0) {
-            const int ky = tap / a.KS, kx = tap - ky * a.KS;
-            const int sy = a.up ? (((py[i] + ky - 1) >> 1) + 1) : py[i] * a.stride + ky + a.oy;
-            const int sx = a.up ? (((px[i] + kx - 1) >> 1) + 1) : px[i] * a.stride + kx + a.ox;
-            const unsigned short* p = a.in + (((long long)pn[i] * a.Hp + sy) * a.Wp + sx) * a.Cin + c0 + acol[i];
-            lds_dma16(st + 8 * i * CV_ROWB, p);
+            int pix;
+            if (a.up) {
+                const int sy = ((py[i] + t_ky - 1) >> 1) + 1, sx = ((px[i] + t_kx - 1) >> 1) + 1;
+                pix = (pbase[i] + sy) * a.Wp + sx;
+            } else {
+                pix = pbase[i] + t_ky * a.Wp + t_kx;
+            }
+            lds_dma16(st + 8 * i * CV_ROWB, a.in + (long long)pix * a.Cin + t_c0 + acol[i]);
         } else {
-            lds_dma16(st + CV_TILE_B + 8 * i * CV_ROWB, wsrc[i] + (long long)tap * a.Cin + c0);
+            lds_dma16(st + CV_TILE_B + 8 * i * CV_ROWB, wsrc[i] + (long long)kt * CV_K);
         }
     };
     f32x16 acc[2][2];
@@ -152,6 +168,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
         if (p < ktiles) {
 #pragma unroll
             for (int dnum = 0; dnum < 8; ++dnum) issue_one(p, dnum);
+            advance();
         }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int newer = ktiles - 1 - kt < CV_NS - 2 ? ktiles - 1 - kt : CV_NS - 2;
@@ -162,9 +179,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
         const bool refill = kt + CV_NS - 1 < ktiles;
         const unsigned char* st = lds + (kt % CV_NS) * CV_STAGE_B;
         bf16x8 am[2][2], wf[2][2];
+        // (what a step's first MFMA takes is read last and the next step's reads go out behind that MFMA: csrc/infonce_fused.hip, round 6)
         auto read_step = [&](int s, int set) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 1; i >= 0; --i) {
                 am[set][i] = *reinterpret_cast<const bf16x8*>(st + fom[s][i]);
                 wf[set][i] = *reinterpret_cast<const bf16x8*>(st + fon[s][i]);
             }
@@ -172,7 +190,6 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
         read_step(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (s + 1 < 4) read_step(s + 1, (s + 1) & 1);
 #if !defined(EEG_EMU)
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -183,12 +200,22 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
                 for (int i = 0; i < 2; ++i) {
                     acc[j][i] = F16 ? cv_mfma_f16(wf[set][j], am[set][i], acc[j][i]) : mfma_bf16_32x32x16(wf[set][j], am[set][i], acc[j][i]);
                     const int mi = 4 * s + 2 * j + i;
+                    if (j == 0 && i == 0 && s + 1 < 4) {
+#if !defined(EEG_EMU)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                        read_step(s + 1, (s + 1) & 1);
+#if !defined(EEG_EMU)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                    }
                     if (refill && (mi & 1)) issue_one(kt + CV_NS - 1, mi >> 1);
                 }
 #if !defined(EEG_EMU)
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+        if (refill) advance();
     }
     // ---- epilogue: lane (r32, h) owns pixel m = m0 + 64 wm + 32 i + r32; registers 4 eq .. 4 eq + 3 of n tile j are channels n0 + 64 wn + 32 j + 8 eq + 4 h ..
 #pragma unroll
@@ -227,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_small16_kernel(const cv_args a) {
     __syncthreads();
     const long long total = (long long)a.M * a.Cout;
     const int hw = a.Ho * a.Wo;
+    const bool vec8 = (a.Cin & 7) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += 256LL * gridDim.x) {
         const int m = (int)(q / a.Cout), co = (int)(q - (long long)m * a.Cout);
         const int n_ = m / hw, rem = m - n_ * hw, y = rem / a.Wo, x = rem - y * a.Wo;
@@ -237,7 +265,15 @@ __global__ __launch_bounds__(256) void conv_small16_kernel(const cv_args a) {
                 const int sx = a.up ? (((x + kx - 1) >> 1) + 1) : x * a.stride + kx + a.ox;
                 const unsigned short* p = a.in + (((long long)n_ * a.Hp + sy) * a.Wp + sx) * a.Cin;
                 const unsigned short* w = wl + (co * kk + ky * a.KS + kx) * a.Cin;
-                for (int ci = 0; ci < a.Cin; ++ci) acc += cv_to_f32<F16>(p[ci]) * cv_to_f32<F16>(w[ci]);
+                if (vec8) {                                  // 16-byte reads of both operands (conv_out, 128 -> 3 at 1024 x 1024: 6.1 -> ms with 2-byte reads); same summation order
+                    for (int ci = 0; ci < a.Cin; ci += 8) {
+                        const cv_u16x8 pv = *reinterpret_cast<const cv_u16x8*>(p + ci), wv = *reinterpret_cast<const cv_u16x8*>(w + ci);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc += cv_to_f32<F16>(pv[e]) * cv_to_f32<F16>(wv[e]);
+                    }
+                } else {
+                    for (int ci = 0; ci < a.Cin; ++ci) acc += cv_to_f32<F16>(p[ci]) * cv_to_f32<F16>(w[ci]);
+                }
             }
         const long long opix = (((long long)n_ * a.Hop + y + a.opad) * a.Wop + x + a.opad) * a.Cout;
         if (a.R) acc += cv_to_f32<F16>(a.R[opix + co]);
@@ -245,26 +281,63 @@ __global__ __launch_bounds__(256) void conv_small16_kernel(const cv_args a) {
     }
 }
 
-// ---- GroupNorm over a padded NHWC tensor (interior pixels only).  Statistics: workgroup = (image, block of 64 pixels); thread t owns channels t, t + 256, ..
-// of its pixel block (coalesced 2-byte reads along the channels); per-channel sums meet per group in LDS, one fp64 atomic pair per (workgroup, group).
+// ---- GroupNorm over a padded NHWC tensor (interior pixels only).  Statistics: workgroup = (image, block of GN_PB pixels); thread = (8 consecutive channels, pixel lane):
+// 16-byte reads, the pixels of a lane independent of one another (loads in flight), the two 4-channel halves summed apart (a group has >= 4 channels); the sums meet
+// per group in LDS, one fp64 atomic pair per (workgroup, group).  (The first version gave a thread one CHANNEL and walked its 64 pixels one 2-byte read after the
+// other, an integer division each: 7.5 ms of a 35 ms decode for ~3 GB of reads.)  Channel counts the vector form does not take (C % 8, 256 % (C / 8)) walk as before.
+constexpr int GN_PB = 256;
 template <bool F16>
 __global__ __launch_bounds__(256) void gn_stats16_kernel(const unsigned short* __restrict__ x, int H, int W, int C, int pad, int groups, double* __restrict__ sums) {
     EEG_LDS_BASE(float, red);                                // [2][groups]
     const int n_ = blockIdx.y, t = threadIdx.x, hw = H * W, Wp = W + 2 * pad, Hp = H + 2 * pad;
     for (int i = t; i < 2 * groups; i += 256) red[i] = 0.f;
     __syncthreads();
-    const int p0 = blockIdx.x * 64, p1 = p0 + 64 < hw ? p0 + 64 : hw;
-    const int cpg = C / groups;
-    for (int c = t; c < C; c += 256) {
-        float s = 0.f, q = 0.f;
-        for (int p = p0; p < p1; ++p) {
+    const int p0 = blockIdx.x * GN_PB, p1 = p0 + GN_PB < hw ? p0 + GN_PB : hw;
+    const int cpg = C / groups, c8n = C / 8;
+    if ((C & 7) == 0 && c8n <= 256 && 256 % c8n == 0 && (groups & 1) == 0 && groups <= 256 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const int cc = t % c8n, pl = t / c8n, ppi = 256 / c8n;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll 4
+        for (int p = p0 + pl; p < p1; p += ppi) {
             const int y = p / W, xx = p - y * W;
-            const float v = cv_to_f32<F16>(x[(((long long)n_ * Hp + y + pad) * Wp + xx + pad) * C + c]);
-            s += v;
-            q += v * v;
+            const cv_u16x8 v = *reinterpret_cast<const cv_u16x8*>(x + (((long long)n_ * Hp + y + pad) * Wp + xx + pad) * C + 8 * cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = cv_to_f32<F16>(v[e]), b = cv_to_f32<F16>(v[4 + e]);
+                s0 += a; q0 += a * a;
+                s1 += b; q1 += b * b;
+            }
         }
-        atomicAdd(red + c / cpg, s);
-        atomicAdd(red + groups + c / cpg, q);
+        // fixed-order combine (two decodes of one latent are bit-identical: tests/test_vae_gpu.py): every thread leaves its two half-chunk pairs in LDS, thread g
+        // adds group g's entries -- half-chunks g cpg / 4 .. of every pixel lane -- in index order
+        float* part = red + 2 * groups;                      // [256][4]
+        *reinterpret_cast<f32x4*>(part + 4 * t) = f32x4{s0, q0, s1, q1};
+        __syncthreads();
+        if (t < groups) {
+            const int hpg = cpg / 4;                         // 4-channel half-chunks per group
+            float s_ = 0.f, q = 0.f;
+            for (int l = 0; l < ppi; ++l)
+                for (int k = 0; k < hpg; ++k) {
+                    const int hc = t * hpg + k;              // half-chunk index along the channels: thread (l, hc >> 1), half hc & 1
+                    const float* e = part + 4 * (l * c8n + (hc >> 1)) + 2 * (hc & 1);
+                    s_ += e[0];
+                    q += e[1];
+                }
+            red[t] = s_;
+            red[groups + t] = q;
+        }
+    } else {
+        for (int c = t; c < C; c += 256) {
+            float s_ = 0.f, q = 0.f;
+            for (int p = p0; p < p1; ++p) {
+                const int y = p / W, xx = p - y * W;
+                const float v = cv_to_f32<F16>(x[(((long long)n_ * Hp + y + pad) * Wp + xx + pad) * C + c]);
+                s_ += v;
+                q += v * v;
+            }
+            atomicAdd(red + c / cpg, s_);
+            atomicAdd(red + groups + c / cpg, q);
+        }
     }
     __syncthreads();
     for (int g = t; g < groups; g += 256) {
@@ -272,23 +345,30 @@ __global__ __launch_bounds__(256) void gn_stats16_kernel(const unsigned short* _
         atomicAdd(sums + ((long long)n_ * groups + g) * 2 + 1, (double)red[groups + g]);
     }
 }
-// apply: y = (x - mean) * rstd * gamma + beta (then SiLU if `silu`), written into another frame (its own padding); 4 consecutive channels per thread
+// apply: y = (x - mean) * rstd * gamma + beta (then SiLU if `silu`), written into another frame (its own padding); 4 consecutive channels per thread.  Every workgroup
+// first turns the (image, group) sums into a (mean, 1 / sqrt(var + eps)) table in LDS (the first version redid the fp64 division and square root per 4 channels)
 template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply16_kernel(const unsigned short* __restrict__ x, int N, int H, int W, int C, int pad, int groups,
                                                           const double* __restrict__ sums, const unsigned short* __restrict__ gamma,
                                                           const unsigned short* __restrict__ beta, float eps, int silu_on, unsigned short* __restrict__ y, int opad) {
+    EEG_LDS_BASE(float, tab);                                // [N * groups][2]
     const int c4n = C / 4, hw = H * W, Wp = W + 2 * pad, Hp = H + 2 * pad, Wop = W + 2 * opad, Hop = H + 2 * opad, cpg = C / groups;
     const long long total = (long long)N * hw * c4n;
     const double cnt = (double)hw * cpg;
+    for (int i = threadIdx.x; i < N * groups; i += 256) {
+        const double mu = sums[2 * (long long)i] / cnt;
+        double var = sums[2 * (long long)i + 1] / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        tab[2 * i] = (float)mu;
+        tab[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += 256LL * gridDim.x) {
         const int c = 4 * (int)(q % c4n);
         const long long pq = q / c4n;
         const int n_ = (int)(pq / hw), p = (int)(pq - (long long)n_ * hw), yy = p / W, xx = p - yy * W;
         const int g = c / cpg;                               // (cpg % 4 == 0: the 4 channels share a group)
-        const double mu = sums[((long long)n_ * groups + g) * 2] / cnt;
-        double var = sums[((long long)n_ * groups + g) * 2 + 1] / cnt - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mean = tab[2 * (n_ * groups + g)], rstd = tab[2 * (n_ * groups + g) + 1];
         const cv_u16x4 xv = *reinterpret_cast<const cv_u16x4*>(x + (((long long)n_ * Hp + yy + pad) * Wp + xx + pad) * C + c);
         const cv_u16x4 gv = *reinterpret_cast<const cv_u16x4*>(gamma + c), bv = *reinterpret_cast<const cv_u16x4*>(beta + c);
         cv_u16x4 o;
@@ -407,16 +487,17 @@ extern "C" int eegclip_groupnorm16(const void* x, int N, int H, int W, int C, in
          reinterpret_cast<uintptr_t>(sums)) & 7u)
         return EEGCLIP_EALIGN;
     const bool f16 = dtype == EEGCLIP_DT_F16;
+    if ((long long)N * groups > 4096) return EEGCLIP_EINVAL;     // (the apply kernel keeps the (mean, rstd) table of every (image, group) in LDS)
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)N * groups * 2 * sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    const dim3 gs((unsigned)((H * W + 63) / 64), (unsigned)N);
-    const size_t lds = 2 * (size_t)groups * sizeof(float);
+    const dim3 gs((unsigned)((H * W + GN_PB - 1) / GN_PB), (unsigned)N);
+    const size_t lds = (2 * (size_t)groups + 256 * 4) * sizeof(float);
     if (f16) EEG_LAUNCH((gn_stats16_kernel<true>), gs, dim3(256), lds, stream, static_cast<const unsigned short*>(x), H, W, C, pad, groups, sums);
     else     EEG_LAUNCH((gn_stats16_kernel<false>), gs, dim3(256), lds, stream, static_cast<const unsigned short*>(x), H, W, C, pad, groups, sums);
     long long g = ((long long)N * H * W * (C / 4) + 255) / 256;
     if (g > 16384) g = 16384;
 #define EEG_GNA(F)                                                                                                                                        \
-    EEG_LAUNCH((gn_apply16_kernel<F>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const unsigned short*>(x), N, H, W, C, pad, groups, sums,      \
+    EEG_LAUNCH((gn_apply16_kernel<F>), dim3((unsigned)g), dim3(256), (size_t)N * groups * 2 * sizeof(float), stream, static_cast<const unsigned short*>(x), N, H, W, C, pad, groups, sums,      \
                static_cast<const unsigned short*>(gamma), static_cast<const unsigned short*>(beta), eps, silu_on, static_cast<unsigned short*>(y), out_pad)
     if (f16) EEG_GNA(true);
     else     EEG_GNA(false);
