@@ -360,7 +360,11 @@ int eegclip_sampler_step(const void* x, const void* eps_u, const void* eps_c, co
  *                swapped block's gradient matrix produced TRANSPOSED (rows = gathered queries, columns = the rank's targets; col0 may be negative).
  * planes = 1: one bf16 product (features rounded to bf16: logit error ~2^-9 |q||k|, the throughput mode); planes = 2: q k = q_hi k_hi + q_hi k_lo +
  * q_lo k_hi, fp32 accumulate (logits within ~5e-5 of exact fp32 products: the parity mode).  All blocks of one call share n, N, D; at most 8.
- * Supported shapes: n, N, D multiples of 64 (eegclip_infonce_fused_supported); anything else takes the GEMM + lse_rows/lse_cols route. */
+ * Supported shapes: n, N, D multiples of 64 (eegclip_infonce_fused_supported); anything else takes the GEMM + lse_rows/lse_cols route.
+ * Tile form (the library's choice when the upper bits of `planes` are 0): 64 x 64 logits per workgroup for small blocks, 128 x 128 once 256 such tiles exist,
+ * 256 x 256 (one product only; forward, and the gradient pass only when it finalises the forward's partials) once 256 of THOSE exist -- N >= 4096 square.
+ * Benches / tests may force it: bits 8..15 = 64 | 128 | 255 (= 256 x 256), bits 16..17 = 1 (4 waves) | 2 (8 waves) | 3 (4 MFMA + 4 producer waves), bit 18 = the
+ * 8-wave forms without the cross-barrier fragment prefetch.  The forward and a FINALISING gradient pass of one block must use the same tile form (partial layout). */
 typedef struct {
     const void* q_hi;     /* (n, D) bf16 */
     const void* q_lo;     /* (n, D) bf16 or NULL (planes = 1) */
