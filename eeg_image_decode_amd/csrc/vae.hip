@@ -18,7 +18,12 @@
 
 namespace eeg {
 
-constexpr int CV_T = 128, CV_K = 64, CV_NS = 4;
+// LDS stages of the implicit-GEMM conv: 2 (64 KB: two workgroups per CU, the other's MFMAs cover this one's barrier and DMA waits) measured 19.9-20.0 ms per
+// 1024 x 1024 decode against 20.8-20.9 with 3 or 4 stages (one workgroup per CU), three builds alternated on one box
+#ifndef CV_NS_BUILD
+#define CV_NS_BUILD 2
+#endif
+constexpr int CV_T = 128, CV_K = 64, CV_NS = CV_NS_BUILD;
 constexpr int CV_ROWB = 2 * CV_K;
 constexpr int CV_TILE_B = CV_T * CV_ROWB;
 constexpr int CV_STAGE_B = 2 * CV_TILE_B;
@@ -89,17 +94,22 @@ struct cv_args {
     int M, tiles_n, ntiles, chunk;
 };
 
-template <bool F16>
-__global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
+// SPEC (round 6): four extra PRODUCER waves issue every LDS-DMA instruction (and do the address arithmetic in front of it); the four MFMA waves only read
+// fragments and feed the matrix pipe, and meet the producers at the one barrier per k-tile -- a wave that does both is in order and stalls in every DMA issue
+// with its MFMAs unissued behind it (csrc/infonce_fused.hip, NPRD).
+template <bool F16, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void conv16_kernel(const cv_args a) {
     EEG_LDS_BASE(unsigned char, lds);
     const int logical = (int)(blockIdx.x & 7) * a.chunk + (int)(blockIdx.x >> 3);
     if (logical >= a.ntiles) return;
     const int m0 = (logical / a.tiles_n) * CV_T, n0 = (logical % a.tiles_n) * CV_T;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave_ = wave_uniform(t >> 6);
+    const bool producer = SPEC && wave_ >= 4;                 // (wave-uniform)
+    const int wave = wave_ & 3;                               // index among the MFMA waves / among the DMA waves
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
     auto swz = [](int row) { return (row >> 1) & 7; };
-    // DMA roles (csrc/gemm16.hip): wave w deposits rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per instruction
+    // DMA roles (csrc/gemm16.hip): DMA wave w deposits rows 32 w .. 32 w + 31 of both tiles, 8 rows (1 KB) per instruction
     const int drow = lane >> 3, dpos = lane & 7;
     int pn[4], py[4], px[4], acol[4], pbase[4];
     const unsigned short* wsrc[4];
@@ -163,20 +173,39 @@ __global__ __launch_bounds__(256) void conv16_kernel(const cv_args a) {
             fon[s][i] = CV_TILE_B + rn * CV_ROWB + (((2 * s + h) ^ swz(rn)) & 7) * 16;
         }
     const int ktiles = a.KS * a.KS * cpt;
+    if (!SPEC || producer) {
 #pragma unroll
-    for (int p = 0; p < CV_NS - 1; ++p)
-        if (p < ktiles) {
+        for (int p = 0; p < CV_NS - 1; ++p)
+            if (p < ktiles) {
 #pragma unroll
-            for (int dnum = 0; dnum < 8; ++dnum) issue_one(p, dnum);
-            advance();
+                for (int dnum = 0; dnum < 8; ++dnum) issue_one(p, dnum);
+                advance();
+            }
+    }
+    if (producer) {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int newer = ktiles - 1 - kt < CV_NS - 2 ? ktiles - 1 - kt : CV_NS - 2;
+            if (newer >= 2) wait_vmcnt<16>();
+            else if (newer == 1) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+            raw_barrier();                                    // the one meeting point of the two kinds of waves per k-tile
+            if (kt + CV_NS - 1 < ktiles) {
+#pragma unroll
+                for (int dnum = 0; dnum < 8; ++dnum) issue_one(kt + CV_NS - 1, dnum);
+                advance();
+            }
         }
+        return;                                               // (the epilogue has no barrier)
+    }
     for (int kt = 0; kt < ktiles; ++kt) {
-        const int newer = ktiles - 1 - kt < CV_NS - 2 ? ktiles - 1 - kt : CV_NS - 2;
-        if (newer >= 2) wait_vmcnt<16>();
-        else if (newer == 1) wait_vmcnt<8>();
-        else wait_vmcnt<0>();
+        if (!SPEC) {
+            const int newer = ktiles - 1 - kt < CV_NS - 2 ? ktiles - 1 - kt : CV_NS - 2;
+            if (newer >= 2) wait_vmcnt<16>();
+            else if (newer == 1) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+        }
         raw_barrier();
-        const bool refill = kt + CV_NS - 1 < ktiles;
+        const bool refill = !SPEC && kt + CV_NS - 1 < ktiles;
         const unsigned char* st = lds + (kt % CV_NS) * CV_STAGE_B;
         bf16x8 am[2][2], wf[2][2];
         // (what a step's first MFMA takes is read last and the next step's reads go out behind that MFMA: csrc/infonce_fused.hip, round 6)
@@ -464,8 +493,14 @@ extern "C" int eegclip_conv16(const eegclip_conv16_desc* d, void* stream) {
         a.ntiles = a.tiles_n * ((a.M + CV_T - 1) / CV_T);
         a.chunk = (a.ntiles + 7) / 8;
         const size_t lds = (size_t)CV_NS * CV_STAGE_B;
-        if (f16) EEG_LAUNCH((conv16_kernel<true>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
-        else     EEG_LAUNCH((conv16_kernel<false>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
+        static const bool spec = [] { const char* e = getenv("EEGCLIP_CONV16_PRODUCERS"); return !(e && e[0] == '0'); }();      // (A/B aid)
+        if (spec) {
+            if (f16) EEG_LAUNCH((conv16_kernel<true, true>), dim3((unsigned)(8 * a.chunk)), dim3(512), lds, stream, a);
+            else     EEG_LAUNCH((conv16_kernel<false, true>), dim3((unsigned)(8 * a.chunk)), dim3(512), lds, stream, a);
+        } else {
+            if (f16) EEG_LAUNCH((conv16_kernel<true, false>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
+            else     EEG_LAUNCH((conv16_kernel<false, false>), dim3((unsigned)(8 * a.chunk)), dim3(256), lds, stream, a);
+        }
         return (int)hipGetLastError();
     }
     const size_t wbytes = (size_t)d->Cout * d->KS * d->KS * d->Cin * 2;
