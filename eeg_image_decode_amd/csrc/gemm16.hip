@@ -19,7 +19,12 @@
 
 namespace eeg {
 
-constexpr int G16_T = 128, G16_K = 64, G16_NS = 4;
+// LDS stages: 2 (64 KB: two workgroups per CU) measured 16.4 ms per step of the SDXL-shaped sampling loop against 16.8-17.1 with 3 or 4 stages (one workgroup per
+// CU), three builds alternated on one box (round 6; the same finding as the VAE's implicit-GEMM conv, csrc/vae.hip)
+#ifndef G16_NS_BUILD
+#define G16_NS_BUILD 2
+#endif
+constexpr int G16_T = 128, G16_K = 64, G16_NS = G16_NS_BUILD;
 constexpr int G16_ROWB = 2 * G16_K;                       // 128-byte LDS rows
 constexpr int G16_TILE_B = G16_T * G16_ROWB;              // one operand tile
 constexpr int G16_STAGE_B = 2 * G16_TILE_B;
