@@ -135,9 +135,19 @@ def infonce_small(aq, tp, n, T_, Dm, weights, sc, acc, Gp):
 
 
 def add_slabs(slabs):
-    """slabs[0] + slabs[1] + .. in that order (what the slab-consuming kernels compute, bit for bit)"""
+    """slabs[0] + slabs[1] + .. in that order (what the slab-consuming kernels compute, bit for bit) -- ONE launch: eegclip_head_act's `pre` output is the slab
+    sum (no bias, the activation output not requested); S - 1 torch adds were S - 1 launches and allocations on the host path of the row-sharded loss"""
+    S = slabs.shape[0]
+    if S == 1:
+        return slabs[0]
+    M, N = slabs.shape[1], slabs.shape[2]
+    if slabs.is_contiguous() and N % 4 == 0 and S <= 16:
+        out = torch.empty(M, N, dtype=torch.float32, device=slabs.device)
+        check(lib().eegclip_head_act(slabs.data_ptr(), S, M * N, None, out.data_ptr(), None, None, None, M, N, _stream()), "head_act (slab sum)")
+        out._eegclip_keep = slabs
+        return out
     out = slabs[0]
-    for i in range(1, slabs.shape[0]):
+    for i in range(1, S):
         out = out + slabs[i]
     return out
 
